@@ -1,0 +1,467 @@
+/*
+ * oracle/oracle_lockstep.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of mc3's per-iteration chain update (mc3/chain.py:183-299)
+ * in the LOCKSTEP form the HIP kernels implement: all chains advance together
+ * from a snapshot of the population taken at the last Z refresh, and every
+ * random number is a pure function Philox4x32-10(seed; iteration, chain, slot).
+ * The proposal / bounds / Metropolis / Z-append rules are the reference's, line
+ * by line (citations below); what differs from the reference is only (i) the
+ * generator (the reference uses NumPy's MT19937 stream, chain.py:185-259) and
+ * (ii) Jacobi instead of Gauss-Seidel visibility of the other chains
+ * (SURVEY.md 3.3-12).  oracle/chain_sequential.py restates the reference's own
+ * sequential form and is pinned bit-for-bit against the reference; this file
+ * shares its step rules and is the bit-exact checker for the GPU.
+ *
+ * Arithmetic contract (DESIGN.md "Arithmetic contract"): built with
+ * -ffp-contract=off; a fused multiply-add happens only where written
+ * (model Horner/dot, the squared-residual accumulation, the D4 filter taps,
+ * and inside include/mc3hip_detmath.h).  Sums over data points follow the
+ * canonical order "tiles in order; inside a tile `vlanes` strided partial sums,
+ * then a halving tree".
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this file's library.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "mc3hip_detmath.h"
+
+enum { LS_MRW = 0, LS_DEMC = 1, LS_SNOOKER = 2 };
+enum { LS_POLY = 0, LS_LINEAR = 1 };
+
+typedef struct {
+    int32_t nchains, chain0, nlocal;
+    int32_t nparams, nfree, nshare, ndata;
+    int32_t sampler, wlike, model_kind, nmodel, thinning;
+    int32_t ngprior;
+    int32_t tile, vlanes;
+    int32_t _pad;
+    int64_t M0, zlen;
+    uint64_t seed;
+    double gamma, fepsilon;
+    const int32_t *ifree, *ishare, *share_src, *igprior;
+    const double *params, *pmin, *pmax, *pstep, *prior, *priorlow, *priorup;
+    const double *indep, *data, *w;
+} ls_problem;
+
+typedef struct {
+    double *Z, *log_post;
+    int32_t *zchain;
+    double *X, *chisq;
+    int64_t *numaccept, *outbounds;     /* [nchains], [nfree] */
+    double *best_chisq;
+    int64_t *best_iter;
+    double *bestx;
+    double *trace_chisq;                /* optional [niter][nchains] */
+    int32_t *trace_flag;                /* bit0 in-bounds, bit1 accepted, bit2 snooker jump */
+    const double *snap0;                /* population seen by refresh 0 */
+    int64_t refresh_done;
+} ls_state;
+
+/* ---- Philox4x32-10 (Salmon et al. 2011), written out independently of the
+ * device implementation in mc3_amd/csrc/philox.h; both are pinned to the
+ * Random123 known-answer vectors in tests/test_philox.py. */
+void ls_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int round = 0; round < 10; round++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* two 64-bit draws for (iteration, chain, slot) */
+static void draw2(uint64_t seed, uint64_t iter, uint32_t chain, uint32_t slot,
+                  uint64_t *q0, uint64_t *q1)
+{
+    const uint32_t ctr[4] = { (uint32_t)iter, (uint32_t)(iter >> 32), chain, slot };
+    const uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    uint32_t w[4];
+    ls_philox4x32_10(ctr, key, w);
+    *q0 = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    *q1 = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+}
+
+static double u01(uint64_t q) { return (double)(q >> 11) * 0x1.0p-53; }          /* [0,1) */
+static double u01_open(uint64_t q) { return (double)((q >> 11) + 1) * 0x1.0p-53; } /* (0,1] */
+static uint64_t bounded(uint64_t q, uint64_t n)                                   /* [0,n) */
+{
+    return (uint64_t)(((unsigned __int128)q * n) >> 64);
+}
+
+/* ---- model ---------------------------------------------------------------- */
+static inline double model_at(const ls_problem *P, const double *p, int i)
+{
+    if (P->model_kind == LS_POLY) {
+        const double x = P->indep[i];
+        double m = p[P->nmodel - 1];
+        for (int j = P->nmodel - 2; j >= 0; j--)
+            m = mc3_fma(m, x, p[j]);
+        return m;
+    }
+    const double *A = P->indep;                 /* column k at A + k*ndata */
+    double m = A[i] * p[0];
+    for (int k = 1; k < P->nmodel; k++)
+        m = mc3_fma(A[(size_t)k * P->ndata + i], p[k], m);
+    return m;
+}
+
+void ls_eval_model(const ls_problem *P, const double *p, double *out)
+{
+    for (int i = 0; i < P->ndata; i++)
+        out[i] = model_at(P, p, i);
+}
+
+/* prior term: mc3/stats/stats.py:211-216 + src_c/include/stats.h:96-106 */
+static double prior_term(const ls_problem *P, const double *p)
+{
+    double pr = 0.0;
+    for (int g = 0; g < P->ngprior; g++) {
+        const int j = P->igprior[g];
+        const double d = p[j] - P->prior[j];
+        const double s = (d > 0.0) ? d / P->priorup[j] : d / P->priorlow[j];
+        pr = pr + s * s;
+    }
+    return pr;
+}
+
+static double halving_tree(double *part, int n)
+{
+    for (int s = n / 2; s >= 1; s /= 2)
+        for (int l = 0; l < s; l++)
+            part[l] = part[l] + part[l + s];
+    return part[0];
+}
+
+/* Gaussian chi-squared: src_c/_chisq.c:131-137 with w = 1/uncert, in the
+ * canonical summation order.  model == +inf anywhere => +inf (chain.py:322). */
+static double gauss_chisq(const ls_problem *P, const double *p, double *part)
+{
+    const int VL = P->vlanes;
+    const int tile = (P->tile > 0) ? P->tile : P->ndata;
+    int sawinf = 0;
+    double total = 0.0;
+    for (int t0 = 0; t0 < P->ndata; t0 += tile) {
+        const int t1 = (t0 + tile < P->ndata) ? t0 + tile : P->ndata;
+        for (int l = 0; l < VL; l++) {
+            double acc = 0.0;
+            for (int i = t0 + l; i < t1; i += VL) {
+                const double m = model_at(P, p, i);
+                if (m == INFINITY)
+                    sawinf = 1;
+                const double r = (m - P->data[i]) * P->w[i];
+                acc = mc3_fma(r, r, acc);
+            }
+            part[l] = acc;
+        }
+        total = total + halving_tree(part, VL);
+    }
+    if (sawinf)
+        return INFINITY;
+    return total + prior_term(P, p);
+}
+
+/* Wavelet pseudo chi-squared: src_c/_dwt.c:76-114, wavelet.h:27-36,115-117.
+ * ndata = 2^M.  Detail coefficients are consumed as they are produced (they
+ * are final once written, wavelet.h:33,36), weighted by 1/sigma_W^2 of their
+ * scale; only the smooth half goes on to the next level. */
+static const double D4C0 = 0.4829629131445341, D4C1 = 0.83651630373780772,
+                    D4C2 = 0.22414386804201339, D4C3 = -0.12940952255126034;
+
+static double wavelet_chisq(const ls_problem *P, const double *p,
+                            double *buf0, double *buf1, double *part)
+{
+    const int N = P->ndata;
+    const int VL = P->vlanes;
+    int M = 0;
+    while ((1 << M) < N)
+        M++;
+    const double gam = p[P->nparams - 3];
+    const double sr = p[P->nparams - 2];
+    const double sw = p[P->nparams - 1];
+    const double sr2 = sr * sr, sw2 = sw * sw;
+    int sawinf = 0;
+    for (int i = 0; i < N; i++) {
+        const double m = model_at(P, p, i);
+        if (m == INFINITY)
+            sawinf = 1;
+        buf0[i] = P->data[i] - m;
+    }
+    if (sawinf)
+        return INFINITY;
+    for (int l = 0; l < VL; l++)
+        part[l] = 0.0;
+    double *a = buf0, *b = buf1;
+    for (int nn = N; nn >= 4; nn >>= 1) {
+        const int nh = nn >> 1;
+        int m = 0;
+        while ((1 << m) < nh)
+            m++;                                       /* scale of this level's details */
+        const double sW2 = sr2 * mc3_det_exp2(-gam * (double)m) + sw2;
+        const double inv = 1.0 / sW2;
+        for (int i = 0; i < nh; i++) {
+            const double a0 = a[2*i], a1 = a[2*i + 1];
+            const double a2 = a[(2*i + 2) & (nn - 1)], a3 = a[(2*i + 3) & (nn - 1)];
+            double s = D4C0 * a0;
+            s = mc3_fma(D4C1, a1, s);
+            s = mc3_fma(D4C2, a2, s);
+            s = mc3_fma(D4C3, a3, s);
+            double d = D4C3 * a0;
+            d = mc3_fma(-D4C2, a1, d);
+            d = mc3_fma(D4C1, a2, d);
+            d = mc3_fma(-D4C0, a3, d);
+            b[i] = s;
+            const int l = i % VL;
+            part[l] = mc3_fma(d * d, inv, part[l]);
+        }
+        double *t = a; a = b; b = t;
+    }
+    const double T = halving_tree(part, VL);
+    const double sS2 = sr2 * mc3_det_exp2(-gam) * 0.72134752 + sw2;
+    const double S = (a[0] * a[0]) / sS2 + (a[1] * a[1]) / sS2;
+    double Lg = 2.0 * mc3_det_log(6.283185307179586 * sS2);
+    for (int m = 1; m < M; m++) {
+        const double sW2 = sr2 * mc3_det_exp2(-gam * (double)m) + sw2;
+        Lg = Lg + (double)(1 << m) * mc3_det_log(6.283185307179586 * sW2);
+    }
+    return ((S + Lg) + T) + prior_term(P, p);
+}
+
+typedef struct {
+    double *part, *buf0, *buf1, *nextp, *jump, *normal;
+} ls_scratch;
+
+static double eval_chisq(const ls_problem *P, const double *p, ls_scratch *S)
+{
+    if (P->wlike)
+        return wavelet_chisq(P, p, S->buf0, S->buf1, S->part);
+    return gauss_chisq(P, p, S->part);
+}
+
+/* chisq for n parameter vectors (rows of `params`, nparams each) */
+int ls_eval_chisq(const ls_problem *P, const double *params, int n, double *out)
+{
+    ls_scratch S;
+    S.part = malloc(sizeof(double) * (size_t)P->vlanes);
+    S.buf0 = malloc(sizeof(double) * (size_t)P->ndata);
+    S.buf1 = malloc(sizeof(double) * (size_t)P->ndata);
+    for (int r = 0; r < n; r++)
+        out[r] = eval_chisq(P, params + (size_t)r * P->nparams, &S);
+    free(S.part); free(S.buf0); free(S.buf1);
+    return 0;
+}
+
+/* ---- one chain, one iteration: mc3/chain.py:190-274 ----------------------- */
+static void chain_step(const ls_problem *P, ls_state *St, ls_scratch *S,
+                       int c, int64_t iter, const double *snap, int64_t zsize,
+                       double *tr_chisq, int32_t *tr_flag)
+{
+    const int nf = P->nfree;
+    double *x = St->X + (size_t)c * nf;
+    double *nextp = S->nextp, *jump = S->jump, *normal = S->normal;
+    uint64_t q0, q1;
+    double mrfactor = 1.0;
+    int sjump = 0;
+    const double *z = NULL;
+    int32_t flag = 0;
+
+    /* support-distribution draw, chain.py:185 (Box-Muller on slots 3+) */
+    const int need_normal = (P->sampler == LS_MRW) || (P->fepsilon != 0.0);
+    for (int k = 0; k < nf; k++)
+        normal[k] = 0.0;
+    if (need_normal) {
+        for (int j = 0; 2 * j < nf; j++) {
+            draw2(P->seed, (uint64_t)iter, (uint32_t)c, (uint32_t)(3 + j), &q0, &q1);
+            const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(q0)));
+            double sn, cs;
+            mc3_det_sincos2pi(u01(q1), &sn, &cs);
+            normal[2*j] = (rad * cs) * P->pstep[P->ifree[2*j]];
+            if (2*j + 1 < nf)
+                normal[2*j + 1] = (rad * sn) * P->pstep[P->ifree[2*j + 1]];
+        }
+    }
+
+    if (P->sampler == LS_SNOOKER) {                       /* chain.py:195-217 */
+        draw2(P->seed, (uint64_t)iter, (uint32_t)c, 0, &q0, &q1);
+        int64_t iR1 = (int64_t)bounded(q0, (uint64_t)zsize);
+        int64_t iR2 = 1 + (int64_t)bounded(q1, (uint64_t)(zsize - 1));
+        if (iR2 == iR1)
+            iR2 = 0;
+        draw2(P->seed, (uint64_t)iter, (uint32_t)c, 1, &q0, &q1);
+        sjump = u01(q0) < 0.1;
+        const int64_t iz = (int64_t)bounded(q1, (uint64_t)zsize);
+        const double *Z1 = St->Z + (size_t)iR1 * nf, *Z2 = St->Z + (size_t)iR2 * nf;
+        if (sjump) {
+            flag |= 4;
+            draw2(P->seed, (uint64_t)iter, (uint32_t)c, 2, &q0, &q1);
+            const double gs = 1.2 + (2.2 - 1.2) * u01(q0);
+            z = St->Z + (size_t)iz * nf;
+            int same = 1;
+            for (int k = 0; k < nf; k++)
+                if (z[k] != x[k])
+                    same = 0;
+            if (same) {
+                for (int k = 0; k < nf; k++)
+                    jump[k] = gs * (Z2[k] - Z1[k]);
+            } else {
+                double zp1 = 0.0, zp2 = 0.0, dd = 0.0;
+                for (int k = 0; k < nf; k++) {
+                    const double dz = x[k] - z[k];
+                    zp1 = zp1 + Z1[k] * dz;
+                    zp2 = zp2 + Z2[k] * dz;
+                    dd = dd + dz * dz;
+                }
+                for (int k = 0; k < nf; k++)
+                    jump[k] = ((gs * (zp1 - zp2)) * (x[k] - z[k])) / dd;
+            }
+        } else {
+            for (int k = 0; k < nf; k++)
+                jump[k] = P->gamma * (Z1[k] - Z2[k]) + P->fepsilon * normal[k];
+        }
+    } else if (P->sampler == LS_MRW) {                    /* chain.py:219-220 */
+        for (int k = 0; k < nf; k++)
+            jump[k] = normal[k];
+    } else {                                              /* chain.py:221-232 */
+        const int n = P->nchains;
+        draw2(P->seed, (uint64_t)iter, (uint32_t)c, 0, &q0, &q1);
+        int r1 = 1 + (int)bounded(q0, (uint64_t)(n - 1));
+        if (r1 == c)
+            r1 = 0;
+        int r2 = (r1 + 2 + (int)bounded(q1, (uint64_t)(n - 2))) % n;
+        if (r2 == c)
+            r2 = (r1 + 1) % n;
+        const double *x1 = snap + (size_t)r1 * nf, *x2 = snap + (size_t)r2 * nf;
+        for (int k = 0; k < nf; k++)
+            jump[k] = P->gamma * (x1[k] - x2[k]) + P->fepsilon * normal[k];
+    }
+
+    /* proposal and boundaries, chain.py:235-243 */
+    memcpy(nextp, P->params, sizeof(double) * (size_t)P->nparams);
+    int anyout = 0;
+    for (int k = 0; k < nf; k++) {
+        const int j = P->ifree[k];
+        nextp[j] = x[k] + jump[k];
+        if (nextp[j] < P->pmin[j] || nextp[j] > P->pmax[j])
+            anyout = 1;
+    }
+    double nextchisq = NAN;
+    if (anyout) {
+        for (int k = 0; k < nf; k++) {
+            const int j = P->ifree[k];
+            if (nextp[j] < P->pmin[j] || nextp[j] > P->pmax[j]) {
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+                St->outbounds[k] += 1;
+            }
+        }
+    } else {
+        flag |= 1;
+        for (int s = 0; s < P->nshare; s++)               /* chain.py:246-247 */
+            nextp[P->ishare[s]] = nextp[P->share_src[s]];
+        nextchisq = eval_chisq(P, nextp, S);              /* chain.py:249 */
+        if (sjump) {                                      /* chain.py:251-255 */
+            double cnorm = 0.0, nnorm = 0.0;
+            for (int k = 0; k < nf; k++) {
+                const double dc = x[k] - z[k];
+                const double dn = nextp[P->ifree[k]] - z[k];
+                cnorm = cnorm + dc * dc;
+                nnorm = nnorm + dn * dn;
+            }
+            mrfactor = mc3_det_pow_half(nnorm / cnorm, nf - 1);
+        }
+        const int uslot = (P->sampler == LS_SNOOKER) ? 2 : 1;
+        draw2(P->seed, (uint64_t)iter, (uint32_t)c, (uint32_t)uslot, &q0, &q1);
+        const double u = (P->sampler == LS_SNOOKER) ? u01(q1) : u01(q0);
+        const double ratio = mc3_det_exp(0.5 * (St->chisq[c] - nextchisq)) * mrfactor;
+        if (ratio > u) {                                  /* chain.py:257-274 */
+            flag |= 2;
+            for (int k = 0; k < nf; k++)
+                x[k] = nextp[P->ifree[k]];
+            St->chisq[c] = nextchisq;
+            St->numaccept[c] += 1;
+            if (nextchisq < St->best_chisq[c]) {
+                St->best_chisq[c] = nextchisq;
+                St->best_iter[c] = iter;
+                memcpy(St->bestx + (size_t)c * nf, x, sizeof(double) * (size_t)nf);
+            }
+        }
+    }
+    if (tr_chisq)
+        *tr_chisq = nextchisq;
+    if (tr_flag)
+        *tr_flag = flag;
+}
+
+/* Advance chains [chain0, chain0+nlocal) by nrefresh Z refreshes of `thinning`
+ * iterations each.  Rows of the other chains must already be in Z when a later
+ * refresh needs them (the multi-rank exchange is the caller's business). */
+int ls_run(const ls_problem *P, ls_state *St, int64_t nrefresh, int nthreads)
+{
+    const int nf = P->nfree;
+    const int64_t R0 = St->refresh_done;
+    if (P->M0 + (R0 + nrefresh) * P->nchains > P->zlen)
+        return -1;
+    for (int64_t R = R0; R < R0 + nrefresh; R++) {
+        const double *snap = (R == 0) ? St->snap0
+                           : St->Z + (size_t)(P->M0 + (R - 1) * P->nchains) * nf;
+        const int64_t zsize = P->M0 + R * P->nchains;
+        const int64_t row0 = P->M0 + R * P->nchains;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+        {
+            ls_scratch S;
+            S.part = malloc(sizeof(double) * (size_t)P->vlanes);
+            S.buf0 = malloc(sizeof(double) * (size_t)P->ndata);
+            S.buf1 = malloc(sizeof(double) * (size_t)P->ndata);
+            S.nextp = malloc(sizeof(double) * (size_t)P->nparams);
+            S.jump = malloc(sizeof(double) * (size_t)nf);
+            S.normal = malloc(sizeof(double) * (size_t)nf);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+            for (int c = P->chain0; c < P->chain0 + P->nlocal; c++) {
+                for (int j = 0; j < P->thinning; j++) {
+                    const int64_t iter = R * P->thinning + j;
+                    const int64_t trow = (R - R0) * P->thinning + j;
+                    chain_step(P, St, &S, c, iter, snap, zsize,
+                               St->trace_chisq ? St->trace_chisq + trow * P->nchains + c : NULL,
+                               St->trace_flag ? St->trace_flag + trow * P->nchains + c : NULL);
+                }
+                /* Z append, chain.py:276-289 (strided slot M0 + ID + k*nchains) */
+                const int64_t row = row0 + c;
+                memcpy(St->Z + (size_t)row * nf, St->X + (size_t)c * nf,
+                       sizeof(double) * (size_t)nf);
+                St->log_post[row] = -0.5 * St->chisq[c];
+                St->zchain[row] = c;
+            }
+            free(S.part); free(S.buf0); free(S.buf1);
+            free(S.nextp); free(S.jump); free(S.normal);
+        }
+    }
+    St->refresh_done = R0 + nrefresh;
+    return 0;
+}
+
+/* exported so tests can pin the shared deterministic functions to libm */
+double ls_det_exp(double x) { return mc3_det_exp(x); }
+double ls_det_exp2(double x) { return mc3_det_exp2(x); }
+double ls_det_log(double x) { return mc3_det_log(x); }
+void ls_det_sincos2pi(double u, double *s, double *c) { mc3_det_sincos2pi(u, s, c); }
+double ls_det_pow_half(double b, int e2) { return mc3_det_pow_half(b, e2); }

@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the reference itself.
+
+Runs ONLY in the build container, where /root/reference exists:
+
+    make -C oracle ref            # the reference's C modules -> oracle/_ref
+    python tests/golden/make_golden.py
+
+It imports mc3 v3.2.1 straight from /root/reference (nothing is copied) with
+oracle/_ref on sys.path for its compiled modules, makes the runs deterministic
+the way SURVEY.md section 8c describes -- ``mc3.chain.random.randint`` replaced
+by a constant (the reference reseeds NumPy from it inside the forked worker,
+mc3/chain.py:180), ``np.random.seed`` set in the parent, ``ncpu=1`` -- and
+stores inputs + outputs as small fixtures.  The fixtures are data only; no
+reference source travels.
+"""
+import io
+import os
+import sys
+import contextlib
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, 'oracle', '_ref'))
+sys.path.insert(0, '/root/reference')
+
+import numpy as np  # noqa: E402
+import mc3  # noqa: E402
+import mc3.stats as ms  # noqa: E402
+import mc3.chain  # noqa: E402
+
+CHAIN_SEED = 4242
+
+
+class _ConstRandom:
+    """Stand-in for the ``random`` module inside mc3.chain (HZ1)."""
+    @staticmethod
+    def randint(a, b):
+        return CHAIN_SEED
+
+
+sys.modules['mc3.chain'].random = _ConstRandom
+
+
+def quad(p, x):
+    return p[0] + p[1]*x + p[2]*x**2.0
+
+
+def line_shared(p, x):
+    # 5 parameters: p3 is shared with p1 (pstep=-2), p4 is fixed
+    return p[0] + p[1]*x + p[2]*x**2.0 + (p[3] - p[1])*x + (p[4] - 1.0)
+
+
+def tutorial_data(ndata, seed=314):
+    """examples/tutorial.py:22-29 at a chosen size."""
+    rs = np.random.RandomState(seed)
+    x = np.linspace(0, 10, ndata)
+    p_true = [3.0, -2.4, 0.5]
+    y = quad(p_true, x)
+    uncert = np.sqrt(np.abs(y))
+    data = y + rs.normal(0, uncert)
+    return x, data, uncert
+
+
+_captured = {}
+_orig_update_output = ms.update_output
+
+
+def _capture_update_output(output, chain, hsize):
+    _captured['outbounds'] = np.array(chain.outbounds[:], dtype=np.int64)
+    _captured['numaccept'] = int(chain.numaccept.value)
+    _captured['chainsize'] = np.array(chain.chainsize, dtype=np.int64)
+    return _orig_update_output(output, chain, hsize)
+
+
+sys.modules['mc3.mcmc_driver'].ms.update_output = _capture_update_output
+
+
+def run_case(name, hub_seed, func, **kw):
+    np.random.seed(hub_seed)
+    cwd = os.getcwd()
+    os.chdir('/tmp')
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = mc3.sample(func=func, ncpu=1, plots=False, grtest=False,
+                             log=None, **kw)
+    finally:
+        os.chdir(cwd)
+    save = dict(
+        hub_seed=hub_seed, chain_seed=CHAIN_SEED,
+        data=kw['data'], uncert=kw['uncert'], x=kw['indparams'][0],
+        params=kw['params'], pstep=kw['pstep'],
+        pmin=kw.get('pmin', np.tile(-np.inf, len(kw['params']))),
+        pmax=kw.get('pmax', np.tile(np.inf, len(kw['params']))),
+        prior=kw.get('prior', np.zeros(len(kw['params']))),
+        priorlow=kw.get('priorlow', np.zeros(len(kw['params']))),
+        priorup=kw.get('priorup', np.zeros(len(kw['params']))),
+        nchains=kw['nchains'], nsamples=kw['nsamples'],
+        sampler=kw['sampler'], wlike=kw.get('wlike', False),
+        thinning=kw.get('thinning', 1), burnin=kw.get('burnin', 0),
+        fgamma=kw.get('fgamma', 1.0), fepsilon=kw.get('fepsilon', 0.0),
+        hsize=kw.get('hsize', 10), kickoff=kw.get('kickoff', 'normal'),
+        outbounds=_captured['outbounds'], numaccept=_captured['numaccept'],
+        chainsize=_captured['chainsize'],
+    )
+    for key, val in out.items():
+        if key in ('pnames', 'texnames'):
+            continue
+        save['out_' + key] = np.asarray(val)
+    np.savez_compressed(os.path.join(HERE, f'seq_{name}.npz'), **save)
+    print(f'{name}: numaccept={save["numaccept"]} outbounds={save["outbounds"]} '
+          f'rows={len(out["posterior"])}')
+
+
+def chain_cases():
+    x, data, uncert = tutorial_data(100)
+    base = dict(data=data, uncert=uncert, indparams=[x],
+                params=np.array([10.0, -2.0, 0.1]),
+                pstep=np.array([1.0, 0.5, 0.1]),
+                pmin=np.array([-10.0, -20.0, -10.0]),
+                pmax=np.array([40.0, 20.0, 10.0]))
+    run_case('quad_snooker', 11, quad, sampler='snooker', nchains=7,
+             nsamples=2100, burnin=20, **base)
+    run_case('quad_demc', 12, quad, sampler='demc', nchains=8,
+             nsamples=2400, burnin=20, **base)
+    run_case('quad_mrw', 13, quad, sampler='mrw', nchains=7,
+             nsamples=1400, burnin=10, **base)
+    run_case('quad_demc_eps_thin', 14, quad, sampler='demc', nchains=9,
+             nsamples=1800, thinning=2, fepsilon=0.01, fgamma=0.9, burnin=10,
+             **base)
+    # tight bounds (out-of-bounds counters), Gaussian priors (two-sided),
+    # one shared and one fixed parameter, uniform kickoff:
+    x, data, uncert = tutorial_data(64)
+    run_case('shared_priors_snooker', 15, line_shared,
+             data=data, uncert=uncert, indparams=[x],
+             params=np.array([3.2, -2.2, 0.45, -2.2, 1.0]),
+             pstep=np.array([0.3, 0.1, 0.03, -2, 0.0]),
+             pmin=np.array([2.0, -3.0, 0.42, -3.0, 0.0]),
+             pmax=np.array([4.5, -1.9, 0.56, -1.9, 2.0]),
+             prior=np.array([3.0, 0.0, 0.5, 0.0, 0.0]),
+             priorlow=np.array([0.5, 0.0, 0.02, 0.0, 0.0]),
+             priorup=np.array([0.25, 0.0, 0.04, 0.0, 0.0]),
+             sampler='snooker', nchains=8, nsamples=2400, burnin=10,
+             kickoff='uniform')
+    # wavelet likelihood: quad + (gamma fixed, sigma_r, sigma_w), ndata = 2^6
+    rs = np.random.RandomState(99)
+    x = np.linspace(0, 10, 64)
+    y = quad([3.0, -2.4, 0.5], x)
+    data = y + rs.normal(0, 1.0, 64) + 0.5*np.sin(2*np.pi*x)
+    uncert = np.ones(64)
+    run_case('wavelet_snooker', 16, quad,
+             data=data, uncert=uncert, indparams=[x],
+             params=np.array([3.0, -2.4, 0.5, 1.0, 0.5, 1.0]),
+             pstep=np.array([0.3, 0.1, 0.02, 0.0, 0.1, 0.1]),
+             pmin=np.array([-10.0, -20.0, -10.0, 0.0, 0.01, 0.01]),
+             pmax=np.array([40.0, 20.0, 10.0, 2.0, 10.0, 10.0]),
+             sampler='snooker', nchains=7, nsamples=1400, burnin=10,
+             wlike=True)
+
+
+def kernel_vectors():
+    """Standalone likelihood-kernel vectors: (params, data) -> chisq."""
+    out = {}
+    rs = np.random.RandomState(2718)
+    for ndata in (8, 32, 1000, 16384):
+        x, data, uncert = tutorial_data(ndata, seed=1000 + ndata)
+        P = np.array([3.0, -2.4, 0.5]) + rs.normal(0, [0.3, 0.1, 0.02], (6, 3))
+        prior = np.array([3.0, 0.0, 0.5])
+        plow = np.array([0.5, 0.0, 0.02])
+        pup = np.array([0.25, 0.0, 0.04])
+        c0 = [ms.chisq(quad(p, x), data, uncert) for p in P]
+        c1 = [ms.chisq(quad(p, x), data, uncert, p, prior, plow, pup) for p in P]
+        out[f'gauss_{ndata}_params'] = P
+        out[f'gauss_{ndata}_chisq'] = np.array(c0)
+        out[f'gauss_{ndata}_chisq_priors'] = np.array(c1)
+        out[f'gauss_{ndata}_residuals0'] = ms.residuals(
+            quad(P[0], x), data, uncert, P[0], prior, plow, pup)
+    out['gauss_prior'] = prior
+    out['gauss_priorlow'] = plow
+    out['gauss_priorup'] = pup
+    for ndata in (2, 4, 8, 32, 1024, 16384):
+        rs2 = np.random.RandomState(2000 + ndata)
+        x = np.linspace(0, 10, ndata)
+        data = quad([3.0, -2.4, 0.5], x) + rs2.normal(0, 1.0, ndata) \
+            + 0.5*np.sin(2*np.pi*x)
+        P = np.zeros((5, 6))
+        P[:, 0:3] = np.array([3.0, -2.4, 0.5]) + rs.normal(0, [0.3, 0.1, 0.02], (5, 3))
+        P[:, 3] = 1.0
+        P[:, 4] = rs.uniform(0.1, 2.0, 5)
+        P[:, 5] = rs.uniform(0.5, 2.0, 5)
+        prior = np.array([3.0, 0.0, 0.5, 0.0, 0.5, 0.0])
+        plow = np.array([0.5, 0.0, 0.0, 0.0, 0.2, 0.0])
+        pup = np.array([0.25, 0.0, 0.0, 0.0, 0.1, 0.0])
+        c0 = [ms.dwt_chisq(quad(p[0:3], x), data, p) for p in P]
+        c1 = [ms.dwt_chisq(quad(p[0:3], x), data, p, prior, plow, pup) for p in P]
+        out[f'dwt_{ndata}_params'] = P
+        out[f'dwt_{ndata}_chisq'] = np.array(c0)
+        out[f'dwt_{ndata}_chisq_priors'] = np.array(c1)
+    out['dwt_prior'] = prior
+    out['dwt_priorlow'] = plow
+    out['dwt_priorup'] = pup
+    # D4 transform vectors (forward / inverse), power-of-two and padded sizes
+    for n in (4, 8, 32, 100, 1024):
+        v = np.random.RandomState(3000 + n).normal(0, 1, n)
+        out[f'daub4_{n}_in'] = v
+        out[f'daub4_{n}_fwd'] = ms.dwt_daub4(v)
+        out[f'daub4_{n}_inv'] = ms.dwt_daub4(v, True)
+    # log_prior vectors
+    post = rs.normal([3.0, 0.5], [0.5, 0.05], (40, 2))
+    out['logprior_post'] = post
+    out['logprior_value'] = ms.log_prior(
+        post, np.array([3.0, 0.0, 0.5]), np.array([0.5, 0.0, 0.02]),
+        np.array([0.25, 0.0, 0.04]), np.array([1.0, 0.0, 0.1]))
+    np.savez_compressed(os.path.join(HERE, 'kernel_vectors.npz'), **out)
+    print('kernel_vectors:', len(out), 'arrays')
+
+
+if __name__ == '__main__':
+    kernel_vectors()
+    chain_cases()
