@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- million chain-steps/sec of the MI355X chain-update path.
+
+Workload (BASELINE.json configs[1], "C2"): quadratic 3-parameter fit,
+ndata=1000, 256 chains per GPU, sampler='demc', thinning=1, fepsilon=0,
+synthetic data as in examples/tutorial.py:22-46 of the reference (SURVEY.md
+section 8d).  A "step" is one Z refresh: every chain of the ensemble advances
+`thinning` iterations (proposal -> model -> chisq -> Metropolis -> Z append) in
+one launch of the fused step kernel.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+N > 1 is weak scaling: 256*N chains, rank r owns chains [256 r, 256 (r+1)); the
+only data-path collective is one in-place RCCL all-gather of the refresh's new
+Z rows (libmc3hip calls RCCL itself; torch.distributed/gloo is only used to
+hand out the RCCL id, for the barriers and for the max-over-ranks time).
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CHAINS_PER_GPU = 256
+NDATA = 1000
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# algorithmic bytes per chain-step, Gaussian poly, nfree=3:
+#   8*S*ndata + 8*nfree*(R+1) + 8 with S=3 streams (x, data, uncert), R=3 rows
+BYTES_PER_CHAIN_STEP = 8*3*NDATA + 8*3*(3 + 1) + 8
+
+
+def quad(p, x):
+    return p[0] + p[1]*x + p[2]*x**2.0
+
+
+def c2_problem(nchains, nrefresh, thinning=1):
+    rs = np.random.RandomState(314)
+    x = np.linspace(0, 10, NDATA)
+    y = quad([3.0, -2.4, 0.5], x)
+    uncert = np.sqrt(np.abs(y))
+    data = y + rs.normal(0, uncert)
+    return dict(data=data, uncert=uncert, indep=x,
+                params=np.array([10.0, -2.0, 0.1]),
+                pstep=np.array([1.0, 0.5, 0.1]),
+                pmin=np.array([-10.0, -20.0, -10.0]),
+                pmax=np.array([40.0, 20.0, 10.0]),
+                nchains=nchains, nsamples=nchains*nrefresh*thinning,
+                thinning=thinning, sampler='demc', model='poly', seed=12345,
+                hsize=10)
+
+
+def initial_population(prob, eval_chisq):
+    """M0 = hsize*nchains in-bounds draws around the initial guess
+    (mcmc_driver.py:229-262), chisq from the device."""
+    rs = np.random.RandomState(5)
+    M0 = prob['hsize']*prob['nchains']
+    x0, sig = prob['params'], prob['pstep']
+    Z0 = np.empty((0, 3))
+    while len(Z0) < M0:
+        trial = rs.normal(x0, sig, (2*M0, 3))
+        ok = np.all((trial >= prob['pmin']) & (trial <= prob['pmax']), axis=1)
+        Z0 = np.concatenate([Z0, trial[ok]])
+    Z0 = np.ascontiguousarray(Z0[:M0])
+    return Z0, -0.5*eval_chisq(Z0)
+
+
+def cpu_baseline(target_seconds=12.0):
+    """The oracle (oracle/oracle_lockstep.c: the same lockstep chain update in
+    plain C, OpenMP over chains) on this box's host cores, same C2 workload,
+    bounded to ~target_seconds."""
+    from oracle import lockstep as ls
+    cores = os.cpu_count() or 1
+    prob = c2_problem(CHAINS_PER_GPU, 200000)
+    orc = ls.LockstepRun(**{k: v for k, v in prob.items()})
+    Z0, lp0 = initial_population(prob, lambda Z: orc.eval_chisq(Z))
+    orc.set_population(Z0, lp0)
+    orc.run(nrefresh=50, nthreads=cores)                 # warm up
+    t0 = time.perf_counter()
+    orc.run(nrefresh=200, nthreads=cores)
+    per = (time.perf_counter() - t0)/200
+    n = int(max(200, min(150000, target_seconds/per)))
+    t0 = time.perf_counter()
+    orc.run(nrefresh=n, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {
+        'value': CHAINS_PER_GPU*n/dt/1e6, 'unit': 'million chain-steps/sec',
+        'cores': cores, 'kind': 'port',
+        'sample': f'{n} iterations of the same 256-chain C2 workload '
+                  f'({dt:.1f} s), oracle_lockstep.c with {cores} OpenMP threads',
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=40000)
+    ap.add_argument('--warmup', type=int, default=2048)
+    ap.add_argument('--thinning', type=int, default=1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus N>1 must be launched with torch.distributed.run '
+                     '(one process per GPU)')
+        args.gpus = world
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    from mc3_amd import engine
+
+    nchains = CHAINS_PER_GPU*world
+    nrefresh = args.steps + args.warmup
+    prob = c2_problem(nchains, nrefresh, args.thinning)
+    gpu = engine.DeviceChains(device=local_rank, chain0=rank*CHAINS_PER_GPU,
+                              nlocal=CHAINS_PER_GPU, **prob)
+    Z0, lp0 = initial_population(prob, gpu.eval_chisq)
+    gpu.set_population(Z0, lp0)
+    if world > 1:
+        ids = [engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        gpu.comm_init(ids[0], rank, world)
+
+    def barrier():
+        gpu.sync()
+        if world > 1:
+            torch.cuda.synchronize(local_rank)
+            dist.barrier()
+
+    gpu.run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    gpu.run(args.steps, sync=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    gpu_ms = gpu.last_run_ms()          # HIP events on the library's stream
+    if world > 1:
+        t = torch.tensor([dt, gpu_ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, gpu_ms = float(t[0]), float(t[1])
+
+    st = gpu.state()
+    accept = float(st['numaccept'].sum())/(CHAINS_PER_GPU*nrefresh*args.thinning)
+    chain_steps = nchains*args.steps*args.thinning
+    value = chain_steps/dt/1e6
+
+    # roofline of the dominant (only) kernel: step_kernel, one launch per step
+    launch_s = gpu_ms*1e-3/args.steps
+    bytes_per_launch = BYTES_PER_CHAIN_STEP*CHAINS_PER_GPU*args.thinning
+    achieved = bytes_per_launch/launch_s/1e9
+    out = {
+        'metric': 'million chain-steps/sec (nchains x iters/s), 256-chain quad fit ndata=1000',
+        'value': value, 'unit': 'million chain-steps/sec',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': dt*1e3/args.steps, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {
+            'workload': 'C2: quadratic 3-param fit, ndata=1000, 256 chains/GPU, '
+                        "sampler='demc', fepsilon=0",
+            'nchains': nchains, 'ndata': NDATA, 'thinning': args.thinning,
+            'chains_per_gpu': CHAINS_PER_GPU,
+            'parallelism': f'chains sharded x{world}' if world > 1 else 'single GPU',
+            'collective': 'one in-place RCCL all-gather of new Z rows per refresh'
+                          if world > 1 else None,
+            'waves_per_chain': gpu.plan['waves_per_chain'],
+            'graph_nodes': gpu.plan['graph_nodes'] if world == 1 else 0,
+            'acceptance_rate': accept,
+        },
+        'roofline': {
+            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBS, 'traffic': None,
+            'kernel': 'mc3hip::step_kernel',
+            'algorithmic_bytes_per_launch': bytes_per_launch,
+            'avg_launch_us': launch_s*1e6,
+            'note': 'algorithmic bytes (SURVEY 8d): x/data/uncert are chain-invariant '
+                    'and L2-resident, so hardware HBM traffic is far smaller; '
+                    'avg_launch_us = HIP-event time of the timed region / launches '
+                    '(includes inter-launch gaps)',
+        },
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    gpu.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

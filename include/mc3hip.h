@@ -1,0 +1,179 @@
+/*
+ * mc3hip.h -- C-ABI of libmc3hip.so: mc3's per-iteration chain update on MI355X.
+ *
+ * Drop-in boundary.  The reference has no C-ABI for this
+ * path: its native code is two CPython modules (_chisq, _dwt) called from a
+ * Python loop that runs in forked worker processes.  The entry points below are
+ * what a binding for the same path binds instead -- plain pointers and sizes, no
+ * Python, NumPy or torch types.  Each one cites the reference code it replaces
+ * (paths relative to the mc3 v3.2.1 tree).  INTEGRATION.md shows the ctypes
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns MC3HIP_OK (0) or a negative error code and never
+ *     aborts the process; mc3hip_last_error() gives the message (thread-local).
+ *   - host arrays are contiguous float64 / int32 / int64, C order.  (The
+ *     reference reads arbitrary strides through INDd, src_c/include/ind.h:7;
+ *     the Python edge makes arrays contiguous before calling.)
+ *   - the caller owns every host buffer; the library owns device memory for the
+ *     lifetime of the context and never keeps a host pointer after a call.
+ *   - one context drives one GPU on one HIP stream; contexts are independent.
+ */
+#ifndef MC3HIP_H
+#define MC3HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MC3HIP_OK            0
+#define MC3HIP_ERR_ARG      -1   /* invalid argument / unsupported configuration */
+#define MC3HIP_ERR_HIP      -2   /* HIP runtime error (message has the HIP string) */
+#define MC3HIP_ERR_STATE    -3   /* call sequence error (e.g. run before set_population) */
+#define MC3HIP_ERR_FULL     -4   /* Z buffer exhausted (chain.py:279 "stop when we fill Z") */
+#define MC3HIP_ERR_COMM     -5   /* RCCL error */
+
+/* sampler: mc3/chain.py:195,219,221 */
+#define MC3HIP_MRW      0
+#define MC3HIP_DEMC     1
+#define MC3HIP_SNOOKER  2
+
+/* declared model family (the reference calls an arbitrary Python callable,
+ * chain.py:317-319; the device path evaluates these two families in-kernel) */
+#define MC3HIP_MODEL_POLY    0   /* model_i = sum_k p[k] * x_i^k, k < nmodel      */
+#define MC3HIP_MODEL_LINEAR  1   /* model_i = sum_k A[k][i] * p[k], k < nmodel    */
+
+#define MC3HIP_FLAG_NO_GRAPH  1u /* launch eagerly instead of through a hipGraph  */
+
+#define MC3HIP_MAX_FREE     64
+#define MC3HIP_MAX_PARAMS  128
+
+typedef struct mc3hip_ctx mc3hip_ctx;
+
+/*
+ * Everything Chain.__init__ receives (mc3/chain.py:22-155) plus the sizes
+ * mcmc() derives (mc3/mcmc_driver.py:116-134).
+ */
+typedef struct mc3hip_problem {
+    int32_t struct_bytes;   /* sizeof(mc3hip_problem), checked                          */
+    int32_t device;         /* HIP device ordinal                                       */
+    int32_t nchains;        /* total number of chains (all ranks)                       */
+    int32_t chain0;         /* first chain owned by this context                        */
+    int32_t nlocal;         /* chains owned by this context (contiguous block)          */
+    int32_t nparams;        /* len(params), incl. fixed and shared                      */
+    int32_t ndata;
+    int32_t sampler;        /* MC3HIP_MRW / _DEMC / _SNOOKER                            */
+    int32_t wlike;          /* 0: Gaussian chisq (_chisq.c:111); 1: wavelet (_dwt.c:56) */
+    int32_t model_kind;     /* MC3HIP_MODEL_*                                           */
+    int32_t nmodel;         /* model coefficients = params[0:nmodel]                    */
+    int32_t thinning;       /* iterations per Z refresh (chain.py:276)                  */
+    uint32_t flags;
+    int32_t trace_iters;    /* >0: keep per-step chisq/flags of the last run (tests)    */
+    int64_t M0;             /* rows of the initial population (mcmc_driver.py:127)      */
+    int64_t zlen;           /* total Z rows = M0 + nzchain*nchains (mcmc_driver.py:134) */
+    uint64_t seed;          /* Philox key                                               */
+    double gamma;           /* fgamma*2.38/sqrt(2 nfree) (chain.py:175)                 */
+    double fepsilon;        /* chain.py:217,232                                         */
+    const double *params;   /* [nparams] initial / fixed values                         */
+    const double *pstep;    /* [nparams] >0 free, 0 fixed, <0 shared (chain.py:141-142) */
+    const double *pmin;     /* [nparams]                                                */
+    const double *pmax;     /* [nparams]                                                */
+    const double *prior;    /* [nparams]                                                */
+    const double *priorlow; /* [nparams] Gaussian prior iff priorlow>0 and priorup>0    */
+    const double *priorup;  /* [nparams]                               (stats.py:211)   */
+    const double *indep;    /* POLY: x[ndata]; LINEAR: A[nmodel][ndata]                 */
+    const double *data;     /* [ndata]                                                  */
+    const double *uncert;   /* [ndata] (unused when wlike, chain.py:327-329)            */
+} mc3hip_problem;
+
+/* how the library sums over data points (the checker follows the same order) */
+typedef struct mc3hip_plan {
+    int32_t vlanes;         /* strided partial sums per tile                  */
+    int32_t tile;           /* points per tile, 0 = one tile                  */
+    int32_t waves_per_chain;
+    int32_t graph_nodes;    /* refreshes per hipGraph replay, 0 = eager       */
+} mc3hip_plan;
+
+/* Replaces Chain.__init__ + the shared-memory allocation of mcmc()
+ * (mc3/chain.py:22-155, mc3/mcmc_driver.py:143-221): uploads the problem and
+ * allocates Z / log_post / zchain / freepars / counters on the device. */
+int mc3hip_create(const mc3hip_problem *problem, mc3hip_ctx **out);
+void mc3hip_destroy(mc3hip_ctx *ctx);
+const char *mc3hip_last_error(void);
+int mc3hip_get_plan(const mc3hip_ctx *ctx, mc3hip_plan *plan);
+
+/* Replaces the hub's Z[0:M0] / log_post[0:M0] fill and the workers' start-up
+ * (mcmc_driver.py:260-261, chain.py:163-170): Z0 is [M0][nfree], the chains start
+ * from its first nchains rows unless X0/chisq0 ([nchains][nfree], [nchains]) are
+ * given (resume: chain.py:166-169). */
+int mc3hip_set_population(mc3hip_ctx *ctx, const double *Z0,
+                          const double *log_post0, const double *X0,
+                          const double *chisq0);
+
+/* Replaces Chain.run's loop (mc3/chain.py:183-299) and the hub's per-iteration
+ * barrier (mcmc_driver.py:300-307): advance every local chain by nrefresh Z
+ * refreshes (nrefresh*thinning iterations).  Asynchronous; mc3hip_sync waits. */
+int mc3hip_run(mc3hip_ctx *ctx, int64_t nrefresh);
+int mc3hip_sync(mc3hip_ctx *ctx);
+/* GPU time in ms between the start and end of the last mc3hip_run (HIP events
+ * recorded on the context's stream). */
+int mc3hip_last_run_ms(mc3hip_ctx *ctx, float *ms);
+
+/* What update_output reads from the Chain object (mc3/stats/stats.py:813-826):
+ * rows [row0, row0+nrows) of Z / log_post / zchain.  Any pointer may be NULL. */
+int mc3hip_get_rows(mc3hip_ctx *ctx, int64_t row0, int64_t nrows, double *Z,
+                    double *log_post, int32_t *zchain);
+/* Current chain states and counters (freepars, chisq, numaccept, outbounds and
+ * the best-fit tracking of chain.py:261-274), indexed by LOCAL chain.  best_iter
+ * is the iteration at which a chain found its best state (-1: never accepted).
+ * Any pointer may be NULL. */
+int mc3hip_get_state(mc3hip_ctx *ctx, double *X, double *chisq,
+                     int64_t *numaccept, int64_t *outbounds,
+                     double *best_chisq, int64_t *best_iter, double *bestx,
+                     int64_t *refresh_done);
+/* Per-step trace of the last run (problem.trace_iters > 0): chisq of the
+ * proposal and flags (bit0 in bounds, bit1 accepted, bit2 snooker jump),
+ * [iters][nlocal]. */
+int mc3hip_get_trace(mc3hip_ctx *ctx, int64_t iters, double *chisq,
+                     int32_t *flags);
+
+/* Replaces Chain.eval_model(params, ret='chisq') -> ms.chisq / ms.dwt_chisq
+ * (chain.py:302-340, stats.py:150-284, _chisq.c:111-140, _dwt.c:56-119) for n
+ * parameter vectors at once ([n][nparams], shared parameters already copied). */
+int mc3hip_eval_chisq(mc3hip_ctx *ctx, const double *params, int32_t n,
+                      double *chisq_out);
+/* Replaces Chain.eval_model(params, ret='model') for the declared family. */
+int mc3hip_eval_model(mc3hip_ctx *ctx, const double *params, double *model_out);
+
+/* Replaces ms.dwt_daub4 (_dwt.c:154-186, wavelet.h:16-128): n is padded to the
+ * next power of two with zeros, out must hold that many doubles. */
+int mc3hip_dwt_daub4(int32_t device, const double *in, int32_t n,
+                     int32_t inverse, double *out);
+
+/* Multi-GPU (no reference counterpart; replaces the multiprocessing fan-out,
+ * mcmc_driver.py:204-221): one context per rank owns a contiguous block of
+ * chains; after every refresh the new Z rows are exchanged with ONE in-place
+ * ncclAllGather (RCCL) so that the next proposals see the whole population.
+ * unique_id: 128 bytes from mc3hip_comm_unique_id on rank 0, sent to the other
+ * ranks by the caller. */
+int mc3hip_comm_unique_id(void *unique_id_128);
+int mc3hip_comm_init(mc3hip_ctx *ctx, const void *unique_id_128, int32_t rank,
+                     int32_t nranks);
+/* Exchange log_post rows [row0, row0+nrows) that other ranks own (needed only
+ * when the posterior is read back). */
+int mc3hip_comm_gather_log_post(mc3hip_ctx *ctx);
+
+/* Self tests used by tests/ on the GPU: evaluate the shared deterministic
+ * functions on the device (op: 0 exp, 1 log, 2 exp2, 3 sin2pi, 4 cos2pi,
+ * 5 sqrt, 6 1/x) and Philox4x32-10 ([n][4] counters, one key). */
+int mc3hip_selftest_math(int32_t device, int32_t op, const double *in,
+                         int32_t n, double *out);
+int mc3hip_selftest_philox(int32_t device, const uint32_t *ctr, int32_t n,
+                           const uint32_t key[2], uint32_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MC3HIP_H */

@@ -1,0 +1,645 @@
+// chain_kernels.h -- the fused chain-update kernels (gfx950, wave64).
+//
+// One workgroup advances one chain through `thinning` iterations of
+//   proposal -> bounds -> shared params -> model -> chisq -> Metropolis -> Z append
+// (mc3/chain.py:185-289) with every other chain seen through the population
+// snapshot of the previous Z refresh.  WPC waves (64*WPC threads) share one chain:
+// the data sum is split over 1024 "virtual lanes" (point i belongs to lane
+// i mod 1024); a thread owns 16/WPC of them, so the summation order -- strided
+// partial sums, then a halving tree over the 1024 lanes -- is the same for every
+// WPC and is what oracle/oracle_lockstep.c follows.  No MFMA: with <= 10 model
+// coefficients there is no dense contraction to feed it.
+//
+// Arithmetic contract: compiled with -ffp-contract=off; fused multiply-adds only
+// where written (model, squared-residual accumulation, D4 taps, detmath).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "philox.h"
+#include "../../include/mc3hip.h"
+#include "../../include/mc3hip_detmath.h"
+
+namespace mc3hip {
+
+constexpr int VLANES = 1024;
+
+// model tags
+constexpr int MT_POLY_GENERIC = 0;   // runtime nmodel, coefficients read from LDS
+constexpr int MT_POLY2 = 2;          // p0 + p1 x
+constexpr int MT_POLY3 = 3;          // p0 + p1 x + p2 x^2
+constexpr int MT_POLY4 = 4;
+constexpr int MT_LINEAR = 100;       // sum_k A[k][i] p[k]
+
+struct DevProblem {
+    int32_t nchains, chain0, nlocal, nparams, nfree, nshare, ndata;
+    int32_t sampler, wlike, nmodel, thinning, ngprior, trace_iters;
+    int64_t M0;
+    uint64_t seed;
+    double gamma, fepsilon;
+    const int32_t *ifree, *ishare, *share_src, *igprior;
+    const double *params, *pmin, *pmax, *pstep, *prior, *priorlow, *priorup;
+    const double *indep, *data, *w;
+    double *Z, *log_post;
+    int32_t *zchain;
+    double *X, *chisq;
+    long long *numaccept;
+    unsigned long long *outbounds;
+    double *best_chisq;
+    long long *best_iter;
+    double *bestx;
+    const double *snap0;
+    double *trace_chisq;
+    int32_t *trace_flag;
+    const long long *ctl;   // ctl[0] = refresh base of this replay, ctl[1] = first refresh of the run
+};
+
+// ---- model evaluation ------------------------------------------------------
+template <int MT>
+struct Model {
+    double cf[(MT >= 1 && MT <= 8) ? MT : 1];
+    const double *coef;     // LDS copy of the proposal (generic / linear)
+    const double *indep;
+    int nmodel, ndata;
+
+    __device__ __forceinline__ void init(const DevProblem &P, const double *s_nextp)
+    {
+        coef = s_nextp;
+        indep = P.indep;
+        nmodel = P.nmodel;
+        ndata = P.ndata;
+        if constexpr (MT >= 1 && MT <= 8) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                cf[j] = s_nextp[j];
+        }
+    }
+    __device__ __forceinline__ double at(int i) const
+    {
+        if constexpr (MT >= 1 && MT <= 8) {
+            const double x = indep[i];
+            double m = cf[MT - 1];
+#pragma unroll
+            for (int j = MT - 2; j >= 0; --j)
+                m = mc3_fma(m, x, cf[j]);
+            return m;
+        } else if constexpr (MT == MT_POLY_GENERIC) {
+            const double x = indep[i];
+            double m = coef[nmodel - 1];
+            for (int j = nmodel - 2; j >= 0; --j)
+                m = mc3_fma(m, x, coef[j]);
+            return m;
+        } else {
+            double m = indep[i] * coef[0];
+            for (int k = 1; k < nmodel; ++k)
+                m = mc3_fma(indep[(size_t)k * ndata + i], coef[k], m);
+            return m;
+        }
+    }
+};
+
+__device__ __forceinline__ bool is_pos_inf(double v)
+{
+    return mc3_bits(v) == 0x7ff0000000000000ull;
+}
+
+// Halving tree over the 1024 virtual lanes.  acc[v] is this thread's partial for
+// virtual lane  lane + 64*(wave + WPC*v).  Strides >= 64*WPC are in-thread,
+// strides 64*WPC/2..64 go through LDS, strides 32..1 are wave shuffles.
+// The result is valid in every lane of wave 0.
+template <int WPC>
+__device__ __forceinline__ double lane_tree(double (&acc)[16 / WPC], double *s_part)
+{
+    constexpr int NV = 16 / WPC;
+#pragma unroll
+    for (int s = NV / 2; s >= 1; s >>= 1) {
+#pragma unroll
+        for (int v = 0; v < s; ++v)
+            acc[v] = acc[v] + acc[v + s];
+    }
+    double t = acc[0];
+    if constexpr (WPC > 1) {
+        __syncthreads();                      // s_part may still be read by wave 0
+        s_part[threadIdx.x] = t;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            double p[WPC];
+#pragma unroll
+            for (int w = 0; w < WPC; ++w)
+                p[w] = s_part[threadIdx.x + 64 * w];
+#pragma unroll
+            for (int s = WPC / 2; s >= 1; s >>= 1) {
+#pragma unroll
+                for (int w = 0; w < s; ++w)
+                    p[w] = p[w] + p[w + s];
+            }
+            t = p[0];
+        }
+    }
+    if (threadIdx.x < 64) {
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1)
+            t = t + __shfl_down(t, s, 64);
+        t = __shfl(t, 0, 64);
+    }
+    return t;
+}
+
+// Gaussian chi-squared data term, src_c/_chisq.c:131-133 with w = 1/uncert.
+// Returns +inf when any model value is +inf (chain.py:322-323).
+template <int WPC, int MT>
+__device__ double block_gauss(const DevProblem &P, const double *s_nextp, double *s_part)
+{
+    constexpr int NV = 16 / WPC;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    Model<MT> model;
+    model.init(P, s_nextp);
+    double acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        acc[v] = 0.0;
+    int sawinf = 0;
+    const int n = P.ndata;
+    for (int base = 0; base < n; base += VLANES) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int i = base + lane + 64 * (wv + WPC * v);
+            if (i < n) {
+                const double m = model.at(i);
+                sawinf |= is_pos_inf(m);
+                const double r = (m - P.data[i]) * P.w[i];
+                acc[v] = mc3_fma(r, r, acc[v]);
+            }
+        }
+    }
+    const double total = lane_tree<WPC>(acc, s_part);
+    sawinf = __syncthreads_or(sawinf);
+    return sawinf ? mc3_from_bits(0x7ff0000000000000ull) : total;
+}
+
+constexpr double D4C0 = 0.4829629131445341, D4C1 = 0.83651630373780772,
+                 D4C2 = 0.22414386804201339, D4C3 = -0.12940952255126034;
+
+__device__ __forceinline__ void d4_pair(double a0, double a1, double a2, double a3,
+                                        double &s, double &d)
+{
+    s = D4C0 * a0;
+    s = mc3_fma(D4C1, a1, s);
+    s = mc3_fma(D4C2, a2, s);
+    s = mc3_fma(D4C3, a3, s);
+    d = D4C3 * a0;
+    d = mc3_fma(-D4C2, a1, d);
+    d = mc3_fma(D4C1, a2, d);
+    d = mc3_fma(-D4C0, a3, d);
+}
+
+__device__ __forceinline__ int ilog2(int n)
+{
+    int m = 0;
+    while ((1 << m) < n)
+        ++m;
+    return m;
+}
+
+// Wavelet pseudo chi-squared (Carter & Winn 2009 eqs. 32-34), src_c/_dwt.c:76-114
+// over the D4 pyramid of src_c/include/wavelet.h:27-36,115-117, ndata = 2^M.
+// Level 0 takes the residuals data-model straight from global memory; the smooth
+// half of each level ping-pongs between two LDS buffers (N/2 and N/4 doubles);
+// detail coefficients are final when produced, so they are squared, weighted
+// by 1/sigma_W^2 of their scale and accumulated without ever being stored.
+template <int WPC, int MT>
+__device__ double block_wavelet(const DevProblem &P, const double *s_nextp, double *s_part,
+                                double *bufA, double *bufB)
+{
+    constexpr int NV = 16 / WPC;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int N = P.ndata;
+    Model<MT> model;
+    model.init(P, s_nextp);
+    const double gam = s_nextp[P.nparams - 3];
+    const double sr = s_nextp[P.nparams - 2];
+    const double sw = s_nextp[P.nparams - 1];
+    const double sr2 = sr * sr, sw2 = sw * sw;
+    double acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        acc[v] = 0.0;
+    int sawinf = 0;
+    const double *src = bufA;
+    if (N >= 4) {
+        const int nh = N >> 1;
+        {
+            const int m = ilog2(nh);
+            const double inv = 1.0 / (sr2 * mc3_det_exp2(-gam * (double)m) + sw2);
+            for (int base = 0; base < nh; base += VLANES) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int i = base + lane + 64 * (wv + WPC * v);
+                    if (i < nh) {
+                        const int j0 = 2 * i, j1 = 2 * i + 1;
+                        const int j2 = (2 * i + 2) & (N - 1), j3 = (2 * i + 3) & (N - 1);
+                        const double m0 = model.at(j0), m1 = model.at(j1);
+                        const double m2 = model.at(j2), m3 = model.at(j3);
+                        sawinf |= is_pos_inf(m0) | is_pos_inf(m1) | is_pos_inf(m2) |
+                                  is_pos_inf(m3);
+                        double s, d;
+                        d4_pair(P.data[j0] - m0, P.data[j1] - m1, P.data[j2] - m2,
+                                P.data[j3] - m3, s, d);
+                        bufA[i] = s;
+                        acc[v] = mc3_fma(d * d, inv, acc[v]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        double *dst = bufB;
+        double *cur = bufA;
+        for (int nn = nh; nn >= 4; nn >>= 1) {
+            const int nh2 = nn >> 1;
+            const int m = ilog2(nh2);
+            const double inv = 1.0 / (sr2 * mc3_det_exp2(-gam * (double)m) + sw2);
+            for (int base = 0; base < nh2; base += VLANES) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int i = base + lane + 64 * (wv + WPC * v);
+                    if (i < nh2) {
+                        double s, d;
+                        d4_pair(cur[2 * i], cur[2 * i + 1], cur[(2 * i + 2) & (nn - 1)],
+                                cur[(2 * i + 3) & (nn - 1)], s, d);
+                        dst[i] = s;
+                        acc[v] = mc3_fma(d * d, inv, acc[v]);
+                    }
+                }
+            }
+            __syncthreads();
+            double *t = cur;
+            cur = dst;
+            dst = t;
+        }
+        src = cur;
+    } else {
+        if (threadIdx.x < 2) {
+            const double m = model.at(threadIdx.x);
+            sawinf |= is_pos_inf(m);
+            bufA[threadIdx.x] = P.data[threadIdx.x] - m;
+        }
+        __syncthreads();
+    }
+    const double a0 = src[0], a1 = src[1];
+    const double T = lane_tree<WPC>(acc, s_part);
+    sawinf = __syncthreads_or(sawinf);
+    if (sawinf)
+        return mc3_from_bits(0x7ff0000000000000ull);
+    const int M = ilog2(N);
+    const double sS2 = sr2 * mc3_det_exp2(-gam) * 0.72134752 + sw2;
+    const double S = (a0 * a0) / sS2 + (a1 * a1) / sS2;
+    double Lg = 2.0 * mc3_det_log(6.283185307179586 * sS2);
+    for (int m = 1; m < M; ++m) {
+        const double sW2 = sr2 * mc3_det_exp2(-gam * (double)m) + sw2;
+        Lg = Lg + (double)(1 << m) * mc3_det_log(6.283185307179586 * sW2);
+    }
+    return (S + Lg) + T;
+}
+
+// prior term, mc3/stats/stats.py:211-216 + src_c/include/stats.h:96-106
+__device__ __forceinline__ double prior_term(const DevProblem &P, const double *s_nextp)
+{
+    double pr = 0.0;
+    for (int g = 0; g < P.ngprior; ++g) {
+        const int j = P.igprior[g];
+        const double d = s_nextp[j] - P.prior[j];
+        const double s = (d > 0.0) ? d / P.priorup[j] : d / P.priorlow[j];
+        pr = pr + s * s;
+    }
+    return pr;
+}
+
+// chisq of the parameter vector in s_nextp; valid in wave 0
+template <int WPC, int MT>
+__device__ __forceinline__ double block_chisq(const DevProblem &P, const double *s_nextp,
+                                              double *s_part, double *bufA, double *bufB)
+{
+    double c;
+    if (P.wlike)
+        c = block_wavelet<WPC, MT>(P, s_nextp, s_part, bufA, bufB);
+    else
+        c = block_gauss<WPC, MT>(P, s_nextp, s_part);
+    if (is_pos_inf(c))
+        return c;
+    return c + prior_term(P, s_nextp);
+}
+
+// serial sum over lanes 0..n-1 of a wave, in lane order
+__device__ __forceinline__ double lane_serial_sum(double t, int n)
+{
+    double s = 0.0;
+    for (int k = 0; k < n; ++k)
+        s = s + __shfl(t, k, 64);
+    return s;
+}
+
+struct SmemLayout {
+    double *part, *nextp, *bufA, *bufB;
+    int *flag;
+};
+
+__device__ __forceinline__ SmemLayout carve(double *smem, const DevProblem &P, int nthreads)
+{
+    SmemLayout L;
+    L.part = smem;
+    L.nextp = smem + nthreads;
+    L.flag = reinterpret_cast<int *>(L.nextp + MC3HIP_MAX_PARAMS);
+    L.bufA = L.nextp + MC3HIP_MAX_PARAMS + 2;
+    const int na = (P.ndata / 2 > 2) ? P.ndata / 2 : 2;
+    L.bufB = L.bufA + na;
+    return L;
+}
+
+static inline size_t smem_bytes(int nthreads, int ndata, int wlike)
+{
+    size_t n = (size_t)nthreads + MC3HIP_MAX_PARAMS + 2;
+    if (wlike) {
+        const size_t na = (ndata / 2 > 2) ? ndata / 2 : 2;
+        const size_t nb = (ndata / 4 > 2) ? ndata / 4 : 2;
+        n += na + nb;
+    } else {
+        n += 4;
+    }
+    return n * sizeof(double);
+}
+
+// ---- the chain update -------------------------------------------------------
+template <int WPC, int MT>
+__global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, const int roff)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const SmemLayout L = carve(smem, P, 64 * WPC);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool wave0 = tid < 64;
+    const int lc = blockIdx.x;                 // local chain
+    const int c = P.chain0 + lc;               // global chain id
+    const int nf = P.nfree;
+    const long long R = P.ctl[0] + roff;       // refresh index
+    const double *snap = (R == 0) ? P.snap0
+                                  : P.Z + (size_t)(P.M0 + (R - 1) * P.nchains) * nf;
+    const long long zsize = P.M0 + R * P.nchains;
+    const bool mine = wave0 && lane < nf;      // lane k of wave 0 owns free parameter k
+    const int jfree = mine ? P.ifree[lane] : 0;
+
+    // chain state lives in wave 0's registers for the whole launch
+    double xk = mine ? P.X[(size_t)lc * nf + lane] : 0.0;
+    double cur = P.chisq[lc];
+    double best = P.best_chisq[lc];
+    long long nacc = 0;
+    const double pmin_k = mine ? P.pmin[jfree] : 0.0;
+    const double pmax_k = mine ? P.pmax[jfree] : 0.0;
+    const bool need_normal = (P.sampler == MC3HIP_MRW) || (P.fepsilon != 0.0);
+    const double pstep_k = (mine && need_normal) ? P.pstep[jfree] : 0.0;
+
+    for (int j = 0; j < P.thinning; ++j) {
+        const uint64_t iter = (uint64_t)(R * P.thinning + j);
+        double npk = 0.0, zk = 0.0;
+        double mrfactor = 1.0;
+        bool sjump = false, outk = false;
+        int flags = 0;
+        if (wave0) {
+            // support-distribution draw, chain.py:185
+            double normal_k = 0.0;
+            if (need_normal && mine) {
+                const Draw2 d = draw2(P.seed, iter, (uint32_t)c, (uint32_t)(3 + (lane >> 1)));
+                const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(d.q0)));
+                double sn, cs;
+                mc3_det_sincos2pi(u01(d.q1), &sn, &cs);
+                normal_k = (rad * ((lane & 1) ? sn : cs)) * pstep_k;
+            }
+            double jump_k = 0.0;
+            if (P.sampler == MC3HIP_SNOOKER) {                       // chain.py:195-217
+                const Draw2 d0 = draw2(P.seed, iter, (uint32_t)c, 0u);
+                long long iR1 = (long long)bounded(d0.q0, (uint64_t)zsize);
+                long long iR2 = 1 + (long long)bounded(d0.q1, (uint64_t)(zsize - 1));
+                if (iR2 == iR1)
+                    iR2 = 0;
+                const Draw2 d1 = draw2(P.seed, iter, (uint32_t)c, 1u);
+                sjump = u01(d1.q0) < 0.1;
+                const long long iz = (long long)bounded(d1.q1, (uint64_t)zsize);
+                const double z1 = mine ? P.Z[(size_t)iR1 * nf + lane] : 0.0;
+                const double z2 = mine ? P.Z[(size_t)iR2 * nf + lane] : 0.0;
+                if (sjump) {
+                    flags |= 4;
+                    const Draw2 d2 = draw2(P.seed, iter, (uint32_t)c, 2u);
+                    const double gs = 1.2 + (2.2 - 1.2) * u01(d2.q0);
+                    zk = mine ? P.Z[(size_t)iz * nf + lane] : 0.0;
+                    const bool same = __all(!mine || zk == xk);
+                    if (same) {
+                        jump_k = gs * (z2 - z1);
+                    } else {
+                        const double dz = xk - zk;
+                        const double zp1 = lane_serial_sum(z1 * dz, nf);
+                        const double zp2 = lane_serial_sum(z2 * dz, nf);
+                        const double dd = lane_serial_sum(dz * dz, nf);
+                        jump_k = ((gs * (zp1 - zp2)) * dz) / dd;
+                    }
+                } else {
+                    jump_k = P.gamma * (z1 - z2) + P.fepsilon * normal_k;
+                }
+            } else if (P.sampler == MC3HIP_MRW) {                    // chain.py:219-220
+                jump_k = normal_k;
+            } else {                                                 // chain.py:221-232
+                const int n = P.nchains;
+                const Draw2 d0 = draw2(P.seed, iter, (uint32_t)c, 0u);
+                int r1 = 1 + (int)bounded(d0.q0, (uint64_t)(n - 1));
+                if (r1 == c)
+                    r1 = 0;
+                int r2 = (r1 + 2 + (int)bounded(d0.q1, (uint64_t)(n - 2))) % n;
+                if (r2 == c)
+                    r2 = (r1 + 1) % n;
+                const double x1 = mine ? snap[(size_t)r1 * nf + lane] : 0.0;
+                const double x2 = mine ? snap[(size_t)r2 * nf + lane] : 0.0;
+                jump_k = P.gamma * (x1 - x2) + P.fepsilon * normal_k;
+            }
+            // proposal and boundaries, chain.py:235-243
+            npk = xk + jump_k;
+            outk = mine && (npk < pmin_k || npk > pmax_k);
+            const bool anyout = __any(outk);
+            for (int q = lane; q < P.nparams; q += 64)
+                L.nextp[q] = P.params[q];
+            if (mine)
+                L.nextp[jfree] = npk;
+            if (lane == 0) {
+                for (int s = 0; s < P.nshare; ++s)                   // chain.py:246-247
+                    L.nextp[P.ishare[s]] = L.nextp[P.share_src[s]];
+                L.flag[0] = anyout ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        const bool anyout = L.flag[0] != 0;
+        double nextchisq = mc3_from_bits(0x7ff8000000000000ull);
+        if (!anyout) {
+            flags |= 1;
+            nextchisq = block_chisq<WPC, MT>(P, L.nextp, L.part, L.bufA, L.bufB);  // chain.py:249
+            if (wave0) {
+                if (sjump) {                                         // chain.py:251-255
+                    const double dc = xk - zk, dn = npk - zk;
+                    const double cnorm = lane_serial_sum(mine ? dc * dc : 0.0, nf);
+                    const double nnorm = lane_serial_sum(mine ? dn * dn : 0.0, nf);
+                    mrfactor = mc3_det_pow_half(nnorm / cnorm, nf - 1);
+                }
+                const Draw2 du = draw2(P.seed, iter, (uint32_t)c,
+                                       (P.sampler == MC3HIP_SNOOKER) ? 2u : 1u);
+                const double u = (P.sampler == MC3HIP_SNOOKER) ? u01(du.q1) : u01(du.q0);
+                const double ratio = mc3_det_exp(0.5 * (cur - nextchisq)) * mrfactor;
+                if (ratio > u) {                                     // chain.py:257-274
+                    flags |= 2;
+                    xk = npk;
+                    cur = nextchisq;
+                    nacc += 1;
+                    if (nextchisq < best) {
+                        best = nextchisq;
+                        if (mine)
+                            P.bestx[(size_t)lc * nf + lane] = xk;
+                        if (lane == 0)
+                            P.best_iter[lc] = (long long)iter;
+                    }
+                }
+            }
+        } else if (outk) {
+            atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
+        }
+        if (P.trace_iters > 0 && tid == 0) {
+            const long long trow = (R - P.ctl[1]) * P.thinning + j;
+            if (trow >= 0 && trow < P.trace_iters) {
+                P.trace_chisq[trow * P.nlocal + lc] = nextchisq;
+                P.trace_flag[trow * P.nlocal + lc] = flags;
+            }
+        }
+        __syncthreads();
+    }
+    // Z append, chain.py:276-289 (strided slot M0 + ID + k*nchains)
+    if (wave0) {
+        const long long row = P.M0 + R * P.nchains + c;
+        if (mine) {
+            P.X[(size_t)lc * nf + lane] = xk;
+            P.Z[(size_t)row * nf + lane] = xk;
+        }
+        if (lane == 0) {
+            P.chisq[lc] = cur;
+            P.best_chisq[lc] = best;
+            P.numaccept[lc] += nacc;
+            P.log_post[row] = -0.5 * cur;
+            P.zchain[row] = c;
+        }
+    }
+}
+
+// chisq for arbitrary parameter vectors (Chain.eval_model(ret='chisq'))
+template <int WPC, int MT>
+__global__ __launch_bounds__(64 * WPC) void eval_chisq_kernel(const DevProblem P,
+                                                              const double *params,
+                                                              double *out)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const SmemLayout L = carve(smem, P, 64 * WPC);
+    for (int q = threadIdx.x; q < P.nparams; q += 64 * WPC)
+        L.nextp[q] = params[(size_t)blockIdx.x * P.nparams + q];
+    __syncthreads();
+    const double c = block_chisq<WPC, MT>(P, L.nextp, L.part, L.bufA, L.bufB);
+    if (threadIdx.x == 0)
+        out[blockIdx.x] = c;
+}
+
+template <int MT>
+__global__ void eval_model_kernel(const DevProblem P, const double *params, double *out)
+{
+    __shared__ double s_p[MC3HIP_MAX_PARAMS];
+    for (int q = threadIdx.x; q < P.nparams; q += blockDim.x)
+        s_p[q] = params[q];
+    __syncthreads();
+    Model<MT> model;
+    model.init(P, s_p);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.ndata;
+         i += gridDim.x * blockDim.x)
+        out[i] = model.at(i);
+}
+
+// standalone D4 transform (ms.dwt_daub4): one workgroup, global-memory ping-pong
+__global__ void daub4_kernel(double *a, double *tmp, int n, int inverse)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (!inverse) {
+        for (int nn = n; nn >= 4; nn >>= 1) {
+            const int nh = nn >> 1;
+            for (int i = tid; i < nh; i += nt) {
+                double s, d;
+                d4_pair(a[2 * i], a[2 * i + 1], a[(2 * i + 2) & (nn - 1)],
+                        a[(2 * i + 3) & (nn - 1)], s, d);
+                tmp[i] = s;
+                tmp[i + nh] = d;
+            }
+            __syncthreads();
+            for (int i = tid; i < nn; i += nt)
+                a[i] = tmp[i];
+            __syncthreads();
+        }
+    } else {
+        for (int nn = 4; nn <= n; nn <<= 1) {                        // wavelet.h:37-43
+            const int nh = nn >> 1;
+            for (int i = tid; i < nh; i += nt) {
+                const int im = (i + nh - 1) & (nh - 1);
+                const double sp = a[im], dp = a[im + nh], sc = a[i], dc = a[i + nh];
+                double e = D4C2 * sp;
+                e = mc3_fma(D4C1, dp, e);
+                e = mc3_fma(D4C0, sc, e);
+                e = mc3_fma(D4C3, dc, e);
+                double o = D4C3 * sp;
+                o = mc3_fma(-D4C0, dp, o);
+                o = mc3_fma(D4C1, sc, o);
+                o = mc3_fma(-D4C2, dc, o);
+                tmp[2 * i] = e;
+                tmp[2 * i + 1] = o;
+            }
+            __syncthreads();
+            for (int i = tid; i < nn; i += nt)
+                a[i] = tmp[i];
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void set_ctl_kernel(long long *ctl, long long base, long long run0)
+{
+    ctl[0] = base;
+    if (run0 >= 0)
+        ctl[1] = run0;
+}
+
+__global__ void selftest_math_kernel(int op, const double *in, int n, double *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const double x = in[i];
+    double r, s, c;
+    switch (op) {
+    case 0: r = mc3_det_exp(x); break;
+    case 1: r = mc3_det_log(x); break;
+    case 2: r = mc3_det_exp2(x); break;
+    case 3: mc3_det_sincos2pi(x, &s, &c); r = s; break;
+    case 4: mc3_det_sincos2pi(x, &s, &c); r = c; break;
+    case 5: r = __builtin_sqrt(x); break;
+    default: r = 1.0 / x; break;
+    }
+    out[i] = r;
+}
+
+__global__ void selftest_philox_kernel(const uint32_t *ctr, int n, uint32_t k0, uint32_t k1,
+                                       uint32_t *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    uint32_t w[4];
+    philox4x32_10(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], ctr[4 * i + 3], k0, k1, w);
+    for (int q = 0; q < 4; ++q)
+        out[4 * i + q] = w[q];
+}
+
+}  // namespace mc3hip

@@ -1,0 +1,866 @@
+// mc3hip.hip -- C-ABI (include/mc3hip.h) over the chain-update kernels.
+//
+// Host side of the drop-in boundary: owns the device copies of what the
+// reference keeps in multiprocessing shared memory (mc3/mcmc_driver.py:143-202),
+// launches one fused step kernel per Z refresh on a private HIP stream --
+// batched into a hipGraph so the launch-bound inner loop costs no host time --
+// and, across GPUs, exchanges the new Z rows with one in-place RCCL all-gather
+// per refresh (librccl is dlopen'ed on first use, so single-GPU users do not
+// need it).
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "chain_kernels.h"
+
+using namespace mc3hip;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                               \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess)                                                       \
+            return fail(MC3HIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr,             \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                 \
+    } while (0)
+
+// ---- RCCL through dlopen -----------------------------------------------------
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+struct Rccl {
+    void *handle = nullptr;
+    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+constexpr int NCCL_FLOAT64 = 8;   // ncclDataType_t: ncclDouble
+
+int load_rccl()
+{
+    if (g_rccl.handle)
+        return MC3HIP_OK;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *h = nullptr;
+    for (const char *n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h)
+            break;
+    }
+    if (!h)
+        return fail(MC3HIP_ERR_COMM, "cannot dlopen librccl.so: %s", dlerror());
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather ||
+        !g_rccl.CommDestroy)
+        return fail(MC3HIP_ERR_COMM, "librccl.so lacks an expected symbol");
+    g_rccl.handle = h;
+    return MC3HIP_OK;
+}
+
+int choose_wpc(int nlocal, int ndata, int wlike)
+{
+    // One wave per chain when there are enough chains to fill the chip or the
+    // data sum is short; otherwise split a chain's data over 4 or 16 waves.
+    const char *env = getenv("MC3HIP_WPC");
+    if (env) {
+        const int v = atoi(env);
+        if (v == 1 || v == 4 || v == 16)
+            return v;
+    }
+    if (wlike)
+        return (ndata >= 4096) ? 16 : (ndata >= 512 ? 4 : 1);
+    if (ndata <= 2048)
+        return 1;
+    if (nlocal >= 1024)
+        return 1;
+    if (ndata <= 32768 || nlocal >= 256)
+        return 4;
+    return 16;
+}
+
+}  // namespace
+
+struct mc3hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    DevProblem P{};
+    int model_kind = 0, mt = 0, wpc = 1;
+    size_t smem = 0;
+    int64_t zlen = 0;
+    int64_t refresh_done = 0;
+    bool populated = false;
+    uint32_t flags = 0;
+    std::vector<void *> allocs;
+    long long *ctl = nullptr;
+    double *eval_params = nullptr, *eval_out = nullptr;
+    int eval_cap = 0;
+    double *model_out = nullptr;
+    // graph
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_nodes = 0;
+    // comm
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    int64_t logpost_gathered = 0;   // refreshes whose log_post rows are already exchanged
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(mc3hip_ctx *c, T **ptr, size_t count)
+{
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, (count ? count : 1) * sizeof(T)));
+    c->allocs.push_back(p);
+    *ptr = static_cast<T *>(p);
+    return MC3HIP_OK;
+}
+
+template <typename T>
+int dev_upload(mc3hip_ctx *c, const T **dst, const T *src, size_t count)
+{
+    T *p = nullptr;
+    int rc = dev_alloc(c, &p, count);
+    if (rc)
+        return rc;
+    if (count)
+        HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    *dst = p;
+    return MC3HIP_OK;
+}
+
+template <int WPC, int MT>
+void launch_step_t(mc3hip_ctx *c, int roff)
+{
+    hipLaunchKernelGGL((step_kernel<WPC, MT>), dim3(c->P.nlocal), dim3(64 * WPC), c->smem,
+                       c->stream, c->P, roff);
+}
+
+template <int WPC, int MT>
+void launch_eval_t(mc3hip_ctx *c, int n)
+{
+    hipLaunchKernelGGL((eval_chisq_kernel<WPC, MT>), dim3(n), dim3(64 * WPC), c->smem,
+                       c->stream, c->P, (const double *)c->eval_params, c->eval_out);
+}
+
+template <int MT>
+void launch_model_t(mc3hip_ctx *c)
+{
+    const int nb = (c->P.ndata + 255) / 256;
+    hipLaunchKernelGGL((eval_model_kernel<MT>), dim3(nb > 1024 ? 1024 : nb), dim3(256), 0,
+                       c->stream, c->P, (const double *)c->eval_params, c->model_out);
+}
+
+#define DISPATCH_MT(FN, WPC, ...)                                                   \
+    switch (c->mt) {                                                                \
+    case MT_POLY2: FN<WPC, MT_POLY2>(__VA_ARGS__); break;                           \
+    case MT_POLY3: FN<WPC, MT_POLY3>(__VA_ARGS__); break;                           \
+    case MT_POLY4: FN<WPC, MT_POLY4>(__VA_ARGS__); break;                           \
+    case MT_LINEAR: FN<WPC, MT_LINEAR>(__VA_ARGS__); break;                         \
+    default: FN<WPC, MT_POLY_GENERIC>(__VA_ARGS__); break;                          \
+    }
+
+#define DISPATCH(FN, ...)                                                           \
+    switch (c->wpc) {                                                               \
+    case 16: DISPATCH_MT(FN, 16, __VA_ARGS__) break;                                \
+    case 4: DISPATCH_MT(FN, 4, __VA_ARGS__) break;                                  \
+    default: DISPATCH_MT(FN, 1, __VA_ARGS__) break;                                 \
+    }
+
+void launch_step(mc3hip_ctx *c, int roff) { DISPATCH(launch_step_t, c, roff) }
+void launch_eval(mc3hip_ctx *c, int n) { DISPATCH(launch_eval_t, c, n) }
+
+void launch_model(mc3hip_ctx *c)
+{
+    switch (c->mt) {
+    case MT_POLY2: launch_model_t<MT_POLY2>(c); break;
+    case MT_POLY3: launch_model_t<MT_POLY3>(c); break;
+    case MT_POLY4: launch_model_t<MT_POLY4>(c); break;
+    case MT_LINEAR: launch_model_t<MT_LINEAR>(c); break;
+    default: launch_model_t<MT_POLY_GENERIC>(c); break;
+    }
+}
+
+int set_smem_attr(mc3hip_ctx *c)
+{
+    // kernels that need more than the default 64 KiB of dynamic LDS must opt in
+    if (c->smem <= 64 * 1024)
+        return MC3HIP_OK;
+#define SET_ATTR(WPC, MT)                                                                  \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&step_kernel<WPC, MT>),     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->smem)); \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&eval_chisq_kernel<WPC, MT>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->smem));
+#define SET_ATTR_MT(WPC)                                                            \
+    switch (c->mt) {                                                                \
+    case MT_POLY2: SET_ATTR(WPC, MT_POLY2) break;                                   \
+    case MT_POLY3: SET_ATTR(WPC, MT_POLY3) break;                                   \
+    case MT_POLY4: SET_ATTR(WPC, MT_POLY4) break;                                   \
+    case MT_LINEAR: SET_ATTR(WPC, MT_LINEAR) break;                                 \
+    default: SET_ATTR(WPC, MT_POLY_GENERIC) break;                                  \
+    }
+    switch (c->wpc) {
+    case 16: SET_ATTR_MT(16) break;
+    case 4: SET_ATTR_MT(4) break;
+    default: SET_ATTR_MT(1) break;
+    }
+    return MC3HIP_OK;
+}
+
+int exchange_rows(mc3hip_ctx *c, int64_t R)
+{
+    // one in-place all-gather of the refresh's Z rows: rank r's chains are the
+    // contiguous block [chain0, chain0+nlocal) of the nchains rows of refresh R
+    const size_t nf = (size_t)c->P.nfree;
+    double *base = c->P.Z + (size_t)(c->P.M0 + R * c->P.nchains) * nf;
+    const double *send = base + (size_t)c->P.chain0 * nf;
+    int rc = g_rccl.AllGather(send, base, (size_t)c->P.nlocal * nf, NCCL_FLOAT64, c->comm,
+                              c->stream);
+    if (rc != 0)
+        return fail(MC3HIP_ERR_COMM, "ncclAllGather failed: %s",
+                    g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    return MC3HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mc3hip_last_error(void) { return g_err.c_str(); }
+
+int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
+{
+    if (!pr || !out)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    if (pr->struct_bytes != (int32_t)sizeof(mc3hip_problem))
+        return fail(MC3HIP_ERR_ARG, "mc3hip_problem size mismatch (%d vs %zu)",
+                    pr->struct_bytes, sizeof(mc3hip_problem));
+    if (pr->nparams < 1 || pr->nparams > MC3HIP_MAX_PARAMS)
+        return fail(MC3HIP_ERR_ARG, "nparams=%d outside [1,%d]", pr->nparams,
+                    MC3HIP_MAX_PARAMS);
+    if (pr->ndata < 1)
+        return fail(MC3HIP_ERR_ARG, "ndata must be positive");
+    if (pr->nchains < 1 || pr->nlocal < 1 || pr->chain0 < 0 ||
+        pr->chain0 + pr->nlocal > pr->nchains)
+        return fail(MC3HIP_ERR_ARG, "bad chain partition (nchains=%d chain0=%d nlocal=%d)",
+                    pr->nchains, pr->chain0, pr->nlocal);
+    if (pr->sampler < MC3HIP_MRW || pr->sampler > MC3HIP_SNOOKER)
+        return fail(MC3HIP_ERR_ARG, "unknown sampler %d", pr->sampler);
+    if (pr->sampler == MC3HIP_DEMC && pr->nchains < 3)
+        return fail(MC3HIP_ERR_ARG, "demc needs at least 3 chains (chain.py:223-229)");
+    if (pr->thinning < 1)
+        return fail(MC3HIP_ERR_ARG, "thinning must be >= 1");
+    if (pr->model_kind != MC3HIP_MODEL_POLY && pr->model_kind != MC3HIP_MODEL_LINEAR)
+        return fail(MC3HIP_ERR_ARG, "unknown model family %d", pr->model_kind);
+    const int noise = pr->wlike ? 3 : 0;
+    if (pr->nmodel < 1 || pr->nmodel + noise > pr->nparams)
+        return fail(MC3HIP_ERR_ARG, "nmodel=%d does not fit nparams=%d%s", pr->nmodel,
+                    pr->nparams, pr->wlike ? " (wavelet: last three are noise parameters)" : "");
+    if (pr->wlike) {
+        // src_c/_dwt.c:94 transforms the unpadded length: only 2^M is well defined
+        if (pr->ndata < 2 || (pr->ndata & (pr->ndata - 1)))
+            return fail(MC3HIP_ERR_ARG,
+                        "wavelet likelihood needs power-of-two ndata (got %d)", pr->ndata);
+        if (pr->ndata > 16384)
+            return fail(MC3HIP_ERR_ARG, "wavelet likelihood supports ndata <= 16384");
+    }
+    if (pr->M0 < 2 || pr->zlen < pr->M0)
+        return fail(MC3HIP_ERR_ARG, "bad Z sizes (M0=%lld zlen=%lld)", (long long)pr->M0,
+                    (long long)pr->zlen);
+    if (pr->M0 < pr->nchains)
+        return fail(MC3HIP_ERR_ARG, "M0 must be >= nchains (hsize >= 1)");
+    if (!pr->params || !pr->pstep || !pr->pmin || !pr->pmax || !pr->prior || !pr->priorlow ||
+        !pr->priorup || !pr->indep || !pr->data || (!pr->wlike && !pr->uncert))
+        return fail(MC3HIP_ERR_ARG, "null input array");
+
+    // parameter bookkeeping: chain.py:141-150
+    std::vector<int32_t> ifree, ishare, share_src, igprior;
+    for (int j = 0; j < pr->nparams; ++j) {
+        if (pr->pstep[j] > 0)
+            ifree.push_back(j);
+        else if (pr->pstep[j] < 0) {
+            const int src = -(int)pr->pstep[j] - 1;                  // chain.py:247
+            if (src < 0 || src >= pr->nparams)
+                return fail(MC3HIP_ERR_ARG, "shared parameter %d points outside params", j);
+            ishare.push_back(j);
+            share_src.push_back(src);
+        }
+        if (pr->priorlow[j] > 0 && pr->priorup[j] > 0)
+            igprior.push_back(j);                                    // stats.py:211
+    }
+    if (ifree.empty() || (int)ifree.size() > MC3HIP_MAX_FREE)
+        return fail(MC3HIP_ERR_ARG, "nfree=%zu outside [1,%d]", ifree.size(), MC3HIP_MAX_FREE);
+
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (pr->device < 0 || pr->device >= ndev)
+        return fail(MC3HIP_ERR_HIP, "device %d not present (%d devices)", pr->device, ndev);
+    HIP_TRY(hipSetDevice(pr->device));
+
+    mc3hip_ctx *c = new mc3hip_ctx();
+    c->device = pr->device;
+    c->flags = pr->flags;
+    c->zlen = pr->zlen;
+    c->model_kind = pr->model_kind;
+    int rc = MC3HIP_OK;
+#define TRY(expr)                                                                   \
+    do {                                                                            \
+        rc = (expr);                                                                \
+        if (rc) {                                                                   \
+            mc3hip_destroy(c);                                                      \
+            return rc;                                                              \
+        }                                                                           \
+    } while (0)
+#define HIP_TRY_C(expr)                                                             \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            mc3hip_destroy(c);                                                      \
+            return fail(MC3HIP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+        }                                                                           \
+    } while (0)
+    HIP_TRY_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY_C(hipEventCreate(&c->ev0));
+    HIP_TRY_C(hipEventCreate(&c->ev1));
+
+    DevProblem &P = c->P;
+    P.nchains = pr->nchains;
+    P.chain0 = pr->chain0;
+    P.nlocal = pr->nlocal;
+    P.nparams = pr->nparams;
+    P.nfree = (int)ifree.size();
+    P.nshare = (int)ishare.size();
+    P.ndata = pr->ndata;
+    P.sampler = pr->sampler;
+    P.wlike = pr->wlike ? 1 : 0;
+    P.nmodel = pr->nmodel;
+    P.thinning = pr->thinning;
+    P.ngprior = (int)igprior.size();
+    P.trace_iters = pr->trace_iters > 0 ? pr->trace_iters : 0;
+    P.M0 = pr->M0;
+    P.seed = pr->seed;
+    P.gamma = pr->gamma;
+    P.fepsilon = pr->fepsilon;
+    const size_t np = (size_t)pr->nparams, nd = (size_t)pr->ndata, nf = ifree.size();
+    TRY(dev_upload(c, &P.ifree, ifree.data(), ifree.size()));
+    TRY(dev_upload(c, &P.ishare, ishare.data(), ishare.size()));
+    TRY(dev_upload(c, &P.share_src, share_src.data(), share_src.size()));
+    TRY(dev_upload(c, &P.igprior, igprior.data(), igprior.size()));
+    TRY(dev_upload(c, &P.params, pr->params, np));
+    TRY(dev_upload(c, &P.pmin, pr->pmin, np));
+    TRY(dev_upload(c, &P.pmax, pr->pmax, np));
+    TRY(dev_upload(c, &P.pstep, pr->pstep, np));
+    TRY(dev_upload(c, &P.prior, pr->prior, np));
+    TRY(dev_upload(c, &P.priorlow, pr->priorlow, np));
+    TRY(dev_upload(c, &P.priorup, pr->priorup, np));
+    const size_t nindep = (pr->model_kind == MC3HIP_MODEL_LINEAR) ? nd * (size_t)pr->nmodel : nd;
+    TRY(dev_upload(c, &P.indep, pr->indep, nindep));
+    TRY(dev_upload(c, &P.data, pr->data, nd));
+    {
+        // w = 1/uncert once (IEEE division on the host), so the hot loop multiplies
+        std::vector<double> w(nd, 1.0);
+        if (!pr->wlike)
+            for (size_t i = 0; i < nd; ++i)
+                w[i] = 1.0 / pr->uncert[i];
+        TRY(dev_upload(c, &P.w, w.data(), nd));
+    }
+    const size_t zl = (size_t)pr->zlen, nl = (size_t)pr->nlocal;
+    TRY(dev_alloc(c, &P.Z, zl * nf));
+    TRY(dev_alloc(c, &P.log_post, zl));
+    TRY(dev_alloc(c, &P.zchain, zl));
+    TRY(dev_alloc(c, &P.X, nl * nf));
+    TRY(dev_alloc(c, &P.chisq, nl));
+    TRY(dev_alloc(c, &P.numaccept, nl));
+    TRY(dev_alloc(c, &P.outbounds, nf));
+    TRY(dev_alloc(c, &P.best_chisq, nl));
+    TRY(dev_alloc(c, &P.best_iter, nl));
+    TRY(dev_alloc(c, &P.bestx, nl * nf));
+    {
+        double *snap = nullptr;
+        TRY(dev_alloc(c, &snap, (size_t)pr->nchains * nf));
+        P.snap0 = snap;
+    }
+    if (P.trace_iters > 0) {
+        TRY(dev_alloc(c, &P.trace_chisq, (size_t)P.trace_iters * nl));
+        TRY(dev_alloc(c, &P.trace_flag, (size_t)P.trace_iters * nl));
+    }
+    TRY(dev_alloc(c, &c->ctl, 2));
+    P.ctl = c->ctl;
+    HIP_TRY_C(hipMemset(c->ctl, 0, 2 * sizeof(long long)));
+    HIP_TRY_C(hipMemset(P.Z, 0, zl * nf * sizeof(double)));
+    HIP_TRY_C(hipMemset(P.log_post, 0, zl * sizeof(double)));
+    HIP_TRY_C(hipMemset(P.zchain, 0xff, zl * sizeof(int32_t)));      // -1, mcmc_driver.py:170
+    HIP_TRY_C(hipMemset(P.numaccept, 0, nl * sizeof(long long)));
+    HIP_TRY_C(hipMemset(P.outbounds, 0, nf * sizeof(unsigned long long)));
+    HIP_TRY_C(hipMemset(P.bestx, 0, nl * nf * sizeof(double)));
+    TRY(dev_alloc(c, &c->model_out, nd));
+
+    if (pr->model_kind == MC3HIP_MODEL_LINEAR)
+        c->mt = MT_LINEAR;
+    else if (pr->nmodel >= 2 && pr->nmodel <= 4)
+        c->mt = pr->nmodel;
+    else
+        c->mt = MT_POLY_GENERIC;
+    c->wpc = choose_wpc(pr->nlocal, pr->ndata, pr->wlike);
+    c->smem = smem_bytes(64 * c->wpc, pr->ndata, pr->wlike);
+    if (c->smem > 160 * 1024) {
+        mc3hip_destroy(c);
+        return fail(MC3HIP_ERR_ARG, "problem needs %zu bytes of LDS (> 160 KiB)", c->smem);
+    }
+    TRY(set_smem_attr(c));
+    c->graph_nodes = (c->flags & MC3HIP_FLAG_NO_GRAPH) ? 0 : 256;
+    if (getenv("MC3HIP_NO_GRAPH"))
+        c->graph_nodes = 0;
+    if (const char *g = getenv("MC3HIP_GRAPH_NODES"))
+        c->graph_nodes = atoi(g) > 0 ? atoi(g) : 0;
+#undef TRY
+#undef HIP_TRY_C
+    *out = c;
+    return MC3HIP_OK;
+}
+
+void mc3hip_destroy(mc3hip_ctx *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    if (c->stream)
+        (void)hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.CommDestroy)
+        g_rccl.CommDestroy(c->comm);
+    if (c->graph_exec)
+        (void)hipGraphExecDestroy(c->graph_exec);
+    if (c->graph)
+        (void)hipGraphDestroy(c->graph);
+    for (void *p : c->allocs)
+        (void)hipFree(p);
+    if (c->ev0)
+        (void)hipEventDestroy(c->ev0);
+    if (c->ev1)
+        (void)hipEventDestroy(c->ev1);
+    if (c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
+{
+    if (!c || !plan)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    plan->vlanes = VLANES;
+    plan->tile = 0;
+    plan->waves_per_chain = c->wpc;
+    plan->graph_nodes = c->graph_nodes;
+    return MC3HIP_OK;
+}
+
+int mc3hip_set_population(mc3hip_ctx *c, const double *Z0, const double *log_post0,
+                          const double *X0, const double *chisq0)
+{
+    if (!c || !Z0 || !log_post0)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    if ((X0 == nullptr) != (chisq0 == nullptr))
+        return fail(MC3HIP_ERR_ARG, "X0 and chisq0 must be given together");
+    HIP_TRY(hipSetDevice(c->device));
+    const DevProblem &P = c->P;
+    const size_t nf = (size_t)P.nfree, M0 = (size_t)P.M0, nc = (size_t)P.nchains,
+                 nl = (size_t)P.nlocal;
+    HIP_TRY(hipMemcpy(P.Z, Z0, M0 * nf * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(P.log_post, log_post0, M0 * sizeof(double), hipMemcpyHostToDevice));
+    // chains start from the first nchains rows of Z: chain.py:163-170
+    const double *Xs = X0 ? X0 : Z0;
+    std::vector<double> chi(nc);
+    for (size_t i = 0; i < nc; ++i)
+        chi[i] = chisq0 ? chisq0[i] : -2.0 * log_post0[i];
+    HIP_TRY(hipMemcpy(const_cast<double *>(P.snap0), Xs, nc * nf * sizeof(double),
+                      hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(P.X, Xs + (size_t)P.chain0 * nf, nl * nf * sizeof(double),
+                      hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(P.chisq, chi.data() + P.chain0, nl * sizeof(double),
+                      hipMemcpyHostToDevice));
+    std::vector<double> inf(nl, INFINITY);
+    std::vector<long long> neg(nl, -1);
+    HIP_TRY(hipMemcpy(P.best_chisq, inf.data(), nl * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(P.best_iter, neg.data(), nl * sizeof(long long), hipMemcpyHostToDevice));
+    c->populated = true;
+    return MC3HIP_OK;
+}
+
+static int build_graph(mc3hip_ctx *c)
+{
+    HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    for (int r = 0; r < c->graph_nodes; ++r)
+        launch_step(c, r);
+    hipError_t e = hipStreamEndCapture(c->stream, &c->graph);
+    if (e != hipSuccess)
+        return fail(MC3HIP_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+    return MC3HIP_OK;
+}
+
+int mc3hip_run(mc3hip_ctx *c, int64_t nrefresh)
+{
+    if (!c)
+        return fail(MC3HIP_ERR_ARG, "null context");
+    if (!c->populated)
+        return fail(MC3HIP_ERR_STATE, "mc3hip_set_population has not been called");
+    if (nrefresh < 0)
+        return fail(MC3HIP_ERR_ARG, "negative nrefresh");
+    const DevProblem &P = c->P;
+    if (P.M0 + (c->refresh_done + nrefresh) * P.nchains > c->zlen)
+        return fail(MC3HIP_ERR_FULL, "Z holds %lld rows: cannot run %lld more refreshes after %lld",
+                    (long long)c->zlen, (long long)nrefresh, (long long)c->refresh_done);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    int64_t R = c->refresh_done;
+    const int64_t Rend = R + nrefresh;
+    const long long run0 = R;
+    bool first = true;
+    const bool use_graph = c->graph_nodes > 0 && c->comm == nullptr;
+    if (use_graph && nrefresh >= c->graph_nodes && !c->graph_exec) {
+        int rc = build_graph(c);
+        if (rc)
+            return rc;
+    }
+    while (R < Rend) {
+        const int64_t left = Rend - R;
+        if (use_graph && left >= c->graph_nodes) {
+            hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl,
+                               (long long)R, first ? run0 : -1LL);
+            HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+            R += c->graph_nodes;
+        } else {
+            const int64_t n = left;
+            hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl,
+                               (long long)R, first ? run0 : -1LL);
+            for (int64_t r = 0; r < n; ++r) {
+                launch_step(c, (int)r);
+                if (c->comm) {
+                    int rc = exchange_rows(c, R + r);
+                    if (rc)
+                        return rc;
+                }
+            }
+            R += n;
+        }
+        first = false;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    c->refresh_done = Rend;
+    return MC3HIP_OK;
+}
+
+int mc3hip_sync(mc3hip_ctx *c)
+{
+    if (!c)
+        return fail(MC3HIP_ERR_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MC3HIP_OK;
+}
+
+int mc3hip_last_run_ms(mc3hip_ctx *c, float *ms)
+{
+    if (!c || !ms)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    if (!c->timed)
+        return fail(MC3HIP_ERR_STATE, "no run to time yet");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return MC3HIP_OK;
+}
+
+int mc3hip_get_rows(mc3hip_ctx *c, int64_t row0, int64_t nrows, double *Z, double *log_post,
+                    int32_t *zchain)
+{
+    if (!c)
+        return fail(MC3HIP_ERR_ARG, "null context");
+    if (row0 < 0 || nrows < 0 || row0 + nrows > c->zlen)
+        return fail(MC3HIP_ERR_ARG, "rows [%lld,%lld) outside Z", (long long)row0,
+                    (long long)(row0 + nrows));
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t nf = (size_t)c->P.nfree;
+    if (Z)
+        HIP_TRY(hipMemcpy(Z, c->P.Z + (size_t)row0 * nf, (size_t)nrows * nf * sizeof(double),
+                          hipMemcpyDeviceToHost));
+    if (log_post)
+        HIP_TRY(hipMemcpy(log_post, c->P.log_post + row0, (size_t)nrows * sizeof(double),
+                          hipMemcpyDeviceToHost));
+    if (zchain)
+        HIP_TRY(hipMemcpy(zchain, c->P.zchain + row0, (size_t)nrows * sizeof(int32_t),
+                          hipMemcpyDeviceToHost));
+    return MC3HIP_OK;
+}
+
+int mc3hip_get_state(mc3hip_ctx *c, double *X, double *chisq, int64_t *numaccept,
+                     int64_t *outbounds, double *best_chisq, int64_t *best_iter, double *bestx,
+                     int64_t *refresh_done)
+{
+    if (!c)
+        return fail(MC3HIP_ERR_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const DevProblem &P = c->P;
+    const size_t nf = (size_t)P.nfree, nl = (size_t)P.nlocal;
+    if (X)
+        HIP_TRY(hipMemcpy(X, P.X, nl * nf * sizeof(double), hipMemcpyDeviceToHost));
+    if (chisq)
+        HIP_TRY(hipMemcpy(chisq, P.chisq, nl * sizeof(double), hipMemcpyDeviceToHost));
+    if (numaccept)
+        HIP_TRY(hipMemcpy(numaccept, P.numaccept, nl * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (outbounds)
+        HIP_TRY(hipMemcpy(outbounds, P.outbounds, nf * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (best_chisq)
+        HIP_TRY(hipMemcpy(best_chisq, P.best_chisq, nl * sizeof(double), hipMemcpyDeviceToHost));
+    if (best_iter)
+        HIP_TRY(hipMemcpy(best_iter, P.best_iter, nl * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (bestx)
+        HIP_TRY(hipMemcpy(bestx, P.bestx, nl * nf * sizeof(double), hipMemcpyDeviceToHost));
+    if (refresh_done)
+        *refresh_done = c->refresh_done;
+    return MC3HIP_OK;
+}
+
+int mc3hip_get_trace(mc3hip_ctx *c, int64_t iters, double *chisq, int32_t *flags)
+{
+    if (!c)
+        return fail(MC3HIP_ERR_ARG, "null context");
+    if (iters < 0 || iters > c->P.trace_iters)
+        return fail(MC3HIP_ERR_ARG, "trace holds %d iterations", c->P.trace_iters);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)iters * (size_t)c->P.nlocal;
+    if (chisq)
+        HIP_TRY(hipMemcpy(chisq, c->P.trace_chisq, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (flags)
+        HIP_TRY(hipMemcpy(flags, c->P.trace_flag, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return MC3HIP_OK;
+}
+
+int mc3hip_eval_chisq(mc3hip_ctx *c, const double *params, int32_t n, double *chisq_out)
+{
+    if (!c || !params || !chisq_out)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    if (n < 0)
+        return fail(MC3HIP_ERR_ARG, "negative count");
+    if (n == 0)
+        return MC3HIP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t np = (size_t)c->P.nparams;
+    if (n > c->eval_cap) {
+        // grow-only scratch; freed with the context
+        int cap = n < 1024 ? 1024 : n;
+        double *p = nullptr, *o = nullptr;
+        int rc = dev_alloc(c, &p, (size_t)cap * np);
+        if (rc)
+            return rc;
+        rc = dev_alloc(c, &o, (size_t)cap);
+        if (rc)
+            return rc;
+        c->eval_params = p;
+        c->eval_out = o;
+        c->eval_cap = cap;
+    }
+    HIP_TRY(hipMemcpyAsync(c->eval_params, params, (size_t)n * np * sizeof(double),
+                           hipMemcpyHostToDevice, c->stream));
+    launch_eval(c, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(chisq_out, c->eval_out, (size_t)n * sizeof(double),
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MC3HIP_OK;
+}
+
+int mc3hip_eval_model(mc3hip_ctx *c, const double *params, double *model_out)
+{
+    if (!c || !params || !model_out)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->eval_cap < 1) {
+        double *p = nullptr, *o = nullptr;
+        int rc = dev_alloc(c, &p, (size_t)1024 * c->P.nparams);
+        if (rc)
+            return rc;
+        rc = dev_alloc(c, &o, (size_t)1024);
+        if (rc)
+            return rc;
+        c->eval_params = p;
+        c->eval_out = o;
+        c->eval_cap = 1024;
+    }
+    HIP_TRY(hipMemcpyAsync(c->eval_params, params, (size_t)c->P.nparams * sizeof(double),
+                           hipMemcpyHostToDevice, c->stream));
+    launch_model(c);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(model_out, c->model_out, (size_t)c->P.ndata * sizeof(double),
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MC3HIP_OK;
+}
+
+int mc3hip_dwt_daub4(int32_t device, const double *in, int32_t n, int32_t inverse, double *out)
+{
+    if (!in || !out || n < 1)
+        return fail(MC3HIP_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    int nw = 1;
+    while (nw < n)
+        nw <<= 1;
+    double *a = nullptr, *tmp = nullptr;
+    HIP_TRY(hipMalloc(&a, (size_t)nw * sizeof(double)));
+    if (hipMalloc(&tmp, (size_t)nw * sizeof(double)) != hipSuccess) {
+        (void)hipFree(a);
+        return fail(MC3HIP_ERR_HIP, "hipMalloc failed");
+    }
+    int rc = MC3HIP_OK;
+    hipError_t e = hipMemset(a, 0, (size_t)nw * sizeof(double));
+    if (e == hipSuccess)
+        e = hipMemcpy(a, in, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(daub4_kernel, dim3(1), dim3(1024), 0, 0, a, tmp, nw, inverse ? 1 : 0);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpy(out, a, (size_t)nw * sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        rc = fail(MC3HIP_ERR_HIP, "dwt_daub4: %s", hipGetErrorString(e));
+    (void)hipFree(a);
+    (void)hipFree(tmp);
+    return rc;
+}
+
+int mc3hip_comm_unique_id(void *unique_id_128)
+{
+    if (!unique_id_128)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    int rc = load_rccl();
+    if (rc)
+        return rc;
+    ncclUniqueId id;
+    rc = g_rccl.GetUniqueId(&id);
+    if (rc != 0)
+        return fail(MC3HIP_ERR_COMM, "ncclGetUniqueId failed (%d)", rc);
+    memcpy(unique_id_128, &id, sizeof id);
+    return MC3HIP_OK;
+}
+
+int mc3hip_comm_init(mc3hip_ctx *c, const void *unique_id_128, int32_t rank, int32_t nranks)
+{
+    if (!c || !unique_id_128)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks)
+        return fail(MC3HIP_ERR_ARG, "bad rank %d of %d", rank, nranks);
+    // the in-place all-gather needs equal contiguous blocks in rank order
+    if (c->P.nlocal * nranks != c->P.nchains || c->P.chain0 != rank * c->P.nlocal)
+        return fail(MC3HIP_ERR_ARG,
+                    "rank %d must own chains [%d,%d) of %d (equal contiguous blocks)", rank,
+                    rank * c->P.nlocal, (rank + 1) * c->P.nlocal, c->P.nchains);
+    int rc = load_rccl();
+    if (rc)
+        return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, unique_id_128, sizeof id);
+    rc = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+    if (rc != 0) {
+        c->comm = nullptr;
+        return fail(MC3HIP_ERR_COMM, "ncclCommInitRank failed: %s",
+                    g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    }
+    c->rank = rank;
+    c->nranks = nranks;
+    return MC3HIP_OK;
+}
+
+int mc3hip_comm_gather_log_post(mc3hip_ctx *c)
+{
+    if (!c)
+        return fail(MC3HIP_ERR_ARG, "null context");
+    if (!c->comm)
+        return MC3HIP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    // log_post rows are not needed by proposals, so they are exchanged lazily:
+    // one in-place all-gather per not-yet-exchanged refresh
+    for (int64_t R = c->logpost_gathered; R < c->refresh_done; ++R) {
+        double *base = c->P.log_post + (size_t)(c->P.M0 + R * c->P.nchains);
+        int rc = g_rccl.AllGather(base + c->P.chain0, base, (size_t)c->P.nlocal, NCCL_FLOAT64,
+                                  c->comm, c->stream);
+        if (rc != 0)
+            return fail(MC3HIP_ERR_COMM, "ncclAllGather(log_post) failed (%d)", rc);
+    }
+    c->logpost_gathered = c->refresh_done;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MC3HIP_OK;
+}
+
+int mc3hip_selftest_math(int32_t device, int32_t op, const double *in, int32_t n, double *out)
+{
+    if (!in || !out || n < 1)
+        return fail(MC3HIP_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    double *di = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(&di, (size_t)n * sizeof(double)));
+    HIP_TRY(hipMalloc(&dout, (size_t)n * sizeof(double)));
+    HIP_TRY(hipMemcpy(di, in, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(selftest_math_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op,
+                       (const double *)di, n, dout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(di);
+    (void)hipFree(dout);
+    return MC3HIP_OK;
+}
+
+int mc3hip_selftest_philox(int32_t device, const uint32_t *ctr, int32_t n, const uint32_t key[2],
+                           uint32_t *out)
+{
+    if (!ctr || !out || !key || n < 1)
+        return fail(MC3HIP_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    uint32_t *dc = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(&dc, (size_t)n * 16));
+    HIP_TRY(hipMalloc(&dout, (size_t)n * 16));
+    HIP_TRY(hipMemcpy(dc, ctr, (size_t)n * 16, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(selftest_philox_kernel, dim3((n + 255) / 256), dim3(256), 0, 0,
+                       (const uint32_t *)dc, n, key[0], key[1], dout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, (size_t)n * 16, hipMemcpyDeviceToHost));
+    (void)hipFree(dc);
+    (void)hipFree(dout);
+    return MC3HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,249 @@
+"""DeviceChains: the walker ensemble on one MI355X.
+
+Host-side counterpart of the reference's ``Chain`` workers plus the shared
+memory ``mcmc()`` allocates for them (mc3/chain.py:18-155,
+mc3/mcmc_driver.py:143-221).  Everything numeric happens in libmc3hip.so; this
+class only marshals NumPy arrays through the C-ABI (include/mc3hip.h) and
+mirrors the attributes ``update_output`` reads from a Chain
+(mc3/stats/stats.py:813-871).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, f64, dptr, iptr, lptr
+
+
+class DeviceChains:
+    """nchains walkers (or the block [chain0, chain0+nlocal) of them) on one GPU.
+
+    model: 'poly'   -> indep = x[ndata],          model = sum_k p[k] x^k
+           'linear' -> indep = A[nmodel, ndata],  model = sum_k A[k] p[k]
+    The model coefficients are params[0:nmodel]; with wlike=True the last three
+    parameters are the wavelet noise parameters (chain.py:317, _dwt.c:76-79).
+    """
+
+    def __init__(self, data, uncert, indep, params, pstep, pmin=None, pmax=None,
+                 prior=None, priorlow=None, priorup=None, nchains=7,
+                 nsamples=None, sampler='snooker', wlike=False, thinning=1,
+                 fgamma=1.0, fepsilon=0.0, hsize=10, model='poly', nmodel=None,
+                 seed=0, device=0, chain0=0, nlocal=None, M0=None, zlen=None,
+                 trace_iters=0, no_graph=False):
+        self._ctx = None
+        self.lib = _lib.load()
+        self.params = f64(params).copy()
+        npar = len(self.params)
+        self.pstep = f64(pstep).copy()
+        self.pmin = f64(np.tile(-np.inf, npar) if pmin is None else pmin)
+        self.pmax = f64(np.tile(np.inf, npar) if pmax is None else pmax)
+        zeros = np.zeros(npar)
+        self.prior = f64(zeros if prior is None else prior)
+        self.priorlow = f64(zeros if priorlow is None else priorlow)
+        self.priorup = f64(zeros if priorup is None else priorup)
+        self.data = f64(data)
+        self.ndata = len(self.data)
+        self.uncert = f64(np.ones(self.ndata) if uncert is None else uncert)
+        self.indep = f64(indep)
+        if sampler not in _lib.SAMPLERS:
+            raise ValueError(f"Invalid sampler '{sampler}', select from "
+                             "['mrw', 'demc', 'snooker']")
+        self.sampler = sampler
+        self.wlike = bool(wlike)
+        self.thinning = int(thinning)
+        self.nchains = int(nchains)
+        self.chain0 = int(chain0)
+        self.nlocal = self.nchains - self.chain0 if nlocal is None else int(nlocal)
+        self.ifree = np.where(self.pstep > 0)[0]
+        self.ishare = np.where(self.pstep < 0)[0]
+        self.nfree = len(self.ifree)
+        self.hsize = int(hsize)
+        if nmodel is None:
+            nmodel = npar - 3 if self.wlike else npar
+        self.nmodel = int(nmodel)
+        self.model = model
+        want = (self.ndata,) if model == 'poly' else (self.nmodel, self.ndata)
+        if self.indep.shape != want:
+            raise ValueError(f"indep has shape {self.indep.shape}, the '{model}' "
+                             f"model needs {want}")
+        # sizes: mcmc_driver.py:127-134
+        self.M0 = self.hsize*self.nchains if M0 is None else int(M0)
+        if zlen is None:
+            self.nzchain = int(np.ceil(nsamples/self.nchains/self.thinning))
+            zlen = self.M0 + self.nzchain*self.nchains
+        else:
+            self.nzchain = (int(zlen) - self.M0)//self.nchains
+        self.zlen = int(zlen)
+        self.seed = int(seed)
+        # chain.py:175
+        self.gamma = float(fgamma*2.38/np.sqrt(2*self.nfree)) if self.nfree else 0.0
+        self.fepsilon = float(fepsilon)
+
+        P = _lib.Problem()
+        P.struct_bytes = ctypes.sizeof(_lib.Problem)
+        P.device = int(device)
+        P.nchains, P.chain0, P.nlocal = self.nchains, self.chain0, self.nlocal
+        P.nparams, P.ndata = npar, self.ndata
+        P.sampler = _lib.SAMPLERS[sampler]
+        P.wlike = int(self.wlike)
+        P.model_kind = {'poly': _lib.MODEL_POLY, 'linear': _lib.MODEL_LINEAR}[model]
+        P.nmodel = self.nmodel
+        P.thinning = self.thinning
+        P.flags = _lib.FLAG_NO_GRAPH if no_graph else 0
+        P.trace_iters = int(trace_iters)
+        P.M0, P.zlen = self.M0, self.zlen
+        P.seed = self.seed
+        P.gamma, P.fepsilon = self.gamma, self.fepsilon
+        for name in ('params', 'pstep', 'pmin', 'pmax', 'prior', 'priorlow',
+                     'priorup', 'indep', 'data', 'uncert'):
+            setattr(P, name, dptr(getattr(self, name)))
+        ctx = ctypes.c_void_p()
+        check(self.lib.mc3hip_create(ctypes.byref(P), ctypes.byref(ctx)))
+        self._ctx = ctx
+        self.trace_iters = int(trace_iters)
+        plan = _lib.Plan()
+        check(self.lib.mc3hip_get_plan(self._ctx, ctypes.byref(plan)))
+        self.plan = {'vlanes': plan.vlanes, 'tile': plan.tile,
+                     'waves_per_chain': plan.waves_per_chain,
+                     'graph_nodes': plan.graph_nodes}
+
+    # -- lifetime --------------------------------------------------------------
+    def close(self):
+        if self._ctx is not None:
+            self.lib.mc3hip_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- the hot path ----------------------------------------------------------
+    def set_population(self, Z0, log_post0, X0=None, chisq0=None):
+        Z0 = f64(Z0)
+        log_post0 = f64(log_post0)
+        if Z0.shape != (self.M0, self.nfree) or log_post0.shape != (self.M0,):
+            raise ValueError('initial population must be [M0, nfree] and [M0]')
+        X0 = None if X0 is None else f64(X0)
+        chisq0 = None if chisq0 is None else f64(chisq0)
+        check(self.lib.mc3hip_set_population(self._ctx, dptr(Z0), dptr(log_post0),
+                                             dptr(X0), dptr(chisq0)))
+
+    def run(self, nrefresh=None, sync=True):
+        """Advance every local chain by nrefresh*thinning iterations."""
+        if nrefresh is None:
+            nrefresh = self.nzchain - self.refresh_done
+        check(self.lib.mc3hip_run(self._ctx, int(nrefresh)))
+        if sync:
+            check(self.lib.mc3hip_sync(self._ctx))
+        return self
+
+    def sync(self):
+        check(self.lib.mc3hip_sync(self._ctx))
+
+    def last_run_ms(self):
+        ms = ctypes.c_float()
+        check(self.lib.mc3hip_last_run_ms(self._ctx, ctypes.byref(ms)))
+        return float(ms.value)
+
+    # -- read-back ---------------------------------------------------------------
+    def rows(self, row0=0, nrows=None):
+        """(Z, log_post, zchain) for rows [row0, row0+nrows)."""
+        if nrows is None:
+            nrows = self.zlen - row0
+        Z = np.empty((nrows, self.nfree))
+        lp = np.empty(nrows)
+        zc = np.empty(nrows, np.int32)
+        check(self.lib.mc3hip_get_rows(self._ctx, int(row0), int(nrows), dptr(Z),
+                                       dptr(lp), iptr(zc)))
+        return Z, lp, zc
+
+    def state(self):
+        nl, nf = self.nlocal, self.nfree
+        out = {
+            'X': np.empty((nl, nf)), 'chisq': np.empty(nl),
+            'numaccept': np.empty(nl, np.int64), 'outbounds': np.empty(nf, np.int64),
+            'best_chisq': np.empty(nl), 'best_iter': np.empty(nl, np.int64),
+            'bestx': np.empty((nl, nf)),
+        }
+        done = ctypes.c_int64()
+        check(self.lib.mc3hip_get_state(
+            self._ctx, dptr(out['X']), dptr(out['chisq']), lptr(out['numaccept']),
+            lptr(out['outbounds']), dptr(out['best_chisq']), lptr(out['best_iter']),
+            dptr(out['bestx']), ctypes.byref(done)))
+        out['refresh_done'] = int(done.value)
+        return out
+
+    @property
+    def refresh_done(self):
+        done = ctypes.c_int64()
+        check(self.lib.mc3hip_get_state(self._ctx, None, None, None, None, None,
+                                        None, None, ctypes.byref(done)))
+        return int(done.value)
+
+    def trace(self, iters=None):
+        iters = self.trace_iters if iters is None else int(iters)
+        chisq = np.empty((iters, self.nlocal))
+        flags = np.empty((iters, self.nlocal), np.int32)
+        check(self.lib.mc3hip_get_trace(self._ctx, iters, dptr(chisq), iptr(flags)))
+        return chisq, flags
+
+    # -- Chain.eval_model (chain.py:302-340) on the device ----------------------
+    def eval_chisq(self, params):
+        """chisq for one parameter vector or an [n, nparams] batch."""
+        p = f64(np.atleast_2d(params))
+        if p.shape[1] != len(self.params):
+            raise ValueError('parameter vectors must have nparams entries')
+        out = np.empty(len(p))
+        check(self.lib.mc3hip_eval_chisq(self._ctx, dptr(p), len(p), dptr(out)))
+        return out[0] if np.ndim(params) == 1 else out
+
+    def expand_free(self, free):
+        """[n, nfree] free-parameter rows -> [n, nparams] full vectors (fixed
+        values kept, shared parameters copied, chain.py:246-247)."""
+        free = f64(np.atleast_2d(free))
+        full = np.tile(self.params, (len(free), 1))
+        full[:, self.ifree] = free
+        for s in self.ishare:
+            full[:, s] = full[:, -int(self.pstep[s]) - 1]
+        return full
+
+    def eval_model_values(self, params):
+        p = f64(params)
+        out = np.empty(self.ndata)
+        check(self.lib.mc3hip_eval_model(self._ctx, dptr(p), dptr(out)))
+        return out
+
+    # -- multi-GPU ----------------------------------------------------------------
+    def comm_init(self, unique_id, rank, nranks):
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        check(self.lib.mc3hip_comm_init(self._ctx, buf, int(rank), int(nranks)))
+
+    def comm_gather_log_post(self):
+        check(self.lib.mc3hip_comm_gather_log_post(self._ctx))
+
+
+def comm_unique_id():
+    buf = ctypes.create_string_buffer(128)
+    check(_lib.load().mc3hip_comm_unique_id(buf))
+    return buf.raw
+
+
+def dwt_daub4(array, inverse=False, device=0):
+    """ms.dwt_daub4 on the device (src_c/_dwt.c:154-186)."""
+    a = f64(array)
+    n = len(a)
+    nw = 1
+    while nw < n:
+        nw <<= 1
+    out = np.empty(nw)
+    check(_lib.load().mc3hip_dwt_daub4(int(device), dptr(a), n, int(bool(inverse)),
+                                       dptr(out)))
+    return out

@@ -1,0 +1,225 @@
+"""oracle/lockstep.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+ctypes front end of oracle_lockstep.c: the reference's chain-update rules
+(mc3/chain.py:183-299) in the lockstep / Philox form the HIP kernels implement.
+This is the bit-exact checker for the GPU path: same seed, same inputs =>
+identical Z rows, chain ids, accept and out-of-bounds counters, chisq values.
+"""
+import ctypes
+
+import numpy as np
+
+from . import kernels as ok
+
+SAMPLERS = {'mrw': 0, 'demc': 1, 'snooker': 2}
+MODELS = {'poly': 0, 'linear': 1}
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int32)
+_lp = ctypes.POINTER(ctypes.c_int64)
+
+
+class _Problem(ctypes.Structure):
+    _fields_ = [
+        ('nchains', ctypes.c_int32), ('chain0', ctypes.c_int32),
+        ('nlocal', ctypes.c_int32),
+        ('nparams', ctypes.c_int32), ('nfree', ctypes.c_int32),
+        ('nshare', ctypes.c_int32), ('ndata', ctypes.c_int32),
+        ('sampler', ctypes.c_int32), ('wlike', ctypes.c_int32),
+        ('model_kind', ctypes.c_int32), ('nmodel', ctypes.c_int32),
+        ('thinning', ctypes.c_int32),
+        ('ngprior', ctypes.c_int32),
+        ('tile', ctypes.c_int32), ('vlanes', ctypes.c_int32),
+        ('_pad', ctypes.c_int32),
+        ('M0', ctypes.c_int64), ('zlen', ctypes.c_int64),
+        ('seed', ctypes.c_uint64),
+        ('gamma', ctypes.c_double), ('fepsilon', ctypes.c_double),
+        ('ifree', _ip), ('ishare', _ip), ('share_src', _ip), ('igprior', _ip),
+        ('params', _dp), ('pmin', _dp), ('pmax', _dp), ('pstep', _dp),
+        ('prior', _dp), ('priorlow', _dp), ('priorup', _dp),
+        ('indep', _dp), ('data', _dp), ('w', _dp),
+    ]
+
+
+class _State(ctypes.Structure):
+    _fields_ = [
+        ('Z', _dp), ('log_post', _dp), ('zchain', _ip),
+        ('X', _dp), ('chisq', _dp),
+        ('numaccept', _lp), ('outbounds', _lp),
+        ('best_chisq', _dp), ('best_iter', _lp), ('bestx', _dp),
+        ('trace_chisq', _dp), ('trace_flag', _ip),
+        ('snap0', _dp),
+        ('refresh_done', ctypes.c_int64),
+    ]
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class LockstepRun:
+    """One lockstep run on the CPU.
+
+    indep: x[ndata] for model='poly' (coefficients = params[0:nmodel]),
+           A[nmodel, ndata] for model='linear' (model = sum_k A[k]*params[k]).
+    tile/vlanes: the data-sum order ("reduction plan") of the kernel this run is
+    checking; the HIP library reports the plan it used.
+    """
+
+    def __init__(self, data, uncert, indep, params, pstep, pmin=None, pmax=None,
+                 prior=None, priorlow=None, priorup=None, nchains=7,
+                 nsamples=None, sampler='snooker', wlike=False, thinning=1,
+                 fgamma=1.0, fepsilon=0.0, hsize=10, model='poly', nmodel=None,
+                 seed=0, tile=0, vlanes=None, chain0=0, nlocal=None, M0=None):
+        L = ok.lib()
+        L.ls_run.restype = ctypes.c_int
+        L.ls_eval_chisq.restype = ctypes.c_int
+        self.L = L
+        self.params = _f(params)
+        npar = len(self.params)
+        self.pstep = _f(pstep)
+        self.pmin = _f(np.tile(-np.inf, npar) if pmin is None else pmin)
+        self.pmax = _f(np.tile(np.inf, npar) if pmax is None else pmax)
+        zeros = np.zeros(npar)
+        self.prior = _f(zeros if prior is None else prior)
+        self.priorlow = _f(zeros if priorlow is None else priorlow)
+        self.priorup = _f(zeros if priorup is None else priorup)
+        self.data = _f(data)
+        self.w = _f(1.0/np.asarray(uncert, float))
+        self.indep = _f(indep)
+        self.ndata = len(self.data)
+        self.ifree = _i(np.where(self.pstep > 0)[0])
+        self.ishare = _i(np.where(self.pstep < 0)[0])
+        # chain.py:247: nextp[s] = nextp[-int(pstep[s])-1]
+        self.share_src = _i([(-int(self.pstep[s]) - 1) % npar for s in self.ishare])
+        self.igprior = _i(np.where((self.priorlow > 0) & (self.priorup > 0))[0])
+        self.nfree = len(self.ifree)
+        self.nchains = int(nchains)
+        self.thinning = int(thinning)
+        self.sampler = sampler
+        self.wlike = bool(wlike)
+        if nmodel is None:
+            nmodel = npar - 3 if wlike else npar
+        self.nmodel = int(nmodel)
+        if vlanes is None:
+            vlanes = 1024 if wlike else 256
+        self.hsize = int(hsize)
+        self.M0 = self.hsize*self.nchains if M0 is None else int(M0)
+        self.nzchain = int(np.ceil(nsamples/self.nchains/self.thinning))
+        self.zlen = self.M0 + self.nzchain*self.nchains
+        nf = self.nfree
+        self.Z = np.zeros((self.zlen, nf))
+        self.log_post = np.zeros(self.zlen)
+        self.zchain = -np.ones(self.zlen, np.int32)
+        self.X = np.zeros((self.nchains, nf))
+        self.chisq = np.zeros(self.nchains)
+        self.numaccept = np.zeros(self.nchains, np.int64)
+        self.outbounds = np.zeros(nf, np.int64)
+        self.best_chisq = np.full(self.nchains, np.inf)
+        self.best_iter = -np.ones(self.nchains, np.int64)
+        self.bestx = np.zeros((self.nchains, nf))
+        self.snap0 = np.zeros((self.nchains, nf))
+        self.trace_chisq = None
+        self.trace_flag = None
+        # gamma as the host computes it (chain.py:175)
+        self.gamma = float(fgamma*2.38/np.sqrt(2*nf))
+
+        P = _Problem()
+        P.nchains = self.nchains
+        P.chain0 = int(chain0)
+        P.nlocal = self.nchains - int(chain0) if nlocal is None else int(nlocal)
+        P.nparams = npar
+        P.nfree = nf
+        P.nshare = len(self.ishare)
+        P.ndata = self.ndata
+        P.sampler = SAMPLERS[sampler]
+        P.wlike = int(self.wlike)
+        P.model_kind = MODELS[model]
+        P.nmodel = self.nmodel
+        P.thinning = self.thinning
+        P.ngprior = len(self.igprior)
+        P.tile = int(tile)
+        P.vlanes = int(vlanes)
+        P.M0 = self.M0
+        P.zlen = self.zlen
+        P.seed = int(seed)
+        P.gamma = self.gamma
+        P.fepsilon = float(fepsilon)
+        for name in ('ifree', 'ishare', 'share_src', 'igprior'):
+            setattr(P, name, getattr(self, name).ctypes.data_as(_ip))
+        for name in ('params', 'pmin', 'pmax', 'pstep', 'prior', 'priorlow',
+                     'priorup', 'indep', 'data', 'w'):
+            setattr(P, name, getattr(self, name).ctypes.data_as(_dp))
+        self.P = P
+        S = _State()
+        S.refresh_done = 0
+        self.S = S
+        self._bind()
+
+    def _bind(self):
+        S = self.S
+        S.Z = self.Z.ctypes.data_as(_dp)
+        S.log_post = self.log_post.ctypes.data_as(_dp)
+        S.zchain = self.zchain.ctypes.data_as(_ip)
+        S.X = self.X.ctypes.data_as(_dp)
+        S.chisq = self.chisq.ctypes.data_as(_dp)
+        S.numaccept = self.numaccept.ctypes.data_as(_lp)
+        S.outbounds = self.outbounds.ctypes.data_as(_lp)
+        S.best_chisq = self.best_chisq.ctypes.data_as(_dp)
+        S.best_iter = self.best_iter.ctypes.data_as(_lp)
+        S.bestx = self.bestx.ctypes.data_as(_dp)
+        S.snap0 = self.snap0.ctypes.data_as(_dp)
+
+    def set_population(self, Z0, log_post0):
+        """Initial Z rows (mcmc_driver.py:260-261); chains start from the first
+        nchains of them (chain.py:163-170)."""
+        Z0 = _f(Z0)
+        self.Z[0:self.M0] = Z0
+        self.log_post[0:self.M0] = log_post0
+        self.X[:] = Z0[0:self.nchains]
+        self.snap0[:] = Z0[0:self.nchains]
+        self.chisq[:] = -2.0*np.asarray(log_post0)[0:self.nchains]
+
+    def eval_chisq(self, params):
+        params = _f(np.atleast_2d(params))
+        out = np.empty(len(params))
+        self.L.ls_eval_chisq(ctypes.byref(self.P), params.ctypes.data_as(_dp),
+                             ctypes.c_int(len(params)), out.ctypes.data_as(_dp))
+        return out
+
+    def eval_model(self, params):
+        out = np.empty(self.ndata)
+        self.L.ls_eval_model(ctypes.byref(self.P), _f(params).ctypes.data_as(_dp),
+                             out.ctypes.data_as(_dp))
+        return out
+
+    def run(self, nrefresh=None, trace=False, nthreads=1):
+        if nrefresh is None:
+            nrefresh = self.nzchain - self.S.refresh_done
+        if trace:
+            self.trace_chisq = np.full((nrefresh*self.thinning, self.nchains), np.nan)
+            self.trace_flag = np.zeros((nrefresh*self.thinning, self.nchains), np.int32)
+            self.S.trace_chisq = self.trace_chisq.ctypes.data_as(_dp)
+            self.S.trace_flag = self.trace_flag.ctypes.data_as(_ip)
+        else:
+            self.S.trace_chisq = None
+            self.S.trace_flag = None
+        rc = self.L.ls_run(ctypes.byref(self.P), ctypes.byref(self.S),
+                           ctypes.c_int64(nrefresh), ctypes.c_int(nthreads))
+        if rc != 0:
+            raise RuntimeError(f'ls_run failed ({rc})')
+        return self
+
+
+def philox4x32_10(ctr, key):
+    """Philox through the C restatement (for the known-answer test)."""
+    L = ok.lib()
+    c = (ctypes.c_uint32*4)(*ctr)
+    k = (ctypes.c_uint32*2)(*key)
+    o = (ctypes.c_uint32*4)()
+    L.ls_philox4x32_10(c, k, o)
+    return tuple(int(v) for v in o)

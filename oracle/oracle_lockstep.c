@@ -171,7 +171,7 @@ static double gauss_chisq(const ls_problem *P, const double *p, double *part)
         }
         total = total + halving_tree(part, VL);
     }
-    if (sawinf)
+    if (sawinf || total == INFINITY)
         return INFINITY;
     return total + prior_term(P, p);
 }
@@ -239,7 +239,10 @@ static double wavelet_chisq(const ls_problem *P, const double *p,
         const double sW2 = sr2 * mc3_det_exp2(-gam * (double)m) + sw2;
         Lg = Lg + (double)(1 << m) * mc3_det_log(6.283185307179586 * sW2);
     }
-    return ((S + Lg) + T) + prior_term(P, p);
+    const double c = (S + Lg) + T;
+    if (c == INFINITY)
+        return c;
+    return c + prior_term(P, p);
 }
 
 typedef struct {

@@ -1,0 +1,338 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle.
+
+Bar (north_star): accept counts bit-exact under a fixed seed, chisq within 1e-10
+relative of the reference.  The lockstep oracle is built to the same arithmetic
+contract as the kernels, so here everything -- Z rows, log-posteriors, chain
+ids, accept / out-of-bounds counters, per-step chisq and flags -- is compared
+for exact equality; the reference's own numbers (golden vectors generated from
+its compiled C) are compared at 1e-10.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from mc3_amd import engine
+    return engine
+
+
+def run_pair(eng, prob, trace=True, nrefresh=None, **gpu_kw):
+    orc = H.make_oracle(prob)
+    Z0, lp0 = H.initial_population(orc)
+    orc.set_population(Z0, lp0)
+    niter = orc.nzchain*orc.thinning
+    gpu = eng.DeviceChains(trace_iters=niter if trace else 0, **prob, **gpu_kw)
+    gpu.set_population(Z0, lp0)
+    assert gpu.plan['vlanes'] == orc.P.vlanes
+    orc.run(nrefresh=nrefresh, trace=trace, nthreads=4)
+    gpu.run(nrefresh=nrefresh)
+    return orc, gpu
+
+
+def assert_same(orc, gpu, trace=True):
+    Z, lp, zc = gpu.rows()
+    st = gpu.state()
+    if trace:
+        tc, tf = gpu.trace(orc.trace_flag.shape[0])
+        np.testing.assert_array_equal(tf, orc.trace_flag)
+        np.testing.assert_array_equal(tc, orc.trace_chisq)
+    np.testing.assert_array_equal(zc, orc.zchain)
+    np.testing.assert_array_equal(Z, orc.Z)
+    np.testing.assert_array_equal(lp, orc.log_post)
+    np.testing.assert_array_equal(st['numaccept'], orc.numaccept)
+    np.testing.assert_array_equal(st['outbounds'], orc.outbounds)
+    np.testing.assert_array_equal(st['X'], orc.X)
+    np.testing.assert_array_equal(st['chisq'], orc.chisq)
+    np.testing.assert_array_equal(st['best_chisq'], orc.best_chisq)
+    np.testing.assert_array_equal(st['best_iter'], orc.best_iter)
+    acc = st['best_iter'] >= 0
+    np.testing.assert_array_equal(st['bestx'][acc], orc.bestx[acc])
+    assert st['numaccept'].sum() > 0
+
+
+# ---- building blocks -------------------------------------------------------
+def test_device_math_matches_host_bit_for_bit(eng):
+    import ctypes
+    from mc3_amd import _lib
+    from oracle import kernels as ok
+    L, O = _lib.load(), ok.lib()
+    rs = np.random.RandomState(0)
+    cases = {
+        0: (np.concatenate([rs.uniform(-745, 710, 50000), rs.normal(0, 1, 50000)]), O.ls_det_exp),
+        1: (np.exp(rs.uniform(-700, 700, 100000)), O.ls_det_log),
+        2: (rs.uniform(-60, 60, 100000), O.ls_det_exp2),
+    }
+    for op, (xs, host) in cases.items():
+        xs = np.ascontiguousarray(xs)
+        out = np.empty_like(xs)
+        _lib.check(L.mc3hip_selftest_math(0, op, _lib.dptr(xs), len(xs), _lib.dptr(out)))
+        want = np.array([host(float(x)) for x in xs])
+        np.testing.assert_array_equal(out, want)
+    us = np.ascontiguousarray(rs.uniform(0, 1, 100000))
+    s, c = ctypes.c_double(), ctypes.c_double()
+    ws, wc = np.empty_like(us), np.empty_like(us)
+    for i, u in enumerate(us):
+        O.ls_det_sincos2pi(float(u), ctypes.byref(s), ctypes.byref(c))
+        ws[i], wc[i] = s.value, c.value
+    for op, want in ((3, ws), (4, wc)):
+        out = np.empty_like(us)
+        _lib.check(L.mc3hip_selftest_math(0, op, _lib.dptr(us), len(us), _lib.dptr(out)))
+        np.testing.assert_array_equal(out, want)
+    # IEEE sqrt and division are correctly rounded on the device
+    xs = np.ascontiguousarray(np.exp(rs.uniform(-300, 300, 100000)))
+    out = np.empty_like(xs)
+    _lib.check(L.mc3hip_selftest_math(0, 5, _lib.dptr(xs), len(xs), _lib.dptr(out)))
+    np.testing.assert_array_equal(out, np.sqrt(xs))
+    _lib.check(L.mc3hip_selftest_math(0, 6, _lib.dptr(xs), len(xs), _lib.dptr(out)))
+    np.testing.assert_array_equal(out, 1.0/xs)
+
+
+def test_device_philox_known_answers(eng):
+    from mc3_amd import _lib
+    from oracle import lockstep as ls
+    L = _lib.load()
+    rs = np.random.RandomState(1)
+    ctr = rs.randint(0, 2**32, (1000, 4), dtype=np.uint64).astype(np.uint32)
+    ctr[0] = 0
+    ctr[1] = 0xffffffff
+    ctr[2] = [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]
+    up = _lib._up
+    for key in ((0, 0), (0xffffffff, 0xffffffff), (0xa4093822, 0x299f31d0)):
+        k = np.array(key, np.uint32)
+        out = np.empty_like(ctr)
+        _lib.check(L.mc3hip_selftest_philox(0, ctr.ctypes.data_as(up), len(ctr),
+                                            k.ctypes.data_as(up), out.ctypes.data_as(up)))
+        for i in range(0, len(ctr), 37):
+            assert tuple(out[i]) == ls.philox4x32_10(tuple(int(v) for v in ctr[i]), key)
+        if key == (0, 0):
+            assert tuple(out[0]) == (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)
+        if key == (0xffffffff, 0xffffffff):
+            assert tuple(out[1]) == (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)
+        if key == (0xa4093822, 0x299f31d0):
+            assert tuple(out[2]) == (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
+
+
+# ---- likelihood kernels against the reference's golden vectors --------------
+@pytest.mark.parametrize('ndata', [8, 32, 1000, 16384])
+def test_gauss_chisq_vs_reference_vectors(eng, golden_dir, ndata):
+    kv = np.load(os.path.join(golden_dir, 'kernel_vectors.npz'))
+    x, data, uncert = H.tutorial_data(ndata, 1000 + ndata)
+    P = kv[f'gauss_{ndata}_params']
+    base = dict(data=data, uncert=uncert, indep=x, params=P[0], pstep=np.ones(3),
+                nchains=4, nsamples=40, sampler='demc')
+    with eng.DeviceChains(**base) as g:
+        got = g.eval_chisq(P)
+        np.testing.assert_allclose(got, kv[f'gauss_{ndata}_chisq'], rtol=1e-10)
+        model = g.eval_model_values(P[0])
+        np.testing.assert_allclose(model, H.quad(P[0], x), rtol=1e-13, atol=1e-13)
+    pri = dict(prior=kv['gauss_prior'], priorlow=kv['gauss_priorlow'],
+               priorup=kv['gauss_priorup'])
+    with eng.DeviceChains(**base, **pri) as g:
+        got = g.eval_chisq(P)
+        np.testing.assert_allclose(got, kv[f'gauss_{ndata}_chisq_priors'], rtol=1e-10)
+        orc = H.make_oracle(dict(base, **pri))
+        np.testing.assert_array_equal(got, orc.eval_chisq(P))
+
+
+@pytest.mark.parametrize('ndata', [2, 4, 8, 32, 1024, 16384])
+def test_wavelet_chisq_vs_reference_vectors(eng, golden_dir, ndata):
+    kv = np.load(os.path.join(golden_dir, 'kernel_vectors.npz'))
+    rs2 = np.random.RandomState(2000 + ndata)
+    x = np.linspace(0, 10, ndata)
+    data = H.quad([3.0, -2.4, 0.5], x) + rs2.normal(0, 1.0, ndata) \
+        + 0.5*np.sin(2*np.pi*x)
+    P = kv[f'dwt_{ndata}_params']
+    base = dict(data=data, uncert=np.ones(ndata), indep=x, params=P[0],
+                pstep=np.array([1.0, 1, 1, 0, 1, 1]), nchains=4, nsamples=40,
+                sampler='snooker', wlike=True)
+    for wpc in ('1', '4', '16'):
+        os.environ['MC3HIP_WPC'] = wpc
+        try:
+            with eng.DeviceChains(**base) as g:
+                assert g.plan['waves_per_chain'] == int(wpc)
+                got = g.eval_chisq(P)
+        finally:
+            del os.environ['MC3HIP_WPC']
+        np.testing.assert_allclose(got, kv[f'dwt_{ndata}_chisq'], rtol=1e-10)
+        np.testing.assert_array_equal(got, H.make_oracle(base).eval_chisq(P))
+    pri = dict(prior=kv['dwt_prior'], priorlow=kv['dwt_priorlow'],
+               priorup=kv['dwt_priorup'])
+    with eng.DeviceChains(**base, **pri) as g:
+        np.testing.assert_allclose(g.eval_chisq(P), kv[f'dwt_{ndata}_chisq_priors'],
+                                   rtol=1e-10)
+
+
+def test_known_answers_of_the_reference_tests(eng):
+    """tests/test_stats.py:135-171 of the reference, through the device."""
+    data = np.array([1.1, 1.2, 0.9, 1.0])
+    uncert = np.full(4, 0.1)
+    base = dict(data=data, uncert=uncert, indep=np.zeros(4), nchains=4, nsamples=40,
+                sampler='demc')
+    with eng.DeviceChains(params=np.array([1.0]), pstep=np.array([1.0]), **base) as g:
+        np.testing.assert_allclose(g.eval_chisq(np.array([1.0])), 6.0, rtol=1e-13)
+    # a constant model (nmodel=1) with two extra parameters carrying the priors
+    with eng.DeviceChains(params=np.array([1.0, 2.5, 5.5]), pstep=np.ones(3), nmodel=1,
+                          prior=np.array([0.0, 2.0, 5.0]),
+                          priorlow=np.array([0.0, 0.0, 1.0]),
+                          priorup=np.array([0.0, 0.0, 1.0]), **base) as g:
+        np.testing.assert_allclose(g.eval_chisq(np.array([1.0, 2.5, 5.5])), 6.25,
+                                   rtol=1e-13)
+    data = np.array([2.0, 0.0, 3.0, -2.0, -1.0, 2.0, 2.0, 0.0])
+    wb = dict(data=data, uncert=np.ones(8), indep=np.zeros(8), nchains=4, nsamples=40,
+              sampler='snooker', wlike=True, pstep=np.array([1.0, 0, 1, 1]))
+    p = np.array([1.0, 1.0, 0.1, 0.1])
+    with eng.DeviceChains(params=p, **wb) as g:
+        np.testing.assert_allclose(g.eval_chisq(p), 1693.22308882, rtol=1e-10)
+    with eng.DeviceChains(params=p, prior=np.array([0, 1.0, 0.2, 0.3]),
+                          priorlow=np.array([0, 0.0, 0.0, 0.1]),
+                          priorup=np.array([0, 0.0, 0.0, 0.1]), **wb) as g:
+        np.testing.assert_allclose(g.eval_chisq(p), 1697.2230888243134, rtol=1e-10)
+
+
+@pytest.mark.parametrize('n', [4, 8, 32, 100, 1024])
+def test_daub4_vs_reference_vectors(eng, golden_dir, n):
+    kv = np.load(os.path.join(golden_dir, 'kernel_vectors.npz'))
+    v = kv[f'daub4_{n}_in']
+    np.testing.assert_allclose(eng.dwt_daub4(v), kv[f'daub4_{n}_fwd'],
+                               rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(eng.dwt_daub4(v, True), kv[f'daub4_{n}_inv'],
+                               rtol=1e-12, atol=1e-13)
+    # round trip (reference tests/test_stats.py:296-302)
+    nw = len(kv[f'daub4_{n}_fwd'])
+    pad = np.zeros(nw)
+    pad[:n] = v
+    np.testing.assert_allclose(eng.dwt_daub4(eng.dwt_daub4(v, True)), pad, atol=1e-10)
+
+
+# ---- the chain update: bit-exact against the lockstep oracle ---------------
+@pytest.mark.parametrize('sampler,extra', [
+    ('demc', {}),
+    ('snooker', {}),
+    ('mrw', {}),
+    ('demc', {'fepsilon': 0.01, 'fgamma': 0.9, 'thinning': 2}),
+    ('snooker', {'fepsilon': 0.02, 'thinning': 3}),
+])
+def test_quad_chains_bit_exact(eng, sampler, extra):
+    prob = H.quad_problem(sampler=sampler, nchains=9, nsamples=9*150*extra.get('thinning', 1),
+                          **extra)
+    orc, gpu = run_pair(eng, prob)
+    assert_same(orc, gpu)
+    gpu.close()
+
+
+@pytest.mark.parametrize('sampler', ['snooker', 'demc'])
+def test_shared_fixed_priors_bounds_bit_exact(eng, sampler):
+    prob = H.shared_problem(sampler=sampler)
+    orc, gpu = run_pair(eng, prob)
+    assert_same(orc, gpu)
+    assert gpu.state()['outbounds'].sum() > 0      # the bounds do bite
+    gpu.close()
+
+
+@pytest.mark.parametrize('ndata', [64, 1024])
+def test_wavelet_chains_bit_exact(eng, ndata):
+    prob = H.wavelet_problem(ndata=ndata, nsamples=7*60)
+    orc, gpu = run_pair(eng, prob)
+    assert_same(orc, gpu)
+    gpu.close()
+
+
+def test_linear_model_chains_bit_exact(eng):
+    prob = H.linear_problem()
+    orc, gpu = run_pair(eng, prob)
+    assert_same(orc, gpu)
+    gpu.close()
+
+
+@pytest.mark.parametrize('wpc', ['1', '4', '16'])
+def test_waves_per_chain_do_not_change_results(eng, wpc):
+    prob = H.quad_problem(ndata=3000, nchains=8, nsamples=8*40, sampler='snooker')
+    os.environ['MC3HIP_WPC'] = wpc
+    try:
+        orc, gpu = run_pair(eng, prob)
+    finally:
+        del os.environ['MC3HIP_WPC']
+    assert gpu.plan['waves_per_chain'] == int(wpc)
+    assert_same(orc, gpu)
+    gpu.close()
+
+
+def test_graph_replay_equals_eager_and_resumes(eng):
+    """600 refreshes = two 256-node graph replays + an eager tail; split into
+    several run() calls; against one eager run and the oracle."""
+    prob = H.quad_problem(nchains=8, nsamples=8*600, sampler='demc')
+    orc, eager = run_pair(eng, prob, trace=False, no_graph=True)
+    assert eager.plan['graph_nodes'] == 0
+    graph = eng.DeviceChains(**prob)
+    assert graph.plan['graph_nodes'] == 256
+    Z0, lp0 = H.initial_population(orc)
+    graph.set_population(Z0, lp0)
+    graph.run(300)
+    graph.run(300)
+    assert_same(orc, eager, trace=False)
+    assert_same(orc, graph, trace=False)
+    with pytest.raises(Exception, match='cannot run'):
+        graph.run(1)
+    eager.close()
+    graph.close()
+
+
+def test_headline_config_c2_matches_oracle(eng):
+    """BASELINE config #2 (256 chains, ndata=1000, demc) for 400 iterations:
+    bit-exact against the oracle, then properties at full length."""
+    prob = H.quad_problem(ndata=1000, nchains=256, nsamples=256*400, sampler='demc')
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
+def test_headline_config_c2_properties_full_size(eng):
+    """Size-independent properties on a long C2 run (20000 iterations): every
+    row written once by its chain, log_post consistent with a re-evaluation of
+    the stored parameters, acceptance counts consistent with the rows."""
+    prob = H.quad_problem(ndata=1000, nchains=256, nsamples=256*20000, sampler='demc')
+    gpu = eng.DeviceChains(**prob)
+    orc = H.make_oracle(dict(prob, nsamples=256*10))
+    Z0, lp0 = H.initial_population(orc)
+    gpu.set_population(Z0, lp0)
+    gpu.run()
+    Z, lp, zc = gpu.rows()
+    st = gpu.state()
+    M0, n = gpu.M0, gpu.nchains
+    assert np.all(zc[:M0] == -1)
+    assert np.all(zc[M0:] == np.tile(np.arange(n), gpu.nzchain))
+    # rows only change on acceptance: count state changes per chain
+    hist = Z[M0:].reshape(gpu.nzchain, n, gpu.nfree)
+    prev = np.concatenate([Z0[None, :n], hist[:-1]])
+    changed = np.any(hist != prev, axis=2).sum(axis=0)
+    np.testing.assert_array_equal(changed, st['numaccept'])
+    # log_post of a sample of rows == -chisq/2 of the stored parameters
+    idx = np.random.RandomState(0).randint(M0, len(Z), 4000)
+    re = gpu.eval_chisq(Z[idx])
+    np.testing.assert_array_equal(lp[idx], -0.5*re)
+    # the sampler found the posterior: mean within 5 sigma/sqrt(n_eff) of truth
+    post = Z[M0 + n*2000:]
+    assert np.all(np.abs(post.mean(axis=0) - [3.0, -2.4, 0.5]) < [1.5, 0.6, 0.06])
+    rate = st['numaccept'].sum()/(gpu.nzchain*n)
+    assert 0.1 < rate < 0.5
+    gpu.close()
+
+
+def test_error_paths(eng):
+    prob = H.quad_problem()
+    with pytest.raises(Exception, match='demc needs at least 3 chains'):
+        eng.DeviceChains(**dict(prob, nchains=2))
+    with pytest.raises(Exception, match='power-of-two'):
+        eng.DeviceChains(**dict(H.wavelet_problem(), data=np.ones(60),
+                                uncert=np.ones(60), indep=np.ones(60)))
+    g = eng.DeviceChains(**prob)
+    with pytest.raises(Exception, match='set_population'):
+        g.run(1)
+    g.close()
