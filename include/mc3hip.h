@@ -173,6 +173,10 @@ int mc3hip_selftest_math(int32_t device, int32_t op, const double *in,
 int mc3hip_selftest_philox(int32_t device, const uint32_t *ctr, int32_t n,
                            const uint32_t key[2], uint32_t *out);
 
+/* Diagnostic builds (-DMC3HIP_STAMPS) record the shader clock at five phases of
+ * the last step-kernel launch (workgroup 0); the product build returns zeros. */
+int mc3hip_debug_stamps(mc3hip_ctx *ctx, uint64_t *out16);
+
 #ifdef __cplusplus
 }
 #endif

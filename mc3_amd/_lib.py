@@ -78,6 +78,7 @@ SYMBOLS = {
     'mc3hip_comm_unique_id': (ctypes.c_int, [_vp]),
     'mc3hip_comm_init': (ctypes.c_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int32]),
     'mc3hip_comm_gather_log_post': (ctypes.c_int, [_vp]),
+    'mc3hip_debug_stamps': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
     'mc3hip_selftest_math': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, _dp, ctypes.c_int32, _dp]),
     'mc3hip_selftest_philox': (ctypes.c_int, [ctypes.c_int32, _up, ctypes.c_int32, _up, _up]),
 }

@@ -38,6 +38,7 @@ struct DevProblem {
     double gamma, fepsilon;
     const int32_t *ifree, *ishare, *share_src, *igprior;
     const double *params, *pmin, *pmax, *pstep, *prior, *priorlow, *priorup;
+    const double *fmin, *fmax, *fstep;   // pmin/pmax/pstep gathered at ifree[k]
     const double *indep, *data, *w;
     double *Z, *log_post;
     int32_t *zchain;
@@ -51,7 +52,23 @@ struct DevProblem {
     double *trace_chisq;
     int32_t *trace_flag;
     const long long *ctl;   // ctl[0] = refresh base of this replay, ctl[1] = first refresh of the run
+    unsigned long long *stamps;   // diagnostic build only (MC3HIP_STAMPS): s_memtime per phase
 };
+
+// In-kernel phase stamps for the diagnostic build (never compiled into the product
+// library): drain outstanding memory operations, then read the shader clock.
+#ifdef MC3HIP_STAMPS
+#define MC3_STAMP(slot)                                                                   \
+    do {                                                                                  \
+        unsigned long long t_;                                                            \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" \
+                     : "=s"(t_)::"memory");                                               \
+        if (threadIdx.x == 0 && blockIdx.x == 0)                                          \
+            P.stamps[slot] = t_;                                                          \
+    } while (0)
+#else
+#define MC3_STAMP(slot) do { } while (0)
+#endif
 
 // ---- model evaluation ------------------------------------------------------
 template <int MT>
@@ -73,21 +90,26 @@ struct Model {
                 cf[j] = s_nextp[j];
         }
     }
-    __device__ __forceinline__ double at(int i) const
+    // polynomial families at abscissa x (Horner, fused multiply-adds)
+    __device__ __forceinline__ double at_x(double x) const
     {
         if constexpr (MT >= 1 && MT <= 8) {
-            const double x = indep[i];
             double m = cf[MT - 1];
 #pragma unroll
             for (int j = MT - 2; j >= 0; --j)
                 m = mc3_fma(m, x, cf[j]);
             return m;
-        } else if constexpr (MT == MT_POLY_GENERIC) {
-            const double x = indep[i];
+        } else {
             double m = coef[nmodel - 1];
             for (int j = nmodel - 2; j >= 0; --j)
                 m = mc3_fma(m, x, coef[j]);
             return m;
+        }
+    }
+    __device__ __forceinline__ double at(int i) const
+    {
+        if constexpr (MT != MT_LINEAR) {
+            return at_x(indep[i]);
         } else {
             double m = indep[i] * coef[0];
             for (int k = 1; k < nmodel; ++k)
@@ -102,9 +124,86 @@ __device__ __forceinline__ bool is_pos_inf(double v)
     return mc3_bits(v) == 0x7ff0000000000000ull;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
+// the vector-memory counter, which would serialise the data loads this kernel
+// deliberately keeps in flight across the proposal phase; gfx950's s_barrier
+// itself waits for no counter.  One wave per workgroup needs no barrier at all:
+// a wave's LDS instructions execute in order.
+template <int WPC>
+__device__ __forceinline__ void block_sync()
+{
+    if constexpr (WPC == 1) {
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0) only
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+template <int WPC>
+__device__ __forceinline__ int block_or(int pred, int *s_flag)
+{
+    int any = __any(pred) ? 1 : 0;
+    if constexpr (WPC > 1) {
+        if (threadIdx.x == 0)
+            s_flag[1] = 0;
+        block_sync<WPC>();
+        if (any && (threadIdx.x & 63) == 0)
+            s_flag[1] = 1;
+        block_sync<WPC>();
+        any = s_flag[1];
+    }
+    return any;
+}
+
+__device__ __forceinline__ double make_double(int lo, int hi) { return __hiloint2double(hi, lo); }
+
+// v[l] + v[l ^ 32], v[l] + v[l ^ 16]: gfx950 lane-swap instructions (VALU only)
+__device__ __forceinline__ double add_xor32(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return make_double(a[0], b[0]) + make_double(a[1], b[1]);
+}
+__device__ __forceinline__ double add_xor16(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return make_double(a[0], b[0]) + make_double(a[1], b[1]);
+}
+// v[l] + v[(l + N) mod 16 within its row of 16]: DPP row rotate
+template <int N>
+__device__ __forceinline__ double add_ror(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x120 + N, 0xf, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xf, 0xf, false);
+    return v + make_double(lo2, hi2);
+}
+// sum over the 64 lanes of a wave, pairing strides 32,16,8,4,2,1; every lane
+// receives the total
+__device__ __forceinline__ double wave_sum(double t)
+{
+    t = add_xor32(t);
+    t = add_xor16(t);
+    t = add_ror<8>(t);
+    t = add_ror<4>(t);
+    t = add_ror<2>(t);
+    t = add_ror<1>(t);
+    return t;
+}
+
+__device__ __forceinline__ double read_lane(double v, int k)
+{
+    return make_double(__builtin_amdgcn_readlane(__double2loint(v), k),
+                       __builtin_amdgcn_readlane(__double2hiint(v), k));
+}
+
 // Halving tree over the 1024 virtual lanes.  acc[v] is this thread's partial for
 // virtual lane  lane + 64*(wave + WPC*v).  Strides >= 64*WPC are in-thread,
-// strides 64*WPC/2..64 go through LDS, strides 32..1 are wave shuffles.
+// strides 64*WPC/2..64 go through LDS, strides 32..1 are in-wave lane swaps.
 // The result is valid in every lane of wave 0.
 template <int WPC>
 __device__ __forceinline__ double lane_tree(double (&acc)[16 / WPC], double *s_part)
@@ -118,9 +217,9 @@ __device__ __forceinline__ double lane_tree(double (&acc)[16 / WPC], double *s_p
     }
     double t = acc[0];
     if constexpr (WPC > 1) {
-        __syncthreads();                      // s_part may still be read by wave 0
+        block_sync<WPC>();                    // s_part may still be read by wave 0
         s_part[threadIdx.x] = t;
-        __syncthreads();
+        block_sync<WPC>();
         if (threadIdx.x < 64) {
             double p[WPC];
 #pragma unroll
@@ -135,44 +234,91 @@ __device__ __forceinline__ double lane_tree(double (&acc)[16 / WPC], double *s_p
             t = p[0];
         }
     }
-    if (threadIdx.x < 64) {
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1)
-            t = t + __shfl_down(t, s, 64);
-        t = __shfl(t, 0, 64);
-    }
+    if (threadIdx.x < 64)
+        t = wave_sum(t);
     return t;
 }
 
+// The first 1024-point tile of (x, data, w) held in registers: loaded once at
+// kernel entry -- before the proposal is known, so the load latency overlaps the
+// RNG / partner-row phase -- and reused by every iteration of the launch.
+template <int WPC, int MT>
+struct DataTile {
+    static constexpr int NV = 16 / WPC;
+    double x[NV], d[NV], w[NV];
+
+    __device__ __forceinline__ void load(const DevProblem &P)
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int last = P.ndata - 1;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            int i = lane + 64 * (wv + WPC * v);
+            i = i < last ? i : last;             // clamp: out-of-range lanes are masked later
+            d[v] = P.data[i];
+            w[v] = P.w[i];
+            if constexpr (MT != MT_LINEAR)
+                x[v] = P.indep[i];
+        }
+    }
+};
+
 // Gaussian chi-squared data term, src_c/_chisq.c:131-133 with w = 1/uncert.
 // Returns +inf when any model value is +inf (chain.py:322-323).
-template <int WPC, int MT>
-__device__ double block_gauss(const DevProblem &P, const double *s_nextp, double *s_part)
+template <int WPC, int MT, bool MULTI>
+__device__ double block_gauss(const DevProblem &P, const double *s_nextp, double *s_part,
+                              int *s_flag, const DataTile<WPC, MT> &tile)
 {
     constexpr int NV = 16 / WPC;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     Model<MT> model;
     model.init(P, s_nextp);
     double acc[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v)
-        acc[v] = 0.0;
     int sawinf = 0;
     const int n = P.ndata;
-    for (int base = 0; base < n; base += VLANES) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int i = lane + 64 * (wv + WPC * v);
+        const bool valid = i < n;
+        double m;
+        if constexpr (MT == MT_LINEAR)
+            m = model.at(valid ? i : n - 1);
+        else
+            m = model.at_x(tile.x[v]);
+        sawinf |= valid && is_pos_inf(m);
+        double r = (m - tile.d[v]) * tile.w[v];
+        r = valid ? r : 0.0;
+        acc[v] = mc3_fma(r, r, 0.0);
+    }
+    // points beyond the first tile are streamed (MULTI = ndata > 1024)
+    for (int base = VLANES; MULTI && base < n; base += VLANES) {
+        double xs[NV], ds[NV], ws[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {                // issue every load of the tile first
+            int i = base + lane + 64 * (wv + WPC * v);
+            i = i < n ? i : n - 1;
+            ds[v] = P.data[i];
+            ws[v] = P.w[i];
+            if constexpr (MT != MT_LINEAR)
+                xs[v] = P.indep[i];
+        }
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int i = base + lane + 64 * (wv + WPC * v);
-            if (i < n) {
-                const double m = model.at(i);
-                sawinf |= is_pos_inf(m);
-                const double r = (m - P.data[i]) * P.w[i];
-                acc[v] = mc3_fma(r, r, acc[v]);
-            }
+            const bool valid = i < n;
+            double m;
+            if constexpr (MT == MT_LINEAR)
+                m = model.at(valid ? i : n - 1);
+            else
+                m = model.at_x(xs[v]);
+            sawinf |= valid && is_pos_inf(m);
+            double r = (m - ds[v]) * ws[v];
+            r = valid ? r : 0.0;
+            acc[v] = mc3_fma(r, r, acc[v]);
         }
     }
     const double total = lane_tree<WPC>(acc, s_part);
-    sawinf = __syncthreads_or(sawinf);
+    sawinf = block_or<WPC>(sawinf, s_flag);
     return sawinf ? mc3_from_bits(0x7ff0000000000000ull) : total;
 }
 
@@ -208,7 +354,7 @@ __device__ __forceinline__ int ilog2(int n)
 // by 1/sigma_W^2 of their scale and accumulated without ever being stored.
 template <int WPC, int MT>
 __device__ double block_wavelet(const DevProblem &P, const double *s_nextp, double *s_part,
-                                double *bufA, double *bufB)
+                                int *s_flag, double *bufA, double *bufB)
 {
     constexpr int NV = 16 / WPC;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -250,7 +396,7 @@ __device__ double block_wavelet(const DevProblem &P, const double *s_nextp, doub
                 }
             }
         }
-        __syncthreads();
+        block_sync<WPC>();
         double *dst = bufB;
         double *cur = bufA;
         for (int nn = nh; nn >= 4; nn >>= 1) {
@@ -270,7 +416,7 @@ __device__ double block_wavelet(const DevProblem &P, const double *s_nextp, doub
                     }
                 }
             }
-            __syncthreads();
+            block_sync<WPC>();
             double *t = cur;
             cur = dst;
             dst = t;
@@ -282,11 +428,11 @@ __device__ double block_wavelet(const DevProblem &P, const double *s_nextp, doub
             sawinf |= is_pos_inf(m);
             bufA[threadIdx.x] = P.data[threadIdx.x] - m;
         }
-        __syncthreads();
+        block_sync<WPC>();
     }
     const double a0 = src[0], a1 = src[1];
     const double T = lane_tree<WPC>(acc, s_part);
-    sawinf = __syncthreads_or(sawinf);
+    sawinf = block_or<WPC>(sawinf, s_flag);
     if (sawinf)
         return mc3_from_bits(0x7ff0000000000000ull);
     const int M = ilog2(N);
@@ -314,26 +460,27 @@ __device__ __forceinline__ double prior_term(const DevProblem &P, const double *
 }
 
 // chisq of the parameter vector in s_nextp; valid in wave 0
-template <int WPC, int MT>
+template <int WPC, int MT, bool WL, bool MULTI>
 __device__ __forceinline__ double block_chisq(const DevProblem &P, const double *s_nextp,
-                                              double *s_part, double *bufA, double *bufB)
+                                              double *s_part, int *s_flag, double *bufA,
+                                              double *bufB, const DataTile<WPC, MT> &tile)
 {
     double c;
-    if (P.wlike)
-        c = block_wavelet<WPC, MT>(P, s_nextp, s_part, bufA, bufB);
+    if constexpr (WL)
+        c = block_wavelet<WPC, MT>(P, s_nextp, s_part, s_flag, bufA, bufB);
     else
-        c = block_gauss<WPC, MT>(P, s_nextp, s_part);
+        c = block_gauss<WPC, MT, MULTI>(P, s_nextp, s_part, s_flag, tile);
     if (is_pos_inf(c))
         return c;
     return c + prior_term(P, s_nextp);
 }
 
-// serial sum over lanes 0..n-1 of a wave, in lane order
+// serial sum over lanes 0..n-1 of a wave, in lane order (v_readlane broadcasts)
 __device__ __forceinline__ double lane_serial_sum(double t, int n)
 {
     double s = 0.0;
     for (int k = 0; k < n; ++k)
-        s = s + __shfl(t, k, 64);
+        s = s + read_lane(t, k);
     return s;
 }
 
@@ -368,13 +515,14 @@ static inline size_t smem_bytes(int nthreads, int ndata, int wlike)
 }
 
 // ---- the chain update -------------------------------------------------------
-template <int WPC, int MT>
+template <int WPC, int MT, bool WL, bool MULTI>
 __global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, const int roff)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const SmemLayout L = carve(smem, P, 64 * WPC);
+    MC3_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
-    const bool wave0 = tid < 64;
+    const bool wave0 = (WPC == 1) ? true : (tid < 64);
     const int lc = blockIdx.x;                 // local chain
     const int c = P.chain0 + lc;               // global chain id
     const int nf = P.nfree;
@@ -383,24 +531,46 @@ __global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, cons
                                   : P.Z + (size_t)(P.M0 + (R - 1) * P.nchains) * nf;
     const long long zsize = P.M0 + R * P.nchains;
     const bool mine = wave0 && lane < nf;      // lane k of wave 0 owns free parameter k
-    const int jfree = mine ? P.ifree[lane] : 0;
 
-    // chain state lives in wave 0's registers for the whole launch
-    double xk = mine ? P.X[(size_t)lc * nf + lane] : 0.0;
+    // Everything that does not depend on the proposal is requested first, so the
+    // memory latencies overlap each other and the RNG arithmetic: the data tile
+    // (registers, kept for all iterations of the launch), the chain state, the
+    // per-parameter bounds and the fixed parameter values.
+    DataTile<WPC, MT> tile;
+    if constexpr (!WL)
+        tile.load(P);
+    // own state = this chain's row of the snapshot (same pages as the partner rows
+    // requested a few hundred cycles later, so their translation is already warm)
+    double xk = mine ? snap[(size_t)c * nf + lane] : 0.0;
     double cur = P.chisq[lc];
     double best = P.best_chisq[lc];
-    long long nacc = 0;
-    const double pmin_k = mine ? P.pmin[jfree] : 0.0;
-    const double pmax_k = mine ? P.pmax[jfree] : 0.0;
+    const long long nacc0 = P.numaccept[lc];
+    const int jfree = mine ? P.ifree[lane] : 0;
+    const double pmin_k = mine ? P.fmin[lane] : 0.0;
+    const double pmax_k = mine ? P.fmax[lane] : 0.0;
     const bool need_normal = (P.sampler == MC3HIP_MRW) || (P.fepsilon != 0.0);
-    const double pstep_k = (mine && need_normal) ? P.pstep[jfree] : 0.0;
+    const double pstep_k = (mine && need_normal) ? P.fstep[lane] : 0.0;
+    const double fixed0 = (wave0 && lane < P.nparams) ? P.params[lane] : 0.0;
+    const double fixed1 = (wave0 && lane + 64 < P.nparams) ? P.params[lane + 64] : 0.0;
+    long long nacc = 0;
+    MC3_STAMP(1);
 
     for (int j = 0; j < P.thinning; ++j) {
         const uint64_t iter = (uint64_t)(R * P.thinning + j);
-        double npk = 0.0, zk = 0.0;
+        double npk = 0.0, zk = 0.0, u = 0.0;
         double mrfactor = 1.0;
         bool sjump = false, outk = false;
         int flags = 0;
+        // The index / acceptance draws depend only on (seed, iteration, chain): they
+        // are wave-uniform, so Philox runs on the scalar unit (every wave repeats it).
+        const Draw2 d0 = draw2(P.seed, iter, (uint32_t)c, 0u);
+        Draw2 d1 = d0, d2 = d0;
+        if (P.sampler == MC3HIP_SNOOKER) {
+            d1 = draw2(P.seed, iter, (uint32_t)c, 1u);
+            d2 = draw2(P.seed, iter, (uint32_t)c, 2u);
+        }
+        // Metropolis draw, chain.py:259
+        u = (P.sampler == MC3HIP_SNOOKER) ? u01(d2.q1) : u01(d0.q1);
         if (wave0) {
             // support-distribution draw, chain.py:185
             double normal_k = 0.0;
@@ -413,19 +583,16 @@ __global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, cons
             }
             double jump_k = 0.0;
             if (P.sampler == MC3HIP_SNOOKER) {                       // chain.py:195-217
-                const Draw2 d0 = draw2(P.seed, iter, (uint32_t)c, 0u);
                 long long iR1 = (long long)bounded(d0.q0, (uint64_t)zsize);
                 long long iR2 = 1 + (long long)bounded(d0.q1, (uint64_t)(zsize - 1));
                 if (iR2 == iR1)
                     iR2 = 0;
-                const Draw2 d1 = draw2(P.seed, iter, (uint32_t)c, 1u);
                 sjump = u01(d1.q0) < 0.1;
                 const long long iz = (long long)bounded(d1.q1, (uint64_t)zsize);
                 const double z1 = mine ? P.Z[(size_t)iR1 * nf + lane] : 0.0;
                 const double z2 = mine ? P.Z[(size_t)iR2 * nf + lane] : 0.0;
                 if (sjump) {
                     flags |= 4;
-                    const Draw2 d2 = draw2(P.seed, iter, (uint32_t)c, 2u);
                     const double gs = 1.2 + (2.2 - 1.2) * u01(d2.q0);
                     zk = mine ? P.Z[(size_t)iz * nf + lane] : 0.0;
                     const bool same = __all(!mine || zk == xk);
@@ -445,13 +612,13 @@ __global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, cons
                 jump_k = normal_k;
             } else {                                                 // chain.py:221-232
                 const int n = P.nchains;
-                const Draw2 d0 = draw2(P.seed, iter, (uint32_t)c, 0u);
-                int r1 = 1 + (int)bounded(d0.q0, (uint64_t)(n - 1));
+                int r1 = 1 + (int)bounded32((uint32_t)(d0.q0 >> 32), (uint32_t)(n - 1));
                 if (r1 == c)
                     r1 = 0;
-                int r2 = (r1 + 2 + (int)bounded(d0.q1, (uint64_t)(n - 2))) % n;
+                int r2 = r1 + 2 + (int)bounded32((uint32_t)d0.q0, (uint32_t)(n - 2));  // < 2n
+                r2 = (r2 >= n) ? r2 - n : r2;                               // (...) % n
                 if (r2 == c)
-                    r2 = (r1 + 1) % n;
+                    r2 = (r1 + 1 == n) ? 0 : r1 + 1;                        // (r1+1) % n
                 const double x1 = mine ? snap[(size_t)r1 * nf + lane] : 0.0;
                 const double x2 = mine ? snap[(size_t)r2 * nf + lane] : 0.0;
                 jump_k = P.gamma * (x1 - x2) + P.fepsilon * normal_k;
@@ -460,22 +627,29 @@ __global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, cons
             npk = xk + jump_k;
             outk = mine && (npk < pmin_k || npk > pmax_k);
             const bool anyout = __any(outk);
-            for (int q = lane; q < P.nparams; q += 64)
-                L.nextp[q] = P.params[q];
+            if (lane < P.nparams)
+                L.nextp[lane] = fixed0;
+            if (lane + 64 < P.nparams)
+                L.nextp[lane + 64] = fixed1;
+            __builtin_amdgcn_wave_barrier();
             if (mine)
                 L.nextp[jfree] = npk;
+            __builtin_amdgcn_wave_barrier();
             if (lane == 0) {
                 for (int s = 0; s < P.nshare; ++s)                   // chain.py:246-247
                     L.nextp[P.ishare[s]] = L.nextp[P.share_src[s]];
                 L.flag[0] = anyout ? 1 : 0;
             }
         }
-        __syncthreads();
+        block_sync<WPC>();
+        MC3_STAMP(2);
         const bool anyout = L.flag[0] != 0;
         double nextchisq = mc3_from_bits(0x7ff8000000000000ull);
         if (!anyout) {
             flags |= 1;
-            nextchisq = block_chisq<WPC, MT>(P, L.nextp, L.part, L.bufA, L.bufB);  // chain.py:249
+            nextchisq = block_chisq<WPC, MT, WL, MULTI>(P, L.nextp, L.part, L.flag, L.bufA, L.bufB,
+                                             tile);                  // chain.py:249
+            MC3_STAMP(3);
             if (wave0) {
                 if (sjump) {                                         // chain.py:251-255
                     const double dc = xk - zk, dn = npk - zk;
@@ -483,9 +657,6 @@ __global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, cons
                     const double nnorm = lane_serial_sum(mine ? dn * dn : 0.0, nf);
                     mrfactor = mc3_det_pow_half(nnorm / cnorm, nf - 1);
                 }
-                const Draw2 du = draw2(P.seed, iter, (uint32_t)c,
-                                       (P.sampler == MC3HIP_SNOOKER) ? 2u : 1u);
-                const double u = (P.sampler == MC3HIP_SNOOKER) ? u01(du.q1) : u01(du.q0);
                 const double ratio = mc3_det_exp(0.5 * (cur - nextchisq)) * mrfactor;
                 if (ratio > u) {                                     // chain.py:257-274
                     flags |= 2;
@@ -511,7 +682,7 @@ __global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, cons
                 P.trace_flag[trow * P.nlocal + lc] = flags;
             }
         }
-        __syncthreads();
+        block_sync<WPC>();
     }
     // Z append, chain.py:276-289 (strided slot M0 + ID + k*nchains)
     if (wave0) {
@@ -523,25 +694,29 @@ __global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, cons
         if (lane == 0) {
             P.chisq[lc] = cur;
             P.best_chisq[lc] = best;
-            P.numaccept[lc] += nacc;
+            P.numaccept[lc] = nacc0 + nacc;
             P.log_post[row] = -0.5 * cur;
             P.zchain[row] = c;
         }
     }
+    MC3_STAMP(4);
 }
 
 // chisq for arbitrary parameter vectors (Chain.eval_model(ret='chisq'))
-template <int WPC, int MT>
+template <int WPC, int MT, bool WL>
 __global__ __launch_bounds__(64 * WPC) void eval_chisq_kernel(const DevProblem P,
                                                               const double *params,
                                                               double *out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const SmemLayout L = carve(smem, P, 64 * WPC);
+    DataTile<WPC, MT> tile;
+    if constexpr (!WL)
+        tile.load(P);
     for (int q = threadIdx.x; q < P.nparams; q += 64 * WPC)
         L.nextp[q] = params[(size_t)blockIdx.x * P.nparams + q];
     __syncthreads();
-    const double c = block_chisq<WPC, MT>(P, L.nextp, L.part, L.bufA, L.bufB);
+    const double c = block_chisq<WPC, MT, WL, true>(P, L.nextp, L.part, L.flag, L.bufA, L.bufB, tile);
     if (threadIdx.x == 0)
         out[blockIdx.x] = c;
 }

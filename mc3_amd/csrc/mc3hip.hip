@@ -119,6 +119,8 @@ struct mc3hip_ctx {
     bool populated = false;
     uint32_t flags = 0;
     std::vector<void *> allocs;
+    char *arena = nullptr;
+    size_t arena_used = 0;
     long long *ctl = nullptr;
     double *eval_params = nullptr, *eval_out = nullptr;
     int eval_cap = 0;
@@ -135,11 +137,32 @@ struct mc3hip_ctx {
 
 namespace {
 
+// Small arrays are carved out of one arena so that everything a step kernel
+// touches besides Z sits in a few adjacent pages (each separate hipMalloc is its
+// own page-table walk at the start of every launch).
+constexpr size_t ARENA_BYTES = 4u << 20, ARENA_MAX_ITEM = 256u << 10;
+
 template <typename T>
 int dev_alloc(mc3hip_ctx *c, T **ptr, size_t count)
 {
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    if (bytes <= ARENA_MAX_ITEM) {
+        if (!c->arena) {
+            void *a = nullptr;
+            HIP_TRY(hipMalloc(&a, ARENA_BYTES));
+            c->allocs.push_back(a);
+            c->arena = static_cast<char *>(a);
+            c->arena_used = 0;
+        }
+        const size_t off = (c->arena_used + 255) & ~size_t(255);
+        if (off + bytes <= ARENA_BYTES) {
+            *ptr = reinterpret_cast<T *>(c->arena + off);
+            c->arena_used = off + bytes;
+            return MC3HIP_OK;
+        }
+    }
     void *p = nullptr;
-    HIP_TRY(hipMalloc(&p, (count ? count : 1) * sizeof(T)));
+    HIP_TRY(hipMalloc(&p, bytes));
     c->allocs.push_back(p);
     *ptr = static_cast<T *>(p);
     return MC3HIP_OK;
@@ -161,15 +184,26 @@ int dev_upload(mc3hip_ctx *c, const T **dst, const T *src, size_t count)
 template <int WPC, int MT>
 void launch_step_t(mc3hip_ctx *c, int roff)
 {
-    hipLaunchKernelGGL((step_kernel<WPC, MT>), dim3(c->P.nlocal), dim3(64 * WPC), c->smem,
-                       c->stream, c->P, roff);
+    if (c->P.wlike)
+        hipLaunchKernelGGL((step_kernel<WPC, MT, true, false>), dim3(c->P.nlocal),
+                           dim3(64 * WPC), c->smem, c->stream, c->P, roff);
+    else if (c->P.ndata > VLANES)
+        hipLaunchKernelGGL((step_kernel<WPC, MT, false, true>), dim3(c->P.nlocal),
+                           dim3(64 * WPC), c->smem, c->stream, c->P, roff);
+    else
+        hipLaunchKernelGGL((step_kernel<WPC, MT, false, false>), dim3(c->P.nlocal),
+                           dim3(64 * WPC), c->smem, c->stream, c->P, roff);
 }
 
 template <int WPC, int MT>
 void launch_eval_t(mc3hip_ctx *c, int n)
 {
-    hipLaunchKernelGGL((eval_chisq_kernel<WPC, MT>), dim3(n), dim3(64 * WPC), c->smem,
-                       c->stream, c->P, (const double *)c->eval_params, c->eval_out);
+    if (c->P.wlike)
+        hipLaunchKernelGGL((eval_chisq_kernel<WPC, MT, true>), dim3(n), dim3(64 * WPC), c->smem,
+                           c->stream, c->P, (const double *)c->eval_params, c->eval_out);
+    else
+        hipLaunchKernelGGL((eval_chisq_kernel<WPC, MT, false>), dim3(n), dim3(64 * WPC), c->smem,
+                           c->stream, c->P, (const double *)c->eval_params, c->eval_out);
 }
 
 template <int MT>
@@ -216,10 +250,11 @@ int set_smem_attr(mc3hip_ctx *c)
     if (c->smem <= 64 * 1024)
         return MC3HIP_OK;
 #define SET_ATTR(WPC, MT)                                                                  \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&step_kernel<WPC, MT>),     \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&step_kernel<WPC, MT, true, false>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->smem)); \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&eval_chisq_kernel<WPC, MT>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->smem));
+    HIP_TRY(hipFuncSetAttribute(                                                            \
+        reinterpret_cast<const void *>(&eval_chisq_kernel<WPC, MT, true>),                  \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->smem));
 #define SET_ATTR_MT(WPC)                                                            \
     switch (c->mt) {                                                                \
     case MT_POLY2: SET_ATTR(WPC, MT_POLY2) break;                                   \
@@ -382,6 +417,17 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
     TRY(dev_upload(c, &P.prior, pr->prior, np));
     TRY(dev_upload(c, &P.priorlow, pr->priorlow, np));
     TRY(dev_upload(c, &P.priorup, pr->priorup, np));
+    {
+        std::vector<double> fmin(nf), fmax(nf), fstep(nf);
+        for (size_t k = 0; k < nf; ++k) {
+            fmin[k] = pr->pmin[ifree[k]];
+            fmax[k] = pr->pmax[ifree[k]];
+            fstep[k] = pr->pstep[ifree[k]];
+        }
+        TRY(dev_upload(c, &P.fmin, fmin.data(), nf));
+        TRY(dev_upload(c, &P.fmax, fmax.data(), nf));
+        TRY(dev_upload(c, &P.fstep, fstep.data(), nf));
+    }
     const size_t nindep = (pr->model_kind == MC3HIP_MODEL_LINEAR) ? nd * (size_t)pr->nmodel : nd;
     TRY(dev_upload(c, &P.indep, pr->indep, nindep));
     TRY(dev_upload(c, &P.data, pr->data, nd));
@@ -415,6 +461,8 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
     }
     TRY(dev_alloc(c, &c->ctl, 2));
     P.ctl = c->ctl;
+    TRY(dev_alloc(c, &P.stamps, 16));
+    HIP_TRY_C(hipMemset(P.stamps, 0, 16 * sizeof(unsigned long long)));
     HIP_TRY_C(hipMemset(c->ctl, 0, 2 * sizeof(long long)));
     HIP_TRY_C(hipMemset(P.Z, 0, zl * nf * sizeof(double)));
     HIP_TRY_C(hipMemset(P.log_post, 0, zl * sizeof(double)));
@@ -823,6 +871,17 @@ int mc3hip_comm_gather_log_post(mc3hip_ctx *c)
     }
     c->logpost_gathered = c->refresh_done;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return MC3HIP_OK;
+}
+
+/* diagnostic build only: the 16 phase stamps of the last launch (zeros otherwise) */
+int mc3hip_debug_stamps(mc3hip_ctx *c, uint64_t *out16)
+{
+    if (!c || !out16)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out16, c->P.stamps, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return MC3HIP_OK;
 }
 

@@ -68,5 +68,7 @@ __device__ __forceinline__ double u01_open(uint64_t q)
 // integer in [0,n) (np.random.randint, chain.py:197-203,223-227): high half of the
 // 128-bit product, bias < n/2^64
 __device__ __forceinline__ uint64_t bounded(uint64_t q, uint64_t n) { return __umul64hi(q, n); }
+// same from a 32-bit word (chain indices, n <= 2^20: bias < n/2^32)
+__device__ __forceinline__ uint32_t bounded32(uint32_t w, uint32_t n) { return __umulhi(w, n); }
 
 }  // namespace mc3hip

@@ -106,7 +106,7 @@ class LockstepRun:
             nmodel = npar - 3 if wlike else npar
         self.nmodel = int(nmodel)
         if vlanes is None:
-            vlanes = 1024 if wlike else 256
+            vlanes = 1024
         self.hsize = int(hsize)
         self.M0 = self.hsize*self.nchains if M0 is None else int(M0)
         self.nzchain = int(np.ceil(nsamples/self.nchains/self.thinning))

@@ -103,6 +103,10 @@ static uint64_t bounded(uint64_t q, uint64_t n)                                 
 {
     return (uint64_t)(((unsigned __int128)q * n) >> 64);
 }
+static uint32_t bounded32(uint32_t w, uint32_t n)                                 /* [0,n) */
+{
+    return (uint32_t)(((uint64_t)w * n) >> 32);
+}
 
 /* ---- model ---------------------------------------------------------------- */
 static inline double model_at(const ls_problem *P, const double *p, int i)
@@ -342,10 +346,10 @@ static void chain_step(const ls_problem *P, ls_state *St, ls_scratch *S,
     } else {                                              /* chain.py:221-232 */
         const int n = P->nchains;
         draw2(P->seed, (uint64_t)iter, (uint32_t)c, 0, &q0, &q1);
-        int r1 = 1 + (int)bounded(q0, (uint64_t)(n - 1));
+        int r1 = 1 + (int)bounded32((uint32_t)(q0 >> 32), (uint32_t)(n - 1));
         if (r1 == c)
             r1 = 0;
-        int r2 = (r1 + 2 + (int)bounded(q1, (uint64_t)(n - 2))) % n;
+        int r2 = (r1 + 2 + (int)bounded32((uint32_t)q0, (uint32_t)(n - 2))) % n;
         if (r2 == c)
             r2 = (r1 + 1) % n;
         const double *x1 = snap + (size_t)r1 * nf, *x2 = snap + (size_t)r2 * nf;
@@ -388,9 +392,10 @@ static void chain_step(const ls_problem *P, ls_state *St, ls_scratch *S,
             }
             mrfactor = mc3_det_pow_half(nnorm / cnorm, nf - 1);
         }
-        const int uslot = (P->sampler == LS_SNOOKER) ? 2 : 1;
+        /* Metropolis draw: second word of slot 2 (snooker) or of slot 0 */
+        const int uslot = (P->sampler == LS_SNOOKER) ? 2 : 0;
         draw2(P->seed, (uint64_t)iter, (uint32_t)c, (uint32_t)uslot, &q0, &q1);
-        const double u = (P->sampler == LS_SNOOKER) ? u01(q1) : u01(q0);
+        const double u = u01(q1);
         const double ratio = mc3_det_exp(0.5 * (St->chisq[c] - nextchisq)) * mrfactor;
         if (ratio > u) {                                  /* chain.py:257-274 */
             flag |= 2;
@@ -420,22 +425,24 @@ int ls_run(const ls_problem *P, ls_state *St, int64_t nrefresh, int nthreads)
     const int64_t R0 = St->refresh_done;
     if (P->M0 + (R0 + nrefresh) * P->nchains > P->zlen)
         return -1;
-    for (int64_t R = R0; R < R0 + nrefresh; R++) {
-        const double *snap = (R == 0) ? St->snap0
-                           : St->Z + (size_t)(P->M0 + (R - 1) * P->nchains) * nf;
-        const int64_t zsize = P->M0 + R * P->nchains;
-        const int64_t row0 = P->M0 + R * P->nchains;
+    /* one thread team for the whole call; chains of a refresh are independent,
+     * the implicit barrier of the omp-for separates refreshes */
 #ifdef _OPENMP
 #pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
 #endif
-        {
-            ls_scratch S;
-            S.part = malloc(sizeof(double) * (size_t)P->vlanes);
-            S.buf0 = malloc(sizeof(double) * (size_t)P->ndata);
-            S.buf1 = malloc(sizeof(double) * (size_t)P->ndata);
-            S.nextp = malloc(sizeof(double) * (size_t)P->nparams);
-            S.jump = malloc(sizeof(double) * (size_t)nf);
-            S.normal = malloc(sizeof(double) * (size_t)nf);
+    {
+        ls_scratch S;
+        S.part = malloc(sizeof(double) * (size_t)P->vlanes);
+        S.buf0 = malloc(sizeof(double) * (size_t)P->ndata);
+        S.buf1 = malloc(sizeof(double) * (size_t)P->ndata);
+        S.nextp = malloc(sizeof(double) * (size_t)P->nparams);
+        S.jump = malloc(sizeof(double) * (size_t)nf);
+        S.normal = malloc(sizeof(double) * (size_t)nf);
+        for (int64_t R = R0; R < R0 + nrefresh; R++) {
+            const double *snap = (R == 0) ? St->snap0
+                               : St->Z + (size_t)(P->M0 + (R - 1) * P->nchains) * nf;
+            const int64_t zsize = P->M0 + R * P->nchains;
+            const int64_t row0 = P->M0 + R * P->nchains;
 #ifdef _OPENMP
 #pragma omp for schedule(static)
 #endif
@@ -454,9 +461,9 @@ int ls_run(const ls_problem *P, ls_state *St, int64_t nrefresh, int nthreads)
                 St->log_post[row] = -0.5 * St->chisq[c];
                 St->zchain[row] = c;
             }
-            free(S.part); free(S.buf0); free(S.buf1);
-            free(S.nextp); free(S.jump); free(S.normal);
         }
+        free(S.part); free(S.buf0); free(S.buf1);
+        free(S.nextp); free(S.jump); free(S.normal);
     }
     St->refresh_done = R0 + nrefresh;
     return 0;
