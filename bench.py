@@ -102,9 +102,12 @@ def cpu_baseline(target_seconds=12.0):
             best_threads, best_rate = nt, r
         elif r < 0.5*best_rate:
             break
-    n = int(max(200, min(300000, target_seconds*best_rate)))
+    chunk = int(max(100, best_rate))            # about one second of work
+    n = 0
     t0 = time.perf_counter()
-    orc.run(nrefresh=n, nthreads=best_threads)
+    while time.perf_counter() - t0 < target_seconds and n + chunk <= 390000:
+        orc.run(nrefresh=chunk, nthreads=best_threads)
+        n += chunk
     dt = time.perf_counter() - t0
     return {
         'value': CHAINS_PER_GPU*n/dt/1e6, 'unit': 'million chain-steps/sec',
