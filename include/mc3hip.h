@@ -125,6 +125,11 @@ int mc3hip_last_run_ms(mc3hip_ctx *ctx, float *ms);
  * rows [row0, row0+nrows) of Z / log_post / zchain.  Any pointer may be NULL. */
 int mc3hip_get_rows(mc3hip_ctx *ctx, int64_t row0, int64_t nrows, double *Z,
                     double *log_post, int32_t *zchain);
+/* Overwrite rows of Z / log_post that ANOTHER rank owns (host-staged exchange for
+ * callers that cannot use the RCCL path below; same visibility rule: rows of
+ * refresh R must be in place before refresh R+1 runs). */
+int mc3hip_put_rows(mc3hip_ctx *ctx, int64_t row0, int64_t nrows, const double *Z,
+                    const double *log_post);
 /* Current chain states and counters (freepars, chisq, numaccept, outbounds and
  * the best-fit tracking of chain.py:261-274), indexed by LOCAL chain.  best_iter
  * is the iteration at which a chain found its best state (-1: never accepted).

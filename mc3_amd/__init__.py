@@ -7,6 +7,9 @@ src_c/_dwt.c), behind mc3's own ``sample()`` / ``mcmc()`` API.  Host code is
 plain Python + NumPy over a ctypes C-ABI (include/mc3hip.h); all numerics run
 in hand-written HIP kernels (mc3_amd/csrc).  There is no CPU fallback.
 """
-from .engine import DeviceChains, dwt_daub4, comm_unique_id  # noqa: F401
-
 __version__ = '0.1.0'
+
+from .engine import DeviceChains, dwt_daub4, comm_unique_id  # noqa: E402,F401
+from .sampler_driver import sample  # noqa: E402,F401
+from .mcmc_driver import mcmc  # noqa: E402,F401
+from . import models, stats, utils, parallel  # noqa: E402,F401

@@ -673,6 +673,26 @@ int mc3hip_get_rows(mc3hip_ctx *c, int64_t row0, int64_t nrows, double *Z, doubl
     return MC3HIP_OK;
 }
 
+int mc3hip_put_rows(mc3hip_ctx *c, int64_t row0, int64_t nrows, const double *Z,
+                    const double *log_post)
+{
+    if (!c)
+        return fail(MC3HIP_ERR_ARG, "null context");
+    if (row0 < c->P.M0 || nrows < 0 || row0 + nrows > c->zlen)
+        return fail(MC3HIP_ERR_ARG, "rows [%lld,%lld) outside the chain rows of Z",
+                    (long long)row0, (long long)(row0 + nrows));
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t nf = (size_t)c->P.nfree;
+    if (Z)
+        HIP_TRY(hipMemcpy(c->P.Z + (size_t)row0 * nf, Z, (size_t)nrows * nf * sizeof(double),
+                          hipMemcpyHostToDevice));
+    if (log_post)
+        HIP_TRY(hipMemcpy(c->P.log_post + row0, log_post, (size_t)nrows * sizeof(double),
+                          hipMemcpyHostToDevice));
+    return MC3HIP_OK;
+}
+
 int mc3hip_get_state(mc3hip_ctx *c, double *X, double *chisq, int64_t *numaccept,
                      int64_t *outbounds, double *best_chisq, int64_t *best_iter, double *bestx,
                      int64_t *refresh_done)

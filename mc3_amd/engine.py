@@ -165,6 +165,12 @@ class DeviceChains:
                                        dptr(lp), iptr(zc)))
         return Z, lp, zc
 
+    def put_rows(self, row0, Z, log_post=None):
+        """Install rows another rank produced (host-staged exchange)."""
+        Z = f64(Z)
+        lp = None if log_post is None else f64(log_post)
+        check(self.lib.mc3hip_put_rows(self._ctx, int(row0), len(Z), dptr(Z), dptr(lp)))
+
     def state(self):
         nl, nf = self.nlocal, self.nfree
         out = {

@@ -1,0 +1,119 @@
+"""Sharding the walker ensemble over ranks (one process per GPU).
+
+Chains are independent within an iteration; the only coupling is that proposals
+read other chains' states -- for DEMC the population of the previous Z refresh,
+for snooker the shared history Z (mc3/chain.py:204-217,230-232).  Rank r owns
+the contiguous block of chains [r*n, (r+1)*n) and a full replica of Z; after
+every refresh the new rows are exchanged so the next proposals see the whole
+population:
+
+* ``native`` (GPU): ONE in-place ``ncclAllGather`` (RCCL over xGMI) issued by
+  libmc3hip on its own stream -- mc3hip_comm_init / mc3hip_run.
+* host-staged (any engine, used by the CPU tests with gloo and as a fallback):
+  rows are read back, all-gathered through ``torch.distributed`` and installed
+  with ``put_rows``.
+
+The random numbers are keyed by GLOBAL chain id, so a sharded run reproduces
+the single-rank run bit for bit.  The reference has no counterpart: its workers
+share memory inside one host (mc3/mcmc_driver.py:143-221).
+"""
+import numpy as np
+
+
+class SingleRank:
+    rank = 0
+    size = 1
+    native = False
+
+    def partition(self, nchains):
+        return 0, nchains
+
+    def broadcast(self, obj):
+        return obj
+
+    def setup(self, engine):
+        pass
+
+    def exchange(self, engine, refresh):
+        pass
+
+    def finish(self, engine):
+        pass
+
+    def reduce_state(self, state):
+        return state
+
+
+class TorchDistComm:
+    """Communicator over an initialised ``torch.distributed`` process group."""
+
+    def __init__(self, use_rccl=True, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+        self.use_rccl = use_rccl
+        self.native = False
+
+    def partition(self, nchains):
+        if nchains % self.size:
+            raise ValueError(f'nchains ({nchains}) must be a multiple of the '
+                             f'number of ranks ({self.size})')
+        n = nchains//self.size
+        return self.rank*n, n
+
+    def broadcast(self, obj):
+        box = [obj if self.rank == 0 else None]
+        self.dist.broadcast_object_list(box, src=0, group=self.group)
+        return box[0]
+
+    def setup(self, engine):
+        """RCCL inside the library when the engine offers it, else host-staged."""
+        if self.size == 1:
+            return
+        if self.use_rccl and hasattr(engine, 'comm_init'):
+            from . import engine as eng
+            uid = self.broadcast(eng.comm_unique_id() if self.rank == 0 else None)
+            engine.comm_init(uid, self.rank, self.size)
+            self.native = True
+
+    def exchange(self, engine, refresh):
+        """Make the rows of ``refresh`` complete on every rank."""
+        if self.size == 1 or self.native:
+            return
+        import torch
+        n = engine.nlocal
+        row0 = engine.M0 + refresh*engine.nchains
+        Z, lp, _ = engine.rows(row0 + engine.chain0, n)
+        mine = torch.from_numpy(np.concatenate([Z, lp[:, None]], axis=1).copy())
+        parts = [torch.empty_like(mine) for _ in range(self.size)]
+        self.dist.all_gather(parts, mine, group=self.group)
+        for r, part in enumerate(parts):
+            if r == self.rank:
+                continue
+            a = part.numpy()
+            engine.put_rows(row0 + r*n, a[:, :-1], a[:, -1])
+
+    def finish(self, engine):
+        """Complete what the per-refresh exchange leaves out (log_post rows on
+        the native path)."""
+        if self.size > 1 and self.native:
+            engine.comm_gather_log_post()
+
+    def reduce_state(self, state):
+        """Gather per-chain state from every rank (chain order) and sum the
+        per-parameter out-of-bounds counters."""
+        if self.size == 1:
+            return state
+        box = [None]*self.size
+        self.dist.all_gather_object(box, state, group=self.group)
+        out = {}
+        for key in state:
+            if key == 'outbounds':
+                out[key] = np.sum([b[key] for b in box], axis=0)
+            elif key == 'refresh_done':
+                out[key] = state[key]
+            else:
+                out[key] = np.concatenate([b[key] for b in box], axis=0)
+        return out

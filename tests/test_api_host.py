@@ -1,0 +1,245 @@
+"""Host side of the drop-in boundary on CPU: mc3_amd.sample()/mcmc() keep the
+reference's signature, argument checks, error messages and output dictionary
+(mc3/sampler_driver.py:25-601, mc3/mcmc_driver.py:18-378).  The chains are run
+by the lockstep oracle injected through ``engine_factory`` (the GPU tests run
+the same calls on the device and demand identical dictionaries)."""
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+
+import mc3_amd
+from mc3_amd import models, parallel
+from mc3_amd import utils as mu
+from oracle_engine import OracleChains
+import helpers as H
+
+
+def quad(p, x):
+    return p[0] + p[1]*x + p[2]*x**2.0
+
+
+x, data, uncert = H.tutorial_data(100)
+params = np.array([10.0, -2.0, 0.1])
+pstep = np.array([1.0, 0.5, 0.1])
+pmin = np.array([-10.0, -20.0, -10.0])
+pmax = np.array([40.0, 20.0, 10.0])
+quiet = dict(engine_factory=OracleChains, seed=7)
+
+
+def run(**kw):
+    base = dict(data=data, uncert=uncert, func=quad, params=np.copy(params),
+                indparams=[x], pstep=pstep, pmin=pmin, pmax=pmax,
+                sampler='snooker', nsamples=2100, burnin=20, nchains=7,
+                log=mu.Log(verb=0), **quiet)
+    base.update(kw)
+    np.random.seed(11)
+    return mc3_amd.sample(**base)
+
+
+def test_signature_matches_reference():
+    """Names, order and defaults of mc3.sample (sampler_driver.py:25-38) and the
+    32 positional arguments of mcmc (mcmc_driver.py:18-26)."""
+    want = [
+        ('data', None), ('uncert', None), ('func', None), ('params', None),
+        ('indparams', []), ('indparams_dict', {}), ('pmin', None), ('pmax', None),
+        ('pstep', None), ('prior', None), ('priorlow', None), ('priorup', None),
+        ('sampler', None), ('ncpu', None), ('leastsq', None), ('chisqscale', False),
+        ('nchains', 7), ('nsamples', None), ('burnin', 0), ('thinning', 1),
+        ('grtest', True), ('grbreak', 0.0), ('grnmin', 0.5), ('wlike', False),
+        ('fgamma', 1.0), ('fepsilon', 0.0), ('hsize', 10), ('kickoff', 'normal'),
+        ('plots', False), ('theme', 'blue'), ('statistics', 'med_central'),
+        ('ioff', False), ('showbp', True), ('savefile', None), ('resume', False),
+        ('rms', False), ('log', None), ('pnames', None), ('texnames', None),
+    ]
+    sig = inspect.signature(mc3_amd.sample)
+    got = [(n, p.default) for n, p in sig.parameters.items() if n != 'kwargs']
+    assert got == want
+    names = list(inspect.signature(mc3_amd.mcmc).parameters)
+    assert names[:32] == [
+        'data', 'uncert', 'func', 'params', 'indparams', 'indparams_dict',
+        'pmin', 'pmax', 'pstep', 'prior', 'priorlow', 'priorup', 'nchains',
+        'ncpu', 'nsamples', 'sampler', 'wlike', 'fit_output', 'grtest',
+        'grbreak', 'grnmin', 'burnin', 'thinning', 'fgamma', 'fepsilon', 'hsize',
+        'kickoff', 'savefile', 'resume', 'log', 'pnames', 'texnames']
+
+
+def test_output_dictionary_matches_reference_layout(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'seq_quad_snooker.npz'))
+    out = run()
+    ref_keys = {k[4:] for k in g.files if k.startswith('out_')}
+    assert ref_keys - set(out) == set()
+    assert set(out) - ref_keys == {'pnames', 'texnames'}
+    for key in sorted(ref_keys):
+        got, want = np.asarray(out[key]), g['out_' + key]
+        assert got.shape == want.shape, key
+        assert got.dtype.kind == want.dtype.kind, key
+    # the initial population is drawn from the same NumPy stream as the
+    # reference's (mcmc_driver.py:229-262): with equal seeds its best row is the
+    # same row, so before any chain step the two runs share their starting point
+    assert out['posterior'].shape == (2100, 3)
+    assert np.all(out['zchain'] == np.tile(np.arange(7), 300))
+    assert out['acceptance_rate'] > 5.0
+    np.testing.assert_allclose(out['chisq'], -2*out['log_post'], rtol=1e-14)
+    assert out['best_chisq'] == pytest.approx(-2*out['best_log_post'])
+    assert out['best_chisq'] <= out['chisq'].min()*(1 + 1e-12)
+    # same posterior as the reference within Monte-Carlo error
+    ref_post = g['out_posterior'][g['out_zmask']]
+    post = out['posterior'][out['zmask']]
+    sd = ref_post.std(axis=0)
+    assert np.all(np.abs(post.mean(axis=0) - ref_post.mean(axis=0)) < 0.5*sd)
+    np.testing.assert_allclose(out['best_chisq'], g['out_best_chisq'], rtol=0.02)
+    np.testing.assert_allclose(out['BIC'] - out['best_chisq'], 3*np.log(100))
+
+
+def test_initial_population_equals_reference(golden_dir):
+    """Z[0:M0] of a reference run and of mc3_amd with the same NumPy seed."""
+    g = np.load(os.path.join(golden_dir, 'seq_quad_demc.npz'))
+    from oracle import chain_sequential as cseq
+    seq = cseq.SequentialRun(
+        data=g['data'], uncert=g['uncert'], func=quad, params=g['params'],
+        indparams=[g['x']], pmin=g['pmin'], pmax=g['pmax'], pstep=g['pstep'],
+        nchains=8, nsamples=2400, sampler='demc')
+    seq.init_population(np.random.RandomState(int(g['hub_seed'])))
+    captured = {}
+
+    class Spy(OracleChains):
+        def set_population(self, Z0, lp0, X0=None, chisq0=None):
+            captured['Z0'], captured['lp0'] = Z0.copy(), lp0.copy()
+            super().set_population(Z0, lp0, X0, chisq0)
+
+    np.random.seed(int(g['hub_seed']))
+    mc3_amd.sample(data=g['data'], uncert=g['uncert'], func=quad,
+                   params=g['params'], indparams=[g['x']], pstep=g['pstep'],
+                   pmin=g['pmin'], pmax=g['pmax'], sampler='demc', nsamples=2400,
+                   burnin=20, nchains=8, log=mu.Log(verb=0), engine_factory=Spy,
+                   seed=1)
+    np.testing.assert_array_equal(captured['Z0'], seq.Z[:seq.M0])
+    np.testing.assert_allclose(captured['lp0'], seq.log_post[:seq.M0], rtol=1e-12)
+
+
+def test_shared_and_fixed_parameters():
+    """reference tests/test_mcmc.py:85-109: shared parameters equal their
+    source, fixed ones keep their value, in every statistic."""
+    def quad4(p, x):
+        return p[0] + p[1]*x + p[2]*x**2.0 + 0.0*p[3]
+    out = run(func=quad4, params=np.array([10.0, -2.0, 0.1, -2.0]),
+              pstep=np.array([1.0, 0.5, 0.0, -2]),
+              pmin=np.array([-10.0, -20, -10, -20]), pmax=np.array([40.0, 20, 10, 20]),
+              sampler='demc', nchains=8, nsamples=2400)
+    assert out['posterior'].shape[1] == 2
+    for key in ('bestp', 'meanp', 'medianp', 'median_low_bounds', 'mode'):
+        assert out[key][3] == out[key][1]
+    assert out['bestp'][2] == 0.1 and out['stdp'][2] == 0.0
+    assert out['CRlo'][2] == 0.0 and out['CRhi'][2] == 0.0
+
+
+def test_model_recognition():
+    low = models.lower(quad, params, [x], {}, 100, False, pstep)
+    assert (low.family, low.ncoef, low.offset) == ('poly', 3, None)
+    A = np.array([np.ones(100), np.sin(x), x**2])
+    low = models.lower(lambda p, A: 1.5 + p @ A, params, [A], {}, 100, False, pstep)
+    assert low.family == 'linear' and np.allclose(low.offset, 1.5)
+    np.testing.assert_allclose(low.indep, A, rtol=1e-12, atol=1e-12)
+    with pytest.raises(ValueError, match='not linear in its parameters'):
+        models.lower(lambda p, x: p[0]*np.exp(p[1]*x), params[:2], [x], {}, 100,
+                     False, pstep[:2])
+    out = run(func=models.Polynomial(3))
+    ref = run()
+    np.testing.assert_array_equal(out['posterior'], ref['posterior'])
+    # an affine callable with an offset samples the same posterior as the
+    # equivalent shifted data set
+    out_off = run(func=lambda p, x: 2.0 + quad(p, x), data=data + 2.0)
+    np.testing.assert_allclose(out_off['posterior'], ref['posterior'], rtol=1e-9)
+
+
+def test_wavelet_likelihood_through_sample():
+    prob = H.wavelet_problem()
+    out = mc3_amd.sample(
+        data=prob['data'], uncert=prob['uncert'], func=quad, params=prob['params'],
+        indparams=[prob['indep']], pstep=prob['pstep'], pmin=prob['pmin'],
+        pmax=prob['pmax'], sampler='snooker', nsamples=1400, burnin=10, nchains=7,
+        wlike=True, log=mu.Log(verb=0), **quiet)
+    assert out['posterior'].shape == (1400, 5)
+    assert out['bestp'][3] == 1.0                   # gamma is fixed
+    from oracle import kernels as ok
+    best = ok.dwt_chisq(quad(out['bestp'][:3], prob['indep']), prob['data'],
+                        out['bestp'])
+    np.testing.assert_allclose(-2*out['best_log_post'], best, rtol=1e-10)
+
+
+def test_savefile_resume_and_grbreak(tmp_path):
+    sf = str(tmp_path / 'run.npz')
+    first = run(savefile=sf, sampler='demc', nchains=8, nsamples=1600, grtest=True)
+    saved = np.load(sf)
+    np.testing.assert_array_equal(saved['posterior'], first['posterior'])
+    assert float(saved['chisq_factor']) == 1.0
+    more = run(savefile=sf, resume=True, sampler='demc', nchains=8, nsamples=800,
+               seed=8)
+    assert more['posterior'].shape == (1600 + 800, 3)
+    np.testing.assert_array_equal(more['posterior'][:1600], first['posterior'])
+    assert np.all(more['zchain'][1600:] == np.tile(np.arange(8), 100))
+    # the resumed chains continue from their last states (chain.py:166-169)
+    last = first['posterior'][-8:]
+    moved = more['posterior'][1600:1608]
+    assert np.sum(np.all(moved == last, axis=1)) >= 2      # rejected steps repeat
+    stopped = run(sampler='demc', nchains=8, nsamples=80000, grbreak=1.05,
+                  grnmin=800, burnin=100)
+    assert len(stopped['posterior']) < 80000
+
+
+# ---- the reference's error-path tests (tests/test_mcmc.py:328-409) ----------
+def test_error_messages():
+    base = dict(data=data, uncert=uncert, func=quad, params=np.copy(params),
+                sampler='snooker', indparams=[x], pstep=pstep, nsamples=1e4,
+                burnin=100, log=mu.Log(verb=0), **quiet)
+
+    def without(key, **extra):
+        kw = dict(base)
+        kw.pop(key, None)
+        kw.update(extra)
+        return kw
+    with pytest.raises(ValueError, match="'data' is a required argument"):
+        mc3_amd.sample(**without('data'))
+    with pytest.raises(ValueError, match="'uncert' is a required argument"):
+        mc3_amd.sample(**without('uncert'))
+    with pytest.raises(ValueError, match="'func' must be either a callable or an iterable"):
+        mc3_amd.sample(**without('func'))
+    with pytest.raises(ValueError, match="'params' is a required argument"):
+        mc3_amd.sample(**without('params'))
+    with pytest.raises(ValueError, match="'sampler' is a required argument"):
+        mc3_amd.sample(**without('sampler'))
+    with pytest.raises(ValueError, match="'nsamples' is a required argument for MCMC runs"):
+        mc3_amd.sample(**without('nsamples'))
+    msg = re.escape('The number of burned-in samples (2000) is greater than the '
+                    'number of iterations per chain (1429)')
+    with pytest.raises(ValueError, match=msg):
+        mc3_amd.sample(**without('burnin', burnin=2000))
+    msg = re.escape("Invalid 'leastsq' input (invalid). Must select from ['lm', 'trf']")
+    with pytest.raises(ValueError, match=msg):
+        mc3_amd.sample(**without('leastsq', leastsq='invalid'))
+    with pytest.raises(ValueError, match='Some initial-guess values are out of bounds'):
+        mc3_amd.sample(**without('pmax', pmax=np.array([5.0, 20.0, 10.0])))
+    with pytest.raises(ValueError, match=r'size of the data array \(100\) does not '
+                                         r'match the size of the func\(\) output \(50\)'):
+        mc3_amd.sample(**without('indparams', indparams=[x[:50]]))
+    # bounds that leave no room for the initial population
+    with pytest.raises(ValueError, match='Cannot populate an initial sample set'):
+        mc3_amd.sample(**without('pmax', pmin=np.array([9.9999999, -20, -10.0]),
+                                 pmax=np.array([10.0000001, 20.0, 10.0])))
+    # no CPU fallback: without an engine override the GPU library is required
+    assert mc3_amd.mcmc.__defaults__[-1] is None
+
+
+def test_burn_matches_reference_docstring_example():
+    Z = np.expand_dims([0., 1, 10, 20, 30, 11, 31, 21, 12, 22, 32], axis=1)
+    zchain = np.array([-1, -1, 0, 1, 2, 0, 2, 1, 0, 1, 2])
+    post, zc, zmask = mu.burn({'posterior': Z, 'zchain': zchain, 'burnin': 1})
+    assert list(post[:, 0]) == [11, 12, 21, 22, 31, 32]
+    assert list(zmask) == [5, 8, 7, 9, 6, 10]
+    post, zc, zmask = mu.burn({'posterior': Z, 'zchain': zchain, 'burnin': 1}, sort=False)
+    assert list(post[:, 0]) == [11, 31, 21, 12, 22, 32]
+    post, _, _ = mu.burn({'posterior': Z, 'zchain': zchain, 'burnin': 1}, burnin=0)
+    assert list(post[:, 0]) == [10, 11, 12, 20, 21, 22, 30, 31, 32]

@@ -1,0 +1,51 @@
+"""The N>1 path on CPU: two ranks (gloo) each own half of the chains, exchange
+the new Z rows after every refresh, and must reproduce the single-rank run bit
+for bit (the draws are keyed by global chain id)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import mc3_amd
+from mc3_amd import utils as mu
+from oracle_engine import OracleChains
+import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize('sampler,thinning', [('demc', 1), ('snooker', 2)])
+def test_two_ranks_reproduce_single_rank(tmp_path, sampler, thinning):
+    out_path = str(tmp_path / 'shard')
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()),
+           os.path.join(ROOT, 'tests', 'dist_worker.py'), out_path, sampler,
+           str(thinning)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+
+    x, data, uncert = H.tutorial_data(100)
+    np.random.seed(100)
+    single = mc3_amd.sample(
+        data=data, uncert=uncert, func=H.quad, params=np.array([10.0, -2.0, 0.1]),
+        indparams=[x], pstep=np.array([1.0, 0.5, 0.1]),
+        pmin=np.array([-10.0, -20.0, -10.0]), pmax=np.array([40.0, 20.0, 10.0]),
+        sampler=sampler, nsamples=8*120*thinning, burnin=10, nchains=8,
+        thinning=thinning, grtest=False, log=mu.Log(verb=0),
+        engine_factory=OracleChains, seed=99)
+    for rank in (0, 1):
+        got = np.load(f'{out_path}.rank{rank}.npz')
+        for key in ('posterior', 'zchain', 'log_post', 'chisq', 'bestp',
+                    'acceptance_rate', 'best_log_post', 'medianp', 'stdp'):
+            np.testing.assert_array_equal(got[key], single[key], err_msg=key)

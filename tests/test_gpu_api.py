@@ -1,0 +1,133 @@
+"""mc3_amd.sample() on the GPU: identical output dictionary to the same call
+with the CPU checker injected, and the reference's posterior (golden run of
+mc3 v3.2.1) within Monte-Carlo error."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def quad(p, x):
+    return p[0] + p[1]*x + p[2]*x**2.0
+
+
+def both(**kw):
+    import mc3_amd
+    from mc3_amd import utils as mu
+    from oracle_engine import OracleChains
+    outs = []
+    for factory in (None, OracleChains):
+        np.random.seed(3)
+        extra = {} if factory is None else {'engine_factory': factory}
+        outs.append(mc3_amd.sample(log=mu.Log(verb=0), seed=21, **kw, **extra))
+    return outs
+
+
+def assert_same_dict(gpu, cpu):
+    assert set(gpu) == set(cpu)
+    for key in gpu:
+        if key in ('pnames', 'texnames'):
+            continue
+        np.testing.assert_array_equal(np.asarray(gpu[key]), np.asarray(cpu[key]),
+                                      err_msg=key)
+
+
+@pytest.mark.parametrize('sampler', ['snooker', 'demc', 'mrw'])
+def test_sample_gpu_equals_cpu_checker(sampler, golden_dir):
+    x, data, uncert = H.tutorial_data(100)
+    gpu, cpu = both(data=data, uncert=uncert, func=quad,
+                    params=np.array([10.0, -2.0, 0.1]), indparams=[x],
+                    pstep=np.array([1.0, 0.5, 0.1]),
+                    pmin=np.array([-10.0, -20.0, -10.0]),
+                    pmax=np.array([40.0, 20.0, 10.0]),
+                    sampler=sampler, nsamples=2100, burnin=20, nchains=7)
+    assert_same_dict(gpu, cpu)
+    if sampler == 'snooker':
+        g = np.load(os.path.join(golden_dir, 'seq_quad_snooker.npz'))
+        ref = g['out_posterior'][g['out_zmask']]
+        post = gpu['posterior'][gpu['zmask']]
+        assert np.all(np.abs(post.mean(0) - ref.mean(0)) < 0.5*ref.std(0))
+        np.testing.assert_allclose(gpu['best_chisq'], g['out_best_chisq'], rtol=0.02)
+
+
+def test_sample_gpu_shared_priors_wavelet_linear():
+    import mc3_amd
+    prob = H.shared_problem()
+    poly5 = mc3_amd.models.Polynomial(5)
+    gpu, cpu = both(data=prob['data'], uncert=prob['uncert'], func=poly5,
+                    params=prob['params'], indparams=[prob['indep']],
+                    pstep=prob['pstep'], pmin=prob['pmin'], pmax=prob['pmax'],
+                    prior=prob['prior'], priorlow=prob['priorlow'],
+                    priorup=prob['priorup'], sampler='snooker', nsamples=1600,
+                    burnin=10, nchains=8, kickoff='uniform')
+    assert_same_dict(gpu, cpu)
+    prob = H.wavelet_problem()
+    gpu, cpu = both(data=prob['data'], uncert=prob['uncert'], func=quad,
+                    params=prob['params'], indparams=[prob['indep']],
+                    pstep=prob['pstep'], pmin=prob['pmin'], pmax=prob['pmax'],
+                    sampler='snooker', nsamples=1400, burnin=10, nchains=7, wlike=True)
+    assert_same_dict(gpu, cpu)
+    prob = H.linear_problem(nsamples=1600)
+    gpu, cpu = both(data=prob['data'], uncert=prob['uncert'],
+                    func=lambda p, A: p @ A, params=prob['params'],
+                    indparams=[prob['indep']], pstep=prob['pstep'],
+                    pmin=prob['pmin'], pmax=prob['pmax'], prior=prob['prior'],
+                    priorlow=prob['priorlow'], priorup=prob['priorup'],
+                    sampler='demc', nsamples=1600, burnin=10, nchains=16)
+    assert_same_dict(gpu, cpu)
+
+
+def test_rccl_path_single_rank():
+    """The RCCL entry points load and run (one rank: the all-gather is a copy);
+    the multi-rank data flow is covered on CPU by test_distributed_gloo.py."""
+    from mc3_amd import engine
+    prob = H.quad_problem(nchains=8, nsamples=8*50, sampler='snooker')
+    orc = H.make_oracle(prob)
+    Z0, lp0 = H.initial_population(orc)
+    orc.set_population(Z0, lp0)
+    orc.run()
+    with engine.DeviceChains(**prob) as gpu:
+        gpu.set_population(Z0, lp0)
+        uid = engine.comm_unique_id()
+        assert len(uid) == 128
+        gpu.comm_init(uid, 0, 1)
+        gpu.run()
+        gpu.comm_gather_log_post()
+        Z, lp, zc = gpu.rows()
+    np.testing.assert_array_equal(Z, orc.Z)
+    np.testing.assert_array_equal(lp, orc.log_post)
+
+
+def test_put_rows_host_staged_exchange():
+    """Two contexts on one GPU, each owning half of the chains, exchanging rows
+    through the host after every refresh == the unsharded run."""
+    from mc3_amd import engine
+    prob = H.quad_problem(nchains=8, nsamples=8*40, sampler='demc')
+    orc = H.make_oracle(prob)
+    Z0, lp0 = H.initial_population(orc)
+    orc.set_population(Z0, lp0)
+    orc.run()
+    a = engine.DeviceChains(chain0=0, nlocal=4, **prob)
+    b = engine.DeviceChains(chain0=4, nlocal=4, **prob)
+    for g in (a, b):
+        g.set_population(Z0, lp0)
+    for R in range(orc.nzchain):
+        a.run(1)
+        b.run(1)
+        r0 = orc.M0 + R*8
+        Za, la, _ = a.rows(r0, 4)
+        Zb, lb, _ = b.rows(r0 + 4, 4)
+        a.put_rows(r0 + 4, Zb, lb)
+        b.put_rows(r0, Za, la)
+    for g in (a, b):
+        Z, lp, zc = g.rows()
+        np.testing.assert_array_equal(Z, orc.Z)
+        np.testing.assert_array_equal(lp, orc.log_post)
+    acc = np.concatenate([a.state()['numaccept'], b.state()['numaccept']])
+    np.testing.assert_array_equal(acc, orc.numaccept)
+    a.close()
+    b.close()
