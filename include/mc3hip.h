@@ -45,7 +45,8 @@ extern "C" {
 #define MC3HIP_MODEL_POLY    0   /* model_i = sum_k p[k] * x_i^k, k < nmodel      */
 #define MC3HIP_MODEL_LINEAR  1   /* model_i = sum_k A[k][i] * p[k], k < nmodel    */
 
-#define MC3HIP_FLAG_NO_GRAPH  1u /* launch eagerly instead of through a hipGraph  */
+#define MC3HIP_FLAG_NO_GRAPH    1u /* launch eagerly instead of through a hipGraph  */
+#define MC3HIP_FLAG_NO_PERSIST  2u /* never use the persistent kernel               */
 
 #define MC3HIP_MAX_FREE     64
 #define MC3HIP_MAX_PARAMS  128
@@ -94,6 +95,9 @@ typedef struct mc3hip_plan {
     int32_t tile;           /* points per tile, 0 = one tile                  */
     int32_t waves_per_chain;
     int32_t graph_nodes;    /* refreshes per hipGraph replay, 0 = eager       */
+    int32_t persistent;     /* >0: refreshes per launch of the persistent kernel
+                               (in-launch hand-off of Z rows), 0 = one launch per refresh */
+    int32_t reserved;
 } mc3hip_plan;
 
 /* Replaces Chain.__init__ + the shared-memory allocation of mcmc()

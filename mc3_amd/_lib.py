@@ -21,6 +21,7 @@ ERR_ARG, ERR_HIP, ERR_STATE, ERR_FULL, ERR_COMM = -1, -2, -3, -4, -5
 MRW, DEMC, SNOOKER = 0, 1, 2
 MODEL_POLY, MODEL_LINEAR = 0, 1
 FLAG_NO_GRAPH = 1
+FLAG_NO_PERSIST = 2
 MAX_FREE, MAX_PARAMS = 64, 128
 
 SAMPLERS = {'mrw': MRW, 'demc': DEMC, 'snooker': SNOOKER}
@@ -49,7 +50,8 @@ class Plan(ctypes.Structure):
     """mc3hip_plan"""
     _fields_ = [('vlanes', ctypes.c_int32), ('tile', ctypes.c_int32),
                 ('waves_per_chain', ctypes.c_int32),
-                ('graph_nodes', ctypes.c_int32)]
+                ('graph_nodes', ctypes.c_int32),
+                ('persistent', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 class Mc3HipError(RuntimeError):

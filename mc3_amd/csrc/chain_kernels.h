@@ -515,8 +515,62 @@ static inline size_t smem_bytes(int nthreads, int ndata, int wlike)
 }
 
 // ---- the chain update -------------------------------------------------------
-template <int WPC, int MT, bool WL, bool MULTI>
-__global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, const int roff)
+// A Z row read through the in-launch hand-off (persistent kernel): rows are
+// published with agent-scope 8-byte stores and consumed with agent-scope loads
+// (sc1: they bypass the CU's L1, which another CU's stores never refresh); a row
+// that is not there yet still holds the all-ones NaN pattern the Z buffer is
+// filled with at creation, so every double is its own "ready" flag -- no separate
+// flag, fence or ordering is needed (8-byte stores are single-copy atomic).
+// A chain state can never legitimately be NaN: a NaN proposal has a NaN or
+// out-of-bounds chisq and is rejected (chain.py:257-260).
+constexpr unsigned long long ROW_PENDING = 0xffffffffffffffffull;
+constexpr int CTL_ABORT = 2;                   // ctl[2] != 0: a wait timed out
+
+__device__ __forceinline__ double load_published(const double *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Wave-level wait until every participating lane's value has been published.
+// Bounded: gives up (and tells everybody) after ~1 s so a lost workgroup can
+// never hang the device.
+template <int NVAL>
+__device__ __forceinline__ bool wait_rows(const double *const (&addr)[NVAL], double (&val)[NVAL],
+                                          bool active, long long *ctl)
+{
+    for (unsigned spins = 0;; ++spins) {
+        bool ready = true;
+        if (active) {
+#pragma unroll
+            for (int q = 0; q < NVAL; ++q) {
+                val[q] = load_published(addr[q]);
+                ready &= mc3_bits(val[q]) != ROW_PENDING;
+            }
+        }
+        if (__all(ready))
+            return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 1023u) == 1023u) {
+            const long long ab = __hip_atomic_load(&ctl[CTL_ABORT], __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+            if (ab != 0 || spins > (1u << 24)) {
+                if (ab == 0 && (threadIdx.x & 63) == 0)
+                    __hip_atomic_store(&ctl[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+}
+
+// One chain, refreshes [R0, R0 + nref).  PERSIST = false: one refresh per launch,
+// other chains are seen through rows a previous launch wrote (plain loads).
+// PERSIST = true: many refreshes per launch; the tile, the chain state and all
+// constants stay in registers, and the other chains' rows arrive through the
+// in-launch hand-off above.
+template <int WPC, int MT, bool WL, bool MULTI, bool PERSIST>
+__device__ __forceinline__ void run_chain(const DevProblem &P, const long long R0,
+                                          const int nref)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const SmemLayout L = carve(smem, P, 64 * WPC);
@@ -526,10 +580,6 @@ __global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, cons
     const int lc = blockIdx.x;                 // local chain
     const int c = P.chain0 + lc;               // global chain id
     const int nf = P.nfree;
-    const long long R = P.ctl[0] + roff;       // refresh index
-    const double *snap = (R == 0) ? P.snap0
-                                  : P.Z + (size_t)(P.M0 + (R - 1) * P.nchains) * nf;
-    const long long zsize = P.M0 + R * P.nchains;
     const bool mine = wave0 && lane < nf;      // lane k of wave 0 owns free parameter k
 
     // Everything that does not depend on the proposal is requested first, so the
@@ -539,9 +589,11 @@ __global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, cons
     DataTile<WPC, MT> tile;
     if constexpr (!WL)
         tile.load(P);
-    // own state = this chain's row of the snapshot (same pages as the partner rows
-    // requested a few hundred cycles later, so their translation is already warm)
-    double xk = mine ? snap[(size_t)c * nf + lane] : 0.0;
+    // own state = this chain's row of the first snapshot (same pages as the partner
+    // rows requested a few hundred cycles later, so their translation is warm)
+    const double *snap_first = (R0 == 0) ? P.snap0
+                                         : P.Z + (size_t)(P.M0 + (R0 - 1) * P.nchains) * nf;
+    double xk = mine ? snap_first[(size_t)c * nf + lane] : 0.0;
     double cur = P.chisq[lc];
     double best = P.best_chisq[lc];
     const long long nacc0 = P.numaccept[lc];
@@ -553,8 +605,14 @@ __global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, cons
     const double fixed0 = (wave0 && lane < P.nparams) ? P.params[lane] : 0.0;
     const double fixed1 = (wave0 && lane + 64 < P.nparams) ? P.params[lane + 64] : 0.0;
     long long nacc = 0;
+    long long *ctl_rw = const_cast<long long *>(P.ctl);
+    bool alive = true;
     MC3_STAMP(1);
 
+    for (long long R = R0; R < R0 + nref && alive; ++R) {
+    const double *snap = (R == 0) ? P.snap0
+                                  : P.Z + (size_t)(P.M0 + (R - 1) * P.nchains) * nf;
+    const long long zsize = P.M0 + R * P.nchains;
     for (int j = 0; j < P.thinning; ++j) {
         const uint64_t iter = (uint64_t)(R * P.thinning + j);
         double npk = 0.0, zk = 0.0, u = 0.0;
@@ -589,12 +647,25 @@ __global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, cons
                     iR2 = 0;
                 sjump = u01(d1.q0) < 0.1;
                 const long long iz = (long long)bounded(d1.q1, (uint64_t)zsize);
-                const double z1 = mine ? P.Z[(size_t)iR1 * nf + lane] : 0.0;
-                const double z2 = mine ? P.Z[(size_t)iR2 * nf + lane] : 0.0;
+                double z1 = 0.0, z2 = 0.0;
+                if constexpr (PERSIST) {
+                    const int kk = mine ? lane : 0;
+                    const double *const addr[3] = {P.Z + (size_t)iR1 * nf + kk,
+                                                   P.Z + (size_t)iR2 * nf + kk,
+                                                   P.Z + (size_t)iz * nf + kk};
+                    double val[3] = {0.0, 0.0, 0.0};
+                    alive = wait_rows<3>(addr, val, mine, ctl_rw);
+                    z1 = val[0];
+                    z2 = val[1];
+                    zk = val[2];
+                } else {
+                    z1 = mine ? P.Z[(size_t)iR1 * nf + lane] : 0.0;
+                    z2 = mine ? P.Z[(size_t)iR2 * nf + lane] : 0.0;
+                    zk = (mine && sjump) ? P.Z[(size_t)iz * nf + lane] : 0.0;
+                }
                 if (sjump) {
                     flags |= 4;
                     const double gs = 1.2 + (2.2 - 1.2) * u01(d2.q0);
-                    zk = mine ? P.Z[(size_t)iz * nf + lane] : 0.0;
                     const bool same = __all(!mine || zk == xk);
                     if (same) {
                         jump_k = gs * (z2 - z1);
@@ -619,8 +690,19 @@ __global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, cons
                 r2 = (r2 >= n) ? r2 - n : r2;                               // (...) % n
                 if (r2 == c)
                     r2 = (r1 + 1 == n) ? 0 : r1 + 1;                        // (r1+1) % n
-                const double x1 = mine ? snap[(size_t)r1 * nf + lane] : 0.0;
-                const double x2 = mine ? snap[(size_t)r2 * nf + lane] : 0.0;
+                double x1 = 0.0, x2 = 0.0;
+                if constexpr (PERSIST) {
+                    const int kk = mine ? lane : 0;
+                    const double *const addr[2] = {snap + (size_t)r1 * nf + kk,
+                                                   snap + (size_t)r2 * nf + kk};
+                    double val[2] = {0.0, 0.0};
+                    alive = wait_rows<2>(addr, val, mine, ctl_rw);
+                    x1 = val[0];
+                    x2 = val[1];
+                } else {
+                    x1 = mine ? snap[(size_t)r1 * nf + lane] : 0.0;
+                    x2 = mine ? snap[(size_t)r2 * nf + lane] : 0.0;
+                }
                 jump_k = P.gamma * (x1 - x2) + P.fepsilon * normal_k;
             }
             // proposal and boundaries, chain.py:235-243
@@ -639,11 +721,17 @@ __global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, cons
                 for (int s = 0; s < P.nshare; ++s)                   // chain.py:246-247
                     L.nextp[P.ishare[s]] = L.nextp[P.share_src[s]];
                 L.flag[0] = anyout ? 1 : 0;
+                L.flag[2] = alive ? 1 : 0;
             }
         }
         block_sync<WPC>();
         MC3_STAMP(2);
         const bool anyout = L.flag[0] != 0;
+        if constexpr (PERSIST) {
+            alive = L.flag[2] != 0;
+            if (!alive)
+                break;                         // a wait timed out: stop this chain
+        }
         double nextchisq = mc3_from_bits(0x7ff8000000000000ull);
         if (!anyout) {
             flags |= 1;
@@ -684,23 +772,51 @@ __global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, cons
         }
         block_sync<WPC>();
     }
+    if (!alive)
+        break;
     // Z append, chain.py:276-289 (strided slot M0 + ID + k*nchains)
     if (wave0) {
         const long long row = P.M0 + R * P.nchains + c;
         if (mine) {
-            P.X[(size_t)lc * nf + lane] = xk;
-            P.Z[(size_t)row * nf + lane] = xk;
+            if constexpr (PERSIST)
+                __hip_atomic_store(&P.Z[(size_t)row * nf + lane], xk, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);      // publish (sc1)
+            else
+                P.Z[(size_t)row * nf + lane] = xk;
         }
         if (lane == 0) {
-            P.chisq[lc] = cur;
-            P.best_chisq[lc] = best;
-            P.numaccept[lc] = nacc0 + nacc;
             P.log_post[row] = -0.5 * cur;
             P.zchain[row] = c;
         }
     }
+    }   // refreshes
+    if (wave0) {
+        if (mine)
+            P.X[(size_t)lc * nf + lane] = xk;
+        if (lane == 0) {
+            P.chisq[lc] = cur;
+            P.best_chisq[lc] = best;
+            P.numaccept[lc] = nacc0 + nacc;
+        }
+    }
     MC3_STAMP(4);
 }
+
+// one Z refresh per launch (also the multi-GPU path: a collective follows each launch)
+template <int WPC, int MT, bool WL, bool MULTI>
+__global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, const int roff)
+{
+    run_chain<WPC, MT, WL, MULTI, false>(P, P.ctl[0] + roff, 1);
+}
+
+// many Z refreshes per launch with in-launch hand-off of the new rows; every
+// workgroup of the grid must be resident (the host checks before choosing this path)
+template <int WPC, int MT, bool WL, bool MULTI>
+__global__ __launch_bounds__(64 * WPC) void persist_kernel(const DevProblem P, const int nref)
+{
+    run_chain<WPC, MT, WL, MULTI, true>(P, P.ctl[0], nref);
+}
+
 
 // chisq for arbitrary parameter vectors (Chain.eval_model(ret='chisq'))
 template <int WPC, int MT, bool WL>
@@ -782,8 +898,10 @@ __global__ void daub4_kernel(double *a, double *tmp, int n, int inverse)
 __global__ void set_ctl_kernel(long long *ctl, long long base, long long run0)
 {
     ctl[0] = base;
-    if (run0 >= 0)
+    if (run0 >= 0) {
         ctl[1] = run0;
+        ctl[CTL_ABORT] = 0;
+    }
 }
 
 __global__ void selftest_math_kernel(int op, const double *in, int n, double *out)

@@ -129,6 +129,8 @@ struct mc3hip_ctx {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int graph_nodes = 0;
+    int persist_refs = 0;           // refreshes per persistent launch, 0 = off
+    bool persist_checked = false;
     // comm
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
@@ -196,6 +198,43 @@ void launch_step_t(mc3hip_ctx *c, int roff)
 }
 
 template <int WPC, int MT>
+void launch_persist_t(mc3hip_ctx *c, int nref)
+{
+    if (c->P.wlike)
+        hipLaunchKernelGGL((persist_kernel<WPC, MT, true, false>), dim3(c->P.nlocal),
+                           dim3(64 * WPC), c->smem, c->stream, c->P, nref);
+    else if (c->P.ndata > VLANES)
+        hipLaunchKernelGGL((persist_kernel<WPC, MT, false, true>), dim3(c->P.nlocal),
+                           dim3(64 * WPC), c->smem, c->stream, c->P, nref);
+    else
+        hipLaunchKernelGGL((persist_kernel<WPC, MT, false, false>), dim3(c->P.nlocal),
+                           dim3(64 * WPC), c->smem, c->stream, c->P, nref);
+}
+
+// workgroups of the persistent kernel that fit on one CU (0 on error)
+template <int WPC, int MT>
+void persist_blocks_per_cu_t(mc3hip_ctx *c, int *out)
+{
+    int nb = 0;
+    hipError_t e;
+    if (c->P.wlike) {
+        if (c->smem > 64 * 1024)
+            (void)hipFuncSetAttribute(
+                reinterpret_cast<const void *>(&persist_kernel<WPC, MT, true, false>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->smem);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &nb, persist_kernel<WPC, MT, true, false>, 64 * WPC, c->smem);
+    } else if (c->P.ndata > VLANES) {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &nb, persist_kernel<WPC, MT, false, true>, 64 * WPC, c->smem);
+    } else {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &nb, persist_kernel<WPC, MT, false, false>, 64 * WPC, c->smem);
+    }
+    *out = (e == hipSuccess) ? nb : 0;
+}
+
+template <int WPC, int MT>
 void launch_eval_t(mc3hip_ctx *c, int n)
 {
     if (c->P.wlike)
@@ -231,6 +270,36 @@ void launch_model_t(mc3hip_ctx *c)
     }
 
 void launch_step(mc3hip_ctx *c, int roff) { DISPATCH(launch_step_t, c, roff) }
+void launch_persist(mc3hip_ctx *c, int nref) { DISPATCH(launch_persist_t, c, nref) }
+void persist_blocks_per_cu(mc3hip_ctx *c, int *out) { DISPATCH(persist_blocks_per_cu_t, c, out) }
+
+// The persistent kernel spins on rows other workgroups publish, so EVERY workgroup
+// of its grid must be resident at once.  Residency comes from the grid size alone:
+// use it only when nlocal fits the occupancy the runtime reports, with one
+// workgroup per CU of slack when more than one fits (the API can over-report by
+// one, MI355X_MICROARCH.md "Residency and cooperative launch").
+int decide_persist(mc3hip_ctx *c)
+{
+    if (c->persist_checked)
+        return c->persist_refs;
+    c->persist_checked = true;
+    c->persist_refs = 0;
+    if ((c->flags & MC3HIP_FLAG_NO_PERSIST) || getenv("MC3HIP_NO_PERSIST"))
+        return 0;
+    int nb = 0;
+    persist_blocks_per_cu(c, &nb);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess)
+        return 0;
+    const int per_cu = nb > 1 ? nb - 1 : nb;
+    const long long capacity = (long long)per_cu * prop.multiProcessorCount;
+    if (nb < 1 || c->P.nlocal > capacity)
+        return 0;
+    c->persist_refs = 16384;
+    if (const char *e = getenv("MC3HIP_PERSIST_REFS"))
+        c->persist_refs = atoi(e) > 0 ? atoi(e) : 0;
+    return c->persist_refs;
+}
 void launch_eval(mc3hip_ctx *c, int n) { DISPATCH(launch_eval_t, c, n) }
 
 void launch_model(mc3hip_ctx *c)
@@ -459,12 +528,13 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         TRY(dev_alloc(c, &P.trace_chisq, (size_t)P.trace_iters * nl));
         TRY(dev_alloc(c, &P.trace_flag, (size_t)P.trace_iters * nl));
     }
-    TRY(dev_alloc(c, &c->ctl, 2));
+    TRY(dev_alloc(c, &c->ctl, 4));
     P.ctl = c->ctl;
     TRY(dev_alloc(c, &P.stamps, 16));
     HIP_TRY_C(hipMemset(P.stamps, 0, 16 * sizeof(unsigned long long)));
-    HIP_TRY_C(hipMemset(c->ctl, 0, 2 * sizeof(long long)));
-    HIP_TRY_C(hipMemset(P.Z, 0, zl * nf * sizeof(double)));
+    HIP_TRY_C(hipMemset(c->ctl, 0, 4 * sizeof(long long)));
+    // all-ones = "row not written yet" (the persistent kernel's hand-off sentinel)
+    HIP_TRY_C(hipMemset(P.Z, 0xff, zl * nf * sizeof(double)));
     HIP_TRY_C(hipMemset(P.log_post, 0, zl * sizeof(double)));
     HIP_TRY_C(hipMemset(P.zchain, 0xff, zl * sizeof(int32_t)));      // -1, mcmc_driver.py:170
     HIP_TRY_C(hipMemset(P.numaccept, 0, nl * sizeof(long long)));
@@ -528,6 +598,8 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
     plan->tile = 0;
     plan->waves_per_chain = c->wpc;
     plan->graph_nodes = c->graph_nodes;
+    plan->persistent = c->comm ? 0 : decide_persist(const_cast<mc3hip_ctx *>(c));
+    plan->reserved = 0;
     return MC3HIP_OK;
 }
 
@@ -593,7 +665,8 @@ int mc3hip_run(mc3hip_ctx *c, int64_t nrefresh)
     const int64_t Rend = R + nrefresh;
     const long long run0 = R;
     bool first = true;
-    const bool use_graph = c->graph_nodes > 0 && c->comm == nullptr;
+    const int persist = c->comm ? 0 : decide_persist(c);
+    const bool use_graph = c->graph_nodes > 0 && c->comm == nullptr && persist == 0;
     if (use_graph && nrefresh >= c->graph_nodes && !c->graph_exec) {
         int rc = build_graph(c);
         if (rc)
@@ -601,7 +674,13 @@ int mc3hip_run(mc3hip_ctx *c, int64_t nrefresh)
     }
     while (R < Rend) {
         const int64_t left = Rend - R;
-        if (use_graph && left >= c->graph_nodes) {
+        if (persist > 0) {
+            const int n = (int)(left < persist ? left : persist);
+            hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl,
+                               (long long)R, first ? run0 : -1LL);
+            launch_persist(c, n);
+            R += n;
+        } else if (use_graph && left >= c->graph_nodes) {
             hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl,
                                (long long)R, first ? run0 : -1LL);
             HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
@@ -635,6 +714,15 @@ int mc3hip_sync(mc3hip_ctx *c)
         return fail(MC3HIP_ERR_ARG, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->persist_refs > 0) {
+        long long ab = 0;
+        HIP_TRY(hipMemcpy(&ab, c->ctl + CTL_ABORT, sizeof ab, hipMemcpyDeviceToHost));
+        if (ab != 0)
+            return fail(MC3HIP_ERR_STATE,
+                        "persistent kernel: a wait for another chain's Z row timed out "
+                        "(workgroups not co-resident?); the run is incomplete -- "
+                        "recreate the context with MC3HIP_FLAG_NO_PERSIST");
+    }
     return MC3HIP_OK;
 }
 

@@ -29,7 +29,7 @@ class DeviceChains:
                  nsamples=None, sampler='snooker', wlike=False, thinning=1,
                  fgamma=1.0, fepsilon=0.0, hsize=10, model='poly', nmodel=None,
                  seed=0, device=0, chain0=0, nlocal=None, M0=None, zlen=None,
-                 trace_iters=0, no_graph=False):
+                 trace_iters=0, no_graph=False, no_persist=False):
         self._ctx = None
         self.lib = _lib.load()
         self.params = f64(params).copy()
@@ -89,7 +89,8 @@ class DeviceChains:
         P.model_kind = {'poly': _lib.MODEL_POLY, 'linear': _lib.MODEL_LINEAR}[model]
         P.nmodel = self.nmodel
         P.thinning = self.thinning
-        P.flags = _lib.FLAG_NO_GRAPH if no_graph else 0
+        P.flags = (_lib.FLAG_NO_GRAPH if no_graph else 0) | \
+            (_lib.FLAG_NO_PERSIST if no_persist else 0)
         P.trace_iters = int(trace_iters)
         P.M0, P.zlen = self.M0, self.zlen
         P.seed = self.seed
@@ -105,7 +106,8 @@ class DeviceChains:
         check(self.lib.mc3hip_get_plan(self._ctx, ctypes.byref(plan)))
         self.plan = {'vlanes': plan.vlanes, 'tile': plan.tile,
                      'waves_per_chain': plan.waves_per_chain,
-                     'graph_nodes': plan.graph_nodes}
+                     'graph_nodes': plan.graph_nodes,
+                     'persistent': plan.persistent}
 
     # -- lifetime --------------------------------------------------------------
     def close(self):

@@ -16,7 +16,7 @@ class OracleChains:
                  nsamples=None, sampler='snooker', wlike=False, thinning=1,
                  fgamma=1.0, fepsilon=0.0, hsize=10, model='poly', nmodel=None,
                  seed=0, device=0, chain0=0, nlocal=None, M0=None, zlen=None,
-                 trace_iters=0, no_graph=False, nthreads=1):
+                 trace_iters=0, no_graph=False, no_persist=False, nthreads=1):
         if M0 is None:
             M0 = hsize*nchains
         if nsamples is None:
@@ -38,7 +38,7 @@ class OracleChains:
         self.prior, self.priorlow, self.priorup = r.prior, r.priorlow, r.priorup
         self.ifree = np.where(r.pstep > 0)[0]
         self.ishare = np.where(r.pstep < 0)[0]
-        self.plan = {'vlanes': 1024, 'tile': 0, 'waves_per_chain': 0, 'graph_nodes': 0}
+        self.plan = {'vlanes': 1024, 'tile': 0, 'waves_per_chain': 0, 'graph_nodes': 0, 'persistent': 0}
 
     def close(self):
         pass

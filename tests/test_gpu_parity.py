@@ -264,24 +264,57 @@ def test_waves_per_chain_do_not_change_results(eng, wpc):
     gpu.close()
 
 
-def test_graph_replay_equals_eager_and_resumes(eng):
-    """600 refreshes = two 256-node graph replays + an eager tail; split into
-    several run() calls; against one eager run and the oracle."""
+def test_launch_modes_agree_and_resume(eng):
+    """600 refreshes through the three launch structures -- eager (one launch per
+    refresh), hipGraph (two 256-node replays + an eager tail) and the persistent
+    kernel (in-launch hand-off of the Z rows) -- split into several run() calls;
+    all equal to the oracle."""
     prob = H.quad_problem(nchains=8, nsamples=8*600, sampler='demc')
-    orc, eager = run_pair(eng, prob, trace=False, no_graph=True)
-    assert eager.plan['graph_nodes'] == 0
-    graph = eng.DeviceChains(**prob)
-    assert graph.plan['graph_nodes'] == 256
+    orc, eager = run_pair(eng, prob, trace=False, no_graph=True, no_persist=True)
+    assert eager.plan['graph_nodes'] == 0 and eager.plan['persistent'] == 0
     Z0, lp0 = H.initial_population(orc)
-    graph.set_population(Z0, lp0)
-    graph.run(300)
-    graph.run(300)
-    assert_same(orc, eager, trace=False)
-    assert_same(orc, graph, trace=False)
+    graph = eng.DeviceChains(no_persist=True, **prob)
+    assert graph.plan['graph_nodes'] == 256 and graph.plan['persistent'] == 0
+    persist = eng.DeviceChains(**prob)
+    assert persist.plan['persistent'] > 0
+    for g in (graph, persist):
+        g.set_population(Z0, lp0)
+        g.run(300)
+        g.run(37)
+        g.run(263)
+    for g in (eager, graph, persist):
+        assert_same(orc, g, trace=False)
     with pytest.raises(Exception, match='cannot run'):
         graph.run(1)
-    eager.close()
-    graph.close()
+    for g in (eager, graph, persist):
+        g.close()
+
+
+@pytest.mark.parametrize('builder,kw', [
+    (H.quad_problem, dict(sampler='snooker', nchains=9, nsamples=9*150)),
+    (H.quad_problem, dict(sampler='demc', nchains=9, nsamples=9*300, thinning=2,
+                          fepsilon=0.01)),
+    (H.shared_problem, dict()),
+    (H.wavelet_problem, dict(nsamples=7*60)),
+    (H.linear_problem, dict()),
+])
+def test_per_refresh_launch_path_bit_exact(eng, builder, kw):
+    """The one-launch-per-refresh path (what multi-GPU runs use) on every model /
+    sampler family; the default tests above exercise the persistent kernel."""
+    prob = builder(**kw)
+    orc, gpu = run_pair(eng, prob, no_persist=True)
+    assert gpu.plan['persistent'] == 0
+    assert_same(orc, gpu)
+    gpu.close()
+
+
+def test_persistent_kernel_many_chains(eng):
+    """2048 chains: eight single-wave workgroups per CU must all be resident;
+    the library falls back to per-refresh launches when they are not."""
+    prob = H.quad_problem(ndata=256, nchains=2048, nsamples=2048*60, sampler='demc')
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
 
 
 def test_headline_config_c2_matches_oracle(eng):
