@@ -180,9 +180,22 @@ def main():
     chain_steps = nchains*args.steps*args.thinning
     value = chain_steps/dt/1e6
 
-    # roofline of the dominant (only) kernel: step_kernel, one launch per step
-    launch_s = gpu_ms*1e-3/args.steps
-    bytes_per_launch = BYTES_PER_CHAIN_STEP*CHAINS_PER_GPU*args.thinning
+    # roofline of the dominant (only) kernel.  Persistent path: one launch covers
+    # `persistent` refreshes; per-refresh path: one launch per refresh.
+    per = gpu.plan['persistent'] if world == 1 else 0
+    if per > 0:
+        launches = -(-args.steps//per)
+        kernel = 'mc3hip::persist_fast_kernel' if gpu.plan['fast'] else 'mc3hip::persist_kernel'
+        structure = (f'persistent kernel, {per} refreshes per launch, Z rows handed '
+                     'between workgroups in-launch')
+    else:
+        launches = args.steps
+        kernel = 'mc3hip::step_kernel'
+        structure = 'one launch per refresh' + \
+            (f' (hipGraph of {gpu.plan["graph_nodes"]} nodes)' if world == 1 else
+             ' + one RCCL all-gather per refresh')
+    launch_s = gpu_ms*1e-3/launches
+    bytes_per_launch = BYTES_PER_CHAIN_STEP*CHAINS_PER_GPU*args.thinning*args.steps/launches
     achieved = bytes_per_launch/launch_s/1e9
     out = {
         'metric': 'million chain-steps/sec (nchains x iters/s), 256-chain quad fit ndata=1000',
@@ -199,20 +212,21 @@ def main():
             'parallelism': f'chains sharded x{world}' if world > 1 else 'single GPU',
             'collective': 'one in-place RCCL all-gather of new Z rows per refresh'
                           if world > 1 else None,
+            'launch_structure': structure,
             'waves_per_chain': gpu.plan['waves_per_chain'],
-            'graph_nodes': gpu.plan['graph_nodes'] if world == 1 else 0,
             'acceptance_rate': accept,
         },
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBS, 'traffic': None,
-            'kernel': 'mc3hip::step_kernel',
+            'kernel': kernel, 'launches': launches,
             'algorithmic_bytes_per_launch': bytes_per_launch,
             'avg_launch_us': launch_s*1e6,
-            'note': 'algorithmic bytes (SURVEY 8d): x/data/uncert are chain-invariant '
-                    'and L2-resident, so hardware HBM traffic is far smaller; '
-                    'avg_launch_us = HIP-event time of the timed region / launches '
-                    '(includes inter-launch gaps)',
+            'note': 'algorithmic bytes (SURVEY 8d: 24104 B per chain-step) x chain-steps '
+                    'per launch / average launch duration (HIP events on the library '
+                    'stream over the timed region / launches). x/data/uncert are '
+                    'chain-invariant: they live in registers for a whole launch, so '
+                    'hardware HBM traffic is far below the algorithmic figure',
         },
     }
     if rank == 0:

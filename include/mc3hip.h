@@ -97,7 +97,8 @@ typedef struct mc3hip_plan {
     int32_t graph_nodes;    /* refreshes per hipGraph replay, 0 = eager       */
     int32_t persistent;     /* >0: refreshes per launch of the persistent kernel
                                (in-launch hand-off of Z rows), 0 = one launch per refresh */
-    int32_t reserved;
+    int32_t fast;           /* 1: the lean persistent instance (one wave per chain, fully
+                               free polynomial, Gaussian chisq, no priors/shared/epsilon) */
 } mc3hip_plan;
 
 /* Replaces Chain.__init__ + the shared-memory allocation of mcmc()

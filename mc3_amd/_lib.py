@@ -51,7 +51,7 @@ class Plan(ctypes.Structure):
     _fields_ = [('vlanes', ctypes.c_int32), ('tile', ctypes.c_int32),
                 ('waves_per_chain', ctypes.c_int32),
                 ('graph_nodes', ctypes.c_int32),
-                ('persistent', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+                ('persistent', ctypes.c_int32), ('fast', ctypes.c_int32)]
 
 
 class Mc3HipError(RuntimeError):

@@ -32,6 +32,7 @@ constexpr int MT_LINEAR = 100;       // sum_k A[k][i] p[k]
 
 struct DevProblem {
     int32_t nchains, chain0, nlocal, nparams, nfree, nshare, ndata;
+    int32_t npad;          // ndata rounded up to a multiple of 1024 (Gaussian data sum)
     int32_t sampler, wlike, nmodel, thinning, ngprior, trace_iters;
     int64_t M0;
     uint64_t seed;
@@ -70,24 +71,41 @@ struct DevProblem {
 #define MC3_STAMP(slot) do { } while (0)
 #endif
 
+__device__ __forceinline__ double make_double(int lo, int hi) { return __hiloint2double(hi, lo); }
+
 // ---- model evaluation ------------------------------------------------------
 template <int MT>
 struct Model {
     double cf[(MT >= 1 && MT <= 8) ? MT : 1];
     const double *coef;     // LDS copy of the proposal (generic / linear)
     const double *indep;
-    int nmodel, ndata;
+    int nmodel, ndata;      // ndata = column stride of A (the padded length)
 
     __device__ __forceinline__ void init(const DevProblem &P, const double *s_nextp)
     {
         coef = s_nextp;
         indep = P.indep;
         nmodel = P.nmodel;
-        ndata = P.ndata;
+        ndata = P.npad;
         if constexpr (MT >= 1 && MT <= 8) {
 #pragma unroll
             for (int j = 0; j < MT; ++j)
                 cf[j] = s_nextp[j];
+        }
+    }
+    // coefficients straight from wave 0's lanes (lane j holds parameter j): the
+    // fast path of fully-free polynomial models, no LDS round trip
+    __device__ __forceinline__ void init_from_lanes(const DevProblem &P, double npk)
+    {
+        coef = nullptr;
+        indep = P.indep;
+        nmodel = P.nmodel;
+        ndata = P.npad;
+        if constexpr (MT >= 1 && MT <= 8) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                cf[j] = make_double(__builtin_amdgcn_readlane(__double2loint(npk), j),
+                                    __builtin_amdgcn_readlane(__double2hiint(npk), j));
         }
     }
     // polynomial families at abscissa x (Horner, fused multiply-adds)
@@ -155,8 +173,6 @@ __device__ __forceinline__ int block_or(int pred, int *s_flag)
     }
     return any;
 }
-
-__device__ __forceinline__ double make_double(int lo, int hi) { return __hiloint2double(hi, lo); }
 
 // v[l] + v[l ^ 32], v[l] + v[l ^ 16]: gfx950 lane-swap instructions (VALU only)
 __device__ __forceinline__ double add_xor32(double v)
@@ -247,14 +263,15 @@ struct DataTile {
     static constexpr int NV = 16 / WPC;
     double x[NV], d[NV], w[NV];
 
+    // The device copies of x / data / w are padded to a multiple of 1024 points
+    // (x and data repeat the last point, w = 0), so the tile needs no bounds
+    // checks: a padded point adds fma(0, 0, acc) = acc.
     __device__ __forceinline__ void load(const DevProblem &P)
     {
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        const int last = P.ndata - 1;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            int i = lane + 64 * (wv + WPC * v);
-            i = i < last ? i : last;             // clamp: out-of-range lanes are masked later
+            const int i = lane + 64 * (wv + WPC * v);
             d[v] = P.data[i];
             w[v] = P.w[i];
             if constexpr (MT != MT_LINEAR)
@@ -266,37 +283,48 @@ struct DataTile {
 // Gaussian chi-squared data term, src_c/_chisq.c:131-133 with w = 1/uncert.
 // Returns +inf when any model value is +inf (chain.py:322-323).
 template <int WPC, int MT, bool MULTI>
+__device__ __forceinline__ double block_gauss_model(const DevProblem &P, const Model<MT> &model,
+                                                    double *s_part, int *s_flag,
+                                                    const DataTile<WPC, MT> &tile);
+
+template <int WPC, int MT, bool MULTI>
 __device__ double block_gauss(const DevProblem &P, const double *s_nextp, double *s_part,
                               int *s_flag, const DataTile<WPC, MT> &tile)
 {
-    constexpr int NV = 16 / WPC;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     Model<MT> model;
     model.init(P, s_nextp);
+    return block_gauss_model<WPC, MT, MULTI>(P, model, s_part, s_flag, tile);
+}
+
+template <int WPC, int MT, bool MULTI>
+__device__ __forceinline__ double block_gauss_model(const DevProblem &P, const Model<MT> &model,
+                                                    double *s_part, int *s_flag,
+                                                    const DataTile<WPC, MT> &tile)
+{
+    constexpr int NV = 16 / WPC;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double acc[NV];
-    int sawinf = 0;
-    const int n = P.ndata;
+    // +inf trap (chain.py:322-323) through a running maximum: one v_max_f64 per
+    // point instead of a compare/and/or chain; IEEE maxNum ignores NaNs.
+    double mmax = -1.0;
+    const int npad = P.npad;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        const int i = lane + 64 * (wv + WPC * v);
-        const bool valid = i < n;
         double m;
         if constexpr (MT == MT_LINEAR)
-            m = model.at(valid ? i : n - 1);
+            m = model.at(lane + 64 * (wv + WPC * v));
         else
             m = model.at_x(tile.x[v]);
-        sawinf |= valid && is_pos_inf(m);
-        double r = (m - tile.d[v]) * tile.w[v];
-        r = valid ? r : 0.0;
+        mmax = __builtin_fmax(mmax, m);
+        const double r = (m - tile.d[v]) * tile.w[v];
         acc[v] = mc3_fma(r, r, 0.0);
     }
     // points beyond the first tile are streamed (MULTI = ndata > 1024)
-    for (int base = VLANES; MULTI && base < n; base += VLANES) {
+    for (int base = VLANES; MULTI && base < npad; base += VLANES) {
         double xs[NV], ds[NV], ws[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {                // issue every load of the tile first
-            int i = base + lane + 64 * (wv + WPC * v);
-            i = i < n ? i : n - 1;
+            const int i = base + lane + 64 * (wv + WPC * v);
             ds[v] = P.data[i];
             ws[v] = P.w[i];
             if constexpr (MT != MT_LINEAR)
@@ -304,21 +332,18 @@ __device__ double block_gauss(const DevProblem &P, const double *s_nextp, double
         }
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int i = base + lane + 64 * (wv + WPC * v);
-            const bool valid = i < n;
             double m;
             if constexpr (MT == MT_LINEAR)
-                m = model.at(valid ? i : n - 1);
+                m = model.at(base + lane + 64 * (wv + WPC * v));
             else
                 m = model.at_x(xs[v]);
-            sawinf |= valid && is_pos_inf(m);
-            double r = (m - ds[v]) * ws[v];
-            r = valid ? r : 0.0;
+            mmax = __builtin_fmax(mmax, m);
+            const double r = (m - ds[v]) * ws[v];
             acc[v] = mc3_fma(r, r, acc[v]);
         }
     }
     const double total = lane_tree<WPC>(acc, s_part);
-    sawinf = block_or<WPC>(sawinf, s_flag);
+    const int sawinf = block_or<WPC>(is_pos_inf(mmax), s_flag);
     return sawinf ? mc3_from_bits(0x7ff0000000000000ull) : total;
 }
 
@@ -531,22 +556,20 @@ __device__ __forceinline__ double load_published(const double *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Wave-level wait until every participating lane's value has been published.
-// Bounded: gives up (and tells everybody) after ~1 s so a lost workgroup can
-// never hang the device.
+// Wave-level wait until every lane's values have been published (all 64 lanes
+// poll; lanes beyond nfree repeat lane 0's addresses).  The first read is issued
+// by the caller so that independent scalar work can overlap its latency; this
+// only spins when something is still pending.  Bounded: gives up (and tells
+// everybody) after ~1 s so a lost workgroup can never hang the device.
 template <int NVAL>
 __device__ __forceinline__ bool wait_rows(const double *const (&addr)[NVAL], double (&val)[NVAL],
-                                          bool active, long long *ctl)
+                                          long long *ctl)
 {
     for (unsigned spins = 0;; ++spins) {
         bool ready = true;
-        if (active) {
 #pragma unroll
-            for (int q = 0; q < NVAL; ++q) {
-                val[q] = load_published(addr[q]);
-                ready &= mc3_bits(val[q]) != ROW_PENDING;
-            }
-        }
+        for (int q = 0; q < NVAL; ++q)
+            ready &= mc3_bits(val[q]) != ROW_PENDING;
         if (__all(ready))
             return true;
         __builtin_amdgcn_s_sleep(1);
@@ -560,7 +583,28 @@ __device__ __forceinline__ bool wait_rows(const double *const (&addr)[NVAL], dou
                 return false;
             }
         }
+#pragma unroll
+        for (int q = 0; q < NVAL; ++q)
+            val[q] = load_published(addr[q]);
     }
+}
+
+// the wave-uniform draws of one iteration (slots 0..2)
+struct Draws {
+    Draw2 d0, d1, d2;
+};
+
+__device__ __forceinline__ Draws make_draws(const DevProblem &P, uint64_t iter, int c, int sampler)
+{
+    Draws D;
+    D.d0 = draw2(P.seed, iter, (uint32_t)c, 0u);
+    D.d1 = D.d0;
+    D.d2 = D.d0;
+    if (sampler == MC3HIP_SNOOKER) {
+        D.d1 = draw2(P.seed, iter, (uint32_t)c, 1u);
+        D.d2 = draw2(P.seed, iter, (uint32_t)c, 2u);
+    }
+    return D;
 }
 
 // One chain, refreshes [R0, R0 + nref).  PERSIST = false: one refresh per launch,
@@ -568,10 +612,20 @@ __device__ __forceinline__ bool wait_rows(const double *const (&addr)[NVAL], dou
 // PERSIST = true: many refreshes per launch; the tile, the chain state and all
 // constants stay in registers, and the other chains' rows arrive through the
 // in-launch hand-off above.
-template <int WPC, int MT, bool WL, bool MULTI, bool PERSIST>
+//
+// SMP >= 0 fixes the sampler at compile time.  FAST is the lean instance for the
+// commonest shape -- one wave per chain, Gaussian chisq, every parameter a free
+// polynomial coefficient, no priors / shared parameters / support distribution /
+// trace: the proposal goes from lanes to the model through v_readlane instead of
+// LDS and all the dead generality (and its scalar-register pressure) is compiled
+// out.  Same arithmetic, same results.
+template <int WPC, int MT, bool WL, bool MULTI, bool PERSIST, int SMP = -1, bool FAST = false>
 __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R0,
                                           const int nref)
 {
+    static_assert(!FAST || (WPC == 1 && !WL && !MULTI && SMP >= 0 && MT >= 1 && MT <= 8),
+                  "FAST needs one wave, Gaussian chisq, a compile-time sampler and degree");
+    const int sampler = (SMP >= 0) ? SMP : P.sampler;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const SmemLayout L = carve(smem, P, 64 * WPC);
     MC3_STAMP(0);
@@ -600,15 +654,20 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     const int jfree = mine ? P.ifree[lane] : 0;
     const double pmin_k = mine ? P.fmin[lane] : 0.0;
     const double pmax_k = mine ? P.fmax[lane] : 0.0;
-    const bool need_normal = (P.sampler == MC3HIP_MRW) || (P.fepsilon != 0.0);
+    const bool need_normal = !FAST && ((sampler == MC3HIP_MRW) || (P.fepsilon != 0.0));
     const double pstep_k = (mine && need_normal) ? P.fstep[lane] : 0.0;
-    const double fixed0 = (wave0 && lane < P.nparams) ? P.params[lane] : 0.0;
-    const double fixed1 = (wave0 && lane + 64 < P.nparams) ? P.params[lane + 64] : 0.0;
+    const double fixed0 = (!FAST && wave0 && lane < P.nparams) ? P.params[lane] : 0.0;
+    const double fixed1 = (!FAST && wave0 && lane + 64 < P.nparams) ? P.params[lane + 64] : 0.0;
     long long nacc = 0;
     long long *ctl_rw = const_cast<long long *>(P.ctl);
     bool alive = true;
     MC3_STAMP(1);
 
+    // The index / acceptance draws depend only on (seed, iteration, chain): they
+    // are wave-uniform, so Philox runs on the scalar unit (every wave repeats it),
+    // and the next iteration's are computed while this iteration's partner rows
+    // are in flight.
+    Draws nxt = make_draws(P, (uint64_t)(R0 * P.thinning), c, sampler);
     for (long long R = R0; R < R0 + nref && alive; ++R) {
     const double *snap = (R == 0) ? P.snap0
                                   : P.Z + (size_t)(P.M0 + (R - 1) * P.nchains) * nf;
@@ -617,18 +676,13 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
         const uint64_t iter = (uint64_t)(R * P.thinning + j);
         double npk = 0.0, zk = 0.0, u = 0.0;
         double mrfactor = 1.0;
-        bool sjump = false, outk = false;
+        bool sjump = false, outk = false, fast_anyout = false;
         int flags = 0;
-        // The index / acceptance draws depend only on (seed, iteration, chain): they
-        // are wave-uniform, so Philox runs on the scalar unit (every wave repeats it).
-        const Draw2 d0 = draw2(P.seed, iter, (uint32_t)c, 0u);
-        Draw2 d1 = d0, d2 = d0;
-        if (P.sampler == MC3HIP_SNOOKER) {
-            d1 = draw2(P.seed, iter, (uint32_t)c, 1u);
-            d2 = draw2(P.seed, iter, (uint32_t)c, 2u);
-        }
+        const Draw2 d0 = nxt.d0, d1 = nxt.d1, d2 = nxt.d2;
+        if constexpr (!PERSIST)
+            nxt = make_draws(P, iter + 1, c, sampler);
         // Metropolis draw, chain.py:259
-        u = (P.sampler == MC3HIP_SNOOKER) ? u01(d2.q1) : u01(d0.q1);
+        u = (sampler == MC3HIP_SNOOKER) ? u01(d2.q1) : u01(d0.q1);
         if (wave0) {
             // support-distribution draw, chain.py:185
             double normal_k = 0.0;
@@ -640,7 +694,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 normal_k = (rad * ((lane & 1) ? sn : cs)) * pstep_k;
             }
             double jump_k = 0.0;
-            if (P.sampler == MC3HIP_SNOOKER) {                       // chain.py:195-217
+            if (sampler == MC3HIP_SNOOKER) {                       // chain.py:195-217
                 long long iR1 = (long long)bounded(d0.q0, (uint64_t)zsize);
                 long long iR2 = 1 + (long long)bounded(d0.q1, (uint64_t)(zsize - 1));
                 if (iR2 == iR1)
@@ -653,8 +707,12 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                     const double *const addr[3] = {P.Z + (size_t)iR1 * nf + kk,
                                                    P.Z + (size_t)iR2 * nf + kk,
                                                    P.Z + (size_t)iz * nf + kk};
-                    double val[3] = {0.0, 0.0, 0.0};
-                    alive = wait_rows<3>(addr, val, mine, ctl_rw);
+                    double val[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        val[q] = load_published(addr[q]);
+                    nxt = make_draws(P, iter + 1, c, sampler);
+                    alive = wait_rows<3>(addr, val, ctl_rw);
                     z1 = val[0];
                     z2 = val[1];
                     zk = val[2];
@@ -679,8 +737,10 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 } else {
                     jump_k = P.gamma * (z1 - z2) + P.fepsilon * normal_k;
                 }
-            } else if (P.sampler == MC3HIP_MRW) {                    // chain.py:219-220
+            } else if (sampler == MC3HIP_MRW) {                    // chain.py:219-220
                 jump_k = normal_k;
+                if constexpr (PERSIST)
+                    nxt = make_draws(P, iter + 1, c, sampler);
             } else {                                                 // chain.py:221-232
                 const int n = P.nchains;
                 int r1 = 1 + (int)bounded32((uint32_t)(d0.q0 >> 32), (uint32_t)(n - 1));
@@ -695,8 +755,12 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                     const int kk = mine ? lane : 0;
                     const double *const addr[2] = {snap + (size_t)r1 * nf + kk,
                                                    snap + (size_t)r2 * nf + kk};
-                    double val[2] = {0.0, 0.0};
-                    alive = wait_rows<2>(addr, val, mine, ctl_rw);
+                    double val[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        val[q] = load_published(addr[q]);
+                    nxt = make_draws(P, iter + 1, c, sampler);
+                    alive = wait_rows<2>(addr, val, ctl_rw);
                     x1 = val[0];
                     x2 = val[1];
                 } else {
@@ -709,6 +773,9 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
             npk = xk + jump_k;
             outk = mine && (npk < pmin_k || npk > pmax_k);
             const bool anyout = __any(outk);
+            if constexpr (FAST) {
+                fast_anyout = anyout;
+            } else {
             if (lane < P.nparams)
                 L.nextp[lane] = fixed0;
             if (lane + 64 < P.nparams)
@@ -723,20 +790,34 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 L.flag[0] = anyout ? 1 : 0;
                 L.flag[2] = alive ? 1 : 0;
             }
+            }
         }
-        block_sync<WPC>();
-        MC3_STAMP(2);
-        const bool anyout = L.flag[0] != 0;
-        if constexpr (PERSIST) {
-            alive = L.flag[2] != 0;
-            if (!alive)
-                break;                         // a wait timed out: stop this chain
+        bool anyout;
+        if constexpr (FAST) {
+            anyout = fast_anyout;
+            if (PERSIST && !alive)
+                break;
+        } else {
+            block_sync<WPC>();
+            MC3_STAMP(2);
+            anyout = L.flag[0] != 0;
+            if constexpr (PERSIST) {
+                alive = L.flag[2] != 0;
+                if (!alive)
+                    break;                     // a wait timed out: stop this chain
+            }
         }
         double nextchisq = mc3_from_bits(0x7ff8000000000000ull);
         if (!anyout) {
             flags |= 1;
-            nextchisq = block_chisq<WPC, MT, WL, MULTI>(P, L.nextp, L.part, L.flag, L.bufA, L.bufB,
-                                             tile);                  // chain.py:249
+            if constexpr (FAST) {
+                Model<MT> model;
+                model.init_from_lanes(P, npk);
+                nextchisq = block_gauss_model<WPC, MT, MULTI>(P, model, L.part, L.flag, tile);
+            } else {
+                nextchisq = block_chisq<WPC, MT, WL, MULTI>(P, L.nextp, L.part, L.flag, L.bufA,
+                                                            L.bufB, tile);   // chain.py:249
+            }
             MC3_STAMP(3);
             if (wave0) {
                 if (sjump) {                                         // chain.py:251-255
@@ -763,14 +844,15 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
         } else if (outk) {
             atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
         }
-        if (P.trace_iters > 0 && tid == 0) {
+        if (!FAST && P.trace_iters > 0 && tid == 0) {
             const long long trow = (R - P.ctl[1]) * P.thinning + j;
             if (trow >= 0 && trow < P.trace_iters) {
                 P.trace_chisq[trow * P.nlocal + lc] = nextchisq;
                 P.trace_flag[trow * P.nlocal + lc] = flags;
             }
         }
-        block_sync<WPC>();
+        if constexpr (!FAST)
+            block_sync<WPC>();
     }
     if (!alive)
         break;
@@ -817,6 +899,14 @@ __global__ __launch_bounds__(64 * WPC) void persist_kernel(const DevProblem P, c
     run_chain<WPC, MT, WL, MULTI, true>(P, P.ctl[0], nref);
 }
 
+
+// the lean instance (see run_chain): one wave per chain, MT free polynomial
+// coefficients, Gaussian chisq, ndata <= 1024, no priors/shared/fixed/epsilon/trace
+template <int MT, int SMP>
+__global__ __launch_bounds__(64) void persist_fast_kernel(const DevProblem P, const int nref)
+{
+    run_chain<1, MT, false, false, true, SMP, true>(P, P.ctl[0], nref);
+}
 
 // chisq for arbitrary parameter vectors (Chain.eval_model(ret='chisq'))
 template <int WPC, int MT, bool WL>

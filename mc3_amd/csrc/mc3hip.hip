@@ -131,6 +131,7 @@ struct mc3hip_ctx {
     int graph_nodes = 0;
     int persist_refs = 0;           // refreshes per persistent launch, 0 = off
     bool persist_checked = false;
+    bool fast = false;              // lean persistent instance selected
     // comm
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
@@ -189,7 +190,7 @@ void launch_step_t(mc3hip_ctx *c, int roff)
     if (c->P.wlike)
         hipLaunchKernelGGL((step_kernel<WPC, MT, true, false>), dim3(c->P.nlocal),
                            dim3(64 * WPC), c->smem, c->stream, c->P, roff);
-    else if (c->P.ndata > VLANES)
+    else if (c->P.npad > VLANES)
         hipLaunchKernelGGL((step_kernel<WPC, MT, false, true>), dim3(c->P.nlocal),
                            dim3(64 * WPC), c->smem, c->stream, c->P, roff);
     else
@@ -203,12 +204,65 @@ void launch_persist_t(mc3hip_ctx *c, int nref)
     if (c->P.wlike)
         hipLaunchKernelGGL((persist_kernel<WPC, MT, true, false>), dim3(c->P.nlocal),
                            dim3(64 * WPC), c->smem, c->stream, c->P, nref);
-    else if (c->P.ndata > VLANES)
+    else if (c->P.npad > VLANES)
         hipLaunchKernelGGL((persist_kernel<WPC, MT, false, true>), dim3(c->P.nlocal),
                            dim3(64 * WPC), c->smem, c->stream, c->P, nref);
     else
         hipLaunchKernelGGL((persist_kernel<WPC, MT, false, false>), dim3(c->P.nlocal),
                            dim3(64 * WPC), c->smem, c->stream, c->P, nref);
+}
+
+// the lean persistent instance applies when nothing of the general machinery is
+// needed (chain_kernels.h run_chain FAST)
+bool fast_eligible(const mc3hip_ctx *c)
+{
+    const DevProblem &P = c->P;
+    return c->wpc == 1 && !P.wlike && P.ndata <= VLANES && c->mt >= 2 && c->mt <= 4 &&
+           P.nparams == P.nfree && P.nmodel == P.nparams && P.nshare == 0 &&
+           P.ngprior == 0 && P.fepsilon == 0.0 && P.trace_iters == 0 &&
+           (P.sampler == MC3HIP_DEMC || P.sampler == MC3HIP_SNOOKER) &&
+           !getenv("MC3HIP_NO_FAST");
+}
+
+template <int MT>
+void launch_fast_t(mc3hip_ctx *c, int nref)
+{
+    if (c->P.sampler == MC3HIP_DEMC)
+        hipLaunchKernelGGL((persist_fast_kernel<MT, MC3HIP_DEMC>), dim3(c->P.nlocal), dim3(64),
+                           c->smem, c->stream, c->P, nref);
+    else
+        hipLaunchKernelGGL((persist_fast_kernel<MT, MC3HIP_SNOOKER>), dim3(c->P.nlocal),
+                           dim3(64), c->smem, c->stream, c->P, nref);
+}
+
+void launch_fast(mc3hip_ctx *c, int nref)
+{
+    switch (c->mt) {
+    case MT_POLY2: launch_fast_t<MT_POLY2>(c, nref); break;
+    case MT_POLY3: launch_fast_t<MT_POLY3>(c, nref); break;
+    default: launch_fast_t<MT_POLY4>(c, nref); break;
+    }
+}
+
+template <int MT>
+int fast_blocks_per_cu_t(mc3hip_ctx *c)
+{
+    int nb = 0;
+    hipError_t e = (c->P.sampler == MC3HIP_DEMC)
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(
+              &nb, persist_fast_kernel<MT, MC3HIP_DEMC>, 64, c->smem)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(
+              &nb, persist_fast_kernel<MT, MC3HIP_SNOOKER>, 64, c->smem);
+    return e == hipSuccess ? nb : 0;
+}
+
+int fast_blocks_per_cu(mc3hip_ctx *c)
+{
+    switch (c->mt) {
+    case MT_POLY2: return fast_blocks_per_cu_t<MT_POLY2>(c);
+    case MT_POLY3: return fast_blocks_per_cu_t<MT_POLY3>(c);
+    default: return fast_blocks_per_cu_t<MT_POLY4>(c);
+    }
 }
 
 // workgroups of the persistent kernel that fit on one CU (0 on error)
@@ -224,7 +278,7 @@ void persist_blocks_per_cu_t(mc3hip_ctx *c, int *out)
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->smem);
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
             &nb, persist_kernel<WPC, MT, true, false>, 64 * WPC, c->smem);
-    } else if (c->P.ndata > VLANES) {
+    } else if (c->P.npad > VLANES) {
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
             &nb, persist_kernel<WPC, MT, false, true>, 64 * WPC, c->smem);
     } else {
@@ -287,7 +341,11 @@ int decide_persist(mc3hip_ctx *c)
     if ((c->flags & MC3HIP_FLAG_NO_PERSIST) || getenv("MC3HIP_NO_PERSIST"))
         return 0;
     int nb = 0;
-    persist_blocks_per_cu(c, &nb);
+    c->fast = fast_eligible(c);
+    if (c->fast)
+        nb = fast_blocks_per_cu(c);
+    else
+        persist_blocks_per_cu(c, &nb);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess)
         return 0;
@@ -497,16 +555,25 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         TRY(dev_upload(c, &P.fmax, fmax.data(), nf));
         TRY(dev_upload(c, &P.fstep, fstep.data(), nf));
     }
-    const size_t nindep = (pr->model_kind == MC3HIP_MODEL_LINEAR) ? nd * (size_t)pr->nmodel : nd;
-    TRY(dev_upload(c, &P.indep, pr->indep, nindep));
-    TRY(dev_upload(c, &P.data, pr->data, nd));
     {
-        // w = 1/uncert once (IEEE division on the host), so the hot loop multiplies
-        std::vector<double> w(nd, 1.0);
-        if (!pr->wlike)
-            for (size_t i = 0; i < nd; ++i)
-                w[i] = 1.0 / pr->uncert[i];
-        TRY(dev_upload(c, &P.w, w.data(), nd));
+        // Device copies padded to a multiple of 1024 points: x / A columns and data
+        // repeat the last point, w = 1/uncert (IEEE division on the host, so the hot
+        // loop multiplies) is 0 in the padding -- a padded point contributes exactly 0.
+        const size_t npad = (nd + VLANES - 1) / VLANES * VLANES;
+        P.npad = (int32_t)npad;
+        const size_t ncol = (pr->model_kind == MC3HIP_MODEL_LINEAR) ? (size_t)pr->nmodel : 1;
+        std::vector<double> buf(npad * ncol);
+        for (size_t k = 0; k < ncol; ++k)
+            for (size_t i = 0; i < npad; ++i)
+                buf[k * npad + i] = pr->indep[k * nd + (i < nd ? i : nd - 1)];
+        TRY(dev_upload(c, &P.indep, buf.data(), npad * ncol));
+        std::vector<double> d(npad), w(npad, 0.0);
+        for (size_t i = 0; i < npad; ++i)
+            d[i] = pr->data[i < nd ? i : nd - 1];
+        for (size_t i = 0; i < nd; ++i)
+            w[i] = pr->wlike ? 1.0 : 1.0 / pr->uncert[i];
+        TRY(dev_upload(c, &P.data, d.data(), npad));
+        TRY(dev_upload(c, &P.w, w.data(), npad));
     }
     const size_t zl = (size_t)pr->zlen, nl = (size_t)pr->nlocal;
     TRY(dev_alloc(c, &P.Z, zl * nf));
@@ -599,7 +666,7 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
     plan->waves_per_chain = c->wpc;
     plan->graph_nodes = c->graph_nodes;
     plan->persistent = c->comm ? 0 : decide_persist(const_cast<mc3hip_ctx *>(c));
-    plan->reserved = 0;
+    plan->fast = (plan->persistent > 0 && c->fast) ? 1 : 0;
     return MC3HIP_OK;
 }
 
@@ -678,7 +745,10 @@ int mc3hip_run(mc3hip_ctx *c, int64_t nrefresh)
             const int n = (int)(left < persist ? left : persist);
             hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl,
                                (long long)R, first ? run0 : -1LL);
-            launch_persist(c, n);
+            if (c->fast)
+                launch_fast(c, n);
+            else
+                launch_persist(c, n);
             R += n;
         } else if (use_graph && left >= c->graph_nodes) {
             hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl,

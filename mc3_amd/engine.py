@@ -107,7 +107,7 @@ class DeviceChains:
         self.plan = {'vlanes': plan.vlanes, 'tile': plan.tile,
                      'waves_per_chain': plan.waves_per_chain,
                      'graph_nodes': plan.graph_nodes,
-                     'persistent': plan.persistent}
+                     'persistent': plan.persistent, 'fast': plan.fast}
 
     # -- lifetime --------------------------------------------------------------
     def close(self):

@@ -157,18 +157,25 @@ static double halving_tree(double *part, int n)
 static double gauss_chisq(const ls_problem *P, const double *p, double *part)
 {
     const int VL = P->vlanes;
-    const int tile = (P->tile > 0) ? P->tile : P->ndata;
+    /* The kernels pad the data to a multiple of `vlanes` points that repeat the
+     * last point with weight 0: a padded point adds fma(r, r, acc) with
+     * r = (model_last - data_last) * 0.  Spelled out here so that even the
+     * non-finite corner (model = -inf or NaN) is mirrored exactly. */
+    const int npad = (P->ndata + VL - 1) / VL * VL;
+    const int tile = (P->tile > 0) ? P->tile : npad;
     int sawinf = 0;
     double total = 0.0;
-    for (int t0 = 0; t0 < P->ndata; t0 += tile) {
-        const int t1 = (t0 + tile < P->ndata) ? t0 + tile : P->ndata;
+    for (int t0 = 0; t0 < npad; t0 += tile) {
+        const int t1 = (t0 + tile < npad) ? t0 + tile : npad;
         for (int l = 0; l < VL; l++) {
             double acc = 0.0;
             for (int i = t0 + l; i < t1; i += VL) {
-                const double m = model_at(P, p, i);
+                const int ii = (i < P->ndata) ? i : P->ndata - 1;
+                const double m = model_at(P, p, ii);
                 if (m == INFINITY)
                     sawinf = 1;
-                const double r = (m - P->data[i]) * P->w[i];
+                const double wi = (i < P->ndata) ? P->w[ii] : 0.0;
+                const double r = (m - P->data[ii]) * wi;
                 acc = mc3_fma(r, r, acc);
             }
             part[l] = acc;
