@@ -194,6 +194,15 @@ def main():
         structure = 'one launch per refresh' + \
             (f' (hipGraph of {gpu.plan["graph_nodes"]} nodes)' if world == 1 else
              ' + one RCCL all-gather per refresh')
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'r01b_c2_pmc.json')
+    if os.path.exists(pmc) and args.thinning == 1:
+        with open(pmc) as f:
+            rec = json.load(f)
+        if rec['kernel'].startswith(kernel):
+            # HBM bytes per launch from the PMC counters of the same kernel
+            # (separate rocprofv3 --pmc passes, gfx950 FETCH_SIZE correction)
+            traffic = rec['hbm_bytes_per_chain_step']*CHAINS_PER_GPU*args.steps/launches
     launch_s = gpu_ms*1e-3/launches
     bytes_per_launch = BYTES_PER_CHAIN_STEP*CHAINS_PER_GPU*args.thinning*args.steps/launches
     achieved = bytes_per_launch/launch_s/1e9
@@ -218,7 +227,7 @@ def main():
         },
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-            'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBS, 'traffic': None,
+            'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic,
             'kernel': kernel, 'launches': launches,
             'algorithmic_bytes_per_launch': bytes_per_launch,
             'avg_launch_us': launch_s*1e6,
@@ -226,7 +235,9 @@ def main():
                     'per launch / average launch duration (HIP events on the library '
                     'stream over the timed region / launches). x/data/uncert are '
                     'chain-invariant: they live in registers for a whole launch, so '
-                    'hardware HBM traffic is far below the algorithmic figure',
+                    'hardware HBM traffic (traffic: bytes per launch from '
+                    'profiles/r01b_c2_pmc.json, FETCH_SIZE doubled per the gfx950 note) '
+                    'is far below the algorithmic figure',
         },
     }
     if rank == 0:
