@@ -369,3 +369,127 @@ def test_error_paths(eng):
     with pytest.raises(Exception, match='set_population'):
         g.run(1)
     g.close()
+
+
+# ---- BASELINE.json configs 4 and 5 at full size ----------------------------
+def test_config_c4_wavelet_full_size(eng):
+    """C4: wavelet likelihood, ndata = 2^14, 256 chains, snooker -- 12 iterations
+    bit-exact against the oracle (1 chain per CU, 96 KiB of LDS each)."""
+    prob = H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*12)
+    orc, gpu = run_pair(eng, prob, trace=True)
+    assert gpu.plan['waves_per_chain'] == 16
+    assert_same(orc, gpu)
+    gpu.close()
+
+
+def test_config_c5_linear_full_size(eng):
+    """C5 (single-GPU share and the whole ensemble): 10-parameter linear model,
+    ndata = 1e5, Gaussian priors on three parameters, bounds on all, demc."""
+    for nchains, chain0, nlocal in ((512, 0, 512), (512, 128, 128)):
+        prob = H.linear_problem(ndata=100000, nchains=nchains, nsamples=nchains*6)
+        orc = H.make_oracle(prob, chain0=chain0, nlocal=nlocal)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu = eng.DeviceChains(chain0=chain0, nlocal=nlocal, **prob)
+        gpu.set_population(Z0, lp0)
+        nref = 6 if nlocal == nchains else 1      # a shard can only do one refresh alone
+        orc.run(nrefresh=nref, nthreads=4)
+        gpu.run(nref)
+        Z, lp, zc = gpu.rows()
+        st = gpu.state()
+        rows = slice(orc.M0, orc.M0 + nref*nchains)
+        own = np.tile((np.arange(nchains) >= chain0) & (np.arange(nchains) < chain0 + nlocal), nref)
+        np.testing.assert_array_equal(Z[rows][own], orc.Z[rows][own])
+        np.testing.assert_array_equal(lp[rows][own], orc.log_post[rows][own])
+        np.testing.assert_array_equal(st['numaccept'], orc.numaccept[chain0:chain0 + nlocal])
+        np.testing.assert_array_equal(st['outbounds'], orc.outbounds)
+        gpu.close()
+
+
+# ---- edge cases: smallest / ragged / largest shapes -------------------------
+@pytest.mark.parametrize('ndata', [1, 2, 63, 65, 1023, 1024, 1025, 2049, 5000])
+@pytest.mark.parametrize('wpc', ['1', '4'])
+def test_ragged_data_sizes(eng, ndata, wpc):
+    """Data lengths around the 64-lane and 1024-point tile edges (single tile,
+    exactly one tile, one point into the second tile, several tiles)."""
+    prob = H.quad_problem(ndata=max(ndata, 1), nchains=5, nsamples=5*30, sampler='demc')
+    if ndata == 1:
+        prob.update(data=prob['data'][:1], uncert=np.array([1.0]), indep=prob['indep'][:1])
+    os.environ['MC3HIP_WPC'] = wpc
+    try:
+        orc, gpu = run_pair(eng, prob)
+    finally:
+        del os.environ['MC3HIP_WPC']
+    assert_same(orc, gpu)
+    gpu.close()
+
+
+def test_smallest_ensembles_and_single_free_parameter(eng):
+    # demc needs 3 chains (chain.py:223-229); snooker/mrw run with 1
+    for sampler, nchains in (('demc', 3), ('snooker', 1), ('mrw', 1), ('snooker', 2)):
+        prob = H.quad_problem(nchains=nchains, nsamples=nchains*200, sampler=sampler,
+                              hsize=10)
+        orc, gpu = run_pair(eng, prob)
+        assert_same(orc, gpu)
+        gpu.close()
+    # one free parameter: snooker's Hastings exponent (nfree-1)/2 is 0
+    prob = H.quad_problem(nchains=6, nsamples=6*300, sampler='snooker',
+                          pstep=np.array([1.0, 0.0, 0.0]),
+                          params=np.array([3.0, -2.4, 0.5]))
+    orc, gpu = run_pair(eng, prob)
+    assert_same(orc, gpu)
+    gpu.close()
+
+
+@pytest.mark.parametrize('sampler', ['demc', 'snooker'])
+def test_largest_parameter_counts(eng, sampler):
+    """MC3HIP_MAX_FREE = 64 free parameters out of MC3HIP_MAX_PARAMS = 128 (the
+    rest shared with a free one or fixed): a 128-column linear model."""
+    rs = np.random.RandomState(3)
+    ndata, npar = 300, 128
+    A = rs.normal(0, 1, (npar, ndata))
+    p_true = rs.normal(0, 1, npar)
+    pstep = np.zeros(npar)
+    pstep[:64] = 0.02
+    pstep[64:96] = -(np.arange(32) + 1)        # shared with parameters 0..31
+    p_true[64:96] = p_true[0:32]
+    data = p_true @ A + rs.normal(0, 1, ndata)
+    prior = np.zeros(npar)
+    plow = np.zeros(npar)
+    pup = np.zeros(npar)
+    prior[10:20] = p_true[10:20]
+    plow[10:20] = 0.3
+    pup[10:20] = 0.6
+    prob = dict(data=data, uncert=np.ones(ndata), indep=A, params=p_true.copy(),
+                pstep=pstep, pmin=np.full(npar, -6.0), pmax=np.full(npar, 6.0),
+                prior=prior, priorlow=plow, priorup=pup, nchains=70,
+                nsamples=70*40, sampler=sampler, model='linear', seed=11)
+    orc, gpu = run_pair(eng, prob)
+    assert_same(orc, gpu)
+    gpu.close()
+    from mc3_amd import engine
+    with pytest.raises(Exception, match='nfree=65 outside'):
+        ps = pstep.copy()
+        ps[96] = 0.02
+        engine.DeviceChains(**dict(prob, pstep=ps))
+    with pytest.raises(Exception, match='nparams=129 outside'):
+        engine.DeviceChains(**dict(prob, params=np.zeros(129), pstep=np.ones(129),
+                                   pmin=None, pmax=None, prior=None, priorlow=None,
+                                   priorup=None, indep=np.zeros((129, ndata))))
+
+
+def test_nonfinite_models_are_rejected_like_the_reference(eng):
+    """chain.py:322-323 / SURVEY 3.3-6: a +inf model value means chisq = inf
+    (always rejected); a NaN model gives a NaN chisq, and NaN > u is False."""
+    x = np.linspace(0, 10, 50)
+    x[7] = np.inf                                   # p1*inf -> +inf for p1 > 0
+    data = np.ones(50)
+    base = dict(data=data, uncert=np.ones(50), indep=x, params=np.array([1.0, 0.5]),
+                pstep=np.array([0.1, 0.1]), nchains=4, nsamples=40, sampler='demc')
+    with eng.DeviceChains(**base) as g:
+        c = g.eval_chisq(np.array([[1.0, 0.5], [1.0, -0.5], [1.0, 0.0]]))
+        orc = H.make_oracle(base).eval_chisq(np.array([[1.0, 0.5], [1.0, -0.5], [1.0, 0.0]]))
+    assert c[0] == np.inf                           # +inf trapped
+    assert c[1] == np.inf                           # -inf model: (m-d)^2 = inf
+    assert np.isnan(c[2])                           # 0*inf = NaN model
+    np.testing.assert_array_equal(c, orc)

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Throughput of the BASELINE.json configurations other than the headline one
+(bench.py measures C2).  Not the judged bench line: a development tool whose
+output goes to profiles/.
+
+    python tools/bench_configs.py [c2 c3share c4 c5 c5share ...]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from mc3_amd import engine  # noqa: E402
+import helpers as H  # noqa: E402
+
+
+def population(g, prob, seed=5):
+    """In-bounds draws around the start with finite chisq, evaluated on the device."""
+    rs = np.random.RandomState(seed)
+    ifree = g.ifree
+    Z0 = np.empty((0, g.nfree))
+    lp0 = np.empty(0)
+    while len(Z0) < g.M0:
+        trial = rs.normal(g.params[ifree], g.pstep[ifree], (2*g.M0, g.nfree))
+        full = g.expand_free(trial)
+        ok = np.all((full >= g.pmin) & (full <= g.pmax), axis=1)
+        lp = -0.5*g.eval_chisq(full[ok])
+        fin = np.isfinite(lp)
+        Z0 = np.concatenate([Z0, trial[ok][fin]])
+        lp0 = np.concatenate([lp0, lp[fin]])
+    return np.ascontiguousarray(Z0[:g.M0]), np.ascontiguousarray(lp0[:g.M0])
+
+
+CONFIGS = {
+    'c2': lambda n: (H.quad_problem(ndata=1000, nchains=256, nsamples=256*n, sampler='demc'), {}),
+    'c2snooker': lambda n: (H.quad_problem(ndata=1000, nchains=256, nsamples=256*n,
+                                           sampler='snooker'), {}),
+    'c3one': lambda n: (H.quad_problem(ndata=1000, nchains=2048, nsamples=2048*n,
+                                       sampler='demc'), {}),
+    'c4': lambda n: (H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*n), {}),
+    'c5': lambda n: (H.linear_problem(ndata=100000, nchains=512, nsamples=512*n), {}),
+    'c5share': lambda n: (H.linear_problem(ndata=100000, nchains=512, nsamples=512*n),
+                          dict(chain0=0, nlocal=128)),
+}
+BYTES = {'c2': 24104, 'c2snooker': 24104, 'c3one': 24104, 'c4': 8*2*16384 + 8*5*4 + 8,
+         'c5': 8*12*100000 + 8*10*4 + 8, 'c5share': 8*12*100000 + 8*10*4 + 8}
+ITERS = {'c2': 20000, 'c2snooker': 20000, 'c3one': 4000, 'c4': 400, 'c5': 30, 'c5share': 1}
+
+
+def main():
+    names = sys.argv[1:] or ['c2', 'c2snooker', 'c3one', 'c4', 'c5']
+    for name in names:
+        n = ITERS[name]
+        prob, extra = CONFIGS[name](n + max(2, n//10))
+        g = engine.DeviceChains(**prob, **extra)
+        Z0, lp0 = population(g, prob)
+        g.set_population(Z0, lp0)
+        if name != 'c5share':
+            g.run(max(2, n//10))
+        t0 = time.perf_counter()
+        g.run(n)
+        dt = time.perf_counter() - t0
+        steps = g.nlocal*n*g.thinning
+        rate = steps/dt/1e6
+        acc = g.state()['numaccept'].sum()/(g.nlocal*g.refresh_done*g.thinning)
+        print(json.dumps({
+            'config': name, 'nchains': g.nchains, 'nlocal': g.nlocal, 'ndata': g.ndata,
+            'sampler': g.sampler, 'wlike': g.wlike, 'iterations': n,
+            'million_chain_steps_per_s': round(rate, 3),
+            'us_per_iteration': round(dt/n*1e6, 2),
+            'algorithmic_GBps': round(rate*1e6*BYTES[name]/1e9, 1),
+            'frac_of_8TBps': round(rate*1e6*BYTES[name]/8e12, 4),
+            'plan': g.plan, 'acceptance': round(float(acc), 3)}), flush=True)
+        g.close()
+
+
+if __name__ == '__main__':
+    main()
