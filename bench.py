@@ -136,8 +136,11 @@ def main():
                      '(one process per GPU)')
         args.gpus = world
 
+    # MC3HIP_BENCH_FORCE_COMM=1 drives the multi-rank code path (gloo group, RCCL
+    # communicator, one all-gather per refresh) with a single rank, for testing
+    force_comm = bool(os.environ.get('MC3HIP_BENCH_FORCE_COMM')) and world == 1
     dist = None
-    if world > 1:
+    if world > 1 or force_comm:
         import torch
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -152,14 +155,14 @@ def main():
                               nlocal=CHAINS_PER_GPU, **prob)
     Z0, lp0 = initial_population(prob, gpu.eval_chisq)
     gpu.set_population(Z0, lp0)
-    if world > 1:
+    if world > 1 or force_comm:
         ids = [engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         gpu.comm_init(ids[0], rank, world)
 
     def barrier():
         gpu.sync()
-        if world > 1:
+        if world > 1 or force_comm:
             torch.cuda.synchronize(local_rank)
             dist.barrier()
 
@@ -170,7 +173,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gpu_ms = gpu.last_run_ms()          # HIP events on the library's stream
-    if world > 1:
+    if world > 1 or force_comm:
         t = torch.tensor([dt, gpu_ms], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, gpu_ms = float(t[0]), float(t[1])
@@ -182,7 +185,8 @@ def main():
 
     # roofline of the dominant (only) kernel.  Persistent path: one launch covers
     # `persistent` refreshes; per-refresh path: one launch per refresh.
-    per = gpu.plan['persistent'] if world == 1 else 0
+    multi = world > 1 or force_comm
+    per = 0 if multi else gpu.plan['persistent']
     if per > 0:
         launches = -(-args.steps//per)
         kernel = 'mc3hip::persist_fast_kernel' if gpu.plan['fast'] else 'mc3hip::persist_kernel'
@@ -192,8 +196,8 @@ def main():
         launches = args.steps
         kernel = 'mc3hip::step_kernel'
         structure = 'one launch per refresh' + \
-            (f' (hipGraph of {gpu.plan["graph_nodes"]} nodes)' if world == 1 else
-             ' + one RCCL all-gather per refresh')
+            (' + one RCCL all-gather per refresh' if multi else
+             f' (hipGraph of {gpu.plan["graph_nodes"]} nodes)')
     traffic = None
     pmc = os.path.join(ROOT, 'profiles', 'r01b_c2_pmc.json')
     if os.path.exists(pmc) and args.thinning == 1:
@@ -245,7 +249,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
     gpu.close()
-    if world > 1:
+    if world > 1 or force_comm:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -54,7 +54,17 @@ struct DevProblem {
     int32_t *trace_flag;
     const long long *ctl;   // ctl[0] = refresh base of this replay, ctl[1] = first refresh of the run
     unsigned long long *stamps;   // diagnostic build only (MC3HIP_STAMPS): s_memtime per phase
+    // tiled plan (large ndata): proposal / data sum / accept are separate launches
+    int32_t tile, ntiles;         // points per tile (0 = fused plan), tiles in npad
+    double *sc_nextp;             // [nlocal][nparams] proposed parameter vectors
+    double *sc_npk;               // [nlocal][nfree]   proposed free parameters
+    double *sc_scal;              // [nlocal][2]       Metropolis draw u, Hastings factor
+    int32_t *sc_flag;             // [nlocal]          bit0 out of bounds, bit1 snooker jump
+    double *sc_part;              // [nlocal][ntiles]  per-tile data sums
 };
+
+constexpr int PH_FUSED = 0, PH_PROPOSE = 1, PH_FINISH = 2;
+constexpr int SC_STRIDE = MC3HIP_MAX_PARAMS + 16;   // doubles per sc_nextp row (zero padded)
 
 // In-kernel phase stamps for the diagnostic build (never compiled into the product
 // library): drain outstanding memory operations, then read the shader clock.
@@ -540,6 +550,134 @@ static inline size_t smem_bytes(int nthreads, int ndata, int wlike)
 }
 
 // ---- the chain update -------------------------------------------------------
+// ---- tiled plan: data sums for every chain, one launch ------------------------
+// For large ndata the fused kernel would make every chain stream the whole data
+// set (and the design matrix) through its own workgroup.  Here a workgroup keeps
+// ONE tile of (A or x, data, w) in registers -- 1024 threads, thread l owns virtual
+// lane l with its TP points (tile = 1024*TP: 4096 for <= 4 coefficients, 2048 above,
+// so that tile + 16 partial sums fit the 128-register budget of a 1024-thread group) -- and loops over a block of chains, so
+// the tile is read once per launch instead of once per chain.  Chains are taken
+// 16 at a time: every thread produces 16 partial sums, one LDS exchange, then
+// wave g reduces chain g over the 1024 lanes in the canonical order (strides
+// 512..64 across waves, 32..1 inside the wave).  Output: sc_part[chain][tile];
+// the finish kernel adds the tiles in order.
+template <int KMAX, bool LINEAR, int TP>
+__global__ __launch_bounds__(1024) void tile_chisq_kernel(
+    const DevProblem P, const int chain_block,
+    // separate read-only kernel arguments so that the wave-uniform coefficient reads
+    // become scalar loads (s_load) instead of 64-lane vector loads
+    const double *__restrict__ nextp, const int32_t *__restrict__ out_of_bounds)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_x[];   // [16][1024]
+    const int l = threadIdx.x, lane = l & 63, wv = l >> 6;
+    const int t = blockIdx.x;
+    const int K = P.nmodel;
+    const size_t base = (size_t)t * (1024 * TP) + l;      // TP points per thread
+    double a[TP][LINEAR ? KMAX : 1], d[TP], w[TP];
+#pragma unroll
+    for (int q = 0; q < TP; ++q) {
+        const size_t i = base + 1024 * q;
+        d[q] = P.data[i];
+        w[q] = P.w[i];
+        if constexpr (LINEAR) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                a[q][k] = (k < K) ? P.indep[(size_t)k * P.npad + i] : 0.0;
+        } else {
+            a[q][0] = P.indep[i];
+        }
+    }
+    const int c0 = blockIdx.y * chain_block;
+    const int c1 = (c0 + chain_block < P.nlocal) ? c0 + chain_block : P.nlocal;
+    for (int cb = c0; cb < c1; cb += 16) {
+        double part[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int lc = cb + g;
+            double acc = 0.0;
+            if (lc < c1 && !(out_of_bounds[lc] & 1)) {
+                // coefficients beyond K read the (zeroed) padding of the scratch row
+                double cf[KMAX];
+                const double *__restrict__ np = nextp + (size_t)lc * SC_STRIDE;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    cf[k] = np[k];
+#pragma unroll
+                for (int q = 0; q < TP; ++q) {
+                    double m;
+                    if constexpr (LINEAR) {
+                        // columns k >= K are zero in registers and in cf: the extra
+                        // fma(0, 0, m) leave m unchanged, no per-term guard needed
+                        m = a[q][0] * cf[0];
+#pragma unroll
+                        for (int k = 1; k < KMAX; ++k)
+                            m = mc3_fma(a[q][k], cf[k], m);
+                    } else {
+                        m = 0.0;                  // Horner from coefficient K-1 down
+#pragma unroll
+                        for (int k = KMAX - 1; k >= 0; --k) {
+                            if (k == K - 1)
+                                m = cf[k];
+                            else if (k < K - 1)
+                                m = mc3_fma(m, a[q][0], cf[k]);
+                        }
+                    }
+                    const double r = (m - d[q]) * w[q];
+                    acc = mc3_fma(r, r, acc);
+                }
+            }
+            part[g] = acc;
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g)
+            s_x[g * 1024 + l] = part[g];
+        block_sync<16>();
+        {
+            const int lc = cb + wv;                     // wave wv reduces chain cb + wv
+            double p[16];
+#pragma unroll
+            for (int w2 = 0; w2 < 16; ++w2)
+                p[w2] = s_x[wv * 1024 + lane + 64 * w2];
+#pragma unroll
+            for (int s2 = 8; s2 >= 1; s2 >>= 1) {
+#pragma unroll
+                for (int w2 = 0; w2 < s2; ++w2)
+                    p[w2] = p[w2] + p[w2 + s2];
+            }
+            const double tot = wave_sum(p[0]);
+            if (lane == 0 && lc < c1)
+                P.sc_part[(size_t)lc * P.ntiles + t] = tot;
+        }
+        block_sync<16>();
+    }
+}
+
+// chisq of a chain from the per-tile sums (tiles added in order) plus the prior
+// term.  The +inf-model trap of chain.py:322-323 is resolved lazily: a +inf model
+// value always makes the sum non-finite (w > 0), so only a non-finite sum needs
+// the scan that tells "+inf model" (chisq = inf) from any other overflow.
+template <int MT>
+__device__ __forceinline__ double finish_chisq(const DevProblem &P, int lc)
+{
+    const double *np = P.sc_nextp + (size_t)lc * SC_STRIDE;
+    double total = 0.0;
+    for (int t = 0; t < P.ntiles; ++t)
+        total = total + P.sc_part[(size_t)lc * P.ntiles + t];
+    const bool finite = (mc3_bits(total) & 0x7ff0000000000000ull) != 0x7ff0000000000000ull;
+    if (!finite) {
+        Model<MT> model;
+        model.init(P, np);
+        int saw = 0;
+        for (int i = threadIdx.x; i < P.ndata; i += blockDim.x)
+            saw |= is_pos_inf(model.at(i));
+        if (__any(saw))
+            return mc3_from_bits(0x7ff0000000000000ull);
+    }
+    if (is_pos_inf(total))
+        return total;
+    return total + prior_term(P, np);
+}
+
 // A Z row read through the in-launch hand-off (persistent kernel): rows are
 // published with agent-scope 8-byte stores and consumed with agent-scope loads
 // (sc1: they bypass the CU's L1, which another CU's stores never refresh); a row
@@ -619,10 +757,18 @@ __device__ __forceinline__ Draws make_draws(const DevProblem &P, uint64_t iter, 
 // trace: the proposal goes from lanes to the model through v_readlane instead of
 // LDS and all the dead generality (and its scalar-register pressure) is compiled
 // out.  Same arithmetic, same results.
-template <int WPC, int MT, bool WL, bool MULTI, bool PERSIST, int SMP = -1, bool FAST = false>
+//
+// PHASE splits one iteration over three launches for the tiled plan: PH_PROPOSE
+// stops after the proposal (written to global scratch), a tile kernel computes the
+// data sums for all chains, PH_FINISH resumes at the Metropolis test.  jb..je is the
+// range of iterations of the refresh this call covers (fused: 0..thinning).
+template <int WPC, int MT, bool WL, bool MULTI, bool PERSIST, int SMP = -1, bool FAST = false,
+          int PHASE = PH_FUSED>
 __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R0,
-                                          const int nref)
+                                          const int nref, const int jb = 0, int je = -1)
 {
+    if (je < 0)
+        je = P.thinning;
     static_assert(!FAST || (WPC == 1 && !WL && !MULTI && SMP >= 0 && MT >= 1 && MT <= 8),
                   "FAST needs one wave, Gaussian chisq, a compile-time sampler and degree");
     const int sampler = (SMP >= 0) ? SMP : P.sampler;
@@ -641,13 +787,16 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     // (registers, kept for all iterations of the launch), the chain state, the
     // per-parameter bounds and the fixed parameter values.
     DataTile<WPC, MT> tile;
-    if constexpr (!WL)
+    if constexpr (!WL && PHASE == PH_FUSED)
         tile.load(P);
     // own state = this chain's row of the first snapshot (same pages as the partner
-    // rows requested a few hundred cycles later, so their translation is warm)
+    // rows requested a few hundred cycles later, so their translation is warm); in
+    // the middle of a refresh (tiled plan, thinning > 1) it is the saved state
     const double *snap_first = (R0 == 0) ? P.snap0
                                          : P.Z + (size_t)(P.M0 + (R0 - 1) * P.nchains) * nf;
-    double xk = mine ? snap_first[(size_t)c * nf + lane] : 0.0;
+    double xk = 0.0;
+    if (mine)
+        xk = (jb == 0) ? snap_first[(size_t)c * nf + lane] : P.X[(size_t)lc * nf + lane];
     double cur = P.chisq[lc];
     double best = P.best_chisq[lc];
     const long long nacc0 = P.numaccept[lc];
@@ -667,12 +816,12 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     // are wave-uniform, so Philox runs on the scalar unit (every wave repeats it),
     // and the next iteration's are computed while this iteration's partner rows
     // are in flight.
-    Draws nxt = make_draws(P, (uint64_t)(R0 * P.thinning), c, sampler);
+    Draws nxt = make_draws(P, (uint64_t)(R0 * P.thinning + jb), c, sampler);
     for (long long R = R0; R < R0 + nref && alive; ++R) {
     const double *snap = (R == 0) ? P.snap0
                                   : P.Z + (size_t)(P.M0 + (R - 1) * P.nchains) * nf;
     const long long zsize = P.M0 + R * P.nchains;
-    for (int j = 0; j < P.thinning; ++j) {
+    for (int j = jb; j < je; ++j) {
         const uint64_t iter = (uint64_t)(R * P.thinning + j);
         double npk = 0.0, zk = 0.0, u = 0.0;
         double mrfactor = 1.0;
@@ -683,7 +832,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
             nxt = make_draws(P, iter + 1, c, sampler);
         // Metropolis draw, chain.py:259
         u = (sampler == MC3HIP_SNOOKER) ? u01(d2.q1) : u01(d0.q1);
-        if (wave0) {
+        if (PHASE != PH_FINISH && wave0) {
             // support-distribution draw, chain.py:185
             double normal_k = 0.0;
             if (need_normal && mine) {
@@ -791,6 +940,42 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 L.flag[2] = alive ? 1 : 0;
             }
             }
+            if constexpr (PHASE == PH_PROPOSE) {
+                // hand the proposal to the tile and finish kernels
+                if (sjump && !anyout) {                              // chain.py:251-255
+                    const double dc = xk - zk, dn = npk - zk;
+                    const double cnorm = lane_serial_sum(mine ? dc * dc : 0.0, nf);
+                    const double nnorm = lane_serial_sum(mine ? dn * dn : 0.0, nf);
+                    mrfactor = mc3_det_pow_half(nnorm / cnorm, nf - 1);
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int q = lane; q < P.nparams; q += 64)
+                    P.sc_nextp[(size_t)lc * SC_STRIDE + q] = L.nextp[q];
+                if (mine)
+                    P.sc_npk[(size_t)lc * nf + lane] = npk;
+                if (lane == 0) {
+                    P.sc_scal[2 * lc] = u;
+                    P.sc_scal[2 * lc + 1] = mrfactor;
+                    P.sc_flag[lc] = (anyout ? 1 : 0) | (sjump ? 2 : 0);
+                }
+                if (outk)
+                    atomicAdd(&P.outbounds[lane], 1ull);             // chain.py:242-243
+                return;
+            }
+        }
+        if constexpr (PHASE == PH_FINISH) {
+            // resume: the proposal and its scalars come back from global scratch
+            const int fl = P.sc_flag[lc];
+            npk = mine ? P.sc_npk[(size_t)lc * nf + lane] : 0.0;
+            u = P.sc_scal[2 * lc];
+            mrfactor = P.sc_scal[2 * lc + 1];
+            sjump = (fl & 2) != 0;
+            if (sjump)
+                flags |= 4;
+            if (tid == 0) {
+                L.flag[0] = fl & 1;
+                L.flag[2] = 1;
+            }
         }
         bool anyout;
         if constexpr (FAST) {
@@ -814,13 +999,15 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 Model<MT> model;
                 model.init_from_lanes(P, npk);
                 nextchisq = block_gauss_model<WPC, MT, MULTI>(P, model, L.part, L.flag, tile);
+            } else if constexpr (PHASE == PH_FINISH) {
+                nextchisq = finish_chisq<MT>(P, lc);
             } else {
                 nextchisq = block_chisq<WPC, MT, WL, MULTI>(P, L.nextp, L.part, L.flag, L.bufA,
                                                             L.bufB, tile);   // chain.py:249
             }
             MC3_STAMP(3);
             if (wave0) {
-                if (sjump) {                                         // chain.py:251-255
+                if (PHASE != PH_FINISH && sjump) {                   // chain.py:251-255
                     const double dc = xk - zk, dn = npk - zk;
                     const double cnorm = lane_serial_sum(mine ? dc * dc : 0.0, nf);
                     const double nnorm = lane_serial_sum(mine ? dn * dn : 0.0, nf);
@@ -841,7 +1028,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                     }
                 }
             }
-        } else if (outk) {
+        } else if (PHASE != PH_FINISH && outk) {
             atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
         }
         if (!FAST && P.trace_iters > 0 && tid == 0) {
@@ -857,7 +1044,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     if (!alive)
         break;
     // Z append, chain.py:276-289 (strided slot M0 + ID + k*nchains)
-    if (wave0) {
+    if (wave0 && je == P.thinning) {
         const long long row = P.M0 + R * P.nchains + c;
         if (mine) {
             if constexpr (PERSIST)
@@ -899,6 +1086,21 @@ __global__ __launch_bounds__(64 * WPC) void persist_kernel(const DevProblem P, c
     run_chain<WPC, MT, WL, MULTI, true>(P, P.ctl[0], nref);
 }
 
+
+// tiled plan: proposal and Metropolis/accept halves of one iteration (one wave per chain)
+template <int MT>
+__global__ __launch_bounds__(64) void propose_kernel(const DevProblem P, const int roff,
+                                                     const int j)
+{
+    run_chain<1, MT, false, false, false, -1, false, PH_PROPOSE>(P, P.ctl[0] + roff, 1, j, j + 1);
+}
+
+template <int MT>
+__global__ __launch_bounds__(64) void finish_kernel(const DevProblem P, const int roff,
+                                                    const int j)
+{
+    run_chain<1, MT, false, false, false, -1, false, PH_FINISH>(P, P.ctl[0] + roff, 1, j, j + 1);
+}
 
 // the lean instance (see run_chain): one wave per chain, MT free polynomial
 // coefficients, Gaussian chisq, ndata <= 1024, no priors/shared/fixed/epsilon/trace

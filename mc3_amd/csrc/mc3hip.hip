@@ -132,6 +132,8 @@ struct mc3hip_ctx {
     int persist_refs = 0;           // refreshes per persistent launch, 0 = off
     bool persist_checked = false;
     bool fast = false;              // lean persistent instance selected
+    int tile_kmax = 0;              // tiled plan: coefficient capacity of the tile kernel
+    int tile_chain_block = 0;       // chains per workgroup column of the tile kernel
     // comm
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
@@ -210,6 +212,76 @@ void launch_persist_t(mc3hip_ctx *c, int nref)
     else
         hipLaunchKernelGGL((persist_kernel<WPC, MT, false, false>), dim3(c->P.nlocal),
                            dim3(64 * WPC), c->smem, c->stream, c->P, nref);
+}
+
+template <int MT>
+void launch_propose_t(mc3hip_ctx *c, int roff, int j)
+{
+    hipLaunchKernelGGL((propose_kernel<MT>), dim3(c->P.nlocal), dim3(64), c->smem, c->stream,
+                       c->P, roff, j);
+}
+template <int MT>
+void launch_finish_t(mc3hip_ctx *c, int roff, int j)
+{
+    hipLaunchKernelGGL((finish_kernel<MT>), dim3(c->P.nlocal), dim3(64), c->smem, c->stream,
+                       c->P, roff, j);
+}
+#define DISPATCH_MT1(FN, ...)                                                       \
+    switch (c->mt) {                                                                \
+    case MT_POLY2: FN<MT_POLY2>(__VA_ARGS__); break;                                \
+    case MT_POLY3: FN<MT_POLY3>(__VA_ARGS__); break;                                \
+    case MT_POLY4: FN<MT_POLY4>(__VA_ARGS__); break;                                \
+    case MT_LINEAR: FN<MT_LINEAR>(__VA_ARGS__); break;                              \
+    default: FN<MT_POLY_GENERIC>(__VA_ARGS__); break;                               \
+    }
+
+template <int KMAX, bool LINEAR>
+void launch_tile_t(mc3hip_ctx *c)
+{
+    const int ncol = (c->P.nlocal + c->tile_chain_block - 1) / c->tile_chain_block;
+    constexpr int TP = KMAX <= 4 ? 4 : 2;
+    hipLaunchKernelGGL((tile_chisq_kernel<KMAX, LINEAR, TP>), dim3(c->P.ntiles, ncol),
+                       dim3(1024), 16 * 1024 * sizeof(double), c->stream, c->P,
+                       c->tile_chain_block, (const double *)c->P.sc_nextp,
+                       (const int32_t *)c->P.sc_flag);
+}
+
+int tile_set_attr(mc3hip_ctx *c)
+{
+    const int bytes = 16 * 1024 * (int)sizeof(double);
+#define TILE_ATTR(KMAX, LIN)                                                               \
+    HIP_TRY(hipFuncSetAttribute(                                                           \
+        reinterpret_cast<const void *>(&tile_chisq_kernel<KMAX, LIN, (KMAX <= 4 ? 4 : 2)>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    const bool lin = c->mt == MT_LINEAR;
+    switch (c->tile_kmax) {
+    case 4: if (lin) { TILE_ATTR(4, true) } else { TILE_ATTR(4, false) } break;
+    case 8: if (lin) { TILE_ATTR(8, true) } else { TILE_ATTR(8, false) } break;
+    case 12: if (lin) { TILE_ATTR(12, true) } else { TILE_ATTR(12, false) } break;
+    default: if (lin) { TILE_ATTR(16, true) } else { TILE_ATTR(16, false) } break;
+    }
+    return MC3HIP_OK;
+}
+
+void launch_tile(mc3hip_ctx *c)
+{
+    const bool lin = c->mt == MT_LINEAR;
+    switch (c->tile_kmax) {
+    case 4: lin ? launch_tile_t<4, true>(c) : launch_tile_t<4, false>(c); break;
+    case 8: lin ? launch_tile_t<8, true>(c) : launch_tile_t<8, false>(c); break;
+    case 12: lin ? launch_tile_t<12, true>(c) : launch_tile_t<12, false>(c); break;
+    default: lin ? launch_tile_t<16, true>(c) : launch_tile_t<16, false>(c); break;
+    }
+}
+
+// one refresh of the tiled plan: thinning x (propose, tile sums, finish)
+void launch_refresh_tiled(mc3hip_ctx *c, int roff)
+{
+    for (int j = 0; j < c->P.thinning; ++j) {
+        DISPATCH_MT1(launch_propose_t, c, roff, j)
+        launch_tile(c);
+        DISPATCH_MT1(launch_finish_t, c, roff, j)
+    }
 }
 
 // the lean persistent instance applies when nothing of the general machinery is
@@ -323,9 +395,17 @@ void launch_model_t(mc3hip_ctx *c)
     default: DISPATCH_MT(FN, 1, __VA_ARGS__) break;                                 \
     }
 
-void launch_step(mc3hip_ctx *c, int roff) { DISPATCH(launch_step_t, c, roff) }
+void launch_step_fused(mc3hip_ctx *c, int roff) { DISPATCH(launch_step_t, c, roff) }
 void launch_persist(mc3hip_ctx *c, int nref) { DISPATCH(launch_persist_t, c, nref) }
 void persist_blocks_per_cu(mc3hip_ctx *c, int *out) { DISPATCH(persist_blocks_per_cu_t, c, out) }
+
+void launch_step(mc3hip_ctx *c, int roff)
+{
+    if (c->P.tile > 0)
+        launch_refresh_tiled(c, roff);
+    else
+        launch_step_fused(c, roff);
+}
 
 // The persistent kernel spins on rows other workgroups publish, so EVERY workgroup
 // of its grid must be resident at once.  Residency comes from the grid size alone:
@@ -338,7 +418,7 @@ int decide_persist(mc3hip_ctx *c)
         return c->persist_refs;
     c->persist_checked = true;
     c->persist_refs = 0;
-    if ((c->flags & MC3HIP_FLAG_NO_PERSIST) || getenv("MC3HIP_NO_PERSIST"))
+    if ((c->flags & MC3HIP_FLAG_NO_PERSIST) || getenv("MC3HIP_NO_PERSIST") || c->P.tile > 0)
         return 0;
     int nb = 0;
     c->fast = fast_eligible(c);
@@ -559,8 +639,15 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         // Device copies padded to a multiple of 1024 points: x / A columns and data
         // repeat the last point, w = 1/uncert (IEEE division on the host, so the hot
         // loop multiplies) is 0 in the padding -- a padded point contributes exactly 0.
-        const size_t npad = (nd + VLANES - 1) / VLANES * VLANES;
+        // tiled plan (chain_kernels.h tile_chisq_kernel): Gaussian chisq over at least
+        // four 4096-point tiles, enough chains to amortise a tile, <= 16 coefficients
+        const bool tiled = !pr->wlike && nd >= 4 * 4096 && pr->nlocal >= 16 &&
+                           pr->nmodel <= 16 && !getenv("MC3HIP_NO_TILED");
+        P.tile = tiled ? (pr->nmodel <= 4 ? 4096 : 2048) : 0;
+        const size_t unit = tiled ? (size_t)P.tile : VLANES;
+        const size_t npad = (nd + unit - 1) / unit * unit;
         P.npad = (int32_t)npad;
+        P.ntiles = tiled ? (int32_t)(npad / unit) : 0;
         const size_t ncol = (pr->model_kind == MC3HIP_MODEL_LINEAR) ? (size_t)pr->nmodel : 1;
         std::vector<double> buf(npad * ncol);
         for (size_t k = 0; k < ncol; ++k)
@@ -595,6 +682,19 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         TRY(dev_alloc(c, &P.trace_chisq, (size_t)P.trace_iters * nl));
         TRY(dev_alloc(c, &P.trace_flag, (size_t)P.trace_iters * nl));
     }
+    if (P.tile > 0) {
+        TRY(dev_alloc(c, &P.sc_nextp, nl * (size_t)SC_STRIDE));
+        HIP_TRY_C(hipMemset(P.sc_nextp, 0, nl * (size_t)SC_STRIDE * sizeof(double)));
+        TRY(dev_alloc(c, &P.sc_npk, nl * nf));
+        TRY(dev_alloc(c, &P.sc_scal, nl * 2));
+        TRY(dev_alloc(c, &P.sc_flag, nl));
+        TRY(dev_alloc(c, &P.sc_part, nl * (size_t)P.ntiles));
+        c->tile_kmax = pr->nmodel <= 4 ? 4 : pr->nmodel <= 8 ? 8 : pr->nmodel <= 12 ? 12 : 16;
+        // chains per workgroup column: aim at two waves of workgroups over the CUs
+        int cb = (int)((nl * (size_t)P.ntiles + 511) / 512);
+        cb = (cb + 15) / 16 * 16;
+        c->tile_chain_block = cb < 16 ? 16 : cb;
+    }
     TRY(dev_alloc(c, &c->ctl, 4));
     P.ctl = c->ctl;
     TRY(dev_alloc(c, &P.stamps, 16));
@@ -622,6 +722,11 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         return fail(MC3HIP_ERR_ARG, "problem needs %zu bytes of LDS (> 160 KiB)", c->smem);
     }
     TRY(set_smem_attr(c));
+    if (P.tile > 0) {
+        TRY(tile_set_attr(c));
+        if (pr->thinning > 16)
+            c->flags |= MC3HIP_FLAG_NO_GRAPH;       // keep the captured graph small
+    }
     c->graph_nodes = (c->flags & MC3HIP_FLAG_NO_GRAPH) ? 0 : 256;
     if (getenv("MC3HIP_NO_GRAPH"))
         c->graph_nodes = 0;
@@ -662,7 +767,7 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
     if (!c || !plan)
         return fail(MC3HIP_ERR_ARG, "null argument");
     plan->vlanes = VLANES;
-    plan->tile = 0;
+    plan->tile = c->P.tile;
     plan->waves_per_chain = c->wpc;
     plan->graph_nodes = c->graph_nodes;
     plan->persistent = c->comm ? 0 : decide_persist(const_cast<mc3hip_ctx *>(c));

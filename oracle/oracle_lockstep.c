@@ -161,7 +161,8 @@ static double gauss_chisq(const ls_problem *P, const double *p, double *part)
      * last point with weight 0: a padded point adds fma(r, r, acc) with
      * r = (model_last - data_last) * 0.  Spelled out here so that even the
      * non-finite corner (model = -inf or NaN) is mirrored exactly. */
-    const int npad = (P->ndata + VL - 1) / VL * VL;
+    const int unit = (P->tile > 0) ? P->tile : VL;
+    const int npad = (P->ndata + unit - 1) / unit * unit;
     const int tile = (P->tile > 0) ? P->tile : npad;
     int sawinf = 0;
     double total = 0.0;

@@ -24,11 +24,12 @@ def eng():
 
 
 def run_pair(eng, prob, trace=True, nrefresh=None, **gpu_kw):
-    orc = H.make_oracle(prob)
+    niter = int(np.ceil(prob['nsamples']/prob['nchains']))
+    gpu = eng.DeviceChains(trace_iters=niter if trace else 0, **prob, **gpu_kw)
+    # the oracle sums the data in the order ("plan") the library reports
+    orc = H.make_oracle(prob, tile=gpu.plan['tile'], vlanes=gpu.plan['vlanes'])
     Z0, lp0 = H.initial_population(orc)
     orc.set_population(Z0, lp0)
-    niter = orc.nzchain*orc.thinning
-    gpu = eng.DeviceChains(trace_iters=niter if trace else 0, **prob, **gpu_kw)
     gpu.set_population(Z0, lp0)
     assert gpu.plan['vlanes'] == orc.P.vlanes
     orc.run(nrefresh=nrefresh, trace=trace, nthreads=4)
@@ -387,10 +388,11 @@ def test_config_c5_linear_full_size(eng):
     ndata = 1e5, Gaussian priors on three parameters, bounds on all, demc."""
     for nchains, chain0, nlocal in ((512, 0, 512), (512, 128, 128)):
         prob = H.linear_problem(ndata=100000, nchains=nchains, nsamples=nchains*6)
-        orc = H.make_oracle(prob, chain0=chain0, nlocal=nlocal)
+        gpu = eng.DeviceChains(chain0=chain0, nlocal=nlocal, **prob)
+        assert gpu.plan['tile'] == 2048                 # the tiled plan (10 coefficients)
+        orc = H.make_oracle(prob, chain0=chain0, nlocal=nlocal, tile=gpu.plan['tile'])
         Z0, lp0 = H.initial_population(orc)
         orc.set_population(Z0, lp0)
-        gpu = eng.DeviceChains(chain0=chain0, nlocal=nlocal, **prob)
         gpu.set_population(Z0, lp0)
         nref = 6 if nlocal == nchains else 1      # a shard can only do one refresh alone
         orc.run(nrefresh=nref, nthreads=4)
@@ -493,3 +495,43 @@ def test_nonfinite_models_are_rejected_like_the_reference(eng):
     assert c[1] == np.inf                           # -inf model: (m-d)^2 = inf
     assert np.isnan(c[2])                           # 0*inf = NaN model
     np.testing.assert_array_equal(c, orc)
+
+
+@pytest.mark.parametrize('kind,sampler,thinning', [
+    ('poly', 'demc', 1), ('poly', 'snooker', 2), ('linear', 'demc', 3),
+    ('linear', 'snooker', 1)])
+def test_tiled_plan_bit_exact(eng, kind, sampler, thinning):
+    """Large ndata takes the tiled plan (proposal / per-tile data sums for all
+    chains / accept as separate launches): 20 000 points = 5 tiles of 4096, with
+    priors, bounds, a shared and a fixed parameter."""
+    if kind == 'poly':
+        prob = H.quad_problem(ndata=20000, nchains=40, nsamples=40*25*thinning,
+                              sampler=sampler, thinning=thinning,
+                              prior=np.array([3.0, 0.0, 0.5]),
+                              priorlow=np.array([0.5, 0.0, 0.02]),
+                              priorup=np.array([0.25, 0.0, 0.04]))
+    else:
+        prob = H.linear_problem(ndata=20000, nmodel=7, nchains=40,
+                                nsamples=40*25*thinning, sampler=sampler,
+                                thinning=thinning)
+        prob['pstep'] = prob['pstep'].copy()
+        prob['pstep'][5] = -2          # shared with parameter 1
+        prob['pstep'][6] = 0.0         # fixed
+        prob['params'] = prob['params'].copy()
+        prob['params'][5] = prob['params'][1]
+    orc, gpu = run_pair(eng, prob)
+    assert gpu.plan['tile'] == (4096 if kind == 'poly' else 2048) and gpu.plan['persistent'] == 0
+    assert_same(orc, gpu)
+    # the fused plan (one workgroup streams all the data for its chain) gives the
+    # same chains up to the summation order: compare chisq of stored rows
+    Z, lp, zc = gpu.rows()
+    gpu.close()
+    os.environ['MC3HIP_NO_TILED'] = '1'
+    try:
+        fused = eng.DeviceChains(**prob)
+        assert fused.plan['tile'] == 0
+        re = fused.eval_chisq(fused.expand_free(Z[-40:]))
+        fused.close()
+    finally:
+        del os.environ['MC3HIP_NO_TILED']
+    np.testing.assert_allclose(-0.5*re, lp[-40:], rtol=1e-12)
