@@ -389,7 +389,7 @@ __device__ __forceinline__ int ilog2(int n)
 // by 1/sigma_W^2 of their scale and accumulated without ever being stored.
 template <int WPC, int MT>
 __device__ double block_wavelet(const DevProblem &P, const double *s_nextp, double *s_part,
-                                int *s_flag, double *bufA, double *bufB)
+                                int *s_flag, double *s_tab, double *bufA, double *bufB)
 {
     constexpr int NV = 16 / WPC;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -400,6 +400,21 @@ __device__ double block_wavelet(const DevProblem &P, const double *s_nextp, doub
     const double sr = s_nextp[P.nparams - 2];
     const double sw = s_nextp[P.nparams - 1];
     const double sr2 = sr * sr, sw2 = sw * sw;
+    const int M = ilog2(N);
+    // The per-scale noise terms depend only on the three noise parameters: lane m of
+    // wave 0 computes sigma_W^2(m), its reciprocal (table in LDS, read by every level)
+    // and its share of the log-determinant -- one exp2 + log per lane instead of
+    // M of each on every thread.
+    double logterm = 0.0;
+    if (threadIdx.x < 64) {
+        const int m = lane;
+        if (m >= 1 && m < M) {
+            const double sW2 = sr2 * mc3_det_exp2(-gam * (double)m) + sw2;
+            s_tab[m] = 1.0 / sW2;
+            logterm = (double)(1 << m) * mc3_det_log(6.283185307179586 * sW2);
+        }
+    }
+    block_sync<WPC>();
     double acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -410,21 +425,34 @@ __device__ double block_wavelet(const DevProblem &P, const double *s_nextp, doub
         const int nh = N >> 1;
         {
             const int m = ilog2(nh);
-            const double inv = 1.0 / (sr2 * mc3_det_exp2(-gam * (double)m) + sw2);
+            const double inv = s_tab[m];
             for (int base = 0; base < nh; base += VLANES) {
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     const int i = base + lane + 64 * (wv + WPC * v);
                     if (i < nh) {
-                        const int j0 = 2 * i, j1 = 2 * i + 1;
-                        const int j2 = (2 * i + 2) & (N - 1), j3 = (2 * i + 3) & (N - 1);
-                        const double m0 = model.at(j0), m1 = model.at(j1);
-                        const double m2 = model.at(j2), m3 = model.at(j3);
+                        // points 2i..2i+3 (wrapping): two aligned 16-byte loads per array
+                        const int j0 = 2 * i, j2 = (2 * i + 2) & (N - 1);
+                        double m0, m1, m2, m3;
+                        if constexpr (MT == MT_LINEAR) {
+                            m0 = model.at(j0);
+                            m1 = model.at(j0 + 1);
+                            m2 = model.at(j2);
+                            m3 = model.at(j2 + 1);
+                        } else {
+                            const double2 xa = *reinterpret_cast<const double2 *>(P.indep + j0);
+                            const double2 xb = *reinterpret_cast<const double2 *>(P.indep + j2);
+                            m0 = model.at_x(xa.x);
+                            m1 = model.at_x(xa.y);
+                            m2 = model.at_x(xb.x);
+                            m3 = model.at_x(xb.y);
+                        }
                         sawinf |= is_pos_inf(m0) | is_pos_inf(m1) | is_pos_inf(m2) |
                                   is_pos_inf(m3);
+                        const double2 da = *reinterpret_cast<const double2 *>(P.data + j0);
+                        const double2 db = *reinterpret_cast<const double2 *>(P.data + j2);
                         double s, d;
-                        d4_pair(P.data[j0] - m0, P.data[j1] - m1, P.data[j2] - m2,
-                                P.data[j3] - m3, s, d);
+                        d4_pair(da.x - m0, da.y - m1, db.x - m2, db.y - m3, s, d);
                         bufA[i] = s;
                         acc[v] = mc3_fma(d * d, inv, acc[v]);
                     }
@@ -437,15 +465,17 @@ __device__ double block_wavelet(const DevProblem &P, const double *s_nextp, doub
         for (int nn = nh; nn >= 4; nn >>= 1) {
             const int nh2 = nn >> 1;
             const int m = ilog2(nh2);
-            const double inv = 1.0 / (sr2 * mc3_det_exp2(-gam * (double)m) + sw2);
+            const double inv = s_tab[m];
             for (int base = 0; base < nh2; base += VLANES) {
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     const int i = base + lane + 64 * (wv + WPC * v);
                     if (i < nh2) {
                         double s, d;
-                        d4_pair(cur[2 * i], cur[2 * i + 1], cur[(2 * i + 2) & (nn - 1)],
-                                cur[(2 * i + 3) & (nn - 1)], s, d);
+                        const double2 ca = *reinterpret_cast<const double2 *>(cur + 2 * i);
+                        const double2 cc = *reinterpret_cast<const double2 *>(
+                            cur + ((2 * i + 2) & (nn - 1)));       // ds_read_b128
+                        d4_pair(ca.x, ca.y, cc.x, cc.y, s, d);
                         dst[i] = s;
                         acc[v] = mc3_fma(d * d, inv, acc[v]);
                     }
@@ -470,14 +500,13 @@ __device__ double block_wavelet(const DevProblem &P, const double *s_nextp, doub
     sawinf = block_or<WPC>(sawinf, s_flag);
     if (sawinf)
         return mc3_from_bits(0x7ff0000000000000ull);
-    const int M = ilog2(N);
+    if (threadIdx.x >= 64)
+        return 0.0;                               // the value is only used by wave 0
     const double sS2 = sr2 * mc3_det_exp2(-gam) * 0.72134752 + sw2;
     const double S = (a0 * a0) / sS2 + (a1 * a1) / sS2;
     double Lg = 2.0 * mc3_det_log(6.283185307179586 * sS2);
-    for (int m = 1; m < M; ++m) {
-        const double sW2 = sr2 * mc3_det_exp2(-gam * (double)m) + sw2;
-        Lg = Lg + (double)(1 << m) * mc3_det_log(6.283185307179586 * sW2);
-    }
+    for (int m = 1; m < M; ++m)
+        Lg = Lg + read_lane(logterm, m);          // scales added in order
     return (S + Lg) + T;
 }
 
@@ -497,12 +526,13 @@ __device__ __forceinline__ double prior_term(const DevProblem &P, const double *
 // chisq of the parameter vector in s_nextp; valid in wave 0
 template <int WPC, int MT, bool WL, bool MULTI>
 __device__ __forceinline__ double block_chisq(const DevProblem &P, const double *s_nextp,
-                                              double *s_part, int *s_flag, double *bufA,
-                                              double *bufB, const DataTile<WPC, MT> &tile)
+                                              double *s_part, int *s_flag, double *s_tab,
+                                              double *bufA, double *bufB,
+                                              const DataTile<WPC, MT> &tile)
 {
     double c;
     if constexpr (WL)
-        c = block_wavelet<WPC, MT>(P, s_nextp, s_part, s_flag, bufA, bufB);
+        c = block_wavelet<WPC, MT>(P, s_nextp, s_part, s_flag, s_tab, bufA, bufB);
     else
         c = block_gauss<WPC, MT, MULTI>(P, s_nextp, s_part, s_flag, tile);
     if (is_pos_inf(c))
@@ -520,7 +550,7 @@ __device__ __forceinline__ double lane_serial_sum(double t, int n)
 }
 
 struct SmemLayout {
-    double *part, *nextp, *bufA, *bufB;
+    double *part, *nextp, *tab, *bufA, *bufB;
     int *flag;
 };
 
@@ -530,7 +560,8 @@ __device__ __forceinline__ SmemLayout carve(double *smem, const DevProblem &P, i
     L.part = smem;
     L.nextp = smem + nthreads;
     L.flag = reinterpret_cast<int *>(L.nextp + MC3HIP_MAX_PARAMS);
-    L.bufA = L.nextp + MC3HIP_MAX_PARAMS + 2;
+    L.tab = L.nextp + MC3HIP_MAX_PARAMS + 2;            // 32 doubles: per-scale 1/sigma_W^2
+    L.bufA = L.tab + 32;
     const int na = (P.ndata / 2 > 2) ? P.ndata / 2 : 2;
     L.bufB = L.bufA + na;
     return L;
@@ -538,7 +569,7 @@ __device__ __forceinline__ SmemLayout carve(double *smem, const DevProblem &P, i
 
 static inline size_t smem_bytes(int nthreads, int ndata, int wlike)
 {
-    size_t n = (size_t)nthreads + MC3HIP_MAX_PARAMS + 2;
+    size_t n = (size_t)nthreads + MC3HIP_MAX_PARAMS + 2 + 32;
     if (wlike) {
         const size_t na = (ndata / 2 > 2) ? ndata / 2 : 2;
         const size_t nb = (ndata / 4 > 2) ? ndata / 4 : 2;
@@ -822,6 +853,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                                   : P.Z + (size_t)(P.M0 + (R - 1) * P.nchains) * nf;
     const long long zsize = P.M0 + R * P.nchains;
     for (int j = jb; j < je; ++j) {
+        MC3_STAMP(5);
         const uint64_t iter = (uint64_t)(R * P.thinning + j);
         double npk = 0.0, zk = 0.0, u = 0.0;
         double mrfactor = 1.0;
@@ -1002,8 +1034,8 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
             } else if constexpr (PHASE == PH_FINISH) {
                 nextchisq = finish_chisq<MT>(P, lc);
             } else {
-                nextchisq = block_chisq<WPC, MT, WL, MULTI>(P, L.nextp, L.part, L.flag, L.bufA,
-                                                            L.bufB, tile);   // chain.py:249
+                nextchisq = block_chisq<WPC, MT, WL, MULTI>(P, L.nextp, L.part, L.flag, L.tab,
+                                                            L.bufA, L.bufB, tile);   // chain.py:249
             }
             MC3_STAMP(3);
             if (wave0) {
@@ -1040,6 +1072,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
         }
         if constexpr (!FAST)
             block_sync<WPC>();
+        MC3_STAMP(6);
     }
     if (!alive)
         break;
@@ -1124,7 +1157,8 @@ __global__ __launch_bounds__(64 * WPC) void eval_chisq_kernel(const DevProblem P
     for (int q = threadIdx.x; q < P.nparams; q += 64 * WPC)
         L.nextp[q] = params[(size_t)blockIdx.x * P.nparams + q];
     __syncthreads();
-    const double c = block_chisq<WPC, MT, WL, true>(P, L.nextp, L.part, L.flag, L.bufA, L.bufB, tile);
+    const double c = block_chisq<WPC, MT, WL, true>(P, L.nextp, L.part, L.flag, L.tab, L.bufA,
+                                                    L.bufB, tile);
     if (threadIdx.x == 0)
         out[blockIdx.x] = c;
 }

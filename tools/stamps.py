@@ -16,6 +16,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 from mc3_amd import build as b, _lib  # noqa: E402
 
 lib = os.path.join(ROOT, 'mc3_amd', 'libmc3hip_stamps.so')
@@ -27,25 +29,38 @@ _lib.LIB_PATH = lib
 from mc3_amd import engine  # noqa: E402
 import bench  # noqa: E402
 
-wpc = os.environ.get('MC3HIP_WPC', '1')
-prob = bench.c2_problem(256, 3000)
-g = engine.DeviceChains(no_graph=True, **prob)
-Z0, lp0 = bench.initial_population(prob, g.eval_chisq)
+import helpers as H  # noqa: E402
+
+which = ([a for a in sys.argv[1:] if not a.startswith('--')] or ['c2'])[0]
+if which == 'c4':
+    prob = H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*400)
+    ini = H.initial_population
+else:
+    prob = bench.c2_problem(256, 3000)
+mode = os.environ.get('STAMP_MODE', 'persist')
+kw = dict(no_graph=True, no_persist=True) if mode == 'launch' else {}
+g = engine.DeviceChains(**prob, **kw)
+if which == 'c4':
+    import tools_pop
+    Z0, lp0 = tools_pop.population(g)
+else:
+    Z0, lp0 = bench.initial_population(prob, g.eval_chisq)
 g.set_population(Z0, lp0)
-g.run(500)
-names = ['entry->loads', 'loads->proposal', 'proposal->chisq', 'chisq->end']
-acc = np.zeros(4)
+g.run(100)
+names = ['5 top -> 2 proposal done', '2 -> 3 chisq done', '3 -> 6 iteration end']
+acc = np.zeros(3)
 n = 0
-for _ in range(200):
-    g.run(1)
+for _ in range(60):
+    g.run(5 if mode != 'launch' else 1)
     out = (ctypes.c_uint64*16)()
     _lib.check(g.lib.mc3hip_debug_stamps(g._ctx, out))
-    t = np.array(out[:5], dtype=np.float64)
-    if t[3] == 0 or np.any(np.diff(t) < 0):
-        continue            # out-of-bounds proposal: no chisq phase
+    t = np.array([out[5], out[2], out[3], out[6]], dtype=np.float64)
+    if np.any(np.diff(t) <= 0):
+        continue            # out-of-bounds proposal in the last iteration: no chisq phase
     acc += np.diff(t)
     n += 1
-print(f'WPC={wpc}  {n} launches, mean shader-clock cycles per phase (workgroup 0):')
-for k, v in zip(names, acc/n):
-    print(f'  {k:18s} {v:9.0f}')
-print(f'  {"total":18s} {acc.sum()/n:9.0f}')
+print(f'{which} mode={mode} plan={g.plan}: {n} samples, mean shader-clock cycles per phase '
+      '(workgroup 0, last iteration of a launch):')
+for k, v in zip(names, acc/max(n, 1)):
+    print(f'  {k:28s} {v:9.0f}')
+print(f'  {"iteration":28s} {acc.sum()/max(n, 1):9.0f}')
