@@ -149,6 +149,13 @@ int mc3hip_get_state(mc3hip_ctx *ctx, double *X, double *chisq,
 int mc3hip_get_trace(mc3hip_ctx *ctx, int64_t iters, double *chisq,
                      int32_t *flags);
 
+/* The reductions of the Gelman-Rubin test (mc3/stats/gelman.py:12-92, called from
+ * the hub at mcmc_driver.py:327-346) on the device: mean and population variance of
+ * every free parameter per chain over the refreshes done so far, skipping each
+ * chain's first `burn` rows; [nchains][nfree] each.  The caller combines them into
+ * the potential scale reduction factor; Z is not copied to the host. */
+int mc3hip_chain_moments(mc3hip_ctx *ctx, int64_t burn, double *mean, double *var);
+
 /* Replaces Chain.eval_model(params, ret='chisq') -> ms.chisq / ms.dwt_chisq
  * (chain.py:302-340, stats.py:150-284, _chisq.c:111-140, _dwt.c:56-119) for n
  * parameter vectors at once ([n][nparams], shared parameters already copied). */

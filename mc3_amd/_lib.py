@@ -75,6 +75,7 @@ SYMBOLS = {
     'mc3hip_put_rows': (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, _dp, _dp]),
     'mc3hip_get_state': (ctypes.c_int, [_vp, _dp, _dp, _lp, _lp, _dp, _lp, _dp, _lp]),
     'mc3hip_get_trace': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _ip]),
+    'mc3hip_chain_moments': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _dp]),
     'mc3hip_eval_chisq': (ctypes.c_int, [_vp, _dp, ctypes.c_int32, _dp]),
     'mc3hip_eval_model': (ctypes.c_int, [_vp, _dp, _dp]),
     'mc3hip_dwt_daub4': (ctypes.c_int, [ctypes.c_int32, _dp, ctypes.c_int32, ctypes.c_int32, _dp]),

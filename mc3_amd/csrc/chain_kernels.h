@@ -1221,6 +1221,51 @@ __global__ void daub4_kernel(double *a, double *tmp, int n, int inverse)
     }
 }
 
+// Per-chain mean and (population) variance of every free parameter over the rows a
+// chain has written, skipping its first `burn` rows: the reductions the
+// Gelman-Rubin test needs (mc3/stats/gelman.py:12-92) without copying Z to the host.
+// One workgroup per chain; two passes (mean, then squared deviations).
+__global__ __launch_bounds__(256) void chain_moments_kernel(const double *Z, long long M0,
+                                                            int nchains, int nf,
+                                                            long long nref, long long burn,
+                                                            double *mean, double *var)
+{
+    __shared__ double s_red[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    const long long n = nref - burn;
+    for (int k = 0; k < nf; ++k) {
+        double acc = 0.0;
+        for (long long r = burn + t; r < nref; r += 256)
+            acc += Z[(size_t)(M0 + r * nchains + c) * nf + k];
+        s_red[t] = acc;
+        __syncthreads();
+        for (int s2 = 128; s2 >= 1; s2 >>= 1) {
+            if (t < s2)
+                s_red[t] += s_red[t + s2];
+            __syncthreads();
+        }
+        const double mu = s_red[0] / (double)n;
+        __syncthreads();
+        acc = 0.0;
+        for (long long r = burn + t; r < nref; r += 256) {
+            const double d = Z[(size_t)(M0 + r * nchains + c) * nf + k] - mu;
+            acc += d * d;
+        }
+        s_red[t] = acc;
+        __syncthreads();
+        for (int s2 = 128; s2 >= 1; s2 >>= 1) {
+            if (t < s2)
+                s_red[t] += s_red[t + s2];
+            __syncthreads();
+        }
+        if (t == 0) {
+            mean[(size_t)c * nf + k] = mu;
+            var[(size_t)c * nf + k] = s_red[0] / (double)n;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void set_ctl_kernel(long long *ctl, long long base, long long run0)
 {
     ctl[0] = base;

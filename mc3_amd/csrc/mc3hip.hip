@@ -1001,6 +1001,34 @@ int mc3hip_get_trace(mc3hip_ctx *c, int64_t iters, double *chisq, int32_t *flags
     return MC3HIP_OK;
 }
 
+int mc3hip_chain_moments(mc3hip_ctx *c, int64_t burn, double *mean, double *var)
+{
+    if (!c || !mean || !var)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    if (burn < 0 || burn >= c->refresh_done)
+        return fail(MC3HIP_ERR_ARG, "burn=%lld leaves no rows (%lld refreshes done)",
+                    (long long)burn, (long long)c->refresh_done);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)c->P.nchains * (size_t)c->P.nfree;
+    double *dm = nullptr, *dv = nullptr;
+    HIP_TRY(hipMalloc(&dm, 2 * n * sizeof(double)));
+    dv = dm + n;
+    hipLaunchKernelGGL(chain_moments_kernel, dim3(c->P.nchains), dim3(256), 0, c->stream,
+                       (const double *)c->P.Z, (long long)c->P.M0, c->P.nchains, c->P.nfree,
+                       (long long)c->refresh_done, (long long)burn, dm, dv);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(mean, dm, n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(var, dv, n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dm);
+    if (e != hipSuccess)
+        return fail(MC3HIP_ERR_HIP, "chain_moments: %s", hipGetErrorString(e));
+    return MC3HIP_OK;
+}
+
 int mc3hip_eval_chisq(mc3hip_ctx *c, const double *params, int32_t n, double *chisq_out)
 {
     if (!c || !params || !chisq_out)

@@ -203,6 +203,15 @@ class DeviceChains:
         check(self.lib.mc3hip_get_trace(self._ctx, iters, dptr(chisq), iptr(flags)))
         return chisq, flags
 
+    def chain_moments(self, burn=0):
+        """Per-chain mean and variance of the free parameters over the rows written
+        so far (first ``burn`` rows of each chain skipped), computed on the device:
+        the inputs of the Gelman-Rubin test (mc3/stats/gelman.py)."""
+        mean = np.empty((self.nchains, self.nfree))
+        var = np.empty((self.nchains, self.nfree))
+        check(self.lib.mc3hip_chain_moments(self._ctx, int(burn), dptr(mean), dptr(var)))
+        return mean, var
+
     # -- Chain.eval_model (chain.py:302-340) on the device ----------------------
     def eval_chisq(self, params):
         """chisq for one parameter vector or an [n, nparams] batch."""

@@ -267,8 +267,12 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
             f"Out-of-bound Trials:\n{view.outbounds}\n"
             f"Best Parameters: (chisq={-2*view.best_log_post:.4f})\n"
             f"{view.bestp[ifree]}", width=80)
-        need_rows = (savefile is not None) or \
-            (grtest and np.all(view.chainsize > (zburn + hsize)))
+        run_gr = grtest and np.all(view.chainsize > (zburn + hsize))
+        # the Gelman-Rubin reductions run on the device when the chains started in
+        # this call (regular row layout); Z is then only read back for a savefile
+        device_gr = run_gr and not resume and hasattr(engine, 'chain_moments') \
+            and (comm.size == 1 or comm.native)
+        need_rows = (savefile is not None) or (run_gr and not device_gr)
         if need_rows:
             if comm.native:
                 comm.finish(engine)
@@ -276,8 +280,12 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
         if savefile is not None and comm.rank == 0:
             ms.update_output(output, view, hsize)
             np.savez(savefile, **output)
-        if grtest and np.all(view.chainsize > (zburn + hsize)):
-            psrf = ms.gelman_rubin(view.Z, view.zchain, zburn)
+        if run_gr:
+            if device_gr:
+                mean, var = engine.chain_moments(zburn)
+                psrf = ms.gelman_rubin_from_moments(mean, var, done - zburn)
+            else:
+                psrf = ms.gelman_rubin(view.Z, view.zchain, zburn)
             log.msg(f"Gelman-Rubin statistics for free parameters:\n{psrf}",
                     width=80)
             if np.all(psrf < 1.01):

@@ -68,6 +68,11 @@ def marginal_statistics(posterior, statistics='med_central', quantile=0.683,
     if pdf is None or xpdf is None:
         pdf = [None]*nparams
         xpdf = [None]*nparams
+    if statistics == 'med_central' and quantile is not None:
+        # median and both bounds from a single selection pass
+        low, values, high = np.percentile(
+            posterior, [50*(1 - quantile), 50.0, 50*(1 + quantile)], axis=0)
+        return values, low, high
     if statistics.startswith('med_'):
         values = np.median(posterior, axis=0)
     elif statistics.startswith('max_'):
@@ -156,12 +161,41 @@ def update_output(output, chain, hsize):
     return posterior
 
 
+def gelman_rubin_from_moments(mean, var, niter):
+    """PSRF from per-chain means and (population) variances over ``niter`` samples
+    each -- psrf() of mc3/stats/gelman.py:64-92 with the reductions done elsewhere
+    (mc3_amd.engine.DeviceChains.chain_moments)."""
+    nchains = len(mean)
+    W = np.mean(var, axis=0)
+    B = niter/(nchains - 1.0)*np.sum((mean - np.mean(mean, axis=0))**2, axis=0)
+    V = W*(niter - 1.0)/niter + B*(nchains + 1.0)/(niter*nchains)
+    return np.sqrt(V/W)
+
+
 def gelman_rubin(Z, zchain, burnin):
     """Potential scale reduction factor per parameter (mc3/stats/gelman.py:12-92)."""
     Z = np.asarray(Z)
     zchain = np.asarray(zchain)
     nchains = int(np.amax(zchain)) + 1
     npars = Z.shape[1]
+    # Fast path for the regular layout (rows in repeating chain order after the
+    # initial population): one reshape instead of a scan per chain.
+    first = int(np.argmax(zchain >= 0))
+    body = zchain[first:]
+    if len(body) % nchains == 0 and np.all(zchain[:first] < 0) and \
+            np.array_equal(body[:nchains], np.arange(nchains)) and \
+            np.array_equal(body[-nchains:], np.arange(nchains)) and \
+            np.array_equal(body.reshape(-1, nchains)[:, 0], np.zeros(len(body)//nchains, body.dtype)):
+        niter = len(body)//nchains - burnin
+        if niter < 1:
+            print('Not enough samples for Gelman-Rubin test.')
+            return np.zeros(npars)
+        chains = Z[first:].reshape(-1, nchains, npars)[burnin:]     # [iter, chain, par]
+        W = np.mean(np.var(chains, axis=0), axis=0)
+        means = np.mean(chains, axis=0)
+        B = niter/(nchains - 1.0)*np.sum((means - np.mean(means, axis=0))**2, axis=0)
+        V = W*(niter - 1.0)/niter + B*(nchains + 1.0)/(niter*nchains)
+        return np.sqrt(V/W)
     counts = np.array([np.sum(zchain == c) for c in range(nchains)]) - burnin
     niter = int(np.amin(counts))
     if niter < 1:

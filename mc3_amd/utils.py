@@ -28,6 +28,23 @@ def burn(Zdict=None, burnin=None, Z=None, zchain=None, sort=True):
         if burnin is None:
             burnin = Zdict['burnin']
     zchain = np.asarray(zchain)
+    # Fast path for the layout the device produces (and mrw/demc in the reference,
+    # mc3/chain.py:164,288): optional initial rows marked -1, then rows in
+    # repeating chain order 0..n-1.  Same result as the general scan below.
+    nvalid0 = int(np.argmax(zchain >= 0)) if np.any(zchain >= 0) else len(zchain)
+    body = zchain[nvalid0:]
+    nchains_r = int(body.max()) + 1 if len(body) else 0
+    if nchains_r > 0 and len(body) % nchains_r == 0 and np.all(zchain[:nvalid0] < 0) and \
+            np.array_equal(body.reshape(-1, nchains_r),
+                           np.broadcast_to(np.arange(nchains_r, dtype=body.dtype),
+                                           (len(body)//nchains_r, nchains_r))):
+        niter = len(body)//nchains_r
+        it = np.arange(min(burnin, niter), niter)
+        if sort:
+            zmask = (nvalid0 + it[None, :]*nchains_r + np.arange(nchains_r)[:, None]).ravel()
+        else:
+            zmask = (nvalid0 + it[:, None]*nchains_r + np.arange(nchains_r)[None, :]).ravel()
+        return Z[zmask], zchain[zmask], zmask
     keep = np.zeros(len(zchain), bool)
     for c in range(int(np.amax(zchain)) + 1):
         keep[np.flatnonzero(zchain == c)[burnin:]] = True

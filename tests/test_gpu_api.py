@@ -131,3 +131,23 @@ def test_put_rows_host_staged_exchange():
     np.testing.assert_array_equal(acc, orc.numaccept)
     a.close()
     b.close()
+
+
+def test_device_gelman_rubin_matches_host():
+    """mc3hip_chain_moments + gelman_rubin_from_moments == the host statistic
+    (mc3/stats/gelman.py restated in mc3_amd.stats.gelman_rubin) on the same rows."""
+    from mc3_amd import engine, stats as ms
+    prob = H.quad_problem(ndata=100, nchains=16, nsamples=16*3000, sampler='demc')
+    orc = H.make_oracle(prob)
+    Z0, lp0 = H.initial_population(orc)
+    with engine.DeviceChains(**prob) as gpu:
+        gpu.set_population(Z0, lp0)
+        gpu.run(1234)
+        Z, lp, zc = gpu.rows(0, gpu.M0 + 1234*16)
+        for burn in (0, 100):
+            mean, var = gpu.chain_moments(burn)
+            got = ms.gelman_rubin_from_moments(mean, var, 1234 - burn)
+            want = ms.gelman_rubin(Z, zc, burn)
+            np.testing.assert_allclose(got, want, rtol=1e-11)
+        with pytest.raises(Exception, match='leaves no rows'):
+            gpu.chain_moments(1234)
