@@ -47,6 +47,8 @@ extern "C" {
 
 #define MC3HIP_FLAG_NO_GRAPH    1u /* launch eagerly instead of through a hipGraph  */
 #define MC3HIP_FLAG_NO_PERSIST  2u /* never use the persistent kernel               */
+#define MC3HIP_FLAG_P2P         4u /* allocate Z / log_post fine-grained and IPC-shareable
+                                      so that mc3hip_p2p_attach can be used               */
 
 #define MC3HIP_MAX_FREE     64
 #define MC3HIP_MAX_PARAMS  128
@@ -181,6 +183,19 @@ int mc3hip_comm_init(mc3hip_ctx *ctx, const void *unique_id_128, int32_t rank,
 /* Exchange log_post rows [row0, row0+nrows) that other ranks own (needed only
  * when the posterior is read back). */
 int mc3hip_comm_gather_log_post(mc3hip_ctx *ctx);
+
+/* Peer-to-peer variant of the multi-GPU exchange (contexts created with
+ * MC3HIP_FLAG_P2P, one per rank/process, equal contiguous chain blocks): every rank
+ * exports IPC handles of its Z / log_post replicas (128 bytes), the caller hands
+ * all ranks' handles to every rank, and from then on the persistent kernel publishes
+ * each new row straight into every replica (system-scope stores over xGMI) and polls
+ * its local one -- no collective and no kernel boundary between iterations.  The
+ * caller must barrier across ranks after attach (before the first run) and after
+ * mc3hip_sync (before reading rows back: peers may still be storing into this
+ * replica). */
+int mc3hip_p2p_export(mc3hip_ctx *ctx, void *handles_128);
+int mc3hip_p2p_attach(mc3hip_ctx *ctx, int32_t rank, int32_t nranks,
+                      const void *all_handles /* [nranks][128] */);
 
 /* Self tests used by tests/ on the GPU: evaluate the shared deterministic
  * functions on the device (op: 0 exp, 1 log, 2 exp2, 3 sin2pi, 4 cos2pi,

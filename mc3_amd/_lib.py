@@ -22,6 +22,7 @@ MRW, DEMC, SNOOKER = 0, 1, 2
 MODEL_POLY, MODEL_LINEAR = 0, 1
 FLAG_NO_GRAPH = 1
 FLAG_NO_PERSIST = 2
+FLAG_P2P = 4
 MAX_FREE, MAX_PARAMS = 64, 128
 
 SAMPLERS = {'mrw': MRW, 'demc': DEMC, 'snooker': SNOOKER}
@@ -82,6 +83,8 @@ SYMBOLS = {
     'mc3hip_comm_unique_id': (ctypes.c_int, [_vp]),
     'mc3hip_comm_init': (ctypes.c_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int32]),
     'mc3hip_comm_gather_log_post': (ctypes.c_int, [_vp]),
+    'mc3hip_p2p_export': (ctypes.c_int, [_vp, _vp]),
+    'mc3hip_p2p_attach': (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, _vp]),
     'mc3hip_debug_stamps': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
     'mc3hip_selftest_math': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, _dp, ctypes.c_int32, _dp]),
     'mc3hip_selftest_philox': (ctypes.c_int, [ctypes.c_int32, _up, ctypes.c_int32, _up, _up]),

@@ -54,6 +54,11 @@ struct DevProblem {
     int32_t *trace_flag;
     const long long *ctl;   // ctl[0] = refresh base of this replay, ctl[1] = first refresh of the run
     unsigned long long *stamps;   // diagnostic build only (MC3HIP_STAMPS): s_memtime per phase
+    // peer-to-peer hand-off across GPUs (persistent kernel): rank p's replicas of Z and
+    // log_post, mapped into this process; [0..npeers), entry `rank` is the local one
+    int32_t npeers, rank;
+    double *const *peerZ;
+    double *const *peerLP;
     // tiled plan (large ndata): proposal / data sum / accept are separate launches
     int32_t tile, ntiles;         // points per tile (0 = fused plan), tiles in npad
     double *sc_nextp;             // [nlocal][nparams] proposed parameter vectors
@@ -720,9 +725,15 @@ __device__ __forceinline__ double finish_chisq(const DevProblem &P, int lc)
 constexpr unsigned long long ROW_PENDING = 0xffffffffffffffffull;
 constexpr int CTL_ABORT = 2;                   // ctl[2] != 0: a wait timed out
 
+template <bool SYS = false>
 __device__ __forceinline__ double load_published(const double *p)
 {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // SYS: the row may have been stored by another GPU (system scope, fine-grained
+    // memory); otherwise by another CU of this GPU (agent scope)
+    if constexpr (SYS)
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Wave-level wait until every lane's values have been published (all 64 lanes
@@ -730,7 +741,7 @@ __device__ __forceinline__ double load_published(const double *p)
 // by the caller so that independent scalar work can overlap its latency; this
 // only spins when something is still pending.  Bounded: gives up (and tells
 // everybody) after ~1 s so a lost workgroup can never hang the device.
-template <int NVAL>
+template <int NVAL, bool SYS = false>
 __device__ __forceinline__ bool wait_rows(const double *const (&addr)[NVAL], double (&val)[NVAL],
                                           long long *ctl)
 {
@@ -754,7 +765,7 @@ __device__ __forceinline__ bool wait_rows(const double *const (&addr)[NVAL], dou
         }
 #pragma unroll
         for (int q = 0; q < NVAL; ++q)
-            val[q] = load_published(addr[q]);
+            val[q] = load_published<SYS>(addr[q]);
     }
 }
 
@@ -793,8 +804,12 @@ __device__ __forceinline__ Draws make_draws(const DevProblem &P, uint64_t iter, 
 // stops after the proposal (written to global scratch), a tile kernel computes the
 // data sums for all chains, PH_FINISH resumes at the Metropolis test.  jb..je is the
 // range of iterations of the refresh this call covers (fused: 0..thinning).
+// P2P (persistent only): the ensemble is sharded over GPUs; a chain publishes its new
+// row into EVERY rank's replica of Z (peer-to-peer stores over xGMI, system scope) and
+// polls its local replica, so the in-launch hand-off spans GPUs and no collective or
+// kernel boundary separates iterations.
 template <int WPC, int MT, bool WL, bool MULTI, bool PERSIST, int SMP = -1, bool FAST = false,
-          int PHASE = PH_FUSED>
+          int PHASE = PH_FUSED, bool P2P = false>
 __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R0,
                                           const int nref, const int jb = 0, int je = -1)
 {
@@ -891,9 +906,9 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                     double val[3];
 #pragma unroll
                     for (int q = 0; q < 3; ++q)
-                        val[q] = load_published(addr[q]);
+                        val[q] = load_published<P2P>(addr[q]);
                     nxt = make_draws(P, iter + 1, c, sampler);
-                    alive = wait_rows<3>(addr, val, ctl_rw);
+                    alive = wait_rows<3, P2P>(addr, val, ctl_rw);
                     z1 = val[0];
                     z2 = val[1];
                     zk = val[2];
@@ -939,9 +954,9 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                     double val[2];
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
-                        val[q] = load_published(addr[q]);
+                        val[q] = load_published<P2P>(addr[q]);
                     nxt = make_draws(P, iter + 1, c, sampler);
-                    alive = wait_rows<2>(addr, val, ctl_rw);
+                    alive = wait_rows<2, P2P>(addr, val, ctl_rw);
                     x1 = val[0];
                     x2 = val[1];
                 } else {
@@ -1080,14 +1095,25 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     if (wave0 && je == P.thinning) {
         const long long row = P.M0 + R * P.nchains + c;
         if (mine) {
-            if constexpr (PERSIST)
+            if constexpr (P2P) {
+                for (int pr = 0; pr < P.npeers; ++pr)               // publish everywhere
+                    __hip_atomic_store(&P.peerZ[pr][(size_t)row * nf + lane], xk,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else if constexpr (PERSIST) {
                 __hip_atomic_store(&P.Z[(size_t)row * nf + lane], xk, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);      // publish (sc1)
-            else
+            } else {
                 P.Z[(size_t)row * nf + lane] = xk;
+            }
         }
         if (lane == 0) {
-            P.log_post[row] = -0.5 * cur;
+            if constexpr (P2P) {
+                for (int pr = 0; pr < P.npeers; ++pr)
+                    __hip_atomic_store(&P.peerLP[pr][row], -0.5 * cur, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                P.log_post[row] = -0.5 * cur;
+            }
             P.zchain[row] = c;
         }
     }
@@ -1113,10 +1139,10 @@ __global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, cons
 
 // many Z refreshes per launch with in-launch hand-off of the new rows; every
 // workgroup of the grid must be resident (the host checks before choosing this path)
-template <int WPC, int MT, bool WL, bool MULTI>
+template <int WPC, int MT, bool WL, bool MULTI, bool P2P = false>
 __global__ __launch_bounds__(64 * WPC) void persist_kernel(const DevProblem P, const int nref)
 {
-    run_chain<WPC, MT, WL, MULTI, true>(P, P.ctl[0], nref);
+    run_chain<WPC, MT, WL, MULTI, true, -1, false, PH_FUSED, P2P>(P, P.ctl[0], nref);
 }
 
 
@@ -1137,10 +1163,10 @@ __global__ __launch_bounds__(64) void finish_kernel(const DevProblem P, const in
 
 // the lean instance (see run_chain): one wave per chain, MT free polynomial
 // coefficients, Gaussian chisq, ndata <= 1024, no priors/shared/fixed/epsilon/trace
-template <int MT, int SMP>
+template <int MT, int SMP, bool P2P = false>
 __global__ __launch_bounds__(64) void persist_fast_kernel(const DevProblem P, const int nref)
 {
-    run_chain<1, MT, false, false, true, SMP, true>(P, P.ctl[0], nref);
+    run_chain<1, MT, false, false, true, SMP, true, PH_FUSED, P2P>(P, P.ctl[0], nref);
 }
 
 // chisq for arbitrary parameter vectors (Chain.eval_model(ret='chisq'))

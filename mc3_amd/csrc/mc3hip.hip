@@ -138,6 +138,9 @@ struct mc3hip_ctx {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     int64_t logpost_gathered = 0;   // refreshes whose log_post rows are already exchanged
+    // peer-to-peer hand-off
+    int p2p_ranks = 0;
+    std::vector<void *> p2p_opened;
 };
 
 namespace {
@@ -201,8 +204,26 @@ void launch_step_t(mc3hip_ctx *c, int roff)
 }
 
 template <int WPC, int MT>
+void launch_persist_p2p_t(mc3hip_ctx *c, int nref)
+{
+    if (c->P.wlike)
+        hipLaunchKernelGGL((persist_kernel<WPC, MT, true, false, true>), dim3(c->P.nlocal),
+                           dim3(64 * WPC), c->smem, c->stream, c->P, nref);
+    else if (c->P.npad > VLANES)
+        hipLaunchKernelGGL((persist_kernel<WPC, MT, false, true, true>), dim3(c->P.nlocal),
+                           dim3(64 * WPC), c->smem, c->stream, c->P, nref);
+    else
+        hipLaunchKernelGGL((persist_kernel<WPC, MT, false, false, true>), dim3(c->P.nlocal),
+                           dim3(64 * WPC), c->smem, c->stream, c->P, nref);
+}
+
+template <int WPC, int MT>
 void launch_persist_t(mc3hip_ctx *c, int nref)
 {
+    if (c->p2p_ranks > 1) {
+        launch_persist_p2p_t<WPC, MT>(c, nref);
+        return;
+    }
     if (c->P.wlike)
         hipLaunchKernelGGL((persist_kernel<WPC, MT, true, false>), dim3(c->P.nlocal),
                            dim3(64 * WPC), c->smem, c->stream, c->P, nref);
@@ -299,6 +320,15 @@ bool fast_eligible(const mc3hip_ctx *c)
 template <int MT>
 void launch_fast_t(mc3hip_ctx *c, int nref)
 {
+    if (c->p2p_ranks > 1) {
+        if (c->P.sampler == MC3HIP_DEMC)
+            hipLaunchKernelGGL((persist_fast_kernel<MT, MC3HIP_DEMC, true>), dim3(c->P.nlocal),
+                               dim3(64), c->smem, c->stream, c->P, nref);
+        else
+            hipLaunchKernelGGL((persist_fast_kernel<MT, MC3HIP_SNOOKER, true>),
+                               dim3(c->P.nlocal), dim3(64), c->smem, c->stream, c->P, nref);
+        return;
+    }
     if (c->P.sampler == MC3HIP_DEMC)
         hipLaunchKernelGGL((persist_fast_kernel<MT, MC3HIP_DEMC>), dim3(c->P.nlocal), dim3(64),
                            c->smem, c->stream, c->P, nref);
@@ -663,8 +693,20 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         TRY(dev_upload(c, &P.w, w.data(), npad));
     }
     const size_t zl = (size_t)pr->zlen, nl = (size_t)pr->nlocal;
-    TRY(dev_alloc(c, &P.Z, zl * nf));
-    TRY(dev_alloc(c, &P.log_post, zl));
+    if (pr->flags & MC3HIP_FLAG_P2P) {
+        // replicas other GPUs store into while kernels run: fine-grained (coherent at
+        // system scope), own allocations so that they can be exported through IPC
+        void *pz = nullptr, *pl = nullptr;
+        HIP_TRY_C(hipExtMallocWithFlags(&pz, zl * nf * sizeof(double), hipDeviceMallocFinegrained));
+        c->allocs.push_back(pz);
+        HIP_TRY_C(hipExtMallocWithFlags(&pl, zl * sizeof(double), hipDeviceMallocFinegrained));
+        c->allocs.push_back(pl);
+        P.Z = static_cast<double *>(pz);
+        P.log_post = static_cast<double *>(pl);
+    } else {
+        TRY(dev_alloc(c, &P.Z, zl * nf));
+        TRY(dev_alloc(c, &P.log_post, zl));
+    }
     TRY(dev_alloc(c, &P.zchain, zl));
     TRY(dev_alloc(c, &P.X, nl * nf));
     TRY(dev_alloc(c, &P.chisq, nl));
@@ -747,6 +789,8 @@ void mc3hip_destroy(mc3hip_ctx *c)
         (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy)
         g_rccl.CommDestroy(c->comm);
+    for (void *p : c->p2p_opened)
+        (void)hipIpcCloseMemHandle(p);
     if (c->graph_exec)
         (void)hipGraphExecDestroy(c->graph_exec);
     if (c->graph)
@@ -930,9 +974,17 @@ int mc3hip_get_rows(mc3hip_ctx *c, int64_t row0, int64_t nrows, double *Z, doubl
     if (log_post)
         HIP_TRY(hipMemcpy(log_post, c->P.log_post + row0, (size_t)nrows * sizeof(double),
                           hipMemcpyDeviceToHost));
-    if (zchain)
+    if (zchain) {
         HIP_TRY(hipMemcpy(zchain, c->P.zchain + row0, (size_t)nrows * sizeof(int32_t),
                           hipMemcpyDeviceToHost));
+        if (c->P.nlocal < c->P.nchains) {
+            // a shard only marks its own rows; the chain of a written row is its
+            // position in the refresh (chain.py:288 strided slot)
+            const int64_t done_end = c->P.M0 + c->refresh_done * c->P.nchains;
+            for (int64_t r = row0 > c->P.M0 ? row0 : c->P.M0; r < row0 + nrows && r < done_end; ++r)
+                zchain[r - row0] = (int32_t)((r - c->P.M0) % c->P.nchains);
+        }
+    }
     return MC3HIP_OK;
 }
 
@@ -1161,6 +1213,73 @@ int mc3hip_comm_init(mc3hip_ctx *c, const void *unique_id_128, int32_t rank, int
     }
     c->rank = rank;
     c->nranks = nranks;
+    return MC3HIP_OK;
+}
+
+int mc3hip_p2p_export(mc3hip_ctx *c, void *handles_128)
+{
+    if (!c || !handles_128)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    if (!(c->flags & MC3HIP_FLAG_P2P))
+        return fail(MC3HIP_ERR_STATE, "context was not created with MC3HIP_FLAG_P2P");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    HIP_TRY(hipSetDevice(c->device));
+    hipIpcMemHandle_t h[2];
+    HIP_TRY(hipIpcGetMemHandle(&h[0], c->P.Z));
+    HIP_TRY(hipIpcGetMemHandle(&h[1], c->P.log_post));
+    memcpy(handles_128, h, sizeof h);
+    return MC3HIP_OK;
+}
+
+int mc3hip_p2p_attach(mc3hip_ctx *c, int32_t rank, int32_t nranks, const void *all_handles)
+{
+    if (!c || !all_handles)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    if (!(c->flags & MC3HIP_FLAG_P2P))
+        return fail(MC3HIP_ERR_STATE, "context was not created with MC3HIP_FLAG_P2P");
+    if (nranks < 2 || nranks > 64 || rank < 0 || rank >= nranks)
+        return fail(MC3HIP_ERR_ARG, "bad rank %d of %d", rank, nranks);
+    if (c->P.nlocal * nranks != c->P.nchains || c->P.chain0 != rank * c->P.nlocal)
+        return fail(MC3HIP_ERR_ARG,
+                    "rank %d must own chains [%d,%d) of %d (equal contiguous blocks)", rank,
+                    rank * c->P.nlocal, (rank + 1) * c->P.nlocal, c->P.nchains);
+    if (c->comm)
+        return fail(MC3HIP_ERR_STATE, "an RCCL communicator is already attached");
+    if (decide_persist(c) <= 0)
+        return fail(MC3HIP_ERR_STATE,
+                    "the peer-to-peer hand-off needs the persistent kernel, which this "
+                    "problem cannot use (tiled plan, or too many chains to be co-resident)");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<double *> pz(nranks), pl(nranks);
+    const hipIpcMemHandle_t *h = static_cast<const hipIpcMemHandle_t *>(all_handles);
+    for (int r = 0; r < nranks; ++r) {
+        if (r == rank) {
+            pz[r] = c->P.Z;
+            pl[r] = c->P.log_post;
+            continue;
+        }
+        void *z = nullptr, *l = nullptr;
+        HIP_TRY(hipIpcOpenMemHandle(&z, h[2 * r], hipIpcMemLazyEnablePeerAccess));
+        c->p2p_opened.push_back(z);
+        HIP_TRY(hipIpcOpenMemHandle(&l, h[2 * r + 1], hipIpcMemLazyEnablePeerAccess));
+        c->p2p_opened.push_back(l);
+        pz[r] = static_cast<double *>(z);
+        pl[r] = static_cast<double *>(l);
+    }
+    double **dz = nullptr, **dl = nullptr;
+    int rc = dev_alloc(c, &dz, (size_t)nranks);
+    if (rc)
+        return rc;
+    rc = dev_alloc(c, &dl, (size_t)nranks);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpy(dz, pz.data(), nranks * sizeof(double *), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dl, pl.data(), nranks * sizeof(double *), hipMemcpyHostToDevice));
+    c->P.peerZ = dz;
+    c->P.peerLP = dl;
+    c->P.npeers = nranks;
+    c->P.rank = rank;
+    c->p2p_ranks = nranks;
     return MC3HIP_OK;
 }
 

@@ -29,7 +29,7 @@ class DeviceChains:
                  nsamples=None, sampler='snooker', wlike=False, thinning=1,
                  fgamma=1.0, fepsilon=0.0, hsize=10, model='poly', nmodel=None,
                  seed=0, device=0, chain0=0, nlocal=None, M0=None, zlen=None,
-                 trace_iters=0, no_graph=False, no_persist=False):
+                 trace_iters=0, no_graph=False, no_persist=False, p2p=False):
         self._ctx = None
         self.lib = _lib.load()
         self.params = f64(params).copy()
@@ -90,7 +90,8 @@ class DeviceChains:
         P.nmodel = self.nmodel
         P.thinning = self.thinning
         P.flags = (_lib.FLAG_NO_GRAPH if no_graph else 0) | \
-            (_lib.FLAG_NO_PERSIST if no_persist else 0)
+            (_lib.FLAG_NO_PERSIST if no_persist else 0) | \
+            (_lib.FLAG_P2P if p2p else 0)
         P.trace_iters = int(trace_iters)
         P.M0, P.zlen = self.M0, self.zlen
         P.seed = self.seed
@@ -242,6 +243,17 @@ class DeviceChains:
     def comm_init(self, unique_id, rank, nranks):
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)
         check(self.lib.mc3hip_comm_init(self._ctx, buf, int(rank), int(nranks)))
+
+    def p2p_export(self):
+        """IPC handles (128 bytes) of this rank's Z / log_post replicas."""
+        buf = ctypes.create_string_buffer(128)
+        check(self.lib.mc3hip_p2p_export(self._ctx, buf))
+        return buf.raw
+
+    def p2p_attach(self, rank, handles):
+        """handles: the 128-byte export of every rank, in rank order."""
+        blob = ctypes.create_string_buffer(b''.join(handles), 128*len(handles))
+        check(self.lib.mc3hip_p2p_attach(self._ctx, int(rank), len(handles), blob))
 
     def comm_gather_log_post(self):
         check(self.lib.mc3hip_comm_gather_log_post(self._ctx))

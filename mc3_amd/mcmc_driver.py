@@ -128,7 +128,8 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
         priorup=priorup, nchains=nchains, sampler=sampler, wlike=wlike,
         thinning=thinning, fgamma=fgamma, fepsilon=fepsilon, hsize=hsize,
         model=lowered.family, nmodel=lowered.ncoef, seed=seed, device=device,
-        chain0=chain0, nlocal=nlocal, M0=M0, zlen=zlen)
+        chain0=chain0, nlocal=nlocal, M0=M0, zlen=zlen,
+        **({'p2p': True} if comm.wants_p2p else {}))
     view = ChainView(engine, func, indparams, indparams_dict, data, wlike,
                      lowered.offset)
     bestp = np.copy(params)
@@ -217,6 +218,8 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
         """Pull state (and rows) from the device into the Chain-shaped view."""
         if final:
             comm.finish(engine)
+        else:
+            comm.quiesce(engine)
         st = comm.reduce_state(engine.state())
         done = st['refresh_done']
         # global best: chain.py:268-274 applied to every accepted state in

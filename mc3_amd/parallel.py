@@ -7,8 +7,13 @@ the contiguous block of chains [r*n, (r+1)*n) and a full replica of Z; after
 every refresh the new rows are exchanged so the next proposals see the whole
 population:
 
-* ``native`` (GPU): ONE in-place ``ncclAllGather`` (RCCL over xGMI) issued by
-  libmc3hip on its own stream -- mc3hip_comm_init / mc3hip_run.
+* ``p2p`` (GPU, preferred): the persistent kernel publishes every new row straight
+  into every rank's replica (peer-to-peer stores over xGMI into IPC-mapped,
+  fine-grained memory) and polls its local one -- the single-GPU in-launch hand-off
+  extended across GPUs; no collective, no kernel boundary between iterations
+  (mc3hip_p2p_export / mc3hip_p2p_attach).
+* ``rccl`` (GPU, fallback): ONE in-place ``ncclAllGather`` (RCCL over xGMI) per
+  refresh issued by libmc3hip on its own stream -- mc3hip_comm_init / mc3hip_run.
 * host-staged (any engine, used by the CPU tests with gloo and as a fallback):
   rows are read back, all-gathered through ``torch.distributed`` and installed
   with ``put_rows``.
@@ -24,6 +29,11 @@ class SingleRank:
     rank = 0
     size = 1
     native = False
+    mode = 'single'
+    wants_p2p = False
+
+    def quiesce(self, engine):
+        pass
 
     def partition(self, nchains):
         return 0, nchains
@@ -47,14 +57,22 @@ class SingleRank:
 class TorchDistComm:
     """Communicator over an initialised ``torch.distributed`` process group."""
 
-    def __init__(self, use_rccl=True, group=None):
+    def __init__(self, use_rccl=True, use_p2p=True, group=None):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
         self.use_rccl = use_rccl
+        self.wants_p2p = bool(use_p2p) and self.size > 1
         self.native = False
+        self.mode = 'host'
+
+    def _all_ok(self, ok):
+        """True iff every rank reports success."""
+        box = [None]*self.size
+        self.dist.all_gather_object(box, bool(ok), group=self.group)
+        return all(box)
 
     def partition(self, nchains):
         if nchains % self.size:
@@ -72,11 +90,36 @@ class TorchDistComm:
         """RCCL inside the library when the engine offers it, else host-staged."""
         if self.size == 1:
             return
+        if self.wants_p2p and hasattr(engine, 'p2p_export'):
+            # every rank must succeed at every step, or all fall back together
+            handle, ok = None, False
+            try:
+                if engine.plan.get('persistent', 0) > 0:
+                    handle = engine.p2p_export()
+                    ok = True
+            except Exception:
+                ok = False
+            if self._all_ok(ok):
+                handles = [None]*self.size
+                self.dist.all_gather_object(handles, handle, group=self.group)
+                try:
+                    engine.p2p_attach(self.rank, handles)
+                    ok = True
+                except Exception:
+                    ok = False
+                if self._all_ok(ok):
+                    self.dist.barrier(group=self.group)   # every replica is ready
+                    self.native = True
+                    self.mode = 'p2p'
+                    return
+                if ok:
+                    raise RuntimeError('peer-to-peer attach succeeded on some ranks only')
         if self.use_rccl and hasattr(engine, 'comm_init'):
             from . import engine as eng
             uid = self.broadcast(eng.comm_unique_id() if self.rank == 0 else None)
             engine.comm_init(uid, self.rank, self.size)
             self.native = True
+            self.mode = 'rccl'
 
     def exchange(self, engine, refresh):
         """Make the rows of ``refresh`` complete on every rank."""
@@ -95,11 +138,20 @@ class TorchDistComm:
             a = part.numpy()
             engine.put_rows(row0 + r*n, a[:, :-1], a[:, -1])
 
+    def quiesce(self, engine):
+        """After this, the rows of every completed refresh are in the local
+        replica: with peer-to-peer stores the other ranks may still be writing
+        when the local kernel has finished."""
+        if self.size > 1 and self.mode == 'p2p':
+            engine.sync()
+            self.dist.barrier(group=self.group)
+
     def finish(self, engine):
         """Complete what the per-refresh exchange leaves out (log_post rows on
-        the native path)."""
-        if self.size > 1 and self.native:
+        the RCCL path)."""
+        if self.size > 1 and self.mode == 'rccl':
             engine.comm_gather_log_post()
+        self.quiesce(engine)
 
     def reduce_state(self, state):
         """Gather per-chain state from every rank (chain order) and sum the

@@ -16,7 +16,7 @@ class OracleChains:
                  nsamples=None, sampler='snooker', wlike=False, thinning=1,
                  fgamma=1.0, fepsilon=0.0, hsize=10, model='poly', nmodel=None,
                  seed=0, device=0, chain0=0, nlocal=None, M0=None, zlen=None,
-                 trace_iters=0, no_graph=False, no_persist=False, nthreads=1):
+                 trace_iters=0, no_graph=False, no_persist=False, p2p=False, nthreads=1):
         if M0 is None:
             M0 = hsize*nchains
         if nsamples is None:

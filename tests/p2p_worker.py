@@ -1,0 +1,43 @@
+"""Worker for tests/test_gpu_p2p.py: one rank of a sharded mcmc() run on the GPU
+with the peer-to-peer hand-off.  All ranks share device 0 (the test box has one
+GPU): two processes, two contexts, two persistent kernels resident at once, each
+publishing its rows into both replicas through IPC-mapped memory."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import torch.distributed as dist  # noqa: E402
+
+import mc3_amd  # noqa: E402
+from mc3_amd import parallel, utils as mu  # noqa: E402
+import helpers as H  # noqa: E402
+
+
+def main():
+    out_path, sampler, thinning, niter = (sys.argv[1], sys.argv[2], int(sys.argv[3]),
+                                          int(sys.argv[4]))
+    dist.init_process_group('gloo')
+    comm = parallel.TorchDistComm(use_p2p=True, use_rccl=False)
+    x, data, uncert = H.tutorial_data(100)
+    np.random.seed(100 + comm.rank)
+    out = mc3_amd.sample(
+        data=data, uncert=uncert, func=H.quad, params=np.array([10.0, -2.0, 0.1]),
+        indparams=[x], pstep=np.array([1.0, 0.5, 0.1]),
+        pmin=np.array([-10.0, -20.0, -10.0]), pmax=np.array([40.0, 20.0, 10.0]),
+        sampler=sampler, nsamples=16*niter*thinning, burnin=10, nchains=16,
+        thinning=thinning, grtest=True, log=mu.Log(verb=0), seed=99, comm=comm,
+        device=0)
+    assert comm.mode == 'p2p', comm.mode
+    np.savez(f'{out_path}.rank{comm.rank}.npz',
+             **{k: v for k, v in out.items() if k not in ('pnames', 'texnames')})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
