@@ -130,6 +130,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if 'MC3HIP_BENCH_DEVICE' in os.environ:      # testing: several ranks on one GPU
+        local_rank = int(os.environ['MC3HIP_BENCH_DEVICE'])
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit('bench.py --gpus N>1 must be launched with torch.distributed.run '
@@ -146,25 +148,55 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo', rank=rank, world_size=world)
 
-    from mc3_amd import engine
+    from mc3_amd import engine, parallel
 
     nchains = CHAINS_PER_GPU*world
     nrefresh = args.steps + args.warmup
-    prob = c2_problem(nchains, nrefresh, args.thinning)
-    gpu = engine.DeviceChains(device=local_rank, chain0=rank*CHAINS_PER_GPU,
-                              nlocal=CHAINS_PER_GPU, **prob)
-    Z0, lp0 = initial_population(prob, gpu.eval_chisq)
-    gpu.set_population(Z0, lp0)
-    if world > 1 or force_comm:
-        ids = [engine.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        gpu.comm_init(ids[0], rank, world)
+    prob = c2_problem(nchains, nrefresh + 64, args.thinning)
+    comm = None
+    exchange = None
+
+    def make_engine(p2p):
+        g = engine.DeviceChains(device=local_rank, chain0=rank*CHAINS_PER_GPU,
+                                nlocal=CHAINS_PER_GPU, p2p=p2p, **prob)
+        Z0, lp0 = initial_population(prob, g.eval_chisq)
+        g.set_population(Z0, lp0)
+        return g
+
+    if world > 1:
+        # preferred: the in-launch hand-off across GPUs (peer-to-peer stores into every
+        # rank's Z replica); validated on a short run, else one RCCL all-gather per
+        # refresh.  Every rank takes the same branch.
+        comm = parallel.TorchDistComm(use_p2p=not os.environ.get('MC3HIP_BENCH_NO_P2P'))
+        gpu = make_engine(comm.wants_p2p)
+        comm.setup(gpu)
+        if comm.mode == 'p2p':
+            try:
+                gpu.run(64)
+                comm.quiesce(gpu)
+                ok = True
+            except Exception as e:          # noqa: BLE001
+                print(f'[rank {rank}] peer-to-peer hand-off failed ({e}); using RCCL',
+                      file=sys.stderr, flush=True)
+                ok = False
+            if not comm._all_ok(ok):
+                gpu.close()
+                comm = parallel.TorchDistComm(use_p2p=False)
+                gpu = make_engine(False)
+                comm.setup(gpu)
+        exchange = comm.mode
+    else:
+        gpu = make_engine(False)
+        if force_comm:
+            ids = [engine.comm_unique_id()]
+            gpu.comm_init(ids[0], 0, 1)
+            exchange = 'rccl'
 
     def barrier():
         gpu.sync()
         if world > 1 or force_comm:
             torch.cuda.synchronize(local_rank)
-            dist.barrier()
+            dist.barrier()          # with peer-to-peer stores: every peer has finished too
 
     gpu.run(args.warmup)
     barrier()
@@ -178,15 +210,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, gpu_ms = float(t[0]), float(t[1])
 
+    consistent = None
+    if world > 1:
+        # every rank must hold the same Z rows: compare a digest of the last refreshes
+        done = gpu.refresh_done
+        Zt, _, _ = gpu.rows(gpu.M0 + (done - 8)*nchains, 8*nchains)
+        digest = float(np.sum(Zt*np.arange(1, Zt.size + 1).reshape(Zt.shape)))
+        box = [None]*world
+        dist.all_gather_object(box, digest)
+        consistent = bool(all(d == box[0] for d in box) and np.all(np.isfinite(Zt)))
     st = gpu.state()
-    accept = float(st['numaccept'].sum())/(CHAINS_PER_GPU*nrefresh*args.thinning)
+    accept = float(st['numaccept'].sum())/(CHAINS_PER_GPU*gpu.refresh_done*args.thinning)
     chain_steps = nchains*args.steps*args.thinning
     value = chain_steps/dt/1e6
 
     # roofline of the dominant (only) kernel.  Persistent path: one launch covers
     # `persistent` refreshes; per-refresh path: one launch per refresh.
     multi = world > 1 or force_comm
-    per = 0 if multi else gpu.plan['persistent']
+    per = gpu.plan['persistent'] if (not multi or exchange == 'p2p') else 0
     if per > 0:
         launches = -(-args.steps//per)
         kernel = 'mc3hip::persist_fast_kernel' if gpu.plan['fast'] else 'mc3hip::persist_kernel'
@@ -223,11 +264,14 @@ def main():
             'nchains': nchains, 'ndata': NDATA, 'thinning': args.thinning,
             'chains_per_gpu': CHAINS_PER_GPU,
             'parallelism': f'chains sharded x{world}' if world > 1 else 'single GPU',
-            'collective': 'one in-place RCCL all-gather of new Z rows per refresh'
-                          if world > 1 else None,
+            'collective': {None: None, 'rccl': 'one in-place RCCL all-gather of new Z rows per '
+                           'refresh', 'p2p': 'none: every new Z row is stored peer-to-peer into '
+                           'every rank\'s replica by the persistent kernel (xGMI)',
+                           'host': 'host-staged'}[exchange],
             'launch_structure': structure,
             'waves_per_chain': gpu.plan['waves_per_chain'],
             'acceptance_rate': accept,
+            'replicas_consistent': consistent,
         },
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
