@@ -241,7 +241,7 @@ def main():
              f' (hipGraph of {gpu.plan["graph_nodes"]} nodes)')
     traffic = None
     pmc = os.path.join(ROOT, 'profiles', 'r01b_c2_pmc.json')
-    if os.path.exists(pmc) and args.thinning == 1:
+    if os.path.exists(pmc) and args.thinning == 1 and world == 1:
         with open(pmc) as f:
             rec = json.load(f)
         if rec['kernel'].startswith(kernel):
