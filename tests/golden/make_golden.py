@@ -216,6 +216,45 @@ def kernel_vectors():
     print('kernel_vectors:', len(out), 'arrays')
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and 'tutorial' not in sys.argv:
     kernel_vectors()
     chain_cases()
+
+
+def tutorial_summary():
+    """BASELINE.json configs[0]: examples/tutorial.py (quadratic fit, snooker,
+    nchains=7, nsamples=1e5, burnin=1000) run by the reference itself; only summary
+    statistics are kept (the comparison is statistical: different generator)."""
+    np.random.seed(314)
+    x = np.linspace(0, 10, 1000)
+    p_true = [3.0, -2.4, 0.5]
+    y = quad(p_true, x)
+    uncert = np.sqrt(np.abs(y))
+    data = y + np.random.normal(0, uncert)
+    np.random.seed(2)
+    cwd = os.getcwd()
+    os.chdir('/tmp')
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = mc3.sample(
+                data=data, uncert=uncert, func=quad, params=np.array([10.0, -2.0, 0.1]),
+                indparams=[x], pmin=np.array([-10.0, -20.0, -10.0]),
+                pmax=np.array([40.0, 20.0, 10.0]), pstep=np.array([1.0, 0.5, 0.1]),
+                sampler='snooker', nsamples=1e5, burnin=1000, nchains=7, ncpu=1,
+                grtest=True, plots=False, log=None)
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(
+        os.path.join(HERE, 'tutorial_summary.npz'),
+        meanp=out['meanp'], stdp=out['stdp'], medianp=out['medianp'],
+        median_low_bounds=out['median_low_bounds'],
+        median_high_bounds=out['median_high_bounds'], bestp=out['bestp'],
+        best_chisq=out['best_chisq'], red_chisq=out['red_chisq'], BIC=out['BIC'],
+        stddev_residuals=out['stddev_residuals'],
+        acceptance_rate=out['acceptance_rate'], nrows=len(out['posterior']))
+    print('tutorial_summary:', out['meanp'], out['stdp'], out['best_chisq'],
+          out['acceptance_rate'])
+
+
+if __name__ == '__main__' and 'tutorial' in sys.argv:
+    tutorial_summary()

@@ -151,3 +151,38 @@ def test_device_gelman_rubin_matches_host():
             np.testing.assert_allclose(got, want, rtol=1e-11)
         with pytest.raises(Exception, match='leaves no rows'):
             gpu.chain_moments(1234)
+
+
+def test_tutorial_config_against_reference_summary(golden_dir):
+    """BASELINE.json configs[0]: examples/tutorial.py (quadratic fit, snooker, 7
+    chains, 1e5 samples, burnin 1000).  The reference ran it with its own generator
+    (tests/golden/tutorial_summary.npz); the GPU run must agree within Monte-Carlo
+    error on every posterior summary and find the same best fit."""
+    import mc3_amd
+    from mc3_amd import utils as mu
+    g = np.load(os.path.join(golden_dir, 'tutorial_summary.npz'))
+    np.random.seed(314)
+    x = np.linspace(0, 10, 1000)
+    y = quad([3.0, -2.4, 0.5], x)
+    uncert = np.sqrt(np.abs(y))
+    data = y + np.random.normal(0, uncert)
+    np.random.seed(2)
+    out = mc3_amd.sample(
+        data=data, uncert=uncert, func=quad, params=np.array([10.0, -2.0, 0.1]),
+        indparams=[x], pmin=np.array([-10.0, -20.0, -10.0]),
+        pmax=np.array([40.0, 20.0, 10.0]), pstep=np.array([1.0, 0.5, 0.1]),
+        sampler='snooker', nsamples=1e5, burnin=1000, nchains=7, grtest=True,
+        log=mu.Log(verb=0), seed=5)
+    assert len(out['posterior']) == int(g['nrows'])
+    sd = g['stdp']
+    # ~1e5 samples with autocorrelation: means within 0.1 sigma, widths within 6 %
+    assert np.all(np.abs(out['meanp'] - g['meanp']) < 0.1*sd)
+    assert np.all(np.abs(out['medianp'] - g['medianp']) < 0.1*sd)
+    assert np.all(np.abs(out['stdp']/sd - 1.0) < 0.06)
+    assert np.all(np.abs(out['median_low_bounds'] - g['median_low_bounds']) < 0.15*sd)
+    assert np.all(np.abs(out['median_high_bounds'] - g['median_high_bounds']) < 0.15*sd)
+    # the best fit is a property of the data, not of the sampler
+    np.testing.assert_allclose(out['best_chisq'], g['best_chisq'], rtol=2e-4)
+    np.testing.assert_allclose(out['bestp'], g['bestp'], atol=0.3*sd.max(), rtol=0.05)
+    np.testing.assert_allclose(out['stddev_residuals'], g['stddev_residuals'], rtol=1e-3)
+    assert abs(out['acceptance_rate'] - g['acceptance_rate']) < 4.0
