@@ -319,9 +319,6 @@ __device__ __forceinline__ double block_gauss_model(const DevProblem &P, const M
     constexpr int NV = 16 / WPC;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double acc[NV];
-    // +inf trap (chain.py:322-323) through a running maximum: one v_max_f64 per
-    // point instead of a compare/and/or chain; IEEE maxNum ignores NaNs.
-    double mmax = -1.0;
     const int npad = P.npad;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -330,7 +327,6 @@ __device__ __forceinline__ double block_gauss_model(const DevProblem &P, const M
             m = model.at(lane + 64 * (wv + WPC * v));
         else
             m = model.at_x(tile.x[v]);
-        mmax = __builtin_fmax(mmax, m);
         const double r = (m - tile.d[v]) * tile.w[v];
         acc[v] = mc3_fma(r, r, 0.0);
     }
@@ -352,14 +348,28 @@ __device__ __forceinline__ double block_gauss_model(const DevProblem &P, const M
                 m = model.at(base + lane + 64 * (wv + WPC * v));
             else
                 m = model.at_x(xs[v]);
-            mmax = __builtin_fmax(mmax, m);
             const double r = (m - ds[v]) * ws[v];
             acc[v] = mc3_fma(r, r, acc[v]);
         }
     }
+    // The "+inf model => chisq = inf" trap of chain.py:322-323 is resolved lazily: a
+    // +inf model value makes its own partial sum non-finite (inf, or NaN where w = 0),
+    // so only then are the model values scanned to tell a +inf model from any other
+    // overflow.  The hot path pays nothing for it.
+    double any = 0.0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        any = any + acc[v];                           // finite iff every partial is
+    const bool bad = (mc3_bits(any) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
     const double total = lane_tree<WPC>(acc, s_part);
-    const int sawinf = block_or<WPC>(is_pos_inf(mmax), s_flag);
-    return sawinf ? mc3_from_bits(0x7ff0000000000000ull) : total;
+    if (block_or<WPC>(bad, s_flag)) {
+        int saw = 0;
+        for (int i = threadIdx.x; i < P.ndata; i += 64 * WPC)
+            saw |= is_pos_inf(model.at(i));
+        if (block_or<WPC>(saw, s_flag))
+            return mc3_from_bits(0x7ff0000000000000ull);
+    }
+    return total;
 }
 
 constexpr double D4C0 = 0.4829629131445341, D4C1 = 0.83651630373780772,
