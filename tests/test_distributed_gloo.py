@@ -49,3 +49,28 @@ def test_two_ranks_reproduce_single_rank(tmp_path, sampler, thinning):
         for key in ('posterior', 'zchain', 'log_post', 'chisq', 'bestp',
                     'acceptance_rate', 'best_log_post', 'medianp', 'stdp'):
             np.testing.assert_array_equal(got[key], single[key], err_msg=key)
+
+
+def test_communicator_mode_selection_single_process():
+    """Mode selection logic without a process group: a single rank never sets up
+    an exchange; the partition is the whole ensemble."""
+    from mc3_amd import parallel
+    comm = parallel.SingleRank()
+    assert comm.partition(12) == (0, 12)
+    assert comm.mode == 'single' and not comm.wants_p2p and not comm.native
+    assert comm.broadcast({'a': 1}) == {'a': 1}
+    state = {'numaccept': np.arange(3)}
+    assert comm.reduce_state(state) is state
+
+
+def test_peer_to_peer_falls_back_together():
+    """If any rank cannot export its replica, every rank drops the peer-to-peer
+    mode (no rank may end up alone in it)."""
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()),
+           os.path.join(ROOT, 'tests', 'p2p_fallback_worker.py')]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert res.stdout.count('fallback ok') == 2
