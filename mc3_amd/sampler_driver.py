@@ -239,10 +239,17 @@ def sample(
     posterior, zchain, zmask = mu.burn(
         Z=output['posterior'], zchain=output['zchain'], burnin=output['burnin'])
     bestp = output['bestp']
-    stats = ms.calc_sample_statistics(posterior, bestp, pstep, calc_hpd=True)
-    (output['medianp'], output['meanp'], output['stdp'],
-     output['median_low_bounds'], output['median_high_bounds'],
-     output['mode'], output['hpd_low_bounds'], output['hpd_high_bounds']) = stats
+    # the median / central-interval statistics of this same burned posterior were
+    # computed by update_output (sampler_driver.py:490-497 recomputes them); only the
+    # KDE-based mode and HPD bounds are added here
+    if 'medianp' in output and 'zmask' in output and len(output['zmask']) == len(zmask):
+        mode, hlo, hhi = ms.hpd_statistics(posterior, bestp, pstep)
+    else:
+        stats = ms.calc_sample_statistics(posterior, bestp, pstep, calc_hpd=True)
+        (output['medianp'], output['meanp'], output['stdp'],
+         output['median_low_bounds'], output['median_high_bounds'],
+         mode, hlo, hhi) = stats
+    output['mode'], output['hpd_low_bounds'], output['hpd_high_bounds'] = mode, hlo, hhi
     output['CRlo'] = output['hpd_low_bounds'] - bestp
     output['CRhi'] = output['hpd_high_bounds'] - bestp
     output['CRlo'][pstep == 0] = output['CRhi'][pstep == 0] = 0.0

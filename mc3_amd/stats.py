@@ -119,6 +119,19 @@ def calc_sample_statistics(posterior, bestp, pstep, quantile=0.683,
     return base + (out['mode'], out['hlow'], out['hhigh'])
 
 
+def hpd_statistics(posterior, bestp, pstep, quantile=0.683):
+    """The KDE half of calc_sample_statistics(calc_hpd=True): marginal mode and
+    highest-posterior-density bounds over all parameters."""
+    pstep = np.asarray(pstep, float)
+    ifree = np.flatnonzero(pstep > 0)
+    mode, lo, hi = np.copy(bestp), np.copy(bestp), np.copy(bestp)
+    mode[ifree], lo[ifree], hi[ifree] = marginal_statistics(posterior, 'max_like', quantile)
+    for i in np.flatnonzero(pstep < 0):
+        j = -int(pstep[i]) - 1
+        mode[i], lo[i], hi[i] = mode[j], lo[j], hi[j]
+    return mode, lo, hi
+
+
 def calc_bestfit_statistics(bestp, chain):
     """best chisq, reduced chisq, BIC, log-posterior, model and residual scatter
     at the best-fitting parameters (stats.py:855-873)."""

@@ -22,15 +22,16 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize('sampler,thinning,niter', [('demc', 1, 400), ('snooker', 2, 200)])
-def test_two_processes_peer_to_peer(tmp_path, sampler, thinning, niter):
+@pytest.mark.parametrize('nproc,sampler,thinning,niter', [
+    (2, 'demc', 1, 400), (2, 'snooker', 2, 200), (4, 'demc', 1, 300), (4, 'snooker', 1, 300)])
+def test_processes_peer_to_peer(tmp_path, nproc, sampler, thinning, niter):
     import mc3_amd
     from mc3_amd import utils as mu
     from oracle_engine import OracleChains
     out_path = str(tmp_path / 'p2p')
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-           '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           f'--nproc-per-node={nproc}', '--master-addr', '127.0.0.1',
            '--master-port', str(free_port()),
            os.path.join(ROOT, 'tests', 'p2p_worker.py'), out_path, sampler,
            str(thinning), str(niter)]
@@ -46,7 +47,7 @@ def test_two_processes_peer_to_peer(tmp_path, sampler, thinning, niter):
         sampler=sampler, nsamples=16*niter*thinning, burnin=10, nchains=16,
         thinning=thinning, grtest=True, log=mu.Log(verb=0),
         engine_factory=OracleChains, seed=99)
-    for rank in (0, 1):
+    for rank in range(nproc):
         got = np.load(f'{out_path}.rank{rank}.npz')
         for key in ('posterior', 'zchain', 'log_post', 'chisq', 'bestp',
                     'acceptance_rate', 'best_log_post', 'medianp', 'stdp'):
