@@ -121,8 +121,8 @@ def cpu_baseline(target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40000)
-    ap.add_argument('--warmup', type=int, default=2048)
+    ap.add_argument('--steps', type=int, default=49152)      # 3 launches of 16384 refreshes
+    ap.add_argument('--warmup', type=int, default=16384)     # 1 launch of the same size
     ap.add_argument('--thinning', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()

@@ -1,0 +1,84 @@
+"""The drop-in boundary without a GPU: libmc3hip.so loads, exports every entry
+point include/mc3hip.h declares, the ctypes mirror of its structs has the C
+layout, and the product never reaches into oracle/.  No compute calls here."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'mc3hip.h')
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(mc3hip_\w+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mc3_amd import _lib
+    lib = _lib.load()
+    names = declared_functions()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), f'{name} declared in include/mc3hip.h but not exported'
+    assert sorted(_lib.SYMBOLS) == names, 'mc3_amd/_lib.py binds a different set of symbols'
+
+
+def test_error_reporting_without_a_gpu():
+    """Argument errors are reported through return codes + mc3hip_last_error, never
+    by aborting; with no GPU present creation fails with a HIP error code."""
+    from mc3_amd import _lib
+    lib = _lib.load()
+    assert lib.mc3hip_create(None, None) == _lib.ERR_ARG
+    assert b'null' in lib.mc3hip_last_error()
+    P = _lib.Problem()
+    P.struct_bytes = 1
+    ctx = ctypes.c_void_p()
+    assert lib.mc3hip_create(ctypes.byref(P), ctypes.byref(ctx)) == _lib.ERR_ARG
+    assert b'size mismatch' in lib.mc3hip_last_error()
+    assert lib.mc3hip_run(None, 1) == _lib.ERR_ARG
+    lib.mc3hip_destroy(None)
+
+
+def test_ctypes_structs_match_the_c_layout(tmp_path):
+    from mc3_amd import _lib
+    src = tmp_path / 'layout.c'
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "mc3hip.h"\n'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(mc3hip_problem),'
+        ' offsetof(mc3hip_problem, M0), offsetof(mc3hip_problem, gamma),'
+        ' offsetof(mc3hip_problem, uncert), sizeof(mc3hip_plan),'
+        ' offsetof(mc3hip_plan, persistent)); return 0;}\n')
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(_lib.Problem), _lib.Problem.M0.offset, _lib.Problem.gamma.offset,
+            _lib.Problem.uncert.offset, ctypes.sizeof(_lib.Plan), _lib.Plan.persistent.offset]
+    assert got == want
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use
+    oracle/: nothing under mc3_amd/ (Python or C++) mentions it."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'mc3_amd')):
+        for f in files:
+            if f.endswith(('.py', '.h', '.hip', '.cpp')):
+                text = open(os.path.join(dirpath, f), errors='ignore').read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M) or \
+                        'liboracle' in text or 'oracle/' in text.replace('oracle/oracle_lockstep.c follows', ''):
+                    bad.append(os.path.join(dirpath, f))
+    assert bad == []
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from mc3_amd import _lib
+    monkeypatch.setattr(_lib, '_LIB', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(ImportError, match='no CPU fallback'):
+        _lib.load()
