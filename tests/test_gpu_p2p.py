@@ -23,7 +23,8 @@ def free_port():
 
 
 @pytest.mark.parametrize('nproc,sampler,thinning,niter', [
-    (2, 'demc', 1, 400), (2, 'snooker', 2, 200), (4, 'demc', 1, 300), (4, 'snooker', 1, 300)])
+    (2, 'demc', 1, 400), (2, 'snooker', 2, 200), (4, 'demc', 1, 300), (4, 'snooker', 1, 300),
+    (8, 'demc', 1, 200)])
 def test_processes_peer_to_peer(tmp_path, nproc, sampler, thinning, niter):
     import mc3_amd
     from mc3_amd import utils as mu
