@@ -166,6 +166,25 @@ int mc3hip_eval_chisq(mc3hip_ctx *ctx, const double *params, int32_t n,
 /* Replaces Chain.eval_model(params, ret='model') for the declared family. */
 int mc3hip_eval_model(mc3hip_ctx *ctx, const double *params, double *model_out);
 
+/* The public functions of the reference's two C extension modules on arbitrary
+ * model arrays (what mc3.stats.chisq / residuals / dwt_chisq call,
+ * mc3/stats/stats.py:97-284): _chisq.residuals (src_c/_chisq.c:37-79),
+ * _chisq.chisq (:111-140) and _dwt.chisq (src_c/_dwt.c:56-119).  off/plow/pup are the
+ * np Gaussian-prior entries (param - prior, lower and upper widths) the Python
+ * wrapper selects (stats.py:211-216); np may be 0.  residuals_out holds n + np
+ * doubles.  dwt_chisq needs power-of-two n <= 2^24 (see mc3hip_create). */
+int mc3hip_residuals(int32_t device, const double *model, const double *data,
+                     const double *uncert, int32_t n, const double *off,
+                     const double *plow, const double *pup, int32_t np,
+                     double *residuals_out);
+int mc3hip_chisq(int32_t device, const double *model, const double *data,
+                 const double *uncert, int32_t n, const double *off, const double *plow,
+                 const double *pup, int32_t np, double *chisq_out);
+int mc3hip_dwt_chisq(int32_t device, const double *params, int32_t nparams,
+                     const double *model, const double *data, int32_t n,
+                     const double *off, const double *plow, const double *pup,
+                     int32_t np, double *chisq_out);
+
 /* Replaces ms.dwt_daub4 (_dwt.c:154-186, wavelet.h:16-128): n is padded to the
  * next power of two with zeros, out must hold that many doubles. */
 int mc3hip_dwt_daub4(int32_t device, const double *in, int32_t n,

@@ -79,6 +79,12 @@ SYMBOLS = {
     'mc3hip_chain_moments': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _dp]),
     'mc3hip_eval_chisq': (ctypes.c_int, [_vp, _dp, ctypes.c_int32, _dp]),
     'mc3hip_eval_model': (ctypes.c_int, [_vp, _dp, _dp]),
+    'mc3hip_residuals': (ctypes.c_int, [ctypes.c_int32, _dp, _dp, _dp, ctypes.c_int32, _dp, _dp,
+                                        _dp, ctypes.c_int32, _dp]),
+    'mc3hip_chisq': (ctypes.c_int, [ctypes.c_int32, _dp, _dp, _dp, ctypes.c_int32, _dp, _dp, _dp,
+                                    ctypes.c_int32, _dp]),
+    'mc3hip_dwt_chisq': (ctypes.c_int, [ctypes.c_int32, _dp, ctypes.c_int32, _dp, _dp,
+                                        ctypes.c_int32, _dp, _dp, _dp, ctypes.c_int32, _dp]),
     'mc3hip_dwt_daub4': (ctypes.c_int, [ctypes.c_int32, _dp, ctypes.c_int32, ctypes.c_int32, _dp]),
     'mc3hip_comm_unique_id': (ctypes.c_int, [_vp]),
     'mc3hip_comm_init': (ctypes.c_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int32]),

@@ -1257,6 +1257,49 @@ __global__ void daub4_kernel(double *a, double *tmp, int n, int inverse)
     }
 }
 
+// ---- standalone likelihood kernels: the public functions of the reference's
+// _chisq / _dwt extension modules on arbitrary model arrays --------------------
+// residuals, src_c/_chisq.c:37-79: (model-data)/uncert, then the prior residuals
+__global__ void residuals_kernel(const double *model, const double *data, const double *uncert,
+                                 int n, const double *off, const double *plow,
+                                 const double *pup, int np, double *out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n + np; i += gridDim.x * blockDim.x) {
+        if (i < n) {
+            out[i] = (model[i] - data[i]) / uncert[i];
+        } else {
+            const int j = i - n;
+            out[i] = (off[j] > 0.0) ? off[j] / pup[j] : off[j] / plow[j];
+        }
+    }
+}
+
+// Sum of squares of v[0..n) with optional per-element weights given by scale
+// (wavelet: weight = inv[floor(log2 j)] for j >= 2, 0 below): one workgroup of 1024
+// threads, canonical order (strided partials over 1024 lanes, halving tree).
+__global__ __launch_bounds__(1024) void sumsq_kernel(const double *v, int n, const double *inv,
+                                                     double *out)
+{
+    __shared__ double s_part[1024];
+    double acc[1] = {0.0};
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        if (inv == nullptr) {
+            acc[0] = mc3_fma(v[i], v[i], acc[0]);
+        } else if (i >= 2) {
+            acc[0] = mc3_fma(v[i] * v[i], inv[31 - __clz(i)], acc[0]);
+        }
+    }
+    const double t = lane_tree<16>(acc, s_part);
+    if (threadIdx.x == 0)
+        out[0] = t;
+}
+
+__global__ void diff_kernel(const double *a, const double *b, int n, int npad, double *out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += gridDim.x * blockDim.x)
+        out[i] = (i < n) ? a[i] - b[i] : 0.0;
+}
+
 // Per-chain mean and (population) variance of every free parameter over the rows a
 // chain has written, skipping its first `burn` rows: the reductions the
 // Gelman-Rubin test needs (mc3/stats/gelman.py:12-92) without copying Z to the host.

@@ -1173,6 +1173,152 @@ int mc3hip_dwt_daub4(int32_t device, const double *in, int32_t n, int32_t invers
     return rc;
 }
 
+namespace {
+
+// device buffers of one standalone call, released on scope exit
+struct Scratch {
+    std::vector<void *> ptrs;
+    ~Scratch()
+    {
+        for (void *p : ptrs)
+            (void)hipFree(p);
+    }
+    double *up(const double *src, size_t n, hipError_t *e)
+    {
+        void *p = nullptr;
+        if (*e == hipSuccess)
+            *e = hipMalloc(&p, (n ? n : 1) * sizeof(double));
+        if (*e == hipSuccess)
+            ptrs.push_back(p);
+        if (*e == hipSuccess && src && n)
+            *e = hipMemcpy(p, src, n * sizeof(double), hipMemcpyHostToDevice);
+        return static_cast<double *>(p);
+    }
+};
+
+// prior term on the host exactly as src_c/include/stats.h:96-106 (np is tiny)
+double host_priors(const double *off, const double *plow, const double *pup, int np)
+{
+    double pr = 0.0;
+    for (int j = 0; j < np; ++j) {
+        const double s = (off[j] > 0.0) ? off[j] / pup[j] : off[j] / plow[j];
+        pr = pr + s * s;
+    }
+    return pr;
+}
+
+}  // namespace
+
+int mc3hip_residuals(int32_t device, const double *model, const double *data,
+                     const double *uncert, int32_t n, const double *off, const double *plow,
+                     const double *pup, int32_t np, double *out)
+{
+    if (!model || !data || !uncert || !out || n < 0 || np < 0 || (np > 0 && (!off || !plow || !pup)))
+        return fail(MC3HIP_ERR_ARG, "bad argument");
+    if (n + np == 0)
+        return MC3HIP_OK;
+    HIP_TRY(hipSetDevice(device));
+    Scratch S;
+    hipError_t e = hipSuccess;
+    double *dm = S.up(model, n, &e), *dd = S.up(data, n, &e), *du = S.up(uncert, n, &e);
+    double *dof = S.up(off, np, &e), *dlo = S.up(plow, np, &e), *dup = S.up(pup, np, &e);
+    double *dout = S.up(nullptr, (size_t)n + np, &e);
+    if (e == hipSuccess) {
+        const int nb = (n + np + 255) / 256;
+        hipLaunchKernelGGL(residuals_kernel, dim3(nb > 1024 ? 1024 : nb), dim3(256), 0, 0,
+                           (const double *)dm, (const double *)dd, (const double *)du, n,
+                           (const double *)dof, (const double *)dlo, (const double *)dup, np, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpy(out, dout, ((size_t)n + np) * sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        return fail(MC3HIP_ERR_HIP, "residuals: %s", hipGetErrorString(e));
+    return MC3HIP_OK;
+}
+
+int mc3hip_chisq(int32_t device, const double *model, const double *data, const double *uncert,
+                 int32_t n, const double *off, const double *plow, const double *pup, int32_t np,
+                 double *chisq_out)
+{
+    if (!model || !data || !uncert || !chisq_out || n < 1 || np < 0 ||
+        (np > 0 && (!off || !plow || !pup)))
+        return fail(MC3HIP_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    Scratch S;
+    hipError_t e = hipSuccess;
+    double *dm = S.up(model, n, &e), *dd = S.up(data, n, &e), *du = S.up(uncert, n, &e);
+    double *dres = S.up(nullptr, n, &e), *dout = S.up(nullptr, 1, &e);
+    double total = 0.0;
+    if (e == hipSuccess) {
+        const int nb = (n + 255) / 256;
+        hipLaunchKernelGGL(residuals_kernel, dim3(nb > 1024 ? 1024 : nb), dim3(256), 0, 0,
+                           (const double *)dm, (const double *)dd, (const double *)du, n,
+                           (const double *)nullptr, (const double *)nullptr,
+                           (const double *)nullptr, 0, dres);
+        hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, 0, (const double *)dres, n,
+                           (const double *)nullptr, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpy(&total, dout, sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        return fail(MC3HIP_ERR_HIP, "chisq: %s", hipGetErrorString(e));
+    *chisq_out = total + (np > 0 ? host_priors(off, plow, pup, np) : 0.0);
+    return MC3HIP_OK;
+}
+
+int mc3hip_dwt_chisq(int32_t device, const double *params, int32_t nparams, const double *model,
+                     const double *data, int32_t n, const double *off, const double *plow,
+                     const double *pup, int32_t np, double *chisq_out)
+{
+    if (!params || !model || !data || !chisq_out || np < 0 || (np > 0 && (!off || !plow || !pup)))
+        return fail(MC3HIP_ERR_ARG, "bad argument");
+    if (nparams < 3)
+        return fail(MC3HIP_ERR_ARG, "Wavelet chisq should have at least three parameters");
+    if (n < 2 || (n & (n - 1)) || n > (1 << 24))
+        return fail(MC3HIP_ERR_ARG, "wavelet likelihood needs power-of-two ndata (got %d)", n);
+    HIP_TRY(hipSetDevice(device));
+    const double gam = params[nparams - 3], sr = params[nparams - 2], sw = params[nparams - 1];
+    int M = 0;
+    while ((1 << M) < n)
+        ++M;
+    // per-scale weights, same arithmetic as the in-kernel table (block_wavelet)
+    std::vector<double> inv(32, 0.0);
+    const double sr2 = sr * sr, sw2 = sw * sw;
+    double Lg = 0.0;
+    const double sS2 = sr2 * mc3_det_exp2(-gam) * 0.72134752 + sw2;
+    Lg = 2.0 * mc3_det_log(6.283185307179586 * sS2);
+    for (int m = 1; m < M; ++m) {
+        const double sW2 = sr2 * mc3_det_exp2(-gam * (double)m) + sw2;
+        inv[m] = 1.0 / sW2;
+        Lg = Lg + (double)(1 << m) * mc3_det_log(6.283185307179586 * sW2);
+    }
+    Scratch S;
+    hipError_t e = hipSuccess;
+    double *dm = S.up(model, n, &e), *dd = S.up(data, n, &e), *dinv = S.up(inv.data(), 32, &e);
+    double *dres = S.up(nullptr, n, &e), *dtmp = S.up(nullptr, n, &e), *dout = S.up(nullptr, 1, &e);
+    double T = 0.0, head[2] = {0.0, 0.0};
+    if (e == hipSuccess) {
+        const int nb = (n + 255) / 256;
+        hipLaunchKernelGGL(diff_kernel, dim3(nb > 1024 ? 1024 : nb), dim3(256), 0, 0,
+                           (const double *)dd, (const double *)dm, n, n, dres);   // data - model
+        hipLaunchKernelGGL(daub4_kernel, dim3(1), dim3(1024), 0, 0, dres, dtmp, n, 0);
+        hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, 0, (const double *)dres, n,
+                           (const double *)dinv, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpy(&T, dout, sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+        e = hipMemcpy(head, dres, 2 * sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        return fail(MC3HIP_ERR_HIP, "dwt_chisq: %s", hipGetErrorString(e));
+    const double Ssm = (head[0] * head[0]) / sS2 + (head[1] * head[1]) / sS2;
+    *chisq_out = ((Ssm + Lg) + T) + (np > 0 ? host_priors(off, plow, pup, np) : 0.0);
+    return MC3HIP_OK;
+}
+
 int mc3hip_comm_unique_id(void *unique_id_128)
 {
     if (!unique_id_128)

@@ -34,6 +34,69 @@ def log_prior(posterior, prior, priorlow, priorup, pstep):
     return logp[0] if np.size(logp) == 1 else logp
 
 
+# ---- the L1 likelihood functions (mc3.stats.chisq / residuals / dwt_chisq /
+# dwt_daub4) on arbitrary model arrays, evaluated on the device --------------------
+def _prior_args(params, priors, priorlow, priorup):
+    """The Gaussian-prior selection of stats.py:211-216."""
+    if params is None or priors is None or priorlow is None or priorup is None:
+        return None, None, None, 0
+    params, priors, priorlow, priorup = (np.asarray(a, float) for a in
+                                         (params, priors, priorlow, priorup))
+    ip = (priorlow > 0) & (priorup > 0)
+    return (np.ascontiguousarray((params - priors)[ip]), np.ascontiguousarray(priorlow[ip]),
+            np.ascontiguousarray(priorup[ip]), int(np.sum(ip)))
+
+
+def residuals(model, data, uncert, params=None, priors=None, priorlow=None,
+              priorup=None, device=0):
+    """mc3.stats.residuals (stats.py:97-147 -> src_c/_chisq.c:37-79)."""
+    from . import _lib
+    m, d, u = (_lib.f64(a) for a in (model, data, uncert))
+    off, lo, up, npri = _prior_args(params, priors, priorlow, priorup)
+    out = np.empty(len(m) + npri)
+    _lib.check(_lib.load().mc3hip_residuals(
+        device, _lib.dptr(m), _lib.dptr(d), _lib.dptr(u), len(m), _lib.dptr(off),
+        _lib.dptr(lo), _lib.dptr(up), npri, _lib.dptr(out)))
+    return out
+
+
+def chisq(model, data, uncert, params=None, priors=None, priorlow=None,
+          priorup=None, device=0):
+    """mc3.stats.chisq (stats.py:150-216 -> src_c/_chisq.c:111-140)."""
+    import ctypes
+    from . import _lib
+    m, d, u = (_lib.f64(a) for a in (model, data, uncert))
+    off, lo, up, npri = _prior_args(params, priors, priorlow, priorup)
+    out = ctypes.c_double()
+    _lib.check(_lib.load().mc3hip_chisq(
+        device, _lib.dptr(m), _lib.dptr(d), _lib.dptr(u), len(m), _lib.dptr(off),
+        _lib.dptr(lo), _lib.dptr(up), npri,
+        ctypes.cast(ctypes.byref(out), ctypes.POINTER(ctypes.c_double))))
+    return out.value
+
+
+def dwt_chisq(model, data, params, priors=None, priorlow=None, priorup=None, device=0):
+    """mc3.stats.dwt_chisq (stats.py:219-284 -> src_c/_dwt.c:56-119)."""
+    import ctypes
+    from . import _lib
+    if len(params) < 3:
+        raise ValueError('Wavelet chisq should have at least three parameters')
+    m, d, p = (_lib.f64(a) for a in (model, data, params))
+    off, lo, up, npri = _prior_args(p, priors, priorlow, priorup)
+    out = ctypes.c_double()
+    _lib.check(_lib.load().mc3hip_dwt_chisq(
+        device, _lib.dptr(p), len(p), _lib.dptr(m), _lib.dptr(d), len(d), _lib.dptr(off),
+        _lib.dptr(lo), _lib.dptr(up), npri,
+        ctypes.cast(ctypes.byref(out), ctypes.POINTER(ctypes.c_double))))
+    return out.value
+
+
+def dwt_daub4(array, inverse=False, device=0):
+    """mc3.stats.dwt_daub4 (src_c/_dwt.c:154-186)."""
+    from . import engine
+    return engine.dwt_daub4(array, inverse, device)
+
+
 def cred_region(posterior=None, quantile=0.6827, pdf=None, xpdf=None):
     """Highest-posterior-density region from a Gaussian-KDE of a 1D sample
     (stats.py:395-467): returns (pdf, xpdf, HPDmin)."""

@@ -535,3 +535,59 @@ def test_tiled_plan_bit_exact(eng, kind, sampler, thinning):
     finally:
         del os.environ['MC3HIP_NO_TILED']
     np.testing.assert_allclose(-0.5*re, lp[-40:], rtol=1e-12)
+
+
+# ---- mc3.stats' likelihood functions on arbitrary model arrays ---------------
+def test_stats_functions_known_answers_of_the_reference():
+    """tests/test_stats.py:115-171 of the reference, through mc3_amd.stats (device)."""
+    from mc3_amd import stats as ms
+    data = np.array([1.1, 1.2, 0.9, 1.0])
+    model = np.ones(4)
+    uncert = np.full(4, 0.1)
+    np.testing.assert_allclose(ms.residuals(model, data, uncert), [-1.0, -2.0, 1.0, 0.0],
+                               atol=1e-14)
+    params, priors = np.array([2.5, 5.5]), np.array([2.0, 5.0])
+    plow = pup = np.array([0.0, 1.0])
+    np.testing.assert_allclose(ms.residuals(model, data, uncert, params, priors, plow, pup),
+                               [-1.0, -2.0, 1.0, 0.0, 0.5], atol=1e-14)
+    np.testing.assert_allclose(ms.chisq(model, data, uncert), 6.0, rtol=1e-14)
+    np.testing.assert_allclose(ms.chisq(model, data, uncert, params, priors, plow, pup), 6.25,
+                               rtol=1e-14)
+    data = np.array([2.0, 0.0, 3.0, -2.0, -1.0, 2.0, 2.0, 0.0])
+    model = np.ones(8)
+    params = np.array([1.0, 0.1, 0.1])
+    np.testing.assert_allclose(ms.dwt_chisq(model, data, params), 1693.22308882)
+    np.testing.assert_allclose(
+        ms.dwt_chisq(model, data, params, np.array([1.0, 0.2, 0.3]),
+                     np.array([0.0, 0.0, 0.1]), np.array([0.0, 0.0, 0.1])),
+        1697.2230888243134, rtol=1e-13)
+    with pytest.raises(ValueError, match='at least three parameters'):
+        ms.dwt_chisq(model, data, np.array([1.0, 0.1]))
+    e4 = np.zeros(32)
+    e4[4] = 1.0
+    np.testing.assert_allclose(ms.dwt_daub4(ms.dwt_daub4(e4, True)), e4, atol=1e-8)
+
+
+def test_stats_functions_vs_reference_vectors(golden_dir):
+    from mc3_amd import stats as ms
+    kv = np.load(os.path.join(golden_dir, 'kernel_vectors.npz'))
+    for ndata in (8, 32, 1000, 16384):
+        x, data, uncert = H.tutorial_data(ndata, 1000 + ndata)
+        P = kv[f'gauss_{ndata}_params']
+        pri = (kv['gauss_prior'], kv['gauss_priorlow'], kv['gauss_priorup'])
+        got0 = [ms.chisq(H.quad(p, x), data, uncert) for p in P[:3]]
+        got1 = [ms.chisq(H.quad(p, x), data, uncert, p, *pri) for p in P[:3]]
+        np.testing.assert_allclose(got0, kv[f'gauss_{ndata}_chisq'][:3], rtol=1e-10)
+        np.testing.assert_allclose(got1, kv[f'gauss_{ndata}_chisq_priors'][:3], rtol=1e-10)
+        res = ms.residuals(H.quad(P[0], x), data, uncert, P[0], *pri)
+        np.testing.assert_allclose(res, kv[f'gauss_{ndata}_residuals0'], rtol=1e-13)
+    for ndata in (2, 4, 8, 32, 1024, 16384):
+        rs2 = np.random.RandomState(2000 + ndata)
+        x = np.linspace(0, 10, ndata)
+        data = H.quad([3.0, -2.4, 0.5], x) + rs2.normal(0, 1.0, ndata) + 0.5*np.sin(2*np.pi*x)
+        P = kv[f'dwt_{ndata}_params']
+        pri = (kv['dwt_prior'], kv['dwt_priorlow'], kv['dwt_priorup'])
+        got0 = [ms.dwt_chisq(H.quad(p[:3], x), data, p) for p in P[:3]]
+        got1 = [ms.dwt_chisq(H.quad(p[:3], x), data, p, *pri) for p in P[:3]]
+        np.testing.assert_allclose(got0, kv[f'dwt_{ndata}_chisq'][:3], rtol=1e-10)
+        np.testing.assert_allclose(got1, kv[f'dwt_{ndata}_chisq_priors'][:3], rtol=1e-10)
