@@ -186,3 +186,31 @@ def test_tutorial_config_against_reference_summary(golden_dir):
     np.testing.assert_allclose(out['bestp'], g['bestp'], atol=0.3*sd.max(), rtol=0.05)
     np.testing.assert_allclose(out['stddev_residuals'], g['stddev_residuals'], rtol=1e-3)
     assert abs(out['acceptance_rate'] - g['acceptance_rate']) < 4.0
+
+
+def test_resume_and_early_stop_gpu_equals_cpu_checker(tmp_path):
+    """savefile -> resume (chains restart from their last Z rows, chain.py:166-169)
+    and a Gelman-Rubin early stop (mcmc_driver.py:335-346), GPU vs CPU checker."""
+    import mc3_amd
+    from mc3_amd import utils as mu
+    from oracle_engine import OracleChains
+    x, data, uncert = H.tutorial_data(100)
+    base = dict(data=data, uncert=uncert, func=quad, params=np.array([10.0, -2.0, 0.1]),
+                indparams=[x], pstep=np.array([1.0, 0.5, 0.1]),
+                pmin=np.array([-10.0, -20.0, -10.0]), pmax=np.array([40.0, 20.0, 10.0]),
+                sampler='demc', nchains=8, burnin=20, log=mu.Log(verb=0))
+    outs = {}
+    for name, extra in (('gpu', {}), ('cpu', {'engine_factory': OracleChains})):
+        sf = str(tmp_path / f'{name}.npz')
+        np.random.seed(4)
+        first = mc3_amd.sample(nsamples=1600, savefile=sf, seed=1, **base, **extra)
+        np.random.seed(5)
+        more = mc3_amd.sample(nsamples=800, savefile=sf, resume=True, seed=2, **base, **extra)
+        np.random.seed(6)
+        stop = mc3_amd.sample(nsamples=80000, grbreak=1.05, grnmin=800, seed=3,
+                              **dict(base, burnin=100), **extra)
+        outs[name] = (first, more, stop)
+    for g, c in zip(outs['gpu'], outs['cpu']):
+        assert_same_dict(g, c)
+    assert outs['gpu'][1]['posterior'].shape == (2400, 3)
+    assert len(outs['gpu'][2]['posterior']) < 80000
