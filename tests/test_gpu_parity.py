@@ -24,7 +24,8 @@ def eng():
 
 
 def run_pair(eng, prob, trace=True, nrefresh=None, **gpu_kw):
-    niter = int(np.ceil(prob['nsamples']/prob['nchains']))
+    thin = prob.get('thinning', 1)
+    niter = int(np.ceil(prob['nsamples']/prob['nchains']/thin))*thin
     gpu = eng.DeviceChains(trace_iters=niter if trace else 0, **prob, **gpu_kw)
     # the oracle sums the data in the order ("plan") the library reports
     orc = H.make_oracle(prob, tile=gpu.plan['tile'], vlanes=gpu.plan['vlanes'])
