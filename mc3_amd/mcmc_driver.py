@@ -159,6 +159,7 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
             lo, hi = pmin[ifree], pmax[ifree]
             Z0 = np.empty((M0, nfree))
             lp0 = np.empty(M0)
+            stale = np.array(params, float)
             filled = failed = 0
             while filled < M0 and failed < 100*M0:
                 block = max(256, 2*(M0 - filled))
@@ -168,8 +169,20 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
                     trial = np.random.uniform(lo, hi, (block, nfree))
                 else:
                     log.error(f"Invalid kickoff '{kickoff}'")
-                full = engine.expand_free(trial)
-                inside = ~(np.any(full > pmax, axis=1) | np.any(full < pmin, axis=1))
+                # Bounds are tested on the full vector BEFORE the shared parameters
+                # are refreshed, i.e. with the copies left by the last in-bounds trial
+                # (mcmc_driver.py:249-255) -- a sequential rule, kept on the host; only
+                # the chisq evaluations are batched on the device.
+                full = np.empty((block, len(params)))
+                inside = np.zeros(block, bool)
+                for i in range(block):
+                    stale[ifree] = trial[i]
+                    if np.any(stale > pmax) or np.any(stale < pmin):
+                        continue
+                    for s in ishare:
+                        stale[s] = stale[-int(pstep[s]) - 1]
+                    inside[i] = True
+                    full[i] = stale
                 lp = np.full(block, -np.inf)
                 if np.any(inside):
                     with np.errstate(all='ignore'):

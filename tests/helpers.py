@@ -116,7 +116,11 @@ def initial_population(orc, seed=5):
     lp0 = np.empty(orc.M0)
     values = orc.params.copy()
     filled = 0
+    failed = 0
     while filled < orc.M0:
+        failed += 1
+        if failed > 200*orc.M0 + 1000:
+            raise ValueError('Cannot populate an initial sample set of parameters')
         trial = rs.normal(x0, sig)
         values[ifree] = trial
         if np.any(values > orc.pmax) or np.any(values < orc.pmin):

@@ -54,6 +54,10 @@ def random_problem(seed):
         pstep[0] = 0.05
     lo = p_true - rs.uniform(0.05, 3.0, nparams)
     hi = p_true + rs.uniform(0.05, 3.0, nparams)
+    for j in range(nparams):            # a shared parameter lives inside its source's bounds
+        if pstep[j] < 0:
+            src = -int(pstep[j]) - 1
+            lo[j], hi[j] = lo[src], hi[src]
     if wlike:
         lo[-2:] = 0.01
     prior = np.zeros(nparams)
