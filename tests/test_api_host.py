@@ -243,3 +243,39 @@ def test_burn_matches_reference_docstring_example():
     assert list(post[:, 0]) == [11, 31, 21, 12, 22, 32]
     post, _, _ = mu.burn({'posterior': Z, 'zchain': zchain, 'burnin': 1}, burnin=0)
     assert list(post[:, 0]) == [10, 11, 12, 20, 21, 22, 30, 31, 32]
+
+
+def test_initial_population_with_shared_parameters_equals_reference(golden_dir):
+    """The hub tests bounds BEFORE refreshing the shared parameters, i.e. with the
+    copies left by the previous in-bounds trial (mcmc_driver.py:249-255); uniform
+    kickoff, tight bounds, one shared and one fixed parameter."""
+    g = np.load(os.path.join(golden_dir, 'seq_shared_priors_snooker.npz'))
+
+    def line_shared(p, x):
+        return p[0] + p[1]*x + p[2]*x**2.0 + (p[3] - p[1])*x + (p[4] - 1.0)
+
+    from oracle import chain_sequential as cseq
+    seq = cseq.SequentialRun(
+        data=g['data'], uncert=g['uncert'], func=line_shared, params=g['params'],
+        indparams=[g['x']], pmin=g['pmin'], pmax=g['pmax'], pstep=g['pstep'],
+        prior=g['prior'], priorlow=g['priorlow'], priorup=g['priorup'],
+        nchains=8, nsamples=2400, sampler='snooker', kickoff='uniform')
+    seq.init_population(np.random.RandomState(int(g['hub_seed'])))
+    captured = {}
+
+    class Spy(OracleChains):
+        def set_population(self, Z0, lp0, X0=None, chisq0=None):
+            captured['Z0'], captured['lp0'] = Z0.copy(), lp0.copy()
+            super().set_population(Z0, lp0, X0, chisq0)
+
+    np.random.seed(int(g['hub_seed']))
+    out = mc3_amd.sample(
+        data=g['data'], uncert=g['uncert'], func=line_shared, params=g['params'],
+        indparams=[g['x']], pstep=g['pstep'], pmin=g['pmin'], pmax=g['pmax'],
+        prior=g['prior'], priorlow=g['priorlow'], priorup=g['priorup'],
+        sampler='snooker', nsamples=2400, burnin=10, nchains=8, kickoff='uniform',
+        log=mu.Log(verb=0), engine_factory=Spy, seed=1)
+    np.testing.assert_array_equal(captured['Z0'], seq.Z[:seq.M0])
+    np.testing.assert_allclose(captured['lp0'], seq.log_post[:seq.M0], rtol=1e-10)
+    # shared parameter follows its source, fixed one keeps its value
+    assert out['bestp'][3] == out['bestp'][1] and out['bestp'][4] == 1.0
