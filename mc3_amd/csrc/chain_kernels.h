@@ -57,6 +57,8 @@ struct DevProblem {
     // peer-to-peer hand-off across GPUs (persistent kernel): rank p's replicas of Z and
     // log_post, mapped into this process; [0..npeers), entry `rank` is the local one
     int32_t npeers, rank;
+    int32_t test_abort;           // tests: refresh at which chain `chain0` gives up (-1 = never)
+    int32_t _pad_test;
     double *const *peerZ;
     double *const *peerLP;
     // tiled plan (large ndata): proposal / data sum / accept are separate launches
@@ -766,7 +768,7 @@ __device__ __forceinline__ bool wait_rows(const double *const (&addr)[NVAL], dou
         if ((spins & 1023u) == 1023u) {
             const long long ab = __hip_atomic_load(&ctl[CTL_ABORT], __ATOMIC_RELAXED,
                                                    __HIP_MEMORY_SCOPE_AGENT);
-            if (ab != 0 || spins > (1u << 24)) {
+            if (ab != 0 || spins > (1u << 23)) {
                 if (ab == 0 && (threadIdx.x & 63) == 0)
                     __hip_atomic_store(&ctl[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
@@ -866,6 +868,11 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     long long nacc = 0;
     long long *ctl_rw = const_cast<long long *>(P.ctl);
     bool alive = true;
+    if constexpr (PERSIST) {
+        // a launch queued behind one that gave up must not run: its inputs are missing
+        if (__hip_atomic_load(&ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            return;
+    }
     MC3_STAMP(1);
 
     // The index / acceptance draws depend only on (seed, iteration, chain): they
@@ -874,6 +881,14 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     // are in flight.
     Draws nxt = make_draws(P, (uint64_t)(R0 * P.thinning + jb), c, sampler);
     for (long long R = R0; R < R0 + nref && alive; ++R) {
+    if constexpr (PERSIST) {
+        if (P.test_abort >= 0 && R == P.test_abort && lc == 0) {     // test hook
+            if (tid == 0)
+                __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
     const double *snap = (R == 0) ? P.snap0
                                   : P.Z + (size_t)(P.M0 + (R - 1) * P.nchains) * nf;
     const long long zsize = P.M0 + R * P.nchains;
@@ -1348,10 +1363,8 @@ __global__ __launch_bounds__(256) void chain_moments_kernel(const double *Z, lon
 __global__ void set_ctl_kernel(long long *ctl, long long base, long long run0)
 {
     ctl[0] = base;
-    if (run0 >= 0) {
-        ctl[1] = run0;
-        ctl[CTL_ABORT] = 0;
-    }
+    if (run0 >= 0)
+        ctl[1] = run0;      // ctl[CTL_ABORT] is only ever cleared by the host (settle)
 }
 
 __global__ void selftest_math_kernel(int op, const double *in, int n, double *out)

@@ -132,6 +132,13 @@ struct mc3hip_ctx {
     int persist_refs = 0;           // refreshes per persistent launch, 0 = off
     bool persist_checked = false;
     bool fast = false;              // lean persistent instance selected
+    // checkpoint of the per-chain state taken before the first persistent launch that
+    // has not been confirmed yet (recovery if a launch gives up)
+    char *ckpt = nullptr;
+    int64_t ckpt_R = 0;
+    bool ckpt_valid = false;
+    long long last_run0 = 0;
+    int recoveries = 0;
     int tile_kmax = 0;              // tiled plan: coefficient capacity of the tile kernel
     int tile_chain_block = 0;       // chains per workgroup column of the tile kernel
     // comm
@@ -459,7 +466,10 @@ int decide_persist(mc3hip_ctx *c)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess)
         return 0;
-    const int per_cu = nb > 1 ? nb - 1 : nb;
+    // one workgroup per CU of slack when several fit, unless the caller asks for the
+    // full figure (a launch that turns out not to be resident gives up after a
+    // bounded wait and the run is redone with per-refresh launches, see settle())
+    const int per_cu = (nb > 1 && !getenv("MC3HIP_PERSIST_FULL_OCCUPANCY")) ? nb - 1 : nb;
     const long long capacity = (long long)per_cu * prop.multiProcessorCount;
     if (nb < 1 || c->P.nlocal > capacity)
         return 0;
@@ -737,6 +747,16 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         cb = (cb + 15) / 16 * 16;
         c->tile_chain_block = cb < 16 ? 16 : cb;
     }
+    P.test_abort = -1;
+    if (const char *ta = getenv("MC3HIP_TEST_ABORT_AT"))
+        P.test_abort = atoi(ta);
+    {
+        // checkpoint area: X, bestx [nl*nf]; chisq, best_chisq [nl]; numaccept,
+        // best_iter [nl]; outbounds [nf] -- all 8-byte words
+        char *ck = nullptr;
+        TRY(dev_alloc(c, &ck, (2 * nl * nf + 4 * nl + nf) * 8));
+        c->ckpt = ck;
+    }
     TRY(dev_alloc(c, &c->ctl, 4));
     P.ctl = c->ctl;
     TRY(dev_alloc(c, &P.stamps, 16));
@@ -851,6 +871,107 @@ int mc3hip_set_population(mc3hip_ctx *c, const double *Z0, const double *log_pos
     return MC3HIP_OK;
 }
 
+// copy the per-chain state to (save = true) or from the checkpoint area, stream-ordered
+static int checkpoint_copy(mc3hip_ctx *c, bool save)
+{
+    const DevProblem &P = c->P;
+    const size_t nl = (size_t)P.nlocal, nf = (size_t)P.nfree;
+    struct Item { void *ptr; size_t bytes; };
+    const Item items[] = {
+        {P.X, nl * nf * 8}, {P.bestx, nl * nf * 8}, {P.chisq, nl * 8}, {P.best_chisq, nl * 8},
+        {P.numaccept, nl * 8}, {P.best_iter, nl * 8}, {P.outbounds, nf * 8}};
+    char *at = c->ckpt;
+    for (const Item &it : items) {
+        if (save)
+            HIP_TRY(hipMemcpyAsync(at, it.ptr, it.bytes, hipMemcpyDeviceToDevice, c->stream));
+        else
+            HIP_TRY(hipMemcpyAsync(it.ptr, at, it.bytes, hipMemcpyDeviceToDevice, c->stream));
+        at += it.bytes;
+    }
+    return MC3HIP_OK;
+}
+
+static int build_graph(mc3hip_ctx *c);
+
+// refreshes [R, Rend) through one launch per refresh (hipGraph batches + eager tail)
+static int enqueue_per_refresh(mc3hip_ctx *c, int64_t R, int64_t Rend, long long run0)
+{
+    bool first = true;
+    const bool use_graph = c->graph_nodes > 0 && c->comm == nullptr;
+    if (use_graph && Rend - R >= c->graph_nodes && !c->graph_exec) {
+        int rc = build_graph(c);
+        if (rc)
+            return rc;
+    }
+    while (R < Rend) {
+        const int64_t left = Rend - R;
+        hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl, (long long)R,
+                           first ? run0 : -1LL);
+        if (use_graph && left >= c->graph_nodes) {
+            HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+            R += c->graph_nodes;
+        } else {
+            for (int64_t r = 0; r < left; ++r) {
+                launch_step(c, (int)r);
+                if (c->comm) {
+                    int rc = exchange_rows(c, R + r);
+                    if (rc)
+                        return rc;
+                }
+            }
+            R += left;
+        }
+        first = false;
+    }
+    HIP_TRY(hipGetLastError());
+    return MC3HIP_OK;
+}
+
+// Wait for the stream; if a persistent launch gave up (a wait for another chain's row
+// timed out: its workgroups were not all resident), discard everything since the
+// checkpoint and redo it with one launch per refresh.  Results are identical -- both
+// paths run the same run_chain -- only slower; the context stays on that path.
+static int settle(mc3hip_ctx *c)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->persist_refs <= 0)
+        return MC3HIP_OK;
+    long long ab = 0;
+    HIP_TRY(hipMemcpy(&ab, c->ctl + CTL_ABORT, sizeof ab, hipMemcpyDeviceToHost));
+    if (ab == 0) {
+        c->ckpt_valid = false;
+        return MC3HIP_OK;
+    }
+    if (c->p2p_ranks > 1)
+        return fail(MC3HIP_ERR_STATE,
+                    "persistent kernel: a wait for another rank's Z row timed out; the "
+                    "peer-to-peer run is incomplete on every rank");
+    if (!c->ckpt_valid)
+        return fail(MC3HIP_ERR_STATE, "persistent kernel gave up and no checkpoint is pending");
+    const DevProblem &P = c->P;
+    const size_t nf = (size_t)P.nfree;
+    const size_t row0 = (size_t)(P.M0 + c->ckpt_R * P.nchains);
+    const size_t nrows = (size_t)((c->refresh_done - c->ckpt_R) * P.nchains);
+    int rc = checkpoint_copy(c, false);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemsetAsync(P.Z + row0 * nf, 0xff, nrows * nf * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(P.zchain + row0, 0xff, nrows * sizeof(int32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(P.log_post + row0, 0, nrows * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(c->ctl + CTL_ABORT, 0, sizeof(long long), c->stream));
+    c->persist_refs = 0;            // this context stays on per-refresh launches
+    c->persist_checked = true;
+    c->fast = false;
+    c->ckpt_valid = false;
+    c->recoveries += 1;
+    rc = enqueue_per_refresh(c, c->ckpt_R, c->refresh_done, c->last_run0);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MC3HIP_OK;
+}
+
 static int build_graph(mc3hip_ctx *c)
 {
     HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -880,17 +1001,19 @@ int mc3hip_run(mc3hip_ctx *c, int64_t nrefresh)
     int64_t R = c->refresh_done;
     const int64_t Rend = R + nrefresh;
     const long long run0 = R;
-    bool first = true;
+    c->last_run0 = run0;
     const int persist = c->comm ? 0 : decide_persist(c);
-    const bool use_graph = c->graph_nodes > 0 && c->comm == nullptr && persist == 0;
-    if (use_graph && nrefresh >= c->graph_nodes && !c->graph_exec) {
-        int rc = build_graph(c);
-        if (rc)
-            return rc;
-    }
-    while (R < Rend) {
-        const int64_t left = Rend - R;
-        if (persist > 0) {
+    if (persist > 0) {
+        if (!c->ckpt_valid && c->p2p_ranks <= 1) {
+            int rc = checkpoint_copy(c, true);
+            if (rc)
+                return rc;
+            c->ckpt_R = R;
+            c->ckpt_valid = true;
+        }
+        bool first = true;
+        while (R < Rend) {
+            const int64_t left = Rend - R;
             const int n = (int)(left < persist ? left : persist);
             hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl,
                                (long long)R, first ? run0 : -1LL);
@@ -899,26 +1022,12 @@ int mc3hip_run(mc3hip_ctx *c, int64_t nrefresh)
             else
                 launch_persist(c, n);
             R += n;
-        } else if (use_graph && left >= c->graph_nodes) {
-            hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl,
-                               (long long)R, first ? run0 : -1LL);
-            HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
-            R += c->graph_nodes;
-        } else {
-            const int64_t n = left;
-            hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl,
-                               (long long)R, first ? run0 : -1LL);
-            for (int64_t r = 0; r < n; ++r) {
-                launch_step(c, (int)r);
-                if (c->comm) {
-                    int rc = exchange_rows(c, R + r);
-                    if (rc)
-                        return rc;
-                }
-            }
-            R += n;
+            first = false;
         }
-        first = false;
+    } else {
+        int rc = enqueue_per_refresh(c, R, Rend, run0);
+        if (rc)
+            return rc;
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -931,18 +1040,7 @@ int mc3hip_sync(mc3hip_ctx *c)
 {
     if (!c)
         return fail(MC3HIP_ERR_ARG, "null context");
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->persist_refs > 0) {
-        long long ab = 0;
-        HIP_TRY(hipMemcpy(&ab, c->ctl + CTL_ABORT, sizeof ab, hipMemcpyDeviceToHost));
-        if (ab != 0)
-            return fail(MC3HIP_ERR_STATE,
-                        "persistent kernel: a wait for another chain's Z row timed out "
-                        "(workgroups not co-resident?); the run is incomplete -- "
-                        "recreate the context with MC3HIP_FLAG_NO_PERSIST");
-    }
-    return MC3HIP_OK;
+    return settle(c);
 }
 
 int mc3hip_last_run_ms(mc3hip_ctx *c, float *ms)
@@ -965,8 +1063,11 @@ int mc3hip_get_rows(mc3hip_ctx *c, int64_t row0, int64_t nrows, double *Z, doubl
     if (row0 < 0 || nrows < 0 || row0 + nrows > c->zlen)
         return fail(MC3HIP_ERR_ARG, "rows [%lld,%lld) outside Z", (long long)row0,
                     (long long)(row0 + nrows));
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        const int rc_settle = settle(c);
+        if (rc_settle)
+            return rc_settle;
+    }
     const size_t nf = (size_t)c->P.nfree;
     if (Z)
         HIP_TRY(hipMemcpy(Z, c->P.Z + (size_t)row0 * nf, (size_t)nrows * nf * sizeof(double),
@@ -996,8 +1097,11 @@ int mc3hip_put_rows(mc3hip_ctx *c, int64_t row0, int64_t nrows, const double *Z,
     if (row0 < c->P.M0 || nrows < 0 || row0 + nrows > c->zlen)
         return fail(MC3HIP_ERR_ARG, "rows [%lld,%lld) outside the chain rows of Z",
                     (long long)row0, (long long)(row0 + nrows));
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        const int rc_settle = settle(c);
+        if (rc_settle)
+            return rc_settle;
+    }
     const size_t nf = (size_t)c->P.nfree;
     if (Z)
         HIP_TRY(hipMemcpy(c->P.Z + (size_t)row0 * nf, Z, (size_t)nrows * nf * sizeof(double),
@@ -1014,8 +1118,11 @@ int mc3hip_get_state(mc3hip_ctx *c, double *X, double *chisq, int64_t *numaccept
 {
     if (!c)
         return fail(MC3HIP_ERR_ARG, "null context");
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        const int rc_settle = settle(c);
+        if (rc_settle)
+            return rc_settle;
+    }
     const DevProblem &P = c->P;
     const size_t nf = (size_t)P.nfree, nl = (size_t)P.nlocal;
     if (X)
@@ -1043,8 +1150,11 @@ int mc3hip_get_trace(mc3hip_ctx *c, int64_t iters, double *chisq, int32_t *flags
         return fail(MC3HIP_ERR_ARG, "null context");
     if (iters < 0 || iters > c->P.trace_iters)
         return fail(MC3HIP_ERR_ARG, "trace holds %d iterations", c->P.trace_iters);
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        const int rc_settle = settle(c);
+        if (rc_settle)
+            return rc_settle;
+    }
     const size_t n = (size_t)iters * (size_t)c->P.nlocal;
     if (chisq)
         HIP_TRY(hipMemcpy(chisq, c->P.trace_chisq, n * sizeof(double), hipMemcpyDeviceToHost));
@@ -1060,7 +1170,11 @@ int mc3hip_chain_moments(mc3hip_ctx *c, int64_t burn, double *mean, double *var)
     if (burn < 0 || burn >= c->refresh_done)
         return fail(MC3HIP_ERR_ARG, "burn=%lld leaves no rows (%lld refreshes done)",
                     (long long)burn, (long long)c->refresh_done);
-    HIP_TRY(hipSetDevice(c->device));
+    {
+        const int rc_settle = settle(c);
+        if (rc_settle)
+            return rc_settle;
+    }
     const size_t n = (size_t)c->P.nchains * (size_t)c->P.nfree;
     double *dm = nullptr, *dv = nullptr;
     HIP_TRY(hipMalloc(&dm, 2 * n * sizeof(double)));
@@ -1455,8 +1569,11 @@ int mc3hip_debug_stamps(mc3hip_ctx *c, uint64_t *out16)
 {
     if (!c || !out16)
         return fail(MC3HIP_ERR_ARG, "null argument");
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        const int rc_settle = settle(c);
+        if (rc_settle)
+            return rc_settle;
+    }
     HIP_TRY(hipMemcpy(out16, c->P.stamps, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return MC3HIP_OK;
 }

@@ -103,12 +103,18 @@ class DeviceChains:
         check(self.lib.mc3hip_create(ctypes.byref(P), ctypes.byref(ctx)))
         self._ctx = ctx
         self.trace_iters = int(trace_iters)
+
+    @property
+    def plan(self):
+        """How the library runs this problem right now (summation order, launch
+        structure); the launch structure can change if a persistent launch had to
+        be redone (see mc3hip_sync)."""
         plan = _lib.Plan()
         check(self.lib.mc3hip_get_plan(self._ctx, ctypes.byref(plan)))
-        self.plan = {'vlanes': plan.vlanes, 'tile': plan.tile,
-                     'waves_per_chain': plan.waves_per_chain,
-                     'graph_nodes': plan.graph_nodes,
-                     'persistent': plan.persistent, 'fast': plan.fast}
+        return {'vlanes': plan.vlanes, 'tile': plan.tile,
+                'waves_per_chain': plan.waves_per_chain,
+                'graph_nodes': plan.graph_nodes,
+                'persistent': plan.persistent, 'fast': plan.fast}
 
     # -- lifetime --------------------------------------------------------------
     def close(self):

@@ -592,3 +592,36 @@ def test_stats_functions_vs_reference_vectors(golden_dir):
         got1 = [ms.dwt_chisq(H.quad(p[:3], x), data, p, *pri) for p in P[:3]]
         np.testing.assert_allclose(got0, kv[f'dwt_{ndata}_chisq'][:3], rtol=1e-10)
         np.testing.assert_allclose(got1, kv[f'dwt_{ndata}_chisq_priors'][:3], rtol=1e-10)
+
+
+@pytest.mark.parametrize('sampler', ['demc', 'snooker'])
+def test_persistent_launch_gives_up_and_run_is_redone(eng, sampler):
+    """If a persistent launch cannot complete (here: chain 0 gives up at refresh 7 of
+    the second run() call through a test hook; in the field: workgroups not all
+    resident), the library restores the checkpoint and redoes the work with one
+    launch per refresh -- same results, context demoted to that path."""
+    prob = H.quad_problem(nchains=12, nsamples=12*90, sampler=sampler)
+    orc = H.make_oracle(prob)
+    Z0, lp0 = H.initial_population(orc)
+    orc.set_population(Z0, lp0)
+    orc.run()
+    os.environ['MC3HIP_TEST_ABORT_AT'] = '37'
+    try:
+        gpu = eng.DeviceChains(**prob)
+    finally:
+        del os.environ['MC3HIP_TEST_ABORT_AT']
+    gpu.set_population(Z0, lp0)
+    assert gpu.plan['persistent'] > 0
+    gpu.run(30)                      # completes
+    gpu.run(40, sync=False)          # gives up inside (refresh 37) ...
+    gpu.run(20)                      # ... queued behind it; everything since refresh 30 is redone
+    assert gpu.plan['persistent'] == 0
+    Z, lp, zc = gpu.rows()
+    st = gpu.state()
+    np.testing.assert_array_equal(Z, orc.Z)
+    np.testing.assert_array_equal(lp, orc.log_post)
+    np.testing.assert_array_equal(zc, orc.zchain)
+    np.testing.assert_array_equal(st['numaccept'], orc.numaccept)
+    np.testing.assert_array_equal(st['outbounds'], orc.outbounds)
+    np.testing.assert_array_equal(st['best_chisq'], orc.best_chisq)
+    gpu.close()
