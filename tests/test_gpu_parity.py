@@ -311,11 +311,13 @@ def test_per_refresh_launch_path_bit_exact(eng, builder, kw):
 
 
 def test_persistent_kernel_many_chains(eng):
-    """2048 chains: eight single-wave workgroups per CU must all be resident;
-    the library falls back to per-refresh launches when they are not."""
+    """2048 chains: eight single-wave workgroups per CU, all resident (the full
+    occupancy the runtime reports); were they not, the launch would give up and the
+    library would redo the run with per-refresh launches."""
     prob = H.quad_problem(ndata=256, nchains=2048, nsamples=2048*60, sampler='demc')
     orc, gpu = run_pair(eng, prob, trace=False)
     assert_same(orc, gpu, trace=False)
+    assert gpu.plan['persistent'] > 0
     gpu.close()
 
 
