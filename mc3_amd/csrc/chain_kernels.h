@@ -752,7 +752,8 @@ __device__ __forceinline__ double load_published(const double *p)
 // poll; lanes beyond nfree repeat lane 0's addresses).  The first read is issued
 // by the caller so that independent scalar work can overlap its latency; this
 // only spins when something is still pending.  Bounded: gives up (and tells
-// everybody) after ~1 s so a lost workgroup can never hang the device.
+// everybody) after a few seconds so a lost workgroup can never hang the device;
+// the host then restores its checkpoint and redoes the run (mc3hip.hip settle()).
 template <int NVAL, bool SYS = false>
 __device__ __forceinline__ bool wait_rows(const double *const (&addr)[NVAL], double (&val)[NVAL],
                                           long long *ctl)

@@ -1,12 +1,17 @@
 // mc3hip.hip -- C-ABI (include/mc3hip.h) over the chain-update kernels.
 //
-// Host side of the drop-in boundary: owns the device copies of what the
-// reference keeps in multiprocessing shared memory (mc3/mcmc_driver.py:143-202),
-// launches one fused step kernel per Z refresh on a private HIP stream --
-// batched into a hipGraph so the launch-bound inner loop costs no host time --
-// and, across GPUs, exchanges the new Z rows with one in-place RCCL all-gather
-// per refresh (librccl is dlopen'ed on first use, so single-GPU users do not
-// need it).
+// Host side of the drop-in boundary: owns the device copies of what the reference
+// keeps in multiprocessing shared memory (mc3/mcmc_driver.py:143-202) and drives the
+// chain update on a private HIP stream in one of three launch structures
+// (decide_persist, mc3hip_run):
+//   - persistent: ONE launch for up to 16384 Z refreshes, the new rows handed between
+//     workgroups inside the launch (single GPU, or several GPUs through
+//     mc3hip_p2p_attach); checkpointed, recoverable (settle());
+//   - per refresh: one fused step kernel per refresh, batched into a hipGraph, or
+//     eagerly with one in-place RCCL all-gather after each (librccl is dlopen'ed on
+//     first use, so single-GPU users do not need it);
+//   - tiled: proposal / per-tile data sums for all chains / accept as three launches
+//     per iteration for large data sets.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <cmath>
