@@ -15,6 +15,8 @@ from oracle_engine import OracleChains
 import helpers as H
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the first `import torch` in a fresh container can take minutes in every worker
+pytestmark = pytest.mark.timeout(1200)
 
 
 def free_port():
@@ -32,7 +34,7 @@ def test_two_ranks_reproduce_single_rank(tmp_path, sampler, thinning):
            '--master-port', str(free_port()),
            os.path.join(ROOT, 'tests', 'dist_worker.py'), out_path, sampler,
            str(thinning)]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1000)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
 
     x, data, uncert = H.tutorial_data(100)
@@ -71,6 +73,6 @@ def test_peer_to_peer_falls_back_together():
            '--nproc-per-node=2', '--master-addr', '127.0.0.1',
            '--master-port', str(free_port()),
            os.path.join(ROOT, 'tests', 'p2p_fallback_worker.py')]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1000)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert res.stdout.count('fallback ok') == 2

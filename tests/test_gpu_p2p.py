@@ -12,7 +12,8 @@ import pytest
 
 import helpers as H
 
-pytestmark = pytest.mark.gpu
+# the first `import torch` on a fresh box can take minutes in every worker process
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1200)]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -36,7 +37,7 @@ def test_processes_peer_to_peer(tmp_path, nproc, sampler, thinning, niter):
            '--master-port', str(free_port()),
            os.path.join(ROOT, 'tests', 'p2p_worker.py'), out_path, sampler,
            str(thinning), str(niter)]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1000)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-6000:]
 
     x, data, uncert = H.tutorial_data(100)
