@@ -84,8 +84,15 @@ constexpr int SC_STRIDE = MC3HIP_MAX_PARAMS + 16;   // doubles per sc_nextp row 
         if (threadIdx.x == 0 && blockIdx.x == 0)                                          \
             P.stamps[slot] = t_;                                                          \
     } while (0)
+// non-draining tick accumulators for the persistent loop: sums of shader-clock
+// deltas per phase over all iterations of workgroup 0 (slots 8..11), count in slot 12
+#define MC3_TICK(var)                                                                     \
+    do {                                                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");       \
+    } while (0)
 #else
 #define MC3_STAMP(slot) do { } while (0)
+#define MC3_TICK(var) do { } while (0)
 #endif
 
 __device__ __forceinline__ double make_double(int lo, int hi) { return __hiloint2double(hi, lo); }
@@ -782,6 +789,14 @@ __device__ __forceinline__ bool wait_rows(const double *const (&addr)[NVAL], dou
     }
 }
 
+// Keep a wave-uniform value where it was computed: an empty asm that "uses" it, so
+// neither the IR-level sinking pass nor the scheduler can move the (scalar) Philox
+// arithmetic of the next iteration out of the shadow of the partner-row loads.
+__device__ __forceinline__ void pin_scalar(uint64_t &q)
+{
+    asm volatile("; pin" : "+s"(q));
+}
+
 // the wave-uniform draws of one iteration (slots 0..2)
 struct Draws {
     Draw2 d0, d1, d2;
@@ -895,6 +910,8 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     const long long zsize = P.M0 + R * P.nchains;
     for (int j = jb; j < je; ++j) {
         MC3_STAMP(5);
+        unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+        MC3_TICK(tk0);
         const uint64_t iter = (uint64_t)(R * P.thinning + j);
         double npk = 0.0, zk = 0.0, u = 0.0;
         double mrfactor = 1.0;
@@ -933,7 +950,15 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
 #pragma unroll
                     for (int q = 0; q < 3; ++q)
                         val[q] = load_published<P2P>(addr[q]);
+                    __builtin_amdgcn_sched_barrier(0);
                     nxt = make_draws(P, iter + 1, c, sampler);
+                    pin_scalar(nxt.d0.q0);
+                    pin_scalar(nxt.d0.q1);
+                    pin_scalar(nxt.d1.q0);
+                    pin_scalar(nxt.d1.q1);
+                    pin_scalar(nxt.d2.q0);
+                    pin_scalar(nxt.d2.q1);
+                    __builtin_amdgcn_sched_barrier(0);
                     alive = wait_rows<3, P2P>(addr, val, ctl_rw);
                     z1 = val[0];
                     z2 = val[1];
@@ -981,8 +1006,13 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
                         val[q] = load_published<P2P>(addr[q]);
+                    __builtin_amdgcn_sched_barrier(0);
                     nxt = make_draws(P, iter + 1, c, sampler);
+                    pin_scalar(nxt.d0.q0);
+                    pin_scalar(nxt.d0.q1);
+                    __builtin_amdgcn_sched_barrier(0);
                     alive = wait_rows<2, P2P>(addr, val, ctl_rw);
+                    MC3_TICK(tk1);
                     x1 = val[0];
                     x2 = val[1];
                 } else {
@@ -1079,6 +1109,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                                                             L.bufA, L.bufB, tile);   // chain.py:249
             }
             MC3_STAMP(3);
+            MC3_TICK(tk2);
             if (wave0) {
                 if (PHASE != PH_FINISH && sjump) {                   // chain.py:251-255
                     const double dc = xk - zk, dn = npk - zk;
@@ -1114,6 +1145,15 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
         if constexpr (!FAST)
             block_sync<WPC>();
         MC3_STAMP(6);
+#ifdef MC3HIP_STAMPS
+        MC3_TICK(tk3);
+        if (threadIdx.x == 0 && blockIdx.x == 0 && tk1 != 0 && tk2 != 0) {
+            P.stamps[8] += tk1 - tk0;      // top -> partner rows arrived
+            P.stamps[9] += tk2 - tk1;      // -> chisq reduced
+            P.stamps[10] += tk3 - tk2;     // -> end of iteration (accept; publish is after)
+            P.stamps[12] += 1;
+        }
+#endif
     }
     if (!alive)
         break;

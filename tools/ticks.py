@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Diagnostic (separate -DMC3HIP_STAMPS build): average shader-clock cycles per phase
+of one iteration of the persistent kernel (workgroup 0, non-draining ticks)."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mc3_amd import _lib  # noqa: E402
+_lib.LIB_PATH = os.path.join(ROOT, 'mc3_amd', 'libmc3hip_stamps.so')
+from mc3_amd import engine  # noqa: E402
+import bench  # noqa: E402
+
+thin = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+prob = bench.c2_problem(256, 20000, thin)
+g = engine.DeviceChains(**prob)
+Z0, lp0 = bench.initial_population(prob, g.eval_chisq)
+g.set_population(Z0, lp0)
+g.run(2000)
+out = (ctypes.c_uint64*16)()
+_lib.check(g.lib.mc3hip_debug_stamps(g._ctx, out))
+a = np.array(out[:], dtype=np.float64)
+g.run(16000)
+_lib.check(g.lib.mc3hip_debug_stamps(g._ctx, out))
+b = np.array(out[:], dtype=np.float64) - a
+n = b[12]
+print(f'thinning={thin} plan={g.plan} iterations sampled (in-bounds, workgroup 0): {int(n)}')
+print(f'  top -> partner rows arrived   {b[8]/n:8.0f} cycles')
+print(f'  -> chisq reduced              {b[9]/n:8.0f}')
+print(f'  -> end of iteration           {b[10]/n:8.0f}')
+print(f'  sum                           {(b[8]+b[9]+b[10])/n:8.0f}   '
+      f'(wall {g.last_run_ms()*1e3/16000/thin:.3f} us per iteration)')
