@@ -836,8 +836,10 @@ __device__ __forceinline__ Draws make_draws(const DevProblem &P, uint64_t iter, 
 // row into EVERY rank's replica of Z (peer-to-peer stores over xGMI, system scope) and
 // polls its local replica, so the in-launch hand-off spans GPUs and no collective or
 // kernel boundary separates iterations.
+// TH = 1: exactly one iteration per refresh (thinning = 1, the default), known at
+// compile time so that the inner loop and its control flow disappear.
 template <int WPC, int MT, bool WL, bool MULTI, bool PERSIST, int SMP = -1, bool FAST = false,
-          int PHASE = PH_FUSED, bool P2P = false>
+          int PHASE = PH_FUSED, bool P2P = false, int TH = 0>
 __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R0,
                                           const int nref, const int jb = 0, int je = -1)
 {
@@ -895,7 +897,13 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     // are wave-uniform, so Philox runs on the scalar unit (every wave repeats it),
     // and the next iteration's are computed while this iteration's partner rows
     // are in flight.
-    Draws nxt = make_draws(P, (uint64_t)(R0 * P.thinning + jb), c, sampler);
+    Draws nxt = make_draws(P, (TH == 1) ? (uint64_t)R0 : (uint64_t)(R0 * P.thinning + jb), c,
+                           sampler);
+    // diagnostic build only: per-phase tick sums kept in registers, stored once at exit
+    unsigned long long tk_prev3 = 0, tk_prevend = 0;
+    unsigned long long ta8 = 0, ta9 = 0, ta10 = 0, ta11 = 0, ta12 = 0, ta13 = 0;
+    (void)tk_prev3; (void)tk_prevend;
+    (void)ta8; (void)ta9; (void)ta10; (void)ta11; (void)ta12; (void)ta13;
     for (long long R = R0; R < R0 + nref && alive; ++R) {
     if constexpr (PERSIST) {
         if (P.test_abort >= 0 && R == P.test_abort && lc == 0) {     // test hook
@@ -908,11 +916,19 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     const double *snap = (R == 0) ? P.snap0
                                   : P.Z + (size_t)(P.M0 + (R - 1) * P.nchains) * nf;
     const long long zsize = P.M0 + R * P.nchains;
-    for (int j = jb; j < je; ++j) {
+    const int jfirst = (TH == 1) ? 0 : jb;
+    const int jlast = (TH == 1) ? 1 : je;
+    for (int j = jfirst; j < jlast; ++j) {
         MC3_STAMP(5);
         unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
         MC3_TICK(tk0);
-        const uint64_t iter = (uint64_t)(R * P.thinning + j);
+#ifdef MC3HIP_STAMPS
+        if (tk_prevend != 0) {
+            ta11 += tk_prevend - tk_prev3;   // end of iteration -> row published
+            ta13 += tk0 - tk_prevend;        // -> top of the next iteration
+        }
+#endif
+        const uint64_t iter = (TH == 1) ? (uint64_t)R : (uint64_t)(R * P.thinning + j);
         double npk = 0.0, zk = 0.0, u = 0.0;
         double mrfactor = 1.0;
         bool sjump = false, outk = false, fast_anyout = false;
@@ -1147,18 +1163,19 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
         MC3_STAMP(6);
 #ifdef MC3HIP_STAMPS
         MC3_TICK(tk3);
-        if (threadIdx.x == 0 && blockIdx.x == 0 && tk1 != 0 && tk2 != 0) {
-            P.stamps[8] += tk1 - tk0;      // top -> partner rows arrived
-            P.stamps[9] += tk2 - tk1;      // -> chisq reduced
-            P.stamps[10] += tk3 - tk2;     // -> end of iteration (accept; publish is after)
-            P.stamps[12] += 1;
+        if (tk1 != 0 && tk2 != 0) {
+            ta8 += tk1 - tk0;      // top -> partner rows arrived
+            ta9 += tk2 - tk1;      // -> chisq reduced
+            ta10 += tk3 - tk2;     // -> end of iteration (accept; publish is after)
+            ta12 += 1;
         }
+        tk_prev3 = tk3;
 #endif
     }
     if (!alive)
         break;
     // Z append, chain.py:276-289 (strided slot M0 + ID + k*nchains)
-    if (wave0 && je == P.thinning) {
+    if (wave0 && (TH == 1 || je == P.thinning)) {
         const long long row = P.M0 + R * P.nchains + c;
         if (mine) {
             if constexpr (P2P) {
@@ -1183,6 +1200,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
             P.zchain[row] = c;
         }
     }
+    MC3_TICK(tk_prevend);
     }   // refreshes
     if (wave0) {
         if (mine)
@@ -1194,6 +1212,12 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
         }
     }
     MC3_STAMP(4);
+#ifdef MC3HIP_STAMPS
+    if (PERSIST && threadIdx.x == 0 && blockIdx.x == 0) {
+        P.stamps[8] += ta8; P.stamps[9] += ta9; P.stamps[10] += ta10;
+        P.stamps[11] += ta11; P.stamps[12] += ta12; P.stamps[13] += ta13;
+    }
+#endif
 }
 
 // one Z refresh per launch (also the multi-GPU path: a collective follows each launch)
@@ -1229,10 +1253,10 @@ __global__ __launch_bounds__(64) void finish_kernel(const DevProblem P, const in
 
 // the lean instance (see run_chain): one wave per chain, MT free polynomial
 // coefficients, Gaussian chisq, ndata <= 1024, no priors/shared/fixed/epsilon/trace
-template <int MT, int SMP, bool P2P = false>
+template <int MT, int SMP, bool P2P = false, int TH = 0>
 __global__ __launch_bounds__(64) void persist_fast_kernel(const DevProblem P, const int nref)
 {
-    run_chain<1, MT, false, false, true, SMP, true, PH_FUSED, P2P>(P, P.ctl[0], nref);
+    run_chain<1, MT, false, false, true, SMP, true, PH_FUSED, P2P, TH>(P, P.ctl[0], nref);
 }
 
 // chisq for arbitrary parameter vectors (Chain.eval_model(ret='chisq'))

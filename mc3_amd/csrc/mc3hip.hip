@@ -329,24 +329,32 @@ bool fast_eligible(const mc3hip_ctx *c)
            !getenv("MC3HIP_NO_FAST");
 }
 
+template <int MT, int SMP, bool P2P>
+void launch_fast_tt(mc3hip_ctx *c, int nref)
+{
+    if (c->P.thinning == 1)
+        hipLaunchKernelGGL((persist_fast_kernel<MT, SMP, P2P, 1>), dim3(c->P.nlocal), dim3(64),
+                           c->smem, c->stream, c->P, nref);
+    else
+        hipLaunchKernelGGL((persist_fast_kernel<MT, SMP, P2P, 0>), dim3(c->P.nlocal), dim3(64),
+                           c->smem, c->stream, c->P, nref);
+}
+
 template <int MT>
 void launch_fast_t(mc3hip_ctx *c, int nref)
 {
+    const bool demc = c->P.sampler == MC3HIP_DEMC;
     if (c->p2p_ranks > 1) {
-        if (c->P.sampler == MC3HIP_DEMC)
-            hipLaunchKernelGGL((persist_fast_kernel<MT, MC3HIP_DEMC, true>), dim3(c->P.nlocal),
-                               dim3(64), c->smem, c->stream, c->P, nref);
+        if (demc)
+            launch_fast_tt<MT, MC3HIP_DEMC, true>(c, nref);
         else
-            hipLaunchKernelGGL((persist_fast_kernel<MT, MC3HIP_SNOOKER, true>),
-                               dim3(c->P.nlocal), dim3(64), c->smem, c->stream, c->P, nref);
-        return;
+            launch_fast_tt<MT, MC3HIP_SNOOKER, true>(c, nref);
+    } else {
+        if (demc)
+            launch_fast_tt<MT, MC3HIP_DEMC, false>(c, nref);
+        else
+            launch_fast_tt<MT, MC3HIP_SNOOKER, false>(c, nref);
     }
-    if (c->P.sampler == MC3HIP_DEMC)
-        hipLaunchKernelGGL((persist_fast_kernel<MT, MC3HIP_DEMC>), dim3(c->P.nlocal), dim3(64),
-                           c->smem, c->stream, c->P, nref);
-    else
-        hipLaunchKernelGGL((persist_fast_kernel<MT, MC3HIP_SNOOKER>), dim3(c->P.nlocal),
-                           dim3(64), c->smem, c->stream, c->P, nref);
 }
 
 void launch_fast(mc3hip_ctx *c, int nref)
@@ -362,11 +370,12 @@ template <int MT>
 int fast_blocks_per_cu_t(mc3hip_ctx *c)
 {
     int nb = 0;
+    // the least favourable instance (runtime thinning, peer-to-peer stores) sizes the grid
     hipError_t e = (c->P.sampler == MC3HIP_DEMC)
         ? hipOccupancyMaxActiveBlocksPerMultiprocessor(
-              &nb, persist_fast_kernel<MT, MC3HIP_DEMC>, 64, c->smem)
+              &nb, persist_fast_kernel<MT, MC3HIP_DEMC, true, 0>, 64, c->smem)
         : hipOccupancyMaxActiveBlocksPerMultiprocessor(
-              &nb, persist_fast_kernel<MT, MC3HIP_SNOOKER>, 64, c->smem);
+              &nb, persist_fast_kernel<MT, MC3HIP_SNOOKER, true, 0>, 64, c->smem);
     return e == hipSuccess ? nb : 0;
 }
 

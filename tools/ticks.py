@@ -31,5 +31,7 @@ print(f'thinning={thin} plan={g.plan} iterations sampled (in-bounds, workgroup 0
 print(f'  top -> partner rows arrived   {b[8]/n:8.0f} cycles')
 print(f'  -> chisq reduced              {b[9]/n:8.0f}')
 print(f'  -> end of iteration           {b[10]/n:8.0f}')
-print(f'  sum                           {(b[8]+b[9]+b[10])/n:8.0f}   '
+print(f'  -> row published              {b[11]/n:8.0f}')
+print(f'  -> top of next iteration      {b[13]/n:8.0f}')
+print(f'  sum                           {(b[8]+b[9]+b[10]+b[11]+b[13])/n:8.0f}   '
       f'(wall {g.last_run_ms()*1e3/16000/thin:.3f} us per iteration)')
