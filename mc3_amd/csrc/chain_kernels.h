@@ -22,6 +22,12 @@
 namespace mc3hip {
 
 constexpr int VLANES = 1024;
+// Z rows are padded on the device to whole 128-byte lines (ZROW doubles, or a multiple of
+// it for more than 16 free parameters): rows are written by different chains -- different
+// CUs and XCDs -- at the same moment, and write-through stores that share a line
+// serialise on it.  Measured on C2: 165 -> 194 M chain-steps/s.  The C-ABI packs and
+// unpacks, so callers keep seeing dense [rows][nfree] arrays.
+constexpr int ZROW = 16;
 
 // model tags
 constexpr int MT_POLY_GENERIC = 0;   // runtime nmodel, coefficients read from LDS
@@ -33,6 +39,7 @@ constexpr int MT_LINEAR = 100;       // sum_k A[k][i] p[k]
 struct DevProblem {
     int32_t nchains, chain0, nlocal, nparams, nfree, nshare, ndata;
     int32_t npad;          // ndata rounded up to a multiple of 1024 (Gaussian data sum)
+    int32_t zs, _pad_zs;   // doubles per row of Z and snap0 on the device (multiple of ZROW)
     int32_t sampler, wlike, nmodel, thinning, ngprior, trace_iters;
     int64_t M0;
     uint64_t seed;
@@ -763,9 +770,11 @@ __device__ __forceinline__ double load_published(const double *p)
 // the host then restores its checkpoint and redoes the run (mc3hip.hip settle()).
 template <int NVAL, bool SYS = false>
 __device__ __forceinline__ bool wait_rows(const double *const (&addr)[NVAL], double (&val)[NVAL],
-                                          long long *ctl)
+                                          long long *ctl, unsigned long long *nspin = nullptr)
 {
     for (unsigned spins = 0;; ++spins) {
+        if (nspin && spins)
+            *nspin += 1;                      // diagnostic build: polls beyond the first
         bool ready = true;
 #pragma unroll
         for (int q = 0; q < NVAL; ++q)
@@ -774,10 +783,15 @@ __device__ __forceinline__ bool wait_rows(const double *const (&addr)[NVAL], dou
             return true;
         __builtin_amdgcn_s_sleep(1);
         if ((spins & 1023u) == 1023u) {
-            const long long ab = __hip_atomic_load(&ctl[CTL_ABORT], __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
+            // (made wave-uniform by hand: a per-lane load would make this exit, and with it
+            // every value live across the chain loop, divergent in the compiler's eyes)
+            const int ab = __builtin_amdgcn_readfirstlane(
+                (int)(__hip_atomic_load(&ctl[CTL_ABORT], __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT) != 0));
             if (ab != 0 || spins > (1u << 23)) {
-                if (ab == 0 && (threadIdx.x & 63) == 0)
+                // every lane stores the same word: a lane-0 branch right at this exit would
+                // again make the exit look divergent
+                if (ab == 0)
                     __hip_atomic_store(&ctl[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 return false;
@@ -813,6 +827,19 @@ __device__ __forceinline__ Draws make_draws(const DevProblem &P, uint64_t iter, 
         D.d2 = draw2(P.seed, iter, (uint32_t)c, 2u);
     }
     return D;
+}
+
+// DEMC partners, chain.py:221-232: r1 != c, r2 != c, r2 != r1, from the two 32-bit
+// halves of one draw
+__device__ __forceinline__ void demc_partners(uint64_t q0, int n, int c, int &r1, int &r2)
+{
+    r1 = 1 + (int)bounded32((uint32_t)(q0 >> 32), (uint32_t)(n - 1));
+    if (r1 == c)
+        r1 = 0;
+    r2 = r1 + 2 + (int)bounded32((uint32_t)q0, (uint32_t)(n - 2));   // < 2n
+    r2 = (r2 >= n) ? r2 - n : r2;                                      // (...) % n
+    if (r2 == c)
+        r2 = (r1 + 1 == n) ? 0 : r1 + 1;                               // (r1+1) % n
 }
 
 // One chain, refreshes [R0, R0 + nref).  PERSIST = false: one refresh per launch,
@@ -856,6 +883,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     const int lc = blockIdx.x;                 // local chain
     const int c = P.chain0 + lc;               // global chain id
     const int nf = P.nfree;
+    const int zs = P.zs;                       // row stride of Z / snap0 (padded lines)
     const bool mine = wave0 && lane < nf;      // lane k of wave 0 owns free parameter k
 
     // Everything that does not depend on the proposal is requested first, so the
@@ -869,10 +897,10 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     // rows requested a few hundred cycles later, so their translation is warm); in
     // the middle of a refresh (tiled plan, thinning > 1) it is the saved state
     const double *snap_first = (R0 == 0) ? P.snap0
-                                         : P.Z + (size_t)(P.M0 + (R0 - 1) * P.nchains) * nf;
+                                         : P.Z + (size_t)(P.M0 + (R0 - 1) * P.nchains) * zs;
     double xk = 0.0;
     if (mine)
-        xk = (jb == 0) ? snap_first[(size_t)c * nf + lane] : P.X[(size_t)lc * nf + lane];
+        xk = (jb == 0) ? snap_first[(size_t)c * zs + lane] : P.X[(size_t)lc * nf + lane];
     double cur = P.chisq[lc];
     double best = P.best_chisq[lc];
     const long long nacc0 = P.numaccept[lc];
@@ -888,7 +916,8 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     bool alive = true;
     if constexpr (PERSIST) {
         // a launch queued behind one that gave up must not run: its inputs are missing
-        if (__hip_atomic_load(&ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+        if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
+                &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
             return;
     }
     MC3_STAMP(1);
@@ -901,20 +930,20 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                            sampler);
     // diagnostic build only: per-phase tick sums kept in registers, stored once at exit
     unsigned long long tk_prev3 = 0, tk_prevend = 0;
-    unsigned long long ta8 = 0, ta9 = 0, ta10 = 0, ta11 = 0, ta12 = 0, ta13 = 0;
+    unsigned long long ta8 = 0, ta9 = 0, ta10 = 0, ta11 = 0, ta12 = 0, ta13 = 0, ta14 = 0, ta15 = 0;
+    (void)ta14; (void)ta15;
     (void)tk_prev3; (void)tk_prevend;
     (void)ta8; (void)ta9; (void)ta10; (void)ta11; (void)ta12; (void)ta13;
     for (long long R = R0; R < R0 + nref && alive; ++R) {
     if constexpr (PERSIST) {
         if (P.test_abort >= 0 && R == P.test_abort && lc == 0) {     // test hook
-            if (tid == 0)
-                __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);             // (all lanes, same word)
             return;
         }
     }
     const double *snap = (R == 0) ? P.snap0
-                                  : P.Z + (size_t)(P.M0 + (R - 1) * P.nchains) * nf;
+                                  : P.Z + (size_t)(P.M0 + (R - 1) * P.nchains) * zs;
     const long long zsize = P.M0 + R * P.nchains;
     const int jfirst = (TH == 1) ? 0 : jb;
     const int jlast = (TH == 1) ? 1 : je;
@@ -959,9 +988,9 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 double z1 = 0.0, z2 = 0.0;
                 if constexpr (PERSIST) {
                     const int kk = mine ? lane : 0;
-                    const double *const addr[3] = {P.Z + (size_t)iR1 * nf + kk,
-                                                   P.Z + (size_t)iR2 * nf + kk,
-                                                   P.Z + (size_t)iz * nf + kk};
+                    const double *const addr[3] = {P.Z + (size_t)iR1 * zs + kk,
+                                                   P.Z + (size_t)iR2 * zs + kk,
+                                                   P.Z + (size_t)iz * zs + kk};
                     double val[3];
 #pragma unroll
                     for (int q = 0; q < 3; ++q)
@@ -976,13 +1005,14 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                     pin_scalar(nxt.d2.q1);
                     __builtin_amdgcn_sched_barrier(0);
                     alive = wait_rows<3, P2P>(addr, val, ctl_rw);
+                    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see lean_demc_kernel
                     z1 = val[0];
                     z2 = val[1];
                     zk = val[2];
                 } else {
-                    z1 = mine ? P.Z[(size_t)iR1 * nf + lane] : 0.0;
-                    z2 = mine ? P.Z[(size_t)iR2 * nf + lane] : 0.0;
-                    zk = (mine && sjump) ? P.Z[(size_t)iz * nf + lane] : 0.0;
+                    z1 = mine ? P.Z[(size_t)iR1 * zs + lane] : 0.0;
+                    z2 = mine ? P.Z[(size_t)iR2 * zs + lane] : 0.0;
+                    zk = (mine && sjump) ? P.Z[(size_t)iz * zs + lane] : 0.0;
                 }
                 if (sjump) {
                     flags |= 4;
@@ -1005,35 +1035,39 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 if constexpr (PERSIST)
                     nxt = make_draws(P, iter + 1, c, sampler);
             } else {                                                 // chain.py:221-232
-                const int n = P.nchains;
-                int r1 = 1 + (int)bounded32((uint32_t)(d0.q0 >> 32), (uint32_t)(n - 1));
-                if (r1 == c)
-                    r1 = 0;
-                int r2 = r1 + 2 + (int)bounded32((uint32_t)d0.q0, (uint32_t)(n - 2));  // < 2n
-                r2 = (r2 >= n) ? r2 - n : r2;                               // (...) % n
-                if (r2 == c)
-                    r2 = (r1 + 1 == n) ? 0 : r1 + 1;                        // (r1+1) % n
+                int r1, r2;
+                demc_partners(d0.q0, P.nchains, c, r1, r2);
                 double x1 = 0.0, x2 = 0.0;
                 if constexpr (PERSIST) {
                     const int kk = mine ? lane : 0;
-                    const double *const addr[2] = {snap + (size_t)r1 * nf + kk,
-                                                   snap + (size_t)r2 * nf + kk};
+                    const double *const addr[2] = {snap + (size_t)r1 * zs + kk,
+                                                   snap + (size_t)r2 * zs + kk};
                     double val[2];
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
                         val[q] = load_published<P2P>(addr[q]);
+#ifdef MC3HIP_STAMPS
+                    unsigned long long tkL;
+                    MC3_TICK(tkL);
+                    ta15 += tkL - tk0;
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                     nxt = make_draws(P, iter + 1, c, sampler);
                     pin_scalar(nxt.d0.q0);
                     pin_scalar(nxt.d0.q1);
                     __builtin_amdgcn_sched_barrier(0);
+#ifdef MC3HIP_STAMPS
+                    alive = wait_rows<2, P2P>(addr, val, ctl_rw, &ta14);
+#else
                     alive = wait_rows<2, P2P>(addr, val, ctl_rw);
+#endif
+                    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see lean_demc_kernel
                     MC3_TICK(tk1);
                     x1 = val[0];
                     x2 = val[1];
                 } else {
-                    x1 = mine ? snap[(size_t)r1 * nf + lane] : 0.0;
-                    x2 = mine ? snap[(size_t)r2 * nf + lane] : 0.0;
+                    x1 = mine ? snap[(size_t)r1 * zs + lane] : 0.0;
+                    x2 = mine ? snap[(size_t)r2 * zs + lane] : 0.0;
                 }
                 jump_k = P.gamma * (x1 - x2) + P.fepsilon * normal_k;
             }
@@ -1180,13 +1214,13 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
         if (mine) {
             if constexpr (P2P) {
                 for (int pr = 0; pr < P.npeers; ++pr)               // publish everywhere
-                    __hip_atomic_store(&P.peerZ[pr][(size_t)row * nf + lane], xk,
+                    __hip_atomic_store(&P.peerZ[pr][(size_t)row * zs + lane], xk,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             } else if constexpr (PERSIST) {
-                __hip_atomic_store(&P.Z[(size_t)row * nf + lane], xk, __ATOMIC_RELAXED,
+                __hip_atomic_store(&P.Z[(size_t)row * zs + lane], xk, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);      // publish (sc1)
             } else {
-                P.Z[(size_t)row * nf + lane] = xk;
+                P.Z[(size_t)row * zs + lane] = xk;
             }
         }
         if (lane == 0) {
@@ -1216,6 +1250,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     if (PERSIST && threadIdx.x == 0 && blockIdx.x == 0) {
         P.stamps[8] += ta8; P.stamps[9] += ta9; P.stamps[10] += ta10;
         P.stamps[11] += ta11; P.stamps[12] += ta12; P.stamps[13] += ta13;
+        P.stamps[14] += ta14; P.stamps[15] += ta15;
     }
 #endif
 }
@@ -1260,6 +1295,202 @@ __global__ __launch_bounds__(64) void persist_fast_kernel(const DevProblem P, co
 }
 
 // chisq for arbitrary parameter vectors (Chain.eval_model(ret='chisq'))
+// ---------------------------------------------------------------------------------
+// The headline shape written out by hand: lean instance (see run_chain FAST), DEMC,
+// thinning = 1, persistent.  Same arithmetic and the same results as
+// run_chain<1, MT, false, false, true, MC3HIP_DEMC, true>; what differs is only how the
+// loop is laid out for ONE wave that nothing else on its SIMD hides latencies for:
+//   * every address is a pointer bumped by a constant per refresh (MT = nfree is a
+//     compile-time constant), no 64-bit index arithmetic in the loop;
+//   * everything of refresh R+1 that does not depend on chain states -- Philox, the
+//     Metropolis draw, the partner indices and their byte offsets -- is computed in the
+//     shadow of refresh R's partner-row wait;
+//   * the Metropolis update is a select, not a branch; only the rare events (new best
+//     fit, out-of-bounds proposal, a failed wait) leave the straight line.
+template <int MT, bool P2P>
+__global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const int nref)
+{
+    constexpr int NF = MT;
+    constexpr int ZS = ZROW;                 // doubles per Z row: one 128-byte line (NF <= 16)
+    constexpr int LM = P2P ? 1 : 0;
+    const int lane = threadIdx.x;
+    const int lc = blockIdx.x;
+    const int c = P.chain0 + lc;
+    const bool mine = lane < NF;
+    const int kk = mine ? lane : 0;
+    long long *ctl_rw = const_cast<long long *>(P.ctl);
+    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
+            &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+        return;
+    MC3_STAMP(0);
+    DataTile<1, MT> tile;
+    tile.load(P);
+    const long long R0 = P.ctl[0];
+    const int n = P.nchains;
+    const size_t blockstride = (size_t)n * ZS;                   // doubles per refresh
+    // rows of refresh R0 - 1 (the current states) and of refresh R0 (to be published)
+    const double *pbase = (R0 == 0) ? P.snap0 : P.Z + (size_t)(P.M0 + (R0 - 1) * n) * ZS;
+    double *zblock = P.Z + (size_t)(P.M0 + R0 * n) * ZS;
+    double *lp_row = P.log_post + (P.M0 + R0 * n + c);
+    int32_t *zc_row = P.zchain + (P.M0 + R0 * n + c);
+    double xk = mine ? pbase[(size_t)c * ZS + lane] : 0.0;
+    double cur = P.chisq[lc];
+    double best = P.best_chisq[lc];
+    const long long nacc0 = P.numaccept[lc];
+    const double pmin_k = mine ? P.fmin[lane] : 0.0;
+    const double pmax_k = mine ? P.fmax[lane] : 0.0;
+    const double gamma = P.gamma, feps = P.fepsilon;
+    const long long abort_at = (P.test_abort >= 0 && lc == 0) ? (long long)P.test_abort : -1;
+    int nacc = 0;
+    bool alive = true;
+    MC3_STAMP(1);
+
+    // draws of the first refresh
+    Draw2 d = draw2(P.seed, (uint64_t)R0, (uint32_t)c, 0u);
+    double u = u01(d.q1);
+    int r1, r2;
+    demc_partners(d.q0, n, c, r1, r2);
+    int off1 = r1 * ZS + kk, off2 = r2 * ZS + kk;
+
+    unsigned long long tk_prev3 = 0, tk_prevend = 0;
+    unsigned long long ta8 = 0, ta9 = 0, ta10 = 0, ta11 = 0, ta12 = 0, ta13 = 0, ta14 = 0, ta15 = 0;
+    (void)tk_prev3; (void)tk_prevend; (void)ta8; (void)ta9; (void)ta10; (void)ta11; (void)ta12;
+    (void)ta13; (void)ta14; (void)ta15;
+    const long long Rend = R0 + nref;
+    // every load issued so far is complete before the loop is entered, so that no path
+    // through it carries a pending load to the latch (see the note after wait_rows)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (long long R = R0; R < Rend; ++R) {
+        unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+        (void)tk0; (void)tk1; (void)tk2; (void)tk3;
+        MC3_TICK(tk0);
+#ifdef MC3HIP_STAMPS
+        if (tk_prevend != 0) {
+            ta11 += tk_prevend - tk_prev3;
+            ta13 += tk0 - tk_prevend;
+        }
+#endif
+        if (R == abort_at) {                                         // test hook
+            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);             // (all lanes, same word)
+            break;            // (the host restores its checkpoint after an abort)
+        }
+        // partner rows of this refresh (chain.py:221-232), requested first
+        const double *const addr[2] = {pbase + off1, pbase + off2};
+        double val[2];
+        val[0] = load_published<LM>(addr[0]);
+        val[1] = load_published<LM>(addr[1]);
+#ifdef MC3HIP_STAMPS
+        unsigned long long tkL;
+        MC3_TICK(tkL);
+        ta15 += tkL - tk0;
+#endif
+        const double u_now = u;
+        __builtin_amdgcn_sched_barrier(0);
+        // ... and behind them everything of the next refresh that needs no chain state
+        d = draw2(P.seed, (uint64_t)(R + 1), (uint32_t)c, 0u);
+        pin_scalar(d.q0);
+        pin_scalar(d.q1);
+        u = u01(d.q1);                                               // chain.py:259
+        demc_partners(d.q0, n, c, r1, r2);
+        off1 = r1 * ZS + kk;
+        off2 = r2 * ZS + kk;
+        asm volatile("; pin" : "+v"(u), "+v"(off1), "+v"(off2));
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef MC3HIP_STAMPS
+        alive = wait_rows<2, LM>(addr, val, ctl_rw, &ta14);
+#else
+        alive = wait_rows<2, LM>(addr, val, ctl_rw);
+#endif
+        // Tell the compiler's wait-count bookkeeping that nothing is pending on EITHER way
+        // out of the poll loop (it merges the paths): otherwise it guards the registers
+        // of the polls with waits at the loop latch, and those stall on the acknowledgement
+        // of the row just published (loads and stores share the counter on gfx9).
+        __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0), already true
+        MC3_TICK(tk1);
+        if (!alive)
+            break;
+        // proposal and boundaries, chain.py:232-243
+        const double jump_k = gamma * (val[0] - val[1]) + feps * 0.0;
+        const double npk = xk + jump_k;
+        const bool outk = mine && (npk < pmin_k || npk > pmax_k);
+        if (!__any(outk)) {
+            Model<MT> model;
+            model.init_from_lanes(P, npk);
+            const double nextchisq =
+                block_gauss_model<1, MT, false>(P, model, nullptr, nullptr, tile);   // chain.py:249
+            MC3_TICK(tk2);
+            const double ratio = mc3_det_exp(0.5 * (cur - nextchisq)) * 1.0;
+            const bool acc = ratio > u_now;                          // chain.py:257-274
+            xk = acc ? npk : xk;
+            if (__any(acc && nextchisq < best)) {
+                best = nextchisq;
+                if (mine)
+                    P.bestx[(size_t)lc * NF + lane] = xk;
+                if (lane == 0)
+                    P.best_iter[lc] = R;
+            }
+            cur = acc ? nextchisq : cur;
+            nacc += acc ? 1 : 0;
+        } else if (outk) {
+            atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
+        }
+#ifdef MC3HIP_STAMPS
+        MC3_TICK(tk3);
+        if (tk2 != 0) {
+            ta8 += tk1 - tk0;
+            ta9 += tk2 - tk1;
+            ta10 += tk3 - tk2;
+            ta12 += 1;
+        }
+        tk_prev3 = tk3;
+#endif
+        // Z append, chain.py:276-289: publish the row, then the bookkeeping columns
+        if constexpr (P2P) {
+            const size_t zoff = (size_t)(zblock - P.Z) + (size_t)c * ZS + lane;
+            const size_t roff = (size_t)(lp_row - P.log_post);
+            for (int pr = 0; pr < P.npeers; ++pr) {
+                if (mine)
+                    __hip_atomic_store(&P.peerZ[pr][zoff], xk, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+                if (lane == 0)
+                    __hip_atomic_store(&P.peerLP[pr][roff], -0.5 * cur, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            if (lane == 0)
+                *zc_row = c;
+        } else {
+            if (mine)
+                __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);        // publish (sc1)
+            if (lane == 0) {
+                *lp_row = -0.5 * cur;
+                *zc_row = c;
+            }
+        }
+        pbase = zblock;
+        zblock += blockstride;
+        lp_row += n;
+        zc_row += n;
+        MC3_TICK(tk_prevend);
+    }
+    if (mine)
+        P.X[(size_t)lc * NF + lane] = xk;
+    if (lane == 0) {
+        P.chisq[lc] = cur;
+        P.best_chisq[lc] = best;
+        P.numaccept[lc] = nacc0 + nacc;
+    }
+    MC3_STAMP(4);
+#ifdef MC3HIP_STAMPS
+    if (lc == 0 && lane == 0) {
+        P.stamps[8] += ta8; P.stamps[9] += ta9; P.stamps[10] += ta10;
+        P.stamps[11] += ta11; P.stamps[12] += ta12; P.stamps[13] += ta13;
+        P.stamps[14] += ta14; P.stamps[15] += ta15;
+    }
+#endif
+}
+
 template <int WPC, int MT, bool WL>
 __global__ __launch_bounds__(64 * WPC) void eval_chisq_kernel(const DevProblem P,
                                                               const double *params,
@@ -1385,7 +1616,7 @@ __global__ void diff_kernel(const double *a, const double *b, int n, int npad, d
 // Gelman-Rubin test needs (mc3/stats/gelman.py:12-92) without copying Z to the host.
 // One workgroup per chain; two passes (mean, then squared deviations).
 __global__ __launch_bounds__(256) void chain_moments_kernel(const double *Z, long long M0,
-                                                            int nchains, int nf,
+                                                            int nchains, int nf, int zs,
                                                             long long nref, long long burn,
                                                             double *mean, double *var)
 {
@@ -1395,7 +1626,7 @@ __global__ __launch_bounds__(256) void chain_moments_kernel(const double *Z, lon
     for (int k = 0; k < nf; ++k) {
         double acc = 0.0;
         for (long long r = burn + t; r < nref; r += 256)
-            acc += Z[(size_t)(M0 + r * nchains + c) * nf + k];
+            acc += Z[(size_t)(M0 + r * nchains + c) * zs + k];
         s_red[t] = acc;
         __syncthreads();
         for (int s2 = 128; s2 >= 1; s2 >>= 1) {
@@ -1407,7 +1638,7 @@ __global__ __launch_bounds__(256) void chain_moments_kernel(const double *Z, lon
         __syncthreads();
         acc = 0.0;
         for (long long r = burn + t; r < nref; r += 256) {
-            const double d = Z[(size_t)(M0 + r * nchains + c) * nf + k] - mu;
+            const double d = Z[(size_t)(M0 + r * nchains + c) * zs + k] - mu;
             acc += d * d;
         }
         s_red[t] = acc;
@@ -1423,6 +1654,25 @@ __global__ __launch_bounds__(256) void chain_moments_kernel(const double *Z, lon
         }
         __syncthreads();
     }
+}
+
+// dense [rows][nf] (what the C-ABI exchanges) <-> padded [rows][zs] (device layout of Z)
+__global__ void pack_rows_kernel(double *dense, const double *padded, long long nrows, int nf,
+                                 int zs)
+{
+    const long long total = nrows * nf;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x)
+        dense[i] = padded[(i / nf) * zs + (i % nf)];
+}
+
+__global__ void unpack_rows_kernel(double *padded, const double *dense, long long nrows, int nf,
+                                   int zs)
+{
+    const long long total = nrows * nf;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x)
+        padded[(i / nf) * zs + (i % nf)] = dense[i];
 }
 
 __global__ void set_ctl_kernel(long long *ctl, long long base, long long run0)

@@ -137,6 +137,8 @@ struct mc3hip_ctx {
     int persist_refs = 0;           // refreshes per persistent launch, 0 = off
     bool persist_checked = false;
     bool fast = false;              // lean persistent instance selected
+    double *stage = nullptr;        // dense staging for Z row transfers (grow-only)
+    size_t stage_doubles = 0;
     // checkpoint of the per-chain state taken before the first persistent launch that
     // has not been confirmed yet (recovery if a launch gives up)
     char *ckpt = nullptr;
@@ -344,6 +346,16 @@ template <int MT>
 void launch_fast_t(mc3hip_ctx *c, int nref)
 {
     const bool demc = c->P.sampler == MC3HIP_DEMC;
+    if (demc && c->P.thinning == 1 && c->P.nfree == MT && !getenv("MC3HIP_NO_LEAN")) {
+        // the headline shape has a loop of its own (chain_kernels.h lean_demc_kernel)
+        if (c->p2p_ranks > 1)
+            hipLaunchKernelGGL((lean_demc_kernel<MT, true>), dim3(c->P.nlocal), dim3(64), 0,
+                               c->stream, c->P, nref);
+        else
+            hipLaunchKernelGGL((lean_demc_kernel<MT, false>), dim3(c->P.nlocal), dim3(64), 0,
+                               c->stream, c->P, nref);
+        return;
+    }
     if (c->p2p_ranks > 1) {
         if (demc)
             launch_fast_tt<MT, MC3HIP_DEMC, true>(c, nref);
@@ -376,6 +388,11 @@ int fast_blocks_per_cu_t(mc3hip_ctx *c)
               &nb, persist_fast_kernel<MT, MC3HIP_DEMC, true, 0>, 64, c->smem)
         : hipOccupancyMaxActiveBlocksPerMultiprocessor(
               &nb, persist_fast_kernel<MT, MC3HIP_SNOOKER, true, 0>, 64, c->smem);
+    if (e == hipSuccess && c->P.sampler == MC3HIP_DEMC) {
+        int nl = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nl, lean_demc_kernel<MT, true>, 64, 0);
+        nb = nl < nb ? nl : nb;
+    }
     return e == hipSuccess ? nb : 0;
 }
 
@@ -533,14 +550,76 @@ int set_smem_attr(mc3hip_ctx *c)
     return MC3HIP_OK;
 }
 
+// ---- dense host rows <-> padded device rows (chain_kernels.h ZROW) ----------------------
+constexpr size_t STAGE_MAX_DOUBLES = size_t(8) << 20;      // 64 MiB of staging at most
+#define RC_TRY(expr)                                                                \
+    do {                                                                            \
+        const int rc_try_ = (expr);                                                 \
+        if (rc_try_)                                                                \
+            return rc_try_;                                                         \
+    } while (0)
+
+static int stage_reserve(mc3hip_ctx *c, size_t doubles)
+{
+    if (doubles <= c->stage_doubles)
+        return MC3HIP_OK;
+    if (c->stage)
+        HIP_TRY(hipFree(c->stage));
+    c->stage = nullptr;
+    c->stage_doubles = 0;
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, doubles * sizeof(double)));
+    c->stage = static_cast<double *>(p);
+    c->stage_doubles = doubles;
+    return MC3HIP_OK;
+}
+
+static int rows_to_device(mc3hip_ctx *c, double *padded, const double *host, size_t nrows)
+{
+    const size_t nf = (size_t)c->P.nfree, zs = (size_t)c->P.zs;
+    const size_t chunk = STAGE_MAX_DOUBLES / nf ? STAGE_MAX_DOUBLES / nf : 1;
+    for (size_t r = 0; r < nrows; r += chunk) {
+        const size_t m = nrows - r < chunk ? nrows - r : chunk;
+        RC_TRY(stage_reserve(c, m * nf));
+        HIP_TRY(hipMemcpyAsync(c->stage, host + r * nf, m * nf * sizeof(double),
+                               hipMemcpyHostToDevice, c->stream));
+        const int blocks = (int)((m * nf + 255) / 256 < 4096 ? (m * nf + 255) / 256 : 4096);
+        hipLaunchKernelGGL(unpack_rows_kernel, dim3(blocks), dim3(256), 0, c->stream,
+                           padded + r * zs, (const double *)c->stage, (long long)m, (int)nf,
+                           (int)zs);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return MC3HIP_OK;
+}
+
+static int rows_to_host(mc3hip_ctx *c, double *host, const double *padded, size_t nrows)
+{
+    const size_t nf = (size_t)c->P.nfree, zs = (size_t)c->P.zs;
+    const size_t chunk = STAGE_MAX_DOUBLES / nf ? STAGE_MAX_DOUBLES / nf : 1;
+    for (size_t r = 0; r < nrows; r += chunk) {
+        const size_t m = nrows - r < chunk ? nrows - r : chunk;
+        RC_TRY(stage_reserve(c, m * nf));
+        const int blocks = (int)((m * nf + 255) / 256 < 4096 ? (m * nf + 255) / 256 : 4096);
+        hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, c->stream, c->stage,
+                           padded + r * zs, (long long)m, (int)nf, (int)zs);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(host + r * nf, c->stage, m * nf * sizeof(double),
+                               hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return MC3HIP_OK;
+}
+
 int exchange_rows(mc3hip_ctx *c, int64_t R)
 {
     // one in-place all-gather of the refresh's Z rows: rank r's chains are the
     // contiguous block [chain0, chain0+nlocal) of the nchains rows of refresh R
-    const size_t nf = (size_t)c->P.nfree;
-    double *base = c->P.Z + (size_t)(c->P.M0 + R * c->P.nchains) * nf;
-    const double *send = base + (size_t)c->P.chain0 * nf;
-    int rc = g_rccl.AllGather(send, base, (size_t)c->P.nlocal * nf, NCCL_FLOAT64, c->comm,
+    // (whole padded rows: zs doubles each)
+    const size_t zs = (size_t)c->P.zs;
+    double *base = c->P.Z + (size_t)(c->P.M0 + R * c->P.nchains) * zs;
+    const double *send = base + (size_t)c->P.chain0 * zs;
+    int rc = g_rccl.AllGather(send, base, (size_t)c->P.nlocal * zs, NCCL_FLOAT64, c->comm,
                               c->stream);
     if (rc != 0)
         return fail(MC3HIP_ERR_COMM, "ncclAllGather failed: %s",
@@ -718,18 +797,20 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         TRY(dev_upload(c, &P.w, w.data(), npad));
     }
     const size_t zl = (size_t)pr->zlen, nl = (size_t)pr->nlocal;
+    P.zs = (int32_t)(((nf + ZROW - 1) / ZROW) * ZROW);       // whole 128-byte lines per row
+    const size_t zs = (size_t)P.zs;
     if (pr->flags & MC3HIP_FLAG_P2P) {
         // replicas other GPUs store into while kernels run: fine-grained (coherent at
         // system scope), own allocations so that they can be exported through IPC
         void *pz = nullptr, *pl = nullptr;
-        HIP_TRY_C(hipExtMallocWithFlags(&pz, zl * nf * sizeof(double), hipDeviceMallocFinegrained));
+        HIP_TRY_C(hipExtMallocWithFlags(&pz, zl * zs * sizeof(double), hipDeviceMallocFinegrained));
         c->allocs.push_back(pz);
         HIP_TRY_C(hipExtMallocWithFlags(&pl, zl * sizeof(double), hipDeviceMallocFinegrained));
         c->allocs.push_back(pl);
         P.Z = static_cast<double *>(pz);
         P.log_post = static_cast<double *>(pl);
     } else {
-        TRY(dev_alloc(c, &P.Z, zl * nf));
+        TRY(dev_alloc(c, &P.Z, zl * zs));
         TRY(dev_alloc(c, &P.log_post, zl));
     }
     TRY(dev_alloc(c, &P.zchain, zl));
@@ -742,7 +823,7 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
     TRY(dev_alloc(c, &P.bestx, nl * nf));
     {
         double *snap = nullptr;
-        TRY(dev_alloc(c, &snap, (size_t)pr->nchains * nf));
+        TRY(dev_alloc(c, &snap, (size_t)pr->nchains * zs));
         P.snap0 = snap;
     }
     if (P.trace_iters > 0) {
@@ -778,7 +859,16 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
     HIP_TRY_C(hipMemset(P.stamps, 0, 16 * sizeof(unsigned long long)));
     HIP_TRY_C(hipMemset(c->ctl, 0, 4 * sizeof(long long)));
     // all-ones = "row not written yet" (the persistent kernel's hand-off sentinel)
-    HIP_TRY_C(hipMemset(P.Z, 0xff, zl * nf * sizeof(double)));
+    HIP_TRY_C(hipMemset(P.Z, 0xff, zl * zs * sizeof(double)));
+#if defined(MC3HIP_MBOX_STRIDE) && MC3HIP_MBOX_STRIDE
+    {
+        const size_t nmb = (size_t)(zl - P.M0 + P.nchains) * MC3HIP_MBOX_STRIDE;
+        void *pm = nullptr;
+        HIP_TRY_C(hipMalloc(&pm, nmb * sizeof(double)));
+        HIP_TRY_C(hipMemset(pm, 0xff, nmb * sizeof(double)));
+        P.mbox = static_cast<double *>(pm);
+    }
+#endif
     HIP_TRY_C(hipMemset(P.log_post, 0, zl * sizeof(double)));
     HIP_TRY_C(hipMemset(P.zchain, 0xff, zl * sizeof(int32_t)));      // -1, mcmc_driver.py:170
     HIP_TRY_C(hipMemset(P.numaccept, 0, nl * sizeof(long long)));
@@ -832,6 +922,8 @@ void mc3hip_destroy(mc3hip_ctx *c)
         (void)hipGraphDestroy(c->graph);
     for (void *p : c->allocs)
         (void)hipFree(p);
+    if (c->stage)
+        (void)hipFree(c->stage);
     if (c->ev0)
         (void)hipEventDestroy(c->ev0);
     if (c->ev1)
@@ -865,15 +957,14 @@ int mc3hip_set_population(mc3hip_ctx *c, const double *Z0, const double *log_pos
     const DevProblem &P = c->P;
     const size_t nf = (size_t)P.nfree, M0 = (size_t)P.M0, nc = (size_t)P.nchains,
                  nl = (size_t)P.nlocal;
-    HIP_TRY(hipMemcpy(P.Z, Z0, M0 * nf * sizeof(double), hipMemcpyHostToDevice));
+    RC_TRY(rows_to_device(c, P.Z, Z0, M0));
     HIP_TRY(hipMemcpy(P.log_post, log_post0, M0 * sizeof(double), hipMemcpyHostToDevice));
     // chains start from the first nchains rows of Z: chain.py:163-170
     const double *Xs = X0 ? X0 : Z0;
     std::vector<double> chi(nc);
     for (size_t i = 0; i < nc; ++i)
         chi[i] = chisq0 ? chisq0[i] : -2.0 * log_post0[i];
-    HIP_TRY(hipMemcpy(const_cast<double *>(P.snap0), Xs, nc * nf * sizeof(double),
-                      hipMemcpyHostToDevice));
+    RC_TRY(rows_to_device(c, const_cast<double *>(P.snap0), Xs, nc));
     HIP_TRY(hipMemcpy(P.X, Xs + (size_t)P.chain0 * nf, nl * nf * sizeof(double),
                       hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(P.chisq, chi.data() + P.chain0, nl * sizeof(double),
@@ -971,7 +1062,8 @@ static int settle(mc3hip_ctx *c)
     int rc = checkpoint_copy(c, false);
     if (rc)
         return rc;
-    HIP_TRY(hipMemsetAsync(P.Z + row0 * nf, 0xff, nrows * nf * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(P.Z + row0 * (size_t)P.zs, 0xff,
+                           nrows * (size_t)P.zs * sizeof(double), c->stream));
     HIP_TRY(hipMemsetAsync(P.zchain + row0, 0xff, nrows * sizeof(int32_t), c->stream));
     HIP_TRY(hipMemsetAsync(P.log_post + row0, 0, nrows * sizeof(double), c->stream));
     HIP_TRY(hipMemsetAsync(c->ctl + CTL_ABORT, 0, sizeof(long long), c->stream));
@@ -1083,10 +1175,8 @@ int mc3hip_get_rows(mc3hip_ctx *c, int64_t row0, int64_t nrows, double *Z, doubl
         if (rc_settle)
             return rc_settle;
     }
-    const size_t nf = (size_t)c->P.nfree;
     if (Z)
-        HIP_TRY(hipMemcpy(Z, c->P.Z + (size_t)row0 * nf, (size_t)nrows * nf * sizeof(double),
-                          hipMemcpyDeviceToHost));
+        RC_TRY(rows_to_host(c, Z, c->P.Z + (size_t)row0 * (size_t)c->P.zs, (size_t)nrows));
     if (log_post)
         HIP_TRY(hipMemcpy(log_post, c->P.log_post + row0, (size_t)nrows * sizeof(double),
                           hipMemcpyDeviceToHost));
@@ -1117,10 +1207,8 @@ int mc3hip_put_rows(mc3hip_ctx *c, int64_t row0, int64_t nrows, const double *Z,
         if (rc_settle)
             return rc_settle;
     }
-    const size_t nf = (size_t)c->P.nfree;
     if (Z)
-        HIP_TRY(hipMemcpy(c->P.Z + (size_t)row0 * nf, Z, (size_t)nrows * nf * sizeof(double),
-                          hipMemcpyHostToDevice));
+        RC_TRY(rows_to_device(c, c->P.Z + (size_t)row0 * (size_t)c->P.zs, Z, (size_t)nrows));
     if (log_post)
         HIP_TRY(hipMemcpy(c->P.log_post + row0, log_post, (size_t)nrows * sizeof(double),
                           hipMemcpyHostToDevice));
@@ -1196,7 +1284,7 @@ int mc3hip_chain_moments(mc3hip_ctx *c, int64_t burn, double *mean, double *var)
     dv = dm + n;
     hipLaunchKernelGGL(chain_moments_kernel, dim3(c->P.nchains), dim3(256), 0, c->stream,
                        (const double *)c->P.Z, (long long)c->P.M0, c->P.nchains, c->P.nfree,
-                       (long long)c->refresh_done, (long long)burn, dm, dv);
+                       c->P.zs, (long long)c->refresh_done, (long long)burn, dm, dv);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipMemcpyAsync(mean, dm, n * sizeof(double), hipMemcpyDeviceToHost, c->stream);

@@ -10,7 +10,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mc3_amd import _lib  # noqa: E402
-_lib.LIB_PATH = os.path.join(ROOT, 'mc3_amd', 'libmc3hip_stamps.so')
+_lib.LIB_PATH = (os.environ.get('MC3HIP_TICKS_LIB')
+                 or os.path.join(ROOT, 'mc3_amd', 'libmc3hip_stamps.so'))
 from mc3_amd import engine  # noqa: E402
 import bench  # noqa: E402
 
@@ -29,6 +30,7 @@ b = np.array(out[:], dtype=np.float64) - a
 n = b[12]
 print(f'thinning={thin} plan={g.plan} iterations sampled (in-bounds, workgroup 0): {int(n)}')
 print(f'  top -> partner rows arrived   {b[8]/n:8.0f} cycles')
+print(f'     (top -> loads issued {b[15]/n:6.0f}; extra polls per iteration {b[14]/n:.3f})')
 print(f'  -> chisq reduced              {b[9]/n:8.0f}')
 print(f'  -> end of iteration           {b[10]/n:8.0f}')
 print(f'  -> row published              {b[11]/n:8.0f}')
