@@ -232,7 +232,8 @@ def main():
     per = gpu.plan['persistent'] if (not multi or exchange == 'p2p') else 0
     if per > 0:
         launches = -(-args.steps//per)
-        kernel = 'mc3hip::persist_fast_kernel' if gpu.plan['fast'] else 'mc3hip::persist_kernel'
+        kernel = {2: 'mc3hip::lean_demc_kernel', 1: 'mc3hip::persist_fast_kernel',
+                  0: 'mc3hip::persist_kernel'}[gpu.plan['fast']]
         structure = (f'persistent kernel, {per} refreshes per launch, Z rows handed '
                      'between workgroups in-launch')
     else:
@@ -242,7 +243,7 @@ def main():
             (' + one RCCL all-gather per refresh' if multi else
              f' (hipGraph of {gpu.plan["graph_nodes"]} nodes)')
     traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'r01d_c2_pmc.json')
+    pmc = os.path.join(ROOT, 'profiles', 'r01f_c2_pmc.json')
     if os.path.exists(pmc) and args.thinning == 1 and world == 1:
         with open(pmc) as f:
             rec = json.load(f)
@@ -286,7 +287,7 @@ def main():
                     'stream over the timed region / launches). x/data/uncert are '
                     'chain-invariant: they live in registers for a whole launch, so '
                     'hardware HBM traffic (traffic: bytes per launch from '
-                    'profiles/r01d_c2_pmc.json, FETCH_SIZE doubled per the gfx950 note) '
+                    'profiles/r01f_c2_pmc.json, FETCH_SIZE doubled per the gfx950 note) '
                     'is far below the algorithmic figure',
         },
     }

@@ -100,7 +100,8 @@ typedef struct mc3hip_plan {
     int32_t persistent;     /* >0: refreshes per launch of the persistent kernel
                                (in-launch hand-off of Z rows), 0 = one launch per refresh */
     int32_t fast;           /* 1: the lean persistent instance (one wave per chain, fully
-                               free polynomial, Gaussian chisq, no priors/shared/epsilon) */
+                               free polynomial, Gaussian chisq, no priors/shared/epsilon);
+                               2: its hand-laid-out DEMC / thinning = 1 loop (lean_demc_kernel) */
 } mc3hip_plan;
 
 /* Replaces Chain.__init__ + the shared-memory allocation of mcmc()

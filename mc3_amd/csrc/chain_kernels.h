@@ -370,14 +370,12 @@ __device__ __forceinline__ double block_gauss_model(const DevProblem &P, const M
     }
     // The "+inf model => chisq = inf" trap of chain.py:322-323 is resolved lazily: a
     // +inf model value makes its own partial sum non-finite (inf, or NaN where w = 0),
-    // so only then are the model values scanned to tell a +inf model from any other
-    // overflow.  The hot path pays nothing for it.
-    double any = 0.0;
-#pragma unroll
-    for (int v = 0; v < NV; ++v)
-        any = any + acc[v];                           // finite iff every partial is
-    const bool bad = (mc3_bits(any) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
+    // and a non-finite partial makes the total non-finite (inf + x, inf - inf, NaN + x),
+    // so only a non-finite total has the model values scanned to tell a +inf model from
+    // any other overflow.  The hot path pays one compare for it.
     const double total = lane_tree<WPC>(acc, s_part);
+    const bool bad = threadIdx.x < 64 &&
+                     (mc3_bits(total) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
     if (block_or<WPC>(bad, s_flag)) {
         int saw = 0;
         for (int i = threadIdx.x; i < P.ndata; i += 64 * WPC)
@@ -1343,6 +1341,9 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
     const long long abort_at = (P.test_abort >= 0 && lc == 0) ? (long long)P.test_abort : -1;
     int nacc = 0;
     bool alive = true;
+    // log_post / zchain of the last (up to) 64 refreshes wait in lane (R - R0) mod 64 and
+    // are written 64 at a time: nobody reads them inside the launch
+    double lpbuf = 0.0;
     MC3_STAMP(1);
 
     // draws of the first refresh
@@ -1357,6 +1358,7 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
     (void)tk_prev3; (void)tk_prevend; (void)ta8; (void)ta9; (void)ta10; (void)ta11; (void)ta12;
     (void)ta13; (void)ta14; (void)ta15;
     const long long Rend = R0 + nref;
+    long long rdone = R0;                    // refreshes completed (published) by this launch
     // every load issued so far is complete before the loop is entered, so that no path
     // through it carries a pending load to the latch (see the note after wait_rows)
     __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -1376,6 +1378,9 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
             break;            // (the host restores its checkpoint after an abort)
         }
         // partner rows of this refresh (chain.py:221-232), requested first
+        // (a short pause lets the stores of the previous refresh clear the memory pipeline
+        // ahead of the polls: +3 % measured, 64..192 cycles all the same)
+        __builtin_amdgcn_s_sleep(1);
         const double *const addr[2] = {pbase + off1, pbase + off2};
         double val[2];
         val[0] = load_published<LM>(addr[0]);
@@ -1463,16 +1468,31 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
             if (mine)
                 __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);        // publish (sc1)
-            if (lane == 0) {
-                *lp_row = -0.5 * cur;
-                *zc_row = c;
+            const int slot = (int)(R - R0) & 63;
+            lpbuf = (lane == slot) ? -0.5 * cur : lpbuf;
+            if (slot == 63) {
+                lp_row[(size_t)lane * n] = lpbuf;
+                zc_row[(size_t)lane * n] = c;
+                lp_row += (size_t)64 * n;
+                zc_row += (size_t)64 * n;
             }
         }
         pbase = zblock;
         zblock += blockstride;
-        lp_row += n;
-        zc_row += n;
+        if constexpr (P2P) {
+            lp_row += n;
+            zc_row += n;
+        }
         MC3_TICK(tk_prevend);
+        rdone = R + 1;
+    }
+    if constexpr (!P2P) {
+        // the unwritten tail of the bookkeeping columns (also after an early exit)
+        const int left = (int)(rdone - R0) & 63;
+        if (lane < left) {
+            lp_row[(size_t)lane * n] = lpbuf;
+            zc_row[(size_t)lane * n] = c;
+        }
     }
     if (mine)
         P.X[(size_t)lc * NF + lane] = xk;

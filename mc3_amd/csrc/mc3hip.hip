@@ -342,12 +342,18 @@ void launch_fast_tt(mc3hip_ctx *c, int nref)
                            c->smem, c->stream, c->P, nref);
 }
 
+// the headline shape (DEMC, thinning 1) has a loop of its own: lean_demc_kernel
+bool lean_demc_eligible(const mc3hip_ctx *c)
+{
+    return c->fast && c->P.sampler == MC3HIP_DEMC && c->P.thinning == 1 &&
+           c->P.nfree == c->mt && c->P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
+}
+
 template <int MT>
 void launch_fast_t(mc3hip_ctx *c, int nref)
 {
     const bool demc = c->P.sampler == MC3HIP_DEMC;
-    if (demc && c->P.thinning == 1 && c->P.nfree == MT && !getenv("MC3HIP_NO_LEAN")) {
-        // the headline shape has a loop of its own (chain_kernels.h lean_demc_kernel)
+    if (lean_demc_eligible(c)) {
         if (c->p2p_ranks > 1)
             hipLaunchKernelGGL((lean_demc_kernel<MT, true>), dim3(c->P.nlocal), dim3(64), 0,
                                c->stream, c->P, nref);
@@ -942,7 +948,7 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
     plan->waves_per_chain = c->wpc;
     plan->graph_nodes = c->graph_nodes;
     plan->persistent = c->comm ? 0 : decide_persist(const_cast<mc3hip_ctx *>(c));
-    plan->fast = (plan->persistent > 0 && c->fast) ? 1 : 0;
+    plan->fast = (plan->persistent > 0 && c->fast) ? (lean_demc_eligible(c) ? 2 : 1) : 0;
     return MC3HIP_OK;
 }
 
