@@ -46,7 +46,7 @@ MC3_HD double mc3_from_bits(uint64_t u)
 MC3_HD double mc3_pow2i(int k) { return mc3_from_bits((uint64_t)(k + 1023) << 52); }
 
 /* exp(x): Cody-Waite reduction x = k*ln2 + r, |r| <= ln2/2, degree-13 Taylor
- * polynomial (truncation < 5e-18 relative), result scaled by 2^k in two exact
+ * polynomial (truncation < 5e-18 relative; Estrin order), result scaled by 2^k in two exact
  * halves so that overflow/underflow round once.
  * exp(NaN)=NaN, exp(x>709.78..)=+inf, exp(x<-745.2)=0. */
 MC3_HD double mc3_det_exp(double x)
@@ -60,20 +60,24 @@ MC3_HD double mc3_det_exp(double x)
     const double kd = __builtin_rint(x * 1.4426950408889634);
     double r = mc3_fma(-kd, 6.93147180369123816490e-01, x);
     r = mc3_fma(-kd, 1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;            /* 1/13! */
-    p = mc3_fma(p, r, 2.08767569878681e-09);      /* 1/12! */
-    p = mc3_fma(p, r, 2.505210838544172e-08);     /* 1/11! */
-    p = mc3_fma(p, r, 2.755731922398589e-07);     /* 1/10! */
-    p = mc3_fma(p, r, 2.7557319223985893e-06);    /* 1/9!  */
-    p = mc3_fma(p, r, 2.48015873015873e-05);      /* 1/8!  */
-    p = mc3_fma(p, r, 0.0001984126984126984);     /* 1/7!  */
-    p = mc3_fma(p, r, 0.001388888888888889);      /* 1/6!  */
-    p = mc3_fma(p, r, 0.008333333333333333);      /* 1/5!  */
-    p = mc3_fma(p, r, 0.041666666666666664);      /* 1/4!  */
-    p = mc3_fma(p, r, 0.16666666666666666);       /* 1/3!  */
-    p = mc3_fma(p, r, 0.5);
-    p = mc3_fma(p, r, 1.0);
-    p = mc3_fma(p, r, 1.0);
+    /* Estrin's scheme: four dependent fused steps instead of thirteen (a single
+     * wavefront waits on this chain once per iteration) */
+    const double r2 = r * r;
+    const double a0 = mc3_fma(1.0, r, 1.0);                                   /* 1/1!, 1/0! */
+    const double a1 = mc3_fma(0.16666666666666666, r, 0.5);                   /* 1/3!, 1/2! */
+    const double a2 = mc3_fma(0.008333333333333333, r, 0.041666666666666664); /* 1/5!, 1/4! */
+    const double a3 = mc3_fma(0.0001984126984126984, r, 0.001388888888888889);
+    const double a4 = mc3_fma(2.7557319223985893e-06, r, 2.48015873015873e-05);
+    const double a5 = mc3_fma(2.505210838544172e-08, r, 2.755731922398589e-07);
+    const double a6 = mc3_fma(1.6059043836821613e-10, r, 2.08767569878681e-09); /* 1/13!, 1/12! */
+    const double r4 = r2 * r2;
+    const double b0 = mc3_fma(a1, r2, a0);
+    const double b1 = mc3_fma(a3, r2, a2);
+    const double b2 = mc3_fma(a5, r2, a4);
+    const double r8 = r4 * r4;
+    const double d0 = mc3_fma(b1, r4, b0);
+    const double d1 = mc3_fma(a6, r4, b2);
+    const double p = mc3_fma(d1, r8, d0);
     const int k = (int)kd;
     const int k1 = k / 2;
     const int k2 = k - k1;

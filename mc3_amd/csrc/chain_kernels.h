@@ -225,8 +225,9 @@ template <int N>
 __device__ __forceinline__ double add_ror(double v)
 {
     const int lo = __double2loint(v), hi = __double2hiint(v);
-    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x120 + N, 0xf, 0xf, false);
-    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xf, 0xf, false);
+    // (a rotation reads a valid lane everywhere: no "old" value to initialise)
+    const int lo2 = __builtin_amdgcn_mov_dpp(lo, 0x120 + N, 0xf, 0xf, true);
+    const int hi2 = __builtin_amdgcn_mov_dpp(hi, 0x120 + N, 0xf, 0xf, true);
     return v + make_double(lo2, hi2);
 }
 // sum over the 64 lanes of a wave, pairing strides 32,16,8,4,2,1; every lane
