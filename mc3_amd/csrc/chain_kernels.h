@@ -377,7 +377,7 @@ __device__ __forceinline__ double block_gauss_model(const DevProblem &P, const M
     const double total = lane_tree<WPC>(acc, s_part);
     const bool bad = threadIdx.x < 64 &&
                      (mc3_bits(total) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
-    if (block_or<WPC>(bad, s_flag)) {
+    if (__builtin_expect(block_or<WPC>(bad, s_flag), 0)) {
         int saw = 0;
         for (int i = threadIdx.x; i < P.ndata; i += 64 * WPC)
             saw |= is_pos_inf(model.at(i));
@@ -781,7 +781,7 @@ __device__ __forceinline__ bool wait_rows(const double *const (&addr)[NVAL], dou
         if (__all(ready))
             return true;
         __builtin_amdgcn_s_sleep(1);
-        if ((spins & 1023u) == 1023u) {
+        if (__builtin_expect((spins & 1023u) == 1023u, 0)) {
             // (made wave-uniform by hand: a per-lane load would make this exit, and with it
             // every value live across the chain loop, divergent in the compiler's eyes)
             const int ab = __builtin_amdgcn_readfirstlane(
@@ -799,6 +799,49 @@ __device__ __forceinline__ bool wait_rows(const double *const (&addr)[NVAL], dou
 #pragma unroll
         for (int q = 0; q < NVAL; ++q)
             val[q] = load_published<SYS>(addr[q]);
+    }
+}
+
+// The same wait with K polls kept in flight (in-order return: the oldest is checked while
+// the younger ones travel), so that memory is sampled every round trip / K.
+template <int K, int SYS>
+__device__ __forceinline__ bool poll_ring(const double *const (&addr)[2], double (&v)[K][2],
+                                          double (&val)[2], long long *ctl,
+                                          unsigned long long *nspin = nullptr)
+{
+    for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const bool pend0 = __any(mc3_bits(v[q][0]) == ROW_PENDING);
+            const bool pend1 = __any(mc3_bits(v[q][1]) == ROW_PENDING);
+            if (!pend0 && !pend1) {
+                val[0] = v[q][0];
+                val[1] = v[q][1];
+                return true;
+            }
+            if (nspin)
+                *nspin += 1;
+            // only what is still missing is asked for again: every extra request on the
+            // fabric slows everybody's hand-off (K = 2, 3, 4 polls in flight: 181, 173,
+            // 140 M chain-steps/s against 197 for one)
+            // (asked again at once: a pause of 64 / 128 / 256 / 512 cycles here measured
+            // 197 / 195 / 191 / 182 M chain-steps/s against 205 without)
+            if (K > 1 || pend0)
+                v[q][0] = load_published<SYS>(addr[0]);
+            if (K > 1 || pend1)
+                v[q][1] = load_published<SYS>(addr[1]);
+        }
+        if (__builtin_expect((spins & 255u) == 255u, 0)) {
+            const int ab = __builtin_amdgcn_readfirstlane(
+                (int)(__hip_atomic_load(&ctl[CTL_ABORT], __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT) != 0));
+            if (ab != 0 || spins > (1u << 22)) {
+                if (ab == 0)
+                    __hip_atomic_store(&ctl[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
     }
 }
 
@@ -1360,6 +1403,19 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
     (void)ta13; (void)ta14; (void)ta15;
     const long long Rend = R0 + nref;
     long long rdone = R0;                    // refreshes completed (published) by this launch
+    auto flush_columns = [&](int count) {
+        if (lane < count) {
+            if constexpr (P2P) {
+                const size_t roff = (size_t)(lp_row - P.log_post) + (size_t)lane * n;
+                for (int pr = 0; pr < P.npeers; ++pr)
+                    __hip_atomic_store(&P.peerLP[pr][roff], lpbuf, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                lp_row[(size_t)lane * n] = lpbuf;
+            }
+            zc_row[(size_t)lane * n] = c;
+        }
+    };
     // every load issued so far is complete before the loop is entered, so that no path
     // through it carries a pending load to the latch (see the note after wait_rows)
     __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -1373,7 +1429,7 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
             ta13 += tk0 - tk_prevend;
         }
 #endif
-        if (R == abort_at) {                                         // test hook
+        if (__builtin_expect(R == abort_at, 0)) {                                         // test hook
             __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);             // (all lanes, same word)
             break;            // (the host restores its checkpoint after an abort)
@@ -1384,8 +1440,16 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
         __builtin_amdgcn_s_sleep(1);
         const double *const addr[2] = {pbase + off1, pbase + off2};
         double val[2];
-        val[0] = load_published<LM>(addr[0]);
-        val[1] = load_published<LM>(addr[1]);
+#ifndef MC3HIP_POLL_RING
+#define MC3HIP_POLL_RING 1       // polls kept in flight (experiments: see poll_ring)
+#endif
+#ifndef MC3HIP_RING_SLEEP
+#define MC3HIP_RING_SLEEP 4
+#endif
+        constexpr int KR = MC3HIP_POLL_RING;
+        double ring[KR][2];
+        ring[0][0] = load_published<LM>(addr[0]);
+        ring[0][1] = load_published<LM>(addr[1]);
 #ifdef MC3HIP_STAMPS
         unsigned long long tkL;
         MC3_TICK(tkL);
@@ -1403,24 +1467,27 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
         off2 = r2 * ZS + kk;
         asm volatile("; pin" : "+v"(u), "+v"(off1), "+v"(off2));
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 1; q < KR; ++q) {
+            if (q > 1)
+                __builtin_amdgcn_s_sleep(MC3HIP_RING_SLEEP);
+            ring[q][0] = load_published<LM>(addr[0]);
+            ring[q][1] = load_published<LM>(addr[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #ifdef MC3HIP_STAMPS
-        alive = wait_rows<2, LM>(addr, val, ctl_rw, &ta14);
+        alive = poll_ring<KR, LM>(addr, ring, val, ctl_rw, &ta14);
 #else
-        alive = wait_rows<2, LM>(addr, val, ctl_rw);
+        alive = poll_ring<KR, LM>(addr, ring, val, ctl_rw);
 #endif
-        // Tell the compiler's wait-count bookkeeping that nothing is pending on EITHER way
-        // out of the poll loop (it merges the paths): otherwise it guards the registers
-        // of the polls with waits at the loop latch, and those stall on the acknowledgement
-        // of the row just published (loads and stores share the counter on gfx9).
-        __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0), already true
         MC3_TICK(tk1);
-        if (!alive)
+        if (__builtin_expect(!alive, 0))
             break;
         // proposal and boundaries, chain.py:232-243
         const double jump_k = gamma * (val[0] - val[1]) + feps * 0.0;
         const double npk = xk + jump_k;
         const bool outk = mine && (npk < pmin_k || npk > pmax_k);
-        if (!__any(outk)) {
+        if (__builtin_expect(!__any(outk), 1)) {
             Model<MT> model;
             model.init_from_lanes(P, npk);
             const double nextchisq =
@@ -1429,7 +1496,7 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
             const double ratio = mc3_det_exp(0.5 * (cur - nextchisq)) * 1.0;
             const bool acc = ratio > u_now;                          // chain.py:257-274
             xk = acc ? npk : xk;
-            if (__any(acc && nextchisq < best)) {
+            if (__builtin_expect(__any(acc && nextchisq < best), 0)) {
                 best = nextchisq;
                 if (mine)
                     P.bestx[(size_t)lc * NF + lane] = xk;
@@ -1451,50 +1518,37 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
         }
         tk_prev3 = tk3;
 #endif
-        // Z append, chain.py:276-289: publish the row, then the bookkeeping columns
+        // Every poll has long returned.  Saying so here keeps the compiler's wait-count
+        // bookkeeping from guarding the poll registers at the loop latch, where a wait would
+        // stall on the acknowledgement of the row about to be published (loads and stores
+        // share the counter on gfx9).
+        __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0), already true
+        // Z append, chain.py:276-289: publish the row ...
         if constexpr (P2P) {
             const size_t zoff = (size_t)(zblock - P.Z) + (size_t)c * ZS + lane;
-            const size_t roff = (size_t)(lp_row - P.log_post);
-            for (int pr = 0; pr < P.npeers; ++pr) {
-                if (mine)
+            if (mine)
+                for (int pr = 0; pr < P.npeers; ++pr)                // ... into every replica
                     __hip_atomic_store(&P.peerZ[pr][zoff], xk, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_SYSTEM);
-                if (lane == 0)
-                    __hip_atomic_store(&P.peerLP[pr][roff], -0.5 * cur, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            if (lane == 0)
-                *zc_row = c;
         } else {
             if (mine)
                 __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);        // publish (sc1)
-            const int slot = (int)(R - R0) & 63;
-            lpbuf = (lane == slot) ? -0.5 * cur : lpbuf;
-            if (slot == 63) {
-                lp_row[(size_t)lane * n] = lpbuf;
-                zc_row[(size_t)lane * n] = c;
-                lp_row += (size_t)64 * n;
-                zc_row += (size_t)64 * n;
-            }
+        }
+        // ... and park the bookkeeping columns
+        const int slot = (int)(R - R0) & 63;
+        lpbuf = (lane == slot) ? -0.5 * cur : lpbuf;
+        if (__builtin_expect(slot == 63, 0)) {
+            flush_columns(64);
+            lp_row += (size_t)64 * n;
+            zc_row += (size_t)64 * n;
         }
         pbase = zblock;
         zblock += blockstride;
-        if constexpr (P2P) {
-            lp_row += n;
-            zc_row += n;
-        }
         MC3_TICK(tk_prevend);
         rdone = R + 1;
     }
-    if constexpr (!P2P) {
-        // the unwritten tail of the bookkeeping columns (also after an early exit)
-        const int left = (int)(rdone - R0) & 63;
-        if (lane < left) {
-            lp_row[(size_t)lane * n] = lpbuf;
-            zc_row[(size_t)lane * n] = c;
-        }
-    }
+    flush_columns((int)(rdone - R0) & 63);       // the unwritten tail (also after an early exit)
     if (mine)
         P.X[(size_t)lc * NF + lane] = xk;
     if (lane == 0) {
