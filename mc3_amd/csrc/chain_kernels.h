@@ -774,13 +774,17 @@ __device__ __forceinline__ bool wait_rows(const double *const (&addr)[NVAL], dou
     for (unsigned spins = 0;; ++spins) {
         if (nspin && spins)
             *nspin += 1;                      // diagnostic build: polls beyond the first
-        bool ready = true;
+        bool pend[NVAL];
+        bool any_pending = false;
 #pragma unroll
-        for (int q = 0; q < NVAL; ++q)
-            ready &= mc3_bits(val[q]) != ROW_PENDING;
-        if (__all(ready))
+        for (int q = 0; q < NVAL; ++q) {
+            pend[q] = __any(mc3_bits(val[q]) == ROW_PENDING);
+            any_pending |= pend[q];
+        }
+        if (!any_pending)
             return true;
-        __builtin_amdgcn_s_sleep(1);
+        // (no pause, and only the rows still missing are asked for again: every extra request
+        // on the fabric and every cycle of back-off measurably slows the hand-off)
         if (__builtin_expect((spins & 1023u) == 1023u, 0)) {
             // (made wave-uniform by hand: a per-lane load would make this exit, and with it
             // every value live across the chain loop, divergent in the compiler's eyes)
@@ -798,7 +802,8 @@ __device__ __forceinline__ bool wait_rows(const double *const (&addr)[NVAL], dou
         }
 #pragma unroll
         for (int q = 0; q < NVAL; ++q)
-            val[q] = load_published<SYS>(addr[q]);
+            if (pend[q])
+                val[q] = load_published<SYS>(addr[q]);
     }
 }
 
