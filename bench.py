@@ -243,7 +243,7 @@ def main():
             (' + one RCCL all-gather per refresh' if multi else
              f' (hipGraph of {gpu.plan["graph_nodes"]} nodes)')
     traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'r01f_c2_pmc.json')
+    pmc = os.path.join(ROOT, 'profiles', 'r01g_c2_pmc.json')
     if os.path.exists(pmc) and args.thinning == 1 and world == 1:
         with open(pmc) as f:
             rec = json.load(f)
@@ -287,7 +287,7 @@ def main():
                     'stream over the timed region / launches). x/data/uncert are '
                     'chain-invariant: they live in registers for a whole launch, so '
                     'hardware HBM traffic (traffic: bytes per launch from '
-                    'profiles/r01f_c2_pmc.json, FETCH_SIZE doubled per the gfx950 note) '
+                    'profiles/r01g_c2_pmc.json, FETCH_SIZE doubled per the gfx950 note) '
                     'is far below the algorithmic figure',
         },
     }
