@@ -876,6 +876,55 @@ __device__ __forceinline__ Draws make_draws(const DevProblem &P, uint64_t iter, 
     return D;
 }
 
+// The same draws for 21 consecutive iterations at once, on the vector unit: lane
+// 3*(iter - base) + slot holds the four words of (iter, chain, slot).  The scalar Philox
+// of make_draws costs a wave ~350 issue slots per call; it is free only while the wave
+// waits for memory anyway.  Where nothing is left to wait for (persistent snooker, whose
+// rows are requested an iteration ahead) a batch costs ~50 cycles per iteration instead.
+struct DrawBatch {
+    uint32_t w0, w1, w2, w3;
+    long long base;
+};
+constexpr int DRAW_BATCH = 21;
+
+__device__ __forceinline__ void fill_draws(DrawBatch &B, const DevProblem &P, long long iter0,
+                                           int c)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    const uint64_t it = (uint64_t)iter0 + (uint64_t)(lane / 3u);
+    uint32_t w[4];
+    philox4x32_10((uint32_t)it, (uint32_t)(it >> 32), (uint32_t)c, lane % 3u, (uint32_t)P.seed,
+                  (uint32_t)(P.seed >> 32), w);
+    B.w0 = w[0];
+    B.w1 = w[1];
+    B.w2 = w[2];
+    B.w3 = w[3];
+    B.base = iter0;
+}
+
+__device__ __forceinline__ Draw2 batch_draw(const DrawBatch &B, int l)
+{
+    Draw2 d;
+    d.q0 = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)B.w0, l) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)B.w1, l) << 32);
+    d.q1 = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)B.w2, l) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)B.w3, l) << 32);
+    return d;
+}
+
+__device__ __forceinline__ Draws get_draws(DrawBatch &B, const DevProblem &P, long long iter,
+                                           int c)
+{
+    if (iter < B.base || iter >= B.base + DRAW_BATCH)
+        fill_draws(B, P, iter, c);
+    const int l = 3 * (int)(iter - B.base);
+    Draws D;
+    D.d0 = batch_draw(B, l);
+    D.d1 = batch_draw(B, l + 1);
+    D.d2 = batch_draw(B, l + 2);
+    return D;
+}
+
 // DEMC partners, chain.py:221-232: r1 != c, r2 != c, r2 != r1, from the two 32-bit
 // halves of one draw
 __device__ __forceinline__ void demc_partners(uint64_t q0, int n, int c, int &r1, int &r2)
@@ -975,6 +1024,35 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     // are in flight.
     Draws nxt = make_draws(P, (TH == 1) ? (uint64_t)R0 : (uint64_t)(R0 * P.thinning + jb), c,
                            sampler);
+    // Persistent snooker: the three Z rows of an iteration (chain.py:195-205) come from the
+    // whole history, almost always rows published long ago, so they are requested one
+    // iteration ahead -- as soon as the previous iteration's rows have been consumed -- and
+    // the fabric round trip hides behind the chisq.  A row of the newest refresh may still
+    // be the sentinel when it is looked at; the usual poll loop then asks again.
+    const double *sa[3] = {nullptr, nullptr, nullptr};
+    double sv[3] = {0.0, 0.0, 0.0};
+    auto request_snooker = [&](const Draws &D, long long zsz) {
+        const long long iR1 = (long long)bounded(D.d0.q0, (uint64_t)zsz);
+        long long iR2 = 1 + (long long)bounded(D.d0.q1, (uint64_t)(zsz - 1));
+        if (iR2 == iR1)
+            iR2 = 0;
+        const long long iz = (long long)bounded(D.d1.q1, (uint64_t)zsz);
+        const int kk = mine ? lane : 0;
+        sa[0] = P.Z + (size_t)iR1 * zs + kk;
+        sa[1] = P.Z + (size_t)iR2 * zs + kk;
+        sa[2] = P.Z + (size_t)iz * zs + kk;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            sv[q] = load_published<P2P>(sa[q]);
+    };
+    constexpr bool SNOOKER_AHEAD = PERSIST && (SMP < 0 || SMP == MC3HIP_SNOOKER);
+    DrawBatch batch;
+    batch.w0 = batch.w1 = batch.w2 = batch.w3 = 0u;
+    batch.base = -(long long)DRAW_BATCH - 1;      // empty
+    if constexpr (SNOOKER_AHEAD) {
+        if (sampler == MC3HIP_SNOOKER && wave0)
+            request_snooker(nxt, P.M0 + R0 * P.nchains);
+    }
     // diagnostic build only: per-phase tick sums kept in registers, stored once at exit
     unsigned long long tk_prev3 = 0, tk_prevend = 0;
     unsigned long long ta8 = 0, ta9 = 0, ta10 = 0, ta11 = 0, ta12 = 0, ta13 = 0, ta14 = 0, ta15 = 0;
@@ -1034,28 +1112,20 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 const long long iz = (long long)bounded(d1.q1, (uint64_t)zsize);
                 double z1 = 0.0, z2 = 0.0;
                 if constexpr (PERSIST) {
-                    const int kk = mine ? lane : 0;
-                    const double *const addr[3] = {P.Z + (size_t)iR1 * zs + kk,
-                                                   P.Z + (size_t)iR2 * zs + kk,
-                                                   P.Z + (size_t)iz * zs + kk};
-                    double val[3];
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        val[q] = load_published<P2P>(addr[q]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    nxt = make_draws(P, iter + 1, c, sampler);
-                    pin_scalar(nxt.d0.q0);
-                    pin_scalar(nxt.d0.q1);
-                    pin_scalar(nxt.d1.q0);
-                    pin_scalar(nxt.d1.q1);
-                    pin_scalar(nxt.d2.q0);
-                    pin_scalar(nxt.d2.q1);
-                    __builtin_amdgcn_sched_barrier(0);
+                    // requested during the previous iteration (request_snooker)
+                    const double *const addr[3] = {sa[0], sa[1], sa[2]};
+                    double val[3] = {sv[0], sv[1], sv[2]};
+                    nxt = get_draws(batch, P, (long long)iter + 1, c);
                     alive = wait_rows<3, P2P>(addr, val, ctl_rw);
                     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see lean_demc_kernel
                     z1 = val[0];
                     z2 = val[1];
                     zk = val[2];
+                    // the next iteration's rows: its history also holds this refresh's rows
+                    // once this iteration is the last of the refresh
+                    if (alive)
+                        request_snooker(nxt, (TH == 1 || j + 1 == jlast) ? zsize + P.nchains
+                                                                         : zsize);
                 } else {
                     z1 = mine ? P.Z[(size_t)iR1 * zs + lane] : 0.0;
                     z2 = mine ? P.Z[(size_t)iR2 * zs + lane] : 0.0;
@@ -1238,6 +1308,12 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 P.trace_chisq[trow * P.nlocal + lc] = nextchisq;
                 P.trace_flag[trow * P.nlocal + lc] = flags;
             }
+        }
+        if constexpr (SNOOKER_AHEAD) {
+            // the rows requested ahead have long arrived: saying so before the publish keeps
+            // the wait for them from landing behind the stores (see lean_demc_kernel)
+            if (sampler == MC3HIP_SNOOKER)
+                __builtin_amdgcn_s_waitcnt(0x0F70);
         }
         if constexpr (!FAST)
             block_sync<WPC>();
