@@ -445,6 +445,7 @@ __device__ double block_wavelet(const DevProblem &P, const double *s_nextp, doub
         }
     }
     block_sync<WPC>();
+    MC3_STAMP(8);
     double acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -490,6 +491,7 @@ __device__ double block_wavelet(const DevProblem &P, const double *s_nextp, doub
             }
         }
         block_sync<WPC>();
+        MC3_STAMP(9);
         double *dst = bufB;
         double *cur = bufA;
         for (int nn = nh; nn >= 4; nn >>= 1) {
@@ -512,10 +514,15 @@ __device__ double block_wavelet(const DevProblem &P, const double *s_nextp, doub
                 }
             }
             block_sync<WPC>();
+            if (nn == nh)
+                MC3_STAMP(10);
+            if (nn == 2048)
+                MC3_STAMP(11);
             double *t = cur;
             cur = dst;
             dst = t;
         }
+        MC3_STAMP(12);
         src = cur;
     } else {
         if (threadIdx.x < 2) {
@@ -528,6 +535,7 @@ __device__ double block_wavelet(const DevProblem &P, const double *s_nextp, doub
     const double a0 = src[0], a1 = src[1];
     const double T = lane_tree<WPC>(acc, s_part);
     sawinf = block_or<WPC>(sawinf, s_flag);
+    MC3_STAMP(13);
     if (sawinf)
         return mc3_from_bits(0x7ff0000000000000ull);
     if (threadIdx.x >= 64)
