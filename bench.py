@@ -152,6 +152,13 @@ def main():
 
     from mc3_amd import engine, parallel
 
+    if world > 1:
+        # a multi-rank run that stops making progress must not hang the node: dump every
+        # thread's stack and exit after MC3HIP_BENCH_WATCHDOG seconds (default 900)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ.get('MC3HIP_BENCH_WATCHDOG', 900)),
+                                          exit=True)
+
     nchains = CHAINS_PER_GPU*world
     nrefresh = args.steps + args.warmup
     prob = c2_problem(nchains, nrefresh + 64, args.thinning)

@@ -808,10 +808,19 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
     if (pr->flags & MC3HIP_FLAG_P2P) {
         // replicas other GPUs store into while kernels run: fine-grained (coherent at
         // system scope), own allocations so that they can be exported through IPC
+        // Opening the IPC handle of an allocation of 2 GiB <= size < 4 GiB from another
+        // process never returned (ROCm 7.2, dmabuf IPC; 1.9, 4.0 and 5.0 GiB are fine), so
+        // such a replica is rounded up to 4 GiB.
+        auto ipc_safe = [](size_t bytes) {
+            return (bytes >= (size_t(1) << 31) && bytes < (size_t(1) << 32)) ? (size_t(1) << 32)
+                                                                             : bytes;
+        };
         void *pz = nullptr, *pl = nullptr;
-        HIP_TRY_C(hipExtMallocWithFlags(&pz, zl * zs * sizeof(double), hipDeviceMallocFinegrained));
+        HIP_TRY_C(hipExtMallocWithFlags(&pz, ipc_safe(zl * zs * sizeof(double)),
+                                        hipDeviceMallocFinegrained));
         c->allocs.push_back(pz);
-        HIP_TRY_C(hipExtMallocWithFlags(&pl, zl * sizeof(double), hipDeviceMallocFinegrained));
+        HIP_TRY_C(hipExtMallocWithFlags(&pl, ipc_safe(zl * sizeof(double)),
+                                        hipDeviceMallocFinegrained));
         c->allocs.push_back(pl);
         P.Z = static_cast<double *>(pz);
         P.log_post = static_cast<double *>(pl);
@@ -1628,10 +1637,17 @@ int mc3hip_p2p_attach(mc3hip_ctx *c, int32_t rank, int32_t nranks, const void *a
             continue;
         }
         void *z = nullptr, *l = nullptr;
+        const bool dbg = getenv("MC3HIP_DEBUG") != nullptr;
+        if (dbg)
+            fprintf(stderr, "[mc3hip rank %d] opening Z of rank %d\n", rank, r);
         HIP_TRY(hipIpcOpenMemHandle(&z, h[2 * r], hipIpcMemLazyEnablePeerAccess));
         c->p2p_opened.push_back(z);
+        if (dbg)
+            fprintf(stderr, "[mc3hip rank %d] opening log_post of rank %d\n", rank, r);
         HIP_TRY(hipIpcOpenMemHandle(&l, h[2 * r + 1], hipIpcMemLazyEnablePeerAccess));
         c->p2p_opened.push_back(l);
+        if (dbg)
+            fprintf(stderr, "[mc3hip rank %d] opened rank %d\n", rank, r);
         pz[r] = static_cast<double *>(z);
         pl[r] = static_cast<double *>(l);
     }

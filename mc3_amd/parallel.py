@@ -102,11 +102,17 @@ class TorchDistComm:
             if self._all_ok(ok):
                 handles = [None]*self.size
                 self.dist.all_gather_object(handles, handle, group=self.group)
-                try:
-                    engine.p2p_attach(self.rank, handles)
-                    ok = True
-                except Exception:
-                    ok = False
+                # One rank at a time: concurrent hipIpcOpenMemHandle calls from several
+                # processes have been seen to block each other forever (4 ranks on one
+                # device, ROCm 7.2); the opens are a few milliseconds each.
+                ok = True
+                for turn in range(self.size):
+                    if turn == self.rank:
+                        try:
+                            engine.p2p_attach(self.rank, handles)
+                        except Exception:
+                            ok = False
+                    self.dist.barrier(group=self.group)
                 if self._all_ok(ok):
                     self.dist.barrier(group=self.group)   # every replica is ready
                     self.native = True
