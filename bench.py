@@ -4,9 +4,12 @@
 Workload (BASELINE.json configs[1], "C2"): quadratic 3-parameter fit,
 ndata=1000, 256 chains per GPU, sampler='demc', thinning=1, fepsilon=0,
 synthetic data as in examples/tutorial.py:22-46 of the reference (SURVEY.md
-section 8d).  A "step" is one Z refresh: every chain of the ensemble advances
-`thinning` iterations (proposal -> model -> chisq -> Metropolis -> Z append) in
-one launch of the fused step kernel.
+section 8d).  A "step" is one batch of `--refreshes` Z refreshes (default 16 384 =
+one launch of the persistent kernel, 4.19 M chain-steps per GPU): in every refresh
+every chain of the ensemble advances `thinning` iterations (proposal -> model ->
+chisq -> Metropolis -> Z append).  Whatever --steps/--warmup are given, a step is
+long against launch and synchronisation overheads; the batch shrinks only when Z
+(128 B per chain and refresh) would not fit a 24 GiB budget.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
@@ -123,8 +126,11 @@ def cpu_baseline(target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=49152)      # 3 launches of 16384 refreshes
-    ap.add_argument('--warmup', type=int, default=16384)     # 1 launch of the same size
+    ap.add_argument('--steps', type=int, default=3)          # timed batches of Z refreshes
+    ap.add_argument('--warmup', type=int, default=1)         # untimed batches of the same size
+    ap.add_argument('--refreshes', type=int, default=0,
+                    help='Z refreshes per step (default 16384 = one persistent launch; '
+                         'fewer when (steps+warmup) batches of Z would exceed 24 GiB)')
     ap.add_argument('--thinning', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -160,7 +166,11 @@ def main():
                                           exit=True)
 
     nchains = CHAINS_PER_GPU*world
-    nrefresh = args.steps + args.warmup
+    nbatch = max(1, args.steps) + max(0, args.warmup)
+    row_bytes = nchains*(16*8 + 8 + 4)            # padded Z row + log_post + zchain
+    R = args.refreshes or int(max(64, min(16384, (24 << 30)//(row_bytes*nbatch))))
+    nref_timed, nref_warm = max(1, args.steps)*R, max(0, args.warmup)*R
+    nrefresh = nref_timed + nref_warm
     prob = c2_problem(nchains, nrefresh + 64, args.thinning)
     comm = None
     exchange = None
@@ -207,10 +217,11 @@ def main():
             torch.cuda.synchronize(local_rank)
             dist.barrier()          # with peer-to-peer stores: every peer has finished too
 
-    gpu.run(args.warmup)
+    if nref_warm:
+        gpu.run(nref_warm)
     barrier()
     t0 = time.perf_counter()
-    gpu.run(args.steps, sync=False)
+    gpu.run(nref_timed, sync=False)
     barrier()
     dt = time.perf_counter() - t0
     gpu_ms = gpu.last_run_ms()          # HIP events on the library's stream
@@ -230,7 +241,7 @@ def main():
         consistent = bool(all(d == box[0] for d in box) and np.all(np.isfinite(Zt)))
     st = gpu.state()
     accept = float(st['numaccept'].sum())/(CHAINS_PER_GPU*gpu.refresh_done*args.thinning)
-    chain_steps = nchains*args.steps*args.thinning
+    chain_steps = nchains*nref_timed*args.thinning
     value = chain_steps/dt/1e6
 
     # roofline of the dominant (only) kernel.  Persistent path: one launch covers
@@ -238,13 +249,13 @@ def main():
     multi = world > 1 or force_comm
     per = gpu.plan['persistent'] if (not multi or exchange == 'p2p') else 0
     if per > 0:
-        launches = -(-args.steps//per)
+        launches = -(-nref_timed//per)
         kernel = {2: 'mc3hip::lean_demc_kernel', 1: 'mc3hip::persist_fast_kernel',
                   0: 'mc3hip::persist_kernel'}[gpu.plan['fast']]
         structure = (f'persistent kernel, {per} refreshes per launch, Z rows handed '
                      'between workgroups in-launch')
     else:
-        launches = args.steps
+        launches = nref_timed
         kernel = 'mc3hip::step_kernel'
         structure = 'one launch per refresh' + \
             (' + one RCCL all-gather per refresh' if multi else
@@ -257,21 +268,24 @@ def main():
         if rec['kernel'].startswith(kernel):
             # HBM bytes per launch from the PMC counters of the same kernel
             # (separate rocprofv3 --pmc passes, gfx950 FETCH_SIZE correction)
-            traffic = rec['hbm_bytes_per_chain_step']*CHAINS_PER_GPU*args.steps/launches
+            traffic = rec['hbm_bytes_per_chain_step']*CHAINS_PER_GPU*nref_timed/launches
     launch_s = gpu_ms*1e-3/launches
-    bytes_per_launch = BYTES_PER_CHAIN_STEP*CHAINS_PER_GPU*args.thinning*args.steps/launches
+    bytes_per_launch = BYTES_PER_CHAIN_STEP*CHAINS_PER_GPU*args.thinning*nref_timed/launches
     achieved = bytes_per_launch/launch_s/1e9
     out = {
         'metric': METRIC,
         'value': value, 'unit': 'million chain-steps/sec',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': dt*1e3/args.steps, 'higher_is_better': True,
+        'n_gpus': world, 'steps': max(1, args.steps), 'warmup': max(0, args.warmup),
+        'ms_per_step': dt*1e3/max(1, args.steps), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
         'data': 'synthetic',
         'config': {
             'workload': 'C2: quadratic 3-param fit, ndata=1000, 256 chains/GPU, '
                         "sampler='demc', fepsilon=0",
             'nchains': nchains, 'ndata': NDATA, 'thinning': args.thinning,
+            'step': f'{R} Z refreshes of all {nchains} chains = {nchains*R*args.thinning} '
+                    'chain-steps',
+            'refreshes_per_step': R,
             'chains_per_gpu': CHAINS_PER_GPU,
             'parallelism': f'chains sharded x{world}' if world > 1 else 'single GPU',
             'collective': {None: None, 'rccl': 'one in-place RCCL all-gather of new Z rows per '

@@ -808,12 +808,12 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
     if (pr->flags & MC3HIP_FLAG_P2P) {
         // replicas other GPUs store into while kernels run: fine-grained (coherent at
         // system scope), own allocations so that they can be exported through IPC
-        // Opening the IPC handle of an allocation of 2 GiB <= size < 4 GiB from another
-        // process never returned (ROCm 7.2, dmabuf IPC; 1.9, 4.0 and 5.0 GiB are fine), so
-        // such a replica is rounded up to 4 GiB.
+        // Opening the IPC handle of an allocation whose size has bit 31 set (2..4 GiB,
+        // 6..8 GiB, ...) from another process never returned (ROCm 7.2, dmabuf IPC: 2.5, 3.1
+        // and 6.0 GiB hang; 1.9, 4.0 and 5.0 GiB are fine), so such a replica is rounded up to
+        // the next multiple of 4 GiB.
         auto ipc_safe = [](size_t bytes) {
-            return (bytes >= (size_t(1) << 31) && bytes < (size_t(1) << 32)) ? (size_t(1) << 32)
-                                                                             : bytes;
+            return (bytes & (size_t(1) << 31)) ? ((bytes >> 32) + 1) << 32 : bytes;
         };
         void *pz = nullptr, *pl = nullptr;
         HIP_TRY_C(hipExtMallocWithFlags(&pz, ipc_safe(zl * zs * sizeof(double)),
