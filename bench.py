@@ -312,14 +312,21 @@ def main():
                     'is far below the algorithmic figure',
         },
     }
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline()
     gpu.close()
     if world > 1 or force_comm:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line goes out last, behind anything native libraries (RCCL's version
+        # banner) still hold in the C stdio buffer
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':
