@@ -55,6 +55,14 @@ ITERS['c5'] = 300
 
 def main():
     names = sys.argv[1:] or ['c2', 'c2snooker', 'c3one', 'c4', 'c5']
+    if len(names) > 1:
+        # one fresh process per configuration: after the multi-GB allocations of an earlier
+        # configuration have been freed, the streaming kernels of C5 were seen to run 2-3x
+        # slower in the same process (placement of the new allocations)
+        import subprocess
+        for name in names:
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), name])
+        return
     for name in names:
         n = ITERS[name]
         prob, extra = CONFIGS[name](n + max(2, n//10))
