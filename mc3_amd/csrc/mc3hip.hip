@@ -875,20 +875,14 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
     HIP_TRY_C(hipMemset(c->ctl, 0, 4 * sizeof(long long)));
     // all-ones = "row not written yet" (the persistent kernel's hand-off sentinel)
     HIP_TRY_C(hipMemset(P.Z, 0xff, zl * zs * sizeof(double)));
-#if defined(MC3HIP_MBOX_STRIDE) && MC3HIP_MBOX_STRIDE
-    {
-        const size_t nmb = (size_t)(zl - P.M0 + P.nchains) * MC3HIP_MBOX_STRIDE;
-        void *pm = nullptr;
-        HIP_TRY_C(hipMalloc(&pm, nmb * sizeof(double)));
-        HIP_TRY_C(hipMemset(pm, 0xff, nmb * sizeof(double)));
-        P.mbox = static_cast<double *>(pm);
-    }
-#endif
     HIP_TRY_C(hipMemset(P.log_post, 0, zl * sizeof(double)));
     HIP_TRY_C(hipMemset(P.zchain, 0xff, zl * sizeof(int32_t)));      // -1, mcmc_driver.py:170
     HIP_TRY_C(hipMemset(P.numaccept, 0, nl * sizeof(long long)));
     HIP_TRY_C(hipMemset(P.outbounds, 0, nf * sizeof(unsigned long long)));
     HIP_TRY_C(hipMemset(P.bestx, 0, nl * nf * sizeof(double)));
+    // the fills ran on the null stream; everything else runs on c->stream, which does not
+    // synchronise with it
+    HIP_TRY_C(hipDeviceSynchronize());
     TRY(dev_alloc(c, &c->model_out, nd));
 
     if (pr->model_kind == MC3HIP_MODEL_LINEAR)
