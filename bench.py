@@ -126,8 +126,8 @@ def cpu_baseline(target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)          # timed batches of Z refreshes
-    ap.add_argument('--warmup', type=int, default=1)         # untimed batches of the same size
+    ap.add_argument('--steps', type=int, default=12)         # timed batches of Z refreshes
+    ap.add_argument('--warmup', type=int, default=2)         # untimed batches of the same size
     ap.add_argument('--refreshes', type=int, default=0,
                     help='Z refreshes per step (default 16384 = one persistent launch; '
                          'fewer when (steps+warmup) batches of Z would exceed 24 GiB)')
