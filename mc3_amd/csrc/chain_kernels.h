@@ -1529,13 +1529,7 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
         __builtin_amdgcn_s_sleep(1);
         const double *const addr[2] = {pbase + off1, pbase + off2};
         double val[2];
-#ifndef MC3HIP_POLL_RING
-#define MC3HIP_POLL_RING 1       // polls kept in flight (experiments: see poll_ring)
-#endif
-#ifndef MC3HIP_RING_SLEEP
-#define MC3HIP_RING_SLEEP 4
-#endif
-        constexpr int KR = MC3HIP_POLL_RING;
+        constexpr int KR = 1;            // polls kept in flight: more measured slower (poll_ring)
         double ring[KR][2];
         ring[0][0] = load_published<LM>(addr[0]);
         ring[0][1] = load_published<LM>(addr[1]);
@@ -1556,14 +1550,6 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
         off2 = r2 * ZS + kk;
         asm volatile("; pin" : "+v"(u), "+v"(off1), "+v"(off2));
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 1; q < KR; ++q) {
-            if (q > 1)
-                __builtin_amdgcn_s_sleep(MC3HIP_RING_SLEEP);
-            ring[q][0] = load_published<LM>(addr[0]);
-            ring[q][1] = load_published<LM>(addr[1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
 #ifdef MC3HIP_STAMPS
         alive = poll_ring<KR, LM>(addr, ring, val, ctl_rw, &ta14);
 #else
