@@ -853,10 +853,30 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         TRY(dev_alloc(c, &P.sc_flag, nl));
         TRY(dev_alloc(c, &P.sc_part, nl * (size_t)P.ntiles));
         c->tile_kmax = pr->nmodel <= 4 ? 4 : pr->nmodel <= 8 ? 8 : pr->nmodel <= 12 ? 12 : 16;
-        // chains per workgroup column: aim at two waves of workgroups over the CUs
-        int cb = (int)((nl * (size_t)P.ntiles + 511) / 512);
-        cb = (cb + 15) / 16 * 16;
-        c->tile_chain_block = cb < 16 ? 16 : cb;
+        // chains per workgroup column (a multiple of the 16-chain block): one workgroup fits
+        // a CU (128 KiB of LDS), so the kernel runs in rounds of `CUs` workgroups; pick the
+        // column height with the fewest (rounds x blocks per workgroup), the tile load
+        // counted as a fifth of a block.  C5: 49 tiles x 512 chains -> 112 chains per column,
+        // 245 workgroups, one round of 7 blocks instead of two rounds of 4.
+        int cus = 256;
+        {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, c->device) == hipSuccess &&
+                prop.multiProcessorCount > 0)
+                cus = prop.multiProcessorCount;
+        }
+        int best_cb = 16;
+        double best_cost = 1e300;
+        for (int cb = 16; cb <= (int)((nl + 15) / 16 * 16); cb += 16) {
+            const long long ncol = ((long long)nl + cb - 1) / cb;
+            const long long rounds = ((long long)P.ntiles * ncol + cus - 1) / cus;
+            const double cost = (double)rounds * (cb / 16 + 0.2);
+            if (cost < best_cost) {
+                best_cost = cost;
+                best_cb = cb;
+            }
+        }
+        c->tile_chain_block = best_cb;
     }
     P.test_abort = -1;
     if (const char *ta = getenv("MC3HIP_TEST_ABORT_AT"))
