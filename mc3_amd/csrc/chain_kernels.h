@@ -1011,7 +1011,9 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     const int jfree = mine ? P.ifree[lane] : 0;
     const double pmin_k = mine ? P.fmin[lane] : 0.0;
     const double pmax_k = mine ? P.fmax[lane] : 0.0;
-    const bool need_normal = !FAST && ((sampler == MC3HIP_MRW) || (P.fepsilon != 0.0));
+    // (the lean instance has no support distribution, fepsilon = 0; its MRW flavour draws)
+    const bool need_normal = FAST ? (SMP == MC3HIP_MRW)
+                                  : ((sampler == MC3HIP_MRW) || (P.fepsilon != 0.0));
     const double pstep_k = (mine && need_normal) ? P.fstep[lane] : 0.0;
     const double fixed0 = (!FAST && wave0 && lane < P.nparams) ? P.params[lane] : 0.0;
     const double fixed1 = (!FAST && wave0 && lane + 64 < P.nparams) ? P.params[lane + 64] : 0.0;

@@ -327,7 +327,8 @@ bool fast_eligible(const mc3hip_ctx *c)
     return c->wpc == 1 && !P.wlike && P.ndata <= VLANES && c->mt >= 2 && c->mt <= 4 &&
            P.nparams == P.nfree && P.nmodel == P.nparams && P.nshare == 0 &&
            P.ngprior == 0 && P.fepsilon == 0.0 && P.trace_iters == 0 &&
-           (P.sampler == MC3HIP_DEMC || P.sampler == MC3HIP_SNOOKER) &&
+           (P.sampler == MC3HIP_DEMC || P.sampler == MC3HIP_SNOOKER ||
+            P.sampler == MC3HIP_MRW) &&
            !getenv("MC3HIP_NO_FAST");
 }
 
@@ -353,6 +354,13 @@ template <int MT>
 void launch_fast_t(mc3hip_ctx *c, int nref)
 {
     const bool demc = c->P.sampler == MC3HIP_DEMC;
+    if (c->P.sampler == MC3HIP_MRW) {
+        if (c->p2p_ranks > 1)
+            launch_fast_tt<MT, MC3HIP_MRW, true>(c, nref);
+        else
+            launch_fast_tt<MT, MC3HIP_MRW, false>(c, nref);
+        return;
+    }
     if (lean_demc_eligible(c)) {
         if (c->p2p_ranks > 1)
             hipLaunchKernelGGL((lean_demc_kernel<MT, true>), dim3(c->P.nlocal), dim3(64), 0,
@@ -392,6 +400,9 @@ int fast_blocks_per_cu_t(mc3hip_ctx *c)
     hipError_t e = (c->P.sampler == MC3HIP_DEMC)
         ? hipOccupancyMaxActiveBlocksPerMultiprocessor(
               &nb, persist_fast_kernel<MT, MC3HIP_DEMC, true, 0>, 64, c->smem)
+        : (c->P.sampler == MC3HIP_MRW)
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(
+              &nb, persist_fast_kernel<MT, MC3HIP_MRW, true, 0>, 64, c->smem)
         : hipOccupancyMaxActiveBlocksPerMultiprocessor(
               &nb, persist_fast_kernel<MT, MC3HIP_SNOOKER, true, 0>, 64, c->smem);
     if (e == hipSuccess && c->P.sampler == MC3HIP_DEMC) {
