@@ -139,6 +139,26 @@ struct Model {
                                     __builtin_amdgcn_readlane(__double2hiint(npk), j));
         }
     }
+    // (lane k holds FREE parameter k; coefficient j is free parameter kf[j], or -- kf[j] < 0
+    // -- the fixed value fx[j])
+    __device__ __forceinline__ void init_from_lanes(const DevProblem &P, double npk,
+                                                    const int (&kf)[MT >= 1 && MT <= 8 ? MT : 1],
+                                                    const double (&fx)[MT >= 1 && MT <= 8 ? MT : 1])
+    {
+        coef = nullptr;
+        indep = P.indep;
+        nmodel = P.nmodel;
+        ndata = P.npad;
+        if constexpr (MT >= 1 && MT <= 8) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int src = kf[j] < 0 ? 0 : kf[j];
+                const double v = make_double(__builtin_amdgcn_readlane(__double2loint(npk), src),
+                                             __builtin_amdgcn_readlane(__double2hiint(npk), src));
+                cf[j] = kf[j] < 0 ? fx[j] : v;
+            }
+        }
+    }
     // polynomial families at abscissa x (Horner, fused multiply-adds)
     __device__ __forceinline__ double at_x(double x) const
     {
@@ -933,6 +953,24 @@ __device__ __forceinline__ Draws get_draws(DrawBatch &B, const DevProblem &P, lo
     return D;
 }
 
+// coefficient j of a fully-polynomial parameter vector: the free parameter it is (kf[j]) or
+// its fixed value (fx[j], kf[j] = -1); wave-uniform, computed once per launch
+template <int MT>
+__device__ __forceinline__ void coefficient_map(const DevProblem &P, int (&kf)[MT], double (&fx)[MT])
+{
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        kf[j] = -1;
+        fx[j] = P.params[j];
+    }
+    for (int k = 0; k < P.nfree; ++k) {
+        const int j = P.ifree[k];
+#pragma unroll
+        for (int q = 0; q < MT; ++q)
+            kf[q] = (q == j) ? k : kf[q];
+    }
+}
+
 // DEMC partners, chain.py:221-232: r1 != c, r2 != c, r2 != r1, from the two 32-bit
 // halves of one draw
 __device__ __forceinline__ void demc_partners(uint64_t q0, int n, int c, int &r1, int &r2)
@@ -970,7 +1008,7 @@ __device__ __forceinline__ void demc_partners(uint64_t q0, int n, int c, int &r1
 // TH = 1: exactly one iteration per refresh (thinning = 1, the default), known at
 // compile time so that the inner loop and its control flow disappear.
 template <int WPC, int MT, bool WL, bool MULTI, bool PERSIST, int SMP = -1, bool FAST = false,
-          int PHASE = PH_FUSED, bool P2P = false, int TH = 0>
+          int PHASE = PH_FUSED, bool P2P = false, int TH = 0, bool FX = false>
 __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R0,
                                           const int nref, const int jb = 0, int je = -1)
 {
@@ -1020,6 +1058,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     long long nacc = 0;
     long long *ctl_rw = const_cast<long long *>(P.ctl);
     bool alive = true;
+
     if constexpr (PERSIST) {
         // a launch queued behind one that gave up must not run: its inputs are missing
         if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
@@ -1277,7 +1316,17 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
             flags |= 1;
             if constexpr (FAST) {
                 Model<MT> model;
-                model.init_from_lanes(P, npk);
+                if constexpr (!FX) {
+                    model.init_from_lanes(P, npk);             // every coefficient is free
+                } else {
+                    // FX: some coefficients are fixed (a separate instantiation, so that the
+                    // all-free kernels stay exactly as they were tuned)
+                    constexpr int NKF = (MT >= 1 && MT <= 8) ? MT : 1;
+                    int kf[NKF];
+                    double fx[NKF];
+                    coefficient_map<NKF>(P, kf, fx);
+                    model.init_from_lanes(P, npk, kf, fx);
+                }
                 nextchisq = block_gauss_model<WPC, MT, MULTI>(P, model, L.part, L.flag, tile);
             } else if constexpr (PHASE == PH_FINISH) {
                 nextchisq = finish_chisq<MT>(P, lc);
@@ -1421,10 +1470,10 @@ __global__ __launch_bounds__(64) void finish_kernel(const DevProblem P, const in
 
 // the lean instance (see run_chain): one wave per chain, MT free polynomial
 // coefficients, Gaussian chisq, ndata <= 1024, no priors/shared/fixed/epsilon/trace
-template <int MT, int SMP, bool P2P = false, int TH = 0>
+template <int MT, int SMP, bool P2P = false, int TH = 0, bool FX = false>
 __global__ __launch_bounds__(64) void persist_fast_kernel(const DevProblem P, const int nref)
 {
-    run_chain<1, MT, false, false, true, SMP, true, PH_FUSED, P2P, TH>(P, P.ctl[0], nref);
+    run_chain<1, MT, false, false, true, SMP, true, PH_FUSED, P2P, TH, FX>(P, P.ctl[0], nref);
 }
 
 // chisq for arbitrary parameter vectors (Chain.eval_model(ret='chisq'))
@@ -1433,23 +1482,23 @@ __global__ __launch_bounds__(64) void persist_fast_kernel(const DevProblem P, co
 // thinning = 1, persistent.  Same arithmetic and the same results as
 // run_chain<1, MT, false, false, true, MC3HIP_DEMC, true>; what differs is only how the
 // loop is laid out for ONE wave that nothing else on its SIMD hides latencies for:
-//   * every address is a pointer bumped by a constant per refresh (MT = nfree is a
-//     compile-time constant), no 64-bit index arithmetic in the loop;
+//   * every address is a pointer bumped by a constant per refresh (one 128-byte line per
+//     row), no 64-bit index arithmetic in the loop;
 //   * everything of refresh R+1 that does not depend on chain states -- Philox, the
 //     Metropolis draw, the partner indices and their byte offsets -- is computed in the
 //     shadow of refresh R's partner-row wait;
 //   * the Metropolis update is a select, not a branch; only the rare events (new best
 //     fit, out-of-bounds proposal, a failed wait) leave the straight line.
-template <int MT, bool P2P>
+template <int MT, bool P2P, bool FX = false>
 __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const int nref)
 {
-    constexpr int NF = MT;
+    const int nf = FX ? P.nfree : MT;        // FX: some coefficients are fixed (nfree < MT)
     constexpr int ZS = ZROW;                 // doubles per Z row: one 128-byte line (NF <= 16)
     constexpr int LM = P2P ? 1 : 0;
     const int lane = threadIdx.x;
     const int lc = blockIdx.x;
     const int c = P.chain0 + lc;
-    const bool mine = lane < NF;
+    const bool mine = lane < nf;
     const int kk = mine ? lane : 0;
     long long *ctl_rw = const_cast<long long *>(P.ctl);
     if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
@@ -1566,7 +1615,14 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
         const bool outk = mine && (npk < pmin_k || npk > pmax_k);
         if (__builtin_expect(!__any(outk), 1)) {
             Model<MT> model;
-            model.init_from_lanes(P, npk);
+            if constexpr (!FX) {
+                model.init_from_lanes(P, npk);                 // every coefficient is free
+            } else {
+                int kf[MT];                                    // FX: some are fixed
+                double fx[MT];
+                coefficient_map<MT>(P, kf, fx);
+                model.init_from_lanes(P, npk, kf, fx);
+            }
             const double nextchisq =
                 block_gauss_model<1, MT, false>(P, model, nullptr, nullptr, tile);   // chain.py:249
             MC3_TICK(tk2);
@@ -1576,7 +1632,7 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
             if (__builtin_expect(__any(acc && nextchisq < best), 0)) {
                 best = nextchisq;
                 if (mine)
-                    P.bestx[(size_t)lc * NF + lane] = xk;
+                    P.bestx[(size_t)lc * nf + lane] = xk;
                 if (lane == 0)
                     P.best_iter[lc] = R;
             }
@@ -1627,7 +1683,7 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
     }
     flush_columns((int)(rdone - R0) & 63);       // the unwritten tail (also after an early exit)
     if (mine)
-        P.X[(size_t)lc * NF + lane] = xk;
+        P.X[(size_t)lc * nf + lane] = xk;
     if (lane == 0) {
         P.chisq[lc] = cur;
         P.best_chisq[lc] = best;

@@ -324,8 +324,13 @@ void launch_refresh_tiled(mc3hip_ctx *c, int roff)
 bool fast_eligible(const mc3hip_ctx *c)
 {
     const DevProblem &P = c->P;
+    // (fixed coefficients are fine: the kernels map coefficient j to its free parameter or
+    // to its fixed value, chain_kernels.h coefficient_map)
+    // instantiated for one GPU and thinning = 1 only: FX of persist_fast_kernel)
+    const bool fixed_ok = P.nparams == P.nfree ||
+                          (P.nfree >= 1 && P.thinning == 1 && !(c->flags & MC3HIP_FLAG_P2P));
     return c->wpc == 1 && !P.wlike && P.ndata <= VLANES && c->mt >= 2 && c->mt <= 4 &&
-           P.nparams == P.nfree && P.nmodel == P.nparams && P.nshare == 0 &&
+           fixed_ok && P.nmodel == P.nparams && P.nshare == 0 &&
            P.ngprior == 0 && P.fepsilon == 0.0 && P.trace_iters == 0 &&
            (P.sampler == MC3HIP_DEMC || P.sampler == MC3HIP_SNOOKER ||
             P.sampler == MC3HIP_MRW) &&
@@ -335,6 +340,13 @@ bool fast_eligible(const mc3hip_ctx *c)
 template <int MT, int SMP, bool P2P>
 void launch_fast_tt(mc3hip_ctx *c, int nref)
 {
+    if constexpr (!P2P) {
+        if (c->P.nfree != c->P.nparams) {          // fixed coefficients (thinning = 1 only)
+            hipLaunchKernelGGL((persist_fast_kernel<MT, SMP, false, 1, true>),
+                               dim3(c->P.nlocal), dim3(64), c->smem, c->stream, c->P, nref);
+            return;
+        }
+    }
     if (c->P.thinning == 1)
         hipLaunchKernelGGL((persist_fast_kernel<MT, SMP, P2P, 1>), dim3(c->P.nlocal), dim3(64),
                            c->smem, c->stream, c->P, nref);
@@ -347,7 +359,7 @@ void launch_fast_tt(mc3hip_ctx *c, int nref)
 bool lean_demc_eligible(const mc3hip_ctx *c)
 {
     return c->fast && c->P.sampler == MC3HIP_DEMC && c->P.thinning == 1 &&
-           c->P.nfree == c->mt && c->P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
+           c->P.nparams == c->mt && c->P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
 }
 
 template <int MT>
@@ -365,6 +377,9 @@ void launch_fast_t(mc3hip_ctx *c, int nref)
         if (c->p2p_ranks > 1)
             hipLaunchKernelGGL((lean_demc_kernel<MT, true>), dim3(c->P.nlocal), dim3(64), 0,
                                c->stream, c->P, nref);
+        else if (c->P.nfree != c->P.nparams)
+            hipLaunchKernelGGL((lean_demc_kernel<MT, false, true>), dim3(c->P.nlocal), dim3(64),
+                               0, c->stream, c->P, nref);
         else
             hipLaunchKernelGGL((lean_demc_kernel<MT, false>), dim3(c->P.nlocal), dim3(64), 0,
                                c->stream, c->P, nref);

@@ -321,6 +321,20 @@ def test_persistent_kernel_many_chains(eng):
     gpu.close()
 
 
+@pytest.mark.parametrize('sampler', ['demc', 'snooker', 'mrw'])
+def test_lean_instances_with_a_fixed_coefficient(eng, sampler):
+    """A fixed polynomial coefficient (pstep = 0) keeps the problem on the lean persistent
+    instances (FX instantiations: coefficient j is a free parameter or a fixed value)."""
+    prob = H.quad_problem(ndata=500, nchains=64, nsamples=64*300, sampler=sampler)
+    prob['pstep'] = np.array(prob['pstep'], float)
+    prob['pstep'][1] = 0.0
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert gpu.nfree == 2
+    assert gpu.plan['persistent'] > 0 and gpu.plan['fast'] in (1, 2)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
 def test_headline_config_c2_matches_oracle(eng):
     """BASELINE config #2 (256 chains, ndata=1000, demc) for 400 iterations:
     bit-exact against the oracle, then properties at full length."""
