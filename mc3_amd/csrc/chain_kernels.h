@@ -1058,6 +1058,12 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     long long nacc = 0;
     long long *ctl_rw = const_cast<long long *>(P.ctl);
     bool alive = true;
+    constexpr int NKF = (FX && MT >= 1 && MT <= 8) ? MT : 1;
+    int kf[NKF];
+    double fx[NKF];
+    if constexpr (FX)
+        coefficient_map<NKF>(P, kf, fx);
+    (void)kf; (void)fx;
 
     if constexpr (PERSIST) {
         // a launch queued behind one that gave up must not run: its inputs are missing
@@ -1321,10 +1327,6 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 } else {
                     // FX: some coefficients are fixed (a separate instantiation, so that the
                     // all-free kernels stay exactly as they were tuned)
-                    constexpr int NKF = (MT >= 1 && MT <= 8) ? MT : 1;
-                    int kf[NKF];
-                    double fx[NKF];
-                    coefficient_map<NKF>(P, kf, fx);
                     model.init_from_lanes(P, npk, kf, fx);
                 }
                 nextchisq = block_gauss_model<WPC, MT, MULTI>(P, model, L.part, L.flag, tile);
@@ -1525,6 +1527,11 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
     const long long abort_at = (P.test_abort >= 0 && lc == 0) ? (long long)P.test_abort : -1;
     int nacc = 0;
     bool alive = true;
+    int kf[MT];
+    double fx[MT];
+    if constexpr (FX)
+        coefficient_map<MT>(P, kf, fx);
+    (void)kf; (void)fx;
     // log_post / zchain of the last (up to) 64 refreshes wait in lane (R - R0) mod 64 and
     // are written 64 at a time: nobody reads them inside the launch
     double lpbuf = 0.0;
@@ -1618,10 +1625,7 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
             if constexpr (!FX) {
                 model.init_from_lanes(P, npk);                 // every coefficient is free
             } else {
-                int kf[MT];                                    // FX: some are fixed
-                double fx[MT];
-                coefficient_map<MT>(P, kf, fx);
-                model.init_from_lanes(P, npk, kf, fx);
+                model.init_from_lanes(P, npk, kf, fx);         // FX: some are fixed
             }
             const double nextchisq =
                 block_gauss_model<1, MT, false>(P, model, nullptr, nullptr, tile);   // chain.py:249

@@ -25,5 +25,6 @@ for smp in ('demc', 'snooker', 'mrw'):
     Zg, lg, zg = g.rows(0, nrow); Zo, lo, zo = o.rows(0, nrow)
     same = np.array_equal(Zg, Zo) and np.array_equal(lg, lo) and np.array_equal(g.state()['numaccept'], o.state()['numaccept'])
     t0 = time.perf_counter(); g.run(400); dt = time.perf_counter() - t0
+    print(f'{256*400/dt/1e6:.1f} M chain-steps/s', end=' ')
     print(smp, 'plan', g.plan['fast'], g.plan['persistent'], 'identical to oracle:', same, 'accepted', int(g.state()['numaccept'].sum()))
     g.close()
