@@ -971,6 +971,32 @@ __device__ __forceinline__ void coefficient_map(const DevProblem &P, int (&kf)[M
     }
 }
 
+// prior_term for the lean FX instances: the proposal is in the lanes (free parameter k in
+// lane k), not in LDS; same terms in the same order
+template <int MT>
+__device__ __forceinline__ double prior_from_lanes(const DevProblem &P, double npk,
+                                                   const int (&kf)[MT], const double (&fx)[MT])
+{
+    double pr = 0.0;
+    for (int g = 0; g < P.ngprior; ++g) {
+        const int j = P.igprior[g];
+        int k = -1;
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < MT; ++q) {
+            k = (q == j) ? kf[q] : k;
+            v = (q == j) ? fx[q] : v;
+        }
+        if (k >= 0)
+            v = make_double(__builtin_amdgcn_readlane(__double2loint(npk), k),
+                            __builtin_amdgcn_readlane(__double2hiint(npk), k));
+        const double d = v - P.prior[j];
+        const double s = (d > 0.0) ? d / P.priorup[j] : d / P.priorlow[j];
+        pr = pr + s * s;
+    }
+    return pr;
+}
+
 // DEMC partners, chain.py:221-232: r1 != c, r2 != c, r2 != r1, from the two 32-bit
 // halves of one draw
 __device__ __forceinline__ void demc_partners(uint64_t q0, int n, int c, int &r1, int &r2)
@@ -1325,11 +1351,13 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 if constexpr (!FX) {
                     model.init_from_lanes(P, npk);             // every coefficient is free
                 } else {
-                    // FX: some coefficients are fixed (a separate instantiation, so that the
-                    // all-free kernels stay exactly as they were tuned)
+                    // FX: some coefficients are fixed and/or carry Gaussian priors (a separate
+                    // instantiation, so that the plain kernels stay exactly as they were tuned)
                     model.init_from_lanes(P, npk, kf, fx);
                 }
                 nextchisq = block_gauss_model<WPC, MT, MULTI>(P, model, L.part, L.flag, tile);
+                if constexpr (FX)
+                    nextchisq = nextchisq + prior_from_lanes<NKF>(P, npk, kf, fx);
             } else if constexpr (PHASE == PH_FINISH) {
                 nextchisq = finish_chisq<MT>(P, lc);
             } else {
@@ -1627,8 +1655,10 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
             } else {
                 model.init_from_lanes(P, npk, kf, fx);         // FX: some are fixed
             }
-            const double nextchisq =
+            double nextchisq =
                 block_gauss_model<1, MT, false>(P, model, nullptr, nullptr, tile);   // chain.py:249
+            if constexpr (FX)
+                nextchisq = nextchisq + prior_from_lanes<MT>(P, npk, kf, fx);
             MC3_TICK(tk2);
             const double ratio = mc3_det_exp(0.5 * (cur - nextchisq)) * 1.0;
             const bool acc = ratio > u_now;                          // chain.py:257-274

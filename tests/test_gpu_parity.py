@@ -335,6 +335,21 @@ def test_lean_instances_with_a_fixed_coefficient(eng, sampler):
     gpu.close()
 
 
+@pytest.mark.parametrize('sampler', ['demc', 'snooker', 'mrw'])
+def test_lean_instances_with_gaussian_priors(eng, sampler):
+    """Gaussian priors (one symmetric, one asymmetric) and a fixed coefficient on the lean
+    persistent instances: the prior term is built from the lanes in the oracle's order."""
+    prob = H.quad_problem(ndata=500, nchains=64, nsamples=64*300, sampler=sampler)
+    prob['pstep'] = np.array([1.0, 0.0, 0.1])
+    prob['prior'] = np.array([3.2, 0.0, 0.45])
+    prob['priorlow'] = np.array([0.5, 0.0, 0.02])
+    prob['priorup'] = np.array([0.5, 0.0, 0.05])
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert gpu.plan['persistent'] > 0 and gpu.plan['fast'] in (1, 2)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
 def test_headline_config_c2_matches_oracle(eng):
     """BASELINE config #2 (256 chains, ndata=1000, demc) for 400 iterations:
     bit-exact against the oracle, then properties at full length."""
