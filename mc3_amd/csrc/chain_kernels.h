@@ -969,6 +969,22 @@ __device__ __forceinline__ void coefficient_map(const DevProblem &P, int (&kf)[M
         for (int q = 0; q < MT; ++q)
             kf[q] = (q == j) ? k : kf[q];
     }
+    // shared parameters copy their source, in order (chain.py:246-247)
+    for (int sh = 0; sh < P.nshare; ++sh) {
+        const int j = P.ishare[sh], src = P.share_src[sh];
+        int k = -1;
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < MT; ++q) {
+            k = (q == src) ? kf[q] : k;
+            v = (q == src) ? fx[q] : v;
+        }
+#pragma unroll
+        for (int q = 0; q < MT; ++q) {
+            kf[q] = (q == j) ? k : kf[q];
+            fx[q] = (q == j) ? v : fx[q];
+        }
+    }
 }
 
 // prior_term for the lean FX instances: the proposal is in the lanes (free parameter k in

@@ -327,10 +327,10 @@ bool fast_eligible(const mc3hip_ctx *c)
     // (fixed coefficients and Gaussian priors are fine: the FX kernels map coefficient j to
     // its free parameter or to its fixed value, chain_kernels.h coefficient_map)
     // instantiated for one GPU and thinning = 1 only: FX of persist_fast_kernel)
-    const bool plain = P.nparams == P.nfree && P.ngprior == 0;
+    const bool plain = P.nparams == P.nfree && P.ngprior == 0 && P.nshare == 0;
     const bool fx_ok = P.nfree >= 1 && P.thinning == 1 && !(c->flags & MC3HIP_FLAG_P2P);
     return c->wpc == 1 && !P.wlike && P.ndata <= VLANES && c->mt >= 2 && c->mt <= 4 &&
-           (plain || fx_ok) && P.nmodel == P.nparams && P.nshare == 0 &&
+           (plain || fx_ok) && P.nmodel == P.nparams &&
            P.fepsilon == 0.0 && P.trace_iters == 0 &&
            (P.sampler == MC3HIP_DEMC || P.sampler == MC3HIP_SNOOKER ||
             P.sampler == MC3HIP_MRW) &&
@@ -341,7 +341,7 @@ template <int MT, int SMP, bool P2P>
 void launch_fast_tt(mc3hip_ctx *c, int nref)
 {
     if constexpr (!P2P) {
-        if (c->P.nfree != c->P.nparams || c->P.ngprior > 0) {   // FX (thinning = 1 only)
+        if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0) {   // FX
             hipLaunchKernelGGL((persist_fast_kernel<MT, SMP, false, 1, true>),
                                dim3(c->P.nlocal), dim3(64), c->smem, c->stream, c->P, nref);
             return;
@@ -377,7 +377,7 @@ void launch_fast_t(mc3hip_ctx *c, int nref)
         if (c->p2p_ranks > 1)
             hipLaunchKernelGGL((lean_demc_kernel<MT, true>), dim3(c->P.nlocal), dim3(64), 0,
                                c->stream, c->P, nref);
-        else if (c->P.nfree != c->P.nparams || c->P.ngprior > 0)
+        else if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)
             hipLaunchKernelGGL((lean_demc_kernel<MT, false, true>), dim3(c->P.nlocal), dim3(64),
                                0, c->stream, c->P, nref);
         else

@@ -350,6 +350,22 @@ def test_lean_instances_with_gaussian_priors(eng, sampler):
     gpu.close()
 
 
+@pytest.mark.parametrize('sampler', ['demc', 'snooker'])
+def test_lean_instances_with_a_shared_coefficient(eng, sampler):
+    """A shared parameter (pstep < 0: copies another parameter) on the lean instances."""
+    x, data, uncert = H.tutorial_data(400)
+    prob = dict(data=data, uncert=uncert, indep=x,
+                params=np.array([3.0, -2.4, 0.5, 0.5]),          # cubic term tied to the quadratic
+                pstep=np.array([1.0, 0.5, 0.1, -3.0]),
+                pmin=np.array([-10.0, -20.0, -10.0, -10.0]),
+                pmax=np.array([40.0, 20.0, 10.0, 10.0]),
+                nchains=32, nsamples=32*300, sampler=sampler, model='poly', seed=77)
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert gpu.plan['persistent'] > 0 and gpu.plan['fast'] in (1, 2)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
 def test_headline_config_c2_matches_oracle(eng):
     """BASELINE config #2 (256 chains, ndata=1000, demc) for 400 iterations:
     bit-exact against the oracle, then properties at full length."""
