@@ -1056,7 +1056,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
 {
     if (je < 0)
         je = P.thinning;
-    static_assert(!FAST || (WPC == 1 && !WL && !MULTI && SMP >= 0 && MT >= 1 && MT <= 8),
+    static_assert(!FAST || (WPC == 1 && !WL && SMP >= 0 && MT >= 1 && MT <= 8),
                   "FAST needs one wave, Gaussian chisq, a compile-time sampler and degree");
     const int sampler = (SMP >= 0) ? SMP : P.sampler;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1516,10 +1516,11 @@ __global__ __launch_bounds__(64) void finish_kernel(const DevProblem P, const in
 
 // the lean instance (see run_chain): one wave per chain, MT free polynomial
 // coefficients, Gaussian chisq, ndata <= 1024, no priors/shared/fixed/epsilon/trace
-template <int MT, int SMP, bool P2P = false, int TH = 0, bool FX = false>
+// (MULTI: more than 1024 points; the first tile stays in registers, the rest is streamed)
+template <int MT, int SMP, bool P2P = false, int TH = 0, bool FX = false, bool MULTI = false>
 __global__ __launch_bounds__(64) void persist_fast_kernel(const DevProblem P, const int nref)
 {
-    run_chain<1, MT, false, false, true, SMP, true, PH_FUSED, P2P, TH, FX>(P, P.ctl[0], nref);
+    run_chain<1, MT, false, MULTI, true, SMP, true, PH_FUSED, P2P, TH, FX>(P, P.ctl[0], nref);
 }
 
 // chisq for arbitrary parameter vectors (Chain.eval_model(ret='chisq'))
@@ -1535,7 +1536,7 @@ __global__ __launch_bounds__(64) void persist_fast_kernel(const DevProblem P, co
 //     shadow of refresh R's partner-row wait;
 //   * the Metropolis update is a select, not a branch; only the rare events (new best
 //     fit, out-of-bounds proposal, a failed wait) leave the straight line.
-template <int MT, bool P2P, bool FX = false>
+template <int MT, bool P2P, bool FX = false, bool MULTI = false>
 __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const int nref)
 {
     const int nf = FX ? P.nfree : MT;        // FX: some coefficients are fixed (nfree < MT)
@@ -1672,7 +1673,7 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
                 model.init_from_lanes(P, npk, kf, fx);         // FX: some are fixed
             }
             double nextchisq =
-                block_gauss_model<1, MT, false>(P, model, nullptr, nullptr, tile);   // chain.py:249
+                block_gauss_model<1, MT, MULTI>(P, model, nullptr, nullptr, tile);   // chain.py:249
             if constexpr (FX)
                 nextchisq = nextchisq + prior_from_lanes<MT>(P, npk, kf, fx);
             MC3_TICK(tk2);

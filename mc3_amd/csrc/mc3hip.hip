@@ -100,7 +100,7 @@ int choose_wpc(int nlocal, int ndata, int wlike)
     }
     if (wlike)
         return (ndata >= 4096) ? 16 : (ndata >= 512 ? 4 : 1);
-    if (ndata <= 2048)
+    if (ndata <= 4096)
         return 1;
     if (nlocal >= 1024)
         return 1;
@@ -329,7 +329,10 @@ bool fast_eligible(const mc3hip_ctx *c)
     // instantiated for one GPU and thinning = 1 only: FX of persist_fast_kernel)
     const bool plain = P.nparams == P.nfree && P.ngprior == 0 && P.nshare == 0;
     const bool fx_ok = P.nfree >= 1 && P.thinning == 1 && !(c->flags & MC3HIP_FLAG_P2P);
-    return c->wpc == 1 && !P.wlike && P.ndata <= VLANES && c->mt >= 2 && c->mt <= 4 &&
+    // more than one 1024-point tile (streamed): plain problems, one GPU, thinning = 1
+    const bool multi = P.npad > VLANES;
+    const bool size_ok = !multi || (plain && fx_ok && P.tile == 0);
+    return c->wpc == 1 && !P.wlike && size_ok && c->mt >= 2 && c->mt <= 4 &&
            (plain || fx_ok) && P.nmodel == P.nparams &&
            P.fepsilon == 0.0 && P.trace_iters == 0 &&
            (P.sampler == MC3HIP_DEMC || P.sampler == MC3HIP_SNOOKER ||
@@ -341,6 +344,11 @@ template <int MT, int SMP, bool P2P>
 void launch_fast_tt(mc3hip_ctx *c, int nref)
 {
     if constexpr (!P2P) {
+        if (c->P.npad > VLANES) {                  // streamed tiles (plain, thinning = 1 only)
+            hipLaunchKernelGGL((persist_fast_kernel<MT, SMP, false, 1, false, true>),
+                               dim3(c->P.nlocal), dim3(64), c->smem, c->stream, c->P, nref);
+            return;
+        }
         if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0) {   // FX
             hipLaunchKernelGGL((persist_fast_kernel<MT, SMP, false, 1, true>),
                                dim3(c->P.nlocal), dim3(64), c->smem, c->stream, c->P, nref);
@@ -377,6 +385,9 @@ void launch_fast_t(mc3hip_ctx *c, int nref)
         if (c->p2p_ranks > 1)
             hipLaunchKernelGGL((lean_demc_kernel<MT, true>), dim3(c->P.nlocal), dim3(64), 0,
                                c->stream, c->P, nref);
+        else if (c->P.npad > VLANES)
+            hipLaunchKernelGGL((lean_demc_kernel<MT, false, false, true>), dim3(c->P.nlocal),
+                               dim3(64), 0, c->stream, c->P, nref);
         else if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)
             hipLaunchKernelGGL((lean_demc_kernel<MT, false, true>), dim3(c->P.nlocal), dim3(64),
                                0, c->stream, c->P, nref);
