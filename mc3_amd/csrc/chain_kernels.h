@@ -318,12 +318,12 @@ struct DataTile {
     // The device copies of x / data / w are padded to a multiple of 1024 points
     // (x and data repeat the last point, w = 0), so the tile needs no bounds
     // checks: a padded point adds fma(0, 0, acc) = acc.
-    __device__ __forceinline__ void load(const DevProblem &P)
+    __device__ __forceinline__ void load(const DevProblem &P, int base = 0)
     {
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int i = lane + 64 * (wv + WPC * v);
+            const int i = base + lane + 64 * (wv + WPC * v);
             d[v] = P.data[i];
             w[v] = P.w[i];
             if constexpr (MT != MT_LINEAR)
@@ -334,10 +334,12 @@ struct DataTile {
 
 // Gaussian chi-squared data term, src_c/_chisq.c:131-133 with w = 1/uncert.
 // Returns +inf when any model value is +inf (chain.py:322-323).
-template <int WPC, int MT, bool MULTI>
+// (T1: the second 1024-point tile is register-resident too, in tile1)
+template <int WPC, int MT, bool MULTI, bool T1 = false>
 __device__ __forceinline__ double block_gauss_model(const DevProblem &P, const Model<MT> &model,
                                                     double *s_part, int *s_flag,
-                                                    const DataTile<WPC, MT> &tile);
+                                                    const DataTile<WPC, MT> &tile,
+                                                    const DataTile<WPC, MT> *tile1 = nullptr);
 
 template <int WPC, int MT, bool MULTI>
 __device__ double block_gauss(const DevProblem &P, const double *s_nextp, double *s_part,
@@ -348,10 +350,11 @@ __device__ double block_gauss(const DevProblem &P, const double *s_nextp, double
     return block_gauss_model<WPC, MT, MULTI>(P, model, s_part, s_flag, tile);
 }
 
-template <int WPC, int MT, bool MULTI>
+template <int WPC, int MT, bool MULTI, bool T1>
 __device__ __forceinline__ double block_gauss_model(const DevProblem &P, const Model<MT> &model,
                                                     double *s_part, int *s_flag,
-                                                    const DataTile<WPC, MT> &tile)
+                                                    const DataTile<WPC, MT> &tile,
+                                                    const DataTile<WPC, MT> *tile1)
 {
     constexpr int NV = 16 / WPC;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -367,8 +370,16 @@ __device__ __forceinline__ double block_gauss_model(const DevProblem &P, const M
         const double r = (m - tile.d[v]) * tile.w[v];
         acc[v] = mc3_fma(r, r, 0.0);
     }
-    // points beyond the first tile are streamed (MULTI = ndata > 1024)
-    for (int base = VLANES; MULTI && base < npad; base += VLANES) {
+    if constexpr (T1) {                               // second tile, also in registers
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const double m = model.at_x(tile1->x[v]);
+            const double r = (m - tile1->d[v]) * tile1->w[v];
+            acc[v] = mc3_fma(r, r, acc[v]);
+        }
+    }
+    // points beyond the register-resident tiles are streamed (MULTI = ndata > 1024)
+    for (int base = (T1 ? 2 : 1) * VLANES; MULTI && base < npad; base += VLANES) {
         double xs[NV], ds[NV], ws[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {                // issue every load of the tile first
@@ -1554,6 +1565,9 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
     MC3_STAMP(0);
     DataTile<1, MT> tile;
     tile.load(P);
+    DataTile<1, MT> tile1;                   // MULTI: points 1024..2047 stay in registers too
+    if constexpr (MULTI)
+        tile1.load(P, VLANES);
     const long long R0 = P.ctl[0];
     const int n = P.nchains;
     const size_t blockstride = (size_t)n * ZS;                   // doubles per refresh
@@ -1673,7 +1687,8 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
                 model.init_from_lanes(P, npk, kf, fx);         // FX: some are fixed
             }
             double nextchisq =
-                block_gauss_model<1, MT, MULTI>(P, model, nullptr, nullptr, tile);   // chain.py:249
+                block_gauss_model<1, MT, MULTI, MULTI>(P, model, nullptr, nullptr, tile,
+                                                       &tile1);          // chain.py:249
             if constexpr (FX)
                 nextchisq = nextchisq + prior_from_lanes<MT>(P, npk, kf, fx);
             MC3_TICK(tk2);
