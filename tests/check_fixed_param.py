@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Development check: a fixed polynomial coefficient on the lean persistent instances, against the oracle."""
+"""Test-side check (uses the CPU checker, hence under tests/): a fixed polynomial coefficient on the lean persistent instances, against the oracle."""
 import sys, os, time
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import bench
 from mc3_amd import engine

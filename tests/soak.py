@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off soak: a long C2 run on the GPU against the oracle (OpenMP on the host
-cores), compared exactly.  python tools/soak.py [iterations] [sampler]"""
+cores), compared exactly.  python tests/soak.py [iterations] [sampler]"""
 import os
 import sys
 import time
