@@ -1,7 +1,6 @@
 """Shared problem builders for the parity tests (CPU oracle and GPU)."""
 import numpy as np
 
-from oracle import lockstep as ls
 
 
 def quad(p, x):
@@ -101,7 +100,8 @@ def linear_problem(ndata=512, nmodel=10, nchains=16, nsamples=1600,
 def make_oracle(prob, **extra):
     kw = dict(prob)
     kw.update(extra)
-    return ls.LockstepRun(**kw)
+    from oracle import lockstep as ls      # (lazily: tools/ import this module for the
+    return ls.LockstepRun(**kw)            # problem builders only and must not load oracle/)
 
 
 def initial_population(orc, seed=5):
