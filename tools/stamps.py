@@ -64,6 +64,9 @@ print(f'{which} mode={mode} plan={g.plan}: {n} samples, mean shader-clock cycles
 for k, v in zip(names, acc/max(n, 1)):
     print(f'  {k:28s} {v:9.0f}')
 print(f'  {"iteration":28s} {acc.sum()/max(n, 1):9.0f}')
+if n == 0:
+    print('  (no samples: the hand-laid-out DEMC loop keeps per-phase tick sums instead -- '
+          'tools/ticks.py; or STAMP_MODE=launch / MC3HIP_NO_LEAN=1 for the stamped kernels)')
 if which == 'c4':
     w = [int(out[i]) for i in (2, 8, 9, 10, 11, 12, 13, 3)]
     lab = ['chisq entry -> noise table', '-> level 0 (global -> LDS)', '-> level 1', '-> levels 2..3',
