@@ -1088,6 +1088,9 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     DataTile<WPC, MT> tile;
     if constexpr (!WL && PHASE == PH_FUSED)
         tile.load(P);
+    DataTile<WPC, MT> tile1;                   // lean + MULTI: points 1024..2047 resident too
+    if constexpr (FAST && MULTI)
+        tile1.load(P, VLANES);
     // own state = this chain's row of the first snapshot (same pages as the partner
     // rows requested a few hundred cycles later, so their translation is warm); in
     // the middle of a refresh (tiled plan, thinning > 1) it is the saved state
@@ -1382,7 +1385,8 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                     // instantiation, so that the plain kernels stay exactly as they were tuned)
                     model.init_from_lanes(P, npk, kf, fx);
                 }
-                nextchisq = block_gauss_model<WPC, MT, MULTI>(P, model, L.part, L.flag, tile);
+                nextchisq = block_gauss_model<WPC, MT, MULTI, MULTI>(P, model, L.part, L.flag, tile,
+                                                                     &tile1);
                 if constexpr (FX)
                     nextchisq = nextchisq + prior_from_lanes<NKF>(P, npk, kf, fx);
             } else if constexpr (PHASE == PH_FINISH) {
