@@ -366,6 +366,18 @@ def test_lean_instances_with_a_shared_coefficient(eng, sampler):
     gpu.close()
 
 
+@pytest.mark.parametrize('ndata', [1500, 2048, 2049, 3000, 4096, 4097])
+def test_lean_demc_with_more_than_one_tile(eng, ndata):
+    """More than 1024 points on the lean DEMC loop: two 1024-point tiles in registers, the
+    rest streamed (<= 4096 points); beyond that the general instance on four waves."""
+    prob = H.quad_problem(ndata=ndata, nchains=32, nsamples=32*150, sampler='demc')
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert gpu.plan['persistent'] > 0
+    assert (gpu.plan['fast'] == 2) == (ndata <= 4096)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
 def test_headline_config_c2_matches_oracle(eng):
     """BASELINE config #2 (256 chains, ndata=1000, demc) for 400 iterations:
     bit-exact against the oracle, then properties at full length."""
