@@ -215,6 +215,40 @@ class LockstepRun:
         return self
 
 
+    def run_tape(self, kind, value, fma_dot=True, trace=True):
+        """The reference's own sequential loop (ls_run_tape) fed a tape of its
+        np.random draws.  Returns a dict: rc (0 = the whole tape was consumed with
+        every draw of the recorded kind), numaccept, best_chisq, bestx, steps and
+        -- with trace -- per-step chisq / flags in visiting order."""
+        kind = np.ascontiguousarray(kind, dtype=np.int8)
+        value = _f(value)
+        nmax = (self.nzchain + 2)*self.thinning*self.nchains
+        if trace:
+            self.trace_chisq = np.full(nmax, np.nan)
+            self.trace_flag = np.zeros(nmax, np.int32)
+            self.S.trace_chisq = self.trace_chisq.ctypes.data_as(_dp)
+            self.S.trace_flag = self.trace_flag.ctypes.data_as(_ip)
+        else:
+            self.S.trace_chisq = None
+            self.S.trace_flag = None
+        ibest = int(np.argmax(self.log_post[0:self.M0]))      # mcmc_driver.py:273-278
+        gbest = ctypes.c_double(-2.0*self.log_post[ibest])
+        gbestx = self.Z[ibest].copy()
+        nacc = ctypes.c_int64(0)
+        steps = ctypes.c_int64(0)
+        self.L.ls_run_tape.restype = ctypes.c_int
+        rc = self.L.ls_run_tape(
+            ctypes.byref(self.P), ctypes.byref(self.S), value.ctypes.data_as(_dp),
+            kind.ctypes.data_as(ctypes.POINTER(ctypes.c_int8)),
+            ctypes.c_int64(len(value)), ctypes.c_int(int(fma_dot)), ctypes.byref(nacc),
+            ctypes.byref(gbest), gbestx.ctypes.data_as(_dp), ctypes.byref(steps))
+        n = int(steps.value)
+        return {'rc': int(rc), 'numaccept': int(nacc.value), 'best_chisq': gbest.value,
+                'bestx': gbestx, 'steps': n,
+                'trace_chisq': self.trace_chisq[:n] if trace else None,
+                'trace_flag': self.trace_flag[:n] if trace else None}
+
+
 def philox4x32_10(ctr, key):
     """Philox through the C restatement (for the known-answer test)."""
     L = ok.lib()

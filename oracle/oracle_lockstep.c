@@ -9,9 +9,21 @@
  * by line (citations below); what differs from the reference is only (i) the
  * generator (the reference uses NumPy's MT19937 stream, chain.py:185-259) and
  * (ii) Jacobi instead of Gauss-Seidel visibility of the other chains
- * (SURVEY.md 3.3-12).  oracle/chain_sequential.py restates the reference's own
- * sequential form and is pinned bit-for-bit against the reference; this file
- * shares its step rules and is the bit-exact checker for the GPU.
+ * (SURVEY.md 3.3-12).
+ *
+ * ONE step function, two drivers.  chain_step() below is the only statement of the
+ * step rules; it takes its random numbers from a draw source (ls_draws) and sees
+ * the other chains through whatever the driver hands it:
+ *   ls_run()       lockstep driver -- Philox draws, population snapshot of the last
+ *                  refresh (what the HIP kernels do; the GPU's bit-exact checker);
+ *   ls_run_tape()  the reference's own sequential loop (chain.py:183-299, one
+ *                  worker) -- draws read from a TAPE recorded from the reference's
+ *                  np.random calls, chains updated one after another so that each
+ *                  sees the previous one's new state.  Replaying the reference runs
+ *                  of tests/golden/seq_*.npz through it must reproduce them (Z rows,
+ *                  accept and out-of-bounds counters, best fit: identical; chisq to
+ *                  1e-10): tests/test_oracle_tape.py.  That pins the very function
+ *                  that checks the GPU to the reference, not a sibling of it.
  *
  * Arithmetic contract (DESIGN.md "Arithmetic contract"): built with
  * -ffp-contract=off; a fused multiply-add happens only where written
@@ -106,6 +118,111 @@ static uint64_t bounded(uint64_t q, uint64_t n)                                 
 static uint32_t bounded32(uint32_t w, uint32_t n)                                 /* [0,n) */
 {
     return (uint32_t)(((uint64_t)w * n) >> 32);
+}
+
+/* ---- draw source ------------------------------------------------------------
+ * What the step rules ask for, in the reference's call order:
+ *   index(lo, hi)    np.random.randint(lo, hi)        integer in [lo, hi)
+ *   uniform(lo, hi)  np.random.uniform(lo, hi)        lo + (hi-lo)*[0,1)
+ * Philox mode computes each from (seed; iteration, chain, slot) -- a pure function,
+ * so the order of the requests does not matter; tape mode hands out the values the
+ * reference's generator produced, in order, and checks that the KIND of every
+ * request is the kind that was recorded (a step rule that asked for a different
+ * draw sequence than the reference did fails right there). */
+enum { DR_IR1, DR_IR2, DR_SJUMP, DR_IZ, DR_GS, DR_R1, DR_R2, DR_METRO };
+enum { TK_NORMAL = 0, TK_INDEX = 1, TK_UNIFORM = 2 };
+
+typedef struct {
+    int tape_mode;
+    /* Philox */
+    uint64_t seed, iter;
+    uint32_t chain;
+    int sampler;
+    /* tape */
+    const double *tape;
+    const int8_t *kind;
+    int64_t pos, len;
+    int error;                 /* 1 = ran off the tape, 2 = kind mismatch */
+    /* dot products of the snooker projection: the reference calls np.dot, i.e. the BLAS
+     * ddot of the box the goldens were recorded on, whose scalar tail contracts
+     * multiply-add; the lockstep contract rounds every product */
+    int fma_dot;
+} ls_draws;
+
+static double tape_next(ls_draws *D, int kind)
+{
+    if (D->pos >= D->len) {
+        D->error = D->error ? D->error : 1;
+        return 0.0;
+    }
+    if (D->kind[D->pos] != kind)
+        D->error = D->error ? D->error : 2;
+    return D->tape[D->pos++];
+}
+
+static int64_t draw_index(ls_draws *D, int id, int64_t lo, int64_t hi)
+{
+    if (D->tape_mode)
+        return (int64_t)tape_next(D, TK_INDEX);
+    uint64_t q0, q1;
+    draw2(D->seed, D->iter, D->chain, (id == DR_IZ) ? 1u : 0u, &q0, &q1);
+    switch (id) {
+    case DR_IR1: return lo + (int64_t)bounded(q0, (uint64_t)(hi - lo));
+    case DR_IR2: return lo + (int64_t)bounded(q1, (uint64_t)(hi - lo));
+    case DR_IZ:  return lo + (int64_t)bounded(q1, (uint64_t)(hi - lo));
+    case DR_R1:  return lo + (int64_t)bounded32((uint32_t)(q0 >> 32), (uint32_t)(hi - lo));
+    default:     return lo + (int64_t)bounded32((uint32_t)q0, (uint32_t)(hi - lo));   /* DR_R2 */
+    }
+}
+
+static double draw_uniform(ls_draws *D, int id, double lo, double hi)
+{
+    if (D->tape_mode)
+        return tape_next(D, TK_UNIFORM);
+    uint64_t q0, q1;
+    double u;
+    switch (id) {
+    case DR_SJUMP: draw2(D->seed, D->iter, D->chain, 1u, &q0, &q1); u = u01(q0); break;
+    case DR_GS:    draw2(D->seed, D->iter, D->chain, 2u, &q0, &q1); u = u01(q0); break;
+    default:       /* DR_METRO: second word of slot 2 (snooker) or of slot 0 */
+        draw2(D->seed, D->iter, D->chain, (D->sampler == LS_SNOOKER) ? 2u : 0u, &q0, &q1);
+        u = u01(q1);
+        break;
+    }
+    if (lo == 0.0 && hi == 1.0)
+        return u;
+    return lo + (hi - lo) * u;
+}
+
+/* support-distribution draw N(0, pstep[ifree]), chain.py:185.  Philox: one vector per
+ * chain and iteration (Box-Muller on slots 3+); tape: the next nfree recorded values
+ * (the reference draws ONE vector per worker-iteration, shared by its chains). */
+static void draw_normal(ls_draws *D, const ls_problem *P, double *normal)
+{
+    const int nf = P->nfree;
+    if (D->tape_mode) {
+        for (int k = 0; k < nf; k++)
+            normal[k] = tape_next(D, TK_NORMAL);
+        return;
+    }
+    uint64_t q0, q1;
+    for (int j = 0; 2 * j < nf; j++) {
+        draw2(D->seed, D->iter, D->chain, (uint32_t)(3 + j), &q0, &q1);
+        const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(q0)));
+        double sn, cs;
+        mc3_det_sincos2pi(u01(q1), &sn, &cs);
+        normal[2*j] = (rad * cs) * P->pstep[P->ifree[2*j]];
+        if (2*j + 1 < nf)
+            normal[2*j + 1] = (rad * sn) * P->pstep[P->ifree[2*j + 1]];
+    }
+}
+
+static double dotn(const ls_draws *D, const double *a, const double *b, int n)
+{
+    double s = 0.0;                                     /* sum_k a[k] b[k], in index order */
+    for (int k = 0; k < n; k++)
+        s = D->fma_dot ? mc3_fma(a[k], b[k], s) : s + a[k] * b[k];
+    return s;
 }
 
 /* ---- model ---------------------------------------------------------------- */
@@ -258,7 +375,7 @@ static double wavelet_chisq(const ls_problem *P, const double *p,
 }
 
 typedef struct {
-    double *part, *buf0, *buf1, *nextp, *jump, *normal;
+    double *part, *buf0, *buf1, *nextp, *jump, *normal, *dz;
 } ls_scratch;
 
 static double eval_chisq(const ls_problem *P, const double *p, ls_scratch *S)
@@ -272,6 +389,7 @@ static double eval_chisq(const ls_problem *P, const double *p, ls_scratch *S)
 int ls_eval_chisq(const ls_problem *P, const double *params, int n, double *out)
 {
     ls_scratch S;
+    memset(&S, 0, sizeof S);
     S.part = malloc(sizeof(double) * (size_t)P->vlanes);
     S.buf0 = malloc(sizeof(double) * (size_t)P->ndata);
     S.buf1 = malloc(sizeof(double) * (size_t)P->ndata);
@@ -281,50 +399,35 @@ int ls_eval_chisq(const ls_problem *P, const double *params, int n, double *out)
     return 0;
 }
 
-/* ---- one chain, one iteration: mc3/chain.py:190-274 ----------------------- */
-static void chain_step(const ls_problem *P, ls_state *St, ls_scratch *S,
-                       int c, int64_t iter, const double *snap, int64_t zsize,
-                       double *tr_chisq, int32_t *tr_flag)
+/* ---- one chain, one iteration: mc3/chain.py:190-274 -----------------------
+ * x        this chain's current free parameters (updated in place on acceptance)
+ * normal   the support-distribution draw of this iteration (chain.py:185)
+ * pop      what DEMC sees of the other chains, [nchains][nfree]: the snapshot of the
+ *          last refresh (lockstep) or the live states (sequential, chain.py:230-232)
+ * zsize    rows of Z visible to snooker (chain.py:197-203) */
+static void chain_step(const ls_problem *P, ls_state *St, ls_scratch *S, ls_draws *D,
+                       int c, int64_t iter, const double *normal, const double *pop,
+                       int64_t zsize, double *tr_chisq, int32_t *tr_flag)
 {
     const int nf = P->nfree;
     double *x = St->X + (size_t)c * nf;
-    double *nextp = S->nextp, *jump = S->jump, *normal = S->normal;
-    uint64_t q0, q1;
+    double *nextp = S->nextp, *jump = S->jump;
     double mrfactor = 1.0;
     int sjump = 0;
     const double *z = NULL;
     int32_t flag = 0;
 
-    /* support-distribution draw, chain.py:185 (Box-Muller on slots 3+) */
-    const int need_normal = (P->sampler == LS_MRW) || (P->fepsilon != 0.0);
-    for (int k = 0; k < nf; k++)
-        normal[k] = 0.0;
-    if (need_normal) {
-        for (int j = 0; 2 * j < nf; j++) {
-            draw2(P->seed, (uint64_t)iter, (uint32_t)c, (uint32_t)(3 + j), &q0, &q1);
-            const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(q0)));
-            double sn, cs;
-            mc3_det_sincos2pi(u01(q1), &sn, &cs);
-            normal[2*j] = (rad * cs) * P->pstep[P->ifree[2*j]];
-            if (2*j + 1 < nf)
-                normal[2*j + 1] = (rad * sn) * P->pstep[P->ifree[2*j + 1]];
-        }
-    }
-
     if (P->sampler == LS_SNOOKER) {                       /* chain.py:195-217 */
-        draw2(P->seed, (uint64_t)iter, (uint32_t)c, 0, &q0, &q1);
-        int64_t iR1 = (int64_t)bounded(q0, (uint64_t)zsize);
-        int64_t iR2 = 1 + (int64_t)bounded(q1, (uint64_t)(zsize - 1));
+        const int64_t iR1 = draw_index(D, DR_IR1, 0, zsize);
+        int64_t iR2 = draw_index(D, DR_IR2, 1, zsize);
         if (iR2 == iR1)
             iR2 = 0;
-        draw2(P->seed, (uint64_t)iter, (uint32_t)c, 1, &q0, &q1);
-        sjump = u01(q0) < 0.1;
-        const int64_t iz = (int64_t)bounded(q1, (uint64_t)zsize);
+        sjump = draw_uniform(D, DR_SJUMP, 0.0, 1.0) < 0.1;
         const double *Z1 = St->Z + (size_t)iR1 * nf, *Z2 = St->Z + (size_t)iR2 * nf;
         if (sjump) {
             flag |= 4;
-            draw2(P->seed, (uint64_t)iter, (uint32_t)c, 2, &q0, &q1);
-            const double gs = 1.2 + (2.2 - 1.2) * u01(q0);
+            const int64_t iz = draw_index(D, DR_IZ, 0, zsize);
+            const double gs = draw_uniform(D, DR_GS, 1.2, 2.2);
             z = St->Z + (size_t)iz * nf;
             int same = 1;
             for (int k = 0; k < nf; k++)
@@ -334,15 +437,14 @@ static void chain_step(const ls_problem *P, ls_state *St, ls_scratch *S,
                 for (int k = 0; k < nf; k++)
                     jump[k] = gs * (Z2[k] - Z1[k]);
             } else {
-                double zp1 = 0.0, zp2 = 0.0, dd = 0.0;
-                for (int k = 0; k < nf; k++) {
-                    const double dz = x[k] - z[k];
-                    zp1 = zp1 + Z1[k] * dz;
-                    zp2 = zp2 + Z2[k] * dz;
-                    dd = dd + dz * dz;
-                }
+                double *dz = S->dz;
                 for (int k = 0; k < nf; k++)
-                    jump[k] = ((gs * (zp1 - zp2)) * (x[k] - z[k])) / dd;
+                    dz[k] = x[k] - z[k];
+                const double zp1 = dotn(D, Z1, dz, nf);
+                const double zp2 = dotn(D, Z2, dz, nf);
+                const double dd = dotn(D, dz, dz, nf);
+                for (int k = 0; k < nf; k++)
+                    jump[k] = ((gs * (zp1 - zp2)) * dz[k]) / dd;
             }
         } else {
             for (int k = 0; k < nf; k++)
@@ -353,19 +455,21 @@ static void chain_step(const ls_problem *P, ls_state *St, ls_scratch *S,
             jump[k] = normal[k];
     } else {                                              /* chain.py:221-232 */
         const int n = P->nchains;
-        draw2(P->seed, (uint64_t)iter, (uint32_t)c, 0, &q0, &q1);
-        int r1 = 1 + (int)bounded32((uint32_t)(q0 >> 32), (uint32_t)(n - 1));
+        int r1 = (int)draw_index(D, DR_R1, 1, n);
         if (r1 == c)
             r1 = 0;
-        int r2 = (r1 + 2 + (int)bounded32((uint32_t)q0, (uint32_t)(n - 2))) % n;
+        int r2 = (r1 + (int)draw_index(D, DR_R2, 2, n)) % n;
         if (r2 == c)
             r2 = (r1 + 1) % n;
-        const double *x1 = snap + (size_t)r1 * nf, *x2 = snap + (size_t)r2 * nf;
+        const double *x1 = pop + (size_t)r1 * nf, *x2 = pop + (size_t)r2 * nf;
         for (int k = 0; k < nf; k++)
             jump[k] = P->gamma * (x1[k] - x2[k]) + P->fepsilon * normal[k];
     }
 
-    /* proposal and boundaries, chain.py:235-243 */
+    /* proposal and boundaries, chain.py:235-243.  nextp keeps whatever the previous
+     * step of this worker left in its fixed and shared entries (chain.py:175: one
+     * array for the whole run); they are rewritten before use, so starting from
+     * params every time is the same thing. */
     memcpy(nextp, P->params, sizeof(double) * (size_t)P->nparams);
     int anyout = 0;
     for (int k = 0; k < nf; k++) {
@@ -391,19 +495,20 @@ static void chain_step(const ls_problem *P, ls_state *St, ls_scratch *S,
             nextp[P->ishare[s]] = nextp[P->share_src[s]];
         nextchisq = eval_chisq(P, nextp, S);              /* chain.py:249 */
         if (sjump) {                                      /* chain.py:251-255 */
+            double *np_free = S->dz;                      /* (dz is dead by now) */
+            for (int k = 0; k < nf; k++)
+                np_free[k] = nextp[P->ifree[k]];
             double cnorm = 0.0, nnorm = 0.0;
             for (int k = 0; k < nf; k++) {
                 const double dc = x[k] - z[k];
-                const double dn = nextp[P->ifree[k]] - z[k];
-                cnorm = cnorm + dc * dc;
-                nnorm = nnorm + dn * dn;
+                const double dn = np_free[k] - z[k];
+                cnorm = D->fma_dot ? mc3_fma(dc, dc, cnorm) : cnorm + dc * dc;
+                nnorm = D->fma_dot ? mc3_fma(dn, dn, nnorm) : nnorm + dn * dn;
             }
             mrfactor = mc3_det_pow_half(nnorm / cnorm, nf - 1);
         }
-        /* Metropolis draw: second word of slot 2 (snooker) or of slot 0 */
-        const int uslot = (P->sampler == LS_SNOOKER) ? 2 : 0;
-        draw2(P->seed, (uint64_t)iter, (uint32_t)c, (uint32_t)uslot, &q0, &q1);
-        const double u = u01(q1);
+        /* Metropolis draw -- only for proposals inside the boundaries (chain.py:259) */
+        const double u = draw_uniform(D, DR_METRO, 0.0, 1.0);
         const double ratio = mc3_det_exp(0.5 * (St->chisq[c] - nextchisq)) * mrfactor;
         if (ratio > u) {                                  /* chain.py:257-274 */
             flag |= 2;
@@ -424,9 +529,27 @@ static void chain_step(const ls_problem *P, ls_state *St, ls_scratch *S,
         *tr_flag = flag;
 }
 
-/* Advance chains [chain0, chain0+nlocal) by nrefresh Z refreshes of `thinning`
- * iterations each.  Rows of the other chains must already be in Z when a later
- * refresh needs them (the multi-rank exchange is the caller's business). */
+static void scratch_alloc(const ls_problem *P, ls_scratch *S)
+{
+    S->part = malloc(sizeof(double) * (size_t)P->vlanes);
+    S->buf0 = malloc(sizeof(double) * (size_t)P->ndata);
+    S->buf1 = malloc(sizeof(double) * (size_t)P->ndata);
+    S->nextp = malloc(sizeof(double) * (size_t)P->nparams);
+    S->jump = malloc(sizeof(double) * (size_t)P->nfree);
+    S->normal = malloc(sizeof(double) * (size_t)P->nfree);
+    S->dz = malloc(sizeof(double) * (size_t)P->nfree);
+}
+
+static void scratch_free(ls_scratch *S)
+{
+    free(S->part); free(S->buf0); free(S->buf1);
+    free(S->nextp); free(S->jump); free(S->normal); free(S->dz);
+}
+
+/* LOCKSTEP driver.  Advance chains [chain0, chain0+nlocal) by nrefresh Z refreshes of
+ * `thinning` iterations each: Philox draws, every chain sees the others through the
+ * snapshot of the previous refresh.  Rows of the other chains must already be in Z
+ * when a later refresh needs them (the multi-rank exchange is the caller's business). */
 int ls_run(const ls_problem *P, ls_state *St, int64_t nrefresh, int nthreads)
 {
     const int nf = P->nfree;
@@ -440,12 +563,14 @@ int ls_run(const ls_problem *P, ls_state *St, int64_t nrefresh, int nthreads)
 #endif
     {
         ls_scratch S;
-        S.part = malloc(sizeof(double) * (size_t)P->vlanes);
-        S.buf0 = malloc(sizeof(double) * (size_t)P->ndata);
-        S.buf1 = malloc(sizeof(double) * (size_t)P->ndata);
-        S.nextp = malloc(sizeof(double) * (size_t)P->nparams);
-        S.jump = malloc(sizeof(double) * (size_t)nf);
-        S.normal = malloc(sizeof(double) * (size_t)nf);
+        scratch_alloc(P, &S);
+        ls_draws D;
+        memset(&D, 0, sizeof D);
+        D.seed = P->seed;
+        D.sampler = P->sampler;
+        const int need_normal = (P->sampler == LS_MRW) || (P->fepsilon != 0.0);
+        for (int k = 0; k < nf; k++)
+            S.normal[k] = 0.0;
         for (int64_t R = R0; R < R0 + nrefresh; R++) {
             const double *snap = (R == 0) ? St->snap0
                                : St->Z + (size_t)(P->M0 + (R - 1) * P->nchains) * nf;
@@ -458,7 +583,11 @@ int ls_run(const ls_problem *P, ls_state *St, int64_t nrefresh, int nthreads)
                 for (int j = 0; j < P->thinning; j++) {
                     const int64_t iter = R * P->thinning + j;
                     const int64_t trow = (R - R0) * P->thinning + j;
-                    chain_step(P, St, &S, c, iter, snap, zsize,
+                    D.iter = (uint64_t)iter;
+                    D.chain = (uint32_t)c;
+                    if (need_normal)
+                        draw_normal(&D, P, S.normal);
+                    chain_step(P, St, &S, &D, c, iter, S.normal, snap, zsize,
                                St->trace_chisq ? St->trace_chisq + trow * P->nchains + c : NULL,
                                St->trace_flag ? St->trace_flag + trow * P->nchains + c : NULL);
                 }
@@ -470,11 +599,93 @@ int ls_run(const ls_problem *P, ls_state *St, int64_t nrefresh, int nthreads)
                 St->zchain[row] = c;
             }
         }
-        free(S.part); free(S.buf0); free(S.buf1);
-        free(S.nextp); free(S.jump); free(S.normal);
+        scratch_free(&S);
     }
     St->refresh_done = R0 + nrefresh;
     return 0;
+}
+
+/* SEQUENTIAL driver: the reference's worker loop with ncpu = 1 (chain.py:183-299),
+ * replaying a tape of the reference's np.random draws (kind[] = TK_*, value[]).
+ * Chains are visited one after another inside an iteration and see each other's
+ * already-updated states (freepars for DEMC, chain.py:230-232; Z and zsize for
+ * snooker, :197-217); rows are appended every `thinning` iterations at the strided
+ * slot (mrw/demc, :288) or at zsize (snooker, :281-282 -- the same slot with one
+ * worker); the run ends when Z is full (:279-280, so snooker makes one more partial
+ * pass whose steps still count) or when chain 0 is complete (mrw/demc, :297-299).
+ * The global best fit follows chain.py:268-274: *gbest_chisq/gbestx on entry = the
+ * initial population's best (mcmc_driver.py:273-278).
+ * Returns 0, or 1 (tape too short) / 2 (a draw of another kind was recorded: the
+ * step rules diverged from the reference) / 3 (tape not used up). */
+int ls_run_tape(const ls_problem *P, ls_state *St, const double *tape, const int8_t *kind,
+                int64_t ntape, int fma_dot, int64_t *numaccept_total, double *gbest_chisq,
+                double *gbestx, int64_t *steps_done)
+{
+    const int nf = P->nfree, n = P->nchains;
+    ls_scratch S;
+    scratch_alloc(P, &S);
+    ls_draws D;
+    memset(&D, 0, sizeof D);
+    D.tape_mode = 1;
+    D.tape = tape;
+    D.kind = kind;
+    D.len = ntape;
+    D.sampler = P->sampler;
+    D.fma_dot = fma_dot;
+    int64_t zsize = P->M0, nsteps = 0, iter = 0;
+    int64_t *index = malloc(sizeof(int64_t) * (size_t)n);
+    int64_t *chainsize = malloc(sizeof(int64_t) * (size_t)n);
+    for (int c = 0; c < n; c++) {
+        index[c] = P->M0 + c;                             /* chain.py:163-164 */
+        chainsize[c] = P->M0 / n;
+    }
+    const int64_t chainlen = P->zlen / n;                 /* chain.py:155 */
+    int njump = 0, done = 0;
+    while (!done && !D.error) {
+        njump += 1;
+        draw_normal(&D, P, S.normal);                     /* chain.py:185: one per iteration */
+        for (int c = 0; c < n && !D.error; c++) {
+            const int acc0 = (int)St->numaccept[c];
+            chain_step(P, St, &S, &D, c, iter, S.normal, St->X, zsize,
+                       St->trace_chisq ? St->trace_chisq + nsteps : NULL,
+                       St->trace_flag ? St->trace_flag + nsteps : NULL);
+            nsteps += 1;
+            if ((int)St->numaccept[c] != acc0 && St->chisq[c] < *gbest_chisq) {
+                *gbest_chisq = St->chisq[c];              /* chain.py:268-274 */
+                memcpy(gbestx, St->X + (size_t)c * nf, sizeof(double) * (size_t)nf);
+            }
+            if (njump == P->thinning) {                   /* chain.py:276-289 */
+                if (zsize == P->zlen) {
+                    done = 1;
+                    break;
+                }
+                if (P->sampler == LS_SNOOKER)
+                    index[c] = zsize;
+                zsize += 1;
+                St->zchain[index[c]] = c;
+                memcpy(St->Z + (size_t)index[c] * nf, St->X + (size_t)c * nf,
+                       sizeof(double) * (size_t)nf);
+                St->log_post[index[c]] = -0.5 * St->chisq[c];
+                index[c] += n;
+                chainsize[c] += 1;
+            }
+        }
+        if (njump == P->thinning)
+            njump = 0;
+        iter += 1;
+        if (P->sampler != LS_SNOOKER && chainsize[0] == chainlen)
+            done = 1;                                     /* chain.py:297-299 */
+    }
+    int64_t total = 0;
+    for (int c = 0; c < n; c++)
+        total += St->numaccept[c];
+    *numaccept_total = total;
+    *steps_done = nsteps;
+    St->refresh_done = (zsize - P->M0) / n;
+    const int rc = D.error ? D.error : (D.pos != D.len ? 3 : 0);
+    free(index); free(chainsize);
+    scratch_free(&S);
+    return rc;
 }
 
 /* exported so tests can pin the shared deterministic functions to libm */

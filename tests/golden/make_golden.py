@@ -43,6 +43,68 @@ class _ConstRandom:
 sys.modules['mc3.chain'].random = _ConstRandom
 
 
+# ---- the draw tape -----------------------------------------------------------
+# Every np.random call the worker makes (mc3/chain.py:185-259) is forwarded to the real
+# generator and its result recorded: kind 0 = one element of the normal vector, 1 =
+# randint, 2 = uniform.  The worker is a forked process, so the tape is written to a
+# scratch file when Chain.run returns and picked up by the parent.
+TAPE_PATH = '/tmp/mc3_golden_tape.npz'
+
+
+class _RecordingRandom:
+    def __init__(self):
+        self.kinds, self.values = [], []
+
+    def seed(self, s):
+        np.random.seed(s)
+
+    def normal(self, *a, **k):
+        v = np.random.normal(*a, **k)
+        for x in np.atleast_1d(v):
+            self.kinds.append(0)
+            self.values.append(float(x))
+        return v
+
+    def randint(self, *a, **k):
+        v = np.random.randint(*a, **k)
+        self.kinds.append(1)
+        self.values.append(float(v))
+        return v
+
+    def uniform(self, *a, **k):
+        v = np.random.uniform(*a, **k)
+        self.kinds.append(2)
+        self.values.append(float(v))
+        return v
+
+
+class _NumpyProxy:
+    """``np`` as mc3.chain sees it: everything is NumPy's, except ``random``."""
+    def __init__(self):
+        self.random = _RecordingRandom()
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+
+_proxy = _NumpyProxy()
+sys.modules['mc3.chain'].np = _proxy
+_orig_run = sys.modules['mc3.chain'].Chain.run
+
+
+def _recorded_run(self):
+    _proxy.random.kinds.clear()
+    _proxy.random.values.clear()
+    try:
+        _orig_run(self)
+    finally:
+        np.savez(TAPE_PATH, kind=np.array(_proxy.random.kinds, np.int8),
+                 value=np.array(_proxy.random.values, np.float64))
+
+
+sys.modules['mc3.chain'].Chain.run = _recorded_run
+
+
 def quad(p, x):
     return p[0] + p[1]*x + p[2]*x**2.0
 
@@ -71,6 +133,11 @@ def _capture_update_output(output, chain, hsize):
     _captured['outbounds'] = np.array(chain.outbounds[:], dtype=np.int64)
     _captured['numaccept'] = int(chain.numaccept.value)
     _captured['chainsize'] = np.array(chain.chainsize, dtype=np.int64)
+    # the initial population (mcmc_driver.py:229-270): rows the chains did not write
+    Z = np.array(chain.Z).reshape(-1, chain.nfree)
+    init = np.array(chain.zchain) < 0
+    _captured['Z0'] = Z[init].copy()
+    _captured['log_post0'] = np.array(chain.log_post)[init].copy()
     return _orig_update_output(output, chain, hsize)
 
 
@@ -81,13 +148,17 @@ def run_case(name, hub_seed, func, **kw):
     np.random.seed(hub_seed)
     cwd = os.getcwd()
     os.chdir('/tmp')
+    if os.path.exists(TAPE_PATH):
+        os.remove(TAPE_PATH)
     try:
         with contextlib.redirect_stdout(io.StringIO()):
             out = mc3.sample(func=func, ncpu=1, plots=False, grtest=False,
                              log=None, **kw)
     finally:
         os.chdir(cwd)
+    tape = np.load(TAPE_PATH)
     save = dict(
+        tape_kind=tape['kind'], tape_value=tape['value'],
         hub_seed=hub_seed, chain_seed=CHAIN_SEED,
         data=kw['data'], uncert=kw['uncert'], x=kw['indparams'][0],
         params=kw['params'], pstep=kw['pstep'],
@@ -103,6 +174,7 @@ def run_case(name, hub_seed, func, **kw):
         hsize=kw.get('hsize', 10), kickoff=kw.get('kickoff', 'normal'),
         outbounds=_captured['outbounds'], numaccept=_captured['numaccept'],
         chainsize=_captured['chainsize'],
+        Z0=_captured['Z0'], log_post0=_captured['log_post0'],
     )
     for key, val in out.items():
         if key in ('pnames', 'texnames'):
@@ -143,6 +215,22 @@ def chain_cases():
              priorup=np.array([0.25, 0.0, 0.04, 0.0, 0.0]),
              sampler='snooker', nchains=8, nsamples=2400, burnin=10,
              kickoff='uniform')
+    # DEMC with two-sided Gaussian priors on two parameters (+ support distribution):
+    x, data, uncert = tutorial_data(100)
+    run_case('quad_demc_priors', 17, quad, sampler='demc', nchains=8,
+             nsamples=2400, burnin=20, fepsilon=0.005,
+             prior=np.array([3.0, 0.0, 0.5]),
+             priorlow=np.array([0.5, 0.0, 0.02]),
+             priorup=np.array([0.25, 0.0, 0.04]), **base)
+    # MRW inside tight boundaries: many out-of-bounds proposals (which consume no
+    # acceptance draw, chain.py:241-243,259)
+    run_case('quad_mrw_bounds', 18, quad, sampler='mrw', nchains=7,
+             nsamples=2100, burnin=10,
+             data=data, uncert=uncert, indparams=[x],
+             params=np.array([4.0, -2.5, 0.5]),
+             pstep=np.array([1.0, 0.5, 0.1]),
+             pmin=np.array([3.5, -2.8, 0.45]),
+             pmax=np.array([6.5, -2.2, 0.56]))
     # wavelet likelihood: quad + (gamma fixed, sigma_r, sigma_w), ndata = 2^6
     rs = np.random.RandomState(99)
     x = np.linspace(0, 10, 64)

@@ -189,7 +189,7 @@ def line_shared(p, x):
 CASES = {
     'quad_snooker': quad, 'quad_demc': quad, 'quad_mrw': quad,
     'quad_demc_eps_thin': quad, 'shared_priors_snooker': line_shared,
-    'wavelet_snooker': quad,
+    'wavelet_snooker': quad, 'quad_demc_priors': quad, 'quad_mrw_bounds': quad,
 }
 
 
