@@ -34,6 +34,8 @@ extern "C" {
 #define MC3HIP_ERR_STATE    -3   /* call sequence error (e.g. run before set_population) */
 #define MC3HIP_ERR_FULL     -4   /* Z buffer exhausted (chain.py:279 "stop when we fill Z") */
 #define MC3HIP_ERR_COMM     -5   /* RCCL error */
+#define MC3HIP_ERR_ABORTED  -6   /* peer-to-peer mode: a persistent launch gave up waiting for
+                                    another rank's rows; see mc3hip_p2p_rollback             */
 
 /* sampler: mc3/chain.py:195,219,221 */
 #define MC3HIP_MRW      0
@@ -102,6 +104,9 @@ typedef struct mc3hip_plan {
     int32_t fast;           /* 1: the lean persistent instance (one wave per chain, fully
                                free polynomial, Gaussian chisq, no priors/shared/epsilon);
                                2: its hand-laid-out DEMC / thinning = 1 loop (lean_demc_kernel) */
+    int32_t comm_graph;     /* >0: the RCCL exchange runs inside a hipGraph of that many
+                               refreshes (step kernel + all-gather + scatter per refresh)   */
+    int32_t recoveries;     /* persistent launches that gave up and were redone so far        */
 } mc3hip_plan;
 
 /* Replaces Chain.__init__ + the shared-memory allocation of mcmc()
@@ -216,6 +221,22 @@ int mc3hip_comm_gather_log_post(mc3hip_ctx *ctx);
 int mc3hip_p2p_export(mc3hip_ctx *ctx, void *handles_128);
 int mc3hip_p2p_attach(mc3hip_ctx *ctx, int32_t rank, int32_t nranks,
                       const void *all_handles /* [nranks][128] */);
+/* Undo mc3hip_p2p_attach (e.g. when it succeeded on some ranks only): unmaps the peers'
+ * replicas; the context is a single-rank / RCCL / host-staged context again. */
+int mc3hip_p2p_detach(mc3hip_ctx *ctx);
+/* Recovery of the peer-to-peer mode, the counterpart of what mc3hip_sync does by itself on
+ * one GPU.  When mc3hip_sync (or any read-back call) returned MC3HIP_ERR_ABORTED on ANY
+ * rank, every rank -- after all of them have synchronised and met at a barrier, so that
+ * nobody stores into a replica any more -- calls this: the per-chain state goes back to
+ * the checkpoint taken before the first unconfirmed run, the rows written since are
+ * discarded, the peer-to-peer hand-off is dropped, and [*from_refresh, *to_refresh) is
+ * what has to be redone through mc3hip_comm_init or the host-staged exchange
+ * (mc3hip_run + mc3hip_put_rows).  Contract that makes the checkpoint sufficient: in
+ * peer-to-peer mode a caller starts the next mc3hip_run only after all ranks agreed that
+ * the previous ones completed. */
+int mc3hip_p2p_rollback(mc3hip_ctx *ctx, int64_t *from_refresh, int64_t *to_refresh);
+/* Drop the RCCL communicator of mc3hip_comm_init (fall back to the host-staged exchange). */
+int mc3hip_comm_destroy(mc3hip_ctx *ctx);
 
 /* Self tests used by tests/ on the GPU: evaluate the shared deterministic
  * functions on the device (op: 0 exp, 1 log, 2 exp2, 3 sin2pi, 4 cos2pi,

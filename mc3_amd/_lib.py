@@ -17,7 +17,7 @@ _lp = ctypes.POINTER(ctypes.c_int64)
 _up = ctypes.POINTER(ctypes.c_uint32)
 
 OK = 0
-ERR_ARG, ERR_HIP, ERR_STATE, ERR_FULL, ERR_COMM = -1, -2, -3, -4, -5
+ERR_ARG, ERR_HIP, ERR_STATE, ERR_FULL, ERR_COMM, ERR_ABORTED = -1, -2, -3, -4, -5, -6
 MRW, DEMC, SNOOKER = 0, 1, 2
 MODEL_POLY, MODEL_LINEAR = 0, 1
 FLAG_NO_GRAPH = 1
@@ -52,7 +52,8 @@ class Plan(ctypes.Structure):
     _fields_ = [('vlanes', ctypes.c_int32), ('tile', ctypes.c_int32),
                 ('waves_per_chain', ctypes.c_int32),
                 ('graph_nodes', ctypes.c_int32),
-                ('persistent', ctypes.c_int32), ('fast', ctypes.c_int32)]
+                ('persistent', ctypes.c_int32), ('fast', ctypes.c_int32),
+                ('comm_graph', ctypes.c_int32), ('recoveries', ctypes.c_int32)]
 
 
 class Mc3HipError(RuntimeError):
@@ -91,6 +92,9 @@ SYMBOLS = {
     'mc3hip_comm_gather_log_post': (ctypes.c_int, [_vp]),
     'mc3hip_p2p_export': (ctypes.c_int, [_vp, _vp]),
     'mc3hip_p2p_attach': (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, _vp]),
+    'mc3hip_p2p_detach': (ctypes.c_int, [_vp]),
+    'mc3hip_p2p_rollback': (ctypes.c_int, [_vp, _lp, _lp]),
+    'mc3hip_comm_destroy': (ctypes.c_int, [_vp]),
     'mc3hip_debug_stamps': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
     'mc3hip_selftest_math': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, _dp, ctypes.c_int32, _dp]),
     'mc3hip_selftest_philox': (ctypes.c_int, [ctypes.c_int32, _up, ctypes.c_int32, _up, _up]),

@@ -75,6 +75,10 @@ struct DevProblem {
     double *sc_scal;              // [nlocal][2]       Metropolis draw u, Hastings factor
     int32_t *sc_flag;             // [nlocal]          bit0 out of bounds, bit1 snooker jump
     double *sc_part;              // [nlocal][ntiles]  per-tile data sums
+    // RCCL exchange inside a hipGraph: slot `roff` of this ring receives the rows of the
+    // refresh a graph node produced (fixed addresses, so the captured all-gather can be
+    // replayed); nullptr = off
+    double *xring;
 };
 
 constexpr int PH_FUSED = 0, PH_PROPOSE = 1, PH_FINISH = 2;
@@ -1499,10 +1503,65 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
 }
 
 // one Z refresh per launch (also the multi-GPU path: a collective follows each launch)
+// (multi-GPU, graph-captured exchange) this chain's new row also goes into slot `roff` of
+// the exchange ring, where the captured all-gather finds it at a fixed address.  The row of
+// a refresh is the chain's state at its end, which run_chain has just stored to P.X from
+// these very lanes.
+__device__ __forceinline__ void ring_out(const DevProblem &P, int roff)
+{
+    if (P.xring != nullptr && threadIdx.x < (unsigned)P.nfree)
+        P.xring[((size_t)roff * P.nchains + P.chain0 + blockIdx.x) * P.zs + threadIdx.x] =
+            P.X[(size_t)blockIdx.x * P.nfree + threadIdx.x];
+}
+
 template <int WPC, int MT, bool WL, bool MULTI>
 __global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, const int roff)
 {
     run_chain<WPC, MT, WL, MULTI, false>(P, P.ctl[0] + roff, 1);
+    ring_out(P, roff);
+}
+
+// after the all-gather: the other ranks' rows of ring slot `roff` go to their place in Z
+// (refresh ctl[0] + roff); own rows are already there
+__global__ void ring_in_kernel(const DevProblem P, const int roff)
+{
+    const size_t zs = (size_t)P.zs;
+    const double *src = P.xring + (size_t)roff * P.nchains * zs;
+    double *dst = P.Z + (size_t)(P.M0 + (P.ctl[0] + roff) * P.nchains) * zs;
+    const int nf = P.nfree;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.nchains * nf;
+         i += gridDim.x * blockDim.x) {
+        const int row = i / nf, k = i - row * nf;
+        if (row < P.chain0 || row >= P.chain0 + P.nlocal)
+            dst[(size_t)row * zs + k] = src[(size_t)row * zs + k];
+    }
+}
+
+// log_post of this rank's chains over refreshes [R0, R0+nref) -> dense [nref][nlocal]
+// (send buffer of ONE all-gather), and back from the gathered [nranks][nref][nlocal]
+__global__ void logpost_pack_kernel(const DevProblem P, long long R0, long long nref,
+                                    double *dense)
+{
+    const long long total = nref * P.nlocal;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / P.nlocal, lc = i - r * P.nlocal;
+        dense[i] = P.log_post[P.M0 + (R0 + r) * P.nchains + P.chain0 + lc];
+    }
+}
+
+__global__ void logpost_unpack_kernel(const DevProblem P, long long R0, long long nref,
+                                      const double *gathered)
+{
+    const long long total = nref * P.nchains;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / P.nchains, ch = i - r * P.nchains;
+        const long long rank = ch / P.nlocal, lc = ch - rank * P.nlocal;
+        if (rank != P.chain0 / P.nlocal)
+            P.log_post[P.M0 + (R0 + r) * P.nchains + ch] =
+                gathered[(rank * nref + r) * P.nlocal + lc];
+    }
 }
 
 // many Z refreshes per launch with in-launch hand-off of the new rows; every
@@ -1527,6 +1586,8 @@ __global__ __launch_bounds__(64) void finish_kernel(const DevProblem P, const in
                                                     const int j)
 {
     run_chain<1, MT, false, false, false, -1, false, PH_FINISH>(P, P.ctl[0] + roff, 1, j, j + 1);
+    if (j + 1 == P.thinning)
+        ring_out(P, roff);
 }
 
 // the lean instance (see run_chain): one wave per chain, MT free polynomial

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -148,10 +149,21 @@ struct mc3hip_ctx {
     int recoveries = 0;
     int tile_kmax = 0;              // tiled plan: coefficient capacity of the tile kernel
     int tile_chain_block = 0;       // chains per workgroup column of the tile kernel
+    bool ckpt_settled = false;      // peer-to-peer: the launches since the checkpoint completed
+                                    // HERE; confirmed by the caller's next mc3hip_run
+    double *moments = nullptr;      // scratch of mc3hip_chain_moments (2 x nchains x nfree)
     // comm
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     int64_t logpost_gathered = 0;   // refreshes whose log_post rows are already exchanged
+    // RCCL exchange captured in a hipGraph: per refresh (step kernel, all-gather of ring
+    // slot r, ring_in kernel) x comm_graph_nodes
+    double *xring = nullptr;
+    int comm_graph_nodes = 0;
+    hipGraph_t cgraph = nullptr;
+    hipGraphExec_t cgraph_exec = nullptr;
+    bool comm_graph_failed = false;
+    bool comm_warm = false;         // one eager collective has run (RCCL set up its channels)
     // peer-to-peer hand-off
     int p2p_ranks = 0;
     std::vector<void *> p2p_opened;
@@ -215,38 +227,6 @@ void launch_step_t(mc3hip_ctx *c, int roff)
     else
         hipLaunchKernelGGL((step_kernel<WPC, MT, false, false>), dim3(c->P.nlocal),
                            dim3(64 * WPC), c->smem, c->stream, c->P, roff);
-}
-
-template <int WPC, int MT>
-void launch_persist_p2p_t(mc3hip_ctx *c, int nref)
-{
-    if (c->P.wlike)
-        hipLaunchKernelGGL((persist_kernel<WPC, MT, true, false, true>), dim3(c->P.nlocal),
-                           dim3(64 * WPC), c->smem, c->stream, c->P, nref);
-    else if (c->P.npad > VLANES)
-        hipLaunchKernelGGL((persist_kernel<WPC, MT, false, true, true>), dim3(c->P.nlocal),
-                           dim3(64 * WPC), c->smem, c->stream, c->P, nref);
-    else
-        hipLaunchKernelGGL((persist_kernel<WPC, MT, false, false, true>), dim3(c->P.nlocal),
-                           dim3(64 * WPC), c->smem, c->stream, c->P, nref);
-}
-
-template <int WPC, int MT>
-void launch_persist_t(mc3hip_ctx *c, int nref)
-{
-    if (c->p2p_ranks > 1) {
-        launch_persist_p2p_t<WPC, MT>(c, nref);
-        return;
-    }
-    if (c->P.wlike)
-        hipLaunchKernelGGL((persist_kernel<WPC, MT, true, false>), dim3(c->P.nlocal),
-                           dim3(64 * WPC), c->smem, c->stream, c->P, nref);
-    else if (c->P.npad > VLANES)
-        hipLaunchKernelGGL((persist_kernel<WPC, MT, false, true>), dim3(c->P.nlocal),
-                           dim3(64 * WPC), c->smem, c->stream, c->P, nref);
-    else
-        hipLaunchKernelGGL((persist_kernel<WPC, MT, false, false>), dim3(c->P.nlocal),
-                           dim3(64 * WPC), c->smem, c->stream, c->P, nref);
 }
 
 template <int MT>
@@ -340,29 +320,6 @@ bool fast_eligible(const mc3hip_ctx *c)
            !getenv("MC3HIP_NO_FAST");
 }
 
-template <int MT, int SMP, bool P2P>
-void launch_fast_tt(mc3hip_ctx *c, int nref)
-{
-    if constexpr (!P2P) {
-        if (c->P.npad > VLANES) {                  // streamed tiles (plain, thinning = 1 only)
-            hipLaunchKernelGGL((persist_fast_kernel<MT, SMP, false, 1, false, true>),
-                               dim3(c->P.nlocal), dim3(64), c->smem, c->stream, c->P, nref);
-            return;
-        }
-        if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0) {   // FX
-            hipLaunchKernelGGL((persist_fast_kernel<MT, SMP, false, 1, true>),
-                               dim3(c->P.nlocal), dim3(64), c->smem, c->stream, c->P, nref);
-            return;
-        }
-    }
-    if (c->P.thinning == 1)
-        hipLaunchKernelGGL((persist_fast_kernel<MT, SMP, P2P, 1>), dim3(c->P.nlocal), dim3(64),
-                           c->smem, c->stream, c->P, nref);
-    else
-        hipLaunchKernelGGL((persist_fast_kernel<MT, SMP, P2P, 0>), dim3(c->P.nlocal), dim3(64),
-                           c->smem, c->stream, c->P, nref);
-}
-
 // the headline shape (DEMC, thinning 1) has a loop of its own: lean_demc_kernel
 bool lean_demc_eligible(const mc3hip_ctx *c)
 {
@@ -370,105 +327,103 @@ bool lean_demc_eligible(const mc3hip_ctx *c)
            c->P.nparams == c->mt && c->P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
 }
 
-template <int MT>
-void launch_fast_t(mc3hip_ctx *c, int nref)
+// The lean kernels all have the signature (DevProblem, int nref).  ONE function picks the
+// instance a context runs, so that the launch and the occupancy query that sizes the
+// persistent grid can never disagree (the MULTI / FX instances use more than twice the
+// registers of the plain ones: 4 single-wave workgroups per CU instead of 8).
+typedef void (*fast_kernel_fn)(const DevProblem, const int);
+
+template <int MT, int SMP>
+fast_kernel_fn fast_instance_tt(const mc3hip_ctx *c, bool p2p)
 {
-    const bool demc = c->P.sampler == MC3HIP_DEMC;
-    if (c->P.sampler == MC3HIP_MRW) {
-        if (c->p2p_ranks > 1)
-            launch_fast_tt<MT, MC3HIP_MRW, true>(c, nref);
-        else
-            launch_fast_tt<MT, MC3HIP_MRW, false>(c, nref);
-        return;
-    }
+    if (p2p)
+        return c->P.thinning == 1 ? persist_fast_kernel<MT, SMP, true, 1>
+                                  : persist_fast_kernel<MT, SMP, true, 0>;
+    if (c->P.npad > VLANES)                        // streamed tiles (plain, thinning = 1 only)
+        return persist_fast_kernel<MT, SMP, false, 1, false, true>;
+    if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)   // FX
+        return persist_fast_kernel<MT, SMP, false, 1, true>;
+    return c->P.thinning == 1 ? persist_fast_kernel<MT, SMP, false, 1>
+                              : persist_fast_kernel<MT, SMP, false, 0>;
+}
+
+template <int MT>
+fast_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
+{
+    if (c->P.sampler == MC3HIP_MRW)
+        return fast_instance_tt<MT, MC3HIP_MRW>(c, p2p);
     if (lean_demc_eligible(c)) {
-        if (c->p2p_ranks > 1)
-            hipLaunchKernelGGL((lean_demc_kernel<MT, true>), dim3(c->P.nlocal), dim3(64), 0,
-                               c->stream, c->P, nref);
-        else if (c->P.npad > VLANES)
-            hipLaunchKernelGGL((lean_demc_kernel<MT, false, false, true>), dim3(c->P.nlocal),
-                               dim3(64), 0, c->stream, c->P, nref);
-        else if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)
-            hipLaunchKernelGGL((lean_demc_kernel<MT, false, true>), dim3(c->P.nlocal), dim3(64),
-                               0, c->stream, c->P, nref);
-        else
-            hipLaunchKernelGGL((lean_demc_kernel<MT, false>), dim3(c->P.nlocal), dim3(64), 0,
-                               c->stream, c->P, nref);
-        return;
+        if (p2p)
+            return lean_demc_kernel<MT, true>;
+        if (c->P.npad > VLANES)
+            return lean_demc_kernel<MT, false, false, true>;
+        if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)
+            return lean_demc_kernel<MT, false, true>;
+        return lean_demc_kernel<MT, false>;
     }
-    if (c->p2p_ranks > 1) {
-        if (demc)
-            launch_fast_tt<MT, MC3HIP_DEMC, true>(c, nref);
-        else
-            launch_fast_tt<MT, MC3HIP_SNOOKER, true>(c, nref);
-    } else {
-        if (demc)
-            launch_fast_tt<MT, MC3HIP_DEMC, false>(c, nref);
-        else
-            launch_fast_tt<MT, MC3HIP_SNOOKER, false>(c, nref);
+    if (c->P.sampler == MC3HIP_DEMC)
+        return fast_instance_tt<MT, MC3HIP_DEMC>(c, p2p);
+    return fast_instance_tt<MT, MC3HIP_SNOOKER>(c, p2p);
+}
+
+fast_kernel_fn fast_instance(const mc3hip_ctx *c, bool p2p)
+{
+    switch (c->mt) {
+    case MT_POLY2: return fast_instance_t<MT_POLY2>(c, p2p);
+    case MT_POLY3: return fast_instance_t<MT_POLY3>(c, p2p);
+    default: return fast_instance_t<MT_POLY4>(c, p2p);
     }
+}
+
+// dynamic LDS of the lean kernels: the hand-laid-out loop uses none
+size_t fast_smem(const mc3hip_ctx *c)
+{
+    return (c->P.sampler != MC3HIP_MRW && lean_demc_eligible(c)) ? 0 : c->smem;
 }
 
 void launch_fast(mc3hip_ctx *c, int nref)
 {
-    switch (c->mt) {
-    case MT_POLY2: launch_fast_t<MT_POLY2>(c, nref); break;
-    case MT_POLY3: launch_fast_t<MT_POLY3>(c, nref); break;
-    default: launch_fast_t<MT_POLY4>(c, nref); break;
-    }
+    hipLaunchKernelGGL(fast_instance(c, c->p2p_ranks > 1), dim3(c->P.nlocal), dim3(64),
+                       fast_smem(c), c->stream, c->P, nref);
 }
 
-template <int MT>
-int fast_blocks_per_cu_t(mc3hip_ctx *c)
+int blocks_per_cu(const void *kernel, int threads, size_t smem)
 {
     int nb = 0;
-    // the least favourable instance (runtime thinning, peer-to-peer stores) sizes the grid
-    hipError_t e = (c->P.sampler == MC3HIP_DEMC)
-        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(
-              &nb, persist_fast_kernel<MT, MC3HIP_DEMC, true, 0>, 64, c->smem)
-        : (c->P.sampler == MC3HIP_MRW)
-        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(
-              &nb, persist_fast_kernel<MT, MC3HIP_MRW, true, 0>, 64, c->smem)
-        : hipOccupancyMaxActiveBlocksPerMultiprocessor(
-              &nb, persist_fast_kernel<MT, MC3HIP_SNOOKER, true, 0>, 64, c->smem);
-    if (e == hipSuccess && c->P.sampler == MC3HIP_DEMC) {
-        int nl = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nl, lean_demc_kernel<MT, true>, 64, 0);
-        nb = nl < nb ? nl : nb;
-    }
-    return e == hipSuccess ? nb : 0;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, smem) ==
+                   hipSuccess ? nb : 0;
 }
 
+// co-resident single-wave workgroups per CU of the instance that will run; a context
+// created for the peer-to-peer mode is sized for both its instances (it runs the plain
+// one until the peers are attached, and again after a roll-back)
 int fast_blocks_per_cu(mc3hip_ctx *c)
 {
-    switch (c->mt) {
-    case MT_POLY2: return fast_blocks_per_cu_t<MT_POLY2>(c);
-    case MT_POLY3: return fast_blocks_per_cu_t<MT_POLY3>(c);
-    default: return fast_blocks_per_cu_t<MT_POLY4>(c);
+    const bool p2p = c->p2p_ranks > 1;
+    int nb = blocks_per_cu(reinterpret_cast<const void *>(fast_instance(c, p2p)), 64,
+                           fast_smem(c));
+    if ((c->flags & MC3HIP_FLAG_P2P) && !p2p) {
+        const int np = blocks_per_cu(reinterpret_cast<const void *>(fast_instance(c, true)),
+                                     64, fast_smem(c));
+        nb = np < nb ? np : nb;
     }
+    return nb;
 }
 
-// workgroups of the persistent kernel that fit on one CU (0 on error)
+// workgroups of the general persistent kernel that fit on one CU (0 on error): the exact
+// instance (likelihood, tile count, peer-to-peer stores) that will be launched
 template <int WPC, int MT>
-void persist_blocks_per_cu_t(mc3hip_ctx *c, int *out)
+void persist_instance_t(mc3hip_ctx *c, bool p2p, fast_kernel_fn *out)
 {
-    int nb = 0;
-    hipError_t e;
-    if (c->P.wlike) {
-        if (c->smem > 64 * 1024)
-            (void)hipFuncSetAttribute(
-                reinterpret_cast<const void *>(&persist_kernel<WPC, MT, true, false>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->smem);
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &nb, persist_kernel<WPC, MT, true, false>, 64 * WPC, c->smem);
-    } else if (c->P.npad > VLANES) {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &nb, persist_kernel<WPC, MT, false, true>, 64 * WPC, c->smem);
-    } else {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &nb, persist_kernel<WPC, MT, false, false>, 64 * WPC, c->smem);
-    }
-    *out = (e == hipSuccess) ? nb : 0;
+    fast_kernel_fn f;
+    if (c->P.wlike)
+        f = p2p ? persist_kernel<WPC, MT, true, false, true> : persist_kernel<WPC, MT, true, false>;
+    else if (c->P.npad > VLANES)
+        f = p2p ? persist_kernel<WPC, MT, false, true, true> : persist_kernel<WPC, MT, false, true>;
+    else
+        f = p2p ? persist_kernel<WPC, MT, false, false, true>
+                : persist_kernel<WPC, MT, false, false>;
+    *out = f;
 }
 
 template <int WPC, int MT>
@@ -507,8 +462,36 @@ void launch_model_t(mc3hip_ctx *c)
     }
 
 void launch_step_fused(mc3hip_ctx *c, int roff) { DISPATCH(launch_step_t, c, roff) }
-void launch_persist(mc3hip_ctx *c, int nref) { DISPATCH(launch_persist_t, c, nref) }
-void persist_blocks_per_cu(mc3hip_ctx *c, int *out) { DISPATCH(persist_blocks_per_cu_t, c, out) }
+fast_kernel_fn persist_instance(mc3hip_ctx *c, bool p2p)
+{
+    fast_kernel_fn f = nullptr;
+    DISPATCH(persist_instance_t, c, p2p, &f)
+    return f;
+}
+
+void launch_persist(mc3hip_ctx *c, int nref)
+{
+    hipLaunchKernelGGL(persist_instance(c, c->p2p_ranks > 1), dim3(c->P.nlocal),
+                       dim3(64 * c->wpc), c->smem, c->stream, c->P, nref);
+}
+
+void persist_blocks_per_cu(mc3hip_ctx *c, int *out)
+{
+    const bool p2p = c->p2p_ranks > 1;
+    const void *f = reinterpret_cast<const void *>(persist_instance(c, p2p));
+    if (c->smem > 64 * 1024)
+        (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->smem);
+    int nb = blocks_per_cu(f, 64 * c->wpc, c->smem);
+    if ((c->flags & MC3HIP_FLAG_P2P) && !p2p) {
+        const void *g = reinterpret_cast<const void *>(persist_instance(c, true));
+        if (c->smem > 64 * 1024)
+            (void)hipFuncSetAttribute(g, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)c->smem);
+        const int np = blocks_per_cu(g, 64 * c->wpc, c->smem);
+        nb = np < nb ? np : nb;
+    }
+    *out = nb;
+}
 
 void launch_step(mc3hip_ctx *c, int roff)
 {
@@ -986,6 +969,10 @@ void mc3hip_destroy(mc3hip_ctx *c)
         (void)hipGraphExecDestroy(c->graph_exec);
     if (c->graph)
         (void)hipGraphDestroy(c->graph);
+    if (c->cgraph_exec)
+        (void)hipGraphExecDestroy(c->cgraph_exec);
+    if (c->cgraph)
+        (void)hipGraphDestroy(c->cgraph);
     for (void *p : c->allocs)
         (void)hipFree(p);
     if (c->stage)
@@ -1009,6 +996,8 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
     plan->graph_nodes = c->graph_nodes;
     plan->persistent = c->comm ? 0 : decide_persist(const_cast<mc3hip_ctx *>(c));
     plan->fast = (plan->persistent > 0 && c->fast) ? (lean_demc_eligible(c) ? 2 : 1) : 0;
+    plan->comm_graph = c->cgraph_exec ? c->comm_graph_nodes : 0;
+    plan->recoveries = c->recoveries;
     return MC3HIP_OK;
 }
 
@@ -1065,6 +1054,62 @@ static int checkpoint_copy(mc3hip_ctx *c, bool save)
 
 static int build_graph(mc3hip_ctx *c);
 
+// RCCL exchange inside a hipGraph (multi-GPU fallback path): `comm_graph_nodes` refreshes
+// per replay, each one (step kernel -> ring slot r) + (in-place ncclAllGather of slot r)
+// + (ring_in kernel: the peers' rows to their place in Z).  The all-gather's buffers must
+// have fixed addresses to be replayed, hence the ring instead of Z itself.  A failure to
+// capture (an RCCL build that cannot) demotes the context to eager launches, once.
+static int build_comm_graph(mc3hip_ctx *c)
+{
+    const size_t zs = (size_t)c->P.zs, slot = (size_t)c->P.nchains * zs;
+    int G = c->graph_nodes;
+    const size_t cap = (size_t(256) << 20) / (slot * sizeof(double));   // ring <= 256 MiB
+    if ((size_t)G > cap)
+        G = (int)cap;
+    if (G < 2) {
+        c->comm_graph_failed = true;
+        return MC3HIP_OK;
+    }
+    if (!c->xring) {
+        void *p = nullptr;
+        HIP_TRY(hipMalloc(&p, (size_t)G * slot * sizeof(double)));
+        c->allocs.push_back(p);
+        c->xring = static_cast<double *>(p);
+    }
+    c->P.xring = c->xring;
+    bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+    if (ok) {
+        const int nb = (c->P.nchains * c->P.nfree + 255) / 256;
+        for (int r = 0; r < G && ok; ++r) {
+            launch_step(c, r);
+            double *base = c->xring + (size_t)r * slot;
+            ok = g_rccl.AllGather(base + (size_t)c->P.chain0 * zs, base,
+                                  (size_t)c->P.nlocal * zs, NCCL_FLOAT64, c->comm,
+                                  c->stream) == 0;
+            hipLaunchKernelGGL(ring_in_kernel, dim3(nb > 64 ? 64 : nb), dim3(256), 0, c->stream,
+                               c->P, r);
+        }
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(c->stream, &g);   // always ends the capture
+        ok = ok && e == hipSuccess && g != nullptr;
+        if (ok)
+            ok = hipGraphInstantiate(&c->cgraph_exec, g, nullptr, nullptr, 0) == hipSuccess;
+        if (ok)
+            c->cgraph = g;
+        else if (g)
+            (void)hipGraphDestroy(g);
+    }
+    c->P.xring = nullptr;           // eager launches exchange in place in Z
+    if (!ok) {
+        (void)hipGetLastError();
+        c->comm_graph_failed = true;
+        c->cgraph_exec = nullptr;
+        return MC3HIP_OK;
+    }
+    c->comm_graph_nodes = G;
+    return MC3HIP_OK;
+}
+
 // refreshes [R, Rend) through one launch per refresh (hipGraph batches + eager tail)
 static int enqueue_per_refresh(mc3hip_ctx *c, int64_t R, int64_t Rend, long long run0)
 {
@@ -1075,25 +1120,42 @@ static int enqueue_per_refresh(mc3hip_ctx *c, int64_t R, int64_t Rend, long long
         if (rc)
             return rc;
     }
+    const bool want_cgraph = c->graph_nodes > 0 && c->comm != nullptr && !c->comm_graph_failed;
     while (R < Rend) {
-        const int64_t left = Rend - R;
+        int64_t left = Rend - R;
         hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl, (long long)R,
                            first ? run0 : -1LL);
+        first = false;
         if (use_graph && left >= c->graph_nodes) {
             HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
             R += c->graph_nodes;
-        } else {
-            for (int64_t r = 0; r < left; ++r) {
-                launch_step(c, (int)r);
-                if (c->comm) {
-                    int rc = exchange_rows(c, R + r);
-                    if (rc)
-                        return rc;
-                }
-            }
-            R += left;
+            continue;
         }
-        first = false;
+        if (want_cgraph && c->comm_warm && !c->cgraph_exec && !c->comm_graph_failed &&
+            left >= 2) {
+            int rc = build_comm_graph(c);
+            if (rc)
+                return rc;
+        }
+        if (c->cgraph_exec && left >= c->comm_graph_nodes) {
+            HIP_TRY(hipGraphLaunch(c->cgraph_exec, c->stream));
+            R += c->comm_graph_nodes;
+            continue;
+        }
+        // eager: the whole remainder, or -- before the first capture -- one refresh, whose
+        // collective lets RCCL set up its channels outside the capture
+        if (want_cgraph && !c->comm_warm)
+            left = 1;
+        for (int64_t r = 0; r < left; ++r) {
+            launch_step(c, (int)r);
+            if (c->comm) {
+                int rc = exchange_rows(c, R + r);
+                if (rc)
+                    return rc;
+                c->comm_warm = true;
+            }
+        }
+        R += left;
     }
     HIP_TRY(hipGetLastError());
     return MC3HIP_OK;
@@ -1112,13 +1174,20 @@ static int settle(mc3hip_ctx *c)
     long long ab = 0;
     HIP_TRY(hipMemcpy(&ab, c->ctl + CTL_ABORT, sizeof ab, hipMemcpyDeviceToHost));
     if (ab == 0) {
-        c->ckpt_valid = false;
+        // single GPU: the launches since the checkpoint are complete.  Peer-to-peer: complete
+        // HERE; another rank may have given up, so the checkpoint stays until the caller,
+        // having agreed with the other ranks, starts the next run
+        if (c->p2p_ranks > 1)
+            c->ckpt_settled = true;
+        else
+            c->ckpt_valid = false;
         return MC3HIP_OK;
     }
     if (c->p2p_ranks > 1)
-        return fail(MC3HIP_ERR_STATE,
-                    "persistent kernel: a wait for another rank's Z row timed out; the "
-                    "peer-to-peer run is incomplete on every rank");
+        return fail(MC3HIP_ERR_ABORTED,
+                    "persistent kernel: a wait for another rank's Z row timed out; every "
+                    "rank must roll back (mc3hip_p2p_rollback) and redo refreshes [%lld,%lld)",
+                    (long long)c->ckpt_R, (long long)c->refresh_done);
     if (!c->ckpt_valid)
         return fail(MC3HIP_ERR_STATE, "persistent kernel gave up and no checkpoint is pending");
     const DevProblem &P = c->P;
@@ -1177,12 +1246,13 @@ int mc3hip_run(mc3hip_ctx *c, int64_t nrefresh)
     c->last_run0 = run0;
     const int persist = c->comm ? 0 : decide_persist(c);
     if (persist > 0) {
-        if (!c->ckpt_valid && c->p2p_ranks <= 1) {
+        if (!c->ckpt_valid || c->ckpt_settled) {
             int rc = checkpoint_copy(c, true);
             if (rc)
                 return rc;
             c->ckpt_R = R;
             c->ckpt_valid = true;
+            c->ckpt_settled = false;
         }
         bool first = true;
         while (R < Rend) {
@@ -1345,9 +1415,9 @@ int mc3hip_chain_moments(mc3hip_ctx *c, int64_t burn, double *mean, double *var)
             return rc_settle;
     }
     const size_t n = (size_t)c->P.nchains * (size_t)c->P.nfree;
-    double *dm = nullptr, *dv = nullptr;
-    HIP_TRY(hipMalloc(&dm, 2 * n * sizeof(double)));
-    dv = dm + n;
+    if (!c->moments)
+        RC_TRY(dev_alloc(c, &c->moments, 2 * n));       // freed with the context
+    double *dm = c->moments, *dv = dm + n;
     hipLaunchKernelGGL(chain_moments_kernel, dim3(c->P.nchains), dim3(256), 0, c->stream,
                        (const double *)c->P.Z, (long long)c->P.M0, c->P.nchains, c->P.nfree,
                        c->P.zs, (long long)c->refresh_done, (long long)burn, dm, dv);
@@ -1358,7 +1428,6 @@ int mc3hip_chain_moments(mc3hip_ctx *c, int64_t burn, double *mean, double *var)
         e = hipMemcpyAsync(var, dv, n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess)
         e = hipStreamSynchronize(c->stream);
-    (void)hipFree(dm);
     if (e != hipSuccess)
         return fail(MC3HIP_ERR_HIP, "chain_moments: %s", hipGetErrorString(e));
     return MC3HIP_OK;
@@ -1458,24 +1527,59 @@ int mc3hip_dwt_daub4(int32_t device, const double *in, int32_t n, int32_t invers
 
 namespace {
 
-// device buffers of one standalone call, released on scope exit
+// Device buffers of one standalone call, carved out of a per-device arena that is kept
+// between calls (grow-only up to 256 MiB; a larger one is released when the call ends), so
+// that mc3hip_chisq / residuals / dwt_chisq on small arrays pay for their copies and
+// launches, not for allocations.  Calls on one device serialise on the arena's lock.
+struct Arena {
+    std::mutex lock;
+    void *base = nullptr;
+    size_t bytes = 0;
+};
+Arena g_arena[64];
+
 struct Scratch {
-    std::vector<void *> ptrs;
+    Arena *a = nullptr;
+    size_t used = 0;
+    // total_doubles: an upper bound of everything up() will be asked for
+    Scratch(int device, size_t total_doubles, int nbuffers, hipError_t *e)
+    {
+        a = &g_arena[(device >= 0 && device < 64) ? device : 0];
+        a->lock.lock();
+        const size_t need = (total_doubles + 32 * (size_t)nbuffers + 32) * sizeof(double);
+        if (need > a->bytes) {
+            if (a->base)
+                (void)hipFree(a->base);
+            a->base = nullptr;
+            a->bytes = 0;
+            *e = hipMalloc(&a->base, need);
+            if (*e == hipSuccess)
+                a->bytes = need;
+        }
+    }
     ~Scratch()
     {
-        for (void *p : ptrs)
-            (void)hipFree(p);
+        if (a->bytes > (size_t(256) << 20)) {
+            (void)hipFree(a->base);
+            a->base = nullptr;
+            a->bytes = 0;
+        }
+        a->lock.unlock();
     }
     double *up(const double *src, size_t n, hipError_t *e)
     {
-        void *p = nullptr;
-        if (*e == hipSuccess)
-            *e = hipMalloc(&p, (n ? n : 1) * sizeof(double));
-        if (*e == hipSuccess)
-            ptrs.push_back(p);
-        if (*e == hipSuccess && src && n)
+        if (*e != hipSuccess)
+            return nullptr;
+        const size_t bytes = ((n ? n : 1) * sizeof(double) + 255) & ~size_t(255);
+        if (used + bytes > a->bytes) {
+            *e = hipErrorOutOfMemory;
+            return nullptr;
+        }
+        double *p = reinterpret_cast<double *>(static_cast<char *>(a->base) + used);
+        used += bytes;
+        if (src && n)
             *e = hipMemcpy(p, src, n * sizeof(double), hipMemcpyHostToDevice);
-        return static_cast<double *>(p);
+        return p;
     }
 };
 
@@ -1501,8 +1605,8 @@ int mc3hip_residuals(int32_t device, const double *model, const double *data,
     if (n + np == 0)
         return MC3HIP_OK;
     HIP_TRY(hipSetDevice(device));
-    Scratch S;
     hipError_t e = hipSuccess;
+    Scratch S(device, 4 * ((size_t)n + np), 7, &e);
     double *dm = S.up(model, n, &e), *dd = S.up(data, n, &e), *du = S.up(uncert, n, &e);
     double *dof = S.up(off, np, &e), *dlo = S.up(plow, np, &e), *dup = S.up(pup, np, &e);
     double *dout = S.up(nullptr, (size_t)n + np, &e);
@@ -1528,8 +1632,8 @@ int mc3hip_chisq(int32_t device, const double *model, const double *data, const 
         (np > 0 && (!off || !plow || !pup)))
         return fail(MC3HIP_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(device));
-    Scratch S;
     hipError_t e = hipSuccess;
+    Scratch S(device, 4 * (size_t)n + 1, 5, &e);
     double *dm = S.up(model, n, &e), *dd = S.up(data, n, &e), *du = S.up(uncert, n, &e);
     double *dres = S.up(nullptr, n, &e), *dout = S.up(nullptr, 1, &e);
     double total = 0.0;
@@ -1577,8 +1681,8 @@ int mc3hip_dwt_chisq(int32_t device, const double *params, int32_t nparams, cons
         inv[m] = 1.0 / sW2;
         Lg = Lg + (double)(1 << m) * mc3_det_log(6.283185307179586 * sW2);
     }
-    Scratch S;
     hipError_t e = hipSuccess;
+    Scratch S(device, 4 * (size_t)n + 33, 6, &e);
     double *dm = S.up(model, n, &e), *dd = S.up(data, n, &e), *dinv = S.up(inv.data(), 32, &e);
     double *dres = S.up(nullptr, n, &e), *dtmp = S.up(nullptr, n, &e), *dout = S.up(nullptr, 1, &e);
     double T = 0.0, head[2] = {0.0, 0.0};
@@ -1716,6 +1820,14 @@ int mc3hip_p2p_attach(mc3hip_ctx *c, int32_t rank, int32_t nranks, const void *a
     c->P.npeers = nranks;
     c->P.rank = rank;
     c->p2p_ranks = nranks;
+    // the grid must be co-resident for the instance that stores to the peers
+    c->persist_checked = false;
+    if (decide_persist(c) <= 0) {
+        (void)mc3hip_p2p_detach(c);
+        return fail(MC3HIP_ERR_STATE,
+                    "the peer-to-peer instance of the persistent kernel cannot keep %d "
+                    "workgroups resident", c->P.nlocal);
+    }
     return MC3HIP_OK;
 }
 
@@ -1726,17 +1838,108 @@ int mc3hip_comm_gather_log_post(mc3hip_ctx *c)
     if (!c->comm)
         return MC3HIP_OK;
     HIP_TRY(hipSetDevice(c->device));
-    // log_post rows are not needed by proposals, so they are exchanged lazily:
-    // one in-place all-gather per not-yet-exchanged refresh
-    for (int64_t R = c->logpost_gathered; R < c->refresh_done; ++R) {
-        double *base = c->P.log_post + (size_t)(c->P.M0 + R * c->P.nchains);
-        int rc = g_rccl.AllGather(base + c->P.chain0, base, (size_t)c->P.nlocal, NCCL_FLOAT64,
-                                  c->comm, c->stream);
+    // log_post rows are not needed by proposals, so they are exchanged lazily, and in bulk:
+    // this rank's entries of all not-yet-exchanged refreshes are packed into one dense
+    // buffer, ONE all-gather moves everybody's, a kernel scatters them (chunked by the
+    // staging buffer: 64 MiB hold half a million refreshes of C3)
+    const DevProblem &P = c->P;
+    const size_t per_ref = (size_t)P.nlocal + (size_t)P.nchains;
+    const int64_t chunk = (int64_t)(STAGE_MAX_DOUBLES / per_ref ? STAGE_MAX_DOUBLES / per_ref : 1);
+    for (int64_t R = c->logpost_gathered; R < c->refresh_done; R += chunk) {
+        const int64_t n = c->refresh_done - R < chunk ? c->refresh_done - R : chunk;
+        RC_TRY(stage_reserve(c, (size_t)n * per_ref));
+        double *send = c->stage, *recv = c->stage + (size_t)n * P.nlocal;
+        const int nb = (int)(((size_t)n * P.nchains + 255) / 256 < 2048
+                                 ? ((size_t)n * P.nchains + 255) / 256 : 2048);
+        hipLaunchKernelGGL(logpost_pack_kernel, dim3(nb), dim3(256), 0, c->stream, P,
+                           (long long)R, (long long)n, send);
+        int rc = g_rccl.AllGather(send, recv, (size_t)n * P.nlocal, NCCL_FLOAT64, c->comm,
+                                  c->stream);
         if (rc != 0)
             return fail(MC3HIP_ERR_COMM, "ncclAllGather(log_post) failed (%d)", rc);
+        hipLaunchKernelGGL(logpost_unpack_kernel, dim3(nb), dim3(256), 0, c->stream, P,
+                           (long long)R, (long long)n, (const double *)recv);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));      // the staging buffer is reused
     }
     c->logpost_gathered = c->refresh_done;
+    return MC3HIP_OK;
+}
+
+int mc3hip_comm_destroy(mc3hip_ctx *c)
+{
+    if (!c)
+        return fail(MC3HIP_ERR_ARG, "null context");
+    if (!c->comm)
+        return MC3HIP_OK;
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->cgraph_exec)
+        (void)hipGraphExecDestroy(c->cgraph_exec);
+    if (c->cgraph)
+        (void)hipGraphDestroy(c->cgraph);
+    c->cgraph_exec = nullptr;
+    c->cgraph = nullptr;
+    c->comm_graph_nodes = 0;
+    if (g_rccl.CommDestroy)
+        g_rccl.CommDestroy(c->comm);
+    c->comm = nullptr;
+    c->comm_warm = false;
+    c->nranks = 1;
+    return MC3HIP_OK;
+}
+
+int mc3hip_p2p_detach(mc3hip_ctx *c)
+{
+    if (!c)
+        return fail(MC3HIP_ERR_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (void *p : c->p2p_opened)
+        (void)hipIpcCloseMemHandle(p);
+    c->p2p_opened.clear();
+    c->p2p_ranks = 0;
+    c->P.npeers = 0;
+    c->P.peerZ = nullptr;
+    c->P.peerLP = nullptr;
+    c->persist_checked = false;         // sized again for the instance that will run
+    return MC3HIP_OK;
+}
+
+int mc3hip_p2p_rollback(mc3hip_ctx *c, int64_t *from_refresh, int64_t *to_refresh)
+{
+    if (!c || !from_refresh || !to_refresh)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    if (!(c->flags & MC3HIP_FLAG_P2P))
+        return fail(MC3HIP_ERR_STATE, "context was not created with MC3HIP_FLAG_P2P");
+    if (!c->ckpt_valid)
+        return fail(MC3HIP_ERR_STATE, "no checkpoint is pending: nothing to roll back to");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const DevProblem &P = c->P;
+    const size_t row0 = (size_t)(P.M0 + c->ckpt_R * P.nchains);
+    const size_t nrows = (size_t)((c->refresh_done - c->ckpt_R) * P.nchains);
+    RC_TRY(checkpoint_copy(c, false));
+    // the caller guarantees that every rank's kernels have ended: nobody stores here any more
+    HIP_TRY(hipMemsetAsync(P.Z + row0 * (size_t)P.zs, 0xff,
+                           nrows * (size_t)P.zs * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(P.zchain + row0, 0xff, nrows * sizeof(int32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(P.log_post + row0, 0, nrows * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(c->ctl + CTL_ABORT, 0, sizeof(long long), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *from_refresh = c->ckpt_R;
+    *to_refresh = c->refresh_done;
+    c->refresh_done = c->ckpt_R;
+    c->ckpt_valid = false;
+    c->ckpt_settled = false;
+    c->recoveries += 1;
+    // the peers stay mapped until the context goes, but are no longer stored to: from here
+    // on the context runs one launch per refresh with an explicit exchange
+    c->p2p_ranks = 0;
+    c->P.npeers = 0;
+    c->persist_refs = 0;
+    c->persist_checked = true;
+    c->fast = false;
     return MC3HIP_OK;
 }
 
@@ -1759,16 +1962,18 @@ int mc3hip_selftest_math(int32_t device, int32_t op, const double *in, int32_t n
     if (!in || !out || n < 1)
         return fail(MC3HIP_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(device));
-    double *di = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc(&di, (size_t)n * sizeof(double)));
-    HIP_TRY(hipMalloc(&dout, (size_t)n * sizeof(double)));
-    HIP_TRY(hipMemcpy(di, in, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(selftest_math_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op,
-                       (const double *)di, n, dout);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, dout, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(di);
-    (void)hipFree(dout);
+    hipError_t e = hipSuccess;
+    Scratch S(device, 2 * (size_t)n, 2, &e);       // released on every way out
+    double *di = S.up(in, (size_t)n, &e), *dout = S.up(nullptr, (size_t)n, &e);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(selftest_math_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op,
+                           (const double *)di, n, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpy(out, dout, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        return fail(MC3HIP_ERR_HIP, "selftest_math: %s", hipGetErrorString(e));
     return MC3HIP_OK;
 }
 
@@ -1778,16 +1983,20 @@ int mc3hip_selftest_philox(int32_t device, const uint32_t *ctr, int32_t n, const
     if (!ctr || !out || !key || n < 1)
         return fail(MC3HIP_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(device));
-    uint32_t *dc = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc(&dc, (size_t)n * 16));
-    HIP_TRY(hipMalloc(&dout, (size_t)n * 16));
-    HIP_TRY(hipMemcpy(dc, ctr, (size_t)n * 16, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(selftest_philox_kernel, dim3((n + 255) / 256), dim3(256), 0, 0,
-                       (const uint32_t *)dc, n, key[0], key[1], dout);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, dout, (size_t)n * 16, hipMemcpyDeviceToHost));
-    (void)hipFree(dc);
-    (void)hipFree(dout);
+    hipError_t e = hipSuccess;
+    Scratch S(device, 4 * (size_t)n, 2, &e);       // (16 bytes per counter = 2 doubles)
+    uint32_t *dc = reinterpret_cast<uint32_t *>(
+        S.up(reinterpret_cast<const double *>(ctr), (size_t)n * 2, &e));
+    uint32_t *dout = reinterpret_cast<uint32_t *>(S.up(nullptr, (size_t)n * 2, &e));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(selftest_philox_kernel, dim3((n + 255) / 256), dim3(256), 0, 0,
+                           (const uint32_t *)dc, n, key[0], key[1], dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpy(out, dout, (size_t)n * 16, hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        return fail(MC3HIP_ERR_HIP, "selftest_philox: %s", hipGetErrorString(e));
     return MC3HIP_OK;
 }
 

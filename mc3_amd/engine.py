@@ -114,7 +114,8 @@ class DeviceChains:
         return {'vlanes': plan.vlanes, 'tile': plan.tile,
                 'waves_per_chain': plan.waves_per_chain,
                 'graph_nodes': plan.graph_nodes,
-                'persistent': plan.persistent, 'fast': plan.fast}
+                'persistent': plan.persistent, 'fast': plan.fast,
+                'comm_graph': plan.comm_graph, 'recoveries': plan.recoveries}
 
     # -- lifetime --------------------------------------------------------------
     def close(self):
@@ -263,6 +264,20 @@ class DeviceChains:
 
     def comm_gather_log_post(self):
         check(self.lib.mc3hip_comm_gather_log_post(self._ctx))
+
+    def comm_destroy(self):
+        check(self.lib.mc3hip_comm_destroy(self._ctx))
+
+    def p2p_detach(self):
+        check(self.lib.mc3hip_p2p_detach(self._ctx))
+
+    def p2p_rollback(self):
+        """After a peer-to-peer launch gave up on any rank (and every rank has
+        synchronised): back to the checkpoint; returns the refreshes [r0, r1) to redo
+        through another exchange."""
+        r0, r1 = ctypes.c_int64(), ctypes.c_int64()
+        check(self.lib.mc3hip_p2p_rollback(self._ctx, ctypes.byref(r0), ctypes.byref(r1)))
+        return int(r0.value), int(r1.value)
 
 
 def comm_unique_id():

@@ -275,7 +275,9 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
                 comm.exchange(engine, done)
                 done += 1
         else:
-            engine.run(todo)
+            # (not waited for here: snapshot() synchronises -- and, on several GPUs,
+            # is where the ranks agree that the segment completed everywhere)
+            engine.run(todo, sync=False)
             done = int(edge)
         nrows = snapshot()
         log.progressbar((nrows + 1.0 - pre_zsize)/(nzchain*nchains))

@@ -31,6 +31,10 @@ class SingleRank:
     native = False
     mode = 'single'
     wants_p2p = False
+    recoveries = 0
+
+    def barrier(self):
+        pass
 
     def quiesce(self, engine):
         pass
@@ -67,6 +71,7 @@ class TorchDistComm:
         self.wants_p2p = bool(use_p2p) and self.size > 1
         self.native = False
         self.mode = 'host'
+        self.recoveries = 0
 
     def _all_ok(self, ok):
         """True iff every rank reports success."""
@@ -81,17 +86,22 @@ class TorchDistComm:
         n = nchains//self.size
         return self.rank*n, n
 
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
     def broadcast(self, obj):
         box = [obj if self.rank == 0 else None]
         self.dist.broadcast_object_list(box, src=0, group=self.group)
         return box[0]
 
     def setup(self, engine):
-        """RCCL inside the library when the engine offers it, else host-staged."""
+        """Choose the exchange: peer-to-peer hand-off, else RCCL inside the library,
+        else host-staged.  Every step is put to the vote (``_all_ok``): either all
+        ranks take it or all fall through together, so no rank is ever left waiting
+        in a collective for peers that went another way."""
         if self.size == 1:
             return
         if self.wants_p2p and hasattr(engine, 'p2p_export'):
-            # every rank must succeed at every step, or all fall back together
             handle, ok = None, False
             try:
                 if engine.plan.get('persistent', 0) > 0:
@@ -114,18 +124,38 @@ class TorchDistComm:
                             ok = False
                     self.dist.barrier(group=self.group)
                 if self._all_ok(ok):
-                    self.dist.barrier(group=self.group)   # every replica is ready
                     self.native = True
                     self.mode = 'p2p'
                     return
                 if ok:
-                    raise RuntimeError('peer-to-peer attach succeeded on some ranks only')
-        if self.use_rccl and hasattr(engine, 'comm_init'):
-            from . import engine as eng
-            uid = self.broadcast(eng.comm_unique_id() if self.rank == 0 else None)
+                    engine.p2p_detach()       # attached here, not everywhere: undo
+                self.dist.barrier(group=self.group)
+        self._setup_rccl(engine)
+
+    def _setup_rccl(self, engine):
+        """RCCL communicator inside the library, by consensus; host-staged otherwise."""
+        self.native = False
+        self.mode = 'host'
+        if not (self.use_rccl and hasattr(engine, 'comm_init')):
+            return
+        from . import engine as eng
+        uid, ok = None, True
+        try:
+            uid = eng.comm_unique_id()        # (also proves librccl loads on this rank)
+        except Exception:
+            ok = False
+        if not self._all_ok(ok):
+            return
+        uid = self.broadcast(uid)
+        try:
             engine.comm_init(uid, self.rank, self.size)
+        except Exception:
+            ok = False
+        if self._all_ok(ok):
             self.native = True
             self.mode = 'rccl'
+        elif ok:
+            engine.comm_destroy()
 
     def exchange(self, engine, refresh):
         """Make the rows of ``refresh`` complete on every rank."""
@@ -145,12 +175,40 @@ class TorchDistComm:
             engine.put_rows(row0 + r*n, a[:, :-1], a[:, -1])
 
     def quiesce(self, engine):
-        """After this, the rows of every completed refresh are in the local
-        replica: with peer-to-peer stores the other ranks may still be writing
-        when the local kernel has finished."""
+        """After this, the rows of every completed refresh are in the local replica
+        on every rank.  With peer-to-peer stores the other ranks may still be writing
+        when the local kernel has finished, and a launch may have given up on some
+        rank (a wait for a peer's row timed out): the ranks vote, and if anybody
+        failed everybody rolls back to the checkpoint and redoes the lost refreshes
+        through RCCL or the host -- the multi-GPU counterpart of what the library
+        does by itself on one GPU (mc3hip_sync)."""
         if self.size > 1 and self.mode == 'p2p':
+            from ._lib import Mc3HipError, ERR_ABORTED
+            ok = True
+            try:
+                engine.sync()
+            except Mc3HipError as err:
+                if err.code != ERR_ABORTED:
+                    raise
+                ok = False
+            if not self._all_ok(ok):          # (the vote is also the barrier)
+                self.recover(engine)
+
+    def recover(self, engine):
+        """Every rank: kernels have ended (sync was attempted) and the vote has been
+        taken, so nobody stores into a replica any more."""
+        r0, r1 = engine.p2p_rollback()
+        self.recoveries += 1
+        self.dist.barrier(group=self.group)
+        self._setup_rccl(engine)
+        if self.native:
+            engine.run(r1 - r0)
             engine.sync()
-            self.dist.barrier(group=self.group)
+        else:
+            for R in range(r0, r1):
+                engine.run(1)
+                self.exchange(engine, R)
+        self.dist.barrier(group=self.group)
 
     def finish(self, engine):
         """Complete what the per-refresh exchange leaves out (log_post rows on

@@ -1,12 +1,16 @@
 """sample(): mc3's user-facing driver with the chains on an MI355X.
 
-Same signature, defaults, argument checks, error messages and output
-dictionary as ``mc3.sample`` (mc3/sampler_driver.py:25-601); the call to
-``mcmc()`` at :448-457 goes to mc3_amd.mcmc_driver.mcmc.  What is outside the
-hot path is NOT re-implemented: the least-squares pre-fit (``leastsq``), plots,
-themes and the text summary file are delegated to an installed ``mc3`` when one
-is importable, and refused / skipped with a clear message otherwise
-(SURVEY.md section 2).
+Same signature, defaults, error messages and output dictionary as ``mc3.sample``
+(mc3/sampler_driver.py:25-601); the call to ``mcmc()`` at :448-457 goes to
+mc3_amd.mcmc_driver.mcmc.  What is outside the hot path is NOT re-implemented:
+the least-squares pre-fit (``leastsq`` / ``chisqscale``, SciPy-bound, mc3/fit_driver.py)
+is refused with one message, plots are skipped with a warning, parameter / data files
+are not read.
+
+Layout: the argument handling is a pipeline of small normalisers over one
+``_Inputs`` record, each stating the rule of the reference it implements; only the
+error texts (which the reference's tests match on, tests/test_mcmc.py:328-409) are
+shared with it.
 """
 import importlib
 import os
@@ -20,13 +24,137 @@ from .mcmc_driver import mcmc
 
 __all__ = ['sample']
 
+SAMPLERS = ['mrw', 'demc', 'snooker']
 
-def _reference():
-    try:
-        import mc3
-        return mc3
-    except Exception:
-        return None
+
+class _Inputs:
+    """The array-valued arguments of sample() on their way to mcmc()."""
+    __slots__ = ('data', 'uncert', 'params', 'pmin', 'pmax', 'pstep', 'prior',
+                 'priorlow', 'priorup', 'pnames', 'texnames')
+
+
+def _require(log, **named):
+    """'x' is a required argument -- in the order given."""
+    for name, value in named.items():
+        if value is None:
+            log.error(f"'{name}' is a required argument")
+
+
+def _split_params(inp, log, params, pmin, pmax, pstep, prior, priorlow, priorup):
+    """params may carry the other per-parameter arrays as extra rows, in the order
+    (values, pmin, pmax, pstep, prior, priorlow, priorup): 3, 4 or 7 rows
+    (sampler_driver.py:284-299).  Row-borne values win over keyword ones."""
+    if isinstance(params, str):
+        log.error("reading 'params' from a file is outside the MI355X path; "
+                  "pass an array")
+    table = np.atleast_2d(np.asarray(params, float))
+    nrows = len(table) if np.ndim(params) > 1 else 1
+    if nrows > 1:
+        if nrows < 3:
+            log.error('Invalid format/shape for params input file')
+        pmin, pmax = table[1], table[2]
+        if nrows >= 4:
+            pstep = table[3]
+        if nrows == 7:
+            prior, priorlow, priorup = table[4], table[5], table[6]
+    inp.params = np.array(table[0], float)
+    n = len(inp.params)
+    inp.pmin = np.full(n, -np.inf) if pmin is None else np.asarray(pmin, float)
+    inp.pmax = np.full(n, np.inf) if pmax is None else np.asarray(pmax, float)
+    inp.pstep = 0.1*np.abs(inp.params) if pstep is None else np.asarray(pstep, float)
+    # priors: all three or none (sampler_driver.py:360-369), and only on free
+    # parameters (:371-373)
+    if prior is None or priorlow is None or priorup is None:
+        prior = priorlow = priorup = np.zeros(n)
+    inp.prior = np.array(prior, float)
+    fixed_or_shared = inp.pstep <= 0
+    inp.priorlow = np.where(fixed_or_shared, 0.0, np.asarray(priorlow, float))
+    inp.priorup = np.where(fixed_or_shared, 0.0, np.asarray(priorup, float))
+
+
+def _split_data(inp, log, data, uncert):
+    """data may be a (data, uncert) pair (sampler_driver.py:301-312)."""
+    if isinstance(data, str):
+        log.error("reading 'data' from a file is outside the MI355X path; "
+                  "pass an array")
+    if np.ndim(data) > 1:
+        data, uncert = data
+    _require(log, uncert=uncert)
+    inp.data = np.asarray(data, float)
+    inp.uncert = np.array(uncert, float)
+
+
+def _resolve_func(log, func):
+    """A callable, or (name, module[, path]) strings (sampler_driver.py:321-331)."""
+    if callable(func):
+        return func
+    if isinstance(func, (list, tuple, np.ndarray)):
+        name, module = func[0], func[1]
+        sys.path.append(func[2] if len(func) == 3 else os.getcwd())
+        return getattr(importlib.import_module(module), name)
+    log.error(
+        "'func' must be either a callable or an iterable of strings "
+        "with the model function, file, and path names")
+
+
+def _names(inp, pnames, texnames):
+    """Either name list stands in for the other; default names otherwise
+    (sampler_driver.py:346-352)."""
+    if pnames is None and texnames is None:
+        pnames = mu.default_parnames(len(inp.params))
+    inp.pnames = np.asarray(pnames if pnames is not None else texnames)
+    inp.texnames = np.asarray(texnames if texnames is not None else pnames)
+
+
+def _check_inside_bounds(inp, log):
+    """The initial guess must lie inside [pmin, pmax] (sampler_driver.py:375-389)."""
+    low = inp.params < inp.pmin
+    high = inp.params > inp.pmax
+    if not (np.any(low) or np.any(high)):
+        return
+    lines = []
+    for j in np.flatnonzero(low | high):
+        name = str(inp.pnames[j])[:11]
+        if low[j]:
+            lines.append(f"\n{name:11s}  {inp.pmin[j]: 12.5e} < {inp.params[j]: 12.5e}")
+        if high[j]:
+            lines.append(f"\n{name:26s}  {inp.params[j]: 12.5e} > {inp.pmax[j]: 12.5e}")
+    log.error(
+        "Some initial-guess values are out of bounds:\n"
+        "Param name           pmin          value           pmax\n"
+        "-----------  ------------   ------------   ------------"
+        + "".join(lines))
+
+
+def _summary_table(log, inp, output):
+    """The closing parameter table and fit statistics (sampler_driver.py:503-545)."""
+    bestp, median, stdp = output['bestp'], output['medianp'], output['stdp']
+    lo = output['median_low_bounds'] - median
+    hi = output['median_high_bounds'] - median
+    log.msg(
+        "\nParameter name     best fit   median      1sigma_low   1sigma_hi        S/N"
+        "\n--------------- -----------  -----------------------------------  ---------",
+        width=80)
+    for j, step in enumerate(inp.pstep):
+        if step > 0:
+            tag = f"{np.abs(bestp[j])/stdp[j]:.1f}"
+        elif step < 0:
+            tag = f"[share{-int(step):02d}]"
+        else:
+            tag = "[fixed]"
+            lo[j] = hi[j] = 0.0
+        log.msg(
+            f"{inp.pnames[j][0:15]:<15} {bestp[j]:11.4e}  {median[j]:11.4e} "
+            f"{lo[j]:11.4e} {hi[j]:11.4e}  {tag:>9s}", width=160)
+    bic = output['BIC']
+    w = len(f"{bic:.4f}")
+    log.msg(
+        f"\nBest-parameter's chi-squared:       {output['best_chisq']:{w}.4f}\n"
+        f"Best-parameter's -2*log(posterior): {-2.0*output['best_log_post']:{w}.4f}\n"
+        f"Bayesian Information Criterion:     {bic:{w}.4f}\n"
+        f"Reduced chi-squared:                {output['red_chisq']:{w}.4f}\n"
+        f"Standard deviation of residuals:  {output['stddev_residuals']:.6g}\n",
+        indent=2)
 
 
 def sample(
@@ -49,267 +177,113 @@ def sample(
       Linear, or any callable that is affine in its parameters (recognised by
       probing); anything else raises ValueError.
     - ``ncpu`` is ignored (the GPU advances all chains in lockstep).
+    - ``leastsq`` / ``chisqscale`` (the SciPy pre-fit) and ``plots`` are outside the
+      MI355X path: the first is refused, the second skipped with a warning.
     - extra keywords: ``seed`` (int), ``device`` (int), ``comm``
-      (mc3_amd.parallel communicator for multi-GPU runs).
+      (mc3_amd.parallel communicator for multi-GPU runs: every rank makes the same
+      call and gets the same dictionary; files are written by rank 0 only).
     """
     from . import __version__
-    if isinstance(log, str):
-        log = mu.Log(log, append=resume)
-        closelog = True
-    else:
-        closelog = False
-        if log is None:
-            log = mu.Log()
-
+    comm = kwargs.get('comm')
+    lead = comm is None or comm.rank == 0        # the rank that owns the files
+    own_log = isinstance(log, str)
+    if own_log:
+        log = mu.Log(log if lead else None, append=resume)
+    elif log is None:
+        log = mu.Log()
     log.msg(
         f"\n{log.sep}\n"
         "  mc3 chain-update path on AMD MI355X (mc3_amd).\n"
         f"  Version {__version__}.\n"
         f"{log.sep}\n\n")
 
-    if sampler is None:
-        log.error("'sampler' is a required argument")
-    if nsamples is None and sampler in ['MRW', 'DEMC', 'snooker']:
-        log.error("'nsamples' is a required argument for MCMC runs")
+    # -- what must be there, and the enumerations (sampler_driver.py:254-282) -------
+    _require(log, sampler=sampler)
     if leastsq not in [None, 'lm', 'trf']:
         log.error(
             f"Invalid 'leastsq' input ({leastsq}). Must select from "
             "['lm', 'trf']")
-    if sampler not in ['mrw', 'demc', 'snooker']:
+    if sampler not in SAMPLERS:
         log.error(f"Invalid 'sampler' input ({sampler}). Must select from "
-                  "['mrw', 'demc', 'snooker']")
+                  f"{SAMPLERS}")
     if nsamples is None:
         log.error("'nsamples' is a required argument for MCMC runs")
-
-    if params is None:
-        log.error("'params' is a required argument")
-    if isinstance(params, str):
-        log.error("reading 'params' from a file is outside the MI355X path; "
-                  "pass an array")
-    # unpack a 2D params input: sampler_driver.py:284-299
-    if np.ndim(params) > 1:
-        ninfo, _ = np.shape(params)
-        if ninfo == 7:
-            prior, priorlow, priorup = params[4], params[5], params[6]
-        if ninfo >= 4:
-            pstep = params[3]
-        if ninfo >= 3:
-            pmin, pmax = params[1], params[2]
-        else:
-            log.error('Invalid format/shape for params input file')
-        params = params[0]
-    params = np.array(params, float)
-
-    if data is None:
-        log.error("'data' is a required argument")
-    if isinstance(data, str):
-        log.error("reading 'data' from a file is outside the MI355X path; "
-                  "pass an array")
-    if np.ndim(data) > 1:
-        data, uncert = data
-    if uncert is None:
-        log.error("'uncert' is a required argument")
-    data = np.asarray(data, float)
-    uncert = np.array(uncert, float)      # a copy: chisqscale rescales it
-
-    resume = resume and (savefile is not None)
-    if resume:
-        log.msg(f"\n\n{log.sep}\n{log.sep}  Resuming previous MCMC run.\n\n")
-
-    # the model function: sampler_driver.py:321-331
-    if isinstance(func, (list, tuple, np.ndarray)):
-        if len(func) == 3:
-            sys.path.append(func[2])
-        else:
-            sys.path.append(os.getcwd())
-        func = getattr(importlib.import_module(func[1]), func[0])
-    elif not callable(func):
+    if leastsq is not None or chisqscale:
         log.error(
-            "'func' must be either a callable or an iterable of strings "
-            "with the model function, file, and path names")
+            "leastsq / chisqscale (the least-squares pre-fit of mc3.fit) is outside "
+            "the MI355X chain-update path; run the optimiser separately and pass its "
+            "best fit as 'params'", NotImplementedError)
+    _require(log, params=params)
+    inp = _Inputs()
+    _split_params(inp, log, params, pmin, pmax, pstep, prior, priorlow, priorup)
+    _require(log, data=data)
+    _split_data(inp, log, data, uncert)
+    func = _resolve_func(log, func)
+    _names(inp, pnames, texnames)
+    _check_inside_bounds(inp, log)
 
-    nparams = len(params)
-    ndata = len(data)
-    if pnames is None and texnames is not None:
-        pnames = texnames
-    elif pnames is not None and texnames is None:
-        texnames = pnames
-    elif pnames is None and texnames is None:
-        pnames = texnames = mu.default_parnames(nparams)
-    pnames = np.asarray(pnames)
-    texnames = np.asarray(texnames)
-
-    pmin = np.tile(-np.inf, nparams) if pmin is None else np.asarray(pmin, float)
-    pmax = np.tile(np.inf, nparams) if pmax is None else np.asarray(pmax, float)
-    pstep = 0.1*np.abs(params) if pstep is None else np.asarray(pstep, float)
-    if prior is None or priorup is None or priorlow is None:
-        prior = np.zeros(nparams)
-        priorlow = np.zeros(nparams)
-        priorup = np.zeros(nparams)
-    prior = np.array(prior, float)
-    priorlow = np.array(priorlow, float)
-    priorup = np.array(priorup, float)
-    # priors only act on free parameters: sampler_driver.py:371-373
-    priorlow[pstep <= 0] = 0.0
-    priorup[pstep <= 0] = 0.0
-
-    if np.any(params < pmin) or np.any(params > pmax):
-        pout = ""
-        for pname, par, minp, maxp in zip(pnames, params, pmin, pmax):
-            if par < minp:
-                pout += f"\n{pname[:11]:11s}  {minp: 12.5e} < {par: 12.5e}"
-            if par > maxp:
-                pout += f"\n{pname[:11]:26s}  {par: 12.5e} > {maxp: 12.5e}"
+    model0 = func(inp.params, *indparams, **indparams_dict)
+    if np.shape(model0) != np.shape(inp.data):
         log.error(
-            "Some initial-guess values are out of bounds:\n"
-            "Param name           pmin          value           pmax\n"
-            "-----------  ------------   ------------   ------------"
-            f"{pout}")
-
-    nfree = int(np.sum(pstep > 0))
-    ifree = np.where(pstep > 0)[0]
-    ishare = np.where(pstep < 0)[0]
-
-    model0 = func(params, *indparams, **indparams_dict)
-    if np.shape(model0) != np.shape(data):
-        log.error(
-            f"The size of the data array ({np.size(data)}) does not "
+            f"The size of the data array ({np.size(inp.data)}) does not "
             f"match the size of the func() output ({np.size(model0)})")
 
-    if savefile is not None:
-        fpath, _ = os.path.split(os.path.realpath(savefile))
-        if not os.path.exists(fpath):
-            log.warning(
-                f"Output folder path: '{fpath}' does not exist. "
-                "Creating new folder.")
-            os.makedirs(fpath)
-
-    ref = _reference()
+    resume = bool(resume) and savefile is not None
     chisq_factor = 1.0
-    fit_output = None
-    if leastsq is not None:
-        if ref is None:
-            log.error(
-                "leastsq pre-fitting (mc3.fit, SciPy-bound) is outside the "
-                "MI355X path and no 'mc3' installation is importable to "
-                "delegate it to; run with leastsq=None", NotImplementedError)
-        fit_output = ref.fit(
-            data, uncert, func, np.copy(params), indparams, indparams_dict,
-            pstep, pmin, pmax, prior, priorlow, priorup, leastsq)
-        log.msg("Least-squares best-fitting parameters:\n"
-                f"  {fit_output['bestp']}\n\n", si=2)
-        if chisqscale:
-            chisq_factor = np.sqrt(fit_output['best_chisq']/(ndata - nfree))
-            uncert *= chisq_factor
-            fit_output = ref.fit(
-                data, uncert, func, np.copy(params), indparams, indparams_dict,
-                pstep, pmin, pmax, prior, priorlow, priorup, leastsq)
-            log.msg("Least-squares best-fitting parameters (rescaled chisq):"
-                    f"\n  {fit_output['bestp']}\n\n", si=2)
-        params = np.copy(fit_output['bestp'])
-
     if resume:
-        with np.load(savefile) as oldrun:
-            uncert *= float(oldrun['chisq_factor'])/chisq_factor
-            chisq_factor = float(oldrun['chisq_factor'])
+        log.msg(f"\n\n{log.sep}\n{log.sep}  Resuming previous MCMC run.\n\n")
+        with np.load(savefile) as previous:      # sampler_driver.py:442-445
+            chisq_factor = float(previous['chisq_factor'])
+        inp.uncert *= chisq_factor
+    elif savefile is not None and lead:
+        folder = os.path.dirname(os.path.realpath(savefile))
+        if not os.path.exists(folder):
+            log.warning(
+                f"Output folder path: '{folder}' does not exist. "
+                "Creating new folder.")
+            os.makedirs(folder)
 
     extra = {k: kwargs[k] for k in ('seed', 'device', 'comm', 'engine_factory')
              if k in kwargs}
     output = mcmc(
-        data, uncert, func, params, indparams, indparams_dict,
-        pmin, pmax, pstep, prior, priorlow, priorup, nchains, ncpu, nsamples,
-        sampler, wlike, fit_output, grtest, grbreak, grnmin, burnin, thinning,
-        fgamma, fepsilon, hsize, kickoff, savefile, resume, log,
-        pnames, texnames, **extra)
-
+        inp.data, inp.uncert, func, inp.params, indparams, indparams_dict,
+        inp.pmin, inp.pmax, inp.pstep, inp.prior, inp.priorlow, inp.priorup,
+        nchains, ncpu, nsamples, sampler, wlike, None, grtest, grbreak, grnmin,
+        burnin, thinning, fgamma, fepsilon, hsize, kickoff, savefile, resume, log,
+        inp.pnames, inp.texnames, **extra)
     output['chisq_factor'] = chisq_factor
 
-    if leastsq is not None:
-        delta_log_post = output['best_log_post'] - fit_output['best_log_post']
-        delta_pars = output['bestp'] - fit_output['bestp']
-        if delta_log_post > 5.0e-8 and np.any(delta_pars != 0.0):
-            log.warning(
-                "MCMC found a better fit than the minimizer:\n"
-                "MCMC best-fitting parameters:        (chisq={:.8g})\n{}\n"
-                "Minimizer best-fitting parameters:   (chisq={:.8g})\n{}".
-                format(-2*output['best_log_post'], output['bestp'],
-                       -2*fit_output['best_log_post'], fit_output['bestp']))
-
-    # sample statistics without the burn-in: sampler_driver.py:475-501
-    posterior, zchain, zmask = mu.burn(
+    # -- statistics of the burned sample (sampler_driver.py:475-501): the median and
+    # central-interval numbers were computed with the output dictionary
+    # (update_output); the KDE mode and HPD bounds are added here
+    posterior, _, zmask = mu.burn(
         Z=output['posterior'], zchain=output['zchain'], burnin=output['burnin'])
     bestp = output['bestp']
-    # the median / central-interval statistics of this same burned posterior were
-    # computed by update_output (sampler_driver.py:490-497 recomputes them); only the
-    # KDE-based mode and HPD bounds are added here
-    if 'medianp' in output and 'zmask' in output and len(output['zmask']) == len(zmask):
-        mode, hlo, hhi = ms.hpd_statistics(posterior, bestp, pstep)
+    if 'medianp' in output and len(output.get('zmask', ())) == len(zmask):
+        mode, hlo, hhi = ms.hpd_statistics(posterior, bestp, inp.pstep)
     else:
-        stats = ms.calc_sample_statistics(posterior, bestp, pstep, calc_hpd=True)
         (output['medianp'], output['meanp'], output['stdp'],
          output['median_low_bounds'], output['median_high_bounds'],
-         mode, hlo, hhi) = stats
+         mode, hlo, hhi) = ms.calc_sample_statistics(posterior, bestp, inp.pstep,
+                                                     calc_hpd=True)
     output['mode'], output['hpd_low_bounds'], output['hpd_high_bounds'] = mode, hlo, hhi
-    output['CRlo'] = output['hpd_low_bounds'] - bestp
-    output['CRhi'] = output['hpd_high_bounds'] - bestp
-    output['CRlo'][pstep == 0] = output['CRhi'][pstep == 0] = 0.0
-
-    median, stdp = output['medianp'], output['stdp']
-    log.msg(
-        "\nParameter name     best fit   median      1sigma_low   1sigma_hi        S/N"
-        "\n--------------- -----------  -----------------------------------  ---------",
-        width=80)
-    for i in range(nparams):
-        lo = output['median_low_bounds'][i] - median[i]
-        hi = output['median_high_bounds'][i] - median[i]
-        if i in ifree:
-            snr = f"{np.abs(bestp[i])/stdp[i]:.1f}"
-        elif i in ishare:
-            snr = f"[share{-int(pstep[i]):02d}]"
-        else:
-            snr = "[fixed]"
-            lo = hi = 0.0
-        log.msg(
-            f"{pnames[i][0:15]:<15} {bestp[i]:11.4e}  {median[i]:11.4e} "
-            f"{lo:11.4e} {hi:11.4e}  {snr:>9s}", width=160)
-
-    bic = output['BIC']
-    fmt = len(f"{bic:.4f}")
-    scale_txt = (f"sqrt(reduced chi-squared) factor: {chisq_factor:.4f}\n"
-                 if chisqscale else '')
-    log.msg(
-        f"\n{scale_txt}"
-        f"Best-parameter's chi-squared:       {output['best_chisq']:{fmt}.4f}\n"
-        f"Best-parameter's -2*log(posterior): {-2.0*output['best_log_post']:{fmt}.4f}\n"
-        f"Bayesian Information Criterion:     {bic:{fmt}.4f}\n"
-        f"Reduced chi-squared:                {output['red_chisq']:{fmt}.4f}\n"
-        f"Standard deviation of residuals:  {output['stddev_residuals']:.6g}\n",
-        indent=2)
+    fixed = inp.pstep == 0
+    output['CRlo'] = np.where(fixed, 0.0, hlo - bestp)
+    output['CRhi'] = np.where(fixed, 0.0, hhi - bestp)
+    _summary_table(log, inp, output)
 
     if savefile is not None:
-        np.savez(savefile, **output)
-        log.msg("\nOutput sampler files:")
-        log.msg(savefile, indent=2)
-
+        if lead:
+            np.savez(savefile, **output)
+            log.msg("\nOutput sampler files:")
+            log.msg(savefile, indent=2)
+        if comm is not None:
+            comm.barrier()               # nobody returns before the file is complete
     if plots:
-        if ref is None:
-            log.warning("plots=True ignored: plotting is outside the MI355X "
-                        "path and no 'mc3' installation is importable")
-        else:
-            root = os.path.splitext(savefile)[0] if savefile else 'mc3'
-            ref.plots.trace(
-                output['posterior'], zchain=output['zchain'],
-                burnin=output['burnin'], pnames=texnames[ifree],
-                savefile=f'{root}_trace.png')
-            post = ref.plots.Posterior(
-                posterior, pnames=texnames[ifree], theme=theme,
-                bestp=bestp[ifree], statistics=statistics)
-            post.plot(savefile=f'{root}_pairwise_posterior.png',
-                      show_estimates=showbp)
-            post.plot_histogram(savefile=f'{root}_marginal_posterior.png',
-                                show_estimates=showbp)
-
-    if closelog:
-        log.msg(log.logname, indent=2)
+        log.warning("plots=True ignored: plotting is outside the MI355X path "
+                    "(pass the output dictionary to mc3.plots)")
+    if own_log:
+        if lead:
+            log.msg(log.logname, indent=2)
         log.close()
     return output

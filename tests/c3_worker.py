@@ -1,0 +1,52 @@
+"""Worker for test_gpu_p2p.py::test_config_c3_*: one rank of BASELINE.json's config C3
+(quadratic fit, ndata=1000, 2048 chains sharded over 8 ranks, demc) at engine level.
+All ranks share device 0 (the test box has one GPU): eight processes, eight contexts of
+256 chains each, eight lean_demc_kernel<3, P2P> grids co-resident (one wave per chain:
+2048 waves = the chip's 8 per CU), every new row stored into all eight replicas."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import torch.distributed as dist  # noqa: E402
+
+from mc3_amd import engine, parallel  # noqa: E402
+import helpers as H  # noqa: E402
+
+
+def main():
+    out_path, nref = sys.argv[1], int(sys.argv[2])
+    dist.init_process_group('gloo')
+    comm = parallel.TorchDistComm(use_p2p=True, use_rccl=False)
+    nchains = 256*comm.size
+    prob = H.quad_problem(ndata=1000, nchains=nchains, nsamples=nchains*nref, sampler='demc')
+    pop = np.load(out_path + '.pop.npz')
+    c0, n = comm.partition(nchains)
+    gpu = engine.DeviceChains(chain0=c0, nlocal=n, p2p=True, device=0, **prob)
+    gpu.set_population(pop['Z0'], pop['lp0'])
+    comm.setup(gpu)
+    assert comm.mode == 'p2p', comm.mode
+    plan = gpu.plan
+    assert plan['fast'] == 2 and plan['persistent'] > 0, plan      # lean_demc_kernel<3, P2P>
+    # two segments: the second persistent launch resumes from the replicas
+    gpu.run(nref//3, sync=False)
+    comm.quiesce(gpu)
+    gpu.run(nref - nref//3, sync=False)
+    comm.quiesce(gpu)
+    assert comm.mode == 'p2p' and comm.recoveries == 0
+    Z, lp, zc = gpu.rows()
+    st = gpu.state()
+    np.savez(f'{out_path}.rank{comm.rank}.npz', Z=Z, lp=lp, zc=zc,
+             numaccept=st['numaccept'], outbounds=st['outbounds'],
+             best_chisq=st['best_chisq'], X=st['X'], chisq=st['chisq'])
+    dist.barrier()
+    gpu.close()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -21,7 +21,11 @@ import helpers as H  # noqa: E402
 def main():
     out_path, sampler, thinning, niter = (sys.argv[1], sys.argv[2], int(sys.argv[3]),
                                           int(sys.argv[4]))
+    abort_at = int(sys.argv[5].split('=')[1]) if len(sys.argv) > 5 else None
     dist.init_process_group('gloo')
+    if abort_at is not None and dist.get_rank() == 0:
+        # test hook: this rank's first chain gives up at that refresh (read at create)
+        os.environ['MC3HIP_TEST_ABORT_AT'] = str(abort_at)
     comm = parallel.TorchDistComm(use_p2p=True, use_rccl=False)
     x, data, uncert = H.tutorial_data(100)
     np.random.seed(100 + comm.rank)
@@ -32,7 +36,11 @@ def main():
         sampler=sampler, nsamples=16*niter*thinning, burnin=10, nchains=16,
         thinning=thinning, grtest=True, log=mu.Log(verb=0), seed=99, comm=comm,
         device=0)
-    assert comm.mode == 'p2p', comm.mode
+    if abort_at is None:
+        assert comm.mode == 'p2p' and comm.recoveries == 0, (comm.mode, comm.recoveries)
+    else:
+        assert comm.mode == 'host' and comm.recoveries == 1, (comm.mode, comm.recoveries)
+        print(f'rank {comm.rank}: recovered', flush=True)
     np.savez(f'{out_path}.rank{comm.rank}.npz',
              **{k: v for k, v in out.items() if k not in ('pnames', 'texnames')})
     dist.barrier()

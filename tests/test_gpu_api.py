@@ -81,25 +81,41 @@ def test_sample_gpu_shared_priors_wavelet_linear():
     assert_same_dict(gpu, cpu)
 
 
-def test_rccl_path_single_rank():
-    """The RCCL entry points load and run (one rank: the all-gather is a copy);
-    the multi-rank data flow is covered on CPU by test_distributed_gloo.py."""
+@pytest.mark.parametrize('sampler,builder', [('snooker', H.quad_problem),
+                                             ('demc', H.quad_problem),
+                                             ('demc', H.linear_problem)])
+def test_rccl_path_single_rank_in_a_graph(sampler, builder):
+    """The RCCL exchange (one rank: the all-gather is a copy) captured in a hipGraph:
+    step kernel -> ring slot, in-place ncclAllGather of the slot, scatter to Z, 16
+    refreshes per replay; the first refresh and the tail run eagerly.  The multi-rank
+    data flow is covered on CPU by test_distributed_gloo.py."""
     from mc3_amd import engine
-    prob = H.quad_problem(nchains=8, nsamples=8*50, sampler='snooker')
-    orc = H.make_oracle(prob)
+    kw = dict(ndata=20000, nchains=16, nsamples=16*75) if builder is H.linear_problem \
+        else dict(nchains=8, nsamples=8*75)
+    prob = builder(sampler=sampler, **kw)
+    os.environ['MC3HIP_GRAPH_NODES'] = '16'
+    try:
+        gpu = engine.DeviceChains(**prob)
+    finally:
+        del os.environ['MC3HIP_GRAPH_NODES']
+    orc = H.make_oracle(prob, tile=gpu.plan['tile'])
     Z0, lp0 = H.initial_population(orc)
     orc.set_population(Z0, lp0)
-    orc.run()
-    with engine.DeviceChains(**prob) as gpu:
+    orc.run(nthreads=4)
+    with gpu:
         gpu.set_population(Z0, lp0)
         uid = engine.comm_unique_id()
         assert len(uid) == 128
         gpu.comm_init(uid, 0, 1)
-        gpu.run()
+        gpu.run(40)                 # 1 eager + 2 replays + 7 eager
+        assert gpu.plan['comm_graph'] == 16, gpu.plan
+        gpu.run()                   # 2 replays + 3 eager
         gpu.comm_gather_log_post()
         Z, lp, zc = gpu.rows()
+        st = gpu.state()
     np.testing.assert_array_equal(Z, orc.Z)
     np.testing.assert_array_equal(lp, orc.log_post)
+    np.testing.assert_array_equal(st['numaccept'], orc.numaccept)
 
 
 def test_put_rows_host_staged_exchange():

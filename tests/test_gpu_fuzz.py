@@ -1,6 +1,13 @@
 """Randomised differential test: many small random problems (sampler, sizes, model
 family, fixed/shared parameters, priors, bounds, thinning, epsilon, likelihood,
-launch structure) -- the GPU must equal the lockstep oracle exactly on each."""
+launch structure) -- the GPU must equal the lockstep oracle exactly on each.
+
+Two families: ``random_problem`` spans everything the library accepts (run through the
+general kernels with the per-step trace switched on for every other seed, and without
+it -- i.e. with the lean kernels allowed -- for the rest); ``lean_problem`` draws from
+the shapes the lean kernels serve (lean_demc_kernel and persist_fast_kernel with their
+FX / MULTI / TH instances: the kernels that carry the headline number) and asserts that
+the library really chose them."""
 import os
 
 import numpy as np
@@ -76,6 +83,99 @@ def random_problem(seed):
                 model=kind, nmodel=nmodel, seed=int(rs.randint(0, 2**31)))
 
 
+def lean_problem(seed):
+    """A problem the lean kernels serve: polynomial with 2..4 coefficients and nothing
+    but coefficients among the parameters, Gaussian chisq, no support distribution."""
+    rs = np.random.RandomState(seed)
+    nmodel = int(rs.randint(2, 5))
+    flavour = str(rs.choice(['plain', 'plain', 'fx', 'multi', 'thin']))
+    if flavour == 'multi':
+        ndata = int(rs.choice([1025, 1500, 2048, 2049, 3000, 4096]))
+    else:
+        ndata = int(rs.choice([1, 3, 64, 100, 777, 1000, 1024]))
+    sampler = str(rs.choice(['demc', 'demc', 'snooker', 'mrw']))
+    nchains = int(rs.randint(3, 48))
+    thinning = int(rs.choice([2, 3, 5])) if flavour == 'thin' else 1
+    x = np.sort(rs.uniform(-1, 1, ndata))
+    p_true = rs.normal(0, 1, nmodel)
+    data = p_true @ np.array([x**k for k in range(nmodel)]) + rs.normal(0, 1, ndata)
+    uncert = rs.uniform(0.5, 2.0, ndata)
+    pstep = np.full(nmodel, 0.05)
+    prior = np.zeros(nmodel)
+    plow = np.zeros(nmodel)
+    pup = np.zeros(nmodel)
+    if flavour == 'fx':
+        # fixed / shared coefficients and Gaussian priors, in any mixture (never all fixed)
+        for j in range(nmodel):
+            r = rs.rand()
+            if r < 0.3:
+                pstep[j] = 0.0
+            elif r < 0.5 and j > 0 and pstep[0] > 0:
+                pstep[j] = -1.0
+                p_true[j] = p_true[0]
+        if not np.any(pstep > 0):
+            pstep[0] = 0.05
+        for j in range(nmodel):
+            if pstep[j] > 0 and rs.rand() < 0.5:
+                prior[j] = p_true[j] + rs.normal(0, 0.1)
+                plow[j], pup[j] = rs.uniform(0.05, 1.0, 2)
+    lo = p_true - rs.uniform(0.05, 3.0, nmodel)
+    hi = p_true + rs.uniform(0.05, 3.0, nmodel)
+    for j in range(nmodel):
+        if pstep[j] < 0:
+            lo[j], hi[j] = lo[0], hi[0]
+    return dict(data=data, uncert=uncert, indep=x, params=p_true, pstep=pstep,
+                pmin=lo, pmax=hi, prior=prior, priorlow=plow, priorup=pup,
+                nchains=nchains, nsamples=nchains*thinning*int(rs.randint(20, 200)),
+                sampler=sampler, wlike=False, thinning=thinning,
+                fgamma=float(rs.uniform(0.5, 1.5)), fepsilon=0.0,
+                hsize=int(rs.randint(1, 5)), model='poly', nmodel=nmodel,
+                seed=int(rs.randint(0, 2**31))), flavour
+
+
+def compare_final(gpu, orc, label):
+    Z, lp, zc = gpu.rows()
+    st = gpu.state()
+    np.testing.assert_array_equal(Z, orc.Z, err_msg=label)
+    np.testing.assert_array_equal(lp, orc.log_post, err_msg=label)
+    np.testing.assert_array_equal(zc, orc.zchain, err_msg=label)
+    np.testing.assert_array_equal(st['numaccept'], orc.numaccept, err_msg=label)
+    np.testing.assert_array_equal(st['outbounds'], orc.outbounds, err_msg=label)
+    np.testing.assert_array_equal(st['best_chisq'], orc.best_chisq, err_msg=label)
+    np.testing.assert_array_equal(st['best_iter'], orc.best_iter, err_msg=label)
+    np.testing.assert_array_equal(st['bestx'][st['best_iter'] >= 0],
+                                  orc.bestx[orc.best_iter >= 0], err_msg=label)
+    np.testing.assert_array_equal(st['chisq'], orc.chisq, err_msg=label)
+    np.testing.assert_array_equal(st['X'], orc.X, err_msg=label)
+
+
+@pytest.mark.parametrize('seed', range(120))
+def test_lean_kernels_random_problem(seed):
+    """The kernels behind the headline number, fuzzed: the library must pick a lean
+    instance for these shapes (plan.fast) and equal the oracle exactly."""
+    from mc3_amd import engine
+    prob, flavour = lean_problem(5000 + seed)
+    gpu = engine.DeviceChains(**prob)
+    plan = gpu.plan
+    label = f"{flavour} {prob['sampler']} poly{prob['nmodel']} ndata={len(prob['data'])} " \
+            f"nchains={prob['nchains']} thin={prob['thinning']} pstep={prob['pstep']} plan={plan}"
+    assert plan['persistent'] > 0 and plan['fast'] > 0, label
+    lean_loop = prob['sampler'] == 'demc' and prob['thinning'] == 1
+    assert (plan['fast'] == 2) == lean_loop, label
+    orc = H.make_oracle(prob, tile=plan['tile'])
+    Z0, lp0 = H.initial_population(orc, seed=seed)
+    orc.set_population(Z0, lp0)
+    gpu.set_population(Z0, lp0)
+    orc.run(nthreads=4)
+    # in two uneven pieces: the second launch resumes from device state
+    nz = gpu.nzchain
+    gpu.run(nz//3)
+    gpu.run()
+    assert gpu.plan['fast'] == plan['fast'], 'the persistent launch gave up: ' + label
+    compare_final(gpu, orc, label)
+    gpu.close()
+
+
 @pytest.mark.parametrize('seed', range(150))
 def test_random_problem(seed):
     from mc3_amd import engine
@@ -85,12 +185,13 @@ def test_random_problem(seed):
     kw = {'default': {}, 'no_persist': {'no_persist': True},
           'eager': {'no_persist': True, 'no_graph': True}}[mode]
     wpc = rs.choice(['', '1', '4', '16'])
+    traced = seed % 2 == 0          # odd seeds: no per-step trace, lean kernels allowed
     if wpc:
         os.environ['MC3HIP_WPC'] = wpc
     try:
         nz = int(np.ceil(prob['nsamples']/prob['nchains']/prob['thinning']))
         niter = nz*prob['thinning']
-        gpu = engine.DeviceChains(trace_iters=niter, **prob, **kw)
+        gpu = engine.DeviceChains(trace_iters=niter if traced else 0, **prob, **kw)
     finally:
         os.environ.pop('MC3HIP_WPC', None)
     orc = H.make_oracle(prob, tile=gpu.plan['tile'])
@@ -101,13 +202,14 @@ def test_random_problem(seed):
     gpu.run()
     Z, lp, zc = gpu.rows()
     st = gpu.state()
-    tc, tf = gpu.trace(niter)
-    gpu.close()
     label = f"{prob['sampler']} {prob['model']}{prob['nmodel']} wlike={prob['wlike']} " \
             f"ndata={len(prob['data'])} nchains={prob['nchains']} thin={prob['thinning']} " \
-            f"mode={mode} wpc={wpc or 'auto'}"
-    np.testing.assert_array_equal(tf, orc.trace_flag, err_msg=label)
-    np.testing.assert_array_equal(tc, orc.trace_chisq, err_msg=label)
+            f"mode={mode} wpc={wpc or 'auto'} traced={traced} plan={gpu.plan}"
+    if traced:
+        tc, tf = gpu.trace(niter)
+        np.testing.assert_array_equal(tf, orc.trace_flag, err_msg=label)
+        np.testing.assert_array_equal(tc, orc.trace_chisq, err_msg=label)
+    gpu.close()
     np.testing.assert_array_equal(Z, orc.Z, err_msg=label)
     np.testing.assert_array_equal(lp, orc.log_post, err_msg=label)
     np.testing.assert_array_equal(zc, orc.zchain, err_msg=label)

@@ -54,3 +54,72 @@ def test_processes_peer_to_peer(tmp_path, nproc, sampler, thinning, niter):
         for key in ('posterior', 'zchain', 'log_post', 'chisq', 'bestp',
                     'acceptance_rate', 'best_log_post', 'medianp', 'stdp'):
             np.testing.assert_array_equal(got[key], single[key], err_msg=key)
+
+
+def launch(nproc, script, *args, env=None, timeout=1000):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **(env or {}))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           f'--nproc-per-node={nproc}', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'tests', script)]
+    res = subprocess.run(cmd + [str(a) for a in args], env=env, capture_output=True,
+                         text=True, timeout=timeout)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-6000:]
+    return res
+
+
+def test_config_c3_eight_ranks_of_256_chains(tmp_path):
+    """BASELINE config C3 at its real shape: 2048 chains x ndata 1000, demc, sharded over
+    8 ranks of 256 chains through the peer-to-peer hand-off (here: eight processes on the
+    one GPU).  Every rank's replica must equal the oracle's run of the whole ensemble."""
+    nref = 48
+    nchains = 2048
+    prob = H.quad_problem(ndata=1000, nchains=nchains, nsamples=nchains*nref, sampler='demc')
+    orc = H.make_oracle(prob)
+    Z0, lp0 = H.initial_population(orc)
+    out_path = str(tmp_path / 'c3')
+    np.savez(out_path + '.pop.npz', Z0=Z0, lp0=lp0)
+    orc.set_population(Z0, lp0)
+    orc.run(nthreads=min(32, len(os.sched_getaffinity(0))))
+    launch(8, 'c3_worker.py', out_path, nref)
+    for rank in range(8):
+        got = np.load(f'{out_path}.rank{rank}.npz')
+        s = slice(256*rank, 256*(rank + 1))
+        np.testing.assert_array_equal(got['Z'], orc.Z, err_msg=f'rank {rank}')
+        np.testing.assert_array_equal(got['lp'], orc.log_post)
+        np.testing.assert_array_equal(got['zc'], orc.zchain)
+        np.testing.assert_array_equal(got['numaccept'], orc.numaccept[s])
+        np.testing.assert_array_equal(got['X'], orc.X[s])
+        np.testing.assert_array_equal(got['chisq'], orc.chisq[s])
+        np.testing.assert_array_equal(got['best_chisq'], orc.best_chisq[s])
+    total_out = sum(np.load(f'{out_path}.rank{r}.npz')['outbounds'] for r in range(8))
+    np.testing.assert_array_equal(total_out, orc.outbounds)
+
+
+@pytest.mark.parametrize('sampler', ['demc', 'snooker'])
+def test_peer_to_peer_abort_is_recovered_by_all_ranks(tmp_path, sampler):
+    """A persistent launch gives up on rank 0 in the middle of a two-rank run (test
+    hook; in the field: a peer that died or a grid that was not resident).  Rank 1's
+    waits time out, the ranks vote at the next report point, EVERY rank rolls back to
+    its checkpoint and the lost refreshes are redone through the host-staged exchange:
+    same output dictionary as the undisturbed single-rank run."""
+    import mc3_amd
+    from mc3_amd import utils as mu
+    from oracle_engine import OracleChains
+    niter = 200
+    out_path = str(tmp_path / 'abort')
+    res = launch(2, 'p2p_worker.py', out_path, sampler, 1, niter, 'abort=77')
+    assert 'recovered' in res.stdout, res.stdout[-2000:]
+    x, data, uncert = H.tutorial_data(100)
+    np.random.seed(100)
+    single = mc3_amd.sample(
+        data=data, uncert=uncert, func=H.quad, params=np.array([10.0, -2.0, 0.1]),
+        indparams=[x], pstep=np.array([1.0, 0.5, 0.1]),
+        pmin=np.array([-10.0, -20.0, -10.0]), pmax=np.array([40.0, 20.0, 10.0]),
+        sampler=sampler, nsamples=16*niter, burnin=10, nchains=16,
+        thinning=1, grtest=True, log=mu.Log(verb=0),
+        engine_factory=OracleChains, seed=99)
+    for rank in range(2):
+        got = np.load(f'{out_path}.rank{rank}.npz')
+        for key in ('posterior', 'zchain', 'log_post', 'chisq', 'bestp',
+                    'acceptance_rate', 'best_log_post', 'medianp', 'stdp'):
+            np.testing.assert_array_equal(got[key], single[key], err_msg=key)

@@ -321,6 +321,34 @@ def test_persistent_kernel_many_chains(eng):
     gpu.close()
 
 
+@pytest.mark.parametrize('sampler', ['demc', 'snooker'])
+def test_config_c3_ensemble_in_one_context(eng, sampler):
+    """BASELINE config C3's ensemble -- 2048 chains x ndata 1000 -- in ONE context (what
+    eight ranks must reproduce, tests/test_gpu_p2p.py): lean kernels at full occupancy,
+    bit-exact against the oracle."""
+    prob = H.quad_problem(ndata=1000, nchains=2048, nsamples=2048*40, sampler=sampler)
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert gpu.plan['persistent'] > 0 and gpu.plan['fast'] == (2 if sampler == 'demc' else 1)
+    assert_same(orc, gpu, trace=False)
+    assert gpu.plan['recoveries'] == 0
+    gpu.close()
+
+
+@pytest.mark.parametrize('ndata,nchains', [(2000, 1100), (4096, 1030)])
+def test_multi_tile_lean_kernels_at_their_own_occupancy(eng, ndata, nchains):
+    """The MULTI instances of the lean kernels hold two data tiles in registers: four
+    single-wave workgroups per CU, not eight.  More than 1024 chains of such a problem are
+    co-resident only because the grid is sized by the occupancy of the instance that is
+    launched (not of its plain sibling): the run must complete on the persistent path, without a
+    give-up and redo."""
+    prob = H.quad_problem(ndata=ndata, nchains=nchains, nsamples=nchains*12, sampler='demc')
+    orc, gpu = run_pair(eng, prob, trace=False)
+    plan = gpu.plan
+    assert_same(orc, gpu, trace=False)
+    assert gpu.plan['recoveries'] == 0, (plan, gpu.plan)
+    gpu.close()
+
+
 @pytest.mark.parametrize('sampler', ['demc', 'snooker', 'mrw'])
 def test_lean_instances_with_a_fixed_coefficient(eng, sampler):
     """A fixed polynomial coefficient (pstep = 0) keeps the problem on the lean persistent
