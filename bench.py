@@ -191,14 +191,14 @@ def main():
         comm.setup(gpu)
         if comm.mode == 'p2p':
             try:
-                gpu.run(64)
-                comm.quiesce(gpu)
-                ok = True
+                gpu.run(64, sync=False)
+                comm.quiesce(gpu)           # (recovers by itself if a launch gave up)
+                ok = comm.mode == 'p2p'     # ... but then the run stays on that exchange
             except Exception as e:          # noqa: BLE001
                 print(f'[rank {rank}] peer-to-peer hand-off failed ({e}); using RCCL',
                       file=sys.stderr, flush=True)
                 ok = False
-            if not comm._all_ok(ok):
+            if not comm._all_ok(ok) and comm.mode == 'p2p':
                 gpu.close()
                 comm = parallel.TorchDistComm(use_p2p=False)
                 gpu = make_engine(False)
@@ -212,16 +212,30 @@ def main():
             exchange = 'rccl'
 
     def barrier():
+        # multi-rank: quiesce() drains the library's stream, lets the ranks agree that
+        # the segment completed everywhere (peer-to-peer stores: every peer has finished
+        # too) and, if a launch gave up anywhere, rolls all of them back and redoes it
+        if comm is not None:
+            comm.quiesce(gpu)
         gpu.sync()
         if world > 1 or force_comm:
-            torch.cuda.synchronize(local_rank)
-            dist.barrier()          # with peer-to-peer stores: every peer has finished too
+            dist.barrier()
+
+    def advance(n):
+        if comm is not None and not comm.native:
+            # host-staged exchange (no peer access and no RCCL): one refresh at a time
+            for _ in range(n):
+                R = gpu.refresh_done
+                gpu.run(1)
+                comm.exchange(gpu, R)
+        else:
+            gpu.run(n, sync=False)
 
     if nref_warm:
-        gpu.run(nref_warm)
+        advance(nref_warm)
     barrier()
     t0 = time.perf_counter()
-    gpu.run(nref_timed, sync=False)
+    advance(nref_timed)
     barrier()
     dt = time.perf_counter() - t0
     gpu_ms = gpu.last_run_ms()          # HIP events on the library's stream
@@ -247,6 +261,9 @@ def main():
     # roofline of the dominant (only) kernel.  Persistent path: one launch covers
     # `persistent` refreshes; per-refresh path: one launch per refresh.
     multi = world > 1 or force_comm
+    if comm is not None:
+        exchange = comm.mode           # (a recovery inside the run changes the exchange)
+    cgraph = gpu.plan['comm_graph']
     per = gpu.plan['persistent'] if (not multi or exchange == 'p2p') else 0
     if per > 0:
         launches = -(-nref_timed//per)
@@ -258,17 +275,22 @@ def main():
         launches = nref_timed
         kernel = 'mc3hip::step_kernel'
         structure = 'one launch per refresh' + \
-            (' + one RCCL all-gather per refresh' if multi else
+            ((f' + one RCCL all-gather per refresh, captured in a hipGraph of {cgraph} '
+              'refreshes (step kernel, all-gather, scatter kernel each)' if cgraph else
+              ' + one RCCL all-gather per refresh (eager)') if multi else
              f' (hipGraph of {gpu.plan["graph_nodes"]} nodes)')
     traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'r01g_c2_pmc.json')
-    if os.path.exists(pmc) and args.thinning == 1 and world == 1:
+    hbm_per_step = None
+    pmc = next((q for q in (os.path.join(ROOT, 'profiles', n) for n in
+                            ('r02_c2_pmc.json', 'r01g_c2_pmc.json')) if os.path.exists(q)), None)
+    if pmc and args.thinning == 1 and world == 1:
         with open(pmc) as f:
             rec = json.load(f)
         if rec['kernel'].startswith(kernel):
             # HBM bytes per launch from the PMC counters of the same kernel
             # (separate rocprofv3 --pmc passes, gfx950 FETCH_SIZE correction)
-            traffic = rec['hbm_bytes_per_chain_step']*CHAINS_PER_GPU*nref_timed/launches
+            hbm_per_step = rec['hbm_bytes_per_chain_step']
+            traffic = hbm_per_step*CHAINS_PER_GPU*nref_timed/launches
     launch_s = gpu_ms*1e-3/launches
     bytes_per_launch = BYTES_PER_CHAIN_STEP*CHAINS_PER_GPU*args.thinning*nref_timed/launches
     achieved = bytes_per_launch/launch_s/1e9
@@ -289,13 +311,24 @@ def main():
             'chains_per_gpu': CHAINS_PER_GPU,
             'parallelism': f'chains sharded x{world}' if world > 1 else 'single GPU',
             'collective': {None: None, 'rccl': 'one in-place RCCL all-gather of new Z rows per '
-                           'refresh', 'p2p': 'none: every new Z row is stored peer-to-peer into '
+                           'refresh' + (f', replayed from a hipGraph ({cgraph} refreshes per '
+                                        'replay)' if cgraph else ', eager'), 'p2p': 'none: every new Z row is stored peer-to-peer into '
                            'every rank\'s replica by the persistent kernel (xGMI)',
                            'host': 'host-staged'}[exchange],
             'launch_structure': structure,
             'waves_per_chain': gpu.plan['waves_per_chain'],
             'acceptance_rate': accept,
             'replicas_consistent': consistent,
+            'recoveries': gpu.plan['recoveries'] + (comm.recoveries if comm else 0),
+            # what "the same results as the reference" means here
+            'semantics': 'lockstep (Jacobi) DEMC: during refresh R a chain sees the others '
+                         'through the rows of refresh R-1 (the reference updates the chains '
+                         'of a worker one after another, Gauss-Seidel); draws are '
+                         'Philox4x32-10 keyed by (seed, iteration, chain), one support-'
+                         'distribution vector per chain (the reference: MT19937, one per '
+                         'worker-iteration); ncpu is ignored.  Bit-exact against '
+                         'oracle/oracle_lockstep.c, whose step function replays the '
+                         'reference\'s own runs from a draw tape (tests/test_oracle_tape.py)',
         },
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
@@ -303,6 +336,25 @@ def main():
             'kernel': kernel, 'launches': launches,
             'algorithmic_bytes_per_launch': bytes_per_launch,
             'avg_launch_us': launch_s*1e6,
+            # the honest denominators next to the contractual one: what the memory
+            # system really moved, and the latency chain that really bounds an iteration
+            'hw': None if hbm_per_step is None else {
+                'hbm_GBs': hbm_per_step*chain_steps/world/(gpu_ms*1e-3)/1e9,
+                'frac_of_peak': hbm_per_step*chain_steps/world/(gpu_ms*1e-3)/1e9/HBM_PEAK_GBS,
+                'hbm_bytes_per_chain_step': hbm_per_step,
+                'source': os.path.basename(pmc)},
+            'latency_model': {
+                'us_per_iteration': launch_s*1e6*launches/nref_timed/args.thinning,
+                'floor_us': 0.8 + 0.42,
+                'floor': 'every iteration of every chain needs two rows other chains (other '
+                         'CUs, other XCDs) produced in the iteration before: one cross-CU '
+                         'hand-off (MI355X_MICROARCH.md "handoff-1to1" 0.8 us) + the dependent '
+                         'FP64 chain of one wave alone on its SIMD, proposal -> chisq of 1000 '
+                         'points (16 per lane) -> 6 cross-lane adds -> exp -> accept, '
+                         '~1000 cycles = 0.42 us at 2.4 GHz (tools/ticks.py)',
+                'note': 'one wave per CU on 256 CUs = 1/4 of the SIMDs, ~2 % of the FP64 vector '
+                        'peak: the workload (256 chains, 1000 points) cannot fill the chip; '
+                        'it is latency-bound, neither bandwidth- nor FLOP-bound'},
             'note': 'algorithmic bytes (SURVEY 8d: 24104 B per chain-step) x chain-steps '
                     'per launch / average launch duration (HIP events on the library '
                     'stream over the timed region / launches). x/data/uncert are '

@@ -75,6 +75,12 @@ struct DevProblem {
     double *sc_scal;              // [nlocal][2]       Metropolis draw u, Hastings factor
     int32_t *sc_flag;             // [nlocal]          bit0 out of bounds, bit1 snooker jump
     double *sc_part;              // [nlocal][ntiles]  per-tile data sums
+    // wavelet likelihood, abscissae on np.linspace's grid (x_i = fl(fl(i*step) + x0), last
+    // point = wl_xlast; checked bit for bit at creation): they are recomputed instead of
+    // stored, which frees the LDS for the data values
+    int32_t wl_grid, _pad_grid;
+    double wl_x0, wl_step, wl_xlast;
+    const double *data_t;         // wavelet: the data as [j][t] (thread t's j-th point)
     // RCCL exchange inside a hipGraph: slot `roff` of this ring receives the rows of the
     // refresh a graph node produced (fixed addresses, so the captured all-gather can be
     // replayed); nullptr = off
@@ -446,141 +452,330 @@ __device__ __forceinline__ int ilog2(int n)
     return m;
 }
 
-// Wavelet pseudo chi-squared (Carter & Winn 2009 eqs. 32-34), src_c/_dwt.c:76-114
-// over the D4 pyramid of src_c/include/wavelet.h:27-36,115-117, ndata = 2^M.
-// Level 0 takes the residuals data-model straight from global memory; the smooth
-// half of each level ping-pongs between two LDS buffers (N/2 and N/4 doubles);
-// detail coefficients are final when produced, so they are squared, weighted
-// by 1/sigma_W^2 of their scale and accumulated without ever being stored.
+// ---- wavelet likelihood: blocked D4 pyramid -------------------------------------------
+// Wavelet pseudo chi-squared (Carter & Winn 2009 eqs. 32-34), src_c/_dwt.c:76-114 over
+// the D4 pyramid of src_c/include/wavelet.h:27-36,115-117, ndata = 2^M <= 32 T.
+//
+// T = 64 WPC threads share a chain.  Thread t owns the CONTIGUOUS block of B = N/Ta points
+// [B t, B t + B) (Ta = min(T, N/2) threads take part; B is one of 2..32 and a compile-time
+// constant of the code that runs, wavelet_body<.., B>).  The data values sit in LDS for
+// the whole launch and the abscissae are recomputed (wavelet_stage below), so an
+// iteration reads no global memory but the proposal:
+//   A  log2 B levels inside the block, in registers; a level's halo (the next block's
+//      first two values, wrapping like wavelet.h:35-36) comes through LDS, one raw
+//      barrier per level from the second on; one value per thread is left;
+//   B  (more than 64 left) those values, Ta/64 per lane, go through wave 0 the same way
+//      -- no barrier, a wave's LDS traffic is ordered;
+//   C  the last <= 64 values, one per lane, level by level through LDS, still wave 0.
+// Detail coefficients are final when produced: an owner (thread / lane) adds the squares
+// of its details of one level, acc = fma(d, d, acc), and folds the level in with the weight
+// of its scale, w = fma(acc, 1/sigma_W^2, w); stage sums are halving trees, total
+// (A + B) + C (the CPU checker states the same order).
+// (Before: strided levels ping-ponging through 96 KiB of LDS, x and data re-read from L2
+// every iteration, 13 barriers, half of the instruction stream index arithmetic.)
+constexpr int WB = 32;                        // points per thread at most
+
+// What a thread needs of the chain-invariant inputs is its block of B abscissae and B data
+// values (plus the next block's first two of each).  One of the two arrays lives in LDS as
+// [j][t] (lane-contiguous: conflict-free), staged once per launch:
+//   * the DATA, when the abscissae need no storage: they lie on numpy.linspace's grid
+//     (P.wl_grid, checked bit for bit at creation) and are recomputed, or the model is a
+//     design matrix; nothing chain-invariant is then read from global memory in the loop;
+//   * otherwise the ABSCISSAE, and the data come from global memory in the same [j][t]
+//     layout (P.data_t; L2-resident, coalesced) -- the slower, general path.
+// The caller synchronises the workgroup before the first use.
 template <int WPC, int MT>
-__device__ double block_wavelet(const DevProblem &P, const double *s_nextp, double *s_part,
-                                int *s_flag, double *s_tab, double *bufA, double *bufB)
+__device__ __forceinline__ void wavelet_stage(const DevProblem &P, double *xs)
 {
-    constexpr int NV = 16 / WPC;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int T = 64 * WPC;
     const int N = P.ndata;
+    const int Ta = (N / 2 < T) ? (N / 2 > 0 ? N / 2 : 1) : T;
+    const int B = N / Ta;
+    if ((int)threadIdx.x >= Ta)
+        return;
+    const double *src = (MT == MT_LINEAR || P.wl_grid) ? P.data : P.indep;
+    for (int j = 0; j < B; ++j)
+        xs[j * T + threadIdx.x] = src[B * threadIdx.x + j];
+}
+
+// one level inside a block: v[0..NV) (+ halo at v[NV], v[NV+1]) -> v[0..NV/2), details
+// squared into the returned sum; every index static
+template <int NV, int CAP>
+__device__ __forceinline__ double block_level(double (&v)[CAP])
+{
+    static_assert(NV + 2 <= CAP, "halo slots");
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < NV / 2; ++j) {
+        double s, d;
+        d4_pair(v[2 * j], v[2 * j + 1], v[2 * j + 2], v[2 * j + 3], s, d);
+        v[j] = s;                              // (inputs of later pairs start at 2j + 2 > j)
+        acc = mc3_fma(d, d, acc);
+    }
+    return acc;
+}
+
+// stage B / stage A from the second level on: levels NV -> NV/2 -> ... -> 1 with the halo
+// exchanged through `hb` (two buffers of `stride` double2, indexed by level parity);
+// SYNC = workgroup barrier (stage A) or none (one wave, stage B)
+template <int NV, int CAP, int WPC, bool SYNC>
+__device__ __forceinline__ void block_levels(double (&v)[CAP], double &w, const double *s_tab,
+                                             int &mscale, double2 *hb, int stride, int me,
+                                             int next, bool active, int lev)
+{
+    if constexpr (NV >= 2) {
+        double2 *h = hb + (lev & 1) * stride;
+        if (active)
+            h[me] = make_double2(v[0], v[1]);
+        if constexpr (SYNC)
+            block_sync<WPC>();
+        else
+            __builtin_amdgcn_wave_barrier();
+        const double2 hv = h[next];
+        v[NV] = hv.x;
+        v[NV + 1] = hv.y;
+        const double acc = block_level<NV, CAP>(v);
+        w = mc3_fma(acc, s_tab[mscale], w);
+        mscale -= 1;
+        block_levels<NV / 2, CAP, WPC, SYNC>(v, w, s_tab, mscale, hb, stride, me, next, active,
+                                             lev + 1);
+    }
+}
+
+// Level 0 of stage A: streams the residuals data - model (src_c/_dwt.c:89) of the block,
+// two new points per output pair, so that only the B/2 smooth values are ever held.
+// GRID: x recomputed on np.linspace's grid, data from LDS; otherwise x from LDS, data from
+// the register-resident tile.  Returns the level's sum of squared details.
+template <int WPC, int MT, int B, bool GRID, int CAP>
+__device__ __forceinline__ double wavelet_level0(const DevProblem &P, const Model<MT> &model,
+                                                 const double *xs, int me, int next, int Ta,
+                                                 int &sawinf, double (&v)[CAP])
+{
+    constexpr int T = 64 * WPC;
+    const int N = P.ndata;
+    const int base = B * me;
+    double fbase = (double)base, fnext = (double)(B * next);
+    const double *xme = xs + me, *xnext = xs + next;
+    const double *dme = P.data_t + me, *dnext = P.data_t + next;
+    // All of this is invariant across the iterations of a persistent launch, and the
+    // optimiser would hoist it out of the chain loop -- 2 B values per thread parked in
+    // registers (and spilled) for good.  The empty asm makes the inputs opaque per call.
+    asm volatile("; per-iteration inputs" : "+v"(fbase), "+v"(fnext), "+v"(xme), "+v"(xnext),
+                 "+v"(dme), "+v"(dnext));
+    auto resid = [&](int j) {                           // j: static index into the block;
+        double m, dv;                                   // B, B+1: the next block's first two
+        if constexpr (MT == MT_LINEAR) {
+            m = model.at(j < B ? base + j : (base + j) & (N - 1));
+            dv = (j < B) ? xme[j * T] : xnext[(j - B) * T];
+        } else if constexpr (GRID) {
+            // numpy.linspace: y = arange(num) * step + start, y[-1] = stop
+            const double fi = (j < B) ? fbase + (double)j : fnext + (double)(j - B);
+            double x = fi * P.wl_step + P.wl_x0;
+            if (j == B - 1)
+                x = (me == Ta - 1) ? P.wl_xlast : x;
+            if (j >= B && N <= 2)
+                x = (j - B == N - 1) ? P.wl_xlast : x;
+            m = model.at_x(x);
+            dv = (j < B) ? xme[j * T] : xnext[(j - B) * T];
+        } else {
+            const double x = (j < B) ? xme[j * T] : xnext[(j - B) * T];
+            m = model.at_x(x);
+            dv = (j < B) ? dme[j * T] : dnext[(j - B) * T];
+        }
+        sawinf |= is_pos_inf(m);
+        return dv - m;
+    };
+    double acc0 = 0.0;
+    if (N >= 4) {
+        double r0 = resid(0), r1 = resid(1);
+#pragma unroll
+        for (int j = 0; j < B / 2; ++j) {
+            const double r2 = resid(2 * j + 2), r3 = resid(2 * j + 3);
+            double s, d;
+            d4_pair(r0, r1, r2, r3, s, d);
+            v[j] = s;
+            acc0 = mc3_fma(d, d, acc0);
+            r0 = r2;
+            r1 = r3;
+        }
+    } else {
+        v[0] = resid(0);                                // N = 2: no level at all
+        v[1] = resid(1);
+    }
+    return acc0;
+}
+
+template <int WPC, int MT, int B>
+__device__ __forceinline__ double wavelet_body(const DevProblem &P, const double *s_nextp,
+                                               double *s_part, int *s_flag, double *s_tab,
+                                               double *s_halo, const double *xs)
+{
+    constexpr int T = 64 * WPC;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int N = P.ndata;
+    const int M = ilog2(N);
+    const int Ta = N / B;                               // threads that own a block
+    const bool active = tid < Ta;
+    const int me = active ? tid : 0;
+    const int next = (me + 1 == Ta) ? 0 : me + 1;
     Model<MT> model;
     model.init(P, s_nextp);
     const double gam = s_nextp[P.nparams - 3];
     const double sr = s_nextp[P.nparams - 2];
     const double sw = s_nextp[P.nparams - 1];
     const double sr2 = sr * sr, sw2 = sw * sw;
-    const int M = ilog2(N);
     // The per-scale noise terms depend only on the three noise parameters: lane m of
-    // wave 0 computes sigma_W^2(m), its reciprocal (table in LDS, read by every level)
-    // and its share of the log-determinant -- one exp2 + log per lane instead of
-    // M of each on every thread.
+    // wave 0 computes sigma_W^2(m), its reciprocal (table in LDS; first needed when level
+    // 0 is folded in, behind the whole level's arithmetic) and its share of the
+    // log-determinant -- one exp2 + log per lane instead of M of each on every thread.
     double logterm = 0.0;
-    if (threadIdx.x < 64) {
+    if (tid < 64) {
         const int m = lane;
         if (m >= 1 && m < M) {
             const double sW2 = sr2 * mc3_det_exp2(-gam * (double)m) + sw2;
             s_tab[m] = 1.0 / sW2;
             logterm = (double)(1 << m) * mc3_det_log(6.283185307179586 * sW2);
         }
+        if (WPC > 1 && tid == 0)
+            s_flag[1] = 0;                              // "a model value was +inf"
     }
-    block_sync<WPC>();
     MC3_STAMP(8);
-    double acc[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v)
-        acc[v] = 0.0;
+    // ---- stage A: log2 B levels in registers ------------------------------------------
+    constexpr int HB = (B / 2 > 2) ? B / 2 : 2;
+    double v[HB + 2];
     int sawinf = 0;
-    const double *src = bufA;
+    double w = 0.0;
+    int mscale = M - 1;                                 // scale of the current level's details
+    int nn = N;
+    double acc0;
+    if (MT != MT_LINEAR && P.wl_grid)
+        acc0 = wavelet_level0<WPC, MT, B, true, HB + 2>(P, model, xs, me, next, Ta, sawinf, v);
+    else
+        acc0 = wavelet_level0<WPC, MT, B, false, HB + 2>(P, model, xs, me, next, Ta, sawinf, v);
+    if (N >= 4)
+        nn >>= 1;
+    double2 *halo = reinterpret_cast<double2 *>(s_halo);  // [2][T]
+    block_sync<WPC>();                                  // s_tab is there, s_flag[1] cleared
+    if (WPC > 1 && sawinf)
+        s_flag[1] = 1;                                  // read behind the stage-A barrier
     if (N >= 4) {
-        const int nh = N >> 1;
-        {
-            const int m = ilog2(nh);
-            const double inv = s_tab[m];
-            for (int base = 0; base < nh; base += VLANES) {
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    const int i = base + lane + 64 * (wv + WPC * v);
-                    if (i < nh) {
-                        // points 2i..2i+3 (wrapping): two aligned 16-byte loads per array
-                        const int j0 = 2 * i, j2 = (2 * i + 2) & (N - 1);
-                        double m0, m1, m2, m3;
-                        if constexpr (MT == MT_LINEAR) {
-                            m0 = model.at(j0);
-                            m1 = model.at(j0 + 1);
-                            m2 = model.at(j2);
-                            m3 = model.at(j2 + 1);
-                        } else {
-                            const double2 xa = *reinterpret_cast<const double2 *>(P.indep + j0);
-                            const double2 xb = *reinterpret_cast<const double2 *>(P.indep + j2);
-                            m0 = model.at_x(xa.x);
-                            m1 = model.at_x(xa.y);
-                            m2 = model.at_x(xb.x);
-                            m3 = model.at_x(xb.y);
-                        }
-                        sawinf |= is_pos_inf(m0) | is_pos_inf(m1) | is_pos_inf(m2) |
-                                  is_pos_inf(m3);
-                        const double2 da = *reinterpret_cast<const double2 *>(P.data + j0);
-                        const double2 db = *reinterpret_cast<const double2 *>(P.data + j2);
-                        double s, d;
-                        d4_pair(da.x - m0, da.y - m1, db.x - m2, db.y - m3, s, d);
-                        bufA[i] = s;
-                        acc[v] = mc3_fma(d * d, inv, acc[v]);
-                    }
-                }
-            }
-        }
-        block_sync<WPC>();
-        MC3_STAMP(9);
-        double *dst = bufB;
-        double *cur = bufA;
-        for (int nn = nh; nn >= 4; nn >>= 1) {
-            const int nh2 = nn >> 1;
-            const int m = ilog2(nh2);
-            const double inv = s_tab[m];
-            for (int base = 0; base < nh2; base += VLANES) {
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    const int i = base + lane + 64 * (wv + WPC * v);
-                    if (i < nh2) {
-                        double s, d;
-                        const double2 ca = *reinterpret_cast<const double2 *>(cur + 2 * i);
-                        const double2 cc = *reinterpret_cast<const double2 *>(
-                            cur + ((2 * i + 2) & (nn - 1)));       // ds_read_b128
-                        d4_pair(ca.x, ca.y, cc.x, cc.y, s, d);
-                        dst[i] = s;
-                        acc[v] = mc3_fma(d * d, inv, acc[v]);
-                    }
-                }
-            }
-            block_sync<WPC>();
-            if (nn == nh)
-                MC3_STAMP(10);
-            if (nn == 2048)
-                MC3_STAMP(11);
-            double *t = cur;
-            cur = dst;
-            dst = t;
-        }
-        MC3_STAMP(12);
-        src = cur;
-    } else {
-        if (threadIdx.x < 2) {
-            const double m = model.at(threadIdx.x);
-            sawinf |= is_pos_inf(m);
-            bufA[threadIdx.x] = P.data[threadIdx.x] - m;
-        }
-        block_sync<WPC>();
+        w = mc3_fma(acc0, s_tab[mscale], w);
+        mscale -= 1;
+        block_levels<B / 2, HB + 2, WPC, true>(v, w, s_tab, mscale, halo, T, me, next, active, 1);
+        nn = Ta;                                        // one value per thread
     }
-    const double a0 = src[0], a1 = src[1];
-    const double T = lane_tree<WPC>(acc, s_part);
-    sawinf = block_or<WPC>(sawinf, s_flag);
+    if (!active)
+        w = 0.0;
+    MC3_STAMP(9);
+    // ---- sum of stage A over the threads; the Ta values left go to wave 0 ----------------
+    double sumA, u = v[0];
+    if constexpr (WPC > 1) {
+        // (a buffer of its own: the last halo exchange may still be being read by a wave
+        // that is behind)
+        double *ubuf = s_halo + 4 * T + 64;             // [T]
+        s_part[tid] = w;
+        ubuf[tid] = v[0];
+        block_sync<WPC>();
+        if (tid >= 64)
+            return 0.0;                                 // the value is only used by wave 0
+        double p[WPC];
+#pragma unroll
+        for (int q = 0; q < WPC; ++q)
+            p[q] = s_part[lane + 64 * q];
+#pragma unroll
+        for (int s2 = WPC / 2; s2 >= 1; s2 >>= 1) {
+#pragma unroll
+            for (int q = 0; q < s2; ++q)
+                p[q] = p[q] + p[q + s2];
+        }
+        sumA = wave_sum(p[0]);
+        sawinf = s_flag[1];
+        // ---- stage B: T values, WPC per lane, levels inside the lane (Ta = T here: the
+        // geometries with several waves all have full blocks) ---------------------------------
+        double vb[WPC + 2];
+#pragma unroll
+        for (int j = 0; j < WPC; ++j)
+            vb[j] = ubuf[WPC * lane + j];
+        {
+            const int hbase = (WPC * (lane + 1)) & (T - 1);
+            vb[WPC] = ubuf[hbase];
+            vb[WPC + 1] = ubuf[hbase + 1];
+        }
+        double wb = 0.0;
+        {
+            const double acc = block_level<WPC, WPC + 2>(vb);
+            wb = mc3_fma(acc, s_tab[mscale], wb);
+            mscale -= 1;
+        }
+        block_levels<WPC / 2, WPC + 2, 1, false>(vb, wb, s_tab, mscale, halo + T, 64, lane,
+                                                 (lane + 1) & 63, true, 1);
+        sumA = sumA + wave_sum(wb);                     // (A + B)
+        u = vb[0];
+        nn = 64;
+    } else {
+        sumA = wave_sum(w);
+        sawinf = __any(sawinf) ? 1 : 0;
+    }
+    MC3_STAMP(10);
+    // ---- stage C: nn <= 64 values, one per lane ------------------------------------------
+    double wc = 0.0;
+    double *cbuf = s_halo + 4 * T;                      // [64], wave-private
+    while (nn >= 4) {
+        const int nh = nn >> 1;
+        __builtin_amdgcn_wave_barrier();
+        cbuf[lane] = u;
+        __builtin_amdgcn_wave_barrier();
+        const int i2 = (lane < nh) ? 2 * lane : 0;
+        const double2 ca = *reinterpret_cast<const double2 *>(cbuf + i2);
+        const double2 cc = *reinterpret_cast<const double2 *>(cbuf + ((i2 + 2) & (nn - 1)));
+        double s, d;
+        d4_pair(ca.x, ca.y, cc.x, cc.y, s, d);
+        if (lane < nh)
+            wc = mc3_fma(d * d, s_tab[mscale], wc);
+        u = s;
+        nn = nh;
+        mscale -= 1;
+    }
+    const double Tsum = sumA + wave_sum(wc);
+    // the two smooth coefficients left (N = 2: the two residuals, both in thread 0)
+    const double a0 = read_lane(u, 0), a1 = (N == 2) ? read_lane(v[1], 0) : read_lane(u, 1);
     MC3_STAMP(13);
     if (sawinf)
         return mc3_from_bits(0x7ff0000000000000ull);
-    if (threadIdx.x >= 64)
-        return 0.0;                               // the value is only used by wave 0
     const double sS2 = sr2 * mc3_det_exp2(-gam) * 0.72134752 + sw2;
     const double S = (a0 * a0) / sS2 + (a1 * a1) / sS2;
     double Lg = 2.0 * mc3_det_log(6.283185307179586 * sS2);
     for (int m = 1; m < M; ++m)
         Lg = Lg + read_lane(logterm, m);          // scales added in order
-    return (S + Lg) + T;
+    return (S + Lg) + Tsum;
+}
+
+// The geometry is a function of ndata alone (mc3hip.hip choose_wpc): one wave up to 2048
+// points (B = ndata/64, at least 2), four waves at 4096 (B = 16), eight above (B = 16, 32).
+template <int WPC, int MT>
+__device__ double block_wavelet(const DevProblem &P, const double *s_nextp, double *s_part,
+                                int *s_flag, double *s_tab, double *s_halo, const double *xs)
+{
+    constexpr int T = 64 * WPC;
+    const int B = (P.ndata / 2 < T) ? 2 : P.ndata / T;
+#define MC3_WL_BODY(BB)                                                                       \
+    return wavelet_body<WPC, MT, BB>(P, s_nextp, s_part, s_flag, s_tab, s_halo, xs)
+    if constexpr (WPC == 8) {
+        if (B == 32)
+            MC3_WL_BODY(32);
+        MC3_WL_BODY(16);
+    } else if constexpr (WPC == 4) {
+        MC3_WL_BODY(16);
+    } else {
+        switch (B) {
+        case 32: MC3_WL_BODY(32);
+        case 16: MC3_WL_BODY(16);
+        case 8: MC3_WL_BODY(8);
+        case 4: MC3_WL_BODY(4);
+        default: MC3_WL_BODY(2);
+        }
+    }
+#undef MC3_WL_BODY
 }
 
 // prior term, mc3/stats/stats.py:211-216 + src_c/include/stats.h:96-106
@@ -600,12 +795,12 @@ __device__ __forceinline__ double prior_term(const DevProblem &P, const double *
 template <int WPC, int MT, bool WL, bool MULTI>
 __device__ __forceinline__ double block_chisq(const DevProblem &P, const double *s_nextp,
                                               double *s_part, int *s_flag, double *s_tab,
-                                              double *bufA, double *bufB,
+                                              double *s_halo, const double *s_xs,
                                               const DataTile<WPC, MT> &tile)
 {
     double c;
     if constexpr (WL)
-        c = block_wavelet<WPC, MT>(P, s_nextp, s_part, s_flag, s_tab, bufA, bufB);
+        c = block_wavelet<WPC, MT>(P, s_nextp, s_part, s_flag, s_tab, s_halo, s_xs);
     else
         c = block_gauss<WPC, MT, MULTI>(P, s_nextp, s_part, s_flag, tile);
     if (is_pos_inf(c))
@@ -623,7 +818,7 @@ __device__ __forceinline__ double lane_serial_sum(double t, int n)
 }
 
 struct SmemLayout {
-    double *part, *nextp, *tab, *bufA, *bufB;
+    double *part, *nextp, *tab, *halo, *xs;
     int *flag;
 };
 
@@ -634,22 +829,15 @@ __device__ __forceinline__ SmemLayout carve(double *smem, const DevProblem &P, i
     L.nextp = smem + nthreads;
     L.flag = reinterpret_cast<int *>(L.nextp + MC3HIP_MAX_PARAMS);
     L.tab = L.nextp + MC3HIP_MAX_PARAMS + 2;            // 32 doubles: per-scale 1/sigma_W^2
-    L.bufA = L.tab + 32;
-    const int na = (P.ndata / 2 > 2) ? P.ndata / 2 : 2;
-    L.bufB = L.bufA + na;
+    L.halo = L.tab + 32;       // wavelet: two halo buffers of 2 doubles per thread, 64 for
+    L.xs = L.halo + 5 * nthreads + 64;     // stage C, one value per thread; then x as [B][T]
     return L;
 }
 
 static inline size_t smem_bytes(int nthreads, int ndata, int wlike)
 {
     size_t n = (size_t)nthreads + MC3HIP_MAX_PARAMS + 2 + 32;
-    if (wlike) {
-        const size_t na = (ndata / 2 > 2) ? ndata / 2 : 2;
-        const size_t nb = (ndata / 4 > 2) ? ndata / 4 : 2;
-        n += na + nb;
-    } else {
-        n += 4;
-    }
+    n += wlike ? 5 * (size_t)nthreads + 64 + (size_t)(ndata > 128 ? ndata : 128) : 4;
     return n * sizeof(double);
 }
 
@@ -1092,6 +1280,10 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     DataTile<WPC, MT> tile;
     if constexpr (!WL && PHASE == PH_FUSED)
         tile.load(P);
+    if constexpr (WL) {                        // wavelet: the data (or the abscissae) into LDS
+        wavelet_stage<WPC, MT>(P, L.xs);
+        block_sync<WPC>();
+    }
     DataTile<WPC, MT> tile1;                   // lean + MULTI: points 1024..2047 resident too
     if constexpr (FAST && MULTI)
         tile1.load(P, VLANES);
@@ -1397,7 +1589,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 nextchisq = finish_chisq<MT>(P, lc);
             } else {
                 nextchisq = block_chisq<WPC, MT, WL, MULTI>(P, L.nextp, L.part, L.flag, L.tab,
-                                                            L.bufA, L.bufB, tile);   // chain.py:249
+                                                            L.halo, L.xs, tile);   // chain.py:249
             }
             MC3_STAMP(3);
             MC3_TICK(tk2);
@@ -1840,11 +2032,13 @@ __global__ __launch_bounds__(64 * WPC) void eval_chisq_kernel(const DevProblem P
     DataTile<WPC, MT> tile;
     if constexpr (!WL)
         tile.load(P);
+    if constexpr (WL)
+        wavelet_stage<WPC, MT>(P, L.xs);         // (the __syncthreads below covers it)
     for (int q = threadIdx.x; q < P.nparams; q += 64 * WPC)
         L.nextp[q] = params[(size_t)blockIdx.x * P.nparams + q];
     __syncthreads();
-    const double c = block_chisq<WPC, MT, WL, true>(P, L.nextp, L.part, L.flag, L.tab, L.bufA,
-                                                    L.bufB, tile);
+    const double c = block_chisq<WPC, MT, WL, true>(P, L.nextp, L.part, L.flag, L.tab, L.halo,
+                                                    L.xs, tile);
     if (threadIdx.x == 0)
         out[blockIdx.x] = c;
 }

@@ -94,13 +94,20 @@ int choose_wpc(int nlocal, int ndata, int wlike)
     // One wave per chain when there are enough chains to fill the chip or the
     // data sum is short; otherwise split a chain's data over 4 or 16 waves.
     const char *env = getenv("MC3HIP_WPC");
+    if (wlike) {
+        // blocked D4 pyramid (chain_kernels.h block_wavelet): at most 32 points per thread;
+        // one wave per chain up to 2048 points (no barrier at all), four at 4096, eight
+        // above (two per SIMD: a wave alone issues FP64 at half rate).  The geometry is a
+        // function of ndata alone; the summation order follows it, mc3hip_get_plan reports
+        // it and the checker follows.
+        (void)env;
+        return (ndata > 4096) ? 8 : (ndata > 2048 ? 4 : 1);
+    }
     if (env) {
         const int v = atoi(env);
         if (v == 1 || v == 4 || v == 16)
             return v;
     }
-    if (wlike)
-        return (ndata >= 4096) ? 16 : (ndata >= 512 ? 4 : 1);
     if (ndata <= 4096)
         return 1;
     if (nlocal >= 1024)
@@ -215,12 +222,18 @@ int dev_upload(mc3hip_ctx *c, const T **dst, const T *src, size_t count)
     return MC3HIP_OK;
 }
 
+// Waves per chain are dispatched as {1, 4, 16}; the wavelet geometries have 1, 4 or 8:
+// the widest one rides on the dispatch slot of the widest Gaussian one.
+template <int WPC>
+constexpr int wavelet_waves() { return WPC == 16 ? 8 : WPC; }
+
 template <int WPC, int MT>
 void launch_step_t(mc3hip_ctx *c, int roff)
 {
+    constexpr int WW = wavelet_waves<WPC>();
     if (c->P.wlike)
-        hipLaunchKernelGGL((step_kernel<WPC, MT, true, false>), dim3(c->P.nlocal),
-                           dim3(64 * WPC), c->smem, c->stream, c->P, roff);
+        hipLaunchKernelGGL((step_kernel<WW, MT, true, false>), dim3(c->P.nlocal),
+                           dim3(64 * WW), c->smem, c->stream, c->P, roff);
     else if (c->P.npad > VLANES)
         hipLaunchKernelGGL((step_kernel<WPC, MT, false, true>), dim3(c->P.nlocal),
                            dim3(64 * WPC), c->smem, c->stream, c->P, roff);
@@ -416,8 +429,9 @@ template <int WPC, int MT>
 void persist_instance_t(mc3hip_ctx *c, bool p2p, fast_kernel_fn *out)
 {
     fast_kernel_fn f;
+    constexpr int WW = wavelet_waves<WPC>();
     if (c->P.wlike)
-        f = p2p ? persist_kernel<WPC, MT, true, false, true> : persist_kernel<WPC, MT, true, false>;
+        f = p2p ? persist_kernel<WW, MT, true, false, true> : persist_kernel<WW, MT, true, false>;
     else if (c->P.npad > VLANES)
         f = p2p ? persist_kernel<WPC, MT, false, true, true> : persist_kernel<WPC, MT, false, true>;
     else
@@ -429,8 +443,9 @@ void persist_instance_t(mc3hip_ctx *c, bool p2p, fast_kernel_fn *out)
 template <int WPC, int MT>
 void launch_eval_t(mc3hip_ctx *c, int n)
 {
+    constexpr int WW = wavelet_waves<WPC>();
     if (c->P.wlike)
-        hipLaunchKernelGGL((eval_chisq_kernel<WPC, MT, true>), dim3(n), dim3(64 * WPC), c->smem,
+        hipLaunchKernelGGL((eval_chisq_kernel<WW, MT, true>), dim3(n), dim3(64 * WW), c->smem,
                            c->stream, c->P, (const double *)c->eval_params, c->eval_out);
     else
         hipLaunchKernelGGL((eval_chisq_kernel<WPC, MT, false>), dim3(n), dim3(64 * WPC), c->smem,
@@ -456,6 +471,7 @@ void launch_model_t(mc3hip_ctx *c)
 
 #define DISPATCH(FN, ...)                                                           \
     switch (c->wpc) {                                                               \
+    case 8:                                                                         \
     case 16: DISPATCH_MT(FN, 16, __VA_ARGS__) break;                                \
     case 4: DISPATCH_MT(FN, 4, __VA_ARGS__) break;                                  \
     default: DISPATCH_MT(FN, 1, __VA_ARGS__) break;                                 \
@@ -555,10 +571,11 @@ int set_smem_attr(mc3hip_ctx *c)
     if (c->smem <= 64 * 1024)
         return MC3HIP_OK;
 #define SET_ATTR(WPC, MT)                                                                  \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&step_kernel<WPC, MT, true, false>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->smem)); \
     HIP_TRY(hipFuncSetAttribute(                                                            \
-        reinterpret_cast<const void *>(&eval_chisq_kernel<WPC, MT, true>),                  \
+        reinterpret_cast<const void *>(&step_kernel<wavelet_waves<WPC>(), MT, true, false>), \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->smem));                         \
+    HIP_TRY(hipFuncSetAttribute(                                                            \
+        reinterpret_cast<const void *>(&eval_chisq_kernel<wavelet_waves<WPC>(), MT, true>), \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->smem));
 #define SET_ATTR_MT(WPC)                                                            \
     switch (c->mt) {                                                                \
@@ -569,6 +586,7 @@ int set_smem_attr(mc3hip_ctx *c)
     default: SET_ATTR(WPC, MT_POLY_GENERIC) break;                                  \
     }
     switch (c->wpc) {
+    case 8:
     case 16: SET_ATTR_MT(16) break;
     case 4: SET_ATTR_MT(4) break;
     default: SET_ATTR_MT(1) break;
@@ -821,6 +839,32 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
             w[i] = pr->wlike ? 1.0 : 1.0 / pr->uncert[i];
         TRY(dev_upload(c, &P.data, d.data(), npad));
         TRY(dev_upload(c, &P.w, w.data(), npad));
+    }
+    if (pr->wlike && pr->model_kind == MC3HIP_MODEL_POLY && nd >= 2 && !getenv("MC3HIP_NO_GRID")) {
+        // abscissae made by numpy.linspace (y = arange(num) * step + start, y[-1] = stop)?
+        // Checked bit for bit; if so the wavelet kernel recomputes them (block_wavelet)
+        const double x0 = pr->indep[0], xl = pr->indep[nd - 1];
+        const double step = (xl - x0) / (double)(nd - 1);
+        bool grid = step != 0.0 && std::isfinite(step);
+        for (size_t i = 0; grid && i + 1 < nd; ++i) {
+            volatile double prod = (double)i * step;         // (separately rounded, no fma)
+            grid = (prod + x0) == pr->indep[i];
+        }
+        P.wl_grid = grid ? 1 : 0;
+        P.wl_x0 = x0;
+        P.wl_step = step;
+        P.wl_xlast = xl;
+    }
+    if (pr->wlike) {
+        // the data in the blocked layout of the wavelet kernel, [j][t] = point B t + j
+        const int T = 64 * choose_wpc(pr->nlocal, pr->ndata, 1);
+        const int Ta = (pr->ndata / 2 < T) ? (pr->ndata / 2 > 0 ? pr->ndata / 2 : 1) : T;
+        const int B = pr->ndata / Ta;
+        std::vector<double> dt((size_t)B * T, 0.0);
+        for (int t = 0; t < Ta; ++t)
+            for (int j = 0; j < B; ++j)
+                dt[(size_t)j * T + t] = pr->data[(size_t)B * t + j];
+        TRY(dev_upload(c, &P.data_t, dt.data(), dt.size()));
     }
     const size_t zl = (size_t)pr->zlen, nl = (size_t)pr->nlocal;
     P.zs = (int32_t)(((nf + ZROW - 1) / ZROW) * ZROW);       // whole 128-byte lines per row

@@ -30,7 +30,7 @@ class _Problem(ctypes.Structure):
         ('thinning', ctypes.c_int32),
         ('ngprior', ctypes.c_int32),
         ('tile', ctypes.c_int32), ('vlanes', ctypes.c_int32),
-        ('_pad', ctypes.c_int32),
+        ('wl_threads', ctypes.c_int32),
         ('M0', ctypes.c_int64), ('zlen', ctypes.c_int64),
         ('seed', ctypes.c_uint64),
         ('gamma', ctypes.c_double), ('fepsilon', ctypes.c_double),
@@ -66,15 +66,17 @@ class LockstepRun:
 
     indep: x[ndata] for model='poly' (coefficients = params[0:nmodel]),
            A[nmodel, ndata] for model='linear' (model = sum_k A[k]*params[k]).
-    tile/vlanes: the data-sum order ("reduction plan") of the kernel this run is
-    checking; the HIP library reports the plan it used.
+    tile/vlanes/wl_threads: the data-sum order ("reduction plan") of the kernel this
+    run is checking; the HIP library reports the plan it used (wl_threads = 64 x
+    waves per chain on the wavelet path).
     """
 
     def __init__(self, data, uncert, indep, params, pstep, pmin=None, pmax=None,
                  prior=None, priorlow=None, priorup=None, nchains=7,
                  nsamples=None, sampler='snooker', wlike=False, thinning=1,
                  fgamma=1.0, fepsilon=0.0, hsize=10, model='poly', nmodel=None,
-                 seed=0, tile=0, vlanes=None, chain0=0, nlocal=None, M0=None):
+                 seed=0, tile=0, vlanes=None, chain0=0, nlocal=None, M0=None,
+                 wl_threads=0):
         L = ok.lib()
         L.ls_run.restype = ctypes.c_int
         L.ls_eval_chisq.restype = ctypes.c_int
@@ -144,6 +146,7 @@ class LockstepRun:
         P.ngprior = len(self.igprior)
         P.tile = int(tile)
         P.vlanes = int(vlanes)
+        P.wl_threads = int(wl_threads)      # 0: the library's default geometry
         P.M0 = self.M0
         P.zlen = self.zlen
         P.seed = int(seed)

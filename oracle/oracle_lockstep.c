@@ -53,7 +53,7 @@ typedef struct {
     int32_t sampler, wlike, model_kind, nmodel, thinning;
     int32_t ngprior;
     int32_t tile, vlanes;
-    int32_t _pad;
+    int32_t wl_threads;     /* wavelet path: threads that share a chain (64 * waves) */
     int64_t M0, zlen;
     uint64_t seed;
     double gamma, fepsilon;
@@ -307,19 +307,69 @@ static double gauss_chisq(const ls_problem *P, const double *p, double *part)
 
 /* Wavelet pseudo chi-squared: src_c/_dwt.c:76-114, wavelet.h:27-36,115-117.
  * ndata = 2^M.  Detail coefficients are consumed as they are produced (they
- * are final once written, wavelet.h:33,36), weighted by 1/sigma_W^2 of their
- * scale; only the smooth half goes on to the next level. */
+ * are final once written, wavelet.h:33,36); only the smooth half goes on to the
+ * next level.  The pyramid is the reference's; what is canonical here is only the
+ * ORDER in which the squared details are added up, which follows the blocked
+ * layout of the kernel (chain_kernels.h block_wavelet) for T = wl_threads threads:
+ *   pre    while more than 32 T values are left: output i of a level belongs to
+ *          thread i mod T (large ndata only);
+ *   A      Ta = min(T, n/2) threads own contiguous blocks of B = n/Ta values and run
+ *          log2 B levels inside their block (halo: the next block's first two
+ *          values, wrapping), leaving one value per thread;
+ *   B      more than 64 values left: the same again with 64 lanes of one wave;
+ *   C      at most 64 values left, one per lane: output i of a level belongs to
+ *          lane i.
+ * An owner adds the squares of its details of one level in index order,
+ * acc = fma(d, d, acc), and folds the level in with the weight of its scale,
+ * w = fma(acc, 1/sigma_W^2, w); the owners' w are summed by a halving tree per
+ * stage, and the stages as (A + B) + C (pre shares A's accumulators). */
 static const double D4C0 = 0.4829629131445341, D4C1 = 0.83651630373780772,
                     D4C2 = 0.22414386804201339, D4C3 = -0.12940952255126034;
+
+/* threads per chain of the wavelet geometry: as given, or the library's default rule
+ * (mc3hip.hip choose_wpc: one wave up to 2048 points, four at 4096, eight above) */
+static int wl_threads_of(const ls_problem *P)
+{
+    if (P->wl_threads >= 64)
+        return P->wl_threads;
+    return P->ndata > 4096 ? 512 : (P->ndata > 2048 ? 256 : 64);
+}
+
+static int ilog2i(int n)
+{
+    int m = 0;
+    while ((1 << m) < n)
+        m++;
+    return m;
+}
+
+/* one level nn -> nn/2 of a[] into b[]; detail i is added to acc[owner(i)] */
+static void d4_level(const double *a, double *b, int nn, double *acc, int block, int stride_T)
+{
+    const int nh = nn >> 1;
+    for (int i = 0; i < nh; i++) {
+        const double a0 = a[2*i], a1 = a[2*i + 1];
+        const double a2 = a[(2*i + 2) & (nn - 1)], a3 = a[(2*i + 3) & (nn - 1)];
+        double s = D4C0 * a0;
+        s = mc3_fma(D4C1, a1, s);
+        s = mc3_fma(D4C2, a2, s);
+        s = mc3_fma(D4C3, a3, s);
+        double d = D4C3 * a0;
+        d = mc3_fma(-D4C2, a1, d);
+        d = mc3_fma(D4C1, a2, d);
+        d = mc3_fma(-D4C0, a3, d);
+        b[i] = s;
+        const int owner = stride_T ? i % stride_T : i / block;
+        acc[owner] = mc3_fma(d, d, acc[owner]);
+    }
+}
 
 static double wavelet_chisq(const ls_problem *P, const double *p,
                             double *buf0, double *buf1, double *part)
 {
     const int N = P->ndata;
-    const int VL = P->vlanes;
-    int M = 0;
-    while ((1 << M) < N)
-        M++;
+    const int T = wl_threads_of(P);
+    const int M = ilog2i(N);
     const double gam = p[P->nparams - 3];
     const double sr = p[P->nparams - 2];
     const double sw = p[P->nparams - 1];
@@ -333,34 +383,73 @@ static double wavelet_chisq(const ls_problem *P, const double *p,
     }
     if (sawinf)
         return INFINITY;
-    for (int l = 0; l < VL; l++)
-        part[l] = 0.0;
-    double *a = buf0, *b = buf1;
-    for (int nn = N; nn >= 4; nn >>= 1) {
-        const int nh = nn >> 1;
-        int m = 0;
-        while ((1 << m) < nh)
-            m++;                                       /* scale of this level's details */
-        const double sW2 = sr2 * mc3_det_exp2(-gam * (double)m) + sw2;
-        const double inv = 1.0 / sW2;
-        for (int i = 0; i < nh; i++) {
-            const double a0 = a[2*i], a1 = a[2*i + 1];
-            const double a2 = a[(2*i + 2) & (nn - 1)], a3 = a[(2*i + 3) & (nn - 1)];
-            double s = D4C0 * a0;
-            s = mc3_fma(D4C1, a1, s);
-            s = mc3_fma(D4C2, a2, s);
-            s = mc3_fma(D4C3, a3, s);
-            double d = D4C3 * a0;
-            d = mc3_fma(-D4C2, a1, d);
-            d = mc3_fma(D4C1, a2, d);
-            d = mc3_fma(-D4C0, a3, d);
-            b[i] = s;
-            const int l = i % VL;
-            part[l] = mc3_fma(d * d, inv, part[l]);
+    double inv[32];
+    for (int m = 1; m < M; m++)
+        inv[m] = 1.0 / (sr2 * mc3_det_exp2(-gam * (double)m) + sw2);
+    /* part[] holds 2 T doubles here: w[T] and acc[T] (scratch_alloc sizes it) */
+    double *w = part, *acc = part + T;
+    double *a = buf0, *b = buf1, *t;
+    int nn = N;
+    for (int l = 0; l < T; l++)
+        w[l] = acc[l] = 0.0;
+    /* pre: strided owners while the blocks would exceed 32 values per thread */
+    while (nn > 32 * T) {
+        d4_level(a, b, nn, acc, 0, T);
+        const double iv = inv[ilog2i(nn >> 1)];
+        for (int l = 0; l < T; l++) {
+            w[l] = mc3_fma(acc[l], iv, w[l]);
+            acc[l] = 0.0;
         }
-        double *t = a; a = b; b = t;
+        t = a; a = b; b = t;
+        nn >>= 1;
     }
-    const double T = halving_tree(part, VL);
+    /* A: contiguous blocks, levels inside the block */
+    double sumA = 0.0, sumB = 0.0, sumC = 0.0;
+    {
+        const int Ta = (nn / 2 < T) ? (nn / 2 > 0 ? nn / 2 : 1) : T;
+        for (int n = nn / Ta; n >= 2 && nn >= 4; n >>= 1) {
+            d4_level(a, b, nn, acc, n / 2, 0);
+            const double iv = inv[ilog2i(nn >> 1)];
+            for (int l = 0; l < Ta; l++) {
+                w[l] = mc3_fma(acc[l], iv, w[l]);
+                acc[l] = 0.0;
+            }
+            t = a; a = b; b = t;
+            nn >>= 1;
+        }
+        sumA = halving_tree(w, T);
+    }
+    /* B: one wave, blocks of nn/64 */
+    if (nn > 64) {
+        for (int l = 0; l < 64; l++)
+            w[l] = acc[l] = 0.0;
+        for (int n = nn / 64; n >= 2 && nn >= 4; n >>= 1) {
+            d4_level(a, b, nn, acc, n / 2, 0);
+            const double iv = inv[ilog2i(nn >> 1)];
+            for (int l = 0; l < 64; l++) {
+                w[l] = mc3_fma(acc[l], iv, w[l]);
+                acc[l] = 0.0;
+            }
+            t = a; a = b; b = t;
+            nn >>= 1;
+        }
+        sumB = halving_tree(w, 64);
+    }
+    /* C: one value per lane */
+    for (int l = 0; l < 64; l++)
+        w[l] = acc[l] = 0.0;
+    while (nn >= 4) {
+        d4_level(a, b, nn, acc, 1, 0);
+        const double iv = inv[ilog2i(nn >> 1)];
+        for (int l = 0; l < 64; l++) {
+            w[l] = mc3_fma(acc[l], iv, w[l]);
+            acc[l] = 0.0;
+        }
+        t = a; a = b; b = t;
+        nn >>= 1;
+    }
+    sumC = halving_tree(w, 64);
+    const double Tsum = (sumA + sumB) + sumC;
     const double sS2 = sr2 * mc3_det_exp2(-gam) * 0.72134752 + sw2;
     const double S = (a[0] * a[0]) / sS2 + (a[1] * a[1]) / sS2;
     double Lg = 2.0 * mc3_det_log(6.283185307179586 * sS2);
@@ -368,7 +457,7 @@ static double wavelet_chisq(const ls_problem *P, const double *p,
         const double sW2 = sr2 * mc3_det_exp2(-gam * (double)m) + sw2;
         Lg = Lg + (double)(1 << m) * mc3_det_log(6.283185307179586 * sW2);
     }
-    const double c = (S + Lg) + T;
+    const double c = (S + Lg) + Tsum;
     if (c == INFINITY)
         return c;
     return c + prior_term(P, p);
@@ -377,6 +466,13 @@ static double wavelet_chisq(const ls_problem *P, const double *p,
 typedef struct {
     double *part, *buf0, *buf1, *nextp, *jump, *normal, *dz;
 } ls_scratch;
+
+static size_t part_doubles(const ls_problem *P)
+{
+    const size_t T = (size_t)wl_threads_of(P);
+    const size_t n = 2 * T > 128 ? 2 * T : 128;
+    return n > (size_t)P->vlanes ? n : (size_t)P->vlanes;
+}
 
 static double eval_chisq(const ls_problem *P, const double *p, ls_scratch *S)
 {
@@ -390,7 +486,7 @@ int ls_eval_chisq(const ls_problem *P, const double *params, int n, double *out)
 {
     ls_scratch S;
     memset(&S, 0, sizeof S);
-    S.part = malloc(sizeof(double) * (size_t)P->vlanes);
+    S.part = malloc(sizeof(double) * part_doubles(P));
     S.buf0 = malloc(sizeof(double) * (size_t)P->ndata);
     S.buf1 = malloc(sizeof(double) * (size_t)P->ndata);
     for (int r = 0; r < n; r++)
@@ -531,7 +627,7 @@ static void chain_step(const ls_problem *P, ls_state *St, ls_scratch *S, ls_draw
 
 static void scratch_alloc(const ls_problem *P, ls_scratch *S)
 {
-    S->part = malloc(sizeof(double) * (size_t)P->vlanes);
+    S->part = malloc(sizeof(double) * part_doubles(P));
     S->buf0 = malloc(sizeof(double) * (size_t)P->ndata);
     S->buf1 = malloc(sizeof(double) * (size_t)P->ndata);
     S->nextp = malloc(sizeof(double) * (size_t)P->nparams);

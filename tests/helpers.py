@@ -97,8 +97,15 @@ def linear_problem(ndata=512, nmodel=10, nchains=16, nsamples=1600,
     return prob
 
 
-def make_oracle(prob, **extra):
+def make_oracle(prob, plan=None, **extra):
+    """The lockstep oracle for a problem; ``plan`` (DeviceChains.plan) makes it sum the
+    data in the order the library reports: tile size, virtual lanes and -- wavelet
+    likelihood -- the threads that share a chain."""
     kw = dict(prob)
+    if plan is not None:
+        kw.update(tile=plan['tile'], vlanes=plan['vlanes'])
+        if prob.get('wlike'):
+            kw['wl_threads'] = 64*plan['waves_per_chain']
     kw.update(extra)
     from oracle import lockstep as ls      # (lazily: tools/ import this module for the
     return ls.LockstepRun(**kw)            # problem builders only and must not load oracle/)

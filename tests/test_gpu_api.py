@@ -98,7 +98,7 @@ def test_rccl_path_single_rank_in_a_graph(sampler, builder):
         gpu = engine.DeviceChains(**prob)
     finally:
         del os.environ['MC3HIP_GRAPH_NODES']
-    orc = H.make_oracle(prob, tile=gpu.plan['tile'])
+    orc = H.make_oracle(prob, plan=gpu.plan)
     Z0, lp0 = H.initial_population(orc)
     orc.set_population(Z0, lp0)
     orc.run(nthreads=4)

@@ -162,7 +162,7 @@ def test_lean_kernels_random_problem(seed):
     assert plan['persistent'] > 0 and plan['fast'] > 0, label
     lean_loop = prob['sampler'] == 'demc' and prob['thinning'] == 1
     assert (plan['fast'] == 2) == lean_loop, label
-    orc = H.make_oracle(prob, tile=plan['tile'])
+    orc = H.make_oracle(prob, plan=plan)
     Z0, lp0 = H.initial_population(orc, seed=seed)
     orc.set_population(Z0, lp0)
     gpu.set_population(Z0, lp0)
@@ -194,7 +194,7 @@ def test_random_problem(seed):
         gpu = engine.DeviceChains(trace_iters=niter if traced else 0, **prob, **kw)
     finally:
         os.environ.pop('MC3HIP_WPC', None)
-    orc = H.make_oracle(prob, tile=gpu.plan['tile'])
+    orc = H.make_oracle(prob, plan=gpu.plan)
     Z0, lp0 = H.initial_population(orc, seed=seed)
     orc.set_population(Z0, lp0)
     gpu.set_population(Z0, lp0)

@@ -28,7 +28,7 @@ def run_pair(eng, prob, trace=True, nrefresh=None, **gpu_kw):
     niter = int(np.ceil(prob['nsamples']/prob['nchains']/thin))*thin
     gpu = eng.DeviceChains(trace_iters=niter if trace else 0, **prob, **gpu_kw)
     # the oracle sums the data in the order ("plan") the library reports
-    orc = H.make_oracle(prob, tile=gpu.plan['tile'], vlanes=gpu.plan['vlanes'])
+    orc = H.make_oracle(prob, plan=gpu.plan)
     Z0, lp0 = H.initial_population(orc)
     orc.set_population(Z0, lp0)
     gpu.set_population(Z0, lp0)
@@ -154,16 +154,14 @@ def test_wavelet_chisq_vs_reference_vectors(eng, golden_dir, ndata):
     base = dict(data=data, uncert=np.ones(ndata), indep=x, params=P[0],
                 pstep=np.array([1.0, 1, 1, 0, 1, 1]), nchains=4, nsamples=40,
                 sampler='snooker', wlike=True)
-    for wpc in ('1', '4', '16'):
-        os.environ['MC3HIP_WPC'] = wpc
-        try:
-            with eng.DeviceChains(**base) as g:
-                assert g.plan['waves_per_chain'] == int(wpc)
-                got = g.eval_chisq(P)
-        finally:
-            del os.environ['MC3HIP_WPC']
-        np.testing.assert_allclose(got, kv[f'dwt_{ndata}_chisq'], rtol=1e-10)
-        np.testing.assert_array_equal(got, H.make_oracle(base).eval_chisq(P))
+    # the geometry of the blocked pyramid is a function of ndata alone (1, 4 or 8 waves
+    # per chain); the checker follows the one the plan reports
+    with eng.DeviceChains(**base) as g:
+        plan = g.plan
+        assert plan['waves_per_chain'] == (8 if ndata > 4096 else 4 if ndata > 2048 else 1)
+        got = g.eval_chisq(P)
+    np.testing.assert_allclose(got, kv[f'dwt_{ndata}_chisq'], rtol=1e-10)
+    np.testing.assert_array_equal(got, H.make_oracle(base, plan=plan).eval_chisq(P))
     pri = dict(prior=kv['dwt_prior'], priorlow=kv['dwt_priorlow'],
                priorup=kv['dwt_priorup'])
     with eng.DeviceChains(**base, **pri) as g:
@@ -238,9 +236,18 @@ def test_shared_fixed_priors_bounds_bit_exact(eng, sampler):
     gpu.close()
 
 
-@pytest.mark.parametrize('ndata', [64, 1024])
+@pytest.mark.parametrize('ndata', [2, 4, 8, 16, 64, 128, 256, 512, 1024, 2048, 4096, 8192])
 def test_wavelet_chains_bit_exact(eng, ndata):
     prob = H.wavelet_problem(ndata=ndata, nsamples=7*60)
+    orc, gpu = run_pair(eng, prob)
+    assert_same(orc, gpu)
+    gpu.close()
+
+
+@pytest.mark.parametrize('sampler', ['demc', 'mrw'])
+@pytest.mark.parametrize('ndata', [32, 512, 4096, 16384])
+def test_wavelet_other_samplers_bit_exact(eng, ndata, sampler):
+    prob = H.wavelet_problem(ndata=ndata, nsamples=7*30, sampler=sampler)
     orc, gpu = run_pair(eng, prob)
     assert_same(orc, gpu)
     gpu.close()
@@ -463,10 +470,10 @@ def test_error_paths(eng):
 # ---- BASELINE.json configs 4 and 5 at full size ----------------------------
 def test_config_c4_wavelet_full_size(eng):
     """C4: wavelet likelihood, ndata = 2^14, 256 chains, snooker -- 12 iterations
-    bit-exact against the oracle (1 chain per CU, 96 KiB of LDS each)."""
+    bit-exact against the oracle (1 chain per CU: 8 waves, 32 points per thread)."""
     prob = H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*12)
     orc, gpu = run_pair(eng, prob, trace=True)
-    assert gpu.plan['waves_per_chain'] == 16
+    assert gpu.plan['waves_per_chain'] == 8
     assert_same(orc, gpu)
     gpu.close()
 

@@ -49,7 +49,7 @@ CONFIGS = {
 }
 BYTES = {'c2': 24104, 'c2snooker': 24104, 'c3one': 24104, 'c4': 8*2*16384 + 8*5*4 + 8,
          'c5': 8*12*100000 + 8*10*4 + 8, 'c5share': 8*12*100000 + 8*10*4 + 8}
-ITERS = {'c2': 20000, 'c2snooker': 20000, 'c3one': 4000, 'c4': 400, 'c5': 30, 'c5share': 1}
+ITERS = {'c2': 20000, 'c2snooker': 20000, 'c3one': 4000, 'c4': 4000, 'c5': 30, 'c5share': 1}
 ITERS['c5'] = 300
 
 

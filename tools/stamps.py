@@ -68,9 +68,9 @@ if n == 0:
     print('  (no samples: the hand-laid-out DEMC loop keeps per-phase tick sums instead -- '
           'tools/ticks.py; or STAMP_MODE=launch / MC3HIP_NO_LEAN=1 for the stamped kernels)')
 if which == 'c4':
-    w = [int(out[i]) for i in (2, 8, 9, 10, 11, 12, 13, 3)]
-    lab = ['chisq entry -> noise table', '-> level 0 (global -> LDS)', '-> level 1', '-> levels 2..3',
-           '-> levels 4..12', '-> final reduction', '-> chisq done']
+    w = [int(out[i]) for i in (2, 8, 9, 10, 13, 3)]
+    lab = ['chisq entry -> noise table issued', '-> stage A (levels in registers)',
+           '-> tree + stage B (wave 0)', '-> stage C (wave 0)', '-> chisq done']
     print('  wavelet, last sample:')
     for k, v in zip(lab, np.diff(w)):
         print(f'    {k:30s} {v:9d}')
