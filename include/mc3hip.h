@@ -117,6 +117,17 @@ void mc3hip_destroy(mc3hip_ctx *ctx);
 const char *mc3hip_last_error(void);
 int mc3hip_get_plan(const mc3hip_ctx *ctx, mc3hip_plan *plan);
 
+/* Replaces the hub's initial-population loop (mc3/mcmc_driver.py:229-270): M0 trial
+ * vectors around the initial guess (kickoff 0: params + pstep * N(0,1); 1: uniform between
+ * the boundaries), the reference's acceptance rule applied in trial order (inside the
+ * boundaries -- shared parameters tested with the copies the last accepted trial left --
+ * and finite chisq; at most 100 M0 failures), chisq on the device.  Trials are drawn from
+ * Philox(seed) on a stream of their own, so the population does not depend on how the
+ * chains are sharded.  Z0 [M0][nfree] and log_post0 [M0] receive the rows (zeros beyond
+ * *filled); the caller applies the reference's "filled >= M0 - 1" test. */
+int mc3hip_init_population(mc3hip_ctx *ctx, int32_t kickoff, uint64_t seed, double *Z0,
+                           double *log_post0, int64_t *filled, int64_t *failed);
+
 /* Replaces the hub's Z[0:M0] / log_post[0:M0] fill and the workers' start-up
  * (mcmc_driver.py:260-261, chain.py:163-170): Z0 is [M0][nfree], the chains start
  * from its first nchains rows unless X0/chisq0 ([nchains][nfree], [nchains]) are
@@ -163,6 +174,10 @@ int mc3hip_get_trace(mc3hip_ctx *ctx, int64_t iters, double *chisq,
  * chain's first `burn` rows; [nchains][nfree] each.  The caller combines them into
  * the potential scale reduction factor; Z is not copied to the host. */
 int mc3hip_chain_moments(mc3hip_ctx *ctx, int64_t burn, double *mean, double *var);
+/* The same over the first nrefresh refreshes' rows as they stand in Z, whoever wrote them
+ * (rows installed with mc3hip_put_rows, e.g. those of a run that is being resumed). */
+int mc3hip_chain_moments_rows(mc3hip_ctx *ctx, int64_t nrefresh, int64_t burn,
+                              double *mean, double *var);
 
 /* Replaces Chain.eval_model(params, ret='chisq') -> ms.chisq / ms.dwt_chisq
  * (chain.py:302-340, stats.py:150-284, _chisq.c:111-140, _dwt.c:56-119) for n

@@ -95,10 +95,15 @@ MC3_HD double mc3_det_exp2(double y)
     if (y < -1080.0)
         return 0.0;
     const double kd = __builtin_rint(y);
-    const double p = mc3_det_exp((y - kd) * 0.6931471805599453);
     const int k = (int)kd;
     const int k1 = k / 2;
     const int k2 = k - k1;
+    /* integer y (the wavelet noise model with gamma = 1, the only value the reference
+     * supports, src_c/_dwt.c:42): mc3_det_exp(0) is exactly 1, so the product below is the
+     * same number without the polynomial (tests/test_detmath_philox.py checks every k) */
+    if (y == kd)
+        return mc3_pow2i(k1) * mc3_pow2i(k2);
+    const double p = mc3_det_exp((y - kd) * 0.6931471805599453);
     return (p * mc3_pow2i(k1)) * mc3_pow2i(k2);
 }
 

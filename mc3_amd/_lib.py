@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libmc3hip.so')
+# (MC3HIP_LIBRARY: a diagnostic build of the same library, e.g. tools/stamps.py's)
+LIB_PATH = os.environ.get('MC3HIP_LIBRARY') or os.path.join(HERE, 'libmc3hip.so')
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int32)
@@ -69,6 +70,8 @@ SYMBOLS = {
     'mc3hip_destroy': (None, [_vp]),
     'mc3hip_last_error': (ctypes.c_char_p, []),
     'mc3hip_get_plan': (ctypes.c_int, [_vp, ctypes.POINTER(Plan)]),
+    'mc3hip_init_population': (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_uint64, _dp, _dp,
+                                              _lp, _lp]),
     'mc3hip_set_population': (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp]),
     'mc3hip_run': (ctypes.c_int, [_vp, ctypes.c_int64]),
     'mc3hip_sync': (ctypes.c_int, [_vp]),
@@ -78,6 +81,7 @@ SYMBOLS = {
     'mc3hip_get_state': (ctypes.c_int, [_vp, _dp, _dp, _lp, _lp, _dp, _lp, _dp, _lp]),
     'mc3hip_get_trace': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _ip]),
     'mc3hip_chain_moments': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _dp]),
+    'mc3hip_chain_moments_rows': (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, _dp, _dp]),
     'mc3hip_eval_chisq': (ctypes.c_int, [_vp, _dp, ctypes.c_int32, _dp]),
     'mc3hip_eval_model': (ctypes.c_int, [_vp, _dp, _dp]),
     'mc3hip_residuals': (ctypes.c_int, [ctypes.c_int32, _dp, _dp, _dp, ctypes.c_int32, _dp, _dp,

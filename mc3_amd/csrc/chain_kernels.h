@@ -107,9 +107,37 @@ constexpr int SC_STRIDE = MC3HIP_MAX_PARAMS + 16;   // doubles per sc_nextp row 
     do {                                                                                  \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");       \
     } while (0)
+// Non-draining stamps for the kernels with dynamic LDS (wavelet path): the shader clock
+// goes to a spare corner of the LDS noise table (slots 16..31 of `tab`, SmemLayout) and is
+// copied out once per iteration (MC3_LSTAMP_FLUSH), so that no stamp waits for the store
+// of the one before it.
+extern __shared__ __attribute__((aligned(16))) double mc3_smem_stamps_[];
+#ifdef MC3HIP_NO_LSTAMP
+#define MC3_LSTAMP(slot) do { } while (0)
+#define MC3_LSTAMP_FLUSH() do { } while (0)
+#else
+#define MC3_LSTAMP(slot)                                                                  \
+    do {                                                                                  \
+        /* (the builtin, not inline asm with an SGPR output: some stamps sit in control    \
+           flow the compiler considers divergent) */                                      \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                       \
+        if (threadIdx.x == 0 && blockIdx.x == 0)                                          \
+            reinterpret_cast<unsigned long long *>(mc3_smem_stamps_)[blockDim.x +         \
+                MC3HIP_MAX_PARAMS + 2 + 16 + (slot)] = t_;                                \
+    } while (0)
+#define MC3_LSTAMP_FLUSH()                                                                \
+    do {                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.x == 0)                                          \
+            for (int q_ = 0; q_ < 16; ++q_)                                               \
+                P.stamps[q_] = reinterpret_cast<unsigned long long *>(                    \
+                    mc3_smem_stamps_)[blockDim.x + MC3HIP_MAX_PARAMS + 2 + 16 + q_];      \
+    } while (0)
+#endif
 #else
 #define MC3_STAMP(slot) do { } while (0)
 #define MC3_TICK(var) do { } while (0)
+#define MC3_LSTAMP(slot) do { } while (0)
+#define MC3_LSTAMP_FLUSH() do { } while (0)
 #endif
 
 __device__ __forceinline__ double make_double(int lo, int hi) { return __hiloint2double(hi, lo); }
@@ -517,14 +545,16 @@ __device__ __forceinline__ double block_level(double (&v)[CAP])
 
 // stage B / stage A from the second level on: levels NV -> NV/2 -> ... -> 1 with the halo
 // exchanged through `hb` (two buffers of `stride` double2, indexed by level parity);
-// SYNC = workgroup barrier (stage A) or none (one wave, stage B)
-template <int NV, int CAP, int WPC, bool SYNC>
-__device__ __forceinline__ void block_levels(double (&v)[CAP], double &w, const double *s_tab,
-                                             int &mscale, double2 *hb, int stride, int me,
-                                             int next, bool active, int lev)
+// SYNC = workgroup barrier (stage A) or none (one wave, stage B).  accs[LEV], accs[LEV+1],
+// ... receive the levels' sums of squared details (weighted later, in level order).
+template <int NV, int CAP, int WPC, bool SYNC, int LEV, int NACC>
+__device__ __forceinline__ void block_levels(double (&v)[CAP], double (&accs)[NACC],
+                                             double2 *hb, int stride, int me, int next,
+                                             bool active)
 {
     if constexpr (NV >= 2) {
-        double2 *h = hb + (lev & 1) * stride;
+        static_assert(LEV < NACC, "one slot per level");
+        double2 *h = hb + (LEV & 1) * stride;
         if (active)
             h[me] = make_double2(v[0], v[1]);
         if constexpr (SYNC)
@@ -534,12 +564,24 @@ __device__ __forceinline__ void block_levels(double (&v)[CAP], double &w, const 
         const double2 hv = h[next];
         v[NV] = hv.x;
         v[NV + 1] = hv.y;
-        const double acc = block_level<NV, CAP>(v);
-        w = mc3_fma(acc, s_tab[mscale], w);
-        mscale -= 1;
-        block_levels<NV / 2, CAP, WPC, SYNC>(v, w, s_tab, mscale, hb, stride, me, next, active,
-                                             lev + 1);
+        accs[LEV] = block_level<NV, CAP>(v);
+        block_levels<NV / 2, CAP, WPC, SYNC, LEV + 1, NACC>(v, accs, hb, stride, me, next, active);
     }
+}
+
+constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n / 2); }
+
+// the levels' sums of squared details folded in with the weights of their scales
+// (1/sigma_W^2 of scale m0, m0 - 1, ...), in level order
+template <int NLEV, int NACC>
+__device__ __forceinline__ double weigh_levels(const double (&accs)[NACC], const double *s_tab,
+                                               int m0)
+{
+    double w = 0.0;
+#pragma unroll
+    for (int l = 0; l < NLEV; ++l)
+        w = mc3_fma(accs[l], s_tab[m0 - l], w);
+    return w;
 }
 
 // Level 0 of stage A: streams the residuals data - model (src_c/_dwt.c:89) of the block,
@@ -555,18 +597,34 @@ __device__ __forceinline__ double wavelet_level0(const DevProblem &P, const Mode
     const int N = P.ndata;
     const int base = B * me;
     double fbase = (double)base, fnext = (double)(B * next);
-    const double *xme = xs + me, *xnext = xs + next;
-    const double *dme = P.data_t + me, *dnext = P.data_t + next;
+    int ome = me, onext = next;
     // All of this is invariant across the iterations of a persistent launch, and the
     // optimiser would hoist it out of the chain loop -- 2 B values per thread parked in
-    // registers (and spilled) for good.  The empty asm makes the inputs opaque per call.
-    asm volatile("; per-iteration inputs" : "+v"(fbase), "+v"(fnext), "+v"(xme), "+v"(xnext),
-                 "+v"(dme), "+v"(dnext));
+    // registers (and spilled) for good.  The empty asm makes the inputs opaque per call
+    // (offsets, not pointers: a laundered pointer loses its address space and the LDS
+    // reads would become flat loads).
+    asm volatile("; per-iteration inputs" : "+v"(fbase), "+v"(fnext), "+v"(ome), "+v"(onext));
+    const double *xme = xs + ome, *xnext = xs + onext;
+    const double *dme = P.data_t + ome, *dnext = P.data_t + onext;
+    // what a point needs from LDS / global memory is requested PF points ahead of its use:
+    // far enough to cover the latency behind the arithmetic of the points in between,
+    // near enough to keep only a few values in flight (registers)
+    constexpr int PF = 8;
+    double in0[B + 2], in1[(MT != MT_LINEAR && !GRID) ? B + 2 : 1];
+    auto fetch = [&](int j) {                           // static j
+        in0[j] = (j < B) ? xme[j * T] : xnext[(j - B) * T];
+        if constexpr (MT != MT_LINEAR && !GRID)
+            in1[j] = (j < B) ? dme[j * T] : dnext[(j - B) * T];
+    };
+#pragma unroll
+    for (int j = 0; j < PF + 2 && j < B + 2; ++j)
+        fetch(j);
+    (void)in1;
     auto resid = [&](int j) {                           // j: static index into the block;
         double m, dv;                                   // B, B+1: the next block's first two
         if constexpr (MT == MT_LINEAR) {
             m = model.at(j < B ? base + j : (base + j) & (N - 1));
-            dv = (j < B) ? xme[j * T] : xnext[(j - B) * T];
+            dv = in0[j];
         } else if constexpr (GRID) {
             // numpy.linspace: y = arange(num) * step + start, y[-1] = stop
             const double fi = (j < B) ? fbase + (double)j : fnext + (double)(j - B);
@@ -576,11 +634,10 @@ __device__ __forceinline__ double wavelet_level0(const DevProblem &P, const Mode
             if (j >= B && N <= 2)
                 x = (j - B == N - 1) ? P.wl_xlast : x;
             m = model.at_x(x);
-            dv = (j < B) ? xme[j * T] : xnext[(j - B) * T];
+            dv = in0[j];
         } else {
-            const double x = (j < B) ? xme[j * T] : xnext[(j - B) * T];
-            m = model.at_x(x);
-            dv = (j < B) ? dme[j * T] : dnext[(j - B) * T];
+            m = model.at_x(in0[j]);
+            dv = in1[j];
         }
         sawinf |= is_pos_inf(m);
         return dv - m;
@@ -590,6 +647,10 @@ __device__ __forceinline__ double wavelet_level0(const DevProblem &P, const Mode
         double r0 = resid(0), r1 = resid(1);
 #pragma unroll
         for (int j = 0; j < B / 2; ++j) {
+            if (2 * j + 2 + PF < B + 2) {
+                fetch(2 * j + 2 + PF);
+                fetch(2 * j + 3 + PF);
+            }
             const double r2 = resid(2 * j + 2), r3 = resid(2 * j + 3);
             double s, d;
             d4_pair(r0, r1, r2, r3, s, d);
@@ -605,13 +666,47 @@ __device__ __forceinline__ double wavelet_level0(const DevProblem &P, const Mode
     return acc0;
 }
 
+// The per-scale noise terms depend only on the three noise parameters: lane m computes
+// sigma_W^2(m), its reciprocal (table in LDS) and its share of the log-determinant, lane
+// 0 the smooth coefficients' sigma_S^2 -- one exp2 + log per lane instead of M of each on
+// every thread -- and the log-determinant is summed in scale order.  Results in LDS:
+// s_tab[1..M-1] = 1/sigma_W^2, s_tab[14] = sigma_S^2, s_tab[15] = the log-determinant.
+__device__ __forceinline__ void wavelet_noise_terms(const double *s_nextp, int nparams, int M,
+                                                    double *s_tab)
+{
+    const int lane = threadIdx.x & 63;
+    const double gam = s_nextp[nparams - 3];
+    const double sr = s_nextp[nparams - 2];
+    const double sw = s_nextp[nparams - 1];
+    const double sr2 = sr * sr, sw2 = sw * sw;
+    double term = 0.0;
+    if (lane >= 1 && lane < M) {
+        const double sW2 = sr2 * mc3_det_exp2(-gam * (double)lane) + sw2;
+        s_tab[lane] = 1.0 / sW2;
+        term = (double)(1 << lane) * mc3_det_log(6.283185307179586 * sW2);
+    } else if (lane == 0) {
+        const double sS2 = sr2 * mc3_det_exp2(-gam) * 0.72134752 + sw2;
+        s_tab[14] = sS2;
+        term = 2.0 * mc3_det_log(6.283185307179586 * sS2);
+    }
+    double Lg = read_lane(term, 0);
+    for (int m = 1; m < M; ++m)
+        Lg = Lg + read_lane(term, m);             // scales added in order
+    if (lane == 0)
+        s_tab[15] = Lg;
+}
+
 template <int WPC, int MT, int B>
 __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double *s_nextp,
                                                double *s_part, int *s_flag, double *s_tab,
                                                double *s_halo, const double *xs)
 {
     constexpr int T = 64 * WPC;
+    constexpr int NLA = ilog2c(B);                      // levels of stage A (N >= 4)
+    constexpr int NLB = ilog2c(WPC);                    // levels of stage B
     const int tid = threadIdx.x, lane = tid & 63;
+    // (made wave-uniform by hand so that the per-wave roles below are scalar branches)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = P.ndata;
     const int M = ilog2(N);
     const int Ta = N / B;                               // threads that own a block
@@ -620,63 +715,96 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
     const int next = (me + 1 == Ta) ? 0 : me + 1;
     Model<MT> model;
     model.init(P, s_nextp);
-    const double gam = s_nextp[P.nparams - 3];
-    const double sr = s_nextp[P.nparams - 2];
-    const double sw = s_nextp[P.nparams - 1];
-    const double sr2 = sr * sr, sw2 = sw * sw;
-    // The per-scale noise terms depend only on the three noise parameters: lane m of
-    // wave 0 computes sigma_W^2(m), its reciprocal (table in LDS; first needed when level
-    // 0 is folded in, behind the whole level's arithmetic) and its share of the
-    // log-determinant -- one exp2 + log per lane instead of M of each on every thread.
-    double logterm = 0.0;
-    if (tid < 64) {
-        const int m = lane;
-        if (m >= 1 && m < M) {
-            const double sW2 = sr2 * mc3_det_exp2(-gam * (double)m) + sw2;
-            s_tab[m] = 1.0 / sW2;
-            logterm = (double)(1 << m) * mc3_det_log(6.283185307179586 * sW2);
-        }
-        if (WPC > 1 && tid == 0)
-            s_flag[1] = 0;                              // "a model value was +inf"
-    }
-    MC3_STAMP(8);
+    if (WPC > 1 && tid == 0)
+        s_flag[1] = 0;                                  // "a model value was +inf"
+    // One wave: the noise terms first.  Several waves: the LAST wave computes them after its
+    // share of stage A, while wave 0 is busy with stages B and C -- two long dependent chains
+    // (software exp2 / log; cross-lane levels) side by side instead of one after the other.
+    if constexpr (WPC == 1)
+        wavelet_noise_terms(s_nextp, P.nparams, M, s_tab);
+    MC3_LSTAMP(8);
     // ---- stage A: log2 B levels in registers ------------------------------------------
     constexpr int HB = (B / 2 > 2) ? B / 2 : 2;
     double v[HB + 2];
+    double accA[NLA > 0 ? NLA : 1];
     int sawinf = 0;
-    double w = 0.0;
-    int mscale = M - 1;                                 // scale of the current level's details
     int nn = N;
-    double acc0;
     if (MT != MT_LINEAR && P.wl_grid)
-        acc0 = wavelet_level0<WPC, MT, B, true, HB + 2>(P, model, xs, me, next, Ta, sawinf, v);
+        accA[0] = wavelet_level0<WPC, MT, B, true, HB + 2>(P, model, xs, me, next, Ta, sawinf, v);
     else
-        acc0 = wavelet_level0<WPC, MT, B, false, HB + 2>(P, model, xs, me, next, Ta, sawinf, v);
-    if (N >= 4)
-        nn >>= 1;
+        accA[0] = wavelet_level0<WPC, MT, B, false, HB + 2>(P, model, xs, me, next, Ta, sawinf, v);
+    MC3_LSTAMP(14);
     double2 *halo = reinterpret_cast<double2 *>(s_halo);  // [2][T]
-    block_sync<WPC>();                                  // s_tab is there, s_flag[1] cleared
-    if (WPC > 1 && sawinf)
-        s_flag[1] = 1;                                  // read behind the stage-A barrier
     if (N >= 4) {
-        w = mc3_fma(acc0, s_tab[mscale], w);
-        mscale -= 1;
-        block_levels<B / 2, HB + 2, WPC, true>(v, w, s_tab, mscale, halo, T, me, next, active, 1);
+        block_levels<B / 2, HB + 2, WPC, true, 1, (NLA > 0 ? NLA : 1)>(v, accA, halo, T, me, next,
+                                                                        active);
         nn = Ta;                                        // one value per thread
     }
-    if (!active)
-        w = 0.0;
-    MC3_STAMP(9);
-    // ---- sum of stage A over the threads; the Ta values left go to wave 0 ----------------
+    MC3_LSTAMP(9);
+    const int mA = M - 1;                               // scale of level 0's details
     double sumA, u = v[0];
+    int mscale = (N >= 4) ? mA - NLA : mA;              // scale of the next level's details
+    double accB[NLB > 0 ? NLB : 1];
     if constexpr (WPC > 1) {
         // (a buffer of its own: the last halo exchange may still be being read by a wave
         // that is behind)
         double *ubuf = s_halo + 4 * T + 64;             // [T]
-        s_part[tid] = w;
         ubuf[tid] = v[0];
-        block_sync<WPC>();
-        if (tid >= 64)
+        if (sawinf)
+            s_flag[1] = 1;
+        block_sync<WPC>();                              // (1) the T values are in LDS
+        if (wave == WPC - 1)
+            wavelet_noise_terms(s_nextp, P.nparams, M, s_tab);
+        if (wave == 0) {
+            // ---- stage B: T values, WPC per lane, levels inside the lane -----------------
+            double vb[WPC + 2];
+#pragma unroll
+            for (int j = 0; j < WPC; ++j)
+                vb[j] = ubuf[WPC * lane + j];
+            const int hbase = (WPC * (lane + 1)) & (T - 1);
+            vb[WPC] = ubuf[hbase];
+            vb[WPC + 1] = ubuf[hbase + 1];
+            accB[0] = block_level<WPC, WPC + 2>(vb);
+            block_levels<WPC / 2, WPC + 2, 1, false, 1, (NLB > 0 ? NLB : 1)>(
+                vb, accB, halo + T, 64, lane, (lane + 1) & 63, true);
+            u = vb[0];
+        }
+        mscale -= NLB;
+        nn = 64;
+    }
+    MC3_LSTAMP(10);
+    // ---- stage C: nn <= 64 values, one per lane (wave 0) ------------------------------------
+    double accC[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const int mC = mscale;
+    int nC = 0;
+    if (wave == 0) {
+        double *cbuf = s_halo + 4 * T;                  // [64], wave-private
+#pragma unroll
+        for (int l = 0; l < 6; ++l) {
+            if (nn >= 4) {
+                const int nh = nn >> 1;
+                __builtin_amdgcn_wave_barrier();
+                cbuf[lane] = u;
+                __builtin_amdgcn_wave_barrier();
+                const int i2 = (lane < nh) ? 2 * lane : 0;
+                const double2 ca = *reinterpret_cast<const double2 *>(cbuf + i2);
+                const double2 cc = *reinterpret_cast<const double2 *>(cbuf + ((i2 + 2) & (nn - 1)));
+                double s, d;
+                d4_pair(ca.x, ca.y, cc.x, cc.y, s, d);
+                accC[l] = (lane < nh) ? d * d : 0.0;
+                u = s;
+                nn = nh;
+                nC = l + 1;
+            }
+        }
+    }
+    MC3_LSTAMP(12);
+    double Tsum;
+    if constexpr (WPC > 1) {
+        block_sync<WPC>();                              // (2) the noise terms are in LDS
+        s_part[tid] = (active && N >= 4) ? weigh_levels<NLA>(accA, s_tab, mA) : 0.0;
+        block_sync<WPC>();                              // (3) every thread's stage-A sum
+        if (wave != 0)
             return 0.0;                                 // the value is only used by wave 0
         double p[WPC];
 #pragma unroll
@@ -690,64 +818,27 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
         }
         sumA = wave_sum(p[0]);
         sawinf = s_flag[1];
-        // ---- stage B: T values, WPC per lane, levels inside the lane (Ta = T here: the
-        // geometries with several waves all have full blocks) ---------------------------------
-        double vb[WPC + 2];
-#pragma unroll
-        for (int j = 0; j < WPC; ++j)
-            vb[j] = ubuf[WPC * lane + j];
-        {
-            const int hbase = (WPC * (lane + 1)) & (T - 1);
-            vb[WPC] = ubuf[hbase];
-            vb[WPC + 1] = ubuf[hbase + 1];
-        }
-        double wb = 0.0;
-        {
-            const double acc = block_level<WPC, WPC + 2>(vb);
-            wb = mc3_fma(acc, s_tab[mscale], wb);
-            mscale -= 1;
-        }
-        block_levels<WPC / 2, WPC + 2, 1, false>(vb, wb, s_tab, mscale, halo + T, 64, lane,
-                                                 (lane + 1) & 63, true, 1);
-        sumA = sumA + wave_sum(wb);                     // (A + B)
-        u = vb[0];
-        nn = 64;
+        sumA = sumA + wave_sum(weigh_levels<NLB>(accB, s_tab, mA - NLA));      // (A + B)
     } else {
-        sumA = wave_sum(w);
+        sumA = wave_sum((active && N >= 4) ? weigh_levels<NLA>(accA, s_tab, mA) : 0.0);
         sawinf = __any(sawinf) ? 1 : 0;
     }
-    MC3_STAMP(10);
-    // ---- stage C: nn <= 64 values, one per lane ------------------------------------------
-    double wc = 0.0;
-    double *cbuf = s_halo + 4 * T;                      // [64], wave-private
-    while (nn >= 4) {
-        const int nh = nn >> 1;
-        __builtin_amdgcn_wave_barrier();
-        cbuf[lane] = u;
-        __builtin_amdgcn_wave_barrier();
-        const int i2 = (lane < nh) ? 2 * lane : 0;
-        const double2 ca = *reinterpret_cast<const double2 *>(cbuf + i2);
-        const double2 cc = *reinterpret_cast<const double2 *>(cbuf + ((i2 + 2) & (nn - 1)));
-        double s, d;
-        d4_pair(ca.x, ca.y, cc.x, cc.y, s, d);
-        if (lane < nh)
-            wc = mc3_fma(d * d, s_tab[mscale], wc);
-        u = s;
-        nn = nh;
-        mscale -= 1;
+    {
+        double wc = 0.0;
+#pragma unroll
+        for (int l = 0; l < 6; ++l)
+            if (l < nC)
+                wc = mc3_fma(accC[l], s_tab[mC - l], wc);
+        Tsum = sumA + wave_sum(wc);
     }
-    const double Tsum = sumA + wave_sum(wc);
     // the two smooth coefficients left (N = 2: the two residuals, both in thread 0)
     const double a0 = read_lane(u, 0), a1 = (N == 2) ? read_lane(v[1], 0) : read_lane(u, 1);
-    MC3_STAMP(13);
+    MC3_LSTAMP(13);
     if (sawinf)
         return mc3_from_bits(0x7ff0000000000000ull);
-    const double sS2 = sr2 * mc3_det_exp2(-gam) * 0.72134752 + sw2;
+    const double sS2 = s_tab[14];
     const double S = (a0 * a0) / sS2 + (a1 * a1) / sS2;
-    double Lg = 2.0 * mc3_det_log(6.283185307179586 * sS2);
-    for (int m = 1; m < M; ++m)
-        Lg = Lg + read_lane(logterm, m);          // scales added in order
-    return (S + Lg) + Tsum;
+    return (S + s_tab[15]) + Tsum;
 }
 
 // The geometry is a function of ndata alone (mc3hip.hip choose_wpc): one wave up to 2048
@@ -1380,7 +1471,10 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     const int jfirst = (TH == 1) ? 0 : jb;
     const int jlast = (TH == 1) ? 1 : je;
     for (int j = jfirst; j < jlast; ++j) {
-        MC3_STAMP(5);
+        if constexpr (WL)
+            MC3_LSTAMP(5);
+        else
+            MC3_STAMP(5);
         unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
         MC3_TICK(tk0);
 #ifdef MC3HIP_STAMPS
@@ -1561,7 +1655,10 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 break;
         } else {
             block_sync<WPC>();
-            MC3_STAMP(2);
+            if constexpr (WL)
+                MC3_LSTAMP(2);
+            else
+                MC3_STAMP(2);
             anyout = L.flag[0] != 0;
             if constexpr (PERSIST) {
                 alive = L.flag[2] != 0;
@@ -1591,7 +1688,10 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 nextchisq = block_chisq<WPC, MT, WL, MULTI>(P, L.nextp, L.part, L.flag, L.tab,
                                                             L.halo, L.xs, tile);   // chain.py:249
             }
-            MC3_STAMP(3);
+            if constexpr (WL)
+                MC3_LSTAMP(3);
+            else
+                MC3_STAMP(3);
             MC3_TICK(tk2);
             if (wave0) {
                 if (PHASE != PH_FINISH && sjump) {                   // chain.py:251-255
@@ -1633,7 +1733,12 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
         }
         if constexpr (!FAST)
             block_sync<WPC>();
-        MC3_STAMP(6);
+        if constexpr (WL) {
+            MC3_LSTAMP(6);
+            MC3_LSTAMP_FLUSH();
+        } else {
+            MC3_STAMP(6);
+        }
 #ifdef MC3HIP_STAMPS
         MC3_TICK(tk3);
         if (tk1 != 0 && tk2 != 0) {
@@ -2206,6 +2311,104 @@ __global__ void unpack_rows_kernel(double *padded, const double *dense, long lon
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x)
         padded[(i / nf) * zs + (i % nf)] = dense[i];
+}
+
+// ---- initial population on the device (mc3/mcmc_driver.py:229-270) -------------------
+// Trial t of the kick-off: nfree draws around the initial guess ('normal': params +
+// pstep * N(0,1), Box-Muller pairs; 'uniform': between the boundaries), keyed like every
+// other draw by Philox(seed; counter = (t, chain = 0xffffffff, slot)) -- a chain id no walker
+// has.  One thread per trial writes the full parameter vector (fixed values kept, shared
+// parameters copied, chain.py:246-247) for the chisq kernel, the free parameters, and
+// whether the FREE parameters are inside their boundaries.
+constexpr uint32_t KICKOFF_STREAM = 0xffffffffu;
+
+__global__ void init_trials_kernel(const DevProblem P, int kickoff_uniform, uint64_t seed,
+                                   long long t0, int ntrial, double *full, double *freep,
+                                   int32_t *inside)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntrial)
+        return;
+    const uint64_t t = (uint64_t)(t0 + i);
+    double *row = full + (size_t)i * P.nparams;
+    for (int j = 0; j < P.nparams; ++j)
+        row[j] = P.params[j];
+    int ok = 1;
+    for (int k2 = 0; 2 * k2 < P.nfree; ++k2) {
+        const Draw2 d = draw2(seed, t, KICKOFF_STREAM, (uint32_t)k2);
+        double a, b;
+        if (kickoff_uniform) {
+            a = u01(d.q0);
+            b = u01(d.q1);
+        } else {
+            const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(d.q0)));
+            double sn, cs;
+            mc3_det_sincos2pi(u01(d.q1), &sn, &cs);
+            a = rad * cs;
+            b = rad * sn;
+        }
+        for (int h = 0; h < 2; ++h) {
+            const int k = 2 * k2 + h;
+            if (k >= P.nfree)
+                break;
+            const double r = h ? b : a;
+            const int j = P.ifree[k];
+            const double v = kickoff_uniform ? P.fmin[k] + (P.fmax[k] - P.fmin[k]) * r
+                                             : P.params[j] + P.fstep[k] * r;
+            row[j] = v;
+            freep[(size_t)i * P.nfree + k] = v;
+            ok &= !(v < P.fmin[k] || v > P.fmax[k]);
+        }
+    }
+    for (int sidx = 0; sidx < P.nshare; ++sidx)
+        row[P.ishare[sidx]] = row[P.share_src[sidx]];
+    inside[i] = ok;
+}
+
+// The reference's acceptance rule, in trial order (one thread: the rule is sequential and
+// the work is a few operations per trial).  A trial counts as a failure when a parameter
+// lies outside its boundaries -- tested on the full vector BEFORE the shared parameters are
+// refreshed, i.e. with the copies the last in-bounds trial left (mcmc_driver.py:249-255) --
+// or when its chisq is not finite; the loop ends with M0 rows or after 100 M0 failures.
+// st[0] = rows filled, st[1] = failures, st[2] = trials consumed; stale[] = the shared
+// parameters' current copies.
+__global__ void init_scan_kernel(const DevProblem P, int ntrial, const double *full,
+                                 const double *freep, const int32_t *inside,
+                                 const double *chisq, long long *st, double *stale,
+                                 double *Z0, double *lp0)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0)
+        return;
+    long long filled = st[0], failed = st[1], used = st[2];
+    const long long M0 = P.M0, nmax = 100 * P.M0;
+    for (int i = 0; i < ntrial; ++i) {
+        if (filled == M0 || failed == nmax)
+            break;
+        used += 1;
+        bool ok = inside[i] != 0;
+        for (int sidx = 0; sidx < P.nshare && ok; ++sidx) {
+            const int j = P.ishare[sidx];
+            ok = !(stale[sidx] > P.pmax[j] || stale[sidx] < P.pmin[j]);
+        }
+        if (!ok) {
+            failed += 1;
+            continue;
+        }
+        for (int sidx = 0; sidx < P.nshare; ++sidx)
+            stale[sidx] = full[(size_t)i * P.nparams + P.share_src[sidx]];
+        const double lp = -0.5 * chisq[i];
+        if ((mc3_bits(lp) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull) {
+            failed += 1;                                  // inf or NaN
+            continue;
+        }
+        for (int k = 0; k < P.nfree; ++k)
+            Z0[(size_t)filled * P.nfree + k] = freep[(size_t)i * P.nfree + k];
+        lp0[filled] = lp;
+        filled += 1;
+    }
+    st[0] = filled;
+    st[1] = failed;
+    st[2] = used;
 }
 
 __global__ void set_ctl_kernel(long long *ctl, long long base, long long run0)

@@ -1446,13 +1446,9 @@ int mc3hip_get_trace(mc3hip_ctx *c, int64_t iters, double *chisq, int32_t *flags
     return MC3HIP_OK;
 }
 
-int mc3hip_chain_moments(mc3hip_ctx *c, int64_t burn, double *mean, double *var)
+static int chain_moments(mc3hip_ctx *c, int64_t nrefresh, int64_t burn, double *mean,
+                         double *var)
 {
-    if (!c || !mean || !var)
-        return fail(MC3HIP_ERR_ARG, "null argument");
-    if (burn < 0 || burn >= c->refresh_done)
-        return fail(MC3HIP_ERR_ARG, "burn=%lld leaves no rows (%lld refreshes done)",
-                    (long long)burn, (long long)c->refresh_done);
     {
         const int rc_settle = settle(c);
         if (rc_settle)
@@ -1464,7 +1460,7 @@ int mc3hip_chain_moments(mc3hip_ctx *c, int64_t burn, double *mean, double *var)
     double *dm = c->moments, *dv = dm + n;
     hipLaunchKernelGGL(chain_moments_kernel, dim3(c->P.nchains), dim3(256), 0, c->stream,
                        (const double *)c->P.Z, (long long)c->P.M0, c->P.nchains, c->P.nfree,
-                       c->P.zs, (long long)c->refresh_done, (long long)burn, dm, dv);
+                       c->P.zs, (long long)nrefresh, (long long)burn, dm, dv);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipMemcpyAsync(mean, dm, n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
@@ -1474,6 +1470,42 @@ int mc3hip_chain_moments(mc3hip_ctx *c, int64_t burn, double *mean, double *var)
         e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess)
         return fail(MC3HIP_ERR_HIP, "chain_moments: %s", hipGetErrorString(e));
+    return MC3HIP_OK;
+}
+
+int mc3hip_chain_moments(mc3hip_ctx *c, int64_t burn, double *mean, double *var)
+{
+    if (!c || !mean || !var)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    if (burn < 0 || burn >= c->refresh_done)
+        return fail(MC3HIP_ERR_ARG, "burn=%lld leaves no rows (%lld refreshes done)",
+                    (long long)burn, (long long)c->refresh_done);
+    return chain_moments(c, c->refresh_done, burn, mean, var);
+}
+
+int mc3hip_chain_moments_rows(mc3hip_ctx *c, int64_t nrefresh, int64_t burn, double *mean,
+                              double *var)
+{
+    if (!c || !mean || !var)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    if (burn < 0 || burn >= nrefresh || c->P.M0 + nrefresh * c->P.nchains > c->zlen)
+        return fail(MC3HIP_ERR_ARG, "burn=%lld of %lld refreshes (Z holds %lld rows)",
+                    (long long)burn, (long long)nrefresh, (long long)c->zlen);
+    return chain_moments(c, nrefresh, burn, mean, var);
+}
+
+static int eval_reserve(mc3hip_ctx *c, int n)
+{
+    if (n <= c->eval_cap)
+        return MC3HIP_OK;
+    // grow-only scratch; freed with the context
+    const int cap = n < 1024 ? 1024 : n;
+    double *p = nullptr, *o = nullptr;
+    RC_TRY(dev_alloc(c, &p, (size_t)cap * (size_t)c->P.nparams));
+    RC_TRY(dev_alloc(c, &o, (size_t)cap));
+    c->eval_params = p;
+    c->eval_out = o;
+    c->eval_cap = cap;
     return MC3HIP_OK;
 }
 
@@ -1487,20 +1519,7 @@ int mc3hip_eval_chisq(mc3hip_ctx *c, const double *params, int32_t n, double *ch
         return MC3HIP_OK;
     HIP_TRY(hipSetDevice(c->device));
     const size_t np = (size_t)c->P.nparams;
-    if (n > c->eval_cap) {
-        // grow-only scratch; freed with the context
-        int cap = n < 1024 ? 1024 : n;
-        double *p = nullptr, *o = nullptr;
-        int rc = dev_alloc(c, &p, (size_t)cap * np);
-        if (rc)
-            return rc;
-        rc = dev_alloc(c, &o, (size_t)cap);
-        if (rc)
-            return rc;
-        c->eval_params = p;
-        c->eval_out = o;
-        c->eval_cap = cap;
-    }
+    RC_TRY(eval_reserve(c, n));
     HIP_TRY(hipMemcpyAsync(c->eval_params, params, (size_t)n * np * sizeof(double),
                            hipMemcpyHostToDevice, c->stream));
     launch_eval(c, n);
@@ -1508,6 +1527,70 @@ int mc3hip_eval_chisq(mc3hip_ctx *c, const double *params, int32_t n, double *ch
     HIP_TRY(hipMemcpyAsync(chisq_out, c->eval_out, (size_t)n * sizeof(double),
                            hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return MC3HIP_OK;
+}
+
+int mc3hip_init_population(mc3hip_ctx *c, int32_t kickoff, uint64_t seed, double *Z0,
+                           double *log_post0, int64_t *filled_out, int64_t *failed_out)
+{
+    if (!c || !Z0 || !log_post0 || !filled_out || !failed_out)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    if (kickoff != 0 && kickoff != 1)
+        return fail(MC3HIP_ERR_ARG, "kickoff must be 0 (normal) or 1 (uniform)");
+    HIP_TRY(hipSetDevice(c->device));
+    const DevProblem &P = c->P;
+    const size_t nf = (size_t)P.nfree, M0 = (size_t)P.M0, ns = (size_t)P.nshare;
+    // rounds of trials: generate + chisq in parallel, accept in order
+    const int block = (int)(2 * M0 < 4096 ? 4096 : (2 * M0 > (1u << 20) ? (1u << 20) : 2 * M0));
+    RC_TRY(eval_reserve(c, block));
+    double *freep = nullptr, *dZ0 = nullptr, *dlp0 = nullptr, *stale = nullptr;
+    int32_t *inside = nullptr;
+    long long *st = nullptr;
+    // (scratch of this call: one allocation, released on every way out)
+    const size_t bytes = ((size_t)block * nf + M0 * nf + M0 + ns + 8) * sizeof(double) +
+                         (size_t)block * sizeof(int32_t) + 64;
+    void *buf = nullptr;
+    HIP_TRY(hipMalloc(&buf, bytes));
+    struct Free { void *p; ~Free() { (void)hipFree(p); } } guard{buf};
+    freep = static_cast<double *>(buf);
+    dZ0 = freep + (size_t)block * nf;
+    dlp0 = dZ0 + M0 * nf;
+    stale = dlp0 + M0;
+    st = reinterpret_cast<long long *>(stale + ns + 1);
+    inside = reinterpret_cast<int32_t *>(st + 4);
+    {
+        // the shared parameters' copies start as given (mcmc_driver.py:242: values = params)
+        std::vector<double> h(ns + 1, 0.0);
+        std::vector<double> hp((size_t)P.nparams);
+        HIP_TRY(hipMemcpy(hp.data(), P.params, hp.size() * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<int32_t> hs(ns ? ns : 1);
+        if (ns)
+            HIP_TRY(hipMemcpy(hs.data(), P.ishare, ns * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (size_t q = 0; q < ns; ++q)
+            h[q] = hp[(size_t)hs[q]];
+        HIP_TRY(hipMemcpy(stale, h.data(), (ns + 1) * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemsetAsync(st, 0, 4 * sizeof(long long), c->stream));
+    HIP_TRY(hipMemsetAsync(dZ0, 0, (M0 * nf + M0) * sizeof(double), c->stream));
+    long long host_st[4] = {0, 0, 0, 0};
+    long long t0 = 0;
+    while ((size_t)host_st[0] < M0 && host_st[1] < 100 * (long long)M0) {
+        hipLaunchKernelGGL(init_trials_kernel, dim3((block + 127) / 128), dim3(128), 0, c->stream,
+                           P, kickoff, seed, t0, block, c->eval_params, freep, inside);
+        launch_eval(c, block);
+        hipLaunchKernelGGL(init_scan_kernel, dim3(1), dim3(64), 0, c->stream, P, block,
+                           (const double *)c->eval_params, (const double *)freep,
+                           (const int32_t *)inside, (const double *)c->eval_out, st, stale, dZ0,
+                           dlp0);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(host_st, st, sizeof host_st, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        t0 += block;
+    }
+    HIP_TRY(hipMemcpy(Z0, dZ0, M0 * nf * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(log_post0, dlp0, M0 * sizeof(double), hipMemcpyDeviceToHost));
+    *filled_out = host_st[0];
+    *failed_out = host_st[1];
     return MC3HIP_OK;
 }
 

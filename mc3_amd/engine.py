@@ -136,6 +136,20 @@ class DeviceChains:
         self.close()
 
     # -- the hot path ----------------------------------------------------------
+    def init_population(self, kickoff='normal', seed=None):
+        """The initial population on the device (mc3/mcmc_driver.py:229-270): returns
+        (Z0 [M0, nfree], log_post0 [M0], filled, failed); rows beyond ``filled`` are
+        zeros.  Draws: Philox(seed) on a stream of its own."""
+        if kickoff not in ('normal', 'uniform'):
+            raise ValueError(f"Invalid kickoff '{kickoff}'")
+        Z0 = np.zeros((self.M0, self.nfree))
+        lp0 = np.zeros(self.M0)
+        filled, failed = ctypes.c_int64(), ctypes.c_int64()
+        check(self.lib.mc3hip_init_population(
+            self._ctx, int(kickoff == 'uniform'), int(self.seed if seed is None else seed),
+            dptr(Z0), dptr(lp0), ctypes.byref(filled), ctypes.byref(failed)))
+        return Z0, lp0, int(filled.value), int(failed.value)
+
     def set_population(self, Z0, log_post0, X0=None, chisq0=None):
         Z0 = f64(Z0)
         log_post0 = f64(log_post0)
@@ -211,13 +225,18 @@ class DeviceChains:
         check(self.lib.mc3hip_get_trace(self._ctx, iters, dptr(chisq), iptr(flags)))
         return chisq, flags
 
-    def chain_moments(self, burn=0):
+    def chain_moments(self, burn=0, nrefresh=None):
         """Per-chain mean and variance of the free parameters over the rows written
         so far (first ``burn`` rows of each chain skipped), computed on the device:
-        the inputs of the Gelman-Rubin test (mc3/stats/gelman.py)."""
+        the inputs of the Gelman-Rubin test (mc3/stats/gelman.py).  ``nrefresh``: over
+        that many refreshes' rows as they stand in Z (rows installed with put_rows)."""
         mean = np.empty((self.nchains, self.nfree))
         var = np.empty((self.nchains, self.nfree))
-        check(self.lib.mc3hip_chain_moments(self._ctx, int(burn), dptr(mean), dptr(var)))
+        if nrefresh is None:
+            check(self.lib.mc3hip_chain_moments(self._ctx, int(burn), dptr(mean), dptr(var)))
+        else:
+            check(self.lib.mc3hip_chain_moments_rows(self._ctx, int(nrefresh), int(burn),
+                                                     dptr(mean), dptr(var)))
         return mean, var
 
     # -- Chain.eval_model (chain.py:302-340) on the device ----------------------

@@ -57,20 +57,81 @@ class ChainView:
         return [model, chisq] if ret == 'both' else chisq
 
 
+def numpy_stream_population(engine, params, pstep, pmin, pmax, M0, kickoff):
+    """The reference's kick-off on its own random stream (mcmc_driver.py:229-270): trial
+    vectors from the global NumPy generator in blocks, chisq of a block in one device
+    launch, the acceptance rule applied to whole blocks at once.  Returns (Z0, log_post0,
+    filled); rows beyond ``filled`` are zero."""
+    ifree = np.flatnonzero(pstep > 0)
+    ishare = np.flatnonzero(pstep < 0)
+    src = np.array([-int(pstep[s]) - 1 for s in ishare], int)
+    nfree, npar = len(ifree), len(params)
+    Z0 = np.zeros((M0, nfree))
+    lp0 = np.zeros(M0)
+    values = np.array(params, float)            # (its shared entries: the "stale" copies)
+    filled = failed = 0
+    nmax = 100*M0
+    # The reference tests the boundaries on the full vector BEFORE refreshing the shared
+    # parameters, i.e. with the copies the last accepted-into-bounds trial left (:249-255).
+    # Those copies are values their sources took inside the sources' boundaries, so the
+    # rule can only bite when a shared parameter's own interval is tighter than its
+    # source's (or excludes its initial value); only then is the sequential form needed.
+    stale_can_fail = np.any(pmin[ishare] > pmin[src]) or np.any(pmax[ishare] < pmax[src]) \
+        or np.any(values[ishare] > pmax[ishare]) or np.any(values[ishare] < pmin[ishare])
+    while filled < M0 and failed < nmax:
+        block = max(256, 2*(M0 - filled))
+        if kickoff == 'normal':
+            trial = np.random.normal(params[ifree], pstep[ifree], (block, nfree))
+        else:
+            trial = np.random.uniform(pmin[ifree], pmax[ifree], (block, nfree))
+        full = np.tile(values, (block, 1))
+        full[:, ifree] = trial
+        inside = np.all((trial >= pmin[ifree]) & (trial <= pmax[ifree]), axis=1)
+        if stale_can_fail:
+            for i in np.flatnonzero(inside):     # (rare configuration: trial by trial)
+                if np.any(values[ishare] > pmax[ishare]) or np.any(values[ishare] < pmin[ishare]):
+                    inside[i] = False
+                else:
+                    values[ishare] = full[i, src]
+        full[:, ishare] = full[:, src]
+        lp = np.full(block, -np.inf)
+        if np.any(inside):
+            with np.errstate(all='ignore'):
+                lp[inside] = -0.5*engine.eval_chisq(full[inside])
+        good = inside & np.isfinite(lp)
+        # in trial order: stop at the M0-th accepted row or at the nmax-th failure
+        ngood, nbad = np.cumsum(good), np.cumsum(~good)
+        stop = np.flatnonzero((ngood == M0 - filled) & good)
+        cut = (stop[0] + 1) if len(stop) else block
+        over = np.flatnonzero((nbad == nmax - failed) & ~good)
+        if len(over) and over[0] + 1 < cut:
+            cut = over[0] + 1
+        take = np.flatnonzero(good[:cut])
+        Z0[filled:filled + len(take)] = trial[take]
+        lp0[filled:filled + len(take)] = lp[take]
+        filled += len(take)
+        failed += int(np.sum(~good[:cut]))
+    return Z0, lp0, filled
+
+
 def mcmc(data, uncert, func, params, indparams, indparams_dict,
          pmin, pmax, pstep, prior, priorlow, priorup,
          nchains, ncpu, nsamples, sampler,
          wlike, fit_output, grtest, grbreak, grnmin, burnin, thinning,
          fgamma, fepsilon, hsize, kickoff, savefile, resume, log,
          pnames, texnames,
-         seed=None, device=0, comm=None, engine_factory=None):
+         seed=None, device=0, comm=None, engine_factory=None, kickoff_stream=None):
     """Run the chains and assemble the output dictionary (see module docstring).
 
     ``ncpu`` is accepted for signature compatibility and ignored: the fan-out
     over worker processes (mcmc_driver.py:204-221) is replaced by the device.
     Extra keywords: ``seed`` (Philox key; default random.randint(0, 100000) like
-    chain.py:180), ``device``, ``comm`` (mc3_amd.parallel communicator) and
-    ``engine_factory`` (tests inject a CPU checker; default DeviceChains).
+    chain.py:180), ``device``, ``comm`` (mc3_amd.parallel communicator),
+    ``engine_factory`` (tests inject a CPU checker; default DeviceChains) and
+    ``kickoff_stream``: where the trial vectors of the initial population come from --
+    'philox' (default: drawn, tested and evaluated on the device, keyed by ``seed``) or
+    'numpy' (the global NumPy stream in the reference's order: with np.random.seed set,
+    the population equals the reference's).
     """
     data = np.asarray(data, float)
     params = np.array(params, float)
@@ -149,57 +210,24 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
         chainsize0 = np.array([np.sum(zchain_old == c) for c in range(nchains)])
         zchain0 = np.array(zchain_old, np.int32)
     else:
-        # Initial population: M0 in-bounds draws with finite chisq, at most
-        # 100*M0 failures (mcmc_driver.py:229-270).  Trials are drawn from the
-        # global NumPy stream exactly like the reference, in blocks; the device
-        # evaluates each block's chisq in one launch.
+        # Initial population (mcmc_driver.py:229-270): on the device from Philox(seed)
+        # by default; from the global NumPy stream, like the reference, on request or
+        # when the engine has no device kick-off.
         Z0 = lp0 = None
-        if comm.rank == 0:
-            x0, sigma = params[ifree], pstep[ifree]
-            lo, hi = pmin[ifree], pmax[ifree]
-            Z0 = np.empty((M0, nfree))
-            lp0 = np.empty(M0)
-            stale = np.array(params, float)
-            filled = failed = 0
-            while filled < M0 and failed < 100*M0:
-                block = max(256, 2*(M0 - filled))
-                if kickoff == 'normal':
-                    trial = np.random.normal(x0, sigma, (block, nfree))
-                elif kickoff == 'uniform':
-                    trial = np.random.uniform(lo, hi, (block, nfree))
-                else:
-                    log.error(f"Invalid kickoff '{kickoff}'")
-                # Bounds are tested on the full vector BEFORE the shared parameters
-                # are refreshed, i.e. with the copies left by the last in-bounds trial
-                # (mcmc_driver.py:249-255) -- a sequential rule, kept on the host; only
-                # the chisq evaluations are batched on the device.
-                full = np.empty((block, len(params)))
-                inside = np.zeros(block, bool)
-                for i in range(block):
-                    stale[ifree] = trial[i]
-                    if np.any(stale > pmax) or np.any(stale < pmin):
-                        continue
-                    for s in ishare:
-                        stale[s] = stale[-int(pstep[s]) - 1]
-                    inside[i] = True
-                    full[i] = stale
-                lp = np.full(block, -np.inf)
-                if np.any(inside):
-                    with np.errstate(all='ignore'):
-                        lp[inside] = -0.5*engine.eval_chisq(full[inside])
-                good = inside & np.isfinite(lp)
-                for i in range(block):
-                    if filled == M0 or failed == 100*M0:
-                        break
-                    if good[i]:
-                        Z0[filled] = trial[i]
-                        lp0[filled] = lp[i]
-                        filled += 1
-                    else:
-                        failed += 1
-            if filled < M0 - 1:
-                Z0 = None
-        Z0, lp0 = comm.broadcast((Z0, lp0))
+        if kickoff not in ('normal', 'uniform'):
+            log.error(f"Invalid kickoff '{kickoff}'")
+        if kickoff_stream is None:
+            kickoff_stream = 'philox' if hasattr(engine, 'init_population') else 'numpy'
+        if kickoff_stream == 'philox':
+            # (every rank computes the same rows: the draws depend on the seed alone)
+            Z0, lp0, filled, _ = engine.init_population(kickoff, seed)
+        elif comm.rank == 0:
+            Z0, lp0, filled = numpy_stream_population(
+                engine, params, pstep, pmin, pmax, M0, kickoff)
+        if Z0 is not None and filled < M0 - 1:          # (the reference's test, :264)
+            Z0 = None
+        if kickoff_stream != 'philox':
+            Z0, lp0 = comm.broadcast((Z0, lp0))
         if Z0 is None:
             log.error(
                 'Cannot populate an initial sample set of parameters, try '

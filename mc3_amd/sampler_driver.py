@@ -179,7 +179,9 @@ def sample(
     - ``ncpu`` is ignored (the GPU advances all chains in lockstep).
     - ``leastsq`` / ``chisqscale`` (the SciPy pre-fit) and ``plots`` are outside the
       MI355X path: the first is refused, the second skipped with a warning.
-    - extra keywords: ``seed`` (int), ``device`` (int), ``comm``
+    - extra keywords: ``seed`` (int), ``device`` (int), ``kickoff_stream`` ('philox':
+      initial population drawn on the device, the default; 'numpy': from the global
+      NumPy stream like the reference), ``comm``
       (mc3_amd.parallel communicator for multi-GPU runs: every rank makes the same
       call and gets the same dictionary; files are written by rank 0 only).
     """
@@ -243,8 +245,8 @@ def sample(
                 "Creating new folder.")
             os.makedirs(folder)
 
-    extra = {k: kwargs[k] for k in ('seed', 'device', 'comm', 'engine_factory')
-             if k in kwargs}
+    extra = {k: kwargs[k] for k in ('seed', 'device', 'comm', 'engine_factory',
+                                   'kickoff_stream') if k in kwargs}
     output = mcmc(
         inp.data, inp.uncert, func, inp.params, indparams, indparams_dict,
         inp.pmin, inp.pmax, inp.pstep, inp.prior, inp.priorlow, inp.priorup,

@@ -187,6 +187,20 @@ class LockstepRun:
         self.snap0[:] = Z0[0:self.nchains]
         self.chisq[:] = -2.0*np.asarray(log_post0)[0:self.nchains]
 
+    def init_population(self, kickoff='normal', seed=None):
+        """mcmc_driver.py:229-270 with Philox trial draws (ls_init_population):
+        (Z0, log_post0, filled, failed)."""
+        Z0 = np.zeros((self.M0, self.nfree))
+        lp0 = np.zeros(self.M0)
+        filled, failed = ctypes.c_int64(), ctypes.c_int64()
+        self.L.ls_init_population.restype = ctypes.c_int
+        self.L.ls_init_population(
+            ctypes.byref(self.P), ctypes.c_int(int(kickoff == 'uniform')),
+            ctypes.c_uint64(int(self.P.seed if seed is None else seed)),
+            Z0.ctypes.data_as(_dp), lp0.ctypes.data_as(_dp), ctypes.byref(filled),
+            ctypes.byref(failed))
+        return Z0, lp0, int(filled.value), int(failed.value)
+
     def eval_chisq(self, params):
         params = _f(np.atleast_2d(params))
         out = np.empty(len(params))

@@ -784,6 +784,76 @@ int ls_run_tape(const ls_problem *P, ls_state *St, const double *tape, const int
     return rc;
 }
 
+/* ---- initial population: mc3/mcmc_driver.py:229-270 in the Philox form --------------
+ * Trial t: nfree draws around the initial guess (kickoff 0: params + pstep * N(0,1),
+ * Box-Muller pairs; 1: uniform between the boundaries) from Philox(seed; counter = (t,
+ * chain = 0xffffffff, slot)); accepted in trial order when every parameter is inside its
+ * boundaries -- tested on the full vector BEFORE the shared parameters are refreshed
+ * (:249-255) -- and chisq is finite; ends with M0 rows or after 100 M0 failures.
+ * Z0 [M0][nfree], lp0 [M0] (zero beyond *filled). */
+int ls_init_population(const ls_problem *P, int kickoff, uint64_t seed, double *Z0,
+                       double *lp0, int64_t *filled_out, int64_t *failed_out)
+{
+    const int nf = P->nfree;
+    ls_scratch S;
+    scratch_alloc(P, &S);
+    double *values = malloc(sizeof(double) * (size_t)P->nparams);
+    double *trial = malloc(sizeof(double) * (size_t)nf);
+    memcpy(values, P->params, sizeof(double) * (size_t)P->nparams);
+    memset(Z0, 0, sizeof(double) * (size_t)P->M0 * (size_t)nf);
+    memset(lp0, 0, sizeof(double) * (size_t)P->M0);
+    int64_t filled = 0, failed = 0;
+    const int64_t nmax = 100 * P->M0;
+    for (uint64_t t = 0; filled < P->M0 && failed < nmax; t++) {
+        for (int k2 = 0; 2 * k2 < nf; k2++) {
+            uint64_t q0, q1;
+            draw2(seed, t, 0xffffffffu, (uint32_t)k2, &q0, &q1);
+            double a, b;
+            if (kickoff) {
+                a = u01(q0);
+                b = u01(q1);
+            } else {
+                const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(q0)));
+                double sn, cs;
+                mc3_det_sincos2pi(u01(q1), &sn, &cs);
+                a = rad * cs;
+                b = rad * sn;
+            }
+            for (int h = 0; h < 2 && 2 * k2 + h < nf; h++) {
+                const int k = 2 * k2 + h, j = P->ifree[k];
+                const double r = h ? b : a;
+                trial[k] = kickoff ? P->pmin[j] + (P->pmax[j] - P->pmin[j]) * r
+                                   : P->params[j] + P->pstep[j] * r;
+            }
+        }
+        for (int k = 0; k < nf; k++)
+            values[P->ifree[k]] = trial[k];
+        int out = 0;
+        for (int j = 0; j < P->nparams; j++)
+            if (values[j] > P->pmax[j] || values[j] < P->pmin[j])
+                out = 1;
+        if (out) {
+            failed++;
+            continue;
+        }
+        for (int s = 0; s < P->nshare; s++)
+            values[P->ishare[s]] = values[P->share_src[s]];
+        const double lp = -0.5 * eval_chisq(P, values, &S);
+        if (!(lp - lp == 0.0)) {                          /* inf or NaN */
+            failed++;
+            continue;
+        }
+        memcpy(Z0 + (size_t)filled * nf, trial, sizeof(double) * (size_t)nf);
+        lp0[filled] = lp;
+        filled++;
+    }
+    *filled_out = filled;
+    *failed_out = failed;
+    free(values); free(trial);
+    scratch_free(&S);
+    return 0;
+}
+
 /* exported so tests can pin the shared deterministic functions to libm */
 double ls_det_exp(double x) { return mc3_det_exp(x); }
 double ls_det_exp2(double x) { return mc3_det_exp2(x); }

@@ -300,6 +300,27 @@ def kernel_vectors():
     out['logprior_value'] = ms.log_prior(
         post, np.array([3.0, 0.0, 0.5]), np.array([0.5, 0.0, 0.02]),
         np.array([0.25, 0.0, 0.04]), np.array([1.0, 0.0, 0.1]))
+    # Gelman-Rubin (mc3/stats/gelman.py:12-92): a regular strided layout (what mrw / demc
+    # / the GPU write), three burn-in values, and an irregular one (chains of unequal
+    # length in arrival order)
+    import mc3.stats.gelman as gel
+    rs3 = np.random.RandomState(4040)
+    nch, M0g, nit, npar = 6, 12, 90, 3
+    drift = rs3.normal(0, 0.3, (nch, npar))
+    Zg = np.concatenate([rs3.normal(0, 1, (M0g, npar)),
+                         (rs3.normal(0, 1, (nit, nch, npar)) + drift).reshape(-1, npar)])
+    zcg = np.concatenate([-np.ones(M0g, int), np.tile(np.arange(nch), nit)])
+    out['gr_Z'] = Zg
+    out['gr_zchain'] = zcg
+    out['gr_burnins'] = np.array([0, 7, 40])
+    out['gr_psrf'] = np.array([gel.gelman_rubin(Zg, zcg, int(b)) for b in out['gr_burnins']])
+    order = rs3.permutation(nit*nch)[:400]
+    order.sort()
+    Zi = np.concatenate([Zg[:M0g], Zg[M0g:][order]])
+    zci = np.concatenate([zcg[:M0g], zcg[M0g:][order]])
+    out['gr_irregular_Z'] = Zi
+    out['gr_irregular_zchain'] = zci
+    out['gr_irregular_psrf'] = gel.gelman_rubin(Zi, zci, 5)
     np.savez_compressed(os.path.join(HERE, 'kernel_vectors.npz'), **out)
     print('kernel_vectors:', len(out), 'arrays')
 

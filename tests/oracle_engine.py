@@ -44,6 +44,9 @@ class OracleChains:
     def close(self):
         pass
 
+    def init_population(self, kickoff='normal', seed=None):
+        return self.run_.init_population(kickoff, seed)
+
     def set_population(self, Z0, log_post0, X0=None, chisq0=None):
         r = self.run_
         r.set_population(Z0, log_post0)

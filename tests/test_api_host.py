@@ -115,7 +115,7 @@ def test_initial_population_equals_reference(golden_dir):
                    params=g['params'], indparams=[g['x']], pstep=g['pstep'],
                    pmin=g['pmin'], pmax=g['pmax'], sampler='demc', nsamples=2400,
                    burnin=20, nchains=8, log=mu.Log(verb=0), engine_factory=Spy,
-                   seed=1)
+                   seed=1, kickoff_stream='numpy')
     np.testing.assert_array_equal(captured['Z0'], seq.Z[:seq.M0])
     np.testing.assert_allclose(captured['lp0'], seq.log_post[:seq.M0], rtol=1e-12)
 
@@ -274,8 +274,99 @@ def test_initial_population_with_shared_parameters_equals_reference(golden_dir):
         indparams=[g['x']], pstep=g['pstep'], pmin=g['pmin'], pmax=g['pmax'],
         prior=g['prior'], priorlow=g['priorlow'], priorup=g['priorup'],
         sampler='snooker', nsamples=2400, burnin=10, nchains=8, kickoff='uniform',
-        log=mu.Log(verb=0), engine_factory=Spy, seed=1)
+        log=mu.Log(verb=0), engine_factory=Spy, seed=1, kickoff_stream='numpy')
     np.testing.assert_array_equal(captured['Z0'], seq.Z[:seq.M0])
     np.testing.assert_allclose(captured['lp0'], seq.log_post[:seq.M0], rtol=1e-10)
     # shared parameter follows its source, fixed one keeps its value
     assert out['bestp'][3] == out['bestp'][1] and out['bestp'][4] == 1.0
+
+
+def test_gelman_rubin_equals_the_reference(golden_dir):
+    """mc3_amd.stats.gelman_rubin (both its regular-layout fast path and the general
+    one) and gelman_rubin_from_moments (what the device reductions feed) against
+    outputs of the reference's own mc3.stats.gelman_rubin (mc3/stats/gelman.py:12-92;
+    fixtures made by tests/golden/make_golden.py)."""
+    from mc3_amd import stats as ms
+    kv = np.load(os.path.join(golden_dir, 'kernel_vectors.npz'))
+    Z, zc = kv['gr_Z'], kv['gr_zchain']
+    nch = int(zc.max()) + 1
+    M0 = int(np.sum(zc < 0))
+    for b, want in zip(kv['gr_burnins'], kv['gr_psrf']):
+        np.testing.assert_allclose(ms.gelman_rubin(Z, zc, int(b)), want, rtol=1e-12)
+        chains = Z[M0:].reshape(-1, nch, Z.shape[1])[int(b):]
+        got = ms.gelman_rubin_from_moments(chains.mean(axis=0), chains.var(axis=0),
+                                           len(chains))
+        np.testing.assert_allclose(got, want, rtol=1e-12)
+    np.testing.assert_allclose(
+        ms.gelman_rubin(kv['gr_irregular_Z'], kv['gr_irregular_zchain'], 5),
+        kv['gr_irregular_psrf'], rtol=1e-12)
+
+
+def test_numpy_stream_population_with_a_binding_shared_interval():
+    """The reference tests the boundaries with the shared parameters' STALE copies
+    (mcmc_driver.py:249-255).  When a shared parameter's interval is tighter than its
+    source's that rule bites: the block-wise host path must then equal a literal
+    trial-by-trial statement of the reference's loop."""
+    from mc3_amd.mcmc_driver import numpy_stream_population
+    prob = H.shared_problem()
+    prob['pmax'] = prob['pmax'].copy()
+    prob['pmax'][3] = -19.0                    # p3 <- p1, but p1 may go up to -15
+    eng = OracleChains(**prob)
+    M0 = eng.M0
+
+    def literal(seed):
+        rs = np.random.RandomState(seed)
+        params, pstep, pmin, pmax = (prob[k] for k in ('params', 'pstep', 'pmin', 'pmax'))
+        ifree, ishare = np.flatnonzero(pstep > 0), np.flatnonzero(pstep < 0)
+        values = np.array(params, float)
+        Z0, lp0 = np.zeros((M0, len(ifree))), np.zeros(M0)
+        i = j = 0
+        while i < M0 and j < 100*M0:
+            trial = rs.normal(params[ifree], pstep[ifree])
+            values[ifree] = trial
+            if np.any(values > pmax) or np.any(values < pmin):
+                j += 1
+                continue
+            for s in ishare:
+                values[s] = values[-int(pstep[s]) - 1]
+            lp = -0.5*eng.eval_chisq(values)
+            if not np.isfinite(lp):
+                j += 1
+                continue
+            Z0[i], lp0[i] = trial, lp
+            i += 1
+        return Z0, lp0, i
+
+    want = literal(31)
+    np.random.seed(31)
+    got = numpy_stream_population(eng, prob['params'], prob['pstep'], prob['pmin'],
+                                  prob['pmax'], M0, 'normal')
+    assert got[2] == want[2]
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
+
+
+def test_philox_population_is_the_default_and_deterministic():
+    """Without kickoff_stream the initial population comes from the engine (device:
+    mc3hip_init_population; here the checker's restatement), keyed by the seed alone."""
+    captured = []
+
+    class Spy(OracleChains):
+        def set_population(self, Z0, lp0, X0=None, chisq0=None):
+            captured.append((Z0.copy(), lp0.copy()))
+            super().set_population(Z0, lp0, X0, chisq0)
+
+    x, data, uncert = H.tutorial_data(100)
+    for np_seed in (1, 2):
+        np.random.seed(np_seed)              # must not matter
+        mc3_amd.sample(data=data, uncert=uncert, func=quad, params=np.array([10.0, -2.0, 0.1]),
+                       indparams=[x], pstep=np.array([1.0, 0.5, 0.1]),
+                       pmin=np.array([-10.0, -20.0, -10.0]), pmax=np.array([40.0, 20.0, 10.0]),
+                       sampler='demc', nsamples=800, nchains=8, log=mu.Log(verb=0),
+                       engine_factory=Spy, seed=77)
+    np.testing.assert_array_equal(captured[0][0], captured[1][0])
+    np.testing.assert_array_equal(captured[0][1], captured[1][1])
+    Z0 = captured[0][0]
+    assert Z0.shape == (80, 3) and np.all(np.isfinite(captured[0][1]))
+    # around the initial guess with the proposal widths (chi-by-eye: 80 draws)
+    assert np.all(np.abs(Z0.mean(axis=0) - [10.0, -2.0, 0.1]) < 4*np.array([1.0, 0.5, 0.1])/np.sqrt(80)*2)

@@ -230,3 +230,73 @@ def test_resume_and_early_stop_gpu_equals_cpu_checker(tmp_path):
         assert_same_dict(g, c)
     assert outs['gpu'][1]['posterior'].shape == (2400, 3)
     assert len(outs['gpu'][2]['posterior']) < 80000
+
+
+def test_device_gelman_rubin_equals_the_reference(golden_dir):
+    """The device reductions (mc3hip_chain_moments_rows -> gelman_rubin_from_moments) on
+    the Z rows of the reference fixture against the reference's own gelman_rubin output
+    (mc3/stats/gelman.py:12-92), 1e-10."""
+    from mc3_amd import engine, stats as ms
+    kv = np.load(os.path.join(golden_dir, 'kernel_vectors.npz'))
+    Z, zc = kv['gr_Z'], kv['gr_zchain']
+    nch = int(zc.max()) + 1
+    M0 = int(np.sum(zc < 0))
+    nit = (len(Z) - M0)//nch
+    prob = H.quad_problem(nchains=nch, nsamples=nch*nit, sampler='demc', hsize=M0//nch)
+    with engine.DeviceChains(**prob) as gpu:
+        assert gpu.M0 == M0 and gpu.nfree == Z.shape[1]
+        gpu.set_population(Z[:M0], np.zeros(M0))
+        gpu.put_rows(M0, Z[M0:])
+        for b, want in zip(kv['gr_burnins'], kv['gr_psrf']):
+            mean, var = gpu.chain_moments(int(b), nrefresh=nit)
+            got = ms.gelman_rubin_from_moments(mean, var, nit - int(b))
+            np.testing.assert_allclose(got, want, rtol=1e-10)
+
+
+@pytest.mark.parametrize('builder,kw,kickoff', [
+    (H.quad_problem, dict(nchains=8, nsamples=80), 'normal'),
+    (H.quad_problem, dict(nchains=8, nsamples=80), 'uniform'),
+    (H.quad_problem, dict(ndata=1000, nchains=2048, nsamples=2048), 'normal'),   # C3: M0 = 20480
+    (H.shared_problem, dict(), 'normal'),
+    (H.shared_problem, dict(), 'uniform'),
+    (H.wavelet_problem, dict(ndata=1024), 'normal'),
+    (H.linear_problem, dict(), 'normal'),
+])
+def test_initial_population_on_the_device(builder, kw, kickoff):
+    """mc3hip_init_population (trial draws, boundaries, shared copies, chisq and the
+    in-order acceptance on the device; mc3/mcmc_driver.py:229-270) against the checker's
+    restatement: identical rows, log-posteriors and counters."""
+    from mc3_amd import engine
+    prob = builder(**kw)
+    with engine.DeviceChains(**prob) as gpu:
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        for seed in (prob['seed'], 5):
+            Z0, lp0, filled, failed = gpu.init_population(kickoff, seed)
+            wZ, wlp, wfilled, wfailed = orc.init_population(kickoff, seed)
+            assert (filled, failed) == (wfilled, wfailed)
+            assert filled == gpu.M0
+            np.testing.assert_array_equal(Z0, wZ)
+            np.testing.assert_array_equal(lp0, wlp)
+        assert failed > 0 or builder is not H.shared_problem      # tight bounds do reject
+
+
+def test_initial_population_that_cannot_be_filled():
+    """Boundaries that exclude (almost) every trial: 100 M0 failures, then the same
+    error as the reference (mcmc_driver.py:264-270)."""
+    import mc3_amd
+    from mc3_amd import engine, utils as mu
+    prob = H.quad_problem(nchains=4, nsamples=40, hsize=2)
+    prob['pmin'] = np.array([9.9999, -2.00001, 0.09999])
+    prob['pmax'] = np.array([10.0001, -1.99999, 0.10001])
+    with engine.DeviceChains(**prob) as gpu:
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        got = gpu.init_population('normal', 3)
+        want = orc.init_population('normal', 3)
+        assert got[2:] == want[2:] and got[3] == 100*gpu.M0 and got[2] < gpu.M0 - 1
+        np.testing.assert_array_equal(got[0], want[0])
+    x, data, uncert = H.tutorial_data(100)
+    with pytest.raises(ValueError, match='Cannot populate an initial sample set'):
+        mc3_amd.sample(data=data, uncert=uncert, func=quad, params=prob['params'],
+                       indparams=[x], pstep=prob['pstep'], pmin=prob['pmin'],
+                       pmax=prob['pmax'], sampler='demc', nsamples=400, nchains=4, hsize=2,
+                       log=mu.Log(verb=0), seed=3)

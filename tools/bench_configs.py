@@ -43,14 +43,20 @@ CONFIGS = {
     'c3one': lambda n: (H.quad_problem(ndata=1000, nchains=2048, nsamples=2048*n,
                                        sampler='demc'), {}),
     'c4': lambda n: (H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*n), {}),
+    'c4mrw': lambda n: (H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*n,
+                                          sampler='mrw'), {}),
+    'c4demc': lambda n: (H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*n,
+                                           sampler='demc'), {}),
+    'c4half': lambda n: (H.wavelet_problem(ndata=16384, nchains=128, nsamples=128*n), {}),
     'c5': lambda n: (H.linear_problem(ndata=100000, nchains=512, nsamples=512*n), {}),
     'c5share': lambda n: (H.linear_problem(ndata=100000, nchains=512, nsamples=512*n),
                           dict(chain0=0, nlocal=128)),
 }
-BYTES = {'c2': 24104, 'c2snooker': 24104, 'c3one': 24104, 'c4': 8*2*16384 + 8*5*4 + 8,
+BYTES = {'c4mrw': 8*2*16384 + 8*5*4 + 8, 'c4demc': 8*2*16384 + 8*5*4 + 8, 'c4half': 8*2*16384 + 8*5*4 + 8, 'c2': 24104, 'c2snooker': 24104, 'c3one': 24104, 'c4': 8*2*16384 + 8*5*4 + 8,
          'c5': 8*12*100000 + 8*10*4 + 8, 'c5share': 8*12*100000 + 8*10*4 + 8}
 ITERS = {'c2': 20000, 'c2snooker': 20000, 'c3one': 4000, 'c4': 4000, 'c5': 30, 'c5share': 1}
 ITERS['c5'] = 300
+ITERS.update(c4mrw=4000, c4demc=4000, c4half=4000)
 
 
 def main():

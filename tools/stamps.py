@@ -59,6 +59,10 @@ for _ in range(60):
         continue            # out-of-bounds proposal in the last iteration: no chisq phase
     acc += np.diff(t)
     n += 1
+    if which == 'c4':
+        sel = (5, 2, 8, 14, 9, 10, 12, 13, 3, 6)
+        wl_acc = wl_acc + np.diff([float(out[i]) for i in sel]) if n > 1 \
+            else np.diff([float(out[i]) for i in sel])
 print(f'{which} mode={mode} plan={g.plan}: {n} samples, mean shader-clock cycles per phase '
       '(workgroup 0, last iteration of a launch):')
 for k, v in zip(names, acc/max(n, 1)):
@@ -68,9 +72,10 @@ if n == 0:
     print('  (no samples: the hand-laid-out DEMC loop keeps per-phase tick sums instead -- '
           'tools/ticks.py; or STAMP_MODE=launch / MC3HIP_NO_LEAN=1 for the stamped kernels)')
 if which == 'c4':
-    w = [int(out[i]) for i in (2, 8, 9, 10, 13, 3)]
-    lab = ['chisq entry -> noise table issued', '-> stage A (levels in registers)',
-           '-> tree + stage B (wave 0)', '-> stage C (wave 0)', '-> chisq done']
-    print('  wavelet, last sample:')
-    for k, v in zip(lab, np.diff(w)):
-        print(f'    {k:30s} {v:9d}')
+    lab = ['top -> proposal known (barrier)', '-> wavelet entry',
+           '-> level 0 done (wave 0)', '-> levels 1.. done (stage A)',
+           '-> barrier 1 + stage B (wave 0)', '-> stage C (wave 0)',
+           '-> barriers 2, 3 + weights + tree', '-> chisq done', '-> iteration end']
+    print('  wavelet, mean over the same samples:')
+    for k, v in zip(lab, wl_acc/max(n, 1)):
+        print(f'    {k:34s} {v:9.0f}')
