@@ -179,6 +179,24 @@ int mc3hip_chain_moments(mc3hip_ctx *ctx, int64_t burn, double *mean, double *va
 int mc3hip_chain_moments_rows(mc3hip_ctx *ctx, int64_t nrefresh, int64_t burn,
                               double *mean, double *var);
 
+/* Replaces the NumPy passes of update_output / calc_sample_statistics over the burned
+ * posterior (mc3/stats/stats.py:805-852,876-964; np.mean, np.std, np.percentile) with
+ * reductions over the rows where they are: per free parameter the mean, population
+ * variance, minimum and maximum of the rows of refreshes [burn, nrefresh) (nrefresh <= 0:
+ * all that have run), and exact order statistics (0-based ranks, nranks <= 8, radix
+ * selection) from which the caller interpolates medians and percentiles exactly as NumPy
+ * does.  order_stats is [nranks][nfree]. */
+int mc3hip_posterior_summary(mc3hip_ctx *ctx, int64_t nrefresh, int64_t burn, int32_t nranks,
+                             const int64_t *ranks, double *order_stats, double *mean,
+                             double *var, double *vmin, double *vmax);
+/* output['chisq'] of update_output (stats.py:821): -2 (log_post - log_prior) of rows
+ * [row0, row0+nrows), log_prior as mc3/stats/stats.py:287-392. */
+int mc3hip_get_chisq(mc3hip_ctx *ctx, int64_t row0, int64_t nrows, double *chisq);
+/* The Gaussian kernel density cred_region evaluates through scipy (stats.py:395-467,
+ * gaussian_kde.evaluate): pdf[j] = sum_i exp(-(x_j - s_i)^2 / (2 cov)) / (n sqrt(2 pi cov)). */
+int mc3hip_kde_pdf(int32_t device, const double *sample, int32_t n, const double *x,
+                   int32_t m, double cov, double *pdf);
+
 /* Replaces Chain.eval_model(params, ret='chisq') -> ms.chisq / ms.dwt_chisq
  * (chain.py:302-340, stats.py:150-284, _chisq.c:111-140, _dwt.c:56-119) for n
  * parameter vectors at once ([n][nparams], shared parameters already copied). */

@@ -82,6 +82,12 @@ SYMBOLS = {
     'mc3hip_get_trace': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _ip]),
     'mc3hip_chain_moments': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _dp]),
     'mc3hip_chain_moments_rows': (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, _dp, _dp]),
+    'mc3hip_posterior_summary': (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64,
+                                                ctypes.c_int32, _lp, _dp,
+                                                _dp, _dp, _dp, _dp]),
+    'mc3hip_get_chisq': (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, _dp]),
+    'mc3hip_kde_pdf': (ctypes.c_int, [ctypes.c_int32, _dp, ctypes.c_int32, _dp, ctypes.c_int32,
+                                      ctypes.c_double, _dp]),
     'mc3hip_eval_chisq': (ctypes.c_int, [_vp, _dp, ctypes.c_int32, _dp]),
     'mc3hip_eval_model': (ctypes.c_int, [_vp, _dp, _dp]),
     'mc3hip_residuals': (ctypes.c_int, [ctypes.c_int32, _dp, _dp, _dp, ctypes.c_int32, _dp, _dp,

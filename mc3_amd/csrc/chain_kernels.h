@@ -2294,6 +2294,273 @@ __global__ __launch_bounds__(256) void chain_moments_kernel(const double *Z, lon
     }
 }
 
+// ---- posterior summary on the device (mc3/stats/stats.py:805-852,876-964) -----------------
+// What update_output / calc_sample_statistics compute from the burned posterior with
+// NumPy -- per-parameter mean, standard deviation, extrema, median and central percentiles
+// -- without copying Z anywhere: two deterministic reduction passes and an exact
+// multi-rank radix select over sortable 64-bit keys.
+__device__ __forceinline__ uint64_t sortable_key(double v)
+{
+    const uint64_t b = mc3_bits(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);     // total order of finite doubles
+}
+__device__ __forceinline__ double key_to_double(uint64_t k)
+{
+    return mc3_from_bits((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k);
+}
+
+// pass 1: per block and parameter, sum / min / max of rows [row0, row0 + n); also the
+// sortable keys, dense per parameter (keys[k][i]), for the selection passes
+__global__ __launch_bounds__(256) void summary_pass1_kernel(const double *Z, long long row0,
+                                                            long long n, int nf, int zs,
+                                                            uint64_t *keys, double *part)
+{
+    __shared__ double s_sum[256], s_min[256], s_max[256];
+    const int t = threadIdx.x;
+    for (int k = 0; k < nf; ++k) {
+        double sum = 0.0, lo = INFINITY, hi = -INFINITY;
+        for (long long i = (long long)blockIdx.x * 256 + t; i < n; i += (long long)gridDim.x * 256) {
+            const double v = Z[(size_t)(row0 + i) * zs + k];
+            keys[(size_t)k * n + i] = sortable_key(v);
+            sum += v;
+            lo = v < lo ? v : lo;
+            hi = v > hi ? v : hi;
+        }
+        s_sum[t] = sum; s_min[t] = lo; s_max[t] = hi;
+        __syncthreads();
+        for (int s2 = 128; s2 >= 1; s2 >>= 1) {
+            if (t < s2) {
+                s_sum[t] += s_sum[t + s2];
+                s_min[t] = s_min[t + s2] < s_min[t] ? s_min[t + s2] : s_min[t];
+                s_max[t] = s_max[t + s2] > s_max[t] ? s_max[t + s2] : s_max[t];
+            }
+            __syncthreads();
+        }
+        if (t == 0) {
+            double *o = part + ((size_t)k * gridDim.x + blockIdx.x) * 4;
+            o[0] = s_sum[0]; o[1] = s_min[0]; o[2] = s_max[0];
+        }
+        __syncthreads();
+    }
+}
+
+// between the passes: block partials -> mean / min / max per parameter (one block)
+__global__ __launch_bounds__(256) void summary_finish1_kernel(const double *part, int nblocks,
+                                                              int nf, long long n, double *res)
+{
+    __shared__ double s_sum[256], s_min[256], s_max[256];
+    const int t = threadIdx.x;
+    for (int k = 0; k < nf; ++k) {
+        double sum = 0.0, lo = INFINITY, hi = -INFINITY;
+        for (int b = t; b < nblocks; b += 256) {
+            const double *o = part + ((size_t)k * nblocks + b) * 4;
+            sum += o[0];
+            lo = o[1] < lo ? o[1] : lo;
+            hi = o[2] > hi ? o[2] : hi;
+        }
+        s_sum[t] = sum; s_min[t] = lo; s_max[t] = hi;
+        __syncthreads();
+        for (int s2 = 128; s2 >= 1; s2 >>= 1) {
+            if (t < s2) {
+                s_sum[t] += s_sum[t + s2];
+                s_min[t] = s_min[t + s2] < s_min[t] ? s_min[t + s2] : s_min[t];
+                s_max[t] = s_max[t + s2] > s_max[t] ? s_max[t + s2] : s_max[t];
+            }
+            __syncthreads();
+        }
+        if (t == 0) {
+            res[4 * k] = s_sum[0] / (double)n;          // mean
+            res[4 * k + 2] = s_min[0];
+            res[4 * k + 3] = s_max[0];
+        }
+        __syncthreads();
+    }
+}
+
+// pass 2: sum of squared deviations from the mean (np.var's second pass)
+__global__ __launch_bounds__(256) void summary_pass2_kernel(const double *Z, long long row0,
+                                                            long long n, int nf, int zs,
+                                                            const double *res, double *part)
+{
+    __shared__ double s_sum[256];
+    const int t = threadIdx.x;
+    for (int k = 0; k < nf; ++k) {
+        const double mu = res[4 * k];
+        double sum = 0.0;
+        for (long long i = (long long)blockIdx.x * 256 + t; i < n; i += (long long)gridDim.x * 256) {
+            const double d = Z[(size_t)(row0 + i) * zs + k] - mu;
+            sum += d * d;
+        }
+        s_sum[t] = sum;
+        __syncthreads();
+        for (int s2 = 128; s2 >= 1; s2 >>= 1) {
+            if (t < s2)
+                s_sum[t] += s_sum[t + s2];
+            __syncthreads();
+        }
+        if (t == 0)
+            part[((size_t)k * gridDim.x + blockIdx.x) * 4 + 3] = s_sum[0];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void summary_finish2_kernel(const double *part, int nblocks,
+                                                              int nf, long long n, double *res)
+{
+    __shared__ double s_sum[256];
+    const int t = threadIdx.x;
+    for (int k = 0; k < nf; ++k) {
+        double sum = 0.0;
+        for (int b = t; b < nblocks; b += 256)
+            sum += part[((size_t)k * nblocks + b) * 4 + 3];
+        s_sum[t] = sum;
+        __syncthreads();
+        for (int s2 = 128; s2 >= 1; s2 >>= 1) {
+            if (t < s2)
+                s_sum[t] += s_sum[t + s2];
+            __syncthreads();
+        }
+        if (t == 0)
+            res[4 * k + 1] = s_sum[0] / (double)n;      // population variance
+        __syncthreads();
+    }
+}
+
+// Exact order statistics by radix selection, 8 bits per pass from the top: every
+// (parameter, rank) pair carries the key prefix fixed so far and the rank left inside it;
+// a pass histograms the next byte of the keys that share a pair's prefix (LDS, then one
+// atomic flush per block), a one-block kernel picks each pair's byte.  MAXR ranks at most.
+constexpr int SEL_MAXR = 8;
+struct SelectState {
+    uint64_t prefix[SEL_MAXR];      // key bits fixed so far (high part), rest zero
+    long long rank[SEL_MAXR];       // rank inside the keys that share the prefix
+};
+
+__global__ __launch_bounds__(256) void select_hist_kernel(const uint64_t *keys, long long n, int nr,
+                                                          int pass, const SelectState *st,
+                                                          unsigned int *hist)
+{
+    __shared__ unsigned int s_h[SEL_MAXR * 256];
+    const int k = blockIdx.y, t = threadIdx.x;
+    for (int q = t; q < nr * 256; q += 256)
+        s_h[q] = 0;
+    __syncthreads();
+    const int shift = 56 - 8 * pass;
+    const uint64_t himask = pass ? ~0ull << (shift + 8) : 0ull;
+    uint64_t pre[SEL_MAXR];
+    bool first[SEL_MAXR];           // pairs that share a prefix share the count: the first adds
+    for (int r = 0; r < nr; ++r) {
+        pre[r] = st[k].prefix[r] & himask;
+        first[r] = true;
+        for (int r2 = 0; r2 < r; ++r2)
+            first[r] = first[r] && pre[r2] != pre[r];
+    }
+    const uint64_t *col = keys + (size_t)k * n;
+    for (long long i = (long long)blockIdx.x * 256 + t; i < n; i += (long long)gridDim.x * 256) {
+        const uint64_t key = col[i];
+        const unsigned int digit = (unsigned int)(key >> shift) & 255u;
+        for (int r = 0; r < nr; ++r)
+            if (first[r] && (key & himask) == pre[r])
+                atomicAdd(&s_h[r * 256 + digit], 1u);
+    }
+    __syncthreads();
+    for (int q = t; q < nr * 256; q += 256)
+        if (s_h[q])
+            atomicAdd(&hist[(size_t)k * SEL_MAXR * 256 + q], s_h[q]);
+}
+
+__global__ __launch_bounds__(256) void select_pick_kernel(int nr, int pass, SelectState *st,
+                                                          unsigned int *hist)
+{
+    const int k = blockIdx.x, t = threadIdx.x;
+    const int shift = 56 - 8 * pass;
+    const uint64_t himask = pass ? ~0ull << (shift + 8) : 0ull;
+    __shared__ unsigned int s_h[SEL_MAXR * 256];
+    unsigned int *h = hist + (size_t)k * SEL_MAXR * 256;
+    // a pair without counts of its own reads those of the first pair with its prefix
+    for (int q = t; q < nr * 256; q += 256) {
+        const int r = q >> 8;
+        int owner = r;
+        for (int r2 = r - 1; r2 >= 0; --r2)
+            if ((st[k].prefix[r2] & himask) == (st[k].prefix[r] & himask))
+                owner = r2;
+        s_h[q] = h[owner * 256 + (q & 255)];
+    }
+    __syncthreads();
+    if (t < nr) {
+        long long left = st[k].rank[t];
+        unsigned int d = 0;
+        for (; d < 255; ++d) {
+            const unsigned int cnt = s_h[t * 256 + d];
+            if (left < (long long)cnt)
+                break;
+            left -= cnt;
+        }
+        st[k].rank[t] = left;
+        st[k].prefix[t] = (st[k].prefix[t] & himask) | ((uint64_t)d << shift);
+    }
+    __syncthreads();
+    for (int q = t; q < SEL_MAXR * 256; q += 256)
+        h[q] = 0;
+}
+
+__global__ void select_result_kernel(const SelectState *st, int nf, int nr, double *out)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nf * nr)
+        out[q] = key_to_double(st[q / nr].prefix[q % nr]);      // [nf][nr]
+}
+
+// chisq = -2 (log_post - log_prior) of rows [row0, row0 + n) (mc3/stats/stats.py:821 with
+// log_prior of :287-392: Gaussian priors with two-sided widths where priorlow, priorup > 0;
+// the reference's log-uniform branch where priorlow < 0), and the packed dense copy of the
+// rows' free parameters -- everything update_output needs per row, in one pass
+__global__ void rows_chisq_kernel(const DevProblem P, long long row0, long long n, double *chisq)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const double *z = P.Z + (size_t)(row0 + i) * P.zs;
+        double s = 0.0;
+        for (int k = 0; k < P.nfree; ++k) {
+            const int j = P.ifree[k];
+            double d = 0.0;
+            if (P.priorlow[j] > 0.0 && P.priorup[j] > 0.0) {
+                const double off = z[k] - P.prior[j];
+                d = (off == 0.0) ? 0.0 : off / (off < 0.0 ? P.priorlow[j] : P.priorup[j]);
+            } else if (P.priorlow[j] < 0.0) {
+                d = 2.0 * mc3_det_log(z[k]);
+            }
+            s = s + d * d;
+        }
+        chisq[i] = -2.0 * (P.log_post[row0 + i] - (-0.5 * s));
+    }
+}
+
+// Gaussian kernel density of a 1D sample at m points (scipy.stats.gaussian_kde.evaluate,
+// called by cred_region, mc3/stats/stats.py:395-467): pdf[j] = norm * sum_i exp(-(x_j -
+// s_i)^2 / (2 cov)).  One block per evaluation point.
+__global__ __launch_bounds__(256) void kde_kernel(const double *sample, int n, const double *x,
+                                                  double inv2cov, double norm, double *pdf)
+{
+    __shared__ double s_sum[256];
+    const int t = threadIdx.x;
+    const double xj = x[blockIdx.x];
+    double sum = 0.0;
+    for (int i = t; i < n; i += 256) {
+        const double d = xj - sample[i];
+        sum += mc3_det_exp(-(d * d) * inv2cov);
+    }
+    s_sum[t] = sum;
+    __syncthreads();
+    for (int s2 = 128; s2 >= 1; s2 >>= 1) {
+        if (t < s2)
+            s_sum[t] += s_sum[t + s2];
+        __syncthreads();
+    }
+    if (t == 0)
+        pdf[blockIdx.x] = s_sum[0] * norm;
+}
+
 // dense [rows][nf] (what the C-ABI exchanges) <-> padded [rows][zs] (device layout of Z)
 __global__ void pack_rows_kernel(double *dense, const double *padded, long long nrows, int nf,
                                  int zs)

@@ -1494,6 +1494,113 @@ int mc3hip_chain_moments_rows(mc3hip_ctx *c, int64_t nrefresh, int64_t burn, dou
     return chain_moments(c, nrefresh, burn, mean, var);
 }
 
+int mc3hip_posterior_summary(mc3hip_ctx *c, int64_t nrefresh, int64_t burn, int32_t nranks,
+                             const int64_t *ranks, double *order_stats, double *mean,
+                             double *var, double *vmin, double *vmax)
+{
+    if (!c || !mean || !var || !vmin || !vmax || (nranks > 0 && (!ranks || !order_stats)))
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    if (nranks < 0 || nranks > SEL_MAXR)
+        return fail(MC3HIP_ERR_ARG, "at most %d ranks per call", SEL_MAXR);
+    if (nrefresh <= 0)
+        nrefresh = c->refresh_done;
+    if (burn < 0 || burn >= nrefresh || c->P.M0 + nrefresh * c->P.nchains > c->zlen)
+        return fail(MC3HIP_ERR_ARG, "burn=%lld of %lld refreshes (Z holds %lld rows)",
+                    (long long)burn, (long long)nrefresh, (long long)c->zlen);
+    RC_TRY(settle(c));
+    const DevProblem &P = c->P;
+    const long long n = (long long)(nrefresh - burn) * P.nchains;
+    const long long row0 = P.M0 + burn * P.nchains;
+    for (int r = 0; r < nranks; ++r)
+        if (ranks[r] < 0 || ranks[r] >= n)
+            return fail(MC3HIP_ERR_ARG, "rank %lld outside [0,%lld)", (long long)ranks[r], n);
+    const int nf = P.nfree;
+    const int nblocks = (int)(n / 256 + 1 < 2048 ? n / 256 + 1 : 2048);
+    // scratch of this call: keys [nf][n], block partials, results, selection state
+    const size_t kbytes = (size_t)nf * (size_t)n * sizeof(uint64_t);
+    const size_t pbytes = (size_t)nf * nblocks * 4 * sizeof(double);
+    const size_t rbytes = (size_t)nf * 4 * sizeof(double);
+    const size_t sbytes = (size_t)nf * sizeof(SelectState);
+    const size_t hbytes = (size_t)nf * SEL_MAXR * 256 * sizeof(unsigned int);
+    const size_t obytes = (size_t)nf * SEL_MAXR * sizeof(double);
+    void *buf = nullptr;
+    HIP_TRY(hipMalloc(&buf, kbytes + pbytes + rbytes + sbytes + hbytes + obytes + 1024));
+    struct Free { void *p; ~Free() { (void)hipFree(p); } } guard{buf};
+    char *at = static_cast<char *>(buf);
+    uint64_t *keys = reinterpret_cast<uint64_t *>(at); at += (kbytes + 255) & ~size_t(255);
+    double *part = reinterpret_cast<double *>(at); at += (pbytes + 255) & ~size_t(255);
+    double *res = reinterpret_cast<double *>(at); at += (rbytes + 255) & ~size_t(255);
+    SelectState *st = reinterpret_cast<SelectState *>(at); at += (sbytes + 255) & ~size_t(255);
+    unsigned int *hist = reinterpret_cast<unsigned int *>(at); at += (hbytes + 255) & ~size_t(255);
+    double *ost = reinterpret_cast<double *>(at);
+    hipLaunchKernelGGL(summary_pass1_kernel, dim3(nblocks), dim3(256), 0, c->stream,
+                       (const double *)P.Z, row0, n, nf, P.zs, keys, part);
+    hipLaunchKernelGGL(summary_finish1_kernel, dim3(1), dim3(256), 0, c->stream,
+                       (const double *)part, nblocks, nf, n, res);
+    hipLaunchKernelGGL(summary_pass2_kernel, dim3(nblocks), dim3(256), 0, c->stream,
+                       (const double *)P.Z, row0, n, nf, P.zs, (const double *)res, part);
+    hipLaunchKernelGGL(summary_finish2_kernel, dim3(1), dim3(256), 0, c->stream,
+                       (const double *)part, nblocks, nf, n, res);
+    if (nranks > 0) {
+        std::vector<SelectState> h((size_t)nf);
+        for (int k = 0; k < nf; ++k)
+            for (int r = 0; r < SEL_MAXR; ++r) {
+                h[k].prefix[r] = 0;
+                h[k].rank[r] = r < nranks ? ranks[r] : 0;
+            }
+        HIP_TRY(hipMemcpyAsync(st, h.data(), sbytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(hist, 0, hbytes, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));          // (h goes out of scope below)
+        for (int pass = 0; pass < 8; ++pass) {
+            hipLaunchKernelGGL(select_hist_kernel, dim3(nblocks, nf), dim3(256), 0, c->stream,
+                               (const uint64_t *)keys, n, nranks, pass,
+                               (const SelectState *)st, hist);
+            hipLaunchKernelGGL(select_pick_kernel, dim3(nf), dim3(256), 0, c->stream, nranks,
+                               pass, st, hist);
+        }
+        hipLaunchKernelGGL(select_result_kernel, dim3(1), dim3(nf * SEL_MAXR), 0, c->stream,
+                           (const SelectState *)st, nf, SEL_MAXR, ost);
+    }
+    HIP_TRY(hipGetLastError());
+    std::vector<double> hres((size_t)nf * 4), host((size_t)nf * SEL_MAXR);
+    HIP_TRY(hipMemcpyAsync(hres.data(), res, rbytes, hipMemcpyDeviceToHost, c->stream));
+    if (nranks > 0)
+        HIP_TRY(hipMemcpyAsync(host.data(), ost, obytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < nf; ++k) {
+        mean[k] = hres[4 * k];
+        var[k] = hres[4 * k + 1];
+        vmin[k] = hres[4 * k + 2];
+        vmax[k] = hres[4 * k + 3];
+        for (int r = 0; r < nranks; ++r)
+            order_stats[(size_t)r * nf + k] = host[(size_t)k * SEL_MAXR + r];
+    }
+    return MC3HIP_OK;
+}
+
+int mc3hip_get_chisq(mc3hip_ctx *c, int64_t row0, int64_t nrows, double *chisq)
+{
+    if (!c || !chisq)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    if (row0 < 0 || nrows < 0 || row0 + nrows > c->zlen)
+        return fail(MC3HIP_ERR_ARG, "rows [%lld,%lld) outside Z", (long long)row0,
+                    (long long)(row0 + nrows));
+    RC_TRY(settle(c));
+    const size_t chunk = STAGE_MAX_DOUBLES;
+    for (size_t r = 0; r < (size_t)nrows; r += chunk) {
+        const size_t m = (size_t)nrows - r < chunk ? (size_t)nrows - r : chunk;
+        RC_TRY(stage_reserve(c, m));
+        const int blocks = (int)((m + 255) / 256 < 4096 ? (m + 255) / 256 : 4096);
+        hipLaunchKernelGGL(rows_chisq_kernel, dim3(blocks), dim3(256), 0, c->stream, c->P,
+                           (long long)(row0 + r), (long long)m, c->stage);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(chisq + r, c->stage, m * sizeof(double), hipMemcpyDeviceToHost,
+                               c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return MC3HIP_OK;
+}
+
 static int eval_reserve(mc3hip_ctx *c, int n)
 {
     if (n <= c->eval_cap)
@@ -1830,6 +1937,30 @@ int mc3hip_dwt_chisq(int32_t device, const double *params, int32_t nparams, cons
         return fail(MC3HIP_ERR_HIP, "dwt_chisq: %s", hipGetErrorString(e));
     const double Ssm = (head[0] * head[0]) / sS2 + (head[1] * head[1]) / sS2;
     *chisq_out = ((Ssm + Lg) + T) + (np > 0 ? host_priors(off, plow, pup, np) : 0.0);
+    return MC3HIP_OK;
+}
+
+int mc3hip_kde_pdf(int32_t device, const double *sample, int32_t n, const double *x, int32_t m,
+                   double cov, double *pdf)
+{
+    if (!sample || !x || !pdf || n < 1 || m < 1 || !(cov > 0.0))
+        return fail(MC3HIP_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    hipError_t e = hipSuccess;
+    Scratch S(device, (size_t)n + 2 * (size_t)m, 3, &e);
+    double *ds = S.up(sample, (size_t)n, &e), *dx = S.up(x, (size_t)m, &e);
+    double *dp = S.up(nullptr, (size_t)m, &e);
+    if (e == hipSuccess) {
+        // scipy.stats.gaussian_kde: sum_i exp(-(x - s_i)^2 / (2 cov)) / (n sqrt(2 pi cov))
+        const double norm = 1.0 / ((double)n * std::sqrt(2.0 * 3.14159265358979323846 * cov));
+        hipLaunchKernelGGL(kde_kernel, dim3(m), dim3(256), 0, 0, (const double *)ds, n,
+                           (const double *)dx, 0.5 / cov, norm, dp);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpy(pdf, dp, (size_t)m * sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        return fail(MC3HIP_ERR_HIP, "kde_pdf: %s", hipGetErrorString(e));
     return MC3HIP_OK;
 }
 

@@ -82,6 +82,7 @@ class DeviceChains:
         P = _lib.Problem()
         P.struct_bytes = ctypes.sizeof(_lib.Problem)
         P.device = int(device)
+        self._device = int(device)
         P.nchains, P.chain0, P.nlocal = self.nchains, self.chain0, self.nlocal
         P.nparams, P.ndata = npar, self.ndata
         P.sampler = _lib.SAMPLERS[sampler]
@@ -239,6 +240,31 @@ class DeviceChains:
                                                      dptr(mean), dptr(var)))
         return mean, var
 
+    def posterior_summary(self, burn=0, ranks=(), nrefresh=None):
+        """Mean, population variance, minimum, maximum ([nfree] each) and the order
+        statistics at the 0-based ``ranks`` ([nranks, nfree]) of every free parameter
+        over the rows of refreshes [burn, done) -- computed where the rows are."""
+        ranks = np.ascontiguousarray(ranks, dtype=np.int64)
+        nf = self.nfree
+        mean, var, vmin, vmax = (np.empty(nf) for _ in range(4))
+        order = np.empty((len(ranks), nf))
+        check(self.lib.mc3hip_posterior_summary(
+            self._ctx, int(nrefresh or 0), int(burn), len(ranks), lptr(ranks), dptr(order),
+            dptr(mean), dptr(var), dptr(vmin), dptr(vmax)))
+        return {'mean': mean, 'var': var, 'min': vmin, 'max': vmax, 'order': order,
+                'n': ((nrefresh or self.refresh_done) - int(burn))*self.nchains}
+
+    def chisq_rows(self, row0=0, nrows=None):
+        """-2 (log_post - log_prior) of rows [row0, row0+nrows) (stats.py:821)."""
+        if nrows is None:
+            nrows = self.zlen - row0
+        out = np.empty(nrows)
+        check(self.lib.mc3hip_get_chisq(self._ctx, int(row0), int(nrows), dptr(out)))
+        return out
+
+    def kde_pdf(self, sample, x, cov):
+        return kde_pdf(sample, x, cov, self._device)
+
     # -- Chain.eval_model (chain.py:302-340) on the device ----------------------
     def eval_chisq(self, params):
         """chisq for one parameter vector or an [n, nparams] batch."""
@@ -303,6 +329,16 @@ def comm_unique_id():
     buf = ctypes.create_string_buffer(128)
     check(_lib.load().mc3hip_comm_unique_id(buf))
     return buf.raw
+
+
+def kde_pdf(sample, x, cov, device=0):
+    """Gaussian kernel density of a 1D sample at the points x with kernel variance cov
+    (scipy.stats.gaussian_kde.evaluate as cred_region uses it, stats.py:395-467)."""
+    sample, x = f64(sample), f64(x)
+    out = np.empty(len(x))
+    check(_lib.load().mc3hip_kde_pdf(int(device), dptr(sample), len(sample), dptr(x), len(x),
+                                     float(cov), dptr(out)))
+    return out
 
 
 def dwt_daub4(array, inverse=False, device=0):

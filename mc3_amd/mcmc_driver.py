@@ -120,7 +120,8 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
          wlike, fit_output, grtest, grbreak, grnmin, burnin, thinning,
          fgamma, fepsilon, hsize, kickoff, savefile, resume, log,
          pnames, texnames,
-         seed=None, device=0, comm=None, engine_factory=None, kickoff_stream=None):
+         seed=None, device=0, comm=None, engine_factory=None, kickoff_stream=None,
+         _extras=None):
     """Run the chains and assemble the output dictionary (see module docstring).
 
     ``ncpu`` is accepted for signature compatibility and ignored: the fan-out
@@ -284,10 +285,31 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
         view.zsize = nrows
         return nrows
 
+    host = {'rows': 0}
+
     def pull_rows(nrows):
-        Z, lp, zc = engine.rows(0, nrows)
-        zc[:M0] = zchain0
-        view.Z, view.log_post, view.zchain = Z, lp, zc
+        """Rows [0, nrows) on the host, fetching only what was not fetched before (one
+        host copy for the whole run, filled as the reports come)."""
+        if host['rows'] == 0:
+            host['Z'] = np.empty((zlen, nfree))
+            host['lp'] = np.empty(zlen)
+            host['zc'] = np.empty(zlen, np.int32)
+        r0 = host['rows']
+        if nrows > r0:
+            Z, lp, zc = engine.rows(r0, nrows - r0)
+            host['Z'][r0:nrows], host['lp'][r0:nrows], host['zc'][r0:nrows] = Z, lp, zc
+            if r0 < M0:
+                host['zc'][:M0] = zchain0
+            host['rows'] = nrows
+        view.Z, view.log_post, view.zchain = (host['Z'][:nrows], host['lp'][:nrows],
+                                              host['zc'][:nrows])
+
+    def stats_engine():
+        """The engine, when the posterior statistics can be computed where the rows are:
+        a run that started here (regular row layout) with every row in the local replica."""
+        if resume or not hasattr(engine, 'posterior_summary'):
+            return None
+        return engine if (comm.size == 1 or comm.native) else None
 
     print("Yippee Ki Yay Monte Carlo!")
     log.msg(f"Start MCMC chains  ({time.ctime()})")
@@ -324,7 +346,7 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
                 comm.finish(engine)
             pull_rows(nrows)
         if savefile is not None and comm.rank == 0:
-            ms.update_output(output, view, hsize)
+            ms.update_output(output, view, hsize, stats_engine())
             np.savez(savefile, **output)
         if run_gr:
             if device_gr:
@@ -344,12 +366,15 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
 
     nrows = snapshot(final=True)
     pull_rows(nrows)
-    posterior = ms.update_output(output, view, hsize)
+    summary = ms.update_output(output, view, hsize, stats_engine())
+    if _extras is not None:
+        _extras['summary'] = summary
+        _extras['kde'] = getattr(engine, 'kde_pdf', None) if stats_engine() else None
     engine.close()
 
     Z = output['posterior']
     nsample = len(Z)*thinning
-    nzsample = len(posterior) if posterior is not None else 0
+    nzsample = summary['n'] if summary is not None else 0
     fmt = len(str(nsample))
     log.msg('\nMCMC Summary:\n-------------')
     log.msg(

@@ -247,6 +247,7 @@ def sample(
 
     extra = {k: kwargs[k] for k in ('seed', 'device', 'comm', 'engine_factory',
                                    'kickoff_stream') if k in kwargs}
+    extra['_extras'] = side = {}
     output = mcmc(
         inp.data, inp.uncert, func, inp.params, indparams, indparams_dict,
         inp.pmin, inp.pmax, inp.pstep, inp.prior, inp.priorlow, inp.priorup,
@@ -256,18 +257,21 @@ def sample(
     output['chisq_factor'] = chisq_factor
 
     # -- statistics of the burned sample (sampler_driver.py:475-501): the median and
-    # central-interval numbers were computed with the output dictionary
-    # (update_output); the KDE mode and HPD bounds are added here
-    posterior, _, zmask = mu.burn(
-        Z=output['posterior'], zchain=output['zchain'], burnin=output['burnin'])
+    # central-interval numbers were computed with the output dictionary (update_output,
+    # on the device); the KDE mode and HPD bounds are added here from every thin-th burned
+    # row and the moments already known -- the burned posterior is never materialised
     bestp = output['bestp']
-    if 'medianp' in output and len(output.get('zmask', ())) == len(zmask):
-        mode, hlo, hhi = ms.hpd_statistics(posterior, bestp, inp.pstep)
-    else:
+    summary = side.get('summary')
+    if summary is None:                       # (chains shorter than the burn-in so far)
+        zmask = mu.burn_mask(output['zchain'], output['burnin'])
+        summary = ms.summarise(output['posterior'][zmask])
         (output['medianp'], output['meanp'], output['stdp'],
-         output['median_low_bounds'], output['median_high_bounds'],
-         mode, hlo, hhi) = ms.calc_sample_statistics(posterior, bestp, inp.pstep,
-                                                     calc_hpd=True)
+         output['median_low_bounds'], output['median_high_bounds']) = \
+            ms.statistics_from_summary(summary, bestp, inp.pstep)
+    else:
+        zmask = output['zmask']
+    mode, hlo, hhi = ms.hpd_statistics(output['posterior'], zmask, summary, bestp, inp.pstep,
+                                       kde=side.get('kde'))
     output['mode'], output['hpd_low_bounds'], output['hpd_high_bounds'] = mode, hlo, hhi
     fixed = inp.pstep == 0
     output['CRlo'] = np.where(fixed, 0.0, hlo - bestp)

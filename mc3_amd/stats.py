@@ -4,8 +4,11 @@ Mirrors what ``mcmc()``/``sample()`` call after the chains have run
 (mc3/stats/stats.py: log_prior :287-392, update_output :805-852,
 calc_bestfit_statistics :855-873, calc_sample_statistics :876-964,
 marginal_statistics :667-802, cred_region :395-467; mc3/stats/gelman.py).  These
-are post-run, NumPy/SciPy-bound and outside the hot path; they are kept on the
-host (SURVEY.md section 8f lists device versions as "next").
+are post-run.  With the chains on a device the passes over the whole posterior --
+mean, standard deviation, median and central percentiles, chisq = -2 (log_post -
+log_prior), the kernel density behind the HPD statistics -- run where the rows are
+(``summarise`` / ``update_output`` take the engine); the NumPy
+forms below serve the CPU checker and arbitrary arrays.
 """
 import numpy as np
 
@@ -97,26 +100,88 @@ def dwt_daub4(array, inverse=False, device=0):
     return engine.dwt_daub4(array, inverse, device)
 
 
-def cred_region(posterior=None, quantile=0.6827, pdf=None, xpdf=None):
-    """Highest-posterior-density region from a Gaussian-KDE of a 1D sample
-    (stats.py:395-467): returns (pdf, xpdf, HPDmin)."""
-    import scipy.stats as ss
+def kde_grid(sample, mean, std, amin, amax, kde=None):
+    """The density grid of cred_region (stats.py:440-452): a Gaussian KDE (Scott's
+    bandwidth, as scipy.stats.gaussian_kde) of ``sample`` evaluated at 100 points
+    between max(mean - 6 std, min) and min(mean + 6 std, max), interpolated linearly to
+    3000.  ``kde(sample, x, cov)`` evaluates the density (device); default: NumPy."""
     import scipy.interpolate as si
-    if pdf is None and xpdf is None:
-        thin = max(1, int(np.size(posterior)/120000))
-        kernel = ss.gaussian_kde(posterior[::thin])
-        mean, std = np.mean(posterior), np.std(posterior)
-        lo = max(mean - 6*std, np.amin(posterior))
-        hi = min(mean + 6*std, np.amax(posterior))
-        x = np.linspace(lo, hi, 100)
-        xpdf = np.linspace(lo, hi, 3000)
-        pdf = si.interp1d(x, kernel.evaluate(x))(xpdf)
-    if quantile is None:
-        return pdf, xpdf, 0.0
+    lo = max(mean - 6*std, amin)
+    hi = min(mean + 6*std, amax)
+    x = np.linspace(lo, hi, 100)
+    xpdf = np.linspace(lo, hi, 3000)
+    n = len(sample)
+    cov = np.var(sample, ddof=1)*n**(-0.4)          # Scott: factor n^(-1/5), squared
+    if kde is not None:
+        dens = kde(sample, x, cov)
+    else:
+        d = x[:, None] - sample[None, :]
+        dens = np.sum(np.exp(-0.5*d*d/cov), axis=1)/(n*np.sqrt(2*np.pi*cov))
+    return si.interp1d(x, dens)(xpdf), xpdf
+
+
+def hpd_level(pdf, quantile):
+    """Density level of the highest-posterior-density region holding ``quantile`` of the
+    probability (stats.py:454-467)."""
     order = np.argsort(pdf)[::-1]
     cdf = np.cumsum(pdf[order])
     ihpd = np.flatnonzero(cdf >= quantile*cdf[-1])[0]
-    return pdf, xpdf, np.amin(pdf[order][0:ihpd])
+    return np.amin(pdf[order][0:ihpd])
+
+
+def cred_region(posterior=None, quantile=0.6827, pdf=None, xpdf=None):
+    """Highest-posterior-density region from a Gaussian-KDE of a 1D sample
+    (stats.py:395-467): returns (pdf, xpdf, HPDmin)."""
+    if pdf is None and xpdf is None:
+        thin = max(1, int(np.size(posterior)/120000))
+        pdf, xpdf = kde_grid(posterior[::thin], np.mean(posterior), np.std(posterior),
+                             np.amin(posterior), np.amax(posterior))
+    if quantile is None:
+        return pdf, xpdf, 0.0
+    return pdf, xpdf, hpd_level(pdf, quantile)
+
+
+def percentiles_from_order(n, percents, fetch):
+    """np.percentile(..., method='linear') from exact order statistics: ``fetch(ranks)``
+    returns the values at the 0-based ranks ([nranks, ...]).  NumPy's own arithmetic
+    (virtual index, neighbours, _lerp), so that equal order statistics give equal
+    percentiles bit for bit."""
+    q = np.true_divide(np.asarray(percents, float), 100)
+    virtual = (n - 1)*q                       # numpy's 'linear' method
+    prev = np.floor(virtual).astype(np.int64)
+    nxt = np.minimum(prev + 1, n - 1)
+    prev = np.clip(prev, 0, n - 1)
+    ranks = np.unique(np.concatenate([prev, nxt]))
+    vals = fetch(ranks)
+    out = []
+    for vi, lo, hi in zip(virtual, prev, nxt):
+        a = vals[np.searchsorted(ranks, lo)]
+        b = vals[np.searchsorted(ranks, hi)]
+        t = vi - np.floor(vi)
+        diff = b - a
+        out.append(np.where(t >= 0.5, b - diff*(1 - t), a + diff*t))
+    return np.array(out)
+
+
+def summarise(posterior=None, engine=None, burn=0, quantile=0.683, nrefresh=None):
+    """n, mean, std, min, max, median and the central ``quantile`` bounds of every free
+    parameter of the burned posterior: from the device when ``engine`` offers it (the rows
+    of refreshes [burn, done), wherever they are), else from the array."""
+    pct = [50*(1 - quantile), 50.0, 50*(1 + quantile)]
+    if engine is not None and hasattr(engine, 'posterior_summary'):
+        n = ((nrefresh or engine.refresh_done) - burn)*engine.nchains
+        got = {}
+
+        def fetch(ranks):
+            got.update(engine.posterior_summary(burn, ranks, nrefresh))
+            return got['order']
+        low, med, high = percentiles_from_order(n, pct, fetch)
+        return {'n': n, 'mean': got['mean'], 'std': np.sqrt(got['var']), 'min': got['min'],
+                'max': got['max'], 'median': med, 'low': low, 'high': high}
+    low, med, high = np.percentile(posterior, pct, axis=0)
+    return {'n': len(posterior), 'mean': np.mean(posterior, axis=0),
+            'std': np.std(posterior, axis=0), 'min': np.amin(posterior, axis=0),
+            'max': np.amax(posterior, axis=0), 'median': med, 'low': low, 'high': high}
 
 
 def marginal_statistics(posterior, statistics='med_central', quantile=0.683,
@@ -182,17 +247,44 @@ def calc_sample_statistics(posterior, bestp, pstep, quantile=0.683,
     return base + (out['mode'], out['hlow'], out['hhigh'])
 
 
-def hpd_statistics(posterior, bestp, pstep, quantile=0.683):
-    """The KDE half of calc_sample_statistics(calc_hpd=True): marginal mode and
-    highest-posterior-density bounds over all parameters."""
+def spread_to_all(free_values, bestp, pstep):
+    """[nfree] statistics -> [nparams]: fixed parameters keep bestp, shared ones copy
+    their source (stats.py:938-949)."""
     pstep = np.asarray(pstep, float)
-    ifree = np.flatnonzero(pstep > 0)
-    mode, lo, hi = np.copy(bestp), np.copy(bestp), np.copy(bestp)
-    mode[ifree], lo[ifree], hi[ifree] = marginal_statistics(posterior, 'max_like', quantile)
+    out = np.copy(bestp)
+    out[pstep > 0] = free_values
     for i in np.flatnonzero(pstep < 0):
-        j = -int(pstep[i]) - 1
-        mode[i], lo[i], hi[i] = mode[j], lo[j], hi[j]
-    return mode, lo, hi
+        out[i] = out[-int(pstep[i]) - 1]
+    return out
+
+
+def statistics_from_summary(summary, bestp, pstep):
+    """(medianp, meanp, stdp, median_low_bounds, median_high_bounds) of
+    calc_sample_statistics (stats.py:876-964) from a ``summarise`` result."""
+    std = spread_to_all(summary['std'], np.zeros(len(bestp)), pstep)
+    return (spread_to_all(summary['median'], bestp, pstep),
+            spread_to_all(summary['mean'], bestp, pstep), std,
+            spread_to_all(summary['low'], bestp, pstep),
+            spread_to_all(summary['high'], bestp, pstep))
+
+
+def hpd_statistics(Z, zmask, summary, bestp, pstep, quantile=0.683, kde=None):
+    """The KDE half of calc_sample_statistics(calc_hpd=True) (stats.py:909-935): marginal
+    mode and highest-posterior-density bounds over all parameters.  Only the rows the
+    density is built from -- every thin-th row of the burned posterior Z[zmask], as
+    cred_region thins it -- are touched; the moments come from ``summary``."""
+    thin = max(1, int(len(zmask)/120000))
+    rows = Z[zmask[::thin]]
+    nfree = rows.shape[1]
+    mode, lo, hi = np.empty(nfree), np.empty(nfree), np.empty(nfree)
+    for i in range(nfree):
+        pdf, xpdf = kde_grid(np.ascontiguousarray(rows[:, i]), summary['mean'][i],
+                             summary['std'][i], summary['min'][i], summary['max'][i], kde)
+        mode[i] = xpdf[np.argmax(pdf)]
+        inside = xpdf[pdf > hpd_level(pdf, quantile)]
+        lo[i], hi[i] = np.amin(inside), np.amax(inside)
+    return (spread_to_all(mode, bestp, pstep), spread_to_all(lo, bestp, pstep),
+            spread_to_all(hi, bestp, pstep))
 
 
 def calc_bestfit_statistics(bestp, chain):
@@ -210,17 +302,33 @@ def calc_bestfit_statistics(bestp, chain):
             np.std(best_model - chain.data))
 
 
-def update_output(output, chain, hsize):
-    """Fill the output dictionary from a Chain-shaped object (stats.py:805-852)."""
+def update_output(output, chain, hsize, engine=None):
+    """Fill the output dictionary from a Chain-shaped object (stats.py:805-852).
+    ``engine``: the device engine the rows came from -- chisq and the statistics of the
+    burned posterior are then computed on the device instead of over the host copies.
+    Returns the ``summarise`` result of the burned posterior (None before every chain has
+    passed its burn-in)."""
     zburn = output['burnin']
-    valid = chain.zchain >= 0
-    nsample = np.sum(valid)*chain.thinning
+    zchain = chain.zchain
+    first = int(np.argmax(zchain >= 0)) if np.any(zchain >= 0) else len(zchain)
+    if np.all(zchain[:first] < 0) and np.all(zchain[first:] >= 0):
+        valid = slice(first, len(zchain))        # (the usual layout: views, no copies)
+        nvalid = len(zchain) - first
+    else:
+        valid = zchain >= 0
+        nvalid = int(np.sum(valid))
+    nsample = nvalid*chain.thinning
     Z = chain.Z[valid]
     lp = chain.log_post[valid]
     output['posterior'] = Z
-    output['zchain'] = chain.zchain[valid]
-    output['chisq'] = -2.0*(lp - log_prior(Z, chain.prior, chain.priorlow,
-                                           chain.priorup, chain.pstep))
+    output['zchain'] = zchain[valid]
+    on_device = engine is not None and hasattr(engine, 'chisq_rows') and \
+        isinstance(valid, slice) and first == engine.M0
+    if on_device:
+        output['chisq'] = engine.chisq_rows(first, nvalid)
+    else:
+        output['chisq'] = -2.0*(lp - log_prior(Z, chain.prior, chain.priorlow,
+                                               chain.priorup, chain.pstep))
     output['log_post'] = lp
     output['acceptance_rate'] = chain.numaccept.value*100.0/nsample
     (output['best_chisq'], output['red_chisq'], output['BIC'],
@@ -229,12 +337,17 @@ def update_output(output, chain, hsize):
     output['bestp'] = chain.bestp
     if not np.all(chain.chainsize > (zburn + hsize)):
         return None
-    posterior, _, zmask = mu.burn(Z=Z, zchain=output['zchain'], burnin=zburn)
-    stats = calc_sample_statistics(posterior, chain.bestp, chain.pstep)
+    zmask = mu.burn_mask(output['zchain'], zburn)
+    regular = on_device and len(zmask) == (engine.refresh_done - zburn)*engine.nchains
+    if regular:
+        summary = summarise(engine=engine, burn=zburn)
+    else:
+        summary = summarise(Z[zmask])
     output['zmask'] = zmask
     (output['medianp'], output['meanp'], output['stdp'],
-     output['median_low_bounds'], output['median_high_bounds']) = stats
-    return posterior
+     output['median_low_bounds'], output['median_high_bounds']) = \
+        statistics_from_summary(summary, chain.bestp, chain.pstep)
+    return summary
 
 
 def gelman_rubin_from_moments(mean, var, niter):

@@ -13,6 +13,11 @@ def default_parnames(npars):
     return np.array([f'Param {i+1}' for i in range(npars)])
 
 
+def burn_mask(zchain, burnin, sort=True):
+    """The index array of ``burn`` alone (no row is copied)."""
+    return burn(Z=np.empty((len(zchain), 0)), zchain=zchain, burnin=burnin, sort=sort)[2]
+
+
 def burn(Zdict=None, burnin=None, Z=None, zchain=None, sort=True):
     """Remove the first ``burnin`` samples of every chain.
 

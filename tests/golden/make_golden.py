@@ -321,6 +321,17 @@ def kernel_vectors():
     out['gr_irregular_Z'] = Zi
     out['gr_irregular_zchain'] = zci
     out['gr_irregular_psrf'] = gel.gelman_rubin(Zi, zci, 5)
+    # sample statistics (mc3/stats/stats.py:876-964, calc_hpd=True): a skewed 3-parameter
+    # posterior inside a 5-parameter vector with one fixed and one shared parameter
+    rs4 = np.random.RandomState(5050)
+    post = np.column_stack([rs4.normal(3.0, 0.2, 30000), rs4.gamma(3.0, 0.5, 30000),
+                            rs4.normal(-1.0, 2.0, 30000)**2*0.01 + rs4.normal(0, 0.05, 30000)])
+    sbest = np.array([3.01, 7.0, 1.4, 0.02, 3.01])
+    sstep = np.array([0.1, 0.0, 0.1, 0.1, -1.0])
+    out['stats_posterior'] = post
+    out['stats_bestp'] = sbest
+    out['stats_pstep'] = sstep
+    out['stats_result'] = np.array(ms.calc_sample_statistics(post, sbest, sstep, calc_hpd=True))
     np.savez_compressed(os.path.join(HERE, 'kernel_vectors.npz'), **out)
     print('kernel_vectors:', len(out), 'arrays')
 

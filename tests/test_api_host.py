@@ -370,3 +370,28 @@ def test_philox_population_is_the_default_and_deterministic():
     assert Z0.shape == (80, 3) and np.all(np.isfinite(captured[0][1]))
     # around the initial guess with the proposal widths (chi-by-eye: 80 draws)
     assert np.all(np.abs(Z0.mean(axis=0) - [10.0, -2.0, 0.1]) < 4*np.array([1.0, 0.5, 0.1])/np.sqrt(80)*2)
+
+
+def test_sample_statistics_equal_the_reference(golden_dir):
+    """summarise -> statistics_from_summary + hpd_statistics (what sample() now calls, in
+    their host form) against the reference's calc_sample_statistics(calc_hpd=True)
+    (mc3/stats/stats.py:876-964) on a skewed posterior with a fixed and a shared
+    parameter; percentiles_from_order against np.percentile bit for bit."""
+    from mc3_amd import stats as ms
+    kv = np.load(os.path.join(golden_dir, 'kernel_vectors.npz'))
+    post, bestp, pstep = kv['stats_posterior'], kv['stats_bestp'], kv['stats_pstep']
+    want = kv['stats_result']          # median, mean, std, low, high, mode, hpd low, hpd high
+    summary = ms.summarise(post)
+    got = ms.statistics_from_summary(summary, bestp, pstep)
+    for g, w in zip(got, want[:5]):
+        np.testing.assert_allclose(g, w, rtol=1e-12)
+    zmask = np.arange(len(post))
+    mode, lo, hi = ms.hpd_statistics(post, zmask, summary, bestp, pstep)
+    np.testing.assert_allclose(mode, want[5], rtol=1e-10)
+    np.testing.assert_allclose(lo, want[6], rtol=1e-10)
+    np.testing.assert_allclose(hi, want[7], rtol=1e-10)
+    srt = np.sort(post, axis=0)
+    pct = [15.85, 50.0, 84.15, 0.0, 100.0, 33.333]
+    np.testing.assert_array_equal(
+        ms.percentiles_from_order(len(post), pct, lambda ranks: srt[ranks]),
+        np.percentile(post, pct, axis=0))

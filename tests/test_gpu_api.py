@@ -27,13 +27,23 @@ def both(**kw):
     return outs
 
 
+# computed on the device in the GPU run and with NumPy in the checker's: reductions in
+# another order (mean, std), another exp (KDE, log-uniform priors)
+REDUCED = ('meanp', 'stdp', 'chisq', 'mode', 'hpd_low_bounds', 'hpd_high_bounds', 'CRlo',
+           'CRhi')
+
+
 def assert_same_dict(gpu, cpu):
     assert set(gpu) == set(cpu)
     for key in gpu:
         if key in ('pnames', 'texnames'):
             continue
-        np.testing.assert_array_equal(np.asarray(gpu[key]), np.asarray(cpu[key]),
-                                      err_msg=key)
+        if key in REDUCED:
+            np.testing.assert_allclose(np.asarray(gpu[key]), np.asarray(cpu[key]),
+                                       rtol=1e-10, atol=1e-13, err_msg=key)
+        else:
+            np.testing.assert_array_equal(np.asarray(gpu[key]), np.asarray(cpu[key]),
+                                          err_msg=key)
 
 
 @pytest.mark.parametrize('sampler', ['snooker', 'demc', 'mrw'])
@@ -301,3 +311,61 @@ def test_initial_population_that_cannot_be_filled():
                        indparams=[x], pstep=prob['pstep'], pmin=prob['pmin'],
                        pmax=prob['pmax'], sampler='demc', nsamples=400, nchains=4, hsize=2,
                        log=mu.Log(verb=0), seed=3)
+
+
+def test_posterior_summary_on_the_device_equals_the_reference(golden_dir):
+    """mc3hip_posterior_summary (reductions + exact radix selection where the rows are) and
+    mc3hip_kde_pdf, through the statistics sample() builds from them, against the
+    reference's calc_sample_statistics(calc_hpd=True) fixture (mc3/stats/stats.py:876-964)."""
+    from mc3_amd import engine, stats as ms
+    kv = np.load(os.path.join(golden_dir, 'kernel_vectors.npz'))
+    post, bestp, pstep = kv['stats_posterior'], kv['stats_bestp'], kv['stats_pstep']
+    want = kv['stats_result']
+    nch, M0 = 10, 10
+    nit = len(post)//nch
+    prob = H.quad_problem(nchains=nch, nsamples=nch*nit, sampler='demc', hsize=1)
+    with engine.DeviceChains(**prob) as gpu:
+        gpu.set_population(post[:M0], np.zeros(M0))
+        gpu.put_rows(M0, post)
+        summary = ms.summarise(engine=gpu, burn=0, nrefresh=nit)
+        host = ms.summarise(post)
+        for key in ('median', 'low', 'high', 'min', 'max'):        # exact selection
+            np.testing.assert_array_equal(summary[key], host[key], err_msg=key)
+        np.testing.assert_allclose(summary['mean'], host['mean'], rtol=1e-13)
+        np.testing.assert_allclose(summary['std'], host['std'], rtol=1e-12)
+        got = ms.statistics_from_summary(summary, bestp, pstep)
+        for g, w in zip(got, want[:5]):
+            np.testing.assert_allclose(g, w, rtol=1e-12)
+        mode, lo, hi = ms.hpd_statistics(post, np.arange(len(post)), summary, bestp, pstep,
+                                         kde=gpu.kde_pdf)
+        np.testing.assert_allclose(mode, want[5], rtol=1e-10)
+        np.testing.assert_allclose(lo, want[6], rtol=1e-10)
+        np.testing.assert_allclose(hi, want[7], rtol=1e-10)
+        # a burn-in and other ranks: against NumPy on the same rows
+        burned = post[7*nch:]
+        s2 = gpu.posterior_summary(7, [0, 1, len(burned)//3, len(burned) - 1], nrefresh=nit)
+        srt = np.sort(burned, axis=0)
+        np.testing.assert_array_equal(s2['order'], srt[[0, 1, len(burned)//3, len(burned) - 1]])
+        np.testing.assert_allclose(s2['var'], burned.var(axis=0), rtol=1e-12)
+
+
+def test_kde_and_chisq_rows_on_the_device():
+    from mc3_amd import engine, stats as ms
+    import scipy.stats as ss
+    rs = np.random.RandomState(12)
+    sample = rs.gamma(2.0, 1.0, 50000)
+    x = np.linspace(0.1, 8.0, 100)
+    kernel = ss.gaussian_kde(sample)
+    cov = np.var(sample, ddof=1)*len(sample)**(-0.4)
+    np.testing.assert_allclose(engine.kde_pdf(sample, x, cov), kernel.evaluate(x), rtol=1e-10)
+    # chisq of the rows = -2 (log_post - log_prior), two-sided Gaussian priors
+    prob = H.shared_problem(nsamples=8*60)
+    orc = H.make_oracle(prob)
+    Z0, lp0 = H.initial_population(orc)
+    with engine.DeviceChains(**prob) as gpu:
+        gpu.set_population(Z0, lp0)
+        gpu.run()
+        Z, lp, zc = gpu.rows()
+        want = -2.0*(lp - ms.log_prior(Z, gpu.prior, gpu.priorlow, gpu.priorup, gpu.pstep))
+        np.testing.assert_array_equal(gpu.chisq_rows(), want)
+        np.testing.assert_array_equal(gpu.chisq_rows(gpu.M0 + 3, 50), want[gpu.M0 + 3:gpu.M0 + 53])
