@@ -107,6 +107,11 @@ typedef struct mc3hip_plan {
     int32_t comm_graph;     /* >0: the RCCL exchange runs inside a hipGraph of that many
                                refreshes (step kernel + all-gather + scatter per refresh)   */
     int32_t recoveries;     /* persistent launches that gave up and were redone so far        */
+    int32_t tile_tree;      /* how a tile's 1024 strided partial sums are added up: 0 = one
+                               halving tree over all of them (strides 512..1); 1 = 64 at a
+                               time (strides 32..1), then the 16 group totals (8..1): the
+                               matrix-core tile kernel                                          */
+    int32_t _reserved;
 } mc3hip_plan;
 
 /* Replaces Chain.__init__ + the shared-memory allocation of mcmc()

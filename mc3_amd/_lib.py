@@ -54,7 +54,8 @@ class Plan(ctypes.Structure):
                 ('waves_per_chain', ctypes.c_int32),
                 ('graph_nodes', ctypes.c_int32),
                 ('persistent', ctypes.c_int32), ('fast', ctypes.c_int32),
-                ('comm_graph', ctypes.c_int32), ('recoveries', ctypes.c_int32)]
+                ('comm_graph', ctypes.c_int32), ('recoveries', ctypes.c_int32),
+                ('tile_tree', ctypes.c_int32), ('_reserved', ctypes.c_int32)]
 
 
 class Mc3HipError(RuntimeError):

@@ -263,20 +263,23 @@ void launch_finish_t(mc3hip_ctx *c, int roff, int j)
     default: FN<MT_POLY_GENERIC>(__VA_ARGS__); break;                               \
     }
 
+// LDS of the tile kernel: 16 chains x 1024 partial sums + two buffers of 16 coefficient rows
+constexpr size_t TILE_LDS_BYTES = (16 * 1024 + 2 * 16 * (16 + 2)) * sizeof(double);
+
 template <int KMAX, bool LINEAR>
 void launch_tile_t(mc3hip_ctx *c)
 {
     const int ncol = (c->P.nlocal + c->tile_chain_block - 1) / c->tile_chain_block;
     constexpr int TP = KMAX <= 4 ? 4 : 2;
     hipLaunchKernelGGL((tile_chisq_kernel<KMAX, LINEAR, TP>), dim3(c->P.ntiles, ncol),
-                       dim3(1024), 16 * 1024 * sizeof(double), c->stream, c->P,
+                       dim3(1024), TILE_LDS_BYTES, c->stream, c->P,
                        c->tile_chain_block, (const double *)c->P.sc_nextp,
                        (const int32_t *)c->P.sc_flag);
 }
 
 int tile_set_attr(mc3hip_ctx *c)
 {
-    const int bytes = 16 * 1024 * (int)sizeof(double);
+    const int bytes = (int)TILE_LDS_BYTES;
 #define TILE_ATTR(KMAX, LIN)                                                               \
     HIP_TRY(hipFuncSetAttribute(                                                           \
         reinterpret_cast<const void *>(&tile_chisq_kernel<KMAX, LIN, (KMAX <= 4 ? 4 : 2)>), \
@@ -291,8 +294,32 @@ int tile_set_attr(mc3hip_ctx *c)
     return MC3HIP_OK;
 }
 
+// design-matrix models with two points per virtual lane (5..16 coefficients): the data
+// sums go through the FP64 matrix cores (tile_chisq_mfma_kernel)
+bool tile_uses_mfma(const mc3hip_ctx *c)
+{
+    return c->mt == MT_LINEAR && c->P.tile == 2048 && !getenv("MC3HIP_NO_MFMA");
+}
+
+template <int KB>
+void launch_tile_mfma_t(mc3hip_ctx *c)
+{
+    const int ncol = (c->P.nlocal + c->tile_chain_block - 1) / c->tile_chain_block;
+    hipLaunchKernelGGL((tile_chisq_mfma_kernel<KB>), dim3(c->P.ntiles, ncol), dim3(512),
+                       0, c->stream, c->P, c->tile_chain_block,
+                       (const double *)c->P.sc_nextp, (const int32_t *)c->P.sc_flag);
+}
+
 void launch_tile(mc3hip_ctx *c)
 {
+    if (tile_uses_mfma(c)) {
+        switch ((c->P.nmodel + 3) / 4) {
+        case 2: launch_tile_mfma_t<2>(c); break;
+        case 3: launch_tile_mfma_t<3>(c); break;
+        default: launch_tile_mfma_t<4>(c); break;
+        }
+        return;
+    }
     const bool lin = c->mt == MT_LINEAR;
     switch (c->tile_kmax) {
     case 4: lin ? launch_tile_t<4, true>(c) : launch_tile_t<4, false>(c); break;
@@ -1040,6 +1067,7 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
     plan->graph_nodes = c->graph_nodes;
     plan->persistent = c->comm ? 0 : decide_persist(const_cast<mc3hip_ctx *>(c));
     plan->fast = (plan->persistent > 0 && c->fast) ? (lean_demc_eligible(c) ? 2 : 1) : 0;
+    plan->tile_tree = tile_uses_mfma(c) ? 1 : 0;
     plan->comm_graph = c->cgraph_exec ? c->comm_graph_nodes : 0;
     plan->recoveries = c->recoveries;
     return MC3HIP_OK;

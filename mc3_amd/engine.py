@@ -116,7 +116,8 @@ class DeviceChains:
                 'waves_per_chain': plan.waves_per_chain,
                 'graph_nodes': plan.graph_nodes,
                 'persistent': plan.persistent, 'fast': plan.fast,
-                'comm_graph': plan.comm_graph, 'recoveries': plan.recoveries}
+                'comm_graph': plan.comm_graph, 'recoveries': plan.recoveries,
+                'tile_tree': plan.tile_tree}
 
     # -- lifetime --------------------------------------------------------------
     def close(self):

@@ -54,6 +54,7 @@ typedef struct {
     int32_t ngprior;
     int32_t tile, vlanes;
     int32_t wl_threads;     /* wavelet path: threads that share a chain (64 * waves) */
+    int32_t tile_tree, _pad_tree;   /* 1: 64 partial sums at a time, then the group totals */
     int64_t M0, zlen;
     uint64_t seed;
     double gamma, fepsilon;
@@ -269,6 +270,18 @@ static double halving_tree(double *part, int n)
     return part[0];
 }
 
+/* the `vlanes` strided partial sums of a tile: one halving tree over all of them, or
+ * ("waves first", the matrix-core tile kernel) groups of 64, then the group totals */
+static double tile_sum(double *part, int n, int waves_first)
+{
+    if (!waves_first || n <= 64)
+        return halving_tree(part, n);
+    const int ng = n / 64;
+    for (int w = 0; w < ng; w++)
+        part[w] = halving_tree(part + 64 * w, 64);     /* (w <= 64 w: no overlap) */
+    return halving_tree(part, ng);
+}
+
 /* Gaussian chi-squared: src_c/_chisq.c:131-137 with w = 1/uncert, in the
  * canonical summation order.  model == +inf anywhere => +inf (chain.py:322). */
 static double gauss_chisq(const ls_problem *P, const double *p, double *part)
@@ -298,7 +311,7 @@ static double gauss_chisq(const ls_problem *P, const double *p, double *part)
             }
             part[l] = acc;
         }
-        total = total + halving_tree(part, VL);
+        total = total + tile_sum(part, VL, P->tile_tree);
     }
     if (sawinf || total == INFINITY)
         return INFINITY;

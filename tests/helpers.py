@@ -103,7 +103,8 @@ def make_oracle(prob, plan=None, **extra):
     likelihood -- the threads that share a chain."""
     kw = dict(prob)
     if plan is not None:
-        kw.update(tile=plan['tile'], vlanes=plan['vlanes'])
+        kw.update(tile=plan['tile'], vlanes=plan['vlanes'],
+                  tile_tree=plan.get('tile_tree', 0))
         if prob.get('wlike'):
             kw['wl_threads'] = 64*plan['waves_per_chain']
     kw.update(extra)

@@ -52,8 +52,9 @@ def test_processes_peer_to_peer(tmp_path, nproc, sampler, thinning, niter):
     for rank in range(nproc):
         got = np.load(f'{out_path}.rank{rank}.npz')
         for key in ('posterior', 'zchain', 'log_post', 'chisq', 'bestp',
-                    'acceptance_rate', 'best_log_post', 'medianp', 'stdp'):
+                    'acceptance_rate', 'best_log_post', 'medianp'):
             np.testing.assert_array_equal(got[key], single[key], err_msg=key)
+        np.testing.assert_allclose(got['stdp'], single['stdp'], rtol=1e-12)
 
 
 def launch(nproc, script, *args, env=None, timeout=1000):
@@ -121,5 +122,6 @@ def test_peer_to_peer_abort_is_recovered_by_all_ranks(tmp_path, sampler):
     for rank in range(2):
         got = np.load(f'{out_path}.rank{rank}.npz')
         for key in ('posterior', 'zchain', 'log_post', 'chisq', 'bestp',
-                    'acceptance_rate', 'best_log_post', 'medianp', 'stdp'):
+                    'acceptance_rate', 'best_log_post', 'medianp'):
             np.testing.assert_array_equal(got[key], single[key], err_msg=key)
+        np.testing.assert_allclose(got['stdp'], single['stdp'], rtol=1e-12)

@@ -485,7 +485,7 @@ def test_config_c5_linear_full_size(eng):
         prob = H.linear_problem(ndata=100000, nchains=nchains, nsamples=nchains*6)
         gpu = eng.DeviceChains(chain0=chain0, nlocal=nlocal, **prob)
         assert gpu.plan['tile'] == 2048                 # the tiled plan (10 coefficients)
-        orc = H.make_oracle(prob, chain0=chain0, nlocal=nlocal, tile=gpu.plan['tile'])
+        orc = H.make_oracle(prob, plan=gpu.plan, chain0=chain0, nlocal=nlocal)
         Z0, lp0 = H.initial_population(orc)
         orc.set_population(Z0, lp0)
         gpu.set_population(Z0, lp0)
