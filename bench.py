@@ -135,6 +135,12 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line: whatever native libraries print there meanwhile (gloo's
+    # and RCCL's banners) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -154,6 +160,7 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
         dist.init_process_group('gloo', rank=rank, world_size=world)
 
     from mc3_amd import engine, parallel
@@ -370,14 +377,14 @@ def main():
     if world > 1 or force_comm:
         dist.barrier()
         dist.destroy_process_group()
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)       # (what native code still holds in C stdio)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    os.dup2(json_fd, 1)
     if rank == 0:
-        # the JSON line goes out last, behind anything native libraries (RCCL's version
-        # banner) still hold in the C stdio buffer
-        import ctypes
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
         print(json.dumps(out), flush=True)
 
 
