@@ -70,7 +70,8 @@ typedef struct mc3hip_problem {
     int32_t nparams;        /* len(params), incl. fixed and shared                      */
     int32_t ndata;
     int32_t sampler;        /* MC3HIP_MRW / _DEMC / _SNOOKER                            */
-    int32_t wlike;          /* 0: Gaussian chisq (_chisq.c:111); 1: wavelet (_dwt.c:56) */
+    int32_t wlike;          /* 0: Gaussian chisq (_chisq.c:111); 1: wavelet (_dwt.c:56),
+                               power-of-two ndata <= 2^22                               */
     int32_t model_kind;     /* MC3HIP_MODEL_*                                           */
     int32_t nmodel;         /* model coefficients = params[0:nmodel]                    */
     int32_t thinning;       /* iterations per Z refresh (chain.py:276)                  */

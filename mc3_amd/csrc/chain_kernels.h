@@ -81,6 +81,7 @@ struct DevProblem {
     int32_t wl_grid, _pad_grid;
     double wl_x0, wl_step, wl_xlast;
     const double *data_t;         // wavelet: the data as [j][t] (thread t's j-th point)
+    double *wl_scratch;           // wavelet, ndata > 2^14: [blocks][3 ndata / 4] pre-level values
     // RCCL exchange inside a hipGraph: slot `roff` of this ring receives the rows of the
     // refresh a graph node produced (fixed addresses, so the captured all-gather can be
     // replayed); nullptr = off
@@ -108,7 +109,7 @@ constexpr int SC_STRIDE = MC3HIP_MAX_PARAMS + 16;   // doubles per sc_nextp row 
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");       \
     } while (0)
 // Non-draining stamps for the kernels with dynamic LDS (wavelet path): the shader clock
-// goes to a spare corner of the LDS noise table (slots 16..31 of `tab`, SmemLayout) and is
+// goes to a spare corner of the LDS noise table (slots 32..47 of `tab`, SmemLayout) and is
 // copied out once per iteration (MC3_LSTAMP_FLUSH), so that no stamp waits for the store
 // of the one before it.
 extern __shared__ __attribute__((aligned(16))) double mc3_smem_stamps_[];
@@ -123,14 +124,14 @@ extern __shared__ __attribute__((aligned(16))) double mc3_smem_stamps_[];
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();                       \
         if (threadIdx.x == 0 && blockIdx.x == 0)                                          \
             reinterpret_cast<unsigned long long *>(mc3_smem_stamps_)[blockDim.x +         \
-                MC3HIP_MAX_PARAMS + 2 + 16 + (slot)] = t_;                                \
+                MC3HIP_MAX_PARAMS + 2 + 32 + (slot)] = t_;                                \
     } while (0)
 #define MC3_LSTAMP_FLUSH()                                                                \
     do {                                                                                  \
         if (threadIdx.x == 0 && blockIdx.x == 0)                                          \
             for (int q_ = 0; q_ < 16; ++q_)                                               \
                 P.stamps[q_] = reinterpret_cast<unsigned long long *>(                    \
-                    mc3_smem_stamps_)[blockDim.x + MC3HIP_MAX_PARAMS + 2 + 16 + q_];      \
+                    mc3_smem_stamps_)[blockDim.x + MC3HIP_MAX_PARAMS + 2 + 32 + q_];      \
     } while (0)
 #endif
 #else
@@ -519,8 +520,8 @@ __device__ __forceinline__ void wavelet_stage(const DevProblem &P, double *xs)
     const int N = P.ndata;
     const int Ta = (N / 2 < T) ? (N / 2 > 0 ? N / 2 : 1) : T;
     const int B = N / Ta;
-    if ((int)threadIdx.x >= Ta)
-        return;
+    if ((int)threadIdx.x >= Ta || N > WB * T)
+        return;                                 // (large data sets read global memory)
     const double *src = (MT == MT_LINEAR || P.wl_grid) ? P.data : P.indep;
     for (int j = 0; j < B; ++j)
         xs[j * T + threadIdx.x] = src[B * threadIdx.x + j];
@@ -575,9 +576,8 @@ constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n / 2); }
 // (1/sigma_W^2 of scale m0, m0 - 1, ...), in level order
 template <int NLEV, int NACC>
 __device__ __forceinline__ double weigh_levels(const double (&accs)[NACC], const double *s_tab,
-                                               int m0)
+                                               int m0, double w = 0.0)
 {
-    double w = 0.0;
 #pragma unroll
     for (int l = 0; l < NLEV; ++l)
         w = mc3_fma(accs[l], s_tab[m0 - l], w);
@@ -588,13 +588,16 @@ __device__ __forceinline__ double weigh_levels(const double (&accs)[NACC], const
 // two new points per output pair, so that only the B/2 smooth values are ever held.
 // GRID: x recomputed on np.linspace's grid, data from LDS; otherwise x from LDS, data from
 // the register-resident tile.  Returns the level's sum of squared details.
-template <int WPC, int MT, int B, bool GRID, int CAP>
+// VALUES: the block's inputs are values already (the output of the pre-levels of a large
+// data set, in global memory as a plain array), not residuals to be formed.
+template <int WPC, int MT, int B, bool GRID, int CAP, bool VALUES = false>
 __device__ __forceinline__ double wavelet_level0(const DevProblem &P, const Model<MT> &model,
                                                  const double *xs, int me, int next, int Ta,
-                                                 int &sawinf, double (&v)[CAP])
+                                                 int &sawinf, double (&v)[CAP],
+                                                 const double *values = nullptr)
 {
     constexpr int T = 64 * WPC;
-    const int N = P.ndata;
+    const int N = VALUES ? B * Ta : P.ndata;
     const int base = B * me;
     double fbase = (double)base, fnext = (double)(B * next);
     int ome = me, onext = next;
@@ -612,9 +615,13 @@ __device__ __forceinline__ double wavelet_level0(const DevProblem &P, const Mode
     constexpr int PF = 8;
     double in0[B + 2], in1[(MT != MT_LINEAR && !GRID) ? B + 2 : 1];
     auto fetch = [&](int j) {                           // static j
-        in0[j] = (j < B) ? xme[j * T] : xnext[(j - B) * T];
-        if constexpr (MT != MT_LINEAR && !GRID)
-            in1[j] = (j < B) ? dme[j * T] : dnext[(j - B) * T];
+        if constexpr (VALUES) {
+            in0[j] = (j < B) ? values[B * ome + j] : values[B * onext + (j - B)];
+        } else {
+            in0[j] = (j < B) ? xme[j * T] : xnext[(j - B) * T];
+            if constexpr (MT != MT_LINEAR && !GRID)
+                in1[j] = (j < B) ? dme[j * T] : dnext[(j - B) * T];
+        }
     };
 #pragma unroll
     for (int j = 0; j < PF + 2 && j < B + 2; ++j)
@@ -622,7 +629,9 @@ __device__ __forceinline__ double wavelet_level0(const DevProblem &P, const Mode
     (void)in1;
     auto resid = [&](int j) {                           // j: static index into the block;
         double m, dv;                                   // B, B+1: the next block's first two
-        if constexpr (MT == MT_LINEAR) {
+        if constexpr (VALUES) {
+            return in0[j];
+        } else if constexpr (MT == MT_LINEAR) {
             m = model.at(j < B ? base + j : (base + j) & (N - 1));
             dv = in0[j];
         } else if constexpr (GRID) {
@@ -670,7 +679,8 @@ __device__ __forceinline__ double wavelet_level0(const DevProblem &P, const Mode
 // sigma_W^2(m), its reciprocal (table in LDS) and its share of the log-determinant, lane
 // 0 the smooth coefficients' sigma_S^2 -- one exp2 + log per lane instead of M of each on
 // every thread -- and the log-determinant is summed in scale order.  Results in LDS:
-// s_tab[1..M-1] = 1/sigma_W^2, s_tab[14] = sigma_S^2, s_tab[15] = the log-determinant.
+// s_tab[1..M-1] = 1/sigma_W^2 (M <= 22), s_tab[24] = sigma_S^2, s_tab[25] = the
+// log-determinant.
 __device__ __forceinline__ void wavelet_noise_terms(const double *s_nextp, int nparams, int M,
                                                     double *s_tab)
 {
@@ -686,20 +696,25 @@ __device__ __forceinline__ void wavelet_noise_terms(const double *s_nextp, int n
         term = (double)(1 << lane) * mc3_det_log(6.283185307179586 * sW2);
     } else if (lane == 0) {
         const double sS2 = sr2 * mc3_det_exp2(-gam) * 0.72134752 + sw2;
-        s_tab[14] = sS2;
+        s_tab[24] = sS2;
         term = 2.0 * mc3_det_log(6.283185307179586 * sS2);
     }
     double Lg = read_lane(term, 0);
     for (int m = 1; m < M; ++m)
         Lg = Lg + read_lane(term, m);             // scales added in order
     if (lane == 0)
-        s_tab[15] = Lg;
+        s_tab[25] = Lg;
 }
 
-template <int WPC, int MT, int B>
+// `values` (large data sets): the blocks are cut from that array of B T values -- the
+// output of `npre` pre-levels whose per-thread sums of squared details arrive in accP --
+// instead of from the residuals.
+template <int WPC, int MT, int B, bool VALUES = false>
 __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double *s_nextp,
                                                double *s_part, int *s_flag, double *s_tab,
-                                               double *s_halo, const double *xs)
+                                               double *s_halo, const double *xs,
+                                               const double *values = nullptr, int npre = 0,
+                                               const double *accP = nullptr, int sawinf0 = 0)
 {
     constexpr int T = 64 * WPC;
     constexpr int NLA = ilog2c(B);                      // levels of stage A (N >= 4)
@@ -707,8 +722,8 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
     const int tid = threadIdx.x, lane = tid & 63;
     // (made wave-uniform by hand so that the per-wave roles below are scalar branches)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int N = P.ndata;
-    const int M = ilog2(N);
+    const int M = ilog2(P.ndata);
+    const int N = VALUES ? B * T : P.ndata;             // length of the array stage A starts from
     const int Ta = N / B;                               // threads that own a block
     const bool active = tid < Ta;
     const int me = active ? tid : 0;
@@ -727,9 +742,12 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
     constexpr int HB = (B / 2 > 2) ? B / 2 : 2;
     double v[HB + 2];
     double accA[NLA > 0 ? NLA : 1];
-    int sawinf = 0;
+    int sawinf = sawinf0;
     int nn = N;
-    if (MT != MT_LINEAR && P.wl_grid)
+    if constexpr (VALUES)
+        accA[0] = wavelet_level0<WPC, MT, B, false, HB + 2, true>(P, model, xs, me, next, Ta,
+                                                                  sawinf, v, values);
+    else if (MT != MT_LINEAR && P.wl_grid)
         accA[0] = wavelet_level0<WPC, MT, B, true, HB + 2>(P, model, xs, me, next, Ta, sawinf, v);
     else
         accA[0] = wavelet_level0<WPC, MT, B, false, HB + 2>(P, model, xs, me, next, Ta, sawinf, v);
@@ -741,7 +759,16 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
         nn = Ta;                                        // one value per thread
     }
     MC3_LSTAMP(9);
-    const int mA = M - 1;                               // scale of level 0's details
+    const int mA = M - 1 - npre;                        // scale of stage A's first level
+    // (large data sets) the pre-levels' sums come first, in level order
+    auto stage_a_sum = [&]() {
+        double w0 = 0.0;
+#pragma unroll
+        for (int l = 0; l < 8; ++l)
+            if (VALUES && l < npre)
+                w0 = mc3_fma(accP[l], s_tab[M - 1 - l], w0);
+        return weigh_levels<NLA>(accA, s_tab, mA, w0);
+    };
     double sumA, u = v[0];
     int mscale = (N >= 4) ? mA - NLA : mA;              // scale of the next level's details
     double accB[NLB > 0 ? NLB : 1];
@@ -802,7 +829,7 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
     double Tsum;
     if constexpr (WPC > 1) {
         block_sync<WPC>();                              // (2) the noise terms are in LDS
-        s_part[tid] = (active && N >= 4) ? weigh_levels<NLA>(accA, s_tab, mA) : 0.0;
+        s_part[tid] = (active && N >= 4) ? stage_a_sum() : 0.0;
         block_sync<WPC>();                              // (3) every thread's stage-A sum
         if (wave != 0)
             return 0.0;                                 // the value is only used by wave 0
@@ -820,7 +847,7 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
         sawinf = s_flag[1];
         sumA = sumA + wave_sum(weigh_levels<NLB>(accB, s_tab, mA - NLA));      // (A + B)
     } else {
-        sumA = wave_sum((active && N >= 4) ? weigh_levels<NLA>(accA, s_tab, mA) : 0.0);
+        sumA = wave_sum((active && N >= 4) ? stage_a_sum() : 0.0);
         sawinf = __any(sawinf) ? 1 : 0;
     }
     {
@@ -836,18 +863,102 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
     MC3_LSTAMP(13);
     if (sawinf)
         return mc3_from_bits(0x7ff0000000000000ull);
-    const double sS2 = s_tab[14];
+    const double sS2 = s_tab[24];
     const double S = (a0 * a0) / sS2 + (a1 * a1) / sS2;
-    return (S + s_tab[15]) + Tsum;
+    return (S + s_tab[25]) + Tsum;
+}
+
+// More than 32 points per thread (ndata > 2^14): "pre-levels" bring the pyramid down to
+// 2^14 values first.  Output i of a pre-level belongs to thread i mod T (strided, coalesced);
+// level 0 forms the residuals on the fly from global memory, the smooth values ping-pong
+// between two global buffers of this workgroup (P.wl_scratch); each thread keeps its sum of
+// squared details per pre-level, weighted with the others at the end.  Then the blocked
+// pyramid above runs on the 2^14 values.  Slower per point than the resident path (every
+// level goes through global memory), but any 2^M up to 2^22 fits.
+template <int MT>
+__device__ double wavelet_large(const DevProblem &P, const double *s_nextp, double *s_part,
+                                int *s_flag, double *s_tab, double *s_halo, const double *xs)
+{
+    constexpr int T = 512;
+    const int tid = threadIdx.x;
+    const int N = P.ndata;
+    Model<MT> model;
+    model.init(P, s_nextp);
+    double *bufA = P.wl_scratch + (size_t)blockIdx.x * (3 * (size_t)N / 4), *bufB = bufA + N / 2;
+    double accP[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int sawinf = 0, npre = 0, nn = N;
+    {
+        const int nh = nn >> 1;
+        double acc = 0.0;
+        for (int i = tid; i < nh; i += T) {
+            const int j0 = 2 * i, j2 = (2 * i + 2) & (N - 1);
+            double m0, m1, m2, m3;
+            if constexpr (MT == MT_LINEAR) {
+                m0 = model.at(j0);
+                m1 = model.at(j0 + 1);
+                m2 = model.at(j2);
+                m3 = model.at(j2 + 1);
+            } else {
+                const double2 xa = *reinterpret_cast<const double2 *>(P.indep + j0);
+                const double2 xb = *reinterpret_cast<const double2 *>(P.indep + j2);
+                m0 = model.at_x(xa.x);
+                m1 = model.at_x(xa.y);
+                m2 = model.at_x(xb.x);
+                m3 = model.at_x(xb.y);
+            }
+            sawinf |= is_pos_inf(m0) | is_pos_inf(m1) | is_pos_inf(m2) | is_pos_inf(m3);
+            const double2 da = *reinterpret_cast<const double2 *>(P.data + j0);
+            const double2 db = *reinterpret_cast<const double2 *>(P.data + j2);
+            double s2, d;
+            d4_pair(da.x - m0, da.y - m1, db.x - m2, db.y - m3, s2, d);
+            bufA[i] = s2;
+            acc = mc3_fma(d, d, acc);
+        }
+        accP[0] = acc;
+        npre = 1;
+        nn = nh;
+    }
+    __syncthreads();                 // (also makes the global stores visible to the workgroup)
+    double *cur = bufA, *dst = bufB;
+#pragma unroll
+    for (int l = 1; l < 8; ++l) {
+        if (nn > WB * T) {
+            const int nh = nn >> 1;
+            double acc = 0.0;
+            for (int i = tid; i < nh; i += T) {
+                const double2 ca = *reinterpret_cast<const double2 *>(cur + 2 * i);
+                const double2 cc = *reinterpret_cast<const double2 *>(cur + ((2 * i + 2) & (nn - 1)));
+                double s2, d;
+                d4_pair(ca.x, ca.y, cc.x, cc.y, s2, d);
+                dst[i] = s2;
+                acc = mc3_fma(d, d, acc);
+            }
+            accP[l] = acc;
+            npre = l + 1;
+            nn = nh;
+            double *t2 = cur;
+            cur = dst;
+            dst = t2;
+            __syncthreads();
+        }
+    }
+    return wavelet_body<8, MT, WB, true>(P, s_nextp, s_part, s_flag, s_tab, s_halo, xs, cur, npre,
+                                         accP, sawinf);
 }
 
 // The geometry is a function of ndata alone (mc3hip.hip choose_wpc): one wave up to 2048
 // points (B = ndata/64, at least 2), four waves at 4096 (B = 16), eight above (B = 16, 32).
-template <int WPC, int MT>
+// LARGE (a kernel instance of its own, so that the resident path keeps its register
+// allocation): ndata > 2^14, eight waves, pre-levels through global memory.
+template <int WPC, int MT, bool LARGE = false>
 __device__ double block_wavelet(const DevProblem &P, const double *s_nextp, double *s_part,
                                 int *s_flag, double *s_tab, double *s_halo, const double *xs)
 {
     constexpr int T = 64 * WPC;
+    if constexpr (LARGE) {
+        static_assert(WPC == 8, "the large-data path has eight waves");
+        return wavelet_large<MT>(P, s_nextp, s_part, s_flag, s_tab, s_halo, xs);
+    }
     const int B = (P.ndata / 2 < T) ? 2 : P.ndata / T;
 #define MC3_WL_BODY(BB)                                                                       \
     return wavelet_body<WPC, MT, BB>(P, s_nextp, s_part, s_flag, s_tab, s_halo, xs)
@@ -890,8 +1001,9 @@ __device__ __forceinline__ double block_chisq(const DevProblem &P, const double 
                                               const DataTile<WPC, MT> &tile)
 {
     double c;
-    if constexpr (WL)
-        c = block_wavelet<WPC, MT>(P, s_nextp, s_part, s_flag, s_tab, s_halo, s_xs);
+    if constexpr (WL)       // (MULTI of a wavelet kernel = its large-data instance)
+        c = block_wavelet<WPC, MT, MULTI && WPC == 8>(P, s_nextp, s_part, s_flag, s_tab, s_halo,
+                                                      s_xs);
     else
         c = block_gauss<WPC, MT, MULTI>(P, s_nextp, s_part, s_flag, tile);
     if (is_pos_inf(c))
@@ -919,16 +1031,17 @@ __device__ __forceinline__ SmemLayout carve(double *smem, const DevProblem &P, i
     L.part = smem;
     L.nextp = smem + nthreads;
     L.flag = reinterpret_cast<int *>(L.nextp + MC3HIP_MAX_PARAMS);
-    L.tab = L.nextp + MC3HIP_MAX_PARAMS + 2;            // 32 doubles: per-scale 1/sigma_W^2
-    L.halo = L.tab + 32;       // wavelet: two halo buffers of 2 doubles per thread, 64 for
+    L.tab = L.nextp + MC3HIP_MAX_PARAMS + 2;            // 48 doubles: per-scale 1/sigma_W^2, ...
+    L.halo = L.tab + 48;       // wavelet: two halo buffers of 2 doubles per thread, 64 for
     L.xs = L.halo + 5 * nthreads + 64;     // stage C, one value per thread; then x as [B][T]
     return L;
 }
 
 static inline size_t smem_bytes(int nthreads, int ndata, int wlike)
 {
-    size_t n = (size_t)nthreads + MC3HIP_MAX_PARAMS + 2 + 32;
-    n += wlike ? 5 * (size_t)nthreads + 64 + (size_t)(ndata > 128 ? ndata : 128) : 4;
+    size_t n = (size_t)nthreads + MC3HIP_MAX_PARAMS + 2 + 48;
+    // (beyond 2^14 points nothing is staged in LDS: the pre-levels read global memory)
+    n += wlike ? 5 * (size_t)nthreads + 64 + (size_t)(ndata > 16384 ? 128 : ndata > 128 ? ndata : 128) : 4;
     return n * sizeof(double);
 }
 
@@ -2267,7 +2380,7 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
 #endif
 }
 
-template <int WPC, int MT, bool WL>
+template <int WPC, int MT, bool WL, bool LARGE = false>
 __global__ __launch_bounds__(64 * WPC) void eval_chisq_kernel(const DevProblem P,
                                                               const double *params,
                                                               double *out)
@@ -2282,8 +2395,8 @@ __global__ __launch_bounds__(64 * WPC) void eval_chisq_kernel(const DevProblem P
     for (int q = threadIdx.x; q < P.nparams; q += 64 * WPC)
         L.nextp[q] = params[(size_t)blockIdx.x * P.nparams + q];
     __syncthreads();
-    const double c = block_chisq<WPC, MT, WL, true>(P, L.nextp, L.part, L.flag, L.tab, L.halo,
-                                                    L.xs, tile);
+    const double c = block_chisq<WPC, MT, WL, !WL || LARGE>(P, L.nextp, L.part, L.flag, L.tab,
+                                                            L.halo, L.xs, tile);
     if (threadIdx.x == 0)
         out[blockIdx.x] = c;
 }

@@ -222,6 +222,8 @@ int dev_upload(mc3hip_ctx *c, const T **dst, const T *src, size_t count)
     return MC3HIP_OK;
 }
 
+constexpr int WL_EVAL_BLOCKS = 256;
+
 // Waves per chain are dispatched as {1, 4, 16}; the wavelet geometries have 1, 4 or 8:
 // the widest one rides on the dispatch slot of the widest Gaussian one.
 template <int WPC>
@@ -231,7 +233,10 @@ template <int WPC, int MT>
 void launch_step_t(mc3hip_ctx *c, int roff)
 {
     constexpr int WW = wavelet_waves<WPC>();
-    if (c->P.wlike)
+    if (c->P.wlike && c->P.wl_scratch)                  // (more than 2^14 points)
+        hipLaunchKernelGGL((step_kernel<8, MT, true, true>), dim3(c->P.nlocal), dim3(512),
+                           c->smem, c->stream, c->P, roff);
+    else if (c->P.wlike)
         hipLaunchKernelGGL((step_kernel<WW, MT, true, false>), dim3(c->P.nlocal),
                            dim3(64 * WW), c->smem, c->stream, c->P, roff);
     else if (c->P.npad > VLANES)
@@ -457,7 +462,9 @@ void persist_instance_t(mc3hip_ctx *c, bool p2p, fast_kernel_fn *out)
 {
     fast_kernel_fn f;
     constexpr int WW = wavelet_waves<WPC>();
-    if (c->P.wlike)
+    if (c->P.wlike && c->P.wl_scratch)
+        f = p2p ? persist_kernel<8, MT, true, true, true> : persist_kernel<8, MT, true, true>;
+    else if (c->P.wlike)
         f = p2p ? persist_kernel<WW, MT, true, false, true> : persist_kernel<WW, MT, true, false>;
     else if (c->P.npad > VLANES)
         f = p2p ? persist_kernel<WPC, MT, false, true, true> : persist_kernel<WPC, MT, false, true>;
@@ -471,7 +478,10 @@ template <int WPC, int MT>
 void launch_eval_t(mc3hip_ctx *c, int n)
 {
     constexpr int WW = wavelet_waves<WPC>();
-    if (c->P.wlike)
+    if (c->P.wlike && c->P.wl_scratch)
+        hipLaunchKernelGGL((eval_chisq_kernel<8, MT, true, true>), dim3(n), dim3(512), c->smem,
+                           c->stream, c->P, (const double *)c->eval_params, c->eval_out);
+    else if (c->P.wlike)
         hipLaunchKernelGGL((eval_chisq_kernel<WW, MT, true>), dim3(n), dim3(64 * WW), c->smem,
                            c->stream, c->P, (const double *)c->eval_params, c->eval_out);
     else
@@ -579,7 +589,24 @@ int decide_persist(mc3hip_ctx *c)
         c->persist_refs = atoi(e) > 0 ? atoi(e) : 0;
     return c->persist_refs;
 }
-void launch_eval(mc3hip_ctx *c, int n) { DISPATCH(launch_eval_t, c, n) }
+void launch_eval(mc3hip_ctx *c, int n)
+{
+    if (c->P.wl_scratch && n > WL_EVAL_BLOCKS) {
+        // large wavelet data sets: every workgroup needs its scratch, so the vectors go in
+        // rounds (the kernel reads its inputs / writes its outputs at blockIdx offsets)
+        double *const p0 = c->eval_params, *const o0 = c->eval_out;
+        for (int at = 0; at < n; at += WL_EVAL_BLOCKS) {
+            c->eval_params = p0 + (size_t)at * c->P.nparams;
+            c->eval_out = o0 + at;
+            const int m = n - at < WL_EVAL_BLOCKS ? n - at : WL_EVAL_BLOCKS;
+            DISPATCH(launch_eval_t, c, m)
+        }
+        c->eval_params = p0;
+        c->eval_out = o0;
+        return;
+    }
+    DISPATCH(launch_eval_t, c, n)
+}
 
 void launch_model(mc3hip_ctx *c)
 {
@@ -737,8 +764,8 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         if (pr->ndata < 2 || (pr->ndata & (pr->ndata - 1)))
             return fail(MC3HIP_ERR_ARG,
                         "wavelet likelihood needs power-of-two ndata (got %d)", pr->ndata);
-        if (pr->ndata > 16384)
-            return fail(MC3HIP_ERR_ARG, "wavelet likelihood supports ndata <= 16384");
+        if (pr->ndata > (1 << 22))
+            return fail(MC3HIP_ERR_ARG, "wavelet likelihood supports ndata <= 2^22");
     }
     if (pr->M0 < 2 || pr->zlen < pr->M0)
         return fail(MC3HIP_ERR_ARG, "bad Z sizes (M0=%lld zlen=%lld)", (long long)pr->M0,
@@ -881,6 +908,12 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         P.wl_x0 = x0;
         P.wl_step = step;
         P.wl_xlast = xl;
+    }
+    if (pr->wlike && pr->ndata > 16384) {
+        // pre-level values of the large-data path: two ping-pong buffers per workgroup; the
+        // chisq-evaluation kernel runs at most WL_EVAL_BLOCKS vectors per launch
+        const size_t blocks = (size_t)(pr->nlocal > WL_EVAL_BLOCKS ? pr->nlocal : WL_EVAL_BLOCKS);
+        TRY(dev_alloc(c, &P.wl_scratch, blocks * (3 * nd / 4)));
     }
     if (pr->wlike) {
         // the data in the blocked layout of the wavelet kernel, [j][t] = point B t + j

@@ -244,6 +244,29 @@ def test_wavelet_chains_bit_exact(eng, ndata):
     gpu.close()
 
 
+@pytest.mark.parametrize('ndata', [32768, 131072])
+def test_wavelet_beyond_2_14_points(eng, ndata):
+    """More than 32 points per thread: strided pre-levels through global memory bring the
+    pyramid down to 2^14 values, then the blocked pyramid runs (src_c/_dwt.c:82-94 takes any
+    length).  chisq against the reference-faithful kernels at 1e-10, chains bit-exact
+    against the oracle, persistent and per-refresh launches."""
+    from oracle import kernels as ok
+    prob = H.wavelet_problem(ndata=ndata, nchains=5, nsamples=5*12, sampler='snooker')
+    orc, gpu = run_pair(eng, prob)
+    assert gpu.plan['waves_per_chain'] == 8 and gpu.plan['persistent'] > 0
+    assert_same(orc, gpu)
+    rs = np.random.RandomState(3)
+    P = prob['params'] + rs.normal(0, 1, (300, 6))*prob['pstep']
+    got = gpu.eval_chisq(P)                        # (more vectors than scratch blocks)
+    np.testing.assert_array_equal(got, orc.eval_chisq(P))
+    want = [ok.dwt_chisq(H.quad(p[:3], prob['indep']), prob['data'], p) for p in P[:20]]
+    np.testing.assert_allclose(got[:20], want, rtol=1e-10)
+    gpu.close()
+    orc2, gpu2 = run_pair(eng, prob, no_persist=True)
+    assert_same(orc2, gpu2)
+    gpu2.close()
+
+
 @pytest.mark.parametrize('sampler', ['demc', 'mrw'])
 @pytest.mark.parametrize('ndata', [32, 512, 4096, 16384])
 def test_wavelet_other_samplers_bit_exact(eng, ndata, sampler):

@@ -22,7 +22,12 @@ from mc3_amd import build as b, _lib  # noqa: E402
 
 lib = os.path.join(ROOT, 'mc3_amd', 'libmc3hip_stamps.so')
 if '--build' in sys.argv or not os.path.exists(lib):
-    subprocess.check_call([b.hipcc()] + b.FLAGS + ['-DMC3HIP_STAMPS', '-o', lib, b.SRC])
+    # The LDS stamps of the wavelet path (MC3_LSTAMP) are off by default: with them in, this
+    # compiler version fails the whole translation unit ("illegal VGPR to SGPR copy" at the
+    # scalar pins of the lean kernels); `--lstamp` tries anyway.  Without them `c4` reports
+    # only the three coarse phases; DESIGN.md's C4 breakdown comes from ablation builds.
+    extra = [] if '--lstamp' in sys.argv else ['-DMC3HIP_NO_LSTAMP']
+    subprocess.check_call([b.hipcc()] + b.FLAGS + ['-DMC3HIP_STAMPS'] + extra + ['-o', lib, b.SRC])
     if '--build' in sys.argv:
         sys.exit(0)
 _lib.LIB_PATH = lib
