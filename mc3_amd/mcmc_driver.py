@@ -23,6 +23,38 @@ class _Value:
         self.value = value
 
 
+class _Checkpointer:
+    """The periodic ``np.savez(savefile, **output)`` of the hub (mcmc_driver.py:321-324)
+    on a worker thread, one write in flight: the chains run on while the disk is busy.
+    Safe without copies: the big arrays of ``output`` are views of host rows that were
+    fetched once and are never rewritten (later reports only append behind them)."""
+
+    def __init__(self):
+        self.thread = None
+        self.error = None
+
+    def save(self, path, output):
+        import threading
+        self.wait()
+        frozen = dict(output)
+
+        def work():
+            try:
+                np.savez(path, **frozen)
+            except Exception as err:           # noqa: BLE001 -- re-raised by wait()
+                self.error = err
+        self.thread = threading.Thread(target=work, daemon=True)
+        self.thread.start()
+
+    def wait(self):
+        if self.thread is not None:
+            self.thread.join()
+            self.thread = None
+        if self.error is not None:
+            err, self.error = self.error, None
+            raise err
+
+
 class ChainView:
     """What update_output / calc_bestfit_statistics read from a reference Chain
     (mc3/stats/stats.py:813-871), backed by arrays copied from the device."""
@@ -286,6 +318,7 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
         return nrows
 
     host = {'rows': 0}
+    checkpoint = _Checkpointer()
 
     def pull_rows(nrows):
         """Rows [0, nrows) on the host, fetching only what was not fetched before (one
@@ -347,7 +380,7 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
             pull_rows(nrows)
         if savefile is not None and comm.rank == 0:
             ms.update_output(output, view, hsize, stats_engine())
-            np.savez(savefile, **output)
+            checkpoint.save(savefile, output)
         if run_gr:
             if device_gr:
                 mean, var = engine.chain_moments(zburn)
@@ -366,6 +399,7 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
 
     nrows = snapshot(final=True)
     pull_rows(nrows)
+    checkpoint.wait()
     summary = ms.update_output(output, view, hsize, stats_engine())
     if _extras is not None:
         _extras['summary'] = summary
