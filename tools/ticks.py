@@ -15,10 +15,23 @@ _lib.LIB_PATH = (os.environ.get('MC3HIP_TICKS_LIB')
 from mc3_amd import engine  # noqa: E402
 import bench  # noqa: E402
 
-thin = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-prob = bench.c2_problem(256, 20000, thin)
-g = engine.DeviceChains(**prob)
-Z0, lp0 = bench.initial_population(prob, g.eval_chisq)
+# python tools/ticks.py [thinning]          C2 (lean kernels)
+# python tools/ticks.py c4                  C4's data with sampler='demc' (the general
+#                                           persistent kernel keeps tick sums for demc only)
+if len(sys.argv) > 1 and sys.argv[1] == 'c4':
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import helpers as H
+    import tools_pop
+    thin = 1
+    prob = H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*20000, sampler='demc')
+    g = engine.DeviceChains(**prob)
+    Z0, lp0 = tools_pop.population(g)
+else:
+    thin = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    prob = bench.c2_problem(256, 20000, thin)
+    g = engine.DeviceChains(**prob)
+    Z0, lp0 = bench.initial_population(prob, g.eval_chisq)
 g.set_population(Z0, lp0)
 g.run(2000)
 out = (ctypes.c_uint64*16)()
