@@ -112,7 +112,9 @@ typedef struct mc3hip_plan {
                                halving tree over all of them (strides 512..1); 1 = 64 at a
                                time (strides 32..1), then the 16 group totals (8..1): the
                                matrix-core tile kernel                                          */
-    int32_t _reserved;
+    int32_t resident;       /* 1 = tiled plan in ONE persistent launch: every workgroup keeps
+                               its tile of the design matrix in registers, proposals and
+                               per-tile sums are handed over inside the launch              */
 } mc3hip_plan;
 
 /* Replaces Chain.__init__ + the shared-memory allocation of mcmc()

@@ -75,6 +75,11 @@ struct DevProblem {
     double *sc_scal;              // [nlocal][2]       Metropolis draw u, Hastings factor
     int32_t *sc_flag;             // [nlocal]          bit0 out of bounds, bit1 snooker jump
     double *sc_part;              // [nlocal][ntiles]  per-tile data sums
+    // resident tiled plan (resident_tile_kernel): hand-off areas inside ONE launch, every
+    // double its own "ready" flag (all-ones = not there yet, as for Z rows)
+    double *rs_prop;              // [2][nlocal][RS_ROW] proposed coefficients, by iteration parity
+    double *rs_part;              // [nlocal][rs_ntp]    per-tile data sums of the running iteration
+    int32_t rs_ntp, _pad_rs;      // ntiles rounded up to whole 128-byte lines
     // wavelet likelihood, abscissae on np.linspace's grid (x_i = fl(fl(i*step) + x0), last
     // point = wl_xlast; checked bit for bit at creation): they are recomputed instead of
     // stored, which frees the LDS for the data values
@@ -88,7 +93,8 @@ struct DevProblem {
     double *xring;
 };
 
-constexpr int PH_FUSED = 0, PH_PROPOSE = 1, PH_FINISH = 2;
+constexpr int PH_FUSED = 0, PH_PROPOSE = 1, PH_FINISH = 2, PH_RESIDENT = 3;
+constexpr int RS_ROW = 16;          // doubles per published proposal row: one 128-byte line
 constexpr int SC_STRIDE = MC3HIP_MAX_PARAMS + 16;   // doubles per sc_nextp row (zero padded)
 
 // In-kernel phase stamps for the diagnostic build (never compiled into the product
@@ -1573,6 +1579,343 @@ __device__ __forceinline__ void demc_partners(uint64_t q0, int n, int c, int &r1
         r2 = (r1 + 1 == n) ? 0 : r1 + 1;                               // (r1+1) % n
 }
 
+// ---- resident tiled plan --------------------------------------------------------------
+// The tiled plan as ONE launch (design-matrix models through the matrix cores, one GPU).  The
+// grid is the tile kernel's -- tiles x columns of chains, one workgroup per CU -- but every
+// workgroup keeps its tile (design values, data, weights: 96 + 32 registers per lane at twelve
+// operand rows) for the whole launch instead of reloading 200 KB of it per iteration, and the
+// three phases of an iteration hand over inside the launch instead of at kernel boundaries:
+//   * a wave that OWNS a chain (wave v of workgroup w owns chain w + v * workgroups) runs the
+//     ordinary run_chain for it -- proposal, Metropolis, Z append -- and publishes the proposed
+//     coefficient row (rs_prop, one 128-byte line, by iteration parity);
+//   * all eight waves of every workgroup then compute the data sums of their tile for the
+//     chains of their column, 16 chains at a time, as soon as those rows are there, and
+//     publish one sum per (chain, tile) (rs_part);
+//   * the owner adds the sums of its chain in tile order, hands the slots and the consumed row
+//     back (all-ones), and goes on to the next iteration.
+// Every handed-over double is its own flag (all-ones = not there yet), exactly as for Z rows;
+// no grid barrier, no fence.  Why a row may be reused: a slot is handed back only after all
+// the sums that were computed from it have arrived, and a workgroup asks for the rows of
+// iteration i + 2 only after it has used those of i + 1, which the owner published after
+// handing back those of i.  The data column rides in the contraction as operand row K with
+// coefficient -1 (D = model - data, the same single rounding as the subtraction it replaces).
+// Same arithmetic and the same summation order as tile_chisq_mfma_kernel: the oracle does not
+// know which of the two ran.
+template <int KB>
+struct ResidentTile {
+    // operand rows of the tile: blocks of four rows in registers, except -- with three of
+    // them -- the last, which lives in LDS (64 KB; one read per product): 96 registers of
+    // tile plus the products in flight plus the chain state of an owner wave do not fit 256
+    static constexpr int KR = (KB == 3) ? 2 : KB;
+    double bop[8][2][KR];
+    const double *s_b;      // LDS [16][512]: this thread's operands of row block KR
+    double *s_w;            // LDS [2][16][16]: group totals of the running block of chains
+    const double *s_ww;     // LDS [2048]: the weights of the tile's points (this wave's: + 128 wv)
+    int *s_stop;            // LDS: a wave of this workgroup has given up
+    int t, c0, c1, wv, lane;
+    int par;                // parity of the iteration whose proposals are used next
+    bool failed;            // a wait of this wave timed out: said at the next agreement point
+    // owner waves: the chain, its LDS area ([0..63]: the Gaussian priors as index, centre,
+    // lower and upper width, 16 each), and the first 64 tile sums of the chain, asked for
+    // while the last block of chains is still being computed
+    int own;
+    double *s_own;
+    double *pre_addr;
+    double pre_val;
+
+    __device__ __forceinline__ void load(const DevProblem &P, int tile, int col, int chain_block,
+                                         double *lds_w, int *lds_stop, double *lds_ww,
+                                         double *lds_b)
+    {
+        s_b = lds_b + threadIdx.x;
+        s_w = lds_w;
+        s_stop = lds_stop;
+        t = tile;
+        c0 = col * chain_block;
+        c1 = (c0 + chain_block < P.nlocal) ? c0 + chain_block : P.nlocal;
+        lane = threadIdx.x & 63;
+        wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        par = 0;
+        failed = false;
+        own = -1;
+        s_own = nullptr;
+        pre_addr = nullptr;
+        pre_val = 0.0;
+        const int j = lane & 15, g = lane >> 4, K = P.nmodel;
+#pragma unroll
+        for (int vb = 0; vb < 8; ++vb) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const size_t i = (size_t)t * 2048 + 1024 * h + 128 * wv + 16 * vb + j;
+                // (the weights are the same for the four 16-lane rows of a wave: they live in
+                // LDS, 16 KB, and leave 32 registers to the chain state of the owner waves)
+                if (g == 0)
+                    lds_ww[1024 * h + 128 * wv + 16 * vb + j] = P.w[i];
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    const int k = 4 * kb + g;
+                    const double *src = (k < K) ? P.indep + (size_t)k * P.npad : P.data;
+                    const double v = (k <= K) ? src[i] : 0.0;
+                    if (kb < KR)
+                        bop[vb][h][kb] = v;
+                    else
+                        lds_b[(2 * vb + h) * 512 + threadIdx.x] = v;
+                }
+            }
+        }
+        s_ww = lds_ww + 128 * wv + j;
+    }
+
+    // this wave owns chain lc; `area` is its run_chain LDS area (whose first 64 doubles
+    // run_chain does not use here)
+    __device__ __forceinline__ void set_owner(const DevProblem &P, int lc, double *area)
+    {
+        own = lc;
+        s_own = area;
+        const int n0 = P.ntiles < 64 ? P.ntiles : 64;
+        pre_addr = P.rs_part + (size_t)lc * P.rs_ntp + (lane < n0 ? lane : 0);
+        if (P.ngprior <= 16 && lane < P.ngprior) {
+            const int jp = P.igprior[lane];
+            area[lane] = (double)jp;
+            area[16 + lane] = P.prior[jp];
+            area[32 + lane] = P.priorlow[jp];
+            area[48 + lane] = P.priorup[jp];
+        }
+    }
+
+    // every wave of the workgroup, once per iteration; false (for all of them) = give up
+    __device__ __forceinline__ bool tile_phase(const DevProblem &P, bool alive_in)
+    {
+        if (!alive_in || failed)
+            *s_stop = 1;
+        block_sync<8>();
+        if (*s_stop != 0)
+            return false;
+        long long *ctl = const_cast<long long *>(P.ctl);
+        const double *prop = P.rs_prop + (size_t)par * P.nlocal * RS_ROW;
+        const int j = lane & 15, g = lane >> 4;
+        const double *addr[KB];
+        double aop[KB];
+        auto request = [&](int cb) {
+            const int lc = (cb + j < c1) ? cb + j : c1 - 1;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                addr[kb] = prop + (size_t)lc * RS_ROW + 4 * kb + g;
+                aop[kb] = load_published(addr[kb]);
+            }
+        };
+        // (the weights and the LDS part of the tile are read where they are used: an offset
+        // the compiler cannot see through keeps it from hoisting the reads out of the loops
+        // and parking the values in registers again)
+        int wo = 0;
+        // Step s = 0..15 of a block of chains: half h = s & 1 of block vb = s >> 1 of 16 lanes.
+        // The product of a step, with the coefficients in a[]; bl = its operand from LDS
+        auto product = [&](int st, const double(&a)[KB], double bl) {
+            const int vb = st >> 1, h = st & 1;
+            mc3_v4d m = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                m = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                    a[kb], (kb < KR) ? bop[vb][h][kb < KR ? kb : 0] : bl, m, 0, 0, 0);
+            return m;
+        };
+        auto lds_operand = [&](int st) { return (KR < KB) ? s_b[wo + st * 512] : 0.0; };
+        auto lds_weight = [&](int st) { return s_ww[wo + 1024 * (st & 1) + 16 * (st >> 1)]; };
+        // sum over the 64 lanes of a group (lane 16 q + j): strides 32 and 16 were in-thread,
+        // 8..1 run inside the 16-lane row; lane j = 0 has the defined order
+        auto group_total = [&](const double(&acc)[2][4], int grp, int buf) {
+            double sr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double sg = acc[0][r] + acc[1][r];         // stride 16
+                sg = add_ror<8>(sg);
+                sg = add_ror<4>(sg);
+                sg = add_ror<2>(sg);
+                sr[r] = add_ror<1>(sg);
+            }
+            if (j == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    s_w[(buf * 16 + g + 4 * r) * 16 + 2 * wv + grp] = sr[r];
+            }
+        };
+        // Software pipeline, written out.  FP64 matrix and vector instructions share one pipe
+        // on this chip (tools/probes/mfma_f64_issue_probe.hip: their times add up), so what
+        // can be hidden is latency, not work: the product of step s + 1 is issued before the
+        // residuals of step s are squared, one matrix instruction then a few vector
+        // instructions in turn; the LDS operands of step s + 2 are read during step s; the
+        // cross-lane sum of the first group of 64 lanes runs between the matrix instructions
+        // of the second.  The scheduling barriers keep that order, and with it two products'
+        // worth of registers alive instead of sixteen.  (Carrying the pipeline across the
+        // barrier at the end of a block of chains costs 25 more registers.)
+        request(c0);
+        int buf = 0;
+        for (int cb = c0; cb < c1; cb += 16, buf ^= 1) {
+            if (!wait_rows<KB>(addr, aop, ctl))
+                failed = true;
+            double a[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                a[kb] = aop[kb];
+            if (cb + 16 < c1)
+                request(cb + 16);              // the next block's rows travel behind this one
+            else if (own >= 0)
+                // an owner's tile sums: unless its chain is in the last block of its column
+                // they are there by now, and the round trip hides behind this block
+                pre_val = load_published(pre_addr);
+            asm volatile("; operands of this block" : "+v"(wo));
+            double bl_next = lds_operand(1), w_cur = lds_weight(0), w_next = w_cur;
+            mc3_v4d mc = product(0, a, lds_operand(0)), mn = mc;
+            double accA[2][4], accB[2][4], tmp[4];     // [block of 16 lanes mod 2][chain g + 4 r]
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                const int q = (st >> 1) & 3, h = st & 1;
+                double(&acc)[2][4] = (st < 8) ? accA : accB;
+                __builtin_amdgcn_sched_barrier(0);
+                const double bl = bl_next;
+                if (st < 14)
+                    bl_next = lds_operand(st + 2);
+                if (st < 15) {
+                    w_next = lds_weight(st + 1);
+                    mn = product(st + 1, a, bl);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double res = mc[r] * w_cur;
+                    // strides 32 (blocks 0 + 2, 1 + 3 of the group) as soon as both are there
+                    if (q < 2) {
+                        acc[q][r] = mc3_fma(res, res, h ? acc[q][r] : 0.0);
+                    } else {
+                        tmp[r] = mc3_fma(res, res, h ? tmp[r] : 0.0);
+                        if (h == 1)
+                            acc[q - 2][r] = acc[q - 2][r] + tmp[r];
+                    }
+                }
+                if (st == 8)
+                    group_total(accA, 0, buf);
+                // (two matrix instructions first: the product these squares read was the last
+                // thing issued in the previous step and needs a pipe pass to land)
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);             // MFMA
+#pragma unroll
+                for (int i = 2; i <= KB; ++i) {
+                    if (st == 8)
+                        __builtin_amdgcn_sched_group_barrier(0x002, 36, 0);    // VALU
+                    else
+                        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                    if (i < KB)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mc = mn;
+                w_cur = w_next;
+            }
+            group_total(accB, 1, buf);
+            block_sync<8>();
+            if (lane < 32) {            // wave wv: the 16 group totals of chains cb + 2 wv, + 1
+                const int ch = 2 * wv + (lane >> 4);
+                double s = s_w[(buf * 16 + ch) * 16 + (lane & 15)];
+                s = add_ror<8>(s);
+                s = add_ror<4>(s);
+                s = add_ror<2>(s);
+                s = add_ror<1>(s);
+                if (mc3_bits(s) == ROW_PENDING)        // (a NaN that looks like "not there yet")
+                    s = mc3_from_bits(0x7ff8000000000000ull);
+                if ((lane & 15) == 0 && cb + ch < c1)
+                    __hip_atomic_store(&P.rs_part[(size_t)(cb + ch) * P.rs_ntp + t], s,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        par ^= 1;
+        return true;
+    }
+
+    // owner, before the tile phase: the proposed coefficients of chain lc for everybody
+    __device__ __forceinline__ void publish(const DevProblem &P, int lc, const double *s_nextp)
+    {
+        // (the slots handed back during the previous iteration have landed before the row
+        // that lets anybody write them again leaves)
+        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+        if (lane < RS_ROW) {
+            const int K = P.nmodel;
+            double v = (lane < K) ? s_nextp[lane] : ((lane == K) ? -1.0 : 0.0);
+            if (mc3_bits(v) == ROW_PENDING)
+                v = mc3_from_bits(0x7ff8000000000000ull);
+            __hip_atomic_store(&P.rs_prop[((size_t)par * P.nlocal + lc) * RS_ROW + lane], v,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+    // owner, after the tile phase: the data sum of chain lc, tiles added in order; hands the
+    // slots and the row this iteration used back
+    __device__ __forceinline__ double collect(const DevProblem &P, int lc)
+    {
+        long long *ctl = const_cast<long long *>(P.ctl);
+        double *row = P.rs_part + (size_t)lc * P.rs_ntp;
+        double total = 0.0;
+        for (int t0 = 0; t0 < P.ntiles; t0 += 64) {
+            const int n = (P.ntiles - t0 < 64) ? P.ntiles - t0 : 64;
+            double *mine = row + t0 + (lane < n ? lane : 0);
+            const double *const addr[1] = {mine};
+            // (the first 64 were asked for during the tile phase)
+            double val[1] = {t0 == 0 ? pre_val : load_published(mine)};
+            if (!wait_rows<1>(addr, val, ctl))
+                failed = true;
+            // (in order, eight broadcasts at a time ahead of their dependent additions)
+            int k = 0;
+            for (; k + 8 <= n; k += 8) {
+                double v8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v8[u] = read_lane(val[0], k + u);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    total = total + v8[u];
+            }
+            for (; k < n; ++k)
+                total = total + read_lane(val[0], k);
+            if (lane < n)
+                __hip_atomic_store(mine, mc3_from_bits(ROW_PENDING), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane < RS_ROW)
+            __hip_atomic_store(&P.rs_prop[((size_t)(par ^ 1) * P.nlocal + lc) * RS_ROW + lane],
+                               mc3_from_bits(ROW_PENDING), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        return total;
+    }
+
+    // the chisq of the proposal from that sum (finish_chisq of the three-launch plan)
+    template <int MT>
+    __device__ __forceinline__ double finish(const DevProblem &P, double total,
+                                             const double *s_nextp) const
+    {
+        const bool finite = (mc3_bits(total) & 0x7ff0000000000000ull) != 0x7ff0000000000000ull;
+        if (!finite) {
+            Model<MT> model;
+            model.init(P, s_nextp);
+            int saw = 0;
+            for (int i = lane; i < P.ndata; i += 64)
+                saw |= is_pos_inf(model.at(i));
+            if (__any(saw))
+                return mc3_from_bits(0x7ff0000000000000ull);
+        }
+        if (is_pos_inf(total))
+            return total;
+        if (P.ngprior > 16)
+            return total + prior_term(P, s_nextp);
+        double pr = 0.0;                         // prior_term from the LDS copy of its constants
+        for (int gp = 0; gp < P.ngprior; ++gp) {
+            const int jp = (int)s_own[gp];
+            const double d = s_nextp[jp] - s_own[16 + gp];
+            const double sd = (d > 0.0) ? d / s_own[48 + gp] : d / s_own[32 + gp];
+            pr = pr + sd * sd;
+        }
+        return total + pr;
+    }
+};
+
+struct NoHook {};
+
 // One chain, refreshes [R0, R0 + nref).  PERSIST = false: one refresh per launch,
 // other chains are seen through rows a previous launch wrote (plain loads).
 // PERSIST = true: many refreshes per launch; the tile, the chain state and all
@@ -1596,22 +1939,29 @@ __device__ __forceinline__ void demc_partners(uint64_t q0, int n, int c, int &r1
 // kernel boundary separates iterations.
 // TH = 1: exactly one iteration per refresh (thinning = 1, the default), known at
 // compile time so that the inner loop and its control flow disappear.
+// PH_RESIDENT (resident tiled plan, see ResidentTile): this WAVE owns chain `own_chain` of a
+// workgroup whose waves all take part in the tile phase of every iteration; the data sums
+// come back through `hook`; the wave leaves the loop only when the whole workgroup does.
 template <int WPC, int MT, bool WL, bool MULTI, bool PERSIST, int SMP = -1, bool FAST = false,
-          int PHASE = PH_FUSED, bool P2P = false, int TH = 0, bool FX = false>
+          int PHASE = PH_FUSED, bool P2P = false, int TH = 0, bool FX = false, class H = NoHook>
 __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R0,
-                                          const int nref, const int jb = 0, int je = -1)
+                                          const int nref, const int jb = 0, int je = -1,
+                                          H *hook = nullptr, const int own_chain = 0,
+                                          double *own_smem = nullptr)
 {
     if (je < 0)
         je = P.thinning;
+    static_assert(PHASE != PH_RESIDENT || (WPC == 1 && PERSIST && !FAST && !WL && !P2P),
+                  "the resident tiled plan runs the general one-wave persistent chain");
     static_assert(!FAST || (WPC == 1 && !WL && SMP >= 0 && MT >= 1 && MT <= 8),
                   "FAST needs one wave, Gaussian chisq, a compile-time sampler and degree");
     const int sampler = (SMP >= 0) ? SMP : P.sampler;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const SmemLayout L = carve(smem, P, 64 * WPC);
+    const SmemLayout L = carve(PHASE == PH_RESIDENT ? own_smem : smem, P, 64 * WPC);
     MC3_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const bool wave0 = (WPC == 1) ? true : (tid < 64);
-    const int lc = blockIdx.x;                 // local chain
+    const int lc = (PHASE == PH_RESIDENT) ? own_chain : blockIdx.x;   // local chain
     const int c = P.chain0 + lc;               // global chain id
     const int nf = P.nfree;
     const int zs = P.zs;                       // row stride of Z / snap0 (padded lines)
@@ -1661,7 +2011,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
         coefficient_map<NKF>(P, kf, fx);
     (void)kf; (void)fx;
 
-    if constexpr (PERSIST) {
+    if constexpr (PERSIST && PHASE != PH_RESIDENT) {     // (resident: the kernel has looked)
         // a launch queued behind one that gave up must not run: its inputs are missing
         if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
                 &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
@@ -1696,7 +2046,10 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
         for (int q = 0; q < 3; ++q)
             sv[q] = load_published<P2P>(sa[q]);
     };
-    constexpr bool SNOOKER_AHEAD = PERSIST && (SMP < 0 || SMP == MC3HIP_SNOOKER);
+    // (not in the resident tiled plan: rows and batch would sit in registers across the tile
+    // phase, which needs them all; there the rows are asked for where they are used)
+    constexpr bool SNOOKER_AHEAD =
+        PERSIST && PHASE != PH_RESIDENT && (SMP < 0 || SMP == MC3HIP_SNOOKER);
     DrawBatch batch;
     batch.w0 = batch.w1 = batch.w2 = batch.w3 = 0u;
     batch.base = -(long long)DRAW_BATCH - 1;      // empty
@@ -1707,15 +2060,22 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     // diagnostic build only: per-phase tick sums kept in registers, stored once at exit
     unsigned long long tk_prev3 = 0, tk_prevend = 0;
     unsigned long long ta8 = 0, ta9 = 0, ta10 = 0, ta11 = 0, ta12 = 0, ta13 = 0, ta14 = 0, ta15 = 0;
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0;
+    (void)tr0; (void)tr1; (void)tr2; (void)tr3;
     (void)ta14; (void)ta15;
     (void)tk_prev3; (void)tk_prevend;
     (void)ta8; (void)ta9; (void)ta10; (void)ta11; (void)ta12; (void)ta13;
+    bool give_up = false;                       // resident plan: test hook fired
+    (void)give_up;
     for (long long R = R0; R < R0 + nref && alive; ++R) {
     if constexpr (PERSIST) {
         if (P.test_abort >= 0 && R == P.test_abort && lc == 0) {     // test hook
             __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);             // (all lanes, same word)
-            return;
+            if constexpr (PHASE == PH_RESIDENT)
+                give_up = true;                 // (leaves with its workgroup, below)
+            else
+                return;
         }
     }
     const double *snap = (R == 0) ? P.snap0
@@ -1728,7 +2088,8 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
             MC3_LSTAMP(5);
         else
             MC3_STAMP(5);
-        unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+        unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tkP = 0, tkT = 0, tkC = 0;
+        (void)tkP; (void)tkT; (void)tkC;
         MC3_TICK(tk0);
 #ifdef MC3HIP_STAMPS
         if (tk_prevend != 0) {
@@ -1767,9 +2128,19 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 double z1 = 0.0, z2 = 0.0;
                 if constexpr (PERSIST) {
                     // requested during the previous iteration (request_snooker)
+                    if constexpr (!SNOOKER_AHEAD) {
+                        Draws now;
+                        now.d0 = d0;
+                        now.d1 = d1;
+                        now.d2 = d2;
+                        request_snooker(now, zsize);
+                    }
                     const double *const addr[3] = {sa[0], sa[1], sa[2]};
                     double val[3] = {sv[0], sv[1], sv[2]};
-                    nxt = get_draws(batch, P, (long long)iter + 1, c);
+                    if constexpr (SNOOKER_AHEAD)
+                        nxt = get_draws(batch, P, (long long)iter + 1, c);
+                    else
+                        nxt = make_draws(P, iter + 1, c, sampler);
                     alive = wait_rows<3, P2P>(addr, val, ctl_rw);
                     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see lean_demc_kernel
                     z1 = val[0];
@@ -1777,7 +2148,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                     zk = val[2];
                     // the next iteration's rows: its history also holds this refresh's rows
                     // once this iteration is the last of the refresh
-                    if (alive)
+                    if (SNOOKER_AHEAD && alive)
                         request_snooker(nxt, (TH == 1 || j + 1 == jlast) ? zsize + P.nchains
                                                                          : zsize);
                 } else {
@@ -1863,6 +2234,11 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 L.flag[0] = anyout ? 1 : 0;
                 L.flag[2] = alive ? 1 : 0;
             }
+            if constexpr (PHASE == PH_RESIDENT) {
+                __builtin_amdgcn_wave_barrier();
+                hook->publish(P, lc, L.nextp);
+                MC3_TICK(tkP);
+            }
             }
             if constexpr (PHASE == PH_PROPOSE) {
                 // hand the proposal to the tile and finish kernels
@@ -1913,12 +2289,25 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
             else
                 MC3_STAMP(2);
             anyout = L.flag[0] != 0;
-            if constexpr (PERSIST) {
+            if constexpr (PHASE == PH_RESIDENT) {
+                // the tile phase of this iteration, with the whole workgroup; false for all of
+                // its waves once one of them has given up
+                alive = hook->tile_phase(P, (L.flag[2] != 0) && !give_up);
+                MC3_TICK(tkT);
+                if (!alive)
+                    break;
+            } else if constexpr (PERSIST) {
                 alive = L.flag[2] != 0;
                 if (!alive)
                     break;                     // a wait timed out: stop this chain
             }
         }
+        double tile_total = 0.0;
+        if constexpr (PHASE == PH_RESIDENT)
+            tile_total = hook->collect(P, lc);  // (also of a proposal that is out of bounds:
+                                                // the sums must be seen before the row is reused)
+        (void)tile_total;
+        MC3_TICK(tkC);
         double nextchisq = mc3_from_bits(0x7ff8000000000000ull);
         if (!anyout) {
             flags |= 1;
@@ -1937,6 +2326,8 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                     nextchisq = nextchisq + prior_from_lanes<NKF>(P, npk, kf, fx);
             } else if constexpr (PHASE == PH_FINISH) {
                 nextchisq = finish_chisq<MT>(P, lc);
+            } else if constexpr (PHASE == PH_RESIDENT) {
+                nextchisq = hook->template finish<MT>(P, tile_total, L.nextp);
             } else {
                 nextchisq = block_chisq<WPC, MT, WL, MULTI>(P, L.nextp, L.part, L.flag, L.tab,
                                                             L.halo, L.xs, tile);   // chain.py:249
@@ -1971,7 +2362,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
         } else if (PHASE != PH_FINISH && outk) {
             atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
         }
-        if (!FAST && P.trace_iters > 0 && tid == 0) {
+        if (!FAST && P.trace_iters > 0 && wave0 && lane == 0) {
             const long long trow = (R - P.ctl[1]) * P.thinning + j;
             if (trow >= 0 && trow < P.trace_iters) {
                 P.trace_chisq[trow * P.nlocal + lc] = nextchisq;
@@ -1999,6 +2390,12 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
             ta9 += tk2 - tk1;      // -> chisq reduced
             ta10 += tk3 - tk2;     // -> end of iteration (accept; publish is after)
             ta12 += 1;
+            if constexpr (PHASE == PH_RESIDENT) {
+                tr0 += tkP - tk1;  // rows arrived -> proposal published
+                tr1 += tkT - tkP;  // -> tile phase done (waits for the column's other owners)
+                tr2 += tkC - tkT;  // -> all tiles' sums collected
+                tr3 += tk2 - tkC;  // -> chisq known
+            }
         }
         tk_prev3 = tk3;
 #endif
@@ -2044,10 +2441,13 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     }
     MC3_STAMP(4);
 #ifdef MC3HIP_STAMPS
-    if (PERSIST && threadIdx.x == 0 && blockIdx.x == 0) {
+    if (PERSIST && threadIdx.x == 0 && blockIdx.x == 0 && (PHASE != PH_RESIDENT || lc == 0)) {
         P.stamps[8] += ta8; P.stamps[9] += ta9; P.stamps[10] += ta10;
         P.stamps[11] += ta11; P.stamps[12] += ta12; P.stamps[13] += ta13;
         P.stamps[14] += ta14; P.stamps[15] += ta15;
+        if constexpr (PHASE == PH_RESIDENT) {
+            P.stamps[16] += tr0; P.stamps[17] += tr1; P.stamps[18] += tr2; P.stamps[19] += tr3;
+        }
     }
 #endif
 }
@@ -2122,6 +2522,44 @@ __global__ __launch_bounds__(64 * WPC) void persist_kernel(const DevProblem P, c
     run_chain<WPC, MT, WL, MULTI, true, -1, false, PH_FUSED, P2P>(P, P.ctl[0], nref);
 }
 
+
+// The tiled plan in one launch (ResidentTile above): grid = tiles x columns of chains, eight
+// waves; wave v of workgroup w also owns chain w + v * workgroups.  LDS: group totals
+// [2][16][16], the give-up word, a run_chain area per wave, the tile's 2048 weights, and
+// (three blocks of operand rows) the last block, [16][512].
+template <int KB>
+__global__ __launch_bounds__(512) void resident_tile_kernel(const DevProblem P, const int nref,
+                                                            const int chain_block)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int OWN = 64 + MC3HIP_MAX_PARAMS + 2 + 48 + 4;     // carve() of a one-wave chain
+    int *s_stop = reinterpret_cast<int *>(smem + 512);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    ResidentTile<KB> T;
+    T.load(P, blockIdx.x, blockIdx.y, chain_block, smem, s_stop, smem + 514 + 8 * OWN,
+           smem + 514 + 8 * OWN + 2048);
+    // a launch queued behind one that gave up must not run: its inputs are missing
+    if (threadIdx.x == 0)
+        *s_stop = (__hip_atomic_load(&P.ctl[CTL_ABORT], __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0;
+    block_sync<8>();
+    if (*s_stop != 0)
+        return;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    const int own_chain = wg + (int)(gridDim.x * gridDim.y) * wv;
+    if (own_chain < P.nlocal) {
+        T.set_owner(P, own_chain, smem + 514 + wv * OWN);
+        run_chain<1, MT_LINEAR, false, false, true, -1, false, PH_RESIDENT, false, 0, false,
+                  ResidentTile<KB>>(P, P.ctl[0], nref, 0, -1, &T, own_chain,
+                                    smem + 514 + wv * OWN);
+    } else {
+        // no chain of its own: the tile phase of every iteration, in step with the owners
+        for (int R = 0; R < nref; ++R)
+            for (int j = 0; j < P.thinning; ++j)
+                if (!T.tile_phase(P, true))
+                    return;
+    }
+}
 
 // tiled plan: proposal and Metropolis/accept halves of one iteration (one wave per chain)
 template <int MT>

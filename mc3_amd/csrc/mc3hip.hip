@@ -156,6 +156,8 @@ struct mc3hip_ctx {
     int recoveries = 0;
     int tile_kmax = 0;              // tiled plan: coefficient capacity of the tile kernel
     int tile_chain_block = 0;       // chains per workgroup column of the tile kernel
+    bool resident = false;          // tiled plan as one persistent launch (resident_tile_kernel)
+    int resident_chain_block = 0;   // its column height
     bool ckpt_settled = false;      // peer-to-peer: the launches since the checkpoint completed
                                     // HERE; confirmed by the caller's next mc3hip_run
     double *moments = nullptr;      // scratch of mc3hip_chain_moments (2 x nchains x nfree)
@@ -342,6 +344,41 @@ void launch_refresh_tiled(mc3hip_ctx *c, int roff)
         launch_tile(c);
         DISPATCH_MT1(launch_finish_t, c, roff, j)
     }
+}
+
+// ---- resident tiled plan (chain_kernels.h ResidentTile) --------------------------------
+// LDS: group totals [2][16][16], the give-up word, one run_chain area per wave, 2048 weights,
+// the last block of operand rows [16][512]
+constexpr size_t RESIDENT_OWN = 64 + MC3HIP_MAX_PARAMS + 2 + 48 + 4;
+constexpr size_t RESIDENT_LDS_BYTES = (514 + 8 * RESIDENT_OWN + 2048 + 16 * 512) * sizeof(double);
+
+const void *resident_kernel(const mc3hip_ctx *c)
+{
+    switch ((c->P.nmodel + 4) / 4) {          // operand rows: coefficients + the data column
+    case 2: return reinterpret_cast<const void *>(&resident_tile_kernel<2>);
+    default: return reinterpret_cast<const void *>(&resident_tile_kernel<3>);
+    }
+}
+
+// the problem has the shape the resident kernel is written for (whether its grid fits the
+// device is decide_persist's question)
+bool resident_shape(const mc3hip_ctx *c)
+{
+    return tile_uses_mfma(c) && c->P.nmodel >= 5 && c->P.nmodel <= 11 && c->P.rs_prop &&
+           c->comm == nullptr && c->p2p_ranks <= 1 && !(c->flags & MC3HIP_FLAG_P2P) &&
+           !getenv("MC3HIP_NO_RESIDENT");
+}
+
+void launch_resident(mc3hip_ctx *c, int nref)
+{
+    const int cb = c->resident_chain_block;
+    const int ncol = (c->P.nlocal + cb - 1) / cb;
+    if ((c->P.nmodel + 4) / 4 == 2)
+        hipLaunchKernelGGL((resident_tile_kernel<2>), dim3(c->P.ntiles, ncol), dim3(512),
+                           RESIDENT_LDS_BYTES, c->stream, c->P, nref, cb);
+    else
+        hipLaunchKernelGGL((resident_tile_kernel<3>), dim3(c->P.ntiles, ncol), dim3(512),
+                           RESIDENT_LDS_BYTES, c->stream, c->P, nref, cb);
 }
 
 // the lean persistent instance applies when nothing of the general machinery is
@@ -563,8 +600,39 @@ int decide_persist(mc3hip_ctx *c)
         return c->persist_refs;
     c->persist_checked = true;
     c->persist_refs = 0;
-    if ((c->flags & MC3HIP_FLAG_NO_PERSIST) || getenv("MC3HIP_NO_PERSIST") || c->P.tile > 0)
+    if ((c->flags & MC3HIP_FLAG_NO_PERSIST) || getenv("MC3HIP_NO_PERSIST"))
         return 0;
+    c->resident = false;
+    if (c->P.tile > 0) {
+        // tiled plan: one launch only where the whole grid of the resident kernel -- tiles x
+        // columns of chains -- is on the chip at once and every chain finds an owner wave
+        if (!resident_shape(c))
+            return 0;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) != hipSuccess)
+            return 0;
+        const void *f = resident_kernel(c);
+        (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)RESIDENT_LDS_BYTES);
+        const int per_cu = blocks_per_cu(f, 512, RESIDENT_LDS_BYTES);
+        const long long capacity = (long long)per_cu * prop.multiProcessorCount;
+        const long long maxcol = capacity / c->P.ntiles;
+        if (per_cu < 1 || maxcol < 1)
+            return 0;
+        // the fewest columns that fit, each a multiple of the 16-chain block
+        long long cb = ((long long)c->P.nlocal + maxcol - 1) / maxcol;
+        cb = (cb + 15) / 16 * 16;
+        const long long ncol = ((long long)c->P.nlocal + cb - 1) / cb;
+        if (ncol * c->P.ntiles > capacity || (long long)c->P.nlocal > 8 * ncol * c->P.ntiles)
+            return 0;
+        c->resident = true;
+        c->resident_chain_block = (int)cb;
+        c->fast = false;
+        c->persist_refs = 16384;
+        if (const char *e = getenv("MC3HIP_PERSIST_REFS"))
+            c->persist_refs = atoi(e) > 0 ? atoi(e) : 0;
+        return c->persist_refs;
+    }
     int nb = 0;
     c->fast = fast_eligible(c);
     if (c->fast)
@@ -976,6 +1044,14 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         TRY(dev_alloc(c, &P.sc_scal, nl * 2));
         TRY(dev_alloc(c, &P.sc_flag, nl));
         TRY(dev_alloc(c, &P.sc_part, nl * (size_t)P.ntiles));
+        if (pr->model_kind == MC3HIP_MODEL_LINEAR && P.tile == 2048) {
+            // hand-off areas of the resident tiled plan, all-ones = "not there yet"
+            P.rs_ntp = (P.ntiles + 15) / 16 * 16;
+            TRY(dev_alloc(c, &P.rs_prop, 2 * nl * (size_t)RS_ROW));
+            TRY(dev_alloc(c, &P.rs_part, nl * (size_t)P.rs_ntp));
+            HIP_TRY_C(hipMemset(P.rs_prop, 0xff, 2 * nl * (size_t)RS_ROW * sizeof(double)));
+            HIP_TRY_C(hipMemset(P.rs_part, 0xff, nl * (size_t)P.rs_ntp * sizeof(double)));
+        }
         c->tile_kmax = pr->nmodel <= 4 ? 4 : pr->nmodel <= 8 ? 8 : pr->nmodel <= 12 ? 12 : 16;
         // chains per workgroup column (a multiple of the 16-chain block): one workgroup fits
         // a CU (128 KiB of LDS), so the kernel runs in rounds of `CUs` workgroups; pick the
@@ -1014,8 +1090,8 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
     }
     TRY(dev_alloc(c, &c->ctl, 4));
     P.ctl = c->ctl;
-    TRY(dev_alloc(c, &P.stamps, 16));
-    HIP_TRY_C(hipMemset(P.stamps, 0, 16 * sizeof(unsigned long long)));
+    TRY(dev_alloc(c, &P.stamps, 32));
+    HIP_TRY_C(hipMemset(P.stamps, 0, 32 * sizeof(unsigned long long)));
     HIP_TRY_C(hipMemset(c->ctl, 0, 4 * sizeof(long long)));
     // all-ones = "row not written yet" (the persistent kernel's hand-off sentinel)
     HIP_TRY_C(hipMemset(P.Z, 0xff, zl * zs * sizeof(double)));
@@ -1101,6 +1177,7 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
     plan->persistent = c->comm ? 0 : decide_persist(const_cast<mc3hip_ctx *>(c));
     plan->fast = (plan->persistent > 0 && c->fast) ? (lean_demc_eligible(c) ? 2 : 1) : 0;
     plan->tile_tree = tile_uses_mfma(c) ? 1 : 0;
+    plan->resident = (plan->persistent > 0 && c->resident) ? 1 : 0;
     plan->comm_graph = c->cgraph_exec ? c->comm_graph_nodes : 0;
     plan->recoveries = c->recoveries;
     return MC3HIP_OK;
@@ -1307,6 +1384,13 @@ static int settle(mc3hip_ctx *c)
     HIP_TRY(hipMemsetAsync(P.zchain + row0, 0xff, nrows * sizeof(int32_t), c->stream));
     HIP_TRY(hipMemsetAsync(P.log_post + row0, 0, nrows * sizeof(double), c->stream));
     HIP_TRY(hipMemsetAsync(c->ctl + CTL_ABORT, 0, sizeof(long long), c->stream));
+    if (P.rs_prop) {
+        HIP_TRY(hipMemsetAsync(P.rs_prop, 0xff, 2 * (size_t)P.nlocal * RS_ROW * sizeof(double),
+                               c->stream));
+        HIP_TRY(hipMemsetAsync(P.rs_part, 0xff, (size_t)P.nlocal * P.rs_ntp * sizeof(double),
+                               c->stream));
+    }
+    c->resident = false;
     c->persist_refs = 0;            // this context stays on per-refresh launches
     c->persist_checked = true;
     c->fast = false;
@@ -1365,7 +1449,9 @@ int mc3hip_run(mc3hip_ctx *c, int64_t nrefresh)
             const int n = (int)(left < persist ? left : persist);
             hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl,
                                (long long)R, first ? run0 : -1LL);
-            if (c->fast)
+            if (c->resident)
+                launch_resident(c, n);
+            else if (c->fast)
                 launch_fast(c, n);
             else
                 launch_persist(c, n);
@@ -2097,7 +2183,7 @@ int mc3hip_p2p_attach(mc3hip_ctx *c, int32_t rank, int32_t nranks, const void *a
                     rank * c->P.nlocal, (rank + 1) * c->P.nlocal, c->P.nchains);
     if (c->comm)
         return fail(MC3HIP_ERR_STATE, "an RCCL communicator is already attached");
-    if (decide_persist(c) <= 0)
+    if (c->P.tile > 0 || decide_persist(c) <= 0)
         return fail(MC3HIP_ERR_STATE,
                     "the peer-to-peer hand-off needs the persistent kernel, which this "
                     "problem cannot use (tiled plan, or too many chains to be co-resident)");
@@ -2272,7 +2358,10 @@ int mc3hip_debug_stamps(mc3hip_ctx *c, uint64_t *out16)
         if (rc_settle)
             return rc_settle;
     }
-    HIP_TRY(hipMemcpy(out16, c->P.stamps, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    // (MC3HIP_STAMP_PAGE=1: the second group of sixteen, the resident tiled plan's phases)
+    const char *page = getenv("MC3HIP_STAMP_PAGE");
+    HIP_TRY(hipMemcpy(out16, c->P.stamps + ((page && atoi(page) == 1) ? 16 : 0),
+                      16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return MC3HIP_OK;
 }
 

@@ -117,7 +117,7 @@ class DeviceChains:
                 'graph_nodes': plan.graph_nodes,
                 'persistent': plan.persistent, 'fast': plan.fast,
                 'comm_graph': plan.comm_graph, 'recoveries': plan.recoveries,
-                'tile_tree': plan.tile_tree}
+                'tile_tree': plan.tile_tree, 'resident': plan.resident}
 
     # -- lifetime --------------------------------------------------------------
     def close(self):

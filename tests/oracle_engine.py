@@ -39,7 +39,7 @@ class OracleChains:
         self.ifree = np.where(r.pstep > 0)[0]
         self.ishare = np.where(r.pstep < 0)[0]
         self.plan = {'vlanes': 1024, 'tile': 0, 'waves_per_chain': 0, 'graph_nodes': 0, 'persistent': 0, 'fast': 0,
-                     'comm_graph': 0, 'recoveries': 0, 'tile_tree': 0}
+                     'comm_graph': 0, 'recoveries': 0, 'tile_tree': 0, 'resident': 0}
 
     def close(self):
         pass

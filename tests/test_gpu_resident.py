@@ -1,0 +1,181 @@
+"""The tiled plan in ONE persistent launch (resident_tile_kernel, chain_kernels.h): every
+workgroup keeps its tile of the design matrix on chip, proposals and per-tile sums are
+handed over inside the launch.  Same arithmetic as the three-launch tiled plan, so the same
+oracle (oracle/oracle_lockstep.c, `tile_tree = 1`) checks both, bit for bit.
+
+Reference path: mc3/chain.py:185-289 with the model call of chain.py:317-319 (a design
+matrix times the parameter vector) and the Gaussian chisq of src_c/_chisq.c:111-140.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from test_gpu_parity import run_pair, assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from mc3_amd import engine
+    return engine
+
+
+class env:
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update({k: str(v) for k, v in self.kw.items()})
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def linear(ndata=20000, nmodel=7, nchains=40, niter=25, sampler='demc', thinning=1, **kw):
+    return H.linear_problem(ndata=ndata, nmodel=nmodel, nchains=nchains,
+                            nsamples=nchains*niter*thinning, sampler=sampler,
+                            thinning=thinning, **kw)
+
+
+@pytest.mark.parametrize('nmodel,sampler,thinning', [
+    (7, 'demc', 1), (7, 'snooker', 1), (7, 'mrw', 2), (10, 'demc', 3), (10, 'snooker', 2),
+    (5, 'demc', 1), (11, 'snooker', 1), (8, 'demc', 1)])
+def test_resident_plan_bit_exact(eng, nmodel, sampler, thinning):
+    """20 000 points = 10 tiles of 2048; a shared and a fixed parameter, priors, bounds;
+    5..11 coefficients = two or three blocks of operand rows (the last one in LDS), the data
+    column riding as operand row K."""
+    prob = linear(nmodel=nmodel, sampler=sampler, thinning=thinning)
+    prob['pstep'] = prob['pstep'].copy()
+    prob['params'] = prob['params'].copy()
+    prob['pstep'][nmodel - 2] = -2          # shared with parameter 1
+    prob['pstep'][nmodel - 1] = 0.0         # fixed
+    prob['params'][nmodel - 2] = prob['params'][1]
+    orc, gpu = run_pair(eng, prob)
+    assert gpu.plan['tile'] == 2048 and gpu.plan['tile_tree'] == 1
+    assert gpu.plan['resident'] == 1 and gpu.plan['persistent'] > 0
+    assert_same(orc, gpu)
+    assert gpu.plan['recoveries'] == 0
+    gpu.close()
+
+
+def test_three_launch_plan_still_there(eng):
+    """MC3HIP_NO_RESIDENT=1: the same problem through propose / tile sums / finish as
+    separate launches gives the same chains (it is what a recovery falls back to)."""
+    prob = linear(nmodel=7, sampler='snooker')
+    with env(MC3HIP_NO_RESIDENT=1):
+        orc, gpu = run_pair(eng, prob)
+        assert gpu.plan['resident'] == 0 and gpu.plan['persistent'] == 0
+        assert_same(orc, gpu)
+        gpu.close()
+
+
+def test_twelve_coefficients_keep_the_three_launch_plan(eng):
+    """K = 12 would need a fourth block of operand rows for the data column."""
+    prob = linear(nmodel=12, niter=6)
+    orc, gpu = run_pair(eng, prob)
+    assert gpu.plan['tile'] == 2048 and gpu.plan['resident'] == 0
+    assert_same(orc, gpu)
+    gpu.close()
+
+
+def test_resident_several_launches_and_resume(eng):
+    """Launches of 7 refreshes (MC3HIP_PERSIST_REFS), the run split over three calls: the
+    hand-off areas must be back to "nothing there" at every launch boundary."""
+    prob = linear(nmodel=9, nchains=48, niter=40, sampler='snooker')
+    with env(MC3HIP_PERSIST_REFS=7):
+        gpu = eng.DeviceChains(**prob)
+        assert gpu.plan['resident'] == 1 and gpu.plan['persistent'] == 7
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nrefresh=40, trace=False, nthreads=4)
+        for n in (3, 23, 14):
+            gpu.run(n)
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
+
+
+def test_resident_many_out_of_bounds(eng):
+    """Tight bounds: most proposals leave them, so owners consume sums they do not use
+    (the proposal row may only be reused once every tile has answered)."""
+    prob = linear(nmodel=6, nchains=32, niter=60)
+    prob['pmin'] = prob['params'] - 1.2*np.abs(prob['pstep'])
+    prob['pmax'] = prob['params'] + 1.2*np.abs(prob['pstep'])
+    orc, gpu = run_pair(eng, prob)
+    assert gpu.plan['resident'] == 1
+    assert orc.outbounds.sum() > 50
+    assert_same(orc, gpu)
+    gpu.close()
+
+
+def test_resident_more_than_64_tiles(eng):
+    """140 000 points = 69 tiles: the owner collects the sums 64 at a time; three columns of
+    chains fit the chip."""
+    prob = linear(ndata=140000, nmodel=10, nchains=96, niter=5)
+    orc, gpu = run_pair(eng, prob)
+    assert gpu.plan['resident'] == 1
+    assert_same(orc, gpu)
+    gpu.close()
+
+
+def test_resident_gives_up_and_is_redone(eng):
+    """A wave gives up at refresh 9 (test hook): every workgroup leaves, the host restores
+    its checkpoint and redoes the run with the three-launch plan; same chains."""
+    prob = linear(nmodel=7, nchains=40, niter=25)
+    with env(MC3HIP_TEST_ABORT_AT=9):
+        orc, gpu = run_pair(eng, prob, nrefresh=20)
+    assert gpu.plan['recoveries'] == 1 and gpu.plan['persistent'] == 0
+    tc, tf = gpu.trace(20)
+    np.testing.assert_array_equal(tf, orc.trace_flag)
+    np.testing.assert_array_equal(tc, orc.trace_chisq)
+    gpu.run(5)                                  # and goes on from there
+    orc.run(nrefresh=5, trace=False, nthreads=4)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
+def test_config_c5_resident(eng):
+    """C5 at full size (10 coefficients, 1e5 points, 512 chains): 49 tiles x 5 columns of
+    112 chains = 245 workgroups, one per CU."""
+    prob = H.linear_problem(ndata=100000, nchains=512, nsamples=512*8)
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert gpu.plan['resident'] == 1
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
+@pytest.mark.parametrize('case', range(10))
+def test_resident_random_problems(eng, case):
+    """Random shapes of the resident plan: 5..11 coefficients, 16..90 chains (one to six
+    blocks of 16 per column, ragged last block), 8..20 tiles with a ragged last one, any
+    sampler, thinning, epsilon, fixed / shared parameters."""
+    rs = np.random.RandomState(9000 + case)
+    nmodel = int(rs.randint(5, 12))
+    nchains = int(rs.randint(16, 91))
+    ndata = int(rs.randint(16384, 41000))
+    sampler = ['demc', 'snooker', 'mrw'][case % 3]
+    thinning = int(rs.choice([1, 1, 2, 3]))
+    prob = linear(ndata=ndata, nmodel=nmodel, nchains=nchains, niter=12, sampler=sampler,
+                  thinning=thinning)
+    prob['pstep'] = prob['pstep'].copy()
+    prob['params'] = prob['params'].copy()
+    if rs.rand() < 0.5:
+        prob['pstep'][nmodel - 1] = 0.0
+    if rs.rand() < 0.5:
+        prob['pstep'][nmodel - 2] = -1          # shared with parameter 0
+        prob['params'][nmodel - 2] = prob['params'][0]
+    if sampler != 'mrw' and rs.rand() < 0.5:
+        prob['fepsilon'] = 0.01
+    orc, gpu = run_pair(eng, prob)
+    assert gpu.plan['resident'] == 1, (nmodel, nchains, ndata)
+    assert_same(orc, gpu)
+    gpu.close()

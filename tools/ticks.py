@@ -18,6 +18,39 @@ import bench  # noqa: E402
 # python tools/ticks.py [thinning]          C2 (lean kernels)
 # python tools/ticks.py c4                  C4's data with sampler='demc' (the general
 #                                           persistent kernel keeps tick sums for demc only)
+if len(sys.argv) > 1 and sys.argv[1] == 'c5':
+    # python tools/ticks.py c5     the resident tiled plan: phases of chain 0's owner wave
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import helpers as H
+    import tools_pop
+    NIT = 400
+    prob = H.linear_problem(ndata=100000, nchains=512, nsamples=512*(NIT + 60))
+    g = engine.DeviceChains(**prob)
+    Z0, lp0 = tools_pop.population(g)
+    g.set_population(Z0, lp0)
+    g.run(50)
+
+    def stamps(page):
+        os.environ['MC3HIP_STAMP_PAGE'] = str(page)
+        out = (ctypes.c_uint64*16)()
+        _lib.check(g.lib.mc3hip_debug_stamps(g._ctx, out))
+        return np.array(out[:], dtype=np.float64)
+    a0, a1 = stamps(0), stamps(1)
+    g.run(NIT)
+    b0, b1 = stamps(0) - a0, stamps(1) - a1
+    n = b0[12]
+    print(f'plan={g.plan}; iterations sampled (in bounds, chain 0): {int(n)}; '
+          f'wall {g.last_run_ms()*1e3/NIT:.2f} us per iteration')
+    rows = [('top -> partner rows arrived', b0[8]), ('-> proposal published', b1[0]),
+            ('-> tile phase done (incl. waiting for the column\'s proposals)', b1[1]),
+            ('-> all tile sums collected', b1[2]), ('-> chisq known', b1[3]),
+            ('-> end of iteration (accept)', b0[10]), ('-> row published', b0[11]),
+            ('-> top of next iteration', b0[13])]
+    for k, v in rows:
+        print(f'  {k:62s} {v/n:9.0f} cycles')
+    print(f'  {"sum":62s} {sum(v for _, v in rows)/n:9.0f}')
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == 'c4':
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
