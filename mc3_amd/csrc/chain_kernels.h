@@ -1951,7 +1951,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
 {
     if (je < 0)
         je = P.thinning;
-    static_assert(PHASE != PH_RESIDENT || (WPC == 1 && PERSIST && !FAST && !WL && !P2P),
+    static_assert(PHASE != PH_RESIDENT || (WPC == 1 && PERSIST && !FAST && !WL),
                   "the resident tiled plan runs the general one-wave persistent chain");
     static_assert(!FAST || (WPC == 1 && !WL && SMP >= 0 && MT >= 1 && MT <= 8),
                   "FAST needs one wave, Gaussian chisq, a compile-time sampler and degree");
@@ -2524,10 +2524,13 @@ __global__ __launch_bounds__(64 * WPC) void persist_kernel(const DevProblem P, c
 
 
 // The tiled plan in one launch (ResidentTile above): grid = tiles x columns of chains, eight
-// waves; wave v of workgroup w also owns chain w + v * workgroups.  LDS: group totals
+// waves; wave v of workgroup w also owns chain w + v * workgroups.  P2P: the ensemble is
+// sharded over GPUs, each running this kernel over its own chains; owners publish their Z
+// rows into every rank's replica (run_chain P2P), proposals and tile sums stay local.  LDS:
+// group totals
 // [2][16][16], the give-up word, a run_chain area per wave, the tile's 2048 weights, and
 // (three blocks of operand rows) the last block, [16][512].
-template <int KB>
+template <int KB, bool P2P = false>
 __global__ __launch_bounds__(512) void resident_tile_kernel(const DevProblem P, const int nref,
                                                             const int chain_block)
 {
@@ -2549,7 +2552,7 @@ __global__ __launch_bounds__(512) void resident_tile_kernel(const DevProblem P, 
     const int own_chain = wg + (int)(gridDim.x * gridDim.y) * wv;
     if (own_chain < P.nlocal) {
         T.set_owner(P, own_chain, smem + 514 + wv * OWN);
-        run_chain<1, MT_LINEAR, false, false, true, -1, false, PH_RESIDENT, false, 0, false,
+        run_chain<1, MT_LINEAR, false, false, true, -1, false, PH_RESIDENT, P2P, 0, false,
                   ResidentTile<KB>>(P, P.ctl[0], nref, 0, -1, &T, own_chain,
                                     smem + 514 + wv * OWN);
     } else {

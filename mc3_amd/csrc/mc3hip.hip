@@ -352,12 +352,13 @@ void launch_refresh_tiled(mc3hip_ctx *c, int roff)
 constexpr size_t RESIDENT_OWN = 64 + MC3HIP_MAX_PARAMS + 2 + 48 + 4;
 constexpr size_t RESIDENT_LDS_BYTES = (514 + 8 * RESIDENT_OWN + 2048 + 16 * 512) * sizeof(double);
 
-const void *resident_kernel(const mc3hip_ctx *c)
+typedef void (*resident_kernel_fn)(const DevProblem, const int, const int);
+
+resident_kernel_fn resident_kernel(const mc3hip_ctx *c, bool p2p)
 {
-    switch ((c->P.nmodel + 4) / 4) {          // operand rows: coefficients + the data column
-    case 2: return reinterpret_cast<const void *>(&resident_tile_kernel<2>);
-    default: return reinterpret_cast<const void *>(&resident_tile_kernel<3>);
-    }
+    if ((c->P.nmodel + 4) / 4 == 2)           // operand rows: coefficients + the data column
+        return p2p ? resident_tile_kernel<2, true> : resident_tile_kernel<2, false>;
+    return p2p ? resident_tile_kernel<3, true> : resident_tile_kernel<3, false>;
 }
 
 // the problem has the shape the resident kernel is written for (whether its grid fits the
@@ -365,20 +366,15 @@ const void *resident_kernel(const mc3hip_ctx *c)
 bool resident_shape(const mc3hip_ctx *c)
 {
     return tile_uses_mfma(c) && c->P.nmodel >= 5 && c->P.nmodel <= 11 && c->P.rs_prop &&
-           c->comm == nullptr && c->p2p_ranks <= 1 && !(c->flags & MC3HIP_FLAG_P2P) &&
-           !getenv("MC3HIP_NO_RESIDENT");
+           c->comm == nullptr && !getenv("MC3HIP_NO_RESIDENT");
 }
 
 void launch_resident(mc3hip_ctx *c, int nref)
 {
     const int cb = c->resident_chain_block;
     const int ncol = (c->P.nlocal + cb - 1) / cb;
-    if ((c->P.nmodel + 4) / 4 == 2)
-        hipLaunchKernelGGL((resident_tile_kernel<2>), dim3(c->P.ntiles, ncol), dim3(512),
-                           RESIDENT_LDS_BYTES, c->stream, c->P, nref, cb);
-    else
-        hipLaunchKernelGGL((resident_tile_kernel<3>), dim3(c->P.ntiles, ncol), dim3(512),
-                           RESIDENT_LDS_BYTES, c->stream, c->P, nref, cb);
+    hipLaunchKernelGGL(resident_kernel(c, c->p2p_ranks > 1), dim3(c->P.ntiles, ncol), dim3(512),
+                       RESIDENT_LDS_BYTES, c->stream, c->P, nref, cb);
 }
 
 // the lean persistent instance applies when nothing of the general machinery is
@@ -611,12 +607,25 @@ int decide_persist(mc3hip_ctx *c)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) != hipSuccess)
             return 0;
-        const void *f = resident_kernel(c);
-        (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)RESIDENT_LDS_BYTES);
-        const int per_cu = blocks_per_cu(f, 512, RESIDENT_LDS_BYTES);
+        // (a context made for the peer-to-peer hand-off runs the plain instance until the
+        // peers are attached: both must fit)
+        int per_cu = 1 << 30;
+        for (int p2p = 0; p2p < 2; ++p2p) {
+            if (p2p != (c->p2p_ranks > 1 ? 1 : 0) && !(c->flags & MC3HIP_FLAG_P2P))
+                continue;
+            const void *f = reinterpret_cast<const void *>(resident_kernel(c, p2p != 0));
+            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)RESIDENT_LDS_BYTES);
+            const int nb = blocks_per_cu(f, 512, RESIDENT_LDS_BYTES);
+            per_cu = nb < per_cu ? nb : per_cu;
+        }
         const long long capacity = (long long)per_cu * prop.multiProcessorCount;
-        const long long maxcol = capacity / c->P.ntiles;
+        long long maxcol = capacity / c->P.ntiles;
+        // (ranks that share one device -- the multi-process tests on a one-GPU box -- must
+        // share its CUs too: MC3HIP_RESIDENT_MAXCOL caps the columns of chains per rank)
+        if (const char *e = getenv("MC3HIP_RESIDENT_MAXCOL"))
+            if (atoi(e) > 0 && atoi(e) < maxcol)
+                maxcol = atoi(e);
         if (per_cu < 1 || maxcol < 1)
             return 0;
         // the fewest columns that fit, each a multiple of the 16-chain block
@@ -2183,7 +2192,7 @@ int mc3hip_p2p_attach(mc3hip_ctx *c, int32_t rank, int32_t nranks, const void *a
                     rank * c->P.nlocal, (rank + 1) * c->P.nlocal, c->P.nchains);
     if (c->comm)
         return fail(MC3HIP_ERR_STATE, "an RCCL communicator is already attached");
-    if (c->P.tile > 0 || decide_persist(c) <= 0)
+    if ((c->P.tile > 0 && !resident_shape(c)) || decide_persist(c) <= 0)
         return fail(MC3HIP_ERR_STATE,
                     "the peer-to-peer hand-off needs the persistent kernel, which this "
                     "problem cannot use (tiled plan, or too many chains to be co-resident)");
@@ -2331,6 +2340,12 @@ int mc3hip_p2p_rollback(mc3hip_ctx *c, int64_t *from_refresh, int64_t *to_refres
     HIP_TRY(hipMemsetAsync(P.zchain + row0, 0xff, nrows * sizeof(int32_t), c->stream));
     HIP_TRY(hipMemsetAsync(P.log_post + row0, 0, nrows * sizeof(double), c->stream));
     HIP_TRY(hipMemsetAsync(c->ctl + CTL_ABORT, 0, sizeof(long long), c->stream));
+    if (P.rs_prop) {
+        HIP_TRY(hipMemsetAsync(P.rs_prop, 0xff, 2 * (size_t)P.nlocal * RS_ROW * sizeof(double),
+                               c->stream));
+        HIP_TRY(hipMemsetAsync(P.rs_part, 0xff, (size_t)P.nlocal * P.rs_ntp * sizeof(double),
+                               c->stream));
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     *from_refresh = c->ckpt_R;
     *to_refresh = c->refresh_done;
@@ -2345,6 +2360,7 @@ int mc3hip_p2p_rollback(mc3hip_ctx *c, int64_t *from_refresh, int64_t *to_refres
     c->persist_refs = 0;
     c->persist_checked = true;
     c->fast = false;
+    c->resident = false;
     return MC3HIP_OK;
 }
 

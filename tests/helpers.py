@@ -79,7 +79,13 @@ def linear_problem(ndata=512, nmodel=10, nchains=16, nsamples=1600,
             cols.append(np.cos(np.pi*(k//2 + 1)*t))
     A = np.array(cols)
     p_true = rs.uniform(-1, 1, nmodel)
-    data = p_true @ A + rs.normal(0, 1, ndata)
+    # (accumulated term by term: a BLAS product may split the sum differently with the number
+    # of threads it is given -- torchrun's workers get one -- and every process of a
+    # multi-rank test must build the same data to the last bit)
+    signal = np.zeros(ndata)
+    for k in range(nmodel):
+        signal = signal + p_true[k]*A[k]
+    data = signal + rs.normal(0, 1, ndata)
     prior = np.zeros(nmodel)
     plow = np.zeros(nmodel)
     pup = np.zeros(nmodel)

@@ -96,6 +96,42 @@ def test_config_c3_eight_ranks_of_256_chains(tmp_path):
     np.testing.assert_array_equal(total_out, orc.outbounds)
 
 
+@pytest.mark.parametrize('nranks,per_rank,ndata,nmodel,sampler', [
+    (2, 48, 20000, 7, 'demc'), (4, 32, 30000, 10, 'snooker'), (4, 128, 100000, 10, 'demc')])
+def test_resident_tiled_plan_sharded_over_ranks(tmp_path, nranks, per_rank, ndata, nmodel,
+                                                sampler):
+    """The tiled plan in one launch per rank (resident_tile_kernel<KB, P2P>), the ensemble
+    sharded over ranks through the peer-to-peer hand-off -- the last case is BASELINE config
+    C5's own shape: 512 chains x 1e5 points x 10 coefficients over 4 ranks of 128 chains
+    (here: four processes on the one GPU, which they must share: one column of chains per
+    rank, 4 x 49 tiles = 196 workgroups).  Every rank's replica must equal the oracle's run of
+    the whole ensemble."""
+    nref = 12
+    nchains = nranks*per_rank
+    prob = H.linear_problem(ndata=ndata, nmodel=nmodel, nchains=nchains,
+                            nsamples=nchains*nref, sampler=sampler)
+    orc = H.make_oracle(prob, plan={'tile': 2048, 'vlanes': 1024, 'tile_tree': 1})
+    Z0, lp0 = H.initial_population(orc)
+    out_path = str(tmp_path / 'c5')
+    np.savez(out_path + '.pop.npz', Z0=Z0, lp0=lp0)
+    orc.set_population(Z0, lp0)
+    orc.run(nthreads=min(32, len(os.sched_getaffinity(0))))
+    launch(nranks, 'c5_worker.py', out_path, nref, per_rank, ndata, nmodel, sampler,
+           env={'MC3HIP_RESIDENT_MAXCOL': '1'})
+    for rank in range(nranks):
+        got = np.load(f'{out_path}.rank{rank}.npz')
+        s = slice(per_rank*rank, per_rank*(rank + 1))
+        np.testing.assert_array_equal(got['Z'], orc.Z, err_msg=f'rank {rank}')
+        np.testing.assert_array_equal(got['lp'], orc.log_post)
+        np.testing.assert_array_equal(got['zc'], orc.zchain)
+        np.testing.assert_array_equal(got['numaccept'], orc.numaccept[s])
+        np.testing.assert_array_equal(got['X'], orc.X[s])
+        np.testing.assert_array_equal(got['chisq'], orc.chisq[s])
+        np.testing.assert_array_equal(got['best_chisq'], orc.best_chisq[s])
+    total_out = sum(np.load(f'{out_path}.rank{r}.npz')['outbounds'] for r in range(nranks))
+    np.testing.assert_array_equal(total_out, orc.outbounds)
+
+
 @pytest.mark.parametrize('sampler', ['demc', 'snooker'])
 def test_peer_to_peer_abort_is_recovered_by_all_ranks(tmp_path, sampler):
     """A persistent launch gives up on rank 0 in the middle of a two-rank run (test
@@ -125,3 +161,30 @@ def test_peer_to_peer_abort_is_recovered_by_all_ranks(tmp_path, sampler):
                     'acceptance_rate', 'best_log_post', 'medianp'):
             np.testing.assert_array_equal(got[key], single[key], err_msg=key)
         np.testing.assert_allclose(got['stdp'], single['stdp'], rtol=1e-12)
+
+
+def test_resident_tiled_plan_abort_is_recovered_by_all_ranks(tmp_path):
+    """The same vote / roll-back / redo when the kernel that gives up is the resident tiled
+    plan's (two ranks of 32 chains, 10 tiles; rank 0's first chain gives up at refresh 7 of
+    the second launch): the lost refreshes are redone through the host-staged exchange with
+    the three-launch plan, and every replica still equals the oracle's run."""
+    nref, per_rank, ndata, nmodel = 18, 32, 20000, 7
+    nchains = 2*per_rank
+    prob = H.linear_problem(ndata=ndata, nmodel=nmodel, nchains=nchains,
+                            nsamples=nchains*nref, sampler='demc')
+    orc = H.make_oracle(prob, plan={'tile': 2048, 'vlanes': 1024, 'tile_tree': 1})
+    Z0, lp0 = H.initial_population(orc)
+    out_path = str(tmp_path / 'c5abort')
+    np.savez(out_path + '.pop.npz', Z0=Z0, lp0=lp0)
+    orc.set_population(Z0, lp0)
+    orc.run(nthreads=8)
+    res = launch(2, 'c5_worker.py', out_path, nref, per_rank, ndata, nmodel, 'demc',
+                 'abort=13', env={'MC3HIP_RESIDENT_MAXCOL': '1'})
+    assert 'recovered' in res.stdout, res.stdout[-2000:]
+    for rank in range(2):
+        got = np.load(f'{out_path}.rank{rank}.npz')
+        s = slice(per_rank*rank, per_rank*(rank + 1))
+        np.testing.assert_array_equal(got['Z'], orc.Z, err_msg=f'rank {rank}')
+        np.testing.assert_array_equal(got['lp'], orc.log_post)
+        np.testing.assert_array_equal(got['numaccept'], orc.numaccept[s])
+        np.testing.assert_array_equal(got['chisq'], orc.chisq[s])
