@@ -90,6 +90,11 @@ def main():
             'us_per_iteration': round(dt/n*1e6, 2),
             'algorithmic_GBps': round(rate*1e6*BYTES[name]/1e9, 1),
             'frac_of_8TBps': round(rate*1e6*BYTES[name]/8e12, 4),
+            # design-matrix models: the contraction is what bounds them (FP64 matrix / vector
+            # pipe, 78.6 TFLOP/s dense on MI355X), not the chain-invariant operand streams
+            **({'useful_fp64_TFLOPs': round(rate*1e6*2*g.nmodel*g.ndata/1e12, 2),
+                'frac_of_fp64_peak': round(rate*1e6*2*g.nmodel*g.ndata/78.6e12, 4)}
+               if name.startswith('c5') else {}),
             'plan': g.plan, 'acceptance': round(float(acc), 3)}), flush=True)
         g.close()
 
