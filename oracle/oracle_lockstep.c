@@ -494,6 +494,22 @@ static double eval_chisq(const ls_problem *P, const double *p, ls_scratch *S)
     return gauss_chisq(P, p, S->part);
 }
 
+/* chisq of an arbitrary parameter vector (initial population, best-fit statistics,
+ * Chain.eval_model): the library evaluates those with its one-workgroup-per-vector kernel
+ * whatever plan the chain update runs under, i.e. in the untiled order ("vlanes strided
+ * partial sums over all the data, one halving tree").  Under a tiled plan this differs from
+ * the chain's own sums by rounding only; the checker mirrors it so that whole sample() runs
+ * can be compared bit for bit (tests/test_gpu_api.py). */
+static double eval_chisq_untiled(const ls_problem *P, const double *p, ls_scratch *S)
+{
+    if (P->wlike || P->tile == 0)
+        return eval_chisq(P, p, S);
+    ls_problem Q = *P;
+    Q.tile = 0;
+    Q.tile_tree = 0;
+    return eval_chisq(&Q, p, S);
+}
+
 /* chisq for n parameter vectors (rows of `params`, nparams each) */
 int ls_eval_chisq(const ls_problem *P, const double *params, int n, double *out)
 {
@@ -503,7 +519,7 @@ int ls_eval_chisq(const ls_problem *P, const double *params, int n, double *out)
     S.buf0 = malloc(sizeof(double) * (size_t)P->ndata);
     S.buf1 = malloc(sizeof(double) * (size_t)P->ndata);
     for (int r = 0; r < n; r++)
-        out[r] = eval_chisq(P, params + (size_t)r * P->nparams, &S);
+        out[r] = eval_chisq_untiled(P, params + (size_t)r * P->nparams, &S);
     free(S.part); free(S.buf0); free(S.buf1);
     return 0;
 }
@@ -851,7 +867,7 @@ int ls_init_population(const ls_problem *P, int kickoff, uint64_t seed, double *
         }
         for (int s = 0; s < P->nshare; s++)
             values[P->ishare[s]] = values[P->share_src[s]];
-        const double lp = -0.5 * eval_chisq(P, values, &S);
+        const double lp = -0.5 * eval_chisq_untiled(P, values, &S);
         if (!(lp - lp == 0.0)) {                          /* inf or NaN */
             failed++;
             continue;

@@ -16,7 +16,8 @@ class OracleChains:
                  nsamples=None, sampler='snooker', wlike=False, thinning=1,
                  fgamma=1.0, fepsilon=0.0, hsize=10, model='poly', nmodel=None,
                  seed=0, device=0, chain0=0, nlocal=None, M0=None, zlen=None,
-                 trace_iters=0, no_graph=False, no_persist=False, p2p=False, nthreads=1):
+                 trace_iters=0, no_graph=False, no_persist=False, p2p=False, nthreads=1,
+                 plan=None):
         if M0 is None:
             M0 = hsize*nchains
         if nsamples is None:
@@ -27,7 +28,11 @@ class OracleChains:
             prior=prior, priorlow=priorlow, priorup=priorup, nchains=nchains,
             nsamples=nsamples, sampler=sampler, wlike=wlike, thinning=thinning,
             fgamma=fgamma, fepsilon=fepsilon, hsize=hsize, model=model,
-            nmodel=nmodel, seed=seed, chain0=chain0, nlocal=nlocal, M0=M0)
+            nmodel=nmodel, seed=seed, chain0=chain0, nlocal=nlocal, M0=M0,
+            # (the summation order of the plan the library would choose for this problem:
+            # tests that compare with a GPU run pass DeviceChains.plan's entries)
+            **({k: plan[k] for k in ('tile', 'vlanes', 'tile_tree') if k in plan}
+               if plan else {}))
         r = self.run_
         self.nthreads = nthreads
         self.nchains, self.thinning, self.nfree = r.nchains, r.thinning, r.nfree
@@ -38,8 +43,9 @@ class OracleChains:
         self.prior, self.priorlow, self.priorup = r.prior, r.priorlow, r.priorup
         self.ifree = np.where(r.pstep > 0)[0]
         self.ishare = np.where(r.pstep < 0)[0]
-        self.plan = {'vlanes': 1024, 'tile': 0, 'waves_per_chain': 0, 'graph_nodes': 0, 'persistent': 0, 'fast': 0,
-                     'comm_graph': 0, 'recoveries': 0, 'tile_tree': 0, 'resident': 0}
+        self.plan = {'vlanes': 1024, 'tile': (plan or {}).get('tile', 0), 'waves_per_chain': 0, 'graph_nodes': 0, 'persistent': 0, 'fast': 0,
+                     'comm_graph': 0, 'recoveries': 0, 'tile_tree': (plan or {}).get('tile_tree', 0),
+                     'resident': 0}
 
     def close(self):
         pass

@@ -15,12 +15,14 @@ def quad(p, x):
     return p[0] + p[1]*x + p[2]*x**2.0
 
 
-def both(**kw):
+def both(checker_plan=None, **kw):
+    import functools
     import mc3_amd
     from mc3_amd import utils as mu
     from oracle_engine import OracleChains
     outs = []
-    for factory in (None, OracleChains):
+    checker = functools.partial(OracleChains, plan=checker_plan) if checker_plan else OracleChains
+    for factory in (None, checker):
         np.random.seed(3)
         extra = {} if factory is None else {'engine_factory': factory}
         outs.append(mc3_amd.sample(log=mu.Log(verb=0), seed=21, **kw, **extra))
@@ -88,6 +90,24 @@ def test_sample_gpu_shared_priors_wavelet_linear():
                     pmin=prob['pmin'], pmax=prob['pmax'], prior=prob['prior'],
                     priorlow=prob['priorlow'], priorup=prob['priorup'],
                     sampler='demc', nsamples=1600, burnin=10, nchains=16)
+    assert_same_dict(gpu, cpu)
+
+
+@pytest.mark.parametrize('sampler', ['demc', 'snooker'])
+def test_sample_tiled_problem_equals_cpu_checker(sampler):
+    """sample() end to end on a problem that takes the tiled plan (design matrix, 20 000
+    points: the one-launch resident kernel): initial population, chains, Gelman-Rubin,
+    posterior and best-fit statistics equal the checker's run of the same call, which sums
+    the chain's proposals in the plan's order and arbitrary vectors (initial population,
+    best fit) in the untiled order, as the library does."""
+    prob = H.linear_problem(ndata=20000, nmodel=7)
+    gpu, cpu = both(checker_plan={'tile': 2048, 'vlanes': 1024, 'tile_tree': 1},
+                    data=prob['data'], uncert=prob['uncert'],
+                    func=lambda p, A: p @ A, params=prob['params'],
+                    indparams=[prob['indep']], pstep=prob['pstep'],
+                    pmin=prob['pmin'], pmax=prob['pmax'], prior=prob['prior'],
+                    priorlow=prob['priorlow'], priorup=prob['priorup'],
+                    sampler=sampler, nsamples=32*60, burnin=10, nchains=32)
     assert_same_dict(gpu, cpu)
 
 
