@@ -95,6 +95,8 @@ struct DevProblem {
 
 constexpr int PH_FUSED = 0, PH_PROPOSE = 1, PH_FINISH = 2, PH_RESIDENT = 3;
 constexpr int RS_ROW = 16;          // doubles per published proposal row: one 128-byte line
+constexpr int RS_WCAP = 256;        // chains whose group totals a workgroup collects in LDS
+                                    // before it adds them up (resident tiled plan)
 constexpr int SC_STRIDE = MC3HIP_MAX_PARAMS + 16;   // doubles per sc_nextp row (zero padded)
 
 // In-kernel phase stamps for the diagnostic build (never compiled into the product
@@ -1609,19 +1611,16 @@ struct ResidentTile {
     static constexpr int KR = (KB == 3) ? 2 : KB;
     double bop[8][2][KR];
     const double *s_b;      // LDS [16][512]: this thread's operands of row block KR
-    double *s_w;            // LDS [2][16][16]: group totals of the running block of chains
+    double *s_w;            // LDS [RS_WCAP][16]: group totals of the chains done so far
     const double *s_ww;     // LDS [2048]: the weights of the tile's points (this wave's: + 128 wv)
     int *s_stop;            // LDS: a wave of this workgroup has given up
     int t, c0, c1, wv, lane;
     int par;                // parity of the iteration whose proposals are used next
     bool failed;            // a wait of this wave timed out: said at the next agreement point
-    // owner waves: the chain, its LDS area ([0..63]: the Gaussian priors as index, centre,
-    // lower and upper width, 16 each), and the first 64 tile sums of the chain, asked for
-    // while the last block of chains is still being computed
+    // owner waves: the chain and its LDS area ([0..63]: the Gaussian priors as index, centre,
+    // lower and upper width, 16 each)
     int own;
     double *s_own;
-    double *pre_addr;
-    double pre_val;
 
     __device__ __forceinline__ void load(const DevProblem &P, int tile, int col, int chain_block,
                                          double *lds_w, int *lds_stop, double *lds_ww,
@@ -1639,8 +1638,6 @@ struct ResidentTile {
         failed = false;
         own = -1;
         s_own = nullptr;
-        pre_addr = nullptr;
-        pre_val = 0.0;
         const int j = lane & 15, g = lane >> 4, K = P.nmodel;
 #pragma unroll
         for (int vb = 0; vb < 8; ++vb) {
@@ -1672,8 +1669,6 @@ struct ResidentTile {
     {
         own = lc;
         s_own = area;
-        const int n0 = P.ntiles < 64 ? P.ntiles : 64;
-        pre_addr = P.rs_part + (size_t)lc * P.rs_ntp + (lane < n0 ? lane : 0);
         if (P.ngprior <= 16 && lane < P.ngprior) {
             const int jp = P.igprior[lane];
             area[lane] = (double)jp;
@@ -1723,7 +1718,7 @@ struct ResidentTile {
         auto lds_weight = [&](int st) { return s_ww[wo + 1024 * (st & 1) + 16 * (st >> 1)]; };
         // sum over the 64 lanes of a group (lane 16 q + j): strides 32 and 16 were in-thread,
         // 8..1 run inside the 16-lane row; lane j = 0 has the defined order
-        auto group_total = [&](const double(&acc)[2][4], int grp, int buf) {
+        auto group_total = [&](const double(&acc)[2][4], int grp, int off) {
             double sr[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1736,7 +1731,7 @@ struct ResidentTile {
             if (j == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    s_w[(buf * 16 + g + 4 * r) * 16 + 2 * wv + grp] = sr[r];
+                    s_w[(off + g + 4 * r) * 16 + 2 * wv + grp] = sr[r];
             }
         };
         // Software pipeline, written out.  FP64 matrix and vector instructions share one pipe
@@ -1749,8 +1744,8 @@ struct ResidentTile {
         // worth of registers alive instead of sixteen.  (Carrying the pipeline across the
         // barrier at the end of a block of chains costs 25 more registers.)
         request(c0);
-        int buf = 0;
-        for (int cb = c0; cb < c1; cb += 16, buf ^= 1) {
+        int base = c0;                  // first chain of the window collected in s_w
+        for (int cb = c0; cb < c1; cb += 16) {
             if (!wait_rows<KB>(addr, aop, ctl))
                 failed = true;
             double a[KB];
@@ -1759,10 +1754,6 @@ struct ResidentTile {
                 a[kb] = aop[kb];
             if (cb + 16 < c1)
                 request(cb + 16);              // the next block's rows travel behind this one
-            else if (own >= 0)
-                // an owner's tile sums: unless its chain is in the last block of its column
-                // they are there by now, and the round trip hides behind this block
-                pre_val = load_published(pre_addr);
             asm volatile("; operands of this block" : "+v"(wo));
             double bl_next = lds_operand(1), w_cur = lds_weight(0), w_next = w_cur;
             mc3_v4d mc = product(0, a, lds_operand(0)), mn = mc;
@@ -1792,7 +1783,7 @@ struct ResidentTile {
                     }
                 }
                 if (st == 8)
-                    group_total(accA, 0, buf);
+                    group_total(accA, 0, cb - base);
                 // (two matrix instructions first: the product these squares read was the last
                 // thing issued in the previous step and needs a pipe pass to land)
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);             // MFMA
@@ -1809,20 +1800,32 @@ struct ResidentTile {
                 mc = mn;
                 w_cur = w_next;
             }
-            group_total(accB, 1, buf);
-            block_sync<8>();
-            if (lane < 32) {            // wave wv: the 16 group totals of chains cb + 2 wv, + 1
-                const int ch = 2 * wv + (lane >> 4);
-                double s = s_w[(buf * 16 + ch) * 16 + (lane & 15)];
-                s = add_ror<8>(s);
-                s = add_ror<4>(s);
-                s = add_ror<2>(s);
-                s = add_ror<1>(s);
-                if (mc3_bits(s) == ROW_PENDING)        // (a NaN that looks like "not there yet")
-                    s = mc3_from_bits(0x7ff8000000000000ull);
-                if ((lane & 15) == 0 && cb + ch < c1)
-                    __hip_atomic_store(&P.rs_part[(size_t)(cb + ch) * P.rs_ntp + t], s,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            group_total(accB, 1, cb - base);
+            // The waves of the workgroup are NOT synchronised per block of chains: every wave
+            // leaves its group totals in LDS and goes on (a barrier, an exchange and a
+            // sixteen-lane sum per block cost ~10 % of the phase, and two waves that drift
+            // apart share their SIMD's FP64 pipe better than two in step).  The totals are
+            // added up -- 16 per chain, strides 8..1 -- once per window of RS_WCAP chains,
+            // normally once per iteration.
+            const int end = (cb + 16 < c1) ? cb + 16 : c1;
+            if (end == c1 || end - base == RS_WCAP) {
+                block_sync<8>();
+                for (int ch0 = base + 4 * wv; ch0 < end; ch0 += 32) {
+                    const int ch = ch0 + (lane >> 4);
+                    double sg = s_w[((ch < end ? ch : end - 1) - base) * 16 + (lane & 15)];
+                    sg = add_ror<8>(sg);
+                    sg = add_ror<4>(sg);
+                    sg = add_ror<2>(sg);
+                    sg = add_ror<1>(sg);
+                    if (mc3_bits(sg) == ROW_PENDING)   // (a NaN that looks like "not there yet")
+                        sg = mc3_from_bits(0x7ff8000000000000ull);
+                    if ((lane & 15) == 0 && ch < end)
+                        __hip_atomic_store(&P.rs_part[(size_t)ch * P.rs_ntp + t], sg,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (end < c1)
+                    block_sync<8>();            // (the next window overwrites these totals)
+                base = end;
             }
         }
         par ^= 1;
@@ -1856,8 +1859,7 @@ struct ResidentTile {
             const int n = (P.ntiles - t0 < 64) ? P.ntiles - t0 : 64;
             double *mine = row + t0 + (lane < n ? lane : 0);
             const double *const addr[1] = {mine};
-            // (the first 64 were asked for during the tile phase)
-            double val[1] = {t0 == 0 ? pre_val : load_published(mine)};
+            double val[1] = {load_published(mine)};
             if (!wait_rows<1>(addr, val, ctl))
                 failed = true;
             // (in order, eight broadcasts at a time ahead of their dependent additions)
@@ -1903,13 +1905,19 @@ struct ResidentTile {
             return total;
         if (P.ngprior > 16)
             return total + prior_term(P, s_nextp);
-        double pr = 0.0;                         // prior_term from the LDS copy of its constants
-        for (int gp = 0; gp < P.ngprior; ++gp) {
-            const int jp = (int)s_own[gp];
-            const double d = s_nextp[jp] - s_own[16 + gp];
-            const double sd = (d > 0.0) ? d / s_own[48 + gp] : d / s_own[32 + gp];
-            pr = pr + sd * sd;
+        // prior_term from the LDS copy of its constants: lane g works out term g (the
+        // divisions side by side instead of one after the other), then the terms are added
+        // in order
+        double term = 0.0;
+        if (lane < P.ngprior) {
+            const int jp = (int)s_own[lane];
+            const double d = s_nextp[jp] - s_own[16 + lane];
+            const double sd = (d > 0.0) ? d / s_own[48 + lane] : d / s_own[32 + lane];
+            term = sd * sd;
         }
+        double pr = 0.0;
+        for (int gp = 0; gp < P.ngprior; ++gp)
+            pr = pr + read_lane(term, gp);
         return total + pr;
     }
 };
@@ -2528,7 +2536,7 @@ __global__ __launch_bounds__(64 * WPC) void persist_kernel(const DevProblem P, c
 // sharded over GPUs, each running this kernel over its own chains; owners publish their Z
 // rows into every rank's replica (run_chain P2P), proposals and tile sums stay local.  LDS:
 // group totals
-// [2][16][16], the give-up word, a run_chain area per wave, the tile's 2048 weights, and
+// [RS_WCAP][16], the give-up word, a run_chain area per wave, the tile's 2048 weights, and
 // (three blocks of operand rows) the last block, [16][512].
 template <int KB, bool P2P = false>
 __global__ __launch_bounds__(512) void resident_tile_kernel(const DevProblem P, const int nref,
@@ -2536,11 +2544,12 @@ __global__ __launch_bounds__(512) void resident_tile_kernel(const DevProblem P, 
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int OWN = 64 + MC3HIP_MAX_PARAMS + 2 + 48 + 4;     // carve() of a one-wave chain
-    int *s_stop = reinterpret_cast<int *>(smem + 512);
+    constexpr int W = RS_WCAP * 16;                              // group totals
+    int *s_stop = reinterpret_cast<int *>(smem + W);
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     ResidentTile<KB> T;
-    T.load(P, blockIdx.x, blockIdx.y, chain_block, smem, s_stop, smem + 514 + 8 * OWN,
-           smem + 514 + 8 * OWN + 2048);
+    T.load(P, blockIdx.x, blockIdx.y, chain_block, smem, s_stop, smem + W + 2 + 8 * OWN,
+           smem + W + 2 + 8 * OWN + 2048);
     // a launch queued behind one that gave up must not run: its inputs are missing
     if (threadIdx.x == 0)
         *s_stop = (__hip_atomic_load(&P.ctl[CTL_ABORT], __ATOMIC_RELAXED,
@@ -2551,10 +2560,10 @@ __global__ __launch_bounds__(512) void resident_tile_kernel(const DevProblem P, 
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     const int own_chain = wg + (int)(gridDim.x * gridDim.y) * wv;
     if (own_chain < P.nlocal) {
-        T.set_owner(P, own_chain, smem + 514 + wv * OWN);
+        T.set_owner(P, own_chain, smem + W + 2 + wv * OWN);
         run_chain<1, MT_LINEAR, false, false, true, -1, false, PH_RESIDENT, P2P, 0, false,
                   ResidentTile<KB>>(P, P.ctl[0], nref, 0, -1, &T, own_chain,
-                                    smem + 514 + wv * OWN);
+                                    smem + W + 2 + wv * OWN);
     } else {
         // no chain of its own: the tile phase of every iteration, in step with the owners
         for (int R = 0; R < nref; ++R)

@@ -347,10 +347,11 @@ void launch_refresh_tiled(mc3hip_ctx *c, int roff)
 }
 
 // ---- resident tiled plan (chain_kernels.h ResidentTile) --------------------------------
-// LDS: group totals [2][16][16], the give-up word, one run_chain area per wave, 2048 weights,
+// LDS: group totals [RS_WCAP][16], the give-up word, one run_chain area per wave, 2048 weights,
 // the last block of operand rows [16][512]
 constexpr size_t RESIDENT_OWN = 64 + MC3HIP_MAX_PARAMS + 2 + 48 + 4;
-constexpr size_t RESIDENT_LDS_BYTES = (514 + 8 * RESIDENT_OWN + 2048 + 16 * 512) * sizeof(double);
+constexpr size_t RESIDENT_LDS_BYTES =
+    (RS_WCAP * 16 + 2 + 8 * RESIDENT_OWN + 2048 + 16 * 512) * sizeof(double);
 
 typedef void (*resident_kernel_fn)(const DevProblem, const int, const int);
 

@@ -179,3 +179,15 @@ def test_resident_random_problems(eng, case):
     assert gpu.plan['resident'] == 1, (nmodel, nchains, ndata)
     assert_same(orc, gpu)
     gpu.close()
+
+
+def test_resident_column_longer_than_the_lds_window(eng):
+    """One column of 320 chains (MC3HIP_RESIDENT_MAXCOL=1): the group totals of a workgroup
+    are collected in LDS for 256 chains at a time, so this column is added up in two
+    windows."""
+    prob = linear(ndata=140000, nmodel=9, nchains=320, niter=4)
+    with env(MC3HIP_RESIDENT_MAXCOL=1):
+        orc, gpu = run_pair(eng, prob)
+        assert gpu.plan['resident'] == 1
+        assert_same(orc, gpu)
+        gpu.close()
