@@ -1582,17 +1582,19 @@ __device__ __forceinline__ void demc_partners(uint64_t q0, int n, int c, int &r1
 }
 
 // ---- resident tiled plan --------------------------------------------------------------
-// The tiled plan as ONE launch (design-matrix models through the matrix cores, one GPU).  The
-// grid is the tile kernel's -- tiles x columns of chains, one workgroup per CU -- but every
-// workgroup keeps its tile (design values, data, weights: 96 + 32 registers per lane at twelve
-// operand rows) for the whole launch instead of reloading 200 KB of it per iteration, and the
-// three phases of an iteration hand over inside the launch instead of at kernel boundaries:
+// The tiled plan as ONE launch (design-matrix models through the matrix cores; one GPU, or
+// one launch per GPU with the Z rows published to every rank).  The grid is the tile kernel's
+// -- tiles x columns of chains, one workgroup per CU -- but every workgroup keeps its tile
+// (operand rows in registers and LDS, weights in LDS) for the whole launch instead of
+// reloading 200 KB of it per iteration, and the three phases of an iteration hand over
+// inside the launch instead of at kernel boundaries:
 //   * a wave that OWNS a chain (wave v of workgroup w owns chain w + v * workgroups) runs the
 //     ordinary run_chain for it -- proposal, Metropolis, Z append -- and publishes the proposed
 //     coefficient row (rs_prop, one 128-byte line, by iteration parity);
 //   * all eight waves of every workgroup then compute the data sums of their tile for the
-//     chains of their column, 16 chains at a time, as soon as those rows are there, and
-//     publish one sum per (chain, tile) (rs_part);
+//     chains of their column, 16 chains at a time, as soon as those rows are there, each wave
+//     at its own pace; after the last block one barrier, the sums of the waves are added and
+//     one sum per (chain, tile) is published (rs_part);
 //   * the owner adds the sums of its chain in tile order, hands the slots and the consumed row
 //     back (all-ones), and goes on to the next iteration.
 // Every handed-over double is its own flag (all-ones = not there yet), exactly as for Z rows;
@@ -1617,9 +1619,8 @@ struct ResidentTile {
     int t, c0, c1, wv, lane;
     int par;                // parity of the iteration whose proposals are used next
     bool failed;            // a wait of this wave timed out: said at the next agreement point
-    // owner waves: the chain and its LDS area ([0..63]: the Gaussian priors as index, centre,
-    // lower and upper width, 16 each)
-    int own;
+    // owner waves: their LDS area ([0..63]: the Gaussian priors as index, centre, lower and
+    // upper width, 16 each)
     double *s_own;
 
     __device__ __forceinline__ void load(const DevProblem &P, int tile, int col, int chain_block,
@@ -1636,7 +1637,6 @@ struct ResidentTile {
         wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         par = 0;
         failed = false;
-        own = -1;
         s_own = nullptr;
         const int j = lane & 15, g = lane >> 4, K = P.nmodel;
 #pragma unroll
@@ -1667,7 +1667,6 @@ struct ResidentTile {
     // run_chain does not use here)
     __device__ __forceinline__ void set_owner(const DevProblem &P, int lc, double *area)
     {
-        own = lc;
         s_own = area;
         if (P.ngprior <= 16 && lane < P.ngprior) {
             const int jp = P.igprior[lane];
@@ -3379,6 +3378,28 @@ __global__ void init_scan_kernel(const DevProblem P, int ntrial, const double *f
     st[0] = filled;
     st[1] = failed;
     st[2] = used;
+}
+
+// per-chain state to / from the checkpoint area (8-byte words; the seven items back to back
+// in `ckpt`): one launch instead of seven asynchronous device-to-device copies per run
+struct CheckpointItems {
+    unsigned long long *ptr[7];
+    unsigned long long words[7];
+};
+
+__global__ void checkpoint_kernel(CheckpointItems it, unsigned long long *ckpt, int save)
+{
+    unsigned long long at = 0;
+    for (int k = 0; k < 7; ++k) {
+        for (unsigned long long i = blockIdx.x * blockDim.x + threadIdx.x; i < it.words[k];
+             i += (unsigned long long)gridDim.x * blockDim.x) {
+            if (save)
+                ckpt[at + i] = it.ptr[k][i];
+            else
+                it.ptr[k][i] = ckpt[at + i];
+        }
+        at += it.words[k];
+    }
 }
 
 __global__ void set_ctl_kernel(long long *ctl, long long base, long long run0)

@@ -1229,18 +1229,21 @@ static int checkpoint_copy(mc3hip_ctx *c, bool save)
 {
     const DevProblem &P = c->P;
     const size_t nl = (size_t)P.nlocal, nf = (size_t)P.nfree;
-    struct Item { void *ptr; size_t bytes; };
-    const Item items[] = {
-        {P.X, nl * nf * 8}, {P.bestx, nl * nf * 8}, {P.chisq, nl * 8}, {P.best_chisq, nl * 8},
-        {P.numaccept, nl * 8}, {P.best_iter, nl * 8}, {P.outbounds, nf * 8}};
-    char *at = c->ckpt;
-    for (const Item &it : items) {
-        if (save)
-            HIP_TRY(hipMemcpyAsync(at, it.ptr, it.bytes, hipMemcpyDeviceToDevice, c->stream));
-        else
-            HIP_TRY(hipMemcpyAsync(it.ptr, at, it.bytes, hipMemcpyDeviceToDevice, c->stream));
-        at += it.bytes;
+    // (one kernel: see checkpoint_kernel)
+    CheckpointItems it;
+    void *const ptrs[7] = {P.X, P.bestx, P.chisq, P.best_chisq, P.numaccept, P.best_iter,
+                           P.outbounds};
+    const size_t words[7] = {nl * nf, nl * nf, nl, nl, nl, nl, nf};
+    size_t total = 0;
+    for (int k = 0; k < 7; ++k) {
+        it.ptr[k] = static_cast<unsigned long long *>(ptrs[k]);
+        it.words[k] = words[k];
+        total += words[k];
     }
+    const int blocks = (int)((total + 255) / 256 < 64 ? (total + 255) / 256 : 64);
+    hipLaunchKernelGGL(checkpoint_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, c->stream,
+                       it, reinterpret_cast<unsigned long long *>(c->ckpt), save ? 1 : 0);
+    HIP_TRY(hipGetLastError());
     return MC3HIP_OK;
 }
 
