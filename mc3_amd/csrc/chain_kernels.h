@@ -1065,7 +1065,12 @@ static inline size_t smem_bytes(int nthreads, int ndata, int wlike)
 // wave g reduces chain g over the 1024 lanes in the canonical order (strides
 // 512..64 across waves, 32..1 inside the wave).  Output: sc_part[chain][tile];
 // the finish kernel adds the tiles in order.
-template <int KMAX, bool LINEAR, int TP>
+// KX > 0: the number of coefficients is known at compile time (polynomials of 2..4
+// coefficients, the same family the fused kernels specialise): the Horner chain is KX - 1
+// fused multiply-adds instead of KMAX steps of "is this coefficient there?" selects, which
+// made a quadratic cost five times its arithmetic (58 -> 14 us per launch on 512 chains x
+// 1e5 points).
+template <int KMAX, bool LINEAR, int TP, int KX = 0>
 __global__ __launch_bounds__(1024) void tile_chisq_kernel(
     const DevProblem P, const int chain_block,
     // separate read-only kernel arguments so that the wave-uniform coefficient reads
@@ -1075,7 +1080,8 @@ __global__ __launch_bounds__(1024) void tile_chisq_kernel(
     extern __shared__ __attribute__((aligned(16))) double s_x[];   // [16][1024]
     const int l = threadIdx.x, lane = l & 63, wv = l >> 6;
     const int t = blockIdx.x;
-    const int K = P.nmodel;
+    const int K = KX > 0 ? KX : P.nmodel;
+    static_assert(KX == 0 || (!LINEAR && KX >= 2 && KX <= KMAX), "exact degree: polynomials");
     const size_t base = (size_t)t * (1024 * TP) + l;      // TP points per thread
     double a[TP][LINEAR ? KMAX : 1], d[TP], w[TP];
 #pragma unroll
@@ -1116,21 +1122,49 @@ __global__ __launch_bounds__(1024) void tile_chisq_kernel(
             s_cf[(buf * 16 + g) * CFS + k] = v;
         }
     };
-    stage_coefficients(c0, 0);
-    block_sync<16>();
+    // KX > 0 (KMAX = 4): the 16 x 4 coefficients of a block are exactly one value per lane;
+    // every wave loads them itself (lane 4 g + k: coefficient k of chain cb + g; the next
+    // block's while this one is computed) and hands them to the scalar unit with v_readlane --
+    // no LDS staging, no 80 broadcast reads per block through the LDS pipe all 16 waves share.
+    double cf_lanes = 0.0, cf_next = 0.0;
+    int skip_lanes = 1, skip_next = 1;
+    auto request_coefficients = [&](int cb, double &cfv, int &skipv) {
+        const int g = lane >> 2, lc = cb + g;
+        cfv = (lc < c1) ? nextp[(size_t)lc * SC_STRIDE + (lane & 3)] : 0.0;
+        const int lf = cb + (lane & 15);
+        skipv = (lf < c1) ? (out_of_bounds[lf] & 1) : 1;
+    };
+    if constexpr (KX > 0) {
+        static_assert(KX == 0 || KMAX == 4, "one coefficient per lane");
+        request_coefficients(c0, cf_next, skip_next);
+    } else {
+        stage_coefficients(c0, 0);
+        block_sync<16>();
+    }
     int buf = 0;
     for (int cb = c0; cb < c1; cb += 16, buf ^= 1) {
+        if constexpr (KX > 0) {
+            cf_lanes = cf_next;
+            skip_lanes = skip_next;
+            if (cb + 16 < c1)
+                request_coefficients(cb + 16, cf_next, skip_next);
+        }
         double part[16];
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             double acc = 0.0;
             const double *cfp = s_cf + (buf * 16 + g) * CFS;
-            if (cfp[KMAX] == 0.0) {                       // (wave-uniform: an LDS broadcast)
+            bool wanted;
+            if constexpr (KX > 0)
+                wanted = __builtin_amdgcn_readlane(skip_lanes, g) == 0;
+            else
+                wanted = cfp[KMAX] == 0.0;                // (wave-uniform: an LDS broadcast)
+            if (wanted) {
                 // coefficients beyond K read the (zeroed) padding of the scratch row
                 double cf[KMAX];
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k)
-                    cf[k] = cfp[k];
+                    cf[k] = (KX > 0) ? ((k < KX) ? read_lane(cf_lanes, 4 * g + k) : 0.0) : cfp[k];
 #pragma unroll
                 for (int q = 0; q < TP; ++q) {
                     double m;
@@ -1141,8 +1175,13 @@ __global__ __launch_bounds__(1024) void tile_chisq_kernel(
 #pragma unroll
                         for (int k = 1; k < KMAX; ++k)
                             m = mc3_fma(a[q][k], cf[k], m);
+                    } else if constexpr (KX > 0) {
+                        m = cf[KX - 1];           // Horner from coefficient K-1 down
+#pragma unroll
+                        for (int k = KX - 2; k >= 0; --k)
+                            m = mc3_fma(m, a[q][0], cf[k]);
                     } else {
-                        m = 0.0;                  // Horner from coefficient K-1 down
+                        m = 0.0;                  // (the same with K known at run time only)
 #pragma unroll
                         for (int k = KMAX - 1; k >= 0; --k) {
                             if (k == K - 1)
@@ -1160,8 +1199,10 @@ __global__ __launch_bounds__(1024) void tile_chisq_kernel(
 #pragma unroll
         for (int g = 0; g < 16; ++g)
             s_x[g * 1024 + l] = part[g];
-        if (cb + 16 < c1)
-            stage_coefficients(cb + 16, buf ^ 1);
+        if constexpr (KX == 0) {
+            if (cb + 16 < c1)
+                stage_coefficients(cb + 16, buf ^ 1);
+        }
         block_sync<16>();
         {
             const int lc = cb + wv;                     // wave wv reduces chain cb + wv

@@ -273,15 +273,21 @@ void launch_finish_t(mc3hip_ctx *c, int roff, int j)
 // LDS of the tile kernel: 16 chains x 1024 partial sums + two buffers of 16 coefficient rows
 constexpr size_t TILE_LDS_BYTES = (16 * 1024 + 2 * 16 * (16 + 2)) * sizeof(double);
 
-template <int KMAX, bool LINEAR>
+template <int KMAX, bool LINEAR, int KX = 0>
 void launch_tile_t(mc3hip_ctx *c)
 {
     const int ncol = (c->P.nlocal + c->tile_chain_block - 1) / c->tile_chain_block;
     constexpr int TP = KMAX <= 4 ? 4 : 2;
-    hipLaunchKernelGGL((tile_chisq_kernel<KMAX, LINEAR, TP>), dim3(c->P.ntiles, ncol),
+    hipLaunchKernelGGL((tile_chisq_kernel<KMAX, LINEAR, TP, KX>), dim3(c->P.ntiles, ncol),
                        dim3(1024), TILE_LDS_BYTES, c->stream, c->P,
                        c->tile_chain_block, (const double *)c->P.sc_nextp,
                        (const int32_t *)c->P.sc_flag);
+}
+
+// polynomials of 2..4 coefficients: the instance with the degree compiled in
+int tile_exact_degree(const mc3hip_ctx *c)
+{
+    return (c->mt != MT_LINEAR && c->tile_kmax == 4 && c->P.nmodel >= 2) ? c->P.nmodel : 0;
 }
 
 int tile_set_attr(mc3hip_ctx *c)
@@ -292,6 +298,17 @@ int tile_set_attr(mc3hip_ctx *c)
         reinterpret_cast<const void *>(&tile_chisq_kernel<KMAX, LIN, (KMAX <= 4 ? 4 : 2)>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     const bool lin = c->mt == MT_LINEAR;
+#define TILE_ATTR_X(KX)                                                                    \
+    HIP_TRY(hipFuncSetAttribute(                                                           \
+        reinterpret_cast<const void *>(&tile_chisq_kernel<4, false, 4, KX>),               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    switch (tile_exact_degree(c)) {
+    case 2: TILE_ATTR_X(2) return MC3HIP_OK;
+    case 3: TILE_ATTR_X(3) return MC3HIP_OK;
+    case 4: TILE_ATTR_X(4) return MC3HIP_OK;
+    default: break;
+    }
+#undef TILE_ATTR_X
     switch (c->tile_kmax) {
     case 4: if (lin) { TILE_ATTR(4, true) } else { TILE_ATTR(4, false) } break;
     case 8: if (lin) { TILE_ATTR(8, true) } else { TILE_ATTR(8, false) } break;
@@ -326,6 +343,12 @@ void launch_tile(mc3hip_ctx *c)
         default: launch_tile_mfma_t<4>(c); break;
         }
         return;
+    }
+    switch (tile_exact_degree(c)) {
+    case 2: launch_tile_t<4, false, 2>(c); return;
+    case 3: launch_tile_t<4, false, 3>(c); return;
+    case 4: launch_tile_t<4, false, 4>(c); return;
+    default: break;
     }
     const bool lin = c->mt == MT_LINEAR;
     switch (c->tile_kmax) {

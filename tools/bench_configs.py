@@ -51,11 +51,14 @@ CONFIGS = {
     'c5': lambda n: (H.linear_problem(ndata=100000, nchains=512, nsamples=512*n), {}),
     'c5share': lambda n: (H.linear_problem(ndata=100000, nchains=512, nsamples=512*n),
                           dict(chain0=0, nlocal=128)),
+    # the tiled plan of polynomial models (vector tile kernel, three launches per iteration)
+    'q5': lambda n: (H.quad_problem(ndata=100000, nchains=512, nsamples=512*n), {}),
 }
-BYTES = {'c4mrw': 8*2*16384 + 8*5*4 + 8, 'c4demc': 8*2*16384 + 8*5*4 + 8, 'c4half': 8*2*16384 + 8*5*4 + 8, 'c2': 24104, 'c2snooker': 24104, 'c3one': 24104, 'c4': 8*2*16384 + 8*5*4 + 8,
+BYTES = {'q5': 8*3*100000 + 8*3*4 + 8, 'c4mrw': 8*2*16384 + 8*5*4 + 8, 'c4demc': 8*2*16384 + 8*5*4 + 8, 'c4half': 8*2*16384 + 8*5*4 + 8, 'c2': 24104, 'c2snooker': 24104, 'c3one': 24104, 'c4': 8*2*16384 + 8*5*4 + 8,
          'c5': 8*12*100000 + 8*10*4 + 8, 'c5share': 8*12*100000 + 8*10*4 + 8}
 ITERS = {'c2': 20000, 'c2snooker': 20000, 'c3one': 4000, 'c4': 4000, 'c5': 30, 'c5share': 1}
 ITERS['c5'] = 300
+ITERS['q5'] = 300
 ITERS.update(c4mrw=4000, c4demc=4000, c4half=4000)
 
 
