@@ -1646,8 +1646,123 @@ __device__ __forceinline__ void demc_partners(uint64_t q0, int n, int c, int &r1
 // coefficient -1 (D = model - data, the same single rounding as the subtraction it replaces).
 // Same arithmetic and the same summation order as tile_chisq_mfma_kernel: the oracle does not
 // know which of the two ran.
+// What the owner of a chain does around the tile phase, whatever computes the tile sums
+// (ResidentTile: design matrices through the matrix cores; ResidentPoly: polynomials on the
+// vector unit).
+struct ResidentOwner {
+    int lane;
+    int par;                // parity of the iteration whose proposals are used next
+    bool failed;            // a wait of this wave timed out: said at the next agreement point
+    // owner waves: their LDS area ([0..63]: the Gaussian priors as index, centre, lower and
+    // upper width, 16 each)
+    double *s_own;
+
+    // this wave owns chain lc; `area` is its run_chain LDS area (whose first 64 doubles
+    // run_chain does not use here)
+    __device__ __forceinline__ void set_owner(const DevProblem &P, int lc, double *area)
+    {
+        s_own = area;
+        if (P.ngprior <= 16 && lane < P.ngprior) {
+            const int jp = P.igprior[lane];
+            area[lane] = (double)jp;
+            area[16 + lane] = P.prior[jp];
+            area[32 + lane] = P.priorlow[jp];
+            area[48 + lane] = P.priorup[jp];
+        }
+    }
+
+    // owner, before the tile phase: the proposed coefficients of chain lc for everybody
+    __device__ __forceinline__ void publish(const DevProblem &P, int lc, const double *s_nextp)
+    {
+        // (the slots handed back during the previous iteration have landed before the row
+        // that lets anybody write them again leaves)
+        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+        if (lane < RS_ROW) {
+            const int K = P.nmodel;
+            double v = (lane < K) ? s_nextp[lane] : ((lane == K) ? -1.0 : 0.0);
+            if (mc3_bits(v) == ROW_PENDING)
+                v = mc3_from_bits(0x7ff8000000000000ull);
+            __hip_atomic_store(&P.rs_prop[((size_t)par * P.nlocal + lc) * RS_ROW + lane], v,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+    // owner, after the tile phase: the data sum of chain lc, tiles added in order; hands the
+    // slots and the row this iteration used back
+    __device__ __forceinline__ double collect(const DevProblem &P, int lc)
+    {
+        long long *ctl = const_cast<long long *>(P.ctl);
+        double *row = P.rs_part + (size_t)lc * P.rs_ntp;
+        double total = 0.0;
+        for (int t0 = 0; t0 < P.ntiles; t0 += 64) {
+            const int n = (P.ntiles - t0 < 64) ? P.ntiles - t0 : 64;
+            double *mine = row + t0 + (lane < n ? lane : 0);
+            const double *const addr[1] = {mine};
+            double val[1] = {load_published(mine)};
+            if (!wait_rows<1>(addr, val, ctl))
+                failed = true;
+            // (in order, eight broadcasts at a time ahead of their dependent additions)
+            int k = 0;
+            for (; k + 8 <= n; k += 8) {
+                double v8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v8[u] = read_lane(val[0], k + u);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    total = total + v8[u];
+            }
+            for (; k < n; ++k)
+                total = total + read_lane(val[0], k);
+            if (lane < n)
+                __hip_atomic_store(mine, mc3_from_bits(ROW_PENDING), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane < RS_ROW)
+            __hip_atomic_store(&P.rs_prop[((size_t)(par ^ 1) * P.nlocal + lc) * RS_ROW + lane],
+                               mc3_from_bits(ROW_PENDING), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        return total;
+    }
+
+    // the chisq of the proposal from that sum (finish_chisq of the three-launch plan)
+    template <int MT>
+    __device__ __forceinline__ double finish(const DevProblem &P, double total,
+                                             const double *s_nextp) const
+    {
+        const bool finite = (mc3_bits(total) & 0x7ff0000000000000ull) != 0x7ff0000000000000ull;
+        if (!finite) {
+            Model<MT> model;
+            model.init(P, s_nextp);
+            int saw = 0;
+            for (int i = lane; i < P.ndata; i += 64)
+                saw |= is_pos_inf(model.at(i));
+            if (__any(saw))
+                return mc3_from_bits(0x7ff0000000000000ull);
+        }
+        if (is_pos_inf(total))
+            return total;
+        if (P.ngprior > 16)
+            return total + prior_term(P, s_nextp);
+        // prior_term from the LDS copy of its constants: lane g works out term g (the
+        // divisions side by side instead of one after the other), then the terms are added
+        // in order
+        double term = 0.0;
+        if (lane < P.ngprior) {
+            const int jp = (int)s_own[lane];
+            const double d = s_nextp[jp] - s_own[16 + lane];
+            const double sd = (d > 0.0) ? d / s_own[48 + lane] : d / s_own[32 + lane];
+            term = sd * sd;
+        }
+        double pr = 0.0;
+        for (int gp = 0; gp < P.ngprior; ++gp)
+            pr = pr + read_lane(term, gp);
+        return total + pr;
+    }
+};
+
 template <int KB>
-struct ResidentTile {
+struct ResidentTile : ResidentOwner {
     // operand rows of the tile: blocks of four rows in registers, except -- with three of
     // them -- the last, which lives in LDS (64 KB; one read per product): 96 registers of
     // tile plus the products in flight plus the chain state of an owner wave do not fit 256
@@ -1657,12 +1772,7 @@ struct ResidentTile {
     double *s_w;            // LDS [RS_WCAP][16]: group totals of the chains done so far
     const double *s_ww;     // LDS [2048]: the weights of the tile's points (this wave's: + 128 wv)
     int *s_stop;            // LDS: a wave of this workgroup has given up
-    int t, c0, c1, wv, lane;
-    int par;                // parity of the iteration whose proposals are used next
-    bool failed;            // a wait of this wave timed out: said at the next agreement point
-    // owner waves: their LDS area ([0..63]: the Gaussian priors as index, centre, lower and
-    // upper width, 16 each)
-    double *s_own;
+    int t, c0, c1, wv;
 
     __device__ __forceinline__ void load(const DevProblem &P, int tile, int col, int chain_block,
                                          double *lds_w, int *lds_stop, double *lds_ww,
@@ -1702,20 +1812,6 @@ struct ResidentTile {
             }
         }
         s_ww = lds_ww + 128 * wv + j;
-    }
-
-    // this wave owns chain lc; `area` is its run_chain LDS area (whose first 64 doubles
-    // run_chain does not use here)
-    __device__ __forceinline__ void set_owner(const DevProblem &P, int lc, double *area)
-    {
-        s_own = area;
-        if (P.ngprior <= 16 && lane < P.ngprior) {
-            const int jp = P.igprior[lane];
-            area[lane] = (double)jp;
-            area[16 + lane] = P.prior[jp];
-            area[32 + lane] = P.priorlow[jp];
-            area[48 + lane] = P.priorup[jp];
-        }
     }
 
     // every wave of the workgroup, once per iteration; false (for all of them) = give up
@@ -1872,93 +1968,121 @@ struct ResidentTile {
         return true;
     }
 
-    // owner, before the tile phase: the proposed coefficients of chain lc for everybody
-    __device__ __forceinline__ void publish(const DevProblem &P, int lc, const double *s_nextp)
+};
+
+// The same one-launch plan for polynomials of KX = 2..4 coefficients (tile_chisq_kernel's
+// arithmetic: Horner on the vector unit, 4096 points per tile, lanes first -- one halving tree
+// over the tile's 1024 strided partial sums).  Eight waves: thread l owns virtual lanes l and
+// l + 512 with four points each (x, data, weight: 48 registers), so the first level of the
+// tree is an addition inside the thread; 16 chains at a time, their 64 coefficients one per
+// lane (v_readlane hands them to the scalar unit); the 512 partial sums of a chain cross the
+// workgroup through LDS (two buffers of 16 x 512: one barrier per block of chains), wave v
+// finishes chains 2 v and 2 v + 1.
+template <int KX>
+struct ResidentPoly : ResidentOwner {
+    double x[2][4], d[2][4], w[2][4];
+    double *s_x;            // LDS [2][16][512]
+    int *s_stop;
+    int t, c0, c1, wv;
+
+    __device__ __forceinline__ void load(const DevProblem &P, int tile, int col, int chain_block,
+                                         double *lds_x, int *lds_stop)
     {
-        // (the slots handed back during the previous iteration have landed before the row
-        // that lets anybody write them again leaves)
-        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
-        if (lane < RS_ROW) {
-            const int K = P.nmodel;
-            double v = (lane < K) ? s_nextp[lane] : ((lane == K) ? -1.0 : 0.0);
-            if (mc3_bits(v) == ROW_PENDING)
-                v = mc3_from_bits(0x7ff8000000000000ull);
-            __hip_atomic_store(&P.rs_prop[((size_t)par * P.nlocal + lc) * RS_ROW + lane], v,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_x = lds_x;
+        s_stop = lds_stop;
+        t = tile;
+        c0 = col * chain_block;
+        c1 = (c0 + chain_block < P.nlocal) ? c0 + chain_block : P.nlocal;
+        lane = threadIdx.x & 63;
+        wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        par = 0;
+        failed = false;
+        s_own = nullptr;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const size_t i = (size_t)t * 4096 + threadIdx.x + 512 * v + 1024 * q;
+                x[v][q] = P.indep[i];
+                d[v][q] = P.data[i];
+                w[v][q] = P.w[i];
+            }
         }
     }
 
-    // owner, after the tile phase: the data sum of chain lc, tiles added in order; hands the
-    // slots and the row this iteration used back
-    __device__ __forceinline__ double collect(const DevProblem &P, int lc)
+    __device__ __forceinline__ bool tile_phase(const DevProblem &P, bool alive_in)
     {
+        if (!alive_in || failed)
+            *s_stop = 1;
+        block_sync<8>();
+        if (*s_stop != 0)
+            return false;
         long long *ctl = const_cast<long long *>(P.ctl);
-        double *row = P.rs_part + (size_t)lc * P.rs_ntp;
-        double total = 0.0;
-        for (int t0 = 0; t0 < P.ntiles; t0 += 64) {
-            const int n = (P.ntiles - t0 < 64) ? P.ntiles - t0 : 64;
-            double *mine = row + t0 + (lane < n ? lane : 0);
-            const double *const addr[1] = {mine};
-            double val[1] = {load_published(mine)};
+        const double *prop = P.rs_prop + (size_t)par * P.nlocal * RS_ROW;
+        const int l = threadIdx.x;
+        const double *addr[1];
+        double val[1];
+        auto request = [&](int cb) {
+            const int lc = (cb + (lane >> 2) < c1) ? cb + (lane >> 2) : c1 - 1;
+            addr[0] = prop + (size_t)lc * RS_ROW + (lane & 3);
+            val[0] = load_published(addr[0]);
+        };
+        request(c0);
+        int buf = 0;
+        for (int cb = c0; cb < c1; cb += 16, buf ^= 1) {
             if (!wait_rows<1>(addr, val, ctl))
                 failed = true;
-            // (in order, eight broadcasts at a time ahead of their dependent additions)
-            int k = 0;
-            for (; k + 8 <= n; k += 8) {
-                double v8[8];
+            const double cfv = val[0];
+            if (cb + 16 < c1)
+                request(cb + 16);              // the next block's rows travel behind this one
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    v8[u] = read_lane(val[0], k + u);
+            for (int g = 0; g < 16; ++g) {
+                double cf[KX];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    total = total + v8[u];
+                for (int k = 0; k < KX; ++k)
+                    cf[k] = read_lane(cfv, 4 * g + k);
+                double acc[2];
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    acc[v] = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        double m = cf[KX - 1];            // Horner from coefficient K-1 down
+#pragma unroll
+                        for (int k = KX - 2; k >= 0; --k)
+                            m = mc3_fma(m, x[v][q], cf[k]);
+                        const double r = (m - d[v][q]) * w[v][q];
+                        acc[v] = mc3_fma(r, r, acc[v]);
+                    }
+                }
+                s_x[(buf * 16 + g) * 512 + l] = acc[0] + acc[1];       // stride 512
             }
-            for (; k < n; ++k)
-                total = total + read_lane(val[0], k);
-            if (lane < n)
-                __hip_atomic_store(mine, mc3_from_bits(ROW_PENDING), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            block_sync<8>();
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const int ch = 2 * wv + cc;
+                double p[8];
+#pragma unroll
+                for (int w2 = 0; w2 < 8; ++w2)
+                    p[w2] = s_x[(buf * 16 + ch) * 512 + lane + 64 * w2];
+#pragma unroll
+                for (int s2 = 4; s2 >= 1; s2 >>= 1) {                 // strides 256, 128, 64
+#pragma unroll
+                    for (int w2 = 0; w2 < s2; ++w2)
+                        p[w2] = p[w2] + p[w2 + s2];
+                }
+                double tot = wave_sum(p[0]);                          // strides 32..1
+                if (mc3_bits(tot) == ROW_PENDING)      // (a NaN that looks like "not there yet")
+                    tot = mc3_from_bits(0x7ff8000000000000ull);
+                if (lane == 0 && cb + ch < c1)
+                    __hip_atomic_store(&P.rs_part[(size_t)(cb + ch) * P.rs_ntp + t], tot,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // (no second barrier: the next block writes the other buffer, and this one is not
+            // written again before everybody has passed the next barrier)
         }
-        if (lane < RS_ROW)
-            __hip_atomic_store(&P.rs_prop[((size_t)(par ^ 1) * P.nlocal + lc) * RS_ROW + lane],
-                               mc3_from_bits(ROW_PENDING), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        return total;
-    }
-
-    // the chisq of the proposal from that sum (finish_chisq of the three-launch plan)
-    template <int MT>
-    __device__ __forceinline__ double finish(const DevProblem &P, double total,
-                                             const double *s_nextp) const
-    {
-        const bool finite = (mc3_bits(total) & 0x7ff0000000000000ull) != 0x7ff0000000000000ull;
-        if (!finite) {
-            Model<MT> model;
-            model.init(P, s_nextp);
-            int saw = 0;
-            for (int i = lane; i < P.ndata; i += 64)
-                saw |= is_pos_inf(model.at(i));
-            if (__any(saw))
-                return mc3_from_bits(0x7ff0000000000000ull);
-        }
-        if (is_pos_inf(total))
-            return total;
-        if (P.ngprior > 16)
-            return total + prior_term(P, s_nextp);
-        // prior_term from the LDS copy of its constants: lane g works out term g (the
-        // divisions side by side instead of one after the other), then the terms are added
-        // in order
-        double term = 0.0;
-        if (lane < P.ngprior) {
-            const int jp = (int)s_own[lane];
-            const double d = s_nextp[jp] - s_own[16 + lane];
-            const double sd = (d > 0.0) ? d / s_own[48 + lane] : d / s_own[32 + lane];
-            term = sd * sd;
-        }
-        double pr = 0.0;
-        for (int gp = 0; gp < P.ngprior; ++gp)
-            pr = pr + read_lane(term, gp);
-        return total + pr;
+        par ^= 1;
+        return true;
     }
 };
 
@@ -2606,6 +2730,39 @@ __global__ __launch_bounds__(512) void resident_tile_kernel(const DevProblem P, 
                                     smem + W + 2 + wv * OWN);
     } else {
         // no chain of its own: the tile phase of every iteration, in step with the owners
+        for (int R = 0; R < nref; ++R)
+            for (int j = 0; j < P.thinning; ++j)
+                if (!T.tile_phase(P, true))
+                    return;
+    }
+}
+
+template <int KX, bool P2P = false>
+__global__ __launch_bounds__(512) void resident_poly_kernel(const DevProblem P, const int nref,
+                                                            const int chain_block)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int OWN = 64 + MC3HIP_MAX_PARAMS + 2 + 48 + 4;     // carve() of a one-wave chain
+    constexpr int X = 2 * 16 * 512;                              // the exchange buffers
+    int *s_stop = reinterpret_cast<int *>(smem + X);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    ResidentPoly<KX> T;
+    T.load(P, blockIdx.x, blockIdx.y, chain_block, smem, s_stop);
+    // a launch queued behind one that gave up must not run: its inputs are missing
+    if (threadIdx.x == 0)
+        *s_stop = (__hip_atomic_load(&P.ctl[CTL_ABORT], __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0;
+    block_sync<8>();
+    if (*s_stop != 0)
+        return;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    const int own_chain = wg + (int)(gridDim.x * gridDim.y) * wv;
+    if (own_chain < P.nlocal) {
+        T.set_owner(P, own_chain, smem + X + 2 + wv * OWN);
+        run_chain<1, KX, false, false, true, -1, false, PH_RESIDENT, P2P, 0, false,
+                  ResidentPoly<KX>>(P, P.ctl[0], nref, 0, -1, &T, own_chain,
+                                    smem + X + 2 + wv * OWN);
+    } else {
         for (int R = 0; R < nref; ++R)
             for (int j = 0; j < P.thinning; ++j)
                 if (!T.tile_phase(P, true))

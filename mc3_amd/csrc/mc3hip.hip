@@ -375,22 +375,43 @@ void launch_refresh_tiled(mc3hip_ctx *c, int roff)
 constexpr size_t RESIDENT_OWN = 64 + MC3HIP_MAX_PARAMS + 2 + 48 + 4;
 constexpr size_t RESIDENT_LDS_BYTES =
     (RS_WCAP * 16 + 2 + 8 * RESIDENT_OWN + 2048 + 16 * 512) * sizeof(double);
+// polynomials (ResidentPoly): two exchange buffers [16][512], the give-up word, the areas
+constexpr size_t RESIDENT_POLY_LDS_BYTES = (2 * 16 * 512 + 2 + 8 * RESIDENT_OWN) * sizeof(double);
 
 typedef void (*resident_kernel_fn)(const DevProblem, const int, const int);
 
+// design-matrix models through the matrix cores, or polynomials of 2..4 coefficients
+bool resident_poly(const mc3hip_ctx *c)
+{
+    return c->mt != MT_LINEAR && c->P.tile == 4096 && tile_exact_degree(c) >= 2;
+}
+
+size_t resident_lds_bytes(const mc3hip_ctx *c)
+{
+    return resident_poly(c) ? RESIDENT_POLY_LDS_BYTES : RESIDENT_LDS_BYTES;
+}
+
 resident_kernel_fn resident_kernel(const mc3hip_ctx *c, bool p2p)
 {
+    if (resident_poly(c)) {
+        switch (c->P.nmodel) {
+        case 2: return p2p ? resident_poly_kernel<2, true> : resident_poly_kernel<2, false>;
+        case 3: return p2p ? resident_poly_kernel<3, true> : resident_poly_kernel<3, false>;
+        default: return p2p ? resident_poly_kernel<4, true> : resident_poly_kernel<4, false>;
+        }
+    }
     if ((c->P.nmodel + 4) / 4 == 2)           // operand rows: coefficients + the data column
         return p2p ? resident_tile_kernel<2, true> : resident_tile_kernel<2, false>;
     return p2p ? resident_tile_kernel<3, true> : resident_tile_kernel<3, false>;
 }
 
-// the problem has the shape the resident kernel is written for (whether its grid fits the
+// the problem has the shape a resident kernel is written for (whether its grid fits the
 // device is decide_persist's question)
 bool resident_shape(const mc3hip_ctx *c)
 {
-    return tile_uses_mfma(c) && c->P.nmodel >= 5 && c->P.nmodel <= 11 && c->P.rs_prop &&
-           c->comm == nullptr && !getenv("MC3HIP_NO_RESIDENT");
+    const bool mfma = tile_uses_mfma(c) && c->P.nmodel >= 5 && c->P.nmodel <= 11;
+    return (mfma || resident_poly(c)) && c->P.rs_prop && c->comm == nullptr &&
+           !getenv("MC3HIP_NO_RESIDENT");
 }
 
 void launch_resident(mc3hip_ctx *c, int nref)
@@ -398,7 +419,7 @@ void launch_resident(mc3hip_ctx *c, int nref)
     const int cb = c->resident_chain_block;
     const int ncol = (c->P.nlocal + cb - 1) / cb;
     hipLaunchKernelGGL(resident_kernel(c, c->p2p_ranks > 1), dim3(c->P.ntiles, ncol), dim3(512),
-                       RESIDENT_LDS_BYTES, c->stream, c->P, nref, cb);
+                       resident_lds_bytes(c), c->stream, c->P, nref, cb);
 }
 
 // the lean persistent instance applies when nothing of the general machinery is
@@ -639,8 +660,8 @@ int decide_persist(mc3hip_ctx *c)
                 continue;
             const void *f = reinterpret_cast<const void *>(resident_kernel(c, p2p != 0));
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)RESIDENT_LDS_BYTES);
-            const int nb = blocks_per_cu(f, 512, RESIDENT_LDS_BYTES);
+                                      (int)resident_lds_bytes(c));
+            const int nb = blocks_per_cu(f, 512, resident_lds_bytes(c));
             per_cu = nb < per_cu ? nb : per_cu;
         }
         const long long capacity = (long long)per_cu * prop.multiProcessorCount;
@@ -1077,7 +1098,8 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         TRY(dev_alloc(c, &P.sc_scal, nl * 2));
         TRY(dev_alloc(c, &P.sc_flag, nl));
         TRY(dev_alloc(c, &P.sc_part, nl * (size_t)P.ntiles));
-        if (pr->model_kind == MC3HIP_MODEL_LINEAR && P.tile == 2048) {
+        if ((pr->model_kind == MC3HIP_MODEL_LINEAR && P.tile == 2048) ||
+            (pr->model_kind != MC3HIP_MODEL_LINEAR && P.tile == 4096 && pr->nmodel >= 2)) {
             // hand-off areas of the resident tiled plan, all-ones = "not there yet"
             P.rs_ntp = (P.ntiles + 15) / 16 * 16;
             TRY(dev_alloc(c, &P.rs_prop, 2 * nl * (size_t)RS_ROW));

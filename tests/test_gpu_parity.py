@@ -639,11 +639,18 @@ def test_tiled_plan_bit_exact(eng, kind, sampler, thinning):
         prob['params'][5] = prob['params'][1]
     orc, gpu = run_pair(eng, prob)
     assert gpu.plan['tile'] == (4096 if kind == 'poly' else 2048)
-    # (design-matrix models: one persistent launch, tests/test_gpu_resident.py; polynomials:
-    # proposal / tile sums / finish as three launches per iteration)
-    assert (gpu.plan['persistent'] > 0) == (kind == 'linear')
-    assert gpu.plan['resident'] == (1 if kind == 'linear' else 0)
+    # (one persistent launch, tests/test_gpu_resident.py; MC3HIP_NO_RESIDENT: proposal / tile
+    # sums / finish as three launches per iteration)
+    assert gpu.plan['persistent'] > 0 and gpu.plan['resident'] == 1
     assert_same(orc, gpu)
+    os.environ['MC3HIP_NO_RESIDENT'] = '1'
+    try:
+        orc3, gpu3 = run_pair(eng, prob)
+        assert gpu3.plan['persistent'] == 0 and gpu3.plan['resident'] == 0
+        assert_same(orc3, gpu3)
+        gpu3.close()
+    finally:
+        del os.environ['MC3HIP_NO_RESIDENT']
     # the fused plan (one workgroup streams all the data for its chain) gives the
     # same chains up to the summation order: compare chisq of stored rows
     Z, lp, zc = gpu.rows()

@@ -191,3 +191,94 @@ def test_resident_column_longer_than_the_lds_window(eng):
         assert gpu.plan['resident'] == 1
         assert_same(orc, gpu)
         gpu.close()
+
+
+# ---- polynomials of 2..4 coefficients: the vector-unit flavour (ResidentPoly) --------------
+def poly(ncoef, ndata=20000, nchains=40, niter=25, sampler='demc', thinning=1, **kw):
+    """The tutorial's quadratic data fitted with a polynomial of `ncoef` coefficients."""
+    prob = H.quad_problem(ndata=ndata, nchains=nchains, nsamples=nchains*niter*thinning,
+                          sampler=sampler, thinning=thinning, **kw)
+    params = np.array([10.0, -2.0, 0.1, 0.001])[:ncoef]
+    pstep = np.array([1.0, 0.5, 0.1, 0.002])[:ncoef]
+    pmin = np.array([-10.0, -20.0, -10.0, -1.0])[:ncoef]
+    pmax = np.array([40.0, 20.0, 10.0, 1.0])[:ncoef]
+    prob.update(params=params, pstep=pstep, pmin=pmin, pmax=pmax)
+    for key in ('prior', 'priorlow', 'priorup'):
+        if key in prob:
+            prob[key] = np.resize(prob[key], ncoef)
+    return prob
+
+
+@pytest.mark.parametrize('ncoef,sampler,thinning', [
+    (3, 'demc', 1), (3, 'snooker', 1), (3, 'mrw', 2), (2, 'demc', 3), (4, 'snooker', 2),
+    (4, 'demc', 1)])
+def test_resident_polynomial_bit_exact(eng, ncoef, sampler, thinning):
+    """20 000 points = 5 tiles of 4096, 40 chains = 3 columns: proposals, Horner sums on the
+    vector unit and accept in one persistent launch; priors and bounds; summation order of
+    the three-launch plan (lanes first), so the same oracle."""
+    prob = poly(ncoef, sampler=sampler, thinning=thinning,
+                prior=np.array([3.0, 0.0, 0.5]), priorlow=np.array([0.5, 0.0, 0.02]),
+                priorup=np.array([0.25, 0.0, 0.04]))
+    orc, gpu = run_pair(eng, prob)
+    assert gpu.plan['tile'] == 4096 and gpu.plan['tile_tree'] == 0
+    assert gpu.plan['resident'] == 1 and gpu.plan['persistent'] > 0
+    assert_same(orc, gpu)
+    assert gpu.plan['recoveries'] == 0
+    gpu.close()
+
+
+def test_resident_polynomial_shared_and_fixed(eng):
+    """A shared and a fixed coefficient (the general run_chain carries them)."""
+    prob = poly(4, sampler='snooker')
+    prob['pstep'] = prob['pstep'].copy()
+    prob['params'] = prob['params'].copy()
+    prob['pstep'][3] = 0.0                  # fixed
+    prob['pstep'][2] = -2                   # shared with parameter 1
+    prob['params'][2] = prob['params'][1]
+    prob['pmin'] = prob['pmin'].copy()
+    prob['pmax'] = prob['pmax'].copy()
+    prob['pmin'][2], prob['pmax'][2] = prob['pmin'][1], prob['pmax'][1]
+    orc, gpu = run_pair(eng, prob)
+    assert gpu.plan['resident'] == 1
+    assert_same(orc, gpu)
+    gpu.close()
+
+
+@pytest.mark.parametrize('case', range(8))
+def test_resident_polynomial_random_problems(eng, case):
+    rs = np.random.RandomState(7000 + case)
+    ncoef = int(rs.randint(2, 5))
+    nchains = int(rs.randint(16, 120))
+    ndata = int(rs.randint(16384, 70000))
+    sampler = ['demc', 'snooker', 'mrw'][case % 3]
+    thinning = int(rs.choice([1, 1, 2]))
+    kw = {'fepsilon': 0.01} if (sampler != 'mrw' and rs.rand() < 0.5) else {}
+    prob = poly(ncoef, ndata=ndata, nchains=nchains, niter=10, sampler=sampler,
+                thinning=thinning, **kw)
+    orc, gpu = run_pair(eng, prob)
+    assert gpu.plan['resident'] == 1, (ncoef, nchains, ndata)
+    assert_same(orc, gpu)
+    gpu.close()
+
+
+def test_resident_polynomial_gives_up_and_is_redone(eng):
+    prob = poly(3, niter=25)
+    with env(MC3HIP_TEST_ABORT_AT=9):
+        orc, gpu = run_pair(eng, prob, nrefresh=20)
+    assert gpu.plan['recoveries'] == 1 and gpu.plan['persistent'] == 0
+    tc, tf = gpu.trace(20)
+    np.testing.assert_array_equal(tf, orc.trace_flag)
+    np.testing.assert_array_equal(tc, orc.trace_chisq)
+    gpu.run(5)
+    orc.run(nrefresh=5, trace=False, nthreads=4)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
+def test_resident_polynomial_large(eng):
+    """512 chains x 1e5 points (25 tiles x 10 columns = 250 workgroups), the quadratic."""
+    prob = H.quad_problem(ndata=100000, nchains=512, nsamples=512*6)
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert gpu.plan['resident'] == 1
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
