@@ -29,8 +29,12 @@ def main():
         os.environ['MC3HIP_TEST_ABORT_AT'] = str(abort_at)
     comm = parallel.TorchDistComm(use_p2p=True, use_rccl=False)
     nchains = per_rank*comm.size
-    prob = H.linear_problem(ndata=ndata, nmodel=nmodel, nchains=nchains,
-                            nsamples=nchains*nref, sampler=sampler)
+    if nmodel == 3:         # (the polynomial flavour: the tutorial's quadratic)
+        prob = H.quad_problem(ndata=ndata, nchains=nchains, nsamples=nchains*nref,
+                              sampler=sampler)
+    else:
+        prob = H.linear_problem(ndata=ndata, nmodel=nmodel, nchains=nchains,
+                                nsamples=nchains*nref, sampler=sampler)
     pop = np.load(out_path + '.pop.npz')
     c0, n = comm.partition(nchains)
     trace = int(os.environ.get('C5_WORKER_TRACE', '0'))

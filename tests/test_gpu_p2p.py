@@ -97,7 +97,8 @@ def test_config_c3_eight_ranks_of_256_chains(tmp_path):
 
 
 @pytest.mark.parametrize('nranks,per_rank,ndata,nmodel,sampler', [
-    (2, 48, 20000, 7, 'demc'), (4, 32, 30000, 10, 'snooker'), (4, 128, 100000, 10, 'demc')])
+    (2, 48, 20000, 7, 'demc'), (4, 32, 30000, 10, 'snooker'), (4, 128, 100000, 10, 'demc'),
+    (2, 48, 40000, 3, 'demc'), (4, 32, 40000, 3, 'snooker')])
 def test_resident_tiled_plan_sharded_over_ranks(tmp_path, nranks, per_rank, ndata, nmodel,
                                                 sampler):
     """The tiled plan in one launch per rank (resident_tile_kernel<KB, P2P>), the ensemble
@@ -108,9 +109,15 @@ def test_resident_tiled_plan_sharded_over_ranks(tmp_path, nranks, per_rank, ndat
     the whole ensemble."""
     nref = 12
     nchains = nranks*per_rank
-    prob = H.linear_problem(ndata=ndata, nmodel=nmodel, nchains=nchains,
-                            nsamples=nchains*nref, sampler=sampler)
-    orc = H.make_oracle(prob, plan={'tile': 2048, 'vlanes': 1024, 'tile_tree': 1})
+    if nmodel == 3:         # the polynomial flavour (resident_poly_kernel<3, P2P>)
+        prob = H.quad_problem(ndata=ndata, nchains=nchains, nsamples=nchains*nref,
+                              sampler=sampler)
+        plan = {'tile': 4096, 'vlanes': 1024, 'tile_tree': 0}
+    else:
+        prob = H.linear_problem(ndata=ndata, nmodel=nmodel, nchains=nchains,
+                                nsamples=nchains*nref, sampler=sampler)
+        plan = {'tile': 2048, 'vlanes': 1024, 'tile_tree': 1}
+    orc = H.make_oracle(prob, plan=plan)
     Z0, lp0 = H.initial_population(orc)
     out_path = str(tmp_path / 'c5')
     np.savez(out_path + '.pop.npz', Z0=Z0, lp0=lp0)
