@@ -113,8 +113,10 @@ typedef struct mc3hip_plan {
                                time (strides 32..1), then the 16 group totals (8..1): the
                                matrix-core tile kernel                                          */
     int32_t resident;       /* 1 = tiled plan in ONE persistent launch: every workgroup keeps
-                               its tile of the design matrix in registers, proposals and
-                               per-tile sums are handed over inside the launch              */
+                               its tile of the data (and of the design matrix) on chip,
+                               proposals and per-tile sums are handed over inside the
+                               launch (design matrices of 5..11 columns, polynomials of
+                               2..4 coefficients)                                          */
 } mc3hip_plan;
 
 /* Replaces Chain.__init__ + the shared-memory allocation of mcmc()

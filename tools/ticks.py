@@ -18,14 +18,17 @@ import bench  # noqa: E402
 # python tools/ticks.py [thinning]          C2 (lean kernels)
 # python tools/ticks.py c4                  C4's data with sampler='demc' (the general
 #                                           persistent kernel keeps tick sums for demc only)
-if len(sys.argv) > 1 and sys.argv[1] == 'c5':
-    # python tools/ticks.py c5     the resident tiled plan: phases of chain 0's owner wave
+if len(sys.argv) > 1 and sys.argv[1] in ('c5', 'q5'):
+    # python tools/ticks.py c5 | q5     the resident tiled plans: phases of chain 0's owner wave
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import helpers as H
     import tools_pop
     NIT = 400
-    prob = H.linear_problem(ndata=100000, nchains=512, nsamples=512*(NIT + 60))
+    if sys.argv[1] == 'q5':     # the polynomial flavour of the resident plan
+        prob = H.quad_problem(ndata=100000, nchains=512, nsamples=512*(NIT + 60))
+    else:
+        prob = H.linear_problem(ndata=100000, nchains=512, nsamples=512*(NIT + 60))
     g = engine.DeviceChains(**prob)
     Z0, lp0 = tools_pop.population(g)
     g.set_population(Z0, lp0)
