@@ -31,11 +31,27 @@ def hipcc():
     return exe
 
 
+STAMP = LIB + '.srchash'
+
+
+def source_hash():
+    """Content hash of everything the library is compiled from (and of the flags)."""
+    import hashlib
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    for d in DEPS:
+        with open(d, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def is_stale():
-    if not os.path.exists(LIB):
+    """The library is rebuilt when it is missing or was built from other sources: decided
+    by content, not by modification times (a copy of the tree to another machine need not
+    preserve those, and a spurious rebuild costs minutes)."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    with open(STAMP) as f:
+        return f.read().strip() != source_hash()
 
 
 def build(force=False, verbose=False):
@@ -45,6 +61,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
+    with open(STAMP, 'w') as f:
+        f.write(source_hash() + '\n')
     return LIB
 
 
