@@ -994,9 +994,22 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         // repeat the last point, w = 1/uncert (IEEE division on the host, so the hot
         // loop multiplies) is 0 in the padding -- a padded point contributes exactly 0.
         // tiled plan (chain_kernels.h tile_chisq_kernel): Gaussian chisq over at least
-        // four 4096-point tiles, enough chains to amortise a tile, <= 16 coefficients
-        const bool tiled = !pr->wlike && nd >= 4 * 4096 && pr->nlocal >= 16 &&
-                           pr->nmodel <= 16 && !getenv("MC3HIP_NO_TILED");
+        // four 4096-point tiles, enough chains to amortise a tile, <= 16 coefficients.
+        // Models the one-launch resident kernels take (design matrices of 5..11 columns,
+        // polynomials of 2..4 coefficients) also from 8192 points on when the ensemble is
+        // large: measured on MI355X (tools/mid_range.py) the resident plan costs ~6.5 us +
+        // 0.26 ps per chain-point and iteration, the fused kernels ~1.2 us + 1.4 ps and
+        // more once several workgroups share a CU (8192 x 768: 15.8 us fused, 7.4 tiled;
+        // 16 000 x 2048: 54.7 / 12.0; 16 384 x 256: 7.7 / 7.3; 8192 x 256: 5.0 fused),
+        // crossing near 4 M chain-points.
+        const bool linear_model = pr->model_kind == MC3HIP_MODEL_LINEAR;
+        const bool resident_model = linear_model ? (pr->nmodel >= 5 && pr->nmodel <= 11)
+                                                 : (pr->nmodel >= 2 && pr->nmodel <= 4);
+        const bool big = nd >= 4 * 4096 ||
+                         (resident_model && nd >= 2 * 4096 &&
+                          (long long)nd * pr->nlocal >= 4194304LL);
+        const bool tiled = !pr->wlike && big && pr->nlocal >= 16 && pr->nmodel <= 16 &&
+                           !getenv("MC3HIP_NO_TILED");
         P.tile = tiled ? (pr->nmodel <= 4 ? 4096 : 2048) : 0;
         const size_t unit = tiled ? (size_t)P.tile : VLANES;
         const size_t npad = (nd + unit - 1) / unit * unit;

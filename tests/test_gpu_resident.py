@@ -282,3 +282,20 @@ def test_resident_polynomial_large(eng):
     assert gpu.plan['resident'] == 1
     assert_same(orc, gpu, trace=False)
     gpu.close()
+
+
+@pytest.mark.parametrize('kind,ndata,nchains', [('poly', 12000, 640), ('linear', 9000, 800),
+                                                ('poly', 12000, 256)])
+def test_large_ensembles_take_the_tiled_plan_from_8192_points(eng, kind, ndata, nchains):
+    """Below 16 384 points the tiled (resident) plan is chosen when the ensemble is large
+    enough to pay for its fixed cost (>= 4.2 M chain-points per iteration); the third case
+    stays on the fused kernel.  Bit-exact either way: the oracle follows the plan."""
+    if kind == 'poly':
+        prob = poly(3, ndata=ndata, nchains=nchains, niter=6)
+    else:
+        prob = linear(ndata=ndata, nmodel=8, nchains=nchains, niter=6)
+    orc, gpu = run_pair(eng, prob, trace=False)
+    tiled = ndata*nchains >= 4194304
+    assert (gpu.plan['tile'] > 0) == tiled and gpu.plan['resident'] == (1 if tiled else 0)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
