@@ -26,7 +26,9 @@ if len(sys.argv) > 1 and sys.argv[1] in ('c5', 'q5'):
     import tools_pop
     NIT = 400
     if sys.argv[1] == 'q5':     # the polynomial flavour of the resident plan
-        prob = H.quad_problem(ndata=100000, nchains=512, nsamples=512*(NIT + 60))
+        nd = int(sys.argv[2]) if len(sys.argv) > 2 else 100000      # [ndata [nchains]]
+        nc = int(sys.argv[3]) if len(sys.argv) > 3 else 512
+        prob = H.quad_problem(ndata=nd, nchains=nc, nsamples=nc*(NIT + 60))
     else:
         prob = H.linear_problem(ndata=100000, nchains=512, nsamples=512*(NIT + 60))
     g = engine.DeviceChains(**prob)
