@@ -17,13 +17,12 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 bad = 0
 for case in range(first, first + count):
-    try:
-        T.test_resident_random_problems.__wrapped__(engine, case) \
-            if hasattr(T.test_resident_random_problems, '__wrapped__') \
-            else T.test_resident_random_problems(engine, case)
-        print(case, 'ok', flush=True)
-    except AssertionError as e:
-        bad += 1
-        print(case, 'FAILED', str(e)[:300], flush=True)
+    for name in ('test_resident_random_problems', 'test_resident_polynomial_random_problems'):
+        try:
+            getattr(T, name)(engine, case)
+            print(case, name, 'ok', flush=True)
+        except AssertionError as e:
+            bad += 1
+            print(case, name, 'FAILED', str(e)[:300], flush=True)
 print('failures:', bad)
 sys.exit(1 if bad else 0)
