@@ -299,3 +299,45 @@ def test_large_ensembles_take_the_tiled_plan_from_8192_points(eng, kind, ndata, 
     assert (gpu.plan['tile'] > 0) == tiled and gpu.plan['resident'] == (1 if tiled else 0)
     assert_same(orc, gpu, trace=False)
     gpu.close()
+
+
+@pytest.mark.parametrize('kind', ['poly', 'linear'])
+def test_resident_nonfinite_models_are_rejected_like_the_reference(eng, kind):
+    """chain.py:322-323 under the one-launch tiled plan: an abscissa / design value of +inf
+    makes the model +inf or NaN there depending on the sign of the proposed coefficient; the
+    tile sum is then non-finite and only the scan of the model values tells "+inf model"
+    (chisq = inf) from any other overflow (NaN chisq) -- both rejected, counters, rows and
+    per-step chisq as the oracle's."""
+    if kind == 'poly':
+        prob = poly(3, ndata=20000, nchains=32, niter=15)
+        prob['indep'] = prob['indep'].copy()
+        prob['indep'][777] = np.inf
+    else:
+        prob = linear(ndata=20000, nmodel=6, nchains=32, niter=15)
+        prob['indep'] = prob['indep'].copy()
+        prob['indep'][2, 12345] = np.inf
+    gpu = eng.DeviceChains(trace_iters=15, **prob)
+    assert gpu.plan['resident'] == 1
+    orc = H.make_oracle(prob, plan=gpu.plan)
+    # (a population that is finite in spite of the bad point cannot be drawn: start from
+    # arbitrary in-bounds rows with made-up log-posteriors, the same on both sides)
+    rs = np.random.RandomState(1)
+    ifree = orc.ifree
+    Z0 = rs.normal(orc.params[ifree], 0.3*orc.pstep[ifree], (orc.M0, orc.nfree))
+    lp0 = -0.5*rs.uniform(2e4, 3e4, orc.M0)
+    orc.set_population(Z0, lp0)
+    gpu.set_population(Z0, lp0)
+    orc.run(trace=True, nthreads=4)
+    gpu.run()
+    tc, tf = gpu.trace(15)
+    np.testing.assert_array_equal(tf, orc.trace_flag)
+    np.testing.assert_array_equal(tc, orc.trace_chisq)          # (NaN == NaN here)
+    Z, lp, zc = gpu.rows()
+    np.testing.assert_array_equal(Z, orc.Z)
+    np.testing.assert_array_equal(lp, orc.log_post)
+    np.testing.assert_array_equal(gpu.state()['outbounds'], orc.outbounds)
+    inb = (tf & 1) != 0
+    assert inb.any() and not np.isfinite(tc[inb]).any()      # every in-bounds proposal: inf / NaN
+    assert (np.isnan(tc[inb])).any() or (tc[inb] == np.inf).any()
+    assert gpu.state()['numaccept'].sum() == 0
+    gpu.close()
