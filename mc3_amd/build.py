@@ -1,27 +1,40 @@
 """Build libmc3hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-    python -m mc3_amd.build [--force]
+    python -m mc3_amd.build [--force] [--resource-usage]
+
+The library is several translation units (csrc/mc3hip.hip + one csrc/k_*.hip per kernel
+family) compiled in parallel and linked into ONE shared object.  An object is recompiled
+only when the content of its source, of a header it includes (transitively) or the flags
+changed, so touching one kernel family rebuilds one unit, not the library.
 """
+import concurrent.futures
+import fcntl
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, 'csrc', 'mc3hip.hip')
-DEPS = [
-    SRC,
-    os.path.join(HERE, 'csrc', 'chain_kernels.h'),
-    os.path.join(HERE, 'csrc', 'philox.h'),
-    os.path.join(HERE, '..', 'include', 'mc3hip.h'),
-    os.path.join(HERE, '..', 'include', 'mc3hip_detmath.h'),
-]
+CSRC = os.path.join(HERE, 'csrc')
+# (the slowest first: the pool starts them in this order)
+UNITS = ['k_wavelet_w8.hip', 'k_wavelet_large.hip', 'k_wavelet_w4.hip', 'k_wavelet_w1.hip',
+         'k_general_w1.hip', 'k_general_w4.hip', 'k_general_w16.hip', 'k_lean.hip',
+         'k_resident.hip', 'k_tiled.hip', 'mc3hip.hip']
+SRC = os.path.join(CSRC, 'mc3hip.hip')
 LIB = os.path.join(HERE, 'libmc3hip.so')
+STAMP = LIB + '.srchash'
+OBJDIR = os.path.join(HERE, '..', 'build', 'obj')
 
 # -ffp-contract=off is part of the arithmetic contract (include/mc3hip_detmath.h):
 # fused multiply-adds happen only where the source spells them out.
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off',
-         '-fPIC', '-shared']
+CFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
+          '-fvisibility=hidden']
+LDFLAGS = ['--offload-arch=gfx950', '-shared', '-fPIC']
+FLAGS = CFLAGS          # (what tools that build a diagnostic variant start from)
+
+_INCLUDE = re.compile(r'^\s*#\s*include\s*"([^"]+)"', re.M)
 
 
 def hipcc():
@@ -31,16 +44,37 @@ def hipcc():
     return exe
 
 
-STAMP = LIB + '.srchash'
+def dependencies(path, seen=None):
+    """`path` and every file it includes with "...", transitively (sorted, absolute)."""
+    seen = set() if seen is None else seen
+    path = os.path.normpath(path)
+    if path in seen:
+        return seen
+    seen.add(path)
+    with open(path, errors='ignore') as f:
+        text = f.read()
+    for inc in _INCLUDE.findall(text):
+        dep = os.path.normpath(os.path.join(os.path.dirname(path), inc))
+        if os.path.exists(dep):
+            dependencies(dep, seen)
+    return seen
 
 
-def source_hash():
-    """Content hash of everything the library is compiled from (and of the flags)."""
-    import hashlib
-    h = hashlib.sha256(' '.join(FLAGS).encode())
-    for d in DEPS:
+def unit_hash(unit, extra=()):
+    """Content hash of everything one object is compiled from (and of the flags)."""
+    h = hashlib.sha256(' '.join(list(CFLAGS) + list(extra)).encode())
+    for d in sorted(dependencies(os.path.join(CSRC, unit))):
+        h.update(os.path.relpath(d, HERE).encode())
         with open(d, 'rb') as f:
             h.update(f.read())
+    return h.hexdigest()
+
+
+def source_hash(extra=()):
+    """Content hash of the whole library: its units' hashes and the link flags."""
+    h = hashlib.sha256(' '.join(LDFLAGS).encode())
+    for u in UNITS:
+        h.update(unit_hash(u, extra).encode())
     return h.hexdigest()
 
 
@@ -54,18 +88,81 @@ def is_stale():
         return f.read().strip() != source_hash()
 
 
-def build(force=False, verbose=False):
-    if not force and not is_stale():
-        return LIB
-    cmd = [hipcc()] + FLAGS + ['-o', LIB, SRC]
+def _atomic_write(path, text):
+    tmp = f'{path}.tmp{os.getpid()}'
+    with open(tmp, 'w') as f:
+        f.write(text)
+    os.replace(tmp, path)
+
+
+def _compile(unit, objdir, extra, verbose):
+    """One object, recompiled only when its hash changed.  The hash is taken BEFORE the
+    compiler runs, so a source edited meanwhile is seen as newer next time."""
+    want = unit_hash(unit, extra)
+    obj = os.path.join(objdir, os.path.splitext(unit)[0] + '.o')
+    stamp = obj + '.srchash'
+    if os.path.exists(obj) and os.path.exists(stamp):
+        with open(stamp) as f:
+            if f.read().strip() == want:
+                return obj, False
+    tmp = f'{obj}.tmp{os.getpid()}'
+    cmd = [hipcc()] + CFLAGS + list(extra) + ['-c', os.path.join(CSRC, unit), '-o', tmp]
     if verbose:
-        print(' '.join(cmd))
+        print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
-    with open(STAMP, 'w') as f:
-        f.write(source_hash() + '\n')
-    return LIB
+    os.replace(tmp, obj)
+    _atomic_write(stamp, want + '\n')
+    return obj, True
+
+
+def build(force=False, verbose=False, lib=LIB, extra=(), jobs=None):
+    """Compile the stale units in parallel and link.  `extra`: more compiler flags (a
+    diagnostic variant of the library under another name keeps its own objects)."""
+    extra = tuple(extra)
+    product = os.path.abspath(lib) == os.path.abspath(LIB)
+    if product and not force and not is_stale():
+        return lib
+    objdir = os.path.normpath(OBJDIR if product else
+                              OBJDIR + '_' + hashlib.sha256(' '.join(extra).encode())
+                              .hexdigest()[:10])
+    os.makedirs(objdir, exist_ok=True)
+    # one builder at a time (two processes importing a stale tree at once)
+    with open(os.path.join(objdir, '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if product and not force and not is_stale():
+            return lib
+        want = source_hash(extra)
+        if force:
+            for f in os.listdir(objdir):
+                if f.endswith('.srchash'):
+                    os.remove(os.path.join(objdir, f))
+        jobs = jobs or min(len(UNITS), os.cpu_count() or 1)
+        with concurrent.futures.ThreadPoolExecutor(jobs) as pool:
+            objs = [o for o, _ in pool.map(lambda u: _compile(u, objdir, extra, verbose), UNITS)]
+        tmp = f'{lib}.tmp{os.getpid()}'
+        cmd = [hipcc()] + LDFLAGS + ['-o', tmp] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        os.replace(tmp, lib)                      # the library first, then its stamp
+        if product:
+            _atomic_write(STAMP, want + '\n')
+    return lib
+
+
+def resource_usage(out=sys.stdout):
+    """Registers, spills, scratch and LDS of every kernel instance, from the compiler's
+    remarks (recompiles every unit; nothing is linked)."""
+    for unit in UNITS:
+        cmd = [hipcc()] + CFLAGS + ['-Rpass-analysis=kernel-resource-usage', '-c',
+                                   os.path.join(CSRC, unit), '-o', os.devnull]
+        res = subprocess.run(cmd, stderr=subprocess.PIPE, text=True, check=True)
+        out.write(f'## {unit}\n{res.stderr}')
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv, verbose=True)
-    print(LIB)
+    if '--resource-usage' in sys.argv:
+        resource_usage()
+    else:
+        build(force='--force' in sys.argv, verbose=True)
+        print(LIB)

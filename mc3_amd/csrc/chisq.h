@@ -1,0 +1,59 @@
+// chisq.h -- chisq of a parameter vector: data term (Gaussian or wavelet) + priors.
+#pragma once
+#include "core.h"
+#include "gauss.h"
+
+namespace mc3hip {
+
+// (defined in wavelet.h, which only the wavelet kernels' translation unit includes)
+template <int WPC, int MT>
+__device__ __forceinline__ void wavelet_stage(const DevProblem &P, double *xs);
+template <int WPC, int MT, bool LARGE = false>
+__device__ double block_wavelet(const DevProblem &P, const double *s_nextp, double *s_part,
+                                int *s_flag, double *s_tab, double *s_halo, const double *xs);
+
+// chisq of the parameter vector in s_nextp; valid in wave 0
+template <int WPC, int MT, bool WL, bool MULTI>
+__device__ __forceinline__ double block_chisq(const DevProblem &P, const double *s_nextp,
+                                              double *s_part, int *s_flag, double *s_tab,
+                                              double *s_halo, const double *s_xs,
+                                              const DataTile<WPC, MT> &tile)
+{
+    double c;
+    if constexpr (WL)       // (MULTI of a wavelet kernel = its large-data instance)
+        c = block_wavelet<WPC, MT, MULTI && WPC == 8>(P, s_nextp, s_part, s_flag, s_tab, s_halo,
+                                                      s_xs);
+    else
+        c = block_gauss<WPC, MT, MULTI>(P, s_nextp, s_part, s_flag, tile);
+    if (is_pos_inf(c))
+        return c;
+    return c + prior_term(P, s_nextp);
+}
+
+// chisq of a chain from the per-tile sums (tiles added in order) plus the prior
+// term.  The +inf-model trap of chain.py:322-323 is resolved lazily: a +inf model
+// value always makes the sum non-finite (w > 0), so only a non-finite sum needs
+// the scan that tells "+inf model" (chisq = inf) from any other overflow.
+template <int MT>
+__device__ __forceinline__ double finish_chisq(const DevProblem &P, int lc)
+{
+    const double *np = P.sc_nextp + (size_t)lc * SC_STRIDE;
+    double total = 0.0;
+    for (int t = 0; t < P.ntiles; ++t)
+        total = total + P.sc_part[(size_t)lc * P.ntiles + t];
+    const bool finite = (mc3_bits(total) & 0x7ff0000000000000ull) != 0x7ff0000000000000ull;
+    if (!finite) {
+        Model<MT> model;
+        model.init(P, np);
+        int saw = 0;
+        for (int i = threadIdx.x; i < P.ndata; i += blockDim.x)
+            saw |= is_pos_inf(model.at(i));
+        if (__any(saw))
+            return mc3_from_bits(0x7ff0000000000000ull);
+    }
+    if (is_pos_inf(total))
+        return total;
+    return total + prior_term(P, np);
+}
+
+}  // namespace mc3hip

@@ -1,0 +1,461 @@
+// core.h -- what every chain-update kernel shares (gfx950, wave64): the device view of a
+// problem, model evaluation, the canonical summation tree, the register-resident data tile.
+//
+// One workgroup advances one chain through `thinning` iterations of
+//   proposal -> bounds -> shared params -> model -> chisq -> Metropolis -> Z append
+// (mc3/chain.py:185-289) with every other chain seen through the population
+// snapshot of the previous Z refresh.  WPC waves (64*WPC threads) share one chain:
+// the data sum is split over 1024 "virtual lanes" (point i belongs to lane
+// i mod 1024); a thread owns 16/WPC of them, so the summation order -- strided
+// partial sums, then a halving tree over the 1024 lanes -- is the same for every
+// WPC and is what oracle/oracle_lockstep.c follows.  No MFMA: with <= 10 model
+// coefficients there is no dense contraction to feed it.
+//
+// Arithmetic contract: compiled with -ffp-contract=off; fused multiply-adds only
+// where written (model, squared-residual accumulation, D4 taps, detmath).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "philox.h"
+#include "../../include/mc3hip.h"
+#include "../../include/mc3hip_detmath.h"
+
+namespace mc3hip {
+
+constexpr int VLANES = 1024;
+// Z rows are padded on the device to whole 128-byte lines (ZROW doubles, or a multiple of
+// it for more than 16 free parameters): rows are written by different chains -- different
+// CUs and XCDs -- at the same moment, and write-through stores that share a line
+// serialise on it.  Measured on C2: 165 -> 194 M chain-steps/s.  The C-ABI packs and
+// unpacks, so callers keep seeing dense [rows][nfree] arrays.
+constexpr int ZROW = 16;
+
+// model tags
+constexpr int MT_POLY_GENERIC = 0;   // runtime nmodel, coefficients read from LDS
+constexpr int MT_POLY2 = 2;          // p0 + p1 x
+constexpr int MT_POLY3 = 3;          // p0 + p1 x + p2 x^2
+constexpr int MT_POLY4 = 4;
+constexpr int MT_LINEAR = 100;       // sum_k A[k][i] p[k]
+
+struct DevProblem {
+    int32_t nchains, chain0, nlocal, nparams, nfree, nshare, ndata;
+    int32_t npad;          // ndata rounded up to a multiple of 1024 (Gaussian data sum)
+    int32_t zs, _pad_zs;   // doubles per row of Z and snap0 on the device (multiple of ZROW)
+    int32_t sampler, wlike, nmodel, thinning, ngprior, trace_iters;
+    int64_t M0;
+    uint64_t seed;
+    double gamma, fepsilon;
+    const int32_t *ifree, *ishare, *share_src, *igprior;
+    const double *params, *pmin, *pmax, *pstep, *prior, *priorlow, *priorup;
+    const double *fmin, *fmax, *fstep;   // pmin/pmax/pstep gathered at ifree[k]
+    const double *indep, *data, *w;
+    double *Z, *log_post;
+    int32_t *zchain;
+    double *X, *chisq;
+    long long *numaccept;
+    unsigned long long *outbounds;
+    double *best_chisq;
+    long long *best_iter;
+    double *bestx;
+    const double *snap0;
+    double *trace_chisq;
+    int32_t *trace_flag;
+    const long long *ctl;   // ctl[0] = refresh base of this replay, ctl[1] = first refresh of the run
+    unsigned long long *stamps;   // diagnostic build only (MC3HIP_STAMPS): s_memtime per phase
+    // peer-to-peer hand-off across GPUs (persistent kernel): rank p's replicas of Z and
+    // log_post, mapped into this process; [0..npeers), entry `rank` is the local one
+    int32_t npeers, rank;
+    int32_t test_abort;           // tests: refresh at which chain `chain0` gives up (-1 = never)
+    int32_t _pad_test;
+    double *const *peerZ;
+    double *const *peerLP;
+    // tiled plan (large ndata): proposal / data sum / accept are separate launches
+    int32_t tile, ntiles;         // points per tile (0 = fused plan), tiles in npad
+    double *sc_nextp;             // [nlocal][nparams] proposed parameter vectors
+    double *sc_npk;               // [nlocal][nfree]   proposed free parameters
+    double *sc_scal;              // [nlocal][2]       Metropolis draw u, Hastings factor
+    int32_t *sc_flag;             // [nlocal]          bit0 out of bounds, bit1 snooker jump
+    double *sc_part;              // [nlocal][ntiles]  per-tile data sums
+    // resident tiled plan (resident_tile_kernel): hand-off areas inside ONE launch, every
+    // double its own "ready" flag (all-ones = not there yet, as for Z rows)
+    double *rs_prop;              // [2][nlocal][RS_ROW] proposed coefficients, by iteration parity
+    double *rs_part;              // [nlocal][rs_ntp]    per-tile data sums of the running iteration
+    int32_t rs_ntp, _pad_rs;      // ntiles rounded up to whole 128-byte lines
+    // wavelet likelihood, abscissae on np.linspace's grid (x_i = fl(fl(i*step) + x0), last
+    // point = wl_xlast; checked bit for bit at creation): they are recomputed instead of
+    // stored, which frees the LDS for the data values
+    int32_t wl_grid, _pad_grid;
+    double wl_x0, wl_step, wl_xlast;
+    const double *data_t;         // wavelet: the data as [j][t] (thread t's j-th point)
+    double *wl_scratch;           // wavelet, ndata > 2^14: [blocks][3 ndata / 4] pre-level values
+    // RCCL exchange inside a hipGraph: slot `roff` of this ring receives the rows of the
+    // refresh a graph node produced (fixed addresses, so the captured all-gather can be
+    // replayed); nullptr = off
+    double *xring;
+};
+
+constexpr int PH_FUSED = 0, PH_PROPOSE = 1, PH_FINISH = 2, PH_RESIDENT = 3;
+constexpr int RS_ROW = 16;          // doubles per published proposal row: one 128-byte line
+constexpr int RS_WCAP = 256;        // chains whose group totals a workgroup collects in LDS
+                                    // before it adds them up (resident tiled plan)
+constexpr int SC_STRIDE = MC3HIP_MAX_PARAMS + 16;   // doubles per sc_nextp row (zero padded)
+// in-launch hand-off (handoff.h): a double that still holds this pattern has not been
+// published yet; ctl[CTL_ABORT] != 0: a wait timed out, the launch is giving up
+constexpr unsigned long long ROW_PENDING = 0xffffffffffffffffull;
+constexpr int CTL_ABORT = 2;                   // ctl[2] != 0: a wait timed out
+
+// In-kernel phase stamps for the diagnostic build (never compiled into the product
+// library): drain outstanding memory operations, then read the shader clock.
+#ifdef MC3HIP_STAMPS
+#define MC3_STAMP(slot)                                                                   \
+    do {                                                                                  \
+        unsigned long long t_;                                                            \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" \
+                     : "=s"(t_)::"memory");                                               \
+        if (threadIdx.x == 0 && blockIdx.x == 0)                                          \
+            P.stamps[slot] = t_;                                                          \
+    } while (0)
+// non-draining tick accumulators for the persistent loop: sums of shader-clock
+// deltas per phase over all iterations of workgroup 0 (slots 8..11), count in slot 12
+#define MC3_TICK(var)                                                                     \
+    do {                                                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");       \
+    } while (0)
+// Non-draining stamps for the kernels with dynamic LDS (wavelet path): the shader clock
+// goes to a spare corner of the LDS noise table (slots 32..47 of `tab`, SmemLayout) and is
+// copied out once per iteration (MC3_LSTAMP_FLUSH), so that no stamp waits for the store
+// of the one before it.
+extern __shared__ __attribute__((aligned(16))) double mc3_smem_stamps_[];
+#ifdef MC3HIP_NO_LSTAMP
+#define MC3_LSTAMP(slot) do { } while (0)
+#define MC3_LSTAMP_FLUSH() do { } while (0)
+#else
+#define MC3_LSTAMP(slot)                                                                  \
+    do {                                                                                  \
+        /* (the builtin, not inline asm with an SGPR output: some stamps sit in control    \
+           flow the compiler considers divergent) */                                      \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                       \
+        if (threadIdx.x == 0 && blockIdx.x == 0)                                          \
+            reinterpret_cast<unsigned long long *>(mc3_smem_stamps_)[blockDim.x +         \
+                MC3HIP_MAX_PARAMS + 2 + 32 + (slot)] = t_;                                \
+    } while (0)
+#define MC3_LSTAMP_FLUSH()                                                                \
+    do {                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.x == 0)                                          \
+            for (int q_ = 0; q_ < 16; ++q_)                                               \
+                P.stamps[q_] = reinterpret_cast<unsigned long long *>(                    \
+                    mc3_smem_stamps_)[blockDim.x + MC3HIP_MAX_PARAMS + 2 + 32 + q_];      \
+    } while (0)
+#endif
+#else
+#define MC3_STAMP(slot) do { } while (0)
+#define MC3_TICK(var) do { } while (0)
+#define MC3_LSTAMP(slot) do { } while (0)
+#define MC3_LSTAMP_FLUSH() do { } while (0)
+#endif
+
+// operand / result of v_mfma_f64_16x16x4_f64
+typedef double mc3_v4d __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double make_double(int lo, int hi) { return __hiloint2double(hi, lo); }
+
+// ---- model evaluation ------------------------------------------------------
+template <int MT>
+struct Model {
+    double cf[(MT >= 1 && MT <= 8) ? MT : 1];
+    const double *coef;     // LDS copy of the proposal (generic / linear)
+    const double *indep;
+    int nmodel, ndata;      // ndata = column stride of A (the padded length)
+
+    __device__ __forceinline__ void init(const DevProblem &P, const double *s_nextp)
+    {
+        coef = s_nextp;
+        indep = P.indep;
+        nmodel = P.nmodel;
+        ndata = P.npad;
+        if constexpr (MT >= 1 && MT <= 8) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                cf[j] = s_nextp[j];
+        }
+    }
+    // coefficients straight from wave 0's lanes (lane j holds parameter j): the
+    // fast path of fully-free polynomial models, no LDS round trip
+    __device__ __forceinline__ void init_from_lanes(const DevProblem &P, double npk)
+    {
+        coef = nullptr;
+        indep = P.indep;
+        nmodel = P.nmodel;
+        ndata = P.npad;
+        if constexpr (MT >= 1 && MT <= 8) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                cf[j] = make_double(__builtin_amdgcn_readlane(__double2loint(npk), j),
+                                    __builtin_amdgcn_readlane(__double2hiint(npk), j));
+        }
+    }
+    // (lane k holds FREE parameter k; coefficient j is free parameter kf[j], or -- kf[j] < 0
+    // -- the fixed value fx[j])
+    __device__ __forceinline__ void init_from_lanes(const DevProblem &P, double npk,
+                                                    const int (&kf)[MT >= 1 && MT <= 8 ? MT : 1],
+                                                    const double (&fx)[MT >= 1 && MT <= 8 ? MT : 1])
+    {
+        coef = nullptr;
+        indep = P.indep;
+        nmodel = P.nmodel;
+        ndata = P.npad;
+        if constexpr (MT >= 1 && MT <= 8) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int src = kf[j] < 0 ? 0 : kf[j];
+                const double v = make_double(__builtin_amdgcn_readlane(__double2loint(npk), src),
+                                             __builtin_amdgcn_readlane(__double2hiint(npk), src));
+                cf[j] = kf[j] < 0 ? fx[j] : v;
+            }
+        }
+    }
+    // polynomial families at abscissa x (Horner, fused multiply-adds)
+    __device__ __forceinline__ double at_x(double x) const
+    {
+        if constexpr (MT >= 1 && MT <= 8) {
+            double m = cf[MT - 1];
+#pragma unroll
+            for (int j = MT - 2; j >= 0; --j)
+                m = mc3_fma(m, x, cf[j]);
+            return m;
+        } else {
+            double m = coef[nmodel - 1];
+            for (int j = nmodel - 2; j >= 0; --j)
+                m = mc3_fma(m, x, coef[j]);
+            return m;
+        }
+    }
+    __device__ __forceinline__ double at(int i) const
+    {
+        if constexpr (MT != MT_LINEAR) {
+            return at_x(indep[i]);
+        } else {
+            double m = indep[i] * coef[0];
+            for (int k = 1; k < nmodel; ++k)
+                m = mc3_fma(indep[(size_t)k * ndata + i], coef[k], m);
+            return m;
+        }
+    }
+};
+
+__device__ __forceinline__ bool is_pos_inf(double v)
+{
+    return mc3_bits(v) == 0x7ff0000000000000ull;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
+// the vector-memory counter, which would serialise the data loads this kernel
+// deliberately keeps in flight across the proposal phase; gfx950's s_barrier
+// itself waits for no counter.  One wave per workgroup needs no barrier at all:
+// a wave's LDS instructions execute in order.
+template <int WPC>
+__device__ __forceinline__ void block_sync()
+{
+    if constexpr (WPC == 1) {
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0) only
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+template <int WPC>
+__device__ __forceinline__ int block_or(int pred, int *s_flag)
+{
+    int any = __any(pred) ? 1 : 0;
+    if constexpr (WPC > 1) {
+        if (threadIdx.x == 0)
+            s_flag[1] = 0;
+        block_sync<WPC>();
+        if (any && (threadIdx.x & 63) == 0)
+            s_flag[1] = 1;
+        block_sync<WPC>();
+        any = s_flag[1];
+    }
+    return any;
+}
+
+// v[l] + v[l ^ 32], v[l] + v[l ^ 16]: gfx950 lane-swap instructions (VALU only)
+__device__ __forceinline__ double add_xor32(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return make_double(a[0], b[0]) + make_double(a[1], b[1]);
+}
+__device__ __forceinline__ double add_xor16(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return make_double(a[0], b[0]) + make_double(a[1], b[1]);
+}
+// v[l] + v[(l + N) mod 16 within its row of 16]: DPP row rotate
+template <int N>
+__device__ __forceinline__ double add_ror(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    // (a rotation reads a valid lane everywhere: no "old" value to initialise)
+    const int lo2 = __builtin_amdgcn_mov_dpp(lo, 0x120 + N, 0xf, 0xf, true);
+    const int hi2 = __builtin_amdgcn_mov_dpp(hi, 0x120 + N, 0xf, 0xf, true);
+    return v + make_double(lo2, hi2);
+}
+// sum over the 64 lanes of a wave, pairing strides 32,16,8,4,2,1; every lane
+// receives the total
+__device__ __forceinline__ double wave_sum(double t)
+{
+    t = add_xor32(t);
+    t = add_xor16(t);
+    t = add_ror<8>(t);
+    t = add_ror<4>(t);
+    t = add_ror<2>(t);
+    t = add_ror<1>(t);
+    return t;
+}
+
+__device__ __forceinline__ double read_lane(double v, int k)
+{
+    return make_double(__builtin_amdgcn_readlane(__double2loint(v), k),
+                       __builtin_amdgcn_readlane(__double2hiint(v), k));
+}
+
+// Halving tree over the 1024 virtual lanes.  acc[v] is this thread's partial for
+// virtual lane  lane + 64*(wave + WPC*v).  Strides >= 64*WPC are in-thread,
+// strides 64*WPC/2..64 go through LDS, strides 32..1 are in-wave lane swaps.
+// The result is valid in every lane of wave 0.
+template <int WPC>
+__device__ __forceinline__ double lane_tree(double (&acc)[16 / WPC], double *s_part)
+{
+    constexpr int NV = 16 / WPC;
+#pragma unroll
+    for (int s = NV / 2; s >= 1; s >>= 1) {
+#pragma unroll
+        for (int v = 0; v < s; ++v)
+            acc[v] = acc[v] + acc[v + s];
+    }
+    double t = acc[0];
+    if constexpr (WPC > 1) {
+        block_sync<WPC>();                    // s_part may still be read by wave 0
+        s_part[threadIdx.x] = t;
+        block_sync<WPC>();
+        if (threadIdx.x < 64) {
+            double p[WPC];
+#pragma unroll
+            for (int w = 0; w < WPC; ++w)
+                p[w] = s_part[threadIdx.x + 64 * w];
+#pragma unroll
+            for (int s = WPC / 2; s >= 1; s >>= 1) {
+#pragma unroll
+                for (int w = 0; w < s; ++w)
+                    p[w] = p[w] + p[w + s];
+            }
+            t = p[0];
+        }
+    }
+    if (threadIdx.x < 64)
+        t = wave_sum(t);
+    return t;
+}
+
+// The first 1024-point tile of (x, data, w) held in registers: loaded once at
+// kernel entry -- before the proposal is known, so the load latency overlaps the
+// RNG / partner-row phase -- and reused by every iteration of the launch.
+template <int WPC, int MT>
+struct DataTile {
+    static constexpr int NV = 16 / WPC;
+    double x[NV], d[NV], w[NV];
+
+    // The device copies of x / data / w are padded to a multiple of 1024 points
+    // (x and data repeat the last point, w = 0), so the tile needs no bounds
+    // checks: a padded point adds fma(0, 0, acc) = acc.
+    __device__ __forceinline__ void load(const DevProblem &P, int base = 0)
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int i = base + lane + 64 * (wv + WPC * v);
+            d[v] = P.data[i];
+            w[v] = P.w[i];
+            if constexpr (MT != MT_LINEAR)
+                x[v] = P.indep[i];
+        }
+    }
+};
+
+constexpr double D4C0 = 0.4829629131445341, D4C1 = 0.83651630373780772,
+                 D4C2 = 0.22414386804201339, D4C3 = -0.12940952255126034;
+
+__device__ __forceinline__ void d4_pair(double a0, double a1, double a2, double a3,
+                                        double &s, double &d)
+{
+    s = D4C0 * a0;
+    s = mc3_fma(D4C1, a1, s);
+    s = mc3_fma(D4C2, a2, s);
+    s = mc3_fma(D4C3, a3, s);
+    d = D4C3 * a0;
+    d = mc3_fma(-D4C2, a1, d);
+    d = mc3_fma(D4C1, a2, d);
+    d = mc3_fma(-D4C0, a3, d);
+}
+
+__device__ __forceinline__ int ilog2(int n)
+{
+    int m = 0;
+    while ((1 << m) < n)
+        ++m;
+    return m;
+}
+
+// prior term, mc3/stats/stats.py:211-216 + src_c/include/stats.h:96-106
+__device__ __forceinline__ double prior_term(const DevProblem &P, const double *s_nextp)
+{
+    double pr = 0.0;
+    for (int g = 0; g < P.ngprior; ++g) {
+        const int j = P.igprior[g];
+        const double d = s_nextp[j] - P.prior[j];
+        const double s = (d > 0.0) ? d / P.priorup[j] : d / P.priorlow[j];
+        pr = pr + s * s;
+    }
+    return pr;
+}
+
+// serial sum over lanes 0..n-1 of a wave, in lane order (v_readlane broadcasts)
+__device__ __forceinline__ double lane_serial_sum(double t, int n)
+{
+    double s = 0.0;
+    for (int k = 0; k < n; ++k)
+        s = s + read_lane(t, k);
+    return s;
+}
+
+struct SmemLayout {
+    double *part, *nextp, *tab, *halo, *xs;
+    int *flag;
+};
+
+__device__ __forceinline__ SmemLayout carve(double *smem, const DevProblem &P, int nthreads)
+{
+    SmemLayout L;
+    L.part = smem;
+    L.nextp = smem + nthreads;
+    L.flag = reinterpret_cast<int *>(L.nextp + MC3HIP_MAX_PARAMS);
+    L.tab = L.nextp + MC3HIP_MAX_PARAMS + 2;            // 48 doubles: per-scale 1/sigma_W^2, ...
+    L.halo = L.tab + 48;       // wavelet: two halo buffers of 2 doubles per thread, 64 for
+    L.xs = L.halo + 5 * nthreads + 64;     // stage C, one value per thread; then x as [B][T]
+    return L;
+}
+
+static inline size_t smem_bytes(int nthreads, int ndata, int wlike)
+{
+    size_t n = (size_t)nthreads + MC3HIP_MAX_PARAMS + 2 + 48;
+    // (beyond 2^14 points nothing is staged in LDS: the pre-levels read global memory)
+    n += wlike ? 5 * (size_t)nthreads + 64 + (size_t)(ndata > 16384 ? 128 : ndata > 128 ? ndata : 128) : 4;
+    return n * sizeof(double);
+}
+
+}  // namespace mc3hip

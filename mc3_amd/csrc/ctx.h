@@ -1,0 +1,181 @@
+// ctx.h -- the host-side context behind the C-ABI (include/mc3hip.h) and the seams between
+// the translation units of libmc3hip.so.
+//
+// The library is built from several translation units compiled in parallel: mc3hip.hip (the
+// C-ABI, the launch structure, the small kernels around the chain update) and one or more
+// k_*.hip per kernel family, each of which instantiates its kernels and hands out launchers / kernel
+// pointers through the functions declared at the end of this file.  No device code crosses a
+// translation unit, so no relocatable device code is needed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <vector>
+
+#include "core.h"
+
+typedef struct ncclComm *ncclComm_t;
+
+struct mc3hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    mc3hip::DevProblem P{};
+    int model_kind = 0, mt = 0, wpc = 1;
+    size_t smem = 0;
+    int64_t zlen = 0;
+    int64_t refresh_done = 0;
+    bool populated = false;
+    uint32_t flags = 0;
+    std::vector<void *> allocs;
+    char *arena = nullptr;
+    size_t arena_used = 0;
+    long long *ctl = nullptr;
+    double *eval_params = nullptr, *eval_out = nullptr;
+    int eval_cap = 0;
+    double *model_out = nullptr;
+    // graph
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_nodes = 0;
+    int persist_refs = 0;           // refreshes per persistent launch, 0 = off
+    bool persist_checked = false;
+    bool fast = false;              // lean persistent instance selected
+    double *stage = nullptr;        // dense staging for Z row transfers (grow-only)
+    size_t stage_doubles = 0;
+    // checkpoint of the per-chain state taken before the first persistent launch that
+    // has not been confirmed yet (recovery if a launch gives up)
+    char *ckpt = nullptr;
+    int64_t ckpt_R = 0;
+    bool ckpt_valid = false;
+    long long last_run0 = 0;
+    int recoveries = 0;
+    int tile_kmax = 0;              // tiled plan: coefficient capacity of the tile kernel
+    int tile_chain_block = 0;       // chains per workgroup column of the tile kernel
+    bool resident = false;          // tiled plan as one persistent launch (resident_tile_kernel)
+    int resident_chain_block = 0;   // its column height
+    bool ckpt_settled = false;      // peer-to-peer: the launches since the checkpoint completed
+                                    // HERE; confirmed by the caller's next mc3hip_run
+    double *moments = nullptr;      // scratch of mc3hip_chain_moments (2 x nchains x nfree)
+    // comm
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    int64_t logpost_gathered = 0;   // refreshes whose log_post rows are already exchanged
+    // RCCL exchange captured in a hipGraph: per refresh (step kernel, all-gather of ring
+    // slot r, ring_in kernel) x comm_graph_nodes
+    double *xring = nullptr;
+    int comm_graph_nodes = 0;
+    hipGraph_t cgraph = nullptr;
+    hipGraphExec_t cgraph_exec = nullptr;
+    bool comm_graph_failed = false;
+    bool comm_warm = false;         // one eager collective has run (RCCL set up its channels)
+    // peer-to-peer hand-off
+    int p2p_ranks = 0;
+    std::vector<void *> p2p_opened;
+};
+
+namespace mc3hip {
+namespace host {
+
+// every chain kernel that covers many refreshes has the signature (DevProblem, nref); the
+// resident tiled kernels take their column height as well
+typedef void (*chain_kernel_fn)(const DevProblem, const int);
+typedef void (*resident_kernel_fn)(const DevProblem, const int, const int);
+
+constexpr int WL_EVAL_BLOCKS = 256;
+
+// Waves per chain are dispatched as {1, 4, 16}; the wavelet geometries have 1, 4 or 8:
+// the widest one rides on the dispatch slot of the widest Gaussian one.
+template <int WPC>
+constexpr int wavelet_waves() { return WPC == 16 ? 8 : WPC; }
+
+// ---- which instance serves a context: pure functions of the context ---------------------
+// polynomials of 2..4 coefficients: the tile kernel with the degree compiled in
+inline int tile_exact_degree(const mc3hip_ctx *c)
+{
+    return (c->mt != MT_LINEAR && c->tile_kmax == 4 && c->P.nmodel >= 2) ? c->P.nmodel : 0;
+}
+
+// design-matrix models with two points per virtual lane (5..16 coefficients): the data
+// sums go through the FP64 matrix cores (tile_chisq_mfma_kernel)
+inline bool tile_uses_mfma(const mc3hip_ctx *c)
+{
+    return c->mt == MT_LINEAR && c->P.tile == 2048 && !getenv("MC3HIP_NO_MFMA");
+}
+
+// resident tiled plan: design-matrix models through the matrix cores, or polynomials of
+// 2..4 coefficients
+inline bool resident_poly(const mc3hip_ctx *c)
+{
+    return c->mt != MT_LINEAR && c->P.tile == 4096 && tile_exact_degree(c) >= 2;
+}
+
+// the lean persistent instance applies when nothing of the general machinery is
+// needed (run_chain.h run_chain FAST)
+inline bool fast_eligible(const mc3hip_ctx *c)
+{
+    const DevProblem &P = c->P;
+    // (fixed coefficients and Gaussian priors are fine: the FX kernels map coefficient j to
+    // its free parameter or to its fixed value, handoff.h coefficient_map;
+    // instantiated for one GPU and thinning = 1 only: FX of persist_fast_kernel)
+    const bool plain = P.nparams == P.nfree && P.ngprior == 0 && P.nshare == 0;
+    const bool fx_ok = P.nfree >= 1 && P.thinning == 1 && !(c->flags & MC3HIP_FLAG_P2P);
+    // more than one 1024-point tile (streamed): plain problems, one GPU, thinning = 1
+    const bool multi = P.npad > VLANES;
+    const bool size_ok = !multi || (plain && fx_ok && P.tile == 0);
+    return c->wpc == 1 && !P.wlike && size_ok && c->mt >= 2 && c->mt <= 4 &&
+           (plain || fx_ok) && P.nmodel == P.nparams &&
+           P.fepsilon == 0.0 && P.trace_iters == 0 &&
+           (P.sampler == MC3HIP_DEMC || P.sampler == MC3HIP_SNOOKER ||
+            P.sampler == MC3HIP_MRW) &&
+           !getenv("MC3HIP_NO_FAST");
+}
+
+// the headline shape (DEMC, thinning 1) has a loop of its own: lean_demc_kernel
+inline bool lean_demc_eligible(const mc3hip_ctx *c)
+{
+    return c->fast && c->P.sampler == MC3HIP_DEMC && c->P.thinning == 1 &&
+           c->P.nparams == c->mt && c->P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
+}
+
+// ---- k_general_w{1,4,16}.hip: one workgroup per chain, Gaussian chisq, by waves per chain ---
+void launch_step_gauss_w1(mc3hip_ctx *c, int roff);
+void launch_step_gauss_w4(mc3hip_ctx *c, int roff);
+void launch_step_gauss_w16(mc3hip_ctx *c, int roff);
+chain_kernel_fn persist_instance_gauss_w1(const mc3hip_ctx *c, bool p2p);
+chain_kernel_fn persist_instance_gauss_w4(const mc3hip_ctx *c, bool p2p);
+chain_kernel_fn persist_instance_gauss_w16(const mc3hip_ctx *c, bool p2p);
+void launch_eval_gauss_w1(mc3hip_ctx *c, int n);
+void launch_eval_gauss_w4(mc3hip_ctx *c, int n);
+void launch_eval_gauss_w16(mc3hip_ctx *c, int n);
+
+// ---- k_wavelet_{w1,w4,w8,large}.hip: the same with the wavelet likelihood, by geometry ----
+#define MC3_WAVELET_UNIT(tag)                                                       \
+    void launch_step_wavelet_##tag(mc3hip_ctx *c, int roff);                        \
+    chain_kernel_fn persist_instance_wavelet_##tag(const mc3hip_ctx *c, bool p2p);  \
+    void launch_eval_wavelet_##tag(mc3hip_ctx *c, int n);                           \
+    hipError_t set_smem_attr_wavelet_##tag(mc3hip_ctx *c);
+MC3_WAVELET_UNIT(w1)
+MC3_WAVELET_UNIT(w4)
+MC3_WAVELET_UNIT(w8)
+MC3_WAVELET_UNIT(large)
+#undef MC3_WAVELET_UNIT
+
+// ---- k_lean.hip: the lean one-wave persistent kernels ------------------------------------
+// ONE function picks the instance a context runs, so that the launch and the occupancy query
+// that sizes the persistent grid can never disagree (the MULTI / FX instances use more than
+// twice the registers of the plain ones: 4 single-wave workgroups per CU instead of 8).
+chain_kernel_fn fast_instance(const mc3hip_ctx *c, bool p2p);
+
+// ---- k_tiled.hip: the tiled plan as three launches per iteration -------------------------
+void launch_propose(mc3hip_ctx *c, int roff, int j);
+void launch_finish(mc3hip_ctx *c, int roff, int j);
+void launch_tile(mc3hip_ctx *c);
+hipError_t tile_set_attr(mc3hip_ctx *c);
+
+// ---- k_resident.hip: the tiled plan as one persistent launch -----------------------------
+resident_kernel_fn resident_kernel(const mc3hip_ctx *c, bool p2p);
+size_t resident_lds_bytes(const mc3hip_ctx *c);
+
+}  // namespace host
+}  // namespace mc3hip

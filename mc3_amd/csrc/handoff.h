@@ -1,0 +1,265 @@
+// handoff.h -- in-launch hand-off of Z rows between workgroups, the draws of an iteration.
+#pragma once
+#include "core.h"
+
+namespace mc3hip {
+
+// A Z row read through the in-launch hand-off (persistent kernel): rows are
+// published with agent-scope 8-byte stores and consumed with agent-scope loads
+// (sc1: they bypass the CU's L1, which another CU's stores never refresh); a row
+// that is not there yet still holds the all-ones NaN pattern the Z buffer is
+// filled with at creation, so every double is its own "ready" flag -- no separate
+// flag, fence or ordering is needed (8-byte stores are single-copy atomic).
+// A chain state can never legitimately be NaN: a NaN proposal has a NaN or
+// out-of-bounds chisq and is rejected (chain.py:257-260).
+// (ROW_PENDING, CTL_ABORT: core.h)
+
+template <bool SYS = false>
+__device__ __forceinline__ double load_published(const double *p)
+{
+    // SYS: the row may have been stored by another GPU (system scope, fine-grained
+    // memory); otherwise by another CU of this GPU (agent scope)
+    if constexpr (SYS)
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Wave-level wait until every lane's values have been published (all 64 lanes
+// poll; lanes beyond nfree repeat lane 0's addresses).  The first read is issued
+// by the caller so that independent scalar work can overlap its latency; this
+// only spins when something is still pending.  Bounded: gives up (and tells
+// everybody) after a few seconds so a lost workgroup can never hang the device;
+// the host then restores its checkpoint and redoes the run (mc3hip.hip settle()).
+template <int NVAL, bool SYS = false>
+__device__ __forceinline__ bool wait_rows(const double *const (&addr)[NVAL], double (&val)[NVAL],
+                                          long long *ctl, unsigned long long *nspin = nullptr)
+{
+    for (unsigned spins = 0;; ++spins) {
+        if (nspin && spins)
+            *nspin += 1;                      // diagnostic build: polls beyond the first
+        bool pend[NVAL];
+        bool any_pending = false;
+#pragma unroll
+        for (int q = 0; q < NVAL; ++q) {
+            pend[q] = __any(mc3_bits(val[q]) == ROW_PENDING);
+            any_pending |= pend[q];
+        }
+        if (!any_pending)
+            return true;
+        // (no pause, and only the rows still missing are asked for again: every extra request
+        // on the fabric and every cycle of back-off measurably slows the hand-off)
+        if (__builtin_expect((spins & 1023u) == 1023u, 0)) {
+            // (made wave-uniform by hand: a per-lane load would make this exit, and with it
+            // every value live across the chain loop, divergent in the compiler's eyes)
+            const int ab = __builtin_amdgcn_readfirstlane(
+                (int)(__hip_atomic_load(&ctl[CTL_ABORT], __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT) != 0));
+            if (ab != 0 || spins > (1u << 23)) {
+                // every lane stores the same word: a lane-0 branch right at this exit would
+                // again make the exit look divergent
+                if (ab == 0)
+                    __hip_atomic_store(&ctl[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NVAL; ++q)
+            if (pend[q])
+                val[q] = load_published<SYS>(addr[q]);
+    }
+}
+
+// The same wait with K polls kept in flight (in-order return: the oldest is checked while
+// the younger ones travel), so that memory is sampled every round trip / K.
+template <int K, int SYS>
+__device__ __forceinline__ bool poll_ring(const double *const (&addr)[2], double (&v)[K][2],
+                                          double (&val)[2], long long *ctl,
+                                          unsigned long long *nspin = nullptr)
+{
+    for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const bool pend0 = __any(mc3_bits(v[q][0]) == ROW_PENDING);
+            const bool pend1 = __any(mc3_bits(v[q][1]) == ROW_PENDING);
+            if (!pend0 && !pend1) {
+                val[0] = v[q][0];
+                val[1] = v[q][1];
+                return true;
+            }
+            if (nspin)
+                *nspin += 1;
+            // only what is still missing is asked for again: every extra request on the
+            // fabric slows everybody's hand-off (K = 2, 3, 4 polls in flight: 181, 173,
+            // 140 M chain-steps/s against 197 for one)
+            // (asked again at once: a pause of 64 / 128 / 256 / 512 cycles here measured
+            // 197 / 195 / 191 / 182 M chain-steps/s against 205 without)
+            if (K > 1 || pend0)
+                v[q][0] = load_published<SYS>(addr[0]);
+            if (K > 1 || pend1)
+                v[q][1] = load_published<SYS>(addr[1]);
+        }
+        if (__builtin_expect((spins & 255u) == 255u, 0)) {
+            const int ab = __builtin_amdgcn_readfirstlane(
+                (int)(__hip_atomic_load(&ctl[CTL_ABORT], __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT) != 0));
+            if (ab != 0 || spins > (1u << 22)) {
+                if (ab == 0)
+                    __hip_atomic_store(&ctl[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+}
+
+// Keep a wave-uniform value where it was computed: an empty asm that "uses" it, so
+// neither the IR-level sinking pass nor the scheduler can move the (scalar) Philox
+// arithmetic of the next iteration out of the shadow of the partner-row loads.
+__device__ __forceinline__ void pin_scalar(uint64_t &q)
+{
+    asm volatile("; pin" : "+s"(q));
+}
+
+// the wave-uniform draws of one iteration (slots 0..2)
+struct Draws {
+    Draw2 d0, d1, d2;
+};
+
+__device__ __forceinline__ Draws make_draws(const DevProblem &P, uint64_t iter, int c, int sampler)
+{
+    Draws D;
+    D.d0 = draw2(P.seed, iter, (uint32_t)c, 0u);
+    D.d1 = D.d0;
+    D.d2 = D.d0;
+    if (sampler == MC3HIP_SNOOKER) {
+        D.d1 = draw2(P.seed, iter, (uint32_t)c, 1u);
+        D.d2 = draw2(P.seed, iter, (uint32_t)c, 2u);
+    }
+    return D;
+}
+
+// The same draws for 21 consecutive iterations at once, on the vector unit: lane
+// 3*(iter - base) + slot holds the four words of (iter, chain, slot).  The scalar Philox
+// of make_draws costs a wave ~350 issue slots per call; it is free only while the wave
+// waits for memory anyway.  Where nothing is left to wait for (persistent snooker, whose
+// rows are requested an iteration ahead) a batch costs ~50 cycles per iteration instead.
+struct DrawBatch {
+    uint32_t w0, w1, w2, w3;
+    long long base;
+};
+constexpr int DRAW_BATCH = 21;
+
+__device__ __forceinline__ void fill_draws(DrawBatch &B, const DevProblem &P, long long iter0,
+                                           int c)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    const uint64_t it = (uint64_t)iter0 + (uint64_t)(lane / 3u);
+    uint32_t w[4];
+    philox4x32_10((uint32_t)it, (uint32_t)(it >> 32), (uint32_t)c, lane % 3u, (uint32_t)P.seed,
+                  (uint32_t)(P.seed >> 32), w);
+    B.w0 = w[0];
+    B.w1 = w[1];
+    B.w2 = w[2];
+    B.w3 = w[3];
+    B.base = iter0;
+}
+
+__device__ __forceinline__ Draw2 batch_draw(const DrawBatch &B, int l)
+{
+    Draw2 d;
+    d.q0 = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)B.w0, l) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)B.w1, l) << 32);
+    d.q1 = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)B.w2, l) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)B.w3, l) << 32);
+    return d;
+}
+
+__device__ __forceinline__ Draws get_draws(DrawBatch &B, const DevProblem &P, long long iter,
+                                           int c)
+{
+    if (iter < B.base || iter >= B.base + DRAW_BATCH)
+        fill_draws(B, P, iter, c);
+    const int l = 3 * (int)(iter - B.base);
+    Draws D;
+    D.d0 = batch_draw(B, l);
+    D.d1 = batch_draw(B, l + 1);
+    D.d2 = batch_draw(B, l + 2);
+    return D;
+}
+
+// coefficient j of a fully-polynomial parameter vector: the free parameter it is (kf[j]) or
+// its fixed value (fx[j], kf[j] = -1); wave-uniform, computed once per launch
+template <int MT>
+__device__ __forceinline__ void coefficient_map(const DevProblem &P, int (&kf)[MT], double (&fx)[MT])
+{
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        kf[j] = -1;
+        fx[j] = P.params[j];
+    }
+    for (int k = 0; k < P.nfree; ++k) {
+        const int j = P.ifree[k];
+#pragma unroll
+        for (int q = 0; q < MT; ++q)
+            kf[q] = (q == j) ? k : kf[q];
+    }
+    // shared parameters copy their source, in order (chain.py:246-247)
+    for (int sh = 0; sh < P.nshare; ++sh) {
+        const int j = P.ishare[sh], src = P.share_src[sh];
+        int k = -1;
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < MT; ++q) {
+            k = (q == src) ? kf[q] : k;
+            v = (q == src) ? fx[q] : v;
+        }
+#pragma unroll
+        for (int q = 0; q < MT; ++q) {
+            kf[q] = (q == j) ? k : kf[q];
+            fx[q] = (q == j) ? v : fx[q];
+        }
+    }
+}
+
+// prior_term for the lean FX instances: the proposal is in the lanes (free parameter k in
+// lane k), not in LDS; same terms in the same order
+template <int MT>
+__device__ __forceinline__ double prior_from_lanes(const DevProblem &P, double npk,
+                                                   const int (&kf)[MT], const double (&fx)[MT])
+{
+    double pr = 0.0;
+    for (int g = 0; g < P.ngprior; ++g) {
+        const int j = P.igprior[g];
+        int k = -1;
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < MT; ++q) {
+            k = (q == j) ? kf[q] : k;
+            v = (q == j) ? fx[q] : v;
+        }
+        if (k >= 0)
+            v = make_double(__builtin_amdgcn_readlane(__double2loint(npk), k),
+                            __builtin_amdgcn_readlane(__double2hiint(npk), k));
+        const double d = v - P.prior[j];
+        const double s = (d > 0.0) ? d / P.priorup[j] : d / P.priorlow[j];
+        pr = pr + s * s;
+    }
+    return pr;
+}
+
+// DEMC partners, chain.py:221-232: r1 != c, r2 != c, r2 != r1, from the two 32-bit
+// halves of one draw
+__device__ __forceinline__ void demc_partners(uint64_t q0, int n, int c, int &r1, int &r2)
+{
+    r1 = 1 + (int)bounded32((uint32_t)(q0 >> 32), (uint32_t)(n - 1));
+    if (r1 == c)
+        r1 = 0;
+    r2 = r1 + 2 + (int)bounded32((uint32_t)q0, (uint32_t)(n - 2));   // < 2n
+    r2 = (r2 >= n) ? r2 - n : r2;                                      // (...) % n
+    if (r2 == c)
+        r2 = (r1 + 1 == n) ? 0 : r1 + 1;                               // (r1+1) % n
+}
+
+}  // namespace mc3hip

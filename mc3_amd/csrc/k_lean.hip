@@ -1,0 +1,56 @@
+// k_lean.hip -- instances of the lean one-wave persistent kernels (kernels_lean.h): the
+// hand-laid-out DEMC loop and the lean instances of run_chain, per polynomial degree, sampler,
+// peer-to-peer / fixed-coefficient / streamed-tile flavour.
+#include "ctx.h"
+#include "kernels_lean.h"
+
+namespace mc3hip {
+namespace host {
+namespace {
+
+template <int MT, int SMP>
+chain_kernel_fn fast_instance_tt(const mc3hip_ctx *c, bool p2p)
+{
+    if (p2p)
+        return c->P.thinning == 1 ? persist_fast_kernel<MT, SMP, true, 1>
+                                  : persist_fast_kernel<MT, SMP, true, 0>;
+    if (c->P.npad > VLANES)                        // streamed tiles (plain, thinning = 1 only)
+        return persist_fast_kernel<MT, SMP, false, 1, false, true>;
+    if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)   // FX
+        return persist_fast_kernel<MT, SMP, false, 1, true>;
+    return c->P.thinning == 1 ? persist_fast_kernel<MT, SMP, false, 1>
+                              : persist_fast_kernel<MT, SMP, false, 0>;
+}
+
+template <int MT>
+chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
+{
+    if (c->P.sampler == MC3HIP_MRW)
+        return fast_instance_tt<MT, MC3HIP_MRW>(c, p2p);
+    if (lean_demc_eligible(c)) {
+        if (p2p)
+            return lean_demc_kernel<MT, true>;
+        if (c->P.npad > VLANES)
+            return lean_demc_kernel<MT, false, false, true>;
+        if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)
+            return lean_demc_kernel<MT, false, true>;
+        return lean_demc_kernel<MT, false>;
+    }
+    if (c->P.sampler == MC3HIP_DEMC)
+        return fast_instance_tt<MT, MC3HIP_DEMC>(c, p2p);
+    return fast_instance_tt<MT, MC3HIP_SNOOKER>(c, p2p);
+}
+
+}  // namespace
+
+chain_kernel_fn fast_instance(const mc3hip_ctx *c, bool p2p)
+{
+    switch (c->mt) {
+    case MT_POLY2: return fast_instance_t<MT_POLY2>(c, p2p);
+    case MT_POLY3: return fast_instance_t<MT_POLY3>(c, p2p);
+    default: return fast_instance_t<MT_POLY4>(c, p2p);
+    }
+}
+
+}  // namespace host
+}  // namespace mc3hip

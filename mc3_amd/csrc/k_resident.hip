@@ -1,0 +1,40 @@
+// k_resident.hip -- instances of the tiled plan as ONE persistent launch (resident.h): design
+// matrices through the FP64 matrix cores, polynomials of 2..4 coefficients on the vector unit.
+#include "ctx.h"
+#include "resident.h"
+
+namespace mc3hip {
+namespace host {
+namespace {
+
+// LDS: group totals [RS_WCAP][16], the give-up word, one run_chain area per wave, 2048 weights,
+// the last block of operand rows [16][512]
+constexpr size_t RESIDENT_OWN = 64 + MC3HIP_MAX_PARAMS + 2 + 48 + 4;
+constexpr size_t RESIDENT_LDS_BYTES =
+    (RS_WCAP * 16 + 2 + 8 * RESIDENT_OWN + 2048 + 16 * 512) * sizeof(double);
+// polynomials (ResidentPoly): two exchange buffers [16][512], the give-up word, the areas
+constexpr size_t RESIDENT_POLY_LDS_BYTES = (2 * 16 * 512 + 2 + 8 * RESIDENT_OWN) * sizeof(double);
+
+}  // namespace
+
+size_t resident_lds_bytes(const mc3hip_ctx *c)
+{
+    return resident_poly(c) ? RESIDENT_POLY_LDS_BYTES : RESIDENT_LDS_BYTES;
+}
+
+resident_kernel_fn resident_kernel(const mc3hip_ctx *c, bool p2p)
+{
+    if (resident_poly(c)) {
+        switch (c->P.nmodel) {
+        case 2: return p2p ? resident_poly_kernel<2, true> : resident_poly_kernel<2, false>;
+        case 3: return p2p ? resident_poly_kernel<3, true> : resident_poly_kernel<3, false>;
+        default: return p2p ? resident_poly_kernel<4, true> : resident_poly_kernel<4, false>;
+        }
+    }
+    if ((c->P.nmodel + 4) / 4 == 2)           // operand rows: coefficients + the data column
+        return p2p ? resident_tile_kernel<2, true> : resident_tile_kernel<2, false>;
+    return p2p ? resident_tile_kernel<3, true> : resident_tile_kernel<3, false>;
+}
+
+}  // namespace host
+}  // namespace mc3hip

@@ -1,0 +1,88 @@
+// k_wavelet_impl.h -- instances of the general chain kernels with the wavelet likelihood (the
+// blocked D4 pyramid, wavelet.h) for ONE geometry: MC3_WW = 1, 4 or 8 waves per chain (a
+// function of ndata), or -- MC3_WL_LARGE -- the large-data instances (more than 2^14 points:
+// eight waves, pre-levels through global memory).  Included by k_wavelet_{w1,w4,w8,large}.hip,
+// which are compiled in parallel.
+#include "ctx.h"
+#include "kernels_fused.h"
+#include "wavelet.h"
+
+#define MC3_CAT_(a, b) a##b
+#define MC3_CAT(a, b) MC3_CAT_(a, b)
+#define MC3_FN(name) MC3_CAT(name, MC3_WL_TAG)
+
+namespace mc3hip {
+namespace host {
+namespace {
+
+#ifdef MC3_WL_LARGE
+constexpr int WW = 8;
+constexpr bool LARGE = true;
+#else
+constexpr int WW = MC3_WW;
+constexpr bool LARGE = false;
+#endif
+
+template <int MT>
+void launch_step_t(mc3hip_ctx *c, int roff)
+{
+    hipLaunchKernelGGL((step_kernel<WW, MT, true, LARGE>), dim3(c->P.nlocal), dim3(64 * WW),
+                       c->smem, c->stream, c->P, roff);
+}
+
+template <int MT>
+void persist_instance_t(const mc3hip_ctx *c, bool p2p, chain_kernel_fn *out)
+{
+    *out = p2p ? persist_kernel<WW, MT, true, LARGE, true> : persist_kernel<WW, MT, true, LARGE>;
+}
+
+template <int MT>
+void launch_eval_t(mc3hip_ctx *c, int n)
+{
+    hipLaunchKernelGGL((eval_chisq_kernel<WW, MT, true, LARGE>), dim3(n), dim3(64 * WW), c->smem,
+                       c->stream, c->P, (const double *)c->eval_params, c->eval_out);
+}
+
+// kernels that need more than the default 64 KiB of dynamic LDS must opt in
+template <int MT>
+void set_attr_t(mc3hip_ctx *c, hipError_t *e)
+{
+    *e = hipFuncSetAttribute(reinterpret_cast<const void *>(&step_kernel<WW, MT, true, LARGE>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->smem);
+    if (*e == hipSuccess)
+        *e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&eval_chisq_kernel<WW, MT, true, LARGE>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->smem);
+}
+
+#define DISPATCH_MT(FN, ...)                                                        \
+    switch (c->mt) {                                                                \
+    case MT_POLY2: FN<MT_POLY2>(__VA_ARGS__); break;                                \
+    case MT_POLY3: FN<MT_POLY3>(__VA_ARGS__); break;                                \
+    case MT_POLY4: FN<MT_POLY4>(__VA_ARGS__); break;                                \
+    case MT_LINEAR: FN<MT_LINEAR>(__VA_ARGS__); break;                              \
+    default: FN<MT_POLY_GENERIC>(__VA_ARGS__); break;                               \
+    }
+
+}  // namespace
+
+void MC3_FN(launch_step_wavelet_)(mc3hip_ctx *c, int roff) { DISPATCH_MT(launch_step_t, c, roff) }
+
+chain_kernel_fn MC3_FN(persist_instance_wavelet_)(const mc3hip_ctx *c, bool p2p)
+{
+    chain_kernel_fn f = nullptr;
+    DISPATCH_MT(persist_instance_t, c, p2p, &f)
+    return f;
+}
+
+void MC3_FN(launch_eval_wavelet_)(mc3hip_ctx *c, int n) { DISPATCH_MT(launch_eval_t, c, n) }
+
+hipError_t MC3_FN(set_smem_attr_wavelet_)(mc3hip_ctx *c)
+{
+    hipError_t e = hipSuccess;
+    DISPATCH_MT(set_attr_t, c, &e)
+    return e;
+}
+
+}  // namespace host
+}  // namespace mc3hip

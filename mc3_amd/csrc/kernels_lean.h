@@ -1,0 +1,246 @@
+// kernels_lean.h -- the lean one-wave persistent kernels.
+#pragma once
+#include "run_chain.h"
+
+namespace mc3hip {
+
+// the lean instance (see run_chain): one wave per chain, MT free polynomial
+// coefficients, Gaussian chisq, ndata <= 1024, no priors/shared/fixed/epsilon/trace
+// (MULTI: more than 1024 points; the first tile stays in registers, the rest is streamed)
+template <int MT, int SMP, bool P2P = false, int TH = 0, bool FX = false, bool MULTI = false>
+__global__ __launch_bounds__(64) void persist_fast_kernel(const DevProblem P, const int nref)
+{
+    run_chain<1, MT, false, MULTI, true, SMP, true, PH_FUSED, P2P, TH, FX>(P, P.ctl[0], nref);
+}
+
+// ---------------------------------------------------------------------------------
+// The headline shape written out by hand: lean instance (see run_chain FAST), DEMC,
+// thinning = 1, persistent.  Same arithmetic and the same results as
+// run_chain<1, MT, false, false, true, MC3HIP_DEMC, true>; what differs is only how the
+// loop is laid out for ONE wave that nothing else on its SIMD hides latencies for:
+//   * every address is a pointer bumped by a constant per refresh (one 128-byte line per
+//     row), no 64-bit index arithmetic in the loop;
+//   * everything of refresh R+1 that does not depend on chain states -- Philox, the
+//     Metropolis draw, the partner indices and their byte offsets -- is computed in the
+//     shadow of refresh R's partner-row wait;
+//   * the Metropolis update is a select, not a branch; only the rare events (new best
+//     fit, out-of-bounds proposal, a failed wait) leave the straight line.
+template <int MT, bool P2P, bool FX = false, bool MULTI = false>
+__global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const int nref)
+{
+    const int nf = FX ? P.nfree : MT;        // FX: some coefficients are fixed (nfree < MT)
+    constexpr int ZS = ZROW;                 // doubles per Z row: one 128-byte line (NF <= 16)
+    constexpr int LM = P2P ? 1 : 0;
+    const int lane = threadIdx.x;
+    const int lc = blockIdx.x;
+    const int c = P.chain0 + lc;
+    const bool mine = lane < nf;
+    const int kk = mine ? lane : 0;
+    long long *ctl_rw = const_cast<long long *>(P.ctl);
+    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
+            &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+        return;
+    MC3_STAMP(0);
+    DataTile<1, MT> tile;
+    tile.load(P);
+    DataTile<1, MT> tile1;                   // MULTI: points 1024..2047 stay in registers too
+    if constexpr (MULTI)
+        tile1.load(P, VLANES);
+    const long long R0 = P.ctl[0];
+    const int n = P.nchains;
+    const size_t blockstride = (size_t)n * ZS;                   // doubles per refresh
+    // rows of refresh R0 - 1 (the current states) and of refresh R0 (to be published)
+    const double *pbase = (R0 == 0) ? P.snap0 : P.Z + (size_t)(P.M0 + (R0 - 1) * n) * ZS;
+    double *zblock = P.Z + (size_t)(P.M0 + R0 * n) * ZS;
+    double *lp_row = P.log_post + (P.M0 + R0 * n + c);
+    int32_t *zc_row = P.zchain + (P.M0 + R0 * n + c);
+    double xk = mine ? pbase[(size_t)c * ZS + lane] : 0.0;
+    double cur = P.chisq[lc];
+    double best = P.best_chisq[lc];
+    const long long nacc0 = P.numaccept[lc];
+    const double pmin_k = mine ? P.fmin[lane] : 0.0;
+    const double pmax_k = mine ? P.fmax[lane] : 0.0;
+    const double gamma = P.gamma, feps = P.fepsilon;
+    const long long abort_at = (P.test_abort >= 0 && lc == 0) ? (long long)P.test_abort : -1;
+    int nacc = 0;
+    bool alive = true;
+    int kf[MT];
+    double fx[MT];
+    if constexpr (FX)
+        coefficient_map<MT>(P, kf, fx);
+    (void)kf; (void)fx;
+    // log_post / zchain of the last (up to) 64 refreshes wait in lane (R - R0) mod 64 and
+    // are written 64 at a time: nobody reads them inside the launch
+    double lpbuf = 0.0;
+    MC3_STAMP(1);
+
+    // draws of the first refresh
+    Draw2 d = draw2(P.seed, (uint64_t)R0, (uint32_t)c, 0u);
+    double u = u01(d.q1);
+    int r1, r2;
+    demc_partners(d.q0, n, c, r1, r2);
+    int off1 = r1 * ZS + kk, off2 = r2 * ZS + kk;
+
+    unsigned long long tk_prev3 = 0, tk_prevend = 0;
+    unsigned long long ta8 = 0, ta9 = 0, ta10 = 0, ta11 = 0, ta12 = 0, ta13 = 0, ta14 = 0, ta15 = 0;
+    (void)tk_prev3; (void)tk_prevend; (void)ta8; (void)ta9; (void)ta10; (void)ta11; (void)ta12;
+    (void)ta13; (void)ta14; (void)ta15;
+    const long long Rend = R0 + nref;
+    long long rdone = R0;                    // refreshes completed (published) by this launch
+    auto flush_columns = [&](int count) {
+        if (lane < count) {
+            if constexpr (P2P) {
+                const size_t roff = (size_t)(lp_row - P.log_post) + (size_t)lane * n;
+                for (int pr = 0; pr < P.npeers; ++pr)
+                    __hip_atomic_store(&P.peerLP[pr][roff], lpbuf, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                lp_row[(size_t)lane * n] = lpbuf;
+            }
+            zc_row[(size_t)lane * n] = c;
+        }
+    };
+    // every load issued so far is complete before the loop is entered, so that no path
+    // through it carries a pending load to the latch (see the note after wait_rows)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (long long R = R0; R < Rend; ++R) {
+        unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+        (void)tk0; (void)tk1; (void)tk2; (void)tk3;
+        MC3_TICK(tk0);
+#ifdef MC3HIP_STAMPS
+        if (tk_prevend != 0) {
+            ta11 += tk_prevend - tk_prev3;
+            ta13 += tk0 - tk_prevend;
+        }
+#endif
+        if (__builtin_expect(R == abort_at, 0)) {                                         // test hook
+            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);             // (all lanes, same word)
+            break;            // (the host restores its checkpoint after an abort)
+        }
+        // partner rows of this refresh (chain.py:221-232), requested first
+        // (a short pause lets the stores of the previous refresh clear the memory pipeline
+        // ahead of the polls: +3 % measured, 64..192 cycles all the same)
+        __builtin_amdgcn_s_sleep(1);
+        const double *const addr[2] = {pbase + off1, pbase + off2};
+        double val[2];
+        constexpr int KR = 1;            // polls kept in flight: more measured slower (poll_ring)
+        double ring[KR][2];
+        ring[0][0] = load_published<LM>(addr[0]);
+        ring[0][1] = load_published<LM>(addr[1]);
+#ifdef MC3HIP_STAMPS
+        unsigned long long tkL;
+        MC3_TICK(tkL);
+        ta15 += tkL - tk0;
+#endif
+        const double u_now = u;
+        __builtin_amdgcn_sched_barrier(0);
+        // ... and behind them everything of the next refresh that needs no chain state
+        d = draw2(P.seed, (uint64_t)(R + 1), (uint32_t)c, 0u);
+        pin_scalar(d.q0);
+        pin_scalar(d.q1);
+        u = u01(d.q1);                                               // chain.py:259
+        demc_partners(d.q0, n, c, r1, r2);
+        off1 = r1 * ZS + kk;
+        off2 = r2 * ZS + kk;
+        asm volatile("; pin" : "+v"(u), "+v"(off1), "+v"(off2));
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef MC3HIP_STAMPS
+        alive = poll_ring<KR, LM>(addr, ring, val, ctl_rw, &ta14);
+#else
+        alive = poll_ring<KR, LM>(addr, ring, val, ctl_rw);
+#endif
+        MC3_TICK(tk1);
+        if (__builtin_expect(!alive, 0))
+            break;
+        // proposal and boundaries, chain.py:232-243
+        const double jump_k = gamma * (val[0] - val[1]) + feps * 0.0;
+        const double npk = xk + jump_k;
+        const bool outk = mine && (npk < pmin_k || npk > pmax_k);
+        if (__builtin_expect(!__any(outk), 1)) {
+            Model<MT> model;
+            if constexpr (!FX) {
+                model.init_from_lanes(P, npk);                 // every coefficient is free
+            } else {
+                model.init_from_lanes(P, npk, kf, fx);         // FX: some are fixed
+            }
+            double nextchisq =
+                block_gauss_model<1, MT, MULTI, MULTI>(P, model, nullptr, nullptr, tile,
+                                                       &tile1);          // chain.py:249
+            if constexpr (FX)
+                nextchisq = nextchisq + prior_from_lanes<MT>(P, npk, kf, fx);
+            MC3_TICK(tk2);
+            const double ratio = mc3_det_exp(0.5 * (cur - nextchisq)) * 1.0;
+            const bool acc = ratio > u_now;                          // chain.py:257-274
+            xk = acc ? npk : xk;
+            if (__builtin_expect(__any(acc && nextchisq < best), 0)) {
+                best = nextchisq;
+                if (mine)
+                    P.bestx[(size_t)lc * nf + lane] = xk;
+                if (lane == 0)
+                    P.best_iter[lc] = R;
+            }
+            cur = acc ? nextchisq : cur;
+            nacc += acc ? 1 : 0;
+        } else if (outk) {
+            atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
+        }
+#ifdef MC3HIP_STAMPS
+        MC3_TICK(tk3);
+        if (tk2 != 0) {
+            ta8 += tk1 - tk0;
+            ta9 += tk2 - tk1;
+            ta10 += tk3 - tk2;
+            ta12 += 1;
+        }
+        tk_prev3 = tk3;
+#endif
+        // Every poll has long returned.  Saying so here keeps the compiler's wait-count
+        // bookkeeping from guarding the poll registers at the loop latch, where a wait would
+        // stall on the acknowledgement of the row about to be published (loads and stores
+        // share the counter on gfx9).
+        __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0), already true
+        // Z append, chain.py:276-289: publish the row ...
+        if constexpr (P2P) {
+            const size_t zoff = (size_t)(zblock - P.Z) + (size_t)c * ZS + lane;
+            if (mine)
+                for (int pr = 0; pr < P.npeers; ++pr)                // ... into every replica
+                    __hip_atomic_store(&P.peerZ[pr][zoff], xk, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            if (mine)
+                __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);        // publish (sc1)
+        }
+        // ... and park the bookkeeping columns
+        const int slot = (int)(R - R0) & 63;
+        lpbuf = (lane == slot) ? -0.5 * cur : lpbuf;
+        if (__builtin_expect(slot == 63, 0)) {
+            flush_columns(64);
+            lp_row += (size_t)64 * n;
+            zc_row += (size_t)64 * n;
+        }
+        pbase = zblock;
+        zblock += blockstride;
+        MC3_TICK(tk_prevend);
+        rdone = R + 1;
+    }
+    flush_columns((int)(rdone - R0) & 63);       // the unwritten tail (also after an early exit)
+    if (mine)
+        P.X[(size_t)lc * nf + lane] = xk;
+    if (lane == 0) {
+        P.chisq[lc] = cur;
+        P.best_chisq[lc] = best;
+        P.numaccept[lc] = nacc0 + nacc;
+    }
+    MC3_STAMP(4);
+#ifdef MC3HIP_STAMPS
+    if (lc == 0 && lane == 0) {
+        P.stamps[8] += ta8; P.stamps[9] += ta9; P.stamps[10] += ta10;
+        P.stamps[11] += ta11; P.stamps[12] += ta12; P.stamps[13] += ta13;
+        P.stamps[14] += ta14; P.stamps[15] += ta15;
+    }
+#endif
+}
+
+}  // namespace mc3hip

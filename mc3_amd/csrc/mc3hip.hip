@@ -23,9 +23,11 @@
 #include <string>
 #include <vector>
 
-#include "chain_kernels.h"
+#include "ctx.h"
+#include "post.h"
 
 using namespace mc3hip;
+using namespace mc3hip::host;
 
 namespace {
 
@@ -95,7 +97,7 @@ int choose_wpc(int nlocal, int ndata, int wlike)
     // data sum is short; otherwise split a chain's data over 4 or 16 waves.
     const char *env = getenv("MC3HIP_WPC");
     if (wlike) {
-        // blocked D4 pyramid (chain_kernels.h block_wavelet): at most 32 points per thread;
+        // blocked D4 pyramid (wavelet.h block_wavelet): at most 32 points per thread;
         // one wave per chain up to 2048 points (no barrier at all), four at 4096, eight
         // above (two per SIMD: a wave alone issues FP64 at half rate).  The geometry is a
         // function of ndata alone; the summation order follows it, mc3hip_get_plan reports
@@ -119,64 +121,6 @@ int choose_wpc(int nlocal, int ndata, int wlike)
 
 }  // namespace
 
-struct mc3hip_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
-    DevProblem P{};
-    int model_kind = 0, mt = 0, wpc = 1;
-    size_t smem = 0;
-    int64_t zlen = 0;
-    int64_t refresh_done = 0;
-    bool populated = false;
-    uint32_t flags = 0;
-    std::vector<void *> allocs;
-    char *arena = nullptr;
-    size_t arena_used = 0;
-    long long *ctl = nullptr;
-    double *eval_params = nullptr, *eval_out = nullptr;
-    int eval_cap = 0;
-    double *model_out = nullptr;
-    // graph
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    int graph_nodes = 0;
-    int persist_refs = 0;           // refreshes per persistent launch, 0 = off
-    bool persist_checked = false;
-    bool fast = false;              // lean persistent instance selected
-    double *stage = nullptr;        // dense staging for Z row transfers (grow-only)
-    size_t stage_doubles = 0;
-    // checkpoint of the per-chain state taken before the first persistent launch that
-    // has not been confirmed yet (recovery if a launch gives up)
-    char *ckpt = nullptr;
-    int64_t ckpt_R = 0;
-    bool ckpt_valid = false;
-    long long last_run0 = 0;
-    int recoveries = 0;
-    int tile_kmax = 0;              // tiled plan: coefficient capacity of the tile kernel
-    int tile_chain_block = 0;       // chains per workgroup column of the tile kernel
-    bool resident = false;          // tiled plan as one persistent launch (resident_tile_kernel)
-    int resident_chain_block = 0;   // its column height
-    bool ckpt_settled = false;      // peer-to-peer: the launches since the checkpoint completed
-                                    // HERE; confirmed by the caller's next mc3hip_run
-    double *moments = nullptr;      // scratch of mc3hip_chain_moments (2 x nchains x nfree)
-    // comm
-    ncclComm_t comm = nullptr;
-    int rank = 0, nranks = 1;
-    int64_t logpost_gathered = 0;   // refreshes whose log_post rows are already exchanged
-    // RCCL exchange captured in a hipGraph: per refresh (step kernel, all-gather of ring
-    // slot r, ring_in kernel) x comm_graph_nodes
-    double *xring = nullptr;
-    int comm_graph_nodes = 0;
-    hipGraph_t cgraph = nullptr;
-    hipGraphExec_t cgraph_exec = nullptr;
-    bool comm_graph_failed = false;
-    bool comm_warm = false;         // one eager collective has run (RCCL set up its channels)
-    // peer-to-peer hand-off
-    int p2p_ranks = 0;
-    std::vector<void *> p2p_opened;
-};
 
 namespace {
 
@@ -224,187 +168,18 @@ int dev_upload(mc3hip_ctx *c, const T **dst, const T *src, size_t count)
     return MC3HIP_OK;
 }
 
-constexpr int WL_EVAL_BLOCKS = 256;
-
-// Waves per chain are dispatched as {1, 4, 16}; the wavelet geometries have 1, 4 or 8:
-// the widest one rides on the dispatch slot of the widest Gaussian one.
-template <int WPC>
-constexpr int wavelet_waves() { return WPC == 16 ? 8 : WPC; }
-
-template <int WPC, int MT>
-void launch_step_t(mc3hip_ctx *c, int roff)
-{
-    constexpr int WW = wavelet_waves<WPC>();
-    if (c->P.wlike && c->P.wl_scratch)                  // (more than 2^14 points)
-        hipLaunchKernelGGL((step_kernel<8, MT, true, true>), dim3(c->P.nlocal), dim3(512),
-                           c->smem, c->stream, c->P, roff);
-    else if (c->P.wlike)
-        hipLaunchKernelGGL((step_kernel<WW, MT, true, false>), dim3(c->P.nlocal),
-                           dim3(64 * WW), c->smem, c->stream, c->P, roff);
-    else if (c->P.npad > VLANES)
-        hipLaunchKernelGGL((step_kernel<WPC, MT, false, true>), dim3(c->P.nlocal),
-                           dim3(64 * WPC), c->smem, c->stream, c->P, roff);
-    else
-        hipLaunchKernelGGL((step_kernel<WPC, MT, false, false>), dim3(c->P.nlocal),
-                           dim3(64 * WPC), c->smem, c->stream, c->P, roff);
-}
-
-template <int MT>
-void launch_propose_t(mc3hip_ctx *c, int roff, int j)
-{
-    hipLaunchKernelGGL((propose_kernel<MT>), dim3(c->P.nlocal), dim3(64), c->smem, c->stream,
-                       c->P, roff, j);
-}
-template <int MT>
-void launch_finish_t(mc3hip_ctx *c, int roff, int j)
-{
-    hipLaunchKernelGGL((finish_kernel<MT>), dim3(c->P.nlocal), dim3(64), c->smem, c->stream,
-                       c->P, roff, j);
-}
-#define DISPATCH_MT1(FN, ...)                                                       \
-    switch (c->mt) {                                                                \
-    case MT_POLY2: FN<MT_POLY2>(__VA_ARGS__); break;                                \
-    case MT_POLY3: FN<MT_POLY3>(__VA_ARGS__); break;                                \
-    case MT_POLY4: FN<MT_POLY4>(__VA_ARGS__); break;                                \
-    case MT_LINEAR: FN<MT_LINEAR>(__VA_ARGS__); break;                              \
-    default: FN<MT_POLY_GENERIC>(__VA_ARGS__); break;                               \
-    }
-
-// LDS of the tile kernel: 16 chains x 1024 partial sums + two buffers of 16 coefficient rows
-constexpr size_t TILE_LDS_BYTES = (16 * 1024 + 2 * 16 * (16 + 2)) * sizeof(double);
-
-template <int KMAX, bool LINEAR, int KX = 0>
-void launch_tile_t(mc3hip_ctx *c)
-{
-    const int ncol = (c->P.nlocal + c->tile_chain_block - 1) / c->tile_chain_block;
-    constexpr int TP = KMAX <= 4 ? 4 : 2;
-    hipLaunchKernelGGL((tile_chisq_kernel<KMAX, LINEAR, TP, KX>), dim3(c->P.ntiles, ncol),
-                       dim3(1024), TILE_LDS_BYTES, c->stream, c->P,
-                       c->tile_chain_block, (const double *)c->P.sc_nextp,
-                       (const int32_t *)c->P.sc_flag);
-}
-
-// polynomials of 2..4 coefficients: the instance with the degree compiled in
-int tile_exact_degree(const mc3hip_ctx *c)
-{
-    return (c->mt != MT_LINEAR && c->tile_kmax == 4 && c->P.nmodel >= 2) ? c->P.nmodel : 0;
-}
-
-int tile_set_attr(mc3hip_ctx *c)
-{
-    const int bytes = (int)TILE_LDS_BYTES;
-#define TILE_ATTR(KMAX, LIN)                                                               \
-    HIP_TRY(hipFuncSetAttribute(                                                           \
-        reinterpret_cast<const void *>(&tile_chisq_kernel<KMAX, LIN, (KMAX <= 4 ? 4 : 2)>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    const bool lin = c->mt == MT_LINEAR;
-#define TILE_ATTR_X(KX)                                                                    \
-    HIP_TRY(hipFuncSetAttribute(                                                           \
-        reinterpret_cast<const void *>(&tile_chisq_kernel<4, false, 4, KX>),               \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    switch (tile_exact_degree(c)) {
-    case 2: TILE_ATTR_X(2) return MC3HIP_OK;
-    case 3: TILE_ATTR_X(3) return MC3HIP_OK;
-    case 4: TILE_ATTR_X(4) return MC3HIP_OK;
-    default: break;
-    }
-#undef TILE_ATTR_X
-    switch (c->tile_kmax) {
-    case 4: if (lin) { TILE_ATTR(4, true) } else { TILE_ATTR(4, false) } break;
-    case 8: if (lin) { TILE_ATTR(8, true) } else { TILE_ATTR(8, false) } break;
-    case 12: if (lin) { TILE_ATTR(12, true) } else { TILE_ATTR(12, false) } break;
-    default: if (lin) { TILE_ATTR(16, true) } else { TILE_ATTR(16, false) } break;
-    }
-    return MC3HIP_OK;
-}
-
-// design-matrix models with two points per virtual lane (5..16 coefficients): the data
-// sums go through the FP64 matrix cores (tile_chisq_mfma_kernel)
-bool tile_uses_mfma(const mc3hip_ctx *c)
-{
-    return c->mt == MT_LINEAR && c->P.tile == 2048 && !getenv("MC3HIP_NO_MFMA");
-}
-
-template <int KB>
-void launch_tile_mfma_t(mc3hip_ctx *c)
-{
-    const int ncol = (c->P.nlocal + c->tile_chain_block - 1) / c->tile_chain_block;
-    hipLaunchKernelGGL((tile_chisq_mfma_kernel<KB>), dim3(c->P.ntiles, ncol), dim3(512),
-                       0, c->stream, c->P, c->tile_chain_block,
-                       (const double *)c->P.sc_nextp, (const int32_t *)c->P.sc_flag);
-}
-
-void launch_tile(mc3hip_ctx *c)
-{
-    if (tile_uses_mfma(c)) {
-        switch ((c->P.nmodel + 3) / 4) {
-        case 2: launch_tile_mfma_t<2>(c); break;
-        case 3: launch_tile_mfma_t<3>(c); break;
-        default: launch_tile_mfma_t<4>(c); break;
-        }
-        return;
-    }
-    switch (tile_exact_degree(c)) {
-    case 2: launch_tile_t<4, false, 2>(c); return;
-    case 3: launch_tile_t<4, false, 3>(c); return;
-    case 4: launch_tile_t<4, false, 4>(c); return;
-    default: break;
-    }
-    const bool lin = c->mt == MT_LINEAR;
-    switch (c->tile_kmax) {
-    case 4: lin ? launch_tile_t<4, true>(c) : launch_tile_t<4, false>(c); break;
-    case 8: lin ? launch_tile_t<8, true>(c) : launch_tile_t<8, false>(c); break;
-    case 12: lin ? launch_tile_t<12, true>(c) : launch_tile_t<12, false>(c); break;
-    default: lin ? launch_tile_t<16, true>(c) : launch_tile_t<16, false>(c); break;
-    }
-}
 
 // one refresh of the tiled plan: thinning x (propose, tile sums, finish)
 void launch_refresh_tiled(mc3hip_ctx *c, int roff)
 {
     for (int j = 0; j < c->P.thinning; ++j) {
-        DISPATCH_MT1(launch_propose_t, c, roff, j)
+        launch_propose(c, roff, j);
         launch_tile(c);
-        DISPATCH_MT1(launch_finish_t, c, roff, j)
+        launch_finish(c, roff, j);
     }
 }
 
-// ---- resident tiled plan (chain_kernels.h ResidentTile) --------------------------------
-// LDS: group totals [RS_WCAP][16], the give-up word, one run_chain area per wave, 2048 weights,
-// the last block of operand rows [16][512]
-constexpr size_t RESIDENT_OWN = 64 + MC3HIP_MAX_PARAMS + 2 + 48 + 4;
-constexpr size_t RESIDENT_LDS_BYTES =
-    (RS_WCAP * 16 + 2 + 8 * RESIDENT_OWN + 2048 + 16 * 512) * sizeof(double);
-// polynomials (ResidentPoly): two exchange buffers [16][512], the give-up word, the areas
-constexpr size_t RESIDENT_POLY_LDS_BYTES = (2 * 16 * 512 + 2 + 8 * RESIDENT_OWN) * sizeof(double);
-
-typedef void (*resident_kernel_fn)(const DevProblem, const int, const int);
-
-// design-matrix models through the matrix cores, or polynomials of 2..4 coefficients
-bool resident_poly(const mc3hip_ctx *c)
-{
-    return c->mt != MT_LINEAR && c->P.tile == 4096 && tile_exact_degree(c) >= 2;
-}
-
-size_t resident_lds_bytes(const mc3hip_ctx *c)
-{
-    return resident_poly(c) ? RESIDENT_POLY_LDS_BYTES : RESIDENT_LDS_BYTES;
-}
-
-resident_kernel_fn resident_kernel(const mc3hip_ctx *c, bool p2p)
-{
-    if (resident_poly(c)) {
-        switch (c->P.nmodel) {
-        case 2: return p2p ? resident_poly_kernel<2, true> : resident_poly_kernel<2, false>;
-        case 3: return p2p ? resident_poly_kernel<3, true> : resident_poly_kernel<3, false>;
-        default: return p2p ? resident_poly_kernel<4, true> : resident_poly_kernel<4, false>;
-        }
-    }
-    if ((c->P.nmodel + 4) / 4 == 2)           // operand rows: coefficients + the data column
-        return p2p ? resident_tile_kernel<2, true> : resident_tile_kernel<2, false>;
-    return p2p ? resident_tile_kernel<3, true> : resident_tile_kernel<3, false>;
-}
-
+// ---- resident tiled plan (resident.h ResidentTile / ResidentPoly) ------------------------
 // the problem has the shape a resident kernel is written for (whether its grid fits the
 // device is decide_persist's question)
 bool resident_shape(const mc3hip_ctx *c)
@@ -420,82 +195,6 @@ void launch_resident(mc3hip_ctx *c, int nref)
     const int ncol = (c->P.nlocal + cb - 1) / cb;
     hipLaunchKernelGGL(resident_kernel(c, c->p2p_ranks > 1), dim3(c->P.ntiles, ncol), dim3(512),
                        resident_lds_bytes(c), c->stream, c->P, nref, cb);
-}
-
-// the lean persistent instance applies when nothing of the general machinery is
-// needed (chain_kernels.h run_chain FAST)
-bool fast_eligible(const mc3hip_ctx *c)
-{
-    const DevProblem &P = c->P;
-    // (fixed coefficients and Gaussian priors are fine: the FX kernels map coefficient j to
-    // its free parameter or to its fixed value, chain_kernels.h coefficient_map)
-    // instantiated for one GPU and thinning = 1 only: FX of persist_fast_kernel)
-    const bool plain = P.nparams == P.nfree && P.ngprior == 0 && P.nshare == 0;
-    const bool fx_ok = P.nfree >= 1 && P.thinning == 1 && !(c->flags & MC3HIP_FLAG_P2P);
-    // more than one 1024-point tile (streamed): plain problems, one GPU, thinning = 1
-    const bool multi = P.npad > VLANES;
-    const bool size_ok = !multi || (plain && fx_ok && P.tile == 0);
-    return c->wpc == 1 && !P.wlike && size_ok && c->mt >= 2 && c->mt <= 4 &&
-           (plain || fx_ok) && P.nmodel == P.nparams &&
-           P.fepsilon == 0.0 && P.trace_iters == 0 &&
-           (P.sampler == MC3HIP_DEMC || P.sampler == MC3HIP_SNOOKER ||
-            P.sampler == MC3HIP_MRW) &&
-           !getenv("MC3HIP_NO_FAST");
-}
-
-// the headline shape (DEMC, thinning 1) has a loop of its own: lean_demc_kernel
-bool lean_demc_eligible(const mc3hip_ctx *c)
-{
-    return c->fast && c->P.sampler == MC3HIP_DEMC && c->P.thinning == 1 &&
-           c->P.nparams == c->mt && c->P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
-}
-
-// The lean kernels all have the signature (DevProblem, int nref).  ONE function picks the
-// instance a context runs, so that the launch and the occupancy query that sizes the
-// persistent grid can never disagree (the MULTI / FX instances use more than twice the
-// registers of the plain ones: 4 single-wave workgroups per CU instead of 8).
-typedef void (*fast_kernel_fn)(const DevProblem, const int);
-
-template <int MT, int SMP>
-fast_kernel_fn fast_instance_tt(const mc3hip_ctx *c, bool p2p)
-{
-    if (p2p)
-        return c->P.thinning == 1 ? persist_fast_kernel<MT, SMP, true, 1>
-                                  : persist_fast_kernel<MT, SMP, true, 0>;
-    if (c->P.npad > VLANES)                        // streamed tiles (plain, thinning = 1 only)
-        return persist_fast_kernel<MT, SMP, false, 1, false, true>;
-    if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)   // FX
-        return persist_fast_kernel<MT, SMP, false, 1, true>;
-    return c->P.thinning == 1 ? persist_fast_kernel<MT, SMP, false, 1>
-                              : persist_fast_kernel<MT, SMP, false, 0>;
-}
-
-template <int MT>
-fast_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
-{
-    if (c->P.sampler == MC3HIP_MRW)
-        return fast_instance_tt<MT, MC3HIP_MRW>(c, p2p);
-    if (lean_demc_eligible(c)) {
-        if (p2p)
-            return lean_demc_kernel<MT, true>;
-        if (c->P.npad > VLANES)
-            return lean_demc_kernel<MT, false, false, true>;
-        if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)
-            return lean_demc_kernel<MT, false, true>;
-        return lean_demc_kernel<MT, false>;
-    }
-    if (c->P.sampler == MC3HIP_DEMC)
-        return fast_instance_tt<MT, MC3HIP_DEMC>(c, p2p);
-    return fast_instance_tt<MT, MC3HIP_SNOOKER>(c, p2p);
-}
-
-fast_kernel_fn fast_instance(const mc3hip_ctx *c, bool p2p)
-{
-    switch (c->mt) {
-    case MT_POLY2: return fast_instance_t<MT_POLY2>(c, p2p);
-    case MT_POLY3: return fast_instance_t<MT_POLY3>(c, p2p);
-    default: return fast_instance_t<MT_POLY4>(c, p2p);
-    }
 }
 
 // dynamic LDS of the lean kernels: the hand-laid-out loop uses none
@@ -533,40 +232,6 @@ int fast_blocks_per_cu(mc3hip_ctx *c)
     return nb;
 }
 
-// workgroups of the general persistent kernel that fit on one CU (0 on error): the exact
-// instance (likelihood, tile count, peer-to-peer stores) that will be launched
-template <int WPC, int MT>
-void persist_instance_t(mc3hip_ctx *c, bool p2p, fast_kernel_fn *out)
-{
-    fast_kernel_fn f;
-    constexpr int WW = wavelet_waves<WPC>();
-    if (c->P.wlike && c->P.wl_scratch)
-        f = p2p ? persist_kernel<8, MT, true, true, true> : persist_kernel<8, MT, true, true>;
-    else if (c->P.wlike)
-        f = p2p ? persist_kernel<WW, MT, true, false, true> : persist_kernel<WW, MT, true, false>;
-    else if (c->P.npad > VLANES)
-        f = p2p ? persist_kernel<WPC, MT, false, true, true> : persist_kernel<WPC, MT, false, true>;
-    else
-        f = p2p ? persist_kernel<WPC, MT, false, false, true>
-                : persist_kernel<WPC, MT, false, false>;
-    *out = f;
-}
-
-template <int WPC, int MT>
-void launch_eval_t(mc3hip_ctx *c, int n)
-{
-    constexpr int WW = wavelet_waves<WPC>();
-    if (c->P.wlike && c->P.wl_scratch)
-        hipLaunchKernelGGL((eval_chisq_kernel<8, MT, true, true>), dim3(n), dim3(512), c->smem,
-                           c->stream, c->P, (const double *)c->eval_params, c->eval_out);
-    else if (c->P.wlike)
-        hipLaunchKernelGGL((eval_chisq_kernel<WW, MT, true>), dim3(n), dim3(64 * WW), c->smem,
-                           c->stream, c->P, (const double *)c->eval_params, c->eval_out);
-    else
-        hipLaunchKernelGGL((eval_chisq_kernel<WPC, MT, false>), dim3(n), dim3(64 * WPC), c->smem,
-                           c->stream, c->P, (const double *)c->eval_params, c->eval_out);
-}
-
 template <int MT>
 void launch_model_t(mc3hip_ctx *c)
 {
@@ -575,29 +240,61 @@ void launch_model_t(mc3hip_ctx *c)
                        c->stream, c->P, (const double *)c->eval_params, c->model_out);
 }
 
-#define DISPATCH_MT(FN, WPC, ...)                                                   \
-    switch (c->mt) {                                                                \
-    case MT_POLY2: FN<WPC, MT_POLY2>(__VA_ARGS__); break;                           \
-    case MT_POLY3: FN<WPC, MT_POLY3>(__VA_ARGS__); break;                           \
-    case MT_POLY4: FN<WPC, MT_POLY4>(__VA_ARGS__); break;                           \
-    case MT_LINEAR: FN<WPC, MT_LINEAR>(__VA_ARGS__); break;                         \
-    default: FN<WPC, MT_POLY_GENERIC>(__VA_ARGS__); break;                          \
-    }
-
-#define DISPATCH(FN, ...)                                                           \
+// The general chain kernels are instantiated per likelihood and workgroup width in
+// translation units of their own (ctx.h); a context's c->wpc is 1, 4 or 16 with the Gaussian
+// likelihood, 1, 4 or 8 with the wavelet one (choose_wpc), whose large-data instances (more
+// than 2^14 points, P.wl_scratch) always have eight waves.
+#define MC3_BY_WIDTH(call_gauss, call_wavelet)                                      \
+    if (c->P.wlike) {                                                               \
+        if (c->P.wl_scratch) return call_wavelet(large);                            \
+        switch (c->wpc) {                                                           \
+        case 8: case 16: return call_wavelet(w8);                                   \
+        case 4: return call_wavelet(w4);                                            \
+        default: return call_wavelet(w1);                                           \
+        }                                                                           \
+    }                                                                               \
     switch (c->wpc) {                                                               \
-    case 8:                                                                         \
-    case 16: DISPATCH_MT(FN, 16, __VA_ARGS__) break;                                \
-    case 4: DISPATCH_MT(FN, 4, __VA_ARGS__) break;                                  \
-    default: DISPATCH_MT(FN, 1, __VA_ARGS__) break;                                 \
+    case 16: return call_gauss(w16);                                                \
+    case 4: return call_gauss(w4);                                                  \
+    default: return call_gauss(w1);                                                 \
     }
 
-void launch_step_fused(mc3hip_ctx *c, int roff) { DISPATCH(launch_step_t, c, roff) }
-fast_kernel_fn persist_instance(mc3hip_ctx *c, bool p2p)
+void launch_step_fused(mc3hip_ctx *c, int roff)
 {
-    fast_kernel_fn f = nullptr;
-    DISPATCH(persist_instance_t, c, p2p, &f)
-    return f;
+#define G(tag) launch_step_gauss_##tag(c, roff)
+#define W(tag) launch_step_wavelet_##tag(c, roff)
+    MC3_BY_WIDTH(G, W)
+#undef G
+#undef W
+}
+
+// the exact instance (likelihood, tile count, peer-to-peer stores) of the general persistent
+// kernel that will be launched
+chain_kernel_fn persist_instance(const mc3hip_ctx *c, bool p2p)
+{
+#define G(tag) persist_instance_gauss_##tag(c, p2p)
+#define W(tag) persist_instance_wavelet_##tag(c, p2p)
+    MC3_BY_WIDTH(G, W)
+#undef G
+#undef W
+}
+
+void launch_eval_one(mc3hip_ctx *c, int n)
+{
+#define G(tag) launch_eval_gauss_##tag(c, n)
+#define W(tag) launch_eval_wavelet_##tag(c, n)
+    MC3_BY_WIDTH(G, W)
+#undef G
+#undef W
+}
+
+hipError_t set_smem_attr_wavelet(mc3hip_ctx *c)
+{
+#define G(tag) hipSuccess
+#define W(tag) set_smem_attr_wavelet_##tag(c)
+    MC3_BY_WIDTH(G, W)
+#undef G
+#undef W
 }
 
 void launch_persist(mc3hip_ctx *c, int nref)
@@ -606,6 +303,7 @@ void launch_persist(mc3hip_ctx *c, int nref)
                        dim3(64 * c->wpc), c->smem, c->stream, c->P, nref);
 }
 
+// workgroups of the general persistent kernel that fit on one CU (0 on error)
 void persist_blocks_per_cu(mc3hip_ctx *c, int *out)
 {
     const bool p2p = c->p2p_ranks > 1;
@@ -721,13 +419,13 @@ void launch_eval(mc3hip_ctx *c, int n)
             c->eval_params = p0 + (size_t)at * c->P.nparams;
             c->eval_out = o0 + at;
             const int m = n - at < WL_EVAL_BLOCKS ? n - at : WL_EVAL_BLOCKS;
-            DISPATCH(launch_eval_t, c, m)
+            launch_eval_one(c, m);
         }
         c->eval_params = p0;
         c->eval_out = o0;
         return;
     }
-    DISPATCH(launch_eval_t, c, n)
+    launch_eval_one(c, n);
 }
 
 void launch_model(mc3hip_ctx *c)
@@ -741,36 +439,18 @@ void launch_model(mc3hip_ctx *c)
     }
 }
 
+
 int set_smem_attr(mc3hip_ctx *c)
 {
-    // kernels that need more than the default 64 KiB of dynamic LDS must opt in
-    if (c->smem <= 64 * 1024)
+    // kernels that need more than the default 64 KiB of dynamic LDS must opt in (only the
+    // wavelet kernels do: the data or the abscissae of a chain live in LDS)
+    if (c->smem <= 64 * 1024 || !c->P.wlike)
         return MC3HIP_OK;
-#define SET_ATTR(WPC, MT)                                                                  \
-    HIP_TRY(hipFuncSetAttribute(                                                            \
-        reinterpret_cast<const void *>(&step_kernel<wavelet_waves<WPC>(), MT, true, false>), \
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->smem));                         \
-    HIP_TRY(hipFuncSetAttribute(                                                            \
-        reinterpret_cast<const void *>(&eval_chisq_kernel<wavelet_waves<WPC>(), MT, true>), \
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->smem));
-#define SET_ATTR_MT(WPC)                                                            \
-    switch (c->mt) {                                                                \
-    case MT_POLY2: SET_ATTR(WPC, MT_POLY2) break;                                   \
-    case MT_POLY3: SET_ATTR(WPC, MT_POLY3) break;                                   \
-    case MT_POLY4: SET_ATTR(WPC, MT_POLY4) break;                                   \
-    case MT_LINEAR: SET_ATTR(WPC, MT_LINEAR) break;                                 \
-    default: SET_ATTR(WPC, MT_POLY_GENERIC) break;                                  \
-    }
-    switch (c->wpc) {
-    case 8:
-    case 16: SET_ATTR_MT(16) break;
-    case 4: SET_ATTR_MT(4) break;
-    default: SET_ATTR_MT(1) break;
-    }
+    HIP_TRY(set_smem_attr_wavelet(c));
     return MC3HIP_OK;
 }
 
-// ---- dense host rows <-> padded device rows (chain_kernels.h ZROW) ----------------------
+// ---- dense host rows <-> padded device rows (core.h ZROW) ----------------------
 constexpr size_t STAGE_MAX_DOUBLES = size_t(8) << 20;      // 64 MiB of staging at most
 #define RC_TRY(expr)                                                                \
     do {                                                                            \
@@ -849,6 +529,8 @@ int exchange_rows(mc3hip_ctx *c, int64_t R)
 
 }  // namespace
 
+// (the library is compiled with -fvisibility=hidden: only the C-ABI is exported)
+#pragma GCC visibility push(default)
 extern "C" {
 
 const char *mc3hip_last_error(void) { return g_err.c_str(); }
@@ -993,7 +675,7 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         // Device copies padded to a multiple of 1024 points: x / A columns and data
         // repeat the last point, w = 1/uncert (IEEE division on the host, so the hot
         // loop multiplies) is 0 in the padding -- a padded point contributes exactly 0.
-        // tiled plan (chain_kernels.h tile_chisq_kernel): Gaussian chisq over at least
+        // tiled plan (tiled.h tile_chisq_kernel): Gaussian chisq over at least
         // four 4096-point tiles, enough chains to amortise a tile, <= 16 coefficients.
         // Models the one-launch resident kernels take (design matrices of 5..11 columns,
         // polynomials of 2..4 coefficients) also from 8192 points on when the ensemble is
@@ -1187,7 +869,10 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
     }
     TRY(set_smem_attr(c));
     if (P.tile > 0) {
-        TRY(tile_set_attr(c));
+        if (tile_set_attr(c) != hipSuccess) {
+            mc3hip_destroy(c);
+            return fail(MC3HIP_ERR_HIP, "hipFuncSetAttribute failed for the tile kernel");
+        }
         if (pr->thinning > 16)
             c->flags |= MC3HIP_FLAG_NO_GRAPH;       // keep the captured graph small
     }
@@ -2487,3 +2172,4 @@ int mc3hip_selftest_philox(int32_t device, const uint32_t *ctr, int32_t n, const
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,548 @@
+// resident.h -- the tiled plan as ONE persistent launch.
+#pragma once
+#include "core.h"
+#include "handoff.h"
+#include "run_chain.h"
+
+namespace mc3hip {
+
+// ---- resident tiled plan --------------------------------------------------------------
+// The tiled plan as ONE launch (design-matrix models through the matrix cores; one GPU, or
+// one launch per GPU with the Z rows published to every rank).  The grid is the tile kernel's
+// -- tiles x columns of chains, one workgroup per CU -- but every workgroup keeps its tile
+// (operand rows in registers and LDS, weights in LDS) for the whole launch instead of
+// reloading 200 KB of it per iteration, and the three phases of an iteration hand over
+// inside the launch instead of at kernel boundaries:
+//   * a wave that OWNS a chain (wave v of workgroup w owns chain w + v * workgroups) runs the
+//     ordinary run_chain for it -- proposal, Metropolis, Z append -- and publishes the proposed
+//     coefficient row (rs_prop, one 128-byte line, by iteration parity);
+//   * all eight waves of every workgroup then compute the data sums of their tile for the
+//     chains of their column, 16 chains at a time, as soon as those rows are there, each wave
+//     at its own pace; after the last block one barrier, the sums of the waves are added and
+//     one sum per (chain, tile) is published (rs_part);
+//   * the owner adds the sums of its chain in tile order, hands the slots and the consumed row
+//     back (all-ones), and goes on to the next iteration.
+// Every handed-over double is its own flag (all-ones = not there yet), exactly as for Z rows;
+// no grid barrier, no fence.  Why a row may be reused: a slot is handed back only after all
+// the sums that were computed from it have arrived, and a workgroup asks for the rows of
+// iteration i + 2 only after it has used those of i + 1, which the owner published after
+// handing back those of i.  The data column rides in the contraction as operand row K with
+// coefficient -1 (D = model - data, the same single rounding as the subtraction it replaces).
+// Same arithmetic and the same summation order as tile_chisq_mfma_kernel: the oracle does not
+// know which of the two ran.
+// What the owner of a chain does around the tile phase, whatever computes the tile sums
+// (ResidentTile: design matrices through the matrix cores; ResidentPoly: polynomials on the
+// vector unit).
+struct ResidentOwner {
+    int lane;
+    int par;                // parity of the iteration whose proposals are used next
+    bool failed;            // a wait of this wave timed out: said at the next agreement point
+    // owner waves: their LDS area ([0..63]: the Gaussian priors as index, centre, lower and
+    // upper width, 16 each)
+    double *s_own;
+
+    // this wave owns chain lc; `area` is its run_chain LDS area (whose first 64 doubles
+    // run_chain does not use here)
+    __device__ __forceinline__ void set_owner(const DevProblem &P, int lc, double *area)
+    {
+        s_own = area;
+        if (P.ngprior <= 16 && lane < P.ngprior) {
+            const int jp = P.igprior[lane];
+            area[lane] = (double)jp;
+            area[16 + lane] = P.prior[jp];
+            area[32 + lane] = P.priorlow[jp];
+            area[48 + lane] = P.priorup[jp];
+        }
+    }
+
+    // owner, before the tile phase: the proposed coefficients of chain lc for everybody
+    __device__ __forceinline__ void publish(const DevProblem &P, int lc, const double *s_nextp)
+    {
+        // (the slots handed back during the previous iteration have landed before the row
+        // that lets anybody write them again leaves)
+        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+        if (lane < RS_ROW) {
+            const int K = P.nmodel;
+            double v = (lane < K) ? s_nextp[lane] : ((lane == K) ? -1.0 : 0.0);
+            if (mc3_bits(v) == ROW_PENDING)
+                v = mc3_from_bits(0x7ff8000000000000ull);
+            __hip_atomic_store(&P.rs_prop[((size_t)par * P.nlocal + lc) * RS_ROW + lane], v,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+    // owner, after the tile phase: the data sum of chain lc, tiles added in order; hands the
+    // slots and the row this iteration used back
+    __device__ __forceinline__ double collect(const DevProblem &P, int lc)
+    {
+        long long *ctl = const_cast<long long *>(P.ctl);
+        double *row = P.rs_part + (size_t)lc * P.rs_ntp;
+        double total = 0.0;
+        for (int t0 = 0; t0 < P.ntiles; t0 += 64) {
+            const int n = (P.ntiles - t0 < 64) ? P.ntiles - t0 : 64;
+            double *mine = row + t0 + (lane < n ? lane : 0);
+            const double *const addr[1] = {mine};
+            double val[1] = {load_published(mine)};
+            if (!wait_rows<1>(addr, val, ctl))
+                failed = true;
+            // (in order, eight broadcasts at a time ahead of their dependent additions)
+            int k = 0;
+            for (; k + 8 <= n; k += 8) {
+                double v8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v8[u] = read_lane(val[0], k + u);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    total = total + v8[u];
+            }
+            for (; k < n; ++k)
+                total = total + read_lane(val[0], k);
+            if (lane < n)
+                __hip_atomic_store(mine, mc3_from_bits(ROW_PENDING), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane < RS_ROW)
+            __hip_atomic_store(&P.rs_prop[((size_t)(par ^ 1) * P.nlocal + lc) * RS_ROW + lane],
+                               mc3_from_bits(ROW_PENDING), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        return total;
+    }
+
+    // the chisq of the proposal from that sum (finish_chisq of the three-launch plan)
+    template <int MT>
+    __device__ __forceinline__ double finish(const DevProblem &P, double total,
+                                             const double *s_nextp) const
+    {
+        const bool finite = (mc3_bits(total) & 0x7ff0000000000000ull) != 0x7ff0000000000000ull;
+        if (!finite) {
+            Model<MT> model;
+            model.init(P, s_nextp);
+            int saw = 0;
+            for (int i = lane; i < P.ndata; i += 64)
+                saw |= is_pos_inf(model.at(i));
+            if (__any(saw))
+                return mc3_from_bits(0x7ff0000000000000ull);
+        }
+        if (is_pos_inf(total))
+            return total;
+        if (P.ngprior > 16)
+            return total + prior_term(P, s_nextp);
+        // prior_term from the LDS copy of its constants: lane g works out term g (the
+        // divisions side by side instead of one after the other), then the terms are added
+        // in order
+        double term = 0.0;
+        if (lane < P.ngprior) {
+            const int jp = (int)s_own[lane];
+            const double d = s_nextp[jp] - s_own[16 + lane];
+            const double sd = (d > 0.0) ? d / s_own[48 + lane] : d / s_own[32 + lane];
+            term = sd * sd;
+        }
+        double pr = 0.0;
+        for (int gp = 0; gp < P.ngprior; ++gp)
+            pr = pr + read_lane(term, gp);
+        return total + pr;
+    }
+};
+
+template <int KB>
+struct ResidentTile : ResidentOwner {
+    // operand rows of the tile: blocks of four rows in registers, except -- with three of
+    // them -- the last, which lives in LDS (64 KB; one read per product): 96 registers of
+    // tile plus the products in flight plus the chain state of an owner wave do not fit 256
+    static constexpr int KR = (KB == 3) ? 2 : KB;
+    double bop[8][2][KR];
+    const double *s_b;      // LDS [16][512]: this thread's operands of row block KR
+    double *s_w;            // LDS [RS_WCAP][16]: group totals of the chains done so far
+    const double *s_ww;     // LDS [2048]: the weights of the tile's points (this wave's: + 128 wv)
+    int *s_stop;            // LDS: a wave of this workgroup has given up
+    int t, c0, c1, wv;
+
+    __device__ __forceinline__ void load(const DevProblem &P, int tile, int col, int chain_block,
+                                         double *lds_w, int *lds_stop, double *lds_ww,
+                                         double *lds_b)
+    {
+        s_b = lds_b + threadIdx.x;
+        s_w = lds_w;
+        s_stop = lds_stop;
+        t = tile;
+        c0 = col * chain_block;
+        c1 = (c0 + chain_block < P.nlocal) ? c0 + chain_block : P.nlocal;
+        lane = threadIdx.x & 63;
+        wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        par = 0;
+        failed = false;
+        s_own = nullptr;
+        const int j = lane & 15, g = lane >> 4, K = P.nmodel;
+#pragma unroll
+        for (int vb = 0; vb < 8; ++vb) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const size_t i = (size_t)t * 2048 + 1024 * h + 128 * wv + 16 * vb + j;
+                // (the weights are the same for the four 16-lane rows of a wave: they live in
+                // LDS, 16 KB, and leave 32 registers to the chain state of the owner waves)
+                if (g == 0)
+                    lds_ww[1024 * h + 128 * wv + 16 * vb + j] = P.w[i];
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    const int k = 4 * kb + g;
+                    const double *src = (k < K) ? P.indep + (size_t)k * P.npad : P.data;
+                    const double v = (k <= K) ? src[i] : 0.0;
+                    if (kb < KR)
+                        bop[vb][h][kb] = v;
+                    else
+                        lds_b[(2 * vb + h) * 512 + threadIdx.x] = v;
+                }
+            }
+        }
+        s_ww = lds_ww + 128 * wv + j;
+    }
+
+    // every wave of the workgroup, once per iteration; false (for all of them) = give up
+    __device__ __forceinline__ bool tile_phase(const DevProblem &P, bool alive_in)
+    {
+        if (!alive_in || failed)
+            *s_stop = 1;
+        block_sync<8>();
+        if (*s_stop != 0)
+            return false;
+        long long *ctl = const_cast<long long *>(P.ctl);
+        const double *prop = P.rs_prop + (size_t)par * P.nlocal * RS_ROW;
+        const int j = lane & 15, g = lane >> 4;
+        const double *addr[KB];
+        double aop[KB];
+        auto request = [&](int cb) {
+            const int lc = (cb + j < c1) ? cb + j : c1 - 1;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                addr[kb] = prop + (size_t)lc * RS_ROW + 4 * kb + g;
+                aop[kb] = load_published(addr[kb]);
+            }
+        };
+        // (the weights and the LDS part of the tile are read where they are used: an offset
+        // the compiler cannot see through keeps it from hoisting the reads out of the loops
+        // and parking the values in registers again)
+        int wo = 0;
+        // Step s = 0..15 of a block of chains: half h = s & 1 of block vb = s >> 1 of 16 lanes.
+        // The product of a step, with the coefficients in a[]; bl = its operand from LDS
+        auto product = [&](int st, const double(&a)[KB], double bl) {
+            const int vb = st >> 1, h = st & 1;
+            mc3_v4d m = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                m = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                    a[kb], (kb < KR) ? bop[vb][h][kb < KR ? kb : 0] : bl, m, 0, 0, 0);
+            return m;
+        };
+        auto lds_operand = [&](int st) { return (KR < KB) ? s_b[wo + st * 512] : 0.0; };
+        auto lds_weight = [&](int st) { return s_ww[wo + 1024 * (st & 1) + 16 * (st >> 1)]; };
+        // sum over the 64 lanes of a group (lane 16 q + j): strides 32 and 16 were in-thread,
+        // 8..1 run inside the 16-lane row; lane j = 0 has the defined order
+        auto group_total = [&](const double(&acc)[2][4], int grp, int off) {
+            double sr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double sg = acc[0][r] + acc[1][r];         // stride 16
+                sg = add_ror<8>(sg);
+                sg = add_ror<4>(sg);
+                sg = add_ror<2>(sg);
+                sr[r] = add_ror<1>(sg);
+            }
+            if (j == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    s_w[(off + g + 4 * r) * 16 + 2 * wv + grp] = sr[r];
+            }
+        };
+        // Software pipeline, written out.  FP64 matrix and vector instructions share one pipe
+        // on this chip (tools/probes/mfma_f64_issue_probe.hip: their times add up), so what
+        // can be hidden is latency, not work: the product of step s + 1 is issued before the
+        // residuals of step s are squared, one matrix instruction then a few vector
+        // instructions in turn; the LDS operands of step s + 2 are read during step s; the
+        // cross-lane sum of the first group of 64 lanes runs between the matrix instructions
+        // of the second.  The scheduling barriers keep that order, and with it two products'
+        // worth of registers alive instead of sixteen.  (Carrying the pipeline across the
+        // barrier at the end of a block of chains costs 25 more registers.)
+        request(c0);
+        int base = c0;                  // first chain of the window collected in s_w
+        for (int cb = c0; cb < c1; cb += 16) {
+            if (!wait_rows<KB>(addr, aop, ctl))
+                failed = true;
+            double a[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                a[kb] = aop[kb];
+            if (cb + 16 < c1)
+                request(cb + 16);              // the next block's rows travel behind this one
+            asm volatile("; operands of this block" : "+v"(wo));
+            double bl_next = lds_operand(1), w_cur = lds_weight(0), w_next = w_cur;
+            mc3_v4d mc = product(0, a, lds_operand(0)), mn = mc;
+            double accA[2][4], accB[2][4], tmp[4];     // [block of 16 lanes mod 2][chain g + 4 r]
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                const int q = (st >> 1) & 3, h = st & 1;
+                double(&acc)[2][4] = (st < 8) ? accA : accB;
+                __builtin_amdgcn_sched_barrier(0);
+                const double bl = bl_next;
+                if (st < 14)
+                    bl_next = lds_operand(st + 2);
+                if (st < 15) {
+                    w_next = lds_weight(st + 1);
+                    mn = product(st + 1, a, bl);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double res = mc[r] * w_cur;
+                    // strides 32 (blocks 0 + 2, 1 + 3 of the group) as soon as both are there
+                    if (q < 2) {
+                        acc[q][r] = mc3_fma(res, res, h ? acc[q][r] : 0.0);
+                    } else {
+                        tmp[r] = mc3_fma(res, res, h ? tmp[r] : 0.0);
+                        if (h == 1)
+                            acc[q - 2][r] = acc[q - 2][r] + tmp[r];
+                    }
+                }
+                if (st == 8)
+                    group_total(accA, 0, cb - base);
+                // (two matrix instructions first: the product these squares read was the last
+                // thing issued in the previous step and needs a pipe pass to land)
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);             // MFMA
+#pragma unroll
+                for (int i = 2; i <= KB; ++i) {
+                    if (st == 8)
+                        __builtin_amdgcn_sched_group_barrier(0x002, 36, 0);    // VALU
+                    else
+                        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                    if (i < KB)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mc = mn;
+                w_cur = w_next;
+            }
+            group_total(accB, 1, cb - base);
+            // The waves of the workgroup are NOT synchronised per block of chains: every wave
+            // leaves its group totals in LDS and goes on (a barrier, an exchange and a
+            // sixteen-lane sum per block cost ~10 % of the phase, and two waves that drift
+            // apart share their SIMD's FP64 pipe better than two in step).  The totals are
+            // added up -- 16 per chain, strides 8..1 -- once per window of RS_WCAP chains,
+            // normally once per iteration.
+            const int end = (cb + 16 < c1) ? cb + 16 : c1;
+            if (end == c1 || end - base == RS_WCAP) {
+                block_sync<8>();
+                for (int ch0 = base + 4 * wv; ch0 < end; ch0 += 32) {
+                    const int ch = ch0 + (lane >> 4);
+                    double sg = s_w[((ch < end ? ch : end - 1) - base) * 16 + (lane & 15)];
+                    sg = add_ror<8>(sg);
+                    sg = add_ror<4>(sg);
+                    sg = add_ror<2>(sg);
+                    sg = add_ror<1>(sg);
+                    if (mc3_bits(sg) == ROW_PENDING)   // (a NaN that looks like "not there yet")
+                        sg = mc3_from_bits(0x7ff8000000000000ull);
+                    if ((lane & 15) == 0 && ch < end)
+                        __hip_atomic_store(&P.rs_part[(size_t)ch * P.rs_ntp + t], sg,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (end < c1)
+                    block_sync<8>();            // (the next window overwrites these totals)
+                base = end;
+            }
+        }
+        par ^= 1;
+        return true;
+    }
+
+};
+
+// The same one-launch plan for polynomials of KX = 2..4 coefficients (tile_chisq_kernel's
+// arithmetic: Horner on the vector unit, 4096 points per tile, lanes first -- one halving tree
+// over the tile's 1024 strided partial sums).  Eight waves: thread l owns virtual lanes l and
+// l + 512 with four points each (x, data, weight: 48 registers), so the first level of the
+// tree is an addition inside the thread; 16 chains at a time, their 64 coefficients one per
+// lane (v_readlane hands them to the scalar unit); the 512 partial sums of a chain cross the
+// workgroup through LDS (two buffers of 16 x 512: one barrier per block of chains), wave v
+// finishes chains 2 v and 2 v + 1.
+template <int KX>
+struct ResidentPoly : ResidentOwner {
+    double x[2][4], d[2][4], w[2][4];
+    double *s_x;            // LDS [2][16][512]
+    int *s_stop;
+    int t, c0, c1, wv;
+
+    __device__ __forceinline__ void load(const DevProblem &P, int tile, int col, int chain_block,
+                                         double *lds_x, int *lds_stop)
+    {
+        s_x = lds_x;
+        s_stop = lds_stop;
+        t = tile;
+        c0 = col * chain_block;
+        c1 = (c0 + chain_block < P.nlocal) ? c0 + chain_block : P.nlocal;
+        lane = threadIdx.x & 63;
+        wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        par = 0;
+        failed = false;
+        s_own = nullptr;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const size_t i = (size_t)t * 4096 + threadIdx.x + 512 * v + 1024 * q;
+                x[v][q] = P.indep[i];
+                d[v][q] = P.data[i];
+                w[v][q] = P.w[i];
+            }
+        }
+    }
+
+    __device__ __forceinline__ bool tile_phase(const DevProblem &P, bool alive_in)
+    {
+        if (!alive_in || failed)
+            *s_stop = 1;
+        block_sync<8>();
+        if (*s_stop != 0)
+            return false;
+        long long *ctl = const_cast<long long *>(P.ctl);
+        const double *prop = P.rs_prop + (size_t)par * P.nlocal * RS_ROW;
+        const int l = threadIdx.x;
+        const double *addr[1];
+        double val[1];
+        auto request = [&](int cb) {
+            const int lc = (cb + (lane >> 2) < c1) ? cb + (lane >> 2) : c1 - 1;
+            addr[0] = prop + (size_t)lc * RS_ROW + (lane & 3);
+            val[0] = load_published(addr[0]);
+        };
+        request(c0);
+        int buf = 0;
+        for (int cb = c0; cb < c1; cb += 16, buf ^= 1) {
+            if (!wait_rows<1>(addr, val, ctl))
+                failed = true;
+            const double cfv = val[0];
+            if (cb + 16 < c1)
+                request(cb + 16);              // the next block's rows travel behind this one
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                double cf[KX];
+#pragma unroll
+                for (int k = 0; k < KX; ++k)
+                    cf[k] = read_lane(cfv, 4 * g + k);
+                double acc[2];
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    acc[v] = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        double m = cf[KX - 1];            // Horner from coefficient K-1 down
+#pragma unroll
+                        for (int k = KX - 2; k >= 0; --k)
+                            m = mc3_fma(m, x[v][q], cf[k]);
+                        const double r = (m - d[v][q]) * w[v][q];
+                        acc[v] = mc3_fma(r, r, acc[v]);
+                    }
+                }
+                s_x[(buf * 16 + g) * 512 + l] = acc[0] + acc[1];       // stride 512
+            }
+            block_sync<8>();
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const int ch = 2 * wv + cc;
+                double p[8];
+#pragma unroll
+                for (int w2 = 0; w2 < 8; ++w2)
+                    p[w2] = s_x[(buf * 16 + ch) * 512 + lane + 64 * w2];
+#pragma unroll
+                for (int s2 = 4; s2 >= 1; s2 >>= 1) {                 // strides 256, 128, 64
+#pragma unroll
+                    for (int w2 = 0; w2 < s2; ++w2)
+                        p[w2] = p[w2] + p[w2 + s2];
+                }
+                double tot = wave_sum(p[0]);                          // strides 32..1
+                if (mc3_bits(tot) == ROW_PENDING)      // (a NaN that looks like "not there yet")
+                    tot = mc3_from_bits(0x7ff8000000000000ull);
+                if (lane == 0 && cb + ch < c1)
+                    __hip_atomic_store(&P.rs_part[(size_t)(cb + ch) * P.rs_ntp + t], tot,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // (no second barrier: the next block writes the other buffer, and this one is not
+            // written again before everybody has passed the next barrier)
+        }
+        par ^= 1;
+        return true;
+    }
+};
+
+// The tiled plan in one launch (ResidentTile above): grid = tiles x columns of chains, eight
+// waves; wave v of workgroup w also owns chain w + v * workgroups.  P2P: the ensemble is
+// sharded over GPUs, each running this kernel over its own chains; owners publish their Z
+// rows into every rank's replica (run_chain P2P), proposals and tile sums stay local.  LDS:
+// group totals
+// [RS_WCAP][16], the give-up word, a run_chain area per wave, the tile's 2048 weights, and
+// (three blocks of operand rows) the last block, [16][512].
+template <int KB, bool P2P = false>
+__global__ __launch_bounds__(512) void resident_tile_kernel(const DevProblem P, const int nref,
+                                                            const int chain_block)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int OWN = 64 + MC3HIP_MAX_PARAMS + 2 + 48 + 4;     // carve() of a one-wave chain
+    constexpr int W = RS_WCAP * 16;                              // group totals
+    int *s_stop = reinterpret_cast<int *>(smem + W);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    ResidentTile<KB> T;
+    T.load(P, blockIdx.x, blockIdx.y, chain_block, smem, s_stop, smem + W + 2 + 8 * OWN,
+           smem + W + 2 + 8 * OWN + 2048);
+    // a launch queued behind one that gave up must not run: its inputs are missing
+    if (threadIdx.x == 0)
+        *s_stop = (__hip_atomic_load(&P.ctl[CTL_ABORT], __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0;
+    block_sync<8>();
+    if (*s_stop != 0)
+        return;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    const int own_chain = wg + (int)(gridDim.x * gridDim.y) * wv;
+    if (own_chain < P.nlocal) {
+        T.set_owner(P, own_chain, smem + W + 2 + wv * OWN);
+        run_chain<1, MT_LINEAR, false, false, true, -1, false, PH_RESIDENT, P2P, 0, false,
+                  ResidentTile<KB>>(P, P.ctl[0], nref, 0, -1, &T, own_chain,
+                                    smem + W + 2 + wv * OWN);
+    } else {
+        // no chain of its own: the tile phase of every iteration, in step with the owners
+        for (int R = 0; R < nref; ++R)
+            for (int j = 0; j < P.thinning; ++j)
+                if (!T.tile_phase(P, true))
+                    return;
+    }
+}
+
+template <int KX, bool P2P = false>
+__global__ __launch_bounds__(512) void resident_poly_kernel(const DevProblem P, const int nref,
+                                                            const int chain_block)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int OWN = 64 + MC3HIP_MAX_PARAMS + 2 + 48 + 4;     // carve() of a one-wave chain
+    constexpr int X = 2 * 16 * 512;                              // the exchange buffers
+    int *s_stop = reinterpret_cast<int *>(smem + X);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    ResidentPoly<KX> T;
+    T.load(P, blockIdx.x, blockIdx.y, chain_block, smem, s_stop);
+    // a launch queued behind one that gave up must not run: its inputs are missing
+    if (threadIdx.x == 0)
+        *s_stop = (__hip_atomic_load(&P.ctl[CTL_ABORT], __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0;
+    block_sync<8>();
+    if (*s_stop != 0)
+        return;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    const int own_chain = wg + (int)(gridDim.x * gridDim.y) * wv;
+    if (own_chain < P.nlocal) {
+        T.set_owner(P, own_chain, smem + X + 2 + wv * OWN);
+        run_chain<1, KX, false, false, true, -1, false, PH_RESIDENT, P2P, 0, false,
+                  ResidentPoly<KX>>(P, P.ctl[0], nref, 0, -1, &T, own_chain,
+                                    smem + X + 2 + wv * OWN);
+    } else {
+        for (int R = 0; R < nref; ++R)
+            for (int j = 0; j < P.thinning; ++j)
+                if (!T.tile_phase(P, true))
+                    return;
+    }
+}
+
+}  // namespace mc3hip

@@ -1,0 +1,508 @@
+// wavelet.h -- wavelet likelihood: the blocked D4 pyramid of one chain.
+#pragma once
+#include "core.h"
+#include "chisq.h"
+
+namespace mc3hip {
+
+// ---- wavelet likelihood: blocked D4 pyramid -------------------------------------------
+// Wavelet pseudo chi-squared (Carter & Winn 2009 eqs. 32-34), src_c/_dwt.c:76-114 over
+// the D4 pyramid of src_c/include/wavelet.h:27-36,115-117, ndata = 2^M <= 32 T.
+//
+// T = 64 WPC threads share a chain.  Thread t owns the CONTIGUOUS block of B = N/Ta points
+// [B t, B t + B) (Ta = min(T, N/2) threads take part; B is one of 2..32 and a compile-time
+// constant of the code that runs, wavelet_body<.., B>).  The data values sit in LDS for
+// the whole launch and the abscissae are recomputed (wavelet_stage below), so an
+// iteration reads no global memory but the proposal:
+//   A  log2 B levels inside the block, in registers; a level's halo (the next block's
+//      first two values, wrapping like wavelet.h:35-36) comes through LDS, one raw
+//      barrier per level from the second on; one value per thread is left;
+//   B  (more than 64 left) those values, Ta/64 per lane, go through wave 0 the same way
+//      -- no barrier, a wave's LDS traffic is ordered;
+//   C  the last <= 64 values, one per lane, level by level through LDS, still wave 0.
+// Detail coefficients are final when produced: an owner (thread / lane) adds the squares
+// of its details of one level, acc = fma(d, d, acc), and folds the level in with the weight
+// of its scale, w = fma(acc, 1/sigma_W^2, w); stage sums are halving trees, total
+// (A + B) + C (the CPU checker states the same order).
+// (Before: strided levels ping-ponging through 96 KiB of LDS, x and data re-read from L2
+// every iteration, 13 barriers, half of the instruction stream index arithmetic.)
+constexpr int WB = 32;                        // points per thread at most
+
+// What a thread needs of the chain-invariant inputs is its block of B abscissae and B data
+// values (plus the next block's first two of each).  One of the two arrays lives in LDS as
+// [j][t] (lane-contiguous: conflict-free), staged once per launch:
+//   * the DATA, when the abscissae need no storage: they lie on numpy.linspace's grid
+//     (P.wl_grid, checked bit for bit at creation) and are recomputed, or the model is a
+//     design matrix; nothing chain-invariant is then read from global memory in the loop;
+//   * otherwise the ABSCISSAE, and the data come from global memory in the same [j][t]
+//     layout (P.data_t; L2-resident, coalesced) -- the slower, general path.
+// The caller synchronises the workgroup before the first use.
+template <int WPC, int MT>
+__device__ __forceinline__ void wavelet_stage(const DevProblem &P, double *xs)
+{
+    constexpr int T = 64 * WPC;
+    const int N = P.ndata;
+    const int Ta = (N / 2 < T) ? (N / 2 > 0 ? N / 2 : 1) : T;
+    const int B = N / Ta;
+    if ((int)threadIdx.x >= Ta || N > WB * T)
+        return;                                 // (large data sets read global memory)
+    const double *src = (MT == MT_LINEAR || P.wl_grid) ? P.data : P.indep;
+    for (int j = 0; j < B; ++j)
+        xs[j * T + threadIdx.x] = src[B * threadIdx.x + j];
+}
+
+// one level inside a block: v[0..NV) (+ halo at v[NV], v[NV+1]) -> v[0..NV/2), details
+// squared into the returned sum; every index static
+template <int NV, int CAP>
+__device__ __forceinline__ double block_level(double (&v)[CAP])
+{
+    static_assert(NV + 2 <= CAP, "halo slots");
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < NV / 2; ++j) {
+        double s, d;
+        d4_pair(v[2 * j], v[2 * j + 1], v[2 * j + 2], v[2 * j + 3], s, d);
+        v[j] = s;                              // (inputs of later pairs start at 2j + 2 > j)
+        acc = mc3_fma(d, d, acc);
+    }
+    return acc;
+}
+
+// stage B / stage A from the second level on: levels NV -> NV/2 -> ... -> 1 with the halo
+// exchanged through `hb` (two buffers of `stride` double2, indexed by level parity);
+// SYNC = workgroup barrier (stage A) or none (one wave, stage B).  accs[LEV], accs[LEV+1],
+// ... receive the levels' sums of squared details (weighted later, in level order).
+template <int NV, int CAP, int WPC, bool SYNC, int LEV, int NACC>
+__device__ __forceinline__ void block_levels(double (&v)[CAP], double (&accs)[NACC],
+                                             double2 *hb, int stride, int me, int next,
+                                             bool active)
+{
+    if constexpr (NV >= 2) {
+        static_assert(LEV < NACC, "one slot per level");
+        double2 *h = hb + (LEV & 1) * stride;
+        if (active)
+            h[me] = make_double2(v[0], v[1]);
+        if constexpr (SYNC)
+            block_sync<WPC>();
+        else
+            __builtin_amdgcn_wave_barrier();
+        const double2 hv = h[next];
+        v[NV] = hv.x;
+        v[NV + 1] = hv.y;
+        accs[LEV] = block_level<NV, CAP>(v);
+        block_levels<NV / 2, CAP, WPC, SYNC, LEV + 1, NACC>(v, accs, hb, stride, me, next, active);
+    }
+}
+
+constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n / 2); }
+
+// the levels' sums of squared details folded in with the weights of their scales
+// (1/sigma_W^2 of scale m0, m0 - 1, ...), in level order
+template <int NLEV, int NACC>
+__device__ __forceinline__ double weigh_levels(const double (&accs)[NACC], const double *s_tab,
+                                               int m0, double w = 0.0)
+{
+#pragma unroll
+    for (int l = 0; l < NLEV; ++l)
+        w = mc3_fma(accs[l], s_tab[m0 - l], w);
+    return w;
+}
+
+// Level 0 of stage A: streams the residuals data - model (src_c/_dwt.c:89) of the block,
+// two new points per output pair, so that only the B/2 smooth values are ever held.
+// GRID: x recomputed on np.linspace's grid, data from LDS; otherwise x from LDS, data from
+// the register-resident tile.  Returns the level's sum of squared details.
+// VALUES: the block's inputs are values already (the output of the pre-levels of a large
+// data set, in global memory as a plain array), not residuals to be formed.
+template <int WPC, int MT, int B, bool GRID, int CAP, bool VALUES = false>
+__device__ __forceinline__ double wavelet_level0(const DevProblem &P, const Model<MT> &model,
+                                                 const double *xs, int me, int next, int Ta,
+                                                 int &sawinf, double (&v)[CAP],
+                                                 const double *values = nullptr)
+{
+    constexpr int T = 64 * WPC;
+    const int N = VALUES ? B * Ta : P.ndata;
+    const int base = B * me;
+    double fbase = (double)base, fnext = (double)(B * next);
+    int ome = me, onext = next;
+    // All of this is invariant across the iterations of a persistent launch, and the
+    // optimiser would hoist it out of the chain loop -- 2 B values per thread parked in
+    // registers (and spilled) for good.  The empty asm makes the inputs opaque per call
+    // (offsets, not pointers: a laundered pointer loses its address space and the LDS
+    // reads would become flat loads).
+    asm volatile("; per-iteration inputs" : "+v"(fbase), "+v"(fnext), "+v"(ome), "+v"(onext));
+    const double *xme = xs + ome, *xnext = xs + onext;
+    const double *dme = P.data_t + ome, *dnext = P.data_t + onext;
+    // what a point needs from LDS / global memory is requested PF points ahead of its use:
+    // far enough to cover the latency behind the arithmetic of the points in between,
+    // near enough to keep only a few values in flight (registers)
+    constexpr int PF = 8;
+    double in0[B + 2], in1[(MT != MT_LINEAR && !GRID) ? B + 2 : 1];
+    auto fetch = [&](int j) {                           // static j
+        if constexpr (VALUES) {
+            in0[j] = (j < B) ? values[B * ome + j] : values[B * onext + (j - B)];
+        } else {
+            in0[j] = (j < B) ? xme[j * T] : xnext[(j - B) * T];
+            if constexpr (MT != MT_LINEAR && !GRID)
+                in1[j] = (j < B) ? dme[j * T] : dnext[(j - B) * T];
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < PF + 2 && j < B + 2; ++j)
+        fetch(j);
+    (void)in1;
+    auto resid = [&](int j) {                           // j: static index into the block;
+        double m, dv;                                   // B, B+1: the next block's first two
+        if constexpr (VALUES) {
+            return in0[j];
+        } else if constexpr (MT == MT_LINEAR) {
+            m = model.at(j < B ? base + j : (base + j) & (N - 1));
+            dv = in0[j];
+        } else if constexpr (GRID) {
+            // numpy.linspace: y = arange(num) * step + start, y[-1] = stop
+            const double fi = (j < B) ? fbase + (double)j : fnext + (double)(j - B);
+            double x = fi * P.wl_step + P.wl_x0;
+            if (j == B - 1)
+                x = (me == Ta - 1) ? P.wl_xlast : x;
+            if (j >= B && N <= 2)
+                x = (j - B == N - 1) ? P.wl_xlast : x;
+            m = model.at_x(x);
+            dv = in0[j];
+        } else {
+            m = model.at_x(in0[j]);
+            dv = in1[j];
+        }
+        sawinf |= is_pos_inf(m);
+        return dv - m;
+    };
+    double acc0 = 0.0;
+    if (N >= 4) {
+        double r0 = resid(0), r1 = resid(1);
+#pragma unroll
+        for (int j = 0; j < B / 2; ++j) {
+            if (2 * j + 2 + PF < B + 2) {
+                fetch(2 * j + 2 + PF);
+                fetch(2 * j + 3 + PF);
+            }
+            const double r2 = resid(2 * j + 2), r3 = resid(2 * j + 3);
+            double s, d;
+            d4_pair(r0, r1, r2, r3, s, d);
+            v[j] = s;
+            acc0 = mc3_fma(d, d, acc0);
+            r0 = r2;
+            r1 = r3;
+        }
+    } else {
+        v[0] = resid(0);                                // N = 2: no level at all
+        v[1] = resid(1);
+    }
+    return acc0;
+}
+
+// The per-scale noise terms depend only on the three noise parameters: lane m computes
+// sigma_W^2(m), its reciprocal (table in LDS) and its share of the log-determinant, lane
+// 0 the smooth coefficients' sigma_S^2 -- one exp2 + log per lane instead of M of each on
+// every thread -- and the log-determinant is summed in scale order.  Results in LDS:
+// s_tab[1..M-1] = 1/sigma_W^2 (M <= 22), s_tab[24] = sigma_S^2, s_tab[25] = the
+// log-determinant.
+__device__ __forceinline__ void wavelet_noise_terms(const double *s_nextp, int nparams, int M,
+                                                    double *s_tab)
+{
+    const int lane = threadIdx.x & 63;
+    const double gam = s_nextp[nparams - 3];
+    const double sr = s_nextp[nparams - 2];
+    const double sw = s_nextp[nparams - 1];
+    const double sr2 = sr * sr, sw2 = sw * sw;
+    double term = 0.0;
+    if (lane >= 1 && lane < M) {
+        const double sW2 = sr2 * mc3_det_exp2(-gam * (double)lane) + sw2;
+        s_tab[lane] = 1.0 / sW2;
+        term = (double)(1 << lane) * mc3_det_log(6.283185307179586 * sW2);
+    } else if (lane == 0) {
+        const double sS2 = sr2 * mc3_det_exp2(-gam) * 0.72134752 + sw2;
+        s_tab[24] = sS2;
+        term = 2.0 * mc3_det_log(6.283185307179586 * sS2);
+    }
+    double Lg = read_lane(term, 0);
+    for (int m = 1; m < M; ++m)
+        Lg = Lg + read_lane(term, m);             // scales added in order
+    if (lane == 0)
+        s_tab[25] = Lg;
+}
+
+// `values` (large data sets): the blocks are cut from that array of B T values -- the
+// output of `npre` pre-levels whose per-thread sums of squared details arrive in accP --
+// instead of from the residuals.
+template <int WPC, int MT, int B, bool VALUES = false>
+__device__ __forceinline__ double wavelet_body(const DevProblem &P, const double *s_nextp,
+                                               double *s_part, int *s_flag, double *s_tab,
+                                               double *s_halo, const double *xs,
+                                               const double *values = nullptr, int npre = 0,
+                                               const double *accP = nullptr, int sawinf0 = 0)
+{
+    constexpr int T = 64 * WPC;
+    constexpr int NLA = ilog2c(B);                      // levels of stage A (N >= 4)
+    constexpr int NLB = ilog2c(WPC);                    // levels of stage B
+    const int tid = threadIdx.x, lane = tid & 63;
+    // (made wave-uniform by hand so that the per-wave roles below are scalar branches)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = ilog2(P.ndata);
+    const int N = VALUES ? B * T : P.ndata;             // length of the array stage A starts from
+    const int Ta = N / B;                               // threads that own a block
+    const bool active = tid < Ta;
+    const int me = active ? tid : 0;
+    const int next = (me + 1 == Ta) ? 0 : me + 1;
+    Model<MT> model;
+    model.init(P, s_nextp);
+    if (WPC > 1 && tid == 0)
+        s_flag[1] = 0;                                  // "a model value was +inf"
+    // One wave: the noise terms first.  Several waves: the LAST wave computes them after its
+    // share of stage A, while wave 0 is busy with stages B and C -- two long dependent chains
+    // (software exp2 / log; cross-lane levels) side by side instead of one after the other.
+    if constexpr (WPC == 1)
+        wavelet_noise_terms(s_nextp, P.nparams, M, s_tab);
+    MC3_LSTAMP(8);
+    // ---- stage A: log2 B levels in registers ------------------------------------------
+    constexpr int HB = (B / 2 > 2) ? B / 2 : 2;
+    double v[HB + 2];
+    double accA[NLA > 0 ? NLA : 1];
+    int sawinf = sawinf0;
+    int nn = N;
+    if constexpr (VALUES)
+        accA[0] = wavelet_level0<WPC, MT, B, false, HB + 2, true>(P, model, xs, me, next, Ta,
+                                                                  sawinf, v, values);
+    else if (MT != MT_LINEAR && P.wl_grid)
+        accA[0] = wavelet_level0<WPC, MT, B, true, HB + 2>(P, model, xs, me, next, Ta, sawinf, v);
+    else
+        accA[0] = wavelet_level0<WPC, MT, B, false, HB + 2>(P, model, xs, me, next, Ta, sawinf, v);
+    MC3_LSTAMP(14);
+    double2 *halo = reinterpret_cast<double2 *>(s_halo);  // [2][T]
+    if (N >= 4) {
+        block_levels<B / 2, HB + 2, WPC, true, 1, (NLA > 0 ? NLA : 1)>(v, accA, halo, T, me, next,
+                                                                        active);
+        nn = Ta;                                        // one value per thread
+    }
+    MC3_LSTAMP(9);
+    const int mA = M - 1 - npre;                        // scale of stage A's first level
+    // (large data sets) the pre-levels' sums come first, in level order
+    auto stage_a_sum = [&]() {
+        double w0 = 0.0;
+#pragma unroll
+        for (int l = 0; l < 8; ++l)
+            if (VALUES && l < npre)
+                w0 = mc3_fma(accP[l], s_tab[M - 1 - l], w0);
+        return weigh_levels<NLA>(accA, s_tab, mA, w0);
+    };
+    double sumA, u = v[0];
+    int mscale = (N >= 4) ? mA - NLA : mA;              // scale of the next level's details
+    double accB[NLB > 0 ? NLB : 1];
+    if constexpr (WPC > 1) {
+        // (a buffer of its own: the last halo exchange may still be being read by a wave
+        // that is behind)
+        double *ubuf = s_halo + 4 * T + 64;             // [T]
+        ubuf[tid] = v[0];
+        if (sawinf)
+            s_flag[1] = 1;
+        block_sync<WPC>();                              // (1) the T values are in LDS
+        if (wave == WPC - 1)
+            wavelet_noise_terms(s_nextp, P.nparams, M, s_tab);
+        if (wave == 0) {
+            // ---- stage B: T values, WPC per lane, levels inside the lane -----------------
+            double vb[WPC + 2];
+#pragma unroll
+            for (int j = 0; j < WPC; ++j)
+                vb[j] = ubuf[WPC * lane + j];
+            const int hbase = (WPC * (lane + 1)) & (T - 1);
+            vb[WPC] = ubuf[hbase];
+            vb[WPC + 1] = ubuf[hbase + 1];
+            accB[0] = block_level<WPC, WPC + 2>(vb);
+            block_levels<WPC / 2, WPC + 2, 1, false, 1, (NLB > 0 ? NLB : 1)>(
+                vb, accB, halo + T, 64, lane, (lane + 1) & 63, true);
+            u = vb[0];
+        }
+        mscale -= NLB;
+        nn = 64;
+    }
+    MC3_LSTAMP(10);
+    // ---- stage C: nn <= 64 values, one per lane (wave 0) ------------------------------------
+    double accC[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const int mC = mscale;
+    int nC = 0;
+    if (wave == 0) {
+        double *cbuf = s_halo + 4 * T;                  // [64], wave-private
+#pragma unroll
+        for (int l = 0; l < 6; ++l) {
+            if (nn >= 4) {
+                const int nh = nn >> 1;
+                __builtin_amdgcn_wave_barrier();
+                cbuf[lane] = u;
+                __builtin_amdgcn_wave_barrier();
+                const int i2 = (lane < nh) ? 2 * lane : 0;
+                const double2 ca = *reinterpret_cast<const double2 *>(cbuf + i2);
+                const double2 cc = *reinterpret_cast<const double2 *>(cbuf + ((i2 + 2) & (nn - 1)));
+                double s, d;
+                d4_pair(ca.x, ca.y, cc.x, cc.y, s, d);
+                accC[l] = (lane < nh) ? d * d : 0.0;
+                u = s;
+                nn = nh;
+                nC = l + 1;
+            }
+        }
+    }
+    MC3_LSTAMP(12);
+    double Tsum;
+    if constexpr (WPC > 1) {
+        block_sync<WPC>();                              // (2) the noise terms are in LDS
+        s_part[tid] = (active && N >= 4) ? stage_a_sum() : 0.0;
+        block_sync<WPC>();                              // (3) every thread's stage-A sum
+        if (wave != 0)
+            return 0.0;                                 // the value is only used by wave 0
+        double p[WPC];
+#pragma unroll
+        for (int q = 0; q < WPC; ++q)
+            p[q] = s_part[lane + 64 * q];
+#pragma unroll
+        for (int s2 = WPC / 2; s2 >= 1; s2 >>= 1) {
+#pragma unroll
+            for (int q = 0; q < s2; ++q)
+                p[q] = p[q] + p[q + s2];
+        }
+        sumA = wave_sum(p[0]);
+        sawinf = s_flag[1];
+        sumA = sumA + wave_sum(weigh_levels<NLB>(accB, s_tab, mA - NLA));      // (A + B)
+    } else {
+        sumA = wave_sum((active && N >= 4) ? stage_a_sum() : 0.0);
+        sawinf = __any(sawinf) ? 1 : 0;
+    }
+    {
+        double wc = 0.0;
+#pragma unroll
+        for (int l = 0; l < 6; ++l)
+            if (l < nC)
+                wc = mc3_fma(accC[l], s_tab[mC - l], wc);
+        Tsum = sumA + wave_sum(wc);
+    }
+    // the two smooth coefficients left (N = 2: the two residuals, both in thread 0)
+    const double a0 = read_lane(u, 0), a1 = (N == 2) ? read_lane(v[1], 0) : read_lane(u, 1);
+    MC3_LSTAMP(13);
+    if (sawinf)
+        return mc3_from_bits(0x7ff0000000000000ull);
+    const double sS2 = s_tab[24];
+    const double S = (a0 * a0) / sS2 + (a1 * a1) / sS2;
+    return (S + s_tab[25]) + Tsum;
+}
+
+// More than 32 points per thread (ndata > 2^14): "pre-levels" bring the pyramid down to
+// 2^14 values first.  Output i of a pre-level belongs to thread i mod T (strided, coalesced);
+// level 0 forms the residuals on the fly from global memory, the smooth values ping-pong
+// between two global buffers of this workgroup (P.wl_scratch); each thread keeps its sum of
+// squared details per pre-level, weighted with the others at the end.  Then the blocked
+// pyramid above runs on the 2^14 values.  Slower per point than the resident path (every
+// level goes through global memory), but any 2^M up to 2^22 fits.
+template <int MT>
+__device__ double wavelet_large(const DevProblem &P, const double *s_nextp, double *s_part,
+                                int *s_flag, double *s_tab, double *s_halo, const double *xs)
+{
+    constexpr int T = 512;
+    const int tid = threadIdx.x;
+    const int N = P.ndata;
+    Model<MT> model;
+    model.init(P, s_nextp);
+    double *bufA = P.wl_scratch + (size_t)blockIdx.x * (3 * (size_t)N / 4), *bufB = bufA + N / 2;
+    double accP[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int sawinf = 0, npre = 0, nn = N;
+    {
+        const int nh = nn >> 1;
+        double acc = 0.0;
+        for (int i = tid; i < nh; i += T) {
+            const int j0 = 2 * i, j2 = (2 * i + 2) & (N - 1);
+            double m0, m1, m2, m3;
+            if constexpr (MT == MT_LINEAR) {
+                m0 = model.at(j0);
+                m1 = model.at(j0 + 1);
+                m2 = model.at(j2);
+                m3 = model.at(j2 + 1);
+            } else {
+                const double2 xa = *reinterpret_cast<const double2 *>(P.indep + j0);
+                const double2 xb = *reinterpret_cast<const double2 *>(P.indep + j2);
+                m0 = model.at_x(xa.x);
+                m1 = model.at_x(xa.y);
+                m2 = model.at_x(xb.x);
+                m3 = model.at_x(xb.y);
+            }
+            sawinf |= is_pos_inf(m0) | is_pos_inf(m1) | is_pos_inf(m2) | is_pos_inf(m3);
+            const double2 da = *reinterpret_cast<const double2 *>(P.data + j0);
+            const double2 db = *reinterpret_cast<const double2 *>(P.data + j2);
+            double s2, d;
+            d4_pair(da.x - m0, da.y - m1, db.x - m2, db.y - m3, s2, d);
+            bufA[i] = s2;
+            acc = mc3_fma(d, d, acc);
+        }
+        accP[0] = acc;
+        npre = 1;
+        nn = nh;
+    }
+    __syncthreads();                 // (also makes the global stores visible to the workgroup)
+    double *cur = bufA, *dst = bufB;
+#pragma unroll
+    for (int l = 1; l < 8; ++l) {
+        if (nn > WB * T) {
+            const int nh = nn >> 1;
+            double acc = 0.0;
+            for (int i = tid; i < nh; i += T) {
+                const double2 ca = *reinterpret_cast<const double2 *>(cur + 2 * i);
+                const double2 cc = *reinterpret_cast<const double2 *>(cur + ((2 * i + 2) & (nn - 1)));
+                double s2, d;
+                d4_pair(ca.x, ca.y, cc.x, cc.y, s2, d);
+                dst[i] = s2;
+                acc = mc3_fma(d, d, acc);
+            }
+            accP[l] = acc;
+            npre = l + 1;
+            nn = nh;
+            double *t2 = cur;
+            cur = dst;
+            dst = t2;
+            __syncthreads();
+        }
+    }
+    return wavelet_body<8, MT, WB, true>(P, s_nextp, s_part, s_flag, s_tab, s_halo, xs, cur, npre,
+                                         accP, sawinf);
+}
+
+// The geometry is a function of ndata alone (mc3hip.hip choose_wpc): one wave up to 2048
+// points (B = ndata/64, at least 2), four waves at 4096 (B = 16), eight above (B = 16, 32).
+// LARGE (a kernel instance of its own, so that the resident path keeps its register
+// allocation): ndata > 2^14, eight waves, pre-levels through global memory.
+// (declared, with LARGE = false by default, in chisq.h)
+template <int WPC, int MT, bool LARGE>
+__device__ double block_wavelet(const DevProblem &P, const double *s_nextp, double *s_part,
+                                int *s_flag, double *s_tab, double *s_halo, const double *xs)
+{
+    constexpr int T = 64 * WPC;
+    if constexpr (LARGE) {
+        static_assert(WPC == 8, "the large-data path has eight waves");
+        return wavelet_large<MT>(P, s_nextp, s_part, s_flag, s_tab, s_halo, xs);
+    }
+    const int B = (P.ndata / 2 < T) ? 2 : P.ndata / T;
+#define MC3_WL_BODY(BB)                                                                       \
+    return wavelet_body<WPC, MT, BB>(P, s_nextp, s_part, s_flag, s_tab, s_halo, xs)
+    if constexpr (WPC == 8) {
+        if (B == 32)
+            MC3_WL_BODY(32);
+        MC3_WL_BODY(16);
+    } else if constexpr (WPC == 4) {
+        MC3_WL_BODY(16);
+    } else {
+        switch (B) {
+        case 32: MC3_WL_BODY(32);
+        case 16: MC3_WL_BODY(16);
+        case 8: MC3_WL_BODY(8);
+        case 4: MC3_WL_BODY(4);
+        default: MC3_WL_BODY(2);
+        }
+    }
+#undef MC3_WL_BODY
+}
+
+}  // namespace mc3hip

@@ -323,7 +323,7 @@ static double gauss_chisq(const ls_problem *P, const double *p, double *part)
  * are final once written, wavelet.h:33,36); only the smooth half goes on to the
  * next level.  The pyramid is the reference's; what is canonical here is only the
  * ORDER in which the squared details are added up, which follows the blocked
- * layout of the kernel (chain_kernels.h block_wavelet) for T = wl_threads threads:
+ * layout of the kernel (wavelet.h block_wavelet) for T = wl_threads threads:
  *   pre    while more than 32 T values are left: output i of a level belongs to
  *          thread i mod T (large ndata only);
  *   A      Ta = min(T, n/2) threads own contiguous blocks of B = n/Ta values and run

@@ -1,4 +1,4 @@
-"""The tiled plan in ONE persistent launch (resident_tile_kernel, chain_kernels.h): every
+"""The tiled plan in ONE persistent launch (resident_tile_kernel, resident.h): every
 workgroup keeps its tile of the design matrix on chip, proposals and per-tile sums are
 handed over inside the launch.  Same arithmetic as the three-launch tiled plan, so the same
 oracle (oracle/oracle_lockstep.c, `tile_tree = 1`) checks both, bit for bit.

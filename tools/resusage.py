@@ -2,8 +2,7 @@
 """Summarise `hipcc -Rpass-analysis=kernel-resource-usage` remarks: one line per kernel
 (demangled name, VGPR, AGPR, SGPR, scratch bytes/lane, waves/SIMD, LDS bytes).
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -c -o /tmp/x.o \\
-        mc3_amd/csrc/mc3hip.hip -Rpass-analysis=kernel-resource-usage 2> /tmp/res.txt
+    python -m mc3_amd.build --resource-usage > /tmp/res.txt      # every translation unit
     python tools/resusage.py /tmp/res.txt [substring ...]
 """
 import re
