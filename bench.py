@@ -4,27 +4,41 @@
 Workload (BASELINE.json configs[1], "C2"): quadratic 3-parameter fit,
 ndata=1000, 256 chains per GPU, sampler='demc', thinning=1, fepsilon=0,
 synthetic data as in examples/tutorial.py:22-46 of the reference (SURVEY.md
-section 8d).  A "step" is one batch of `--refreshes` Z refreshes (default 16 384 =
-one launch of the persistent kernel, 4.19 M chain-steps per GPU): in every refresh
-every chain of the ensemble advances `thinning` iterations (proposal -> model ->
-chisq -> Metropolis -> Z append).  Whatever --steps/--warmup are given, a step is
-long against launch and synchronisation overheads; the batch shrinks only when Z
-(128 B per chain and refresh) would not fit a 24 GiB budget.
+section 8d).  A "step" is one batch of `--refreshes` Z refreshes (a whole number of
+launches of the persistent kernel, each 16 384 refreshes = 4.19 M chain-steps per GPU):
+in every refresh every chain of the ensemble advances `thinning` iterations (proposal ->
+model -> chisq -> Metropolis -> Z append).  Whatever --steps/--warmup are given, a step
+is long against launch and synchronisation overheads; the batch is sized so that Z (128 B
+per chain and refresh) fits a memory budget.
 
-    python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
-        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py [--gpus N --steps K --warmup W] [--workload c2|c3|c5]
 
-N > 1 is weak scaling: 256*N chains, rank r owns chains [256 r, 256 (r+1)); the
-only data-path collective is one in-place RCCL all-gather of the refresh's new
-Z rows (libmc3hip calls RCCL itself; torch.distributed/gloo is only used to
-hand out the RCCL id, for the barriers and for the max-over-ranks time).
+N > 1, either way of starting it works:
+  * ``python bench.py --gpus N`` as ONE plain process: it never touches the GPU itself,
+    starts N rank processes (RANK / WORLD_SIZE / MC3HIP_RDV_PORT in their environment),
+    relays rank 0's JSON line, ends everything on a watchdog and exits non-zero if any
+    rank failed;
+  * ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N``:
+    the processes the launcher started are the ranks.
+The ranks meet through mc3_amd.parallel.SocketComm (plain TCP; no torch in this file).
+
+N > 1, what is measured (c2 = weak scaling, 256*N chains; c3 / c5 = strong scaling, BASELINE
+configs 3 and 5: 2048 chains x ndata 1000 and 512 chains x 1e5 points x 10 coefficients
+split over the ranks).  Rank r owns a contiguous block of chains and a full replica of Z:
+  * `value`: the peer-to-peer hand-off (the persistent kernel stores every new Z row into
+    every rank's replica over xGMI; no collective), falling back to RCCL by consensus;
+  * `config.collective_rccl`: a second timed segment through ONE in-place RCCL all-gather of
+    the new Z rows per refresh, replayed from a hipGraph -- the north star's collective --
+    with the rank count RCCL itself reports;
+  * `config.single_gpu_same_ensemble`: the whole ensemble in ONE context on rank 0's GPU,
+    the honest yardstick for "is N GPUs faster than one".
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -35,12 +49,12 @@ sys.path.insert(0, ROOT)
 
 CHAINS_PER_GPU = 256
 # the metric exactly as BASELINE.json names it
-METRIC = 'million chain-steps/sec (nchains\u00d7iters/s), 256-chain quad fit ndata=1000'
+METRIC = 'million chain-steps/sec (nchains×iters/s), 256-chain quad fit ndata=1000'
 NDATA = 1000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# algorithmic bytes per chain-step, Gaussian poly, nfree=3:
-#   8*S*ndata + 8*nfree*(R+1) + 8 with S=3 streams (x, data, uncert), R=3 rows
-BYTES_PER_CHAIN_STEP = 8*3*NDATA + 8*3*(3 + 1) + 8
+FP64_PEAK_TFLOPS = 78.6        # MI355X_MICROARCH.md: dense FP64 vector / matrix
+LAUNCH_REFRESHES = 16384       # refreshes one launch of a persistent kernel covers
+PMC_FILES = ('r03_c2_pmc.json', 'r02_c2_pmc.json', 'r01g_c2_pmc.json')
 
 
 def quad(p, x):
@@ -63,15 +77,53 @@ def c2_problem(nchains, nrefresh, thinning=1):
                 hsize=10)
 
 
-def initial_population(prob, eval_chisq):
+def c5_problem(nchains, nrefresh, thinning=1, ndata=100000, nmodel=10):
+    """BASELINE config 5: linear model on a Legendre / cosine design
+    matrix, unit-variance noise, Gaussian priors (sigma = 1) on three parameters, bounds +-5."""
+    rs = np.random.RandomState(7)
+    t = np.linspace(-1, 1, ndata)
+    A = np.array([np.polynomial.legendre.legval(t, [0]*(k//2) + [1]) if k % 2 == 0
+                  else np.cos(np.pi*(k//2 + 1)*t) for k in range(nmodel)])
+    p_true = rs.uniform(-1, 1, nmodel)
+    signal = np.zeros(ndata)
+    for k in range(nmodel):           # (term by term: every rank must build the same bits)
+        signal = signal + p_true[k]*A[k]
+    data = signal + rs.normal(0, 1, ndata)
+    prior, plow, pup = np.zeros(nmodel), np.zeros(nmodel), np.zeros(nmodel)
+    prior[:3], plow[:3], pup[:3] = p_true[:3], 1.0, 1.0
+    return dict(data=data, uncert=np.ones(ndata), indep=A,
+                params=p_true + rs.normal(0, 0.05, nmodel), pstep=np.full(nmodel, 0.05),
+                pmin=np.full(nmodel, -5.0), pmax=np.full(nmodel, 5.0),
+                prior=prior, priorlow=plow, priorup=pup,
+                nchains=nchains, nsamples=nchains*nrefresh*thinning, thinning=thinning,
+                sampler='demc', model='linear', seed=2024, hsize=10)
+
+
+# name -> (problem builder, chains: per GPU (weak) or in total (strong), scaling, algorithmic
+# bytes per chain-step by SURVEY.md section 8d: 8*S*ndata + 8*nfree*(R+1) + 8, description)
+WORKLOADS = {
+    'c2': (c2_problem, CHAINS_PER_GPU, 'weak', 8*3*NDATA + 8*3*(3 + 1) + 8,
+           "C2: quadratic 3-param fit, ndata=1000, 256 chains/GPU, sampler='demc', fepsilon=0"),
+    'c3': (c2_problem, 2048, 'strong', 8*3*NDATA + 8*3*(3 + 1) + 8,
+           "C3: quadratic 3-param fit, ndata=1000, 2048 chains split over the GPUs, "
+           "sampler='demc', fepsilon=0"),
+    'c5': (c5_problem, 512, 'strong', 8*12*100000 + 8*10*(3 + 1) + 8,
+           "C5: 10-param linear model, ndata=1e5, 512 chains split over the GPUs, Gaussian "
+           "priors + bounds, sampler='demc'"),
+}
+BYTES_PER_CHAIN_STEP = WORKLOADS['c2'][3]
+
+
+def initial_population(prob, eval_chisq, expand=None):
     """M0 = hsize*nchains in-bounds draws around the initial guess
     (mcmc_driver.py:229-262), chisq from the device."""
     rs = np.random.RandomState(5)
     M0 = prob['hsize']*prob['nchains']
     x0, sig = prob['params'], prob['pstep']
-    Z0 = np.empty((0, 3))
+    nf = len(x0)
+    Z0 = np.empty((0, nf))
     while len(Z0) < M0:
-        trial = rs.normal(x0, sig, (2*M0, 3))
+        trial = rs.normal(x0, sig, (2*M0, nf))
         ok = np.all((trial >= prob['pmin']) & (trial <= prob['pmax']), axis=1)
         Z0 = np.concatenate([Z0, trial[ok]])
     Z0 = np.ascontiguousarray(Z0[:M0])
@@ -123,20 +175,90 @@ def cpu_baseline(target_seconds=12.0):
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=12)         # timed batches of Z refreshes
-    ap.add_argument('--warmup', type=int, default=2)         # untimed batches of the same size
-    ap.add_argument('--refreshes', type=int, default=0,
-                    help='Z refreshes per step (default 16384 = one persistent launch; '
-                         'fewer when (steps+warmup) batches of Z would exceed 24 GiB)')
-    ap.add_argument('--thinning', type=int, default=1)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    args = ap.parse_args()
+# ---- N > 1 started as one plain process: the parent of the ranks ----------------------------
+def launch_ranks(args, argv):
+    """Start one process per GPU, relay rank 0's JSON line, watch over them.  This process
+    never initialises the GPU (and never replaces itself: the ranks are children)."""
+    from mc3_amd import parallel
+    n = args.gpus
+    port = parallel.free_port()
+    deadline = time.monotonic() + float(os.environ.get('MC3HIP_BENCH_WATCHDOG', 900)) + 60.0
+    procs = []
+    for r in range(n):
+        env = parallel.rank_env(r, n, port)
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__)] + argv, env=env,
+            stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True,
+            start_new_session=True))
+    failed = []
+    try:
+        while not failed and any(p.poll() is None for p in procs):
+            failed = [f'rank {r} exited with {p.returncode}' for r, p in enumerate(procs)
+                      if p.poll() not in (None, 0)]
+            if not failed and time.monotonic() > deadline:
+                failed = ['watchdog: the ranks did not finish in time']
+            # (rank 0's pipe holds one line: it cannot fill up and block the child)
+            time.sleep(0.05)
+        if failed:
+            time.sleep(0.5)         # (ranks that die of the first one's death: say so too)
+            failed = [f'rank {r} exited with {p.returncode}' for r, p in enumerate(procs)
+                      if p.poll() not in (None, 0)] or failed
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()            # (exactly the processes started here)
+        for p in procs:
+            p.wait()
+    out = procs[0].stdout.read() if procs[0].stdout else ''
+    if not failed:
+        failed = [f'rank {r} exited with {p.returncode}' for r, p in enumerate(procs)
+                  if p.returncode != 0]
+    failed = '; '.join(failed) or None
+    line = next((ln for ln in reversed(out.splitlines()) if ln.startswith('{')), None)
+    if failed or line is None:
+        print(f'bench.py --gpus {n}: {failed or "rank 0 printed no result"}', file=sys.stderr)
+        return 1
+    print(line, flush=True)
+    return 0
 
-    # stdout carries ONE JSON line: whatever native libraries print there meanwhile (gloo's
-    # and RCCL's banners) goes to stderr instead
+
+class DryEngine:
+    """--dry-run: stands in for DeviceChains so that the launcher, the rendezvous and the
+    reporting can be driven on a box without a GPU (tests/test_bench_launcher.py).  It
+    computes nothing and its line says so (`data: dry-run`): never a measurement."""
+
+    def __init__(self, nchains, nlocal, chain0, nrefresh, **_):
+        self.nchains, self.nlocal, self.chain0, self.M0 = nchains, nlocal, chain0, 10*nchains
+        self.refresh_done = 0
+        self.plan = {'persistent': LAUNCH_REFRESHES, 'fast': 2, 'comm_graph': 0,
+                     'graph_nodes': 0, 'waves_per_chain': 1, 'recoveries': 0, 'resident': 0}
+
+    def run(self, n, sync=True):
+        self.refresh_done += n
+        time.sleep(1e-7*n)
+
+    def sync(self):
+        pass
+
+    def last_run_ms(self):
+        return 1.0
+
+    def rows(self, row0, nrows):
+        return np.ones((nrows, 3)), np.zeros(nrows), np.zeros(nrows, np.int32)
+
+    def put_rows(self, row0, Z, log_post=None):
+        pass
+
+    def state(self):
+        return {'numaccept': np.full(self.nlocal, self.refresh_done//4)}
+
+    def close(self):
+        pass
+
+
+def run_rank(args):
+    # stdout carries ONE JSON line: whatever native libraries print there meanwhile (RCCL's
+    # banners) goes to stderr instead
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
@@ -144,26 +266,20 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if 'MC3HIP_BENCH_DEVICE' in os.environ:      # testing: several ranks on one GPU
+    shared_device = 'MC3HIP_BENCH_DEVICE' in os.environ
+    if shared_device:                            # testing: several ranks on one GPU
         local_rank = int(os.environ['MC3HIP_BENCH_DEVICE'])
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus N>1 must be launched with torch.distributed.run '
-                     '(one process per GPU)')
-        args.gpus = world
+    args.gpus = world
 
-    # MC3HIP_BENCH_FORCE_COMM=1 drives the multi-rank code path (gloo group, RCCL
-    # communicator, one all-gather per refresh) with a single rank, for testing
+    from mc3_amd import parallel
+    engine = None
+    if not args.dry_run:
+        from mc3_amd import engine
+
+    # MC3HIP_BENCH_FORCE_COMM=1 drives the RCCL code path (communicator, one all-gather per
+    # refresh) with a single rank, for testing
     force_comm = bool(os.environ.get('MC3HIP_BENCH_FORCE_COMM')) and world == 1
-    dist = None
-    if world > 1 or force_comm:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29517')
-        dist.init_process_group('gloo', rank=rank, world_size=world)
-
-    from mc3_amd import engine, parallel
+    ctl = parallel.SocketComm.from_env() if world > 1 else parallel.SingleRank()
 
     if world > 1:
         # a multi-rank run that stops making progress must not hang the node: dump every
@@ -172,20 +288,49 @@ def main():
         faulthandler.dump_traceback_later(float(os.environ.get('MC3HIP_BENCH_WATCHDOG', 900)),
                                           exit=True)
 
-    nchains = CHAINS_PER_GPU*world
-    nbatch = max(1, args.steps) + max(0, args.warmup)
+    build_problem, wl_chains, scaling, bytes_per_step, wl_text = WORKLOADS[args.workload]
+    if scaling == 'weak':
+        nlocal, nchains = wl_chains, wl_chains*world
+    else:
+        if wl_chains % world:
+            sys.exit(f'--workload {args.workload}: {wl_chains} chains do not split over '
+                     f'{world} ranks')
+        nlocal, nchains = wl_chains//world, wl_chains
+    chain0 = rank*nlocal
+    nsteps, nwarm = max(1, args.steps), max(0, args.warmup)
+    nbatch = nsteps + nwarm
     row_bytes = nchains*(16*8 + 8 + 4)            # padded Z row + log_post + zchain
-    R = args.refreshes or int(max(64, min(16384, (24 << 30)//(row_bytes*nbatch))))
-    nref_timed, nref_warm = max(1, args.steps)*R, max(0, args.warmup)*R
+    # Z grows with the run: a step is as many whole persistent launches as fit the budget
+    # (at most 6: ~0.12 s of GPU time per step at the headline shape, so that the default
+    # run keeps the GPU busy for seconds, not for the half second the driver's utilisation
+    # sampler would miss); never more than half of the free memory of a GPU, shared by the
+    # ranks on it
+    budget = 96 << 30
+    if engine is not None:
+        free, _ = engine.device_memory(local_rank)
+        budget = min(budget, free//2//(world if shared_device else 1))
+    if args.dry_run:
+        if os.environ.get('MC3HIP_BENCH_DRY_FAIL_RANK') == str(rank):
+            sys.exit(3)                           # (test hook: a rank that dies)
+        R = args.refreshes or 4
+    elif args.workload == 'c5':
+        R = args.refreshes or 100                 # (36 us per iteration: 100 per step)
+    else:
+        fit = budget//(row_bytes*nbatch)
+        R = args.refreshes or int(LAUNCH_REFRESHES*min(6, fit//LAUNCH_REFRESHES)
+                                  if fit >= LAUNCH_REFRESHES else max(64, fit))
+    nref_timed, nref_warm = nsteps*R, nwarm*R
     nrefresh = nref_timed + nref_warm
-    prob = c2_problem(nchains, nrefresh + 64, args.thinning)
+    prob = build_problem(nchains, nrefresh + 64, args.thinning)
     comm = None
     exchange = None
 
-    def make_engine(p2p):
-        g = engine.DeviceChains(device=local_rank, chain0=rank*CHAINS_PER_GPU,
-                                nlocal=CHAINS_PER_GPU, p2p=p2p, **prob)
-        Z0, lp0 = initial_population(prob, g.eval_chisq)
+    def make_engine(p2p, prob=prob, chain0=chain0, nlocal=nlocal):
+        if args.dry_run:
+            return DryEngine(prob['nchains'], nlocal, chain0, nrefresh)
+        g = engine.DeviceChains(device=local_rank, chain0=chain0, nlocal=nlocal, p2p=p2p,
+                                **prob)
+        Z0, lp0 = initial_population(prob, lambda Z: g.eval_chisq(g.expand_free(Z)))
         g.set_population(Z0, lp0)
         return g
 
@@ -193,7 +338,8 @@ def main():
         # preferred: the in-launch hand-off across GPUs (peer-to-peer stores into every
         # rank's Z replica); validated on a short run, else one RCCL all-gather per
         # refresh.  Every rank takes the same branch.
-        comm = parallel.TorchDistComm(use_p2p=not os.environ.get('MC3HIP_BENCH_NO_P2P'))
+        comm = ctl
+        comm.wants_p2p = not os.environ.get('MC3HIP_BENCH_NO_P2P') and not args.dry_run
         gpu = make_engine(comm.wants_p2p)
         comm.setup(gpu)
         if comm.mode == 'p2p':
@@ -207,36 +353,36 @@ def main():
                 ok = False
             if not comm._all_ok(ok) and comm.mode == 'p2p':
                 gpu.close()
-                comm = parallel.TorchDistComm(use_p2p=False)
+                comm.wants_p2p = False
                 gpu = make_engine(False)
                 comm.setup(gpu)
         exchange = comm.mode
     else:
         gpu = make_engine(False)
         if force_comm:
-            ids = [engine.comm_unique_id()]
-            gpu.comm_init(ids[0], 0, 1)
+            gpu.comm_init(engine.comm_unique_id(), 0, 1)
             exchange = 'rccl'
 
-    def barrier():
+    def barrier(g=None):
         # multi-rank: quiesce() drains the library's stream, lets the ranks agree that
         # the segment completed everywhere (peer-to-peer stores: every peer has finished
         # too) and, if a launch gave up anywhere, rolls all of them back and redoes it
-        if comm is not None:
-            comm.quiesce(gpu)
-        gpu.sync()
-        if world > 1 or force_comm:
-            dist.barrier()
+        g = g or gpu
+        if comm is not None and g is gpu:
+            comm.quiesce(g)
+        g.sync()
+        ctl.barrier()
 
-    def advance(n):
-        if comm is not None and not comm.native:
+    def advance(n, g=None):
+        g = g or gpu
+        if comm is not None and g is gpu and not comm.native:
             # host-staged exchange (no peer access and no RCCL): one refresh at a time
             for _ in range(n):
-                R = gpu.refresh_done
-                gpu.run(1)
-                comm.exchange(gpu, R)
+                R0 = g.refresh_done
+                g.run(1)
+                comm.exchange(g, R0)
         else:
-            gpu.run(n, sync=False)
+            g.run(n, sync=False)
 
     if nref_warm:
         advance(nref_warm)
@@ -246,10 +392,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gpu_ms = gpu.last_run_ms()          # HIP events on the library's stream
-    if world > 1 or force_comm:
-        t = torch.tensor([dt, gpu_ms], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, gpu_ms = float(t[0]), float(t[1])
+    if world > 1:
+        both = ctl.all_gather((dt, gpu_ms))
+        dt, gpu_ms = max(b[0] for b in both), max(b[1] for b in both)
 
     consistent = None
     if world > 1:
@@ -257,25 +402,39 @@ def main():
         done = gpu.refresh_done
         Zt, _, _ = gpu.rows(gpu.M0 + (done - 8)*nchains, 8*nchains)
         digest = float(np.sum(Zt*np.arange(1, Zt.size + 1).reshape(Zt.shape)))
-        box = [None]*world
-        dist.all_gather_object(box, digest)
+        box = ctl.all_gather(digest)
         consistent = bool(all(d == box[0] for d in box) and np.all(np.isfinite(Zt)))
     st = gpu.state()
-    accept = float(st['numaccept'].sum())/(CHAINS_PER_GPU*gpu.refresh_done*args.thinning)
+    accept = float(st['numaccept'].sum())/(nlocal*gpu.refresh_done*args.thinning)
     chain_steps = nchains*nref_timed*args.thinning
     value = chain_steps/dt/1e6
+    plan = dict(gpu.plan)
+    if comm is not None:
+        exchange = comm.mode           # (a recovery inside the run changes the exchange)
+    recoveries = plan['recoveries'] + (comm.recoveries if comm else 0)
+
+    # ---- N > 1: the north star's collective, and the one-GPU yardstick ---------------------
+    collective_rccl = None
+    single = None
+    if world > 1 and not args.dry_run:
+        gpu.close()
+        collective_rccl = rccl_segment(args, ctl, make_engine, build_problem, nchains, nlocal,
+                                       chain0, local_rank, engine)
+        ctl.barrier()
+        if rank == 0:
+            single = single_gpu_segment(args, build_problem, nchains, local_rank, engine)
+        ctl.barrier()
 
     # roofline of the dominant (only) kernel.  Persistent path: one launch covers
     # `persistent` refreshes; per-refresh path: one launch per refresh.
     multi = world > 1 or force_comm
-    if comm is not None:
-        exchange = comm.mode           # (a recovery inside the run changes the exchange)
-    cgraph = gpu.plan['comm_graph']
-    per = gpu.plan['persistent'] if (not multi or exchange == 'p2p') else 0
+    cgraph = plan['comm_graph']
+    per = plan['persistent'] if (not multi or exchange == 'p2p') else 0
     if per > 0:
         launches = -(-nref_timed//per)
-        kernel = {2: 'mc3hip::lean_demc_kernel', 1: 'mc3hip::persist_fast_kernel',
-                  0: 'mc3hip::persist_kernel'}[gpu.plan['fast']]
+        kernel = 'mc3hip::resident_tile_kernel' if plan.get('resident') else \
+            {2: 'mc3hip::lean_demc_kernel', 1: 'mc3hip::persist_fast_kernel',
+             0: 'mc3hip::persist_kernel'}[plan['fast']]
         structure = (f'persistent kernel, {per} refreshes per launch, Z rows handed '
                      'between workgroups in-launch')
     else:
@@ -285,48 +444,51 @@ def main():
             ((f' + one RCCL all-gather per refresh, captured in a hipGraph of {cgraph} '
               'refreshes (step kernel, all-gather, scatter kernel each)' if cgraph else
               ' + one RCCL all-gather per refresh (eager)') if multi else
-             f' (hipGraph of {gpu.plan["graph_nodes"]} nodes)')
+             f' (hipGraph of {plan["graph_nodes"]} nodes)')
     traffic = None
     hbm_per_step = None
-    pmc = next((q for q in (os.path.join(ROOT, 'profiles', n) for n in
-                            ('r02_c2_pmc.json', 'r01g_c2_pmc.json')) if os.path.exists(q)), None)
-    if pmc and args.thinning == 1 and world == 1:
+    pmc = next((q for q in (os.path.join(ROOT, 'profiles', n) for n in PMC_FILES)
+                if os.path.exists(q)), None)
+    if pmc and args.thinning == 1 and world == 1 and args.workload == 'c2':
         with open(pmc) as f:
             rec = json.load(f)
         if rec['kernel'].startswith(kernel):
             # HBM bytes per launch from the PMC counters of the same kernel
             # (separate rocprofv3 --pmc passes, gfx950 FETCH_SIZE correction)
             hbm_per_step = rec['hbm_bytes_per_chain_step']
-            traffic = hbm_per_step*CHAINS_PER_GPU*nref_timed/launches
+            traffic = hbm_per_step*nlocal*nref_timed/launches
     launch_s = gpu_ms*1e-3/launches
-    bytes_per_launch = BYTES_PER_CHAIN_STEP*CHAINS_PER_GPU*args.thinning*nref_timed/launches
+    bytes_per_launch = bytes_per_step*nlocal*args.thinning*nref_timed/launches
     achieved = bytes_per_launch/launch_s/1e9
     out = {
         'metric': METRIC,
         'value': value, 'unit': 'million chain-steps/sec',
-        'n_gpus': world, 'steps': max(1, args.steps), 'warmup': max(0, args.warmup),
-        'ms_per_step': dt*1e3/max(1, args.steps), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
-        'data': 'synthetic',
+        'n_gpus': world, 'steps': nsteps, 'warmup': nwarm,
+        'ms_per_step': dt*1e3/nsteps, 'higher_is_better': True,
+        'scaling': scaling, 'vs_baseline': None, 'dtype': 'f64',
+        'data': 'dry-run (no GPU work: launcher plumbing only)' if args.dry_run else 'synthetic',
         'config': {
-            'workload': 'C2: quadratic 3-param fit, ndata=1000, 256 chains/GPU, '
-                        "sampler='demc', fepsilon=0",
-            'nchains': nchains, 'ndata': NDATA, 'thinning': args.thinning,
+            'workload': wl_text,
+            'nchains': nchains, 'ndata': len(prob['data']), 'thinning': args.thinning,
             'step': f'{R} Z refreshes of all {nchains} chains = {nchains*R*args.thinning} '
                     'chain-steps',
             'refreshes_per_step': R,
-            'chains_per_gpu': CHAINS_PER_GPU,
+            'chains_per_gpu': nlocal,
             'parallelism': f'chains sharded x{world}' if world > 1 else 'single GPU',
             'collective': {None: None, 'rccl': 'one in-place RCCL all-gather of new Z rows per '
                            'refresh' + (f', replayed from a hipGraph ({cgraph} refreshes per '
-                                        'replay)' if cgraph else ', eager'), 'p2p': 'none: every new Z row is stored peer-to-peer into '
+                                        'replay)' if cgraph else ', eager'),
+                           'p2p': 'none: every new Z row is stored peer-to-peer into '
                            'every rank\'s replica by the persistent kernel (xGMI)',
                            'host': 'host-staged'}[exchange],
+            'collective_rccl': collective_rccl,
+            'single_gpu_same_ensemble': single,
             'launch_structure': structure,
-            'waves_per_chain': gpu.plan['waves_per_chain'],
+            'waves_per_chain': plan['waves_per_chain'],
             'acceptance_rate': accept,
             'replicas_consistent': consistent,
-            'recoveries': gpu.plan['recoveries'] + (comm.recoveries if comm else 0),
+            'recoveries': recoveries,
+            'control_plane': None if world == 1 else 'mc3_amd.parallel.SocketComm (TCP)',
             # what "the same results as the reference" means here
             'semantics': 'lockstep (Jacobi) DEMC: during refresh R a chain sees the others '
                          'through the rows of refresh R-1 (the reference updates the chains '
@@ -338,7 +500,11 @@ def main():
                          'reference\'s own runs from a draw tape (tests/test_oracle_tape.py)',
         },
         'roofline': {
-            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+            # what bounds the kernel is the latency of the hand-off between workgroups and of
+            # one wave's dependent FP64 chain; `frac` stays the contractual figure: the
+            # algorithmic bytes per second against the HBM peak
+            'bound': 'latency', 'contract_bound': 'hbm',
+            'achieved': achieved, 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic,
             'kernel': kernel, 'launches': launches,
             'algorithmic_bytes_per_launch': bytes_per_launch,
@@ -349,34 +515,42 @@ def main():
                 'hbm_GBs': hbm_per_step*chain_steps/world/(gpu_ms*1e-3)/1e9,
                 'frac_of_peak': hbm_per_step*chain_steps/world/(gpu_ms*1e-3)/1e9/HBM_PEAK_GBS,
                 'hbm_bytes_per_chain_step': hbm_per_step,
-                'source': os.path.basename(pmc)},
-            'latency_model': {
-                'us_per_iteration': launch_s*1e6*launches/nref_timed/args.thinning,
-                'floor_us': 0.8 + 0.42,
-                'floor': 'every iteration of every chain needs two rows other chains (other '
-                         'CUs, other XCDs) produced in the iteration before: one cross-CU '
-                         'hand-off (MI355X_MICROARCH.md "handoff-1to1" 0.8 us) + the dependent '
-                         'FP64 chain of one wave alone on its SIMD, proposal -> chisq of 1000 '
-                         'points (16 per lane) -> 6 cross-lane adds -> exp -> accept, '
-                         '~1000 cycles = 0.42 us at 2.4 GHz (tools/ticks.py)',
-                'note': 'one wave per CU on 256 CUs = 1/4 of the SIMDs, ~2 % of the FP64 vector '
-                        'peak: the workload (256 chains, 1000 points) cannot fill the chip; '
-                        'it is latency-bound, neither bandwidth- nor FLOP-bound'},
-            'note': 'algorithmic bytes (SURVEY 8d: 24104 B per chain-step) x chain-steps '
-                    'per launch / average launch duration (HIP events on the library '
-                    'stream over the timed region / launches). x/data/uncert are '
-                    'chain-invariant: they live in registers for a whole launch, so '
-                    'hardware HBM traffic (traffic: bytes per launch from '
-                    'profiles/r01g_c2_pmc.json, FETCH_SIZE doubled per the gfx950 note) '
-                    'is far below the algorithmic figure',
+                'source': 'profiles/' + os.path.basename(pmc)},
+            'note': f'algorithmic bytes (SURVEY 8d: {bytes_per_step} B per chain-step) x '
+                    'chain-steps per launch / average launch duration (HIP events on the '
+                    'library stream over the timed region / launches).  The operand streams '
+                    'are chain-invariant: they live in registers for a whole launch, so '
+                    'hardware HBM traffic (`traffic`: bytes per launch from the PMC passes '
+                    'named in hw.source, FETCH_SIZE doubled per the gfx950 note) is far below '
+                    'the algorithmic figure',
         },
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if args.workload == 'c5':
+        flops = 2.0*10*len(prob['data'])           # per chain-step: the contraction
+        out['roofline']['fp64'] = {
+            'useful_TFLOPs': value*1e6*flops/1e12/world, 'peak': FP64_PEAK_TFLOPS,
+            'frac': value*1e6*flops/1e12/world/FP64_PEAK_TFLOPS,
+            'note': 'design-matrix models: the K = 10 contraction on the shared FP64 matrix / '
+                    'vector pipe is what bounds them, per GPU'}
+    else:
+        out['roofline']['latency_model'] = {
+            'us_per_iteration': launch_s*1e6*launches/nref_timed/args.thinning,
+            'floor_us': 0.8 + 0.42,
+            'floor': 'every iteration of every chain needs two rows other chains (other '
+                     'CUs, other XCDs) produced in the iteration before: one cross-CU '
+                     'hand-off (MI355X_MICROARCH.md "handoff-1to1" 0.8 us) + the dependent '
+                     'FP64 chain of one wave alone on its SIMD, proposal -> chisq of 1000 '
+                     'points (16 per lane) -> 6 cross-lane adds -> exp -> accept, '
+                     '~1000 cycles = 0.42 us at 2.4 GHz (tools/ticks.py)',
+            'note': 'one wave per CU on 256 CUs = 1/4 of the SIMDs, ~2 % of the FP64 vector '
+                    'peak: the workload (256 chains, 1000 points) cannot fill the chip; '
+                    'it is latency-bound, neither bandwidth- nor FLOP-bound'}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry_run:
         out['cpu_baseline'] = cpu_baseline()
-    gpu.close()
-    if world > 1 or force_comm:
-        dist.barrier()
-        dist.destroy_process_group()
+    if world == 1:
+        gpu.close()
+    ctl.barrier()
+    ctl.close()
     import ctypes
     try:
         ctypes.CDLL(None).fflush(None)       # (what native code still holds in C stdio)
@@ -386,6 +560,98 @@ def main():
     os.dup2(json_fd, 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def rccl_segment(args, ctl, make_engine, build_problem, nchains, nlocal, chain0, device, engine):
+    """The same ensemble through ONE in-place RCCL all-gather of the new Z rows per refresh
+    (libmc3hip calls RCCL itself; replayed from a hipGraph), timed on its own: the north
+    star's collective, with RCCL's own word on how many ranks it spanned."""
+    nwarm, ntimed = (8, 24) if args.workload == 'c5' else (768, 3072)
+    prob = build_problem(nchains, nwarm + ntimed + 8, args.thinning)
+    g = None
+    ok, err = True, None
+    try:
+        g = engine.DeviceChains(device=device, chain0=chain0, nlocal=nlocal, **prob)
+        Z0, lp0 = initial_population(prob, lambda Z: g.eval_chisq(g.expand_free(Z)))
+        g.set_population(Z0, lp0)
+    except Exception as e:      # noqa: BLE001
+        ok, err = False, str(e)
+    saved = (ctl.native, ctl.mode)
+    if ctl._all_ok(ok):
+        ctl._setup_rccl(g)
+        ok = ctl.mode == 'rccl'
+        if not ok:
+            err = 'RCCL communicator could not be set up on every rank (RCCL refuses ' \
+                  'several ranks on one device)'
+    else:
+        ok = False
+    ctl.native, ctl.mode = saved
+    out = None
+    if ok:
+        g.run(nwarm)
+        ctl.barrier()
+        t0 = time.perf_counter()
+        g.run(ntimed)
+        ctl.barrier()
+        dt = max(ctl.all_gather(time.perf_counter() - t0))
+        nr, _ = g.comm_info()
+        plan = g.plan
+        out = {'exchange': 'one in-place ncclAllGather of the refresh\'s Z rows per refresh',
+               'rccl_ranks': nr, 'refreshes_timed': ntimed,
+               'us_per_refresh': dt/ntimed*1e6,
+               'million_chain_steps_per_s': nchains*ntimed*args.thinning/dt/1e6,
+               'hipgraph_refreshes_per_replay': plan['comm_graph'],
+               'payload_bytes_per_rank': nlocal*128}
+    else:
+        out = {'error': err or 'not available on every rank'}
+    if g is not None:
+        g.close()
+    return out
+
+
+def single_gpu_segment(args, build_problem, nchains, device, engine):
+    """The whole ensemble in ONE context on one GPU (no exchange at all)."""
+    nwarm, ntimed = (8, 40) if args.workload == 'c5' else (1024, 8192)
+    prob = build_problem(nchains, nwarm + ntimed + 8, args.thinning)
+    try:
+        with engine.DeviceChains(device=device, **prob) as g:
+            Z0, lp0 = initial_population(prob, lambda Z: g.eval_chisq(g.expand_free(Z)))
+            g.set_population(Z0, lp0)
+            g.run(nwarm)
+            t0 = time.perf_counter()
+            g.run(ntimed)
+            dt = time.perf_counter() - t0
+            plan = g.plan
+        return {'nchains': nchains, 'million_chain_steps_per_s':
+                nchains*ntimed*args.thinning/dt/1e6, 'us_per_refresh': dt/ntimed*1e6,
+                'persistent': plan['persistent'], 'refreshes_timed': ntimed}
+    except Exception as e:      # noqa: BLE001
+        return {'error': str(e)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=12)         # timed batches of Z refreshes
+    ap.add_argument('--warmup', type=int, default=2)         # untimed batches of the same size
+    ap.add_argument('--refreshes', type=int, default=0,
+                    help='Z refreshes per step (default: up to 6 persistent launches of 16384, '
+                         'as many as (steps+warmup) batches of Z fit the memory budget)')
+    ap.add_argument('--thinning', type=int, default=1)
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='c2',
+                    help='c2: the headline, 256 chains per GPU (weak scaling); c3 / c5: BASELINE '
+                         'configs 3 and 5, a fixed ensemble split over the GPUs (strong scaling)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='no GPU work: exercises the launcher / rendezvous / reporting only')
+    args = ap.parse_args()
+    if 'RANK' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus and not (world == 1 and args.gpus <= 1):
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}',
+              file=sys.stderr)
+    run_rank(args)
 
 
 if __name__ == '__main__':

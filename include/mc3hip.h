@@ -251,6 +251,14 @@ int mc3hip_comm_init(mc3hip_ctx *ctx, const void *unique_id_128, int32_t rank,
 /* Exchange log_post rows [row0, row0+nrows) that other ranks own (needed only
  * when the posterior is read back). */
 int mc3hip_comm_gather_log_post(mc3hip_ctx *ctx);
+/* What RCCL itself reports for the communicator of mc3hip_comm_init (ncclCommCount,
+ * ncclCommUserRank): the evidence a multi-GPU measurement carries that the collective
+ * really spanned that many ranks.  MC3HIP_ERR_STATE without a communicator. */
+int mc3hip_comm_info(mc3hip_ctx *ctx, int32_t *nranks, int32_t *rank);
+/* Free and total device memory in bytes (hipMemGetInfo): callers size Z, which grows
+ * with the run length (128-byte rows: core.h ZROW), against it.  No reference counterpart
+ * (the reference's Z lives in host shared memory, mcmc_driver.py:158-171). */
+int mc3hip_device_memory(int32_t device, int64_t *free_bytes, int64_t *total_bytes);
 
 /* Peer-to-peer variant of the multi-GPU exchange (contexts created with
  * MC3HIP_FLAG_P2P, one per rank/process, equal contiguous chain blocks): every rank

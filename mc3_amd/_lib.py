@@ -101,6 +101,8 @@ SYMBOLS = {
     'mc3hip_comm_unique_id': (ctypes.c_int, [_vp]),
     'mc3hip_comm_init': (ctypes.c_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int32]),
     'mc3hip_comm_gather_log_post': (ctypes.c_int, [_vp]),
+    'mc3hip_comm_info': (ctypes.c_int, [_vp, _ip, _ip]),
+    'mc3hip_device_memory': (ctypes.c_int, [ctypes.c_int32, _lp, _lp]),
     'mc3hip_p2p_export': (ctypes.c_int, [_vp, _vp]),
     'mc3hip_p2p_attach': (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, _vp]),
     'mc3hip_p2p_detach': (ctypes.c_int, [_vp]),

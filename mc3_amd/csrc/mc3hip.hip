@@ -61,6 +61,8 @@ struct Rccl {
     int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommCount)(const ncclComm_t, int *) = nullptr;
+    int (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
 Rccl g_rccl;
@@ -84,6 +86,8 @@ int load_rccl()
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
+    g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))dlsym(h, "ncclCommUserRank");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather ||
         !g_rccl.CommDestroy)
         return fail(MC3HIP_ERR_COMM, "librccl.so lacks an expected symbol");
@@ -2024,6 +2028,34 @@ int mc3hip_comm_gather_log_post(mc3hip_ctx *c)
         HIP_TRY(hipStreamSynchronize(c->stream));      // the staging buffer is reused
     }
     c->logpost_gathered = c->refresh_done;
+    return MC3HIP_OK;
+}
+
+int mc3hip_comm_info(mc3hip_ctx *c, int32_t *nranks, int32_t *rank)
+{
+    if (!c || !nranks || !rank)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    if (!c->comm)
+        return fail(MC3HIP_ERR_STATE, "no RCCL communicator is attached");
+    if (!g_rccl.CommCount || !g_rccl.CommUserRank)
+        return fail(MC3HIP_ERR_COMM, "librccl.so lacks ncclCommCount / ncclCommUserRank");
+    int n = 0, r = 0;
+    if (g_rccl.CommCount(c->comm, &n) != 0 || g_rccl.CommUserRank(c->comm, &r) != 0)
+        return fail(MC3HIP_ERR_COMM, "ncclCommCount / ncclCommUserRank failed");
+    *nranks = n;
+    *rank = r;
+    return MC3HIP_OK;
+}
+
+int mc3hip_device_memory(int32_t device, int64_t *free_bytes, int64_t *total_bytes)
+{
+    if (!free_bytes || !total_bytes)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    *free_bytes = (int64_t)f;
+    *total_bytes = (int64_t)t;
     return MC3HIP_OK;
 }
 

@@ -314,6 +314,12 @@ class DeviceChains:
     def comm_destroy(self):
         check(self.lib.mc3hip_comm_destroy(self._ctx))
 
+    def comm_info(self):
+        """(nranks, rank) as RCCL itself reports them for the attached communicator."""
+        n, r = ctypes.c_int32(), ctypes.c_int32()
+        check(self.lib.mc3hip_comm_info(self._ctx, ctypes.byref(n), ctypes.byref(r)))
+        return int(n.value), int(r.value)
+
     def p2p_detach(self):
         check(self.lib.mc3hip_p2p_detach(self._ctx))
 
@@ -324,6 +330,13 @@ class DeviceChains:
         r0, r1 = ctypes.c_int64(), ctypes.c_int64()
         check(self.lib.mc3hip_p2p_rollback(self._ctx, ctypes.byref(r0), ctypes.byref(r1)))
         return int(r0.value), int(r1.value)
+
+
+def device_memory(device=0):
+    """(free, total) bytes of device memory."""
+    f, t = ctypes.c_int64(), ctypes.c_int64()
+    check(_lib.load().mc3hip_device_memory(int(device), ctypes.byref(f), ctypes.byref(t)))
+    return int(f.value), int(t.value)
 
 
 def comm_unique_id():

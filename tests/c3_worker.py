@@ -12,16 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
-import torch.distributed as dist  # noqa: E402
-
 from mc3_amd import engine, parallel  # noqa: E402
 import helpers as H  # noqa: E402
+import ranks  # noqa: E402
 
 
 def main():
     out_path, nref = sys.argv[1], int(sys.argv[2])
-    dist.init_process_group('gloo')
-    comm = parallel.TorchDistComm(use_p2p=True, use_rccl=False)
+    comm = ranks.worker_comm(use_p2p=True, use_rccl=False)
     nchains = 256*comm.size
     prob = H.quad_problem(ndata=1000, nchains=nchains, nsamples=nchains*nref, sampler='demc')
     pop = np.load(out_path + '.pop.npz')
@@ -43,9 +41,9 @@ def main():
     np.savez(f'{out_path}.rank{comm.rank}.npz', Z=Z, lp=lp, zc=zc,
              numaccept=st['numaccept'], outbounds=st['outbounds'],
              best_chisq=st['best_chisq'], X=st['X'], chisq=st['chisq'])
-    dist.barrier()
+    comm.barrier()
     gpu.close()
-    dist.destroy_process_group()
+    ranks.finalize(comm)
 
 
 if __name__ == '__main__':

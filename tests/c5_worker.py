@@ -12,10 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
-import torch.distributed as dist  # noqa: E402
-
 from mc3_amd import engine, parallel  # noqa: E402
 import helpers as H  # noqa: E402
+import ranks  # noqa: E402
 
 
 def main():
@@ -23,11 +22,10 @@ def main():
         sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]),
         sys.argv[6])
     abort_at = int(sys.argv[7].split('=')[1]) if len(sys.argv) > 7 else None
-    dist.init_process_group('gloo')
-    if abort_at is not None and dist.get_rank() == 0:
+    if abort_at is not None and int(os.environ.get('RANK', '0')) == 0:
         # test hook: this rank's first chain gives up at that refresh (read at create)
         os.environ['MC3HIP_TEST_ABORT_AT'] = str(abort_at)
-    comm = parallel.TorchDistComm(use_p2p=True, use_rccl=False)
+    comm = ranks.worker_comm(use_p2p=True, use_rccl=False)
     nchains = per_rank*comm.size
     if nmodel == 3:         # (the polynomial flavour: the tutorial's quadratic)
         prob = H.quad_problem(ndata=ndata, nchains=nchains, nsamples=nchains*nref,
@@ -76,9 +74,9 @@ def main():
     np.savez(f'{out_path}.rank{comm.rank}.npz', Z=Z, lp=lp, zc=zc, **extra,
              numaccept=st['numaccept'], outbounds=st['outbounds'],
              best_chisq=st['best_chisq'], X=st['X'], chisq=st['chisq'])
-    dist.barrier()
+    comm.barrier()
     gpu.close()
-    dist.destroy_process_group()
+    ranks.finalize(comm)
 
 
 if __name__ == '__main__':

@@ -1,5 +1,5 @@
 """Worker for tests/test_distributed_gloo.py: one rank of a sharded mcmc() run
-(CPU engine, gloo, host-staged exchange).  Launched by torch.distributed.run."""
+(CPU engine, host-staged exchange), launched by tests/ranks.py with either communicator."""
 import os
 import sys
 
@@ -9,18 +9,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
-import torch.distributed as dist  # noqa: E402
-
 import mc3_amd  # noqa: E402
 from mc3_amd import parallel, utils as mu  # noqa: E402
 from oracle_engine import OracleChains  # noqa: E402
 import helpers as H  # noqa: E402
+import ranks  # noqa: E402
 
 
 def main():
     out_path, sampler, thinning = sys.argv[1], sys.argv[2], int(sys.argv[3])
-    dist.init_process_group('gloo')
-    comm = parallel.TorchDistComm(use_rccl=False)
+    comm = ranks.worker_comm(use_rccl=False)
     x, data, uncert = H.tutorial_data(100)
     np.random.seed(100 + comm.rank)          # ranks deliberately differ: rank 0's
     out = mc3_amd.sample(                    # population must be broadcast
@@ -32,8 +30,7 @@ def main():
         engine_factory=OracleChains, seed=99, comm=comm)
     np.savez(f'{out_path}.rank{comm.rank}.npz',
              **{k: v for k, v in out.items() if k not in ('pnames', 'texnames')})
-    dist.barrier()
-    dist.destroy_process_group()
+    ranks.finalize(comm)
 
 
 if __name__ == '__main__':

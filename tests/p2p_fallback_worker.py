@@ -9,11 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
-import torch.distributed as dist  # noqa: E402
-
 from mc3_amd import parallel  # noqa: E402
 from oracle_engine import OracleChains  # noqa: E402
 import helpers as H  # noqa: E402
+import ranks  # noqa: E402
 
 
 class Flaky(OracleChains):
@@ -21,7 +20,7 @@ class Flaky(OracleChains):
     plan = {'persistent': 1}
 
     def p2p_export(self):
-        if dist.get_rank() == 1:
+        if int(os.environ['RANK']) == 1:
             raise RuntimeError('no IPC here')
         return b'x'*128
 
@@ -30,16 +29,14 @@ class Flaky(OracleChains):
 
 
 def main():
-    dist.init_process_group('gloo')
-    comm = parallel.TorchDistComm(use_p2p=True, use_rccl=False)
+    comm = ranks.worker_comm(use_p2p=True, use_rccl=False)
     prob = H.quad_problem(nchains=8, nsamples=8*20, sampler='demc')
     c0, n = comm.partition(8)
     eng = Flaky(chain0=c0, nlocal=n, **prob)
     eng.plan = {'persistent': 1}
     comm.setup(eng)
     assert comm.mode == 'host' and not comm.native, comm.mode
-    dist.barrier()
-    dist.destroy_process_group()
+    ranks.finalize(comm)
     print('fallback ok')
 
 

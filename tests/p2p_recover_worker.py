@@ -1,5 +1,5 @@
 """Worker for test_distributed_gloo.py::test_peer_to_peer_recovery_logic_on_cpu: the
-vote / roll-back / redo logic of TorchDistComm (mc3_amd/parallel.py) without a GPU.
+vote / roll-back / redo logic of the communicator (mc3_amd/parallel.py Communicator) without a GPU.
 
 The engine EMULATES the peer-to-peer mode on top of the CPU checker: while attached, a rank
 advances the whole ensemble itself (its replica is complete without an exchange, as if
@@ -16,13 +16,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
-import torch.distributed as dist  # noqa: E402
-
 import mc3_amd  # noqa: E402
 from mc3_amd import parallel, utils as mu  # noqa: E402
 from mc3_amd._lib import Mc3HipError, ERR_ABORTED  # noqa: E402
 from oracle_engine import OracleChains  # noqa: E402
 import helpers as H  # noqa: E402
+import ranks  # noqa: E402
 
 ARRAYS = ('Z', 'log_post', 'zchain', 'X', 'chisq', 'numaccept', 'outbounds', 'best_chisq',
           'best_iter', 'bestx')
@@ -44,7 +43,7 @@ class EmulatedP2P(OracleChains):
         return b'h'*128
 
     def p2p_attach(self, rank, handles):
-        assert len(handles) == dist.get_world_size()
+        assert len(handles) == int(os.environ['WORLD_SIZE'])
         self.attached = True
 
     def run(self, nrefresh=None, sync=True):
@@ -56,7 +55,7 @@ class EmulatedP2P(OracleChains):
         return super().run(nrefresh, sync)
 
     def sync(self):
-        if self.attached and dist.get_rank() == 1 and not self.failed_once and \
+        if self.attached and int(os.environ['RANK']) == 1 and not self.failed_once and \
                 self.refresh_done >= FAIL_AFTER:
             self.failed_once = True
             raise Mc3HipError(ERR_ABORTED, 'emulated: a wait for a peer row timed out')
@@ -76,8 +75,7 @@ class EmulatedP2P(OracleChains):
 
 def main():
     out_path = sys.argv[1]
-    dist.init_process_group('gloo')
-    comm = parallel.TorchDistComm(use_rccl=False, use_p2p=True)
+    comm = ranks.worker_comm(use_rccl=False, use_p2p=True)
     x, data, uncert = H.tutorial_data(100)
     out = mc3_amd.sample(
         data=data, uncert=uncert, func=H.quad, params=np.array([10.0, -2.0, 0.1]),
@@ -90,8 +88,7 @@ def main():
     np.savez(f'{out_path}.rank{comm.rank}.npz',
              **{k: v for k, v in out.items() if k not in ('pnames', 'texnames')})
     print('recovered', flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
+    ranks.finalize(comm)
 
 
 if __name__ == '__main__':

@@ -11,22 +11,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
-import torch.distributed as dist  # noqa: E402
-
 import mc3_amd  # noqa: E402
 from mc3_amd import parallel, utils as mu  # noqa: E402
 import helpers as H  # noqa: E402
+import ranks  # noqa: E402
 
 
 def main():
     out_path, sampler, thinning, niter = (sys.argv[1], sys.argv[2], int(sys.argv[3]),
                                           int(sys.argv[4]))
     abort_at = int(sys.argv[5].split('=')[1]) if len(sys.argv) > 5 else None
-    dist.init_process_group('gloo')
-    if abort_at is not None and dist.get_rank() == 0:
+    if abort_at is not None and int(os.environ.get('RANK', '0')) == 0:
         # test hook: this rank's first chain gives up at that refresh (read at create)
         os.environ['MC3HIP_TEST_ABORT_AT'] = str(abort_at)
-    comm = parallel.TorchDistComm(use_p2p=True, use_rccl=False)
+    comm = ranks.worker_comm(use_p2p=True, use_rccl=False)
     x, data, uncert = H.tutorial_data(100)
     np.random.seed(100 + comm.rank)
     out = mc3_amd.sample(
@@ -43,8 +41,7 @@ def main():
         print(f'rank {comm.rank}: recovered', flush=True)
     np.savez(f'{out_path}.rank{comm.rank}.npz',
              **{k: v for k, v in out.items() if k not in ('pnames', 'texnames')})
-    dist.barrier()
-    dist.destroy_process_group()
+    ranks.finalize(comm)
 
 
 if __name__ == '__main__':

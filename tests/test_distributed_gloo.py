@@ -1,8 +1,8 @@
-"""The N>1 path on CPU: two ranks (gloo) each own half of the chains, exchange
-the new Z rows after every refresh, and must reproduce the single-rank run bit
-for bit (the draws are keyed by global chain id)."""
+"""The N>1 path on CPU: two ranks each own half of the chains, exchange the new Z rows
+after every refresh, and must reproduce the single-rank run bit for bit (the draws are
+keyed by global chain id).  Run on both control planes: mc3_amd.parallel.SocketComm
+(plain TCP, no torch) and the TorchDistComm adapter over a gloo process group."""
 import os
-import socket
 import subprocess
 import sys
 
@@ -13,29 +13,18 @@ import mc3_amd
 from mc3_amd import utils as mu
 from oracle_engine import OracleChains
 import helpers as H
+from ranks import launch_ranks
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # the first `import torch` in a fresh container can take minutes in every worker
 pytestmark = pytest.mark.timeout(1200)
 
 
-def free_port():
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        return s.getsockname()[1]
-
-
-@pytest.mark.parametrize('sampler,thinning', [('demc', 1), ('snooker', 2)])
-def test_two_ranks_reproduce_single_rank(tmp_path, sampler, thinning):
+@pytest.mark.parametrize('sampler,thinning,launcher', [
+    ('demc', 1, 'socket'), ('snooker', 2, 'socket'), ('demc', 1, 'torchrun')])
+def test_two_ranks_reproduce_single_rank(tmp_path, sampler, thinning, launcher):
     out_path = str(tmp_path / 'shard')
-    env = dict(os.environ, OMP_NUM_THREADS='1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-           '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-           '--master-port', str(free_port()),
-           os.path.join(ROOT, 'tests', 'dist_worker.py'), out_path, sampler,
-           str(thinning)]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1000)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    launch_ranks(2, 'dist_worker.py', out_path, sampler, thinning, launcher=launcher)
 
     x, data, uncert = H.tutorial_data(100)
     np.random.seed(100)
@@ -68,30 +57,18 @@ def test_communicator_mode_selection_single_process():
 def test_peer_to_peer_falls_back_together():
     """If any rank cannot export its replica, every rank drops the peer-to-peer
     mode (no rank may end up alone in it)."""
-    env = dict(os.environ, OMP_NUM_THREADS='1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-           '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-           '--master-port', str(free_port()),
-           os.path.join(ROOT, 'tests', 'p2p_fallback_worker.py')]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1000)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    assert res.stdout.count('fallback ok') == 2
+    assert launch_ranks(2, 'p2p_fallback_worker.py').count('fallback ok') == 2
 
 
-def test_peer_to_peer_recovery_logic_on_cpu(tmp_path):
+@pytest.mark.parametrize('launcher', ['socket', 'torchrun'])
+def test_peer_to_peer_recovery_logic_on_cpu(tmp_path, launcher):
     """One rank reports an aborted peer-to-peer launch: the ranks vote at the next report
     point, BOTH roll back to their checkpoints and redo the lost refreshes through the
     host-staged exchange; the run ends identical to the undisturbed single-rank run
-    (TorchDistComm.quiesce / recover; the GPU form is tests/test_gpu_p2p.py)."""
+    (Communicator.quiesce / recover; the GPU form is tests/test_gpu_p2p.py)."""
     out_path = str(tmp_path / 'recover')
-    env = dict(os.environ, OMP_NUM_THREADS='1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-           '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-           '--master-port', str(free_port()),
-           os.path.join(ROOT, 'tests', 'p2p_recover_worker.py'), out_path]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1000)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    assert res.stdout.count('recovered') == 2
+    assert launch_ranks(2, 'p2p_recover_worker.py', out_path, launcher=launcher) \
+        .count('recovered') == 2
     x, data, uncert = H.tutorial_data(100)
     single = mc3_amd.sample(
         data=data, uncert=uncert, func=H.quad, params=np.array([10.0, -2.0, 0.1]),
@@ -104,3 +81,58 @@ def test_peer_to_peer_recovery_logic_on_cpu(tmp_path):
         for key in ('posterior', 'zchain', 'log_post', 'chisq', 'bestp',
                     'acceptance_rate', 'best_log_post', 'medianp', 'stdp'):
             np.testing.assert_array_equal(got[key], single[key], err_msg=key)
+
+
+def _socket_ranks(n, env_of_rank, body):
+    """n python processes running `body` (source text) with a SocketComm named comm."""
+    code = ('import os, sys\nsys.path.insert(0, %r)\nfrom mc3_amd import parallel\n'
+            'comm = parallel.SocketComm.from_env(timeout=60)\n' % ROOT) + body + '\ncomm.close()\n'
+    procs = [subprocess.Popen([sys.executable, '-c', code], env=env_of_rank(r),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(n)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so + se
+    return [so for so, _ in outs]
+
+
+BODY = (
+    'box = comm.all_gather({"r": comm.rank, "blob": bytes(1000*comm.rank)})\n'
+    'assert [b["r"] for b in box] == list(range(comm.size))\n'
+    'assert [len(b["blob"]) for b in box] == [1000*r for r in range(comm.size)]\n'
+    'assert comm.broadcast(("from", comm.rank)) == ("from", 0)\n'
+    'comm.barrier()\n'
+    'assert comm._all_ok(True) and not comm._all_ok(comm.rank != 1)\n'
+    'import numpy as np\n'
+    'parts = comm.all_gather(np.full((3, 2), float(comm.rank)))\n'
+    'assert all(np.all(p == r) for r, p in enumerate(parts))\n'
+    'print("rank", comm.rank, "of", comm.size, "ok")\n')
+
+
+def test_socket_comm_primitives_direct_port():
+    """SocketComm over a known port (MC3HIP_RDV_PORT: what bench.py --gpus N and
+    tests/ranks.py hand to their children): all-gather, broadcast, barrier, votes."""
+    from mc3_amd import parallel
+    port = parallel.free_port()
+    outs = _socket_ranks(3, lambda r: parallel.rank_env(r, 3, port), BODY)
+    assert sorted(o.strip() for o in outs) == [f'rank {r} of 3 ok' for r in range(3)]
+
+
+def test_socket_comm_rendezvous_through_a_port_file(tmp_path):
+    """Under a launcher that keeps MASTER_PORT for itself (torch.distributed.run) rank 0
+    listens on an ephemeral port and publishes it in a file; a stale file of a dead run
+    with the same name is ignored (the token does not match / nobody listens)."""
+    from mc3_amd import parallel
+    stale = parallel._port_file('127.0.0.1', '29999', 'run7')
+
+    def env(r):
+        e = dict(os.environ, RANK=str(r), WORLD_SIZE='4', MASTER_ADDR='127.0.0.1',
+                 MASTER_PORT='29999', TORCHELASTIC_RUN_ID='run7', MC3HIP_RDV_DIR=str(tmp_path))
+        e.pop('MC3HIP_RDV_PORT', None)
+        return e
+    stale = os.path.join(str(tmp_path), os.path.basename(stale))
+    with open(stale, 'w') as f:
+        f.write('1 deadbeef\n')           # (port 1: nobody listens there)
+    outs = _socket_ranks(4, env, BODY)
+    assert sorted(o.strip() for o in outs) == [f'rank {r} of 4 ok' for r in range(4)]
+    assert not os.path.exists(stale), 'rank 0 removes its port file when it closes'

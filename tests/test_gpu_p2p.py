@@ -3,42 +3,28 @@ each rank owns half of the chains and a full Z replica, opens the other's replic
 through HIP IPC, publishes its rows into both and polls its own.  Must reproduce
 the single-rank run bit for bit (draws are keyed by global chain id)."""
 import os
-import socket
-import subprocess
-import sys
 
 import numpy as np
 import pytest
 
 import helpers as H
+from ranks import launch_ranks
 
-# the first `import torch` on a fresh box can take minutes in every worker process
+# (the torchrun case: the first `import torch` on a fresh box can take minutes per worker)
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1200)]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def free_port():
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        return s.getsockname()[1]
-
-
-@pytest.mark.parametrize('nproc,sampler,thinning,niter', [
-    (2, 'demc', 1, 400), (2, 'snooker', 2, 200), (4, 'demc', 1, 300), (4, 'snooker', 1, 300),
-    (8, 'demc', 1, 200)])
-def test_processes_peer_to_peer(tmp_path, nproc, sampler, thinning, niter):
+@pytest.mark.parametrize('nproc,sampler,thinning,niter,launcher', [
+    (2, 'demc', 1, 400, 'socket'), (2, 'snooker', 2, 200, 'socket'),
+    (4, 'demc', 1, 300, 'socket'), (4, 'snooker', 1, 300, 'socket'),
+    (8, 'demc', 1, 200, 'socket'), (2, 'demc', 1, 300, 'torchrun')])
+def test_processes_peer_to_peer(tmp_path, nproc, sampler, thinning, niter, launcher):
     import mc3_amd
     from mc3_amd import utils as mu
     from oracle_engine import OracleChains
     out_path = str(tmp_path / 'p2p')
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-           f'--nproc-per-node={nproc}', '--master-addr', '127.0.0.1',
-           '--master-port', str(free_port()),
-           os.path.join(ROOT, 'tests', 'p2p_worker.py'), out_path, sampler,
-           str(thinning), str(niter)]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1000)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-6000:]
+    launch_ranks(nproc, 'p2p_worker.py', out_path, sampler, thinning, niter, launcher=launcher)
 
     x, data, uncert = H.tutorial_data(100)
     np.random.seed(100)
@@ -58,14 +44,7 @@ def test_processes_peer_to_peer(tmp_path, nproc, sampler, thinning, niter):
 
 
 def launch(nproc, script, *args, env=None, timeout=1000):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **(env or {}))
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-           f'--nproc-per-node={nproc}', '--master-addr', '127.0.0.1',
-           '--master-port', str(free_port()), os.path.join(ROOT, 'tests', script)]
-    res = subprocess.run(cmd + [str(a) for a in args], env=env, capture_output=True,
-                         text=True, timeout=timeout)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-6000:]
-    return res
+    return launch_ranks(nproc, script, *args, env=env, timeout=timeout)
 
 
 def test_config_c3_eight_ranks_of_256_chains(tmp_path):
@@ -152,7 +131,7 @@ def test_peer_to_peer_abort_is_recovered_by_all_ranks(tmp_path, sampler):
     niter = 200
     out_path = str(tmp_path / 'abort')
     res = launch(2, 'p2p_worker.py', out_path, sampler, 1, niter, 'abort=77')
-    assert 'recovered' in res.stdout, res.stdout[-2000:]
+    assert 'recovered' in res, res[-2000:]
     x, data, uncert = H.tutorial_data(100)
     np.random.seed(100)
     single = mc3_amd.sample(
@@ -187,7 +166,7 @@ def test_resident_tiled_plan_abort_is_recovered_by_all_ranks(tmp_path):
     orc.run(nthreads=8)
     res = launch(2, 'c5_worker.py', out_path, nref, per_rank, ndata, nmodel, 'demc',
                  'abort=13', env={'MC3HIP_RESIDENT_MAXCOL': '1'})
-    assert 'recovered' in res.stdout, res.stdout[-2000:]
+    assert 'recovered' in res, res[-2000:]
     for rank in range(2):
         got = np.load(f'{out_path}.rank{rank}.npz')
         s = slice(per_rank*rank, per_rank*(rank + 1))
