@@ -117,6 +117,11 @@ typedef struct mc3hip_plan {
                                proposals and per-tile sums are handed over inside the
                                launch (design matrices of 5..11 columns, polynomials of
                                2..4 coefficients)                                          */
+    int32_t chains_per_workgroup; /* persistent launch: chains one workgroup advances per
+                               refresh, one after another (> 1 when the ensemble has more
+                               chains than workgroups can be co-resident; the reference's
+                               workers loop over their chains the same way, chain.py:163,
+                               190-191); results do not depend on it                          */
 } mc3hip_plan;
 
 /* Replaces Chain.__init__ + the shared-memory allocation of mcmc()

@@ -55,7 +55,8 @@ class Plan(ctypes.Structure):
                 ('graph_nodes', ctypes.c_int32),
                 ('persistent', ctypes.c_int32), ('fast', ctypes.c_int32),
                 ('comm_graph', ctypes.c_int32), ('recoveries', ctypes.c_int32),
-                ('tile_tree', ctypes.c_int32), ('resident', ctypes.c_int32)]
+                ('tile_tree', ctypes.c_int32), ('resident', ctypes.c_int32),
+                ('chains_per_workgroup', ctypes.c_int32)]
 
 
 class Mc3HipError(RuntimeError):

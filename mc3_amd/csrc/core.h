@@ -92,6 +92,10 @@ struct DevProblem {
     // refresh a graph node produced (fixed addresses, so the captured all-gather can be
     // replayed); nullptr = off
     double *xring;
+    // several chains per workgroup (run_chain MC): chains a workgroup advances per refresh
+    // (0 = one workgroup per chain) and where their waiting state starts in dynamic LDS (in
+    // doubles); set per launch by the host
+    int32_t mc_chains, mc_off;
 };
 
 constexpr int PH_FUSED = 0, PH_PROPOSE = 1, PH_FINISH = 2, PH_RESIDENT = 3;

@@ -41,6 +41,10 @@ struct mc3hip_ctx {
     int persist_refs = 0;           // refreshes per persistent launch, 0 = off
     bool persist_checked = false;
     bool fast = false;              // lean persistent instance selected
+    int mc_chains = 0;              // chains a workgroup of the persistent kernel advances per
+                                    // refresh (0: one workgroup per chain), its grid and the
+    int mc_grid = 0;                // dynamic LDS with the chains' waiting state appended
+    size_t mc_smem = 0;
     double *stage = nullptr;        // dense staging for Z row transfers (grow-only)
     size_t stage_doubles = 0;
     // checkpoint of the per-chain state taken before the first persistent launch that
@@ -134,7 +138,7 @@ inline bool fast_eligible(const mc3hip_ctx *c)
 // the headline shape (DEMC, thinning 1) has a loop of its own: lean_demc_kernel
 inline bool lean_demc_eligible(const mc3hip_ctx *c)
 {
-    return c->fast && c->P.sampler == MC3HIP_DEMC && c->P.thinning == 1 &&
+    return c->fast && c->mc_chains == 0 && c->P.sampler == MC3HIP_DEMC && c->P.thinning == 1 &&
            c->P.nparams == c->mt && c->P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
 }
 

@@ -31,12 +31,15 @@ void launch_step_t(mc3hip_ctx *c, int roff)
 template <int MT>
 void persist_instance_t(const mc3hip_ctx *c, bool p2p, chain_kernel_fn *out)
 {
+    const bool mc = c->mc_chains > 0 && !p2p;          // several chains per workgroup
     if (c->P.npad > VLANES)
         *out = p2p ? persist_kernel<WPC, MT, false, true, true>
-                   : persist_kernel<WPC, MT, false, true>;
+                   : mc ? persist_kernel<WPC, MT, false, true, false, true>
+                        : persist_kernel<WPC, MT, false, true>;
     else
         *out = p2p ? persist_kernel<WPC, MT, false, false, true>
-                   : persist_kernel<WPC, MT, false, false>;
+                   : mc ? persist_kernel<WPC, MT, false, false, false, true>
+                        : persist_kernel<WPC, MT, false, false>;
 }
 
 template <int MT>

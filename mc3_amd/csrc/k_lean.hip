@@ -8,9 +8,23 @@ namespace mc3hip {
 namespace host {
 namespace {
 
+// the same choices with several chains per wave (c->mc_chains > 0; one GPU)
+template <int MT, int SMP>
+chain_kernel_fn fast_instance_mc(const mc3hip_ctx *c)
+{
+    if (c->P.npad > VLANES)
+        return persist_fast_kernel<MT, SMP, false, 1, false, true, true>;
+    if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)
+        return persist_fast_kernel<MT, SMP, false, 1, true, false, true>;
+    return c->P.thinning == 1 ? persist_fast_kernel<MT, SMP, false, 1, false, false, true>
+                              : persist_fast_kernel<MT, SMP, false, 0, false, false, true>;
+}
+
 template <int MT, int SMP>
 chain_kernel_fn fast_instance_tt(const mc3hip_ctx *c, bool p2p)
 {
+    if (c->mc_chains > 0 && !p2p)
+        return fast_instance_mc<MT, SMP>(c);
     if (p2p)
         return c->P.thinning == 1 ? persist_fast_kernel<MT, SMP, true, 1>
                                   : persist_fast_kernel<MT, SMP, true, 0>;

@@ -33,7 +33,10 @@ void launch_step_t(mc3hip_ctx *c, int roff)
 template <int MT>
 void persist_instance_t(const mc3hip_ctx *c, bool p2p, chain_kernel_fn *out)
 {
-    *out = p2p ? persist_kernel<WW, MT, true, LARGE, true> : persist_kernel<WW, MT, true, LARGE>;
+    const bool mc = c->mc_chains > 0 && !p2p;          // several chains per workgroup
+    *out = p2p ? persist_kernel<WW, MT, true, LARGE, true>
+               : mc ? persist_kernel<WW, MT, true, LARGE, false, true>
+                    : persist_kernel<WW, MT, true, LARGE>;
 }
 
 template <int MT>

@@ -13,10 +13,12 @@ __global__ __launch_bounds__(64 * WPC) void step_kernel(const DevProblem P, cons
 
 // many Z refreshes per launch with in-launch hand-off of the new rows; every
 // workgroup of the grid must be resident (the host checks before choosing this path)
-template <int WPC, int MT, bool WL, bool MULTI, bool P2P = false>
+// (MC: more chains than co-resident workgroups -- a workgroup advances several, run_chain MC)
+template <int WPC, int MT, bool WL, bool MULTI, bool P2P = false, bool MC = false>
 __global__ __launch_bounds__(64 * WPC) void persist_kernel(const DevProblem P, const int nref)
 {
-    run_chain<WPC, MT, WL, MULTI, true, -1, false, PH_FUSED, P2P>(P, P.ctl[0], nref);
+    run_chain<WPC, MT, WL, MULTI, true, -1, false, PH_FUSED, P2P, 0, false, NoHook, MC>(
+        P, P.ctl[0], nref);
 }
 
 // chisq for arbitrary parameter vectors (Chain.eval_model(ret='chisq'))

@@ -7,10 +7,13 @@ namespace mc3hip {
 // the lean instance (see run_chain): one wave per chain, MT free polynomial
 // coefficients, Gaussian chisq, ndata <= 1024, no priors/shared/fixed/epsilon/trace
 // (MULTI: more than 1024 points; the first tile stays in registers, the rest is streamed)
-template <int MT, int SMP, bool P2P = false, int TH = 0, bool FX = false, bool MULTI = false>
+// (MC: more chains than co-resident workgroups -- a wave advances several, run_chain MC)
+template <int MT, int SMP, bool P2P = false, int TH = 0, bool FX = false, bool MULTI = false,
+          bool MC = false>
 __global__ __launch_bounds__(64) void persist_fast_kernel(const DevProblem P, const int nref)
 {
-    run_chain<1, MT, false, MULTI, true, SMP, true, PH_FUSED, P2P, TH, FX>(P, P.ctl[0], nref);
+    run_chain<1, MT, false, MULTI, true, SMP, true, PH_FUSED, P2P, TH, FX, NoHook, MC>(
+        P, P.ctl[0], nref);
 }
 
 // ---------------------------------------------------------------------------------

@@ -207,10 +207,13 @@ size_t fast_smem(const mc3hip_ctx *c)
     return (c->P.sampler != MC3HIP_MRW && lean_demc_eligible(c)) ? 0 : c->smem;
 }
 
+// (several chains per workgroup, run_chain MC: a smaller grid, the chains' waiting state in
+// dynamic LDS behind the kernel's own areas; decide_persist sets the three numbers)
 void launch_fast(mc3hip_ctx *c, int nref)
 {
-    hipLaunchKernelGGL(fast_instance(c, c->p2p_ranks > 1), dim3(c->P.nlocal), dim3(64),
-                       fast_smem(c), c->stream, c->P, nref);
+    const bool mc = c->mc_chains > 0;
+    hipLaunchKernelGGL(fast_instance(c, c->p2p_ranks > 1), dim3(mc ? c->mc_grid : c->P.nlocal),
+                       dim3(64), mc ? c->mc_smem : fast_smem(c), c->stream, c->P, nref);
 }
 
 int blocks_per_cu(const void *kernel, int threads, size_t smem)
@@ -303,8 +306,9 @@ hipError_t set_smem_attr_wavelet(mc3hip_ctx *c)
 
 void launch_persist(mc3hip_ctx *c, int nref)
 {
-    hipLaunchKernelGGL(persist_instance(c, c->p2p_ranks > 1), dim3(c->P.nlocal),
-                       dim3(64 * c->wpc), c->smem, c->stream, c->P, nref);
+    const bool mc = c->mc_chains > 0;
+    hipLaunchKernelGGL(persist_instance(c, c->p2p_ranks > 1), dim3(mc ? c->mc_grid : c->P.nlocal),
+                       dim3(64 * c->wpc), mc ? c->mc_smem : c->smem, c->stream, c->P, nref);
 }
 
 // workgroups of the general persistent kernel that fit on one CU (0 on error)
@@ -337,12 +341,16 @@ void launch_step(mc3hip_ctx *c, int roff)
 // The persistent kernel spins on rows other workgroups publish, so EVERY workgroup
 // of its grid must be resident at once.  Residency comes from the grid size alone:
 // use it only when nlocal fits the occupancy the runtime reports.
+constexpr int MC_MAX_TURNS = 64;
+
 int decide_persist(mc3hip_ctx *c)
 {
     if (c->persist_checked)
         return c->persist_refs;
     c->persist_checked = true;
     c->persist_refs = 0;
+    c->mc_chains = 0;
+    c->P.mc_chains = 0;
     if ((c->flags & MC3HIP_FLAG_NO_PERSIST) || getenv("MC3HIP_NO_PERSIST"))
         return 0;
     c->resident = false;
@@ -405,9 +413,54 @@ int decide_persist(mc3hip_ctx *c)
     // a bounded wait and the run is redone with per-refresh launches (settle()).
     // MC3HIP_PERSIST_MARGIN=1 keeps one workgroup per CU of slack instead.
     const int per_cu = (nb > 1 && getenv("MC3HIP_PERSIST_MARGIN")) ? nb - 1 : nb;
-    const long long capacity = (long long)per_cu * prop.multiProcessorCount;
-    if (nb < 1 || c->P.nlocal > capacity)
+    long long capacity = (long long)per_cu * prop.multiProcessorCount;
+    // (tests: pretend that fewer workgroups fit, so that small ensembles take the
+    // several-chains-per-workgroup path)
+    long long cap_limit = 1LL << 40;
+    if (const char *e = getenv("MC3HIP_PERSIST_CAPACITY"))
+        if (atoll(e) > 0)
+            cap_limit = atoll(e);
+    capacity = capacity < cap_limit ? capacity : cap_limit;
+    if (nb < 1)
         return 0;
+    if (c->P.nlocal > capacity) {
+        // More chains than workgroups can be co-resident: a workgroup advances several per
+        // refresh (run_chain MC), as the reference's workers do with their ncpp chains
+        // (mc3/chain.py:163,190-191).  The fewest turns whose grid fits: the waiting state of
+        // a chain costs zs + 4 doubles of LDS, which can lower the occupancy, so the query is
+        // repeated with the instance and the LDS size that would run.  One GPU only.
+        if ((c->flags & MC3HIP_FLAG_P2P) || c->p2p_ranks > 1 || getenv("MC3HIP_NO_MULTICHAIN"))
+            return 0;
+        const size_t base = c->smem;        // (the hand-laid-out DEMC loop has no MC form)
+        bool found = false;
+        for (int turns = 2; turns <= MC_MAX_TURNS && !found; ++turns) {
+            c->mc_chains = turns;                       // (selects the MC instance)
+            const size_t smem = base + (size_t)turns * (c->P.zs + 4) * sizeof(double);
+            if (smem > 160 * 1024)
+                break;
+            const void *f = reinterpret_cast<const void *>(
+                c->fast ? fast_instance(c, false) : persist_instance(c, false));
+            if (smem > 64 * 1024)
+                (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            int nbm = blocks_per_cu(f, 64 * c->wpc, smem);
+            if (nbm > 1 && getenv("MC3HIP_PERSIST_MARGIN"))
+                nbm -= 1;
+            const long long grid = ((long long)c->P.nlocal + turns - 1) / turns;
+            long long room = (long long)nbm * prop.multiProcessorCount;
+            room = room < cap_limit ? room : cap_limit;
+            if (nbm >= 1 && grid <= room) {
+                c->mc_grid = (int)grid;
+                c->mc_smem = smem;
+                c->P.mc_chains = turns;
+                c->P.mc_off = (int32_t)(base / sizeof(double));
+                found = true;
+            }
+        }
+        if (!found) {
+            c->mc_chains = 0;
+            return 0;
+        }
+    }
     c->persist_refs = 16384;
     if (const char *e = getenv("MC3HIP_PERSIST_REFS"))
         c->persist_refs = atoi(e) > 0 ? atoi(e) : 0;
@@ -937,6 +990,7 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
     plan->resident = (plan->persistent > 0 && c->resident) ? 1 : 0;
     plan->comm_graph = c->cgraph_exec ? c->comm_graph_nodes : 0;
     plan->recoveries = c->recoveries;
+    plan->chains_per_workgroup = (plan->persistent > 0 && c->mc_chains > 0) ? c->mc_chains : 1;
     return MC3HIP_OK;
 }
 

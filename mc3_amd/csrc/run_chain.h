@@ -34,8 +34,20 @@ struct NoHook {};
 // PH_RESIDENT (resident tiled plan, see ResidentTile): this WAVE owns chain `own_chain` of a
 // workgroup whose waves all take part in the tile phase of every iteration; the data sums
 // come back through `hook`; the wave leaves the loop only when the whole workgroup does.
+// MC (persistent only): the ensemble has more chains than workgroups can be co-resident, so a
+// workgroup owns SEVERAL chains -- local chains b, b + G, b + 2 G, ... of a grid of G
+// workgroups, P.mc_chains at most -- and advances them one after another inside every
+// refresh (the reference's workers do the same with their ncpp chains, mc3/chain.py:163,
+// 190-191).  What a chain carries from one refresh to the next (its state, chisq, best
+// chisq, accept count) waits in LDS between its turns; the data tile, the bounds and every
+// other chain-invariant stay in registers.  The hand-off protocol is unchanged -- a chain
+// waits only for rows of the PREVIOUS refresh, and every workgroup finishes refresh R - 1
+// for all its chains before it starts R -- so co-residency of the G workgroups is all that
+// is needed; the draws that are computed one iteration ahead are those of the NEXT TURN
+// (next chain of this workgroup, or its first chain in the next refresh).
 template <int WPC, int MT, bool WL, bool MULTI, bool PERSIST, int SMP = -1, bool FAST = false,
-          int PHASE = PH_FUSED, bool P2P = false, int TH = 0, bool FX = false, class H = NoHook>
+          int PHASE = PH_FUSED, bool P2P = false, int TH = 0, bool FX = false, class H = NoHook,
+          bool MC = false>
 __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R0,
                                           const int nref, const int jb = 0, int je = -1,
                                           H *hook = nullptr, const int own_chain = 0,
@@ -47,14 +59,16 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                   "the resident tiled plan runs the general one-wave persistent chain");
     static_assert(!FAST || (WPC == 1 && !WL && SMP >= 0 && MT >= 1 && MT <= 8),
                   "FAST needs one wave, Gaussian chisq, a compile-time sampler and degree");
+    static_assert(!MC || (PERSIST && PHASE == PH_FUSED && !P2P),
+                  "several chains per workgroup: the one-GPU persistent kernels");
     const int sampler = (SMP >= 0) ? SMP : P.sampler;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const SmemLayout L = carve(PHASE == PH_RESIDENT ? own_smem : smem, P, 64 * WPC);
     MC3_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const bool wave0 = (WPC == 1) ? true : (tid < 64);
-    const int lc = (PHASE == PH_RESIDENT) ? own_chain : blockIdx.x;   // local chain
-    const int c = P.chain0 + lc;               // global chain id
+    int lc = (PHASE == PH_RESIDENT) ? own_chain : blockIdx.x;   // local chain (MC: of the turn)
+    int c = P.chain0 + lc;                     // global chain id
     const int nf = P.nfree;
     const int zs = P.zs;                       // row stride of Z / snap0 (padded lines)
     const bool mine = wave0 && lane < nf;      // lane k of wave 0 owns free parameter k
@@ -83,7 +97,29 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
         xk = (jb == 0) ? snap_first[(size_t)c * zs + lane] : P.X[(size_t)lc * nf + lane];
     double cur = P.chisq[lc];
     double best = P.best_chisq[lc];
-    const long long nacc0 = P.numaccept[lc];
+    const long long nacc0 = MC ? 0 : P.numaccept[lc];
+    // MC: what the chains of this workgroup carry between their turns, in LDS behind the
+    // areas of carve(): slot q = [state (zs doubles) | chisq | best chisq | accept count]
+    const int mc_turns = MC ? P.mc_chains : 1;
+    const int mc_stride = zs + 4;
+    double *const mc_state = MC ? smem + P.mc_off : nullptr;
+    if constexpr (MC) {
+        if (wave0) {
+            for (int q = 0; q < mc_turns; ++q) {
+                const int l = (int)blockIdx.x + q * (int)gridDim.x;
+                if (l >= P.nlocal)
+                    break;
+                double *slot = mc_state + q * mc_stride;
+                if (mine)
+                    slot[lane] = snap_first[(size_t)(P.chain0 + l) * zs + lane];
+                if (lane == 0) {
+                    slot[zs] = P.chisq[l];
+                    slot[zs + 1] = P.best_chisq[l];
+                    slot[zs + 2] = mc3_from_bits((unsigned long long)P.numaccept[l]);
+                }
+            }
+        }
+    }
     const int jfree = mine ? P.ifree[lane] : 0;
     const double pmin_k = mine ? P.fmin[lane] : 0.0;
     const double pmax_k = mine ? P.fmax[lane] : 0.0;
@@ -159,6 +195,29 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     (void)ta8; (void)ta9; (void)ta10; (void)ta11; (void)ta12; (void)ta13;
     bool give_up = false;                       // resident plan: test hook fired
     (void)give_up;
+    // the iteration that follows (iter, this chain) in this workgroup's order, and its chain;
+    // new_refresh: it belongs to the next refresh (whose history holds this refresh's rows)
+    auto draws_ahead = [&](uint64_t iter, bool last_of_refresh, int q, bool &new_refresh) {
+        uint64_t it2 = iter + 1;
+        int c2 = c;
+        new_refresh = last_of_refresh;
+        if constexpr (MC) {
+            if (last_of_refresh) {
+                const int l2 = lc + (int)gridDim.x;
+                if (q + 1 < mc_turns && l2 < P.nlocal) {        // next chain, same refresh
+                    it2 = iter + 1 - (uint64_t)((TH == 1) ? 1 : P.thinning);
+                    c2 = P.chain0 + l2;
+                    new_refresh = false;
+                } else {                                        // first chain, next refresh
+                    c2 = P.chain0 + (int)blockIdx.x;
+                }
+            }
+        }
+        (void)q;
+        if (SNOOKER_AHEAD && !MC && sampler == MC3HIP_SNOOKER)
+            return get_draws(batch, P, (long long)it2, c2);
+        return make_draws(P, it2, c2, sampler);
+    };
     for (long long R = R0; R < R0 + nref && alive; ++R) {
     if constexpr (PERSIST) {
         if (P.test_abort >= 0 && R == P.test_abort && lc == 0) {     // test hook
@@ -175,6 +234,20 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     const long long zsize = P.M0 + R * P.nchains;
     const int jfirst = (TH == 1) ? 0 : jb;
     const int jlast = (TH == 1) ? 1 : je;
+    for (int q = 0; q < mc_turns; ++q) {        // (MC: the chains of this workgroup in turn)
+    if constexpr (MC) {
+        lc = (int)blockIdx.x + q * (int)gridDim.x;
+        if (lc >= P.nlocal)
+            break;
+        c = P.chain0 + lc;
+        if (wave0) {
+            const double *slot = mc_state + q * mc_stride;
+            xk = mine ? slot[lane] : 0.0;
+            cur = slot[zs];
+            best = slot[zs + 1];
+            nacc = (long long)mc3_bits(slot[zs + 2]);
+        }
+    }
     for (int j = jfirst; j < jlast; ++j) {
         if constexpr (WL)
             MC3_LSTAMP(5);
@@ -229,10 +302,8 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                     }
                     const double *const addr[3] = {sa[0], sa[1], sa[2]};
                     double val[3] = {sv[0], sv[1], sv[2]};
-                    if constexpr (SNOOKER_AHEAD)
-                        nxt = get_draws(batch, P, (long long)iter + 1, c);
-                    else
-                        nxt = make_draws(P, iter + 1, c, sampler);
+                    bool ahead_new_refresh;
+                    nxt = draws_ahead(iter, TH == 1 || j + 1 == jlast, q, ahead_new_refresh);
                     alive = wait_rows<3, P2P>(addr, val, ctl_rw);
                     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see lean_demc_kernel
                     z1 = val[0];
@@ -241,8 +312,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                     // the next iteration's rows: its history also holds this refresh's rows
                     // once this iteration is the last of the refresh
                     if (SNOOKER_AHEAD && alive)
-                        request_snooker(nxt, (TH == 1 || j + 1 == jlast) ? zsize + P.nchains
-                                                                         : zsize);
+                        request_snooker(nxt, ahead_new_refresh ? zsize + P.nchains : zsize);
                 } else {
                     z1 = mine ? P.Z[(size_t)iR1 * zs + lane] : 0.0;
                     z2 = mine ? P.Z[(size_t)iR2 * zs + lane] : 0.0;
@@ -266,8 +336,10 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 }
             } else if (sampler == MC3HIP_MRW) {                    // chain.py:219-220
                 jump_k = normal_k;
-                if constexpr (PERSIST)
-                    nxt = make_draws(P, iter + 1, c, sampler);
+                if constexpr (PERSIST) {
+                    bool unused;
+                    nxt = draws_ahead(iter, TH == 1 || j + 1 == jlast, q, unused);
+                }
             } else {                                                 // chain.py:221-232
                 int r1, r2;
                 demc_partners(d0.q0, P.nchains, c, r1, r2);
@@ -286,7 +358,10 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                     ta15 += tkL - tk0;
 #endif
                     __builtin_amdgcn_sched_barrier(0);
-                    nxt = make_draws(P, iter + 1, c, sampler);
+                    {
+                        bool unused;
+                        nxt = draws_ahead(iter, TH == 1 || j + 1 == jlast, q, unused);
+                    }
                     pin_scalar(nxt.d0.q0);
                     pin_scalar(nxt.d0.q1);
                     __builtin_amdgcn_sched_barrier(0);
@@ -520,9 +595,38 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
             P.zchain[row] = c;
         }
     }
+    if constexpr (MC) {
+        if (wave0) {                              // this chain waits for its next turn
+            double *slot = mc_state + q * mc_stride;
+            if (mine)
+                slot[lane] = xk;
+            if (lane == 0) {
+                slot[zs] = cur;
+                slot[zs + 1] = best;
+                slot[zs + 2] = mc3_from_bits((unsigned long long)nacc);
+            }
+        }
+    }
+    }   // turns
     MC3_TICK(tk_prevend);
     }   // refreshes
-    if (wave0) {
+    if constexpr (MC) {
+        if (wave0) {
+            for (int q = 0; q < mc_turns; ++q) {
+                const int l = (int)blockIdx.x + q * (int)gridDim.x;
+                if (l >= P.nlocal)
+                    break;
+                const double *slot = mc_state + q * mc_stride;
+                if (mine)
+                    P.X[(size_t)l * nf + lane] = slot[lane];
+                if (lane == 0) {
+                    P.chisq[l] = slot[zs];
+                    P.best_chisq[l] = slot[zs + 1];
+                    P.numaccept[l] = (long long)mc3_bits(slot[zs + 2]);
+                }
+            }
+        }
+    } else if (wave0) {
         if (mine)
             P.X[(size_t)lc * nf + lane] = xk;
         if (lane == 0) {

@@ -117,7 +117,8 @@ class DeviceChains:
                 'graph_nodes': plan.graph_nodes,
                 'persistent': plan.persistent, 'fast': plan.fast,
                 'comm_graph': plan.comm_graph, 'recoveries': plan.recoveries,
-                'tile_tree': plan.tile_tree, 'resident': plan.resident}
+                'tile_tree': plan.tile_tree, 'resident': plan.resident,
+                'chains_per_workgroup': plan.chains_per_workgroup}
 
     # -- lifetime --------------------------------------------------------------
     def close(self):

@@ -1,0 +1,176 @@
+"""More chains than workgroups can be co-resident: a workgroup of the persistent kernels
+advances SEVERAL chains per refresh (run_chain MC, mc3_amd/csrc/run_chain.h), as the
+reference's workers loop over their ncpp chains (mc3/chain.py:163,190-191).  Results must
+not depend on it: everything is compared with the oracle for exact equality, the launch must
+stay persistent (`plan.persistent > 0`, `chains_per_workgroup > 1`) and must not have been
+redone (`recoveries == 0`).
+
+Big ensembles take the path by themselves (4096 / 8192 chains x ndata 1000: twice / four
+times what fits; 512 / 1024 chains x 2^14 wavelet points: one 8-wave workgroup per CU);
+MC3HIP_PERSIST_CAPACITY (a test hook: pretend that fewer workgroups fit) sends small
+ensembles of every kernel flavour down the same path."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from test_gpu_parity import assert_same, run_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from mc3_amd import engine
+    return engine
+
+
+def check_plan(gpu, turns=None, fast=None):
+    plan = gpu.plan
+    assert plan['persistent'] > 0 and plan['recoveries'] == 0, plan
+    assert plan['chains_per_workgroup'] > 1, plan
+    if turns is not None:
+        assert plan['chains_per_workgroup'] == turns, plan
+    if fast is not None:
+        assert plan['fast'] == fast, plan
+    return plan
+
+
+@pytest.mark.parametrize('nchains,sampler,nref', [
+    (4096, 'demc', 30), (4096, 'snooker', 24), (8192, 'demc', 16), (8192, 'snooker', 12),
+    (2049, 'demc', 40), (5000, 'mrw', 20)])
+def test_big_ensembles_stay_on_the_persistent_path(eng, nchains, sampler, nref):
+    """C2-shaped (quadratic, ndata 1000) beyond the 2048 co-resident single-wave workgroups."""
+    prob = H.quad_problem(ndata=1000, nchains=nchains, nsamples=nchains*nref, sampler=sampler)
+    orc, gpu = run_pair(eng, prob, trace=False)
+    check_plan(gpu, fast=1)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
+@pytest.mark.parametrize('nchains,nref', [(512, 6), (1024, 4), (300, 8)])
+def test_wavelet_ensembles_beyond_one_workgroup_per_cu(eng, nchains, nref):
+    """C4-shaped (2^14 wavelet points, 8 waves and ~155 KB of LDS per chain: one workgroup per
+    CU) with more chains than CUs."""
+    prob = H.wavelet_problem(ndata=16384, nchains=nchains, nsamples=nchains*nref)
+    orc, gpu = run_pair(eng, prob, trace=False)
+    check_plan(gpu, fast=0)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
+def forced(monkeypatch, capacity):
+    monkeypatch.setenv('MC3HIP_PERSIST_CAPACITY', str(capacity))
+
+
+@pytest.mark.parametrize('sampler,thinning', [('demc', 1), ('demc', 3), ('snooker', 1),
+                                              ('snooker', 2), ('mrw', 1), ('mrw', 2)])
+@pytest.mark.parametrize('nchains,capacity', [(16, 5), (23, 4), (64, 1)])
+def test_lean_instances_with_several_chains_per_wave(eng, monkeypatch, sampler, thinning,
+                                                     nchains, capacity):
+    """The lean one-wave kernels (persist_fast_kernel<.., MC>): every sampler, thinning, uneven
+    splits (23 chains over 4 workgroups: 6, 6, 6, 5), ONE workgroup for the whole ensemble."""
+    forced(monkeypatch, capacity)
+    prob = H.quad_problem(ndata=300, nchains=nchains, nsamples=nchains*40*thinning,
+                          sampler=sampler, thinning=thinning)
+    orc, gpu = run_pair(eng, prob, trace=False)
+    check_plan(gpu, turns=-(-nchains//capacity), fast=1)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
+@pytest.mark.parametrize('sampler', ['demc', 'snooker', 'mrw'])
+def test_lean_fixed_coefficient_and_streamed_tiles(eng, monkeypatch, sampler):
+    forced(monkeypatch, 3)
+    prob = H.quad_problem(ndata=500, nchains=10, nsamples=10*60, sampler=sampler)
+    prob['pstep'] = np.array([1.0, 0.0, 0.1])           # FX: the linear coefficient is fixed
+    orc, gpu = run_pair(eng, prob, trace=False)
+    check_plan(gpu, turns=4, fast=1)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+    prob = H.quad_problem(ndata=3000, nchains=10, nsamples=10*40, sampler=sampler)   # MULTI
+    orc, gpu = run_pair(eng, prob, trace=False)
+    check_plan(gpu, turns=4, fast=1)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
+@pytest.mark.parametrize('sampler,thinning,eps', [('snooker', 1, 0.0), ('demc', 2, 0.01),
+                                                  ('mrw', 1, 0.0), ('snooker', 3, 0.02)])
+def test_general_kernel_with_several_chains_per_workgroup(eng, monkeypatch, sampler, thinning,
+                                                          eps):
+    """persist_kernel<.., MC>: shared and fixed parameters, priors, tight bounds, epsilon, the
+    per-step trace (chisq and flags of every iteration of every chain)."""
+    forced(monkeypatch, 3)
+    prob = H.shared_problem(nchains=8, nsamples=8*50*thinning, sampler=sampler,
+                            thinning=thinning, fepsilon=eps)
+    orc, gpu = run_pair(eng, prob, trace=True)
+    check_plan(gpu, turns=3, fast=0)
+    assert_same(orc, gpu, trace=True)
+    gpu.close()
+
+
+@pytest.mark.parametrize('wpc', ['4', '16'])
+def test_general_kernel_wide_workgroups(eng, monkeypatch, wpc):
+    forced(monkeypatch, 2)
+    monkeypatch.setenv('MC3HIP_WPC', wpc)
+    prob = H.quad_problem(ndata=6000, nchains=7, nsamples=7*30, sampler='snooker', fepsilon=0.01)
+    orc, gpu = run_pair(eng, prob, trace=True)
+    plan = check_plan(gpu, turns=4, fast=0)
+    assert plan['waves_per_chain'] == int(wpc)
+    assert_same(orc, gpu, trace=True)
+    gpu.close()
+
+
+@pytest.mark.parametrize('ndata,sampler', [(64, 'snooker'), (2048, 'demc'), (4096, 'snooker'),
+                                           (8192, 'mrw')])
+def test_wavelet_kernels_with_several_chains_per_workgroup(eng, monkeypatch, ndata, sampler):
+    forced(monkeypatch, 3)
+    prob = H.wavelet_problem(ndata=ndata, nchains=8, nsamples=8*25, sampler=sampler)
+    orc, gpu = run_pair(eng, prob, trace=True)
+    check_plan(gpu, turns=3, fast=0)
+    assert_same(orc, gpu, trace=True)
+    gpu.close()
+
+
+def test_linear_model_and_resumed_launches(eng, monkeypatch):
+    """A design-matrix model below the tiled plan; the run cut into pieces (every launch
+    reloads the waiting states from the rows of the refresh before)."""
+    forced(monkeypatch, 4)
+    prob = H.linear_problem(ndata=700, nmodel=6, nchains=12, nsamples=12*60)
+    gpu = eng.DeviceChains(**prob)
+    orc = H.make_oracle(prob, plan=gpu.plan)
+    Z0, lp0 = H.initial_population(orc)
+    orc.set_population(Z0, lp0)
+    gpu.set_population(Z0, lp0)
+    orc.run(nthreads=4)
+    for n in (1, 7, 20, 32):
+        gpu.run(n)
+    check_plan(gpu, turns=3, fast=0)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
+def test_a_launch_that_gives_up_is_redone(eng, monkeypatch):
+    """The test hook makes chain 0 give up at refresh 9: the run is redone from the checkpoint
+    with one launch per refresh, identical to the oracle."""
+    forced(monkeypatch, 3)
+    monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '9')
+    prob = H.quad_problem(ndata=300, nchains=10, nsamples=10*30, sampler='snooker')
+    orc, gpu = run_pair(eng, prob, trace=False)
+    plan = gpu.plan
+    assert plan['recoveries'] == 1 and plan['persistent'] == 0, plan
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
+def test_switch_off(eng, monkeypatch):
+    monkeypatch.setenv('MC3HIP_NO_MULTICHAIN', '1')
+    forced(monkeypatch, 3)
+    prob = H.quad_problem(ndata=300, nchains=10, nsamples=10*20, sampler='demc')
+    orc, gpu = run_pair(eng, prob, trace=False)
+    plan = gpu.plan
+    assert plan['persistent'] == 0 and plan['chains_per_workgroup'] == 1, plan
+    assert_same(orc, gpu, trace=False)
+    gpu.close()

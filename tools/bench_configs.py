@@ -43,6 +43,15 @@ CONFIGS = {
     'c3one': lambda n: (H.quad_problem(ndata=1000, nchains=2048, nsamples=2048*n,
                                        sampler='demc'), {}),
     'c4': lambda n: (H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*n), {}),
+    # beyond what is co-resident at one chain per workgroup: several chains per workgroup
+    'c3x2': lambda n: (H.quad_problem(ndata=1000, nchains=4096, nsamples=4096*n,
+                                      sampler='demc'), {}),
+    'c3x4': lambda n: (H.quad_problem(ndata=1000, nchains=8192, nsamples=8192*n,
+                                      sampler='demc'), {}),
+    'c3x2snooker': lambda n: (H.quad_problem(ndata=1000, nchains=4096, nsamples=4096*n,
+                                             sampler='snooker'), {}),
+    'c4x2': lambda n: (H.wavelet_problem(ndata=16384, nchains=512, nsamples=512*n), {}),
+    'c4x4': lambda n: (H.wavelet_problem(ndata=16384, nchains=1024, nsamples=1024*n), {}),
     'c4mrw': lambda n: (H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*n,
                                           sampler='mrw'), {}),
     'c4demc': lambda n: (H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*n,
@@ -59,7 +68,12 @@ BYTES = {'q5': 8*3*100000 + 8*3*4 + 8, 'c4mrw': 8*2*16384 + 8*5*4 + 8, 'c4demc':
 ITERS = {'c2': 20000, 'c2snooker': 20000, 'c3one': 4000, 'c4': 4000, 'c5': 30, 'c5share': 1}
 ITERS['c5'] = 300
 ITERS['q5'] = 300
-ITERS.update(c4mrw=4000, c4demc=4000, c4half=4000)
+ITERS.update(c4mrw=4000, c4demc=4000, c4half=4000, c3x2=3000, c3x4=2000, c3x2snooker=3000,
+             c4x2=2000, c4x4=1000)
+for _k in ('c3x2', 'c3x4', 'c3x2snooker'):
+    BYTES[_k] = 24104
+for _k in ('c4x2', 'c4x4'):
+    BYTES[_k] = BYTES['c4']
 
 
 def main():

@@ -10,8 +10,10 @@
 //   (a) two devices (A -> B -> A), the cross-GPU hop;
 //   (b) the same pair of kernels on ONE device (two CUs, fine-grained memory, system
 //       scope): what the peer-to-peer flavour of the kernels pays even without a link;
-//   (c) one device, ordinary memory, agent scope: the single-GPU hand-off of the
-//       persistent kernels (MI355X_MICROARCH.md "handoff-1to1").
+//   (c) one device, ordinary memory, agent scope, leader and follower two workgroups of ONE
+//       launch: the single-GPU hand-off of the persistent kernels (MI355X_MICROARCH.md
+//       "handoff-1to1").  (Two separate launches do not see each other's agent-scope
+//       stores to ordinary memory on this stack: measured, both gave up.)
 // Every wait is bounded, so a missing peer mapping ends in an error message, not a hang.
 //
 //   hipcc --offload-arch=gfx950 -O2 -o /tmp/xgmi_handoff tools/probes/xgmi_handoff.hip
@@ -74,6 +76,38 @@ __global__ __launch_bounds__(64) void pingpong(unsigned long long *mine, unsigne
         done = i;
     }
     if (threadIdx.x == 0) {
+        status[0] = done;
+        status[1] = 0;
+    }
+}
+
+// (c): leader and follower as workgroups 0 and 1 of ONE launch (consecutive workgroups go to
+// different XCDs), exactly the situation of the persistent kernels on one GPU
+__global__ __launch_bounds__(64) void pingpong_one_launch(unsigned long long *flag_a,
+                                                          unsigned long long *flag_b, int rounds,
+                                                          unsigned long long *status)
+{
+    const int first = blockIdx.x == 0;
+    unsigned long long *mine = first ? flag_a : flag_b, *theirs = first ? flag_b : flag_a;
+    int done = 0;
+    for (int i = 1; i <= rounds; ++i) {
+        if (first)
+            store_granule<false>(theirs, (unsigned long long)i);
+        unsigned spins = 0;
+        while (load_granule<false>(mine) < (unsigned long long)i) {
+            if (++spins > (1u << 22)) {
+                if (threadIdx.x == 0 && first) {
+                    status[0] = done;
+                    status[1] = 1;
+                }
+                return;
+            }
+        }
+        if (!first)
+            store_granule<false>(theirs, (unsigned long long)i);
+        done = i;
+    }
+    if (threadIdx.x == 0 && first) {
         status[0] = done;
         status[1] = 0;
     }
@@ -175,9 +209,24 @@ int main(int argc, char **argv)
     }
     {
         Side a = make_side(da, false), b = make_side(da, false);
-        run<false>(a, b, 2000);
-        printf(", \"one_gpu_agent_scope\": {\"device\": %d, \"us_per_hop\": %.3f}", da,
-               run<false>(a, b, rounds));
+        auto once = [&](int n) {
+            CHECK(hipSetDevice(da));
+            CHECK(hipMemset(a.flag, 0, 8));
+            CHECK(hipMemset(b.flag, 0, 8));
+            CHECK(hipDeviceSynchronize());
+            const auto t0 = std::chrono::steady_clock::now();
+            hipLaunchKernelGGL(pingpong_one_launch, dim3(2), dim3(64), 0, a.stream, a.flag, b.flag,
+                               n, a.status);
+            CHECK(hipStreamSynchronize(a.stream));
+            const double us = std::chrono::duration<double, std::micro>(
+                                  std::chrono::steady_clock::now() - t0).count();
+            unsigned long long st[2] = {0, 0};
+            CHECK(hipMemcpy(st, a.status, sizeof st, hipMemcpyDeviceToHost));
+            return (st[1] != 0 || (int)st[0] != n) ? -1.0 : us / (2.0 * n);
+        };
+        once(2000);
+        printf(", \"one_gpu_agent_scope_one_launch\": {\"device\": %d, \"us_per_hop\": %.3f}", da,
+               once(rounds));
     }
     printf("}\n");
     return 0;
