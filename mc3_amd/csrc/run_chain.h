@@ -220,7 +220,8 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     };
     for (long long R = R0; R < R0 + nref && alive; ++R) {
     if constexpr (PERSIST) {
-        if (P.test_abort >= 0 && R == P.test_abort && lc == 0) {     // test hook
+        // (MC: lc is the chain of the last turn here; chain 0 belongs to workgroup 0)
+        if (P.test_abort >= 0 && R == P.test_abort && (MC ? blockIdx.x == 0 : lc == 0)) {     // test hook
             __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);             // (all lanes, same word)
             if constexpr (PHASE == PH_RESIDENT)
