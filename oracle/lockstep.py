@@ -203,6 +203,21 @@ class LockstepRun:
             ctypes.byref(failed))
         return Z0, lp0, int(filled.value), int(failed.value)
 
+    def init_population_tape(self, tape):
+        """The same acceptance rule (one C function, init_population_core) fed a tape of trial
+        vectors [ntrial, nfree] -- the reference's own np.random draws: (Z0, log_post0,
+        filled, failed, trials consumed)."""
+        tape = _f(np.atleast_2d(tape))
+        Z0 = np.zeros((self.M0, self.nfree))
+        lp0 = np.zeros(self.M0)
+        filled, failed, used = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        self.L.ls_init_population_tape.restype = ctypes.c_int
+        self.L.ls_init_population_tape(
+            ctypes.byref(self.P), tape.ctypes.data_as(_dp), ctypes.c_int64(len(tape)),
+            Z0.ctypes.data_as(_dp), lp0.ctypes.data_as(_dp), ctypes.byref(filled),
+            ctypes.byref(failed), ctypes.byref(used))
+        return Z0, lp0, int(filled.value), int(failed.value), int(used.value)
+
     def eval_chisq(self, params):
         params = _f(np.atleast_2d(params))
         out = np.empty(len(params))

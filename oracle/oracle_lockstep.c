@@ -820,8 +820,58 @@ int ls_run_tape(const ls_problem *P, ls_state *St, const double *tape, const int
  * boundaries -- tested on the full vector BEFORE the shared parameters are refreshed
  * (:249-255) -- and chisq is finite; ends with M0 rows or after 100 M0 failures.
  * Z0 [M0][nfree], lp0 [M0] (zero beyond *filled). */
-int ls_init_population(const ls_problem *P, int kickoff, uint64_t seed, double *Z0,
-                       double *lp0, int64_t *filled_out, int64_t *failed_out)
+/* Where the trial vectors of the kick-off come from: Philox (what the GPU draws) or a tape of
+ * the reference's own np.random trial vectors (tests/golden/make_golden.py kickoff_case).
+ * ONE statement of the acceptance rule, init_population_core, serves both -- the kick-off's
+ * counterpart of chain_step() and its draw source. */
+typedef struct {
+    const double *tape;     /* [ntape][nfree] recorded trial vectors, or NULL: Philox */
+    int64_t ntape;
+    int kickoff;            /* Philox: 0 normal, 1 uniform */
+    uint64_t seed;
+} kick_source;
+
+/* trial t into trial[nfree]; 0 when the tape has run out */
+static int kick_trial(const ls_problem *P, const kick_source *src, uint64_t t, double *trial)
+{
+    const int nf = P->nfree;
+    if (src->tape) {
+        if ((int64_t)t >= src->ntape)
+            return 0;
+        memcpy(trial, src->tape + (size_t)t * nf, sizeof(double) * (size_t)nf);
+        return 1;
+    }
+    for (int k2 = 0; 2 * k2 < nf; k2++) {
+        uint64_t q0, q1;
+        draw2(src->seed, t, 0xffffffffu, (uint32_t)k2, &q0, &q1);
+        double a, b;
+        if (src->kickoff) {
+            a = u01(q0);
+            b = u01(q1);
+        } else {
+            const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(q0)));
+            double sn, cs;
+            mc3_det_sincos2pi(u01(q1), &sn, &cs);
+            a = rad * cs;
+            b = rad * sn;
+        }
+        for (int h = 0; h < 2 && 2 * k2 + h < nf; h++) {
+            const int k = 2 * k2 + h, j = P->ifree[k];
+            const double r = h ? b : a;
+            trial[k] = src->kickoff ? P->pmin[j] + (P->pmax[j] - P->pmin[j]) * r
+                                    : P->params[j] + P->pstep[j] * r;
+        }
+    }
+    return 1;
+}
+
+/* mcmc_driver.py:240-262: trials in order; a trial fails when any parameter of the full vector
+ * lies outside its boundaries -- tested BEFORE the shared parameters are refreshed, i.e. on
+ * the copies the last in-bounds trial left (:249-255) -- or when its chisq is not finite; ends
+ * with M0 rows or after 100 M0 failures.  *used_out: trials consumed. */
+static void init_population_core(const ls_problem *P, const kick_source *src, double *Z0,
+                                 double *lp0, int64_t *filled_out, int64_t *failed_out,
+                                 int64_t *used_out)
 {
     const int nf = P->nfree;
     ls_scratch S;
@@ -832,29 +882,11 @@ int ls_init_population(const ls_problem *P, int kickoff, uint64_t seed, double *
     memset(Z0, 0, sizeof(double) * (size_t)P->M0 * (size_t)nf);
     memset(lp0, 0, sizeof(double) * (size_t)P->M0);
     int64_t filled = 0, failed = 0;
+    uint64_t t = 0;
     const int64_t nmax = 100 * P->M0;
-    for (uint64_t t = 0; filled < P->M0 && failed < nmax; t++) {
-        for (int k2 = 0; 2 * k2 < nf; k2++) {
-            uint64_t q0, q1;
-            draw2(seed, t, 0xffffffffu, (uint32_t)k2, &q0, &q1);
-            double a, b;
-            if (kickoff) {
-                a = u01(q0);
-                b = u01(q1);
-            } else {
-                const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(q0)));
-                double sn, cs;
-                mc3_det_sincos2pi(u01(q1), &sn, &cs);
-                a = rad * cs;
-                b = rad * sn;
-            }
-            for (int h = 0; h < 2 && 2 * k2 + h < nf; h++) {
-                const int k = 2 * k2 + h, j = P->ifree[k];
-                const double r = h ? b : a;
-                trial[k] = kickoff ? P->pmin[j] + (P->pmax[j] - P->pmin[j]) * r
-                                   : P->params[j] + P->pstep[j] * r;
-            }
-        }
+    for (; filled < P->M0 && failed < nmax; t++) {
+        if (!kick_trial(P, src, t, trial))
+            break;
         for (int k = 0; k < nf; k++)
             values[P->ifree[k]] = trial[k];
         int out = 0;
@@ -878,8 +910,28 @@ int ls_init_population(const ls_problem *P, int kickoff, uint64_t seed, double *
     }
     *filled_out = filled;
     *failed_out = failed;
+    *used_out = (int64_t)t;
     free(values); free(trial);
     scratch_free(&S);
+}
+
+int ls_init_population(const ls_problem *P, int kickoff, uint64_t seed, double *Z0,
+                       double *lp0, int64_t *filled_out, int64_t *failed_out)
+{
+    const kick_source src = {NULL, 0, kickoff, seed};
+    int64_t used;
+    init_population_core(P, &src, Z0, lp0, filled_out, failed_out, &used);
+    return 0;
+}
+
+/* the same rule fed the reference's own trial vectors, tape[ntape][nfree] in the order its hub
+ * drew them */
+int ls_init_population_tape(const ls_problem *P, const double *tape, int64_t ntape, double *Z0,
+                            double *lp0, int64_t *filled_out, int64_t *failed_out,
+                            int64_t *used_out)
+{
+    const kick_source src = {tape, ntape, 0, 0};
+    init_population_core(P, &src, Z0, lp0, filled_out, failed_out, used_out);
     return 0;
 }
 

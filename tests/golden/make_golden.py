@@ -336,7 +336,7 @@ def kernel_vectors():
     print('kernel_vectors:', len(out), 'arrays')
 
 
-if __name__ == '__main__' and 'tutorial' not in sys.argv:
+if __name__ == '__main__' and 'tutorial' not in sys.argv and 'residues' not in sys.argv:
     kernel_vectors()
     chain_cases()
 
@@ -378,3 +378,136 @@ def tutorial_summary():
 
 if __name__ == '__main__' and 'tutorial' in sys.argv:
     tutorial_summary()
+
+
+# ---- round 3: the three parity residues of VERDICT round 2 -------------------------------
+class _HubRandom:
+    """np.random as the hub (mc3/mcmc_driver.py:229-239) sees it: every trial vector of the
+    kick-off is recorded in the order drawn."""
+    def __init__(self):
+        self.trials = []
+
+    def normal(self, *a, **k):
+        v = np.random.normal(*a, **k)
+        self.trials.append(np.array(v, float))
+        return v
+
+    def uniform(self, *a, **k):
+        v = np.random.uniform(*a, **k)
+        self.trials.append(np.array(v, float))
+        return v
+
+    def __getattr__(self, name):
+        return getattr(np.random, name)
+
+
+class _HubProxy:
+    def __init__(self):
+        self.random = _HubRandom()
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+
+def kickoff_case(out, name, hub_seed, func, **kw):
+    """The reference's own kick-off (mcmc_driver.py:229-270) on a short run: the tape of its
+    trial vectors, the rows and log-posteriors it kept."""
+    hub = _HubProxy()
+    sys.modules['mc3.mcmc_driver'].np = hub
+    np.random.seed(hub_seed)
+    cwd = os.getcwd()
+    os.chdir('/tmp')
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            mc3.sample(func=func, ncpu=1, plots=False, grtest=False, log=None, **kw)
+    finally:
+        os.chdir(cwd)
+        sys.modules['mc3.mcmc_driver'].np = np
+    npar = len(kw['params'])
+    tape = np.array(hub.random.trials)
+    M0 = kw.get('hsize', 10)*kw['nchains']
+    assert len(_captured['Z0']) == M0
+    for key, val in dict(
+            tape=tape, Z0=_captured['Z0'], log_post0=_captured['log_post0'],
+            data=kw['data'], uncert=kw['uncert'], x=kw['indparams'][0],
+            params=kw['params'], pstep=kw['pstep'],
+            pmin=kw.get('pmin', np.tile(-np.inf, npar)), pmax=kw.get('pmax', np.tile(np.inf, npar)),
+            prior=kw.get('prior', np.zeros(npar)), priorlow=kw.get('priorlow', np.zeros(npar)),
+            priorup=kw.get('priorup', np.zeros(npar)), nchains=kw['nchains'],
+            hsize=kw.get('hsize', 10), wlike=kw.get('wlike', False),
+            uniform=kw.get('kickoff', 'normal') == 'uniform').items():
+        out[f'kick_{name}_{key}'] = np.asarray(val)
+    print(f'kickoff {name}: {len(tape)} trials drawn for {M0} rows')
+
+
+def residue_vectors():
+    out = {}
+    rs = np.random.RandomState(31415)
+    # (a) log_prior with a two-sided Gaussian, a log-uniform (priorlow < 0) and a uniform
+    # free parameter around a fixed one (mc3/stats/stats.py:287-392)
+    post = np.column_stack([rs.normal(3.0, 0.5, 60), rs.uniform(0.05, 4.0, 60),
+                            rs.normal(-1.0, 2.0, 60)])
+    lp_prior = np.array([3.0, 0.0, 1.0, 0.0])
+    lp_low = np.array([0.5, 0.0, -1.0, 0.0])
+    lp_up = np.array([0.25, 0.0, 0.0, 0.0])
+    lp_step = np.array([1.0, 0.0, 0.3, 2.0])
+    out['logprior2_post'] = post
+    out['logprior2_prior'], out['logprior2_priorlow'] = lp_prior, lp_low
+    out['logprior2_priorup'], out['logprior2_pstep'] = lp_up, lp_step
+    out['logprior2_value'] = ms.log_prior(post, lp_prior, lp_low, lp_up, lp_step)
+    # (b) Gaussian chisq of BASELINE config 5's design-matrix model at its full size
+    # (1e5 points x 10 columns): the model by NumPy, chisq by the reference's _chisq
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import helpers as H
+    prob = H.linear_problem(ndata=100000, nmodel=10, nchains=16, nsamples=16)
+    A, data, uncert = prob['indep'], prob['data'], prob['uncert']
+    P = prob['params'] + rs.normal(0, 0.03, (4, 10))
+    out['c5_params'] = P
+    out['c5_data_checksum'] = np.array([data.sum(), A.sum()])
+    out['c5_chisq'] = np.array([ms.chisq(A.T @ p, data, uncert) for p in P])
+    out['c5_chisq_priors'] = np.array([
+        ms.chisq(A.T @ p, data, uncert, p, prob['prior'], prob['priorlow'], prob['priorup'])
+        for p in P])
+    # (c) the kick-off: the hub's trial vectors as drawn, and what it kept
+    x, data, uncert = tutorial_data(100)
+    base = dict(data=data, uncert=uncert, indparams=[x], sampler='mrw', burnin=0)
+    kickoff_case(out, 'loose', 21, quad, nchains=7, nsamples=70,
+                 params=np.array([10.0, -2.0, 0.1]), pstep=np.array([1.0, 0.5, 0.1]),
+                 pmin=np.array([-10.0, -20.0, -10.0]), pmax=np.array([40.0, 20.0, 10.0]), **base)
+    kickoff_case(out, 'tight', 22, quad, nchains=6, nsamples=60, hsize=5,
+                 params=np.array([4.0, -2.5, 0.5]), pstep=np.array([1.0, 0.5, 0.1]),
+                 pmin=np.array([3.5, -2.8, 0.45]), pmax=np.array([6.5, -2.2, 0.56]), **base)
+    x64, data64, uncert64 = tutorial_data(64)
+    # a shared and a fixed parameter, uniform kick-off.  (A shared parameter whose own interval
+    # is narrower than its source's cannot be recorded: once its copy lands outside, the
+    # reference tests that stale copy forever, mcmc_driver.py:249-255, and gives up.)
+    kickoff_case(out, 'shared_uniform', 23, line_shared, nchains=5, nsamples=50, hsize=8,
+                 data=data64, uncert=uncert64, indparams=[x64], sampler='mrw', burnin=0,
+                 params=np.array([3.2, -2.2, 0.45, -2.2, 1.0]),
+                 pstep=np.array([0.3, 0.1, 0.03, -2, 0.0]),
+                 pmin=np.array([2.0, -3.0, 0.42, -3.0, 0.0]),
+                 pmax=np.array([4.5, -1.9, 0.56, -1.9, 2.0]), kickoff='uniform')
+    kickoff_case(out, 'shared_normal', 24, line_shared, nchains=5, nsamples=50,
+                 data=data64, uncert=uncert64, indparams=[x64], sampler='mrw', burnin=0,
+                 params=np.array([3.2, -2.2, 0.45, -2.2, 1.0]),
+                 pstep=np.array([0.3, 0.1, 0.03, -2, 0.0]),
+                 pmin=np.array([2.0, -2.4, 0.42, -2.4, 0.0]),
+                 pmax=np.array([4.5, -2.1, 0.56, -2.1, 2.0]),
+                 prior=np.array([3.0, 0.0, 0.5, 0.0, 0.0]),
+                 priorlow=np.array([0.5, 0.0, 0.02, 0.0, 0.0]),
+                 priorup=np.array([0.25, 0.0, 0.04, 0.0, 0.0]))
+    rs99 = np.random.RandomState(99)
+    xw = np.linspace(0, 10, 64)
+    dw = quad([3.0, -2.4, 0.5], xw) + rs99.normal(0, 1.0, 64) + 0.5*np.sin(2*np.pi*xw)
+    kickoff_case(out, 'wavelet', 25, quad, nchains=7, nsamples=70, wlike=True,
+                 data=dw, uncert=np.ones(64), indparams=[xw], sampler='mrw', burnin=0,
+                 params=np.array([3.0, -2.4, 0.5, 1.0, 0.5, 1.0]),
+                 pstep=np.array([0.3, 0.1, 0.02, 0.0, 0.1, 0.1]),
+                 pmin=np.array([-10.0, -20.0, -10.0, 0.0, 0.2, 0.2]),
+                 pmax=np.array([40.0, 20.0, 10.0, 2.0, 10.0, 10.0]))
+    np.savez_compressed(os.path.join(HERE, 'residue_vectors.npz'), **out)
+    print('residue_vectors:', len(out), 'arrays')
+
+
+if __name__ == '__main__' and 'residues' in sys.argv:
+    residue_vectors()

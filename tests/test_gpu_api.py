@@ -389,3 +389,28 @@ def test_kde_and_chisq_rows_on_the_device():
         want = -2.0*(lp - ms.log_prior(Z, gpu.prior, gpu.priorlow, gpu.priorup, gpu.pstep))
         np.testing.assert_array_equal(gpu.chisq_rows(), want)
         np.testing.assert_array_equal(gpu.chisq_rows(gpu.M0 + 3, 50), want[gpu.M0 + 3:gpu.M0 + 53])
+
+
+def test_chisq_rows_against_the_reference_log_prior(golden_dir):
+    """mc3hip_get_chisq (rows_chisq_kernel: -2 (log_post - log_prior), mc3/stats/stats.py:821
+    with log_prior of :287-392) against the REFERENCE's log_prior -- a two-sided Gaussian, a
+    log-uniform (priorlow < 0) and a uniform free parameter around a fixed one
+    (tests/golden/residue_vectors.npz, made by tests/golden/make_golden.py residues)."""
+    from mc3_amd import engine
+    kv = np.load(os.path.join(golden_dir, 'residue_vectors.npz'))
+    post, want_lp = kv['logprior2_post'], kv['logprior2_value']
+    x, data, uncert = H.tutorial_data(50)
+    nrows = len(post)
+    lp0 = -0.5*np.random.RandomState(8).uniform(40.0, 90.0, nrows)
+    with engine.DeviceChains(
+            data=data, uncert=uncert, indep=x, params=np.array([3.0, -2.4, 1.0, 0.0]),
+            pstep=kv['logprior2_pstep'], prior=kv['logprior2_prior'],
+            priorlow=kv['logprior2_priorlow'], priorup=kv['logprior2_priorup'],
+            nchains=nrows//10, nsamples=nrows, sampler='mrw', model='poly') as gpu:
+        assert gpu.M0 == nrows and gpu.nfree == post.shape[1]
+        gpu.set_population(post, lp0)
+        got = gpu.chisq_rows(0, nrows)
+    np.testing.assert_allclose(got, -2.0*(lp0 - want_lp), rtol=1e-12)
+    # the prior terms themselves, each kind present and nonzero
+    np.testing.assert_allclose(-0.5*got - lp0, -want_lp, rtol=1e-10)
+    assert np.all(want_lp < -1e-3)

@@ -341,3 +341,43 @@ def test_resident_nonfinite_models_are_rejected_like_the_reference(eng, kind):
     assert (np.isnan(tc[inb])).any() or (tc[inb] == np.inf).any()
     assert gpu.state()['numaccept'].sum() == 0
     gpu.close()
+
+
+@pytest.mark.parametrize('plan_env,want', [
+    ({}, dict(resident=1, tile_tree=1)),                          # one launch, matrix cores
+    ({'MC3HIP_NO_RESIDENT': '1'}, dict(resident=0, tile_tree=1)),  # three launches, matrix cores
+    ({'MC3HIP_NO_MFMA': '1'}, dict(resident=0, tile_tree=0)),      # three launches, vector unit
+])
+def test_tiled_plans_against_the_reference_chisq_at_c5_size(eng, monkeypatch, golden_dir,
+                                                            plan_env, want):
+    """An independent check of the tiled plans' data sums at BASELINE config 5's own size
+    (1e5 points x 10 columns), against the REFERENCE's _chisq (tests/golden/
+    residue_vectors.npz: model by NumPy, chisq by src_c/_chisq.c), not against a checker
+    that follows the library's summation order.  The chain kernels are made to evaluate a
+    given vector p: with every row of the population equal to p a DEMC proposal is p exactly
+    (gamma (x1 - x2) = 0), and its chisq comes back in the per-step trace."""
+    for k, v in plan_env.items():
+        monkeypatch.setenv(k, v)
+    kv = np.load(os.path.join(golden_dir, 'residue_vectors.npz'))
+    nchains = 16
+    prob = H.linear_problem(ndata=100000, nmodel=10, nchains=nchains, nsamples=nchains)
+    np.testing.assert_allclose([prob['data'].sum(), prob['indep'].sum()],
+                               kv['c5_data_checksum'], rtol=1e-12)
+    for with_priors, key in ((True, 'c5_chisq_priors'), (False, 'c5_chisq')):
+        p2 = dict(prob) if with_priors else dict(prob, prior=None, priorlow=None, priorup=None)
+        for p, ref in zip(kv['c5_params'], kv[key]):
+            with eng.DeviceChains(trace_iters=1, **p2) as gpu:
+                plan = gpu.plan
+                assert plan['tile'] == 2048 and plan['tile_tree'] == want['tile_tree'], plan
+                assert plan['resident'] == want['resident'], plan
+                Z0 = np.tile(p, (gpu.M0, 1))
+                gpu.set_population(Z0, np.full(gpu.M0, -1e300), X0=Z0[:nchains],
+                                   chisq0=np.full(nchains, 1e300))
+                gpu.run(1)
+                tc, tf = gpu.trace(1)
+                Z, lp, _ = gpu.rows(gpu.M0, nchains)
+            assert np.all(tf[0] == 3)                      # in bounds, accepted
+            np.testing.assert_array_equal(Z, Z0[:nchains])  # the proposal was p itself
+            assert np.all(tc[0] == tc[0][0])
+            np.testing.assert_allclose(tc[0], ref, rtol=1e-10)
+            np.testing.assert_allclose(-2.0*lp, ref, rtol=1e-10)

@@ -239,3 +239,32 @@ def test_sequential_replay_with_ref_kernels(golden_dir, name):
     np.testing.assert_array_equal(run.Z[v], g['out_posterior'])
     np.testing.assert_array_equal(run.log_post[v], g['out_log_post'])
     assert run.numaccept == int(g['numaccept'])
+
+
+def test_log_prior_with_a_log_uniform_parameter(golden_dir):
+    """mc3/stats/stats.py:287-392 with all three kinds of prior (two-sided Gaussian,
+    log-uniform where priorlow < 0, uniform) around a fixed parameter."""
+    kv = np.load(os.path.join(golden_dir, 'residue_vectors.npz'))
+    got = ok.log_prior(kv['logprior2_post'], kv['logprior2_prior'], kv['logprior2_priorlow'],
+                       kv['logprior2_priorup'], kv['logprior2_pstep'])
+    np.testing.assert_allclose(got, kv['logprior2_value'], rtol=1e-13)
+    assert np.all(kv['logprior2_value'] < 0)
+
+
+def test_design_matrix_chisq_at_full_c5_size(golden_dir):
+    """BASELINE config 5's model (1e5 points x 10 columns): the oracle's chisq -- untiled and
+    in the summation orders of the tiled plans -- against the reference's _chisq."""
+    import helpers as H
+    from oracle import lockstep as ls
+    kv = np.load(os.path.join(golden_dir, 'residue_vectors.npz'))
+    prob = H.linear_problem(ndata=100000, nmodel=10, nchains=16, nsamples=16)
+    np.testing.assert_allclose([prob['data'].sum(), prob['indep'].sum()],
+                               kv['c5_data_checksum'], rtol=1e-12)
+    for extra in ({}, {'tile': 2048, 'vlanes': 1024, 'tile_tree': 1},
+                  {'tile': 2048, 'vlanes': 1024, 'tile_tree': 0}):
+        run = ls.LockstepRun(**prob, **extra)
+        np.testing.assert_allclose(run.eval_chisq(kv['c5_params']), kv['c5_chisq_priors'],
+                                   rtol=1e-10)
+    noprior = dict(prob, prior=None, priorlow=None, priorup=None)
+    np.testing.assert_allclose(ls.LockstepRun(**noprior).eval_chisq(kv['c5_params']),
+                               kv['c5_chisq'], rtol=1e-10)

@@ -151,3 +151,82 @@ def test_fma_flavour_of_the_snooker_dot_products(golden_dir):
     if res['rc'] == 0 and np.array_equal(run.Z[v], g['out_posterior']):
         pytest.skip('both roundings reproduce this run')
     np.testing.assert_allclose(run.Z[v][:200], g['out_posterior'][:200], rtol=1e-9)
+
+
+# ---- the kick-off (mc3/mcmc_driver.py:229-270) --------------------------------------------
+KICK_CASES = ['loose', 'tight', 'shared_uniform', 'shared_normal', 'wavelet']
+
+
+def kickoff_run_for(name, g):
+    k = f'kick_{name}_'
+    shared = name.startswith('shared')
+    x = g[k + 'x']
+    if shared:
+        indep = np.array([np.ones_like(x), np.zeros_like(x), x**2.0, x, np.ones_like(x)])
+        family, offset = 'linear', 1.0
+    else:
+        indep, family, offset = x, 'poly', 0.0
+    wlike = bool(g[k + 'wlike'])
+    nchains = int(g[k + 'nchains'])
+    return ls.LockstepRun(
+        data=g[k + 'data'] + offset, uncert=g[k + 'uncert'], indep=indep,
+        params=g[k + 'params'], pstep=g[k + 'pstep'], pmin=g[k + 'pmin'], pmax=g[k + 'pmax'],
+        prior=g[k + 'prior'], priorlow=g[k + 'priorlow'], priorup=g[k + 'priorup'],
+        nchains=nchains, nsamples=10.0*nchains, sampler='mrw', wlike=wlike,
+        hsize=int(g[k + 'hsize']), model=family, nmodel=3 if wlike else len(g[k + 'params']))
+
+
+@pytest.mark.parametrize('name', KICK_CASES)
+def test_kickoff_rule_replays_the_reference_tape(golden_dir, name):
+    """The acceptance rule of the initial population -- ONE C function, init_population_core,
+    behind a draw source: Philox for ls_init_population, which is what checks the device's
+    init_scan_kernel (tests/test_gpu_api.py) -- fed the trial vectors the reference's hub drew
+    (np.random.normal / uniform, recorded by tests/golden/make_golden.py kickoff_case):
+    the rows it keeps are IDENTICAL to the reference's, their log-posteriors agree to 1e-10,
+    and the trials consumed are exactly those the reference consumed (its generator has
+    always drawn one more vector than its loop looked at, mcmc_driver.py:244-246)."""
+    g = np.load(os.path.join(golden_dir, 'residue_vectors.npz'))
+    k = f'kick_{name}_'
+    run = kickoff_run_for(name, g)
+    tape = g[k + 'tape']
+    assert tape.shape[1] == run.nfree and g[k + 'Z0'].shape == (run.M0, run.nfree)
+    Z0, lp0, filled, failed, used = run.init_population_tape(tape)
+    assert filled == run.M0
+    assert used == len(tape) - 1 and failed == used - filled
+    np.testing.assert_array_equal(Z0, g[k + 'Z0'])
+    np.testing.assert_allclose(lp0, g[k + 'log_post0'], rtol=1e-10)
+    if name == 'tight':
+        assert failed > 5*filled            # (the boundaries really reject)
+
+
+def test_kickoff_tape_is_a_sharp_instrument(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'residue_vectors.npz'))
+    run = kickoff_run_for('tight', g)
+    tape = g['kick_tight_tape'].copy()
+    want = g['kick_tight_Z0']
+    # a rejected trial moved inside the boundaries is kept: every later row shifts
+    bad = np.flatnonzero(np.any((tape < run.pmin[run.ifree]) | (tape > run.pmax[run.ifree]),
+                                axis=1))[0]
+    tape[bad] = want[0]
+    Z0, _, filled, _, used = run.init_population_tape(tape)
+    assert not np.array_equal(Z0, want) and used < len(tape) - 1
+    # a tape cut short cannot fill the population
+    _, _, filled, _, used = run.init_population_tape(g['kick_tight_tape'][:40])
+    assert filled < run.M0 and used == 40
+
+
+def test_philox_kickoff_uses_the_same_rule(golden_dir):
+    """ls_init_population (Philox source) == the core fed the Philox trial vectors as a tape:
+    the draw source is the only difference between what is pinned to the reference above
+    and what checks the GPU."""
+    g = np.load(os.path.join(golden_dir, 'residue_vectors.npz'))
+    for name, kickoff in (('tight', 'normal'), ('shared_uniform', 'uniform')):
+        run = kickoff_run_for(name, g)
+        Z0, lp0, filled, failed = run.init_population(kickoff, seed=77)
+        assert filled == run.M0
+        # reconstruct the trial vectors of the rows kept + the rejected ones is not possible
+        # from outside; instead: the kept rows, replayed as a tape, are all kept again, in order
+        Z1, lp1, filled1, failed1, used1 = run.init_population_tape(Z0)
+        assert filled1 == run.M0 and failed1 == 0 and used1 == run.M0
+        np.testing.assert_array_equal(Z1, Z0)
+        np.testing.assert_array_equal(lp1, lp0)
