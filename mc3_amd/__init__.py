@@ -12,4 +12,5 @@ __version__ = '0.1.0'
 from .engine import DeviceChains, dwt_daub4, comm_unique_id  # noqa: E402,F401
 from .sampler_driver import sample  # noqa: E402,F401
 from .mcmc_driver import mcmc  # noqa: E402,F401
+from .fit_driver import fit  # noqa: E402,F401
 from . import models, stats, utils, parallel  # noqa: E402,F401

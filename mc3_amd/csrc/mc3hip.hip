@@ -95,6 +95,19 @@ int load_rccl()
     return MC3HIP_OK;
 }
 
+// a scratch allocation that grows with the problem must fit what the device has left: say so
+// in the problem's terms instead of failing inside hipMalloc
+int check_device_room(size_t bytes, const char *what)
+{
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
+        return MC3HIP_OK;                   // (cannot tell: let the allocation speak)
+    if (bytes > free_b)
+        return fail(MC3HIP_ERR_ARG, "%s needs %.2f GiB of device memory, %.2f GiB are free",
+                    what, (double)bytes / (1u << 30), (double)free_b / (1u << 30));
+    return MC3HIP_OK;
+}
+
 int choose_wpc(int nlocal, int ndata, int wlike)
 {
     // One wave per chain when there are enough chains to fill the chip or the
@@ -744,8 +757,30 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         const bool linear_model = pr->model_kind == MC3HIP_MODEL_LINEAR;
         const bool resident_model = linear_model ? (pr->nmodel >= 5 && pr->nmodel <= 11)
                                                  : (pr->nmodel >= 2 && pr->nmodel <= 4);
+        // (the mid-range rule was measured with the ONE-launch plan; where that plan cannot
+        // run -- switched off, or a grid of tiles x columns of chains that is not co-resident
+        // with an owner wave for every chain, the test decide_persist applies later -- the
+        // fused kernels keep the shapes below 16 384 points.  An RCCL communicator attached
+        // afterwards also forces three launches per iteration: not knowable here.)
+        bool mid_resident = resident_model && !(pr->flags & MC3HIP_FLAG_NO_PERSIST) &&
+                            !getenv("MC3HIP_NO_PERSIST") && !getenv("MC3HIP_NO_RESIDENT");
+        if (mid_resident) {
+            hipDeviceProp_t prop;
+            const long long tile_pts = pr->nmodel <= 4 ? 4096 : 2048;
+            const long long nt = ((long long)nd + tile_pts - 1) / tile_pts;
+            const long long cus = hipGetDeviceProperties(&prop, c->device) == hipSuccess
+                                      ? prop.multiProcessorCount : 256;
+            const long long maxcol = cus / nt;
+            mid_resident = maxcol >= 1;
+            if (mid_resident) {
+                long long cb = ((long long)pr->nlocal + maxcol - 1) / maxcol;
+                cb = (cb + 15) / 16 * 16;
+                const long long ncol = ((long long)pr->nlocal + cb - 1) / cb;
+                mid_resident = ncol * nt <= cus && (long long)pr->nlocal <= 8 * ncol * nt;
+            }
+        }
         const bool big = nd >= 4 * 4096 ||
-                         (resident_model && nd >= 2 * 4096 &&
+                         (mid_resident && nd >= 2 * 4096 &&
                           (long long)nd * pr->nlocal >= 4194304LL);
         const bool tiled = !pr->wlike && big && pr->nlocal >= 16 && pr->nmodel <= 16 &&
                            !getenv("MC3HIP_NO_TILED");
@@ -787,6 +822,9 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         // pre-level values of the large-data path: two ping-pong buffers per workgroup; the
         // chisq-evaluation kernel runs at most WL_EVAL_BLOCKS vectors per launch
         const size_t blocks = (size_t)(pr->nlocal > WL_EVAL_BLOCKS ? pr->nlocal : WL_EVAL_BLOCKS);
+        TRY(check_device_room(blocks * (3 * nd / 4) * sizeof(double),
+                              "the wavelet likelihood's pre-level scratch (max(nlocal, 256) x "
+                              "3/4 ndata doubles)"));
         TRY(dev_alloc(c, &P.wl_scratch, blocks * (3 * nd / 4)));
     }
     if (pr->wlike) {
@@ -1485,6 +1523,10 @@ int mc3hip_posterior_summary(mc3hip_ctx *c, int64_t nrefresh, int64_t burn, int3
     const size_t hbytes = (size_t)nf * SEL_MAXR * 256 * sizeof(unsigned int);
     const size_t obytes = (size_t)nf * SEL_MAXR * sizeof(double);
     void *buf = nullptr;
+    HIP_TRY(hipSetDevice(c->device));
+    RC_TRY(check_device_room(kbytes + pbytes + rbytes + sbytes + hbytes + obytes + 1024,
+                             "the posterior summary's selection keys (8 bytes per row and free "
+                             "parameter)"));
     HIP_TRY(hipMalloc(&buf, kbytes + pbytes + rbytes + sbytes + hbytes + obytes + 1024));
     struct Free { void *p; ~Free() { (void)hipFree(p); } } guard{buf};
     char *at = static_cast<char *>(buf);

@@ -24,27 +24,59 @@ class _Value:
 
 
 class _Checkpointer:
-    """The periodic ``np.savez(savefile, **output)`` of the hub (mcmc_driver.py:321-324)
-    on a worker thread, one write in flight: the chains run on while the disk is busy.
-    Safe without copies: the big arrays of ``output`` are views of host rows that were
-    fetched once and are never rewritten (later reports only append behind them)."""
+    """The periodic save of the hub (``np.savez(savefile, **output)`` at every report,
+    mcmc_driver.py:321-324) as a file that GROWS: the per-row arrays are appended in place
+    (mc3_amd/npz_stream.py), only the small arrays are rewritten, so a report costs the rows
+    that are new, not the run so far; on a worker thread, one write in flight: the chains run
+    on while the disk is busy.  Safe without copies: the big arrays of ``output`` are views
+    of host rows that were fetched once and are never rewritten (later reports only append
+    behind them)."""
+    GROWN = ('posterior', 'zchain', 'chisq', 'log_post', 'zmask')
 
     def __init__(self):
         self.thread = None
         self.error = None
+        self.writer = None
 
-    def save(self, path, output):
+    def _writer(self, path, output, max_rows):
+        if self.writer is None:
+            from .npz_stream import StreamingNpz
+            nfree = np.shape(output['posterior'])[1]
+            spec = {'posterior': (np.float64, (nfree,), max_rows),
+                    'zchain': (np.asarray(output['zchain']).dtype, (), max_rows),
+                    'chisq': (np.float64, (), max_rows), 'log_post': (np.float64, (), max_rows),
+                    'zmask': (np.intp, (), max_rows)}
+            self.writer = StreamingNpz(path, spec)
+        return self.writer
+
+    def save(self, path, output, max_rows):
         import threading
         self.wait()
         frozen = dict(output)
+        writer = self._writer(path, frozen, max_rows)
 
         def work():
             try:
-                np.savez(path, **frozen)
+                writer.write(frozen)
             except Exception as err:           # noqa: BLE001 -- re-raised by wait()
                 self.error = err
         self.thread = threading.Thread(target=work, daemon=True)
         self.thread.start()
+
+    def finish(self, path, output, max_rows):
+        """The complete output dictionary (what sample() saves at the end): the remaining
+        rows, every small array, and the file is closed."""
+        self.wait()
+        self._writer(path, output, max_rows).write(output)
+        self.close()
+
+    def close(self):
+        if self.thread is not None:
+            self.thread.join()
+            self.thread = None
+        if self.writer is not None:
+            self.writer.close()
+            self.writer = None
 
     def wait(self):
         if self.thread is not None:
@@ -103,29 +135,46 @@ def numpy_stream_population(engine, params, pstep, pmin, pmax, M0, kickoff):
     values = np.array(params, float)            # (its shared entries: the "stale" copies)
     filled = failed = 0
     nmax = 100*M0
-    # The reference tests the boundaries on the full vector BEFORE refreshing the shared
-    # parameters, i.e. with the copies the last accepted-into-bounds trial left (:249-255).
-    # Those copies are values their sources took inside the sources' boundaries, so the
-    # rule can only bite when a shared parameter's own interval is tighter than its
-    # source's (or excludes its initial value); only then is the sequential form needed.
-    stale_can_fail = np.any(pmin[ishare] > pmin[src]) or np.any(pmax[ishare] < pmax[src]) \
+    # The reference tests the boundaries on the FULL vector (fixed entries too) BEFORE
+    # refreshing the shared parameters, i.e. with the copies the last trial that passed the
+    # test left (:249-255), and refreshes them one after another in index order
+    # (chain.py:246-247).  Whole blocks can be judged at once when none of that can matter:
+    # the copies are values their sources took inside the sources' boundaries, so the stale
+    # test can only bite when a shared parameter's own interval is tighter than its source's
+    # (or excludes its initial value), and the order only when a shared parameter's source is
+    # itself shared.  Otherwise: trial by trial, the reference's loop as it stands.
+    sequential = bool(
+        np.any(pmin[ishare] > pmin[src]) or np.any(pmax[ishare] < pmax[src])
         or np.any(values[ishare] > pmax[ishare]) or np.any(values[ishare] < pmin[ishare])
+        or np.any(np.isin(src, ishare)))
+    ifixed = np.flatnonzero(pstep == 0)
+    fixed_outside = bool(np.any(values[ifixed] > pmax[ifixed]) or
+                         np.any(values[ifixed] < pmin[ifixed]))
     while filled < M0 and failed < nmax:
         block = max(256, 2*(M0 - filled))
         if kickoff == 'normal':
             trial = np.random.normal(params[ifree], pstep[ifree], (block, nfree))
         else:
             trial = np.random.uniform(pmin[ifree], pmax[ifree], (block, nfree))
-        full = np.tile(values, (block, 1))
-        full[:, ifree] = trial
-        inside = np.all((trial >= pmin[ifree]) & (trial <= pmax[ifree]), axis=1)
-        if stale_can_fail:
-            for i in np.flatnonzero(inside):     # (rare configuration: trial by trial)
-                if np.any(values[ishare] > pmax[ishare]) or np.any(values[ishare] < pmin[ishare]):
-                    inside[i] = False
-                else:
-                    values[ishare] = full[i, src]
-        full[:, ishare] = full[:, src]
+        if sequential:
+            full = np.empty((block, npar))
+            inside = np.zeros(block, bool)
+            for i in range(block):
+                values[ifree] = trial[i]
+                if np.any(values > pmax) or np.any(values < pmin):
+                    continue
+                for s, q in zip(ishare, src):
+                    values[s] = values[q]
+                full[i] = values
+                inside[i] = True
+        else:
+            full = np.tile(values, (block, 1))
+            full[:, ifree] = trial
+            inside = np.all((trial >= pmin[ifree]) & (trial <= pmax[ifree]), axis=1)
+            if fixed_outside:
+                inside[:] = False                 # (every trial fails the reference's test)
+            for s, q in zip(ishare, src):
+                full[:, s] = full[:, q]
         lp = np.full(block, -np.inf)
         if np.any(inside):
             with np.errstate(all='ignore'):
@@ -350,57 +399,66 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
     nreport = 10
     edges = np.unique(np.ceil(np.arange(1, nreport + 1)*nzchain/nreport).astype(int))
     done = 0
-    for edge in edges:
-        todo = int(edge) - done
-        if comm.size > 1 and not comm.native:
-            for _ in range(todo):
-                engine.run(1)
-                comm.exchange(engine, done)
-                done += 1
-        else:
-            # (not waited for here: snapshot() synchronises -- and, on several GPUs,
-            # is where the ranks agree that the segment completed everywhere)
-            engine.run(todo, sync=False)
-            done = int(edge)
-        nrows = snapshot()
-        log.progressbar((nrows + 1.0 - pre_zsize)/(nzchain*nchains))
-        log.msg(
-            f"Out-of-bound Trials:\n{view.outbounds}\n"
-            f"Best Parameters: (chisq={-2*view.best_log_post:.4f})\n"
-            f"{view.bestp[ifree]}", width=80)
-        run_gr = grtest and np.all(view.chainsize > (zburn + hsize))
-        # the Gelman-Rubin reductions run on the device when the chains started in
-        # this call (regular row layout); Z is then only read back for a savefile
-        device_gr = run_gr and not resume and hasattr(engine, 'chain_moments') \
-            and (comm.size == 1 or comm.native)
-        need_rows = (savefile is not None) or (run_gr and not device_gr)
-        if need_rows:
-            if comm.native:
-                comm.finish(engine)
-            pull_rows(nrows)
-        if savefile is not None and comm.rank == 0:
-            ms.update_output(output, view, hsize, stats_engine())
-            checkpoint.save(savefile, output)
-        if run_gr:
-            if device_gr:
-                mean, var = engine.chain_moments(zburn)
-                psrf = ms.gelman_rubin_from_moments(mean, var, done - zburn)
+    try:
+        for edge in edges:
+            todo = int(edge) - done
+            if comm.size > 1 and not comm.native:
+                for _ in range(todo):
+                    engine.run(1)
+                    comm.exchange(engine, done)
+                    done += 1
             else:
-                psrf = ms.gelman_rubin(view.Z, view.zchain, zburn)
-            log.msg(f"Gelman-Rubin statistics for free parameters:\n{psrf}",
-                    width=80)
-            if np.all(psrf < 1.01):
-                log.msg("All parameters converged to within 1% of unity.")
-            if grbreak > 0.0 and np.all(psrf < grbreak) and nrows > grnmin:
-                log.msg(
-                    "\nAll parameters satisfy the GR convergence "
-                    f"threshold of {grbreak:g}, stopping the MCMC.")
-                break
+                # (not waited for here: snapshot() synchronises -- and, on several GPUs,
+                # is where the ranks agree that the segment completed everywhere)
+                engine.run(todo, sync=False)
+                done = int(edge)
+            nrows = snapshot()
+            log.progressbar((nrows + 1.0 - pre_zsize)/(nzchain*nchains))
+            log.msg(
+                f"Out-of-bound Trials:\n{view.outbounds}\n"
+                f"Best Parameters: (chisq={-2*view.best_log_post:.4f})\n"
+                f"{view.bestp[ifree]}", width=80)
+            run_gr = grtest and np.all(view.chainsize > (zburn + hsize))
+            # the Gelman-Rubin reductions run on the device when the chains started in
+            # this call (regular row layout); Z is then only read back for a savefile
+            device_gr = run_gr and not resume and hasattr(engine, 'chain_moments') \
+                and (comm.size == 1 or comm.native)
+            need_rows = (savefile is not None) or (run_gr and not device_gr)
+            if need_rows:
+                if comm.native:
+                    comm.finish(engine)
+                pull_rows(nrows)
+            if savefile is not None and comm.rank == 0:
+                ms.update_output(output, view, hsize, stats_engine())
+                checkpoint.save(savefile, output, zlen)
+            if run_gr:
+                if device_gr:
+                    mean, var = engine.chain_moments(zburn)
+                    psrf = ms.gelman_rubin_from_moments(mean, var, done - zburn)
+                else:
+                    psrf = ms.gelman_rubin(view.Z, view.zchain, zburn)
+                log.msg(f"Gelman-Rubin statistics for free parameters:\n{psrf}",
+                        width=80)
+                if np.all(psrf < 1.01):
+                    log.msg("All parameters converged to within 1% of unity.")
+                if grbreak > 0.0 and np.all(psrf < grbreak) and nrows > grnmin:
+                    log.msg(
+                        "\nAll parameters satisfy the GR convergence "
+                        f"threshold of {grbreak:g}, stopping the MCMC.")
+                    break
 
+    except BaseException:
+        checkpoint.close()          # (no write left in flight, no half-written file handle)
+        raise
     nrows = snapshot(final=True)
     pull_rows(nrows)
     checkpoint.wait()
     summary = ms.update_output(output, view, hsize, stats_engine())
+    if _extras is not None and savefile is not None and comm.rank == 0:
+        # (sample() adds its statistics and lets the same growing file take the final save)
+        _extras['checkpoint'] = (checkpoint, zlen)
+    else:
+        checkpoint.close()
     if _extras is not None:
         _extras['summary'] = summary
         _extras['kde'] = getattr(engine, 'kde_pdf', None) if stats_engine() else None

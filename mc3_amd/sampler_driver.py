@@ -20,6 +20,7 @@ import numpy as np
 
 from . import stats as ms
 from . import utils as mu
+from .fit_driver import fit
 from .mcmc_driver import mcmc
 
 __all__ = ['sample']
@@ -210,11 +211,6 @@ def sample(
                   f"{SAMPLERS}")
     if nsamples is None:
         log.error("'nsamples' is a required argument for MCMC runs")
-    if leastsq is not None or chisqscale:
-        log.error(
-            "leastsq / chisqscale (the least-squares pre-fit of mc3.fit) is outside "
-            "the MI355X chain-update path; run the optimiser separately and pass its "
-            "best fit as 'params'", NotImplementedError)
     _require(log, params=params)
     inp = _Inputs()
     _split_params(inp, log, params, pmin, pmax, pstep, prior, priorlow, priorup)
@@ -231,12 +227,31 @@ def sample(
             f"match the size of the func() output ({np.size(model0)})")
 
     resume = bool(resume) and savefile is not None
+    # the least-squares pre-fit (sampler_driver.py:411-440): once, on the host; its best fit
+    # is where the chains start.  chisqscale alone (leastsq=None) does nothing, as there
     chisq_factor = 1.0
+    fit_output = None
+    if leastsq is not None:
+        def prefit():
+            return fit(inp.data, inp.uncert, func, np.copy(inp.params), indparams,
+                       indparams_dict, inp.pstep, inp.pmin, inp.pmax, inp.prior,
+                       inp.priorlow, inp.priorup, leastsq)
+        fit_output = prefit()
+        log.msg(f"Least-squares best-fitting parameters:\n  {fit_output['bestp']}\n\n", si=2)
+        if chisqscale:
+            # data uncertainties scaled such that the reduced chisq of the best fit is 1
+            nfree = int(np.sum(inp.pstep > 0))
+            chisq_factor = np.sqrt(fit_output['best_chisq']/(len(inp.data) - nfree))
+            inp.uncert *= chisq_factor
+            fit_output = prefit()
+            log.msg("Least-squares best-fitting parameters (rescaled chisq):"
+                    f"\n  {fit_output['bestp']}\n\n", si=2)
+        inp.params = np.copy(fit_output['bestp'])
     if resume:
         log.msg(f"\n\n{log.sep}\n{log.sep}  Resuming previous MCMC run.\n\n")
         with np.load(savefile) as previous:      # sampler_driver.py:442-445
+            inp.uncert *= float(previous['chisq_factor'])/chisq_factor
             chisq_factor = float(previous['chisq_factor'])
-        inp.uncert *= chisq_factor
     elif savefile is not None and lead:
         folder = os.path.dirname(os.path.realpath(savefile))
         if not os.path.exists(folder):
@@ -251,10 +266,19 @@ def sample(
     output = mcmc(
         inp.data, inp.uncert, func, inp.params, indparams, indparams_dict,
         inp.pmin, inp.pmax, inp.pstep, inp.prior, inp.priorlow, inp.priorup,
-        nchains, ncpu, nsamples, sampler, wlike, None, grtest, grbreak, grnmin,
+        nchains, ncpu, nsamples, sampler, wlike, fit_output, grtest, grbreak, grnmin,
         burnin, thinning, fgamma, fepsilon, hsize, kickoff, savefile, resume, log,
         inp.pnames, inp.texnames, **extra)
     output['chisq_factor'] = chisq_factor
+    if fit_output is not None:                   # sampler_driver.py:462-473
+        better = output['best_log_post'] - fit_output['best_log_post']
+        if better > 5.0e-8 and np.any(output['bestp'] != fit_output['bestp']):
+            log.warning(
+                "MCMC found a better fit than the minimizer:\n"
+                f"MCMC best-fitting parameters:        (chisq={-2*output['best_log_post']:.8g})\n"
+                f"{output['bestp']}\n"
+                f"Minimizer best-fitting parameters:   "
+                f"(chisq={-2*fit_output['best_log_post']:.8g})\n{fit_output['bestp']}")
 
     # -- statistics of the burned sample (sampler_driver.py:475-501): the median and
     # central-interval numbers were computed with the output dictionary (update_output,
@@ -280,7 +304,11 @@ def sample(
 
     if savefile is not None:
         if lead:
-            np.savez(savefile, **output)
+            grown = side.get('checkpoint')
+            if grown is not None:        # the file the reports grew takes the final rows too
+                grown[0].finish(savefile, output, grown[1])
+            else:
+                np.savez(savefile, **output)
             log.msg("\nOutput sampler files:")
             log.msg(savefile, indent=2)
         if comm is not None:

@@ -345,6 +345,41 @@ def test_numpy_stream_population_with_a_binding_shared_interval():
     np.testing.assert_array_equal(got[0], want[0])
     np.testing.assert_array_equal(got[1], want[1])
 
+    # a share OF a share: p4 <- p3 <- p1.  The reference refreshes the shared parameters one
+    # after another in index order (chain.py:246-247), so p4 takes p3's FRESH value
+    prob['pstep'] = np.array([0.3, 1.0, 3.0, -2, -4])
+    prob['pmin'] = np.array([2.0, -30.0, 30.0, -30.0, -30.0])
+    prob['pmax'] = np.array([4.5, -15.0, 60.0, -15.0, -15.0])
+    prob['params'] = np.array([3.2, -22.0, 45.0, -22.0, -22.0])
+    eng = OracleChains(**prob)
+    want = literal(32)
+    np.random.seed(32)
+    got = numpy_stream_population(eng, prob['params'], prob['pstep'], prob['pmin'],
+                                  prob['pmax'], M0, 'normal')
+    assert got[2] == want[2] == M0
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
+    # and the other order: p3 <- p4 <- p1 takes p4's value of the trial BEFORE
+    prob['pstep'] = np.array([0.3, 1.0, 3.0, -5, -2])
+    eng = OracleChains(**prob)
+    want = literal(33)
+    np.random.seed(33)
+    got = numpy_stream_population(eng, prob['params'], prob['pstep'], prob['pmin'],
+                                  prob['pmax'], M0, 'normal')
+    assert got[2] == want[2]
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
+
+    # a FIXED parameter outside its boundaries fails every trial, as in the reference
+    prob = H.shared_problem()
+    prob['pmax'] = prob['pmax'].copy()
+    prob['pmax'][4] = 0.5                      # p4 is fixed at 1.0
+    eng = OracleChains(**prob)
+    np.random.seed(34)
+    got = numpy_stream_population(eng, prob['params'], prob['pstep'], prob['pmin'],
+                                  prob['pmax'], 8, 'normal')
+    assert got[2] == 0
+
 
 def test_philox_population_is_the_default_and_deterministic():
     """Without kickoff_stream the initial population comes from the engine (device:
@@ -395,3 +430,64 @@ def test_sample_statistics_equal_the_reference(golden_dir):
     np.testing.assert_array_equal(
         ms.percentiles_from_order(len(post), pct, lambda ranks: srt[ranks]),
         np.percentile(post, pct, axis=0))
+
+
+def test_fit_matches_the_reference_known_answers():
+    """mc3.fit's documented example (mc3/fit_driver.py:92-124; also the reference's
+    tests/test_fit.py): same best fit from both optimisers, priors honoured, shared and
+    fixed parameters kept."""
+    def quad(p, x):
+        return p[0] + p[1]*x + p[2]*x**2.0
+    np.random.seed(10)
+    x = np.linspace(0, 10, 100)
+    y = quad([3.0, -2.4, 0.5], x)
+    uncert = np.sqrt(np.abs(y))
+    data = y + np.random.normal(0, uncert)
+    params = np.array([10.0, -2.0, 0.1])
+    lm = mc3_amd.fit(data, uncert, quad, np.copy(params), indparams=[x], leastsq='lm')
+    trf = mc3_amd.fit(data, uncert, quad, np.copy(params), indparams=[x], leastsq='trf',
+                      pmin=np.array([-10.0, -20.0, -10.0]), pmax=np.array([40.0, 20.0, 10.0]))
+    np.testing.assert_allclose(lm['bestp'], trf['bestp'], rtol=1e-6)
+    # weighted linear least squares has a closed form
+    A = np.vstack([np.ones_like(x), x, x**2]).T/uncert[:, None]
+    want = np.linalg.lstsq(A, data/uncert, rcond=None)[0]
+    np.testing.assert_allclose(lm['bestp'], want, rtol=1e-7)
+    assert lm['best_chisq'] == pytest.approx(np.sum(((quad(want, x) - data)/uncert)**2), rel=1e-10)
+    assert lm['best_log_post'] == pytest.approx(-0.5*lm['best_chisq'], rel=1e-12)
+    np.testing.assert_allclose(lm['best_model'], quad(lm['bestp'], x))
+    # a Gaussian prior pulls, a fixed parameter stays, a shared one follows its source
+    pri = mc3_amd.fit(data, uncert, quad, np.copy(params), indparams=[x],
+                      prior=np.array([3.5, 0.0, 0.0]), priorlow=np.array([0.01, 0.0, 0.0]),
+                      priorup=np.array([0.01, 0.0, 0.0]))
+    assert abs(pri['bestp'][0] - 3.5) < 0.02 and pri['best_chisq'] > lm['best_chisq']
+    assert pri['best_log_post'] < -0.5*pri['best_chisq'] + 1e-9       # the prior's share
+    fx = mc3_amd.fit(data, uncert, lambda p, x: p[0] + p[1]*x + p[2]*x**2 + 0*p[3],
+                     np.array([10.0, -2.0, 0.1, -2.0]), indparams=[x],
+                     pstep=np.array([1.0, 0.5, 0.0, -2]))
+    assert fx['bestp'][2] == 0.1 and fx['bestp'][3] == fx['bestp'][1]
+    with pytest.raises(ValueError, match="Invalid 'leastsq' input"):
+        mc3_amd.fit(data, uncert, quad, params, indparams=[x], leastsq='invalid')
+
+
+def test_sample_with_the_least_squares_prefit():
+    """leastsq / chisqscale as in mc3/sampler_driver.py:411-473: the chains start from the
+    optimiser's best fit, chisqscale rescales the uncertainties to a reduced chisq of 1
+    (and does nothing without leastsq, as in the reference), chisq_factor is reported."""
+    from oracle_engine import OracleChains
+    x, data, uncert = H.tutorial_data(100)
+    kw = dict(data=data, uncert=uncert*0.5, func=H.quad, params=np.array([10.0, -2.0, 0.1]),
+              indparams=[x], pstep=np.array([1.0, 0.5, 0.1]),
+              pmin=np.array([-10.0, -20.0, -10.0]), pmax=np.array([40.0, 20.0, 10.0]),
+              sampler='snooker', nsamples=7*150, burnin=20, nchains=7, grtest=False,
+              log=mu.Log(verb=0), engine_factory=OracleChains, seed=5)
+    plain = mc3_amd.sample(**kw, chisqscale=True)           # no leastsq: a no-op
+    assert plain['chisq_factor'] == 1.0
+    fitted = mc3_amd.sample(**kw, leastsq='lm')
+    ref = mc3_amd.fit(data, uncert*0.5, H.quad, np.array([10.0, -2.0, 0.1]), indparams=[x])
+    assert fitted['chisq_factor'] == 1.0
+    assert fitted['best_log_post'] >= ref['best_log_post'] - 1e-9
+    assert fitted['best_chisq'] <= plain['best_chisq'] + 1e-9
+    scaled = mc3_amd.sample(**kw, leastsq='trf', chisqscale=True)
+    want = np.sqrt(ref['best_chisq']/(100 - 3))
+    assert scaled['chisq_factor'] == pytest.approx(want, rel=1e-6)
+    assert scaled['red_chisq'] == pytest.approx(1.0, abs=0.05)
