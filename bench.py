@@ -175,6 +175,45 @@ def cpu_baseline(target_seconds=12.0):
     }
 
 
+def end_to_end():
+    """mc3_amd.sample() as a user calls it (an ordinary Python callable as the model, the
+    initial population, ten reports with the Gelman-Rubin test, the posterior statistics, the
+    output dictionary) -- wall seconds, NOT part of `value`: the rows next to the hot path
+     measured where the driver can see them.  Each after one small
+    warm-up call (library load, first launches)."""
+    import io
+    import contextlib
+    import mc3_amd
+    from mc3_amd import utils as mu
+    out = {}
+    p2 = c2_problem(CHAINS_PER_GPU, 1)
+    p5 = c5_problem(512, 1)
+    cases = {
+        'c2_1e7_samples': (dict(
+            data=p2['data'], uncert=p2['uncert'], func=quad, params=p2['params'],
+            indparams=[p2['indep']], pstep=p2['pstep'], pmin=p2['pmin'], pmax=p2['pmax'],
+            sampler='demc', burnin=100, nchains=CHAINS_PER_GPU, grtest=True, seed=3), 1e7),
+        'c5_1e5_samples': (dict(
+            data=p5['data'], uncert=p5['uncert'], func=lambda p, A: p @ A, params=p5['params'],
+            indparams=[p5['indep']], pstep=p5['pstep'], pmin=p5['pmin'], pmax=p5['pmax'],
+            prior=p5['prior'], priorlow=p5['priorlow'], priorup=p5['priorup'],
+            sampler='demc', burnin=20, nchains=512, grtest=True, seed=3), 1e5),
+    }
+    for name, (kw, nsamples) in cases.items():
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                mc3_amd.sample(nsamples=kw['nchains']*100, log=mu.Log(verb=0), **kw)
+                t0 = time.perf_counter()
+                res = mc3_amd.sample(nsamples=nsamples, log=mu.Log(verb=0), **kw)
+                dt = time.perf_counter() - t0
+            out[name] = {'wall_s': dt, 'samples': int(len(res['posterior'])),
+                         'million_samples_per_s': len(res['posterior'])/dt/1e6,
+                         'acceptance_rate': float(res['acceptance_rate'])}
+        except Exception as e:      # noqa: BLE001 -- an extra: never fails the bench line
+            out[name] = {'error': str(e)[:200]}
+    return out
+
+
 # ---- N > 1 started as one plain process: the parent of the ranks ----------------------------
 def launch_ranks(args, argv):
     """Start one process per GPU, relay rank 0's JSON line, watch over them.  This process
@@ -545,10 +584,12 @@ def run_rank(args):
             'note': 'one wave per CU on 256 CUs = 1/4 of the SIMDs, ~2 % of the FP64 vector '
                     'peak: the workload (256 chains, 1000 points) cannot fill the chip; '
                     'it is latency-bound, neither bandwidth- nor FLOP-bound'}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry_run:
-        out['cpu_baseline'] = cpu_baseline()
     if world == 1:
         gpu.close()
+    if rank == 0 and world == 1 and not args.dry_run and not args.no_e2e:
+        out['config']['e2e'] = end_to_end()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry_run:
+        out['cpu_baseline'] = cpu_baseline()
     ctl.barrier()
     ctl.close()
     import ctypes
@@ -642,6 +683,8 @@ def main():
                     help='c2: the headline, 256 chains per GPU (weak scaling); c3 / c5: BASELINE '
                          'configs 3 and 5, a fixed ensemble split over the GPUs (strong scaling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-e2e', action='store_true',
+                    help='skip the end-to-end sample() timings (config.e2e)')
     ap.add_argument('--dry-run', action='store_true',
                     help='no GPU work: exercises the launcher / rendezvous / reporting only')
     args = ap.parse_args()

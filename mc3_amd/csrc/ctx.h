@@ -41,6 +41,8 @@ struct mc3hip_ctx {
     int persist_refs = 0;           // refreshes per persistent launch, 0 = off
     bool persist_checked = false;
     bool fast = false;              // lean persistent instance selected
+    int lean_waves_default = 1;     // waves per chain of the hand-laid-out DEMC loop (ctx.h
+                                    // lean_waves), decided with the grid in decide_persist
     int mc_chains = 0;              // chains a workgroup of the persistent kernel advances per
                                     // refresh (0: one workgroup per chain), its grid and the
     int mc_grid = 0;                // dynamic LDS with the chains' waiting state appended
@@ -140,6 +142,26 @@ inline bool lean_demc_eligible(const mc3hip_ctx *c)
 {
     return c->fast && c->mc_chains == 0 && c->P.sampler == MC3HIP_DEMC && c->P.thinning == 1 &&
            c->P.nparams == c->mt && c->P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
+}
+
+// waves that share the data sum of a chain in the hand-laid-out DEMC loop (kernels_lean.h
+// lean_demc_wide_kernel): 1, 2 or 4.  Several only for the plain headline shape -- every
+// coefficient free, one tile, one GPU -- and only while the chip has SIMDs to spare
+// (at most one chain per CU and helper: beyond that the waves of other chains fill them
+// better).  MC3HIP_LEAN_WAVES=1|2|4 overrides.
+inline int lean_waves(const mc3hip_ctx *c)
+{
+    const DevProblem &P = c->P;
+    const bool plain = P.nparams == P.nfree && P.ngprior == 0 && P.nshare == 0 &&
+                       P.npad <= VLANES && !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1;
+    if (!lean_demc_eligible(c) || !plain)
+        return 1;
+    if (const char *e = getenv("MC3HIP_LEAN_WAVES")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4)
+            return v;
+    }
+    return c->lean_waves_default;
 }
 
 // ---- k_general_w{1,4,16}.hip: one workgroup per chain, Gaussian chisq, by waves per chain ---

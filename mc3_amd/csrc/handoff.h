@@ -249,6 +249,38 @@ __device__ __forceinline__ double prior_from_lanes(const DevProblem &P, double n
     return pr;
 }
 
+// The Metropolis test exp(t) > u (chain.py:257-260, t = (chisq_cur - chisq_new)/2, no
+// Hastings factor) without the exponential on the critical path.  u is known long before t
+// -- it is drawn from (seed, iteration, chain) alone -- so L = log(u) is computed in the
+// shadow of the wait for the partner rows, and the dependent chain chisq -> exp -> compare
+// -> publish (a single wave has nothing to hide it behind) loses its ~25 serial FP64 steps:
+//   t >= L + d  =>  accept,   t <= L - d  =>  reject,   d = 4e-15 (1 + |L|),
+// and ONLY inside that band (a handful of ulps wide: practically never) the exponential
+// itself decides.  The outcome is that of mc3_det_exp(t) > u in every case, so results stay
+// bit-identical to the checker, which always evaluates the exponential:
+//   mc3_det_exp and mc3_det_log are within 2 ulp of exp and log (tests/test_detmath_philox.py),
+//   i.e. det_exp(t) = exp(t)(1 + e1), |e1| < 5e-16, and |L - log u| < 5e-16 |L|; for
+//   t >= L + d:  det_exp(t) >= u exp(d - 5e-16 |L|)(1 - 5e-16) >= u exp(3e-15)(1 - 5e-16) > u,
+//   and symmetrically below.  u = 0 (log = -inf) and a NaN t take the exact path.
+__device__ __forceinline__ void accept_window(double u, double &lo, double &hi)
+{
+    const double L = mc3_det_log(u);
+    const double d = 4e-15 * (1.0 + __builtin_fabs(L));
+    // (u == 0: an empty window that nothing falls outside of -- lo = +inf, hi = -inf would
+    // decide everything; NaNs decide nothing)
+    const bool usable = u > 0.0;
+    lo = usable ? L - d : mc3_from_bits(0x7ff8000000000000ull);
+    hi = usable ? L + d : mc3_from_bits(0x7ff8000000000000ull);
+}
+
+__device__ __forceinline__ bool metropolis_accept(double t, double u, double lo, double hi)
+{
+    const bool sure_yes = t >= hi, sure_no = t <= lo;        // (false for NaNs)
+    if (__builtin_expect(sure_yes || sure_no, 1))
+        return sure_yes;
+    return mc3_det_exp(t) > u;
+}
+
 // DEMC partners, chain.py:221-232: r1 != c, r2 != c, r2 != r1, from the two 32-bit
 // halves of one draw
 __device__ __forceinline__ void demc_partners(uint64_t q0, int n, int c, int &r1, int &r2)

@@ -80,6 +80,9 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
     // draws of the first refresh
     Draw2 d = draw2(P.seed, (uint64_t)R0, (uint32_t)c, 0u);
     double u = u01(d.q1);
+    // the Metropolis test in the log domain, decided ahead of time: see accept_window
+    double acc_lo, acc_hi;
+    accept_window(u, acc_lo, acc_hi);
     int r1, r2;
     demc_partners(d.q0, n, c, r1, r2);
     int off1 = r1 * ZS + kk, off2 = r2 * ZS + kk;
@@ -136,17 +139,18 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
         MC3_TICK(tkL);
         ta15 += tkL - tk0;
 #endif
-        const double u_now = u;
+        const double u_now = u, lo_now = acc_lo, hi_now = acc_hi;
         __builtin_amdgcn_sched_barrier(0);
         // ... and behind them everything of the next refresh that needs no chain state
         d = draw2(P.seed, (uint64_t)(R + 1), (uint32_t)c, 0u);
         pin_scalar(d.q0);
         pin_scalar(d.q1);
         u = u01(d.q1);                                               // chain.py:259
+        accept_window(u, acc_lo, acc_hi);
         demc_partners(d.q0, n, c, r1, r2);
         off1 = r1 * ZS + kk;
         off2 = r2 * ZS + kk;
-        asm volatile("; pin" : "+v"(u), "+v"(off1), "+v"(off2));
+        asm volatile("; pin" : "+v"(u), "+v"(off1), "+v"(off2), "+v"(acc_lo), "+v"(acc_hi));
         __builtin_amdgcn_sched_barrier(0);
 #ifdef MC3HIP_STAMPS
         alive = poll_ring<KR, LM>(addr, ring, val, ctl_rw, &ta14);
@@ -173,8 +177,8 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
             if constexpr (FX)
                 nextchisq = nextchisq + prior_from_lanes<MT>(P, npk, kf, fx);
             MC3_TICK(tk2);
-            const double ratio = mc3_det_exp(0.5 * (cur - nextchisq)) * 1.0;
-            const bool acc = ratio > u_now;                          // chain.py:257-274
+            const bool acc = metropolis_accept(0.5 * (cur - nextchisq), u_now, lo_now,
+                                               hi_now);             // chain.py:257-274
             xk = acc ? npk : xk;
             if (__builtin_expect(__any(acc && nextchisq < best), 0)) {
                 best = nextchisq;
@@ -244,6 +248,219 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
         P.stamps[14] += ta14; P.stamps[15] += ta15;
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------
+// The same loop with the data sum shared by NW waves on different SIMDs of the CU: with 256
+// chains the chip has three of its four SIMDs idle, and a wave alone issues dependent FP64 at
+// a fraction of the pipe's rate (tools/probes/mfma_f64_probe.hip), so the ~1000 cycles of the
+// 16-points-per-lane chisq are the longest compute stretch of the iteration.  Wave 0 is the
+// chain -- poll, proposal, Metropolis, publish, exactly as in lean_demc_kernel; waves 1..NW-1
+// are helpers that sleep at a barrier until wave 0 has put the proposed coefficients in LDS,
+// compute the partial sums of their virtual lanes (thread t owns virtual lanes t + 64 NW j:
+// the canonical order of DataTile<NW>, so the result is bit for bit the one-wave kernel's)
+// and hand them back through LDS.  Two raw barriers per iteration (LDS traffic only: no
+// vector-memory drain), no flag polling: a waiting wave costs its SIMD nothing.
+template <int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void lean_demc_wide_kernel(const DevProblem P, const int nref)
+{
+    static_assert(NW == 2 || NW == 4, "2 or 4 waves share the data sum");
+    constexpr int ZS = ZROW;
+    constexpr int NV = 16 / NW;
+    __shared__ double s_part[64 * NW];
+    __shared__ double s_cf[8];
+    __shared__ int s_cmd[2];                   // 0: compute, 1: nothing this time, 2: leave
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = blockIdx.x;
+    const int c = P.chain0 + lc;
+    long long *ctl_rw = const_cast<long long *>(P.ctl);
+    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
+            &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+        return;
+    // this thread's share of the (only) 1024-point tile: virtual lanes lane + 64 (wave + NW v)
+    DataTile<NW, MT> tile;
+    tile.load(P);
+    auto partial = [&](const double (&cf)[MT]) {
+        double acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            double m = cf[MT - 1];
+#pragma unroll
+            for (int j = MT - 2; j >= 0; --j)
+                m = mc3_fma(m, tile.x[v], cf[j]);
+            const double r = (m - tile.d[v]) * tile.w[v];
+            acc[v] = mc3_fma(r, r, 0.0);
+        }
+#pragma unroll
+        for (int s = NV / 2; s >= 1; s >>= 1) {
+#pragma unroll
+            for (int v = 0; v < s; ++v)
+                acc[v] = acc[v] + acc[v + s];
+        }
+        return acc[0];
+    };
+    if (wave != 0) {
+        // ---- helper waves -------------------------------------------------------------
+        for (;;) {
+            block_sync<NW>();                          // (A) the order of this iteration
+            const int cmd = s_cmd[0];
+            if (cmd == 2)
+                return;
+            if (cmd == 0) {
+                double cf[MT];
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    cf[j] = s_cf[j];
+                s_part[tid] = partial(cf);
+            }
+            block_sync<NW>();                          // (B) the partial sums are in LDS
+        }
+    }
+    // ---- wave 0: the chain ------------------------------------------------------------
+    const bool mine = lane < MT;
+    const int kk = mine ? lane : 0;
+    const long long R0 = P.ctl[0];
+    const int n = P.nchains;
+    const size_t blockstride = (size_t)n * ZS;
+    const double *pbase = (R0 == 0) ? P.snap0 : P.Z + (size_t)(P.M0 + (R0 - 1) * n) * ZS;
+    double *zblock = P.Z + (size_t)(P.M0 + R0 * n) * ZS;
+    double *lp_row = P.log_post + (P.M0 + R0 * n + c);
+    int32_t *zc_row = P.zchain + (P.M0 + R0 * n + c);
+    double xk = mine ? pbase[(size_t)c * ZS + lane] : 0.0;
+    double cur = P.chisq[lc];
+    double best = P.best_chisq[lc];
+    const long long nacc0 = P.numaccept[lc];
+    const double pmin_k = mine ? P.fmin[lane] : 0.0;
+    const double pmax_k = mine ? P.fmax[lane] : 0.0;
+    const double gamma = P.gamma;
+    const long long abort_at = (P.test_abort >= 0 && lc == 0) ? (long long)P.test_abort : -1;
+    int nacc = 0;
+    double lpbuf = 0.0;
+    Draw2 d = draw2(P.seed, (uint64_t)R0, (uint32_t)c, 0u);
+    double u = u01(d.q1);
+    double acc_lo, acc_hi;
+    accept_window(u, acc_lo, acc_hi);
+    int r1, r2;
+    demc_partners(d.q0, n, c, r1, r2);
+    int off1 = r1 * ZS + kk, off2 = r2 * ZS + kk;
+    const long long Rend = R0 + nref;
+    long long rdone = R0;
+    auto flush_columns = [&](int count) {
+        if (lane < count) {
+            lp_row[(size_t)lane * n] = lpbuf;
+            zc_row[(size_t)lane * n] = c;
+        }
+    };
+    auto order = [&](int cmd) {                        // tell the helpers and meet them at (A)
+        if (lane == 0)
+            s_cmd[0] = cmd;
+        block_sync<NW>();
+    };
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (long long R = R0; R < Rend; ++R) {
+        if (__builtin_expect(R == abort_at, 0)) {                                         // test hook
+            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        const double *const addr[2] = {pbase + off1, pbase + off2};
+        double val[2];
+        double ring[1][2];
+        ring[0][0] = load_published<0>(addr[0]);
+        ring[0][1] = load_published<0>(addr[1]);
+        const double u_now = u, lo_now = acc_lo, hi_now = acc_hi;
+        __builtin_amdgcn_sched_barrier(0);
+        d = draw2(P.seed, (uint64_t)(R + 1), (uint32_t)c, 0u);
+        pin_scalar(d.q0);
+        pin_scalar(d.q1);
+        u = u01(d.q1);
+        accept_window(u, acc_lo, acc_hi);
+        demc_partners(d.q0, n, c, r1, r2);
+        off1 = r1 * ZS + kk;
+        off2 = r2 * ZS + kk;
+        asm volatile("; pin" : "+v"(u), "+v"(off1), "+v"(off2), "+v"(acc_lo), "+v"(acc_hi));
+        __builtin_amdgcn_sched_barrier(0);
+        if (__builtin_expect(!poll_ring<1, 0>(addr, ring, val, ctl_rw), 0))
+            break;
+        const double npk = xk + (gamma * (val[0] - val[1]) + P.fepsilon * 0.0);
+        const bool outk = mine && (npk < pmin_k || npk > pmax_k);
+        if (__builtin_expect(!__any(outk), 1)) {
+            if (mine)
+                s_cf[lane] = npk;
+            order(0);                                  // (A)
+            double cf[MT];
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                cf[j] = read_lane(npk, j);
+            const double t0 = partial(cf);
+            block_sync<NW>();                          // (B)
+            double p[NW];
+            p[0] = t0;
+#pragma unroll
+            for (int w = 1; w < NW; ++w)
+                p[w] = s_part[lane + 64 * w];
+#pragma unroll
+            for (int s = NW / 2; s >= 1; s >>= 1) {
+#pragma unroll
+                for (int w = 0; w < s; ++w)
+                    p[w] = p[w] + p[w + s];
+            }
+            double nextchisq = wave_sum(p[0]);
+            if (__builtin_expect((mc3_bits(nextchisq) & 0x7ff0000000000000ull) ==
+                                 0x7ff0000000000000ull, 0)) {
+                // the "+inf model => chisq = inf" trap (chain.py:322-323), resolved lazily as in
+                // block_gauss_model: only a non-finite total has the model values scanned
+                Model<MT> model;
+                model.init_from_lanes(P, npk);
+                int saw = 0;
+                for (int i = lane; i < P.ndata; i += 64)
+                    saw |= is_pos_inf(model.at(i));
+                if (__any(saw))
+                    nextchisq = mc3_from_bits(0x7ff0000000000000ull);
+            }
+            const bool acc = metropolis_accept(0.5 * (cur - nextchisq), u_now, lo_now, hi_now);
+            xk = acc ? npk : xk;
+            if (__builtin_expect(__any(acc && nextchisq < best), 0)) {
+                best = nextchisq;
+                if (mine)
+                    P.bestx[(size_t)lc * MT + lane] = xk;
+                if (lane == 0)
+                    P.best_iter[lc] = R;
+            }
+            cur = acc ? nextchisq : cur;
+            nacc += acc ? 1 : 0;
+        } else {
+            if (outk)
+                atomicAdd(&P.outbounds[lane], 1ull);
+            order(1);                                  // (A): nothing to compute
+            block_sync<NW>();                          // (B)
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (mine)
+            __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        const int slot = (int)(R - R0) & 63;
+        lpbuf = (lane == slot) ? -0.5 * cur : lpbuf;
+        if (__builtin_expect(slot == 63, 0)) {
+            flush_columns(64);
+            lp_row += (size_t)64 * n;
+            zc_row += (size_t)64 * n;
+        }
+        pbase = zblock;
+        zblock += blockstride;
+        rdone = R + 1;
+    }
+    order(2);                                          // the helpers leave
+    flush_columns((int)(rdone - R0) & 63);
+    if (mine)
+        P.X[(size_t)lc * MT + lane] = xk;
+    if (lane == 0) {
+        P.chisq[lc] = cur;
+        P.best_chisq[lc] = best;
+        P.numaccept[lc] = nacc0 + nacc;
+    }
 }
 
 }  // namespace mc3hip

@@ -222,11 +222,19 @@ size_t fast_smem(const mc3hip_ctx *c)
 
 // (several chains per workgroup, run_chain MC: a smaller grid, the chains' waiting state in
 // dynamic LDS behind the kernel's own areas; decide_persist sets the three numbers)
+// threads of a workgroup of the lean instance that runs: one wave, except where helper waves
+// share a chain's data sum (ctx.h lean_waves)
+int fast_threads(const mc3hip_ctx *c, bool p2p)
+{
+    return (p2p || c->mc_chains > 0) ? 64 : 64 * lean_waves(c);
+}
+
 void launch_fast(mc3hip_ctx *c, int nref)
 {
-    const bool mc = c->mc_chains > 0;
-    hipLaunchKernelGGL(fast_instance(c, c->p2p_ranks > 1), dim3(mc ? c->mc_grid : c->P.nlocal),
-                       dim3(64), mc ? c->mc_smem : fast_smem(c), c->stream, c->P, nref);
+    const bool mc = c->mc_chains > 0, p2p = c->p2p_ranks > 1;
+    hipLaunchKernelGGL(fast_instance(c, p2p), dim3(mc ? c->mc_grid : c->P.nlocal),
+                       dim3(fast_threads(c, p2p)), mc ? c->mc_smem : fast_smem(c), c->stream,
+                       c->P, nref);
 }
 
 int blocks_per_cu(const void *kernel, int threads, size_t smem)
@@ -242,8 +250,8 @@ int blocks_per_cu(const void *kernel, int threads, size_t smem)
 int fast_blocks_per_cu(mc3hip_ctx *c)
 {
     const bool p2p = c->p2p_ranks > 1;
-    int nb = blocks_per_cu(reinterpret_cast<const void *>(fast_instance(c, p2p)), 64,
-                           fast_smem(c));
+    int nb = blocks_per_cu(reinterpret_cast<const void *>(fast_instance(c, p2p)),
+                           fast_threads(c, p2p), fast_smem(c));
     if ((c->flags & MC3HIP_FLAG_P2P) && !p2p) {
         const int np = blocks_per_cu(reinterpret_cast<const void *>(fast_instance(c, true)),
                                      64, fast_smem(c));
@@ -412,6 +420,15 @@ int decide_persist(mc3hip_ctx *c)
     }
     int nb = 0;
     c->fast = fast_eligible(c);
+    // helper waves for the hand-laid-out DEMC loop while the chip has SIMDs to spare: four
+    // waves per chain up to one chain per CU, two up to two (measured: tools/lean_waves.py)
+    c->lean_waves_default = 1;
+    if (c->fast && !getenv("MC3HIP_NO_LEAN_HELPERS")) {
+        hipDeviceProp_t pr;
+        const int cus = hipGetDeviceProperties(&pr, c->device) == hipSuccess
+                            ? pr.multiProcessorCount : 256;
+        c->lean_waves_default = c->P.nlocal <= cus ? 4 : (c->P.nlocal <= 2 * cus ? 2 : 1);
+    }
     if (c->fast)
         nb = fast_blocks_per_cu(c);
     else
@@ -1024,6 +1041,8 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
     plan->graph_nodes = c->graph_nodes;
     plan->persistent = c->comm ? 0 : decide_persist(const_cast<mc3hip_ctx *>(c));
     plan->fast = (plan->persistent > 0 && c->fast) ? (lean_demc_eligible(c) ? 2 : 1) : 0;
+    if (plan->fast == 2 && c->p2p_ranks <= 1)
+        plan->waves_per_chain = lean_waves(c);      // (helper waves share the data sum)
     plan->tile_tree = tile_uses_mfma(c) ? 1 : 0;
     plan->resident = (plan->persistent > 0 && c->resident) ? 1 : 0;
     plan->comm_graph = c->cgraph_exec ? c->comm_graph_nodes : 0;

@@ -753,3 +753,70 @@ def test_persistent_launch_gives_up_and_run_is_redone(eng, sampler):
     np.testing.assert_array_equal(st['outbounds'], orc.outbounds)
     np.testing.assert_array_equal(st['best_chisq'], orc.best_chisq)
     gpu.close()
+
+
+@pytest.mark.parametrize('waves', ['1', '2', '4'])
+@pytest.mark.parametrize('case', ['quad', 'line', 'cubic', 'tight', 'ragged'])
+def test_lean_demc_with_helper_waves(eng, monkeypatch, waves, case):
+    """The hand-laid-out DEMC loop with the data sum of a chain shared by 2 or 4 waves
+    (lean_demc_wide_kernel): the canonical summation order is that of one wave, so the runs
+    are identical to the oracle's whatever the number of waves; boundaries that reject most
+    proposals (the helpers are told to sit the iteration out), fewer points than lanes."""
+    monkeypatch.setenv('MC3HIP_LEAN_WAVES', waves)
+    if case == 'quad':
+        prob = H.quad_problem(ndata=1000, nchains=40, nsamples=40*300)
+    elif case == 'ragged':
+        prob = H.quad_problem(ndata=37, nchains=9, nsamples=9*400)
+    elif case == 'tight':
+        prob = H.quad_problem(ndata=200, nchains=12, nsamples=12*400)
+        prob.update(params=np.array([4.0, -2.5, 0.5]), pmin=np.array([3.5, -2.8, 0.45]),
+                    pmax=np.array([6.5, -2.2, 0.56]))
+    else:
+        ncoef = 2 if case == 'line' else 4
+        x, data, uncert = H.tutorial_data(600)
+        prob = dict(data=data, uncert=uncert, indep=x/10.0,
+                    params=np.array([3.0, -20.0, 40.0, 5.0][:ncoef]),
+                    pstep=np.array([0.5, 1.0, 2.0, 1.0][:ncoef]), nchains=16,
+                    nsamples=16*300, sampler='demc', model='poly', seed=9)
+    orc, gpu = run_pair(eng, prob, trace=False)
+    plan = gpu.plan
+    assert plan['fast'] == 2 and plan['persistent'] > 0 and plan['recoveries'] == 0, plan
+    assert plan['waves_per_chain'] == int(waves), plan
+    assert_same(orc, gpu, trace=False)
+    if case == 'tight':
+        assert gpu.state()['outbounds'].sum() > 1000
+    gpu.close()
+
+
+@pytest.mark.parametrize('waves', ['2', '4'])
+def test_lean_demc_helper_waves_resume_abort_and_nonfinite(eng, monkeypatch, waves):
+    monkeypatch.setenv('MC3HIP_LEAN_WAVES', waves)
+    # several launches: the helpers leave and come back with every launch
+    prob = H.quad_problem(ndata=1000, nchains=24, nsamples=24*200)
+    gpu = eng.DeviceChains(**prob)
+    orc = H.make_oracle(prob, plan=gpu.plan)
+    Z0, lp0 = H.initial_population(orc)
+    orc.set_population(Z0, lp0)
+    gpu.set_population(Z0, lp0)
+    orc.run(nthreads=4)
+    for n in (1, 2, 64, 65, 68):
+        gpu.run(n)
+    assert gpu.plan['waves_per_chain'] == int(waves)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+    # a launch that gives up (test hook) is redone from the checkpoint
+    monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '21')
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert gpu.plan['recoveries'] == 1
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+    monkeypatch.delenv('MC3HIP_TEST_ABORT_AT')
+    # model values that overflow: +inf chisq, never accepted, as the oracle says
+    x, data, uncert = H.tutorial_data(500)
+    prob = dict(data=data, uncert=uncert, indep=x*1e150, params=np.array([3.0, -2.4, 0.5]),
+                pstep=np.array([1.0, 0.5, 1e10]), nchains=8, nsamples=8*100, sampler='demc',
+                model='poly', seed=4)
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert gpu.plan['waves_per_chain'] == int(waves)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
