@@ -146,9 +146,8 @@ inline bool lean_demc_eligible(const mc3hip_ctx *c)
 
 // waves that share the data sum of a chain in the hand-laid-out DEMC loop (kernels_lean.h
 // lean_demc_wide_kernel): 1, 2 or 4.  Several only for the plain headline shape -- every
-// coefficient free, one tile, one GPU -- and only while the chip has SIMDs to spare
-// (at most one chain per CU and helper: beyond that the waves of other chains fill them
-// better).  MC3HIP_LEAN_WAVES=1|2|4 overrides.
+// coefficient free, one tile, one GPU -- and only on request (MC3HIP_LEAN_WAVES=2|4): measured
+// slower than one wave (mc3hip.hip decide_persist).
 inline int lean_waves(const mc3hip_ctx *c)
 {
     const DevProblem &P = c->P;

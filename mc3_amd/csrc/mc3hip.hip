@@ -420,15 +420,13 @@ int decide_persist(mc3hip_ctx *c)
     }
     int nb = 0;
     c->fast = fast_eligible(c);
-    // helper waves for the hand-laid-out DEMC loop while the chip has SIMDs to spare: four
-    // waves per chain up to one chain per CU, two up to two (measured: tools/lean_waves.py)
+    // Helper waves for the hand-laid-out DEMC loop (lean_demc_wide_kernel) are NOT the
+    // default: measured on MI355X (tools/lean_waves.py, profiles/r03_lean_waves.jsonl) two /
+    // four waves per chain run C2 at 203 / 207 M chain-steps/s against 219 for one -- the two
+    // barriers and the LDS round trips of the exchange cost more than the three quarters of
+    // the FP64 stream they take off wave 0 -- at every ensemble size from 64 to 1024 chains.
+    // MC3HIP_LEAN_WAVES=2|4 selects them (bit-identical results).
     c->lean_waves_default = 1;
-    if (c->fast && !getenv("MC3HIP_NO_LEAN_HELPERS")) {
-        hipDeviceProp_t pr;
-        const int cus = hipGetDeviceProperties(&pr, c->device) == hipSuccess
-                            ? pr.multiProcessorCount : 256;
-        c->lean_waves_default = c->P.nlocal <= cus ? 4 : (c->P.nlocal <= 2 * cus ? 2 : 1);
-    }
     if (c->fast)
         nb = fast_blocks_per_cu(c);
     else
