@@ -98,7 +98,9 @@ struct DevProblem {
     int32_t mc_chains, mc_off;
 };
 
-constexpr int PH_FUSED = 0, PH_PROPOSE = 1, PH_FINISH = 2, PH_RESIDENT = 3;
+constexpr int PH_FUSED = 0, PH_PROPOSE = 1, PH_FINISH = 2, PH_RESIDENT = 3, PH_CHAINWAVE = 4;
+// the phases in which ONE wave runs the chain and the data term comes back through a hook
+constexpr bool phase_hooked(int phase) { return phase == PH_RESIDENT || phase == PH_CHAINWAVE; }
 constexpr int RS_ROW = 16;          // doubles per published proposal row: one 128-byte line
 constexpr int RS_WCAP = 256;        // chains whose group totals a workgroup collects in LDS
                                     // before it adds them up (resident tiled plan)
@@ -150,6 +152,11 @@ extern __shared__ __attribute__((aligned(16))) double mc3_smem_stamps_[];
                 P.stamps[q_] = reinterpret_cast<unsigned long long *>(                    \
                     mc3_smem_stamps_)[blockDim.x + MC3HIP_MAX_PARAMS + 2 + 32 + q_];      \
     } while (0)
+#endif
+#ifdef MC3HIP_TICKS_ONLY
+// (the draining stamps perturb what the tick sums measure: a ticks-only diagnostic build)
+#undef MC3_STAMP
+#define MC3_STAMP(slot) do { } while (0)
 #endif
 #else
 #define MC3_STAMP(slot) do { } while (0)

@@ -41,6 +41,8 @@ struct mc3hip_ctx {
     int persist_refs = 0;           // refreshes per persistent launch, 0 = off
     bool persist_checked = false;
     bool fast = false;              // lean persistent instance selected
+    bool chainwave = false;         // wavelet likelihood, eight waves: a ninth runs the chain
+                                    // (kernels_wavelet.h wavelet_cw_kernel)
     int lean_waves_default = 1;     // waves per chain of the hand-laid-out DEMC loop (ctx.h
                                     // lean_waves), decided with the grid in decide_persist
     int mc_chains = 0;              // chains a workgroup of the persistent kernel advances per
@@ -89,6 +91,15 @@ typedef void (*chain_kernel_fn)(const DevProblem, const int);
 typedef void (*resident_kernel_fn)(const DevProblem, const int, const int);
 
 constexpr int WL_EVAL_BLOCKS = 256;
+
+// the wavelet kernel with a wave of its own for the chain (kernels_wavelet.h): nine waves, and
+// behind the compute waves' LDS areas the chain wave's own area, the command word, the result
+constexpr int CW_THREADS = 576;
+constexpr int CW_EXTRA_DOUBLES = 64 + MC3HIP_MAX_PARAMS + 2 + 48 + 4 + 4;
+inline bool chainwave_runs(const mc3hip_ctx *c, bool p2p)
+{
+    return c->chainwave && c->mc_chains == 0 && !p2p;
+}
 
 // Waves per chain are dispatched as {1, 4, 16}; the wavelet geometries have 1, 4 or 8:
 // the widest one rides on the dispatch slot of the widest Gaussian one.

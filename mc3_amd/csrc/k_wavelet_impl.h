@@ -6,6 +6,7 @@
 #include "ctx.h"
 #include "kernels_fused.h"
 #include "wavelet.h"
+#include "kernels_wavelet.h"
 
 #define MC3_CAT_(a, b) a##b
 #define MC3_CAT(a, b) MC3_CAT_(a, b)
@@ -34,6 +35,15 @@ template <int MT>
 void persist_instance_t(const mc3hip_ctx *c, bool p2p, chain_kernel_fn *out)
 {
     const bool mc = c->mc_chains > 0 && !p2p;          // several chains per workgroup
+    if constexpr (WW == 8 && !LARGE) {
+        static_assert(CW_EXTRA == CW_EXTRA_DOUBLES, "LDS of the chain wave");
+        if (chainwave_runs(c, p2p)) {                   // a wave of its own for the chain
+            *out = c->P.sampler == MC3HIP_SNOOKER ? wavelet_cw_kernel<MT, MC3HIP_SNOOKER>
+                   : c->P.sampler == MC3HIP_DEMC ? wavelet_cw_kernel<MT, MC3HIP_DEMC>
+                                                 : wavelet_cw_kernel<MT, MC3HIP_MRW>;
+            return;
+        }
+    }
     *out = p2p ? persist_kernel<WW, MT, true, LARGE, true>
                : mc ? persist_kernel<WW, MT, true, LARGE, false, true>
                     : persist_kernel<WW, MT, true, LARGE>;

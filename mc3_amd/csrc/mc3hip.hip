@@ -325,11 +325,22 @@ hipError_t set_smem_attr_wavelet(mc3hip_ctx *c)
 #undef W
 }
 
+// threads and dynamic LDS of the general persistent instance that runs
+int persist_threads(const mc3hip_ctx *c, bool p2p)
+{
+    return chainwave_runs(c, p2p) ? CW_THREADS : 64 * c->wpc;
+}
+size_t persist_smem(const mc3hip_ctx *c, bool p2p)
+{
+    return chainwave_runs(c, p2p) ? c->smem + CW_EXTRA_DOUBLES * sizeof(double) : c->smem;
+}
+
 void launch_persist(mc3hip_ctx *c, int nref)
 {
-    const bool mc = c->mc_chains > 0;
-    hipLaunchKernelGGL(persist_instance(c, c->p2p_ranks > 1), dim3(mc ? c->mc_grid : c->P.nlocal),
-                       dim3(64 * c->wpc), mc ? c->mc_smem : c->smem, c->stream, c->P, nref);
+    const bool mc = c->mc_chains > 0, p2p = c->p2p_ranks > 1;
+    hipLaunchKernelGGL(persist_instance(c, p2p), dim3(mc ? c->mc_grid : c->P.nlocal),
+                       dim3(persist_threads(c, p2p)), mc ? c->mc_smem : persist_smem(c, p2p),
+                       c->stream, c->P, nref);
 }
 
 // workgroups of the general persistent kernel that fit on one CU (0 on error)
@@ -337,9 +348,10 @@ void persist_blocks_per_cu(mc3hip_ctx *c, int *out)
 {
     const bool p2p = c->p2p_ranks > 1;
     const void *f = reinterpret_cast<const void *>(persist_instance(c, p2p));
-    if (c->smem > 64 * 1024)
-        (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->smem);
-    int nb = blocks_per_cu(f, 64 * c->wpc, c->smem);
+    if (persist_smem(c, p2p) > 64 * 1024)
+        (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)persist_smem(c, p2p));
+    int nb = blocks_per_cu(f, persist_threads(c, p2p), persist_smem(c, p2p));
     if ((c->flags & MC3HIP_FLAG_P2P) && !p2p) {
         const void *g = reinterpret_cast<const void *>(persist_instance(c, true));
         if (c->smem > 64 * 1024)
@@ -420,6 +432,10 @@ int decide_persist(mc3hip_ctx *c)
     }
     int nb = 0;
     c->fast = fast_eligible(c);
+    // wavelet likelihood with eight waves per chain: a ninth wave runs the chain
+    c->chainwave = c->P.wlike && c->wpc == 8 && !c->P.wl_scratch &&
+                   !(c->flags & MC3HIP_FLAG_P2P) && !getenv("MC3HIP_NO_CHAINWAVE") &&
+                   c->smem + CW_EXTRA_DOUBLES * sizeof(double) <= 160 * 1024;
     // Helper waves for the hand-laid-out DEMC loop (lean_demc_wide_kernel) are NOT the
     // default: measured on MI355X (tools/lean_waves.py, profiles/r03_lean_waves.jsonl) two /
     // four waves per chain run C2 at 203 / 207 M chain-steps/s against 219 for one -- the two

@@ -34,6 +34,10 @@ struct NoHook {};
 // PH_RESIDENT (resident tiled plan, see ResidentTile): this WAVE owns chain `own_chain` of a
 // workgroup whose waves all take part in the tile phase of every iteration; the data sums
 // come back through `hook`; the wave leaves the loop only when the whole workgroup does.
+// PH_CHAINWAVE (wavelet likelihood, kernels_wavelet.h): this wave does nothing but run the
+// chain; the other waves of the workgroup compute the likelihood of every proposal it
+// publishes.  As PH_RESIDENT, but the wave's registers are its own: snooker rows are asked
+// for an iteration ahead.
 // MC (persistent only): the ensemble has more chains than workgroups can be co-resident, so a
 // workgroup owns SEVERAL chains -- local chains b, b + G, b + 2 G, ... of a grid of G
 // workgroups, P.mc_chains at most -- and advances them one after another inside every
@@ -55,7 +59,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
 {
     if (je < 0)
         je = P.thinning;
-    static_assert(PHASE != PH_RESIDENT || (WPC == 1 && PERSIST && !FAST && !WL),
+    static_assert(!phase_hooked(PHASE) || (WPC == 1 && PERSIST && !FAST && !WL),
                   "the resident tiled plan runs the general one-wave persistent chain");
     static_assert(!FAST || (WPC == 1 && !WL && SMP >= 0 && MT >= 1 && MT <= 8),
                   "FAST needs one wave, Gaussian chisq, a compile-time sampler and degree");
@@ -63,11 +67,11 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                   "several chains per workgroup: the one-GPU persistent kernels");
     const int sampler = (SMP >= 0) ? SMP : P.sampler;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const SmemLayout L = carve(PHASE == PH_RESIDENT ? own_smem : smem, P, 64 * WPC);
+    const SmemLayout L = carve(phase_hooked(PHASE) ? own_smem : smem, P, 64 * WPC);
     MC3_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const bool wave0 = (WPC == 1) ? true : (tid < 64);
-    int lc = (PHASE == PH_RESIDENT) ? own_chain : blockIdx.x;   // local chain (MC: of the turn)
+    int lc = (phase_hooked(PHASE)) ? own_chain : blockIdx.x;   // local chain (MC: of the turn)
     int c = P.chain0 + lc;                     // global chain id
     const int nf = P.nfree;
     const int zs = P.zs;                       // row stride of Z / snap0 (padded lines)
@@ -139,7 +143,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
         coefficient_map<NKF>(P, kf, fx);
     (void)kf; (void)fx;
 
-    if constexpr (PERSIST && PHASE != PH_RESIDENT) {     // (resident: the kernel has looked)
+    if constexpr (PERSIST && !phase_hooked(PHASE)) {     // (resident: the kernel has looked)
         // a launch queued behind one that gave up must not run: its inputs are missing
         if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
                 &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
@@ -195,6 +199,25 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     (void)ta8; (void)ta9; (void)ta10; (void)ta11; (void)ta12; (void)ta13;
     bool give_up = false;                       // resident plan: test hook fired
     (void)give_up;
+    auto normal_draw = [&](uint64_t it, int ch) {
+        double nk = 0.0;
+        if (mine) {
+            const Draw2 d = draw2(P.seed, it, (uint32_t)ch, (uint32_t)(3 + (lane >> 1)));
+            const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(d.q0)));
+            double sn, cs;
+            mc3_det_sincos2pi(u01(d.q1), &sn, &cs);
+            nk = (rad * ((lane & 1) ? sn : cs)) * pstep_k;
+        }
+        return nk;
+    };
+    // PH_CHAINWAVE: what was prepared for the next iteration while the other waves computed
+    double normal_ahead = 0.0;
+    uint64_t normal_ahead_iter = ~0ull;
+    double acc_lo = 0.0, acc_hi = 0.0;          // the Metropolis test in the log domain
+    double jump_ahead = 0.0;                    // snooker: the next ordinary jump
+    uint64_t jump_ahead_iter = ~0ull;
+    (void)normal_ahead; (void)normal_ahead_iter; (void)acc_lo; (void)acc_hi;
+    (void)jump_ahead; (void)jump_ahead_iter;
     // the iteration that follows (iter, this chain) in this workgroup's order, and its chain;
     // new_refresh: it belongs to the next refresh (whose history holds this refresh's rows)
     auto draws_ahead = [&](uint64_t iter, bool last_of_refresh, int q, bool &new_refresh) {
@@ -224,7 +247,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
         if (P.test_abort >= 0 && R == P.test_abort && (MC ? blockIdx.x == 0 : lc == 0)) {     // test hook
             __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);             // (all lanes, same word)
-            if constexpr (PHASE == PH_RESIDENT)
+            if constexpr (phase_hooked(PHASE))
                 give_up = true;                 // (leaves with its workgroup, below)
             else
                 return;
@@ -274,16 +297,19 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
         // Metropolis draw, chain.py:259
         u = (sampler == MC3HIP_SNOOKER) ? u01(d2.q1) : u01(d0.q1);
         if (PHASE != PH_FINISH && wave0) {
-            // support-distribution draw, chain.py:185
+            // support-distribution draw, chain.py:185 (the chain wave of PH_CHAINWAVE has
+            // drawn it while the likelihood of the iteration before was computed)
             double normal_k = 0.0;
-            if (need_normal && mine) {
-                const Draw2 d = draw2(P.seed, iter, (uint32_t)c, (uint32_t)(3 + (lane >> 1)));
-                const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(d.q0)));
-                double sn, cs;
-                mc3_det_sincos2pi(u01(d.q1), &sn, &cs);
-                normal_k = (rad * ((lane & 1) ? sn : cs)) * pstep_k;
+            if (need_normal) {
+                if (PHASE == PH_CHAINWAVE && normal_ahead_iter == iter)
+                    normal_k = normal_ahead;
+                else
+                    normal_k = normal_draw(iter, c);
             }
             double jump_k = 0.0;
+            if (PHASE == PH_CHAINWAVE && sampler == MC3HIP_SNOOKER && jump_ahead_iter == iter) {
+                jump_k = jump_ahead;                               // (formed during the likelihood)
+            } else
             if (sampler == MC3HIP_SNOOKER) {                       // chain.py:195-217
                 long long iR1 = (long long)bounded(d0.q0, (uint64_t)zsize);
                 long long iR2 = 1 + (long long)bounded(d0.q1, (uint64_t)(zsize - 1));
@@ -303,16 +329,20 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                     }
                     const double *const addr[3] = {sa[0], sa[1], sa[2]};
                     double val[3] = {sv[0], sv[1], sv[2]};
-                    bool ahead_new_refresh;
-                    nxt = draws_ahead(iter, TH == 1 || j + 1 == jlast, q, ahead_new_refresh);
+                    bool ahead_new_refresh = false;
+                    if constexpr (PHASE != PH_CHAINWAVE)
+                        nxt = draws_ahead(iter, TH == 1 || j + 1 == jlast, q, ahead_new_refresh);
                     alive = wait_rows<3, P2P>(addr, val, ctl_rw);
-                    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see lean_demc_kernel
+                    // (the chain wave: these rows arrived during the likelihood before last; a
+                    // wait here would only wait for the Z row just published)
+                    if constexpr (PHASE != PH_CHAINWAVE)
+                        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see lean_demc_kernel
                     z1 = val[0];
                     z2 = val[1];
                     zk = val[2];
                     // the next iteration's rows: its history also holds this refresh's rows
                     // once this iteration is the last of the refresh
-                    if (SNOOKER_AHEAD && alive)
+                    if (SNOOKER_AHEAD && PHASE != PH_CHAINWAVE && alive)
                         request_snooker(nxt, ahead_new_refresh ? zsize + P.nchains : zsize);
                 } else {
                     z1 = mine ? P.Z[(size_t)iR1 * zs + lane] : 0.0;
@@ -337,7 +367,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 }
             } else if (sampler == MC3HIP_MRW) {                    // chain.py:219-220
                 jump_k = normal_k;
-                if constexpr (PERSIST) {
+                if constexpr (PERSIST && PHASE != PH_CHAINWAVE) {
                     bool unused;
                     nxt = draws_ahead(iter, TH == 1 || j + 1 == jlast, q, unused);
                 }
@@ -381,6 +411,10 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 }
                 jump_k = P.gamma * (x1 - x2) + P.fepsilon * normal_k;
             }
+#ifdef MC3HIP_STAMPS
+            if (tk1 == 0)
+                MC3_TICK(tk1);               // (samplers without a poll: the jump is known)
+#endif
             // proposal and boundaries, chain.py:235-243
             npk = xk + jump_k;
             outk = mine && (npk < pmin_k || npk > pmax_k);
@@ -402,7 +436,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 L.flag[0] = anyout ? 1 : 0;
                 L.flag[2] = alive ? 1 : 0;
             }
-            if constexpr (PHASE == PH_RESIDENT) {
+            if constexpr (phase_hooked(PHASE)) {
                 __builtin_amdgcn_wave_barrier();
                 hook->publish(P, lc, L.nextp);
                 MC3_TICK(tkP);
@@ -457,9 +491,47 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
             else
                 MC3_STAMP(2);
             anyout = L.flag[0] != 0;
-            if constexpr (PHASE == PH_RESIDENT) {
+            if constexpr (phase_hooked(PHASE)) {
                 // the tile phase of this iteration, with the whole workgroup; false for all of
                 // its waves once one of them has given up
+                if constexpr (PHASE == PH_CHAINWAVE) {
+                    hook->skip = anyout;       // (nothing to compute for a proposal out of bounds)
+                    // what the chain wave does while the other waves compute the likelihood:
+                    // everything of the NEXT iteration that needs no chain state, and the
+                    // logarithm this iteration's Metropolis test will be decided with
+                    const bool last_j = (TH == 1 || j + 1 == jlast);
+                    auto prepare = [&]() {
+                        accept_window(u, acc_lo, acc_hi);
+                        if (sampler != MC3HIP_DEMC) {
+                            bool new_refresh;
+                            nxt = draws_ahead(iter, last_j, q, new_refresh);
+                            if (sampler == MC3HIP_SNOOKER)
+                                request_snooker(nxt, new_refresh ? zsize + P.nchains : zsize);
+                        }
+                        if (need_normal) {
+                            normal_ahead = normal_draw(iter + 1, c);
+                            normal_ahead_iter = iter + 1;
+                        }
+                        if (sampler == MC3HIP_SNOOKER) {
+                            // the next iteration's jump itself, when it is an ordinary one
+                            // (chain.py:216-217; nine in ten) and its two rows are there: it
+                            // needs no chain state, and the likelihood takes longer than the
+                            // rows' round trip
+                            jump_ahead_iter = ~0ull;
+                            if (!(u01(nxt.d1.q0) < 0.1)) {
+                                __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
+                                const bool there = !__any(mc3_bits(sv[0]) == ROW_PENDING ||
+                                                          mc3_bits(sv[1]) == ROW_PENDING);
+                                if (there) {
+                                    jump_ahead = P.gamma * (sv[0] - sv[1]) +
+                                                 P.fepsilon * (need_normal ? normal_ahead : 0.0);
+                                    jump_ahead_iter = iter + 1;
+                                }
+                            }
+                        }
+                    };
+                    alive = hook->tile_phase(P, (L.flag[2] != 0) && !give_up, prepare);
+                } else
                 alive = hook->tile_phase(P, (L.flag[2] != 0) && !give_up);
                 MC3_TICK(tkT);
                 if (!alive)
@@ -471,7 +543,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
             }
         }
         double tile_total = 0.0;
-        if constexpr (PHASE == PH_RESIDENT)
+        if constexpr (phase_hooked(PHASE))
             tile_total = hook->collect(P, lc);  // (also of a proposal that is out of bounds:
                                                 // the sums must be seen before the row is reused)
         (void)tile_total;
@@ -494,7 +566,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                     nextchisq = nextchisq + prior_from_lanes<NKF>(P, npk, kf, fx);
             } else if constexpr (PHASE == PH_FINISH) {
                 nextchisq = finish_chisq<MT>(P, lc);
-            } else if constexpr (PHASE == PH_RESIDENT) {
+            } else if constexpr (phase_hooked(PHASE)) {
                 nextchisq = hook->template finish<MT>(P, tile_total, L.nextp);
             } else {
                 nextchisq = block_chisq<WPC, MT, WL, MULTI>(P, L.nextp, L.part, L.flag, L.tab,
@@ -512,8 +584,12 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                     const double nnorm = lane_serial_sum(mine ? dn * dn : 0.0, nf);
                     mrfactor = mc3_det_pow_half(nnorm / cnorm, nf - 1);
                 }
-                const double ratio = mc3_det_exp(0.5 * (cur - nextchisq)) * mrfactor;
-                if (ratio > u) {                                     // chain.py:257-274
+                bool accepted;
+                if (PHASE == PH_CHAINWAVE && !sjump)                 // (mrfactor = 1 exactly)
+                    accepted = metropolis_accept(0.5 * (cur - nextchisq), u, acc_lo, acc_hi);
+                else
+                    accepted = mc3_det_exp(0.5 * (cur - nextchisq)) * mrfactor > u;
+                if (accepted) {                                      // chain.py:257-274
                     flags |= 2;
                     xk = npk;
                     cur = nextchisq;
@@ -558,7 +634,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
             ta9 += tk2 - tk1;      // -> chisq reduced
             ta10 += tk3 - tk2;     // -> end of iteration (accept; publish is after)
             ta12 += 1;
-            if constexpr (PHASE == PH_RESIDENT) {
+            if constexpr (phase_hooked(PHASE)) {
                 tr0 += tkP - tk1;  // rows arrived -> proposal published
                 tr1 += tkT - tkP;  // -> tile phase done (waits for the column's other owners)
                 tr2 += tkC - tkT;  // -> all tiles' sums collected
@@ -638,11 +714,13 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     }
     MC3_STAMP(4);
 #ifdef MC3HIP_STAMPS
-    if (PERSIST && threadIdx.x == 0 && blockIdx.x == 0 && (PHASE != PH_RESIDENT || lc == 0)) {
+    if (PERSIST && (phase_hooked(PHASE) ? (lane == 0 && lc == 0 && blockIdx.y == 0 &&
+                                           (PHASE == PH_CHAINWAVE || threadIdx.x == 0))
+                                        : (threadIdx.x == 0 && blockIdx.x == 0))) {
         P.stamps[8] += ta8; P.stamps[9] += ta9; P.stamps[10] += ta10;
         P.stamps[11] += ta11; P.stamps[12] += ta12; P.stamps[13] += ta13;
         P.stamps[14] += ta14; P.stamps[15] += ta15;
-        if constexpr (PHASE == PH_RESIDENT) {
+        if constexpr (phase_hooked(PHASE)) {
             P.stamps[16] += tr0; P.stamps[17] += tr1; P.stamps[18] += tr2; P.stamps[19] += tr3;
         }
     }

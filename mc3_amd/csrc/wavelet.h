@@ -233,7 +233,12 @@ __device__ __forceinline__ void wavelet_noise_terms(const double *s_nextp, int n
 // `values` (large data sets): the blocks are cut from that array of B T values -- the
 // output of `npre` pre-levels whose per-thread sums of squared details arrive in accP --
 // instead of from the residuals.
-template <int WPC, int MT, int B, bool VALUES = false>
+// CW (chain-wave kernels, kernels_wavelet.h): the workgroup has one more wave, which runs the
+// chain and has left the noise terms in s_tab BEFORE the first halo barrier of stage A (it
+// takes part in every workgroup barrier here, doing nothing in between): a thread folds its
+// stage-A sums with the weights right away, and the two barriers that waited for the noise
+// terms and for those sums are gone.
+template <int WPC, int MT, int B, bool VALUES = false, bool CW = false>
 __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double *s_nextp,
                                                double *s_part, int *s_flag, double *s_tab,
                                                double *s_halo, const double *xs,
@@ -303,8 +308,10 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
         ubuf[tid] = v[0];
         if (sawinf)
             s_flag[1] = 1;
+        if constexpr (CW)
+            s_part[tid] = (active && N >= 4) ? stage_a_sum() : 0.0;
         block_sync<WPC>();                              // (1) the T values are in LDS
-        if (wave == WPC - 1)
+        if (!CW && wave == WPC - 1)
             wavelet_noise_terms(s_nextp, P.nparams, M, s_tab);
         if (wave == 0) {
             // ---- stage B: T values, WPC per lane, levels inside the lane -----------------
@@ -352,9 +359,11 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
     MC3_LSTAMP(12);
     double Tsum;
     if constexpr (WPC > 1) {
-        block_sync<WPC>();                              // (2) the noise terms are in LDS
-        s_part[tid] = (active && N >= 4) ? stage_a_sum() : 0.0;
-        block_sync<WPC>();                              // (3) every thread's stage-A sum
+        if constexpr (!CW) {
+            block_sync<WPC>();                          // (2) the noise terms are in LDS
+            s_part[tid] = (active && N >= 4) ? stage_a_sum() : 0.0;
+            block_sync<WPC>();                          // (3) every thread's stage-A sum
+        }
         if (wave != 0)
             return 0.0;                                 // the value is only used by wave 0
         double p[WPC];

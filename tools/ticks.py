@@ -56,6 +56,41 @@ if len(sys.argv) > 1 and sys.argv[1] in ('c5', 'q5'):
         print(f'  {k:62s} {v/n:9.0f} cycles')
     print(f'  {"sum":62s} {sum(v for _, v in rows)/n:9.0f}')
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == 'c4cw':
+    # python tools/ticks.py c4cw [sampler]    C4 with the chain-wave kernel: phases of the chain
+    # wave of workgroup 0 (kernels_wavelet.h)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import helpers as H
+    import tools_pop
+    NIT = 4000
+    smp = sys.argv[2] if len(sys.argv) > 2 else 'snooker'
+    prob = H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*(NIT + 600), sampler=smp)
+    g = engine.DeviceChains(**prob)
+    Z0, lp0 = tools_pop.population(g)
+    g.set_population(Z0, lp0)
+    g.run(500)
+
+    def stamps(page):
+        os.environ['MC3HIP_STAMP_PAGE'] = str(page)
+        out = (ctypes.c_uint64*16)()
+        _lib.check(g.lib.mc3hip_debug_stamps(g._ctx, out))
+        return np.array(out[:], dtype=np.float64)
+    a0, a1 = stamps(0), stamps(1)
+    g.run(NIT)
+    b0, b1 = stamps(0) - a0, stamps(1) - a1
+    n = b0[12]
+    print(f'{smp}: plan={g.plan}; iterations sampled (in bounds, chain 0): {int(n)}; '
+          f'wall {g.last_run_ms()*1e3/NIT:.2f} us per iteration')
+    rows = [('top -> jump known (rows arrived)', b0[8]), ('-> proposal published', b1[0]),
+            ('-> likelihood done (the compute waves)', b1[1]),
+            ('-> result collected', b1[2]), ('-> chisq known (priors)', b1[3]),
+            ('-> end of iteration (accept)', b0[10]), ('-> row published', b0[11]),
+            ('-> top of next iteration', b0[13])]
+    for k, v in rows:
+        print(f'  {k:62s} {v/n:9.0f} cycles')
+    print(f'  {"sum":62s} {sum(v for _, v in rows)/n:9.0f}')
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == 'c4':
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
