@@ -136,13 +136,15 @@ extern __shared__ __attribute__((aligned(16))) double mc3_smem_stamps_[];
 #define MC3_LSTAMP(slot) do { } while (0)
 #define MC3_LSTAMP_FLUSH() do { } while (0)
 #else
+// (threads the LDS areas were carved for: a chain-wave workgroup has one wave more)
+#define MC3_LSTAMP_THREADS (blockDim.x > 512 ? 512 : blockDim.x)
 #define MC3_LSTAMP(slot)                                                                  \
     do {                                                                                  \
         /* (the builtin, not inline asm with an SGPR output: some stamps sit in control    \
            flow the compiler considers divergent) */                                      \
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();                       \
         if (threadIdx.x == 0 && blockIdx.x == 0)                                          \
-            reinterpret_cast<unsigned long long *>(mc3_smem_stamps_)[blockDim.x +         \
+            reinterpret_cast<unsigned long long *>(mc3_smem_stamps_)[MC3_LSTAMP_THREADS + \
                 MC3HIP_MAX_PARAMS + 2 + 32 + (slot)] = t_;                                \
     } while (0)
 #define MC3_LSTAMP_FLUSH()                                                                \
@@ -150,7 +152,7 @@ extern __shared__ __attribute__((aligned(16))) double mc3_smem_stamps_[];
         if (threadIdx.x == 0 && blockIdx.x == 0)                                          \
             for (int q_ = 0; q_ < 16; ++q_)                                               \
                 P.stamps[q_] = reinterpret_cast<unsigned long long *>(                    \
-                    mc3_smem_stamps_)[blockDim.x + MC3HIP_MAX_PARAMS + 2 + 32 + q_];      \
+                    mc3_smem_stamps_)[MC3_LSTAMP_THREADS + MC3HIP_MAX_PARAMS + 2 + 32 + q_]; \
     } while (0)
 #endif
 #ifdef MC3HIP_TICKS_ONLY
@@ -316,6 +318,21 @@ __device__ __forceinline__ double add_ror(double v)
     const int hi2 = __builtin_amdgcn_mov_dpp(hi, 0x120 + N, 0xf, 0xf, true);
     return v + make_double(lo2, hi2);
 }
+// lane l receives lane (l + 1) mod 64's value: DPP wave rotate (gfx9), VALU only
+__device__ __forceinline__ double wave_rol1(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x134, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x134, 0xf, 0xf, false);
+    return make_double(lo, hi);
+}
+// lane l receives lane src's value (any src: the LDS crossbar, no LDS memory, no barrier)
+__device__ __forceinline__ double lane_gather(double v, int src)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(4 * src, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(4 * src, __double2hiint(v));
+    return make_double(lo, hi);
+}
+
 // sum over the 64 lanes of a wave, pairing strides 32,16,8,4,2,1; every lane
 // receives the total
 __device__ __forceinline__ double wave_sum(double t)
@@ -327,6 +344,18 @@ __device__ __forceinline__ double wave_sum(double t)
     t = add_ror<2>(t);
     t = add_ror<1>(t);
     return t;
+}
+
+// three such sums at once: the same additions, interleaved, so that the pipeline works on three
+// independent chains instead of waiting on one (a single wave hides no latency by itself)
+__device__ __forceinline__ void wave_sum3(double &a, double &b, double &c)
+{
+    a = add_xor32(a); b = add_xor32(b); c = add_xor32(c);
+    a = add_xor16(a); b = add_xor16(b); c = add_xor16(c);
+    a = add_ror<8>(a); b = add_ror<8>(b); c = add_ror<8>(c);
+    a = add_ror<4>(a); b = add_ror<4>(b); c = add_ror<4>(c);
+    a = add_ror<2>(a); b = add_ror<2>(b); c = add_ror<2>(c);
+    a = add_ror<1>(a); b = add_ror<1>(b); c = add_ror<1>(c);
 }
 
 __device__ __forceinline__ double read_lane(double v, int k)

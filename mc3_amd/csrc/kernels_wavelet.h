@@ -141,7 +141,11 @@ __global__ __launch_bounds__(576) void wavelet_cw_kernel(const DevProblem P, con
     // ---- the compute waves -------------------------------------------------------------------
     for (;;) {
         block_sync<9>();                                // (A)
+        MC3_LSTAMP(0);
+        // (the order and the coefficients in one trip to LDS, not one after the other)
         const int cmd = s_cmd[0];
+        Model<MT> model;
+        model.init(P, L.nextp);
         if (cmd == CW_STOP)
             return;
         if (cmd == CW_SKIP)
@@ -149,13 +153,16 @@ __global__ __launch_bounds__(576) void wavelet_cw_kernel(const DevProblem P, con
         double c;
         if (B == 32)
             c = wavelet_body<8, MT, 32, false, true>(P, L.nextp, L.part, L.flag, L.tab, L.halo,
-                                                     L.xs);
+                                                     L.xs, nullptr, 0, nullptr, 0, &model);
         else
             c = wavelet_body<8, MT, 16, false, true>(P, L.nextp, L.part, L.flag, L.tab, L.halo,
-                                                     L.xs);
+                                                     L.xs, nullptr, 0, nullptr, 0, &model);
         if (tid == 0)
             s_result[0] = c;
+        MC3_LSTAMP(1);
         block_sync<9>();                                // (3)
+        MC3_LSTAMP(2);
+        MC3_LSTAMP_FLUSH();
     }
 }
 

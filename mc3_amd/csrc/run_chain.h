@@ -717,9 +717,11 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     if (PERSIST && (phase_hooked(PHASE) ? (lane == 0 && lc == 0 && blockIdx.y == 0 &&
                                            (PHASE == PH_CHAINWAVE || threadIdx.x == 0))
                                         : (threadIdx.x == 0 && blockIdx.x == 0))) {
-        P.stamps[8] += ta8; P.stamps[9] += ta9; P.stamps[10] += ta10;
-        P.stamps[11] += ta11; P.stamps[12] += ta12; P.stamps[13] += ta13;
-        P.stamps[14] += ta14; P.stamps[15] += ta15;
+        // (the chain wave of PH_CHAINWAVE: second page -- the compute waves' LDS stamps own 0..15)
+        constexpr int TB = (PHASE == PH_CHAINWAVE) ? 16 : 0;
+        P.stamps[TB + 8] += ta8; P.stamps[TB + 9] += ta9; P.stamps[TB + 10] += ta10;
+        P.stamps[TB + 11] += ta11; P.stamps[TB + 12] += ta12; P.stamps[TB + 13] += ta13;
+        P.stamps[TB + 14] += ta14; P.stamps[TB + 15] += ta15;
         if constexpr (phase_hooked(PHASE)) {
             P.stamps[16] += tr0; P.stamps[17] += tr1; P.stamps[18] += tr2; P.stamps[19] += tr3;
         }

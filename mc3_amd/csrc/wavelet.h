@@ -79,16 +79,20 @@ __device__ __forceinline__ void block_levels(double (&v)[CAP], double (&accs)[NA
 {
     if constexpr (NV >= 2) {
         static_assert(LEV < NACC, "one slot per level");
-        double2 *h = hb + (LEV & 1) * stride;
-        if (active)
-            h[me] = make_double2(v[0], v[1]);
-        if constexpr (SYNC)
+        if constexpr (SYNC) {
+            double2 *h = hb + (LEV & 1) * stride;
+            if (active)
+                h[me] = make_double2(v[0], v[1]);
             block_sync<WPC>();
-        else
-            __builtin_amdgcn_wave_barrier();
-        const double2 hv = h[next];
-        v[NV] = hv.x;
-        v[NV + 1] = hv.y;
+            const double2 hv = h[next];
+            v[NV] = hv.x;
+            v[NV + 1] = hv.y;
+        } else {
+            // one wave, every lane taking part, the next block is the next lane's: the halo
+            // comes by a lane rotation instead of a round trip through LDS
+            v[NV] = wave_rol1(v[0]);
+            v[NV + 1] = wave_rol1(v[1]);
+        }
         accs[LEV] = block_level<NV, CAP>(v);
         block_levels<NV / 2, CAP, WPC, SYNC, LEV + 1, NACC>(v, accs, hb, stride, me, next, active);
     }
@@ -243,7 +247,8 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
                                                double *s_part, int *s_flag, double *s_tab,
                                                double *s_halo, const double *xs,
                                                const double *values = nullptr, int npre = 0,
-                                               const double *accP = nullptr, int sawinf0 = 0)
+                                               const double *accP = nullptr, int sawinf0 = 0,
+                                               const Model<MT> *ready_model = nullptr)
 {
     constexpr int T = 64 * WPC;
     constexpr int NLA = ilog2c(B);                      // levels of stage A (N >= 4)
@@ -258,7 +263,10 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
     const int me = active ? tid : 0;
     const int next = (me + 1 == Ta) ? 0 : me + 1;
     Model<MT> model;
-    model.init(P, s_nextp);
+    if (CW && ready_model != nullptr)
+        model = *ready_model;                           // (read together with the order to go)
+    else
+        model.init(P, s_nextp);
     if (WPC > 1 && tid == 0)
         s_flag[1] = 0;                                  // "a model value was +inf"
     // One wave: the noise terms first.  Several waves: the LAST wave computes them after its
@@ -299,6 +307,7 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
         return weigh_levels<NLA>(accA, s_tab, mA, w0);
     };
     double sumA, u = v[0];
+    double pA = 0.0;                                    // CW: this lane's share of stage A's sum
     int mscale = (N >= 4) ? mA - NLA : mA;              // scale of the next level's details
     double accB[NLB > 0 ? NLB : 1];
     if constexpr (WPC > 1) {
@@ -313,6 +322,21 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
         block_sync<WPC>();                              // (1) the T values are in LDS
         if (!CW && wave == WPC - 1)
             wavelet_noise_terms(s_nextp, P.nparams, M, s_tab);
+        if (CW && wave == 0) {
+            // (chain-wave kernels: everybody's stage-A sums are in LDS already -- asked for now,
+            // added up while stage B runs)
+            double p[WPC];
+#pragma unroll
+            for (int q = 0; q < WPC; ++q)
+                p[q] = s_part[lane + 64 * q];
+#pragma unroll
+            for (int s2 = WPC / 2; s2 >= 1; s2 >>= 1) {
+#pragma unroll
+                for (int q = 0; q < s2; ++q)
+                    p[q] = p[q] + p[q + s2];
+            }
+            pA = p[0];
+        }
         if (wave == 0) {
             // ---- stage B: T values, WPC per lane, levels inside the lane -----------------
             double vb[WPC + 2];
@@ -336,19 +360,18 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
     const int mC = mscale;
     int nC = 0;
     if (wave == 0) {
-        double *cbuf = s_halo + 4 * T;                  // [64], wave-private
 #pragma unroll
         for (int l = 0; l < 6; ++l) {
             if (nn >= 4) {
                 const int nh = nn >> 1;
-                __builtin_amdgcn_wave_barrier();
-                cbuf[lane] = u;
-                __builtin_amdgcn_wave_barrier();
+                // lane l < nh takes values 2l .. 2l + 3 (wrapping) straight from the lanes that
+                // hold them (the LDS crossbar: no store, no wait for it, no read-back)
                 const int i2 = (lane < nh) ? 2 * lane : 0;
-                const double2 ca = *reinterpret_cast<const double2 *>(cbuf + i2);
-                const double2 cc = *reinterpret_cast<const double2 *>(cbuf + ((i2 + 2) & (nn - 1)));
+                const int i3 = (i2 + 2) & (nn - 1);
+                const double c0 = lane_gather(u, i2), c1 = lane_gather(u, i2 + 1);
+                const double c2 = lane_gather(u, i3), c3 = lane_gather(u, i3 + 1);
                 double s, d;
-                d4_pair(ca.x, ca.y, cc.x, cc.y, s, d);
+                d4_pair(c0, c1, c2, c3, s, d);
                 accC[l] = (lane < nh) ? d * d : 0.0;
                 u = s;
                 nn = nh;
@@ -366,6 +389,23 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
         }
         if (wave != 0)
             return 0.0;                                 // the value is only used by wave 0
+        if constexpr (CW) {
+            // the three stage sums in one interleaved pass; total (A + B) + C as ever
+            double sA = pA, sB = weigh_levels<NLB>(accB, s_tab, mA - NLA), sC = 0.0;
+#pragma unroll
+            for (int l = 0; l < 6; ++l)
+                if (l < nC)
+                    sC = mc3_fma(accC[l], s_tab[mC - l], sC);
+            wave_sum3(sA, sB, sC);
+            sawinf = s_flag[1];
+            const double a0c = read_lane(u, 0), a1c = read_lane(u, 1);
+            MC3_LSTAMP(13);
+            if (sawinf)
+                return mc3_from_bits(0x7ff0000000000000ull);
+            const double sS2c = s_tab[24];
+            const double Sc = (a0c * a0c) / sS2c + (a1c * a1c) / sS2c;
+            return (Sc + s_tab[25]) + ((sA + sB) + sC);
+        }
         double p[WPC];
 #pragma unroll
         for (int q = 0; q < WPC; ++q)

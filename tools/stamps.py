@@ -38,7 +38,7 @@ import helpers as H  # noqa: E402
 
 which = ([a for a in sys.argv[1:] if not a.startswith('--')] or ['c2'])[0]
 if which == 'c4':
-    prob = H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*400)
+    prob = H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*1200)
     ini = H.initial_population
 else:
     prob = bench.c2_problem(256, 3000)
@@ -76,7 +76,27 @@ print(f'  {"iteration":28s} {acc.sum()/max(n, 1):9.0f}')
 if n == 0:
     print('  (no samples: the hand-laid-out DEMC loop keeps per-phase tick sums instead -- '
           'tools/ticks.py; or STAMP_MODE=launch / MC3HIP_NO_LEAN=1 for the stamped kernels)')
-if which == 'c4':
+if which == 'c4' and g.plan['waves_per_chain'] == 8 and not os.environ.get('MC3HIP_NO_CHAINWAVE'):
+    # the chain-wave kernel: compute wave 0's stamps of the last iteration
+    sel = (0, 8, 14, 9, 10, 12, 13, 1, 2)
+    lab = ['(A) proposal there -> pyramid entry', '-> level 0 done', '-> levels 1.. done (stage A)',
+           '-> barrier (1) + stage B', '-> stage C', '-> sums, chisq', '-> result written',
+           '-> barrier (3) passed (waits for the chain wave)']
+    acc2 = np.zeros(len(lab))
+    m = 0
+    for _ in range(60):
+        g.run(7)
+        out = (ctypes.c_uint64*16)()
+        _lib.check(g.lib.mc3hip_debug_stamps(g._ctx, out))
+        d = np.diff([float(out[i]) for i in sel])
+        if np.all(d > 0) and d.sum() < 1e6:
+            acc2 += d
+            m += 1
+    print(f'  chain-wave kernel, compute wave 0, {m} samples:')
+    for k, v in zip(lab, acc2/max(m, 1)):
+        print(f'    {k:50s} {v:9.0f}')
+    print(f'    {"sum (A) -> (3)":50s} {acc2.sum()/max(m, 1):9.0f}')
+elif which == 'c4':
     lab = ['top -> proposal known (barrier)', '-> wavelet entry',
            '-> level 0 done (wave 0)', '-> levels 1.. done (stage A)',
            '-> barrier 1 + stage B (wave 0)', '-> stage C (wave 0)',

@@ -76,9 +76,9 @@ if len(sys.argv) > 1 and sys.argv[1] == 'c4cw':
         out = (ctypes.c_uint64*16)()
         _lib.check(g.lib.mc3hip_debug_stamps(g._ctx, out))
         return np.array(out[:], dtype=np.float64)
-    a0, a1 = stamps(0), stamps(1)
+    a0, a1 = stamps(1), stamps(1)       # (the chain wave's sums are all on the second page)
     g.run(NIT)
-    b0, b1 = stamps(0) - a0, stamps(1) - a1
+    b0, b1 = stamps(1) - a0, stamps(1) - a1
     n = b0[12]
     print(f'{smp}: plan={g.plan}; iterations sampled (in bounds, chain 0): {int(n)}; '
           f'wall {g.last_run_ms()*1e3/NIT:.2f} us per iteration')
