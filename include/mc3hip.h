@@ -109,9 +109,12 @@ typedef struct mc3hip_plan {
                                refreshes (step kernel + all-gather + scatter per refresh)   */
     int32_t recoveries;     /* persistent launches that gave up and were redone so far        */
     int32_t tile_tree;      /* how a tile's 1024 strided partial sums are added up: 0 = one
-                               halving tree over all of them (strides 512..1); 1 = 64 at a
-                               time (strides 32..1), then the 16 group totals (8..1): the
-                               matrix-core tile kernel                                          */
+                               halving tree over all of them (strides 512..1); 2 = the
+                               matrix-core tile kernels: the weights folded into the operand
+                               rows (design columns and data times w, rounded once), a lane's
+                               sixteen points in step order, the 16 lanes of a row (8..1), the
+                               tile's eight rows (4..1) -- oracle_lockstep.c
+                               gauss_chisq_weighted_rows states it                              */
     int32_t resident;       /* 1 = tiled plan in ONE persistent launch: every workgroup keeps
                                its tile of the data (and of the design matrix) on chip,
                                proposals and per-tile sums are handed over inside the

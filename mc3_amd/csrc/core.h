@@ -49,6 +49,11 @@ struct DevProblem {
     const double *params, *pmin, *pmax, *pstep, *prior, *priorlow, *priorup;
     const double *fmin, *fmax, *fstep;   // pmin/pmax/pstep gathered at ifree[k]
     const double *indep, *data, *w;
+    // tiled plan through the matrix cores (mc3hip_plan.tile_tree = 2): the operand rows with
+    // the weights folded in -- [nmodel + 1][npad]: column k of the design matrix times w, then
+    // the data times w (each product rounded once, on the host) -- so that a residual leaves
+    // the contraction finished and the epilogue is one fused multiply-add per value
+    const double *aw;
     double *Z, *log_post;
     int32_t *zchain;
     double *X, *chisq;

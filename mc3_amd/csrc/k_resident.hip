@@ -7,11 +7,11 @@ namespace mc3hip {
 namespace host {
 namespace {
 
-// LDS: group totals [RS_WCAP][16], the give-up word, one run_chain area per wave, 2048 weights,
-// the last block of operand rows [16][512]
+// LDS: row totals [RS_WCAP][16], the give-up word, one run_chain area per wave, the last block
+// of operand rows [16][512]
 constexpr size_t RESIDENT_OWN = 64 + MC3HIP_MAX_PARAMS + 2 + 48 + 4;
 constexpr size_t RESIDENT_LDS_BYTES =
-    (RS_WCAP * 16 + 2 + 8 * RESIDENT_OWN + 2048 + 16 * 512) * sizeof(double);
+    (RS_WCAP * 16 + 2 + 8 * RESIDENT_OWN + 16 * 512) * sizeof(double);
 // polynomials (ResidentPoly): two exchange buffers [16][512], the give-up word, the areas
 constexpr size_t RESIDENT_POLY_LDS_BYTES = (2 * 16 * 512 + 2 + 8 * RESIDENT_OWN) * sizeof(double);
 

@@ -833,6 +833,20 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
             w[i] = pr->wlike ? 1.0 : 1.0 / pr->uncert[i];
         TRY(dev_upload(c, &P.data, d.data(), npad));
         TRY(dev_upload(c, &P.w, w.data(), npad));
+        if (tiled && linear_model && P.tile == 2048) {
+            // operand rows of the matrix-core tile kernels, weights folded in (core.h aw)
+            std::vector<double> aw((ncol + 1) * npad);
+            for (size_t k = 0; k < ncol; ++k)
+                for (size_t i = 0; i < npad; ++i) {
+                    volatile double prod = buf[k * npad + i] * w[i];    // (rounded: no fma)
+                    aw[k * npad + i] = prod;
+                }
+            for (size_t i = 0; i < npad; ++i) {
+                volatile double prod = d[i] * w[i];
+                aw[ncol * npad + i] = prod;
+            }
+            TRY(dev_upload(c, &P.aw, aw.data(), aw.size()));
+        }
     }
     if (pr->wlike && pr->model_kind == MC3HIP_MODEL_POLY && nd >= 2 && !getenv("MC3HIP_NO_GRID")) {
         // abscissae made by numpy.linspace (y = arange(num) * step + start, y[-1] = stop)?
@@ -1057,7 +1071,7 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
     plan->fast = (plan->persistent > 0 && c->fast) ? (lean_demc_eligible(c) ? 2 : 1) : 0;
     if (plan->fast == 2 && c->p2p_ranks <= 1)
         plan->waves_per_chain = lean_waves(c);      // (helper waves share the data sum)
-    plan->tile_tree = tile_uses_mfma(c) ? 1 : 0;
+    plan->tile_tree = tile_uses_mfma(c) ? 2 : 0;
     plan->resident = (plan->persistent > 0 && c->resident) ? 1 : 0;
     plan->comm_graph = c->cgraph_exec ? c->comm_graph_nodes : 0;
     plan->recoveries = c->recoveries;

@@ -153,14 +153,12 @@ struct ResidentTile : ResidentOwner {
     static constexpr int KR = (KB == 3) ? 2 : KB;
     double bop[8][2][KR];
     const double *s_b;      // LDS [16][512]: this thread's operands of row block KR
-    double *s_w;            // LDS [RS_WCAP][16]: group totals of the chains done so far
-    const double *s_ww;     // LDS [2048]: the weights of the tile's points (this wave's: + 128 wv)
+    double *s_w;            // LDS [RS_WCAP][16]: row totals of the chains done so far ([8..15] = 0)
     int *s_stop;            // LDS: a wave of this workgroup has given up
     int t, c0, c1, wv;
 
     __device__ __forceinline__ void load(const DevProblem &P, int tile, int col, int chain_block,
-                                         double *lds_w, int *lds_stop, double *lds_ww,
-                                         double *lds_b)
+                                         double *lds_w, int *lds_stop, double *lds_b)
     {
         s_b = lds_b + threadIdx.x;
         s_w = lds_w;
@@ -179,15 +177,12 @@ struct ResidentTile : ResidentOwner {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const size_t i = (size_t)t * 2048 + 1024 * h + 128 * wv + 16 * vb + j;
-                // (the weights are the same for the four 16-lane rows of a wave: they live in
-                // LDS, 16 KB, and leave 32 registers to the chain state of the owner waves)
-                if (g == 0)
-                    lds_ww[1024 * h + 128 * wv + 16 * vb + j] = P.w[i];
+                // (operand rows with the weights folded in, P.aw: design columns times w, then
+                // the data times w as row K)
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) {
                     const int k = 4 * kb + g;
-                    const double *src = (k < K) ? P.indep + (size_t)k * P.npad : P.data;
-                    const double v = (k <= K) ? src[i] : 0.0;
+                    const double v = (k <= K) ? P.aw[(size_t)k * P.npad + i] : 0.0;
                     if (kb < KR)
                         bop[vb][h][kb] = v;
                     else
@@ -195,7 +190,6 @@ struct ResidentTile : ResidentOwner {
                 }
             }
         }
-        s_ww = lds_ww + 128 * wv + j;
     }
 
     // every wave of the workgroup, once per iteration; false (for all of them) = give up
@@ -235,34 +229,34 @@ struct ResidentTile : ResidentOwner {
             return m;
         };
         auto lds_operand = [&](int st) { return (KR < KB) ? s_b[wo + st * 512] : 0.0; };
-        auto lds_weight = [&](int st) { return s_ww[wo + 1024 * (st & 1) + 16 * (st >> 1)]; };
-        // sum over the 64 lanes of a group (lane 16 q + j): strides 32 and 16 were in-thread,
-        // 8..1 run inside the 16-lane row; lane j = 0 has the defined order
-        auto group_total = [&](const double(&acc)[2][4], int grp, int off) {
+        // the 16 lanes of a row (strides 8..1; lane j = 0 has the defined order), once per block
+        // of chains: a lane has added up its sixteen points of the tile by then
+        auto row_total = [&](const double(&acc)[4], int off) {
             double sr[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                double sg = acc[0][r] + acc[1][r];         // stride 16
-                sg = add_ror<8>(sg);
+                double sg = add_ror<8>(acc[r]);
                 sg = add_ror<4>(sg);
                 sg = add_ror<2>(sg);
                 sr[r] = add_ror<1>(sg);
             }
             if (j == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    s_w[(off + g + 4 * r) * 16 + 2 * wv + grp] = sr[r];
+                for (int r = 0; r < 4; ++r) {
+                    s_w[(off + g + 4 * r) * 16 + wv] = sr[r];
+                    s_w[(off + g + 4 * r) * 16 + 8 + wv] = 0.0;    // (the tree below is 16 wide)
+                }
             }
         };
         // Software pipeline, written out.  FP64 matrix and vector instructions share one pipe
         // on this chip (tools/probes/mfma_f64_issue_probe.hip: their times add up), so what
         // can be hidden is latency, not work: the product of step s + 1 is issued before the
         // residuals of step s are squared, one matrix instruction then a few vector
-        // instructions in turn; the LDS operands of step s + 2 are read during step s; the
-        // cross-lane sum of the first group of 64 lanes runs between the matrix instructions
-        // of the second.  The scheduling barriers keep that order, and with it two products'
-        // worth of registers alive instead of sixteen.  (Carrying the pipeline across the
-        // barrier at the end of a block of chains costs 25 more registers.)
+        // instructions in turn; the LDS operands of step s + 2 are read during step s.  The
+        // scheduling barriers keep that order, and with it two products' worth of registers
+        // alive instead of sixteen.  The weights are folded into the operand rows
+        // (mc3hip_plan.tile_tree = 2), so the product IS the residual and the vector work of a
+        // step is four fused multiply-adds.
         request(c0);
         int base = c0;                  // first chain of the window collected in s_w
         for (int cb = c0; cb < c1; cb += 16) {
@@ -275,57 +269,38 @@ struct ResidentTile : ResidentOwner {
             if (cb + 16 < c1)
                 request(cb + 16);              // the next block's rows travel behind this one
             asm volatile("; operands of this block" : "+v"(wo));
-            double bl_next = lds_operand(1), w_cur = lds_weight(0), w_next = w_cur;
+            double bl_next = lds_operand(1);
             mc3_v4d mc = product(0, a, lds_operand(0)), mn = mc;
-            double accA[2][4], accB[2][4], tmp[4];     // [block of 16 lanes mod 2][chain g + 4 r]
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};      // chain g + 4 r: this lane's points so far
 #pragma unroll
             for (int st = 0; st < 16; ++st) {
-                const int q = (st >> 1) & 3, h = st & 1;
-                double(&acc)[2][4] = (st < 8) ? accA : accB;
                 __builtin_amdgcn_sched_barrier(0);
                 const double bl = bl_next;
                 if (st < 14)
                     bl_next = lds_operand(st + 2);
-                if (st < 15) {
-                    w_next = lds_weight(st + 1);
+                if (st < 15)
                     mn = product(st + 1, a, bl);
-                }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double res = mc[r] * w_cur;
-                    // strides 32 (blocks 0 + 2, 1 + 3 of the group) as soon as both are there
-                    if (q < 2) {
-                        acc[q][r] = mc3_fma(res, res, h ? acc[q][r] : 0.0);
-                    } else {
-                        tmp[r] = mc3_fma(res, res, h ? tmp[r] : 0.0);
-                        if (h == 1)
-                            acc[q - 2][r] = acc[q - 2][r] + tmp[r];
-                    }
-                }
-                if (st == 8)
-                    group_total(accA, 0, cb - base);
+                for (int r = 0; r < 4; ++r)
+                    acc[r] = mc3_fma(mc[r], mc[r], acc[r]);
                 // (two matrix instructions first: the product these squares read was the last
                 // thing issued in the previous step and needs a pipe pass to land)
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);             // MFMA
 #pragma unroll
                 for (int i = 2; i <= KB; ++i) {
-                    if (st == 8)
-                        __builtin_amdgcn_sched_group_barrier(0x002, 36, 0);    // VALU
-                    else
-                        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);         // VALU
                     if (i < KB)
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 mc = mn;
-                w_cur = w_next;
             }
-            group_total(accB, 1, cb - base);
+            row_total(acc, cb - base);
             // The waves of the workgroup are NOT synchronised per block of chains: every wave
-            // leaves its group totals in LDS and goes on (a barrier, an exchange and a
+            // leaves its row totals in LDS and goes on (a barrier, an exchange and a
             // sixteen-lane sum per block cost ~10 % of the phase, and two waves that drift
             // apart share their SIMD's FP64 pipe better than two in step).  The totals are
-            // added up -- 16 per chain, strides 8..1 -- once per window of RS_WCAP chains,
+            // added up -- eight per chain, strides 4..1 -- once per window of RS_WCAP chains,
             // normally once per iteration.
             const int end = (cb + 16 < c1) ? cb + 16 : c1;
             if (end == c1 || end - base == RS_WCAP) {
@@ -487,8 +462,7 @@ __global__ __launch_bounds__(512) void resident_tile_kernel(const DevProblem P, 
     int *s_stop = reinterpret_cast<int *>(smem + W);
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     ResidentTile<KB> T;
-    T.load(P, blockIdx.x, blockIdx.y, chain_block, smem, s_stop, smem + W + 2 + 8 * OWN,
-           smem + W + 2 + 8 * OWN + 2048);
+    T.load(P, blockIdx.x, blockIdx.y, chain_block, smem, s_stop, smem + W + 2 + 8 * OWN);
     // a launch queued behind one that gave up must not run: its inputs are missing
     if (threadIdx.x == 0)
         *s_stop = (__hip_atomic_load(&P.ctl[CTL_ABORT], __ATOMIC_RELAXED,

@@ -195,31 +195,29 @@ __global__ __launch_bounds__(512) void tile_chisq_mfma_kernel(
     const DevProblem P, const int chain_block, const double *__restrict__ nextp,
     const int32_t *__restrict__ out_of_bounds)
 {
-    // Summation order of this kernel ("waves first", mc3hip_plan.tile_tree = 1): the 1024
-    // virtual lanes of a tile are summed 64 at a time (halving tree, strides 32..1), then
-    // the 16 group totals (strides 8..1).  A wave then hands over a few numbers per block of
-    // chains instead of 16 x 64, and the 128 KiB exchange (and the matrix pipe idling behind
-    // it) of the lanes-first order is gone.  Eight waves (two groups of 64 virtual lanes
-    // each): the design values, data and weights of a wave's 256 points are 160 registers
-    // per lane, which the 128 of a 1024-thread group cannot hold; the matrix pipe is busy
-    // from one wave per SIMD on.
-    __shared__ double s_w[2][16][16];                  // [buffer][chain][group of 64 lanes]
+    // Summation order of the matrix-core kernels (mc3hip_plan.tile_tree = 2; the same in
+    // resident.h ResidentTile): the weights are folded into the operand rows (P.aw: design
+    // columns and data times w), so the contraction delivers the finished residual -- the data
+    // ride as operand row K with coefficient -1 -- and the epilogue is ONE fused multiply-add
+    // per value; a lane accumulates its sixteen points of the tile in step order (block vb,
+    // half h), the 16 lanes of a row are added once per block of chains (strides 8..1), then
+    // the tile's eight rows = waves (4..1).  Eight waves: the operand rows of a wave's 256
+    // points stay in registers; the matrix pipe is busy from one wave per SIMD on.
+    __shared__ double s_w[2][16][16];                  // [buffer][chain][row = wave; 8..15 zero]
     const int l = threadIdx.x, lane = l & 63, wv = l >> 6;
     const int j = lane & 15, g = lane >> 4;
     const int t = blockIdx.x;
     const int K = P.nmodel;
-    double bop[8][2][KB], dd[8][2], ww[8][2];
+    double bop[8][2][KB];
 #pragma unroll
     for (int vb = 0; vb < 8; ++vb) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const size_t i = (size_t)t * 2048 + 1024 * h + 128 * wv + 16 * vb + j;
-            dd[vb][h] = P.data[i];
-            ww[vb][h] = P.w[i];
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 const int k = 4 * kb + g;
-                bop[vb][h][kb] = (k < K) ? P.indep[(size_t)k * P.npad + i] : 0.0;
+                bop[vb][h][kb] = (k <= K) ? P.aw[(size_t)k * P.npad + i] : 0.0;
             }
         }
     }
@@ -228,54 +226,47 @@ __global__ __launch_bounds__(512) void tile_chisq_mfma_kernel(
     int buf = 0;
     for (int cb = c0; cb < c1; cb += 16, buf ^= 1) {
         // this lane's coefficient operand: chain cb + j, coefficients 4 kb + g (the scratch
-        // rows are zero beyond K)
+        // rows are zero beyond K; position K is the data row's -1)
         double aop[KB];
         {
             const int lc = (cb + j < c1) ? cb + j : c1 - 1;
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-                aop[kb] = nextp[(size_t)lc * SC_STRIDE + 4 * kb + g];
-        }
-#pragma unroll
-        for (int grp = 0; grp < 2; ++grp) {
-            double acc[4][4];                          // [block of 16 lanes][chain g + 4 r]
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int vb = 4 * grp + q;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    mc3_v4d m = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int kb = 0; kb < KB; ++kb)
-                        m = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[kb], bop[vb][h][kb], m, 0, 0,
-                                                                  0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const double res = (m[r] - dd[vb][h]) * ww[vb][h];
-                        acc[q][r] = mc3_fma(res, res, h ? acc[q][r] : 0.0);
-                    }
-                }
+            for (int kb = 0; kb < KB; ++kb) {
+                const int k = 4 * kb + g;
+                aop[kb] = (k == K) ? -1.0 : nextp[(size_t)lc * SC_STRIDE + k];
             }
-            // the group's 64 lanes (lane 16 q + j): strides 32 and 16 are in-thread, 8..1
-            // run inside the 16-lane row
+        }
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};          // chain g + 4 r
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double s = (acc[0][r] + acc[2][r]) + (acc[1][r] + acc[3][r]);
-                s = add_ror<8>(s);
-                s = add_ror<4>(s);
-                s = add_ror<2>(s);
-                s = add_ror<1>(s);
-                const int lc = cb + g + 4 * r;
-                const bool skip = lc >= c1 || (out_of_bounds[lc < c1 ? lc : c1 - 1] & 1);
-                if (j == 0)
-                    s_w[buf][g + 4 * r][2 * wv + grp] = skip ? 0.0 : s;
+        for (int st = 0; st < 16; ++st) {
+            const int vb = st >> 1, h = st & 1;
+            mc3_v4d m = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                m = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[kb], bop[vb][h][kb], m, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[r] = mc3_fma(m[r], m[r], acc[r]);
+        }
+        // the 16 lanes of a row
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double s = add_ror<8>(acc[r]);
+            s = add_ror<4>(s);
+            s = add_ror<2>(s);
+            s = add_ror<1>(s);
+            const int lc = cb + g + 4 * r;
+            const bool skip = lc >= c1 || (out_of_bounds[lc < c1 ? lc : c1 - 1] & 1);
+            if (j == 0) {
+                s_w[buf][g + 4 * r][wv] = skip ? 0.0 : s;
+                s_w[buf][g + 4 * r][8 + wv] = 0.0;
             }
         }
         block_sync<8>();
-        if (lane < 32) {                    // wave wv: the 16 group totals of chains cb + 2 wv, + 1
+        if (lane < 32) {                    // wave wv: the eight row totals of chains cb + 2 wv, + 1
             const int ch = 2 * wv + (lane >> 4);
             double s = s_w[buf][ch][lane & 15];
-            s = add_ror<8>(s);
+            s = add_ror<8>(s);              // (+ 0: slots 8..15)
             s = add_ror<4>(s);
             s = add_ror<2>(s);
             s = add_ror<1>(s);

@@ -282,10 +282,61 @@ static double tile_sum(double *part, int n, int waves_first)
     return halving_tree(part, ng);
 }
 
+/* tile_tree = 2 (design matrices through the matrix cores, tile = 2048 points): the weights
+ * are folded into the operands -- column k of the design matrix and the data are multiplied
+ * by w = 1/uncert ONCE, each product rounded, when the problem is set up -- so a residual is
+ *   r_i = fma(-1, (d w)_i, fma((A_{K-1} w)_i, p_{K-1}, ... (A_0 w)_i p_0))
+ * (what v_mfma_f64_16x16x4_f64 computes with the weighted data riding as operand row K with
+ * coefficient -1: its products are added in k order with one rounding each), squared and
+ * accumulated per lane over the lane's sixteen points of the tile in step order; then the 16
+ * lanes of a row (halving tree, strides 8..1), then the tile's eight rows (4..1).  Point of
+ * lane j, row wv, step st (block vb = st / 2, half h = st % 2): 1024 h + 128 wv + 16 vb + j.
+ * The +inf-model trap (chain.py:322-323) is resolved as the kernels do: only a non-finite
+ * total has the (unweighted) model values scanned. */
+static double gauss_chisq_weighted_rows(const ls_problem *P, const double *p)
+{
+    const int tile = P->tile, K = P->nmodel;
+    const int npad = (P->ndata + tile - 1) / tile * tile;
+    const double *A = P->indep;
+    double total = 0.0;
+    for (int t0 = 0; t0 < npad; t0 += tile) {
+        double rows[8];
+        for (int wv = 0; wv < 8; wv++) {
+            double lanes[16];
+            for (int j = 0; j < 16; j++) {
+                double acc = 0.0;
+                for (int st = 0; st < 16; st++) {
+                    const int i = t0 + 1024 * (st & 1) + 128 * wv + 16 * (st >> 1) + j;
+                    const int ii = (i < P->ndata) ? i : P->ndata - 1;
+                    const double wi = (i < P->ndata) ? P->w[ii] : 0.0;
+                    double m = (A[ii] * wi) * p[0];
+                    for (int k = 1; k < K; k++)
+                        m = mc3_fma(A[(size_t)k * P->ndata + ii] * wi, p[k], m);
+                    const double r = mc3_fma(P->data[ii] * wi, -1.0, m);
+                    acc = mc3_fma(r, r, acc);
+                }
+                lanes[j] = acc;
+            }
+            rows[wv] = halving_tree(lanes, 16);
+        }
+        total = total + halving_tree(rows, 8);
+    }
+    if (!(total - total == 0.0)) {                        /* inf or NaN: was a model value +inf? */
+        for (int i = 0; i < P->ndata; i++)
+            if (model_at(P, p, i) == INFINITY)
+                return INFINITY;
+    }
+    if (total == INFINITY)
+        return INFINITY;
+    return total + prior_term(P, p);
+}
+
 /* Gaussian chi-squared: src_c/_chisq.c:131-137 with w = 1/uncert, in the
  * canonical summation order.  model == +inf anywhere => +inf (chain.py:322). */
 static double gauss_chisq(const ls_problem *P, const double *p, double *part)
 {
+    if (P->tile_tree == 2 && P->tile == 2048 && P->model_kind != LS_POLY)
+        return gauss_chisq_weighted_rows(P, p);
     const int VL = P->vlanes;
     /* The kernels pad the data to a multiple of `vlanes` points that repeat the
      * last point with weight 0: a padded point adds fma(r, r, acc) with

@@ -101,7 +101,7 @@ def test_sample_tiled_problem_equals_cpu_checker(sampler):
     the chain's proposals in the plan's order and arbitrary vectors (initial population,
     best fit) in the untiled order, as the library does."""
     prob = H.linear_problem(ndata=20000, nmodel=7)
-    gpu, cpu = both(checker_plan={'tile': 2048, 'vlanes': 1024, 'tile_tree': 1},
+    gpu, cpu = both(checker_plan={'tile': 2048, 'vlanes': 1024, 'tile_tree': 2},
                     data=prob['data'], uncert=prob['uncert'],
                     func=lambda p, A: p @ A, params=prob['params'],
                     indparams=[prob['indep']], pstep=prob['pstep'],

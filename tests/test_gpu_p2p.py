@@ -95,7 +95,7 @@ def test_resident_tiled_plan_sharded_over_ranks(tmp_path, nranks, per_rank, ndat
     else:
         prob = H.linear_problem(ndata=ndata, nmodel=nmodel, nchains=nchains,
                                 nsamples=nchains*nref, sampler=sampler)
-        plan = {'tile': 2048, 'vlanes': 1024, 'tile_tree': 1}
+        plan = {'tile': 2048, 'vlanes': 1024, 'tile_tree': 2}
     orc = H.make_oracle(prob, plan=plan)
     Z0, lp0 = H.initial_population(orc)
     out_path = str(tmp_path / 'c5')
@@ -158,7 +158,7 @@ def test_resident_tiled_plan_abort_is_recovered_by_all_ranks(tmp_path):
     nchains = 2*per_rank
     prob = H.linear_problem(ndata=ndata, nmodel=nmodel, nchains=nchains,
                             nsamples=nchains*nref, sampler='demc')
-    orc = H.make_oracle(prob, plan={'tile': 2048, 'vlanes': 1024, 'tile_tree': 1})
+    orc = H.make_oracle(prob, plan={'tile': 2048, 'vlanes': 1024, 'tile_tree': 2})
     Z0, lp0 = H.initial_population(orc)
     out_path = str(tmp_path / 'c5abort')
     np.savez(out_path + '.pop.npz', Z0=Z0, lp0=lp0)

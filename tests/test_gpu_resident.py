@@ -1,7 +1,7 @@
 """The tiled plan in ONE persistent launch (resident_tile_kernel, resident.h): every
 workgroup keeps its tile of the design matrix on chip, proposals and per-tile sums are
 handed over inside the launch.  Same arithmetic as the three-launch tiled plan, so the same
-oracle (oracle/oracle_lockstep.c, `tile_tree = 1`) checks both, bit for bit.
+oracle (oracle/oracle_lockstep.c, `tile_tree = 2`) checks both, bit for bit.
 
 Reference path: mc3/chain.py:185-289 with the model call of chain.py:317-319 (a design
 matrix times the parameter vector) and the Gaussian chisq of src_c/_chisq.c:111-140.
@@ -59,7 +59,7 @@ def test_resident_plan_bit_exact(eng, nmodel, sampler, thinning):
     prob['pstep'][nmodel - 1] = 0.0         # fixed
     prob['params'][nmodel - 2] = prob['params'][1]
     orc, gpu = run_pair(eng, prob)
-    assert gpu.plan['tile'] == 2048 and gpu.plan['tile_tree'] == 1
+    assert gpu.plan['tile'] == 2048 and gpu.plan['tile_tree'] == 2
     assert gpu.plan['resident'] == 1 and gpu.plan['persistent'] > 0
     assert_same(orc, gpu)
     assert gpu.plan['recoveries'] == 0
@@ -344,8 +344,8 @@ def test_resident_nonfinite_models_are_rejected_like_the_reference(eng, kind):
 
 
 @pytest.mark.parametrize('plan_env,want', [
-    ({}, dict(resident=1, tile_tree=1)),                          # one launch, matrix cores
-    ({'MC3HIP_NO_RESIDENT': '1'}, dict(resident=0, tile_tree=1)),  # three launches, matrix cores
+    ({}, dict(resident=1, tile_tree=2)),                          # one launch, matrix cores
+    ({'MC3HIP_NO_RESIDENT': '1'}, dict(resident=0, tile_tree=2)),  # three launches, matrix cores
     ({'MC3HIP_NO_MFMA': '1'}, dict(resident=0, tile_tree=0)),      # three launches, vector unit
 ])
 def test_tiled_plans_against_the_reference_chisq_at_c5_size(eng, monkeypatch, golden_dir,

@@ -261,6 +261,7 @@ def test_design_matrix_chisq_at_full_c5_size(golden_dir):
     np.testing.assert_allclose([prob['data'].sum(), prob['indep'].sum()],
                                kv['c5_data_checksum'], rtol=1e-12)
     for extra in ({}, {'tile': 2048, 'vlanes': 1024, 'tile_tree': 1},
+                  {'tile': 2048, 'vlanes': 1024, 'tile_tree': 2},
                   {'tile': 2048, 'vlanes': 1024, 'tile_tree': 0}):
         run = ls.LockstepRun(**prob, **extra)
         np.testing.assert_allclose(run.eval_chisq(kv['c5_params']), kv['c5_chisq_priors'],
