@@ -117,9 +117,9 @@ inline int tile_exact_degree(const mc3hip_ctx *c)
 // sums go through the FP64 matrix cores (tile_chisq_mfma_kernel)
 inline bool tile_uses_mfma(const mc3hip_ctx *c)
 {
-    // (5..15 coefficients: with the data as one more operand row, four blocks of four)
-    return c->mt == MT_LINEAR && c->P.tile == 2048 && c->P.nmodel <= 15 &&
-           !getenv("MC3HIP_NO_MFMA");
+    // (2..15 coefficients: with the data as one more operand row, at most four blocks of four)
+    return c->mt == MT_LINEAR && c->P.tile == 2048 && c->P.nmodel >= 2 && c->P.nmodel <= 15 &&
+           c->P.aw != nullptr && !getenv("MC3HIP_NO_MFMA");
 }
 
 // resident tiled plan: design-matrix models through the matrix cores, or polynomials of

@@ -12,6 +12,8 @@ namespace {
 constexpr size_t RESIDENT_OWN = 64 + MC3HIP_MAX_PARAMS + 2 + 48 + 4;
 constexpr size_t RESIDENT_LDS_BYTES =
     (RS_WCAP * 16 + 2 + 8 * RESIDENT_OWN + 16 * 512) * sizeof(double);
+// (only four operand blocks need the last term)
+constexpr size_t RESIDENT_LDS_BYTES_REGS = (RS_WCAP * 16 + 2 + 8 * RESIDENT_OWN) * sizeof(double);
 // polynomials (ResidentPoly): two exchange buffers [16][512], the give-up word, the areas
 constexpr size_t RESIDENT_POLY_LDS_BYTES = (2 * 16 * 512 + 2 + 8 * RESIDENT_OWN) * sizeof(double);
 
@@ -19,7 +21,9 @@ constexpr size_t RESIDENT_POLY_LDS_BYTES = (2 * 16 * 512 + 2 + 8 * RESIDENT_OWN)
 
 size_t resident_lds_bytes(const mc3hip_ctx *c)
 {
-    return resident_poly(c) ? RESIDENT_POLY_LDS_BYTES : RESIDENT_LDS_BYTES;
+    if (resident_poly(c))
+        return RESIDENT_POLY_LDS_BYTES;
+    return (c->P.nmodel + 4) / 4 == 4 ? RESIDENT_LDS_BYTES : RESIDENT_LDS_BYTES_REGS;
 }
 
 resident_kernel_fn resident_kernel(const mc3hip_ctx *c, bool p2p)
@@ -31,9 +35,12 @@ resident_kernel_fn resident_kernel(const mc3hip_ctx *c, bool p2p)
         default: return p2p ? resident_poly_kernel<4, true> : resident_poly_kernel<4, false>;
         }
     }
-    if ((c->P.nmodel + 4) / 4 == 2)           // operand rows: coefficients + the data column
-        return p2p ? resident_tile_kernel<2, true> : resident_tile_kernel<2, false>;
-    return p2p ? resident_tile_kernel<3, true> : resident_tile_kernel<3, false>;
+    switch ((c->P.nmodel + 4) / 4) {          // operand rows: coefficients + the data column
+    case 1: return p2p ? resident_tile_kernel<1, true> : resident_tile_kernel<1, false>;
+    case 2: return p2p ? resident_tile_kernel<2, true> : resident_tile_kernel<2, false>;
+    case 3: return p2p ? resident_tile_kernel<3, true> : resident_tile_kernel<3, false>;
+    default: return p2p ? resident_tile_kernel<4, true> : resident_tile_kernel<4, false>;
+    }
 }
 
 }  // namespace host

@@ -90,6 +90,7 @@ void launch_tile(mc3hip_ctx *c)
 {
     if (tile_uses_mfma(c)) {
         switch ((c->P.nmodel + 4) / 4) {             // operand rows: the coefficients + the data
+        case 1: launch_tile_mfma_t<1>(c); break;
         case 2: launch_tile_mfma_t<2>(c); break;
         case 3: launch_tile_mfma_t<3>(c); break;
         default: launch_tile_mfma_t<4>(c); break;

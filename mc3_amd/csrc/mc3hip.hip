@@ -201,7 +201,7 @@ void launch_refresh_tiled(mc3hip_ctx *c, int roff)
 // device is decide_persist's question)
 bool resident_shape(const mc3hip_ctx *c)
 {
-    const bool mfma = tile_uses_mfma(c) && c->P.nmodel >= 5 && c->P.nmodel <= 11;
+    const bool mfma = tile_uses_mfma(c) && c->P.nmodel >= 2 && c->P.nmodel <= 15;
     return (mfma || resident_poly(c)) && c->P.rs_prop && c->comm == nullptr &&
            !getenv("MC3HIP_NO_RESIDENT");
 }
@@ -786,7 +786,10 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         // 16 000 x 2048: 54.7 / 12.0; 16 384 x 256: 7.7 / 7.3; 8192 x 256: 5.0 fused),
         // crossing near 4 M chain-points.
         const bool linear_model = pr->model_kind == MC3HIP_MODEL_LINEAR;
-        const bool resident_model = linear_model ? (pr->nmodel >= 5 && pr->nmodel <= 11)
+        // (design matrices of 2..15 columns go through the matrix cores, 2048-point tiles)
+        const bool mfma_model = linear_model && pr->nmodel >= 2 && pr->nmodel <= 15 &&
+                                !getenv("MC3HIP_NO_MFMA");
+        const bool resident_model = linear_model ? mfma_model
                                                  : (pr->nmodel >= 2 && pr->nmodel <= 4);
         // (the mid-range rule was measured with the ONE-launch plan; where that plan cannot
         // run -- switched off, or a grid of tiles x columns of chains that is not co-resident
@@ -797,7 +800,7 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
                             !getenv("MC3HIP_NO_PERSIST") && !getenv("MC3HIP_NO_RESIDENT");
         if (mid_resident) {
             hipDeviceProp_t prop;
-            const long long tile_pts = pr->nmodel <= 4 ? 4096 : 2048;
+            const long long tile_pts = (pr->nmodel <= 4 && !mfma_model) ? 4096 : 2048;
             const long long nt = ((long long)nd + tile_pts - 1) / tile_pts;
             const long long cus = hipGetDeviceProperties(&prop, c->device) == hipSuccess
                                       ? prop.multiProcessorCount : 256;
@@ -815,7 +818,7 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
                           (long long)nd * pr->nlocal >= 4194304LL);
         const bool tiled = !pr->wlike && big && pr->nlocal >= 16 && pr->nmodel <= 16 &&
                            !getenv("MC3HIP_NO_TILED");
-        P.tile = tiled ? (pr->nmodel <= 4 ? 4096 : 2048) : 0;
+        P.tile = tiled ? ((pr->nmodel <= 4 && !mfma_model) ? 4096 : 2048) : 0;
         const size_t unit = tiled ? (size_t)P.tile : VLANES;
         const size_t npad = (nd + unit - 1) / unit * unit;
         P.npad = (int32_t)npad;
@@ -833,7 +836,7 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
             w[i] = pr->wlike ? 1.0 : 1.0 / pr->uncert[i];
         TRY(dev_upload(c, &P.data, d.data(), npad));
         TRY(dev_upload(c, &P.w, w.data(), npad));
-        if (tiled && linear_model && P.tile == 2048) {
+        if (tiled && mfma_model) {
             // operand rows of the matrix-core tile kernels, weights folded in (core.h aw)
             std::vector<double> aw((ncol + 1) * npad);
             for (size_t k = 0; k < ncol; ++k)

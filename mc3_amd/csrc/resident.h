@@ -147,10 +147,9 @@ struct ResidentOwner {
 
 template <int KB>
 struct ResidentTile : ResidentOwner {
-    // operand rows of the tile: blocks of four rows in registers, except -- with three of
-    // them -- the last, which lives in LDS (64 KB; one read per product): 96 registers of
-    // tile plus the products in flight plus the chain state of an owner wave do not fit 256
-    static constexpr int KR = (KB == 3) ? 2 : KB;
+    // operand rows of the tile: blocks of four rows in registers (up to three: 96 registers);
+    // a fourth block (12..15 coefficients + the data) lives in LDS, 64 KB, one read per product
+    static constexpr int KR = (KB == 4) ? 3 : KB;
     double bop[8][2][KR];
     const double *s_b;      // LDS [16][512]: this thread's operands of row block KR
     double *s_w;            // LDS [RS_WCAP][16]: row totals of the chains done so far ([8..15] = 0)
@@ -248,15 +247,13 @@ struct ResidentTile : ResidentOwner {
                 }
             }
         };
-        // Software pipeline, written out.  FP64 matrix and vector instructions share one pipe
-        // on this chip (tools/probes/mfma_f64_issue_probe.hip: their times add up), so what
-        // can be hidden is latency, not work: the product of step s + 1 is issued before the
-        // residuals of step s are squared, one matrix instruction then a few vector
-        // instructions in turn; the LDS operands of step s + 2 are read during step s.  The
-        // scheduling barriers keep that order, and with it two products' worth of registers
-        // alive instead of sixteen.  The weights are folded into the operand rows
-        // (mc3hip_plan.tile_tree = 2), so the product IS the residual and the vector work of a
-        // step is four fused multiply-adds.
+        // FP64 matrix and vector instructions share one pipe on this chip
+        // (tools/probes/mfma_f64_issue_probe.hip: their times add up), so what can be hidden is
+        // latency, not work.  With the weights folded into the operand rows
+        // (mc3hip_plan.tile_tree = 2) the product IS the residual and the vector work of a step
+        // is four fused multiply-adds: 255 registers hold the whole tile, and the compiler's own
+        // schedule of the plain loop beats the hand-written software pipeline the heavier
+        // epilogue needed (C5: 33.0 -> 30.4 us per iteration; profiles/r03_c5_schedules.jsonl).
         request(c0);
         int base = c0;                  // first chain of the window collected in s_w
         for (int cb = c0; cb < c1; cb += 16) {
@@ -269,31 +266,13 @@ struct ResidentTile : ResidentOwner {
             if (cb + 16 < c1)
                 request(cb + 16);              // the next block's rows travel behind this one
             asm volatile("; operands of this block" : "+v"(wo));
-            double bl_next = lds_operand(1);
-            mc3_v4d mc = product(0, a, lds_operand(0)), mn = mc;
             double acc[4] = {0.0, 0.0, 0.0, 0.0};      // chain g + 4 r: this lane's points so far
 #pragma unroll
             for (int st = 0; st < 16; ++st) {
-                __builtin_amdgcn_sched_barrier(0);
-                const double bl = bl_next;
-                if (st < 14)
-                    bl_next = lds_operand(st + 2);
-                if (st < 15)
-                    mn = product(st + 1, a, bl);
+                const mc3_v4d m = product(st, a, lds_operand(st));
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    acc[r] = mc3_fma(mc[r], mc[r], acc[r]);
-                // (two matrix instructions first: the product these squares read was the last
-                // thing issued in the previous step and needs a pipe pass to land)
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);             // MFMA
-#pragma unroll
-                for (int i = 2; i <= KB; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);         // VALU
-                    if (i < KB)
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                mc = mn;
+                    acc[r] = mc3_fma(m[r], m[r], acc[r]);
             }
             row_total(acc, cb - base);
             // The waves of the workgroup are NOT synchronised per block of chains: every wave

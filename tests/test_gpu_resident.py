@@ -77,11 +77,30 @@ def test_three_launch_plan_still_there(eng):
         gpu.close()
 
 
-def test_twelve_coefficients_keep_the_three_launch_plan(eng):
-    """K = 12 would need a fourth block of operand rows for the data column."""
-    prob = linear(nmodel=12, niter=6)
+@pytest.mark.parametrize('nmodel,sampler', [(2, 'demc'), (3, 'snooker'), (4, 'demc'), (12, 'demc'),
+                                            (13, 'snooker'), (15, 'demc'), (15, 'mrw')])
+def test_resident_plan_from_two_to_fifteen_columns(eng, nmodel, sampler):
+    """Design matrices of 2..4 columns (one or two blocks of operand rows) and of 12..15 (four:
+    the last in LDS) take the one-launch plan too; the three-launch plan computes the same."""
+    prob = linear(nmodel=nmodel, sampler=sampler, niter=12)
     orc, gpu = run_pair(eng, prob)
-    assert gpu.plan['tile'] == 2048 and gpu.plan['resident'] == 0
+    assert gpu.plan['tile'] == 2048 and gpu.plan['tile_tree'] == 2, gpu.plan
+    assert gpu.plan['resident'] == 1 and gpu.plan['recoveries'] == 0, gpu.plan
+    assert_same(orc, gpu)
+    gpu.close()
+    with env(MC3HIP_NO_RESIDENT=1):
+        orc, gpu = run_pair(eng, prob)
+        assert gpu.plan['resident'] == 0 and gpu.plan['tile_tree'] == 2
+        assert_same(orc, gpu)
+        gpu.close()
+
+
+def test_sixteen_coefficients_keep_the_vector_tile_kernel(eng):
+    """K = 16 plus the data column would be a fifth block of operand rows: the vector tile
+    kernel (three launches, lanes-first order)."""
+    prob = linear(nmodel=16, niter=6)
+    orc, gpu = run_pair(eng, prob)
+    assert gpu.plan['tile'] == 2048 and gpu.plan['resident'] == 0 and gpu.plan['tile_tree'] == 0
     assert_same(orc, gpu)
     gpu.close()
 
