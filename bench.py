@@ -202,7 +202,8 @@ def end_to_end():
     for name, (kw, nsamples) in cases.items():
         try:
             with contextlib.redirect_stdout(io.StringIO()):
-                mc3_amd.sample(nsamples=kw['nchains']*100, log=mu.Log(verb=0), **kw)
+                mc3_amd.sample(nsamples=kw['nchains']*(kw['burnin'] + 100), log=mu.Log(verb=0),
+                               **kw)
                 t0 = time.perf_counter()
                 res = mc3_amd.sample(nsamples=nsamples, log=mu.Log(verb=0), **kw)
                 dt = time.perf_counter() - t0
