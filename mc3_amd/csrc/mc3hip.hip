@@ -1871,7 +1871,7 @@ struct Scratch {
 };
 
 // prior term on the host exactly as src_c/include/stats.h:96-106 (np is tiny)
-double host_priors(const double *off, const double *plow, const double *pup, int np)
+static double host_priors(const double *off, const double *plow, const double *pup, int np)
 {
     double pr = 0.0;
     for (int j = 0; j < np; ++j) {

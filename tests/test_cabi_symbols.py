@@ -29,6 +29,17 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == names, 'mc3_amd/_lib.py binds a different set of symbols'
 
 
+def test_library_exports_no_other_functions():
+    """Built with -fvisibility=hidden: the only functions the dynamic symbol table
+    offers are the C-ABI's (kernel handles are data objects, libstdc++ templates weak)."""
+    from mc3_amd import _lib
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True,
+                         text=True, check=True).stdout
+    functions = [line.split()[2] for line in out.splitlines()
+                 if len(line.split()) == 3 and line.split()[1] == 'T']
+    assert sorted(functions) == declared_functions()
+
+
 def test_error_reporting_without_a_gpu():
     """Argument errors are reported through return codes + mc3hip_last_error, never
     by aborting; with no GPU present creation fails with a HIP error code."""
