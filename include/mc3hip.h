@@ -104,7 +104,9 @@ typedef struct mc3hip_plan {
                                (in-launch hand-off of Z rows), 0 = one launch per refresh */
     int32_t fast;           /* 1: the lean persistent instance (one wave per chain, fully
                                free polynomial, Gaussian chisq, no priors/shared/epsilon);
-                               2: its hand-laid-out DEMC / thinning = 1 loop (lean_demc_kernel) */
+                               2: its hand-laid-out DEMC / thinning = 1 loop (lean_demc_kernel);
+                               3: wavelet likelihood, nine-wave kernel with the hand-structured
+                               chain wave (thinning 1, no priors / shared parameters / trace) */
     int32_t comm_graph;     /* >0: the RCCL exchange runs inside a hipGraph of that many
                                refreshes (step kernel + all-gather + scatter per refresh)   */
     int32_t recoveries;     /* persistent launches that gave up and were redone so far        */

@@ -101,6 +101,9 @@ struct DevProblem {
     // (0 = one workgroup per chain) and where their waiting state starts in dynamic LDS (in
     // doubles); set per launch by the host
     int32_t mc_chains, mc_off;
+    // chain-wave wavelet kernel: the hand-structured chain wave serves this problem
+    // (kernels_wavelet.h lean_chain_wave, host::cw_lean_eligible)
+    int32_t cw_lean;
 };
 
 constexpr int PH_FUSED = 0, PH_PROPOSE = 1, PH_FINISH = 2, PH_RESIDENT = 3, PH_CHAINWAVE = 4;

@@ -96,6 +96,12 @@ constexpr int WL_EVAL_BLOCKS = 256;
 // behind the compute waves' LDS areas the chain wave's own area, the command word, the result
 constexpr int CW_THREADS = 576;
 constexpr int CW_EXTRA_DOUBLES = 64 + MC3HIP_MAX_PARAMS + 2 + 48 + 4 + 4;
+// the shapes the hand-structured chain wave (lean_chain_wave) is written for; everything else
+// runs the general chain behind the same kernel
+inline bool cw_lean_eligible(const mc3hip_ctx *c)
+{
+    return c->P.thinning == 1 && c->P.trace_iters == 0 && c->P.nshare == 0 && c->P.ngprior == 0;
+}
 inline bool chainwave_runs(const mc3hip_ctx *c, bool p2p)
 {
     return c->chainwave && c->mc_chains == 0 && !p2p;

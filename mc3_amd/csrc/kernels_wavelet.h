@@ -99,6 +99,300 @@ struct WaveletHook {
     }
 };
 
+// ---- the chain wave, hand-structured ------------------------------------------------------
+// run_chain behind WaveletHook carries every feature of the general chain (thinning, trace,
+// priors, shared parameters, the resident plans' hooks) and with them ~215 scalar registers
+// spilled to vector lanes: between "chisq there" and the next "proposal there" -- the part of
+// an iteration in which the eight compute waves can only wait -- it spends ~3 000 cycles
+// (tools/ticks.py c4cw), most of them reloading spilled scalars.  This is the same chain for
+// the commonest shape (host::cw_lean_eligible: thinning 1, no trace, no Gaussian priors, no
+// shared parameters), written out so that that path is: read the chisq, two compares, select,
+// store the row, add the jump that is already waiting, bounds, one LDS write, barrier.
+// Everything else of an iteration -- draws, log u, the support-distribution draw, snooker rows
+// and the ordinary snooker jump, DEMC's partner rows -- is asked for or computed while the
+// compute waves work on the likelihood (prepare).  Same arithmetic, same draws, same order
+// of floating-point operations: results are bit-identical to run_chain's.
+#ifdef MC3HIP_STAMPS
+#define CW_TICK(v) MC3_TICK(v)
+#else
+#define CW_TICK(v) do { } while (0)
+#endif
+
+template <int SMP>
+__device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int nref,
+                                                double *s_nextp, double *s_tab, int *s_cmd,
+                                                const double *s_result, const int nhalo,
+                                                const int M)
+{
+    const int lane = threadIdx.x & 63;
+    const int lc = (int)blockIdx.x;
+    const int c = P.chain0 + lc;
+    const int nf = P.nfree, zs = P.zs;
+    const bool mine = lane < nf;
+    const int kk = mine ? lane : 0;
+    const long long R0 = P.ctl[0];
+    long long *ctl_rw = const_cast<long long *>(P.ctl);
+    const double *snap_first = (R0 == 0) ? P.snap0
+                                         : P.Z + (size_t)(P.M0 + (R0 - 1) * P.nchains) * zs;
+    double xk = mine ? snap_first[(size_t)c * zs + lane] : 0.0;
+    double cur = P.chisq[lc];
+    double best = P.best_chisq[lc];
+    const long long nacc0 = P.numaccept[lc];
+    long long nacc = 0;
+    unsigned long long oob = 0;                        // out-of-bounds proposals of this lane's parameter
+    const int jfree = mine ? P.ifree[lane] : 0;
+    const double pmin_k = mine ? P.fmin[lane] : 0.0;
+    const double pmax_k = mine ? P.fmax[lane] : 0.0;
+    const bool need_normal = (SMP == MC3HIP_MRW) || (P.fepsilon != 0.0);
+    const double pstep_k = (mine && need_normal) ? P.fstep[lane] : 0.0;
+    const long long abort_at = (P.test_abort >= 0 && lc == 0) ? (long long)P.test_abort : -1;
+    // the fixed parameters never change: written once, the free ones every iteration
+    if (lane < P.nparams)
+        s_nextp[lane] = P.params[lane];
+    if (lane + 64 < P.nparams)
+        s_nextp[lane + 64] = P.params[lane + 64];
+
+    auto normal_draw = [&](uint64_t it) {              // chain.py:185, as run_chain's
+        double nk = 0.0;
+        if (mine) {
+            const Draw2 d = draw2(P.seed, it, (uint32_t)c, (uint32_t)(3 + (lane >> 1)));
+            const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(d.q0)));
+            double sn, cs;
+            mc3_det_sincos2pi(u01(d.q1), &sn, &cs);
+            nk = (rad * ((lane & 1) ? sn : cs)) * pstep_k;
+        }
+        return nk;
+    };
+    // rows asked for ahead: snooker's three (chain.py:195-205), DEMC's two (chain.py:221-232)
+    constexpr int NR = (SMP == MC3HIP_SNOOKER) ? 3 : 2;
+    const double *ra[NR] = {};
+    double rv[NR] = {};
+    auto request_rows = [&](const Draws &D, long long R) {
+        if constexpr (SMP == MC3HIP_SNOOKER) {
+            const long long zsz = P.M0 + R * P.nchains;
+            const long long iR1 = (long long)bounded(D.d0.q0, (uint64_t)zsz);
+            long long iR2 = 1 + (long long)bounded(D.d0.q1, (uint64_t)(zsz - 1));
+            if (iR2 == iR1)
+                iR2 = 0;
+            const long long iz = (long long)bounded(D.d1.q1, (uint64_t)zsz);
+            ra[0] = P.Z + (size_t)iR1 * zs + kk;
+            ra[1] = P.Z + (size_t)iR2 * zs + kk;
+            ra[2] = P.Z + (size_t)iz * zs + kk;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                rv[q] = load_published<false>(ra[q]);
+        } else if constexpr (SMP == MC3HIP_DEMC) {
+            // (the rows of refresh R - 1: asked for while their chains may still be computing
+            // them -- what is not there yet comes back as the sentinel and is asked for again)
+            const double *snap = (R == 0) ? P.snap0
+                                          : P.Z + (size_t)(P.M0 + (R - 1) * P.nchains) * zs;
+            int r1, r2;
+            demc_partners(D.d0.q0, P.nchains, c, r1, r2);
+            ra[0] = snap + (size_t)r1 * zs + kk;
+            ra[1] = snap + (size_t)r2 * zs + kk;
+            rv[0] = load_published<false>(ra[0]);
+            rv[1] = load_published<false>(ra[1]);
+        }
+    };
+    DrawBatch batch;
+    batch.w0 = batch.w1 = batch.w2 = batch.w3 = 0u;
+    batch.base = -(long long)DRAW_BATCH - 1;           // empty
+    auto draws_of = [&](long long it) {
+        if constexpr (SMP == MC3HIP_SNOOKER)
+            return get_draws(batch, P, it, c);
+        else
+            return make_draws(P, (uint64_t)it, c, SMP);
+    };
+    Draws nxt = draws_of(R0);
+    request_rows(nxt, R0);
+    double normal_ahead = need_normal ? normal_draw((uint64_t)R0) : 0.0;
+    double jump_ahead = 0.0;
+    bool jump_ready = false;                           // snooker: the ordinary jump is formed
+    double acc_lo = 0.0, acc_hi = 0.0;
+    bool alive = true, stopped = false;
+#ifdef MC3HIP_STAMPS
+    unsigned long long ta8 = 0, ta10 = 0, ta11 = 0, ta12 = 0, ta13 = 0;
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tk_end = 0;
+#endif
+
+    for (long long R = R0; R < R0 + nref; ++R) {
+        unsigned long long tk0 = 0, tk1 = 0, tkP = 0, tkT = 0, tkC = 0, tk2 = 0, tk3 = 0;
+        (void)tk0; (void)tk1; (void)tkP; (void)tkT; (void)tkC; (void)tk2; (void)tk3;
+        CW_TICK(tk0);
+#ifdef MC3HIP_STAMPS
+        if (tk_end != 0)
+            ta13 += tk0 - tk_end;
+#endif
+        if (R == abort_at) {                           // test hook
+            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            alive = false;
+        }
+        const Draw2 d0 = nxt.d0, d1 = nxt.d1, d2 = nxt.d2;
+        const double u = (SMP == MC3HIP_SNOOKER) ? u01(d2.q1) : u01(d0.q1);   // chain.py:259
+        const double normal_k = normal_ahead;
+        double jump_k, zk = 0.0;
+        bool sjump = false;
+        if constexpr (SMP == MC3HIP_SNOOKER) {         // chain.py:195-217
+            if (jump_ready) {
+                jump_k = jump_ahead;
+            } else {
+                sjump = u01(d1.q0) < 0.1;
+                alive = wait_rows<3, false>(ra, rv, ctl_rw) && alive;
+                const double z1 = rv[0], z2 = rv[1];
+                zk = rv[2];
+                if (sjump) {
+                    const double gs = 1.2 + (2.2 - 1.2) * u01(d2.q0);
+                    const bool same = __all(!mine || zk == xk);
+                    if (same) {
+                        jump_k = gs * (z2 - z1);
+                    } else {
+                        const double dz = xk - zk;
+                        const double zp1 = lane_serial_sum(z1 * dz, nf);
+                        const double zp2 = lane_serial_sum(z2 * dz, nf);
+                        const double dd = lane_serial_sum(dz * dz, nf);
+                        jump_k = ((gs * (zp1 - zp2)) * dz) / dd;
+                    }
+                } else {
+                    jump_k = P.gamma * (z1 - z2) + P.fepsilon * normal_k;
+                }
+            }
+        } else if constexpr (SMP == MC3HIP_MRW) {      // chain.py:219-220
+            jump_k = normal_k;
+        } else {                                       // chain.py:221-232
+            alive = wait_rows<2, false>(ra, rv, ctl_rw) && alive;
+            jump_k = P.gamma * (rv[0] - rv[1]) + P.fepsilon * normal_k;
+        }
+        CW_TICK(tk1);
+        // proposal and boundaries, chain.py:235-243
+        const double npk = xk + jump_k;
+        const bool outk = mine && (npk < pmin_k || npk > pmax_k);
+        const bool anyout = __any(outk);
+        if (mine)
+            s_nextp[jfree] = npk;
+        const int cmd = !alive ? CW_STOP : (anyout ? CW_SKIP : CW_GO);
+        if (lane == 0)
+            s_cmd[0] = cmd;
+        CW_TICK(tkP);
+        block_sync<9>();                               // (A) the proposal (or the order) is there
+        if (cmd == CW_STOP) {
+            stopped = true;
+            break;
+        }
+        // while the compute waves work: everything of the NEXT iteration that needs no chain
+        // state, and the logarithm this iteration's Metropolis test is decided with
+        auto prepare = [&](bool evaluated) {
+            if (evaluated)
+                accept_window(u, acc_lo, acc_hi);
+            nxt = draws_of(R + 1);
+            if constexpr (SMP != MC3HIP_DEMC)
+                request_rows(nxt, R + 1);
+            if (need_normal)
+                normal_ahead = normal_draw((uint64_t)(R + 1));
+            if constexpr (SMP == MC3HIP_SNOOKER) {
+                // the next jump itself when it is an ordinary one (nine in ten) and its two
+                // rows are there: the likelihood takes longer than their round trip
+                jump_ready = false;
+                if (!(u01(nxt.d1.q0) < 0.1)) {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
+                    const bool there = !__any(mc3_bits(rv[0]) == ROW_PENDING ||
+                                              mc3_bits(rv[1]) == ROW_PENDING);
+                    if (there) {
+                        jump_ahead = P.gamma * (rv[0] - rv[1]) + P.fepsilon * normal_ahead;
+                        jump_ready = true;
+                    }
+                }
+            }
+        };
+        bool accepted = false;
+        if (cmd == CW_SKIP) {
+            oob += outk ? 1ull : 0ull;                 // chain.py:242-243
+            prepare(false);
+            CW_TICK(tk3);
+        } else {
+#ifndef MC3HIP_EXP_NO_NOISE
+            wavelet_noise_terms(s_nextp, P.nparams, M, s_tab);
+#endif
+            for (int k = 0; k < nhalo; ++k)
+                block_sync<9>();                       // the halo barriers of stage A
+            block_sync<9>();                           // (1) the values stage A left
+            prepare(true);
+            if constexpr (SMP != MC3HIP_DEMC)
+                __builtin_amdgcn_s_waitcnt(0x0F70);    // (what was asked for has arrived: said
+                                                       // here, the wait cannot land behind the
+                                                       // stores of the publish)
+            block_sync<9>();                           // (3) the chisq is there
+            CW_TICK(tkT);
+            const double total = s_result[0];
+            CW_TICK(tkC);
+            // (as WaveletHook::finish: the prior term of a problem without priors is 0.0)
+            const double nextchisq = is_pos_inf(total) ? total : total + 0.0;
+            CW_TICK(tk2);
+            if (!sjump) {
+                accepted = metropolis_accept(0.5 * (cur - nextchisq), u, acc_lo, acc_hi);
+            } else {                                   // chain.py:251-255
+                const double dc = xk - zk, dn = npk - zk;
+                const double cnorm = lane_serial_sum(mine ? dc * dc : 0.0, nf);
+                const double nnorm = lane_serial_sum(mine ? dn * dn : 0.0, nf);
+                const double mrfactor = mc3_det_pow_half(nnorm / cnorm, nf - 1);
+                accepted = mc3_det_exp(0.5 * (cur - nextchisq)) * mrfactor > u;
+            }
+            if (accepted) {                            // chain.py:257-274
+                xk = npk;
+                cur = nextchisq;
+                nacc += 1;
+            }
+            CW_TICK(tk3);
+        }
+        // Z append, chain.py:276-289
+        const long long row = P.M0 + R * P.nchains + c;
+        if (mine)
+            __hip_atomic_store(&P.Z[(size_t)row * zs + lane], xk, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);             // publish (sc1)
+        if constexpr (SMP == MC3HIP_DEMC) {
+            // the partners' rows of this refresh: asked for right behind the own row, so that
+            // their round trip runs while the rest of the bookkeeping does
+            request_rows(nxt, R + 1);
+        }
+        if (lane == 0) {
+            P.log_post[row] = -0.5 * cur;
+            P.zchain[row] = c;
+        }
+        if (accepted && cur < best) {
+            best = cur;
+            if (mine)
+                P.bestx[(size_t)lc * nf + lane] = xk;
+            if (lane == 0)
+                P.best_iter[lc] = R;
+        }
+#ifdef MC3HIP_STAMPS
+        CW_TICK(tk_end);
+        if (cmd == CW_GO) {
+            ta8 += tk1 - tk0; tr0 += tkP - tk1; tr1 += tkT - tkP; tr2 += tkC - tkT;
+            tr3 += tk2 - tkC; ta10 += tk3 - tk2; ta11 += tk_end - tk3; ta12 += 1;
+        }
+#endif
+    }
+    if (mine) {
+        P.X[(size_t)lc * nf + lane] = xk;
+        if (oob)
+            atomicAdd(&P.outbounds[lane], oob);
+    }
+    if (lane == 0) {
+        P.chisq[lc] = cur;
+        P.best_chisq[lc] = best;
+        P.numaccept[lc] = nacc0 + nacc;
+    }
+#ifdef MC3HIP_STAMPS
+    if (lane == 0 && lc == 0) {
+        P.stamps[16 + 8] += ta8; P.stamps[16 + 10] += ta10; P.stamps[16 + 11] += ta11;
+        P.stamps[16 + 12] += ta12; P.stamps[16 + 13] += ta13;
+        P.stamps[16] += tr0; P.stamps[17] += tr1; P.stamps[18] += tr2; P.stamps[19] += tr3;
+    }
+#endif
+    return stopped;
+}
+
 // (SMP: the sampler, known at compile time -- the chain wave's path between two likelihoods is
 // what an iteration waits for, so the other samplers' branches are compiled out of it)
 template <int MT, int SMP>
@@ -129,8 +423,12 @@ __global__ __launch_bounds__(576) void wavelet_cw_kernel(const DevProblem P, con
         H.M = ilog2(P.ndata);
         H.skip = false;
         H.stopped = false;
-        run_chain<1, MT, false, false, true, SMP, false, PH_CHAINWAVE, false, 0, false,
-                  WaveletHook>(P, P.ctl[0], nref, 0, -1, &H, (int)blockIdx.x, own);
+        if (P.cw_lean)
+            H.stopped = lean_chain_wave<SMP>(P, nref, L.nextp, L.tab, s_cmd, s_result, H.nhalo,
+                                             H.M);
+        else
+            run_chain<1, MT, false, false, true, SMP, false, PH_CHAINWAVE, false, 0, false,
+                      WaveletHook>(P, P.ctl[0], nref, 0, -1, &H, (int)blockIdx.x, own);
         if (!H.stopped) {                               // the run is over: the others leave too
             if ((tid & 63) == 0)
                 s_cmd[0] = CW_STOP;

@@ -384,6 +384,7 @@ int decide_persist(mc3hip_ctx *c)
     c->persist_refs = 0;
     c->mc_chains = 0;
     c->P.mc_chains = 0;
+    c->P.cw_lean = 0;
     if ((c->flags & MC3HIP_FLAG_NO_PERSIST) || getenv("MC3HIP_NO_PERSIST"))
         return 0;
     c->resident = false;
@@ -436,6 +437,7 @@ int decide_persist(mc3hip_ctx *c)
     c->chainwave = c->P.wlike && c->wpc == 8 && !c->P.wl_scratch &&
                    !(c->flags & MC3HIP_FLAG_P2P) && !getenv("MC3HIP_NO_CHAINWAVE") &&
                    c->smem + CW_EXTRA_DOUBLES * sizeof(double) <= 160 * 1024;
+    c->P.cw_lean = (c->chainwave && cw_lean_eligible(c) && !getenv("MC3HIP_NO_CW_LEAN")) ? 1 : 0;
     // Helper waves for the hand-laid-out DEMC loop (lean_demc_wide_kernel) are NOT the
     // default: measured on MI355X (tools/lean_waves.py, profiles/r03_lean_waves.jsonl) two /
     // four waves per chain run C2 at 203 / 207 M chain-steps/s against 219 for one -- the two
@@ -1074,6 +1076,8 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
     plan->fast = (plan->persistent > 0 && c->fast) ? (lean_demc_eligible(c) ? 2 : 1) : 0;
     if (plan->fast == 2 && c->p2p_ranks <= 1)
         plan->waves_per_chain = lean_waves(c);      // (helper waves share the data sum)
+    if (plan->persistent > 0 && chainwave_runs(c, c->p2p_ranks > 1) && c->P.cw_lean)
+        plan->fast = 3;                             // (wavelet: the hand-structured chain wave)
     plan->tile_tree = tile_uses_mfma(c) ? 2 : 0;
     plan->resident = (plan->persistent > 0 && c->resident) ? 1 : 0;
     plan->comm_graph = c->cgraph_exec ? c->comm_graph_nodes : 0;

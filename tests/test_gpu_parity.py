@@ -811,3 +811,62 @@ def test_lean_demc_helper_waves_resume_and_abort(eng, monkeypatch, waves):
     assert_same(orc, gpu, trace=False)
     gpu.close()
     monkeypatch.delenv('MC3HIP_TEST_ABORT_AT')
+
+
+# ---- wavelet likelihood: the hand-structured chain wave (kernels_wavelet.h) -------------
+def _cw_problem(sampler, ndata, case):
+    prob = H.wavelet_problem(ndata=ndata, nchains=12, nsamples=12*160, sampler=sampler)
+    if case == 'epsilon':
+        prob.update(fepsilon=0.03, fgamma=0.8)
+    elif case == 'tight':           # most proposals leave the box: the likelihood is skipped
+        prob.update(pmin=np.array([2.6, -2.6, 0.47, 0.0, 0.3, 0.8]),
+                    pmax=np.array([3.4, -2.2, 0.53, 2.0, 0.7, 1.2]))
+    elif case == 'wide':            # none does
+        prob.update(pmin=np.full(6, -1e3), pmax=np.full(6, 1e3))
+    return prob
+
+
+@pytest.mark.parametrize('case', ['plain', 'epsilon', 'tight', 'wide'])
+@pytest.mark.parametrize('ndata', [8192, 16384])
+@pytest.mark.parametrize('sampler', ['snooker', 'demc', 'mrw'])
+def test_wavelet_lean_chain_wave_bit_exact(eng, sampler, ndata, case):
+    """Without trace / priors / shared parameters / thinning the ninth wave of the wavelet
+    kernel runs lean_chain_wave instead of the general run_chain: same rows, counters, best
+    fits as the oracle (and therefore as the general chain, which the traced tests run)."""
+    orc, gpu = run_pair(eng, _cw_problem(sampler, ndata, case), trace=False)
+    plan = gpu.plan
+    assert plan['fast'] == 3 and plan['persistent'] > 0 and plan['recoveries'] == 0, plan
+    assert_same(orc, gpu, trace=False)
+    if case == 'tight':
+        assert gpu.state()['outbounds'].sum() > 100
+    gpu.close()
+
+
+@pytest.mark.parametrize('sampler', ['snooker', 'demc', 'mrw'])
+def test_wavelet_lean_chain_wave_resume_abort_and_switch(eng, monkeypatch, sampler):
+    prob = _cw_problem(sampler, 16384, 'plain')
+    # several launches: every launch starts without anything prepared ahead
+    gpu = eng.DeviceChains(**prob)
+    orc = H.make_oracle(prob, plan=gpu.plan)
+    Z0, lp0 = H.initial_population(orc)
+    orc.set_population(Z0, lp0)
+    gpu.set_population(Z0, lp0)
+    orc.run(nthreads=4)
+    for n in (1, 2, 64, 65, 28):
+        gpu.run(n)
+    assert gpu.plan['fast'] == 3
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+    # a launch that gives up (test hook) is redone from the checkpoint
+    monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '21')
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert gpu.plan['recoveries'] == 1
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+    monkeypatch.delenv('MC3HIP_TEST_ABORT_AT')
+    # the general chain behind the same kernel
+    monkeypatch.setenv('MC3HIP_NO_CW_LEAN', '1')
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert gpu.plan['fast'] == 0 and gpu.plan['persistent'] > 0
+    assert_same(orc, gpu, trace=False)
+    gpu.close()

@@ -56,6 +56,10 @@ CONFIGS = {
                                           sampler='mrw'), {}),
     'c4demc': lambda n: (H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*n,
                                            sampler='demc'), {}),
+    # no bounds to speak of: every proposal is evaluated (C4's own bounds reject 3 in 10
+    # snooker proposals before the likelihood, as the reference does)
+    'c4wide': lambda n: (H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*n,
+                                           pmin=np.full(6, -1e3), pmax=np.full(6, 1e3)), {}),
     'c4half': lambda n: (H.wavelet_problem(ndata=16384, nchains=128, nsamples=128*n), {}),
     'c5': lambda n: (H.linear_problem(ndata=100000, nchains=512, nsamples=512*n), {}),
     'c5share': lambda n: (H.linear_problem(ndata=100000, nchains=512, nsamples=512*n),
@@ -68,11 +72,11 @@ BYTES = {'q5': 8*3*100000 + 8*3*4 + 8, 'c4mrw': 8*2*16384 + 8*5*4 + 8, 'c4demc':
 ITERS = {'c2': 20000, 'c2snooker': 20000, 'c3one': 4000, 'c4': 4000, 'c5': 30, 'c5share': 1}
 ITERS['c5'] = 300
 ITERS['q5'] = 300
-ITERS.update(c4mrw=4000, c4demc=4000, c4half=4000, c3x2=3000, c3x4=2000, c3x2snooker=3000,
+ITERS.update(c4wide=4000, c4mrw=4000, c4demc=4000, c4half=4000, c3x2=3000, c3x4=2000, c3x2snooker=3000,
              c4x2=2000, c4x4=1000)
 for _k in ('c3x2', 'c3x4', 'c3x2snooker'):
     BYTES[_k] = 24104
-for _k in ('c4x2', 'c4x4'):
+for _k in ('c4x2', 'c4x4', 'c4wide'):
     BYTES[_k] = BYTES['c4']
 
 
@@ -99,7 +103,9 @@ def main():
         dt = time.perf_counter() - t0
         steps = g.nlocal*n*g.thinning
         rate = steps/dt/1e6
-        acc = g.state()['numaccept'].sum()/(g.nlocal*g.refresh_done*g.thinning)
+        state = g.state()
+        acc = state['numaccept'].sum()/(g.nlocal*g.refresh_done*g.thinning)
+        oob = np.max(state['outbounds'])/(g.nlocal*g.refresh_done*g.thinning)
         print(json.dumps({
             'config': name, 'nchains': g.nchains, 'nlocal': g.nlocal, 'ndata': g.ndata,
             'sampler': g.sampler, 'wlike': g.wlike, 'iterations': n,
@@ -112,7 +118,8 @@ def main():
             **({'useful_fp64_TFLOPs': round(rate*1e6*2*g.nmodel*g.ndata/1e12, 2),
                 'frac_of_fp64_peak': round(rate*1e6*2*g.nmodel*g.ndata/78.6e12, 4)}
                if name.startswith('c5') else {}),
-            'plan': g.plan, 'acceptance': round(float(acc), 3)}), flush=True)
+            'plan': g.plan, 'acceptance': round(float(acc), 3),
+            'out_of_bounds_max_param': round(float(oob), 3)}), flush=True)
         g.close()
 
 

@@ -57,7 +57,7 @@ if len(sys.argv) > 1 and sys.argv[1] in ('c5', 'q5'):
     print(f'  {"sum":62s} {sum(v for _, v in rows)/n:9.0f}')
     sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == 'c4cw':
-    # python tools/ticks.py c4cw [sampler]    C4 with the chain-wave kernel: phases of the chain
+    # python tools/ticks.py c4cw [sampler] [wide]    C4 (wide: bounds that reject nothing) with the chain-wave kernel: phases of the chain
     # wave of workgroup 0 (kernels_wavelet.h)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
@@ -65,7 +65,9 @@ if len(sys.argv) > 1 and sys.argv[1] == 'c4cw':
     import tools_pop
     NIT = 4000
     smp = sys.argv[2] if len(sys.argv) > 2 else 'snooker'
-    prob = H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*(NIT + 600), sampler=smp)
+    wide = dict(pmin=np.full(6, -1e3), pmax=np.full(6, 1e3)) if 'wide' in sys.argv else {}
+    prob = H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*(NIT + 600), sampler=smp,
+                             **wide)
     g = engine.DeviceChains(**prob)
     Z0, lp0 = tools_pop.population(g)
     g.set_population(Z0, lp0)
