@@ -146,18 +146,21 @@ extern __shared__ __attribute__((aligned(16))) double mc3_smem_stamps_[];
 #else
 // (threads the LDS areas were carved for: a chain-wave workgroup has one wave more)
 #define MC3_LSTAMP_THREADS (blockDim.x > 512 ? 512 : blockDim.x)
+// (the thread that stamps: the first of the wave that runs the pyramid's tail -- wave 1 in a
+// chain-wave workgroup, wavelet_body TW)
+#define MC3_LSTAMP_TID (blockDim.x > 512 ? 64u : 0u)
 #define MC3_LSTAMP(slot)                                                                  \
     do {                                                                                  \
         /* (the builtin, not inline asm with an SGPR output: some stamps sit in control    \
            flow the compiler considers divergent) */                                      \
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();                       \
-        if (threadIdx.x == 0 && blockIdx.x == 0)                                          \
+        if (threadIdx.x == MC3_LSTAMP_TID && blockIdx.x == 0)                             \
             reinterpret_cast<unsigned long long *>(mc3_smem_stamps_)[MC3_LSTAMP_THREADS + \
                 MC3HIP_MAX_PARAMS + 2 + 32 + (slot)] = t_;                                \
     } while (0)
 #define MC3_LSTAMP_FLUSH()                                                                \
     do {                                                                                  \
-        if (threadIdx.x == 0 && blockIdx.x == 0)                                          \
+        if (threadIdx.x == MC3_LSTAMP_TID && blockIdx.x == 0)                             \
             for (int q_ = 0; q_ < 16; ++q_)                                               \
                 P.stamps[q_] = reinterpret_cast<unsigned long long *>(                    \
                     mc3_smem_stamps_)[MC3_LSTAMP_THREADS + MC3HIP_MAX_PARAMS + 2 + 32 + q_]; \

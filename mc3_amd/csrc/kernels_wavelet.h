@@ -194,6 +194,56 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
             rv[1] = load_published<false>(ra[1]);
         }
     };
+    // The noise terms of a proposal (wavelet_noise_terms: software exp2, a division and a
+    // logarithm per scale, the ordered log-determinant sum) cost the chain wave ~300 vector
+    // instructions -- issued on a SIMD it shares with two compute waves in the middle of
+    // stage A, which every other wave then waits for at the halo barriers (measured: 0.35 us
+    // of a 4.9 us iteration).  Whenever the NEXT jump is known while the likelihood is still
+    // being computed (MRW always; snooker nine times in ten) the next proposal can only be
+    // one of two vectors -- the jump added to the state as it is, or to this proposal once
+    // accepted -- so the terms of both are computed then, on SIMDs that have nothing else to
+    // do (lanes 0..31: rejected, 32..63: accepted; a scale per lane, M <= 22), and the
+    // Metropolis test merely selects which half goes to LDS.  Same operations on the same
+    // operands as wavelet_noise_terms.
+    int kn[3];                                         // free index of gamma, sigma_r, sigma_w
+    double fixv[3];                                    // (-1: fixed, value in fixv)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const unsigned long long b = __ballot(mine && jfree == P.nparams - 3 + q);
+        kn[q] = b ? (int)__ffsll((long long)b) - 1 : -1;
+        fixv[q] = P.params[P.nparams - 3 + q];
+    }
+    const bool spec_noise = (P.cw_lean & 2) != 0;
+    double na_val = 0.0, na_lg0 = 0.0, na_lg1 = 0.0;
+    bool noise_ready = false, last_accepted = false;
+    auto noise_ahead = [&](double x_rej, double x_acc) {
+        const int half = lane >> 5, m = lane & 31;
+        double pv[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int k = kn[q] >= 0 ? kn[q] : 0;
+            const double a = read_lane(x_rej, k), b = read_lane(x_acc, k);
+            pv[q] = kn[q] >= 0 ? (half ? b : a) : fixv[q];
+        }
+        const double gam = pv[0], sr = pv[1], sw = pv[2];
+        const double sr2 = sr * sr, sw2 = sw * sw;
+        const bool smooth = m == 0;
+        const double e = mc3_det_exp2(smooth ? -gam : -gam * (double)m);
+        const double se = sr2 * e;
+        const double s2 = (smooth ? se * 0.72134752 : se) + sw2;
+        const double lg = mc3_det_log(6.283185307179586 * s2);
+        const double val = smooth ? s2 : 1.0 / s2;
+        const double term = (smooth ? 2.0 : (double)(1 << m)) * lg;
+        double lg0 = read_lane(term, 0), lg1 = read_lane(term, 32);
+        for (int q = 1; q < M; ++q) {                  // scales added in order
+            lg0 = lg0 + read_lane(term, q);
+            lg1 = lg1 + read_lane(term, 32 + q);
+        }
+        na_val = val;
+        na_lg0 = lg0;
+        na_lg1 = lg1;
+        noise_ready = true;
+    };
     DrawBatch batch;
     batch.w0 = batch.w1 = batch.w2 = batch.w3 = 0u;
     batch.base = -(long long)DRAW_BATCH - 1;           // empty
@@ -213,6 +263,7 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
 #ifdef MC3HIP_STAMPS
     unsigned long long ta8 = 0, ta10 = 0, ta11 = 0, ta12 = 0, ta13 = 0;
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tk_end = 0;
+    unsigned long long ta14 = 0, ta15 = 0;             // prepare: all of it / the noise terms
 #endif
 
     for (long long R = R0; R < R0 + nref; ++R) {
@@ -270,6 +321,19 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
         const bool anyout = __any(outk);
         if (mine)
             s_nextp[jfree] = npk;
+        const bool noise_there = noise_ready;          // (prepared for exactly this proposal)
+        if (noise_there) {
+            if ((lane >> 5) == (last_accepted ? 1 : 0)) {
+                const int m = lane & 31;
+                if (m >= 1 && m < M) {
+                    s_tab[m] = na_val;
+                } else if (m == 0) {
+                    s_tab[24] = na_val;
+                    s_tab[25] = last_accepted ? na_lg1 : na_lg0;
+                }
+            }
+        }
+        noise_ready = false;
         const int cmd = !alive ? CW_STOP : (anyout ? CW_SKIP : CW_GO);
         if (lane == 0)
             s_cmd[0] = cmd;
@@ -282,11 +346,17 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
         // while the compute waves work: everything of the NEXT iteration that needs no chain
         // state, and the logarithm this iteration's Metropolis test is decided with
         auto prepare = [&](bool evaluated) {
-            if (evaluated)
-                accept_window(u, acc_lo, acc_hi);
+            unsigned long long tp0 = 0, tp1 = 0, tp2 = 0;
+            (void)tp0; (void)tp1; (void)tp2;
+            CW_TICK(tp0);
             nxt = draws_of(R + 1);
             if constexpr (SMP != MC3HIP_DEMC)
                 request_rows(nxt, R + 1);
+            if (evaluated) {
+                accept_window(u, acc_lo, acc_hi);
+                // (the bounds themselves, not log u with the rest left for after the barrier)
+                asm volatile("; window" : "+v"(acc_lo), "+v"(acc_hi));
+            }
             if (need_normal)
                 normal_ahead = normal_draw((uint64_t)(R + 1));
             if constexpr (SMP == MC3HIP_SNOOKER) {
@@ -302,16 +372,32 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
                         jump_ready = true;
                     }
                 }
+                CW_TICK(tp1);
+                if (jump_ready && spec_noise)
+                    noise_ahead(xk + jump_ahead, npk + jump_ahead);
+            } else if constexpr (SMP == MC3HIP_MRW) {
+                CW_TICK(tp1);
+                if (spec_noise)
+                    noise_ahead(xk + normal_ahead, npk + normal_ahead);
             }
+            CW_TICK(tp2);
+#ifdef MC3HIP_STAMPS
+            if (evaluated) {
+                ta14 += tp2 - tp0;
+                ta15 += (tp1 != 0) ? tp2 - tp1 : 0;
+            }
+#endif
         };
         bool accepted = false;
+        last_accepted = false;
         if (cmd == CW_SKIP) {
             oob += outk ? 1ull : 0ull;                 // chain.py:242-243
             prepare(false);
             CW_TICK(tk3);
         } else {
 #ifndef MC3HIP_EXP_NO_NOISE
-            wavelet_noise_terms(s_nextp, P.nparams, M, s_tab);
+            if (!noise_there)
+                wavelet_noise_terms(s_nextp, P.nparams, M, s_tab);
 #endif
             for (int k = 0; k < nhalo; ++k)
                 block_sync<9>();                       // the halo barriers of stage A
@@ -342,6 +428,7 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
                 cur = nextchisq;
                 nacc += 1;
             }
+            last_accepted = accepted;
             CW_TICK(tk3);
         }
         // Z append, chain.py:276-289
@@ -387,6 +474,7 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
     if (lane == 0 && lc == 0) {
         P.stamps[16 + 8] += ta8; P.stamps[16 + 10] += ta10; P.stamps[16 + 11] += ta11;
         P.stamps[16 + 12] += ta12; P.stamps[16 + 13] += ta13;
+        P.stamps[16 + 14] += ta14; P.stamps[16 + 15] += ta15;
         P.stamps[16] += tr0; P.stamps[17] += tr1; P.stamps[18] += tr2; P.stamps[19] += tr3;
     }
 #endif
@@ -437,6 +525,11 @@ __global__ __launch_bounds__(576) void wavelet_cw_kernel(const DevProblem P, con
         return;
     }
     // ---- the compute waves -------------------------------------------------------------------
+    // (the ninth wave shares a SIMD with two of these, and computes the proposal's noise terms
+    // while they run level 0: it gets the issue slots they leave, not every other one)
+#ifndef MC3HIP_EXP_NO_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     for (;;) {
         block_sync<9>();                                // (A)
         MC3_LSTAMP(0);
@@ -455,7 +548,7 @@ __global__ __launch_bounds__(576) void wavelet_cw_kernel(const DevProblem P, con
         else
             c = wavelet_body<8, MT, 16, false, true>(P, L.nextp, L.part, L.flag, L.tab, L.halo,
                                                      L.xs, nullptr, 0, nullptr, 0, &model);
-        if (tid == 0)
+        if (tid == 64)                                  // (wavelet_body CW: wave 1 runs the tail)
             s_result[0] = c;
         MC3_LSTAMP(1);
         block_sync<9>();                                // (3)

@@ -155,13 +155,11 @@ __device__ __forceinline__ double wavelet_level0(const DevProblem &P, const Mode
     for (int j = 0; j < PF + 2 && j < B + 2; ++j)
         fetch(j);
     (void)in1;
-    auto resid = [&](int j) {                           // j: static index into the block;
-        double m, dv;                                   // B, B+1: the next block's first two
-        if constexpr (VALUES) {
-            return in0[j];
-        } else if constexpr (MT == MT_LINEAR) {
-            m = model.at(j < B ? base + j : (base + j) & (N - 1));
-            dv = in0[j];
+    // the model at point j of the block (B, B+1: the next block's first two); j static in the
+    // pyramid below, a loop index in the rare rescan
+    auto model_value = [&](int j, double xj) {
+        if constexpr (MT == MT_LINEAR) {
+            return model.at(j < B ? base + j : (base + j) & (N - 1));
         } else if constexpr (GRID) {
             // numpy.linspace: y = arange(num) * step + start, y[-1] = stop
             const double fi = (j < B) ? fbase + (double)j : fnext + (double)(j - B);
@@ -170,14 +168,37 @@ __device__ __forceinline__ double wavelet_level0(const DevProblem &P, const Mode
                 x = (me == Ta - 1) ? P.wl_xlast : x;
             if (j >= B && N <= 2)
                 x = (j - B == N - 1) ? P.wl_xlast : x;
-            m = model.at_x(x);
-            dv = in0[j];
+            return model.at_x(x);
         } else {
-            m = model.at_x(in0[j]);
-            dv = in1[j];
+            return model.at_x(xj);
         }
-        sawinf |= is_pos_inf(m);
-        return dv - m;
+    };
+    // A +inf model value makes the likelihood +inf (chain.py:322-323).  Not looked for point
+    // by point: the residual of such a point is -inf (or NaN), every D4 coefficient is
+    // non-zero, so the detail of its pair and with it this level's sum of squares is not
+    // finite -- one test per block below, and only then are the block's model values (and the
+    // two halo points', which enter its last pair) looked at one by one.
+    auto resid = [&](int j) {                           // j: static index into the block
+        if constexpr (VALUES) {
+            return in0[j];
+        } else if constexpr (MT == MT_LINEAR || GRID) {
+            return in0[j] - model_value(j, 0.0);
+        } else {
+            return in1[j] - model_value(j, in0[j]);
+        }
+    };
+    auto rescan = [&]() {
+        int seen = 0;
+        if constexpr (!VALUES) {
+#pragma unroll 1
+            for (int j = 0; j < B + 2; ++j) {
+                double xj = 0.0;
+                if constexpr (MT != MT_LINEAR && !GRID)
+                    xj = (j < B) ? xme[j * T] : xnext[(j - B) * T];
+                seen |= is_pos_inf(model_value(j, xj)) ? 1 : 0;
+            }
+        }
+        return seen;
     };
     double acc0 = 0.0;
     if (N >= 4) {
@@ -196,9 +217,13 @@ __device__ __forceinline__ double wavelet_level0(const DevProblem &P, const Mode
             r0 = r2;
             r1 = r3;
         }
+        if (__builtin_expect(!(__builtin_fabs(acc0) < __builtin_inf()), 0))
+            sawinf |= rescan();
     } else {
         v[0] = resid(0);                                // N = 2: no level at all
         v[1] = resid(1);
+        if (!(__builtin_fabs(v[0]) < __builtin_inf()) || !(__builtin_fabs(v[1]) < __builtin_inf()))
+            sawinf |= rescan();
     }
     return acc0;
 }
@@ -217,15 +242,20 @@ __device__ __forceinline__ void wavelet_noise_terms(const double *s_nextp, int n
     const double sr = s_nextp[nparams - 2];
     const double sw = s_nextp[nparams - 1];
     const double sr2 = sr * sr, sw2 = sw * sw;
+    // (one pass for the smooth scale -- lane 0 -- and the detail scales: the same operations
+    // on each lane's own operands as two branches would do, at half the instructions)
+    const bool smooth = lane == 0;
+    const double e = mc3_det_exp2(smooth ? -gam : -gam * (double)lane);
+    const double se = sr2 * e;
+    const double s2 = (smooth ? se * 0.72134752 : se) + sw2;     // sigma_S^2 / sigma_W^2
+    const double lg = mc3_det_log(6.283185307179586 * s2);
     double term = 0.0;
     if (lane >= 1 && lane < M) {
-        const double sW2 = sr2 * mc3_det_exp2(-gam * (double)lane) + sw2;
-        s_tab[lane] = 1.0 / sW2;
-        term = (double)(1 << lane) * mc3_det_log(6.283185307179586 * sW2);
-    } else if (lane == 0) {
-        const double sS2 = sr2 * mc3_det_exp2(-gam) * 0.72134752 + sw2;
-        s_tab[24] = sS2;
-        term = 2.0 * mc3_det_log(6.283185307179586 * sS2);
+        s_tab[lane] = 1.0 / s2;
+        term = (double)(1 << (lane & 31)) * lg;
+    } else if (smooth) {
+        s_tab[24] = s2;
+        term = 2.0 * lg;
     }
     double Lg = read_lane(term, 0);
     for (int m = 1; m < M; ++m)
@@ -256,6 +286,11 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
     const int tid = threadIdx.x, lane = tid & 63;
     // (made wave-uniform by hand so that the per-wave roles below are scalar branches)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the wave that runs stages B and C alone.  Chain-wave kernels: not wave 0 -- the ninth
+    // wave lands on wave 0's SIMD (waves are dealt round robin, tools/probes/wave_placement.hip),
+    // and what it prepares for the next iteration while the tail runs would take issue slots
+    // from the one wave everybody is waiting for
+    constexpr int TW = (CW && WPC > 1) ? 1 : 0;
     const int M = ilog2(P.ndata);
     const int N = VALUES ? B * T : P.ndata;             // length of the array stage A starts from
     const int Ta = N / B;                               // threads that own a block
@@ -322,7 +357,7 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
         block_sync<WPC>();                              // (1) the T values are in LDS
         if (!CW && wave == WPC - 1)
             wavelet_noise_terms(s_nextp, P.nparams, M, s_tab);
-        if (CW && wave == 0) {
+        if (CW && wave == TW) {
             // (chain-wave kernels: everybody's stage-A sums are in LDS already -- asked for now,
             // added up while stage B runs)
             double p[WPC];
@@ -337,7 +372,7 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
             }
             pA = p[0];
         }
-        if (wave == 0) {
+        if (wave == TW) {
             // ---- stage B: T values, WPC per lane, levels inside the lane -----------------
             double vb[WPC + 2];
 #pragma unroll
@@ -359,7 +394,7 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
     double accC[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     const int mC = mscale;
     int nC = 0;
-    if (wave == 0) {
+    if (wave == TW) {
 #pragma unroll
         for (int l = 0; l < 6; ++l) {
             if (nn >= 4) {
@@ -387,8 +422,8 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
             s_part[tid] = (active && N >= 4) ? stage_a_sum() : 0.0;
             block_sync<WPC>();                          // (3) every thread's stage-A sum
         }
-        if (wave != 0)
-            return 0.0;                                 // the value is only used by wave 0
+        if (wave != TW)
+            return 0.0;                                 // the value is only used by that wave
         if constexpr (CW) {
             // the three stage sums in one interleaved pass; total (A + B) + C as ever
             double sA = pA, sB = weigh_levels<NLB>(accB, s_tab, mA - NLA), sC = 0.0;

@@ -100,8 +100,6 @@ if which == 'c4' and g.plan['waves_per_chain'] == 8 and not os.environ.get('MC3H
     for k, v in zip(lab, acc2/max(m, 1)):
         print(f'    {k:50s} {v:9.0f}')
     print(f'    {"sum (A) -> (3)":50s} {acc2.sum()/max(m, 1):9.0f}')
-    g.run(420)
-    print(f'    wall: {g.last_run_ms()*1e3/420:.2f} us per iteration (this build)')
 elif which == 'c4':
     lab = ['top -> proposal known (barrier)', '-> wavelet entry',
            '-> level 0 done (wave 0)', '-> levels 1.. done (stage A)',
