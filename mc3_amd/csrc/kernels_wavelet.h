@@ -127,13 +127,28 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
     const int lane = threadIdx.x & 63;
     const int lc = (int)blockIdx.x;
     const int c = P.chain0 + lc;
-    const int nf = P.nfree, zs = P.zs;
+    // The launch arguments this loop uses, as scalars of their own.  Left inside the wide
+    // register tuples the kernel arguments arrive in they are spilled and reloaded sixteen
+    // registers at a time for the sake of one (this kernel's scalar registers are full: the
+    // general chain and the compute path live in it too).
+    double *Zr = P.Z, *log_post = P.log_post, *bestx = P.bestx;
+    const double *snap0 = P.snap0;
+    int32_t *zchain = P.zchain;
+    long long *best_iter = P.best_iter;
+    long long M0 = P.M0;
+    uint64_t seed = P.seed;
+    double gamma = P.gamma, fepsilon = P.fepsilon;
+    int nchains = P.nchains, nparams = P.nparams, nf = P.nfree, zs = P.zs;
+    asm volatile("; own" : "+s"(Zr), "+s"(log_post), "+s"(bestx), "+s"(snap0), "+s"(zchain),
+                           "+s"(best_iter), "+s"(M0), "+s"(seed));
+    asm volatile("; own" : "+s"(gamma), "+s"(fepsilon), "+s"(nchains), "+s"(nparams), "+s"(nf),
+                           "+s"(zs));
     const bool mine = lane < nf;
     const int kk = mine ? lane : 0;
     const long long R0 = P.ctl[0];
     long long *ctl_rw = const_cast<long long *>(P.ctl);
-    const double *snap_first = (R0 == 0) ? P.snap0
-                                         : P.Z + (size_t)(P.M0 + (R0 - 1) * P.nchains) * zs;
+    const double *snap_first = (R0 == 0) ? snap0
+                                         : Zr + (size_t)(M0 + (R0 - 1) * nchains) * zs;
     double xk = mine ? snap_first[(size_t)c * zs + lane] : 0.0;
     double cur = P.chisq[lc];
     double best = P.best_chisq[lc];
@@ -143,19 +158,19 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
     const int jfree = mine ? P.ifree[lane] : 0;
     const double pmin_k = mine ? P.fmin[lane] : 0.0;
     const double pmax_k = mine ? P.fmax[lane] : 0.0;
-    const bool need_normal = (SMP == MC3HIP_MRW) || (P.fepsilon != 0.0);
+    const bool need_normal = (SMP == MC3HIP_MRW) || (fepsilon != 0.0);
     const double pstep_k = (mine && need_normal) ? P.fstep[lane] : 0.0;
     const long long abort_at = (P.test_abort >= 0 && lc == 0) ? (long long)P.test_abort : -1;
     // the fixed parameters never change: written once, the free ones every iteration
-    if (lane < P.nparams)
+    if (lane < nparams)
         s_nextp[lane] = P.params[lane];
-    if (lane + 64 < P.nparams)
+    if (lane + 64 < nparams)
         s_nextp[lane + 64] = P.params[lane + 64];
 
     auto normal_draw = [&](uint64_t it) {              // chain.py:185, as run_chain's
         double nk = 0.0;
         if (mine) {
-            const Draw2 d = draw2(P.seed, it, (uint32_t)c, (uint32_t)(3 + (lane >> 1)));
+            const Draw2 d = draw2(seed, it, (uint32_t)c, (uint32_t)(3 + (lane >> 1)));
             const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(d.q0)));
             double sn, cs;
             mc3_det_sincos2pi(u01(d.q1), &sn, &cs);
@@ -169,89 +184,58 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
     double rv[NR] = {};
     auto request_rows = [&](const Draws &D, long long R) {
         if constexpr (SMP == MC3HIP_SNOOKER) {
-            const long long zsz = P.M0 + R * P.nchains;
+            const long long zsz = M0 + R * nchains;
             const long long iR1 = (long long)bounded(D.d0.q0, (uint64_t)zsz);
             long long iR2 = 1 + (long long)bounded(D.d0.q1, (uint64_t)(zsz - 1));
             if (iR2 == iR1)
                 iR2 = 0;
             const long long iz = (long long)bounded(D.d1.q1, (uint64_t)zsz);
-            ra[0] = P.Z + (size_t)iR1 * zs + kk;
-            ra[1] = P.Z + (size_t)iR2 * zs + kk;
-            ra[2] = P.Z + (size_t)iz * zs + kk;
+            ra[0] = Zr + (size_t)iR1 * zs + kk;
+            ra[1] = Zr + (size_t)iR2 * zs + kk;
+            ra[2] = Zr + (size_t)iz * zs + kk;
 #pragma unroll
             for (int q = 0; q < 3; ++q)
                 rv[q] = load_published<false>(ra[q]);
         } else if constexpr (SMP == MC3HIP_DEMC) {
             // (the rows of refresh R - 1: asked for while their chains may still be computing
             // them -- what is not there yet comes back as the sentinel and is asked for again)
-            const double *snap = (R == 0) ? P.snap0
-                                          : P.Z + (size_t)(P.M0 + (R - 1) * P.nchains) * zs;
+            const double *snap = (R == 0) ? snap0
+                                          : Zr + (size_t)(M0 + (R - 1) * nchains) * zs;
             int r1, r2;
-            demc_partners(D.d0.q0, P.nchains, c, r1, r2);
+            demc_partners(D.d0.q0, nchains, c, r1, r2);
             ra[0] = snap + (size_t)r1 * zs + kk;
             ra[1] = snap + (size_t)r2 * zs + kk;
             rv[0] = load_published<false>(ra[0]);
             rv[1] = load_published<false>(ra[1]);
         }
     };
-    // The noise terms of a proposal (wavelet_noise_terms: software exp2, a division and a
-    // logarithm per scale, the ordered log-determinant sum) cost the chain wave ~300 vector
-    // instructions -- issued on a SIMD it shares with two compute waves in the middle of
-    // stage A, which every other wave then waits for at the halo barriers (measured: 0.35 us
-    // of a 4.9 us iteration).  Whenever the NEXT jump is known while the likelihood is still
-    // being computed (MRW always; snooker nine times in ten) the next proposal can only be
-    // one of two vectors -- the jump added to the state as it is, or to this proposal once
-    // accepted -- so the terms of both are computed then, on SIMDs that have nothing else to
-    // do (lanes 0..31: rejected, 32..63: accepted; a scale per lane, M <= 22), and the
-    // Metropolis test merely selects which half goes to LDS.  Same operations on the same
-    // operands as wavelet_noise_terms.
-    int kn[3];                                         // free index of gamma, sigma_r, sigma_w
-    double fixv[3];                                    // (-1: fixed, value in fixv)
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const unsigned long long b = __ballot(mine && jfree == P.nparams - 3 + q);
-        kn[q] = b ? (int)__ffsll((long long)b) - 1 : -1;
-        fixv[q] = P.params[P.nparams - 3 + q];
-    }
-    const bool spec_noise = (P.cw_lean & 2) != 0;
-    double na_val = 0.0, na_lg0 = 0.0, na_lg1 = 0.0;
-    bool noise_ready = false, last_accepted = false;
-    auto noise_ahead = [&](double x_rej, double x_acc) {
-        const int half = lane >> 5, m = lane & 31;
-        double pv[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int k = kn[q] >= 0 ? kn[q] : 0;
-            const double a = read_lane(x_rej, k), b = read_lane(x_acc, k);
-            pv[q] = kn[q] >= 0 ? (half ? b : a) : fixv[q];
-        }
-        const double gam = pv[0], sr = pv[1], sw = pv[2];
-        const double sr2 = sr * sr, sw2 = sw * sw;
-        const bool smooth = m == 0;
-        const double e = mc3_det_exp2(smooth ? -gam : -gam * (double)m);
-        const double se = sr2 * e;
-        const double s2 = (smooth ? se * 0.72134752 : se) + sw2;
-        const double lg = mc3_det_log(6.283185307179586 * s2);
-        const double val = smooth ? s2 : 1.0 / s2;
-        const double term = (smooth ? 2.0 : (double)(1 << m)) * lg;
-        double lg0 = read_lane(term, 0), lg1 = read_lane(term, 32);
-        for (int q = 1; q < M; ++q) {                  // scales added in order
-            lg0 = lg0 + read_lane(term, q);
-            lg1 = lg1 + read_lane(term, 32 + q);
-        }
-        na_val = val;
-        na_lg0 = lg0;
-        na_lg1 = lg1;
-        noise_ready = true;
-    };
     DrawBatch batch;
     batch.w0 = batch.w1 = batch.w2 = batch.w3 = 0u;
     batch.base = -(long long)DRAW_BATCH - 1;           // empty
     auto draws_of = [&](long long it) {
-        if constexpr (SMP == MC3HIP_SNOOKER)
-            return get_draws(batch, P, it, c);
-        else
-            return make_draws(P, (uint64_t)it, c, SMP);
+        Draws D;
+        if constexpr (SMP == MC3HIP_SNOOKER) {         // (get_draws / fill_draws, handoff.h)
+            if (it < batch.base || it >= batch.base + DRAW_BATCH) {
+                const uint64_t bi = (uint64_t)it + (uint64_t)((unsigned)lane / 3u);
+                uint32_t w[4];
+                philox4x32_10((uint32_t)bi, (uint32_t)(bi >> 32), (uint32_t)c,
+                              (unsigned)lane % 3u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+                batch.w0 = w[0];
+                batch.w1 = w[1];
+                batch.w2 = w[2];
+                batch.w3 = w[3];
+                batch.base = it;
+            }
+            const int l = 3 * (int)(it - batch.base);
+            D.d0 = batch_draw(batch, l);
+            D.d1 = batch_draw(batch, l + 1);
+            D.d2 = batch_draw(batch, l + 2);
+        } else {
+            D.d0 = draw2(seed, (uint64_t)it, (uint32_t)c, 0u);
+            D.d1 = D.d0;
+            D.d2 = D.d0;
+        }
+        return D;
     };
     Draws nxt = draws_of(R0);
     request_rows(nxt, R0);
@@ -263,7 +247,7 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
 #ifdef MC3HIP_STAMPS
     unsigned long long ta8 = 0, ta10 = 0, ta11 = 0, ta12 = 0, ta13 = 0;
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tk_end = 0;
-    unsigned long long ta14 = 0, ta15 = 0;             // prepare: all of it / the noise terms
+    unsigned long long ta14 = 0;                       // prepare
 #endif
 
     for (long long R = R0; R < R0 + nref; ++R) {
@@ -305,14 +289,14 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
                         jump_k = ((gs * (zp1 - zp2)) * dz) / dd;
                     }
                 } else {
-                    jump_k = P.gamma * (z1 - z2) + P.fepsilon * normal_k;
+                    jump_k = gamma * (z1 - z2) + fepsilon * normal_k;
                 }
             }
         } else if constexpr (SMP == MC3HIP_MRW) {      // chain.py:219-220
             jump_k = normal_k;
         } else {                                       // chain.py:221-232
             alive = wait_rows<2, false>(ra, rv, ctl_rw) && alive;
-            jump_k = P.gamma * (rv[0] - rv[1]) + P.fepsilon * normal_k;
+            jump_k = gamma * (rv[0] - rv[1]) + fepsilon * normal_k;
         }
         CW_TICK(tk1);
         // proposal and boundaries, chain.py:235-243
@@ -321,19 +305,6 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
         const bool anyout = __any(outk);
         if (mine)
             s_nextp[jfree] = npk;
-        const bool noise_there = noise_ready;          // (prepared for exactly this proposal)
-        if (noise_there) {
-            if ((lane >> 5) == (last_accepted ? 1 : 0)) {
-                const int m = lane & 31;
-                if (m >= 1 && m < M) {
-                    s_tab[m] = na_val;
-                } else if (m == 0) {
-                    s_tab[24] = na_val;
-                    s_tab[25] = last_accepted ? na_lg1 : na_lg0;
-                }
-            }
-        }
-        noise_ready = false;
         const int cmd = !alive ? CW_STOP : (anyout ? CW_SKIP : CW_GO);
         if (lane == 0)
             s_cmd[0] = cmd;
@@ -346,8 +317,8 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
         // while the compute waves work: everything of the NEXT iteration that needs no chain
         // state, and the logarithm this iteration's Metropolis test is decided with
         auto prepare = [&](bool evaluated) {
-            unsigned long long tp0 = 0, tp1 = 0, tp2 = 0;
-            (void)tp0; (void)tp1; (void)tp2;
+            unsigned long long tp0 = 0, tp2 = 0;
+            (void)tp0; (void)tp2;
             CW_TICK(tp0);
             nxt = draws_of(R + 1);
             if constexpr (SMP != MC3HIP_DEMC)
@@ -368,37 +339,31 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
                     const bool there = !__any(mc3_bits(rv[0]) == ROW_PENDING ||
                                               mc3_bits(rv[1]) == ROW_PENDING);
                     if (there) {
-                        jump_ahead = P.gamma * (rv[0] - rv[1]) + P.fepsilon * normal_ahead;
+                        jump_ahead = gamma * (rv[0] - rv[1]) + fepsilon * normal_ahead;
                         jump_ready = true;
                     }
                 }
-                CW_TICK(tp1);
-                if (jump_ready && spec_noise)
-                    noise_ahead(xk + jump_ahead, npk + jump_ahead);
-            } else if constexpr (SMP == MC3HIP_MRW) {
-                CW_TICK(tp1);
-                if (spec_noise)
-                    noise_ahead(xk + normal_ahead, npk + normal_ahead);
             }
             CW_TICK(tp2);
 #ifdef MC3HIP_STAMPS
-            if (evaluated) {
+            if (evaluated)
                 ta14 += tp2 - tp0;
-                ta15 += (tp1 != 0) ? tp2 - tp1 : 0;
-            }
 #endif
         };
         bool accepted = false;
-        last_accepted = false;
         if (cmd == CW_SKIP) {
             oob += outk ? 1ull : 0ull;                 // chain.py:242-243
             prepare(false);
             CW_TICK(tk3);
         } else {
-#ifndef MC3HIP_EXP_NO_NOISE
-            if (!noise_there)
-                wavelet_noise_terms(s_nextp, P.nparams, M, s_tab);
-#endif
+            // (An experiment that lost: whenever the next jump is known during the likelihood
+            // -- MRW always, snooker nine times in ten -- the next proposal is one of two
+            // vectors, and the noise terms of both can be computed then instead of here, where
+            // they take issue slots from two compute waves on this wave's SIMD: 0.2 us of a
+            // 4.8 us iteration to be had.  But the terms are ~2 600 cycles of one wave's
+            // dependent arithmetic, on top of ~2 000 for the rest of prepare(), and the tail
+            // that hides them lasts ~3 300: C4 went from 4.8 to 5.4 us.)
+            wavelet_noise_terms(s_nextp, nparams, M, s_tab);
             for (int k = 0; k < nhalo; ++k)
                 block_sync<9>();                       // the halo barriers of stage A
             block_sync<9>();                           // (1) the values stage A left
@@ -428,13 +393,12 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
                 cur = nextchisq;
                 nacc += 1;
             }
-            last_accepted = accepted;
             CW_TICK(tk3);
         }
         // Z append, chain.py:276-289
-        const long long row = P.M0 + R * P.nchains + c;
+        const long long row = M0 + R * nchains + c;
         if (mine)
-            __hip_atomic_store(&P.Z[(size_t)row * zs + lane], xk, __ATOMIC_RELAXED,
+            __hip_atomic_store(&Zr[(size_t)row * zs + lane], xk, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);             // publish (sc1)
         if constexpr (SMP == MC3HIP_DEMC) {
             // the partners' rows of this refresh: asked for right behind the own row, so that
@@ -442,15 +406,15 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
             request_rows(nxt, R + 1);
         }
         if (lane == 0) {
-            P.log_post[row] = -0.5 * cur;
-            P.zchain[row] = c;
+            log_post[row] = -0.5 * cur;
+            zchain[row] = c;
         }
         if (accepted && cur < best) {
             best = cur;
             if (mine)
-                P.bestx[(size_t)lc * nf + lane] = xk;
+                bestx[(size_t)lc * nf + lane] = xk;
             if (lane == 0)
-                P.best_iter[lc] = R;
+                best_iter[lc] = R;
         }
 #ifdef MC3HIP_STAMPS
         CW_TICK(tk_end);
@@ -474,7 +438,7 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
     if (lane == 0 && lc == 0) {
         P.stamps[16 + 8] += ta8; P.stamps[16 + 10] += ta10; P.stamps[16 + 11] += ta11;
         P.stamps[16 + 12] += ta12; P.stamps[16 + 13] += ta13;
-        P.stamps[16 + 14] += ta14; P.stamps[16 + 15] += ta15;
+        P.stamps[16 + 14] += ta14;
         P.stamps[16] += tr0; P.stamps[17] += tr1; P.stamps[18] += tr2; P.stamps[19] += tr3;
     }
 #endif
@@ -525,11 +489,9 @@ __global__ __launch_bounds__(576) void wavelet_cw_kernel(const DevProblem P, con
         return;
     }
     // ---- the compute waves -------------------------------------------------------------------
-    // (the ninth wave shares a SIMD with two of these, and computes the proposal's noise terms
-    // while they run level 0: it gets the issue slots they leave, not every other one)
-#ifndef MC3HIP_EXP_NO_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
+    // (the ninth wave shares a SIMD with two of these and computes the proposal's noise terms
+    // while they run level 0; raising these waves' priority above its own with
+    // s_setprio measured: nothing)
     for (;;) {
         block_sync<9>();                                // (A)
         MC3_LSTAMP(0);

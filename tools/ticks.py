@@ -94,7 +94,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'c4cw':
     print(f'  {"sum":62s} {sum(v for _, v in rows)/n:9.0f}')
     if g.plan['fast'] == 3:
         print(f'  (inside "likelihood": the chain wave\'s preparation of the next iteration '
-              f'{b0[14]/n:.0f} cycles, of which the noise terms ahead {b0[15]/n:.0f})')
+              f'{b0[14]/n:.0f} cycles)')
     sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == 'c4':
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
