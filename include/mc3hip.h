@@ -106,7 +106,9 @@ typedef struct mc3hip_plan {
                                free polynomial, Gaussian chisq, no priors/shared/epsilon);
                                2: its hand-laid-out DEMC / thinning = 1 loop (lean_demc_kernel);
                                3: wavelet likelihood, nine-wave kernel with the hand-structured
-                               chain wave (thinning 1, no priors / shared parameters / trace) */
+                               chain wave (thinning 1, no priors / shared parameters / trace);
+                               4: resident tiled plan with the hand-structured chain owner
+                               (DEMC, thinning 1, no shared parameters / trace)             */
     int32_t comm_graph;     /* >0: the RCCL exchange runs inside a hipGraph of that many
                                refreshes (step kernel + all-gather + scatter per refresh)   */
     int32_t recoveries;     /* persistent launches that gave up and were redone so far        */

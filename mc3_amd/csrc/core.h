@@ -104,6 +104,9 @@ struct DevProblem {
     // chain-wave wavelet kernel: the hand-structured chain wave serves this problem
     // (kernels_wavelet.h lean_chain_wave, host::cw_lean_eligible)
     int32_t cw_lean;
+    // resident tiled plans: the hand-structured owner serves this problem (resident.h
+    // lean_resident_owner, host::rs_lean_eligible)
+    int32_t rs_lean;
 };
 
 constexpr int PH_FUSED = 0, PH_PROPOSE = 1, PH_FINISH = 2, PH_RESIDENT = 3, PH_CHAINWAVE = 4;
@@ -182,6 +185,20 @@ extern __shared__ __attribute__((aligned(16))) double mc3_smem_stamps_[];
 typedef double mc3_v4d __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double make_double(int lo, int hi) { return __hiloint2double(hi, lo); }
+
+// A launch argument (pointer to global memory) as a scalar of its own: the empty asm detaches
+// it from the wide register tuple the kernel arguments arrive in (which the allocator spills
+// and reloads whole), the address-space type keeps what the optimiser knew about it -- a
+// laundered plain pointer would be accessed with flat instructions.
+template <class T>
+__device__ __forceinline__ T *own_global(T *p)
+{
+    typedef T __attribute__((address_space(1))) *G;
+    G g = (G)p;
+    asm volatile("; own" : "+s"(g));
+    return (T *)g;
+}
+
 
 // ---- model evaluation ------------------------------------------------------
 template <int MT>

@@ -102,6 +102,12 @@ inline bool cw_lean_eligible(const mc3hip_ctx *c)
 {
     return c->P.thinning == 1 && c->P.trace_iters == 0 && c->P.nshare == 0 && c->P.ngprior == 0;
 }
+// ... and those the hand-structured owner of the resident tiled plans is written for
+inline bool rs_lean_eligible(const mc3hip_ctx *c)
+{
+    return c->P.sampler == MC3HIP_DEMC && c->P.thinning == 1 && c->P.trace_iters == 0 &&
+           c->P.nshare == 0;
+}
 inline bool chainwave_runs(const mc3hip_ctx *c, bool p2p)
 {
     return c->chainwave && c->mc_chains == 0 && !p2p;

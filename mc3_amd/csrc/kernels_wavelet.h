@@ -131,16 +131,16 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
     // register tuples the kernel arguments arrive in they are spilled and reloaded sixteen
     // registers at a time for the sake of one (this kernel's scalar registers are full: the
     // general chain and the compute path live in it too).
-    double *Zr = P.Z, *log_post = P.log_post, *bestx = P.bestx;
-    const double *snap0 = P.snap0;
-    int32_t *zchain = P.zchain;
-    long long *best_iter = P.best_iter;
+    double *Zr = own_global(P.Z), *log_post = own_global(P.log_post);
+    double *bestx = own_global(P.bestx);
+    const double *snap0 = own_global(P.snap0);
+    int32_t *zchain = own_global(P.zchain);
+    long long *best_iter = own_global(P.best_iter);
     long long M0 = P.M0;
     uint64_t seed = P.seed;
     double gamma = P.gamma, fepsilon = P.fepsilon;
     int nchains = P.nchains, nparams = P.nparams, nf = P.nfree, zs = P.zs;
-    asm volatile("; own" : "+s"(Zr), "+s"(log_post), "+s"(bestx), "+s"(snap0), "+s"(zchain),
-                           "+s"(best_iter), "+s"(M0), "+s"(seed));
+    asm volatile("; own" : "+s"(M0), "+s"(seed));
     asm volatile("; own" : "+s"(gamma), "+s"(fepsilon), "+s"(nchains), "+s"(nparams), "+s"(nf),
                            "+s"(zs));
     const bool mine = lane < nf;

@@ -385,6 +385,7 @@ int decide_persist(mc3hip_ctx *c)
     c->mc_chains = 0;
     c->P.mc_chains = 0;
     c->P.cw_lean = 0;
+    c->P.rs_lean = 0;
     if ((c->flags & MC3HIP_FLAG_NO_PERSIST) || getenv("MC3HIP_NO_PERSIST"))
         return 0;
     c->resident = false;
@@ -425,6 +426,7 @@ int decide_persist(mc3hip_ctx *c)
             return 0;
         c->resident = true;
         c->resident_chain_block = (int)cb;
+        c->P.rs_lean = (rs_lean_eligible(c) && !getenv("MC3HIP_NO_RS_LEAN")) ? 1 : 0;
         c->fast = false;
         c->persist_refs = 16384;
         if (const char *e = getenv("MC3HIP_PERSIST_REFS"))
@@ -1078,6 +1080,8 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
         plan->waves_per_chain = lean_waves(c);      // (helper waves share the data sum)
     if (plan->persistent > 0 && chainwave_runs(c, c->p2p_ranks > 1) && c->P.cw_lean)
         plan->fast = 3;                             // (wavelet: the hand-structured chain wave)
+    if (plan->persistent > 0 && c->resident && c->P.rs_lean)
+        plan->fast = 4;                             // (resident plans: the hand-structured owner)
     plan->tile_tree = tile_uses_mfma(c) ? 2 : 0;
     plan->resident = (plan->persistent > 0 && c->resident) ? 1 : 0;
     plan->comm_graph = c->cgraph_exec ? c->comm_graph_nodes : 0;

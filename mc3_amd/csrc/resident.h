@@ -424,6 +424,205 @@ struct ResidentPoly : ResidentOwner {
     }
 };
 
+// ---- the owner of a chain, hand-structured ------------------------------------------------
+// run_chain behind the hooks above carries every feature of the general chain, and with them
+// a few hundred scalar registers spilled to vector lanes: of the ~11 000 cycles an owner spends
+// outside the tile phase (tools/ticks.py c5) some 7 000 are its own instructions -- proposal
+// 900, chisq from the sum 1 400, Metropolis 900, Z row 1 200, loop 900 -- while the other
+// seven waves of its workgroup, and every workgroup of its column, wait for it.  This is the
+// same chain for the commonest shape (host::rs_lean_eligible: DEMC, thinning 1, no trace, no
+// shared parameters), as kernels_wavelet.h's lean_chain_wave is for the wavelet kernel: the
+// next draws and log u are computed while the partner rows travel, the partners of the next
+// iteration are asked for right behind the own row, and the launch arguments are scalars of
+// their own.  Same arithmetic in the same order: bit-identical to run_chain's.
+template <int MT, bool P2P, class H>
+__device__ __forceinline__ void lean_resident_owner(const DevProblem &P, const int nref, H &T,
+                                                    const int lc, double *area)
+{
+    const int lane = threadIdx.x & 63;
+    const int c = P.chain0 + lc;
+    double *Zr = own_global(P.Z), *log_post = own_global(P.log_post);
+    double *bestx = own_global(P.bestx);
+    const double *snap0 = own_global(P.snap0);
+    int32_t *zchain = own_global(P.zchain);
+    long long *best_iter = own_global(P.best_iter);
+    long long M0 = P.M0;
+    uint64_t seed = P.seed;
+    double gamma = P.gamma, fepsilon = P.fepsilon;
+    int nchains = P.nchains, nparams = P.nparams, nf = P.nfree, zs = P.zs;
+    asm volatile("; own" : "+s"(M0), "+s"(seed));
+    asm volatile("; own" : "+s"(gamma), "+s"(fepsilon), "+s"(nchains), "+s"(nparams), "+s"(nf),
+                           "+s"(zs));
+    double *s_nextp = area + 64;                       // (carve(): behind the one-wave `part`)
+    const bool mine = lane < nf;
+    const int kk = mine ? lane : 0;
+    const long long R0 = P.ctl[0];
+    long long *ctl_rw = const_cast<long long *>(P.ctl);
+    const double *snap_first = (R0 == 0) ? snap0 : Zr + (size_t)(M0 + (R0 - 1) * nchains) * zs;
+    double xk = mine ? snap_first[(size_t)c * zs + lane] : 0.0;
+    double cur = P.chisq[lc];
+    double best = P.best_chisq[lc];
+    const long long nacc0 = P.numaccept[lc];
+    long long nacc = 0;
+    unsigned long long oob = 0;
+    const int jfree = mine ? P.ifree[lane] : 0;
+    const double pmin_k = mine ? P.fmin[lane] : 0.0;
+    const double pmax_k = mine ? P.fmax[lane] : 0.0;
+    const bool need_normal = fepsilon != 0.0;
+    const double pstep_k = (mine && need_normal) ? P.fstep[lane] : 0.0;
+    const long long abort_at = (P.test_abort >= 0 && lc == 0) ? (long long)P.test_abort : -1;
+    if (lane < nparams)
+        s_nextp[lane] = P.params[lane];
+    if (lane + 64 < nparams)
+        s_nextp[lane + 64] = P.params[lane + 64];
+    auto normal_draw = [&](uint64_t it) {              // chain.py:185, as run_chain's
+        double nk = 0.0;
+        if (mine) {
+            const Draw2 d = draw2(seed, it, (uint32_t)c, (uint32_t)(3 + (lane >> 1)));
+            const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(d.q0)));
+            double sn, cs;
+            mc3_det_sincos2pi(u01(d.q1), &sn, &cs);
+            nk = (rad * ((lane & 1) ? sn : cs)) * pstep_k;
+        }
+        return nk;
+    };
+    // DEMC's two partner rows (chain.py:221-232), of refresh R - 1: asked for while their
+    // chains may still be computing them -- what is not there yet comes back as the sentinel
+    // and is asked for again
+    const double *ra[2] = {nullptr, nullptr};
+    double rv[2] = {0.0, 0.0};
+    auto request_rows = [&](uint64_t q0, long long R) {
+        const double *snap = (R == 0) ? snap0 : Zr + (size_t)(M0 + (R - 1) * nchains) * zs;
+        int r1, r2;
+        demc_partners(q0, nchains, c, r1, r2);
+        ra[0] = snap + (size_t)r1 * zs + kk;
+        ra[1] = snap + (size_t)r2 * zs + kk;
+        rv[0] = load_published<P2P>(ra[0]);
+        rv[1] = load_published<P2P>(ra[1]);
+    };
+    Draw2 nxt = draw2(seed, (uint64_t)R0, (uint32_t)c, 0u);
+    request_rows(nxt.q0, R0);
+    double normal_ahead = need_normal ? normal_draw((uint64_t)R0) : 0.0;
+    bool alive = true, give_up = false;
+#ifdef MC3HIP_STAMPS
+    unsigned long long ta8 = 0, ta10 = 0, ta11 = 0, ta12 = 0, ta13 = 0;
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tk_end = 0;
+#endif
+
+    for (long long R = R0; R < R0 + nref; ++R) {
+        unsigned long long tk0 = 0, tk1 = 0, tkP = 0, tkT = 0, tkC = 0, tk2 = 0, tk3 = 0;
+        (void)tk0; (void)tk1; (void)tkP; (void)tkT; (void)tkC; (void)tk2; (void)tk3;
+        MC3_TICK(tk0);
+#ifdef MC3HIP_STAMPS
+        if (tk_end != 0)
+            ta13 += tk0 - tk_end;
+#endif
+        if (R == abort_at) {                           // test hook
+            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            give_up = true;
+        }
+        const double u = u01(nxt.q1);                  // Metropolis draw, chain.py:259
+        const double normal_k = normal_ahead;
+        // in the shadow of the rows' round trip: the next draws, log u
+        nxt = draw2(seed, (uint64_t)(R + 1), (uint32_t)c, 0u);
+        pin_scalar(nxt.q0);
+        pin_scalar(nxt.q1);
+        double acc_lo, acc_hi;
+        accept_window(u, acc_lo, acc_hi);
+        if (need_normal)
+            normal_ahead = normal_draw((uint64_t)(R + 1));
+        alive = wait_rows<2, P2P>(ra, rv, ctl_rw) && alive;
+        MC3_TICK(tk1);
+        const double jump_k = gamma * (rv[0] - rv[1]) + fepsilon * normal_k;
+        // proposal and boundaries, chain.py:235-243
+        const double npk = xk + jump_k;
+        const bool outk = mine && (npk < pmin_k || npk > pmax_k);
+        const bool anyout = __any(outk);
+        if (mine)
+            s_nextp[jfree] = npk;
+        T.publish(P, lc, s_nextp);
+        MC3_TICK(tkP);
+        alive = T.tile_phase(P, alive && !give_up);
+        MC3_TICK(tkT);
+        if (!alive)
+            break;
+        // (also of a proposal that is out of bounds: the sums must be seen before the row is
+        // reused)
+        const double total = T.collect(P, lc);
+        MC3_TICK(tkC);
+        bool accepted = false;
+        if (!anyout) {
+            const double nextchisq = T.template finish<MT>(P, total, s_nextp);
+            MC3_TICK(tk2);
+            accepted = metropolis_accept(0.5 * (cur - nextchisq), u, acc_lo, acc_hi);
+            if (accepted) {                            // chain.py:257-274
+                xk = npk;
+                cur = nextchisq;
+                nacc += 1;
+            }
+        } else {
+            oob += outk ? 1ull : 0ull;                 // chain.py:242-243
+        }
+        MC3_TICK(tk3);
+        // Z append, chain.py:276-289
+        const long long row = M0 + R * nchains + c;
+        if (mine) {
+            if constexpr (P2P) {
+                for (int pr = 0; pr < P.npeers; ++pr)               // publish everywhere
+                    __hip_atomic_store(&P.peerZ[pr][(size_t)row * zs + lane], xk,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                __hip_atomic_store(&Zr[(size_t)row * zs + lane], xk, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);       // publish (sc1)
+            }
+        }
+        // the partners' rows of this refresh: asked for right behind the own row
+        request_rows(nxt.q0, R + 1);
+        if (lane == 0) {
+            if constexpr (P2P) {
+                for (int pr = 0; pr < P.npeers; ++pr)
+                    __hip_atomic_store(&P.peerLP[pr][row], -0.5 * cur, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                log_post[row] = -0.5 * cur;
+            }
+            zchain[row] = c;
+        }
+        if (accepted && cur < best) {
+            best = cur;
+            if (mine)
+                bestx[(size_t)lc * nf + lane] = xk;
+            if (lane == 0)
+                best_iter[lc] = R;
+        }
+#ifdef MC3HIP_STAMPS
+        MC3_TICK(tk_end);
+        if (!anyout) {
+            ta8 += tk1 - tk0; tr0 += tkP - tk1; tr1 += tkT - tkP; tr2 += tkC - tkT;
+            tr3 += tk2 - tkC; ta10 += tk3 - tk2; ta11 += tk_end - tk3; ta12 += 1;
+        }
+#endif
+    }
+    if (mine) {
+        P.X[(size_t)lc * nf + lane] = xk;
+        if (oob)
+            atomicAdd(&P.outbounds[lane], oob);
+    }
+    if (lane == 0) {
+        P.chisq[lc] = cur;
+        P.best_chisq[lc] = best;
+        P.numaccept[lc] = nacc0 + nacc;
+    }
+#ifdef MC3HIP_STAMPS
+    if (lane == 0 && lc == 0) {
+        P.stamps[8] += ta8; P.stamps[10] += ta10; P.stamps[11] += ta11;
+        P.stamps[12] += ta12; P.stamps[13] += ta13;
+        P.stamps[16] += tr0; P.stamps[17] += tr1; P.stamps[18] += tr2; P.stamps[19] += tr3;
+    }
+#endif
+}
+
 // The tiled plan in one launch (ResidentTile above): grid = tiles x columns of chains, eight
 // waves; wave v of workgroup w also owns chain w + v * workgroups.  P2P: the ensemble is
 // sharded over GPUs, each running this kernel over its own chains; owners publish their Z
@@ -453,9 +652,12 @@ __global__ __launch_bounds__(512) void resident_tile_kernel(const DevProblem P, 
     const int own_chain = wg + (int)(gridDim.x * gridDim.y) * wv;
     if (own_chain < P.nlocal) {
         T.set_owner(P, own_chain, smem + W + 2 + wv * OWN);
-        run_chain<1, MT_LINEAR, false, false, true, -1, false, PH_RESIDENT, P2P, 0, false,
-                  ResidentTile<KB>>(P, P.ctl[0], nref, 0, -1, &T, own_chain,
-                                    smem + W + 2 + wv * OWN);
+        if (P.rs_lean)
+            lean_resident_owner<MT_LINEAR, P2P>(P, nref, T, own_chain, smem + W + 2 + wv * OWN);
+        else
+            run_chain<1, MT_LINEAR, false, false, true, -1, false, PH_RESIDENT, P2P, 0, false,
+                      ResidentTile<KB>>(P, P.ctl[0], nref, 0, -1, &T, own_chain,
+                                        smem + W + 2 + wv * OWN);
     } else {
         // no chain of its own: the tile phase of every iteration, in step with the owners
         for (int R = 0; R < nref; ++R)
@@ -487,9 +689,12 @@ __global__ __launch_bounds__(512) void resident_poly_kernel(const DevProblem P, 
     const int own_chain = wg + (int)(gridDim.x * gridDim.y) * wv;
     if (own_chain < P.nlocal) {
         T.set_owner(P, own_chain, smem + X + 2 + wv * OWN);
-        run_chain<1, KX, false, false, true, -1, false, PH_RESIDENT, P2P, 0, false,
-                  ResidentPoly<KX>>(P, P.ctl[0], nref, 0, -1, &T, own_chain,
-                                    smem + X + 2 + wv * OWN);
+        if (P.rs_lean)
+            lean_resident_owner<KX, P2P>(P, nref, T, own_chain, smem + X + 2 + wv * OWN);
+        else
+            run_chain<1, KX, false, false, true, -1, false, PH_RESIDENT, P2P, 0, false,
+                      ResidentPoly<KX>>(P, P.ctl[0], nref, 0, -1, &T, own_chain,
+                                        smem + X + 2 + wv * OWN);
     } else {
         for (int R = 0; R < nref; ++R)
             for (int j = 0; j < P.thinning; ++j)

@@ -400,3 +400,75 @@ def test_tiled_plans_against_the_reference_chisq_at_c5_size(eng, monkeypatch, go
             assert np.all(tc[0] == tc[0][0])
             np.testing.assert_allclose(tc[0], ref, rtol=1e-10)
             np.testing.assert_allclose(-2.0*lp, ref, rtol=1e-10)
+
+
+# ---- the hand-structured owner (resident.h lean_resident_owner) -----------------------------
+def _lean_case(case):
+    if case == 'c5like':                      # priors on three parameters, bounds on all
+        return linear(nmodel=10, nchains=48, niter=40)
+    if case == 'fixed':                       # a fixed coefficient
+        prob = linear(nmodel=7, nchains=40, niter=40)
+        prob['pstep'] = prob['pstep'].copy()
+        prob['pstep'][5] = 0.0
+        return prob
+    if case == 'epsilon':
+        return linear(nmodel=5, nchains=40, niter=40, fepsilon=0.02, fgamma=0.9)
+    if case == 'tight':                       # most proposals leave the box
+        prob = linear(nmodel=6, nchains=32, niter=60)
+        prob['pmin'] = prob['params'] - 1.2*np.abs(prob['pstep'])
+        prob['pmax'] = prob['params'] + 1.2*np.abs(prob['pstep'])
+        return prob
+    if case == 'tiles69':                     # sums collected 64 at a time
+        return linear(ndata=140000, nmodel=10, nchains=96, niter=5)
+    if case == 'wide12':                      # a block of operand rows in LDS
+        return linear(nmodel=13, nchains=40, niter=30)
+    if case == 'quad':
+        return poly(3, niter=40)
+    if case == 'line':
+        return poly(2, niter=40)
+    if case == 'cubic':
+        return poly(4, niter=40, fepsilon=0.01)
+    raise ValueError(case)
+
+
+@pytest.mark.parametrize('case', ['c5like', 'fixed', 'epsilon', 'tight', 'tiles69', 'wide12',
+                                  'quad', 'line', 'cubic'])
+def test_resident_lean_owner_bit_exact(eng, case):
+    """DEMC, thinning 1, no trace, no shared parameters: the owner of a chain runs
+    lean_resident_owner instead of the general run_chain -- same rows, counters and best fits
+    as the oracle (and so as the general chain, which the traced tests above run)."""
+    orc, gpu = run_pair(eng, _lean_case(case), trace=False)
+    plan = gpu.plan
+    assert plan['resident'] == 1 and plan['fast'] == 4 and plan['recoveries'] == 0, plan
+    assert_same(orc, gpu, trace=False)
+    if case == 'tight':
+        assert gpu.state()['outbounds'].sum() > 50
+    gpu.close()
+
+
+@pytest.mark.parametrize('kind', ['linear', 'poly'])
+def test_resident_lean_owner_resume_abort_and_switch(eng, kind):
+    prob = linear(nmodel=9, nchains=48, niter=40) if kind == 'linear' else poly(3, niter=40)
+    with env(MC3HIP_PERSIST_REFS=7):
+        gpu = eng.DeviceChains(**prob)
+        assert gpu.plan['resident'] == 1 and gpu.plan['persistent'] == 7
+        assert gpu.plan['fast'] == 4
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nrefresh=40, trace=False, nthreads=4)
+        for n in (3, 23, 14):
+            gpu.run(n)
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
+    with env(MC3HIP_TEST_ABORT_AT=9):
+        orc, gpu = run_pair(eng, prob, trace=False)
+        assert gpu.plan['recoveries'] == 1
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
+    with env(MC3HIP_NO_RS_LEAN=1):
+        orc, gpu = run_pair(eng, prob, trace=False)
+        assert gpu.plan['resident'] == 1 and gpu.plan['fast'] == 0
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
