@@ -24,10 +24,13 @@ if has pmc; then
 fi
 # the other configurations on one GPU (each in a fresh process)
 if has configs; then
-    timeout 1200 python tools/bench_configs.py c2 c2snooker c3one c3x2 c3x4 c3x2snooker c4 c4demc c4mrw c4x2 c4x4 c5 q5 \
+    timeout 1200 python tools/bench_configs.py c2 c2snooker c3one c3x2 c3x4 c3x2snooker c4 c4wide c4demc c4mrw c4x2 c4x4 c5 q5 \
         > $out/configs.jsonl 2> $out/configs.err
     MC3HIP_NO_RESIDENT=1 timeout 600 python tools/bench_configs.py c5 q5 > $out/configs_three_launch.jsonl 2> $out/configs3.err
-    MC3HIP_NO_CHAINWAVE=1 timeout 600 python tools/bench_configs.py c4 > $out/configs_no_chainwave.jsonl 2>> $out/configs3.err
+    MC3HIP_NO_CHAINWAVE=1 timeout 600 python tools/bench_configs.py c4 c4wide > $out/configs_no_chainwave.jsonl 2>> $out/configs3.err
+    # the general chain (run_chain) instead of the hand-structured chain wave / chain owner
+    MC3HIP_NO_CW_LEAN=1 MC3HIP_NO_RS_LEAN=1 timeout 600 python tools/bench_configs.py c4 c4wide c5 q5 \
+        > $out/configs_general_chain.jsonl 2>> $out/configs3.err
 fi
 # C4 / C5: kernel trace, instruction mix and stall counters of the dominant kernel
 for cfg in c4 c5; do

@@ -47,6 +47,7 @@ for rel in ('c2_bench.json', 'c2_bench_2ranks_on_1gpu.json', 'c3_bench_8ranks_on
 for rel, name in (('configs.jsonl', 'configs.jsonl'),
                   ('configs_three_launch.jsonl', 'configs_three_launch.jsonl'),
                   ('configs_no_chainwave.jsonl', 'configs_no_chainwave.jsonl'),
+                  ('configs_general_chain.jsonl', 'configs_general_chain.jsonl'),
                   ('kt_c2/c2_kernel_stats.csv', 'c2_lean_kernel_stats.csv'),
                   ('kt_c2/c2_agent_info.csv', 'agent_info.csv'),
                   ('kt_c4/c4_kernel_stats.csv', 'c4_wavelet_kernel_stats.csv'),
