@@ -169,6 +169,16 @@ inline bool lean_demc_eligible(const mc3hip_ctx *c)
            c->P.nparams == c->mt && c->P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
 }
 
+// the headline loop with the draws of 64 refreshes computed at once (lean_demc_kernel BATCH):
+// where more than one wave shares a SIMD (more than 1024 chains on this chip) the loop is
+// bound by the instructions it issues, below that by the hand-off (MC3HIP_LEAN_BATCH=0|1 forces)
+inline bool lean_batch(const mc3hip_ctx *c)
+{
+    if (const char *e = getenv("MC3HIP_LEAN_BATCH"))
+        return atoi(e) != 0;
+    return c->P.nlocal > 1024;
+}
+
 // waves that share the data sum of a chain in the hand-laid-out DEMC loop (kernels_lean.h
 // lean_demc_wide_kernel): 1, 2 or 4.  Several only for the plain headline shape -- every
 // coefficient free, one tile, one GPU -- and only on request (MC3HIP_LEAN_WAVES=2|4): measured

@@ -52,6 +52,8 @@ chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
             return lean_demc_wide_kernel<MT, 4>;
         if (lean_waves(c) == 2)
             return lean_demc_wide_kernel<MT, 2>;
+        if (lean_batch(c))
+            return lean_demc_kernel<MT, false, false, false, true>;
         return lean_demc_kernel<MT, false>;
     }
     if (c->P.sampler == MC3HIP_DEMC)

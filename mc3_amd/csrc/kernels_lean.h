@@ -28,7 +28,13 @@ __global__ __launch_bounds__(64) void persist_fast_kernel(const DevProblem P, co
 //     shadow of refresh R's partner-row wait;
 //   * the Metropolis update is a select, not a branch; only the rare events (new best
 //     fit, out-of-bounds proposal, a failed wait) leave the straight line.
-template <int MT, bool P2P, bool FX = false, bool MULTI = false>
+//
+// BATCH (ensembles of more than one wave per SIMD, where the loop is bound by the instructions
+// it issues, not by the hand-off): the draws of 64 consecutive refreshes are computed at once,
+// one refresh per lane -- Philox, log u and its window, the partners' row offsets as vector
+// instructions once per 64 refreshes instead of ~100 scalar and ~100 vector instructions per
+// refresh -- and a refresh reads its own with v_readlane.  Same draws, same results.
+template <int MT, bool P2P, bool FX = false, bool MULTI = false, bool BATCH = false>
 __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const int nref)
 {
     const int nf = FX ? P.nfree : MT;        // FX: some coefficients are fixed (nfree < MT)
@@ -86,6 +92,23 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
     int r1, r2;
     demc_partners(d.q0, n, c, r1, r2);
     int off1 = r1 * ZS + kk, off2 = r2 * ZS + kk;
+    // BATCH: lane i holds the draws of refresh bbase + i
+    double bu = 0.0, blo = 0.0, bhi = 0.0;
+    int bo1 = 0, bo2 = 0;
+    long long bbase = R0;
+    auto fill = [&](long long base) {
+        const Draw2 dd = draw2(P.seed, (uint64_t)(base + lane), (uint32_t)c, 0u);
+        bu = u01(dd.q1);
+        accept_window(bu, blo, bhi);
+        int q1, q2;
+        demc_partners(dd.q0, n, c, q1, q2);
+        bo1 = q1 * ZS;
+        bo2 = q2 * ZS;
+        bbase = base;
+    };
+    if constexpr (BATCH)
+        fill(R0);
+    (void)bu; (void)blo; (void)bhi; (void)bo1; (void)bo2; (void)bbase;
 
     unsigned long long tk_prev3 = 0, tk_prevend = 0;
     unsigned long long ta8 = 0, ta9 = 0, ta10 = 0, ta11 = 0, ta12 = 0, ta13 = 0, ta14 = 0, ta15 = 0;
@@ -128,6 +151,14 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
         // (a short pause lets the stores of the previous refresh clear the memory pipeline
         // ahead of the polls: +3 % measured, 64..192 cycles all the same)
         __builtin_amdgcn_s_sleep(1);
+        if constexpr (BATCH) {
+            const int idx = (int)(R - bbase);
+            off1 = __builtin_amdgcn_readlane(bo1, idx) + kk;
+            off2 = __builtin_amdgcn_readlane(bo2, idx) + kk;
+            u = read_lane(bu, idx);
+            acc_lo = read_lane(blo, idx);
+            acc_hi = read_lane(bhi, idx);
+        }
         const double *const addr[2] = {pbase + off1, pbase + off2};
         double val[2];
         constexpr int KR = 1;            // polls kept in flight: more measured slower (poll_ring)
@@ -141,6 +172,13 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
 #endif
         const double u_now = u, lo_now = acc_lo, hi_now = acc_hi;
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (BATCH) {
+            // ... and behind them, once in 64 refreshes, the draws of the next 64
+            if (__builtin_expect(R - bbase == 63, 0)) {
+                fill(R + 1);
+                asm volatile("; pin" : "+v"(bu), "+v"(blo), "+v"(bhi), "+v"(bo1), "+v"(bo2));
+            }
+        } else {
         // ... and behind them everything of the next refresh that needs no chain state
         d = draw2(P.seed, (uint64_t)(R + 1), (uint32_t)c, 0u);
         pin_scalar(d.q0);
@@ -151,6 +189,7 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
         off1 = r1 * ZS + kk;
         off2 = r2 * ZS + kk;
         asm volatile("; pin" : "+v"(u), "+v"(off1), "+v"(off2), "+v"(acc_lo), "+v"(acc_hi));
+        }
         __builtin_amdgcn_sched_barrier(0);
 #ifdef MC3HIP_STAMPS
         alive = poll_ring<KR, LM>(addr, ring, val, ctl_rw, &ta14);

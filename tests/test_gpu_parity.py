@@ -870,3 +870,34 @@ def test_wavelet_lean_chain_wave_resume_abort_and_switch(eng, monkeypatch, sampl
     assert gpu.plan['fast'] == 0 and gpu.plan['persistent'] > 0
     assert_same(orc, gpu, trace=False)
     gpu.close()
+
+
+@pytest.mark.parametrize('case', ['quad', 'tight', 'ragged', 'resume'])
+def test_lean_demc_with_the_draws_of_64_refreshes_at_once(eng, monkeypatch, case):
+    """lean_demc_kernel BATCH (the default beyond 1024 chains, forced here): Philox, log u and
+    the partners of 64 consecutive refreshes computed at once, one refresh per lane; launches
+    that start and stop inside a batch."""
+    monkeypatch.setenv('MC3HIP_LEAN_BATCH', '1')
+    if case == 'ragged':
+        prob = H.quad_problem(ndata=37, nchains=9, nsamples=9*400)
+    elif case == 'tight':
+        prob = H.quad_problem(ndata=200, nchains=12, nsamples=12*400)
+        prob.update(params=np.array([4.0, -2.5, 0.5]), pmin=np.array([3.5, -2.8, 0.45]),
+                    pmax=np.array([6.5, -2.2, 0.56]))
+    else:
+        prob = H.quad_problem(ndata=1000, nchains=40, nsamples=40*300)
+    if case == 'resume':
+        gpu = eng.DeviceChains(**prob)
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nthreads=4)
+        for n in (1, 2, 64, 65, 100, 68):
+            gpu.run(n)
+    else:
+        orc, gpu = run_pair(eng, prob, trace=False)
+    plan = gpu.plan
+    assert plan['fast'] == 2 and plan['persistent'] > 0 and plan['recoveries'] == 0, plan
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
