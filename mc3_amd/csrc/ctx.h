@@ -179,6 +179,14 @@ inline bool lean_batch(const mc3hip_ctx *c)
     return c->P.nlocal > 1024;
 }
 
+// ... and so has the same shape with two to four chains per wave: lean_demc_mc_kernel
+inline bool lean_demc_mc_eligible(const mc3hip_ctx *c)
+{
+    return c->fast && c->mc_chains >= 2 && c->mc_chains <= 4 && c->P.sampler == MC3HIP_DEMC &&
+           c->P.thinning == 1 && c->P.nparams == c->mt && c->P.zs == ZROW &&
+           !getenv("MC3HIP_NO_LEAN");
+}
+
 // waves that share the data sum of a chain in the hand-laid-out DEMC loop (kernels_lean.h
 // lean_demc_wide_kernel): 1, 2 or 4.  Several only for the plain headline shape -- every
 // coefficient free, one tile, one GPU -- and only on request (MC3HIP_LEAN_WAVES=2|4): measured

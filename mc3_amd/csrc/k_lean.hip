@@ -41,6 +41,20 @@ chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
 {
     if (c->P.sampler == MC3HIP_MRW)
         return fast_instance_tt<MT, MC3HIP_MRW>(c, p2p);
+    if (lean_demc_mc_eligible(c) && !p2p) {          // 2..4 chains per wave
+#define MC3_LEAN_MC(TT)                                                             \
+        if (c->mc_chains == TT) {                                                   \
+            if (c->P.npad > VLANES)                                                 \
+                return lean_demc_mc_kernel<MT, TT, false, true>;                    \
+            if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)  \
+                return lean_demc_mc_kernel<MT, TT, true>;                           \
+            return lean_demc_mc_kernel<MT, TT>;                                     \
+        }
+        MC3_LEAN_MC(2)
+        MC3_LEAN_MC(3)
+        MC3_LEAN_MC(4)
+#undef MC3_LEAN_MC
+    }
     if (lean_demc_eligible(c)) {
         if (p2p)
             return lean_demc_kernel<MT, true>;

@@ -290,6 +290,208 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
 }
 
 // ---------------------------------------------------------------------------------
+// The same loop for ensembles with more chains than waves can be co-resident (P.mc_chains = T,
+// 2..4; one GPU): a wave owns chains b, b + G, ... b + (T - 1) G of a grid of G and advances
+// them one after another inside every refresh -- the turns of run_chain MC.  There a turn
+// costs ~1.1 us whatever the occupancy (tools/mc_probe.py), of which the arithmetic is ~0.5:
+// every turn waits for the round trip of its own partner rows.  Here
+//   * the partner rows of ALL turns of a refresh are asked for at its top -- they are rows of
+//     the refresh before whichever turn needs them -- so one round trip per refresh is
+//     exposed, not one per turn; nothing is stored before they have all arrived (a wait behind
+//     a store waits for the store's acknowledgement as well: loads and stores share vmcnt);
+//   * T is a compile-time constant and the chains' states stay in registers: no LDS;
+//   * the draws are computed for 64 / T refreshes x T turns at once, one (refresh, turn) per
+//     lane, as in lean_demc_kernel BATCH.
+// The hand-off protocol is unchanged (a chain waits only for rows of the refresh before, and a
+// wave finishes refresh R - 1 for all its chains before it starts R); same arithmetic, same
+// results as run_chain's.
+template <int MT, int T, bool FX = false, bool MULTI = false>
+__global__ __launch_bounds__(64) void lean_demc_mc_kernel(const DevProblem P, const int nref)
+{
+    static_assert(T >= 2 && T <= 4, "2..4 chains per wave");
+    const int nf = FX ? P.nfree : MT;
+    constexpr int ZS = ZROW;
+    constexpr int NB = 64 / T;                 // refreshes per batch of draws
+    const int lane = threadIdx.x;
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    const bool mine = lane < nf;
+    const int kk = mine ? lane : 0;
+    long long *ctl_rw = const_cast<long long *>(P.ctl);
+    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
+            &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+        return;
+    DataTile<1, MT> tile;
+    tile.load(P);
+    DataTile<1, MT> tile1;
+    if constexpr (MULTI)
+        tile1.load(P, VLANES);
+    const long long R0 = P.ctl[0];
+    const int n = P.nchains;
+    const size_t blockstride = (size_t)n * ZS;
+    const double *pbase = (R0 == 0) ? P.snap0 : P.Z + (size_t)(P.M0 + (R0 - 1) * n) * ZS;
+    double *zblock = P.Z + (size_t)(P.M0 + R0 * n) * ZS;
+    double *lp_row = P.log_post + (P.M0 + R0 * n);
+    int32_t *zc_row = P.zchain + (P.M0 + R0 * n);
+    // this wave's chains (the last may not exist: its turn is skipped)
+    bool have[T];
+    int lq[T];
+    double xk[T], cur[T], best[T];
+    int nacc[T];
+#pragma unroll
+    for (int q = 0; q < T; ++q) {
+        have[q] = b + q * G < P.nlocal;
+        lq[q] = have[q] ? b + q * G : b;
+        xk[q] = mine ? pbase[(size_t)(P.chain0 + lq[q]) * ZS + lane] : 0.0;
+        cur[q] = P.chisq[lq[q]];
+        best[q] = P.best_chisq[lq[q]];
+        nacc[q] = 0;
+    }
+    const double pmin_k = mine ? P.fmin[lane] : 0.0;
+    const double pmax_k = mine ? P.fmax[lane] : 0.0;
+    const double gamma = P.gamma, feps = P.fepsilon;
+    const long long abort_at = (P.test_abort >= 0 && b == 0) ? (long long)P.test_abort : -1;
+    bool alive = true;
+    int kf[MT];
+    double fx[MT];
+    if constexpr (FX)
+        coefficient_map<MT>(P, kf, fx);
+    (void)kf; (void)fx;
+    // the draws: lane r T + q holds those of refresh bbase + r, turn q (chain.py:221-232, :259)
+    const int bq = lane % T, br = (lane / T < NB) ? lane / T : NB - 1;
+    const int bl = (b + bq * G < P.nlocal) ? b + bq * G : b;
+    const int bc = P.chain0 + bl;
+    double bu, blo, bhi;
+    int bo1, bo2;
+    long long bbase;
+    auto fill = [&](long long base) {
+        const Draw2 dd = draw2(P.seed, (uint64_t)(base + br), (uint32_t)bc, 0u);
+        bu = u01(dd.q1);
+        accept_window(bu, blo, bhi);
+        int r1, r2;
+        demc_partners(dd.q0, n, bc, r1, r2);
+        bo1 = r1 * ZS;
+        bo2 = r2 * ZS;
+        bbase = base;
+    };
+    fill(R0);
+    const long long Rend = R0 + nref;
+    for (long long R = R0; R < Rend; ++R) {
+        if (__builtin_expect(R == abort_at, 0)) {                                         // test hook
+            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            break;                // (the host restores its checkpoint after an abort)
+        }
+        __builtin_amdgcn_s_sleep(1);
+        // the partner rows of every turn of this refresh, asked for at once
+        const int idx0 = (int)(R - bbase) * T;
+        const double *addr[T][2];
+        double val[T][2], u_q[T], lo_q[T], hi_q[T];
+#pragma unroll
+        for (int q = 0; q < T; ++q) {
+            addr[q][0] = pbase + (__builtin_amdgcn_readlane(bo1, idx0 + q) + kk);
+            addr[q][1] = pbase + (__builtin_amdgcn_readlane(bo2, idx0 + q) + kk);
+            val[q][0] = load_published<false>(addr[q][0]);
+            val[q][1] = load_published<false>(addr[q][1]);
+            u_q[q] = read_lane(bu, idx0 + q);
+            lo_q[q] = read_lane(blo, idx0 + q);
+            hi_q[q] = read_lane(bhi, idx0 + q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (__builtin_expect(R - bbase == NB - 1, 0)) {
+            // ... and behind them, once per batch, the draws of the next NB refreshes
+            fill(R + 1);
+            asm volatile("; pin" : "+v"(bu), "+v"(blo), "+v"(bhi), "+v"(bo1), "+v"(bo2));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < T; ++q) {
+            if (!have[q])
+                continue;
+            const int l = lq[q];
+            const int c = P.chain0 + l;
+            // what is still the sentinel is asked for again (the rows of the refresh before are
+            // the last the other waves have published)
+            if (__builtin_expect(__any(mc3_bits(val[q][0]) == ROW_PENDING ||
+                                       mc3_bits(val[q][1]) == ROW_PENDING), 0)) {
+                const double *const a2[2] = {addr[q][0], addr[q][1]};
+                double v2[2] = {val[q][0], val[q][1]};
+                alive = wait_rows<2, false>(a2, v2, ctl_rw);
+                val[q][0] = v2[0];
+                val[q][1] = v2[1];
+                if (__builtin_expect(!alive, 0))
+                    break;
+            }
+            // proposal and boundaries, chain.py:232-243
+            const double jump_k = gamma * (val[q][0] - val[q][1]) + feps * 0.0;
+            const double npk = xk[q] + jump_k;
+            const bool outk = mine && (npk < pmin_k || npk > pmax_k);
+            if (__builtin_expect(!__any(outk), 1)) {
+                Model<MT> model;
+                if constexpr (!FX) {
+                    model.init_from_lanes(P, npk);
+                } else {
+                    model.init_from_lanes(P, npk, kf, fx);
+                }
+                double nextchisq =
+                    block_gauss_model<1, MT, MULTI, MULTI>(P, model, nullptr, nullptr, tile,
+                                                           &tile1);          // chain.py:249
+                if constexpr (FX)
+                    nextchisq = nextchisq + prior_from_lanes<MT>(P, npk, kf, fx);
+                const bool acc = metropolis_accept(0.5 * (cur[q] - nextchisq), u_q[q], lo_q[q],
+                                                   hi_q[q]);            // chain.py:257-274
+                xk[q] = acc ? npk : xk[q];
+                if (__builtin_expect(__any(acc && nextchisq < best[q]), 0)) {
+                    best[q] = nextchisq;
+                    if (mine)
+                        P.bestx[(size_t)l * nf + lane] = xk[q];
+                    if (lane == 0)
+                        P.best_iter[l] = R;
+                }
+                cur[q] = acc ? nextchisq : cur[q];
+                nacc[q] += acc ? 1 : 0;
+            } else if (outk) {
+                atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
+            }
+            if (q == 0) {
+                // every row asked for at the top has arrived by now: said here, before the
+                // first store of the refresh, no later wait can land behind a store
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+                for (int q2 = 1; q2 < T; ++q2)
+                    asm volatile("; rows of the later turns" : "+v"(val[q2][0]), "+v"(val[q2][1]));
+            }
+            // Z append, chain.py:276-289
+            if (mine)
+                __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk[q], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);            // publish (sc1)
+            if (lane == 0) {
+                lp_row[c] = -0.5 * cur[q];
+                zc_row[c] = c;
+            }
+        }
+        if (__builtin_expect(!alive, 0))
+            break;
+        pbase = zblock;
+        zblock += blockstride;
+        lp_row += n;
+        zc_row += n;
+    }
+#pragma unroll
+    for (int q = 0; q < T; ++q) {
+        if (!have[q])
+            continue;
+        const int l = lq[q];
+        if (mine)
+            P.X[(size_t)l * nf + lane] = xk[q];
+        if (lane == 0) {
+            P.chisq[l] = cur[q];
+            P.best_chisq[l] = best[q];
+            P.numaccept[l] = P.numaccept[l] + nacc[q];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // The same loop with the data sum shared by NW waves on different SIMDs of the CU: with 256
 // chains the chip has three of its four SIMDs idle, and a wave alone issues dependent FP64 at
 // a fraction of the pipe's rate (tools/probes/mfma_f64_probe.hip), so the ~1000 cycles of the

@@ -44,7 +44,8 @@ def test_big_ensembles_stay_on_the_persistent_path(eng, nchains, sampler, nref):
     """C2-shaped (quadratic, ndata 1000) beyond the 2048 co-resident single-wave workgroups."""
     prob = H.quad_problem(ndata=1000, nchains=nchains, nsamples=nchains*nref, sampler=sampler)
     orc, gpu = run_pair(eng, prob, trace=False)
-    check_plan(gpu, fast=1)
+    # (DEMC, two to four chains per wave: the hand-laid-out loop, lean_demc_mc_kernel)
+    check_plan(gpu, fast=2 if sampler == 'demc' else 1)
     assert_same(orc, gpu, trace=False)
     gpu.close()
 
@@ -75,9 +76,18 @@ def test_lean_instances_with_several_chains_per_wave(eng, monkeypatch, sampler, 
     prob = H.quad_problem(ndata=300, nchains=nchains, nsamples=nchains*40*thinning,
                           sampler=sampler, thinning=thinning)
     orc, gpu = run_pair(eng, prob, trace=False)
-    check_plan(gpu, turns=-(-nchains//capacity), fast=1)
+    turns = -(-nchains//capacity)
+    lean_loop = (sampler, thinning) == ('demc', 1) and turns <= 4
+    check_plan(gpu, turns=turns, fast=2 if lean_loop else 1)
     assert_same(orc, gpu, trace=False)
     gpu.close()
+    if lean_loop:
+        # the general lean instance (run_chain MC) behind the switch
+        monkeypatch.setenv('MC3HIP_NO_LEAN', '1')
+        orc, gpu = run_pair(eng, prob, trace=False)
+        check_plan(gpu, turns=turns, fast=1)
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
 
 
 @pytest.mark.parametrize('sampler', ['demc', 'snooker', 'mrw'])
@@ -86,12 +96,12 @@ def test_lean_fixed_coefficient_and_streamed_tiles(eng, monkeypatch, sampler):
     prob = H.quad_problem(ndata=500, nchains=10, nsamples=10*60, sampler=sampler)
     prob['pstep'] = np.array([1.0, 0.0, 0.1])           # FX: the linear coefficient is fixed
     orc, gpu = run_pair(eng, prob, trace=False)
-    check_plan(gpu, turns=4, fast=1)
+    check_plan(gpu, turns=4, fast=2 if sampler == 'demc' else 1)
     assert_same(orc, gpu, trace=False)
     gpu.close()
     prob = H.quad_problem(ndata=3000, nchains=10, nsamples=10*40, sampler=sampler)   # MULTI
     orc, gpu = run_pair(eng, prob, trace=False)
-    check_plan(gpu, turns=4, fast=1)
+    check_plan(gpu, turns=4, fast=2 if sampler == 'demc' else 1)
     assert_same(orc, gpu, trace=False)
     gpu.close()
 
@@ -173,4 +183,45 @@ def test_switch_off(eng, monkeypatch):
     plan = gpu.plan
     assert plan['persistent'] == 0 and plan['chains_per_workgroup'] == 1, plan
     assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
+@pytest.mark.parametrize('turns', [2, 3, 4])
+@pytest.mark.parametrize('case', ['resume', 'abort', 'tight', 'priors', 'ragged'])
+def test_lean_demc_loop_with_several_chains_per_wave(eng, monkeypatch, case, turns):
+    """lean_demc_mc_kernel<.., T>: launches of a few refreshes (each starts a batch of draws
+    anew and reloads the chains' states), a give-up, bounds that reject most proposals,
+    Gaussian priors (FX), an ensemble that leaves the last turn of some waves empty."""
+    nchains = {2: 10, 3: 14, 4: 23}[turns] if case == 'ragged' else 5*turns
+    forced(monkeypatch, 5 if case != 'ragged' else -(-nchains//turns))
+    prob = H.quad_problem(ndata=400, nchains=nchains, nsamples=nchains*70, sampler='demc')
+    if case == 'tight':
+        prob.update(params=np.array([4.0, -2.5, 0.5]), pmin=np.array([3.5, -2.8, 0.45]),
+                    pmax=np.array([6.5, -2.2, 0.56]))
+    if case == 'priors':
+        prob.update(prior=np.array([4.0, 0.0, 0.0]), priorlow=np.array([0.5, 0.0, 0.0]),
+                    priorup=np.array([0.7, 0.0, 0.0]))
+    if case == 'abort':
+        monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '9')
+        orc, gpu = run_pair(eng, prob, trace=False)
+        assert gpu.plan['recoveries'] == 1
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
+        return
+    if case == 'resume':
+        monkeypatch.setenv('MC3HIP_PERSIST_REFS', '7')
+        gpu = eng.DeviceChains(**prob)
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nthreads=4)
+        for n in (1, 2, 30, 37):
+            gpu.run(n)
+    else:
+        orc, gpu = run_pair(eng, prob, trace=False)
+    check_plan(gpu, turns=turns, fast=2)
+    assert_same(orc, gpu, trace=False)
+    if case == 'tight':
+        assert gpu.state()['outbounds'].sum() > 50
     gpu.close()
