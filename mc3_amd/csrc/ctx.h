@@ -110,7 +110,8 @@ inline bool rs_lean_eligible(const mc3hip_ctx *c)
 }
 inline bool chainwave_runs(const mc3hip_ctx *c, bool p2p)
 {
-    return c->chainwave && c->mc_chains == 0 && !p2p;
+    // (several chains per workgroup: only the hand-structured chain wave takes turns)
+    return c->chainwave && !p2p && (c->mc_chains == 0 || c->P.cw_lean != 0);
 }
 
 // Waves per chain are dispatched as {1, 4, 16}; the wavelet geometries have 1, 4 or 8:
@@ -228,6 +229,8 @@ MC3_WAVELET_UNIT(w4)
 MC3_WAVELET_UNIT(w8)
 MC3_WAVELET_UNIT(large)
 #undef MC3_WAVELET_UNIT
+// (k_wavelet_w8mc.hip: the nine-wave kernel with several chains per workgroup)
+chain_kernel_fn persist_instance_wavelet_w8mc(const mc3hip_ctx *c);
 
 // ---- k_lean.hip: the lean one-wave persistent kernels ------------------------------------
 // ONE function picks the instance a context runs, so that the launch and the occupancy query

@@ -38,6 +38,10 @@ void persist_instance_t(const mc3hip_ctx *c, bool p2p, chain_kernel_fn *out)
     if constexpr (WW == 8 && !LARGE) {
         static_assert(CW_EXTRA == CW_EXTRA_DOUBLES, "LDS of the chain wave");
         if (chainwave_runs(c, p2p)) {                   // a wave of its own for the chain
+            if (c->mc_chains > 0) {                     // ... which takes turns: its own unit
+                *out = persist_instance_wavelet_w8mc(c);
+                return;
+            }
             *out = c->P.sampler == MC3HIP_SNOOKER ? wavelet_cw_kernel<MT, MC3HIP_SNOOKER>
                    : c->P.sampler == MC3HIP_DEMC ? wavelet_cw_kernel<MT, MC3HIP_DEMC>
                                                  : wavelet_cw_kernel<MT, MC3HIP_MRW>;

@@ -445,9 +445,414 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
     return stopped;
 }
 
+// The same chain wave for SEVERAL chains per workgroup (more chains than CUs; P.mc_chains > 0,
+// wavelet_cw_kernel<.., MCK = true>).  A function of its own -- and a kernel and a translation
+// unit of their own, k_wavelet_w8mc.hip -- rather than a parameter of lean_chain_wave: the
+// single-chain loop above lost 17 % (C4 3.9 -> 4.6 us) when the two were one piece of code,
+// although every difference folds away at compile time; this code reacts to how it is laid
+// out.  What differs: the chains of a workgroup take turns inside every refresh (run_chain MC),
+// their states wait in LDS between turns, and what is prepared during a likelihood is prepared
+// for the next TURN -- another chain.
+template <int SMP>
+__device__ __forceinline__ bool lean_chain_wave_mc(const DevProblem &P, const int nref,
+                                                double *s_nextp, double *s_tab, int *s_cmd,
+                                                const double *s_result, const int nhalo,
+                                                const int M, double *slots)
+{
+    const int lane = threadIdx.x & 63;
+    // Several chains per workgroup (P.mc_chains > 0: more chains than CUs): chains b, b + G,
+    // ... take turns inside every refresh, as in run_chain MC; what a chain carries from one
+    // refresh to the next waits in LDS (`slots`: [state (zs) | chisq | best | accepts] per
+    // turn), and what is prepared ahead during a likelihood is prepared for the NEXT TURN.
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    constexpr bool mc = true;
+    int nturns = 1;
+    if (mc) {
+        nturns = 0;
+        for (int q = 0; q < P.mc_chains; ++q)
+            nturns += (b + q * G < P.nlocal) ? 1 : 0;
+    }
+    int lc = b;
+    int c = P.chain0 + lc;
+    // The launch arguments this loop uses, as scalars of their own.  Left inside the wide
+    // register tuples the kernel arguments arrive in they are spilled and reloaded sixteen
+    // registers at a time for the sake of one (this kernel's scalar registers are full: the
+    // general chain and the compute path live in it too).
+    double *Zr = own_global(P.Z), *log_post = own_global(P.log_post);
+    double *bestx = own_global(P.bestx);
+    const double *snap0 = own_global(P.snap0);
+    int32_t *zchain = own_global(P.zchain);
+    long long *best_iter = own_global(P.best_iter);
+    long long M0 = P.M0;
+    uint64_t seed = P.seed;
+    double gamma = P.gamma, fepsilon = P.fepsilon;
+    int nchains = P.nchains, nparams = P.nparams, nf = P.nfree, zs = P.zs;
+    asm volatile("; own" : "+s"(M0), "+s"(seed));
+    asm volatile("; own" : "+s"(gamma), "+s"(fepsilon), "+s"(nchains), "+s"(nparams), "+s"(nf),
+                           "+s"(zs));
+    const bool mine = lane < nf;
+    const int kk = mine ? lane : 0;
+    const long long R0 = P.ctl[0];
+    long long *ctl_rw = const_cast<long long *>(P.ctl);
+    const double *snap_first = (R0 == 0) ? snap0
+                                         : Zr + (size_t)(M0 + (R0 - 1) * nchains) * zs;
+    double xk = mine ? snap_first[(size_t)c * zs + lane] : 0.0;
+    double cur = P.chisq[lc];
+    double best = P.best_chisq[lc];
+    long long nacc = P.numaccept[lc];
+    const int sstride = zs + 4;
+    if (mc) {
+        for (int q = 0; q < nturns; ++q) {
+            const int l = b + q * G;
+            double *slot = slots + q * sstride;
+            if (mine)
+                slot[lane] = snap_first[(size_t)(P.chain0 + l) * zs + lane];
+            if (lane == 0) {
+                slot[zs] = P.chisq[l];
+                slot[zs + 1] = P.best_chisq[l];
+                slot[zs + 2] = mc3_from_bits((unsigned long long)P.numaccept[l]);
+            }
+        }
+    }
+    unsigned long long oob = 0;                        // out-of-bounds proposals of this lane's parameter
+    const int jfree = mine ? P.ifree[lane] : 0;
+    const double pmin_k = mine ? P.fmin[lane] : 0.0;
+    const double pmax_k = mine ? P.fmax[lane] : 0.0;
+    const bool need_normal = (SMP == MC3HIP_MRW) || (fepsilon != 0.0);
+    const double pstep_k = (mine && need_normal) ? P.fstep[lane] : 0.0;
+    const long long abort_at = (P.test_abort >= 0 && b == 0) ? (long long)P.test_abort : -1;
+    // the fixed parameters never change: written once, the free ones every iteration
+    if (lane < nparams)
+        s_nextp[lane] = P.params[lane];
+    if (lane + 64 < nparams)
+        s_nextp[lane + 64] = P.params[lane + 64];
+
+    auto normal_draw = [&](uint64_t it, int ch) {      // chain.py:185, as run_chain's
+        double nk = 0.0;
+        if (mine) {
+            const Draw2 d = draw2(seed, it, (uint32_t)ch, (uint32_t)(3 + (lane >> 1)));
+            const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(d.q0)));
+            double sn, cs;
+            mc3_det_sincos2pi(u01(d.q1), &sn, &cs);
+            nk = (rad * ((lane & 1) ? sn : cs)) * pstep_k;
+        }
+        return nk;
+    };
+    // rows asked for ahead: snooker's three (chain.py:195-205), DEMC's two (chain.py:221-232)
+    constexpr int NR = (SMP == MC3HIP_SNOOKER) ? 3 : 2;
+    const double *ra[NR] = {};
+    double rv[NR] = {};
+    auto request_rows = [&](const Draws &D, long long R, int ch) {
+        if constexpr (SMP == MC3HIP_SNOOKER) {
+            const long long zsz = M0 + R * nchains;
+            const long long iR1 = (long long)bounded(D.d0.q0, (uint64_t)zsz);
+            long long iR2 = 1 + (long long)bounded(D.d0.q1, (uint64_t)(zsz - 1));
+            if (iR2 == iR1)
+                iR2 = 0;
+            const long long iz = (long long)bounded(D.d1.q1, (uint64_t)zsz);
+            ra[0] = Zr + (size_t)iR1 * zs + kk;
+            ra[1] = Zr + (size_t)iR2 * zs + kk;
+            ra[2] = Zr + (size_t)iz * zs + kk;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                rv[q] = load_published<false>(ra[q]);
+        } else if constexpr (SMP == MC3HIP_DEMC) {
+            // (the rows of refresh R - 1: asked for while their chains may still be computing
+            // them -- what is not there yet comes back as the sentinel and is asked for again)
+            const double *snap = (R == 0) ? snap0
+                                          : Zr + (size_t)(M0 + (R - 1) * nchains) * zs;
+            int r1, r2;
+            demc_partners(D.d0.q0, nchains, ch, r1, r2);
+            ra[0] = snap + (size_t)r1 * zs + kk;
+            ra[1] = snap + (size_t)r2 * zs + kk;
+            rv[0] = load_published<false>(ra[0]);
+            rv[1] = load_published<false>(ra[1]);
+        }
+    };
+    DrawBatch batch;
+    batch.w0 = batch.w1 = batch.w2 = batch.w3 = 0u;
+    batch.base = -(long long)DRAW_BATCH - 1;           // empty
+    auto draws_of = [&](long long it, int ch) {
+        Draws D;
+        if (SMP == MC3HIP_SNOOKER && mc) {             // (the batch below is one chain's)
+            D.d0 = draw2(seed, (uint64_t)it, (uint32_t)ch, 0u);
+            D.d1 = draw2(seed, (uint64_t)it, (uint32_t)ch, 1u);
+            D.d2 = draw2(seed, (uint64_t)it, (uint32_t)ch, 2u);
+            return D;
+        }
+        if constexpr (SMP == MC3HIP_SNOOKER) {         // (get_draws / fill_draws, handoff.h)
+            if (it < batch.base || it >= batch.base + DRAW_BATCH) {
+                const uint64_t bi = (uint64_t)it + (uint64_t)((unsigned)lane / 3u);
+                uint32_t w[4];
+                philox4x32_10((uint32_t)bi, (uint32_t)(bi >> 32), (uint32_t)c,
+                              (unsigned)lane % 3u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+                batch.w0 = w[0];
+                batch.w1 = w[1];
+                batch.w2 = w[2];
+                batch.w3 = w[3];
+                batch.base = it;
+            }
+            const int l = 3 * (int)(it - batch.base);
+            D.d0 = batch_draw(batch, l);
+            D.d1 = batch_draw(batch, l + 1);
+            D.d2 = batch_draw(batch, l + 2);
+        } else {
+            D.d0 = draw2(seed, (uint64_t)it, (uint32_t)ch, 0u);
+            D.d1 = D.d0;
+            D.d2 = D.d0;
+        }
+        return D;
+    };
+    Draws nxt = draws_of(R0, c);
+    request_rows(nxt, R0, c);
+    double normal_ahead = need_normal ? normal_draw((uint64_t)R0, c) : 0.0;
+    double jump_ahead = 0.0;
+    bool jump_ready = false;                           // snooker: the ordinary jump is formed
+    double acc_lo = 0.0, acc_hi = 0.0;
+    bool alive = true, stopped = false;
+#ifdef MC3HIP_STAMPS
+    unsigned long long ta8 = 0, ta10 = 0, ta11 = 0, ta12 = 0, ta13 = 0;
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tk_end = 0;
+    unsigned long long ta14 = 0;                       // prepare
+#endif
+
+    for (long long R = R0; R < R0 + nref && !stopped; ++R) {
+    for (int q = 0; q < nturns; ++q) {
+        if (mc) {                                      // this turn's chain
+            lc = b + q * G;
+            c = P.chain0 + lc;
+            const double *slot = slots + q * sstride;
+            xk = mine ? slot[lane] : 0.0;
+            cur = slot[zs];
+            best = slot[zs + 1];
+            nacc = (long long)mc3_bits(slot[zs + 2]);
+        }
+        // the turn after this one: the next chain in this refresh, or the first in the next
+        const bool last_turn = q + 1 == nturns;
+        const long long R2 = last_turn ? R + 1 : R;
+        const int c2 = mc ? P.chain0 + b + (last_turn ? 0 : q + 1) * G : c;
+        unsigned long long tk0 = 0, tk1 = 0, tkP = 0, tkT = 0, tkC = 0, tk2 = 0, tk3 = 0;
+        (void)tk0; (void)tk1; (void)tkP; (void)tkT; (void)tkC; (void)tk2; (void)tk3;
+        CW_TICK(tk0);
+#ifdef MC3HIP_STAMPS
+        if (tk_end != 0)
+            ta13 += tk0 - tk_end;
+#endif
+        if (R == abort_at && q == 0) {                 // test hook
+            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            alive = false;
+        }
+        const Draw2 d0 = nxt.d0, d1 = nxt.d1, d2 = nxt.d2;
+        const double u = (SMP == MC3HIP_SNOOKER) ? u01(d2.q1) : u01(d0.q1);   // chain.py:259
+        const double normal_k = normal_ahead;
+        double jump_k, zk = 0.0;
+        bool sjump = false;
+        if constexpr (SMP == MC3HIP_SNOOKER) {         // chain.py:195-217
+            if (jump_ready) {
+                jump_k = jump_ahead;
+            } else {
+                sjump = u01(d1.q0) < 0.1;
+                alive = wait_rows<3, false>(ra, rv, ctl_rw) && alive;
+                const double z1 = rv[0], z2 = rv[1];
+                zk = rv[2];
+                if (sjump) {
+                    const double gs = 1.2 + (2.2 - 1.2) * u01(d2.q0);
+                    const bool same = __all(!mine || zk == xk);
+                    if (same) {
+                        jump_k = gs * (z2 - z1);
+                    } else {
+                        const double dz = xk - zk;
+                        const double zp1 = lane_serial_sum(z1 * dz, nf);
+                        const double zp2 = lane_serial_sum(z2 * dz, nf);
+                        const double dd = lane_serial_sum(dz * dz, nf);
+                        jump_k = ((gs * (zp1 - zp2)) * dz) / dd;
+                    }
+                } else {
+                    jump_k = gamma * (z1 - z2) + fepsilon * normal_k;
+                }
+            }
+        } else if constexpr (SMP == MC3HIP_MRW) {      // chain.py:219-220
+            jump_k = normal_k;
+        } else {                                       // chain.py:221-232
+            alive = wait_rows<2, false>(ra, rv, ctl_rw) && alive;
+            jump_k = gamma * (rv[0] - rv[1]) + fepsilon * normal_k;
+        }
+        CW_TICK(tk1);
+        // proposal and boundaries, chain.py:235-243
+        const double npk = xk + jump_k;
+        const bool outk = mine && (npk < pmin_k || npk > pmax_k);
+        const bool anyout = __any(outk);
+        if (mine)
+            s_nextp[jfree] = npk;
+        const int cmd = !alive ? CW_STOP : (anyout ? CW_SKIP : CW_GO);
+        if (lane == 0)
+            s_cmd[0] = cmd;
+        CW_TICK(tkP);
+        block_sync<9>();                               // (A) the proposal (or the order) is there
+        if (cmd == CW_STOP) {
+            stopped = true;
+            break;
+        }
+        // while the compute waves work: everything of the NEXT iteration that needs no chain
+        // state, and the logarithm this iteration's Metropolis test is decided with
+        auto prepare = [&](bool evaluated) {
+            unsigned long long tp0 = 0, tp2 = 0;
+            (void)tp0; (void)tp2;
+            CW_TICK(tp0);
+            nxt = draws_of(R2, c2);
+            if constexpr (SMP != MC3HIP_DEMC)
+                request_rows(nxt, R2, c2);
+            if (evaluated) {
+                accept_window(u, acc_lo, acc_hi);
+                // (the bounds themselves, not log u with the rest left for after the barrier)
+                asm volatile("; window" : "+v"(acc_lo), "+v"(acc_hi));
+            }
+            if (need_normal)
+                normal_ahead = normal_draw((uint64_t)R2, c2);
+            if constexpr (SMP == MC3HIP_SNOOKER) {
+                // the next jump itself when it is an ordinary one (nine in ten) and its two
+                // rows are there: the likelihood takes longer than their round trip
+                jump_ready = false;
+                if (!(u01(nxt.d1.q0) < 0.1)) {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
+                    const bool there = !__any(mc3_bits(rv[0]) == ROW_PENDING ||
+                                              mc3_bits(rv[1]) == ROW_PENDING);
+                    if (there) {
+                        jump_ahead = gamma * (rv[0] - rv[1]) + fepsilon * normal_ahead;
+                        jump_ready = true;
+                    }
+                }
+            }
+            CW_TICK(tp2);
+#ifdef MC3HIP_STAMPS
+            if (evaluated)
+                ta14 += tp2 - tp0;
+#endif
+        };
+        bool accepted = false;
+        if (cmd == CW_SKIP) {
+            oob += outk ? 1ull : 0ull;                 // chain.py:242-243
+            prepare(false);
+            CW_TICK(tk3);
+        } else {
+            // (An experiment that lost: whenever the next jump is known during the likelihood
+            // -- MRW always, snooker nine times in ten -- the next proposal is one of two
+            // vectors, and the noise terms of both can be computed then instead of here, where
+            // they take issue slots from two compute waves on this wave's SIMD: 0.2 us of a
+            // 4.8 us iteration to be had.  But the terms are ~2 600 cycles of one wave's
+            // dependent arithmetic, on top of ~2 000 for the rest of prepare(), and the tail
+            // that hides them lasts ~3 300: C4 went from 4.8 to 5.4 us.)
+            wavelet_noise_terms(s_nextp, nparams, M, s_tab);
+            for (int k = 0; k < nhalo; ++k)
+                block_sync<9>();                       // the halo barriers of stage A
+            block_sync<9>();                           // (1) the values stage A left
+            prepare(true);
+            if constexpr (SMP != MC3HIP_DEMC)
+                __builtin_amdgcn_s_waitcnt(0x0F70);    // (what was asked for has arrived: said
+                                                       // here, the wait cannot land behind the
+                                                       // stores of the publish)
+            block_sync<9>();                           // (3) the chisq is there
+            CW_TICK(tkT);
+            const double total = s_result[0];
+            CW_TICK(tkC);
+            // (as WaveletHook::finish: the prior term of a problem without priors is 0.0)
+            const double nextchisq = is_pos_inf(total) ? total : total + 0.0;
+            CW_TICK(tk2);
+            if (!sjump) {
+                accepted = metropolis_accept(0.5 * (cur - nextchisq), u, acc_lo, acc_hi);
+            } else {                                   // chain.py:251-255
+                const double dc = xk - zk, dn = npk - zk;
+                const double cnorm = lane_serial_sum(mine ? dc * dc : 0.0, nf);
+                const double nnorm = lane_serial_sum(mine ? dn * dn : 0.0, nf);
+                const double mrfactor = mc3_det_pow_half(nnorm / cnorm, nf - 1);
+                accepted = mc3_det_exp(0.5 * (cur - nextchisq)) * mrfactor > u;
+            }
+            if (accepted) {                            // chain.py:257-274
+                xk = npk;
+                cur = nextchisq;
+                nacc += 1;
+            }
+            CW_TICK(tk3);
+        }
+        // Z append, chain.py:276-289
+        const long long row = M0 + R * nchains + c;
+        if (mine)
+            __hip_atomic_store(&Zr[(size_t)row * zs + lane], xk, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);             // publish (sc1)
+        if constexpr (SMP == MC3HIP_DEMC) {
+            // the next turn's partner rows: asked for right behind the own row, so that their
+            // round trip runs while the rest of the bookkeeping does
+            request_rows(nxt, R2, c2);
+        }
+        if (lane == 0) {
+            log_post[row] = -0.5 * cur;
+            zchain[row] = c;
+        }
+        if (accepted && cur < best) {
+            best = cur;
+            if (mine)
+                bestx[(size_t)lc * nf + lane] = xk;
+            if (lane == 0)
+                best_iter[lc] = R;
+        }
+        if (mc) {                                      // this chain waits for its next turn
+            double *slot = slots + q * sstride;
+            if (mine)
+                slot[lane] = xk;
+            if (lane == 0) {
+                slot[zs] = cur;
+                slot[zs + 1] = best;
+                slot[zs + 2] = mc3_from_bits((unsigned long long)nacc);
+            }
+        }
+#ifdef MC3HIP_STAMPS
+        CW_TICK(tk_end);
+        if (cmd == CW_GO) {
+            ta8 += tk1 - tk0; tr0 += tkP - tk1; tr1 += tkT - tkP; tr2 += tkC - tkT;
+            tr3 += tk2 - tkC; ta10 += tk3 - tk2; ta11 += tk_end - tk3; ta12 += 1;
+        }
+#endif
+    }   // turns
+    }   // refreshes
+    if (mine && oob)
+        atomicAdd(&P.outbounds[lane], oob);
+    if (mc) {
+        for (int q = 0; q < nturns; ++q) {
+            const int l = b + q * G;
+            const double *slot = slots + q * sstride;
+            if (mine)
+                P.X[(size_t)l * nf + lane] = slot[lane];
+            if (lane == 0) {
+                P.chisq[l] = slot[zs];
+                P.best_chisq[l] = slot[zs + 1];
+                P.numaccept[l] = (long long)mc3_bits(slot[zs + 2]);
+            }
+        }
+    } else {
+        if (mine)
+            P.X[(size_t)lc * nf + lane] = xk;
+        if (lane == 0) {
+            P.chisq[lc] = cur;
+            P.best_chisq[lc] = best;
+            P.numaccept[lc] = nacc;
+        }
+    }
+#ifdef MC3HIP_STAMPS
+    if (lane == 0 && b == 0) {
+        P.stamps[16 + 8] += ta8; P.stamps[16 + 10] += ta10; P.stamps[16 + 11] += ta11;
+        P.stamps[16 + 12] += ta12; P.stamps[16 + 13] += ta13;
+        P.stamps[16 + 14] += ta14;
+        P.stamps[16] += tr0; P.stamps[17] += tr1; P.stamps[18] += tr2; P.stamps[19] += tr3;
+    }
+#endif
+    return stopped;
+}
+
 // (SMP: the sampler, known at compile time -- the chain wave's path between two likelihoods is
 // what an iteration waits for, so the other samplers' branches are compiled out of it)
-template <int MT, int SMP>
+// (MCK: the instance for several chains per workgroup, lean_chain_wave_mc)
+template <int MT, int SMP, bool MCK = false>
 __global__ __launch_bounds__(576) void wavelet_cw_kernel(const DevProblem P, const int nref)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -475,12 +880,17 @@ __global__ __launch_bounds__(576) void wavelet_cw_kernel(const DevProblem P, con
         H.M = ilog2(P.ndata);
         H.skip = false;
         H.stopped = false;
-        if (P.cw_lean)
-            H.stopped = lean_chain_wave<SMP>(P, nref, L.nextp, L.tab, s_cmd, s_result, H.nhalo,
-                                             H.M);
-        else
-            run_chain<1, MT, false, false, true, SMP, false, PH_CHAINWAVE, false, 0, false,
-                      WaveletHook>(P, P.ctl[0], nref, 0, -1, &H, (int)blockIdx.x, own);
+        if constexpr (MCK) {
+            H.stopped = lean_chain_wave_mc<SMP>(P, nref, L.nextp, L.tab, s_cmd, s_result, H.nhalo,
+                                                H.M, smem + P.mc_off);
+        } else {
+            if (P.cw_lean)
+                H.stopped = lean_chain_wave<SMP>(P, nref, L.nextp, L.tab, s_cmd, s_result,
+                                                 H.nhalo, H.M);
+            else
+                run_chain<1, MT, false, false, true, SMP, false, PH_CHAINWAVE, false, 0, false,
+                          WaveletHook>(P, P.ctl[0], nref, 0, -1, &H, (int)blockIdx.x, own);
+        }
         if (!H.stopped) {                               // the run is over: the others leave too
             if ((tid & 63) == 0)
                 s_cmd[0] = CW_STOP;

@@ -479,29 +479,42 @@ int decide_persist(mc3hip_ctx *c)
         // repeated with the instance and the LDS size that would run.  One GPU only.
         if ((c->flags & MC3HIP_FLAG_P2P) || c->p2p_ranks > 1 || getenv("MC3HIP_NO_MULTICHAIN"))
             return 0;
-        const size_t base = c->smem;        // (the hand-laid-out DEMC loop has no MC form)
+        // (the nine-wave wavelet kernel takes turns only with its hand-structured chain wave;
+        // should its LDS not leave room for the waiting states, the fused kernel is tried)
         bool found = false;
-        for (int turns = 2; turns <= MC_MAX_TURNS && !found; ++turns) {
-            c->mc_chains = turns;                       // (selects the MC instance)
-            const size_t smem = base + (size_t)turns * (c->P.zs + 4) * sizeof(double);
-            if (smem > 160 * 1024)
-                break;
-            const void *f = reinterpret_cast<const void *>(
-                c->fast ? fast_instance(c, false) : persist_instance(c, false));
-            if (smem > 64 * 1024)
-                (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            int nbm = blocks_per_cu(f, 64 * c->wpc, smem);
-            if (nbm > 1 && getenv("MC3HIP_PERSIST_MARGIN"))
-                nbm -= 1;
-            const long long grid = ((long long)c->P.nlocal + turns - 1) / turns;
-            long long room = (long long)nbm * prop.multiProcessorCount;
-            room = room < cap_limit ? room : cap_limit;
-            if (nbm >= 1 && grid <= room) {
-                c->mc_grid = (int)grid;
-                c->mc_smem = smem;
-                c->P.mc_chains = turns;
-                c->P.mc_off = (int32_t)(base / sizeof(double));
-                found = true;
+        for (int attempt = 0; attempt < 2 && !found; ++attempt) {
+            const bool cw = !c->fast && c->chainwave && c->P.cw_lean != 0;
+            if (attempt == 1) {
+                if (!cw)
+                    break;
+                c->P.cw_lean = 0;
+            }
+            const bool cw_now = attempt == 0 && cw;
+            const size_t base = c->smem + (cw_now ? CW_EXTRA_DOUBLES * sizeof(double) : 0);
+            const int threads = cw_now ? CW_THREADS : 64 * c->wpc;
+            for (int turns = 2; turns <= MC_MAX_TURNS && !found; ++turns) {
+                c->mc_chains = turns;                       // (selects the MC instance)
+                const size_t smem = base + (size_t)turns * (c->P.zs + 4) * sizeof(double);
+                if (smem > 160 * 1024)
+                    break;
+                const void *f = reinterpret_cast<const void *>(
+                    c->fast ? fast_instance(c, false) : persist_instance(c, false));
+                if (smem > 64 * 1024)
+                    (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)smem);
+                int nbm = blocks_per_cu(f, threads, smem);
+                if (nbm > 1 && getenv("MC3HIP_PERSIST_MARGIN"))
+                    nbm -= 1;
+                const long long grid = ((long long)c->P.nlocal + turns - 1) / turns;
+                long long room = (long long)nbm * prop.multiProcessorCount;
+                room = room < cap_limit ? room : cap_limit;
+                if (nbm >= 1 && grid <= room) {
+                    c->mc_grid = (int)grid;
+                    c->mc_smem = smem;
+                    c->P.mc_chains = turns;
+                    c->P.mc_off = (int32_t)(base / sizeof(double));
+                    found = true;
+                }
             }
         }
         if (!found) {

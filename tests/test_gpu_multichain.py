@@ -56,7 +56,7 @@ def test_wavelet_ensembles_beyond_one_workgroup_per_cu(eng, nchains, nref):
     CU) with more chains than CUs."""
     prob = H.wavelet_problem(ndata=16384, nchains=nchains, nsamples=nchains*nref)
     orc, gpu = run_pair(eng, prob, trace=False)
-    check_plan(gpu, fast=0)
+    check_plan(gpu, fast=3)                  # (nine waves, the chain wave takes the turns)
     assert_same(orc, gpu, trace=False)
     gpu.close()
 
@@ -224,4 +224,44 @@ def test_lean_demc_loop_with_several_chains_per_wave(eng, monkeypatch, case, tur
     assert_same(orc, gpu, trace=False)
     if case == 'tight':
         assert gpu.state()['outbounds'].sum() > 50
+    gpu.close()
+
+
+@pytest.mark.parametrize('case', ['plain', 'epsilon', 'tight', 'resume', 'abort', 'general'])
+@pytest.mark.parametrize('ndata,sampler', [(8192, 'snooker'), (16384, 'demc'), (8192, 'mrw'),
+                                           (16384, 'snooker')])
+def test_wavelet_chain_wave_takes_turns(eng, monkeypatch, ndata, sampler, case):
+    """The nine-wave wavelet kernel with several chains per workgroup: the hand-structured
+    chain wave advances them in turn and prepares, during a likelihood, the NEXT turn's
+    proposal (another chain's).  11 chains over 4 workgroups: 3, 3, 3, 2."""
+    forced(monkeypatch, 4)
+    prob = H.wavelet_problem(ndata=ndata, nchains=11, nsamples=11*50, sampler=sampler)
+    if case == 'epsilon':
+        prob.update(fepsilon=0.03, fgamma=0.8)
+    if case == 'tight':
+        prob.update(pmin=np.array([2.6, -2.6, 0.47, 0.0, 0.3, 0.8]),
+                    pmax=np.array([3.4, -2.2, 0.53, 2.0, 0.7, 1.2]))
+    if case == 'abort':
+        monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '9')
+        orc, gpu = run_pair(eng, prob, trace=False)
+        assert gpu.plan['recoveries'] == 1
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
+        return
+    if case == 'general':                  # the fused eight-wave kernel behind the switch
+        monkeypatch.setenv('MC3HIP_NO_CW_LEAN', '1')
+    if case == 'resume':
+        monkeypatch.setenv('MC3HIP_PERSIST_REFS', '7')
+        gpu = eng.DeviceChains(**prob)
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nthreads=4)
+        for n in (1, 2, 30, 17):
+            gpu.run(n)
+    else:
+        orc, gpu = run_pair(eng, prob, trace=False)
+    check_plan(gpu, turns=3, fast=0 if case == 'general' else 3)
+    assert_same(orc, gpu, trace=False)
     gpu.close()
