@@ -225,12 +225,14 @@ void launch_eval_gauss_w16(mc3hip_ctx *c, int n);
     void launch_eval_wavelet_##tag(mc3hip_ctx *c, int n);                           \
     hipError_t set_smem_attr_wavelet_##tag(mc3hip_ctx *c);
 MC3_WAVELET_UNIT(w1)
+MC3_WAVELET_UNIT(w1b)
 MC3_WAVELET_UNIT(w4)
 MC3_WAVELET_UNIT(w8)
 MC3_WAVELET_UNIT(large)
 #undef MC3_WAVELET_UNIT
 // (k_wavelet_w8mc.hip: the nine-wave kernel with several chains per workgroup)
 chain_kernel_fn persist_instance_wavelet_w8mc(const mc3hip_ctx *c);
+chain_kernel_fn persist_instance_wavelet_w8cw(const mc3hip_ctx *c);
 
 // ---- k_lean.hip: the lean one-wave persistent kernels ------------------------------------
 // ONE function picks the instance a context runs, so that the launch and the occupancy query

@@ -6,7 +6,7 @@
 #include "ctx.h"
 #include "kernels_fused.h"
 #include "wavelet.h"
-#include "kernels_wavelet.h"
+#include "kernels_wavelet.h"   // (CW_EXTRA)
 
 #define MC3_CAT_(a, b) a##b
 #define MC3_CAT(a, b) MC3_CAT_(a, b)
@@ -38,13 +38,10 @@ void persist_instance_t(const mc3hip_ctx *c, bool p2p, chain_kernel_fn *out)
     if constexpr (WW == 8 && !LARGE) {
         static_assert(CW_EXTRA == CW_EXTRA_DOUBLES, "LDS of the chain wave");
         if (chainwave_runs(c, p2p)) {                   // a wave of its own for the chain
-            if (c->mc_chains > 0) {                     // ... which takes turns: its own unit
-                *out = persist_instance_wavelet_w8mc(c);
-                return;
-            }
-            *out = c->P.sampler == MC3HIP_SNOOKER ? wavelet_cw_kernel<MT, MC3HIP_SNOOKER>
-                   : c->P.sampler == MC3HIP_DEMC ? wavelet_cw_kernel<MT, MC3HIP_DEMC>
-                                                 : wavelet_cw_kernel<MT, MC3HIP_MRW>;
+            // (the nine-wave kernels are compiled in units of their own, k_wavelet_w8cw.hip and
+            // -- several chains per workgroup -- k_wavelet_w8mc.hip: this unit was the longest)
+            *out = c->mc_chains > 0 ? persist_instance_wavelet_w8mc(c)
+                                    : persist_instance_wavelet_w8cw(c);
             return;
         }
     }
@@ -72,6 +69,24 @@ void set_attr_t(mc3hip_ctx *c, hipError_t *e)
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->smem);
 }
 
+// MC3_MT_SPLIT (the one-wave geometry: five block sizes x five model kinds made this the
+// longest unit of the build): this unit holds the polynomials of 2..4 coefficients, a sister
+// unit -- the same file with MC3_MT_SECOND, tag MC3_WL_TAG2 -- design matrices and the general
+// degree; the public functions of this unit forward what is not theirs.
+#if defined(MC3_MT_SECOND)
+#define DISPATCH_MT(FN, ...)                                                        \
+    switch (c->mt) {                                                                \
+    case MT_LINEAR: FN<MT_LINEAR>(__VA_ARGS__); break;                              \
+    default: FN<MT_POLY_GENERIC>(__VA_ARGS__); break;                               \
+    }
+#elif defined(MC3_MT_SPLIT)
+#define DISPATCH_MT(FN, ...)                                                        \
+    switch (c->mt) {                                                                \
+    case MT_POLY2: FN<MT_POLY2>(__VA_ARGS__); break;                                \
+    case MT_POLY3: FN<MT_POLY3>(__VA_ARGS__); break;                                \
+    default: FN<MT_POLY4>(__VA_ARGS__); break;                                      \
+    }
+#else
 #define DISPATCH_MT(FN, ...)                                                        \
     switch (c->mt) {                                                                \
     case MT_POLY2: FN<MT_POLY2>(__VA_ARGS__); break;                                \
@@ -80,22 +95,40 @@ void set_attr_t(mc3hip_ctx *c, hipError_t *e)
     case MT_LINEAR: FN<MT_LINEAR>(__VA_ARGS__); break;                              \
     default: FN<MT_POLY_GENERIC>(__VA_ARGS__); break;                               \
     }
+#endif
+#if defined(MC3_MT_SPLIT) && !defined(MC3_MT_SECOND)
+#define MC3_FN2(name) MC3_CAT(name, MC3_WL_TAG2)
+#define MC3_NOT_MINE(c) ((c)->mt != MT_POLY2 && (c)->mt != MT_POLY3 && (c)->mt != MT_POLY4)
+#define MC3_FORWARD(call) if (MC3_NOT_MINE(c)) return call;
+#else
+#define MC3_FORWARD(call)
+#endif
 
 }  // namespace
 
-void MC3_FN(launch_step_wavelet_)(mc3hip_ctx *c, int roff) { DISPATCH_MT(launch_step_t, c, roff) }
+void MC3_FN(launch_step_wavelet_)(mc3hip_ctx *c, int roff)
+{
+    MC3_FORWARD(MC3_FN2(launch_step_wavelet_)(c, roff))
+    DISPATCH_MT(launch_step_t, c, roff)
+}
 
 chain_kernel_fn MC3_FN(persist_instance_wavelet_)(const mc3hip_ctx *c, bool p2p)
 {
+    MC3_FORWARD(MC3_FN2(persist_instance_wavelet_)(c, p2p))
     chain_kernel_fn f = nullptr;
     DISPATCH_MT(persist_instance_t, c, p2p, &f)
     return f;
 }
 
-void MC3_FN(launch_eval_wavelet_)(mc3hip_ctx *c, int n) { DISPATCH_MT(launch_eval_t, c, n) }
+void MC3_FN(launch_eval_wavelet_)(mc3hip_ctx *c, int n)
+{
+    MC3_FORWARD(MC3_FN2(launch_eval_wavelet_)(c, n))
+    DISPATCH_MT(launch_eval_t, c, n)
+}
 
 hipError_t MC3_FN(set_smem_attr_wavelet_)(mc3hip_ctx *c)
 {
+    MC3_FORWARD(MC3_FN2(set_smem_attr_wavelet_)(c))
     hipError_t e = hipSuccess;
     DISPATCH_MT(set_attr_t, c, &e)
     return e;
