@@ -155,6 +155,29 @@ __device__ __forceinline__ double wavelet_level0(const DevProblem &P, const Mode
     for (int j = 0; j < PF + 2 && j < B + 2; ++j)
         fetch(j);
     (void)in1;
+    // Design-matrix models: the model values of the block (and of the two halo points), column
+    // by column -- Model::at's order per point, k ascending -- so that a column's values are
+    // consumed as they arrive instead of every point running its own loop over the columns
+    // with all their loads in flight (121 registers spilled in the nine-wave kernel).
+    double mv[(MT == MT_LINEAR && !VALUES) ? B + 2 : 1];
+    if constexpr (MT == MT_LINEAR && !VALUES) {
+        const int pnext = (base + B) & (N - 1);
+        const double *col = model.indep;
+        {
+            const double c0 = model.coef[0];
+#pragma unroll
+            for (int j = 0; j < B + 2; ++j)
+                mv[j] = col[j < B ? base + j : pnext + (j - B)] * c0;
+        }
+        for (int k = 1; k < model.nmodel; ++k) {
+            col += model.ndata;
+            const double ck = model.coef[k];
+#pragma unroll
+            for (int j = 0; j < B + 2; ++j)
+                mv[j] = mc3_fma(col[j < B ? base + j : pnext + (j - B)], ck, mv[j]);
+        }
+    }
+    (void)mv;
     // the model at point j of the block (B, B+1: the next block's first two); j static in the
     // pyramid below, a loop index in the rare rescan
     auto model_value = [&](int j, double xj) {
@@ -181,7 +204,9 @@ __device__ __forceinline__ double wavelet_level0(const DevProblem &P, const Mode
     auto resid = [&](int j) {                           // j: static index into the block
         if constexpr (VALUES) {
             return in0[j];
-        } else if constexpr (MT == MT_LINEAR || GRID) {
+        } else if constexpr (MT == MT_LINEAR) {
+            return in0[j] - mv[j];
+        } else if constexpr (GRID) {
             return in0[j] - model_value(j, 0.0);
         } else {
             return in1[j] - model_value(j, in0[j]);

@@ -103,6 +103,29 @@ def linear_problem(ndata=512, nmodel=10, nchains=16, nsamples=1600,
     return prob
 
 
+def wavelet_linear_problem(ndata=64, nmodel=4, nchains=7, nsamples=7*30, sampler='snooker',
+                           **kw):
+    """Wavelet likelihood with a design-matrix model (Legendre columns): the model call of
+    chain.py:317-319 feeding src_c/_dwt.c:76-114."""
+    rs = np.random.RandomState(5)
+    t = np.linspace(-1, 1, ndata)
+    A = np.array([np.polynomial.legendre.legval(t, [0]*k + [1]) for k in range(nmodel)])
+    p_true = rs.uniform(-1, 1, nmodel)
+    signal = np.zeros(ndata)
+    for k in range(nmodel):
+        signal = signal + p_true[k]*A[k]
+    data = signal + rs.normal(0, 1, ndata) + 0.5*np.sin(6*np.pi*t)
+    prob = dict(data=data, uncert=np.ones(ndata), indep=A,
+                params=np.concatenate([p_true, [1.0, 0.5, 1.0]]),
+                pstep=np.concatenate([np.full(nmodel, 0.05), [0.0, 0.1, 0.1]]),
+                pmin=np.concatenate([np.full(nmodel, -5.0), [0.0, 0.01, 0.01]]),
+                pmax=np.concatenate([np.full(nmodel, 5.0), [2.0, 10.0, 10.0]]),
+                nchains=nchains, nsamples=nsamples, sampler=sampler, wlike=True,
+                model='linear', seed=77)
+    prob.update(kw)
+    return prob
+
+
 def make_oracle(prob, plan=None, **extra):
     """The lockstep oracle for a problem; ``plan`` (DeviceChains.plan) makes it sum the
     data in the order the library reports: tile size, virtual lanes and -- wavelet

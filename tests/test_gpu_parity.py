@@ -901,3 +901,27 @@ def test_lean_demc_with_the_draws_of_64_refreshes_at_once(eng, monkeypatch, case
     assert plan['fast'] == 2 and plan['persistent'] > 0 and plan['recoveries'] == 0, plan
     assert_same(orc, gpu, trace=False)
     gpu.close()
+
+
+# ---- wavelet likelihood x design-matrix model ---------------------------------------------
+@pytest.mark.parametrize('trace', [True, False])
+@pytest.mark.parametrize('ndata,nmodel,sampler', [
+    (64, 4, 'snooker'), (512, 3, 'demc'), (2048, 6, 'mrw'), (4096, 5, 'snooker'),
+    (8192, 4, 'demc'), (16384, 7, 'snooker'), (16384, 3, 'mrw')])
+def test_wavelet_likelihood_with_a_design_matrix_model(eng, ndata, nmodel, sampler, trace):
+    """Every wavelet geometry (one, four, eight waves; traced: the general chain, untraced at
+    8192 / 16384 points: the nine-wave kernel with the hand-structured chain wave) with the
+    model values formed column by column (wavelet_level0, MT_LINEAR)."""
+    prob = H.wavelet_linear_problem(ndata=ndata, nmodel=nmodel, nchains=7, nsamples=7*24,
+                                    sampler=sampler)
+    orc, gpu = run_pair(eng, prob, trace=trace)
+    assert gpu.plan['persistent'] > 0 and gpu.plan['recoveries'] == 0
+    if ndata >= 8192 and not trace:
+        assert gpu.plan['fast'] == 3
+    assert_same(orc, gpu, trace=trace)
+    from oracle import kernels as ok
+    P = prob['params'] + np.random.RandomState(2).normal(0, 1, (6, nmodel + 3))*prob['pstep']
+    got = gpu.eval_chisq(P)
+    want = [ok.dwt_chisq(p[:nmodel] @ prob['indep'], prob['data'], p) for p in P]
+    np.testing.assert_allclose(got, want, rtol=1e-10)
+    gpu.close()
