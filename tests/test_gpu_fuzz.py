@@ -18,12 +18,20 @@ import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-def random_problem(seed):
+def random_problem(seed, wavelet_any_model=False):
+    """wavelet_any_model: the wavelet likelihood with either model kind and up to 2^14 points
+    (the nine-wave kernel's sizes included); the default sequence draws polynomials only under
+    the wavelet likelihood and is kept as it is (its cases are seeded)."""
     rs = np.random.RandomState(seed)
     wlike = rs.rand() < 0.25
     kind = 'poly' if (wlike or rs.rand() < 0.5) else 'linear'
+    if wavelet_any_model:
+        wlike = True
+        kind = str(rs.choice(['poly', 'linear', 'linear']))
     nmodel = int(rs.randint(1, 7)) if kind == 'poly' else int(rs.randint(1, 15))
-    if wlike:
+    if wavelet_any_model:
+        ndata = int(2**rs.choice([1, 3, 6, 9, 11, 12, 13, 13, 14, 14]))
+    elif wlike:
         ndata = int(2**rs.randint(1, 12))
     else:
         ndata = int(rs.choice([1, 2, 7, 64, 100, 1000, 1024, 1025, 3000, 20000]))
@@ -216,3 +224,36 @@ def test_random_problem(seed):
     np.testing.assert_array_equal(st['numaccept'], orc.numaccept, err_msg=label)
     np.testing.assert_array_equal(st['outbounds'], orc.outbounds, err_msg=label)
     np.testing.assert_array_equal(st['best_chisq'], orc.best_chisq, err_msg=label)
+
+
+@pytest.mark.parametrize('seed', range(40))
+def test_random_wavelet_problem_either_model_kind(seed):
+    """The wavelet likelihood with polynomials and design matrices up to 2^14 points, fixed and
+    shared parameters, priors, thinning, epsilon; even seeds traced (the general chain), odd
+    seeds not (the hand-structured chain wave where it applies; run in two pieces)."""
+    from mc3_amd import engine
+    prob = random_problem(9000 + seed, wavelet_any_model=True)
+    traced = seed % 2 == 0
+    nz = int(np.ceil(prob['nsamples']/prob['nchains']/prob['thinning']))
+    niter = nz*prob['thinning']
+    gpu = engine.DeviceChains(trace_iters=niter if traced else 0, **prob)
+    orc = H.make_oracle(prob, plan=gpu.plan)
+    try:
+        Z0, lp0 = H.initial_population(orc, seed=seed)
+    except ValueError:          # (bounds that leave no room around the start: not a case)
+        gpu.close()
+        pytest.skip('no initial population for this draw')
+    orc.set_population(Z0, lp0)
+    gpu.set_population(Z0, lp0)
+    orc.run(trace=True, nthreads=4)
+    if not traced:              # (the trace buffer holds the steps of ONE run)
+        gpu.run(gpu.nzchain//3)
+    gpu.run()
+    label = f"{prob['sampler']} {prob['model']}{prob['nmodel']} ndata={len(prob['data'])} " \
+            f"nchains={prob['nchains']} thin={prob['thinning']} traced={traced} plan={gpu.plan}"
+    if traced:
+        tc, tf = gpu.trace(niter)
+        np.testing.assert_array_equal(tf, orc.trace_flag, err_msg=label)
+        np.testing.assert_array_equal(tc, orc.trace_chisq, err_msg=label)
+    compare_final(gpu, orc, label)
+    gpu.close()
