@@ -233,6 +233,7 @@ MC3_WAVELET_UNIT(large)
 // (k_wavelet_w8mc.hip: the nine-wave kernel with several chains per workgroup)
 chain_kernel_fn persist_instance_wavelet_w8mc(const mc3hip_ctx *c);
 chain_kernel_fn persist_instance_wavelet_w8cw(const mc3hip_ctx *c);
+chain_kernel_fn persist_instance_wavelet_w8cg(const mc3hip_ctx *c);
 
 // ---- k_lean.hip: the lean one-wave persistent kernels ------------------------------------
 // ONE function picks the instance a context runs, so that the launch and the occupancy query

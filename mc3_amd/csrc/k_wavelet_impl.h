@@ -38,10 +38,12 @@ void persist_instance_t(const mc3hip_ctx *c, bool p2p, chain_kernel_fn *out)
     if constexpr (WW == 8 && !LARGE) {
         static_assert(CW_EXTRA == CW_EXTRA_DOUBLES, "LDS of the chain wave");
         if (chainwave_runs(c, p2p)) {                   // a wave of its own for the chain
-            // (the nine-wave kernels are compiled in units of their own, k_wavelet_w8cw.hip and
-            // -- several chains per workgroup -- k_wavelet_w8mc.hip: this unit was the longest)
+            // (the nine-wave kernels are compiled in units of their own: k_wavelet_w8cw.hip, the
+            // hand-structured chain wave; _w8cg, the general chain; _w8mc, several chains per
+            // workgroup)
             *out = c->mc_chains > 0 ? persist_instance_wavelet_w8mc(c)
-                                    : persist_instance_wavelet_w8cw(c);
+                   : c->P.cw_lean   ? persist_instance_wavelet_w8cw(c)
+                                    : persist_instance_wavelet_w8cg(c);
             return;
         }
     }

@@ -1,6 +1,5 @@
-// k_wavelet_w8cw.hip -- the nine-wave wavelet kernel (wavelet_cw_kernel, kernels_wavelet.h): a
-// translation unit of its own, compiled beside k_wavelet_w8.hip (the eight-wave kernels); the
-// ninth wave runs the hand-structured chain (lean_chain_wave).
+// k_wavelet_w8cg.hip -- the nine-wave wavelet kernel whose ninth wave runs the GENERAL chain
+// (wavelet_cw_kernel<.., false, true>: trace, priors, shared parameters, thinning).
 #include "ctx.h"
 #include "kernels_fused.h"
 #include "wavelet.h"
@@ -13,14 +12,14 @@ namespace {
 template <int MT>
 chain_kernel_fn instance_t(const mc3hip_ctx *c)
 {
-    return c->P.sampler == MC3HIP_SNOOKER ? wavelet_cw_kernel<MT, MC3HIP_SNOOKER>
-           : c->P.sampler == MC3HIP_DEMC  ? wavelet_cw_kernel<MT, MC3HIP_DEMC>
-                                          : wavelet_cw_kernel<MT, MC3HIP_MRW>;
+    return c->P.sampler == MC3HIP_SNOOKER ? wavelet_cw_kernel<MT, MC3HIP_SNOOKER, false, true>
+           : c->P.sampler == MC3HIP_DEMC  ? wavelet_cw_kernel<MT, MC3HIP_DEMC, false, true>
+                                          : wavelet_cw_kernel<MT, MC3HIP_MRW, false, true>;
 }
 
 }  // namespace
 
-chain_kernel_fn persist_instance_wavelet_w8cw(const mc3hip_ctx *c)
+chain_kernel_fn persist_instance_wavelet_w8cg(const mc3hip_ctx *c)
 {
     switch (c->mt) {
     case MT_POLY2: return instance_t<MT_POLY2>(c);

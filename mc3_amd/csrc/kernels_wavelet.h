@@ -851,8 +851,10 @@ __device__ __forceinline__ bool lean_chain_wave_mc(const DevProblem &P, const in
 
 // (SMP: the sampler, known at compile time -- the chain wave's path between two likelihoods is
 // what an iteration waits for, so the other samplers' branches are compiled out of it)
-// (MCK: the instance for several chains per workgroup, lean_chain_wave_mc)
-template <int MT, int SMP, bool MCK = false>
+// (MCK: the instance for several chains per workgroup, lean_chain_wave_mc.  GEN: the instance
+// whose ninth wave runs the general chain -- trace, priors, shared parameters, thinning -- so
+// that the kernel of the common shape carries only the hand-structured one)
+template <int MT, int SMP, bool MCK = false, bool GEN = false>
 __global__ __launch_bounds__(576) void wavelet_cw_kernel(const DevProblem P, const int nref)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -883,13 +885,12 @@ __global__ __launch_bounds__(576) void wavelet_cw_kernel(const DevProblem P, con
         if constexpr (MCK) {
             H.stopped = lean_chain_wave_mc<SMP>(P, nref, L.nextp, L.tab, s_cmd, s_result, H.nhalo,
                                                 H.M, smem + P.mc_off);
+        } else if constexpr (GEN) {
+            run_chain<1, MT, false, false, true, SMP, false, PH_CHAINWAVE, false, 0, false,
+                      WaveletHook>(P, P.ctl[0], nref, 0, -1, &H, (int)blockIdx.x, own);
         } else {
-            if (P.cw_lean)
-                H.stopped = lean_chain_wave<SMP>(P, nref, L.nextp, L.tab, s_cmd, s_result,
-                                                 H.nhalo, H.M);
-            else
-                run_chain<1, MT, false, false, true, SMP, false, PH_CHAINWAVE, false, 0, false,
-                          WaveletHook>(P, P.ctl[0], nref, 0, -1, &H, (int)blockIdx.x, own);
+            H.stopped = lean_chain_wave<SMP>(P, nref, L.nextp, L.tab, s_cmd, s_result, H.nhalo,
+                                             H.M);
         }
         if (!H.stopped) {                               // the run is over: the others leave too
             if ((tid & 63) == 0)
