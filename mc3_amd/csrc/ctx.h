@@ -108,6 +108,10 @@ inline bool rs_lean_eligible(const mc3hip_ctx *c)
     return c->P.sampler == MC3HIP_DEMC && c->P.thinning == 1 && c->P.trace_iters == 0 &&
            c->P.nshare == 0;
 }
+inline bool resident_owner_lean(const mc3hip_ctx *c)
+{
+    return rs_lean_eligible(c) && !getenv("MC3HIP_NO_RS_LEAN");
+}
 inline bool chainwave_runs(const mc3hip_ctx *c, bool p2p)
 {
     // (several chains per workgroup: only the hand-structured chain wave takes turns)

@@ -26,21 +26,33 @@ size_t resident_lds_bytes(const mc3hip_ctx *c)
     return (c->P.nmodel + 4) / 4 == 4 ? RESIDENT_LDS_BYTES : RESIDENT_LDS_BYTES_REGS;
 }
 
-resident_kernel_fn resident_kernel(const mc3hip_ctx *c, bool p2p)
+namespace {
+template <bool P2P, bool LEAN>
+resident_kernel_fn pick(const mc3hip_ctx *c)
 {
     if (resident_poly(c)) {
         switch (c->P.nmodel) {
-        case 2: return p2p ? resident_poly_kernel<2, true> : resident_poly_kernel<2, false>;
-        case 3: return p2p ? resident_poly_kernel<3, true> : resident_poly_kernel<3, false>;
-        default: return p2p ? resident_poly_kernel<4, true> : resident_poly_kernel<4, false>;
+        case 2: return resident_poly_kernel<2, P2P, LEAN>;
+        case 3: return resident_poly_kernel<3, P2P, LEAN>;
+        default: return resident_poly_kernel<4, P2P, LEAN>;
         }
     }
     switch ((c->P.nmodel + 4) / 4) {          // operand rows: coefficients + the data column
-    case 1: return p2p ? resident_tile_kernel<1, true> : resident_tile_kernel<1, false>;
-    case 2: return p2p ? resident_tile_kernel<2, true> : resident_tile_kernel<2, false>;
-    case 3: return p2p ? resident_tile_kernel<3, true> : resident_tile_kernel<3, false>;
-    default: return p2p ? resident_tile_kernel<4, true> : resident_tile_kernel<4, false>;
+    case 1: return resident_tile_kernel<1, P2P, LEAN>;
+    case 2: return resident_tile_kernel<2, P2P, LEAN>;
+    case 3: return resident_tile_kernel<3, P2P, LEAN>;
+    default: return resident_tile_kernel<4, P2P, LEAN>;
     }
+}
+}  // namespace
+
+// (the owner -- hand-structured or general -- is a function of the problem alone, so the
+// occupancy query that sizes the grid and the launch agree: ctx.h resident_owner_lean)
+resident_kernel_fn resident_kernel(const mc3hip_ctx *c, bool p2p)
+{
+    const bool lean = resident_owner_lean(c);
+    return p2p ? (lean ? pick<true, true>(c) : pick<true, false>(c))
+               : (lean ? pick<false, true>(c) : pick<false, false>(c));
 }
 
 }  // namespace host

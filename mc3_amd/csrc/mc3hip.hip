@@ -426,7 +426,7 @@ int decide_persist(mc3hip_ctx *c)
             return 0;
         c->resident = true;
         c->resident_chain_block = (int)cb;
-        c->P.rs_lean = (rs_lean_eligible(c) && !getenv("MC3HIP_NO_RS_LEAN")) ? 1 : 0;
+        c->P.rs_lean = resident_owner_lean(c) ? 1 : 0;
         c->fast = false;
         c->persist_refs = 16384;
         if (const char *e = getenv("MC3HIP_PERSIST_REFS"))

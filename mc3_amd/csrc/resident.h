@@ -630,7 +630,9 @@ __device__ __forceinline__ void lean_resident_owner(const DevProblem &P, const i
 // group totals
 // [RS_WCAP][16], the give-up word, a run_chain area per wave, the tile's 2048 weights, and
 // (three blocks of operand rows) the last block, [16][512].
-template <int KB, bool P2P = false>
+// (LEAN: the owners run lean_resident_owner; the two owners are two kernels, so that the one
+// of the common shape does not carry the general chain's registers)
+template <int KB, bool P2P = false, bool LEAN = false>
 __global__ __launch_bounds__(512) void resident_tile_kernel(const DevProblem P, const int nref,
                                                             const int chain_block)
 {
@@ -652,7 +654,7 @@ __global__ __launch_bounds__(512) void resident_tile_kernel(const DevProblem P, 
     const int own_chain = wg + (int)(gridDim.x * gridDim.y) * wv;
     if (own_chain < P.nlocal) {
         T.set_owner(P, own_chain, smem + W + 2 + wv * OWN);
-        if (P.rs_lean)
+        if constexpr (LEAN)
             lean_resident_owner<MT_LINEAR, P2P>(P, nref, T, own_chain, smem + W + 2 + wv * OWN);
         else
             run_chain<1, MT_LINEAR, false, false, true, -1, false, PH_RESIDENT, P2P, 0, false,
@@ -667,7 +669,7 @@ __global__ __launch_bounds__(512) void resident_tile_kernel(const DevProblem P, 
     }
 }
 
-template <int KX, bool P2P = false>
+template <int KX, bool P2P = false, bool LEAN = false>
 __global__ __launch_bounds__(512) void resident_poly_kernel(const DevProblem P, const int nref,
                                                             const int chain_block)
 {
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(512) void resident_poly_kernel(const DevProblem P, 
     const int own_chain = wg + (int)(gridDim.x * gridDim.y) * wv;
     if (own_chain < P.nlocal) {
         T.set_owner(P, own_chain, smem + X + 2 + wv * OWN);
-        if (P.rs_lean)
+        if constexpr (LEAN)
             lean_resident_owner<KX, P2P>(P, nref, T, own_chain, smem + X + 2 + wv * OWN);
         else
             run_chain<1, KX, false, false, true, -1, false, PH_RESIDENT, P2P, 0, false,
