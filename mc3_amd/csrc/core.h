@@ -471,12 +471,11 @@ __device__ __forceinline__ void d4_pair(double a0, double a1, double a2, double 
     d = mc3_fma(-D4C0, a3, d);
 }
 
+// smallest m with 2^m >= n (one instruction: the loop this was ran once per likelihood in the
+// wavelet kernels, fourteen taken branches at 2^14 points)
 __device__ __forceinline__ int ilog2(int n)
 {
-    int m = 0;
-    while ((1 << m) < n)
-        ++m;
-    return m;
+    return n <= 1 ? 0 : 32 - __builtin_clz((unsigned)(n - 1));
 }
 
 // prior term, mc3/stats/stats.py:211-216 + src_c/include/stats.h:96-106
