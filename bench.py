@@ -345,7 +345,9 @@ def run_rank(args):
     # run keeps the GPU busy for seconds, not for the half second the driver's utilisation
     # sampler would miss); never more than half of the free memory of a GPU, shared by the
     # ranks on it
-    budget = 96 << 30
+    # (several ranks: every rank maps every peer's replica -- 32 GiB each keeps eight of them
+    # quick to export, attach and check)
+    budget = (96 << 30) if world == 1 else (32 << 30)
     if engine is not None:
         free, _ = engine.device_memory(local_rank)
         budget = min(budget, free//2//(world if shared_device else 1))
