@@ -610,7 +610,7 @@ def rccl_segment(args, ctl, make_engine, build_problem, nchains, nlocal, chain0,
     """The same ensemble through ONE in-place RCCL all-gather of the new Z rows per refresh
     (libmc3hip calls RCCL itself; replayed from a hipGraph), timed on its own: the north
     star's collective, with RCCL's own word on how many ranks it spanned."""
-    nwarm, ntimed = (8, 24) if args.workload == 'c5' else (768, 3072)
+    nwarm, ntimed = (8, 24) if args.workload == 'c5' else (2048, 8192)
     prob = build_problem(nchains, nwarm + ntimed + 8, args.thinning)
     g = None
     ok, err = True, None
@@ -655,7 +655,9 @@ def rccl_segment(args, ctl, make_engine, build_problem, nchains, nlocal, chain0,
 
 def single_gpu_segment(args, build_problem, nchains, device, engine):
     """The whole ensemble in ONE context on one GPU (no exchange at all)."""
-    nwarm, ntimed = (8, 40) if args.workload == 'c5' else (1024, 8192)
+    # (long enough for the clocks to come back up after the idle seconds before it: with 8192
+    # refreshes -- 10 ms -- the figure of one and the same kernel varied by a factor of two)
+    nwarm, ntimed = (40, 200) if args.workload == 'c5' else (16384, 32768)
     prob = build_problem(nchains, nwarm + ntimed + 8, args.thinning)
     try:
         with engine.DeviceChains(device=device, **prob) as g:
@@ -668,7 +670,8 @@ def single_gpu_segment(args, build_problem, nchains, device, engine):
             plan = g.plan
         return {'nchains': nchains, 'million_chain_steps_per_s':
                 nchains*ntimed*args.thinning/dt/1e6, 'us_per_refresh': dt/ntimed*1e6,
-                'persistent': plan['persistent'], 'refreshes_timed': ntimed}
+                'persistent': plan['persistent'], 'refreshes_timed': ntimed,
+                'chains_per_workgroup': plan.get('chains_per_workgroup', 1)}
     except Exception as e:      # noqa: BLE001
         return {'error': str(e)}
 
