@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Development aid: the generators of tests/test_gpu_fuzz.py on seeds the test suite does not
+use, each problem compared with the oracle exactly (rows, counters, best fits).
+    python tools/fuzz_hunt.py [first_seed] [count]        # prints one line per failure"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from mc3_amd import engine  # noqa: E402
+import helpers as H  # noqa: E402
+import test_gpu_fuzz as F  # noqa: E402
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+bad = 0
+for seed in range(first, first + count):
+    kind = seed % 3 if 'big' not in sys.argv else 3
+    if kind == 3:
+        # ensembles beyond what is co-resident: two to five chains per wave, the shapes the
+        # lean kernels serve (python tools/fuzz_hunt.py <first> <count> big)
+        prob, _ = F.lean_problem(seed)
+        rs = np.random.RandomState(seed)
+        nch = int(rs.randint(2049, 10000))
+        prob.update(nchains=nch, nsamples=nch*int(rs.randint(6, 16))*prob['thinning'])
+    elif kind == 0:
+        prob = F.random_problem(seed)
+    elif kind == 1:
+        prob, _ = F.lean_problem(seed)
+    else:
+        prob = F.random_problem(seed, wavelet_any_model=True)
+    try:
+        gpu = engine.DeviceChains(**prob)
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        try:
+            Z0, lp0 = H.initial_population(orc, seed=seed)
+        except ValueError:
+            gpu.close()
+            continue
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nthreads=4)
+        gpu.run(max(1, gpu.nzchain//3))
+        gpu.run()
+        F.compare_final(gpu, orc, f'seed {seed}')
+        gpu.close()
+    except Exception as e:      # noqa: BLE001
+        bad += 1
+        print(f'FAIL seed {seed} kind {kind}: {str(e)[:300]}', flush=True)
+print(f'{count} seeds from {first}: {bad} failures')
