@@ -41,6 +41,8 @@ chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
 {
     if (c->P.sampler == MC3HIP_MRW)
         return fast_instance_tt<MT, MC3HIP_MRW>(c, p2p);
+    if (lean_snooker_eligible(c) && !p2p)
+        return lean_snooker_kernel<MT>;
     if (lean_demc_mc_eligible(c) && !p2p) {          // 2..4 chains per wave
 #define MC3_LEAN_MC(TT)                                                             \
         if (c->mc_chains == TT) {                                                   \

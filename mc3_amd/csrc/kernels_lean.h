@@ -290,6 +290,224 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
 }
 
 // ---------------------------------------------------------------------------------
+// The snooker sampler (the reference's default) for the same shape, written out by hand: one
+// wave per chain, fully free polynomial, thinning = 1, one GPU.  A snooker iteration needs
+// three rows of the WHOLE history (chain.py:195-205), almost always published long ago, so
+// nothing has to be waited for -- an iteration of the general lean instance still took 1.26 us,
+// all of it the instructions between two chisq sums.  Here
+//   * the draws of 21 refreshes are computed at once (three Philox slots per refresh, one per
+//     lane) TOGETHER with everything that follows from them alone: the row offsets (64-bit
+//     bounded draws against the history length of that refresh), the jump flag, gamma_s, the
+//     Metropolis draw and the window of its logarithm (handoff.h accept_window); an iteration
+//     reads its own with v_readlane;
+//   * the rows of the NEXT refresh are asked for before this refresh's chisq is computed;
+//   * the ordinary jump (nine in ten) is decided in the log domain; a snooker jump proper
+//     (chain.py:207-215, :251-255) takes the exponential and the Hastings factor as ever.
+// Same draws, same arithmetic, same results as run_chain's.
+template <int MT>
+__global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, const int nref)
+{
+    constexpr int nf = MT;
+    constexpr int ZS = ZROW;
+    constexpr int NB = 21;                     // refreshes per batch of draws (3 lanes each)
+    const int lane = threadIdx.x;
+    const int lc = blockIdx.x;
+    const int c = P.chain0 + lc;
+    const bool mine = lane < nf;
+    const int kk = mine ? lane : 0;
+    long long *ctl_rw = const_cast<long long *>(P.ctl);
+    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
+            &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+        return;
+    DataTile<1, MT> tile;
+    tile.load(P);
+    const long long R0 = P.ctl[0];
+    const int n = P.nchains;
+    const size_t blockstride = (size_t)n * ZS;
+    const double *pbase = (R0 == 0) ? P.snap0 : P.Z + (size_t)(P.M0 + (R0 - 1) * n) * ZS;
+    double *zblock = P.Z + (size_t)(P.M0 + R0 * n) * ZS;
+    double *lp_row = P.log_post + (P.M0 + R0 * n + c);
+    int32_t *zc_row = P.zchain + (P.M0 + R0 * n + c);
+    double xk = mine ? pbase[(size_t)c * ZS + lane] : 0.0;
+    double cur = P.chisq[lc];
+    double best = P.best_chisq[lc];
+    const long long nacc0 = P.numaccept[lc];
+    const double pmin_k = mine ? P.fmin[lane] : 0.0;
+    const double pmax_k = mine ? P.fmax[lane] : 0.0;
+    const double gamma = P.gamma, feps = P.fepsilon;
+    const long long abort_at = (P.test_abort >= 0 && lc == 0) ? (long long)P.test_abort : -1;
+    int nacc = 0;
+    double lpbuf = 0.0;
+    // lane 3 i + s: slot s of refresh bbase + i.  A, B by slot: 0 -> the offsets (in doubles)
+    // of rows iR1, iR2; 1 -> the offset of row iz, the jump flag; 2 -> gamma_s, u (as bits)
+    unsigned long long A = 0, B = 0;
+    double blo = 0.0, bhi = 0.0;
+    long long bbase = R0;
+    const int bs = lane % 3, bi = (lane / 3 < NB) ? lane / 3 : NB - 1;
+    auto fill = [&](long long base) {
+        const long long Rl = base + bi;
+        const Draw2 d = draw2(P.seed, (uint64_t)Rl, (uint32_t)c, (uint32_t)bs);
+        const unsigned long long zsz = (unsigned long long)(P.M0 + Rl * n);
+        if (bs == 0) {
+            const unsigned long long iR1 = bounded(d.q0, zsz);
+            unsigned long long iR2 = 1 + bounded(d.q1, zsz - 1);
+            if (iR2 == iR1)
+                iR2 = 0;
+            A = iR1 * ZS;
+            B = iR2 * ZS;
+        } else if (bs == 1) {
+            A = bounded(d.q1, zsz) * ZS;
+            B = (u01(d.q0) < 0.1) ? 1ull : 0ull;
+        } else {
+            A = mc3_bits(1.2 + (2.2 - 1.2) * u01(d.q0));
+            B = mc3_bits(u01(d.q1));
+        }
+        // (every lane: the lanes of slot 2 keep theirs)
+        accept_window(u01(d.q1), blo, bhi);
+        bbase = base;
+    };
+    auto lane64 = [&](unsigned long long v, int l) {
+        return (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l) |
+               ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l)
+                << 32);
+    };
+    // what an iteration needs of its draws, and its three rows
+    struct Step {
+        bool sj;
+        double gs, u, lo, hi;
+        const double *addr[3];
+        double val[3];
+    };
+    auto prepare = [&](long long R, Step &S) {          // (R inside the current batch)
+        const int idx = 3 * (int)(R - bbase);
+        S.addr[0] = P.Z + (lane64(A, idx) + (unsigned)kk);
+        S.addr[1] = P.Z + (lane64(B, idx) + (unsigned)kk);
+        S.addr[2] = P.Z + (lane64(A, idx + 1) + (unsigned)kk);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            S.val[q] = load_published<false>(S.addr[q]);
+        S.sj = lane64(B, idx + 1) != 0;
+        S.gs = mc3_from_bits(lane64(A, idx + 2));
+        S.u = mc3_from_bits(lane64(B, idx + 2));
+        S.lo = read_lane(blo, idx + 2);
+        S.hi = read_lane(bhi, idx + 2);
+    };
+    fill(R0);
+    Step S;
+    prepare(R0, S);
+    const long long Rend = R0 + nref;
+    long long rdone = R0;
+    auto flush_columns = [&](int count) {
+        if (lane < count) {
+            lp_row[(size_t)lane * n] = lpbuf;
+            zc_row[(size_t)lane * n] = c;
+        }
+    };
+    bool alive = true;
+    for (long long R = R0; R < Rend; ++R) {
+        if (__builtin_expect(R == abort_at, 0)) {                                         // test hook
+            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        // this refresh's rows were asked for a refresh ago; one of the newest may still be
+        // the sentinel
+        if (__builtin_expect(__any(mc3_bits(S.val[0]) == ROW_PENDING ||
+                                   mc3_bits(S.val[1]) == ROW_PENDING ||
+                                   mc3_bits(S.val[2]) == ROW_PENDING), 0)) {
+            const double *const a3[3] = {S.addr[0], S.addr[1], S.addr[2]};
+            double v3[3] = {S.val[0], S.val[1], S.val[2]};
+            alive = wait_rows<3, false>(a3, v3, ctl_rw);
+            S.val[0] = v3[0];
+            S.val[1] = v3[1];
+            S.val[2] = v3[2];
+            if (__builtin_expect(!alive, 0))
+                break;
+        }
+        const double z1 = S.val[0], z2 = S.val[1], zk = S.val[2];
+        const bool sjump = S.sj;
+        const double u_now = S.u, lo_now = S.lo, hi_now = S.hi;
+        double jump_k;
+        if (__builtin_expect(sjump, 0)) {                            // chain.py:207-215
+            const double gs = S.gs;
+            const bool same = __all(!mine || zk == xk);
+            if (same) {
+                jump_k = gs * (z2 - z1);
+            } else {
+                const double dz = xk - zk;
+                const double zp1 = lane_serial_sum(z1 * dz, nf);
+                const double zp2 = lane_serial_sum(z2 * dz, nf);
+                const double dd = lane_serial_sum(dz * dz, nf);
+                jump_k = ((gs * (zp1 - zp2)) * dz) / dd;
+            }
+        } else {                                                     // chain.py:216-217
+            jump_k = gamma * (z1 - z2) + feps * 0.0;
+        }
+        // proposal and boundaries, chain.py:235-243
+        const double npk = xk + jump_k;
+        const bool outk = mine && (npk < pmin_k || npk > pmax_k);
+        // the next refresh: its draws (a new batch every 21), its rows asked for now
+        if (__builtin_expect(R + 1 - bbase == NB, 0))
+            fill(R + 1);
+        prepare(R + 1, S);
+        if (__builtin_expect(!__any(outk), 1)) {
+            Model<MT> model;
+            model.init_from_lanes(P, npk);
+            const double nextchisq =
+                block_gauss_model<1, MT, false, false>(P, model, nullptr, nullptr, tile,
+                                                       &tile);               // chain.py:249
+            bool acc;
+            if (__builtin_expect(!sjump, 1)) {
+                acc = metropolis_accept(0.5 * (cur - nextchisq), u_now, lo_now, hi_now);
+            } else {                                                 // chain.py:251-255
+                const double dc = xk - zk, dn = npk - zk;
+                const double cnorm = lane_serial_sum(mine ? dc * dc : 0.0, nf);
+                const double nnorm = lane_serial_sum(mine ? dn * dn : 0.0, nf);
+                const double mrfactor = mc3_det_pow_half(nnorm / cnorm, nf - 1);
+                acc = mc3_det_exp(0.5 * (cur - nextchisq)) * mrfactor > u_now;
+            }
+            xk = acc ? npk : xk;
+            if (__builtin_expect(__any(acc && nextchisq < best), 0)) {
+                best = nextchisq;
+                if (mine)
+                    P.bestx[(size_t)lc * nf + lane] = xk;
+                if (lane == 0)
+                    P.best_iter[lc] = R;
+            }
+            cur = acc ? nextchisq : cur;
+            nacc += acc ? 1 : 0;
+        } else if (outk) {
+            atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
+        }
+        // (the rows asked for above have arrived behind the chisq: said here, the wait for
+        // them cannot land behind the stores below -- see lean_demc_kernel)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("; rows of the next refresh" : "+v"(S.val[0]), "+v"(S.val[1]), "+v"(S.val[2]));
+        // Z append, chain.py:276-289
+        if (mine)
+            __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);            // publish (sc1)
+        const int slot = (int)(R - R0) & 63;
+        lpbuf = (lane == slot) ? -0.5 * cur : lpbuf;
+        if (__builtin_expect(slot == 63, 0)) {
+            flush_columns(64);
+            lp_row += (size_t)64 * n;
+            zc_row += (size_t)64 * n;
+        }
+        zblock += blockstride;
+        rdone = R + 1;
+    }
+    flush_columns((int)(rdone - R0) & 63);
+    if (mine)
+        P.X[(size_t)lc * nf + lane] = xk;
+    if (lane == 0) {
+        P.chisq[lc] = cur;
+        P.best_chisq[lc] = best;
+        P.numaccept[lc] = nacc0 + nacc;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // The same loop for ensembles with more chains than waves can be co-resident (P.mc_chains = T,
 // 2..4; one GPU): a wave owns chains b, b + G, ... b + (T - 1) G of a grid of G and advances
 // them one after another inside every refresh -- the turns of run_chain MC.  There a turn

@@ -358,7 +358,7 @@ def test_config_c3_ensemble_in_one_context(eng, sampler):
     bit-exact against the oracle."""
     prob = H.quad_problem(ndata=1000, nchains=2048, nsamples=2048*40, sampler=sampler)
     orc, gpu = run_pair(eng, prob, trace=False)
-    assert gpu.plan['persistent'] > 0 and gpu.plan['fast'] == (2 if sampler == 'demc' else 1)
+    assert gpu.plan['persistent'] > 0 and gpu.plan['fast'] == 2      # (both hand-laid-out loops)
     assert_same(orc, gpu, trace=False)
     assert gpu.plan['recoveries'] == 0
     gpu.close()
@@ -924,4 +924,57 @@ def test_wavelet_likelihood_with_a_design_matrix_model(eng, ndata, nmodel, sampl
     got = gpu.eval_chisq(P)
     want = [ok.dwt_chisq(p[:nmodel] @ prob['indep'], prob['data'], p) for p in P]
     np.testing.assert_allclose(got, want, rtol=1e-10)
+    gpu.close()
+
+
+@pytest.mark.parametrize('case', ['quad', 'line', 'cubic', 'tight', 'ragged', 'resume', 'abort',
+                                  'tiny-history', 'switch'])
+def test_lean_snooker_loop(eng, monkeypatch, case):
+    """lean_snooker_kernel: the draws of 21 refreshes at once with their row offsets, jump
+    flags and log-u windows; rows asked for a refresh ahead; ordinary jumps decided in the log
+    domain, snooker jumps proper (one in ten) with the Hastings factor.  A short initial
+    history (hsize 1: the newest rows are drawn often and are still pending when asked for)."""
+    if case == 'ragged':
+        prob = H.quad_problem(ndata=37, nchains=9, nsamples=9*400, sampler='snooker')
+    elif case == 'tight':
+        prob = H.quad_problem(ndata=200, nchains=12, nsamples=12*400, sampler='snooker')
+        prob.update(params=np.array([4.0, -2.5, 0.5]), pmin=np.array([3.5, -2.8, 0.45]),
+                    pmax=np.array([6.5, -2.2, 0.56]))
+    elif case in ('line', 'cubic'):
+        ncoef = 2 if case == 'line' else 4
+        x, data, uncert = H.tutorial_data(600)
+        prob = dict(data=data, uncert=uncert, indep=x/10.0,
+                    params=np.array([3.0, -20.0, 40.0, 5.0][:ncoef]),
+                    pstep=np.array([0.5, 1.0, 2.0, 1.0][:ncoef]), nchains=16,
+                    nsamples=16*300, sampler='snooker', model='poly', seed=9)
+    elif case == 'tiny-history':
+        prob = H.quad_problem(ndata=300, nchains=5, nsamples=5*500, sampler='snooker', hsize=1)
+    else:
+        prob = H.quad_problem(ndata=1000, nchains=40, nsamples=40*300, sampler='snooker')
+    if case == 'switch':
+        monkeypatch.setenv('MC3HIP_NO_LEAN', '1')
+    if case == 'abort':
+        monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '21')
+        orc, gpu = run_pair(eng, prob, trace=False)
+        assert gpu.plan['recoveries'] == 1
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
+        return
+    if case == 'resume':
+        gpu = eng.DeviceChains(**prob)
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nthreads=4)
+        for n in (1, 2, 20, 21, 22, 64, 100, 70):
+            gpu.run(n)
+    else:
+        orc, gpu = run_pair(eng, prob, trace=False)
+    plan = gpu.plan
+    assert plan['persistent'] > 0 and plan['recoveries'] == 0, plan
+    assert plan['fast'] == (1 if case == 'switch' else 2), plan
+    assert_same(orc, gpu, trace=False)
+    if case == 'tight':
+        assert gpu.state()['outbounds'].sum() > 50
     gpu.close()

@@ -1,7 +1,7 @@
 """Long runs of the headline kernels against the oracle, compared exactly (the pytest
 form of tests/soak.py): 200 000 iterations x 256 chains of C2 = 51 M chain-steps through
 lean_demc_kernel in 13 persistent launches, and a shorter snooker run through
-persist_fast_kernel.  The oracle side runs with OpenMP on the host cores."""
+lean_snooker_kernel.  The oracle side runs with OpenMP on the host cores."""
 import os
 
 import numpy as np
@@ -12,7 +12,7 @@ import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('sampler,niter,fast', [('demc', 200000, 2), ('snooker', 40000, 1)])
+@pytest.mark.parametrize('sampler,niter,fast', [('demc', 200000, 2), ('snooker', 40000, 2)])
 def test_soak_c2(sampler, niter, fast):
     from mc3_amd import engine
     prob = H.quad_problem(ndata=1000, nchains=256, nsamples=256*niter, sampler=sampler)

@@ -40,6 +40,7 @@ CONFIGS = {
     'c2': lambda n: (H.quad_problem(ndata=1000, nchains=256, nsamples=256*n, sampler='demc'), {}),
     'c2snooker': lambda n: (H.quad_problem(ndata=1000, nchains=256, nsamples=256*n,
                                            sampler='snooker'), {}),
+    'c2mrw': lambda n: (H.quad_problem(ndata=1000, nchains=256, nsamples=256*n, sampler='mrw'), {}),
     'c3one': lambda n: (H.quad_problem(ndata=1000, nchains=2048, nsamples=2048*n,
                                        sampler='demc'), {}),
     'c4': lambda n: (H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*n), {}),
@@ -67,9 +68,9 @@ CONFIGS = {
     # the tiled plan of polynomial models (vector tile kernel, three launches per iteration)
     'q5': lambda n: (H.quad_problem(ndata=100000, nchains=512, nsamples=512*n), {}),
 }
-BYTES = {'q5': 8*3*100000 + 8*3*4 + 8, 'c4mrw': 8*2*16384 + 8*5*4 + 8, 'c4demc': 8*2*16384 + 8*5*4 + 8, 'c4half': 8*2*16384 + 8*5*4 + 8, 'c2': 24104, 'c2snooker': 24104, 'c3one': 24104, 'c4': 8*2*16384 + 8*5*4 + 8,
+BYTES = {'c2mrw': 24104, 'q5': 8*3*100000 + 8*3*4 + 8, 'c4mrw': 8*2*16384 + 8*5*4 + 8, 'c4demc': 8*2*16384 + 8*5*4 + 8, 'c4half': 8*2*16384 + 8*5*4 + 8, 'c2': 24104, 'c2snooker': 24104, 'c3one': 24104, 'c4': 8*2*16384 + 8*5*4 + 8,
          'c5': 8*12*100000 + 8*10*4 + 8, 'c5share': 8*12*100000 + 8*10*4 + 8}
-ITERS = {'c2': 20000, 'c2snooker': 20000, 'c3one': 4000, 'c4': 4000, 'c5': 30, 'c5share': 1}
+ITERS = {'c2': 20000, 'c2snooker': 20000, 'c2mrw': 20000, 'c3one': 4000, 'c4': 4000, 'c5': 30, 'c5share': 1}
 ITERS['c5'] = 300
 ITERS['q5'] = 300
 ITERS.update(c4wide=4000, c4mrw=4000, c4demc=4000, c4half=4000, c3x2=3000, c3x4=2000, c3x2snooker=3000,
