@@ -195,6 +195,16 @@ inline bool lean_snooker_eligible(const mc3hip_ctx *c)
            c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_LEAN");
 }
 
+// ... and the random-walk sampler on the same plain shape: lean_mrw_kernel
+inline bool lean_mrw_eligible(const mc3hip_ctx *c)
+{
+    const DevProblem &P = c->P;
+    return c->fast && c->mc_chains == 0 && P.sampler == MC3HIP_MRW && P.thinning == 1 &&
+           P.nparams == c->mt && P.zs == ZROW && P.npad <= VLANES && P.nfree == P.nparams &&
+           P.ngprior == 0 && P.nshare == 0 && !(c->flags & MC3HIP_FLAG_P2P) &&
+           c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_LEAN");
+}
+
 // ... and so has the same shape with two to four chains per wave: lean_demc_mc_kernel
 inline bool lean_demc_mc_eligible(const mc3hip_ctx *c)
 {

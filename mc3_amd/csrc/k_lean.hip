@@ -39,6 +39,8 @@ chain_kernel_fn fast_instance_tt(const mc3hip_ctx *c, bool p2p)
 template <int MT>
 chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
 {
+    if (lean_mrw_eligible(c) && !p2p)
+        return lean_mrw_kernel<MT>;
     if (c->P.sampler == MC3HIP_MRW)
         return fast_instance_tt<MT, MC3HIP_MRW>(c, p2p);
     if (lean_snooker_eligible(c) && !p2p)

@@ -508,6 +508,139 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
 }
 
 // ---------------------------------------------------------------------------------
+// The random-walk sampler (chain.py:219-220) for the same shape: no other chain is looked at,
+// an iteration is its draws and its chisq -- and the draws (one Philox call for the Metropolis
+// draw, one per two parameters for the normal deviates, a logarithm, a square root, a sine
+// and a cosine each: chain.py:185) were 0.7 of the 1.2 us the lean run_chain instance took.
+// Here they are made for 21 refreshes at once, one (refresh, slot) per lane -- lane 3 i: the
+// Metropolis draw and the window of its logarithm; lanes 3 i + 1, 3 i + 2: the deviates of
+// parameters 0, 1 and 2, 3 -- and an iteration gathers its own (v_readlane, ds_bpermute).
+// Same draws, same arithmetic, same results as run_chain's.
+template <int MT>
+__global__ __launch_bounds__(64) void lean_mrw_kernel(const DevProblem P, const int nref)
+{
+    static_assert(MT >= 1 && MT <= 4, "two slots of normal deviates");
+    constexpr int nf = MT;
+    constexpr int ZS = ZROW;
+    constexpr int NB = 21;
+    const int lane = threadIdx.x;
+    const int lc = blockIdx.x;
+    const int c = P.chain0 + lc;
+    const bool mine = lane < nf;
+    long long *ctl_rw = const_cast<long long *>(P.ctl);
+    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
+            &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+        return;
+    DataTile<1, MT> tile;
+    tile.load(P);
+    const long long R0 = P.ctl[0];
+    const int n = P.nchains;
+    const size_t blockstride = (size_t)n * ZS;
+    const double *pbase = (R0 == 0) ? P.snap0 : P.Z + (size_t)(P.M0 + (R0 - 1) * n) * ZS;
+    double *zblock = P.Z + (size_t)(P.M0 + R0 * n) * ZS;
+    double *lp_row = P.log_post + (P.M0 + R0 * n + c);
+    int32_t *zc_row = P.zchain + (P.M0 + R0 * n + c);
+    double xk = mine ? pbase[(size_t)c * ZS + lane] : 0.0;
+    double cur = P.chisq[lc];
+    double best = P.best_chisq[lc];
+    const long long nacc0 = P.numaccept[lc];
+    const double pmin_k = mine ? P.fmin[lane] : 0.0;
+    const double pmax_k = mine ? P.fmax[lane] : 0.0;
+    const double pstep_k = mine ? P.fstep[lane] : 0.0;
+    const long long abort_at = (P.test_abort >= 0 && lc == 0) ? (long long)P.test_abort : -1;
+    int nacc = 0;
+    double lpbuf = 0.0;
+    // lane 3 i + s of the batch: s = 0 -> u (bu) and its window; s = 1, 2 -> rad cos, rad sin of
+    // Philox slot 3 + (s - 1), i.e. the deviates of parameters 2 (s - 1) and 2 (s - 1) + 1
+    double bu = 0.0, blo = 0.0, bhi = 0.0, bcs = 0.0, bsn = 0.0;
+    long long bbase = R0;
+    const int bs = lane % 3, bi = (lane / 3 < NB) ? lane / 3 : NB - 1;
+    auto fill = [&](long long base) {
+        const Draw2 d = draw2(P.seed, (uint64_t)(base + bi), (uint32_t)c,
+                              bs == 0 ? 0u : (uint32_t)(2 + bs));
+        bu = u01(d.q1);                                              // chain.py:259
+        accept_window(bu, blo, bhi);
+        const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(d.q0)));
+        double sn, cs;
+        mc3_det_sincos2pi(u01(d.q1), &sn, &cs);
+        bcs = rad * cs;
+        bsn = rad * sn;
+        bbase = base;
+    };
+    fill(R0);
+    // lane k's deviate of a refresh sits in lane 3 i + 1 + (k >> 1): cosine branch for even k
+    const int src_off = 1 + (lane >> 1);
+    const long long Rend = R0 + nref;
+    long long rdone = R0;
+    auto flush_columns = [&](int count) {
+        if (lane < count) {
+            lp_row[(size_t)lane * n] = lpbuf;
+            zc_row[(size_t)lane * n] = c;
+        }
+    };
+    for (long long R = R0; R < Rend; ++R) {
+        if (__builtin_expect(R == abort_at, 0)) {                                         // test hook
+            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        if (__builtin_expect(R - bbase == NB, 0))
+            fill(R);
+        const int idx = 3 * (int)(R - bbase);
+        const double u_now = read_lane(bu, idx), lo_now = read_lane(blo, idx),
+                     hi_now = read_lane(bhi, idx);
+        const int src = mine ? idx + src_off : idx;
+        const double gc = lane_gather(bcs, src), gs = lane_gather(bsn, src);
+        // (rad * cos or sin) * pstep, as run_chain's normal_draw
+        const double jump_k = mine ? ((lane & 1) ? gs : gc) * pstep_k : 0.0;
+        // proposal and boundaries, chain.py:235-243
+        const double npk = xk + jump_k;
+        const bool outk = mine && (npk < pmin_k || npk > pmax_k);
+        if (__builtin_expect(!__any(outk), 1)) {
+            Model<MT> model;
+            model.init_from_lanes(P, npk);
+            const double nextchisq =
+                block_gauss_model<1, MT, false, false>(P, model, nullptr, nullptr, tile,
+                                                       &tile);               // chain.py:249
+            const bool acc = metropolis_accept(0.5 * (cur - nextchisq), u_now, lo_now, hi_now);
+            xk = acc ? npk : xk;
+            if (__builtin_expect(__any(acc && nextchisq < best), 0)) {
+                best = nextchisq;
+                if (mine)
+                    P.bestx[(size_t)lc * nf + lane] = xk;
+                if (lane == 0)
+                    P.best_iter[lc] = R;
+            }
+            cur = acc ? nextchisq : cur;
+            nacc += acc ? 1 : 0;
+        } else if (outk) {
+            atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
+        }
+        // Z append, chain.py:276-289
+        if (mine)
+            __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        const int slot = (int)(R - R0) & 63;
+        lpbuf = (lane == slot) ? -0.5 * cur : lpbuf;
+        if (__builtin_expect(slot == 63, 0)) {
+            flush_columns(64);
+            lp_row += (size_t)64 * n;
+            zc_row += (size_t)64 * n;
+        }
+        zblock += blockstride;
+        rdone = R + 1;
+    }
+    flush_columns((int)(rdone - R0) & 63);
+    if (mine)
+        P.X[(size_t)lc * nf + lane] = xk;
+    if (lane == 0) {
+        P.chisq[lc] = cur;
+        P.best_chisq[lc] = best;
+        P.numaccept[lc] = nacc0 + nacc;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // The same loop for ensembles with more chains than waves can be co-resident (P.mc_chains = T,
 // 2..4; one GPU): a wave owns chains b, b + G, ... b + (T - 1) G of a grid of G and advances
 // them one after another inside every refresh -- the turns of run_chain MC.  There a turn

@@ -928,6 +928,56 @@ def test_wavelet_likelihood_with_a_design_matrix_model(eng, ndata, nmodel, sampl
 
 
 @pytest.mark.parametrize('case', ['quad', 'line', 'cubic', 'tight', 'ragged', 'resume', 'abort',
+                                  'switch'])
+def test_lean_mrw_loop(eng, monkeypatch, case):
+    """lean_mrw_kernel: Metropolis draws, their log windows and the normal deviates of 21
+    refreshes at once; two, three and four parameters (one or two slots of deviates)."""
+    if case == 'ragged':
+        prob = H.quad_problem(ndata=37, nchains=9, nsamples=9*400, sampler='mrw')
+    elif case == 'tight':
+        prob = H.quad_problem(ndata=200, nchains=12, nsamples=12*400, sampler='mrw')
+        prob.update(params=np.array([4.0, -2.5, 0.5]), pmin=np.array([3.5, -2.8, 0.45]),
+                    pmax=np.array([6.5, -2.2, 0.56]), pstep=np.array([0.5, 0.2, 0.05]))
+    elif case in ('line', 'cubic'):
+        ncoef = 2 if case == 'line' else 4
+        x, data, uncert = H.tutorial_data(600)
+        prob = dict(data=data, uncert=uncert, indep=x/10.0,
+                    params=np.array([3.0, -20.0, 40.0, 5.0][:ncoef]),
+                    pstep=np.array([0.05, 0.1, 0.2, 0.1][:ncoef]), nchains=16,
+                    nsamples=16*300, sampler='mrw', model='poly', seed=9)
+    else:
+        prob = H.quad_problem(ndata=1000, nchains=40, nsamples=40*300, sampler='mrw')
+        prob['pstep'] = np.array([0.05, 0.02, 0.003])       # (steps that do get accepted)
+    if case == 'switch':
+        monkeypatch.setenv('MC3HIP_NO_LEAN', '1')
+    if case == 'abort':
+        monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '21')
+        orc, gpu = run_pair(eng, prob, trace=False)
+        assert gpu.plan['recoveries'] == 1
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
+        return
+    if case == 'resume':
+        gpu = eng.DeviceChains(**prob)
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nthreads=4)
+        for n in (1, 2, 20, 21, 22, 64, 100, 70):
+            gpu.run(n)
+    else:
+        orc, gpu = run_pair(eng, prob, trace=False)
+    plan = gpu.plan
+    assert plan['persistent'] > 0 and plan['recoveries'] == 0, plan
+    assert plan['fast'] == (1 if case == 'switch' else 2), plan
+    assert_same(orc, gpu, trace=False)
+    if case == 'tight':
+        assert gpu.state()['outbounds'].sum() > 50
+    gpu.close()
+
+
+@pytest.mark.parametrize('case', ['quad', 'line', 'cubic', 'tight', 'ragged', 'resume', 'abort',
                                   'tiny-history', 'switch'])
 def test_lean_snooker_loop(eng, monkeypatch, case):
     """lean_snooker_kernel: the draws of 21 refreshes at once with their row offsets, jump
