@@ -184,25 +184,28 @@ inline bool lean_batch(const mc3hip_ctx *c)
     return c->P.nlocal > 1024;
 }
 
-// ... and the snooker sampler on the plain shape (every coefficient free, one tile, no priors
-// or shared parameters, one chain per wave, one GPU): lean_snooker_kernel
-inline bool lean_snooker_eligible(const mc3hip_ctx *c)
+// every coefficient free, no Gaussian priors, no shared parameters (otherwise: the FX instances)
+inline bool lean_plain_shape(const mc3hip_ctx *c)
 {
-    const DevProblem &P = c->P;
-    return c->fast && c->mc_chains == 0 && P.sampler == MC3HIP_SNOOKER && P.thinning == 1 &&
-           P.nparams == c->mt && P.zs == ZROW && P.npad <= VLANES && P.nfree == P.nparams &&
-           P.ngprior == 0 && P.nshare == 0 && !(c->flags & MC3HIP_FLAG_P2P) &&
-           c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_LEAN");
+    return c->P.nfree == c->P.nparams && c->P.ngprior == 0 && c->P.nshare == 0;
 }
 
-// ... and the random-walk sampler on the same plain shape: lean_mrw_kernel
-inline bool lean_mrw_eligible(const mc3hip_ctx *c)
+// ... and the snooker and the random-walk samplers (one tile, one chain per wave, one GPU):
+// lean_snooker_kernel, lean_mrw_kernel
+inline bool lean_other_sampler_eligible(const mc3hip_ctx *c, int sampler)
 {
     const DevProblem &P = c->P;
-    return c->fast && c->mc_chains == 0 && P.sampler == MC3HIP_MRW && P.thinning == 1 &&
-           P.nparams == c->mt && P.zs == ZROW && P.npad <= VLANES && P.nfree == P.nparams &&
-           P.ngprior == 0 && P.nshare == 0 && !(c->flags & MC3HIP_FLAG_P2P) &&
-           c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_LEAN");
+    return c->fast && c->mc_chains == 0 && P.sampler == sampler && P.thinning == 1 &&
+           P.nparams == c->mt && P.zs == ZROW && P.npad <= VLANES &&
+           !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_LEAN");
+}
+inline bool lean_snooker_eligible(const mc3hip_ctx *c)
+{
+    return lean_other_sampler_eligible(c, MC3HIP_SNOOKER);
+}
+inline bool lean_mrw_eligible(const mc3hip_ctx *c)
+{
+    return lean_other_sampler_eligible(c, MC3HIP_MRW) && c->mt <= 4;
 }
 
 // ... and so has the same shape with two to four chains per wave: lean_demc_mc_kernel

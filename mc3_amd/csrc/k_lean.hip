@@ -40,11 +40,11 @@ template <int MT>
 chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
 {
     if (lean_mrw_eligible(c) && !p2p)
-        return lean_mrw_kernel<MT>;
+        return lean_plain_shape(c) ? lean_mrw_kernel<MT> : lean_mrw_kernel<MT, true>;
     if (c->P.sampler == MC3HIP_MRW)
         return fast_instance_tt<MT, MC3HIP_MRW>(c, p2p);
     if (lean_snooker_eligible(c) && !p2p)
-        return lean_snooker_kernel<MT>;
+        return lean_plain_shape(c) ? lean_snooker_kernel<MT> : lean_snooker_kernel<MT, true>;
     if (lean_demc_mc_eligible(c) && !p2p) {          // 2..4 chains per wave
 #define MC3_LEAN_MC(TT)                                                             \
         if (c->mc_chains == TT) {                                                   \

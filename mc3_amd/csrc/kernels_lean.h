@@ -304,10 +304,11 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
 //   * the ordinary jump (nine in ten) is decided in the log domain; a snooker jump proper
 //     (chain.py:207-215, :251-255) takes the exponential and the Hastings factor as ever.
 // Same draws, same arithmetic, same results as run_chain's.
-template <int MT>
+// (FX: some coefficients are fixed or shared, or carry Gaussian priors -- as lean_demc_kernel's)
+template <int MT, bool FX = false>
 __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, const int nref)
 {
-    constexpr int nf = MT;
+    const int nf = FX ? P.nfree : MT;
     constexpr int ZS = ZROW;
     constexpr int NB = 21;                     // refreshes per batch of draws (3 lanes each)
     const int lane = threadIdx.x;
@@ -338,6 +339,11 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
     const long long abort_at = (P.test_abort >= 0 && lc == 0) ? (long long)P.test_abort : -1;
     int nacc = 0;
     double lpbuf = 0.0;
+    int kf[MT];
+    double fx[MT];
+    if constexpr (FX)
+        coefficient_map<MT>(P, kf, fx);
+    (void)kf; (void)fx;
     // lane 3 i + s: slot s of refresh bbase + i.  A, B by slot: 0 -> the offsets (in doubles)
     // of rows iR1, iR2; 1 -> the offset of row iz, the jump flag; 2 -> gamma_s, u (as bits)
     unsigned long long A = 0, B = 0;
@@ -452,10 +458,16 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
         prepare(R + 1, S);
         if (__builtin_expect(!__any(outk), 1)) {
             Model<MT> model;
-            model.init_from_lanes(P, npk);
-            const double nextchisq =
+            if constexpr (!FX) {
+                model.init_from_lanes(P, npk);
+            } else {
+                model.init_from_lanes(P, npk, kf, fx);
+            }
+            double nextchisq =
                 block_gauss_model<1, MT, false, false>(P, model, nullptr, nullptr, tile,
                                                        &tile);               // chain.py:249
+            if constexpr (FX)
+                nextchisq = nextchisq + prior_from_lanes<MT>(P, npk, kf, fx);
             bool acc;
             if (__builtin_expect(!sjump, 1)) {
                 acc = metropolis_accept(0.5 * (cur - nextchisq), u_now, lo_now, hi_now);
@@ -516,11 +528,11 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
 // Metropolis draw and the window of its logarithm; lanes 3 i + 1, 3 i + 2: the deviates of
 // parameters 0, 1 and 2, 3 -- and an iteration gathers its own (v_readlane, ds_bpermute).
 // Same draws, same arithmetic, same results as run_chain's.
-template <int MT>
+template <int MT, bool FX = false>
 __global__ __launch_bounds__(64) void lean_mrw_kernel(const DevProblem P, const int nref)
 {
     static_assert(MT >= 1 && MT <= 4, "two slots of normal deviates");
-    constexpr int nf = MT;
+    const int nf = FX ? P.nfree : MT;
     constexpr int ZS = ZROW;
     constexpr int NB = 21;
     const int lane = threadIdx.x;
@@ -550,6 +562,11 @@ __global__ __launch_bounds__(64) void lean_mrw_kernel(const DevProblem P, const 
     const long long abort_at = (P.test_abort >= 0 && lc == 0) ? (long long)P.test_abort : -1;
     int nacc = 0;
     double lpbuf = 0.0;
+    int kf[MT];
+    double fx[MT];
+    if constexpr (FX)
+        coefficient_map<MT>(P, kf, fx);
+    (void)kf; (void)fx;
     // lane 3 i + s of the batch: s = 0 -> u (bu) and its window; s = 1, 2 -> rad cos, rad sin of
     // Philox slot 3 + (s - 1), i.e. the deviates of parameters 2 (s - 1) and 2 (s - 1) + 1
     double bu = 0.0, blo = 0.0, bhi = 0.0, bcs = 0.0, bsn = 0.0;
@@ -598,10 +615,16 @@ __global__ __launch_bounds__(64) void lean_mrw_kernel(const DevProblem P, const 
         const bool outk = mine && (npk < pmin_k || npk > pmax_k);
         if (__builtin_expect(!__any(outk), 1)) {
             Model<MT> model;
-            model.init_from_lanes(P, npk);
-            const double nextchisq =
+            if constexpr (!FX) {
+                model.init_from_lanes(P, npk);
+            } else {
+                model.init_from_lanes(P, npk, kf, fx);
+            }
+            double nextchisq =
                 block_gauss_model<1, MT, false, false>(P, model, nullptr, nullptr, tile,
                                                        &tile);               // chain.py:249
+            if constexpr (FX)
+                nextchisq = nextchisq + prior_from_lanes<MT>(P, npk, kf, fx);
             const bool acc = metropolis_accept(0.5 * (cur - nextchisq), u_now, lo_now, hi_now);
             xk = acc ? npk : xk;
             if (__builtin_expect(__any(acc && nextchisq < best), 0)) {

@@ -928,7 +928,7 @@ def test_wavelet_likelihood_with_a_design_matrix_model(eng, ndata, nmodel, sampl
 
 
 @pytest.mark.parametrize('case', ['quad', 'line', 'cubic', 'tight', 'ragged', 'resume', 'abort',
-                                  'switch'])
+                                  'switch', 'fixed', 'priors'])
 def test_lean_mrw_loop(eng, monkeypatch, case):
     """lean_mrw_kernel: Metropolis draws, their log windows and the normal deviates of 21
     refreshes at once; two, three and four parameters (one or two slots of deviates)."""
@@ -948,6 +948,12 @@ def test_lean_mrw_loop(eng, monkeypatch, case):
     else:
         prob = H.quad_problem(ndata=1000, nchains=40, nsamples=40*300, sampler='mrw')
         prob['pstep'] = np.array([0.05, 0.02, 0.003])       # (steps that do get accepted)
+    if case == 'fixed':                    # (FX instance: the linear coefficient is fixed)
+        prob['pstep'] = np.array(prob['pstep'], dtype=float)
+        prob['pstep'][1] = 0.0
+    if case == 'priors':                   # (FX instance: a Gaussian prior, a shared coefficient)
+        prob.update(prior=np.array([4.0, 0.0, 0.0]), priorlow=np.array([0.5, 0.0, 0.0]),
+                    priorup=np.array([0.7, 0.0, 0.0]))
     if case == 'switch':
         monkeypatch.setenv('MC3HIP_NO_LEAN', '1')
     if case == 'abort':
@@ -978,7 +984,7 @@ def test_lean_mrw_loop(eng, monkeypatch, case):
 
 
 @pytest.mark.parametrize('case', ['quad', 'line', 'cubic', 'tight', 'ragged', 'resume', 'abort',
-                                  'tiny-history', 'switch'])
+                                  'tiny-history', 'switch', 'fixed', 'priors'])
 def test_lean_snooker_loop(eng, monkeypatch, case):
     """lean_snooker_kernel: the draws of 21 refreshes at once with their row offsets, jump
     flags and log-u windows; rows asked for a refresh ahead; ordinary jumps decided in the log
@@ -1001,6 +1007,12 @@ def test_lean_snooker_loop(eng, monkeypatch, case):
         prob = H.quad_problem(ndata=300, nchains=5, nsamples=5*500, sampler='snooker', hsize=1)
     else:
         prob = H.quad_problem(ndata=1000, nchains=40, nsamples=40*300, sampler='snooker')
+    if case == 'fixed':                    # (FX instance: the linear coefficient is fixed)
+        prob['pstep'] = np.array(prob['pstep'], dtype=float)
+        prob['pstep'][1] = 0.0
+    if case == 'priors':                   # (FX instance: a Gaussian prior, a shared coefficient)
+        prob.update(prior=np.array([4.0, 0.0, 0.0]), priorlow=np.array([0.5, 0.0, 0.0]),
+                    priorup=np.array([0.7, 0.0, 0.0]))
     if case == 'switch':
         monkeypatch.setenv('MC3HIP_NO_LEAN', '1')
     if case == 'abort':
