@@ -211,9 +211,10 @@ inline bool lean_mrw_eligible(const mc3hip_ctx *c)
 // ... and so has the same shape with two to four chains per wave: lean_demc_mc_kernel
 inline bool lean_demc_mc_eligible(const mc3hip_ctx *c)
 {
-    return c->fast && c->mc_chains >= 2 && c->mc_chains <= 4 && c->P.sampler == MC3HIP_DEMC &&
-           c->P.thinning == 1 && c->P.nparams == c->mt && c->P.zs == ZROW &&
-           !getenv("MC3HIP_NO_LEAN");
+    // (four chains per wave AND two register-resident tiles do not fit the registers)
+    return c->fast && c->mc_chains >= 2 && c->mc_chains <= (c->P.npad > VLANES ? 3 : 4) &&
+           c->P.sampler == MC3HIP_DEMC && c->P.thinning == 1 && c->P.nparams == c->mt &&
+           c->P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
 }
 
 // waves that share the data sum of a chain in the hand-laid-out DEMC loop (kernels_lean.h

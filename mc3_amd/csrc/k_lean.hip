@@ -49,7 +49,7 @@ chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
 #define MC3_LEAN_MC(TT)                                                             \
         if (c->mc_chains == TT) {                                                   \
             if (c->P.npad > VLANES)                                                 \
-                return lean_demc_mc_kernel<MT, TT, false, true>;                    \
+                return lean_demc_mc_kernel<MT, (TT < 4 ? TT : 3), false, true>;     \
             if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)  \
                 return lean_demc_mc_kernel<MT, TT, true>;                           \
             return lean_demc_mc_kernel<MT, TT>;                                     \

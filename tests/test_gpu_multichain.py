@@ -101,7 +101,13 @@ def test_lean_fixed_coefficient_and_streamed_tiles(eng, monkeypatch, sampler):
     gpu.close()
     prob = H.quad_problem(ndata=3000, nchains=10, nsamples=10*40, sampler=sampler)   # MULTI
     orc, gpu = run_pair(eng, prob, trace=False)
-    check_plan(gpu, turns=4, fast=2 if sampler == 'demc' else 1)
+    # (four chains per wave and two register-resident tiles: the general instance)
+    check_plan(gpu, turns=4, fast=1)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+    forced(monkeypatch, 4)
+    orc, gpu = run_pair(eng, prob, trace=False)
+    check_plan(gpu, turns=3, fast=2 if sampler == 'demc' else 1)
     assert_same(orc, gpu, trace=False)
     gpu.close()
 
