@@ -125,6 +125,7 @@ class Communicator:
         in a collective for peers that went another way."""
         if self.size == 1:
             return
+        self._check_shared_device(engine)
         if self.wants_p2p and hasattr(engine, 'p2p_export'):
             handle, ok = None, False
             try:
@@ -154,6 +155,30 @@ class Communicator:
                     engine.p2p_detach()       # attached here, not everywhere: undo
                 self.barrier()
         self._setup_rccl(engine)
+
+    def _check_shared_device(self, engine):
+        """Several ranks on ONE device (a test set-up; a node gives every rank its own GPU):
+        the one-launch tiled plan sizes its grid for a whole device, and the grids of all the
+        ranks on it must be co-resident or they wait for each other forever (until the
+        hand-off gives up).  MC3HIP_RESIDENT_MAXCOL caps a rank's share; without it such a
+        run is refused here, on every rank alike."""
+        import os
+        dev = getattr(engine, '_device', None)
+        plan = getattr(engine, 'plan', None) or {}
+        devices = self.all_gather((dev, bool(plan.get('resident'))))
+        if dev is None:
+            return
+        shared = sum(1 for d, _ in devices if d == dev) > 1
+        anybody = any(s and r for (d, r), s in
+                      zip(devices, [sum(1 for e, _ in devices if e == d) > 1
+                                    for d, _ in devices]))
+        if anybody and 'MC3HIP_RESIDENT_MAXCOL' not in os.environ:
+            raise RuntimeError(
+                'several ranks share a device'
+                + (f' (this rank: device {dev})' if shared else '')
+                + ' and the one-launch tiled plan is in use: set MC3HIP_RESIDENT_MAXCOL '
+                  '(columns of chains per rank) so that their grids fit the device together, '
+                  'or give every rank a GPU of its own')
 
     def _setup_rccl(self, engine):
         """RCCL communicator inside the library, by consensus; host-staged otherwise."""
