@@ -61,6 +61,8 @@ CONFIGS = {
     # snooker proposals before the likelihood, as the reference does)
     'c4wide': lambda n: (H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*n,
                                            pmin=np.full(6, -1e3), pmax=np.full(6, 1e3)), {}),
+    # beyond 2^14 points: pre-levels through global memory, then the blocked pyramid
+    'c4big': lambda n: (H.wavelet_problem(ndata=65536, nchains=256, nsamples=256*n), {}),
     'c4half': lambda n: (H.wavelet_problem(ndata=16384, nchains=128, nsamples=128*n), {}),
     'c5': lambda n: (H.linear_problem(ndata=100000, nchains=512, nsamples=512*n), {}),
     'c5share': lambda n: (H.linear_problem(ndata=100000, nchains=512, nsamples=512*n),
@@ -73,10 +75,11 @@ BYTES = {'c2mrw': 24104, 'q5': 8*3*100000 + 8*3*4 + 8, 'c4mrw': 8*2*16384 + 8*5*
 ITERS = {'c2': 20000, 'c2snooker': 20000, 'c2mrw': 20000, 'c3one': 4000, 'c4': 4000, 'c5': 30, 'c5share': 1}
 ITERS['c5'] = 300
 ITERS['q5'] = 300
-ITERS.update(c4wide=4000, c4mrw=4000, c4demc=4000, c4half=4000, c3x2=3000, c3x4=2000, c3x2snooker=3000,
+ITERS.update(c4big=1000, c4wide=4000, c4mrw=4000, c4demc=4000, c4half=4000, c3x2=3000, c3x4=2000, c3x2snooker=3000,
              c4x2=2000, c4x4=1000)
 for _k in ('c3x2', 'c3x4', 'c3x2snooker'):
     BYTES[_k] = 24104
+BYTES['c4big'] = 8*2*65536 + 8*5*4 + 8
 for _k in ('c4x2', 'c4x4', 'c4wide'):
     BYTES[_k] = BYTES['c4']
 
