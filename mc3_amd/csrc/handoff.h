@@ -25,6 +25,35 @@ __device__ __forceinline__ double load_published(const double *p)
         return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The same load issued from inline assembly: the compiler's wait-count bookkeeping does not
+// know it, so no wait for it is inserted anywhere -- in particular not the `vmcnt(0)` the
+// compiler puts at a loop head when loads and stores are both in flight, which would wait for
+// the acknowledgement of the row just published.  The wave's vector-memory operations are
+// counted in issue order, loads and stores alike (MI355X_MICROARCH.md, "s_waitcnt vmcnt(N)
+// waits until all but the N youngest are done"), so the caller retires these loads with
+// published_arrived<N>: N = operations it is SURE to have issued after them (at least).  The
+// loaded-into variables must not be touched between the two (a copy would read a register the
+// load has not written yet).
+__device__ __forceinline__ double load_published_async(const double *p)
+{
+    double v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void published_arrived(double &a, double &b, double &c)
+{
+    static_assert(N >= 0 && N <= 3, "");
+    if constexpr (N == 0)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c)::"memory");
+    else if constexpr (N == 1)
+        asm volatile("s_waitcnt vmcnt(1)" : "+v"(a), "+v"(b), "+v"(c)::"memory");
+    else if constexpr (N == 2)
+        asm volatile("s_waitcnt vmcnt(2)" : "+v"(a), "+v"(b), "+v"(c)::"memory");
+    else
+        asm volatile("s_waitcnt vmcnt(3)" : "+v"(a), "+v"(b), "+v"(c)::"memory");
+}
+
 // Wave-level wait until every lane's values have been published (all 64 lanes
 // poll; lanes beyond nfree repeat lane 0's addresses).  The first read is issued
 // by the caller so that independent scalar work can overlap its latency; this

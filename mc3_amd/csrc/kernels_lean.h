@@ -384,14 +384,20 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
         const double *addr[3];
         double val[3];
     };
-    auto prepare = [&](long long R, Step &S) {          // (R inside the current batch)
+    auto prepare = [&](long long R, Step &S, bool async) {   // (R inside the current batch)
         const int idx = 3 * (int)(R - bbase);
         S.addr[0] = P.Z + (lane64(A, idx) + (unsigned)kk);
         S.addr[1] = P.Z + (lane64(B, idx) + (unsigned)kk);
         S.addr[2] = P.Z + (lane64(A, idx + 1) + (unsigned)kk);
+        if (async) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
-            S.val[q] = load_published<false>(S.addr[q]);
+            for (int q = 0; q < 3; ++q)
+                S.val[q] = load_published_async(S.addr[q]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                S.val[q] = load_published<false>(S.addr[q]);
+        }
         S.sj = lane64(B, idx + 1) != 0;
         S.gs = mc3_from_bits(lane64(A, idx + 2));
         S.u = mc3_from_bits(lane64(B, idx + 2));
@@ -400,7 +406,12 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
     };
     fill(R0);
     Step S;
-    prepare(R0, S);
+    prepare(R0, S, true);
+    // (retired here: a load the compiler knows of, still pending at the loop head, would make
+    // it guard these registers with a wait INSIDE the loop -- for everything in flight)
+    published_arrived<0>(S.val[0], S.val[1], S.val[2]);
+    // (... and so is everything else loaded so far -- the state, the bounds, the data tile)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     const long long Rend = R0 + nref;
     long long rdone = R0;
     auto flush_columns = [&](int count) {
@@ -416,26 +427,40 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
                                __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
-        // this refresh's rows were asked for a refresh ago; one of the newest may still be
-        // the sentinel
-        if (__builtin_expect(__any(mc3_bits(S.val[0]) == ROW_PENDING ||
-                                   mc3_bits(S.val[1]) == ROW_PENDING ||
-                                   mc3_bits(S.val[2]) == ROW_PENDING), 0)) {
-            const double *const a3[3] = {S.addr[0], S.addr[1], S.addr[2]};
-            double v3[3] = {S.val[0], S.val[1], S.val[2]};
+        // This refresh's rows were asked for at the top of the refresh before and retired at
+        // its bottom; the next refresh's are asked for now, first thing, by loads the
+        // compiler's wait counts do not see (handoff.h load_published_async): they have the
+        // whole iteration to arrive and are retired behind the publish, which they precede
+        // in the wave's queue.
+        Step C = S;
+        if (__builtin_expect(R + 1 - bbase == NB, 0))
+            fill(R + 1);
+        Step Nx;
+        prepare(R + 1, Nx, true);
+        // (one of the newest rows may still be the sentinel)
+        if (__builtin_expect(__any(mc3_bits(C.val[0]) == ROW_PENDING ||
+                                   mc3_bits(C.val[1]) == ROW_PENDING ||
+                                   mc3_bits(C.val[2]) == ROW_PENDING), 0)) {
+            const double *const a3[3] = {C.addr[0], C.addr[1], C.addr[2]};
+            double v3[3] = {C.val[0], C.val[1], C.val[2]};
             alive = wait_rows<3, false>(a3, v3, ctl_rw);
-            S.val[0] = v3[0];
-            S.val[1] = v3[1];
-            S.val[2] = v3[2];
+            // (nothing this path asked for is pending where it joins the other: said in a
+            // form the compiler's bookkeeping reads, or it guards the join with a wait of its
+            // own -- which the loads of the next refresh, just issued, would be waited for at)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            asm volatile("; rows of this refresh" : "+v"(v3[0]), "+v"(v3[1]), "+v"(v3[2]));
+            C.val[0] = v3[0];
+            C.val[1] = v3[1];
+            C.val[2] = v3[2];
             if (__builtin_expect(!alive, 0))
                 break;
         }
-        const double z1 = S.val[0], z2 = S.val[1], zk = S.val[2];
-        const bool sjump = S.sj;
-        const double u_now = S.u, lo_now = S.lo, hi_now = S.hi;
+        const double z1 = C.val[0], z2 = C.val[1], zk = C.val[2];
+        const bool sjump = C.sj;
+        const double u_now = C.u, lo_now = C.lo, hi_now = C.hi;
         double jump_k;
         if (__builtin_expect(sjump, 0)) {                            // chain.py:207-215
-            const double gs = S.gs;
+            const double gs = C.gs;
             const bool same = __all(!mine || zk == xk);
             if (same) {
                 jump_k = gs * (z2 - z1);
@@ -452,10 +477,6 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
         // proposal and boundaries, chain.py:235-243
         const double npk = xk + jump_k;
         const bool outk = mine && (npk < pmin_k || npk > pmax_k);
-        // the next refresh: its draws (a new batch every 21), its rows asked for now
-        if (__builtin_expect(R + 1 - bbase == NB, 0))
-            fill(R + 1);
-        prepare(R + 1, S);
         if (__builtin_expect(!__any(outk), 1)) {
             Model<MT> model;
             if constexpr (!FX) {
@@ -491,14 +512,14 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
         } else if (outk) {
             atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
         }
-        // (the rows asked for above have arrived behind the chisq: said here, the wait for
-        // them cannot land behind the stores below -- see lean_demc_kernel)
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        asm volatile("; rows of the next refresh" : "+v"(S.val[0]), "+v"(S.val[1]), "+v"(S.val[2]));
         // Z append, chain.py:276-289
         if (mine)
             __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);            // publish (sc1)
+        // the next refresh's rows: everything but the youngest operation of this wave -- the
+        // store above at least -- has completed
+        published_arrived<1>(Nx.val[0], Nx.val[1], Nx.val[2]);
+        S = Nx;
         const int slot = (int)(R - R0) & 63;
         lpbuf = (lane == slot) ? -0.5 * cur : lpbuf;
         if (__builtin_expect(slot == 63, 0)) {
