@@ -616,6 +616,10 @@ __global__ __launch_bounds__(64) void lean_mrw_kernel(const DevProblem P, const 
             zc_row[(size_t)lane * n] = c;
         }
     };
+    // (everything loaded so far -- the state, the bounds, the data tile -- retired here: a load
+    // still pending at the loop head would make the compiler guard its registers with a wait
+    // INSIDE the loop, i.e. for the publish of the iteration before as well)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     for (long long R = R0; R < Rend; ++R) {
         if (__builtin_expect(R == abort_at, 0)) {                                         // test hook
             __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
@@ -770,6 +774,10 @@ __global__ __launch_bounds__(64) void lean_demc_mc_kernel(const DevProblem P, co
     };
     fill(R0);
     const long long Rend = R0 + nref;
+    // (everything loaded so far retired here: a load still pending at the loop head would make
+    // the compiler guard its registers with a wait INSIDE the loop -- for the stores of the
+    // turn before as well)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     for (long long R = R0; R < Rend; ++R) {
         if (__builtin_expect(R == abort_at, 0)) {                                         // test hook
             __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
@@ -798,6 +806,12 @@ __global__ __launch_bounds__(64) void lean_demc_mc_kernel(const DevProblem P, co
             asm volatile("; pin" : "+v"(bu), "+v"(blo), "+v"(bhi), "+v"(bo1), "+v"(bo2));
         }
         __builtin_amdgcn_sched_barrier(0);
+        // The rows of ALL turns are waited for here (asked for back to back, they arrive within
+        // a few cycles of each other): a wait further down, behind the stores of a turn, would
+        // wait for those stores' acknowledgements too (loads and stores share vmcnt) -- and the
+        // compiler puts one at every use of a register it believes a load may still be on its
+        // way to, however the path got there.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
         for (int q = 0; q < T; ++q) {
             if (!have[q])
@@ -811,6 +825,12 @@ __global__ __launch_bounds__(64) void lean_demc_mc_kernel(const DevProblem P, co
                 const double *const a2[2] = {addr[q][0], addr[q][1]};
                 double v2[2] = {val[q][0], val[q][1]};
                 alive = wait_rows<2, false>(a2, v2, ctl_rw);
+                // (nothing this path asked for is pending where it joins the other: said in a
+                // form the compiler's bookkeeping reads, or it guards the join -- and the loop
+                // head -- with a wait of its own, which the publish of the turn before, just
+                // issued, would be waited for at)
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                asm volatile("; rows of this turn" : "+v"(v2[0]), "+v"(v2[1]));
                 val[q][0] = v2[0];
                 val[q][1] = v2[1];
                 if (__builtin_expect(!alive, 0))
@@ -846,14 +866,6 @@ __global__ __launch_bounds__(64) void lean_demc_mc_kernel(const DevProblem P, co
                 nacc[q] += acc ? 1 : 0;
             } else if (outk) {
                 atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
-            }
-            if (q == 0) {
-                // every row asked for at the top has arrived by now: said here, before the
-                // first store of the refresh, no later wait can land behind a store
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-#pragma unroll
-                for (int q2 = 1; q2 < T; ++q2)
-                    asm volatile("; rows of the later turns" : "+v"(val[q2][0]), "+v"(val[q2][1]));
             }
             // Z append, chain.py:276-289
             if (mine)
