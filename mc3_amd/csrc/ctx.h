@@ -208,6 +208,23 @@ inline bool lean_mrw_eligible(const mc3hip_ctx *c)
     return lean_other_sampler_eligible(c, MC3HIP_MRW) && c->mt <= 4;
 }
 
+// ... and with two to four chains per wave: lean_snooker_mc_kernel, lean_mrw_mc_kernel
+inline bool lean_other_sampler_mc_eligible(const mc3hip_ctx *c, int sampler)
+{
+    const DevProblem &P = c->P;
+    return c->fast && c->mc_chains >= 2 && c->mc_chains <= 4 && P.sampler == sampler &&
+           P.thinning == 1 && P.nparams == c->mt && P.zs == ZROW && P.npad <= VLANES &&
+           !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_LEAN");
+}
+inline bool lean_snooker_mc_eligible(const mc3hip_ctx *c)
+{
+    return lean_other_sampler_mc_eligible(c, MC3HIP_SNOOKER);
+}
+inline bool lean_mrw_mc_eligible(const mc3hip_ctx *c)
+{
+    return lean_other_sampler_mc_eligible(c, MC3HIP_MRW) && c->mt <= 4;
+}
+
 // ... and so has the same shape with two to four chains per wave: lean_demc_mc_kernel
 inline bool lean_demc_mc_eligible(const mc3hip_ctx *c)
 {

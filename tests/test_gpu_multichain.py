@@ -44,8 +44,14 @@ def test_big_ensembles_stay_on_the_persistent_path(eng, nchains, sampler, nref):
     """C2-shaped (quadratic, ndata 1000) beyond the 2048 co-resident single-wave workgroups."""
     prob = H.quad_problem(ndata=1000, nchains=nchains, nsamples=nchains*nref, sampler=sampler)
     orc, gpu = run_pair(eng, prob, trace=False)
-    # (DEMC, two to four chains per wave: the hand-laid-out loop, lean_demc_mc_kernel)
-    check_plan(gpu, fast=2 if sampler == 'demc' else 1)
+    # (two to four chains per wave: the hand-laid-out loops, lean_demc_mc_kernel,
+    # lean_snooker_mc_kernel, lean_mrw_mc_kernel; with three or four chains per wave those two
+    # fit one wave per SIMD, so 5000 / 8192 chains of theirs take more turns on the general lean
+    # instance)
+    plan = check_plan(gpu)
+    assert plan['fast'] == (2 if plan['chains_per_workgroup'] <= 4 else 1), plan
+    if sampler == 'demc' or nchains <= 4096:
+        assert plan['fast'] == 2, plan
     assert_same(orc, gpu, trace=False)
     gpu.close()
 
@@ -77,7 +83,7 @@ def test_lean_instances_with_several_chains_per_wave(eng, monkeypatch, sampler, 
                           sampler=sampler, thinning=thinning)
     orc, gpu = run_pair(eng, prob, trace=False)
     turns = -(-nchains//capacity)
-    lean_loop = (sampler, thinning) == ('demc', 1) and turns <= 4
+    lean_loop = thinning == 1 and turns <= 4
     check_plan(gpu, turns=turns, fast=2 if lean_loop else 1)
     assert_same(orc, gpu, trace=False)
     gpu.close()
@@ -96,7 +102,7 @@ def test_lean_fixed_coefficient_and_streamed_tiles(eng, monkeypatch, sampler):
     prob = H.quad_problem(ndata=500, nchains=10, nsamples=10*60, sampler=sampler)
     prob['pstep'] = np.array([1.0, 0.0, 0.1])           # FX: the linear coefficient is fixed
     orc, gpu = run_pair(eng, prob, trace=False)
-    check_plan(gpu, turns=4, fast=2 if sampler == 'demc' else 1)
+    check_plan(gpu, turns=4, fast=2)
     assert_same(orc, gpu, trace=False)
     gpu.close()
     prob = H.quad_problem(ndata=3000, nchains=10, nsamples=10*40, sampler=sampler)   # MULTI
@@ -231,6 +237,59 @@ def test_lean_demc_loop_with_several_chains_per_wave(eng, monkeypatch, case, tur
     if case == 'tight':
         assert gpu.state()['outbounds'].sum() > 50
     gpu.close()
+
+
+@pytest.mark.parametrize('turns', [2, 3, 4])
+@pytest.mark.parametrize('sampler', ['snooker', 'mrw'])
+@pytest.mark.parametrize('case', ['resume', 'abort', 'tight', 'priors', 'ragged', 'thin'])
+def test_lean_snooker_and_mrw_loops_with_several_chains_per_wave(eng, monkeypatch, case, sampler,
+                                                                 turns):
+    """lean_snooker_mc_kernel / lean_mrw_mc_kernel<.., T>: launches of a few refreshes, a
+    give-up, bounds that reject most proposals, Gaussian priors (FX), an ensemble that leaves
+    the last turn of some waves empty, a history of one row per chain (snooker draws from the
+    newest rows: the wait for a row that is still the sentinel)."""
+    nchains = {2: 10, 3: 14, 4: 23}[turns] if case == 'ragged' else 5*turns
+    forced(monkeypatch, 5 if case != 'ragged' else -(-nchains//turns))
+    prob = H.quad_problem(ndata=400, nchains=nchains, nsamples=nchains*70, sampler=sampler)
+    if case == 'tight':
+        prob.update(params=np.array([4.0, -2.5, 0.5]), pmin=np.array([3.5, -2.8, 0.45]),
+                    pmax=np.array([6.5, -2.2, 0.56]))
+    if case == 'priors':
+        prob.update(prior=np.array([4.0, 0.0, 0.0]), priorlow=np.array([0.5, 0.0, 0.0]),
+                    priorup=np.array([0.7, 0.0, 0.0]))
+    if case == 'thin':
+        prob.update(hsize=1)
+    if case == 'abort':
+        monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '9')
+        orc, gpu = run_pair(eng, prob, trace=False)
+        assert gpu.plan['recoveries'] == 1
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
+        return
+    if case == 'resume':
+        monkeypatch.setenv('MC3HIP_PERSIST_REFS', '7')
+        gpu = eng.DeviceChains(**prob)
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nthreads=4)
+        for n in (1, 2, 30, 37):
+            gpu.run(n)
+    else:
+        orc, gpu = run_pair(eng, prob, trace=False)
+    check_plan(gpu, turns=turns, fast=2)
+    assert_same(orc, gpu, trace=False)
+    if case == 'tight':
+        assert gpu.state()['outbounds'].sum() > 50
+    gpu.close()
+    # the general lean instance (run_chain MC) behind the switch
+    monkeypatch.setenv('MC3HIP_NO_LEAN', '1')
+    if case != 'resume':
+        orc, gpu = run_pair(eng, prob, trace=False)
+        check_plan(gpu, turns=turns, fast=1)
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
 
 
 @pytest.mark.parametrize('case', ['plain', 'epsilon', 'tight', 'resume', 'abort', 'general'])

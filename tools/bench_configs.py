@@ -51,6 +51,10 @@ CONFIGS = {
                                       sampler='demc'), {}),
     'c3x2snooker': lambda n: (H.quad_problem(ndata=1000, nchains=4096, nsamples=4096*n,
                                              sampler='snooker'), {}),
+    'c3x2mrw': lambda n: (H.quad_problem(ndata=1000, nchains=4096, nsamples=4096*n,
+                                         sampler='mrw'), {}),
+    'c3onesnooker': lambda n: (H.quad_problem(ndata=1000, nchains=2048, nsamples=2048*n,
+                                              sampler='snooker'), {}),
     'c4x2': lambda n: (H.wavelet_problem(ndata=16384, nchains=512, nsamples=512*n), {}),
     'c4x4': lambda n: (H.wavelet_problem(ndata=16384, nchains=1024, nsamples=1024*n), {}),
     'c4mrw': lambda n: (H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*n,
@@ -77,7 +81,8 @@ ITERS['c5'] = 300
 ITERS['q5'] = 300
 ITERS.update(c4big=1000, c4wide=4000, c4mrw=4000, c4demc=4000, c4half=4000, c3x2=3000, c3x4=2000, c3x2snooker=3000,
              c4x2=2000, c4x4=1000)
-for _k in ('c3x2', 'c3x4', 'c3x2snooker'):
+ITERS.update(c3x2mrw=3000, c3onesnooker=4000)
+for _k in ('c3x2', 'c3x4', 'c3x2snooker', 'c3x2mrw', 'c3onesnooker'):
     BYTES[_k] = 24104
 BYTES['c4big'] = 8*2*65536 + 8*5*4 + 8
 for _k in ('c4x2', 'c4x4', 'c4wide'):
