@@ -174,6 +174,13 @@ inline bool lean_demc_eligible(const mc3hip_ctx *c)
            c->P.nparams == c->mt && c->P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
 }
 
+// ... in the peer-to-peer mode with a second wave that carries the rows to the other ranks'
+// replicas (lean_demc_kernel COURIER; MC3HIP_NO_COURIER=1: the chain wave stores them itself)
+inline bool lean_courier(const mc3hip_ctx *c, bool p2p)
+{
+    return p2p && lean_demc_eligible(c) && !getenv("MC3HIP_NO_COURIER");
+}
+
 // the headline loop with the draws of 64 refreshes computed at once (lean_demc_kernel BATCH):
 // where more than one wave shares a SIMD (more than 1024 chains on this chip) the loop is
 // bound by the instructions it issues, below that by the hand-off (MC3HIP_LEAN_BATCH=0|1 forces)

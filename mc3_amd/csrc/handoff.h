@@ -54,6 +54,44 @@ __device__ __forceinline__ void published_arrived(double &a, double &b, double &
         asm volatile("s_waitcnt vmcnt(3)" : "+v"(a), "+v"(b), "+v"(c)::"memory");
 }
 
+// The ranks' replicas (peer-to-peer mode).  The pointers are read ONCE, before the loop: a load
+// of one inside it is waited for together with everything older in the wave's queue -- the
+// store into the previous peer's replica, still on its way over xGMI -- so a row's stores
+// would go out one acknowledged round trip after the other.  Up to PEER_REGS ranks (one
+// node) are kept in scalar registers; ranks beyond that are served the slow way.
+constexpr int PEER_REGS = 8;
+template <class T>
+struct PeerTable {
+    T *p[PEER_REGS];
+    T *const *table;
+    int n;
+    __device__ __forceinline__ void load(T *const *tab, int npeers)
+    {
+        table = tab;
+        n = npeers;
+#pragma unroll
+        for (int r = 0; r < PEER_REGS; ++r) {
+            const unsigned long long q =
+                (unsigned long long)(r < npeers ? tab[r] : (T *)nullptr);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)q);
+            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(q >> 32));
+            p[r] = own_global((T *)(((unsigned long long)hi << 32) | lo));
+        }
+    }
+    // v to element `off` of every replica (but `skip`'s), at system scope
+    __device__ __forceinline__ void store(size_t off, T v, int skip = -1) const
+    {
+#pragma unroll
+        for (int r = 0; r < PEER_REGS; ++r)
+            if (r < n && r != skip)
+                __hip_atomic_store(p[r] + off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int r = PEER_REGS; r < n; ++r)
+            if (r != skip)
+                __hip_atomic_store(&table[r][off], v, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+};
+
 // Wave-level wait until every lane's values have been published (all 64 lanes
 // poll; lanes beyond nfree repeat lane 0's addresses).  The first read is issued
 // by the caller so that independent scalar work can overlap its latency; this

@@ -76,7 +76,8 @@ chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
     }
     if (lean_demc_eligible(c)) {
         if (p2p)
-            return lean_demc_kernel<MT, true>;
+            return lean_courier(c, p2p) ? lean_demc_kernel<MT, true, false, false, false, true>
+                                        : lean_demc_kernel<MT, true>;
         if (c->P.npad > VLANES)
             return lean_demc_kernel<MT, false, false, true>;
         if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)

@@ -34,21 +34,92 @@ __global__ __launch_bounds__(64) void persist_fast_kernel(const DevProblem P, co
 // one refresh per lane -- Philox, log u and its window, the partners' row offsets as vector
 // instructions once per 64 refreshes instead of ~100 scalar and ~100 vector instructions per
 // refresh -- and a refresh reads its own with v_readlane.  Same draws, same results.
-template <int MT, bool P2P, bool FX = false, bool MULTI = false, bool BATCH = false>
-__global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const int nref)
+//
+// COURIER (peer-to-peer mode, several GPUs): the rows for the OTHER ranks' replicas are stored
+// by a second wave of the workgroup.  A wave's loads and stores retire through one counter in
+// issue order (MI355X_MICROARCH.md, s_waitcnt): a poll of the next refresh's partner rows,
+// issued behind the stores into seven remote replicas, would have its data held back until
+// every one of those stores has been acknowledged over xGMI -- a full round trip, where the
+// hand-off itself needs one way.  So the chain wave stores into the LOCAL replica only and
+// leaves the row in an LDS ring; the courier picks it up (it spins on an LDS counter: no
+// vector-memory operation, nothing the chain wave could wait behind) and stores it into the
+// remote replicas, its own counter absorbing the acknowledgements.  Same rows, same results.
+constexpr int COURIER_RING = 64;             // rows the chain wave may be ahead of its courier
+template <int MT, bool P2P, bool FX = false, bool MULTI = false, bool BATCH = false,
+          bool COURIER = false>
+__global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const DevProblem P,
+                                                                      const int nref)
 {
+    static_assert(!COURIER || P2P, "the courier serves the peer-to-peer mode");
     const int nf = FX ? P.nfree : MT;        // FX: some coefficients are fixed (nfree < MT)
     constexpr int ZS = ZROW;                 // doubles per Z row: one 128-byte line (NF <= 16)
     constexpr int LM = P2P ? 1 : 0;
-    const int lane = threadIdx.x;
+    const int lane = COURIER ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     const int lc = blockIdx.x;
     const int c = P.chain0 + lc;
     const bool mine = lane < nf;
     const int kk = mine ? lane : 0;
     long long *ctl_rw = const_cast<long long *>(P.ctl);
-    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
-            &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
-        return;
+    __shared__ double s_ring[COURIER ? COURIER_RING * ZROW : 1];
+    __shared__ int s_cour[4];                // 0: rows handed over, 1: rows sent, 2: done, 3: go
+    (void)s_ring; (void)s_cour;
+    if constexpr (COURIER) {
+        // (one decision for both waves: a courier that left while its chain wave stays --
+        // an abort raised between their two looks at the word -- would never drain the ring)
+        if (threadIdx.x == 0) {
+            s_cour[0] = 0;
+            s_cour[1] = 0;
+            s_cour[2] = 0;
+            s_cour[3] = __hip_atomic_load(&ctl_rw[CTL_ABORT], __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT) == 0;
+        }
+        __syncthreads();
+        if (s_cour[3] == 0)
+            return;
+        if (threadIdx.x >= 64) {
+            // ---- the courier ------------------------------------------------------------
+            const long long R0c = P.ctl[0];
+            size_t zoff = (size_t)(P.M0 + R0c * P.nchains) * ZS + (size_t)c * ZS + lane;
+            const size_t stride = (size_t)P.nchains * ZS;
+            PeerTable<double> peers;
+            peers.load(P.peerZ, P.npeers);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            int sent = 0;
+            for (;;) {
+                const int done = __hip_atomic_load(&s_cour[2], __ATOMIC_ACQUIRE,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int head = __hip_atomic_load(&s_cour[0], __ATOMIC_ACQUIRE,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (head == sent) {
+                    if (done)
+                        break;
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                for (; sent < head; ++sent, zoff += stride) {
+                    const double v = s_ring[(sent % COURIER_RING) * ZS + kk];
+                    if (mine)
+                        peers.store(zoff, v, P.rank);
+                }
+                __hip_atomic_store(&s_cour[1], sent, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            return;
+        }
+    } else {
+        if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
+                &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+            return;
+    }
+    int handed = 0;                          // COURIER: rows left in the ring so far
+    (void)handed;
+    PeerTable<double> peers_z, peers_lp;
+    if constexpr (P2P) {
+        if constexpr (!COURIER)
+            peers_z.load(P.peerZ, P.npeers);
+        peers_lp.load(P.peerLP, P.npeers);
+    }
+    (void)peers_z; (void)peers_lp;
     MC3_STAMP(0);
     DataTile<1, MT> tile;
     tile.load(P);
@@ -120,9 +191,7 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
         if (lane < count) {
             if constexpr (P2P) {
                 const size_t roff = (size_t)(lp_row - P.log_post) + (size_t)lane * n;
-                for (int pr = 0; pr < P.npeers; ++pr)
-                    __hip_atomic_store(&P.peerLP[pr][roff], lpbuf, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_SYSTEM);
+                peers_lp.store(roff, lpbuf);
             } else {
                 lp_row[(size_t)lane * n] = lpbuf;
             }
@@ -247,12 +316,35 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
         // share the counter on gfx9).
         __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0), already true
         // Z append, chain.py:276-289: publish the row ...
-        if constexpr (P2P) {
+        if constexpr (COURIER) {
+            // ... into the local replica, and hand it to the courier for the others
+            if (mine) {
+                __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+                s_ring[(handed % COURIER_RING) * ZS + lane] = xk;
+            }
+            ++handed;
+            __hip_atomic_store(&s_cour[0], handed, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+            // (never a whole ring ahead: looked at once in 16 rows)
+            if (__builtin_expect((handed & 15) == 0, 0)) {
+                while (handed - __hip_atomic_load(&s_cour[1], __ATOMIC_ACQUIRE,
+                                                  __HIP_MEMORY_SCOPE_WORKGROUP) >
+                       COURIER_RING - 16) {
+                    if (__hip_atomic_load(&ctl_rw[CTL_ABORT], __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        alive = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (__builtin_expect(!alive, 0))
+                    break;
+            }
+        } else if constexpr (P2P) {
             const size_t zoff = (size_t)(zblock - P.Z) + (size_t)c * ZS + lane;
             if (mine)
-                for (int pr = 0; pr < P.npeers; ++pr)                // ... into every replica
-                    __hip_atomic_store(&P.peerZ[pr][zoff], xk, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_SYSTEM);
+                peers_z.store(zoff, xk);                             // ... into every replica
         } else {
             if (mine)
                 __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
@@ -271,6 +363,8 @@ __global__ __launch_bounds__(64) void lean_demc_kernel(const DevProblem P, const
         MC3_TICK(tk_prevend);
         rdone = R + 1;
     }
+    if constexpr (COURIER)                       // (the courier drains the ring and leaves)
+        __hip_atomic_store(&s_cour[2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     flush_columns((int)(rdone - R0) & 63);       // the unwritten tail (also after an early exit)
     if (mine)
         P.X[(size_t)lc * nf + lane] = xk;

@@ -226,6 +226,8 @@ size_t fast_smem(const mc3hip_ctx *c)
 // share a chain's data sum (ctx.h lean_waves)
 int fast_threads(const mc3hip_ctx *c, bool p2p)
 {
+    if (lean_courier(c, p2p))
+        return 128;                              // (the chain wave and its courier)
     return (p2p || c->mc_chains > 0) ? 64 : 64 * lean_waves(c);
 }
 
@@ -254,7 +256,7 @@ int fast_blocks_per_cu(mc3hip_ctx *c)
                            fast_threads(c, p2p), fast_smem(c));
     if ((c->flags & MC3HIP_FLAG_P2P) && !p2p) {
         const int np = blocks_per_cu(reinterpret_cast<const void *>(fast_instance(c, true)),
-                                     64, fast_smem(c));
+                                     fast_threads(c, true), fast_smem(c));
         nb = np < nb ? np : nb;
     }
     return nb;

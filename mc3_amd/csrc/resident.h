@@ -454,6 +454,13 @@ __device__ __forceinline__ void lean_resident_owner(const DevProblem &P, const i
     asm volatile("; own" : "+s"(gamma), "+s"(fepsilon), "+s"(nchains), "+s"(nparams), "+s"(nf),
                            "+s"(zs));
     double *s_nextp = area + 64;                       // (carve(): behind the one-wave `part`)
+    // P2P: the ranks' replicas, their pointers read once (handoff.h PeerTable)
+    PeerTable<double> peers_z, peers_lp;
+    if constexpr (P2P) {
+        peers_z.load(P.peerZ, P.npeers);
+        peers_lp.load(P.peerLP, P.npeers);
+    }
+    (void)peers_z; (void)peers_lp;
     const bool mine = lane < nf;
     const int kk = mine ? lane : 0;
     const long long R0 = P.ctl[0];
@@ -569,9 +576,7 @@ __device__ __forceinline__ void lean_resident_owner(const DevProblem &P, const i
         const long long row = M0 + R * nchains + c;
         if (mine) {
             if constexpr (P2P) {
-                for (int pr = 0; pr < P.npeers; ++pr)               // publish everywhere
-                    __hip_atomic_store(&P.peerZ[pr][(size_t)row * zs + lane], xk,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                peers_z.store((size_t)row * zs + lane, xk);          // publish everywhere
             } else {
                 __hip_atomic_store(&Zr[(size_t)row * zs + lane], xk, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);       // publish (sc1)
@@ -581,9 +586,7 @@ __device__ __forceinline__ void lean_resident_owner(const DevProblem &P, const i
         request_rows(nxt.q0, R + 1);
         if (lane == 0) {
             if constexpr (P2P) {
-                for (int pr = 0; pr < P.npeers; ++pr)
-                    __hip_atomic_store(&P.peerLP[pr][row], -0.5 * cur, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_SYSTEM);
+                peers_lp.store((size_t)row, -0.5 * cur);
             } else {
                 log_post[row] = -0.5 * cur;
             }

@@ -102,6 +102,13 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     double cur = P.chisq[lc];
     double best = P.best_chisq[lc];
     const long long nacc0 = MC ? 0 : P.numaccept[lc];
+    // P2P: the ranks' replicas, their pointers read once (handoff.h PeerTable)
+    PeerTable<double> peers_z, peers_lp;
+    if constexpr (P2P) {
+        peers_z.load(P.peerZ, P.npeers);
+        peers_lp.load(P.peerLP, P.npeers);
+    }
+    (void)peers_z; (void)peers_lp;
     // MC: what the chains of this workgroup carry between their turns, in LDS behind the
     // areas of carve(): slot q = [state (zs doubles) | chisq | best chisq | accept count]
     const int mc_turns = MC ? P.mc_chains : 1;
@@ -651,9 +658,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
         const long long row = P.M0 + R * P.nchains + c;
         if (mine) {
             if constexpr (P2P) {
-                for (int pr = 0; pr < P.npeers; ++pr)               // publish everywhere
-                    __hip_atomic_store(&P.peerZ[pr][(size_t)row * zs + lane], xk,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                peers_z.store((size_t)row * zs + lane, xk);          // publish everywhere
             } else if constexpr (PERSIST) {
                 __hip_atomic_store(&P.Z[(size_t)row * zs + lane], xk, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);      // publish (sc1)
@@ -663,9 +668,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
         }
         if (lane == 0) {
             if constexpr (P2P) {
-                for (int pr = 0; pr < P.npeers; ++pr)
-                    __hip_atomic_store(&P.peerLP[pr][row], -0.5 * cur, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_SYSTEM);
+                peers_lp.store((size_t)row, -0.5 * cur);
             } else {
                 P.log_post[row] = -0.5 * cur;
             }

@@ -168,6 +168,11 @@ class Communicator:
         devices = self.all_gather((dev, bool(plan.get('resident'))))
         if dev is None:
             return
+        # (the peer-to-peer instance of the headline loop has a second wave per chain, the
+        # courier: the workgroups of more than four ranks of 256 chains are not co-resident
+        # on ONE device with it -- such a test set-up runs without, MC3HIP_NO_COURIER)
+        if max(sum(1 for e, _ in devices if e == d) for d, _ in devices) > 4:
+            os.environ.setdefault('MC3HIP_NO_COURIER', '1')
         shared = sum(1 for d, _ in devices if d == dev) > 1
         anybody = any(s and r for (d, r), s in
                       zip(devices, [sum(1 for e, _ in devices if e == d) > 1

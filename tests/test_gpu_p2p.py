@@ -20,11 +20,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     (4, 'demc', 1, 300, 'socket'), (4, 'snooker', 1, 300, 'socket'),
     (8, 'demc', 1, 200, 'socket'), (2, 'demc', 1, 300, 'torchrun')])
 def test_processes_peer_to_peer(tmp_path, nproc, sampler, thinning, niter, launcher):
+    p2p_case(tmp_path, nproc, sampler, thinning, niter, launcher)
+
+
+def test_peer_to_peer_without_the_courier(tmp_path):
+    """The headline loop's peer-to-peer instance with the chain wave storing into the other
+    ranks' replicas itself (MC3HIP_NO_COURIER=1; by default a second wave of the workgroup
+    carries the rows, lean_demc_kernel COURIER -- the 2- and 4-rank demc cases above)."""
+    p2p_case(tmp_path, 2, 'demc', 1, 400, 'socket', env={'MC3HIP_NO_COURIER': '1'})
+
+
+def p2p_case(tmp_path, nproc, sampler, thinning, niter, launcher, env=None):
     import mc3_amd
     from mc3_amd import utils as mu
     from oracle_engine import OracleChains
     out_path = str(tmp_path / 'p2p')
-    launch_ranks(nproc, 'p2p_worker.py', out_path, sampler, thinning, niter, launcher=launcher)
+    launch_ranks(nproc, 'p2p_worker.py', out_path, sampler, thinning, niter, launcher=launcher,
+                 env=env)
 
     x, data, uncert = H.tutorial_data(100)
     np.random.seed(100)
