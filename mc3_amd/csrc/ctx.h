@@ -176,9 +176,13 @@ inline bool lean_demc_eligible(const mc3hip_ctx *c)
 
 // ... in the peer-to-peer mode with a second wave that carries the rows to the other ranks'
 // replicas (lean_demc_kernel COURIER; MC3HIP_NO_COURIER=1: the chain wave stores them itself)
+inline bool lean_plain_shape(const mc3hip_ctx *c);
 inline bool lean_courier(const mc3hip_ctx *c, bool p2p)
 {
-    return p2p && lean_demc_eligible(c) && !getenv("MC3HIP_NO_COURIER");
+    if (!p2p)       // (one GPU: an experiment, MC3HIP_LEAN_COURIER=1; measured slower)
+        return getenv("MC3HIP_LEAN_COURIER") && lean_demc_eligible(c) && lean_plain_shape(c) &&
+               c->P.npad <= VLANES && !(c->flags & MC3HIP_FLAG_P2P) && c->P.nlocal <= 1024;
+    return lean_demc_eligible(c) && !getenv("MC3HIP_NO_COURIER");
 }
 
 // the headline loop with the draws of 64 refreshes computed at once (lean_demc_kernel BATCH):

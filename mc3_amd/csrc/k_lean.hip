@@ -82,6 +82,8 @@ chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
             return lean_demc_kernel<MT, false, false, true>;
         if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)
             return lean_demc_kernel<MT, false, true>;
+        if (lean_courier(c, false))
+            return lean_demc_kernel<MT, false, false, false, false, true>;
         if (lean_waves(c) == 4)
             return lean_demc_wide_kernel<MT, 4>;
         if (lean_waves(c) == 2)

@@ -50,7 +50,6 @@ template <int MT, bool P2P, bool FX = false, bool MULTI = false, bool BATCH = fa
 __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const DevProblem P,
                                                                       const int nref)
 {
-    static_assert(!COURIER || P2P, "the courier serves the peer-to-peer mode");
     const int nf = FX ? P.nfree : MT;        // FX: some coefficients are fixed (nfree < MT)
     constexpr int ZS = ZROW;                 // doubles per Z row: one 128-byte line (NF <= 16)
     constexpr int LM = P2P ? 1 : 0;
@@ -61,18 +60,22 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
     const int kk = mine ? lane : 0;
     long long *ctl_rw = const_cast<long long *>(P.ctl);
     __shared__ double s_ring[COURIER ? COURIER_RING * ZROW : 1];
-    __shared__ int s_cour[4];                // 0: rows handed over, 1: rows sent, 2: done, 3: go
+    __shared__ int s_cour[4];                // 1: rows sent (every eighth), 2: done, 3: go
     (void)s_ring; (void)s_cour;
     if constexpr (COURIER) {
         // (one decision for both waves: a courier that left while its chain wave stays --
         // an abort raised between their two looks at the word -- would never drain the ring)
         if (threadIdx.x == 0) {
-            s_cour[0] = 0;
             s_cour[1] = 0;
             s_cour[2] = 0;
             s_cour[3] = __hip_atomic_load(&ctl_rw[CTL_ABORT], __ATOMIC_RELAXED,
                                           __HIP_MEMORY_SCOPE_AGENT) == 0;
         }
+        // (an empty slot of the ring holds the sentinel no row can hold, as an unwritten row
+        // of Z does: the courier polls the slot itself, one LDS read tells it that the row
+        // is there and what it is)
+        for (int i = threadIdx.x; i < COURIER_RING * ZS; i += 128)
+            s_ring[i] = mc3_from_bits(ROW_PENDING);
         __syncthreads();
         if (s_cour[3] == 0)
             return;
@@ -82,27 +85,44 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
             size_t zoff = (size_t)(P.M0 + R0c * P.nchains) * ZS + (size_t)c * ZS + lane;
             const size_t stride = (size_t)P.nchains * ZS;
             PeerTable<double> peers;
-            peers.load(P.peerZ, P.npeers);
+            if constexpr (P2P)
+                peers.load(P.peerZ, P.npeers);
+            double *const zlocal = own_global(P.Z);
+            (void)zlocal;
             __builtin_amdgcn_s_waitcnt(0x0F70);
             int sent = 0;
+            bool last = false;
             for (;;) {
-                const int done = __hip_atomic_load(&s_cour[2], __ATOMIC_ACQUIRE,
+                double *const slot = s_ring + (sent % COURIER_RING) * ZS;
+                const double v = __hip_atomic_load(slot + kk, __ATOMIC_RELAXED,
                                                    __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int head = __hip_atomic_load(&s_cour[0], __ATOMIC_ACQUIRE,
-                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (head == sent) {
-                    if (done)
+                if (__any(mine && mc3_bits(v) == ROW_PENDING)) {
+                    // nothing yet.  Once the chain wave has left, one more look: its last row
+                    // went into the ring before the word that says so
+                    if (last)
                         break;
-                    __builtin_amdgcn_s_sleep(1);
+                    last = __hip_atomic_load(&s_cour[2], __ATOMIC_ACQUIRE,
+                                             __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
                     continue;
                 }
-                for (; sent < head; ++sent, zoff += stride) {
-                    const double v = s_ring[(sent % COURIER_RING) * ZS + kk];
+                last = false;
+                if constexpr (P2P) {
                     if (mine)
                         peers.store(zoff, v, P.rank);
+                } else {
+                    // (one GPU, an experiment: the courier publishes the row)
+                    if (mine)
+                        __hip_atomic_store(zlocal + zoff, v, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
                 }
-                __hip_atomic_store(&s_cour[1], sent, __ATOMIC_RELEASE,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (mine)
+                    __hip_atomic_store(slot + lane, mc3_from_bits(ROW_PENDING), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                ++sent;
+                zoff += stride;
+                if ((sent & 7) == 0)
+                    __hip_atomic_store(&s_cour[1], sent, __ATOMIC_RELEASE,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             return;
         }
@@ -319,13 +339,13 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
         if constexpr (COURIER) {
             // ... into the local replica, and hand it to the courier for the others
             if (mine) {
-                __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_SYSTEM);
-                s_ring[(handed % COURIER_RING) * ZS + lane] = xk;
+                if constexpr (P2P)
+                    __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&s_ring[(handed % COURIER_RING) * ZS + lane], xk,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             ++handed;
-            __hip_atomic_store(&s_cour[0], handed, __ATOMIC_RELEASE,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
             // (never a whole ring ahead: looked at once in 16 rows)
             if (__builtin_expect((handed & 15) == 0, 0)) {
                 while (handed - __hip_atomic_load(&s_cour[1], __ATOMIC_ACQUIRE,

@@ -169,9 +169,11 @@ class Communicator:
         if dev is None:
             return
         # (the peer-to-peer instance of the headline loop has a second wave per chain, the
-        # courier: the workgroups of more than four ranks of 256 chains are not co-resident
-        # on ONE device with it -- such a test set-up runs without, MC3HIP_NO_COURIER)
-        if max(sum(1 for e, _ in devices if e == d) for d, _ in devices) > 4:
+        # courier: the two-wave workgroups of four ranks of 256 chains would fill ONE device
+        # to the last wave slot and are not all co-resident in practice -- a launch gives up
+        # and the run falls back to the host-staged exchange; such a test set-up runs without
+        # the courier, MC3HIP_NO_COURIER)
+        if max(sum(1 for e, _ in devices if e == d) for d, _ in devices) > 2:
             os.environ.setdefault('MC3HIP_NO_COURIER', '1')
         shared = sum(1 for d, _ in devices if d == dev) > 1
         anybody = any(s and r for (d, r), s in

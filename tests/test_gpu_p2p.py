@@ -26,7 +26,8 @@ def test_processes_peer_to_peer(tmp_path, nproc, sampler, thinning, niter, launc
 def test_peer_to_peer_without_the_courier(tmp_path):
     """The headline loop's peer-to-peer instance with the chain wave storing into the other
     ranks' replicas itself (MC3HIP_NO_COURIER=1; by default a second wave of the workgroup
-    carries the rows, lean_demc_kernel COURIER -- the 2- and 4-rank demc cases above)."""
+    carries the rows, lean_demc_kernel COURIER -- the 2-rank demc cases above and the abort
+    case below; more than two ranks on ONE device run without it, mc3_amd/parallel.py)."""
     p2p_case(tmp_path, 2, 'demc', 1, 400, 'socket', env={'MC3HIP_NO_COURIER': '1'})
 
 
