@@ -572,13 +572,18 @@ def run_rank(args):
     else:
         out['roofline']['latency_model'] = {
             'us_per_iteration': launch_s*1e6*launches/nref_timed/args.thinning,
-            'floor_us': 0.8 + 0.42,
+            'floor_us': 0.53 + 0.42,
             'floor': 'every iteration of every chain needs two rows other chains (other '
                      'CUs, other XCDs) produced in the iteration before: one cross-CU '
-                     'hand-off (MI355X_MICROARCH.md "handoff-1to1" 0.8 us) + the dependent '
-                     'FP64 chain of one wave alone on its SIMD, proposal -> chisq of 1000 '
-                     'points (16 per lane) -> 6 cross-lane adds -> exp -> accept, '
-                     '~1000 cycles = 0.42 us at 2.4 GHz (tools/ticks.py)',
+                     'hand-off (0.53 us per hop between two single-wave workgroups on this '
+                     'chip, tools/probes/xgmi_handoff.hip run on one device, '
+                     'profiles/r03_handoff_probe_one_gpu.json; MI355X_MICROARCH.md '
+                     '"handoff-1to1": 0.8 us) + the dependent FP64 chain of one wave alone '
+                     'on its SIMD, proposal -> chisq of 1000 points (16 per lane) -> 6 '
+                     'cross-lane adds -> accept, ~1000 cycles = 0.42 us at 2.4 GHz '
+                     '(tools/ticks.py).  The rest of an iteration is the second partner '
+                     'row (0.27 extra polls per iteration on average: the later of two '
+                     'partners decides) and the publish',
             'note': 'one wave per CU on 256 CUs = 1/4 of the SIMDs, ~2 % of the FP64 vector '
                     'peak: the workload (256 chains, 1000 points) cannot fill the chip; '
                     'it is latency-bound, neither bandwidth- nor FLOP-bound'}
