@@ -50,6 +50,21 @@ class Lowered:
         self.offset = offset
 
 
+# Polynomials of five or more coefficients over many points are handed to the device as a
+# design matrix of the powers of x: as such they run on the one-launch tiled plan (matrix
+# cores, 2..15 columns); as polynomials they would take the three-launch tiled plan -- the
+# degree-specialised one-launch kernels stop at four coefficients.  (The powers are formed
+# here with x**k; the reference's model is the user's callable, whose rounding is its own.)
+POLY_AS_LINEAR_NDATA = 8192
+
+
+def _polynomial(ncoef, x, ndata, wlike, offset=None):
+    x = np.asarray(x, float)
+    if not wlike and 5 <= ncoef <= 15 and ndata >= POLY_AS_LINEAR_NDATA and x.shape == (ndata,):
+        return Lowered('linear', ncoef, np.array([x**k for k in range(ncoef)]), offset)
+    return Lowered('poly', ncoef, x, offset)
+
+
 def lower(func, params, indparams, indparams_dict, ndata, wlike, pstep,
           rtol=1e-9):
     """Map ``func`` onto the device family or raise ValueError."""
@@ -60,7 +75,7 @@ def lower(func, params, indparams, indparams_dict, ndata, wlike, pstep,
         if func.ncoef != nmodel:
             raise ValueError(f'Polynomial({func.ncoef}) needs {func.ncoef} model '
                              f'parameters, got {nmodel}')
-        return Lowered('poly', nmodel, indparams[0])
+        return _polynomial(nmodel, indparams[0], ndata, wlike)
     if family == 'linear':
         A = np.asarray(indparams[0], float)
         if A.shape != (nmodel, ndata):
@@ -103,5 +118,5 @@ def lower(func, params, indparams, indparams_dict, ndata, wlike, pstep,
         x = np.asarray(indparams[0], float)
         powers = np.array([x**k for k in range(nmodel)])
         if np.allclose(cols, powers, rtol=1e-13, atol=0.0):
-            return Lowered('poly', nmodel, x, offset)
+            return _polynomial(nmodel, x, ndata, wlike, offset)
     return Lowered('linear', nmodel, cols, offset)

@@ -146,6 +146,21 @@ def test_model_recognition():
     with pytest.raises(ValueError, match='not linear in its parameters'):
         models.lower(lambda p, x: p[0]*np.exp(p[1]*x), params[:2], [x], {}, 100,
                      False, pstep[:2])
+    # five or more coefficients over many points: the powers of x as a design matrix (the
+    # one-launch tiled plan of the matrix cores); few points, few coefficients or the wavelet
+    # likelihood: a polynomial as ever
+    xb = np.linspace(-1.0, 1.0, 9000)
+    p6 = np.arange(1.0, 7.0)
+    for func in (models.Polynomial(6), lambda p, x: np.polyval(p[::-1], x)):
+        low = models.lower(func, p6, [xb], {}, 9000, False, np.ones(6))
+        assert (low.family, low.ncoef) == ('linear', 6) and low.indep.shape == (6, 9000)
+        np.testing.assert_array_equal(low.indep, np.array([xb**k for k in range(6)]))
+    assert models.lower(models.Polynomial(6), p6, [xb[:100]], {}, 100, False,
+                        np.ones(6)).family == 'poly'
+    assert models.lower(models.Polynomial(4), p6[:4], [xb], {}, 9000, False,
+                        np.ones(4)).family == 'poly'
+    assert models.lower(models.Polynomial(6), np.arange(1.0, 10.0), [xb[:8192]], {}, 8192, True,
+                        np.ones(9)).family == 'poly'
     out = run(func=models.Polynomial(3))
     ref = run()
     np.testing.assert_array_equal(out['posterior'], ref['posterior'])

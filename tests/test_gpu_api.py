@@ -111,6 +111,38 @@ def test_sample_tiled_problem_equals_cpu_checker(sampler):
     assert_same_dict(gpu, cpu)
 
 
+def test_sample_polynomial_of_six_coefficients_over_many_points():
+    """A polynomial of five or more coefficients over many points reaches the device as the
+    design matrix of the powers of x (mc3_amd.models.lower) and takes the one-launch tiled
+    plan of the matrix cores; the output dictionary equals the checker's run of the same
+    call."""
+    import mc3_amd
+    rs = np.random.RandomState(7)
+    ndata = 20000
+    x = np.linspace(-1.0, 1.0, ndata)
+    truth = np.array([1.0, -0.5, 2.0, 0.3, -1.0, 0.7])
+    uncert = np.full(ndata, 0.5)
+    data = np.polyval(truth[::-1], x) + rs.normal(0.0, 0.5, ndata)
+    seen = {}
+    real = mc3_amd.engine.DeviceChains
+
+    def spy(**kw):
+        g = real(**kw)
+        seen.update(model=kw['model'], plan=g.plan)
+        return g
+    kw = dict(data=data, uncert=uncert, func=mc3_amd.models.Polynomial(6),
+              params=truth + 0.01, indparams=[x], pstep=np.full(6, 0.01),
+              pmin=np.full(6, -10.0), pmax=np.full(6, 10.0), sampler='snooker',
+              nsamples=32*50, burnin=10, nchains=32)
+    gpu, cpu = both(checker_plan={'tile': 2048, 'vlanes': 1024, 'tile_tree': 2}, **kw)
+    assert_same_dict(gpu, cpu)
+    from mc3_amd import utils as mu
+    np.random.seed(3)
+    again = mc3_amd.sample(log=mu.Log(verb=0), seed=21, engine_factory=spy, **kw)
+    assert seen['model'] == 'linear' and seen['plan']['resident'] == 1, seen
+    np.testing.assert_array_equal(again['posterior'], gpu['posterior'])
+
+
 @pytest.mark.parametrize('sampler,builder', [('snooker', H.quad_problem),
                                              ('demc', H.quad_problem),
                                              ('demc', H.linear_problem)])

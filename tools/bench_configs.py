@@ -74,6 +74,23 @@ CONFIGS = {
     # the tiled plan of polynomial models (vector tile kernel, three launches per iteration)
     'q5': lambda n: (H.quad_problem(ndata=100000, nchains=512, nsamples=512*n), {}),
 }
+
+
+def _poly6(n, as_matrix):
+    """A polynomial of six coefficients x 1e5 points x 512 chains, as the device's polynomial
+    family (three-launch tiled plan) or as the design matrix of the powers of x that
+    mc3_amd.models.lower() hands over (one-launch plan of the matrix cores)."""
+    prob = H.linear_problem(ndata=100000, nmodel=6, nchains=512, nsamples=512*n)
+    x = np.linspace(-1.0, 1.0, 100000)
+    if as_matrix:
+        prob.update(indep=np.array([x**k for k in range(6)]))
+    else:
+        prob.update(indep=x, model='poly')
+    return prob, {}
+
+
+CONFIGS['p6'] = lambda n: _poly6(n, False)
+CONFIGS['p6matrix'] = lambda n: _poly6(n, True)
 BYTES = {'c2mrw': 24104, 'q5': 8*3*100000 + 8*3*4 + 8, 'c4mrw': 8*2*16384 + 8*5*4 + 8, 'c4demc': 8*2*16384 + 8*5*4 + 8, 'c4half': 8*2*16384 + 8*5*4 + 8, 'c2': 24104, 'c2snooker': 24104, 'c3one': 24104, 'c4': 8*2*16384 + 8*5*4 + 8,
          'c5': 8*12*100000 + 8*10*4 + 8, 'c5share': 8*12*100000 + 8*10*4 + 8}
 ITERS = {'c2': 20000, 'c2snooker': 20000, 'c2mrw': 20000, 'c3one': 4000, 'c4': 4000, 'c5': 30, 'c5share': 1}
@@ -81,7 +98,8 @@ ITERS['c5'] = 300
 ITERS['q5'] = 300
 ITERS.update(c4big=1000, c4wide=4000, c4mrw=4000, c4demc=4000, c4half=4000, c3x2=3000, c3x4=2000, c3x2snooker=3000,
              c4x2=2000, c4x4=1000)
-ITERS.update(c3x2mrw=3000, c3onesnooker=4000)
+ITERS.update(c3x2mrw=3000, c3onesnooker=4000, p6=200, p6matrix=200)
+BYTES['p6'] = BYTES['p6matrix'] = 8*3*100000 + 8*6*4 + 8
 for _k in ('c3x2', 'c3x4', 'c3x2snooker', 'c3x2mrw', 'c3onesnooker'):
     BYTES[_k] = 24104
 BYTES['c4big'] = 8*2*65536 + 8*5*4 + 8
