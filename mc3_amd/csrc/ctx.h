@@ -206,7 +206,10 @@ inline bool lean_plain_shape(const mc3hip_ctx *c)
 inline bool lean_other_sampler_eligible(const mc3hip_ctx *c, int sampler)
 {
     const DevProblem &P = c->P;
-    return c->fast && c->mc_chains == 0 && P.sampler == sampler && P.thinning == 1 &&
+    // (thinning > 1: the THIN instances, plain shapes only)
+    const bool plain = P.nfree == P.nparams && P.ngprior == 0 && P.nshare == 0;
+    return c->fast && c->mc_chains == 0 && P.sampler == sampler &&
+           (P.thinning == 1 || plain) &&
            P.nparams == c->mt && P.zs == ZROW && P.npad <= VLANES &&
            !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_LEAN");
 }

@@ -33,7 +33,13 @@ __device__ __forceinline__ double load_published(const double *p)
 // waits until all but the N youngest are done"), so the caller retires these loads with
 // published_arrived<N>: N = operations it is SURE to have issued after them (at least).  The
 // loaded-into variables must not be touched between the two (a copy would read a register the
-// load has not written yet).
+// load has not written yet) -- and the compiler must have no reason to copy them either: ONE
+// place that loads into a set of variables and ONE that waits for it, in straight-line code or
+// with the loop's back edge behind the wait.  Two load sites on two paths that join, or two
+// waits on two paths, make the variables meet other values at the join, where the compiler
+// puts one of them into the other's register with a copy -- on an iteration short enough (a
+// proposal out of bounds) the copy runs before the load has returned.  Found by a test
+// (test_lean_snooker_and_mrw_loops_with_thinning[tight]); tools/waits.py shows the sites.
 __device__ __forceinline__ double load_published_async(const double *p)
 {
     double v;

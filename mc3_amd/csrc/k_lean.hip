@@ -43,8 +43,11 @@ chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
 #define MC3_LEAN_SOLO_MC(KERNEL, TT)                                                \
         if (c->mc_chains == TT)                                                     \
             return lean_plain_shape(c) ? KERNEL<MT, TT> : KERNEL<MT, TT, true>;
-    if (lean_mrw_eligible(c) && !p2p)
+    if (lean_mrw_eligible(c) && !p2p) {
+        if (c->P.thinning > 1)
+            return lean_mrw_kernel<MT, false, true>;
         return lean_plain_shape(c) ? lean_mrw_kernel<MT> : lean_mrw_kernel<MT, true>;
+    }
     if (lean_mrw_mc_eligible(c) && !p2p) {
         MC3_LEAN_SOLO_MC(lean_mrw_mc_kernel, 2)
         MC3_LEAN_SOLO_MC(lean_mrw_mc_kernel, 3)
@@ -52,8 +55,11 @@ chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
     }
     if (c->P.sampler == MC3HIP_MRW)
         return fast_instance_tt<MT, MC3HIP_MRW>(c, p2p);
-    if (lean_snooker_eligible(c) && !p2p)
+    if (lean_snooker_eligible(c) && !p2p) {
+        if (c->P.thinning > 1)
+            return lean_snooker_kernel<MT, false, true>;
         return lean_plain_shape(c) ? lean_snooker_kernel<MT> : lean_snooker_kernel<MT, true>;
+    }
     if (lean_snooker_mc_eligible(c) && !p2p) {
         MC3_LEAN_SOLO_MC(lean_snooker_mc_kernel, 2)
         MC3_LEAN_SOLO_MC(lean_snooker_mc_kernel, 3)

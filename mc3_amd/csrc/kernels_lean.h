@@ -419,7 +419,9 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
 //     (chain.py:207-215, :251-255) takes the exponential and the Hastings factor as ever.
 // Same draws, same arithmetic, same results as run_chain's.
 // (FX: some coefficients are fixed or shared, or carry Gaussian priors -- as lean_demc_kernel's)
-template <int MT, bool FX = false>
+// (THIN: thinning > 1 -- the iterations between two refreshes draw from the same history and
+// publish nothing; the draws are keyed by the iteration, R thinning + j, as run_chain's)
+template <int MT, bool FX = false, bool THIN = false>
 __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, const int nref)
 {
     const int nf = FX ? P.nfree : MT;
@@ -462,12 +464,15 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
     // of rows iR1, iR2; 1 -> the offset of row iz, the jump flag; 2 -> gamma_s, u (as bits)
     unsigned long long A = 0, B = 0;
     double blo = 0.0, bhi = 0.0;
-    long long bbase = R0;
+    const int th = THIN ? P.thinning : 1;
+    long long bbase = R0 * th;                 // (the batch counts iterations)
     const int bs = lane % 3, bi = (lane / 3 < NB) ? lane / 3 : NB - 1;
     auto fill = [&](long long base) {
         const long long Rl = base + bi;
         const Draw2 d = draw2(P.seed, (uint64_t)Rl, (uint32_t)c, (uint32_t)bs);
-        const unsigned long long zsz = (unsigned long long)(P.M0 + Rl * n);
+        // (the history an iteration draws from: the rows before its refresh)
+        const unsigned long long zsz =
+            (unsigned long long)(P.M0 + (THIN ? Rl / th : Rl) * n);
         if (bs == 0) {
             const unsigned long long iR1 = bounded(d.q0, zsz);
             unsigned long long iR2 = 1 + bounded(d.q1, zsz - 1);
@@ -518,9 +523,9 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
         S.lo = read_lane(blo, idx + 2);
         S.hi = read_lane(bhi, idx + 2);
     };
-    fill(R0);
+    fill(R0 * th);
     Step S;
-    prepare(R0, S, true);
+    prepare(R0 * th, S, true);
     // (retired here: a load the compiler knows of, still pending at the loop head, would make
     // it guard these registers with a wait INSIDE the loop -- for everything in flight)
     published_arrived<0>(S.val[0], S.val[1], S.val[2]);
@@ -546,11 +551,13 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
         // compiler's wait counts do not see (handoff.h load_published_async): they have the
         // whole iteration to arrive and are retired behind the publish, which they precede
         // in the wave's queue.
+        for (int j = 0; j < th; ++j) {
+        const long long it = R * th + j;
         Step C = S;
-        if (__builtin_expect(R + 1 - bbase == NB, 0))
-            fill(R + 1);
+        if (__builtin_expect(it + 1 - bbase == NB, 0))
+            fill(it + 1);
         Step Nx;
-        prepare(R + 1, Nx, true);
+        prepare(it + 1, Nx, true);
         // (one of the newest rows may still be the sentinel)
         if (__builtin_expect(__any(mc3_bits(C.val[0]) == ROW_PENDING ||
                                    mc3_bits(C.val[1]) == ROW_PENDING ||
@@ -567,7 +574,7 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
             C.val[1] = v3[1];
             C.val[2] = v3[2];
             if (__builtin_expect(!alive, 0))
-                break;
+                goto out;
         }
         const double z1 = C.val[0], z2 = C.val[1], zk = C.val[2];
         const bool sjump = C.sj;
@@ -619,21 +626,31 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
                 if (mine)
                     P.bestx[(size_t)lc * nf + lane] = xk;
                 if (lane == 0)
-                    P.best_iter[lc] = R;
+                    P.best_iter[lc] = it;
             }
             cur = acc ? nextchisq : cur;
             nacc += acc ? 1 : 0;
         } else if (outk) {
             atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
         }
-        // Z append, chain.py:276-289
-        if (mine)
-            __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);            // publish (sc1)
-        // the next refresh's rows: everything but the youngest operation of this wave -- the
+        // Z append, chain.py:276-289 (THIN: behind the last iteration of the refresh; the
+        // others leave the state where the kernel leaves it in the end, so that ONE store
+        // follows the loads of the next iteration's rows either way and ONE wait serves both:
+        // two waits on two paths for the same registers would have the compiler copy them
+        // into place ahead of one of the waits -- a copy of what the loads have not written)
+        if (mine) {
+            if (!THIN || j + 1 == th)
+                __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);        // publish (sc1)
+            else
+                __hip_atomic_store(&P.X[(size_t)lc * nf + lane], xk, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // the next iteration's rows: everything but the youngest operation of this wave -- the
         // store above at least -- has completed
         published_arrived<1>(Nx.val[0], Nx.val[1], Nx.val[2]);
         S = Nx;
+        }
         const int slot = (int)(R - R0) & 63;
         lpbuf = (lane == slot) ? -0.5 * cur : lpbuf;
         if (__builtin_expect(slot == 63, 0)) {
@@ -644,6 +661,7 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
         zblock += blockstride;
         rdone = R + 1;
     }
+out:
     flush_columns((int)(rdone - R0) & 63);
     if (mine)
         P.X[(size_t)lc * nf + lane] = xk;
@@ -663,7 +681,9 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
 // Metropolis draw and the window of its logarithm; lanes 3 i + 1, 3 i + 2: the deviates of
 // parameters 0, 1 and 2, 3 -- and an iteration gathers its own (v_readlane, ds_bpermute).
 // Same draws, same arithmetic, same results as run_chain's.
-template <int MT, bool FX = false>
+// (THIN: thinning > 1 -- the iterations between two refreshes publish nothing; the draws are
+// keyed by the iteration, R thinning + j, as run_chain's)
+template <int MT, bool FX = false, bool THIN = false>
 __global__ __launch_bounds__(64) void lean_mrw_kernel(const DevProblem P, const int nref)
 {
     static_assert(MT >= 1 && MT <= 4, "two slots of normal deviates");
@@ -705,7 +725,8 @@ __global__ __launch_bounds__(64) void lean_mrw_kernel(const DevProblem P, const 
     // lane 3 i + s of the batch: s = 0 -> u (bu) and its window; s = 1, 2 -> rad cos, rad sin of
     // Philox slot 3 + (s - 1), i.e. the deviates of parameters 2 (s - 1) and 2 (s - 1) + 1
     double bu = 0.0, blo = 0.0, bhi = 0.0, bcs = 0.0, bsn = 0.0;
-    long long bbase = R0;
+    const int th = THIN ? P.thinning : 1;
+    long long bbase = R0 * th;                 // (the batch counts iterations)
     const int bs = lane % 3, bi = (lane / 3 < NB) ? lane / 3 : NB - 1;
     auto fill = [&](long long base) {
         const Draw2 d = draw2(P.seed, (uint64_t)(base + bi), (uint32_t)c,
@@ -719,7 +740,7 @@ __global__ __launch_bounds__(64) void lean_mrw_kernel(const DevProblem P, const 
         bsn = rad * sn;
         bbase = base;
     };
-    fill(R0);
+    fill(R0 * th);
     // lane k's deviate of a refresh sits in lane 3 i + 1 + (k >> 1): cosine branch for even k
     const int src_off = 1 + (lane >> 1);
     const long long Rend = R0 + nref;
@@ -740,9 +761,11 @@ __global__ __launch_bounds__(64) void lean_mrw_kernel(const DevProblem P, const 
                                __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
-        if (__builtin_expect(R - bbase == NB, 0))
-            fill(R);
-        const int idx = 3 * (int)(R - bbase);
+        for (int j = 0; j < th; ++j) {
+        const long long it = R * th + j;
+        if (__builtin_expect(it - bbase == NB, 0))
+            fill(it);
+        const int idx = 3 * (int)(it - bbase);
         const double u_now = read_lane(bu, idx), lo_now = read_lane(blo, idx),
                      hi_now = read_lane(bhi, idx);
         const int src = mine ? idx + src_off : idx;
@@ -771,12 +794,13 @@ __global__ __launch_bounds__(64) void lean_mrw_kernel(const DevProblem P, const 
                 if (mine)
                     P.bestx[(size_t)lc * nf + lane] = xk;
                 if (lane == 0)
-                    P.best_iter[lc] = R;
+                    P.best_iter[lc] = it;
             }
             cur = acc ? nextchisq : cur;
             nacc += acc ? 1 : 0;
         } else if (outk) {
             atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
+        }
         }
         // Z append, chain.py:276-289
         if (mine)
@@ -900,16 +924,21 @@ __global__ __launch_bounds__(64) void lean_snooker_mc_kernel(const DevProblem P,
         const double *addr[3];
         double val[3];
     };
-    // (R inside the current batch; the rows: asked for, not waited for)
+    // (R inside the current batch.  The rows are asked for by ask(), at ONE place per turn,
+    // and waited for at one: registers that loads the compiler does not see are on their way
+    // to must not meet other values at a join of two paths -- the compiler would copy one of
+    // them into place there, i.e. copy what the load has not written yet)
+    auto ask = [&](Step &S) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            S.val[j] = load_published_async(S.addr[j]);
+    };
     auto prepare = [&](long long R, unsigned long long Aq, unsigned long long Bq, double bloq,
                        double bhiq, Step &S) {
         const int idx = 3 * (int)(R - bbase);
         S.addr[0] = P.Z + (lane64(Aq, idx) + (unsigned)kk);
         S.addr[1] = P.Z + (lane64(Bq, idx) + (unsigned)kk);
         S.addr[2] = P.Z + (lane64(Aq, idx + 1) + (unsigned)kk);
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            S.val[j] = load_published_async(S.addr[j]);
         S.sj = lane64(Bq, idx + 1) != 0;
         S.gs = mc3_from_bits(lane64(Aq, idx + 2));
         S.u = mc3_from_bits(lane64(Bq, idx + 2));
@@ -919,6 +948,7 @@ __global__ __launch_bounds__(64) void lean_snooker_mc_kernel(const DevProblem P,
     fill(R0);
     Step S;
     prepare(R0, A[0], B[0], blo[0], bhi[0], S);
+    ask(S);
     published_arrived<0>(S.val[0], S.val[1], S.val[2]);
     // (... and so is everything else loaded so far: a load the compiler knows of, still pending
     // at the loop head, would make it guard its registers with a wait INSIDE the loop -- for
@@ -962,6 +992,7 @@ __global__ __launch_bounds__(64) void lean_snooker_mc_kernel(const DevProblem P,
                     fill(R + 1);
                 prepare(R + 1, A[0], B[0], blo[0], bhi[0], Nx);
             }
+            ask(Nx);
             // (one of the newest rows may still be the sentinel)
             if (__builtin_expect(__any(mc3_bits(C.val[0]) == ROW_PENDING ||
                                        mc3_bits(C.val[1]) == ROW_PENDING ||

@@ -983,6 +983,49 @@ def test_lean_mrw_loop(eng, monkeypatch, case):
     gpu.close()
 
 
+@pytest.mark.parametrize('sampler', ['snooker', 'mrw'])
+@pytest.mark.parametrize('thinning', [2, 3, 7, 25])
+@pytest.mark.parametrize('case', ['plain', 'resume', 'abort', 'tight', 'tiny-history'])
+def test_lean_snooker_and_mrw_loops_with_thinning(eng, monkeypatch, case, thinning, sampler):
+    """The THIN instances of lean_snooker_kernel / lean_mrw_kernel: `thinning` iterations per
+    refresh, the draws keyed by the iteration, only the last one of a refresh published; a
+    batch of draws (21 iterations) ends anywhere inside a refresh."""
+    nchains = 5 if case == 'tiny-history' else 12
+    prob = H.quad_problem(ndata=300, nchains=nchains, nsamples=nchains*90*thinning,
+                          sampler=sampler, thinning=thinning)
+    if sampler == 'mrw':
+        prob['pstep'] = np.array([0.05, 0.02, 0.003])
+    if case == 'tight':
+        prob.update(params=np.array([4.0, -2.5, 0.5]), pmin=np.array([3.5, -2.8, 0.45]),
+                    pmax=np.array([6.5, -2.2, 0.56]))
+    if case == 'tiny-history':
+        prob.update(hsize=1)
+    if case == 'abort':
+        monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '21')
+        orc, gpu = run_pair(eng, prob, trace=False)
+        assert gpu.plan['recoveries'] == 1
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
+        return
+    if case == 'resume':
+        gpu = eng.DeviceChains(**prob)
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nthreads=4)
+        for n in (1, 2, 20, 21, 22, 24):
+            gpu.run(n)
+    else:
+        orc, gpu = run_pair(eng, prob, trace=False)
+    plan = gpu.plan
+    assert plan['persistent'] > 0 and plan['recoveries'] == 0 and plan['fast'] == 2, plan
+    assert_same(orc, gpu, trace=False)
+    if case == 'tight':
+        assert gpu.state()['outbounds'].sum() > 50
+    gpu.close()
+
+
 @pytest.mark.parametrize('case', ['quad', 'line', 'cubic', 'tight', 'ragged', 'resume', 'abort',
                                   'tiny-history', 'switch', 'fixed', 'priors'])
 def test_lean_snooker_loop(eng, monkeypatch, case):
