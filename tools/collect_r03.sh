@@ -24,7 +24,7 @@ if has pmc; then
 fi
 # the other configurations on one GPU (each in a fresh process)
 if has configs; then
-    timeout 1200 python tools/bench_configs.py c2 c2snooker c2mrw c3one c3onesnooker c3x2 c3x4 c3x2snooker c3x2mrw c4 c4wide c4demc c4mrw c4x2 c4x4 c5 q5 \
+    timeout 1200 python tools/bench_configs.py c2 c2snooker c2mrw c2thin10demc c2thin10snooker c2thin10mrw c3one c3onesnooker c3x2 c3x4 c3x2snooker c3x2mrw c4 c4wide c4demc c4mrw c4x2 c4x4 c5 q5 p6 p6matrix \
         > $out/configs.jsonl 2> $out/configs.err
     MC3HIP_NO_RESIDENT=1 timeout 600 python tools/bench_configs.py c5 q5 > $out/configs_three_launch.jsonl 2> $out/configs3.err
     MC3HIP_NO_CHAINWAVE=1 timeout 600 python tools/bench_configs.py c4 c4wide > $out/configs_no_chainwave.jsonl 2>> $out/configs3.err
