@@ -222,6 +222,16 @@ inline bool lean_mrw_eligible(const mc3hip_ctx *c)
     return lean_other_sampler_eligible(c, MC3HIP_MRW) && c->mt <= 4;
 }
 
+// DEMC with thinning > 1 on the plain headline shape: lean_demc_thin_kernel
+inline bool lean_demc_thin_eligible(const mc3hip_ctx *c)
+{
+    const DevProblem &P = c->P;
+    const bool plain = P.nfree == P.nparams && P.ngprior == 0 && P.nshare == 0;
+    return c->fast && c->mc_chains == 0 && P.sampler == MC3HIP_DEMC && P.thinning > 1 && plain &&
+           P.nparams == c->mt && P.zs == ZROW && P.npad <= VLANES &&
+           !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_LEAN");
+}
+
 // ... and with two to four chains per wave: lean_snooker_mc_kernel, lean_mrw_mc_kernel
 inline bool lean_other_sampler_mc_eligible(const mc3hip_ctx *c, int sampler)
 {

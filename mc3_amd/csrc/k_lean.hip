@@ -66,6 +66,8 @@ chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
         MC3_LEAN_SOLO_MC(lean_snooker_mc_kernel, 4)
     }
 #undef MC3_LEAN_SOLO_MC
+    if (lean_demc_thin_eligible(c) && !p2p)
+        return lean_demc_thin_kernel<MT>;
     if (lean_demc_mc_eligible(c) && !p2p) {          // 2..4 chains per wave
 #define MC3_LEAN_MC(TT)                                                             \
         if (c->mc_chains == TT) {                                                   \

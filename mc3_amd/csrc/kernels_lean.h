@@ -827,6 +827,188 @@ __global__ __launch_bounds__(64) void lean_mrw_kernel(const DevProblem P, const 
 }
 
 // ---------------------------------------------------------------------------------
+// DEMC with thinning > 1 for the headline shape (plain: every coefficient free, one tile, one
+// chain per wave, one GPU).  The `thinning` iterations of a refresh draw their partners anew
+// but look at the same rows -- those of the refresh before (run_chain) -- so only the first
+// one waits for a hand-off; the lean run_chain instance took 0.88 us per iteration at thinning
+// 10, most of it the draws.  Laid out as lean_snooker_kernel: the draws of 64 iterations at
+// once, one per lane (Philox, log u and its window, the partners' row offsets); the two rows
+// of the NEXT iteration asked for first thing by loads the compiler does not see and retired
+// behind this iteration's store (handoff.h load_published_async: one load site, one wait
+// site); a row that is still the sentinel -- the first iteration of a refresh asks for rows
+// its partners are about to publish -- is asked for again the usual way.  Same draws, same
+// arithmetic, same results as run_chain's.
+template <int MT>
+__global__ __launch_bounds__(64) void lean_demc_thin_kernel(const DevProblem P, const int nref)
+{
+    constexpr int ZS = ZROW;
+    constexpr int NB = 64;                     // iterations per batch of draws (one per lane)
+    const int lane = threadIdx.x;
+    const int lc = blockIdx.x;
+    const int c = P.chain0 + lc;
+    const bool mine = lane < MT;
+    const int kk = mine ? lane : 0;
+    long long *ctl_rw = const_cast<long long *>(P.ctl);
+    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
+            &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+        return;
+    DataTile<1, MT> tile;
+    tile.load(P);
+    const long long R0 = P.ctl[0];
+    const int n = P.nchains;
+    const int th = P.thinning;
+    const size_t blockstride = (size_t)n * ZS;
+    // rows of refresh R0 - 1 (the current states) and of refresh R0 (to be published)
+    const double *pbase = (R0 == 0) ? P.snap0 : P.Z + (size_t)(P.M0 + (R0 - 1) * n) * ZS;
+    double *zblock = P.Z + (size_t)(P.M0 + R0 * n) * ZS;
+    double *lp_row = P.log_post + (P.M0 + R0 * n + c);
+    int32_t *zc_row = P.zchain + (P.M0 + R0 * n + c);
+    double xk = mine ? pbase[(size_t)c * ZS + lane] : 0.0;
+    double cur = P.chisq[lc];
+    double best = P.best_chisq[lc];
+    const long long nacc0 = P.numaccept[lc];
+    const double pmin_k = mine ? P.fmin[lane] : 0.0;
+    const double pmax_k = mine ? P.fmax[lane] : 0.0;
+    const double gamma = P.gamma, feps = P.fepsilon;
+    const long long abort_at = (P.test_abort >= 0 && lc == 0) ? (long long)P.test_abort : -1;
+    long long nacc = 0;
+    double lpbuf = 0.0;
+    // lane i: the draws of iteration bbase + i (chain.py:221-232, :259)
+    double bu = 0.0, blo = 0.0, bhi = 0.0;
+    int bo1 = 0, bo2 = 0;
+    long long bbase = R0 * th;
+    auto fill = [&](long long base) {
+        const Draw2 dd = draw2(P.seed, (uint64_t)(base + lane), (uint32_t)c, 0u);
+        bu = u01(dd.q1);
+        accept_window(bu, blo, bhi);
+        int q1, q2;
+        demc_partners(dd.q0, n, c, q1, q2);
+        bo1 = q1 * ZS;
+        bo2 = q2 * ZS;
+        bbase = base;
+    };
+    struct Step {
+        double u, lo, hi;
+        const double *addr[2];
+        double val[2];
+    };
+    // (`it` inside the current batch; `snap`: the rows its refresh looks at)
+    auto prepare = [&](long long it, const double *snap, Step &S) {
+        const int idx = (int)(it - bbase);
+        S.addr[0] = snap + (__builtin_amdgcn_readlane(bo1, idx) + kk);
+        S.addr[1] = snap + (__builtin_amdgcn_readlane(bo2, idx) + kk);
+        S.val[0] = load_published_async(S.addr[0]);
+        S.val[1] = load_published_async(S.addr[1]);
+        S.u = read_lane(bu, idx);
+        S.lo = read_lane(blo, idx);
+        S.hi = read_lane(bhi, idx);
+    };
+    fill(R0 * th);
+    Step S;
+    double spare = 0.0;                        // (published_arrived takes three)
+    prepare(R0 * th, pbase, S);
+    published_arrived<0>(S.val[0], S.val[1], spare);
+    // (... and so is everything else loaded so far: a load the compiler knows of, still pending
+    // at the loop head, would make it guard its registers with a wait INSIDE the loop)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    const long long Rend = R0 + nref;
+    long long rdone = R0;
+    auto flush_columns = [&](int count) {
+        if (lane < count) {
+            lp_row[(size_t)lane * n] = lpbuf;
+            zc_row[(size_t)lane * n] = c;
+        }
+    };
+    bool alive = true;
+    for (long long R = R0; R < Rend; ++R) {
+        if (__builtin_expect(R == abort_at, 0)) {                                         // test hook
+            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        for (int j = 0; j < th; ++j) {
+            const long long it = R * th + j;
+            Step C = S;
+            if (__builtin_expect(it + 1 - bbase == NB, 0))
+                fill(it + 1);
+            // the next iteration's rows: of the same refresh before, or -- behind the last
+            // iteration of this refresh -- the rows this refresh is about to publish
+            Step Nx;
+            prepare(it + 1, (j + 1 < th) ? pbase : (const double *)zblock, Nx);
+            if (__builtin_expect(__any(mc3_bits(C.val[0]) == ROW_PENDING ||
+                                       mc3_bits(C.val[1]) == ROW_PENDING), 0)) {
+                const double *const a2[2] = {C.addr[0], C.addr[1]};
+                double v2[2] = {C.val[0], C.val[1]};
+                alive = wait_rows<2, false>(a2, v2, ctl_rw);
+                // (nothing this path asked for is pending where it joins the other)
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                asm volatile("; rows of this iteration" : "+v"(v2[0]), "+v"(v2[1]));
+                C.val[0] = v2[0];
+                C.val[1] = v2[1];
+                if (__builtin_expect(!alive, 0))
+                    goto out;
+            }
+            // proposal and boundaries, chain.py:232-243
+            const double jump_k = gamma * (C.val[0] - C.val[1]) + feps * 0.0;
+            const double npk = xk + jump_k;
+            const bool outk = mine && (npk < pmin_k || npk > pmax_k);
+            if (__builtin_expect(!__any(outk), 1)) {
+                Model<MT> model;
+                model.init_from_lanes(P, npk);
+                const double nextchisq =
+                    block_gauss_model<1, MT, false, false>(P, model, nullptr, nullptr, tile,
+                                                           &tile);           // chain.py:249
+                const bool acc = metropolis_accept(0.5 * (cur - nextchisq), C.u, C.lo, C.hi);
+                xk = acc ? npk : xk;
+                if (__builtin_expect(__any(acc && nextchisq < best), 0)) {
+                    best = nextchisq;
+                    if (mine)
+                        P.bestx[(size_t)lc * MT + lane] = xk;
+                    if (lane == 0)
+                        P.best_iter[lc] = it;
+                }
+                cur = acc ? nextchisq : cur;
+                nacc += acc ? 1 : 0;
+            } else if (outk) {
+                atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
+            }
+            // Z append behind the last iteration of the refresh, chain.py:276-289; the others
+            // leave the state where the kernel leaves it in the end, so that ONE store follows
+            // the loads of the next iteration's rows either way and one wait serves both
+            if (mine) {
+                if (j + 1 == th)
+                    __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);        // publish (sc1)
+                else
+                    __hip_atomic_store(&P.X[(size_t)lc * MT + lane], xk, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            published_arrived<1>(Nx.val[0], Nx.val[1], spare);
+            S = Nx;
+        }
+        const int slot = (int)(R - R0) & 63;
+        lpbuf = (lane == slot) ? -0.5 * cur : lpbuf;
+        if (__builtin_expect(slot == 63, 0)) {
+            flush_columns(64);
+            lp_row += (size_t)64 * n;
+            zc_row += (size_t)64 * n;
+        }
+        pbase = zblock;
+        zblock += blockstride;
+        rdone = R + 1;
+    }
+out:
+    flush_columns((int)(rdone - R0) & 63);
+    if (mine)
+        P.X[(size_t)lc * MT + lane] = xk;
+    if (lane == 0) {
+        P.chisq[lc] = cur;
+        P.best_chisq[lc] = best;
+        P.numaccept[lc] = nacc0 + nacc;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // lean_snooker_kernel / lean_mrw_kernel for ensembles with more chains than waves can be
 // co-resident (P.mc_chains = T, 2..4; one GPU): a wave owns chains b, b + G, ... of a grid of G
 // and advances them one after another inside every refresh, their states in registers (T a

@@ -1093,7 +1093,8 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
     plan->fast = (plan->persistent > 0 && c->fast)
                      ? ((lean_demc_eligible(c) || lean_demc_mc_eligible(c) ||
                          lean_snooker_eligible(c) || lean_mrw_eligible(c) ||
-                         lean_snooker_mc_eligible(c) || lean_mrw_mc_eligible(c)) ? 2 : 1) : 0;
+                         lean_snooker_mc_eligible(c) || lean_mrw_mc_eligible(c) ||
+                         lean_demc_thin_eligible(c)) ? 2 : 1) : 0;
     if (plan->fast == 2 && c->p2p_ranks <= 1)
         plan->waves_per_chain = lean_waves(c);      // (helper waves share the data sum)
     if (plan->persistent > 0 && chainwave_runs(c, c->p2p_ranks > 1) && c->P.cw_lean)

@@ -983,12 +983,12 @@ def test_lean_mrw_loop(eng, monkeypatch, case):
     gpu.close()
 
 
-@pytest.mark.parametrize('sampler', ['snooker', 'mrw'])
+@pytest.mark.parametrize('sampler', ['snooker', 'mrw', 'demc'])
 @pytest.mark.parametrize('thinning', [2, 3, 7, 25])
 @pytest.mark.parametrize('case', ['plain', 'resume', 'abort', 'tight', 'tiny-history'])
 def test_lean_snooker_and_mrw_loops_with_thinning(eng, monkeypatch, case, thinning, sampler):
-    """The THIN instances of lean_snooker_kernel / lean_mrw_kernel: `thinning` iterations per
-    refresh, the draws keyed by the iteration, only the last one of a refresh published; a
+    """The THIN instances of lean_snooker_kernel / lean_mrw_kernel and lean_demc_thin_kernel:
+    `thinning` iterations per refresh, the draws keyed by the iteration, only the last one of a refresh published; a
     batch of draws (21 iterations) ends anywhere inside a refresh."""
     nchains = 5 if case == 'tiny-history' else 12
     prob = H.quad_problem(ndata=300, nchains=nchains, nsamples=nchains*90*thinning,
