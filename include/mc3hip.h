@@ -104,8 +104,10 @@ typedef struct mc3hip_plan {
                                (in-launch hand-off of Z rows), 0 = one launch per refresh */
     int32_t fast;           /* 1: the lean persistent instance (one wave per chain, fully
                                free polynomial, Gaussian chisq, no priors/shared/epsilon);
-                               2: its hand-laid-out DEMC / thinning = 1 loop (lean_demc_kernel;
-                               two to four chains per wave: lean_demc_mc_kernel);
+                               2: one of the loops laid out by hand for that shape -- DEMC
+                               (lean_demc_kernel; thinning > 1: lean_demc_thin_kernel), snooker
+                               (lean_snooker_kernel), random walk (lean_mrw_kernel), each also
+                               with two to four chains per wave (lean_*_mc_kernel);
                                3: wavelet likelihood, nine-wave kernel with the hand-structured
                                chain wave (thinning 1, no priors / shared parameters / trace);
                                4: resident tiled plan with the hand-structured chain owner
