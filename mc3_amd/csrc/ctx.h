@@ -208,9 +208,11 @@ inline bool lean_other_sampler_eligible(const mc3hip_ctx *c, int sampler)
     const DevProblem &P = c->P;
     // (thinning > 1: the THIN instances, plain shapes only)
     const bool plain = P.nfree == P.nparams && P.ngprior == 0 && P.nshare == 0;
+    // (more than one tile: the MULTI instances, plain shapes with thinning 1 only)
     return c->fast && c->mc_chains == 0 && P.sampler == sampler &&
            (P.thinning == 1 || plain) &&
-           P.nparams == c->mt && P.zs == ZROW && P.npad <= VLANES &&
+           (P.npad <= VLANES || (plain && P.thinning == 1)) &&
+           P.nparams == c->mt && P.zs == ZROW &&
            !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_LEAN");
 }
 inline bool lean_snooker_eligible(const mc3hip_ctx *c)

@@ -46,6 +46,8 @@ chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
     if (lean_mrw_eligible(c) && !p2p) {
         if (c->P.thinning > 1)
             return lean_mrw_kernel<MT, false, true>;
+        if (c->P.npad > VLANES)
+            return lean_mrw_kernel<MT, false, false, true>;
         return lean_plain_shape(c) ? lean_mrw_kernel<MT> : lean_mrw_kernel<MT, true>;
     }
     if (lean_mrw_mc_eligible(c) && !p2p) {
@@ -58,6 +60,8 @@ chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
     if (lean_snooker_eligible(c) && !p2p) {
         if (c->P.thinning > 1)
             return lean_snooker_kernel<MT, false, true>;
+        if (c->P.npad > VLANES)
+            return lean_snooker_kernel<MT, false, false, true>;
         return lean_plain_shape(c) ? lean_snooker_kernel<MT> : lean_snooker_kernel<MT, true>;
     }
     if (lean_snooker_mc_eligible(c) && !p2p) {

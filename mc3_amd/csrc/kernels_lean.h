@@ -421,7 +421,8 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
 // (FX: some coefficients are fixed or shared, or carry Gaussian priors -- as lean_demc_kernel's)
 // (THIN: thinning > 1 -- the iterations between two refreshes draw from the same history and
 // publish nothing; the draws are keyed by the iteration, R thinning + j, as run_chain's)
-template <int MT, bool FX = false, bool THIN = false>
+// (MULTI: more than 1024 points -- the second tile stays in registers too, the rest is streamed)
+template <int MT, bool FX = false, bool THIN = false, bool MULTI = false>
 __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, const int nref)
 {
     const int nf = FX ? P.nfree : MT;
@@ -438,6 +439,9 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
         return;
     DataTile<1, MT> tile;
     tile.load(P);
+    DataTile<1, MT> tile1;
+    if constexpr (MULTI)
+        tile1.load(P, VLANES);
     const long long R0 = P.ctl[0];
     const int n = P.nchains;
     const size_t blockstride = (size_t)n * ZS;
@@ -606,8 +610,8 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
                 model.init_from_lanes(P, npk, kf, fx);
             }
             double nextchisq =
-                block_gauss_model<1, MT, false, false>(P, model, nullptr, nullptr, tile,
-                                                       &tile);               // chain.py:249
+                block_gauss_model<1, MT, MULTI, MULTI>(P, model, nullptr, nullptr, tile,
+                                                       MULTI ? &tile1 : &tile);  // chain.py:249
             if constexpr (FX)
                 nextchisq = nextchisq + prior_from_lanes<MT>(P, npk, kf, fx);
             bool acc;
@@ -683,7 +687,8 @@ out:
 // Same draws, same arithmetic, same results as run_chain's.
 // (THIN: thinning > 1 -- the iterations between two refreshes publish nothing; the draws are
 // keyed by the iteration, R thinning + j, as run_chain's)
-template <int MT, bool FX = false, bool THIN = false>
+// (MULTI: more than 1024 points -- the second tile stays in registers too, the rest is streamed)
+template <int MT, bool FX = false, bool THIN = false, bool MULTI = false>
 __global__ __launch_bounds__(64) void lean_mrw_kernel(const DevProblem P, const int nref)
 {
     static_assert(MT >= 1 && MT <= 4, "two slots of normal deviates");
@@ -700,6 +705,9 @@ __global__ __launch_bounds__(64) void lean_mrw_kernel(const DevProblem P, const 
         return;
     DataTile<1, MT> tile;
     tile.load(P);
+    DataTile<1, MT> tile1;
+    if constexpr (MULTI)
+        tile1.load(P, VLANES);
     const long long R0 = P.ctl[0];
     const int n = P.nchains;
     const size_t blockstride = (size_t)n * ZS;
@@ -783,8 +791,8 @@ __global__ __launch_bounds__(64) void lean_mrw_kernel(const DevProblem P, const 
                 model.init_from_lanes(P, npk, kf, fx);
             }
             double nextchisq =
-                block_gauss_model<1, MT, false, false>(P, model, nullptr, nullptr, tile,
-                                                       &tile);               // chain.py:249
+                block_gauss_model<1, MT, MULTI, MULTI>(P, model, nullptr, nullptr, tile,
+                                                       MULTI ? &tile1 : &tile);  // chain.py:249
             if constexpr (FX)
                 nextchisq = nextchisq + prior_from_lanes<MT>(P, npk, kf, fx);
             const bool acc = metropolis_accept(0.5 * (cur - nextchisq), u_now, lo_now, hi_now);

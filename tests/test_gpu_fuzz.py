@@ -168,9 +168,9 @@ def test_lean_kernels_random_problem(seed):
     label = f"{flavour} {prob['sampler']} poly{prob['nmodel']} ndata={len(prob['data'])} " \
             f"nchains={prob['nchains']} thin={prob['thinning']} pstep={prob['pstep']} plan={plan}"
     assert plan['persistent'] > 0 and plan['fast'] > 0, label
-    # (hand-laid-out loops: DEMC with thinning 1 and streamed tiles; every sampler as long as
-    # the data are one tile, with any thinning)
-    lean_loop = (prob['thinning'] == 1 and prob['sampler'] == 'demc') or len(prob['data']) <= 1024
+    # (hand-laid-out loops: thinning 1 with one, two or streamed tiles; any thinning as long as
+    # the data are one tile)
+    lean_loop = prob['thinning'] == 1 or len(prob['data']) <= 1024
     assert (plan['fast'] == 2) == lean_loop, label
     orc = H.make_oracle(prob, plan=plan)
     Z0, lp0 = H.initial_population(orc, seed=seed)

@@ -1026,6 +1026,29 @@ def test_lean_snooker_and_mrw_loops_with_thinning(eng, monkeypatch, case, thinni
     gpu.close()
 
 
+@pytest.mark.parametrize('sampler', ['snooker', 'mrw'])
+@pytest.mark.parametrize('ndata', [1025, 2048, 2049, 4096])
+def test_lean_snooker_and_mrw_loops_with_streamed_tiles(eng, ndata, sampler):
+    """The MULTI instances of lean_snooker_kernel / lean_mrw_kernel: two tiles in registers, the
+    third and fourth streamed inside the loop (loads the compiler tracks next to the ones it
+    does not)."""
+    prob = H.quad_problem(ndata=ndata, nchains=14, nsamples=14*150, sampler=sampler)
+    if sampler == 'mrw':
+        prob['pstep'] = np.array([0.05, 0.02, 0.003])
+    gpu = eng.DeviceChains(**prob)
+    orc = H.make_oracle(prob, plan=gpu.plan)
+    Z0, lp0 = H.initial_population(orc)
+    orc.set_population(Z0, lp0)
+    gpu.set_population(Z0, lp0)
+    orc.run(nthreads=4)
+    for n in (1, 30, 22, 97):
+        gpu.run(n)
+    plan = gpu.plan
+    assert plan['persistent'] > 0 and plan['recoveries'] == 0 and plan['fast'] == 2, plan
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
 @pytest.mark.parametrize('case', ['quad', 'line', 'cubic', 'tight', 'ragged', 'resume', 'abort',
                                   'tiny-history', 'switch', 'fixed', 'priors'])
 def test_lean_snooker_loop(eng, monkeypatch, case):

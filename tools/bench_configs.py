@@ -93,6 +93,10 @@ def _poly6(n, as_matrix):
 for _smp in ('demc', 'snooker', 'mrw'):
     CONFIGS['c2thin10' + _smp] = (lambda n, _s=_smp: (H.quad_problem(
         ndata=1000, nchains=256, nsamples=256*n*10, sampler=_s, thinning=10), {}))
+# two tiles (streamed-tile instances)
+for _smp in ('demc', 'snooker', 'mrw'):
+    CONFIGS['c2two' + _smp] = (lambda n, _s=_smp: (H.quad_problem(
+        ndata=2000, nchains=256, nsamples=256*n, sampler=_s), {}))
 CONFIGS['p6'] = lambda n: _poly6(n, False)
 CONFIGS['p6matrix'] = lambda n: _poly6(n, True)
 BYTES = {'c2mrw': 24104, 'q5': 8*3*100000 + 8*3*4 + 8, 'c4mrw': 8*2*16384 + 8*5*4 + 8, 'c4demc': 8*2*16384 + 8*5*4 + 8, 'c4half': 8*2*16384 + 8*5*4 + 8, 'c2': 24104, 'c2snooker': 24104, 'c3one': 24104, 'c4': 8*2*16384 + 8*5*4 + 8,
@@ -106,6 +110,8 @@ ITERS.update(c3x2mrw=3000, c3onesnooker=4000, p6=200, p6matrix=200)
 for _smp in ('demc', 'snooker', 'mrw'):
     ITERS['c2thin10' + _smp] = 4000
     BYTES['c2thin10' + _smp] = 24104
+    ITERS['c2two' + _smp] = 10000
+    BYTES['c2two' + _smp] = 48104
 BYTES['p6'] = BYTES['p6matrix'] = 8*3*100000 + 8*6*4 + 8
 for _k in ('c3x2', 'c3x4', 'c3x2snooker', 'c3x2mrw', 'c3onesnooker'):
     BYTES[_k] = 24104
