@@ -3,7 +3,7 @@
 # gpurun_out/r03/ (reduced to profiles/r03_* by tools/reduce_r03.py).
 # rocprofv3 is always given python3 itself (never a wrapper); PMC passes are separate runs with
 # nothing but --pmc (+ --kernel-trace for the kernel names).
-#   bash tools/collect_r03.sh [part ...]      parts: bench kt pmc configs c4 c5 ranks soak
+#   bash tools/collect_r03.sh [part ...]      parts: bench kt pmc configs c4 c5 ranks loops soak
 out=gpurun_out/r03
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -24,7 +24,7 @@ if has pmc; then
 fi
 # the other configurations on one GPU (each in a fresh process)
 if has configs; then
-    timeout 1200 python tools/bench_configs.py c2 c2snooker c2mrw c2thin10demc c2thin10snooker c2thin10mrw c3one c3onesnooker c3x2 c3x4 c3x2snooker c3x2mrw c4 c4wide c4demc c4mrw c4x2 c4x4 c5 q5 p6 p6matrix \
+    timeout 1200 python tools/bench_configs.py c2 c2snooker c2mrw c2thin10demc c2thin10snooker c2thin10mrw c2twodemc c2twosnooker c2twomrw c3one c3onesnooker c3x2 c3x4 c3x2snooker c3x2mrw c4 c4wide c4demc c4mrw c4x2 c4x4 c5 q5 p6 p6matrix \
         > $out/configs.jsonl 2> $out/configs.err
     MC3HIP_NO_RESIDENT=1 timeout 600 python tools/bench_configs.py c5 q5 > $out/configs_three_launch.jsonl 2> $out/configs3.err
     MC3HIP_NO_CHAINWAVE=1 timeout 600 python tools/bench_configs.py c4 c4wide > $out/configs_no_chainwave.jsonl 2>> $out/configs3.err
@@ -60,6 +60,13 @@ if has ranks; then
     MC3HIP_BENCH_FORCE_COMM=1 timeout 600 python bench.py --no-cpu-baseline --no-e2e --steps 2 --warmup 1 --refreshes 4096 \
         > $out/c2_bench_rccl_graph_1rank.json 2> $out/c2_bench_rccl_graph_1rank.err
     timeout 300 sh tools/probes/run_xgmi_handoff.sh > $out/handoff_probe.json 2> $out/handoff_probe.err
+fi
+# kernel statistics of the other hand-laid-out loops
+if has loops; then
+    for cfg in c2snooker c2mrw c3x2snooker c2thin10demc; do
+        timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$cfg -o $cfg -- \
+            python3 tools/bench_configs.py $cfg > $out/kt_$cfg.log 2>&1
+    done
 fi
 has soak && timeout 900 python tests/soak.py 1000000 demc > $out/soak_demc_1e6.txt 2>&1
 ls $out

@@ -52,6 +52,12 @@ for rel, name in (('configs.jsonl', 'configs.jsonl'),
                   ('kt_c2/c2_agent_info.csv', 'agent_info.csv'),
                   ('kt_c4/c4_kernel_stats.csv', 'c4_wavelet_kernel_stats.csv'),
                   ('kt_c5/c5_kernel_stats.csv', 'c5_resident_kernel_stats.csv'),
+                  ('kt_c2snooker/c2snooker_kernel_stats.csv', 'c2snooker_kernel_stats.csv'),
+                  ('kt_c2mrw/c2mrw_kernel_stats.csv', 'c2mrw_kernel_stats.csv'),
+                  ('kt_c3x2snooker/c3x2snooker_kernel_stats.csv',
+                   'c3x2snooker_kernel_stats.csv'),
+                  ('kt_c2thin10demc/c2thin10demc_kernel_stats.csv',
+                   'c2thin10demc_kernel_stats.csv'),
                   ('handoff_probe.json', 'handoff_probe_one_gpu.json')):
     if have(rel):
         shutil.copy(os.path.join(R, rel), os.path.join(D, 'r03_' + name))
