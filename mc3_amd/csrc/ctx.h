@@ -312,6 +312,7 @@ chain_kernel_fn persist_instance_wavelet_w8cg(const mc3hip_ctx *c);
 // that sizes the persistent grid can never disagree (the MULTI / FX instances use more than
 // twice the registers of the plain ones: 4 single-wave workgroups per CU instead of 8).
 chain_kernel_fn fast_instance(const mc3hip_ctx *c, bool p2p);
+chain_kernel_fn lean_other_instance(const mc3hip_ctx *c);   // k_lean2.hip
 
 // ---- k_tiled.hip: the tiled plan as three launches per iteration -------------------------
 void launch_propose(mc3hip_ctx *c, int roff, int j);

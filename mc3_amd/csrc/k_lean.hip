@@ -39,39 +39,12 @@ chain_kernel_fn fast_instance_tt(const mc3hip_ctx *c, bool p2p)
 template <int MT>
 chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
 {
-    // (2..4 chains per wave of the hand-laid-out snooker / random-walk loops)
-#define MC3_LEAN_SOLO_MC(KERNEL, TT)                                                \
-        if (c->mc_chains == TT)                                                     \
-            return lean_plain_shape(c) ? KERNEL<MT, TT> : KERNEL<MT, TT, true>;
-    if (lean_mrw_eligible(c) && !p2p) {
-        if (c->P.thinning > 1)
-            return lean_mrw_kernel<MT, false, true>;
-        if (c->P.npad > VLANES)
-            return lean_mrw_kernel<MT, false, false, true>;
-        return lean_plain_shape(c) ? lean_mrw_kernel<MT> : lean_mrw_kernel<MT, true>;
-    }
-    if (lean_mrw_mc_eligible(c) && !p2p) {
-        MC3_LEAN_SOLO_MC(lean_mrw_mc_kernel, 2)
-        MC3_LEAN_SOLO_MC(lean_mrw_mc_kernel, 3)
-        MC3_LEAN_SOLO_MC(lean_mrw_mc_kernel, 4)
-    }
+    // (the hand-laid-out snooker, random-walk and thinned DEMC loops: k_lean2.hip)
+    if (!p2p)
+        if (chain_kernel_fn f = lean_other_instance(c))
+            return f;
     if (c->P.sampler == MC3HIP_MRW)
         return fast_instance_tt<MT, MC3HIP_MRW>(c, p2p);
-    if (lean_snooker_eligible(c) && !p2p) {
-        if (c->P.thinning > 1)
-            return lean_snooker_kernel<MT, false, true>;
-        if (c->P.npad > VLANES)
-            return lean_snooker_kernel<MT, false, false, true>;
-        return lean_plain_shape(c) ? lean_snooker_kernel<MT> : lean_snooker_kernel<MT, true>;
-    }
-    if (lean_snooker_mc_eligible(c) && !p2p) {
-        MC3_LEAN_SOLO_MC(lean_snooker_mc_kernel, 2)
-        MC3_LEAN_SOLO_MC(lean_snooker_mc_kernel, 3)
-        MC3_LEAN_SOLO_MC(lean_snooker_mc_kernel, 4)
-    }
-#undef MC3_LEAN_SOLO_MC
-    if (lean_demc_thin_eligible(c) && !p2p)
-        return lean_demc_thin_kernel<MT>;
     if (lean_demc_mc_eligible(c) && !p2p) {          // 2..4 chains per wave
 #define MC3_LEAN_MC(TT)                                                             \
         if (c->mc_chains == TT) {                                                   \

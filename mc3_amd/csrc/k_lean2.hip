@@ -1,0 +1,61 @@
+// k_lean2.hip -- instances of the hand-laid-out snooker and random-walk loops (one chain per
+// wave, thinning, streamed tiles, two to four chains per wave) and of the thinned DEMC loop
+// (kernels_lean.h); a translation unit of its own so that the library builds in parallel.
+#include "ctx.h"
+#include "kernels_lean.h"
+
+namespace mc3hip {
+namespace host {
+namespace {
+
+template <int MT>
+chain_kernel_fn lean_other_instance_t(const mc3hip_ctx *c)
+{
+    // (2..4 chains per wave of the hand-laid-out snooker / random-walk loops)
+#define MC3_LEAN_SOLO_MC(KERNEL, TT)                                                \
+        if (c->mc_chains == TT)                                                     \
+            return lean_plain_shape(c) ? KERNEL<MT, TT> : KERNEL<MT, TT, true>;
+    if (lean_mrw_eligible(c)) {
+        if (c->P.thinning > 1)
+            return lean_mrw_kernel<MT, false, true>;
+        if (c->P.npad > VLANES)
+            return lean_mrw_kernel<MT, false, false, true>;
+        return lean_plain_shape(c) ? lean_mrw_kernel<MT> : lean_mrw_kernel<MT, true>;
+    }
+    if (lean_mrw_mc_eligible(c)) {
+        MC3_LEAN_SOLO_MC(lean_mrw_mc_kernel, 2)
+        MC3_LEAN_SOLO_MC(lean_mrw_mc_kernel, 3)
+        MC3_LEAN_SOLO_MC(lean_mrw_mc_kernel, 4)
+    }
+    if (lean_snooker_eligible(c)) {
+        if (c->P.thinning > 1)
+            return lean_snooker_kernel<MT, false, true>;
+        if (c->P.npad > VLANES)
+            return lean_snooker_kernel<MT, false, false, true>;
+        return lean_plain_shape(c) ? lean_snooker_kernel<MT> : lean_snooker_kernel<MT, true>;
+    }
+    if (lean_snooker_mc_eligible(c)) {
+        MC3_LEAN_SOLO_MC(lean_snooker_mc_kernel, 2)
+        MC3_LEAN_SOLO_MC(lean_snooker_mc_kernel, 3)
+        MC3_LEAN_SOLO_MC(lean_snooker_mc_kernel, 4)
+    }
+#undef MC3_LEAN_SOLO_MC
+    if (lean_demc_thin_eligible(c))
+        return lean_demc_thin_kernel<MT>;
+    return nullptr;
+}
+
+}  // namespace
+
+// the kernel of a context that one of these loops serves (one GPU), or nullptr
+chain_kernel_fn lean_other_instance(const mc3hip_ctx *c)
+{
+    switch (c->mt) {
+    case MT_POLY2: return lean_other_instance_t<MT_POLY2>(c);
+    case MT_POLY3: return lean_other_instance_t<MT_POLY3>(c);
+    default: return lean_other_instance_t<MT_POLY4>(c);
+    }
+}
+
+}  // namespace host
+}  // namespace mc3hip
