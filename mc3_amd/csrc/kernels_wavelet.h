@@ -250,6 +250,9 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
     unsigned long long ta14 = 0;                       // prepare
 #endif
 
+    // (everything loaded so far retired here: a load still pending at the loop head makes the
+    // compiler guard its registers with a wait INSIDE the loop -- behind the row's publish)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     for (long long R = R0; R < R0 + nref; ++R) {
         unsigned long long tk0 = 0, tk1 = 0, tkP = 0, tkT = 0, tkC = 0, tk2 = 0, tk3 = 0;
         (void)tk0; (void)tk1; (void)tkP; (void)tkT; (void)tkC; (void)tk2; (void)tk3;

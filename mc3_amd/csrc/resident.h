@@ -516,6 +516,8 @@ __device__ __forceinline__ void lean_resident_owner(const DevProblem &P, const i
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tk_end = 0;
 #endif
 
+    // (everything loaded so far retired here: see lean_chain_wave)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     for (long long R = R0; R < R0 + nref; ++R) {
         unsigned long long tk0 = 0, tk1 = 0, tkP = 0, tkT = 0, tkC = 0, tk2 = 0, tk3 = 0;
         (void)tk0; (void)tk1; (void)tkP; (void)tkT; (void)tkC; (void)tk2; (void)tk3;
