@@ -20,7 +20,9 @@ import ranks  # noqa: E402
 def main():
     out_path, sampler, thinning, niter = (sys.argv[1], sys.argv[2], int(sys.argv[3]),
                                           int(sys.argv[4]))
-    abort_at = int(sys.argv[5].split('=')[1]) if len(sys.argv) > 5 else None
+    extra = dict(a.split('=') for a in sys.argv[5:])
+    abort_at = int(extra['abort']) if 'abort' in extra else None
+    nchains = int(extra.get('nchains', 16))
     if abort_at is not None and int(os.environ.get('RANK', '0')) == 0:
         # test hook: this rank's first chain gives up at that refresh (read at create)
         os.environ['MC3HIP_TEST_ABORT_AT'] = str(abort_at)
@@ -31,7 +33,7 @@ def main():
         data=data, uncert=uncert, func=H.quad, params=np.array([10.0, -2.0, 0.1]),
         indparams=[x], pstep=np.array([1.0, 0.5, 0.1]),
         pmin=np.array([-10.0, -20.0, -10.0]), pmax=np.array([40.0, 20.0, 10.0]),
-        sampler=sampler, nsamples=16*niter*thinning, burnin=10, nchains=16,
+        sampler=sampler, nsamples=nchains*niter*thinning, burnin=10, nchains=nchains,
         thinning=thinning, grtest=True, log=mu.Log(verb=0), seed=99, comm=comm,
         device=0)
     if abort_at is None:
