@@ -336,7 +336,7 @@ def kernel_vectors():
     print('kernel_vectors:', len(out), 'arrays')
 
 
-if __name__ == '__main__' and 'tutorial' not in sys.argv and 'residues' not in sys.argv:
+if __name__ == '__main__' and not {'tutorial', 'residues', 'headline'} & set(sys.argv):
     kernel_vectors()
     chain_cases()
 
@@ -511,3 +511,88 @@ def residue_vectors():
 
 if __name__ == '__main__' and 'residues' in sys.argv:
     residue_vectors()
+
+
+# ---- round 4: the lockstep semantics pinned to the reference at the headline shape -------
+def _summary(out, burn_rows=0):
+    post = np.asarray(out['posterior'])
+    q = np.percentile(post, [2.5, 16, 50, 84, 97.5], axis=0)
+    return dict(meanp=post.mean(0), stdp=post.std(0), quantiles=q,
+                acceptance_rate=out['acceptance_rate'], best_chisq=out['best_chisq'],
+                bestp=out['bestp'], nrows=len(post))
+
+
+def headline_summary():
+    """BASELINE.json configs[1] (256 chains, demc, ndata 1000) and a wavelet-likelihood run
+    (64 chains, 2^10 points, snooker) by the reference itself, ncpu=1: posterior means, widths,
+    quantiles, acceptance rate, best chisq; plus a few hundred mid-run rows with the chisq the
+    reference's own _chisq / _dwt give for them (the direct 1e-10 leg at C2 / C4 sizes)."""
+    save = {}
+    x, data, uncert = tutorial_data(1000)
+    np.random.seed(5)
+    cwd = os.getcwd()
+    os.chdir('/tmp')
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = mc3.sample(
+                data=data, uncert=uncert, func=quad, params=np.array([10.0, -2.0, 0.1]),
+                indparams=[x], pmin=np.array([-10.0, -20.0, -10.0]),
+                pmax=np.array([40.0, 20.0, 10.0]), pstep=np.array([1.0, 0.5, 0.1]),
+                sampler='demc', nsamples=5e5, burnin=500, nchains=256, ncpu=1,
+                grtest=False, plots=False, log=None)
+    finally:
+        os.chdir(cwd)
+    for k, v in _summary(out).items():
+        save['c2_' + k] = np.asarray(v)
+    post = np.asarray(out['posterior'])
+    rows = post[np.linspace(0, len(post) - 1, 300).astype(int)]
+    save['c2_rows'] = rows
+    save['c2_rows_chisq'] = np.array([ms.chisq(quad(p, x), data, uncert) for p in rows])
+    print('c2:', save['c2_meanp'], save['c2_stdp'], save['c2_acceptance_rate'],
+          save['c2_best_chisq'])
+
+    # the wavelet likelihood: 64 chains, 2^10 points, snooker
+    rs = np.random.RandomState(99)
+    xw = np.linspace(0, 10, 1024)
+    yw = quad([3.0, -2.4, 0.5], xw)
+    dw = yw + rs.normal(0, 1.0, 1024) + 0.5*np.sin(2*np.pi*xw)
+    wl = dict(data=dw, uncert=np.ones(1024), indparams=[xw],
+              params=np.array([3.0, -2.4, 0.5, 1.0, 0.5, 1.0]),
+              pstep=np.array([0.3, 0.1, 0.02, 0.0, 0.1, 0.1]),
+              pmin=np.array([-10.0, -20.0, -10.0, 0.0, 0.01, 0.01]),
+              pmax=np.array([40.0, 20.0, 10.0, 2.0, 10.0, 10.0]))
+    np.random.seed(6)
+    os.chdir('/tmp')
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = mc3.sample(func=quad, sampler='snooker', nsamples=2e5, burnin=500,
+                             nchains=64, ncpu=1, wlike=True, grtest=False, plots=False,
+                             log=None, **wl)
+    finally:
+        os.chdir(cwd)
+    for k, v in _summary(out).items():
+        save['wl_' + k] = np.asarray(v)
+    for k, v in wl.items():
+        save['wl_in_' + k] = np.asarray(v[0] if k == 'indparams' else v)
+    print('wl:', save['wl_meanp'], save['wl_stdp'], save['wl_acceptance_rate'],
+          save['wl_best_chisq'])
+
+    # C4-sized direct leg: 2^14 points, rows scattered around the wavelet posterior
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import helpers as H
+    prob = H.wavelet_problem(ndata=16384, nchains=8, nsamples=8)
+    x4, d4 = prob['indep'], prob['data']
+    rs2 = np.random.RandomState(77)
+    P = np.tile(prob['params'], (200, 1))
+    free = np.asarray(prob['pstep']) > 0
+    P[:, free] += rs2.normal(0, 1.0, (200, free.sum()))*np.asarray(prob['pstep'])[free]*0.3
+    P[:, 4:6] = np.abs(P[:, 4:6]) + 0.05
+    save['c4_rows'] = P
+    save['c4_rows_chisq'] = np.array([ms.dwt_chisq(quad(p[0:3], x4), d4, p) for p in P])
+    save['c4_data_checksum'] = np.array([d4.sum(), x4.sum()])
+    np.savez_compressed(os.path.join(HERE, 'headline_summary.npz'), **save)
+    print('headline_summary:', len(save), 'arrays')
+
+
+if __name__ == '__main__' and 'headline' in sys.argv:
+    headline_summary()

@@ -446,3 +446,99 @@ def test_chisq_rows_against_the_reference_log_prior(golden_dir):
     # the prior terms themselves, each kind present and nonzero
     np.testing.assert_allclose(-0.5*got - lp0, -want_lp, rtol=1e-10)
     assert np.all(want_lp < -1e-3)
+
+
+# ---- round 4: the lockstep semantics pinned to the reference at the headline shape ----------
+def _agrees_with(out, g, tag, mean_tol=0.1, width_tol=0.05, acc_tol=2.0):
+    sd = g[tag + '_stdp']
+    post = np.asarray(out['posterior'])
+    assert len(post) == int(g[tag + '_nrows'])
+    assert np.all(np.abs(post.mean(0) - g[tag + '_meanp']) < mean_tol*sd), \
+        (post.mean(0), g[tag + '_meanp'], sd)
+    assert np.all(np.abs(post.std(0)/sd - 1.0) < width_tol), (post.std(0), sd)
+    q = np.percentile(post, [2.5, 16, 50, 84, 97.5], axis=0)
+    # (the tails of a finite sample move more than its centre: 0.1 sigma at the median and
+    # the one-sigma quantiles, 0.2 sigma at the 2.5 / 97.5 % ones)
+    tol = np.array([0.2, 0.1, 0.1, 0.1, 0.2])[:, None]*sd
+    assert np.all(np.abs(q - g[tag + '_quantiles']) < tol), (q, g[tag + '_quantiles'])
+    assert abs(out['acceptance_rate'] - float(g[tag + '_acceptance_rate'])) < acc_tol, \
+        (out['acceptance_rate'], g[tag + '_acceptance_rate'])
+    # the best fit is a property of the data, not of the sampler
+    np.testing.assert_allclose(out['best_chisq'], g[tag + '_best_chisq'], rtol=2e-4)
+
+
+def test_headline_config_c2_against_the_reference_run(golden_dir):
+    """BASELINE.json configs[1] at its own shape -- 256 chains, demc, ndata 1000 -- run by the
+    reference itself (ncpu=1, 5e5 samples, burnin 500; tests/golden/make_golden.py headline:
+    mc3/chain.py:183-299 as the reference runs it, chains one after another) against the
+    GPU's lockstep run of the same call: posterior means within 0.1 sigma, widths within 5 %,
+    quantiles, acceptance rate within 2 points, the same best chisq."""
+    import mc3_amd
+    from mc3_amd import utils as mu
+    g = np.load(os.path.join(golden_dir, 'headline_summary.npz'))
+    x, data, uncert = H.tutorial_data(1000)
+    np.random.seed(5)
+    out = mc3_amd.sample(
+        data=data, uncert=uncert, func=quad, params=np.array([10.0, -2.0, 0.1]),
+        indparams=[x], pmin=np.array([-10.0, -20.0, -10.0]),
+        pmax=np.array([40.0, 20.0, 10.0]), pstep=np.array([1.0, 0.5, 0.1]),
+        sampler='demc', nsamples=5e5, burnin=500, nchains=256, grtest=False,
+        log=mu.Log(verb=0), seed=5)
+    _agrees_with(out, g, 'c2')
+
+
+def test_wavelet_snooker_run_against_the_reference_run(golden_dir):
+    """The wavelet likelihood under snooker -- 64 chains, 2^10 points, 2e5 samples -- by the
+    reference itself against the GPU's run of the same call (src_c/_dwt.c:56-119 inside
+    mc3/chain.py:183-299)."""
+    import mc3_amd
+    from mc3_amd import utils as mu
+    g = np.load(os.path.join(golden_dir, 'headline_summary.npz'))
+    np.random.seed(6)
+    out = mc3_amd.sample(
+        data=g['wl_in_data'], uncert=g['wl_in_uncert'], func=quad, params=g['wl_in_params'],
+        indparams=[g['wl_in_indparams']], pmin=g['wl_in_pmin'], pmax=g['wl_in_pmax'],
+        pstep=g['wl_in_pstep'], sampler='snooker', nsamples=2e5, burnin=500, nchains=64,
+        wlike=True, grtest=False, log=mu.Log(verb=0), seed=6)
+    _agrees_with(out, g, 'wl', acc_tol=3.0)
+
+
+def test_chisq_of_mid_run_rows_against_the_reference_kernels(golden_dir):
+    """The direct 1e-10 leg at C2 and C4 sizes (as residue_vectors.npz is for C5):
+      * 300 rows of the REFERENCE's own C2 run and 200 rows around C4's wavelet posterior,
+        with the chisq its _chisq / _dwt gave them, through the device's evaluation;
+      * rows the CHAIN KERNELS wrote mid-run at C2 and C4 size: -2 log_post against the
+        reference-faithful restatement (oracle_kernels.c, itself pinned to the reference's
+        compiled C at 1e-10 by tests/test_oracle_golden.py) -- no summation plan handed
+        over: the checker adds the terms in the reference's order."""
+    from mc3_amd import engine
+    from oracle import kernels as ok
+    g = np.load(os.path.join(golden_dir, 'headline_summary.npz'))
+    # C2
+    prob = H.quad_problem(ndata=1000, nchains=256, nsamples=256*300)
+    with engine.DeviceChains(**prob) as gpu:
+        got = gpu.eval_chisq(g['c2_rows'])
+        np.testing.assert_allclose(got, g['c2_rows_chisq'], rtol=1e-10)
+        Z0, lp0, filled, _ = gpu.init_population(seed=3)
+        assert filled == gpu.M0
+        gpu.set_population(Z0, lp0)
+        gpu.run()
+        assert gpu.plan['fast'] == 2                     # (lean_demc_kernel wrote these rows)
+        Z, lp, _ = gpu.rows(gpu.M0 + 150*256, 256)
+    want = [ok.chisq(quad(p, prob['indep']), prob['data'], prob['uncert']) for p in Z]
+    np.testing.assert_allclose(-2.0*lp, want, rtol=1e-10)
+    # C4
+    prob = H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*40)
+    assert np.array_equal(g['c4_data_checksum'], [prob['data'].sum(), prob['indep'].sum()])
+    with engine.DeviceChains(**prob) as gpu:
+        got = gpu.eval_chisq(g['c4_rows'])
+        np.testing.assert_allclose(got, g['c4_rows_chisq'], rtol=1e-10)
+        Z0, lp0, filled, _ = gpu.init_population(seed=3)
+        assert filled == gpu.M0
+        gpu.set_population(Z0, lp0)
+        gpu.run()
+        assert gpu.plan['fast'] == 3                     # (the nine-wave kernel's chain wave)
+        Z, lp, _ = gpu.rows(gpu.M0 + 20*256, 64)
+        P = gpu.expand_free(Z)
+    want = [ok.dwt_chisq(quad(p[0:3], prob['indep']), prob['data'], p) for p in P]
+    np.testing.assert_allclose(-2.0*lp, want, rtol=1e-10)
