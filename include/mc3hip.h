@@ -92,6 +92,17 @@ typedef struct mc3hip_problem {
     const double *indep;    /* POLY: x[ndata]; LINEAR: A[nmodel][ndata]                 */
     const double *data;     /* [ndata]                                                  */
     const double *uncert;   /* [ndata] (unused when wlike, chain.py:327-329)            */
+    int32_t zlag;           /* declared cadence of a run sharded over GPUs: the other chains are
+                               seen `zlag` refreshes later than in the strict lockstep -- DEMC
+                               partners of refresh R (chain.py:221-232) are the rows of refresh
+                               R-1-zlag (the first nchains rows of the initial population until
+                               there is one), snooker's history (chain.py:197-205) ends with
+                               refresh R-1-zlag -- so that a row has the time of zlag refreshes
+                               to cross the fabric and an iteration costs max(arithmetic, hop /
+                               zlag), not their sum.  0 = strict (the one-GPU default).  Results
+                               depend on zlag and on nothing else: not on how the chains are
+                               sharded, not on the launch structure              */
+    int32_t reserved0;      /* 0 */
 } mc3hip_problem;
 
 /* how the library sums over data points (the checker follows the same order) */
@@ -132,6 +143,11 @@ typedef struct mc3hip_plan {
                                chains than workgroups can be co-resident; the reference's
                                workers loop over their chains the same way, chain.py:163,
                                190-191); results do not depend on it                          */
+    int32_t zlag;           /* the cadence this context runs (mc3hip_problem.zlag)              */
+    int32_t remote_delay_ns;/* test hook MC3HIP_TEST_REMOTE_DELAY_NS (read at creation): every
+                               row bound for ANOTHER rank's replica is held back that long
+                               before it is stored -- several ranks on one GPU then behave like
+                               ranks an xGMI hop apart; 0 in production                        */
 } mc3hip_plan;
 
 /* Replaces Chain.__init__ + the shared-memory allocation of mcmc()
@@ -166,6 +182,16 @@ int mc3hip_set_population(mc3hip_ctx *ctx, const double *Z0,
  * refreshes (nrefresh*thinning iterations).  Asynchronous; mc3hip_sync waits. */
 int mc3hip_run(mc3hip_ctx *ctx, int64_t nrefresh);
 int mc3hip_sync(mc3hip_ctx *ctx);
+/* Streaming runs: the reference sizes Z for the whole run and stops when it is full
+ * (mc3/mcmc_driver.py:134, chain.py:279-280); a caller that has taken the rows it wants
+ * (mc3hip_get_rows, the streaming checkpoint) recycles the buffer instead.  The last `keep`
+ * refreshes (rows, log_post, zchain) become refreshes [0, keep), everything behind them is
+ * unwritten again, the chains carry on from where they are and draw from Philox(seed) from
+ * then on (iteration numbers start over, so the key must change).  keep >= 1 + zlag, at
+ * most half of the refreshes done; mrw / demc only -- snooker draws from the WHOLE history
+ * (chain.py:197-205), which recycling would cut.  Ranks of a peer-to-peer run all call it
+ * at the same refresh, between two barriers. */
+int mc3hip_recycle(mc3hip_ctx *ctx, int64_t keep, uint64_t seed);
 /* GPU time in ms between the start and end of the last mc3hip_run (HIP events
  * recorded on the context's stream). */
 int mc3hip_last_run_ms(mc3hip_ctx *ctx, float *ms);

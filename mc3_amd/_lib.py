@@ -45,6 +45,7 @@ class Problem(ctypes.Structure):
         ('params', _dp), ('pstep', _dp), ('pmin', _dp), ('pmax', _dp),
         ('prior', _dp), ('priorlow', _dp), ('priorup', _dp),
         ('indep', _dp), ('data', _dp), ('uncert', _dp),
+        ('zlag', ctypes.c_int32), ('reserved0', ctypes.c_int32),
     ]
 
 
@@ -56,7 +57,8 @@ class Plan(ctypes.Structure):
                 ('persistent', ctypes.c_int32), ('fast', ctypes.c_int32),
                 ('comm_graph', ctypes.c_int32), ('recoveries', ctypes.c_int32),
                 ('tile_tree', ctypes.c_int32), ('resident', ctypes.c_int32),
-                ('chains_per_workgroup', ctypes.c_int32)]
+                ('chains_per_workgroup', ctypes.c_int32),
+                ('zlag', ctypes.c_int32), ('remote_delay_ns', ctypes.c_int32)]
 
 
 class Mc3HipError(RuntimeError):
@@ -77,6 +79,7 @@ SYMBOLS = {
     'mc3hip_set_population': (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp]),
     'mc3hip_run': (ctypes.c_int, [_vp, ctypes.c_int64]),
     'mc3hip_sync': (ctypes.c_int, [_vp]),
+    'mc3hip_recycle': (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_uint64]),
     'mc3hip_last_run_ms': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     'mc3hip_get_rows': (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, _dp, _dp, _ip]),
     'mc3hip_put_rows': (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, _dp, _dp]),

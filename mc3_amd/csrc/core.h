@@ -71,7 +71,12 @@ struct DevProblem {
     // log_post, mapped into this process; [0..npeers), entry `rank` is the local one
     int32_t npeers, rank;
     int32_t test_abort;           // tests: refresh at which chain `chain0` gives up (-1 = never)
-    int32_t _pad_test;
+    // declared cadence of a run sharded over GPUs (mc3hip_problem.zlag): the other chains are
+    // seen zlag refreshes later than in the strict lockstep (0)
+    int32_t zlag;
+    // test hook (MC3HIP_TEST_REMOTE_DELAY_NS): rows bound for another rank's replica are held
+    // back this many ticks of the 100 MHz s_memrealtime clock (0 in production)
+    int32_t remote_delay, _pad_delay;
     double *const *peerZ;
     double *const *peerLP;
     // tiled plan (large ndata): proposal / data sum / accept are separate launches

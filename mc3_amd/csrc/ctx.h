@@ -100,7 +100,9 @@ constexpr int CW_EXTRA_DOUBLES = 64 + MC3HIP_MAX_PARAMS + 2 + 48 + 4 + 4;
 // runs the general chain behind the same kernel
 inline bool cw_lean_eligible(const mc3hip_ctx *c)
 {
-    return c->P.thinning == 1 && c->P.trace_iters == 0 && c->P.nshare == 0 && c->P.ngprior == 0;
+    // (the declared multi-GPU cadence, zlag > 0: the general chain behind the same kernel)
+    return c->P.thinning == 1 && c->P.trace_iters == 0 && c->P.nshare == 0 && c->P.ngprior == 0 &&
+           c->P.zlag == 0;
 }
 // ... and those the hand-structured owner of the resident tiled plans is written for
 inline bool rs_lean_eligible(const mc3hip_ctx *c)
@@ -146,6 +148,17 @@ inline bool resident_poly(const mc3hip_ctx *c)
     return c->mt != MT_LINEAR && c->P.tile == 4096 && tile_exact_degree(c) >= 2;
 }
 
+// DEMC in the declared multi-GPU cadence (zlag >= 1: partners are rows of refresh R-1-zlag,
+// published long before they are needed) has a hand-laid-out loop of its own,
+// lean_demc_lag_kernel: one tile, one chain per wave, any thinning, fixed / shared coefficients
+// and priors, one GPU or peer to peer with a courier wave
+inline bool lag_demc_shape(const mc3hip_ctx *c)
+{
+    const DevProblem &P = c->P;
+    return P.zlag > 0 && P.sampler == MC3HIP_DEMC && P.npad <= VLANES && P.zs == ZROW &&
+           !getenv("MC3HIP_NO_LEAN");
+}
+
 // the lean persistent instance applies when nothing of the general machinery is
 // needed (run_chain.h run_chain FAST)
 inline bool fast_eligible(const mc3hip_ctx *c)
@@ -155,7 +168,8 @@ inline bool fast_eligible(const mc3hip_ctx *c)
     // its free parameter or to its fixed value, handoff.h coefficient_map;
     // instantiated for one GPU and thinning = 1 only: FX of persist_fast_kernel)
     const bool plain = P.nparams == P.nfree && P.ngprior == 0 && P.nshare == 0;
-    const bool fx_ok = P.nfree >= 1 && P.thinning == 1 && !(c->flags & MC3HIP_FLAG_P2P);
+    const bool fx_ok = P.nfree >= 1 &&
+                       ((P.thinning == 1 && !(c->flags & MC3HIP_FLAG_P2P)) || lag_demc_shape(c));
     // more than one 1024-point tile (streamed): plain problems, one GPU, thinning = 1
     const bool multi = P.npad > VLANES;
     const bool size_ok = !multi || (plain && fx_ok && P.tile == 0);
@@ -171,18 +185,24 @@ inline bool fast_eligible(const mc3hip_ctx *c)
 inline bool lean_demc_eligible(const mc3hip_ctx *c)
 {
     return c->fast && c->mc_chains == 0 && c->P.sampler == MC3HIP_DEMC && c->P.thinning == 1 &&
-           c->P.nparams == c->mt && c->P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
+           c->P.zlag == 0 && c->P.nparams == c->mt && c->P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
+}
+// ... and so has the declared multi-GPU cadence: lean_demc_lag_kernel
+inline bool lean_demc_lag_eligible(const mc3hip_ctx *c)
+{
+    return c->fast && c->mc_chains == 0 && lag_demc_shape(c) && c->P.nparams == c->mt;
 }
 
 // ... in the peer-to-peer mode with a second wave that carries the rows to the other ranks'
 // replicas (lean_demc_kernel COURIER; MC3HIP_NO_COURIER=1: the chain wave stores them itself)
 inline bool lean_plain_shape(const mc3hip_ctx *c);
+inline bool lean_demc_lag_eligible(const mc3hip_ctx *c);
 inline bool lean_courier(const mc3hip_ctx *c, bool p2p)
 {
     if (!p2p)       // (one GPU: an experiment, MC3HIP_LEAN_COURIER=1; measured slower)
         return getenv("MC3HIP_LEAN_COURIER") && lean_demc_eligible(c) && lean_plain_shape(c) &&
                c->P.npad <= VLANES && !(c->flags & MC3HIP_FLAG_P2P) && c->P.nlocal <= 1024;
-    return lean_demc_eligible(c) && !getenv("MC3HIP_NO_COURIER");
+    return (lean_demc_eligible(c) || lean_demc_lag_eligible(c)) && !getenv("MC3HIP_NO_COURIER");
 }
 
 // the headline loop with the draws of 64 refreshes computed at once (lean_demc_kernel BATCH):
@@ -209,7 +229,9 @@ inline bool lean_other_sampler_eligible(const mc3hip_ctx *c, int sampler)
     // (thinning > 1: the THIN instances, plain shapes only)
     const bool plain = P.nfree == P.nparams && P.ngprior == 0 && P.nshare == 0;
     // (more than one tile: the MULTI instances, plain shapes with thinning 1 only)
+    // (the declared multi-GPU cadence changes what snooker may draw from: see lean_snooker_kernel)
     return c->fast && c->mc_chains == 0 && P.sampler == sampler &&
+           (P.zlag == 0 || sampler == MC3HIP_MRW) &&
            (P.thinning == 1 || plain) &&
            (P.npad <= VLANES || (plain && P.thinning == 1)) &&
            P.nparams == c->mt && P.zs == ZROW &&
@@ -230,6 +252,7 @@ inline bool lean_demc_thin_eligible(const mc3hip_ctx *c)
     const DevProblem &P = c->P;
     const bool plain = P.nfree == P.nparams && P.ngprior == 0 && P.nshare == 0;
     return c->fast && c->mc_chains == 0 && P.sampler == MC3HIP_DEMC && P.thinning > 1 && plain &&
+           P.zlag == 0 &&
            P.nparams == c->mt && P.zs == ZROW && P.npad <= VLANES &&
            !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_LEAN");
 }
@@ -239,7 +262,7 @@ inline bool lean_other_sampler_mc_eligible(const mc3hip_ctx *c, int sampler)
 {
     const DevProblem &P = c->P;
     return c->fast && c->mc_chains >= 2 && c->mc_chains <= 4 && P.sampler == sampler &&
-           P.thinning == 1 && P.nparams == c->mt && P.zs == ZROW && P.npad <= VLANES &&
+           (P.zlag == 0 || sampler == MC3HIP_MRW) && P.thinning == 1 && P.nparams == c->mt && P.zs == ZROW && P.npad <= VLANES &&
            !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_LEAN");
 }
 inline bool lean_snooker_mc_eligible(const mc3hip_ctx *c)
@@ -256,8 +279,8 @@ inline bool lean_demc_mc_eligible(const mc3hip_ctx *c)
 {
     // (four chains per wave AND two register-resident tiles do not fit the registers)
     return c->fast && c->mc_chains >= 2 && c->mc_chains <= (c->P.npad > VLANES ? 3 : 4) &&
-           c->P.sampler == MC3HIP_DEMC && c->P.thinning == 1 && c->P.nparams == c->mt &&
-           c->P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
+           c->P.sampler == MC3HIP_DEMC && c->P.thinning == 1 && c->P.zlag == 0 &&
+           c->P.nparams == c->mt && c->P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
 }
 
 // waves that share the data sum of a chain in the hand-laid-out DEMC loop (kernels_lean.h
@@ -313,6 +336,7 @@ chain_kernel_fn persist_instance_wavelet_w8cg(const mc3hip_ctx *c);
 // twice the registers of the plain ones: 4 single-wave workgroups per CU instead of 8).
 chain_kernel_fn fast_instance(const mc3hip_ctx *c, bool p2p);
 chain_kernel_fn lean_other_instance(const mc3hip_ctx *c);   // k_lean2.hip
+chain_kernel_fn lean_lag_instance(const mc3hip_ctx *c, bool p2p);   // k_lean3.hip
 
 // ---- k_tiled.hip: the tiled plan as three launches per iteration -------------------------
 void launch_propose(mc3hip_ctx *c, int roff, int j);

@@ -40,10 +40,15 @@ __device__ __forceinline__ double load_published(const double *p)
 // puts one of them into the other's register with a copy -- on an iteration short enough (a
 // proposal out of bounds) the copy runs before the load has returned.  Found by a test
 // (test_lean_snooker_and_mrw_loops_with_thinning[tight]); tools/waits.py shows the sites.
+template <bool SYS = false>
 __device__ __forceinline__ double load_published_async(const double *p)
 {
     double v;
-    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");
+    // (SYS: system scope, as load_published<true> -- the row may have come over xGMI)
+    if constexpr (SYS)
+        asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1" : "=&v"(v) : "v"(p) : "memory");
+    else
+        asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");
     return v;
 }
 template <int N>
@@ -97,6 +102,234 @@ struct PeerTable {
                                    __HIP_MEMORY_SCOPE_SYSTEM);
     }
 };
+
+// ---- the courier wave (peer-to-peer mode) ---------------------------------------------------
+// A wave's loads and stores retire through ONE counter in issue order (MI355X_MICROARCH.md,
+// s_waitcnt): a chain wave that stored its row into seven remote replicas would have the data
+// of its next loads held back until every one of those stores is acknowledged over xGMI -- a
+// round trip, where the hand-off needs one way.  So the chain wave stores into the LOCAL
+// replica only and leaves the row in an LDS ring; a second wave of the workgroup, the courier,
+// picks it up (it spins on LDS: no vector-memory operation, nothing the chain wave could wait
+// behind), stores it into the remote replicas, its own counter absorbing the acknowledgements.
+// An empty slot holds the sentinel no row can hold (as an unwritten row of Z does), so one LDS
+// read tells the courier that the row is there and what it is.  s_cour: [1] rows sent (every
+// eighth), [2] the chain wave has left, [3] go / no go.
+constexpr int COURIER_RING = 64;             // rows the chain wave may be ahead of its courier
+
+// both waves, first thing: empty ring, ONE decision for both (a courier that left while its
+// chain wave stays -- an abort raised between their two looks at the word -- would never drain
+// the ring).  false: the launch had been given up before it started
+__device__ __forceinline__ bool courier_begin(double *s_ring, int *s_cour, long long *ctl_rw)
+{
+    if (threadIdx.x == 0) {
+        s_cour[1] = 0;
+        s_cour[2] = 0;
+        s_cour[3] = __hip_atomic_load(&ctl_rw[CTL_ABORT], __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT) == 0;
+    }
+    for (int i = threadIdx.x; i < COURIER_RING * ZROW; i += 128)
+        s_ring[i] = mc3_from_bits(ROW_PENDING);
+    __syncthreads();
+    return s_cour[3] != 0;
+}
+
+__device__ __forceinline__ unsigned realtime_ticks()       // 100 MHz, wraps: differences only
+{
+    return (unsigned)__builtin_amdgcn_s_memrealtime();
+}
+
+// the courier's loop: rows of chain c, refresh R0c onwards, from the ring to every replica but
+// the local one (P2P; otherwise -- one GPU, an experiment -- to the only one).
+// Test hook P.remote_delay (MC3HIP_TEST_REMOTE_DELAY_NS): a row is held back that long after it
+// showed up in the ring -- several ranks on one GPU then see each other as if an xGMI hop
+// apart.  Rows are still picked up at once and sent in order, each when ITS time has come (two
+// cursors), so the hook delays rows without throttling them.
+template <bool P2P>
+__device__ __forceinline__ void courier_run(const DevProblem &P, double *s_ring, int *s_cour,
+                                            const int lane, const int nf, const int c)
+{
+    constexpr int ZS = ZROW;
+    const bool mine = lane < nf;
+    const int kk = mine ? lane : 0;
+    const long long R0c = P.ctl[0];
+    size_t zoff = (size_t)(P.M0 + R0c * P.nchains) * ZS + (size_t)c * ZS + lane;
+    const size_t stride = (size_t)P.nchains * ZS;
+    PeerTable<double> peers;
+    if constexpr (P2P)
+        peers.load(P.peerZ, P.npeers);
+    double *const zlocal = own_global(P.Z);
+    (void)zlocal;
+    const unsigned delay = (unsigned)P.remote_delay;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    int sent = 0;
+    bool last = false;
+    auto send = [&](double *slot, double v) {
+        if constexpr (P2P) {
+            if (mine)
+                peers.store(zoff, v, P.rank);
+        } else {
+            if (mine)
+                __hip_atomic_store(zlocal + zoff, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (mine)
+            __hip_atomic_store(slot + lane, mc3_from_bits(ROW_PENDING), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+        ++sent;
+        zoff += stride;
+        if ((sent & 7) == 0)
+            __hip_atomic_store(&s_cour[1], sent, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    if (__builtin_expect(delay == 0, 1)) {
+        for (;;) {
+            double *const slot = s_ring + (sent % COURIER_RING) * ZS;
+            const double v = __hip_atomic_load(slot + kk, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__any(mine && mc3_bits(v) == ROW_PENDING)) {
+                // nothing yet.  Once the chain wave has left, one more look: its last row went
+                // into the ring before the word that says so
+                if (last)
+                    break;
+                last = __hip_atomic_load(&s_cour[2], __ATOMIC_ACQUIRE,
+                                         __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+                continue;
+            }
+            last = false;
+            send(slot, v);
+        }
+        return;
+    }
+    // the test hook: `seen` rows have shown up (lane s of `stamp`: when the row in slot s did)
+    int seen = 0;
+    unsigned stamp = 0;
+    for (;;) {
+        bool progress = false;
+        if (seen - sent < COURIER_RING) {
+            double *const slot = s_ring + (seen % COURIER_RING) * ZS;
+            const double v = __hip_atomic_load(slot + kk, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!__any(mine && mc3_bits(v) == ROW_PENDING)) {
+                const unsigned now = realtime_ticks();
+                stamp = (lane == seen % COURIER_RING) ? now : stamp;
+                ++seen;
+                progress = true;
+                last = false;
+            }
+        }
+        if (sent < seen) {
+            const unsigned t = (unsigned)__builtin_amdgcn_readlane((int)stamp, sent % COURIER_RING);
+            if (realtime_ticks() - t >= delay) {
+                double *const slot = s_ring + (sent % COURIER_RING) * ZS;
+                const double v = __hip_atomic_load(slot + kk, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                send(slot, v);
+                progress = true;
+            }
+        } else if (!progress) {
+            if (last)
+                break;
+            last = __hip_atomic_load(&s_cour[2], __ATOMIC_ACQUIRE,
+                                     __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+        }
+    }
+}
+
+// the chain wave hands its new row to the courier (after its own store into the local replica);
+// never a whole ring ahead: looked at once in 16 rows.  false: the launch is being given up
+__device__ __forceinline__ bool courier_hand(double *s_ring, int *s_cour, int &handed,
+                                             const int lane, const bool mine, const double xk,
+                                             long long *ctl_rw)
+{
+    if (mine)
+        __hip_atomic_store(&s_ring[(handed % COURIER_RING) * ZROW + lane], xk, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+    ++handed;
+    if (__builtin_expect((handed & 15) == 0, 0)) {
+        while (handed - __hip_atomic_load(&s_cour[1], __ATOMIC_ACQUIRE,
+                                          __HIP_MEMORY_SCOPE_WORKGROUP) > COURIER_RING - 16) {
+            if (__hip_atomic_load(&ctl_rw[CTL_ABORT], __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT) != 0)
+                return false;
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    return true;
+}
+
+// the chain wave leaves (normally, giving up or aborted): the courier drains the ring and goes
+__device__ __forceinline__ void courier_end(int *s_cour)
+{
+    __hip_atomic_store(&s_cour[2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// The same test hook for a chain wave that stores into the remote replicas ITSELF (no courier:
+// more than two ranks on one device, MC3HIP_NO_COURIER): the rows wait in an LDS ring of the
+// wave's own and go out, in order, at the first publish point after their time has come
+// (flush: at the end, after waiting for it).  Without the hook (P.remote_delay = 0) rows are
+// stored at once and this is not used.
+struct DelayedRows {
+    int handed, sent;
+    unsigned stamp;                 // lane s: when the row in slot s was produced
+    size_t zoff, stride;
+    __device__ __forceinline__ void begin(const DevProblem &P, long long R0, int c, int lane)
+    {
+        handed = sent = 0;
+        stamp = 0;
+        zoff = (size_t)(P.M0 + R0 * P.nchains) * ZROW + (size_t)c * ZROW + lane;
+        stride = (size_t)P.nchains * ZROW;
+    }
+    __device__ __forceinline__ void drain(const DevProblem &P, double *s_ring,
+                                          const PeerTable<double> &peers, int lane, bool mine,
+                                          bool all)
+    {
+        const unsigned delay = (unsigned)P.remote_delay;
+        while (sent < handed) {
+            const unsigned t = (unsigned)__builtin_amdgcn_readlane((int)stamp, sent % COURIER_RING);
+            if (realtime_ticks() - t < delay) {
+                if (!all && handed - sent < COURIER_RING)
+                    break;
+                continue;            // (the end of the launch, or a full ring: wait for it)
+            }
+            const double v = s_ring[(sent % COURIER_RING) * ZROW + (mine ? lane : 0)];
+            if (mine)
+                peers.store(zoff, v, P.rank);
+            ++sent;
+            zoff += stride;
+        }
+    }
+    __device__ __forceinline__ void hand(const DevProblem &P, double *s_ring,
+                                         const PeerTable<double> &peers, int lane, bool mine,
+                                         double xk)
+    {
+        if (mine)
+            s_ring[(handed % COURIER_RING) * ZROW + lane] = xk;
+        const unsigned now = realtime_ticks();
+        stamp = (lane == handed % COURIER_RING) ? now : stamp;
+        ++handed;
+        __builtin_amdgcn_wave_barrier();
+        drain(P, s_ring, peers, lane, mine, false);
+    }
+};
+
+// ... and where the chain wave is held itself (the general chain, the owner of the resident
+// tiled plans): the row goes into the local replica at once and into the others after the
+// delay, the wave waiting it out -- a pessimistic model (a real store does not hold the wave,
+// but its acknowledgement holds the wave's next loads back as long)
+__device__ __forceinline__ void store_row_everywhere(const DevProblem &P,
+                                                     const PeerTable<double> &peers, size_t off,
+                                                     double v, bool mine)
+{
+    if (__builtin_expect(P.remote_delay != 0, 0)) {
+        if (mine)
+            __hip_atomic_store(P.Z + off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned t0 = realtime_ticks();
+        while (realtime_ticks() - t0 < (unsigned)P.remote_delay)
+            __builtin_amdgcn_s_sleep(1);
+        if (mine)
+            peers.store(off, v, P.rank);
+    } else if (mine) {
+        peers.store(off, v);
+    }
+}
 
 // Wave-level wait until every lane's values have been published (all 64 lanes
 // poll; lanes beyond nfree repeat lane 0's addresses).  The first read is issued

@@ -39,6 +39,9 @@ chain_kernel_fn fast_instance_tt(const mc3hip_ctx *c, bool p2p)
 template <int MT>
 chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
 {
+    // (the loops of the declared multi-GPU cadence: k_lean3.hip)
+    if (chain_kernel_fn f = lean_lag_instance(c, p2p))
+        return f;
     // (the hand-laid-out snooker, random-walk and thinned DEMC loops: k_lean2.hip)
     if (!p2p)
         if (chain_kernel_fn f = lean_other_instance(c))

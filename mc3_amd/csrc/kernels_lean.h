@@ -44,7 +44,6 @@ __global__ __launch_bounds__(64) void persist_fast_kernel(const DevProblem P, co
 // leaves the row in an LDS ring; the courier picks it up (it spins on an LDS counter: no
 // vector-memory operation, nothing the chain wave could wait behind) and stores it into the
 // remote replicas, its own counter absorbing the acknowledgements.  Same rows, same results.
-constexpr int COURIER_RING = 64;             // rows the chain wave may be ahead of its courier
 template <int MT, bool P2P, bool FX = false, bool MULTI = false, bool BATCH = false,
           bool COURIER = false>
 __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const DevProblem P,
@@ -59,71 +58,16 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
     const bool mine = lane < nf;
     const int kk = mine ? lane : 0;
     long long *ctl_rw = const_cast<long long *>(P.ctl);
-    __shared__ double s_ring[COURIER ? COURIER_RING * ZROW : 1];
+    // (the ring: the courier's, or -- test hook P.remote_delay without a courier -- the chain
+    // wave's own queue of rows whose time has not come, handoff.h DelayedRows)
+    __shared__ double s_ring[(COURIER || P2P) ? COURIER_RING * ZROW : 1];
     __shared__ int s_cour[4];                // 1: rows sent (every eighth), 2: done, 3: go
     (void)s_ring; (void)s_cour;
     if constexpr (COURIER) {
-        // (one decision for both waves: a courier that left while its chain wave stays --
-        // an abort raised between their two looks at the word -- would never drain the ring)
-        if (threadIdx.x == 0) {
-            s_cour[1] = 0;
-            s_cour[2] = 0;
-            s_cour[3] = __hip_atomic_load(&ctl_rw[CTL_ABORT], __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_AGENT) == 0;
-        }
-        // (an empty slot of the ring holds the sentinel no row can hold, as an unwritten row
-        // of Z does: the courier polls the slot itself, one LDS read tells it that the row
-        // is there and what it is)
-        for (int i = threadIdx.x; i < COURIER_RING * ZS; i += 128)
-            s_ring[i] = mc3_from_bits(ROW_PENDING);
-        __syncthreads();
-        if (s_cour[3] == 0)
+        if (!courier_begin(s_ring, s_cour, ctl_rw))
             return;
         if (threadIdx.x >= 64) {
-            // ---- the courier ------------------------------------------------------------
-            const long long R0c = P.ctl[0];
-            size_t zoff = (size_t)(P.M0 + R0c * P.nchains) * ZS + (size_t)c * ZS + lane;
-            const size_t stride = (size_t)P.nchains * ZS;
-            PeerTable<double> peers;
-            if constexpr (P2P)
-                peers.load(P.peerZ, P.npeers);
-            double *const zlocal = own_global(P.Z);
-            (void)zlocal;
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            int sent = 0;
-            bool last = false;
-            for (;;) {
-                double *const slot = s_ring + (sent % COURIER_RING) * ZS;
-                const double v = __hip_atomic_load(slot + kk, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (__any(mine && mc3_bits(v) == ROW_PENDING)) {
-                    // nothing yet.  Once the chain wave has left, one more look: its last row
-                    // went into the ring before the word that says so
-                    if (last)
-                        break;
-                    last = __hip_atomic_load(&s_cour[2], __ATOMIC_ACQUIRE,
-                                             __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
-                    continue;
-                }
-                last = false;
-                if constexpr (P2P) {
-                    if (mine)
-                        peers.store(zoff, v, P.rank);
-                } else {
-                    // (one GPU, an experiment: the courier publishes the row)
-                    if (mine)
-                        __hip_atomic_store(zlocal + zoff, v, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (mine)
-                    __hip_atomic_store(slot + lane, mc3_from_bits(ROW_PENDING), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-                ++sent;
-                zoff += stride;
-                if ((sent & 7) == 0)
-                    __hip_atomic_store(&s_cour[1], sent, __ATOMIC_RELEASE,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            courier_run<P2P>(P, s_ring, s_cour, lane, nf, c);
             return;
         }
     } else {
@@ -140,6 +84,9 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
         peers_lp.load(P.peerLP, P.npeers);
     }
     (void)peers_z; (void)peers_lp;
+    DelayedRows late;
+    late.begin(P, P.ctl[0], c, lane);
+    (void)late;
     MC3_STAMP(0);
     DataTile<1, MT> tile;
     tile.load(P);
@@ -338,33 +285,24 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
         // Z append, chain.py:276-289: publish the row ...
         if constexpr (COURIER) {
             // ... into the local replica, and hand it to the courier for the others
-            if (mine) {
-                if constexpr (P2P)
+            if constexpr (P2P) {
+                if (mine)
                     __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(&s_ring[(handed % COURIER_RING) * ZS + lane], xk,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            ++handed;
-            // (never a whole ring ahead: looked at once in 16 rows)
-            if (__builtin_expect((handed & 15) == 0, 0)) {
-                while (handed - __hip_atomic_load(&s_cour[1], __ATOMIC_ACQUIRE,
-                                                  __HIP_MEMORY_SCOPE_WORKGROUP) >
-                       COURIER_RING - 16) {
-                    if (__hip_atomic_load(&ctl_rw[CTL_ABORT], __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                        alive = false;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                if (__builtin_expect(!alive, 0))
-                    break;
-            }
+            alive = courier_hand(s_ring, s_cour, handed, lane, mine, xk, ctl_rw);
+            if (__builtin_expect(!alive, 0))
+                break;
         } else if constexpr (P2P) {
             const size_t zoff = (size_t)(zblock - P.Z) + (size_t)c * ZS + lane;
-            if (mine)
+            if (__builtin_expect(P.remote_delay != 0, 0)) {           // test hook
+                if (mine)
+                    __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+                late.hand(P, s_ring, peers_z, lane, mine, xk);
+            } else if (mine) {
                 peers_z.store(zoff, xk);                             // ... into every replica
+            }
         } else {
             if (mine)
                 __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
@@ -384,7 +322,11 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
         rdone = R + 1;
     }
     if constexpr (COURIER)                       // (the courier drains the ring and leaves)
-        __hip_atomic_store(&s_cour[2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        courier_end(s_cour);
+    if constexpr (P2P && !COURIER) {
+        if (P.remote_delay != 0)
+            late.drain(P, s_ring, peers_z, lane, mine, true);
+    }
     flush_columns((int)(rdone - R0) & 63);       // the unwritten tail (also after an early exit)
     if (mine)
         P.X[(size_t)lc * nf + lane] = xk;
@@ -1009,6 +951,269 @@ out:
     flush_columns((int)(rdone - R0) & 63);
     if (mine)
         P.X[(size_t)lc * MT + lane] = xk;
+    if (lane == 0) {
+        P.chisq[lc] = cur;
+        P.best_chisq[lc] = best;
+        P.numaccept[lc] = nacc0 + nacc;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// DEMC in the DECLARED MULTI-GPU CADENCE (mc3hip_problem.zlag = D >= 1): during refresh R a chain
+// sees the others through the rows of refresh R - 1 - D (the initial snapshot until there is
+// one) -- oracle_lockstep.c ls_run states it.  In the strict lockstep an iteration is
+// "wait for the partners' rows of the iteration before, then compute": 0.53 us of hand-off on
+// one chip in front of 0.63 us of arithmetic, and h_x in front of it across xGMI (DESIGN.md
+// section 7).  With D >= 1 the rows an iteration needs were published D iterations ago: they
+// have D iterations' time to cross the fabric, and an iteration costs max(arithmetic, h_x / D).
+// Nothing is waited for in the common case, so the loop is lean_demc_thin_kernel's: the draws
+// of 64 iterations at once, one per lane; the two rows of the NEXT iteration asked for first
+// thing by loads the compiler does not see (handoff.h load_published_async: one load site, one
+// wait site) and retired behind this iteration's store; a row that is still the sentinel --
+// D x the iteration time shorter than the hop -- is asked for again the usual way.
+//   any thinning (the `thinning` iterations of a refresh look at the same rows);
+//   FX: some coefficients fixed or shared, Gaussian priors (as lean_demc_kernel's);
+//   P2P: the ensemble is sharded over GPUs -- rows are read from the local replica at system
+//   scope, published into it, and carried to the other replicas by the COURIER wave (handoff.h;
+//   without it the chain wave stores them itself: more than two ranks sharing a device).
+// Same draws, same arithmetic, same results as run_chain's with the same zlag -- on one GPU or
+// sharded over any number of them.
+template <int MT, bool P2P = false, bool FX = false, bool COURIER = false>
+__global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_lag_kernel(const DevProblem P,
+                                                                          const int nref)
+{
+    static_assert(!COURIER || P2P, "the courier carries rows to other ranks' replicas");
+    constexpr int ZS = ZROW;
+    constexpr int NB = 64;                     // iterations per batch of draws (one per lane)
+    const int nf = FX ? P.nfree : MT;
+    const int lane = COURIER ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    const int lc = blockIdx.x;
+    const int c = P.chain0 + lc;
+    const bool mine = lane < nf;
+    const int kk = mine ? lane : 0;
+    long long *ctl_rw = const_cast<long long *>(P.ctl);
+    __shared__ double s_ring[P2P ? COURIER_RING * ZROW : 1];
+    __shared__ int s_cour[4];
+    (void)s_ring; (void)s_cour;
+    if constexpr (COURIER) {
+        if (!courier_begin(s_ring, s_cour, ctl_rw))
+            return;
+        if (threadIdx.x >= 64) {
+            courier_run<true>(P, s_ring, s_cour, lane, nf, c);
+            return;
+        }
+    } else {
+        if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
+                &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+            return;
+    }
+    int handed = 0;
+    (void)handed;
+    PeerTable<double> peers_z, peers_lp;
+    if constexpr (P2P) {
+        if constexpr (!COURIER)
+            peers_z.load(P.peerZ, P.npeers);
+        peers_lp.load(P.peerLP, P.npeers);
+    }
+    (void)peers_z; (void)peers_lp;
+    DelayedRows late;
+    late.begin(P, P.ctl[0], c, lane);
+    (void)late;
+    DataTile<1, MT> tile;
+    tile.load(P);
+    const long long R0 = P.ctl[0];
+    const int n = P.nchains;
+    const int th = P.thinning;
+    const long long D = P.zlag;
+    const size_t blockstride = (size_t)n * ZS;
+    // the rows refresh R looks at: of refresh R - 1 - D
+    auto seen_by = [&](long long R) -> const double * {
+        const long long Rs = R - 1 - D;
+        return (Rs < 0) ? P.snap0 : P.Z + (size_t)(P.M0 + Rs * n) * ZS;
+    };
+    const double *own = (R0 == 0) ? P.snap0 : P.Z + (size_t)(P.M0 + (R0 - 1) * n) * ZS;
+    const double *sb = seen_by(R0);
+    double *zblock = P.Z + (size_t)(P.M0 + R0 * n) * ZS;
+    double *lp_row = P.log_post + (P.M0 + R0 * n + c);
+    int32_t *zc_row = P.zchain + (P.M0 + R0 * n + c);
+    double xk = mine ? own[(size_t)c * ZS + lane] : 0.0;
+    double cur = P.chisq[lc];
+    double best = P.best_chisq[lc];
+    const long long nacc0 = P.numaccept[lc];
+    const double pmin_k = mine ? P.fmin[lane] : 0.0;
+    const double pmax_k = mine ? P.fmax[lane] : 0.0;
+    const double gamma = P.gamma, feps = P.fepsilon;
+    const long long abort_at = (P.test_abort >= 0 && lc == 0) ? (long long)P.test_abort : -1;
+    long long nacc = 0;
+    double lpbuf = 0.0;
+    int kf[MT];
+    double fx[MT];
+    if constexpr (FX)
+        coefficient_map<MT>(P, kf, fx);
+    (void)kf; (void)fx;
+    // lane i: the draws of iteration bbase + i (chain.py:221-232, :259)
+    double bu = 0.0, blo = 0.0, bhi = 0.0;
+    int bo1 = 0, bo2 = 0;
+    long long bbase = R0 * th;
+    auto fill = [&](long long base) {
+        const Draw2 dd = draw2(P.seed, (uint64_t)(base + lane), (uint32_t)c, 0u);
+        bu = u01(dd.q1);
+        accept_window(bu, blo, bhi);
+        int q1, q2;
+        demc_partners(dd.q0, n, c, q1, q2);
+        bo1 = q1 * ZS;
+        bo2 = q2 * ZS;
+        bbase = base;
+    };
+    struct Step {
+        double u, lo, hi;
+        const double *addr[2];
+        double val[2];
+    };
+    // (`it` inside the current batch; `snap`: the rows its refresh looks at)
+    auto prepare = [&](long long it, const double *snap, Step &S) {
+        const int idx = (int)(it - bbase);
+        S.addr[0] = snap + (__builtin_amdgcn_readlane(bo1, idx) + kk);
+        S.addr[1] = snap + (__builtin_amdgcn_readlane(bo2, idx) + kk);
+        S.val[0] = load_published_async<P2P>(S.addr[0]);
+        S.val[1] = load_published_async<P2P>(S.addr[1]);
+        S.u = read_lane(bu, idx);
+        S.lo = read_lane(blo, idx);
+        S.hi = read_lane(bhi, idx);
+    };
+    fill(R0 * th);
+    Step S;
+    double spare = 0.0;                        // (published_arrived takes three)
+    prepare(R0 * th, sb, S);
+    published_arrived<0>(S.val[0], S.val[1], spare);
+    // (... and so is everything else loaded so far: a load the compiler knows of, still pending
+    // at the loop head, would make it guard its registers with a wait INSIDE the loop)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    const long long Rend = R0 + nref;
+    long long rdone = R0;
+    auto flush_columns = [&](int count) {
+        if (lane < count) {
+            if constexpr (P2P) {
+                const size_t roff = (size_t)(lp_row - P.log_post) + (size_t)lane * n;
+                peers_lp.store(roff, lpbuf);
+            } else {
+                lp_row[(size_t)lane * n] = lpbuf;
+            }
+            zc_row[(size_t)lane * n] = c;
+        }
+    };
+    bool alive = true;
+    for (long long R = R0; R < Rend; ++R) {
+        if (__builtin_expect(R == abort_at, 0)) {                                         // test hook
+            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        const double *const sb_next = seen_by(R + 1);
+        for (int j = 0; j < th; ++j) {
+            const long long it = R * th + j;
+            Step C = S;
+            if (__builtin_expect(it + 1 - bbase == NB, 0))
+                fill(it + 1);
+            // the next iteration's rows: of the same refresh, or -- behind the last iteration of
+            // this refresh -- those the next refresh looks at, published D refreshes ago
+            Step Nx;
+            prepare(it + 1, (j + 1 < th) ? sb : sb_next, Nx);
+            if (__builtin_expect(__any(mc3_bits(C.val[0]) == ROW_PENDING ||
+                                       mc3_bits(C.val[1]) == ROW_PENDING), 0)) {
+                const double *const a2[2] = {C.addr[0], C.addr[1]};
+                double v2[2] = {C.val[0], C.val[1]};
+                alive = wait_rows<2, P2P>(a2, v2, ctl_rw);
+                // (nothing this path asked for is pending where it joins the other)
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                asm volatile("; rows of this iteration" : "+v"(v2[0]), "+v"(v2[1]));
+                C.val[0] = v2[0];
+                C.val[1] = v2[1];
+                if (__builtin_expect(!alive, 0))
+                    goto out;
+            }
+            // proposal and boundaries, chain.py:232-243
+            const double jump_k = gamma * (C.val[0] - C.val[1]) + feps * 0.0;
+            const double npk = xk + jump_k;
+            const bool outk = mine && (npk < pmin_k || npk > pmax_k);
+            if (__builtin_expect(!__any(outk), 1)) {
+                Model<MT> model;
+                if constexpr (!FX)
+                    model.init_from_lanes(P, npk);
+                else
+                    model.init_from_lanes(P, npk, kf, fx);
+                double nextchisq =
+                    block_gauss_model<1, MT, false, false>(P, model, nullptr, nullptr, tile,
+                                                           &tile);           // chain.py:249
+                if constexpr (FX)
+                    nextchisq = nextchisq + prior_from_lanes<MT>(P, npk, kf, fx);
+                const bool acc = metropolis_accept(0.5 * (cur - nextchisq), C.u, C.lo, C.hi);
+                xk = acc ? npk : xk;
+                if (__builtin_expect(__any(acc && nextchisq < best), 0)) {
+                    best = nextchisq;
+                    if (mine)
+                        P.bestx[(size_t)lc * nf + lane] = xk;
+                    if (lane == 0)
+                        P.best_iter[lc] = it;
+                }
+                cur = acc ? nextchisq : cur;
+                nacc += acc ? 1 : 0;
+            } else if (outk) {
+                atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
+            }
+            // Z append behind the last iteration of the refresh, chain.py:276-289; the others
+            // leave the state where the kernel leaves it in the end, so that ONE store follows
+            // the loads of the next iteration's rows either way and one wait serves both
+            if (mine) {
+                if (j + 1 == th)
+                    __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
+                                       P2P ? __HIP_MEMORY_SCOPE_SYSTEM
+                                           : __HIP_MEMORY_SCOPE_AGENT);  // publish (sc1)
+                else
+                    __hip_atomic_store(&P.X[(size_t)lc * nf + lane], xk, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            published_arrived<1>(Nx.val[0], Nx.val[1], spare);
+            S = Nx;
+            // ... and to the other ranks' replicas: the courier's business, or -- without one --
+            // behind the wait, so that the rows just asked for do not queue behind these stores
+            if constexpr (P2P) {
+                if (j + 1 == th) {
+                    if constexpr (COURIER) {
+                        alive = courier_hand(s_ring, s_cour, handed, lane, mine, xk, ctl_rw);
+                        if (__builtin_expect(!alive, 0))
+                            goto out;
+                    } else if (__builtin_expect(P.remote_delay != 0, 0)) {     // test hook
+                        late.hand(P, s_ring, peers_z, lane, mine, xk);
+                    } else if (mine) {
+                        peers_z.store((size_t)(zblock - P.Z) + (size_t)c * ZS + lane, xk, P.rank);
+                    }
+                }
+            }
+        }
+        {
+            const int slot = (int)(R - R0) & 63;
+            lpbuf = (lane == slot) ? -0.5 * cur : lpbuf;
+            if (__builtin_expect(slot == 63, 0)) {
+                flush_columns(64);
+                lp_row += (size_t)64 * n;
+                zc_row += (size_t)64 * n;
+            }
+        }
+        sb = sb_next;
+        zblock += blockstride;
+        rdone = R + 1;
+    }
+out:
+    if constexpr (COURIER)
+        courier_end(s_cour);
+    if constexpr (P2P && !COURIER) {
+        if (P.remote_delay != 0)
+            late.drain(P, s_ring, peers_z, lane, mine, true);
+    }
+    flush_columns((int)(rdone - R0) & 63);
+    if (mine)
+        P.X[(size_t)lc * nf + lane] = xk;
     if (lane == 0) {
         P.chisq[lc] = cur;
         P.best_chisq[lc] = best;

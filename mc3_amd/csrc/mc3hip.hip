@@ -217,7 +217,8 @@ void launch_resident(mc3hip_ctx *c, int nref)
 // dynamic LDS of the lean kernels: the hand-laid-out loop uses none
 size_t fast_smem(const mc3hip_ctx *c)
 {
-    return (c->P.sampler != MC3HIP_MRW && lean_demc_eligible(c)) ? 0 : c->smem;
+    return ((c->P.sampler != MC3HIP_MRW && lean_demc_eligible(c)) || lean_demc_lag_eligible(c))
+               ? 0 : c->smem;
 }
 
 // (several chains per workgroup, run_chain MC: a smaller grid, the chains' waiting state in
@@ -473,6 +474,19 @@ int decide_persist(mc3hip_ctx *c)
     capacity = capacity < cap_limit ? capacity : cap_limit;
     if (nb < 1)
         return 0;
+    if (c->fast && c->P.nlocal > capacity && lag_demc_shape(c) && !lean_plain_shape(c) &&
+        (c->P.thinning != 1 || (c->flags & MC3HIP_FLAG_P2P))) {
+        // fixed coefficients / priors with thinning > 1 or peer to peer: only the one-chain-per-
+        // wave loop of the declared cadence is lean there; more chains than it can hold run the
+        // general chain
+        c->fast = false;
+        persist_blocks_per_cu(c, &nb);
+        const int pc = (nb > 1 && getenv("MC3HIP_PERSIST_MARGIN")) ? nb - 1 : nb;
+        capacity = (long long)pc * prop.multiProcessorCount;
+        capacity = capacity < cap_limit ? capacity : cap_limit;
+        if (nb < 1)
+            return 0;
+    }
     if (c->P.nlocal > capacity) {
         // More chains than workgroups can be co-resident: a workgroup advances several per
         // refresh (run_chain MC), as the reference's workers do with their ncpp chains
@@ -677,6 +691,8 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         return fail(MC3HIP_ERR_ARG, "demc needs at least 3 chains (chain.py:223-229)");
     if (pr->thinning < 1)
         return fail(MC3HIP_ERR_ARG, "thinning must be >= 1");
+    if (pr->zlag < 0 || pr->zlag > 64)
+        return fail(MC3HIP_ERR_ARG, "zlag=%d outside [0,64]", pr->zlag);
     if (pr->model_kind != MC3HIP_MODEL_POLY && pr->model_kind != MC3HIP_MODEL_LINEAR)
         return fail(MC3HIP_ERR_ARG, "unknown model family %d", pr->model_kind);
     const int noise = pr->wlike ? 3 : 0;
@@ -993,6 +1009,11 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
     P.test_abort = -1;
     if (const char *ta = getenv("MC3HIP_TEST_ABORT_AT"))
         P.test_abort = atoi(ta);
+    P.zlag = pr->zlag;
+    // test hook: rows for another rank's replica are held back (ticks of the 100 MHz clock)
+    P.remote_delay = 0;
+    if (const char *rd = getenv("MC3HIP_TEST_REMOTE_DELAY_NS"))
+        P.remote_delay = atoi(rd) > 0 ? (atoi(rd) + 5) / 10 : 0;
     {
         // checkpoint area: X, bestx [nl*nf]; chisq, best_chisq [nl]; numaccept,
         // best_iter [nl]; outbounds [nf] -- all 8-byte words
@@ -1094,7 +1115,7 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
                      ? ((lean_demc_eligible(c) || lean_demc_mc_eligible(c) ||
                          lean_snooker_eligible(c) || lean_mrw_eligible(c) ||
                          lean_snooker_mc_eligible(c) || lean_mrw_mc_eligible(c) ||
-                         lean_demc_thin_eligible(c)) ? 2 : 1) : 0;
+                         lean_demc_thin_eligible(c) || lean_demc_lag_eligible(c)) ? 2 : 1) : 0;
     if (plan->fast == 2 && c->p2p_ranks <= 1)
         plan->waves_per_chain = lean_waves(c);      // (helper waves share the data sum)
     if (plan->persistent > 0 && chainwave_runs(c, c->p2p_ranks > 1) && c->P.cw_lean)
@@ -1106,6 +1127,8 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
     plan->comm_graph = c->cgraph_exec ? c->comm_graph_nodes : 0;
     plan->recoveries = c->recoveries;
     plan->chains_per_workgroup = (plan->persistent > 0 && c->mc_chains > 0) ? c->mc_chains : 1;
+    plan->zlag = c->P.zlag;
+    plan->remote_delay_ns = c->P.remote_delay * 10;
     return MC3HIP_OK;
 }
 
@@ -1404,6 +1427,78 @@ int mc3hip_sync(mc3hip_ctx *c)
     if (!c)
         return fail(MC3HIP_ERR_ARG, "null context");
     return settle(c);
+}
+
+// Streaming runs: the last `keep` refreshes move to the front of the chain rows, the rest of
+// Z is unwritten again, the run carries on under a new Philox key (include/mc3hip.h).
+int mc3hip_recycle(mc3hip_ctx *c, int64_t keep, uint64_t seed)
+{
+    if (!c)
+        return fail(MC3HIP_ERR_ARG, "null context");
+    if (!c->populated)
+        return fail(MC3HIP_ERR_STATE, "mc3hip_set_population has not been called");
+    DevProblem &P = c->P;
+    if (P.sampler == MC3HIP_SNOOKER)
+        return fail(MC3HIP_ERR_ARG, "snooker draws from the whole history (chain.py:197-205): "
+                                    "its Z cannot be recycled");
+    if (keep < 1 + (int64_t)P.zlag)
+        return fail(MC3HIP_ERR_ARG, "keep=%lld: the next refresh looks %d refreshes back",
+                    (long long)keep, 1 + P.zlag);
+    {
+        const int rc_settle = settle(c);
+        if (rc_settle)
+            return rc_settle;
+    }
+    const int64_t done = c->refresh_done;
+    if (done < 2 * keep)
+        return fail(MC3HIP_ERR_STATE, "only %lld refreshes done: nothing to recycle with keep=%lld",
+                    (long long)done, (long long)keep);
+    if (c->comm)
+        RC_TRY(mc3hip_comm_gather_log_post(c));
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)P.nchains, zs = (size_t)P.zs;
+    const size_t from = (size_t)(P.M0 + (done - keep) * P.nchains), to = (size_t)P.M0;
+    const size_t rows = (size_t)keep * n, rest = (size_t)(done - keep) * n;
+    HIP_TRY(hipMemcpyAsync(P.Z + to * zs, P.Z + from * zs, rows * zs * sizeof(double),
+                           hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(P.log_post + to, P.log_post + from, rows * sizeof(double),
+                           hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(P.zchain + to, P.zchain + from, rows * sizeof(int32_t),
+                           hipMemcpyDeviceToDevice, c->stream));
+    // (unwritten again: the all-ones pattern the hand-off reads as "not there yet")
+    HIP_TRY(hipMemsetAsync(P.Z + (to + rows) * zs, 0xff, rest * zs * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(P.zchain + to + rows, 0xff, rest * sizeof(int32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(P.log_post + to + rows, 0, rest * sizeof(double), c->stream));
+    if (P.rs_prop) {
+        HIP_TRY(hipMemsetAsync(P.rs_prop, 0xff, 2 * (size_t)P.nlocal * RS_ROW * sizeof(double),
+                               c->stream));
+        HIP_TRY(hipMemsetAsync(P.rs_part, 0xff, (size_t)P.nlocal * P.rs_ntp * sizeof(double),
+                               c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // captured launches carry the problem (and its key) by value: capture again
+    if (c->graph_exec) {
+        (void)hipGraphExecDestroy(c->graph_exec);
+        c->graph_exec = nullptr;
+    }
+    if (c->graph) {
+        (void)hipGraphDestroy(c->graph);
+        c->graph = nullptr;
+    }
+    if (c->cgraph_exec) {
+        (void)hipGraphExecDestroy(c->cgraph_exec);
+        c->cgraph_exec = nullptr;
+    }
+    if (c->cgraph) {
+        (void)hipGraphDestroy(c->cgraph);
+        c->cgraph = nullptr;
+    }
+    P.seed = seed;
+    c->refresh_done = keep;
+    c->ckpt_valid = false;
+    c->ckpt_settled = false;
+    c->logpost_gathered = keep;
+    return MC3HIP_OK;
 }
 
 int mc3hip_last_run_ms(mc3hip_ctx *c, float *ms)

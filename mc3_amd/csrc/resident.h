@@ -498,8 +498,11 @@ __device__ __forceinline__ void lean_resident_owner(const DevProblem &P, const i
     // and is asked for again
     const double *ra[2] = {nullptr, nullptr};
     double rv[2] = {0.0, 0.0};
+    const long long zlag = P.zlag;
     auto request_rows = [&](uint64_t q0, long long R) {
-        const double *snap = (R == 0) ? snap0 : Zr + (size_t)(M0 + (R - 1) * nchains) * zs;
+        // (zlag > 0, the declared multi-GPU cadence: the rows of refresh R - 1 - zlag)
+        const long long Rs = R - 1 - zlag;
+        const double *snap = (Rs < 0) ? snap0 : Zr + (size_t)(M0 + Rs * nchains) * zs;
         int r1, r2;
         demc_partners(q0, nchains, c, r1, r2);
         ra[0] = snap + (size_t)r1 * zs + kk;
@@ -576,13 +579,11 @@ __device__ __forceinline__ void lean_resident_owner(const DevProblem &P, const i
         MC3_TICK(tk3);
         // Z append, chain.py:276-289
         const long long row = M0 + R * nchains + c;
-        if (mine) {
-            if constexpr (P2P) {
-                peers_z.store((size_t)row * zs + lane, xk);          // publish everywhere
-            } else {
-                __hip_atomic_store(&Zr[(size_t)row * zs + lane], xk, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);       // publish (sc1)
-            }
+        if constexpr (P2P) {
+            store_row_everywhere(P, peers_z, (size_t)row * zs + lane, xk, mine);   // publish
+        } else if (mine) {
+            __hip_atomic_store(&Zr[(size_t)row * zs + lane], xk, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);           // publish (sc1)
         }
         // the partners' rows of this refresh: asked for right behind the own row
         request_rows(nxt.q0, R + 1);

@@ -96,6 +96,19 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     // the middle of a refresh (tiled plan, thinning > 1) it is the saved state
     const double *snap_first = (R0 == 0) ? P.snap0
                                          : P.Z + (size_t)(P.M0 + (R0 - 1) * P.nchains) * zs;
+    // What refresh R sees of the OTHER chains: the rows of refresh R - 1 - zlag (DEMC partners)
+    // and the history up to and including that refresh (snooker).  zlag = 0 is the strict
+    // lockstep; the declared cadence of a run sharded over GPUs looks zlag refreshes further
+    // back (mc3hip_problem.zlag), the initial snapshot standing in until there is such a refresh.
+    const long long zlag = P.zlag;
+    auto snapshot_of = [&](long long R) -> const double * {
+        const long long Rs = R - 1 - zlag;
+        return (Rs < 0) ? P.snap0 : P.Z + (size_t)(P.M0 + Rs * P.nchains) * zs;
+    };
+    auto history_of = [&](long long R) -> long long {
+        const long long Rs = R - zlag;
+        return P.M0 + (Rs > 0 ? Rs : 0) * P.nchains;
+    };
     double xk = 0.0;
     if (mine)
         xk = (jb == 0) ? snap_first[(size_t)c * zs + lane] : P.X[(size_t)lc * nf + lane];
@@ -194,7 +207,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     batch.base = -(long long)DRAW_BATCH - 1;      // empty
     if constexpr (SNOOKER_AHEAD) {
         if (sampler == MC3HIP_SNOOKER && wave0)
-            request_snooker(nxt, P.M0 + R0 * P.nchains);
+            request_snooker(nxt, history_of(R0));
     }
     // diagnostic build only: per-phase tick sums kept in registers, stored once at exit
     unsigned long long tk_prev3 = 0, tk_prevend = 0;
@@ -260,9 +273,8 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 return;
         }
     }
-    const double *snap = (R == 0) ? P.snap0
-                                  : P.Z + (size_t)(P.M0 + (R - 1) * P.nchains) * zs;
-    const long long zsize = P.M0 + R * P.nchains;
+    const double *snap = snapshot_of(R);
+    const long long zsize = history_of(R);
     const int jfirst = (TH == 1) ? 0 : jb;
     const int jlast = (TH == 1) ? 1 : je;
     for (int q = 0; q < mc_turns; ++q) {        // (MC: the chains of this workgroup in turn)
@@ -350,7 +362,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                     // the next iteration's rows: its history also holds this refresh's rows
                     // once this iteration is the last of the refresh
                     if (SNOOKER_AHEAD && PHASE != PH_CHAINWAVE && alive)
-                        request_snooker(nxt, ahead_new_refresh ? zsize + P.nchains : zsize);
+                        request_snooker(nxt, ahead_new_refresh ? history_of(R + 1) : zsize);
                 } else {
                     z1 = mine ? P.Z[(size_t)iR1 * zs + lane] : 0.0;
                     z2 = mine ? P.Z[(size_t)iR2 * zs + lane] : 0.0;
@@ -513,7 +525,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                             bool new_refresh;
                             nxt = draws_ahead(iter, last_j, q, new_refresh);
                             if (sampler == MC3HIP_SNOOKER)
-                                request_snooker(nxt, new_refresh ? zsize + P.nchains : zsize);
+                                request_snooker(nxt, new_refresh ? history_of(R + 1) : zsize);
                         }
                         if (need_normal) {
                             normal_ahead = normal_draw(iter + 1, c);
@@ -656,9 +668,10 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     // Z append, chain.py:276-289 (strided slot M0 + ID + k*nchains)
     if (wave0 && (TH == 1 || je == P.thinning)) {
         const long long row = P.M0 + R * P.nchains + c;
+        if constexpr (P2P)
+            store_row_everywhere(P, peers_z, (size_t)row * zs + lane, xk, mine);   // publish
         if (mine) {
             if constexpr (P2P) {
-                peers_z.store((size_t)row * zs + lane, xk);          // publish everywhere
             } else if constexpr (PERSIST) {
                 __hip_atomic_store(&P.Z[(size_t)row * zs + lane], xk, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);      // publish (sc1)

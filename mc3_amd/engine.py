@@ -29,7 +29,7 @@ class DeviceChains:
                  nsamples=None, sampler='snooker', wlike=False, thinning=1,
                  fgamma=1.0, fepsilon=0.0, hsize=10, model='poly', nmodel=None,
                  seed=0, device=0, chain0=0, nlocal=None, M0=None, zlen=None,
-                 trace_iters=0, no_graph=False, no_persist=False, p2p=False):
+                 trace_iters=0, no_graph=False, no_persist=False, p2p=False, zlag=0):
         self._ctx = None
         self.lib = _lib.load()
         self.params = f64(params).copy()
@@ -97,6 +97,9 @@ class DeviceChains:
         P.M0, P.zlen = self.M0, self.zlen
         P.seed = self.seed
         P.gamma, P.fepsilon = self.gamma, self.fepsilon
+        # the declared cadence of a run sharded over GPUs (include/mc3hip.h mc3hip_problem.zlag)
+        self.zlag = int(zlag)
+        P.zlag = self.zlag
         for name in ('params', 'pstep', 'pmin', 'pmax', 'prior', 'priorlow',
                      'priorup', 'indep', 'data', 'uncert'):
             setattr(P, name, dptr(getattr(self, name)))
@@ -118,7 +121,8 @@ class DeviceChains:
                 'persistent': plan.persistent, 'fast': plan.fast,
                 'comm_graph': plan.comm_graph, 'recoveries': plan.recoveries,
                 'tile_tree': plan.tile_tree, 'resident': plan.resident,
-                'chains_per_workgroup': plan.chains_per_workgroup}
+                'chains_per_workgroup': plan.chains_per_workgroup,
+                'zlag': plan.zlag, 'remote_delay_ns': plan.remote_delay_ns}
 
     # -- lifetime --------------------------------------------------------------
     def close(self):
@@ -174,6 +178,14 @@ class DeviceChains:
 
     def sync(self):
         check(self.lib.mc3hip_sync(self._ctx))
+
+    def recycle(self, keep=None, seed=None):
+        """Streaming runs (mc3hip_recycle): the last ``keep`` refreshes (default 1 + zlag, what
+        the next refresh looks at) become the first ones, the rest of Z is free again, the
+        chains carry on under the Philox key ``seed`` (default: the old key + 1)."""
+        keep = 1 + self.zlag if keep is None else int(keep)
+        self.seed = (self.seed + 1) % (1 << 64) if seed is None else int(seed)
+        check(self.lib.mc3hip_recycle(self._ctx, keep, self.seed))
 
     def last_run_ms(self):
         ms = ctypes.c_float()

@@ -54,7 +54,11 @@ typedef struct {
     int32_t ngprior;
     int32_t tile, vlanes;
     int32_t wl_threads;     /* wavelet path: threads that share a chain (64 * waves) */
-    int32_t tile_tree, _pad_tree;   /* 1: 64 partial sums at a time, then the group totals */
+    int32_t tile_tree;      /* 1: 64 partial sums at a time, then the group totals */
+    int32_t zlag;           /* declared cadence of the multi-GPU runs: the other chains are
+                             * seen `zlag` refreshes later -- DEMC partners of refresh R are the
+                             * rows of refresh R-1-zlag (the initial snapshot before there is
+                             * one), snooker's history ends with refresh R-1-zlag; 0 = strict */
     int64_t M0, zlen;
     uint64_t seed;
     double gamma, fepsilon;
@@ -748,9 +752,14 @@ int ls_run(const ls_problem *P, ls_state *St, int64_t nrefresh, int nthreads)
         for (int k = 0; k < nf; k++)
             S.normal[k] = 0.0;
         for (int64_t R = R0; R < R0 + nrefresh; R++) {
-            const double *snap = (R == 0) ? St->snap0
-                               : St->Z + (size_t)(P->M0 + (R - 1) * P->nchains) * nf;
-            const int64_t zsize = P->M0 + R * P->nchains;
+            /* what this refresh sees of the other chains: the rows of refresh R-1-zlag
+             * (zlag = 0: of the refresh before -- per-iteration Jacobi; the declared
+             * cadence of a run sharded over GPUs looks zlag refreshes further back, so
+             * that a row has the time of zlag iterations to cross the fabric) */
+            const int64_t Rs = R - 1 - (int64_t)P->zlag;
+            const double *snap = (Rs < 0) ? St->snap0
+                               : St->Z + (size_t)(P->M0 + Rs * P->nchains) * nf;
+            const int64_t zsize = P->M0 + (Rs + 1 > 0 ? Rs + 1 : 0) * P->nchains;
             const int64_t row0 = P->M0 + R * P->nchains;
 #ifdef _OPENMP
 #pragma omp for schedule(static)

@@ -113,3 +113,80 @@ def test_lockstep_samples_the_reference_posterior():
         assert np.all(np.abs(a.std(axis=0)/sd - 1.0) < 0.15)
         rate = orc.numaccept.sum()/(orc.nzchain*orc.nchains)
         assert 0.05 < rate < 0.6
+
+
+# ---- the declared multi-GPU cadence (zlag >= 1, oracle_lockstep.c ls_run) -----------------
+@pytest.mark.parametrize('sampler,thinning,zlag', [('demc', 1, 1), ('demc', 1, 4),
+                                                   ('snooker', 1, 3), ('demc', 3, 2)])
+def test_lagged_cadence_is_sharding_invariant_and_needs_only_late_rows(sampler, thinning, zlag):
+    """Two 'ranks' that own half of the chains each reproduce the unsharded run of the same
+    zlag bit for bit -- even though a rank receives the other's rows of refresh R only AFTER
+    it has computed refresh R + zlag (the point of the cadence: a row has zlag refreshes' time
+    to arrive; until then its place holds NaNs, which would poison a chain that looked)."""
+    prob = H.quad_problem(sampler=sampler, thinning=thinning, nchains=8,
+                          nsamples=8*50*thinning)
+    full = run_oracle(prob, zlag=zlag)
+    strict = run_oracle(prob)
+    assert not np.array_equal(full.Z, strict.Z)          # (another cadence, another trajectory)
+    halves = [H.make_oracle(prob, chain0=0, nlocal=4, zlag=zlag),
+              H.make_oracle(prob, chain0=4, nlocal=4, zlag=zlag)]
+    Z0, lp0 = H.initial_population(halves[0])
+    for h in halves:
+        h.set_population(Z0, lp0)
+        h.Z[h.M0:] = np.nan
+    n = full.nchains
+    for R in range(full.nzchain):
+        for h in halves:
+            h.run(nrefresh=1)
+        # the exchange delivers what was produced zlag refreshes ago
+        Rl = R - zlag
+        if Rl >= 0:
+            r0 = full.M0 + Rl*n
+            halves[0].Z[r0 + 4:r0 + 8] = halves[1].Z[r0 + 4:r0 + 8]
+            halves[1].Z[r0:r0 + 4] = halves[0].Z[r0:r0 + 4]
+    for R in range(max(0, full.nzchain - zlag), full.nzchain):
+        r0 = full.M0 + R*n
+        halves[0].Z[r0 + 4:r0 + 8] = halves[1].Z[r0 + 4:r0 + 8]
+        halves[1].Z[r0:r0 + 4] = halves[0].Z[r0:r0 + 4]
+    np.testing.assert_array_equal(halves[0].Z, full.Z)
+    np.testing.assert_array_equal(halves[1].Z, full.Z)
+    np.testing.assert_array_equal(halves[0].numaccept + halves[1].numaccept, full.numaccept)
+
+
+def test_lagged_cadence_first_refreshes_see_the_initial_snapshot():
+    """DEMC with zlag = 2: refreshes 0..2 all draw their partners from the first nchains rows
+    of the initial population (there is no refresh R - 3 yet), refresh 3 from refresh 0 --
+    checked by poisoning exactly the rows that must not be looked at."""
+    prob = H.quad_problem(sampler='demc', nchains=8, nsamples=8*6)
+    ref = run_oracle(prob, zlag=2)
+    orc = H.make_oracle(prob, zlag=2)
+    Z0, lp0 = H.initial_population(orc)
+    orc.set_population(Z0, lp0)
+    for R in range(6):
+        orc.run(nrefresh=1)
+        # hide the rows just written from everybody: own state lives in X, and no refresh
+        # before R + 3 may look at them
+        keep = orc.Z[orc.M0 + R*8:orc.M0 + (R + 1)*8].copy()
+        orc.Z[orc.M0 + R*8:orc.M0 + (R + 1)*8] = np.nan
+        if R >= 2:
+            back = R - 2
+            orc.Z[orc.M0 + back*8:orc.M0 + (back + 1)*8] = ref.Z[ref.M0 + back*8:
+                                                                 ref.M0 + (back + 1)*8]
+        assert np.array_equal(keep, ref.Z[ref.M0 + R*8:ref.M0 + (R + 1)*8])
+
+
+def test_lagged_cadence_samples_the_same_posterior():
+    """zlag changes which past states a chain looks at, not what it samples: means and widths
+    of a zlag = 4 run agree with the strict run's within Monte-Carlo error (256 chains would
+    be the production shape; 16 keeps the test short and makes staleness matter more)."""
+    for sampler in ('demc', 'snooker'):
+        prob = H.quad_problem(ndata=100, nchains=16, nsamples=4e4, sampler=sampler)
+        a = run_oracle(prob)
+        b = run_oracle(prob, zlag=4)
+        burn = a.M0 + 16*300
+        sd = a.Z[burn:].std(axis=0)
+        assert np.all(np.abs(a.Z[burn:].mean(axis=0) - b.Z[burn:].mean(axis=0)) < 0.15*sd)
+        assert np.all(np.abs(b.Z[burn:].std(axis=0)/sd - 1.0) < 0.15)
+        ra = a.numaccept.sum()/(a.nzchain*a.nchains)
+        rb = b.numaccept.sum()/(b.nzchain*b.nchains)
+        assert abs(ra - rb) < 0.05
