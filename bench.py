@@ -4,18 +4,21 @@
 Workload (BASELINE.json configs[1], "C2"): quadratic 3-parameter fit,
 ndata=1000, 256 chains per GPU, sampler='demc', thinning=1, fepsilon=0,
 synthetic data as in examples/tutorial.py:22-46 of the reference (SURVEY.md
-section 8d).  A "step" is one batch of `--refreshes` Z refreshes (a whole number of
-launches of the persistent kernel, each 16 384 refreshes = 4.19 M chain-steps per GPU):
-in every refresh every chain of the ensemble advances `thinning` iterations (proposal ->
-model -> chisq -> Metropolis -> Z append).  Whatever --steps/--warmup are given, a step
-is long against launch and synchronisation overheads; the batch is sized so that Z (128 B
-per chain and refresh) fits a memory budget.
+section 8d).  A "step" is one batch of `--refreshes` Z refreshes (default: 18 launches of
+the persistent kernel, each 16 384 refreshes = 4.19 M chain-steps per GPU): in every refresh
+every chain of the ensemble advances `thinning` iterations (proposal -> model -> chisq ->
+Metropolis -> Z append).  Whatever --steps/--warmup are given, a step is long against launch
+and synchronisation overheads, and the default run keeps the GPU busy for seconds on end.
+Z (128 B per chain and refresh) is sized to a memory budget; a run longer than that recycles
+the buffer INSIDE the timed region (mc3hip_recycle: the host has no use for the rows of a
+benchmark; the last refreshes move to the front, the rest is unwritten again, the chains
+carry on) -- config.recycles says how often.
 
     python bench.py [--gpus N --steps K --warmup W] [--workload c2|c3|c5]
 
 N > 1, either way of starting it works:
   * ``python bench.py --gpus N`` as ONE plain process: it never touches the GPU itself,
-    starts N rank processes (RANK / WORLD_SIZE / MC3HIP_RDV_PORT in their environment),
+    starts N rank processes (RANK / WORLD_SIZE / MC3HIP_RDV_FILE / _SECRET in their environment),
     relays rank 0's JSON line, ends everything on a watchdog and exits non-zero if any
     rank failed;
   * ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N``:
@@ -54,7 +57,8 @@ NDATA = 1000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # MI355X_MICROARCH.md: dense FP64 vector / matrix
 LAUNCH_REFRESHES = 16384       # refreshes one launch of a persistent kernel covers
-PMC_FILES = ('r03_c2_pmc.json', 'r02_c2_pmc.json', 'r01g_c2_pmc.json')
+STEP_LAUNCHES = 18             # persistent launches per step (C2: ~0.35 s of GPU time)
+PMC_FILES = ('r04_c2_pmc.json', 'r03_c2_pmc.json', 'r02_c2_pmc.json', 'r01g_c2_pmc.json')
 
 
 def quad(p, x):
@@ -130,7 +134,7 @@ def initial_population(prob, eval_chisq, expand=None):
     return Z0, -0.5*eval_chisq(Z0)
 
 
-def cpu_baseline(target_seconds=12.0):
+def cpu_baseline(target_seconds=10.0):
     """The oracle (oracle/oracle_lockstep.c: the same lockstep chain update in
     plain C, OpenMP over chains) on this box's host cores, same C2 workload,
     bounded to ~target_seconds.  The thread count is the fastest of a short
@@ -170,8 +174,11 @@ def cpu_baseline(target_seconds=12.0):
         'value': CHAINS_PER_GPU*n/dt/1e6, 'unit': 'million chain-steps/sec',
         'cores': best_threads, 'kind': 'port',
         'sample': f'{n} iterations of the same 256-chain C2 workload '
-                  f'({dt:.1f} s), oracle_lockstep.c, {best_threads} OpenMP threads '
-                  f'(best of a calibration up to {usable} usable CPUs)',
+                  f'({dt:.1f} s), oracle_lockstep.c, {best_threads} OpenMP THREADS of one '
+                  f'process with a barrier per refresh (best of a calibration up to {usable} '
+                  'usable CPUs) -- not the processes with chains strided over workers of '
+                  'SURVEY.md 8d(ii); mc3\'s own multiprocessing path cannot travel to the GPU '
+                  'box and is measured in the build container: BASELINE.md section 2b',
     }
 
 
@@ -221,11 +228,11 @@ def launch_ranks(args, argv):
     never initialises the GPU (and never replaces itself: the ranks are children)."""
     from mc3_amd import parallel
     n = args.gpus
-    port = parallel.free_port()
+    rdv = parallel.new_rendezvous()
     deadline = time.monotonic() + float(os.environ.get('MC3HIP_BENCH_WATCHDOG', 900)) + 60.0
     procs = []
     for r in range(n):
-        env = parallel.rank_env(r, n, port)
+        env = parallel.rank_env(r, n, rdv)
         procs.append(subprocess.Popen(
             [sys.executable, os.path.abspath(__file__)] + argv, env=env,
             stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True,
@@ -338,13 +345,9 @@ def run_rank(args):
         nlocal, nchains = wl_chains//world, wl_chains
     chain0 = rank*nlocal
     nsteps, nwarm = max(1, args.steps), max(0, args.warmup)
-    nbatch = nsteps + nwarm
     row_bytes = nchains*(16*8 + 8 + 4)            # padded Z row + log_post + zchain
-    # Z grows with the run: a step is as many whole persistent launches as fit the budget
-    # (at most 6: ~0.12 s of GPU time per step at the headline shape, so that the default
-    # run keeps the GPU busy for seconds, not for the half second the driver's utilisation
-    # sampler would miss); never more than half of the free memory of a GPU, shared by the
-    # ranks on it
+    # Z is sized to a memory budget -- never more than half of the free memory of a GPU,
+    # shared by the ranks on it -- and recycled when a step does not fit any more
     # (several ranks: every rank maps every peer's replica -- 32 GiB each keeps eight of them
     # quick to export, attach and check)
     budget = (96 << 30) if world == 1 else (32 << 30)
@@ -356,22 +359,35 @@ def run_rank(args):
             sys.exit(3)                           # (test hook: a rank that dies)
         R = args.refreshes or 4
     elif args.workload == 'c5':
-        R = args.refreshes or 100                 # (36 us per iteration: 100 per step)
+        R = args.refreshes or 100                 # (~30 us per iteration: 100 per step)
+    elif world == 1:
+        R = args.refreshes or LAUNCH_REFRESHES*STEP_LAUNCHES
     else:
-        fit = budget//(row_bytes*nbatch)
+        # several ranks: the whole run fits Z (re-arming the rows of a 2048-chain ensemble
+        # costs ~0.1 us per refresh against ~0.65 us of work: kept out of the timed region)
+        fit = budget//(row_bytes*(nsteps + nwarm))
         R = args.refreshes or int(LAUNCH_REFRESHES*min(6, fit//LAUNCH_REFRESHES)
                                   if fit >= LAUNCH_REFRESHES else max(64, fit))
     nref_timed, nref_warm = nsteps*R, nwarm*R
     nrefresh = nref_timed + nref_warm
-    prob = build_problem(nchains, nrefresh + 64, args.thinning)
+    fit = max(64, int(budget//row_bytes) - 64)
+    capacity = min(nrefresh + 64, max(fit, 2*min(R, LAUNCH_REFRESHES) + 64))
+    prob = build_problem(nchains, capacity, args.thinning)
     comm = None
     exchange = None
+
+    ctl_opts = {}
 
     def make_engine(p2p, prob=prob, chain0=chain0, nlocal=nlocal):
         if args.dry_run:
             return DryEngine(prob['nchains'], nlocal, chain0, nrefresh)
-        g = engine.DeviceChains(device=local_rank, chain0=chain0, nlocal=nlocal, p2p=p2p,
-                                **prob)
+        # (what the communicator asks of its engine: the declared cadence of a sharded run,
+        # fine-grained Z, no courier wave when more than two ranks share a device)
+        opts = dict(ctl_opts)
+        if not p2p:
+            opts.pop('p2p', None)
+            opts.pop('no_courier', None)
+        g = engine.DeviceChains(device=local_rank, chain0=chain0, nlocal=nlocal, **opts, **prob)
         Z0, lp0 = initial_population(prob, lambda Z: g.eval_chisq(g.expand_free(Z)))
         g.set_population(Z0, lp0)
         return g
@@ -382,6 +398,7 @@ def run_rank(args):
         # refresh.  Every rank takes the same branch.
         comm = ctl
         comm.wants_p2p = not os.environ.get('MC3HIP_BENCH_NO_P2P') and not args.dry_run
+        ctl_opts.update(comm.engine_options(local_rank, args.thinning, args.zlag))
         gpu = make_engine(comm.wants_p2p)
         comm.setup(gpu)
         if comm.mode == 'p2p':
@@ -400,6 +417,8 @@ def run_rank(args):
                 comm.setup(gpu)
         exchange = comm.mode
     else:
+        if args.zlag:
+            ctl_opts['zlag'] = args.zlag
         gpu = make_engine(False)
         if force_comm:
             gpu.comm_init(engine.comm_unique_id(), 0, 1)
@@ -415,7 +434,20 @@ def run_rank(args):
         g.sync()
         ctl.barrier()
 
-    def advance(n, g=None):
+    recycles = [0]
+    gpu_ms_acc = [0.0]
+    run_sizes = []                 # refreshes of every timed mc3hip_run call
+    zlag = int(ctl_opts.get('zlag', 0))
+
+    def recycle(g):
+        # every rank at the same refresh, between two barriers: nobody stores into a replica
+        # while it is being rearranged
+        barrier(g)
+        g.recycle(keep=1 + zlag, seed=prob['seed'] + 1 + recycles[0])
+        ctl.barrier()
+        recycles[0] += 1
+
+    def advance(n, g=None, timed=False):
         g = g or gpu
         if comm is not None and g is gpu and not comm.native:
             # host-staged exchange (no peer access and no RCCL): one refresh at a time
@@ -423,17 +455,33 @@ def run_rank(args):
                 R0 = g.refresh_done
                 g.run(1)
                 comm.exchange(g, R0)
-        else:
+            return
+        if args.dry_run:
             g.run(n, sync=False)
+            return
+        left = n
+        while left:
+            room = g.nzchain - g.refresh_done
+            if room < min(left, LAUNCH_REFRESHES):
+                recycle(g)
+                room = g.nzchain - g.refresh_done
+            m = min(left, room)
+            g.run(m, sync=False)
+            if timed:
+                gpu_ms_acc[0] += g.last_run_ms()    # HIP events on the library's stream
+                run_sizes.append(m)
+            left -= m
 
-    if nref_warm:
-        advance(nref_warm)
+    for _ in range(nwarm):
+        advance(R)
     barrier()
+    recycles_warm = recycles[0]
     t0 = time.perf_counter()
-    advance(nref_timed)
+    for _ in range(nsteps):
+        advance(R, timed=True)
     barrier()
     dt = time.perf_counter() - t0
-    gpu_ms = gpu.last_run_ms()          # HIP events on the library's stream
+    gpu_ms = gpu_ms_acc[0] if gpu_ms_acc[0] > 0 else gpu.last_run_ms()
     if world > 1:
         both = ctl.all_gather((dt, gpu_ms))
         dt, gpu_ms = max(b[0] for b in both), max(b[1] for b in both)
@@ -442,12 +490,13 @@ def run_rank(args):
     if world > 1:
         # every rank must hold the same Z rows: compare a digest of the last refreshes
         done = gpu.refresh_done
-        Zt, _, _ = gpu.rows(gpu.M0 + (done - 8)*nchains, 8*nchains)
+        last = min(8, done)
+        Zt, _, _ = gpu.rows(gpu.M0 + (done - last)*nchains, last*nchains)
         digest = float(np.sum(Zt*np.arange(1, Zt.size + 1).reshape(Zt.shape)))
         box = ctl.all_gather(digest)
         consistent = bool(all(d == box[0] for d in box) and np.all(np.isfinite(Zt)))
     st = gpu.state()
-    accept = float(st['numaccept'].sum())/(nlocal*gpu.refresh_done*args.thinning)
+    accept = float(st['numaccept'].sum())/(nlocal*nrefresh*args.thinning)
     chain_steps = nchains*nref_timed*args.thinning
     value = chain_steps/dt/1e6
     plan = dict(gpu.plan)
@@ -468,10 +517,11 @@ def run_rank(args):
     cgraph = plan['comm_graph']
     per = plan['persistent'] if (not multi or exchange == 'p2p') else 0
     if per > 0:
-        launches = -(-nref_timed//per)
+        launches = sum(-(-m//per) for m in run_sizes) if run_sizes else -(-nref_timed//per)
         kernel = 'mc3hip::resident_tile_kernel' if plan.get('resident') else \
-            {2: 'mc3hip::lean_demc_kernel', 1: 'mc3hip::persist_fast_kernel',
-             0: 'mc3hip::persist_kernel'}[plan['fast']]
+            {2: 'mc3hip::lean_demc_lag_kernel' if plan.get('zlag') else 'mc3hip::lean_demc_kernel',
+             1: 'mc3hip::persist_fast_kernel', 0: 'mc3hip::persist_kernel',
+             4: 'mc3hip::resident_tile_kernel'}[plan['fast']]
         structure = (f'persistent kernel, {per} refreshes per launch, Z rows handed '
                      'between workgroups in-launch')
     else:
@@ -526,15 +576,28 @@ def run_rank(args):
             'replicas_consistent': consistent,
             'recoveries': recoveries,
             'control_plane': None if world == 1 else 'mc3_amd.parallel.SocketComm (TCP)',
+            'recycles_in_timed_region': recycles[0] - recycles_warm,
+            'zlag': plan.get('zlag', 0),
+            'remote_delay_ns': plan.get('remote_delay_ns', 0),
             # what "the same results as the reference" means here
-            'semantics': 'lockstep (Jacobi) DEMC: during refresh R a chain sees the others '
-                         'through the rows of refresh R-1 (the reference updates the chains '
-                         'of a worker one after another, Gauss-Seidel); draws are '
-                         'Philox4x32-10 keyed by (seed, iteration, chain), one support-'
-                         'distribution vector per chain (the reference: MT19937, one per '
-                         'worker-iteration); ncpu is ignored.  Bit-exact against '
-                         'oracle/oracle_lockstep.c, whose step function replays the '
-                         'reference\'s own runs from a draw tape (tests/test_oracle_tape.py)',
+            'semantics': ('lockstep (Jacobi) DEMC: during refresh R a chain sees the others '
+                          'through the rows of refresh R-1 (the reference updates the chains '
+                          'of a worker one after another, Gauss-Seidel)' if not plan.get('zlag')
+                          else
+                          f'lockstep DEMC in the DECLARED MULTI-GPU CADENCE, zlag = '
+                          f'{plan["zlag"]}: during refresh R a chain sees the others through '
+                          f'the rows of refresh R-1-{plan["zlag"]} (the strict lockstep, '
+                          'R-1, is the one-GPU default; the reference updates the chains of a '
+                          'worker one after another, Gauss-Seidel) so that a row has '
+                          f'{plan["zlag"]} iterations\' time to cross xGMI and an iteration '
+                          'costs max(arithmetic, hop/zlag), not their sum; results depend on '
+                          'zlag and not on how the chains are sharded (SURVEY.md H4)') +
+                         '; draws are Philox4x32-10 keyed by (seed, iteration, chain), one '
+                         'support-distribution vector per chain (the reference: MT19937, one '
+                         'per worker-iteration); ncpu is ignored.  Bit-exact against '
+                         'oracle/oracle_lockstep.c (which restates either cadence), whose '
+                         'step function replays the reference\'s own runs from a draw tape '
+                         '(tests/test_oracle_tape.py)',
         },
         'roofline': {
             # what bounds the kernel is the latency of the hand-off between workgroups and of
@@ -543,6 +606,10 @@ def run_rank(args):
             'bound': 'latency', 'contract_bound': 'hbm',
             'achieved': achieved, 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic,
+            # (`traffic` and `hw` come from the committed PMC passes of the same kernel --
+            # rocprofv3 --pmc cannot run inside this process -- not from this run)
+            'traffic_from_profile': traffic is not None, 'measured_in_this_run': {
+                'achieved': True, 'avg_launch_us': True, 'traffic': False, 'hw': False},
             'kernel': kernel, 'launches': launches,
             'algorithmic_bytes_per_launch': bytes_per_launch,
             'avg_launch_us': launch_s*1e6,
@@ -551,7 +618,7 @@ def run_rank(args):
             'hw': None if hbm_per_step is None else {
                 'hbm_GBs': hbm_per_step*chain_steps/world/(gpu_ms*1e-3)/1e9,
                 'frac_of_peak': hbm_per_step*chain_steps/world/(gpu_ms*1e-3)/1e9/HBM_PEAK_GBS,
-                'hbm_bytes_per_chain_step': hbm_per_step,
+                'hbm_bytes_per_chain_step': hbm_per_step, 'from_profile': True,
                 'source': 'profiles/' + os.path.basename(pmc)},
             'note': f'algorithmic bytes (SURVEY 8d: {bytes_per_step} B per chain-step) x '
                     'chain-steps per launch / average launch duration (HIP events on the '
@@ -564,15 +631,29 @@ def run_rank(args):
     }
     if args.workload == 'c5':
         flops = 2.0*10*len(prob['data'])           # per chain-step: the contraction
+        useful = value*1e6*flops/1e12/world
+        # the K = 10 contraction on the FP64 matrix pipe bounds this workload: ITS fraction is
+        # the roofline fraction (the algorithmic bytes of the chain-invariant design matrix
+        # would read ~20x the HBM peak: kept as `hbm_contract`, never as `frac`)
+        out['roofline'].update({
+            'hbm_contract': {'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'frac': achieved/HBM_PEAK_GBS},
+            'bound': 'mfma', 'contract_bound': 'mfma', 'achieved': useful,
+            'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': useful/FP64_PEAK_TFLOPS})
         out['roofline']['fp64'] = {
-            'useful_TFLOPs': value*1e6*flops/1e12/world, 'peak': FP64_PEAK_TFLOPS,
-            'frac': value*1e6*flops/1e12/world/FP64_PEAK_TFLOPS,
+            'useful_TFLOPs': useful, 'peak': FP64_PEAK_TFLOPS,
+            'frac': useful/FP64_PEAK_TFLOPS,
             'note': 'design-matrix models: the K = 10 contraction on the shared FP64 matrix / '
                     'vector pipe is what bounds them, per GPU'}
     else:
+        us_it = launch_s*1e6*launches/nref_timed/args.thinning
+        floor_us = (0.53 + 0.42) if not plan.get('zlag') else 0.42
+        # the physically meaningful fraction next to the contractual one: the latency chain
+        # that bounds an iteration / what an iteration takes
+        out['roofline']['latency_frac'] = floor_us/us_it
         out['roofline']['latency_model'] = {
-            'us_per_iteration': launch_s*1e6*launches/nref_timed/args.thinning,
-            'floor_us': 0.53 + 0.42,
+            'us_per_iteration': us_it,
+            'floor_us': floor_us,
             'floor': 'every iteration of every chain needs two rows other chains (other '
                      'CUs, other XCDs) produced in the iteration before: one cross-CU '
                      'hand-off (0.53 us per hop between two single-wave workgroups on this '
@@ -593,8 +674,15 @@ def run_rank(args):
         out['config']['e2e'] = end_to_end()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry_run:
         out['cpu_baseline'] = cpu_baseline()
+    import threading
+    emit_lock, emitted = threading.Lock(), [False]
+
     def emit():
         import ctypes
+        with emit_lock:                 # (the extras' timer may fire while the main thread
+            if emitted[0]:              # is printing: one line, whoever comes first)
+                return
+            emitted[0] = True
         try:
             ctypes.CDLL(None).fflush(None)   # (what native code still holds in C stdio)
         except OSError:
@@ -604,11 +692,10 @@ def run_rank(args):
         if rank == 0:
             print(json.dumps(out), flush=True)
 
-    if world > 1 and not args.dry_run:
+    if world > 1 and not args.dry_run and not args.no_extras:
         # The two extra segments have never run on more than one physical GPU: should one of
         # them not come back (RCCL's set-up across processes, say), the line with the
         # peer-to-peer figure is printed all the same and every rank leaves.
-        import threading
         limit = float(os.environ.get('MC3HIP_BENCH_EXTRAS_TIMEOUT', 300))
 
         def give_up():
@@ -616,7 +703,9 @@ def run_rank(args):
                 out['config']['collective_rccl'] = {
                     'error': f'no result within {limit:.0f} s; the figure above stands'}
             emit()
-            os._exit(0)
+            # (the figure of record was printed; the hung extras are still an error worth a code)
+            os._exit(0 if out['config'].get('single_gpu_same_ensemble') is not None
+                     or out['config']['collective_rccl'].get('error') is None else 4)
         timer = threading.Timer(limit, give_up)
         timer.daemon = True
         timer.start()
@@ -712,10 +801,17 @@ def main():
                     help='Z refreshes per step (default: up to 6 persistent launches of 16384, '
                          'as many as (steps+warmup) batches of Z fit the memory budget)')
     ap.add_argument('--thinning', type=int, default=1)
+    ap.add_argument('--zlag', type=int, default=None,
+                    help='the declared cadence: the other chains are seen that many refreshes '
+                         'late (default: 0 = strict lockstep on one GPU; over several GPUs the '
+                         'communicator\'s choice, mc3_amd.parallel.DEFAULT_ZLAG)')
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='c2',
                     help='c2: the headline, 256 chains per GPU (weak scaling); c3 / c5: BASELINE '
                          'configs 3 and 5, a fixed ensemble split over the GPUs (strong scaling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='several ranks: skip the two extra segments (RCCL route, one-GPU '
+                         'yardstick) -- sweeps')
     ap.add_argument('--no-e2e', action='store_true',
                     help='skip the end-to-end sample() timings (config.e2e)')
     ap.add_argument('--dry-run', action='store_true',

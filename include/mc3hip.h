@@ -51,6 +51,11 @@ extern "C" {
 #define MC3HIP_FLAG_NO_PERSIST  2u /* never use the persistent kernel               */
 #define MC3HIP_FLAG_P2P         4u /* allocate Z / log_post fine-grained and IPC-shareable
                                       so that mc3hip_p2p_attach can be used               */
+#define MC3HIP_FLAG_NO_COURIER  8u /* peer-to-peer mode: the chain wave stores its rows into
+                                      the other ranks' replicas itself instead of handing
+                                      them to a second wave (for more than two ranks on ONE
+                                      device, a test set-up: the two-wave workgroups of all
+                                      of them would not be co-resident)                    */
 
 #define MC3HIP_MAX_FREE     64
 #define MC3HIP_MAX_PARAMS  128
@@ -116,7 +121,7 @@ typedef struct mc3hip_plan {
     int32_t fast;           /* 1: the lean persistent instance (one wave per chain, fully
                                free polynomial, Gaussian chisq, no priors/shared/epsilon);
                                2: one of the loops laid out by hand for that shape -- DEMC
-                               (lean_demc_kernel; thinning > 1: lean_demc_thin_kernel), snooker
+                               (lean_demc_kernel; thinning > 1 or zlag > 0: lean_demc_lag_kernel), snooker
                                (lean_snooker_kernel), random walk (lean_mrw_kernel), each also
                                with two to four chains per wave (lean_*_mc_kernel);
                                3: wavelet likelihood, nine-wave kernel with the hand-structured

@@ -24,6 +24,7 @@ MODEL_POLY, MODEL_LINEAR = 0, 1
 FLAG_NO_GRAPH = 1
 FLAG_NO_PERSIST = 2
 FLAG_P2P = 4
+FLAG_NO_COURIER = 8
 MAX_FREE, MAX_PARAMS = 64, 128
 
 SAMPLERS = {'mrw': MRW, 'demc': DEMC, 'snooker': SNOOKER}

@@ -148,15 +148,18 @@ inline bool resident_poly(const mc3hip_ctx *c)
     return c->mt != MT_LINEAR && c->P.tile == 4096 && tile_exact_degree(c) >= 2;
 }
 
-// DEMC in the declared multi-GPU cadence (zlag >= 1: partners are rows of refresh R-1-zlag,
-// published long before they are needed) has a hand-laid-out loop of its own,
-// lean_demc_lag_kernel: one tile, one chain per wave, any thinning, fixed / shared coefficients
-// and priors, one GPU or peer to peer with a courier wave
+// DEMC whose partner rows are (mostly) published long before they are needed -- the declared
+// multi-GPU cadence (zlag >= 1: rows of refresh R-1-zlag), thinning > 1 (the iterations of a
+// refresh look at the same rows) -- has a hand-laid-out loop of its own, lean_demc_lag_kernel:
+// one tile, one chain per wave, any thinning, fixed / shared coefficients and priors, one GPU
+// or peer to peer with a courier wave
 inline bool lag_demc_shape(const mc3hip_ctx *c)
 {
     const DevProblem &P = c->P;
-    return P.zlag > 0 && P.sampler == MC3HIP_DEMC && P.npad <= VLANES && P.zs == ZROW &&
-           !getenv("MC3HIP_NO_LEAN");
+    // (... and of the strict lockstep with thinning > 1, zlag = 0: only the first iteration of
+    // a refresh then asks for rows that are just being published and waits for them)
+    return (P.zlag > 0 || P.thinning > 1) && P.sampler == MC3HIP_DEMC && P.npad <= VLANES &&
+           P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
 }
 
 // the lean persistent instance applies when nothing of the general machinery is
@@ -168,17 +171,39 @@ inline bool fast_eligible(const mc3hip_ctx *c)
     // its free parameter or to its fixed value, handoff.h coefficient_map;
     // instantiated for one GPU and thinning = 1 only: FX of persist_fast_kernel)
     const bool plain = P.nparams == P.nfree && P.ngprior == 0 && P.nshare == 0;
+    // (peer to peer: the hand-laid-out snooker / random-walk loops with their courier wave,
+    // k_lean4.hip, and the loop of the declared cadence, k_lean3.hip -- the lean run_chain
+    // instances have no FX x P2P flavour)
+    const bool p2p_flag = (c->flags & MC3HIP_FLAG_P2P) != 0;
+    const bool lean_p2p_other = (P.sampler == MC3HIP_SNOOKER || P.sampler == MC3HIP_MRW) &&
+                                P.npad <= VLANES && P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
     const bool fx_ok = P.nfree >= 1 &&
-                       ((P.thinning == 1 && !(c->flags & MC3HIP_FLAG_P2P)) || lag_demc_shape(c));
+                       ((P.thinning == 1 && (!p2p_flag || lean_p2p_other)) || lag_demc_shape(c));
     // more than one 1024-point tile (streamed): plain problems, one GPU, thinning = 1
     const bool multi = P.npad > VLANES;
     const bool size_ok = !multi || (plain && fx_ok && P.tile == 0);
+    // (the support distribution, fepsilon != 0: the headline loop has an EPS flavour --
+    // lean_demc_kernel: DEMC, strict lockstep, thinning 1, one tile, one GPU)
+    const bool eps_ok = P.fepsilon == 0.0 || P.sampler == MC3HIP_MRW ||   // (chain.py:219-220)
+                        (P.sampler == MC3HIP_DEMC && P.thinning == 1 && P.zlag == 0 && !p2p_flag &&
+                         !multi && P.zs == ZROW && !getenv("MC3HIP_NO_LEAN"));
     return c->wpc == 1 && !P.wlike && size_ok && c->mt >= 2 && c->mt <= 4 &&
            (plain || fx_ok) && P.nmodel == P.nparams &&
-           P.fepsilon == 0.0 && P.trace_iters == 0 &&
+           eps_ok && P.trace_iters == 0 &&
            (P.sampler == MC3HIP_DEMC || P.sampler == MC3HIP_SNOOKER ||
             P.sampler == MC3HIP_MRW) &&
            !getenv("MC3HIP_NO_FAST");
+}
+
+// shapes that ONLY a one-chain-per-wave hand-laid-out loop serves leanly (the lean run_chain
+// instances have no such flavour): an ensemble of them beyond the co-resident waves runs the
+// general chain (mc3hip.hip decide_persist)
+inline bool lean_one_chain_only(const mc3hip_ctx *c)
+{
+    const DevProblem &P = c->P;
+    const bool plain = P.nfree == P.nparams && P.ngprior == 0 && P.nshare == 0;
+    return (P.fepsilon != 0.0 && P.sampler != MC3HIP_MRW) ||
+           (lag_demc_shape(c) && !plain && (P.thinning != 1 || (c->flags & MC3HIP_FLAG_P2P)));
 }
 
 // the headline shape (DEMC, thinning 1) has a loop of its own: lean_demc_kernel
@@ -197,12 +222,16 @@ inline bool lean_demc_lag_eligible(const mc3hip_ctx *c)
 // replicas (lean_demc_kernel COURIER; MC3HIP_NO_COURIER=1: the chain wave stores them itself)
 inline bool lean_plain_shape(const mc3hip_ctx *c);
 inline bool lean_demc_lag_eligible(const mc3hip_ctx *c);
+inline bool lean_snooker_eligible(const mc3hip_ctx *c);
+inline bool lean_mrw_eligible(const mc3hip_ctx *c);
 inline bool lean_courier(const mc3hip_ctx *c, bool p2p)
 {
     if (!p2p)       // (one GPU: an experiment, MC3HIP_LEAN_COURIER=1; measured slower)
         return getenv("MC3HIP_LEAN_COURIER") && lean_demc_eligible(c) && lean_plain_shape(c) &&
                c->P.npad <= VLANES && !(c->flags & MC3HIP_FLAG_P2P) && c->P.nlocal <= 1024;
-    return (lean_demc_eligible(c) || lean_demc_lag_eligible(c)) && !getenv("MC3HIP_NO_COURIER");
+    return (lean_demc_eligible(c) || lean_demc_lag_eligible(c) || lean_snooker_eligible(c) ||
+            lean_mrw_eligible(c)) &&
+           !(c->flags & MC3HIP_FLAG_NO_COURIER) && !getenv("MC3HIP_NO_COURIER");
 }
 
 // the headline loop with the draws of 64 refreshes computed at once (lean_demc_kernel BATCH):
@@ -229,13 +258,12 @@ inline bool lean_other_sampler_eligible(const mc3hip_ctx *c, int sampler)
     // (thinning > 1: the THIN instances, plain shapes only)
     const bool plain = P.nfree == P.nparams && P.ngprior == 0 && P.nshare == 0;
     // (more than one tile: the MULTI instances, plain shapes with thinning 1 only)
-    // (the declared multi-GPU cadence changes what snooker may draw from: see lean_snooker_kernel)
+    // (peer to peer, with a courier wave: the one-tile instances)
+    const bool p2p = (c->flags & MC3HIP_FLAG_P2P) || c->p2p_ranks > 1;
     return c->fast && c->mc_chains == 0 && P.sampler == sampler &&
-           (P.zlag == 0 || sampler == MC3HIP_MRW) &&
            (P.thinning == 1 || plain) &&
-           (P.npad <= VLANES || (plain && P.thinning == 1)) &&
-           P.nparams == c->mt && P.zs == ZROW &&
-           !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_LEAN");
+           (P.npad <= VLANES || (plain && P.thinning == 1 && !p2p)) &&
+           P.nparams == c->mt && P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
 }
 inline bool lean_snooker_eligible(const mc3hip_ctx *c)
 {
@@ -244,17 +272,6 @@ inline bool lean_snooker_eligible(const mc3hip_ctx *c)
 inline bool lean_mrw_eligible(const mc3hip_ctx *c)
 {
     return lean_other_sampler_eligible(c, MC3HIP_MRW) && c->mt <= 4;
-}
-
-// DEMC with thinning > 1 on the plain headline shape: lean_demc_thin_kernel
-inline bool lean_demc_thin_eligible(const mc3hip_ctx *c)
-{
-    const DevProblem &P = c->P;
-    const bool plain = P.nfree == P.nparams && P.ngprior == 0 && P.nshare == 0;
-    return c->fast && c->mc_chains == 0 && P.sampler == MC3HIP_DEMC && P.thinning > 1 && plain &&
-           P.zlag == 0 &&
-           P.nparams == c->mt && P.zs == ZROW && P.npad <= VLANES &&
-           !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_LEAN");
 }
 
 // ... and with two to four chains per wave: lean_snooker_mc_kernel, lean_mrw_mc_kernel
@@ -305,13 +322,10 @@ inline int lean_waves(const mc3hip_ctx *c)
 // ---- k_general_w{1,4,16}.hip: one workgroup per chain, Gaussian chisq, by waves per chain ---
 void launch_step_gauss_w1(mc3hip_ctx *c, int roff);
 void launch_step_gauss_w4(mc3hip_ctx *c, int roff);
-void launch_step_gauss_w16(mc3hip_ctx *c, int roff);
 chain_kernel_fn persist_instance_gauss_w1(const mc3hip_ctx *c, bool p2p);
 chain_kernel_fn persist_instance_gauss_w4(const mc3hip_ctx *c, bool p2p);
-chain_kernel_fn persist_instance_gauss_w16(const mc3hip_ctx *c, bool p2p);
 void launch_eval_gauss_w1(mc3hip_ctx *c, int n);
 void launch_eval_gauss_w4(mc3hip_ctx *c, int n);
-void launch_eval_gauss_w16(mc3hip_ctx *c, int n);
 
 // ---- k_wavelet_{w1,w4,w8,large}.hip: the same with the wavelet likelihood, by geometry ----
 #define MC3_WAVELET_UNIT(tag)                                                       \
@@ -337,6 +351,7 @@ chain_kernel_fn persist_instance_wavelet_w8cg(const mc3hip_ctx *c);
 chain_kernel_fn fast_instance(const mc3hip_ctx *c, bool p2p);
 chain_kernel_fn lean_other_instance(const mc3hip_ctx *c);   // k_lean2.hip
 chain_kernel_fn lean_lag_instance(const mc3hip_ctx *c, bool p2p);   // k_lean3.hip
+chain_kernel_fn lean_other_p2p_instance(const mc3hip_ctx *c);       // k_lean4.hip
 
 // ---- k_tiled.hip: the tiled plan as three launches per iteration -------------------------
 void launch_propose(mc3hip_ctx *c, int roff, int j);

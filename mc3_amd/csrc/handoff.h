@@ -337,11 +337,18 @@ __device__ __forceinline__ void store_row_everywhere(const DevProblem &P,
 // only spins when something is still pending.  Bounded: gives up (and tells
 // everybody) after a few seconds so a lost workgroup can never hang the device;
 // the host then restores its checkpoint and redoes the run (mc3hip.hip settle()).
-template <int NVAL, bool SYS = false>
+struct NoIdle {
+    __device__ __forceinline__ void operator()() const {}
+};
+// (`idle`: called once per round of polls -- the test hook's queue of held-back rows must keep
+// draining while its wave waits, or ranks that wait for each other's held-back rows never meet)
+template <int NVAL, bool SYS = false, class Idle = NoIdle>
 __device__ __forceinline__ bool wait_rows(const double *const (&addr)[NVAL], double (&val)[NVAL],
-                                          long long *ctl, unsigned long long *nspin = nullptr)
+                                          long long *ctl, unsigned long long *nspin = nullptr,
+                                          Idle idle = Idle())
 {
     for (unsigned spins = 0;; ++spins) {
+        idle();
         if (nspin && spins)
             *nspin += 1;                      // diagnostic build: polls beyond the first
         bool pend[NVAL];
@@ -379,12 +386,13 @@ __device__ __forceinline__ bool wait_rows(const double *const (&addr)[NVAL], dou
 
 // The same wait with K polls kept in flight (in-order return: the oldest is checked while
 // the younger ones travel), so that memory is sampled every round trip / K.
-template <int K, int SYS>
+template <int K, int SYS, class Idle = NoIdle>
 __device__ __forceinline__ bool poll_ring(const double *const (&addr)[2], double (&v)[K][2],
                                           double (&val)[2], long long *ctl,
-                                          unsigned long long *nspin = nullptr)
+                                          unsigned long long *nspin = nullptr, Idle idle = Idle())
 {
     for (unsigned spins = 0;; ++spins) {
+        idle();
 #pragma unroll
         for (int q = 0; q < K; ++q) {
             const bool pend0 = __any(mc3_bits(v[q][0]) == ROW_PENDING);

@@ -42,10 +42,10 @@ chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
     // (the loops of the declared multi-GPU cadence: k_lean3.hip)
     if (chain_kernel_fn f = lean_lag_instance(c, p2p))
         return f;
-    // (the hand-laid-out snooker, random-walk and thinned DEMC loops: k_lean2.hip)
-    if (!p2p)
-        if (chain_kernel_fn f = lean_other_instance(c))
-            return f;
+    // (the hand-laid-out snooker, random-walk and thinned DEMC loops: k_lean2.hip; their
+    // peer-to-peer flavours with a courier wave: k_lean4.hip)
+    if (chain_kernel_fn f = p2p ? lean_other_p2p_instance(c) : lean_other_instance(c))
+        return f;
     if (c->P.sampler == MC3HIP_MRW)
         return fast_instance_tt<MT, MC3HIP_MRW>(c, p2p);
     if (lean_demc_mc_eligible(c) && !p2p) {          // 2..4 chains per wave
@@ -63,6 +63,9 @@ chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
 #undef MC3_LEAN_MC
     }
     if (lean_demc_eligible(c)) {
+        if (c->P.fepsilon != 0.0)                        // (one GPU, one tile: fast_eligible)
+            return lean_plain_shape(c) ? lean_demc_kernel<MT, false, false, false, false, false, true>
+                                       : lean_demc_kernel<MT, false, true, false, false, false, true>;
         if (p2p)
             return lean_courier(c, p2p) ? lean_demc_kernel<MT, true, false, false, false, true>
                                         : lean_demc_kernel<MT, true>;

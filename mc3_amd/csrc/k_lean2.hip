@@ -1,6 +1,6 @@
 // k_lean2.hip -- instances of the hand-laid-out snooker and random-walk loops (one chain per
-// wave, thinning, streamed tiles, two to four chains per wave) and of the thinned DEMC loop
-// (kernels_lean.h); a translation unit of its own so that the library builds in parallel.
+// wave, thinning, streamed tiles, two to four chains per wave; kernels_lean.h); a translation
+// unit of its own so that the library builds in parallel.
 #include "ctx.h"
 #include "kernels_lean.h"
 
@@ -40,8 +40,6 @@ chain_kernel_fn lean_other_instance_t(const mc3hip_ctx *c)
         MC3_LEAN_SOLO_MC(lean_snooker_mc_kernel, 4)
     }
 #undef MC3_LEAN_SOLO_MC
-    if (lean_demc_thin_eligible(c))
-        return lean_demc_thin_kernel<MT>;
     return nullptr;
 }
 

@@ -47,9 +47,18 @@ void persist_instance_t(const mc3hip_ctx *c, bool p2p, chain_kernel_fn *out)
             return;
         }
     }
-    *out = p2p ? persist_kernel<WW, MT, true, LARGE, true>
-               : mc ? persist_kernel<WW, MT, true, LARGE, false, true>
-                    : persist_kernel<WW, MT, true, LARGE>;
+    if constexpr (WW == 8 && !LARGE) {
+        // (the fused eight-wave kernel in which wave 0 was also the chain went with round 4:
+        // every instance of it spilled.  Where the nine-wave kernel does not run -- the
+        // peer-to-peer mode -- there is no persistent launch: one launch per refresh, and the
+        // multi-GPU exchange through RCCL or the host)
+        (void)mc;
+        *out = nullptr;
+    } else {
+        *out = p2p ? persist_kernel<WW, MT, true, LARGE, true>
+                   : mc ? persist_kernel<WW, MT, true, LARGE, false, true>
+                        : persist_kernel<WW, MT, true, LARGE>;
+    }
 }
 
 template <int MT>

@@ -44,11 +44,17 @@ __global__ __launch_bounds__(64) void persist_fast_kernel(const DevProblem P, co
 // leaves the row in an LDS ring; the courier picks it up (it spins on an LDS counter: no
 // vector-memory operation, nothing the chain wave could wait behind) and stores it into the
 // remote replicas, its own counter absorbing the acknowledgements.  Same rows, same results.
+//
+// EPS (fepsilon != 0, chain.py:185,232: the support distribution's draw added to the jump): lane
+// k's normal deviate of the NEXT refresh -- Philox slot 3 + k/2, a logarithm, a square root, a
+// sine or cosine, as run_chain's normal_draw -- is computed on the vector unit in the same
+// shadow of the partner rows' round trip as the scalar draws.
 template <int MT, bool P2P, bool FX = false, bool MULTI = false, bool BATCH = false,
-          bool COURIER = false>
+          bool COURIER = false, bool EPS = false>
 __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const DevProblem P,
                                                                       const int nref)
 {
+    static_assert(!EPS || (!P2P && !MULTI && !BATCH && !COURIER), "EPS: the one-GPU headline loop");
     const int nf = FX ? P.nfree : MT;        // FX: some coefficients are fixed (nfree < MT)
     constexpr int ZS = ZROW;                 // doubles per Z row: one 128-byte line (NF <= 16)
     constexpr int LM = P2P ? 1 : 0;
@@ -121,6 +127,19 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
     double lpbuf = 0.0;
     MC3_STAMP(1);
 
+    // EPS: the support distribution's draw of a refresh (chain.py:185), lane k's own
+    const double pstep_k = (EPS && mine) ? P.fstep[lane] : 0.0;
+    auto normal_draw = [&](uint64_t it) {
+        double nk = 0.0;
+        if (mine) {
+            const Draw2 dn = draw2(P.seed, it, (uint32_t)c, (uint32_t)(3 + (lane >> 1)));
+            const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(dn.q0)));
+            double sn, cs;
+            mc3_det_sincos2pi(u01(dn.q1), &sn, &cs);
+            nk = (rad * ((lane & 1) ? sn : cs)) * pstep_k;
+        }
+        return nk;
+    };
     // draws of the first refresh
     Draw2 d = draw2(P.seed, (uint64_t)R0, (uint32_t)c, 0u);
     double u = u01(d.q1);
@@ -130,6 +149,15 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
     int r1, r2;
     demc_partners(d.q0, n, c, r1, r2);
     int off1 = r1 * ZS + kk, off2 = r2 * ZS + kk;
+    // (behind the wave-uniform draws of the same iteration: the two Philox calls share their
+    // first round, which must be computed where it is uniform -- the compiler would otherwise
+    // place it under the lanes' mask and could not hand it to the scalar unit any more)
+    pin_scalar(d.q0);
+    pin_scalar(d.q1);
+    double normal_k = 0.0;
+    if constexpr (EPS)
+        normal_k = normal_draw((uint64_t)R0);
+    (void)normal_k; (void)pstep_k;
     // BATCH: lane i holds the draws of refresh bbase + i
     double bu = 0.0, blo = 0.0, bhi = 0.0;
     int bo1 = 0, bo2 = 0;
@@ -207,6 +235,8 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
         ta15 += tkL - tk0;
 #endif
         const double u_now = u, lo_now = acc_lo, hi_now = acc_hi;
+        const double normal_now = normal_k;
+        (void)normal_now;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (BATCH) {
             // ... and behind them, once in 64 refreshes, the draws of the next 64
@@ -225,18 +255,29 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
         off1 = r1 * ZS + kk;
         off2 = r2 * ZS + kk;
         asm volatile("; pin" : "+v"(u), "+v"(off1), "+v"(off2), "+v"(acc_lo), "+v"(acc_hi));
+        if constexpr (EPS) {
+            normal_k = normal_draw((uint64_t)(R + 1));
+            asm volatile("; pin" : "+v"(normal_k));
+        }
         }
         __builtin_amdgcn_sched_barrier(0);
+        // (test hook, no courier: the rows held back keep going out while this wave waits)
+        auto idle = [&]() {
+            if constexpr (P2P && !COURIER) {
+                if (__builtin_expect(P.remote_delay != 0, 0))
+                    late.drain(P, s_ring, peers_z, lane, mine, false);
+            }
+        };
 #ifdef MC3HIP_STAMPS
-        alive = poll_ring<KR, LM>(addr, ring, val, ctl_rw, &ta14);
+        alive = poll_ring<KR, LM>(addr, ring, val, ctl_rw, &ta14, idle);
 #else
-        alive = poll_ring<KR, LM>(addr, ring, val, ctl_rw);
+        alive = poll_ring<KR, LM>(addr, ring, val, ctl_rw, nullptr, idle);
 #endif
         MC3_TICK(tk1);
         if (__builtin_expect(!alive, 0))
             break;
         // proposal and boundaries, chain.py:232-243
-        const double jump_k = gamma * (val[0] - val[1]) + feps * 0.0;
+        const double jump_k = gamma * (val[0] - val[1]) + feps * (EPS ? normal_now : 0.0);
         const double npk = xk + jump_k;
         const bool outk = mine && (npk < pmin_k || npk > pmax_k);
         if (__builtin_expect(!__any(outk), 1)) {
@@ -364,21 +405,53 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
 // (THIN: thinning > 1 -- the iterations between two refreshes draw from the same history and
 // publish nothing; the draws are keyed by the iteration, R thinning + j, as run_chain's)
 // (MULTI: more than 1024 points -- the second tile stays in registers too, the rest is streamed)
-template <int MT, bool FX = false, bool THIN = false, bool MULTI = false>
-__global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, const int nref)
+// (P2P: the ensemble is sharded over GPUs -- rows are read from the local replica at system
+// scope, published into it, and carried to the other ranks' replicas by the COURIER wave, as
+// lean_demc_kernel's; without it the chain wave stores them itself)
+// (zlag > 0, the declared multi-GPU cadence: the history an iteration draws from ends zlag
+// refreshes earlier -- mc3hip_problem.zlag, oracle_lockstep.c ls_run)
+template <int MT, bool FX = false, bool THIN = false, bool MULTI = false, bool P2P = false,
+          bool COURIER = false>
+__global__ __launch_bounds__(COURIER ? 128 : 64) void lean_snooker_kernel(const DevProblem P,
+                                                                         const int nref)
 {
+    static_assert(!COURIER || P2P, "the courier carries rows to other ranks' replicas");
     const int nf = FX ? P.nfree : MT;
     constexpr int ZS = ZROW;
     constexpr int NB = 21;                     // refreshes per batch of draws (3 lanes each)
-    const int lane = threadIdx.x;
+    const int lane = COURIER ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     const int lc = blockIdx.x;
     const int c = P.chain0 + lc;
     const bool mine = lane < nf;
     const int kk = mine ? lane : 0;
     long long *ctl_rw = const_cast<long long *>(P.ctl);
-    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
-            &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
-        return;
+    __shared__ double s_ring[P2P ? COURIER_RING * ZROW : 1];
+    __shared__ int s_cour[4];
+    (void)s_ring; (void)s_cour;
+    if constexpr (COURIER) {
+        if (!courier_begin(s_ring, s_cour, ctl_rw))
+            return;
+        if (threadIdx.x >= 64) {
+            courier_run<true>(P, s_ring, s_cour, lane, nf, c);
+            return;
+        }
+    } else {
+        if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
+                &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+            return;
+    }
+    int handed = 0;
+    (void)handed;
+    PeerTable<double> peers_z, peers_lp;
+    if constexpr (P2P) {
+        if constexpr (!COURIER)
+            peers_z.load(P.peerZ, P.npeers);
+        peers_lp.load(P.peerLP, P.npeers);
+    }
+    (void)peers_z; (void)peers_lp;
+    DelayedRows late;
+    late.begin(P, P.ctl[0], c, lane);
+    (void)late;
     DataTile<1, MT> tile;
     tile.load(P);
     DataTile<1, MT> tile1;
@@ -411,14 +484,16 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
     unsigned long long A = 0, B = 0;
     double blo = 0.0, bhi = 0.0;
     const int th = THIN ? P.thinning : 1;
+    const long long zlag = P.zlag;
     long long bbase = R0 * th;                 // (the batch counts iterations)
     const int bs = lane % 3, bi = (lane / 3 < NB) ? lane / 3 : NB - 1;
     auto fill = [&](long long base) {
         const long long Rl = base + bi;
         const Draw2 d = draw2(P.seed, (uint64_t)Rl, (uint32_t)c, (uint32_t)bs);
-        // (the history an iteration draws from: the rows before its refresh)
-        const unsigned long long zsz =
-            (unsigned long long)(P.M0 + (THIN ? Rl / th : Rl) * n);
+        // (the history an iteration draws from: the rows before its refresh -- zlag refreshes
+        // before it in the declared multi-GPU cadence)
+        const long long Rh = (THIN ? Rl / th : Rl) - zlag;
+        const unsigned long long zsz = (unsigned long long)(P.M0 + (Rh > 0 ? Rh : 0) * n);
         if (bs == 0) {
             const unsigned long long iR1 = bounded(d.q0, zsz);
             unsigned long long iR2 = 1 + bounded(d.q1, zsz - 1);
@@ -457,11 +532,11 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
         if (async) {
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                S.val[q] = load_published_async(S.addr[q]);
+                S.val[q] = load_published_async<P2P>(S.addr[q]);
         } else {
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                S.val[q] = load_published<false>(S.addr[q]);
+                S.val[q] = load_published<P2P>(S.addr[q]);
         }
         S.sj = lane64(B, idx + 1) != 0;
         S.gs = mc3_from_bits(lane64(A, idx + 2));
@@ -481,7 +556,12 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
     long long rdone = R0;
     auto flush_columns = [&](int count) {
         if (lane < count) {
-            lp_row[(size_t)lane * n] = lpbuf;
+            if constexpr (P2P) {
+                const size_t roff = (size_t)(lp_row - P.log_post) + (size_t)lane * n;
+                peers_lp.store(roff, lpbuf);
+            } else {
+                lp_row[(size_t)lane * n] = lpbuf;
+            }
             zc_row[(size_t)lane * n] = c;
         }
     };
@@ -510,7 +590,12 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
                                    mc3_bits(C.val[2]) == ROW_PENDING), 0)) {
             const double *const a3[3] = {C.addr[0], C.addr[1], C.addr[2]};
             double v3[3] = {C.val[0], C.val[1], C.val[2]};
-            alive = wait_rows<3, false>(a3, v3, ctl_rw);
+            alive = wait_rows<3, P2P>(a3, v3, ctl_rw, nullptr, [&]() {
+                if constexpr (P2P && !COURIER) {             // (test hook: see lean_demc_kernel)
+                    if (__builtin_expect(P.remote_delay != 0, 0))
+                        late.drain(P, s_ring, peers_z, lane, mine, false);
+                }
+            });
             // (nothing this path asked for is pending where it joins the other: said in a
             // form the compiler's bookkeeping reads, or it guards the join with a wait of its
             // own -- which the loads of the next refresh, just issued, would be waited for at)
@@ -587,7 +672,8 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
         if (mine) {
             if (!THIN || j + 1 == th)
                 __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);        // publish (sc1)
+                                   P2P ? __HIP_MEMORY_SCOPE_SYSTEM
+                                       : __HIP_MEMORY_SCOPE_AGENT);  // publish (sc1)
             else
                 __hip_atomic_store(&P.X[(size_t)lc * nf + lane], xk, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
@@ -596,6 +682,21 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
         // store above at least -- has completed
         published_arrived<1>(Nx.val[0], Nx.val[1], Nx.val[2]);
         S = Nx;
+        // ... and to the other ranks' replicas: the courier's business, or -- without one --
+        // behind the wait, so that the rows just asked for do not queue behind these stores
+        if constexpr (P2P) {
+            if (!THIN || j + 1 == th) {
+                if constexpr (COURIER) {
+                    alive = courier_hand(s_ring, s_cour, handed, lane, mine, xk, ctl_rw);
+                    if (__builtin_expect(!alive, 0))
+                        goto out;
+                } else if (__builtin_expect(P.remote_delay != 0, 0)) {         // test hook
+                    late.hand(P, s_ring, peers_z, lane, mine, xk);
+                } else if (mine) {
+                    peers_z.store((size_t)(zblock - P.Z) + (size_t)c * ZS + lane, xk, P.rank);
+                }
+            }
+        }
         }
         const int slot = (int)(R - R0) & 63;
         lpbuf = (lane == slot) ? -0.5 * cur : lpbuf;
@@ -608,6 +709,12 @@ __global__ __launch_bounds__(64) void lean_snooker_kernel(const DevProblem P, co
         rdone = R + 1;
     }
 out:
+    if constexpr (COURIER)
+        courier_end(s_cour);
+    if constexpr (P2P && !COURIER) {
+        if (P.remote_delay != 0)
+            late.drain(P, s_ring, peers_z, lane, mine, true);
+    }
     flush_columns((int)(rdone - R0) & 63);
     if (mine)
         P.X[(size_t)lc * nf + lane] = xk;
@@ -630,21 +737,50 @@ out:
 // (THIN: thinning > 1 -- the iterations between two refreshes publish nothing; the draws are
 // keyed by the iteration, R thinning + j, as run_chain's)
 // (MULTI: more than 1024 points -- the second tile stays in registers too, the rest is streamed)
-template <int MT, bool FX = false, bool THIN = false, bool MULTI = false>
-__global__ __launch_bounds__(64) void lean_mrw_kernel(const DevProblem P, const int nref)
+// (P2P / COURIER: the ensemble is sharded over GPUs; the rows go into every rank's replica, as
+// lean_snooker_kernel's -- nobody waits for them: the run needs them complete at its end)
+template <int MT, bool FX = false, bool THIN = false, bool MULTI = false, bool P2P = false,
+          bool COURIER = false>
+__global__ __launch_bounds__(COURIER ? 128 : 64) void lean_mrw_kernel(const DevProblem P,
+                                                                     const int nref)
 {
     static_assert(MT >= 1 && MT <= 4, "two slots of normal deviates");
+    static_assert(!COURIER || P2P, "the courier carries rows to other ranks' replicas");
     const int nf = FX ? P.nfree : MT;
     constexpr int ZS = ZROW;
     constexpr int NB = 21;
-    const int lane = threadIdx.x;
+    const int lane = COURIER ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     const int lc = blockIdx.x;
     const int c = P.chain0 + lc;
     const bool mine = lane < nf;
     long long *ctl_rw = const_cast<long long *>(P.ctl);
-    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
-            &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
-        return;
+    __shared__ double s_ring[P2P ? COURIER_RING * ZROW : 1];
+    __shared__ int s_cour[4];
+    (void)s_ring; (void)s_cour;
+    if constexpr (COURIER) {
+        if (!courier_begin(s_ring, s_cour, ctl_rw))
+            return;
+        if (threadIdx.x >= 64) {
+            courier_run<true>(P, s_ring, s_cour, lane, nf, c);
+            return;
+        }
+    } else {
+        if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
+                &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+            return;
+    }
+    int handed = 0;
+    (void)handed;
+    PeerTable<double> peers_z, peers_lp;
+    if constexpr (P2P) {
+        if constexpr (!COURIER)
+            peers_z.load(P.peerZ, P.npeers);
+        peers_lp.load(P.peerLP, P.npeers);
+    }
+    (void)peers_z; (void)peers_lp;
+    DelayedRows late;
+    late.begin(P, P.ctl[0], c, lane);
+    (void)late;
     DataTile<1, MT> tile;
     tile.load(P);
     DataTile<1, MT> tile1;
@@ -697,10 +833,16 @@ __global__ __launch_bounds__(64) void lean_mrw_kernel(const DevProblem P, const 
     long long rdone = R0;
     auto flush_columns = [&](int count) {
         if (lane < count) {
-            lp_row[(size_t)lane * n] = lpbuf;
+            if constexpr (P2P) {
+                const size_t roff = (size_t)(lp_row - P.log_post) + (size_t)lane * n;
+                peers_lp.store(roff, lpbuf);
+            } else {
+                lp_row[(size_t)lane * n] = lpbuf;
+            }
             zc_row[(size_t)lane * n] = c;
         }
     };
+    bool alive = true;
     // (everything loaded so far -- the state, the bounds, the data tile -- retired here: a load
     // still pending at the loop head would make the compiler guard its registers with a wait
     // INSIDE the loop, i.e. for the publish of the iteration before as well)
@@ -755,7 +897,18 @@ __global__ __launch_bounds__(64) void lean_mrw_kernel(const DevProblem P, const 
         // Z append, chain.py:276-289
         if (mine)
             __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+                               P2P ? __HIP_MEMORY_SCOPE_SYSTEM : __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (P2P) {
+            if constexpr (COURIER) {
+                alive = courier_hand(s_ring, s_cour, handed, lane, mine, xk, ctl_rw);
+                if (__builtin_expect(!alive, 0))
+                    break;
+            } else if (__builtin_expect(P.remote_delay != 0, 0)) {             // test hook
+                late.hand(P, s_ring, peers_z, lane, mine, xk);
+            } else if (mine) {
+                peers_z.store((size_t)(zblock - P.Z) + (size_t)c * ZS + lane, xk, P.rank);
+            }
+        }
         const int slot = (int)(R - R0) & 63;
         lpbuf = (lane == slot) ? -0.5 * cur : lpbuf;
         if (__builtin_expect(slot == 63, 0)) {
@@ -766,191 +919,16 @@ __global__ __launch_bounds__(64) void lean_mrw_kernel(const DevProblem P, const 
         zblock += blockstride;
         rdone = R + 1;
     }
+    if constexpr (COURIER)
+        courier_end(s_cour);
+    if constexpr (P2P && !COURIER) {
+        if (P.remote_delay != 0)
+            late.drain(P, s_ring, peers_z, lane, mine, true);
+    }
+    (void)alive;
     flush_columns((int)(rdone - R0) & 63);
     if (mine)
         P.X[(size_t)lc * nf + lane] = xk;
-    if (lane == 0) {
-        P.chisq[lc] = cur;
-        P.best_chisq[lc] = best;
-        P.numaccept[lc] = nacc0 + nacc;
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// DEMC with thinning > 1 for the headline shape (plain: every coefficient free, one tile, one
-// chain per wave, one GPU).  The `thinning` iterations of a refresh draw their partners anew
-// but look at the same rows -- those of the refresh before (run_chain) -- so only the first
-// one waits for a hand-off; the lean run_chain instance took 0.88 us per iteration at thinning
-// 10, most of it the draws.  Laid out as lean_snooker_kernel: the draws of 64 iterations at
-// once, one per lane (Philox, log u and its window, the partners' row offsets); the two rows
-// of the NEXT iteration asked for first thing by loads the compiler does not see and retired
-// behind this iteration's store (handoff.h load_published_async: one load site, one wait
-// site); a row that is still the sentinel -- the first iteration of a refresh asks for rows
-// its partners are about to publish -- is asked for again the usual way.  Same draws, same
-// arithmetic, same results as run_chain's.
-template <int MT>
-__global__ __launch_bounds__(64) void lean_demc_thin_kernel(const DevProblem P, const int nref)
-{
-    constexpr int ZS = ZROW;
-    constexpr int NB = 64;                     // iterations per batch of draws (one per lane)
-    const int lane = threadIdx.x;
-    const int lc = blockIdx.x;
-    const int c = P.chain0 + lc;
-    const bool mine = lane < MT;
-    const int kk = mine ? lane : 0;
-    long long *ctl_rw = const_cast<long long *>(P.ctl);
-    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
-            &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
-        return;
-    DataTile<1, MT> tile;
-    tile.load(P);
-    const long long R0 = P.ctl[0];
-    const int n = P.nchains;
-    const int th = P.thinning;
-    const size_t blockstride = (size_t)n * ZS;
-    // rows of refresh R0 - 1 (the current states) and of refresh R0 (to be published)
-    const double *pbase = (R0 == 0) ? P.snap0 : P.Z + (size_t)(P.M0 + (R0 - 1) * n) * ZS;
-    double *zblock = P.Z + (size_t)(P.M0 + R0 * n) * ZS;
-    double *lp_row = P.log_post + (P.M0 + R0 * n + c);
-    int32_t *zc_row = P.zchain + (P.M0 + R0 * n + c);
-    double xk = mine ? pbase[(size_t)c * ZS + lane] : 0.0;
-    double cur = P.chisq[lc];
-    double best = P.best_chisq[lc];
-    const long long nacc0 = P.numaccept[lc];
-    const double pmin_k = mine ? P.fmin[lane] : 0.0;
-    const double pmax_k = mine ? P.fmax[lane] : 0.0;
-    const double gamma = P.gamma, feps = P.fepsilon;
-    const long long abort_at = (P.test_abort >= 0 && lc == 0) ? (long long)P.test_abort : -1;
-    long long nacc = 0;
-    double lpbuf = 0.0;
-    // lane i: the draws of iteration bbase + i (chain.py:221-232, :259)
-    double bu = 0.0, blo = 0.0, bhi = 0.0;
-    int bo1 = 0, bo2 = 0;
-    long long bbase = R0 * th;
-    auto fill = [&](long long base) {
-        const Draw2 dd = draw2(P.seed, (uint64_t)(base + lane), (uint32_t)c, 0u);
-        bu = u01(dd.q1);
-        accept_window(bu, blo, bhi);
-        int q1, q2;
-        demc_partners(dd.q0, n, c, q1, q2);
-        bo1 = q1 * ZS;
-        bo2 = q2 * ZS;
-        bbase = base;
-    };
-    struct Step {
-        double u, lo, hi;
-        const double *addr[2];
-        double val[2];
-    };
-    // (`it` inside the current batch; `snap`: the rows its refresh looks at)
-    auto prepare = [&](long long it, const double *snap, Step &S) {
-        const int idx = (int)(it - bbase);
-        S.addr[0] = snap + (__builtin_amdgcn_readlane(bo1, idx) + kk);
-        S.addr[1] = snap + (__builtin_amdgcn_readlane(bo2, idx) + kk);
-        S.val[0] = load_published_async(S.addr[0]);
-        S.val[1] = load_published_async(S.addr[1]);
-        S.u = read_lane(bu, idx);
-        S.lo = read_lane(blo, idx);
-        S.hi = read_lane(bhi, idx);
-    };
-    fill(R0 * th);
-    Step S;
-    double spare = 0.0;                        // (published_arrived takes three)
-    prepare(R0 * th, pbase, S);
-    published_arrived<0>(S.val[0], S.val[1], spare);
-    // (... and so is everything else loaded so far: a load the compiler knows of, still pending
-    // at the loop head, would make it guard its registers with a wait INSIDE the loop)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    const long long Rend = R0 + nref;
-    long long rdone = R0;
-    auto flush_columns = [&](int count) {
-        if (lane < count) {
-            lp_row[(size_t)lane * n] = lpbuf;
-            zc_row[(size_t)lane * n] = c;
-        }
-    };
-    bool alive = true;
-    for (long long R = R0; R < Rend; ++R) {
-        if (__builtin_expect(R == abort_at, 0)) {                                         // test hook
-            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-        for (int j = 0; j < th; ++j) {
-            const long long it = R * th + j;
-            Step C = S;
-            if (__builtin_expect(it + 1 - bbase == NB, 0))
-                fill(it + 1);
-            // the next iteration's rows: of the same refresh before, or -- behind the last
-            // iteration of this refresh -- the rows this refresh is about to publish
-            Step Nx;
-            prepare(it + 1, (j + 1 < th) ? pbase : (const double *)zblock, Nx);
-            if (__builtin_expect(__any(mc3_bits(C.val[0]) == ROW_PENDING ||
-                                       mc3_bits(C.val[1]) == ROW_PENDING), 0)) {
-                const double *const a2[2] = {C.addr[0], C.addr[1]};
-                double v2[2] = {C.val[0], C.val[1]};
-                alive = wait_rows<2, false>(a2, v2, ctl_rw);
-                // (nothing this path asked for is pending where it joins the other)
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-                asm volatile("; rows of this iteration" : "+v"(v2[0]), "+v"(v2[1]));
-                C.val[0] = v2[0];
-                C.val[1] = v2[1];
-                if (__builtin_expect(!alive, 0))
-                    goto out;
-            }
-            // proposal and boundaries, chain.py:232-243
-            const double jump_k = gamma * (C.val[0] - C.val[1]) + feps * 0.0;
-            const double npk = xk + jump_k;
-            const bool outk = mine && (npk < pmin_k || npk > pmax_k);
-            if (__builtin_expect(!__any(outk), 1)) {
-                Model<MT> model;
-                model.init_from_lanes(P, npk);
-                const double nextchisq =
-                    block_gauss_model<1, MT, false, false>(P, model, nullptr, nullptr, tile,
-                                                           &tile);           // chain.py:249
-                const bool acc = metropolis_accept(0.5 * (cur - nextchisq), C.u, C.lo, C.hi);
-                xk = acc ? npk : xk;
-                if (__builtin_expect(__any(acc && nextchisq < best), 0)) {
-                    best = nextchisq;
-                    if (mine)
-                        P.bestx[(size_t)lc * MT + lane] = xk;
-                    if (lane == 0)
-                        P.best_iter[lc] = it;
-                }
-                cur = acc ? nextchisq : cur;
-                nacc += acc ? 1 : 0;
-            } else if (outk) {
-                atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
-            }
-            // Z append behind the last iteration of the refresh, chain.py:276-289; the others
-            // leave the state where the kernel leaves it in the end, so that ONE store follows
-            // the loads of the next iteration's rows either way and one wait serves both
-            if (mine) {
-                if (j + 1 == th)
-                    __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);        // publish (sc1)
-                else
-                    __hip_atomic_store(&P.X[(size_t)lc * MT + lane], xk, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-            }
-            published_arrived<1>(Nx.val[0], Nx.val[1], spare);
-            S = Nx;
-        }
-        const int slot = (int)(R - R0) & 63;
-        lpbuf = (lane == slot) ? -0.5 * cur : lpbuf;
-        if (__builtin_expect(slot == 63, 0)) {
-            flush_columns(64);
-            lp_row += (size_t)64 * n;
-            zc_row += (size_t)64 * n;
-        }
-        pbase = zblock;
-        zblock += blockstride;
-        rdone = R + 1;
-    }
-out:
-    flush_columns((int)(rdone - R0) & 63);
-    if (mine)
-        P.X[(size_t)lc * MT + lane] = xk;
     if (lane == 0) {
         P.chisq[lc] = cur;
         P.best_chisq[lc] = best;
@@ -966,12 +944,17 @@ out:
 // one chip in front of 0.63 us of arithmetic, and h_x in front of it across xGMI (DESIGN.md
 // section 7).  With D >= 1 the rows an iteration needs were published D iterations ago: they
 // have D iterations' time to cross the fabric, and an iteration costs max(arithmetic, h_x / D).
-// Nothing is waited for in the common case, so the loop is lean_demc_thin_kernel's: the draws
-// of 64 iterations at once, one per lane; the two rows of the NEXT iteration asked for first
+// Nothing is waited for in the common case, so the loop is laid out like lean_snooker_kernel's:
+// the draws of 64 iterations at once, one per lane (Philox, log u and its window, the partners'
+// row offsets); the two rows of the NEXT iteration asked for first
 // thing by loads the compiler does not see (handoff.h load_published_async: one load site, one
 // wait site) and retired behind this iteration's store; a row that is still the sentinel --
 // D x the iteration time shorter than the hop -- is asked for again the usual way.
-//   any thinning (the `thinning` iterations of a refresh look at the same rows);
+//   any thinning (the `thinning` iterations of a refresh draw their partners anew but look at
+//   the same rows) -- also in the STRICT lockstep, zlag = 0 with thinning > 1, where only the
+//   first iteration of a refresh asks for rows its partners are about to publish and waits
+//   (round 3's lean_demc_thin_kernel was this loop for the plain shape: 290 -> 359 M
+//   chain-steps/s at thinning 10);
 //   FX: some coefficients fixed or shared, Gaussian priors (as lean_demc_kernel's);
 //   P2P: the ensemble is sharded over GPUs -- rows are read from the local replica at system
 //   scope, published into it, and carried to the other replicas by the COURIER wave (handoff.h;
@@ -1123,7 +1106,12 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_lag_kernel(const
                                        mc3_bits(C.val[1]) == ROW_PENDING), 0)) {
                 const double *const a2[2] = {C.addr[0], C.addr[1]};
                 double v2[2] = {C.val[0], C.val[1]};
-                alive = wait_rows<2, P2P>(a2, v2, ctl_rw);
+                alive = wait_rows<2, P2P>(a2, v2, ctl_rw, nullptr, [&]() {
+                    if constexpr (P2P && !COURIER) {         // (test hook: see lean_demc_kernel)
+                        if (__builtin_expect(P.remote_delay != 0, 0))
+                            late.drain(P, s_ring, peers_z, lane, mine, false);
+                    }
+                });
                 // (nothing this path asked for is pending where it joins the other)
                 __builtin_amdgcn_s_waitcnt(0x0F70);
                 asm volatile("; rows of this iteration" : "+v"(v2[0]), "+v"(v2[1]));

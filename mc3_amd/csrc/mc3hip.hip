@@ -111,7 +111,7 @@ int check_device_room(size_t bytes, const char *what)
 int choose_wpc(int nlocal, int ndata, int wlike)
 {
     // One wave per chain when there are enough chains to fill the chip or the
-    // data sum is short; otherwise split a chain's data over 4 or 16 waves.
+    // data sum is short; otherwise split a chain's data over 4 waves.
     const char *env = getenv("MC3HIP_WPC");
     if (wlike) {
         // blocked D4 pyramid (wavelet.h block_wavelet): at most 32 points per thread;
@@ -124,16 +124,16 @@ int choose_wpc(int nlocal, int ndata, int wlike)
     }
     if (env) {
         const int v = atoi(env);
-        if (v == 1 || v == 4 || v == 16)
+        if (v == 1 || v == 4)
             return v;
     }
     if (ndata <= 4096)
         return 1;
     if (nlocal >= 1024)
         return 1;
-    if (ndata <= 32768 || nlocal >= 256)
-        return 4;
-    return 16;
+    // (sixteen waves per chain -- 1024 threads, 128 registers each: every instance spilled --
+    // went with round 4; few chains over very many points belong to the tiled plan)
+    return 4;
 }
 
 }  // namespace
@@ -242,6 +242,8 @@ void launch_fast(mc3hip_ctx *c, int nref)
 
 int blocks_per_cu(const void *kernel, int threads, size_t smem)
 {
+    if (!kernel)                     // (no persistent instance serves this context)
+        return 0;
     int nb = 0;
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, smem) ==
                    hipSuccess ? nb : 0;
@@ -279,13 +281,12 @@ void launch_model_t(mc3hip_ctx *c)
     if (c->P.wlike) {                                                               \
         if (c->P.wl_scratch) return call_wavelet(large);                            \
         switch (c->wpc) {                                                           \
-        case 8: case 16: return call_wavelet(w8);                                   \
+        case 8: return call_wavelet(w8);                                            \
         case 4: return call_wavelet(w4);                                            \
         default: return call_wavelet(w1);                                           \
         }                                                                           \
     }                                                                               \
     switch (c->wpc) {                                                               \
-    case 16: return call_gauss(w16);                                                \
     case 4: return call_gauss(w4);                                                  \
     default: return call_gauss(w1);                                                 \
     }
@@ -351,13 +352,13 @@ void persist_blocks_per_cu(mc3hip_ctx *c, int *out)
 {
     const bool p2p = c->p2p_ranks > 1;
     const void *f = reinterpret_cast<const void *>(persist_instance(c, p2p));
-    if (persist_smem(c, p2p) > 64 * 1024)
+    if (f && persist_smem(c, p2p) > 64 * 1024)
         (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)persist_smem(c, p2p));
     int nb = blocks_per_cu(f, persist_threads(c, p2p), persist_smem(c, p2p));
     if ((c->flags & MC3HIP_FLAG_P2P) && !p2p) {
         const void *g = reinterpret_cast<const void *>(persist_instance(c, true));
-        if (c->smem > 64 * 1024)
+        if (g && c->smem > 64 * 1024)
             (void)hipFuncSetAttribute(g, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)c->smem);
         const int np = blocks_per_cu(g, 64 * c->wpc, c->smem);
@@ -440,7 +441,7 @@ int decide_persist(mc3hip_ctx *c)
     c->fast = fast_eligible(c);
     // wavelet likelihood with eight waves per chain: a ninth wave runs the chain
     c->chainwave = c->P.wlike && c->wpc == 8 && !c->P.wl_scratch &&
-                   !(c->flags & MC3HIP_FLAG_P2P) && !getenv("MC3HIP_NO_CHAINWAVE") &&
+                   !(c->flags & MC3HIP_FLAG_P2P) &&
                    c->smem + CW_EXTRA_DOUBLES * sizeof(double) <= 160 * 1024;
     c->P.cw_lean = (c->chainwave && cw_lean_eligible(c) && !getenv("MC3HIP_NO_CW_LEAN")) ? 1 : 0;
     // Helper waves for the hand-laid-out DEMC loop (lean_demc_wide_kernel) are NOT the
@@ -474,11 +475,10 @@ int decide_persist(mc3hip_ctx *c)
     capacity = capacity < cap_limit ? capacity : cap_limit;
     if (nb < 1)
         return 0;
-    if (c->fast && c->P.nlocal > capacity && lag_demc_shape(c) && !lean_plain_shape(c) &&
-        (c->P.thinning != 1 || (c->flags & MC3HIP_FLAG_P2P))) {
-        // fixed coefficients / priors with thinning > 1 or peer to peer: only the one-chain-per-
-        // wave loop of the declared cadence is lean there; more chains than it can hold run the
-        // general chain
+    if (c->fast && c->P.nlocal > capacity && lean_one_chain_only(c)) {
+        // fixed coefficients / priors with thinning > 1 or peer to peer, the support
+        // distribution: only a one-chain-per-wave loop is lean there; more chains than it can
+        // hold run the general chain
         c->fast = false;
         persist_blocks_per_cu(c, &nb);
         const int pc = (nb > 1 && getenv("MC3HIP_PERSIST_MARGIN")) ? nb - 1 : nb;
@@ -515,7 +515,7 @@ int decide_persist(mc3hip_ctx *c)
                     break;
                 const void *f = reinterpret_cast<const void *>(
                     c->fast ? fast_instance(c, false) : persist_instance(c, false));
-                if (smem > 64 * 1024)
+                if (f && smem > 64 * 1024)
                     (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
                                               (int)smem);
                 int nbm = blocks_per_cu(f, threads, smem);
@@ -1115,7 +1115,7 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
                      ? ((lean_demc_eligible(c) || lean_demc_mc_eligible(c) ||
                          lean_snooker_eligible(c) || lean_mrw_eligible(c) ||
                          lean_snooker_mc_eligible(c) || lean_mrw_mc_eligible(c) ||
-                         lean_demc_thin_eligible(c) || lean_demc_lag_eligible(c)) ? 2 : 1) : 0;
+                         lean_demc_lag_eligible(c)) ? 2 : 1) : 0;
     if (plan->fast == 2 && c->p2p_ranks <= 1)
         plan->waves_per_chain = lean_waves(c);      // (helper waves share the data sum)
     if (plan->persistent > 0 && chainwave_runs(c, c->p2p_ranks > 1) && c->P.cw_lean)

@@ -29,7 +29,8 @@ class DeviceChains:
                  nsamples=None, sampler='snooker', wlike=False, thinning=1,
                  fgamma=1.0, fepsilon=0.0, hsize=10, model='poly', nmodel=None,
                  seed=0, device=0, chain0=0, nlocal=None, M0=None, zlen=None,
-                 trace_iters=0, no_graph=False, no_persist=False, p2p=False, zlag=0):
+                 trace_iters=0, no_graph=False, no_persist=False, p2p=False, zlag=0,
+                 no_courier=False):
         self._ctx = None
         self.lib = _lib.load()
         self.params = f64(params).copy()
@@ -92,7 +93,8 @@ class DeviceChains:
         P.thinning = self.thinning
         P.flags = (_lib.FLAG_NO_GRAPH if no_graph else 0) | \
             (_lib.FLAG_NO_PERSIST if no_persist else 0) | \
-            (_lib.FLAG_P2P if p2p else 0)
+            (_lib.FLAG_P2P if p2p else 0) | (_lib.FLAG_NO_COURIER if no_courier else 0)
+        self.no_courier = bool(no_courier)
         P.trace_iters = int(trace_iters)
         P.M0, P.zlen = self.M0, self.zlen
         P.seed = self.seed

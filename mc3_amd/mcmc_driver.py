@@ -202,7 +202,7 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
          fgamma, fepsilon, hsize, kickoff, savefile, resume, log,
          pnames, texnames,
          seed=None, device=0, comm=None, engine_factory=None, kickoff_stream=None,
-         _extras=None):
+         zlag=None, _extras=None):
     """Run the chains and assemble the output dictionary (see module docstring).
 
     ``ncpu`` is accepted for signature compatibility and ignored: the fan-out
@@ -213,7 +213,9 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
     ``kickoff_stream``: where the trial vectors of the initial population come from --
     'philox' (default: drawn, tested and evaluated on the device, keyed by ``seed``) or
     'numpy' (the global NumPy stream in the reference's order: with np.random.seed set,
-    the population equals the reference's).
+    the population equals the reference's); ``zlag``: the declared cadence of a run sharded
+    over GPUs (include/mc3hip.h mc3hip_problem.zlag; default: 0 on one GPU, the
+    communicator's choice -- parallel.DEFAULT_ZLAG -- over several).
     """
     data = np.asarray(data, float)
     params = np.array(params, float)
@@ -272,7 +274,7 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
         thinning=thinning, fgamma=fgamma, fepsilon=fepsilon, hsize=hsize,
         model=lowered.family, nmodel=lowered.ncoef, seed=seed, device=device,
         chain0=chain0, nlocal=nlocal, M0=M0, zlen=zlen,
-        **({'p2p': True} if comm.wants_p2p else {}))
+        **comm.engine_options(device, thinning, zlag))
     view = ChainView(engine, func, indparams, indparams_dict, data, wlike,
                      lowered.offset)
     bestp = np.copy(params)

@@ -30,6 +30,8 @@ The random numbers are keyed by GLOBAL chain id, so a sharded run reproduces
 the single-rank run bit for bit.  The reference has no counterpart: its workers
 share memory inside one host (mc3/mcmc_driver.py:143-221).
 """
+import hashlib
+import hmac
 import os
 import pickle
 import socket
@@ -38,6 +40,12 @@ import tempfile
 import time
 
 import numpy as np
+
+
+# Refreshes (of thinning 1) a row may take to reach the other ranks in the declared cadence of
+# a sharded run: an iteration of the headline loop is ~0.6 us, so four of them cover an xGMI
+# hop of up to ~2.5 us (profiles/r04_delay_sweep.jsonl: where the rate starts to fall per zlag)
+DEFAULT_ZLAG = 4
 
 
 class SingleRank:
@@ -56,6 +64,9 @@ class SingleRank:
 
     def partition(self, nchains):
         return 0, nchains
+
+    def engine_options(self, device=0, thinning=1, zlag=None):
+        return {} if not zlag else {'zlag': int(zlag)}
 
     def broadcast(self, obj):
         return obj
@@ -92,6 +103,7 @@ class Communicator:
         self.native = False
         self.mode = 'host'
         self.recoveries = 0
+        self.crowded = False
 
     # -- primitives ---------------------------------------------------------------
     def all_gather(self, obj):
@@ -117,6 +129,29 @@ class Communicator:
                              f'number of ranks ({self.size})')
         n = nchains//self.size
         return self.rank*n, n
+
+    def engine_options(self, device=0, thinning=1, zlag=None):
+        """What this communicator asks of the engine it is about to be given (keywords of
+        DeviceChains), decided BEFORE the engine exists -- the library sizes its persistent
+        grid from the very kernel instance these select:
+
+        * ``zlag``: the declared cadence of a sharded run (include/mc3hip.h): the other
+          chains are seen ``zlag`` refreshes late, so that a row has that long to cross
+          xGMI.  Default for several ranks: DEFAULT_ZLAG iterations' worth of refreshes
+          (MC3HIP_ZLAG overrides; 0 = the strict lockstep, every iteration then pays the hop);
+        * ``p2p``: fine-grained, IPC-shareable Z (the peer-to-peer hand-off is wanted);
+        * ``no_courier``: more than two ranks share this rank's device (a test set-up)."""
+        if self.size == 1:
+            return {} if not zlag else {'zlag': int(zlag)}
+        if zlag is None:
+            env = os.environ.get('MC3HIP_ZLAG')
+            zlag = int(env) if env is not None else -(-DEFAULT_ZLAG//max(1, int(thinning)))
+        opts = {'zlag': int(self.broadcast(int(zlag)))}
+        if self.wants_p2p:
+            devices = self.all_gather(int(device))
+            self.crowded = max(devices.count(d) for d in devices) > 2
+            opts.update(p2p=True, no_courier=self.crowded)
+        return opts
 
     def setup(self, engine):
         """Choose the exchange: peer-to-peer hand-off, else RCCL inside the library,
@@ -162,19 +197,22 @@ class Communicator:
         ranks on it must be co-resident or they wait for each other forever (until the
         hand-off gives up).  MC3HIP_RESIDENT_MAXCOL caps a rank's share; without it such a
         run is refused here, on every rank alike."""
-        import os
         dev = getattr(engine, '_device', None)
         plan = getattr(engine, 'plan', None) or {}
         devices = self.all_gather((dev, bool(plan.get('resident'))))
         if dev is None:
             return
-        # (the peer-to-peer instance of the headline loop has a second wave per chain, the
+        # (the peer-to-peer instances of the headline loops have a second wave per chain, the
         # courier: the two-wave workgroups of four ranks of 256 chains would fill ONE device
         # to the last wave slot and are not all co-resident in practice -- a launch gives up
         # and the run falls back to the host-staged exchange; such a test set-up runs without
-        # the courier, MC3HIP_NO_COURIER)
-        if max(sum(1 for e, _ in devices if e == d) for d, _ in devices) > 2:
-            os.environ.setdefault('MC3HIP_NO_COURIER', '1')
+        # the courier, which the engine must be CREATED for: engine_options() says so)
+        if self.wants_p2p and max(sum(1 for e, _ in devices if e == d) for d, _ in devices) > 2 \
+                and not getattr(engine, 'no_courier', True) \
+                and not os.environ.get('MC3HIP_NO_COURIER'):
+            raise RuntimeError(
+                'more than two ranks share a device: create the engine with the keywords of '
+                'Communicator.engine_options() (no_courier=True)')
         shared = sum(1 for d, _ in devices if d == dev) > 1
         anybody = any(s and r for (d, r), s in
                       zip(devices, [sum(1 for e, _ in devices if e == d) > 1
@@ -305,6 +343,7 @@ class TorchDistComm(Communicator):
 
 # ---- the torch-free control plane -------------------------------------------------------
 _HDR = struct.Struct('!Q')
+_MAX_FRAME = 1 << 30
 
 
 def _send(sock, obj):
@@ -324,8 +363,50 @@ def _recv_exact(sock, n):
 
 
 def _recv(sock):
+    """A pickled frame -- ONLY ever called on a connection that has passed the handshake
+    below (unpickling runs code: nothing a stranger sent may reach it)."""
     (n,) = _HDR.unpack(_recv_exact(sock, _HDR.size))
+    if n > _MAX_FRAME:
+        raise ConnectionError(f'control frame of {n} bytes')
     return pickle.loads(_recv_exact(sock, n))
+
+
+# The handshake is fixed-size binary, no pickle: rank 0 sends a 16-byte challenge; the rank
+# answers with MAGIC | rank | size | HMAC-SHA256(secret, challenge | rank | size); rank 0 checks
+# it in constant time and answers with HMAC(secret, challenge | b'ok') -- so both sides prove
+# they hold the run's secret (MC3HIP_RDV_SECRET, made by the launcher, or the token of the
+# port file, which only this user can read) before a single frame is unpickled.
+_MAGIC = b'MC3H'
+_HELLO = struct.Struct('!4sII32s')
+
+
+def _mac(secret, *parts):
+    return hmac.new(secret, b''.join(parts), hashlib.sha256).digest()
+
+
+def _handshake_server(conn, secret, size, taken):
+    """The rank behind an accepted connection, or None (a stranger, garbage, a duplicate)."""
+    challenge = os.urandom(16)
+    conn.sendall(challenge)
+    magic, rank, nranks, mac = _HELLO.unpack(_recv_exact(conn, _HELLO.size))
+    want = _mac(secret, challenge, struct.pack('!II', rank, nranks))
+    if magic != _MAGIC or not hmac.compare_digest(mac, want) or nranks != size \
+            or not (0 < rank < size) or rank in taken:
+        return None
+    conn.sendall(_mac(secret, challenge, b'ok'))
+    return rank
+
+
+def _handshake_client(sock, secret, rank, size):
+    challenge = _recv_exact(sock, 16)
+    sock.sendall(_HELLO.pack(_MAGIC, rank, size,
+                             _mac(secret, challenge, struct.pack('!II', rank, size))))
+    answer = _recv_exact(sock, 32)
+    return hmac.compare_digest(answer, _mac(secret, challenge, b'ok'))
+
+
+def _is_loopback(addr):
+    return addr in ('localhost', '::1') or addr.startswith('127.')
 
 
 def _port_file(addr, port, run_id):
@@ -342,25 +423,44 @@ class SocketComm(Communicator):
     Rendezvous, ``SocketComm.from_env()``: RANK and WORLD_SIZE as every launcher sets
     them.  Where rank 0 listens:
 
-    * ``MC3HIP_RDV_PORT`` set (our own launchers: ``bench.py --gpus N``,
-      ``mc3_amd.parallel.spawn``): on MASTER_ADDR at that port;
+    * ``MC3HIP_RDV_FILE`` set (our own launchers: ``bench.py --gpus N``, tests/ranks.py, through
+      ``rank_env``): on MASTER_ADDR at a port of rank 0's own choosing, published in that file
+      (nobody probes for a free port and lets go of it again);
+    * ``MC3HIP_RDV_PORT`` set: on MASTER_ADDR at that port (``MC3HIP_RDV_SECRET`` required);
     * otherwise (under ``torch.distributed.run``, whose agent keeps MASTER_PORT for its
       own store): on an ephemeral port that rank 0 publishes in a file named after
       MASTER_ADDR / MASTER_PORT / the launcher's run id in the temporary directory --
-      one node, which is what this package shards over; the connection is confirmed by
-      a token, so a stale file of an earlier run is never mistaken for this one.
+      one node, which is what this package shards over.
+
+    Every connection proves, in a fixed-size binary handshake (no pickle), that it holds the
+    run's secret -- ``MC3HIP_RDV_SECRET`` or the token in the port file (mode 0600) -- before
+    a frame of it is unpickled; strangers and garbage are dropped and the rendezvous goes on.
+    Only loopback addresses unless ``MC3HIP_RDV_ALLOW_REMOTE=1``.
     """
 
     def __init__(self, rank, size, addr='127.0.0.1', port=0, port_file=None, timeout=300.0,
-                 use_rccl=True, use_p2p=True):
+                 use_rccl=True, use_p2p=True, secret=None, comm_timeout=None):
         super().__init__(rank, size, use_rccl, use_p2p)
+        # `timeout` bounds the rendezvous only; between collectives the ranks may be busy for
+        # as long as a run takes (a checkpoint, a library rebuild on one rank): a dead peer
+        # closes its socket, a hung one is the launcher's watchdog's business
         self.timeout = float(timeout)
+        self.comm_timeout = float(os.environ.get('MC3HIP_COMM_TIMEOUT', 86400.0)
+                                  if comm_timeout is None else comm_timeout)
+        self._secret = secret.encode() if isinstance(secret, str) else secret
         self._peers = []          # rank 0: sockets of ranks 1.., in rank order
         self._up = None           # other ranks: the socket to rank 0
         self._listener = None
         self._port_file = None
         if self.size == 1:
             return
+        if not _is_loopback(addr) and not os.environ.get('MC3HIP_RDV_ALLOW_REMOTE'):
+            raise ValueError(
+                f'SocketComm: {addr} is not a loopback address; this package shards over the '
+                'GPUs of ONE node.  Set MC3HIP_RDV_ALLOW_REMOTE=1 to listen there all the same')
+        if self._secret is None and not port_file:
+            raise ValueError('SocketComm: a fixed port needs the run\'s secret '
+                             '(MC3HIP_RDV_SECRET; mc3_amd.parallel.rank_env makes one)')
         if self.rank == 0:
             self._serve(addr, int(port), port_file)
         else:
@@ -371,15 +471,19 @@ class SocketComm(Communicator):
         rank = int(os.environ.get('RANK', '0'))
         size = int(os.environ.get('WORLD_SIZE', '1'))
         addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
+        secret = os.environ.get('MC3HIP_RDV_SECRET')
+        if 'MC3HIP_RDV_FILE' in os.environ:       # (our launchers: rank 0 picks the port)
+            return cls(rank, size, addr, 0, port_file=os.environ['MC3HIP_RDV_FILE'],
+                       secret=secret, **kw)
         if 'MC3HIP_RDV_PORT' in os.environ:
-            return cls(rank, size, addr, int(os.environ['MC3HIP_RDV_PORT']), **kw)
+            return cls(rank, size, addr, int(os.environ['MC3HIP_RDV_PORT']), secret=secret, **kw)
         run_id = os.environ.get('TORCHELASTIC_RUN_ID', 'none')
         pf = _port_file(addr, os.environ.get('MASTER_PORT', '0'), run_id)
-        return cls(rank, size, addr, 0, port_file=pf, **kw)
+        return cls(rank, size, addr, 0, port_file=pf, secret=secret, **kw)
 
     # -- rendezvous ---------------------------------------------------------------
     def _serve(self, addr, port, port_file):
-        token = os.urandom(8).hex()
+        token = os.urandom(16).hex()
         if port_file and os.path.exists(port_file):
             os.remove(port_file)                  # (left behind by a run that died)
         srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
@@ -388,47 +492,66 @@ class SocketComm(Communicator):
         srv.listen(self.size)
         srv.settimeout(self.timeout)
         self._listener = srv
+        # the secret of this run: the launcher's, or the token only this user can read
+        secret = self._secret if self._secret is not None else token.encode()
         if port_file:
             tmp = f'{port_file}.{os.getpid()}'
-            with open(tmp, 'w') as f:
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+            with os.fdopen(fd, 'w') as f:
                 f.write(f'{srv.getsockname()[1]} {token}\n')
             os.replace(tmp, port_file)
             self._port_file = port_file
         peers = {}
+        deadline = time.monotonic() + self.timeout
         while len(peers) < self.size - 1:
+            if time.monotonic() > deadline:
+                raise TimeoutError(f'rank 0: {self.size - 1 - len(peers)} ranks did not show up '
+                                   f'within {self.timeout:.0f} s')
             conn, _ = srv.accept()
-            conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            conn.settimeout(self.timeout)
-            hello = _recv(conn)
-            if (port_file and hello.get('token') != token) or hello.get('size') != self.size \
-                    or not (0 < hello.get('rank', 0) < self.size) or hello['rank'] in peers:
-                _send(conn, {'ok': False})
-                conn.close()
+            # a connection that sends garbage, the wrong secret or nothing at all is dropped
+            # and the rendezvous goes on: only its own ranks can end it
+            try:
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                conn.settimeout(min(self.timeout, 20.0))
+                rank = _handshake_server(conn, secret, self.size, peers)
+            except (OSError, ConnectionError, struct.error):
+                rank = None
+            if rank is None:
+                try:
+                    conn.close()
+                except OSError:
+                    pass
                 continue
-            _send(conn, {'ok': True})
-            peers[hello['rank']] = conn
+            conn.settimeout(self.comm_timeout)
+            peers[rank] = conn
         self._peers = [peers[r] for r in range(1, self.size)]
 
     def _connect(self, addr, port, port_file):
         deadline = time.monotonic() + self.timeout
         last = None
         while time.monotonic() < deadline:
-            token = None
+            secret = self._secret
+            s = None
             try:
                 if port_file:
                     with open(port_file) as f:
                         p, token = f.read().split()
                     port = int(p)
+                    if secret is None:
+                        secret = token.encode()
                 s = socket.create_connection((addr, port), timeout=self.timeout)
                 s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 s.settimeout(self.timeout)
-                _send(s, {'rank': self.rank, 'size': self.size, 'token': token})
-                if _recv(s).get('ok'):
+                if _handshake_client(s, secret, self.rank, self.size):
+                    s.settimeout(self.comm_timeout)
                     self._up = s
                     return
+                last = ConnectionError('rank 0 did not prove the secret of this run')
                 s.close()
             except (OSError, ValueError, ConnectionError, EOFError) as e:   # not there yet
                 last = e
+                if s is not None:
+                    s.close()
             time.sleep(0.05)
         raise TimeoutError(f'rank {self.rank}: no rendezvous with rank 0 at {addr} '
                            f'({port_file or port}) within {self.timeout:.0f} s: {last}')
@@ -465,16 +588,33 @@ class SocketComm(Communicator):
 
 
 def free_port(addr='127.0.0.1'):
+    """A port that was free a moment ago (for launchers that must name one up front, like
+    ``torch.distributed.run --master-port``; our own ranks meet through ``rank_env``'s file)."""
     with socket.socket() as s:
         s.bind((addr, 0))
         return s.getsockname()[1]
 
 
-def rank_env(rank, size, port, addr='127.0.0.1', base=None):
+def new_rendezvous():
+    """(file, secret) for one launch of ranks on this node: rank 0 publishes its port in the
+    file, everybody proves the secret."""
+    d = os.environ.get('MC3HIP_RDV_DIR') or tempfile.gettempdir()
+    return (os.path.join(d, f'mc3hip_rdv_{os.getpid()}_{os.urandom(6).hex()}.port'),
+            os.urandom(16).hex())
+
+
+def rank_env(rank, size, rendezvous, addr='127.0.0.1', base=None):
     """The environment of rank ``rank`` of ``size`` processes on this node that meet through
-    ``SocketComm.from_env()`` at ``addr:port`` (what ``bench.py --gpus N`` gives its children)."""
+    ``SocketComm.from_env()`` (what ``bench.py --gpus N`` gives its children).  ``rendezvous``
+    is ``new_rendezvous()``'s pair, the same for all ranks of a launch -- or a port number (the
+    secret then comes from ``base`` / the environment, MC3HIP_RDV_SECRET)."""
     env = dict(os.environ if base is None else base)
-    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(size),
-               MASTER_ADDR=addr, MC3HIP_RDV_PORT=str(port))
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(size), MASTER_ADDR=addr)
+    for k in ('MC3HIP_RDV_PORT', 'MC3HIP_RDV_FILE'):
+        env.pop(k, None)
+    if isinstance(rendezvous, (tuple, list)):
+        env.update(MC3HIP_RDV_FILE=rendezvous[0], MC3HIP_RDV_SECRET=rendezvous[1])
+    else:
+        env.update(MC3HIP_RDV_PORT=str(rendezvous))
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # HIP IPC on this driver (dmabuf)
     return env

@@ -2,10 +2,10 @@
 
 Same signature, defaults, error messages and output dictionary as ``mc3.sample``
 (mc3/sampler_driver.py:25-601); the call to ``mcmc()`` at :448-457 goes to
-mc3_amd.mcmc_driver.mcmc.  What is outside the hot path is NOT re-implemented:
-the least-squares pre-fit (``leastsq`` / ``chisqscale``, SciPy-bound, mc3/fit_driver.py)
-is refused with one message, plots are skipped with a warning, parameter / data files
-are not read.
+mc3_amd.mcmc_driver.mcmc.  The least-squares pre-fit (``leastsq`` / ``chisqscale``,
+mc3/fit_driver.py) runs once on the host through mc3_amd.fit, as the reference's does
+through SciPy; what else lies outside the hot path is NOT re-implemented: plots are
+skipped with a warning, parameter / data files are not read.
 
 Layout: the argument handling is a pipeline of small normalisers over one
 ``_Inputs`` record, each stating the rule of the reference it implements; only the
@@ -178,13 +178,16 @@ def sample(
       Linear, or any callable that is affine in its parameters (recognised by
       probing); anything else raises ValueError.
     - ``ncpu`` is ignored (the GPU advances all chains in lockstep).
-    - ``leastsq`` / ``chisqscale`` (the SciPy pre-fit) and ``plots`` are outside the
-      MI355X path: the first is refused, the second skipped with a warning.
+    - ``leastsq`` / ``chisqscale``: the pre-fit runs on the host (mc3_amd.fit, SciPy, once,
+      before the chains), with the reference's outputs; ``plots`` are outside the MI355X
+      path and skipped with a warning.
     - extra keywords: ``seed`` (int), ``device`` (int), ``kickoff_stream`` ('philox':
       initial population drawn on the device, the default; 'numpy': from the global
       NumPy stream like the reference), ``comm``
       (mc3_amd.parallel communicator for multi-GPU runs: every rank makes the same
-      call and gets the same dictionary; files are written by rank 0 only).
+      call and gets the same dictionary; files are written by rank 0 only), ``zlag`` (the
+      declared cadence of a sharded run: the other chains are seen that many refreshes late,
+      include/mc3hip.h; default 0 on one GPU, parallel.DEFAULT_ZLAG over several).
     """
     from . import __version__
     comm = kwargs.get('comm')
@@ -261,7 +264,7 @@ def sample(
             os.makedirs(folder)
 
     extra = {k: kwargs[k] for k in ('seed', 'device', 'comm', 'engine_factory',
-                                   'kickoff_stream') if k in kwargs}
+                                   'kickoff_stream', 'zlag') if k in kwargs}
     extra['_extras'] = side = {}
     output = mcmc(
         inp.data, inp.uncert, func, inp.params, indparams, indparams_dict,

@@ -19,17 +19,30 @@ import ranks  # noqa: E402
 
 def main():
     out_path, nref = sys.argv[1], int(sys.argv[2])
+    # key=value extras: per_rank (256), ndata (1000), sampler (demc), thinning (1), zlag (the
+    # communicator's default), fx (0; 1: a fixed and a shared coefficient, priors)
+    extra = dict(a.split('=') for a in sys.argv[3:])
     comm = ranks.worker_comm(use_p2p=True, use_rccl=False)
-    nchains = 256*comm.size
-    prob = H.quad_problem(ndata=1000, nchains=nchains, nsamples=nchains*nref, sampler='demc')
+    per_rank = int(extra.get('per_rank', 256))
+    thinning = int(extra.get('thinning', 1))
+    nchains = per_rank*comm.size
+    prob = H.lean_shape_problem(nchains, nref, ndata=int(extra.get('ndata', 1000)),
+                                sampler=extra.get('sampler', 'demc'), thinning=thinning,
+                                fx=int(extra.get('fx', 0)))
     pop = np.load(out_path + '.pop.npz')
     c0, n = comm.partition(nchains)
-    gpu = engine.DeviceChains(chain0=c0, nlocal=n, p2p=True, device=0, **prob)
+    opts = comm.engine_options(0, thinning, int(extra['zlag']) if 'zlag' in extra else None)
+    assert opts['p2p'] and opts['no_courier'] == (comm.size > 2), opts
+    gpu = engine.DeviceChains(chain0=c0, nlocal=n, device=0, **opts, **prob)
     gpu.set_population(pop['Z0'], pop['lp0'])
     comm.setup(gpu)
     assert comm.mode == 'p2p', comm.mode
     plan = gpu.plan
-    assert plan['fast'] == 2 and plan['persistent'] > 0, plan      # lean_demc_kernel<3, P2P>
+    # the hand-laid-out loops: lean_demc_kernel<3, P2P> (strict lockstep), lean_demc_lag_kernel
+    # (the declared cadence), lean_snooker_kernel / lean_mrw_kernel with their couriers
+    assert plan['fast'] == 2 and plan['persistent'] > 0 and plan['zlag'] == opts['zlag'], plan
+    if 'MC3HIP_TEST_REMOTE_DELAY_NS' in os.environ:
+        assert plan['remote_delay_ns'] > 0, plan
     # two segments: the second persistent launch resumes from the replicas
     gpu.run(nref//3, sync=False)
     comm.quiesce(gpu)
@@ -38,7 +51,7 @@ def main():
     assert comm.mode == 'p2p' and comm.recoveries == 0
     Z, lp, zc = gpu.rows()
     st = gpu.state()
-    np.savez(f'{out_path}.rank{comm.rank}.npz', Z=Z, lp=lp, zc=zc,
+    np.savez(f'{out_path}.rank{comm.rank}.npz', Z=Z, lp=lp, zc=zc, zlag=plan['zlag'],
              numaccept=st['numaccept'], outbounds=st['outbounds'],
              best_chisq=st['best_chisq'], X=st['X'], chisq=st['chisq'])
     comm.barrier()

@@ -21,7 +21,8 @@ def main():
     out_path, nref, per_rank, ndata, nmodel, sampler = (
         sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]),
         sys.argv[6])
-    abort_at = int(sys.argv[7].split('=')[1]) if len(sys.argv) > 7 else None
+    extra = dict(a.split('=') for a in sys.argv[7:])
+    abort_at = int(extra['abort']) if 'abort' in extra else None
     if abort_at is not None and int(os.environ.get('RANK', '0')) == 0:
         # test hook: this rank's first chain gives up at that refresh (read at create)
         os.environ['MC3HIP_TEST_ABORT_AT'] = str(abort_at)
@@ -36,7 +37,8 @@ def main():
     pop = np.load(out_path + '.pop.npz')
     c0, n = comm.partition(nchains)
     trace = int(os.environ.get('C5_WORKER_TRACE', '0'))
-    gpu = engine.DeviceChains(chain0=c0, nlocal=n, p2p=True, device=0, trace_iters=trace, **prob)
+    opts = comm.engine_options(0, 1, int(extra['zlag']) if 'zlag' in extra else None)
+    gpu = engine.DeviceChains(chain0=c0, nlocal=n, device=0, trace_iters=trace, **opts, **prob)
     gpu.set_population(pop['Z0'], pop['lp0'])
     comm.setup(gpu)
     if os.environ.get('MC3HIP_NO_RESIDENT'):
@@ -71,6 +73,7 @@ def main():
     extra = {}
     if trace:
         extra['tc'], extra['tf'] = gpu.trace(trace)
+    extra['zlag'] = gpu.plan['zlag']
     np.savez(f'{out_path}.rank{comm.rank}.npz', Z=Z, lp=lp, zc=zc, **extra,
              numaccept=st['numaccept'], outbounds=st['outbounds'],
              best_chisq=st['best_chisq'], X=st['X'], chisq=st['chisq'])

@@ -30,6 +30,25 @@ def quad_problem(ndata=100, nchains=8, nsamples=800, sampler='demc', **kw):
     return prob
 
 
+def lean_shape_problem(nchains, nref, ndata=1000, sampler='demc', thinning=1, fx=0, **kw):
+    """The shapes the hand-laid-out one-wave loops serve: the tutorial's quadratic (fx = 0), or
+    a cubic with p2 fixed, p3 shared with p1 and two-sided Gaussian priors (fx = 1)."""
+    if not fx:
+        prob = quad_problem(ndata=ndata, nchains=nchains, nsamples=nchains*nref*thinning,
+                            sampler=sampler, thinning=thinning)
+    else:
+        prob = shared_problem(nchains=nchains, nsamples=nchains*nref*thinning, sampler=sampler,
+                              thinning=thinning)
+        prob['params'] = prob['params'][:4]
+        for k in ('pstep', 'pmin', 'pmax', 'prior', 'priorlow', 'priorup'):
+            prob[k] = prob[k][:4]
+        prob['pstep'] = np.array([0.3, 1.0, 0.0, -2.0])     # p2 fixed, p3 <- p1
+    if sampler == 'mrw':
+        prob['pstep'] = prob['pstep']*np.where(prob['pstep'] > 0, 0.05, 1.0)
+    prob.update(kw)
+    return prob
+
+
 def shared_problem(nchains=8, nsamples=1600, sampler='snooker', **kw):
     """Degree-4 polynomial with tight bounds, two-sided Gaussian priors, a
     shared parameter (p3 <- p1) and a fixed one (p4)."""

@@ -35,7 +35,7 @@ def main():
         pmin=np.array([-10.0, -20.0, -10.0]), pmax=np.array([40.0, 20.0, 10.0]),
         sampler=sampler, nsamples=nchains*niter*thinning, burnin=10, nchains=nchains,
         thinning=thinning, grtest=True, log=mu.Log(verb=0), seed=99, comm=comm,
-        device=0)
+        device=0, **({'zlag': int(extra['zlag'])} if 'zlag' in extra else {}))
     if abort_at is None:
         assert comm.mode == 'p2p' and comm.recoveries == 0, (comm.mode, comm.recoveries)
     else:

@@ -16,7 +16,8 @@ def launch_ranks(nproc, script, *args, env=None, launcher='socket', timeout=1000
     stdout (asserts that every rank exited with 0)."""
     from mc3_amd import parallel
     base = dict(os.environ, OMP_NUM_THREADS='1', HSA_ENABLE_IPC_MODE_LEGACY='0', **(env or {}))
-    base.pop('MC3HIP_RDV_PORT', None)
+    for k in ('MC3HIP_RDV_PORT', 'MC3HIP_RDV_FILE', 'MC3HIP_RDV_SECRET'):
+        base.pop(k, None)
     path = os.path.join(ROOT, 'tests', script)
     argv = [str(a) for a in args]
     port = parallel.free_port()
@@ -27,8 +28,9 @@ def launch_ranks(nproc, script, *args, env=None, launcher='socket', timeout=1000
         res = subprocess.run(cmd, env=base, capture_output=True, text=True, timeout=timeout)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-6000:]
         return res.stdout
+    rdv = parallel.new_rendezvous()
     procs = [subprocess.Popen([sys.executable, path] + argv,
-                              env=parallel.rank_env(r, nproc, port, base=base),
+                              env=parallel.rank_env(r, nproc, rdv, base=base),
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for r in range(nproc)]
     outs = []
@@ -48,7 +50,8 @@ def worker_comm(**kw):
     """In a worker: SocketComm when launched by launch_ranks(launcher='socket'), the
     torch.distributed adapter under torchrun."""
     from mc3_amd import parallel
-    if 'MC3HIP_RDV_PORT' in os.environ or os.environ.get('MC3_TEST_COMM') == 'socket':
+    if 'MC3HIP_RDV_FILE' in os.environ or 'MC3HIP_RDV_PORT' in os.environ \
+            or os.environ.get('MC3_TEST_COMM') == 'socket':
         return parallel.SocketComm.from_env(**kw)
     import torch.distributed as dist
     dist.init_process_group('gloo')

@@ -15,7 +15,8 @@ BENCH = os.path.join(ROOT, 'bench.py')
 
 def run(cmd, env=None, timeout=300):
     e = dict(os.environ, **(env or {}))
-    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MC3HIP_RDV_PORT'):
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MC3HIP_RDV_PORT', 'MC3HIP_RDV_FILE',
+              'MC3HIP_RDV_SECRET'):
         e.pop(k, None)
     return subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=timeout)
 

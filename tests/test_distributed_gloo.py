@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import mc3_amd
-from mc3_amd import utils as mu
+from mc3_amd import parallel, utils as mu
 from oracle_engine import OracleChains
 import helpers as H
 from ranks import launch_ranks
@@ -34,7 +34,10 @@ def test_two_ranks_reproduce_single_rank(tmp_path, sampler, thinning, launcher):
         pmin=np.array([-10.0, -20.0, -10.0]), pmax=np.array([40.0, 20.0, 10.0]),
         sampler=sampler, nsamples=8*120*thinning, burnin=10, nchains=8,
         thinning=thinning, grtest=False, log=mu.Log(verb=0),
-        engine_factory=OracleChains, seed=99)
+        engine_factory=OracleChains, seed=99,
+        # (a sharded run takes the declared multi-GPU cadence by default; ONE rank in the same
+        # cadence is what it must reproduce)
+        zlag=-(-parallel.DEFAULT_ZLAG//thinning))
     for rank in (0, 1):
         got = np.load(f'{out_path}.rank{rank}.npz')
         for key in ('posterior', 'zchain', 'log_post', 'chisq', 'bestp',
@@ -75,7 +78,8 @@ def test_peer_to_peer_recovery_logic_on_cpu(tmp_path, launcher):
         indparams=[x], pstep=np.array([1.0, 0.5, 0.1]),
         pmin=np.array([-10.0, -20.0, -10.0]), pmax=np.array([40.0, 20.0, 10.0]),
         sampler='demc', nsamples=8*120, burnin=10, nchains=8, grtest=True,
-        log=mu.Log(verb=0), engine_factory=OracleChains, seed=99)
+        log=mu.Log(verb=0), engine_factory=OracleChains, seed=99,
+        zlag=parallel.DEFAULT_ZLAG)
     for rank in (0, 1):
         got = np.load(f'{out_path}.rank{rank}.npz')
         for key in ('posterior', 'zchain', 'log_post', 'chisq', 'bestp',
@@ -109,13 +113,76 @@ BODY = (
     'print("rank", comm.rank, "of", comm.size, "ok")\n')
 
 
-def test_socket_comm_primitives_direct_port():
-    """SocketComm over a known port (MC3HIP_RDV_PORT: what bench.py --gpus N and
-    tests/ranks.py hand to their children): all-gather, broadcast, barrier, votes."""
+def test_socket_comm_primitives_launcher_rendezvous():
+    """SocketComm as bench.py --gpus N and tests/ranks.py hand it to their children
+    (rank_env: rank 0 picks the port and publishes it, everybody proves the launch's secret):
+    all-gather, broadcast, barrier, votes."""
+    from mc3_amd import parallel
+    rdv = parallel.new_rendezvous()
+    outs = _socket_ranks(3, lambda r: parallel.rank_env(r, 3, rdv), BODY)
+    assert sorted(o.strip() for o in outs) == [f'rank {r} of 3 ok' for r in range(3)]
+    assert not os.path.exists(rdv[0])
+
+
+def test_socket_comm_fixed_port_needs_and_checks_the_secret():
+    """MC3HIP_RDV_PORT: a fixed port works with MC3HIP_RDV_SECRET and is refused without;
+    while the ranks meet, strangers knock -- one closes at once, one sends garbage, one sends a
+    well-formed hello signed with ANOTHER secret, one sends a pickle (which must never be
+    loaded: it would create a file) -- and the rendezvous goes on undisturbed."""
+    import pickle
+    import socket
+    import struct
+    import threading
+    import time
     from mc3_amd import parallel
     port = parallel.free_port()
-    outs = _socket_ranks(3, lambda r: parallel.rank_env(r, 3, port), BODY)
+    with pytest.raises(ValueError, match='secret'):
+        parallel.SocketComm(1, 2, port=port)
+    base = dict(os.environ, MC3HIP_RDV_SECRET='s3cret-of-this-run')
+    marker = f'/tmp/mc3hip_pwned_{os.getpid()}'
+
+    class Boom:
+        def __reduce__(self):
+            return (open, (marker, 'w'))
+
+    def strangers():
+        blob = pickle.dumps(Boom())
+        payloads = [b'', os.urandom(200),
+                    struct.pack('!4sII32s', b'MC3H', 1, 3, bytes(32)),
+                    struct.pack('!Q', len(blob)) + blob]
+        for _ in range(200):
+            for pl in payloads:
+                try:
+                    with socket.create_connection(('127.0.0.1', port), timeout=1) as s:
+                        s.settimeout(1)
+                        s.recv(16)
+                        s.sendall(pl)
+                        time.sleep(0.01)
+                except OSError:
+                    pass
+            if done.is_set():
+                return
+
+    done = threading.Event()
+    t = threading.Thread(target=strangers, daemon=True)
+
+    def env(r):
+        if r == 0:
+            t.start() if not t.is_alive() and not done.is_set() else None
+        return parallel.rank_env(r, 3, port, base=base)
+    try:
+        outs = _socket_ranks(3, env, 'import time\ntime.sleep(0.5 if comm.rank else 0)\n' + BODY)
+    finally:
+        done.set()
     assert sorted(o.strip() for o in outs) == [f'rank {r} of 3 ok' for r in range(3)]
+    assert not os.path.exists(marker), 'a frame of an unauthenticated connection was unpickled'
+
+
+def test_socket_comm_refuses_addresses_that_are_not_loopback(monkeypatch):
+    from mc3_amd import parallel
+    monkeypatch.delenv('MC3HIP_RDV_ALLOW_REMOTE', raising=False)
+    with pytest.raises(ValueError, match='loopback'):
+        parallel.SocketComm(0, 2, addr='10.1.2.3', port=5555, secret='x')
 
 
 def test_socket_comm_rendezvous_through_a_port_file(tmp_path):
@@ -128,7 +195,8 @@ def test_socket_comm_rendezvous_through_a_port_file(tmp_path):
     def env(r):
         e = dict(os.environ, RANK=str(r), WORLD_SIZE='4', MASTER_ADDR='127.0.0.1',
                  MASTER_PORT='29999', TORCHELASTIC_RUN_ID='run7', MC3HIP_RDV_DIR=str(tmp_path))
-        e.pop('MC3HIP_RDV_PORT', None)
+        for k in ('MC3HIP_RDV_PORT', 'MC3HIP_RDV_FILE', 'MC3HIP_RDV_SECRET'):
+            e.pop(k, None)
         return e
     stale = os.path.join(str(tmp_path), os.path.basename(stale))
     with open(stale, 'w') as f:

@@ -190,3 +190,63 @@ def test_snooker_history_is_not_recycled(eng):
         gpu.run(20)
         with pytest.raises(Exception, match='whole history'):
             gpu.recycle(keep=2, seed=5)
+
+
+# ---- lean_demc_kernel EPS: the headline loop with the support distribution -------------------
+@pytest.mark.parametrize('case', ['plain', 'fx', 'resume', 'abort', 'tight', 'degree2', 'degree4'])
+def test_headline_loop_with_the_support_distribution(eng, monkeypatch, case):
+    """fepsilon != 0 (mc3/chain.py:185,232) on the hand-laid-out DEMC loop: lane k's normal
+    deviate of the next refresh is drawn in the shadow of the partner rows' round trip."""
+    nchains = 12
+    if case == 'fx':
+        prob = H.lean_shape_problem(nchains, 90, ndata=300, fx=1, fepsilon=0.02)
+    elif case == 'degree2':
+        prob = H.quad_problem(ndata=300, nchains=nchains, nsamples=nchains*90, sampler='demc',
+                              fepsilon=0.01)
+        for k in ('params', 'pstep', 'pmin', 'pmax'):
+            prob[k] = prob[k][:2]
+    elif case == 'degree4':
+        prob = H.quad_problem(ndata=300, nchains=nchains, nsamples=nchains*90, sampler='demc',
+                              fepsilon=0.01)
+        prob.update(params=np.append(prob['params'], 0.0), pstep=np.append(prob['pstep'], 0.001),
+                    pmin=np.append(prob['pmin'], -1.0), pmax=np.append(prob['pmax'], 1.0))
+    else:
+        prob = H.quad_problem(ndata=300, nchains=nchains, nsamples=nchains*90, sampler='demc',
+                              fepsilon=0.01)
+    if case == 'tight':
+        prob.update(params=np.array([4.0, -2.5, 0.5]), pmin=np.array([3.5, -2.8, 0.45]),
+                    pmax=np.array([6.5, -2.2, 0.56]))
+    if case == 'abort':
+        monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '21')
+        orc, gpu = run_pair(eng, prob, trace=False)
+        assert gpu.plan['recoveries'] == 1
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
+        return
+    if case == 'resume':
+        gpu = eng.DeviceChains(**prob)
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nthreads=4)
+        for n in (1, 2, 20, 21, 22, 24):
+            gpu.run(n)
+    else:
+        orc, gpu = run_pair(eng, prob, trace=False)
+    plan = gpu.plan
+    assert plan['persistent'] > 0 and plan['recoveries'] == 0 and plan['fast'] == 2, plan
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
+def test_support_distribution_beyond_the_co_resident_waves(eng, monkeypatch):
+    """... and an ensemble of such chains larger than the co-resident grid takes its turns on
+    the general chain (no lean instance has the flavour): still exact."""
+    monkeypatch.setenv('MC3HIP_PERSIST_CAPACITY', '5')
+    prob = H.quad_problem(ndata=300, nchains=16, nsamples=16*40, sampler='demc', fepsilon=0.01)
+    orc, gpu = run_pair(eng, prob, trace=False)
+    plan = gpu.plan
+    assert plan['persistent'] > 0 and plan['chains_per_workgroup'] > 1 and plan['fast'] == 0, plan
+    assert_same(orc, gpu, trace=False)
+    gpu.close()

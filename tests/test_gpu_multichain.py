@@ -133,7 +133,7 @@ def test_general_kernel_with_several_chains_per_workgroup(eng, monkeypatch, samp
     gpu.close()
 
 
-@pytest.mark.parametrize('wpc', ['4', '16'])
+@pytest.mark.parametrize('wpc', ['4'])
 def test_general_kernel_wide_workgroups(eng, monkeypatch, wpc):
     forced(monkeypatch, 2)
     monkeypatch.setenv('MC3HIP_WPC', wpc)
@@ -150,10 +150,19 @@ def test_general_kernel_wide_workgroups(eng, monkeypatch, wpc):
 def test_wavelet_kernels_with_several_chains_per_workgroup(eng, monkeypatch, ndata, sampler):
     forced(monkeypatch, 3)
     prob = H.wavelet_problem(ndata=ndata, nchains=8, nsamples=8*25, sampler=sampler)
-    orc, gpu = run_pair(eng, prob, trace=True)
-    check_plan(gpu, turns=3, fast=0)
-    assert_same(orc, gpu, trace=True)
+    # (8192 points: only the nine-wave kernel with its hand-structured chain wave takes turns --
+    # untraced; the fused eight-wave kernel that served the traced run went with round 4, such
+    # a run is one launch per refresh now)
+    trace = ndata < 8192
+    orc, gpu = run_pair(eng, prob, trace=trace)
+    check_plan(gpu, turns=3, fast=0 if trace else 3)
+    assert_same(orc, gpu, trace=trace)
     gpu.close()
+    if not trace:
+        orc, gpu = run_pair(eng, prob, trace=True)
+        assert gpu.plan['persistent'] == 0
+        assert_same(orc, gpu, trace=True)
+        gpu.close()
 
 
 def test_linear_model_and_resumed_launches(eng, monkeypatch):
@@ -313,8 +322,16 @@ def test_wavelet_chain_wave_takes_turns(eng, monkeypatch, ndata, sampler, case):
         assert_same(orc, gpu, trace=False)
         gpu.close()
         return
-    if case == 'general':                  # the fused eight-wave kernel behind the switch
+    if case == 'general':
+        # the general chain behind the switch: nothing but the hand-structured chain wave takes
+        # turns on this geometry (the fused eight-wave kernel went with round 4), so the run
+        # is one launch per refresh -- the same results
         monkeypatch.setenv('MC3HIP_NO_CW_LEAN', '1')
+        orc, gpu = run_pair(eng, prob, trace=False)
+        assert gpu.plan['persistent'] == 0 and gpu.plan['fast'] == 0, gpu.plan
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
+        return
     if case == 'resume':
         monkeypatch.setenv('MC3HIP_PERSIST_REFS', '7')
         gpu = eng.DeviceChains(**prob)
@@ -327,6 +344,6 @@ def test_wavelet_chain_wave_takes_turns(eng, monkeypatch, ndata, sampler, case):
             gpu.run(n)
     else:
         orc, gpu = run_pair(eng, prob, trace=False)
-    check_plan(gpu, turns=3, fast=0 if case == 'general' else 3)
+    check_plan(gpu, turns=3, fast=3)
     assert_same(orc, gpu, trace=False)
     gpu.close()

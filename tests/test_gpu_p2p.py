@@ -22,7 +22,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # (more ranks than replica pointers are kept in registers: handoff.h PeerTable's slow way)
     (9, 'demc', 1, 120, 'socket'), (9, 'snooker', 1, 120, 'socket')])
 def test_processes_peer_to_peer(tmp_path, nproc, sampler, thinning, niter, launcher):
-    p2p_case(tmp_path, nproc, sampler, thinning, niter, launcher)
+    """The STRICT lockstep across ranks (zlag = 0: every iteration waits for the rows of the
+    one before, wherever they were made)."""
+    p2p_case(tmp_path, nproc, sampler, thinning, niter, launcher, zlag=0)
+
+
+@pytest.mark.parametrize('nproc,sampler,thinning,zlag,delay_ns', [
+    (2, 'demc', 1, None, 0), (2, 'demc', 1, None, 3000), (4, 'demc', 1, None, 2000),
+    (8, 'demc', 1, None, 2000), (2, 'demc', 3, None, 2000), (8, 'demc', 2, 1, 1000),
+    (2, 'snooker', 1, None, 2000), (8, 'snooker', 1, 2, 1000), (2, 'mrw', 1, None, 2000),
+    (2, 'demc', 1, 1, 5000), (9, 'demc', 1, None, 1000)])
+def test_processes_in_the_declared_cadence(tmp_path, nproc, sampler, thinning, zlag, delay_ns):
+    """mc3_amd.sample() over several ranks in the DECLARED MULTI-GPU CADENCE (the default of a
+    sharded run: zlag = parallel.DEFAULT_ZLAG refreshes' worth; here also 1 and 2), with the
+    rows for the other ranks' replicas held back 1-5 us (MC3HIP_TEST_REMOTE_DELAY_NS: ranks on
+    one GPU then see each other as if an xGMI hop apart) -- identical, bit for bit, to ONE
+    rank running the oracle's restatement of the same cadence.  Rows that arrive later than
+    zlag iterations after they were made (5 us against zlag = 1) are waited for: slower, the
+    same results."""
+    from mc3_amd import parallel
+    env = {'MC3HIP_TEST_REMOTE_DELAY_NS': str(delay_ns)} if delay_ns else {}
+    if zlag is None:
+        zlag = -(-parallel.DEFAULT_ZLAG//thinning)
+        p2p_case(tmp_path, nproc, sampler, thinning, 300, 'socket', env=env, want_zlag=zlag)
+    else:
+        p2p_case(tmp_path, nproc, sampler, thinning, 300, 'socket', env=env, zlag=zlag)
 
 
 def test_peer_to_peer_without_the_courier(tmp_path):
@@ -30,17 +54,19 @@ def test_peer_to_peer_without_the_courier(tmp_path):
     ranks' replicas itself (MC3HIP_NO_COURIER=1; by default a second wave of the workgroup
     carries the rows, lean_demc_kernel COURIER -- the 2-rank demc cases above and the abort
     case below; more than two ranks on ONE device run without it, mc3_amd/parallel.py)."""
-    p2p_case(tmp_path, 2, 'demc', 1, 400, 'socket', env={'MC3HIP_NO_COURIER': '1'})
+    p2p_case(tmp_path, 2, 'demc', 1, 400, 'socket', env={'MC3HIP_NO_COURIER': '1'}, zlag=0)
 
 
-def p2p_case(tmp_path, nproc, sampler, thinning, niter, launcher, env=None):
+def p2p_case(tmp_path, nproc, sampler, thinning, niter, launcher, env=None, zlag=None,
+             want_zlag=None):
     import mc3_amd
     from mc3_amd import utils as mu
     from oracle_engine import OracleChains
     out_path = str(tmp_path / 'p2p')
     nchains = 16 if 16 % nproc == 0 else 2*nproc          # (equal blocks of chains per rank)
+    more = [f'zlag={zlag}'] if zlag is not None else []
     launch_ranks(nproc, 'p2p_worker.py', out_path, sampler, thinning, niter,
-                 f'nchains={nchains}', launcher=launcher, env=env)
+                 f'nchains={nchains}', *more, launcher=launcher, env=env)
 
     x, data, uncert = H.tutorial_data(100)
     np.random.seed(100)
@@ -50,7 +76,7 @@ def p2p_case(tmp_path, nproc, sampler, thinning, niter, launcher, env=None):
         pmin=np.array([-10.0, -20.0, -10.0]), pmax=np.array([40.0, 20.0, 10.0]),
         sampler=sampler, nsamples=nchains*niter*thinning, burnin=10, nchains=nchains,
         thinning=thinning, grtest=True, log=mu.Log(verb=0),
-        engine_factory=OracleChains, seed=99)
+        engine_factory=OracleChains, seed=99, zlag=zlag if want_zlag is None else want_zlag)
     for rank in range(nproc):
         got = np.load(f'{out_path}.rank{rank}.npz')
         for key in ('posterior', 'zchain', 'log_post', 'chisq', 'bestp',
@@ -63,23 +89,27 @@ def launch(nproc, script, *args, env=None, timeout=1000):
     return launch_ranks(nproc, script, *args, env=env, timeout=timeout)
 
 
-def test_config_c3_eight_ranks_of_256_chains(tmp_path):
-    """BASELINE config C3 at its real shape: 2048 chains x ndata 1000, demc, sharded over
-    8 ranks of 256 chains through the peer-to-peer hand-off (here: eight processes on the
-    one GPU).  Every rank's replica must equal the oracle's run of the whole ensemble."""
-    nref = 48
-    nchains = 2048
-    prob = H.quad_problem(ndata=1000, nchains=nchains, nsamples=nchains*nref, sampler='demc')
-    orc = H.make_oracle(prob)
+def lean_ranks_case(tmp_path, nranks, nref, zlag, delay_ns=0, **shape):
+    """`nranks` processes on the one GPU, each running the hand-laid-out loop of its shape over
+    its block of chains (tests/c3_worker.py asserts plan.fast == 2): every replica must equal
+    the oracle's run of the whole ensemble in the same cadence."""
+    per_rank = shape.get('per_rank', 256)
+    nchains = per_rank*nranks
+    prob = H.lean_shape_problem(nchains, nref, **{k: v for k, v in shape.items()
+                                                  if k != 'per_rank'})
+    orc = H.make_oracle(prob, zlag=zlag)
     Z0, lp0 = H.initial_population(orc)
     out_path = str(tmp_path / 'c3')
     np.savez(out_path + '.pop.npz', Z0=Z0, lp0=lp0)
     orc.set_population(Z0, lp0)
     orc.run(nthreads=min(32, len(os.sched_getaffinity(0))))
-    launch(8, 'c3_worker.py', out_path, nref)
-    for rank in range(8):
+    launch(nranks, 'c3_worker.py', out_path, nref, f'zlag={zlag}',
+           *[f'{k}={v}' for k, v in shape.items()],
+           env={'MC3HIP_TEST_REMOTE_DELAY_NS': str(delay_ns)} if delay_ns else None)
+    for rank in range(nranks):
         got = np.load(f'{out_path}.rank{rank}.npz')
-        s = slice(256*rank, 256*(rank + 1))
+        s = slice(per_rank*rank, per_rank*(rank + 1))
+        assert int(got['zlag']) == zlag
         np.testing.assert_array_equal(got['Z'], orc.Z, err_msg=f'rank {rank}')
         np.testing.assert_array_equal(got['lp'], orc.log_post)
         np.testing.assert_array_equal(got['zc'], orc.zchain)
@@ -87,15 +117,41 @@ def test_config_c3_eight_ranks_of_256_chains(tmp_path):
         np.testing.assert_array_equal(got['X'], orc.X[s])
         np.testing.assert_array_equal(got['chisq'], orc.chisq[s])
         np.testing.assert_array_equal(got['best_chisq'], orc.best_chisq[s])
-    total_out = sum(np.load(f'{out_path}.rank{r}.npz')['outbounds'] for r in range(8))
+    total_out = sum(np.load(f'{out_path}.rank{r}.npz')['outbounds'] for r in range(nranks))
     np.testing.assert_array_equal(total_out, orc.outbounds)
 
 
-@pytest.mark.parametrize('nranks,per_rank,ndata,nmodel,sampler', [
-    (2, 48, 20000, 7, 'demc'), (4, 32, 30000, 10, 'snooker'), (4, 128, 100000, 10, 'demc'),
-    (2, 48, 40000, 3, 'demc'), (4, 32, 40000, 3, 'snooker')])
+@pytest.mark.parametrize('zlag,delay_ns', [(0, 0), (4, 0), (4, 2000), (1, 3000)])
+def test_config_c3_eight_ranks_of_256_chains(tmp_path, zlag, delay_ns):
+    """BASELINE config C3 at its real shape: 2048 chains x ndata 1000, demc, sharded over
+    8 ranks of 256 chains through the peer-to-peer hand-off (here: eight processes on the
+    one GPU) -- in the strict lockstep and in the declared cadence, the latter also with
+    every row for another rank's replica held back 2-3 us."""
+    lean_ranks_case(tmp_path, 8, 48, zlag, delay_ns)
+
+
+@pytest.mark.parametrize('nranks', [2, 8])
+@pytest.mark.parametrize('shape', [
+    dict(sampler='demc', fx=1), dict(sampler='demc', thinning=3), dict(sampler='demc', fx=1,
+                                                                        thinning=2),
+    dict(sampler='snooker'), dict(sampler='snooker', fx=1), dict(sampler='snooker', thinning=3),
+    dict(sampler='mrw'), dict(sampler='mrw', fx=1), dict(sampler='mrw', thinning=2)],
+    ids=lambda d: '-'.join(f'{k}{v}' for k, v in d.items()))
+def test_hand_laid_out_loops_peer_to_peer(tmp_path, nranks, shape):
+    """Every hand-laid-out loop in its peer-to-peer flavour -- fixed / shared coefficients and
+    priors, thinning > 1, snooker, random walk (mc3/chain.py:195-220) -- with 2 ranks (courier
+    wave) and 8 ranks (the chain wave stores itself) on the one GPU, rows held back 1.5 us,
+    in the declared cadence (demc, snooker) / as ever (mrw looks at nobody)."""
+    lean_ranks_case(tmp_path, nranks, 40, 2, 1500, per_rank=24, ndata=300, **shape)
+
+
+@pytest.mark.parametrize('nranks,per_rank,ndata,nmodel,sampler,zlag', [
+    (2, 48, 20000, 7, 'demc', 0), (4, 32, 30000, 10, 'snooker', 0),
+    (4, 128, 100000, 10, 'demc', 0), (2, 48, 40000, 3, 'demc', 0),
+    (4, 32, 40000, 3, 'snooker', 0), (4, 128, 100000, 10, 'demc', 2),
+    (2, 48, 20000, 7, 'snooker', 1)])
 def test_resident_tiled_plan_sharded_over_ranks(tmp_path, nranks, per_rank, ndata, nmodel,
-                                                sampler):
+                                                sampler, zlag):
     """The tiled plan in one launch per rank (resident_tile_kernel<KB, P2P>), the ensemble
     sharded over ranks through the peer-to-peer hand-off -- the last case is BASELINE config
     C5's own shape: 512 chains x 1e5 points x 10 coefficients over 4 ranks of 128 chains
@@ -112,14 +168,15 @@ def test_resident_tiled_plan_sharded_over_ranks(tmp_path, nranks, per_rank, ndat
         prob = H.linear_problem(ndata=ndata, nmodel=nmodel, nchains=nchains,
                                 nsamples=nchains*nref, sampler=sampler)
         plan = {'tile': 2048, 'vlanes': 1024, 'tile_tree': 2}
-    orc = H.make_oracle(prob, plan=plan)
+    orc = H.make_oracle(prob, plan=plan, zlag=zlag)
     Z0, lp0 = H.initial_population(orc)
     out_path = str(tmp_path / 'c5')
     np.savez(out_path + '.pop.npz', Z0=Z0, lp0=lp0)
     orc.set_population(Z0, lp0)
     orc.run(nthreads=min(32, len(os.sched_getaffinity(0))))
     launch(nranks, 'c5_worker.py', out_path, nref, per_rank, ndata, nmodel, sampler,
-           env={'MC3HIP_RESIDENT_MAXCOL': '1'})
+           f'zlag={zlag}', env={'MC3HIP_RESIDENT_MAXCOL': '1',
+                                **({'MC3HIP_TEST_REMOTE_DELAY_NS': '2000'} if zlag else {})})
     for rank in range(nranks):
         got = np.load(f'{out_path}.rank{rank}.npz')
         s = slice(per_rank*rank, per_rank*(rank + 1))
@@ -146,7 +203,7 @@ def test_peer_to_peer_abort_is_recovered_by_all_ranks(tmp_path, sampler):
     from oracle_engine import OracleChains
     niter = 200
     out_path = str(tmp_path / 'abort')
-    res = launch(2, 'p2p_worker.py', out_path, sampler, 1, niter, 'abort=77')
+    res = launch(2, 'p2p_worker.py', out_path, sampler, 1, niter, 'abort=77', 'zlag=0')
     assert 'recovered' in res, res[-2000:]
     x, data, uncert = H.tutorial_data(100)
     np.random.seed(100)
@@ -181,7 +238,7 @@ def test_resident_tiled_plan_abort_is_recovered_by_all_ranks(tmp_path):
     orc.set_population(Z0, lp0)
     orc.run(nthreads=8)
     res = launch(2, 'c5_worker.py', out_path, nref, per_rank, ndata, nmodel, 'demc',
-                 'abort=13', env={'MC3HIP_RESIDENT_MAXCOL': '1'})
+                 'abort=13', 'zlag=0', env={'MC3HIP_RESIDENT_MAXCOL': '1'})
     assert 'recovered' in res, res[-2000:]
     for rank in range(2):
         got = np.load(f'{out_path}.rank{rank}.npz')

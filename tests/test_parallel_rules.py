@@ -35,16 +35,37 @@ def clean_env(monkeypatch):
 
 
 def test_courier_only_with_at_most_two_ranks_per_device(clean_env):
-    """The peer-to-peer instance of the headline loop runs a second wave per chain (the
-    courier, lean_demc_kernel COURIER); the two-wave workgroups of more than two ranks of 256
-    chains are not all co-resident on ONE device, so such a set-up switches it off -- on every
-    rank alike, whichever device it sits on."""
-    FixedComm(0, [(0, False), (1, False)])._check_shared_device(engine(0))
-    assert 'MC3HIP_NO_COURIER' not in os.environ          # a GPU each
-    FixedComm(1, [(0, False), (0, False)])._check_shared_device(engine(0))
-    assert 'MC3HIP_NO_COURIER' not in os.environ          # two on one device: still fits
-    FixedComm(3, [(0, False), (0, False), (0, False), (1, False)])._check_shared_device(engine(1))
-    assert os.environ.get('MC3HIP_NO_COURIER') == '1'     # three share device 0: all without
+    """The peer-to-peer instances of the headline loops run a second wave per chain (the
+    courier); the two-wave workgroups of more than two ranks of 256 chains are not all
+    co-resident on ONE device, so such a set-up runs without it -- on every rank alike,
+    whichever device it sits on.  Decided BEFORE the engine exists (engine_options: the
+    library sizes its persistent grid from the very kernel instance the flag selects; no
+    environment variable is touched), and checked against the engine at set-up."""
+    class DeviceComm(FixedComm):
+        def __init__(self, rank, devices):
+            super().__init__(rank, devices)
+
+        def broadcast(self, obj):
+            return obj
+
+    opts = DeviceComm(0, [0, 1]).engine_options(device=0)
+    assert opts == {'zlag': parallel.DEFAULT_ZLAG, 'p2p': True, 'no_courier': False}
+    assert DeviceComm(1, [0, 0]).engine_options(device=0)['no_courier'] is False
+    assert DeviceComm(3, [0, 0, 0, 1]).engine_options(device=1)['no_courier'] is True
+    assert DeviceComm(0, [0, 1]).engine_options(device=0, thinning=3)['zlag'] == 2
+    assert DeviceComm(0, [0, 1]).engine_options(device=0, zlag=0)['zlag'] == 0
+    assert 'MC3HIP_NO_COURIER' not in os.environ
+    # an engine created otherwise is refused at set-up, on every rank
+    crowded = [(0, False), (0, False), (0, False), (1, False)]
+    eng = engine(1)
+    eng.no_courier = False
+    with pytest.raises(RuntimeError, match='engine_options'):
+        FixedComm(3, crowded)._check_shared_device(eng)
+    eng.no_courier = True
+    FixedComm(3, crowded)._check_shared_device(eng)
+    # one rank decides nothing
+    assert parallel.SingleRank().engine_options() == {}
+    assert parallel.SingleRank().engine_options(zlag=3) == {'zlag': 3}
 
 
 def test_shared_device_with_the_one_launch_tiled_plan_needs_a_share(clean_env, monkeypatch):

@@ -99,6 +99,67 @@ for _smp in ('demc', 'snooker', 'mrw'):
 for _smp in ('demc', 'snooker', 'mrw'):
     CONFIGS['c2two' + _smp] = (lambda n, _s=_smp: (H.quad_problem(
         ndata=2000, nchains=256, nsamples=256*n, sampler=_s), {}))
+# ---- round 4: the shapes that fall off the hand-laid-out loops (VERDICT r3 row g), all at the
+# headline size -- 256 chains x 1000 points (mc3/chain.py:217,232 epsilon; :246-247 shared
+# parameters; stats.py:211 priors)
+def _off(n, sampler='demc', thinning=1, **kw):
+    return H.quad_problem(ndata=1000, nchains=256, nsamples=256*n*thinning, sampler=sampler,
+                          thinning=thinning, **kw), {}
+
+
+def _polyk(n, k, sampler='demc'):
+    # a polynomial of k coefficients around the tutorial's quadratic (higher orders ~ 0)
+    prob, _ = _off(n, sampler)
+    x = prob['indep']/10.0
+    pad = k - 3
+    prob.update(indep=x,
+                params=np.concatenate([[10.0, -20.0, 10.0], np.zeros(pad)]),
+                pstep=np.concatenate([[1.0, 5.0, 10.0], np.full(pad, 1.0)]),
+                pmin=np.concatenate([[-10.0, -200.0, -1000.0], np.full(pad, -1e4)]),
+                pmax=np.concatenate([[40.0, 200.0, 1000.0], np.full(pad, 1e4)]))
+    return prob, {}
+
+
+def _link(n, k, sampler='demc'):
+    return H.linear_problem(ndata=1000, nmodel=k, nchains=256, nsamples=256*n,
+                            sampler=sampler), {}
+
+
+def _shared(n, sampler='demc', thinning=1):
+    # the quadratic plus a cubic coefficient shared with the linear one (pstep = -2) -- and
+    # tiny in effect: x is scaled to [0, 1]
+    prob, _ = _off(n, sampler, thinning)
+    prob.update(indep=prob['indep']/10.0, params=np.array([10.0, -20.0, 10.0, -20.0]),
+                pstep=np.array([1.0, 5.0, 10.0, -2.0]),
+                pmin=np.array([-10.0, -200.0, -1000.0, -200.0]),
+                pmax=np.array([40.0, 200.0, 1000.0, 200.0]))
+    return prob, {}
+
+
+_PRIOR = dict(prior=np.array([3.0, 0.0, 0.5]), priorlow=np.array([0.5, 0.0, 0.02]),
+              priorup=np.array([0.25, 0.0, 0.04]))
+OFF_LEAN = {
+    'off_shared': lambda n: _shared(n),
+    'off_eps': lambda n: _off(n, fepsilon=0.01),
+    'off_eps_snooker': lambda n: _off(n, 'snooker', fepsilon=0.01),
+    'off_poly5': lambda n: _polyk(n, 5),
+    'off_poly8': lambda n: _polyk(n, 8),
+    'off_lin5': lambda n: _link(n, 5),
+    'off_lin10': lambda n: _link(n, 10),
+    'off_prior_thin10': lambda n: _off(n, thinning=10, **_PRIOR),
+    'off_prior_snooker': lambda n: _off(n, 'snooker', **_PRIOR),
+    'off_prior': lambda n: _off(n, **_PRIOR),
+    'off_shared_thin10': lambda n: _shared(n, thinning=10),
+    'off_poly5_snooker': lambda n: _polyk(n, 5, 'snooker'),
+    'off_lin10_snooker': lambda n: _link(n, 10, 'snooker'),
+}
+CONFIGS.update(OFF_LEAN)
+# the declared multi-GPU cadence on one GPU (zlag 4)
+CONFIGS['c2lag4'] = lambda n: _off(n, zlag=4)
+CONFIGS['c2lag1'] = lambda n: _off(n, zlag=1)
+CONFIGS['c2lag4snooker'] = lambda n: _off(n, 'snooker', zlag=4)
+CONFIGS['c3onelag4'] = lambda n: (H.quad_problem(ndata=1000, nchains=2048, nsamples=2048*n,
+                                                 sampler='demc', zlag=4), {})
 CONFIGS['p6'] = lambda n: _poly6(n, False)
 CONFIGS['p6matrix'] = lambda n: _poly6(n, True)
 BYTES = {'c2mrw': 24104, 'q5': 8*3*100000 + 8*3*4 + 8, 'c4mrw': 8*2*16384 + 8*5*4 + 8, 'c4demc': 8*2*16384 + 8*5*4 + 8, 'c4half': 8*2*16384 + 8*5*4 + 8, 'c2': 24104, 'c2snooker': 24104, 'c3one': 24104, 'c4': 8*2*16384 + 8*5*4 + 8,
@@ -118,6 +179,17 @@ for _smp in ('demc', 'snooker', 'mrw'):
 BYTES['p6'] = BYTES['p6matrix'] = 8*3*100000 + 8*6*4 + 8
 for _k in ('c3x2', 'c3x4', 'c3x2snooker', 'c3x2mrw', 'c3onesnooker'):
     BYTES[_k] = 24104
+for _k in OFF_LEAN:
+    ITERS[_k] = 3000 if 'thin10' in _k else 12000
+    BYTES[_k] = 24104
+BYTES.update(off_poly5=8*3*1000 + 8*5*4 + 8, off_poly8=8*3*1000 + 8*8*4 + 8,
+             off_lin5=8*7*1000 + 8*5*4 + 8, off_lin10=8*12*1000 + 8*10*4 + 8,
+             off_poly5_snooker=8*3*1000 + 8*5*4 + 8, off_lin10_snooker=8*12*1000 + 8*10*4 + 8)
+for _k in ('c2lag4', 'c2lag1', 'c2lag4snooker'):
+    ITERS[_k] = 20000
+    BYTES[_k] = 24104
+ITERS['c3onelag4'] = 4000
+BYTES['c3onelag4'] = 24104
 BYTES['c4big'] = 8*2*65536 + 8*5*4 + 8
 for _k in ('c4x2', 'c4x4', 'c4wide'):
     BYTES[_k] = BYTES['c4']
@@ -161,6 +233,12 @@ def main():
             **({'useful_fp64_TFLOPs': round(rate*1e6*2*g.nmodel*g.ndata/1e12, 2),
                 'frac_of_fp64_peak': round(rate*1e6*2*g.nmodel*g.ndata/78.6e12, 4)}
                if name.startswith('c5') else {}),
+            # the roofline of C4 (its byte figure is void: the chain-invariant streams sit in
+            # LDS): FP64 vector issue.  2 335 FP64 mul / fma wave-instructions per chain-step at
+            # 2^14 points (SQ_INSTS_VALU_FMA_F64 + _MUL_F64 of profiles/r03_c4_pmc.json / 4000
+            # iterations / 256 chains; adds not counted), 4 cycles each, 1024 SIMDs at 2.4 GHz
+            **({'fp64_issue_frac': round(rate*1e6*2335.0*(g.ndata/16384.0)*4/(1024*2.4e9), 4)}
+               if name.startswith('c4') else {}),
             'plan': g.plan, 'acceptance': round(float(acc), 3),
             'out_of_bounds_max_param': round(float(oob), 3)}), flush=True)
         g.close()
