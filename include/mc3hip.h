@@ -148,6 +148,9 @@ typedef struct mc3hip_plan {
                                chains than workgroups can be co-resident; the reference's
                                workers loop over their chains the same way, chain.py:163,
                                190-191); results do not depend on it                          */
+    int32_t jit;            /* 1: the hand-laid-out loop that runs was specialised at run time
+                               for this model (mc3hip_jit_request / mc3hip_jit_install)         */
+    int32_t reserved1;      /* 0 */
     int32_t zlag;           /* the cadence this context runs (mc3hip_problem.zlag)              */
     int32_t remote_delay_ns;/* test hook MC3HIP_TEST_REMOTE_DELAY_NS (read at creation): every
                                row bound for ANOTHER rank's replica is held back that long
@@ -162,6 +165,28 @@ int mc3hip_create(const mc3hip_problem *problem, mc3hip_ctx **out);
 void mc3hip_destroy(mc3hip_ctx *ctx);
 const char *mc3hip_last_error(void);
 int mc3hip_get_plan(const mc3hip_ctx *ctx, mc3hip_plan *plan);
+
+/* Run-time specialisation ("the model ... JIT-specialised into the kernel").  The library is
+ * built with the hand-laid-out one-wave loops for polynomials of 2..4 coefficients; for the
+ * other members of the declared family that fit one register tile -- polynomials of 5..8
+ * coefficients, design matrices of up to 10 columns, ndata <= 1024, one GPU -- the same loop
+ * source is compiled for the very model (coefficient count a compile-time constant, the design
+ * matrix's tile resident in registers) by the caller, who owns a compiler; the library itself
+ * never needs one.
+ *   mc3hip_jit_request: the expression to instantiate, e.g.
+ *     "lean_demc_body<205, false, false, false, false, false, false>" (C string into buf;
+ *     empty: nothing to specialise -- the library has the kernel, or the shape has no loop).
+ *     The caller compiles, for gfx950 and with the library's flags (-O3 -ffp-contract=off),
+ *       #include "kernels_lean.h"
+ *       extern "C" __global__ __launch_bounds__(64)
+ *       void mc3_jit_kernel(const mc3hip::DevProblem P, const int nref) { mc3hip::<expr>(P, nref); }
+ *     into a code object (mc3_amd/jit.py: hipcc --genco, cached on disk by content hash);
+ *   mc3hip_jit_install: hands the code object over (before the first mc3hip_run).  The context
+ *     then runs that kernel wherever it would have run the general chain for want of an
+ *     instance; results are those of the general chain, bit for bit. */
+int mc3hip_jit_request(const mc3hip_ctx *ctx, char *buf, int32_t capacity);
+int mc3hip_jit_install(mc3hip_ctx *ctx, const void *code_object, int64_t bytes,
+                       const char *kernel_name);
 
 /* Replaces the hub's initial-population loop (mc3/mcmc_driver.py:229-270): M0 trial
  * vectors around the initial guess (kickoff 0: params + pstep * N(0,1); 1: uniform between

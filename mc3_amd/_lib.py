@@ -59,6 +59,7 @@ class Plan(ctypes.Structure):
                 ('comm_graph', ctypes.c_int32), ('recoveries', ctypes.c_int32),
                 ('tile_tree', ctypes.c_int32), ('resident', ctypes.c_int32),
                 ('chains_per_workgroup', ctypes.c_int32),
+                ('jit', ctypes.c_int32), ('reserved1', ctypes.c_int32),
                 ('zlag', ctypes.c_int32), ('remote_delay_ns', ctypes.c_int32)]
 
 
@@ -75,6 +76,8 @@ SYMBOLS = {
     'mc3hip_destroy': (None, [_vp]),
     'mc3hip_last_error': (ctypes.c_char_p, []),
     'mc3hip_get_plan': (ctypes.c_int, [_vp, ctypes.POINTER(Plan)]),
+    'mc3hip_jit_request': (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int32]),
+    'mc3hip_jit_install': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_char_p]),
     'mc3hip_init_population': (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_uint64, _dp, _dp,
                                               _lp, _lp]),
     'mc3hip_set_population': (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp]),

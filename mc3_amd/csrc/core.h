@@ -36,6 +36,16 @@ constexpr int MT_POLY2 = 2;          // p0 + p1 x
 constexpr int MT_POLY3 = 3;          // p0 + p1 x + p2 x^2
 constexpr int MT_POLY4 = 4;
 constexpr int MT_LINEAR = 100;       // sum_k A[k][i] p[k]
+// MT_LINK0 + K: the same with K (1..16) columns known at compile time and the design matrix's
+// first 1024-point tile resident in registers -- the specialisations made at run time
+// (mc3_amd/jit.py) for the hand-laid-out one-wave loops
+constexpr int MT_LINK0 = 200;
+constexpr bool mt_is_link(int MT) { return MT > MT_LINK0 && MT <= MT_LINK0 + 16; }
+// coefficients a model tag fixes at compile time (0: a run-time count)
+constexpr int mt_ncoef(int MT)
+{
+    return mt_is_link(MT) ? MT - MT_LINK0 : ((MT >= 1 && MT <= 8) ? MT : 0);
+}
 
 struct DevProblem {
     int32_t nchains, chain0, nlocal, nparams, nfree, nshare, ndata;
@@ -208,7 +218,8 @@ __device__ __forceinline__ T *own_global(T *p)
 // ---- model evaluation ------------------------------------------------------
 template <int MT>
 struct Model {
-    double cf[(MT >= 1 && MT <= 8) ? MT : 1];
+    static constexpr int NC = mt_ncoef(MT);
+    double cf[NC > 0 ? NC : 1];
     const double *coef;     // LDS copy of the proposal (generic / linear)
     const double *indep;
     int nmodel, ndata;      // ndata = column stride of A (the padded length)
@@ -219,23 +230,23 @@ struct Model {
         indep = P.indep;
         nmodel = P.nmodel;
         ndata = P.npad;
-        if constexpr (MT >= 1 && MT <= 8) {
+        if constexpr (NC > 0) {
 #pragma unroll
-            for (int j = 0; j < MT; ++j)
+            for (int j = 0; j < NC; ++j)
                 cf[j] = s_nextp[j];
         }
     }
     // coefficients straight from wave 0's lanes (lane j holds parameter j): the
-    // fast path of fully-free polynomial models, no LDS round trip
+    // fast path of fully-free models, no LDS round trip
     __device__ __forceinline__ void init_from_lanes(const DevProblem &P, double npk)
     {
         coef = nullptr;
         indep = P.indep;
         nmodel = P.nmodel;
         ndata = P.npad;
-        if constexpr (MT >= 1 && MT <= 8) {
+        if constexpr (NC > 0) {
 #pragma unroll
-            for (int j = 0; j < MT; ++j)
+            for (int j = 0; j < NC; ++j)
                 cf[j] = make_double(__builtin_amdgcn_readlane(__double2loint(npk), j),
                                     __builtin_amdgcn_readlane(__double2hiint(npk), j));
         }
@@ -243,16 +254,16 @@ struct Model {
     // (lane k holds FREE parameter k; coefficient j is free parameter kf[j], or -- kf[j] < 0
     // -- the fixed value fx[j])
     __device__ __forceinline__ void init_from_lanes(const DevProblem &P, double npk,
-                                                    const int (&kf)[MT >= 1 && MT <= 8 ? MT : 1],
-                                                    const double (&fx)[MT >= 1 && MT <= 8 ? MT : 1])
+                                                    const int (&kf)[NC > 0 ? NC : 1],
+                                                    const double (&fx)[NC > 0 ? NC : 1])
     {
         coef = nullptr;
         indep = P.indep;
         nmodel = P.nmodel;
         ndata = P.npad;
-        if constexpr (MT >= 1 && MT <= 8) {
+        if constexpr (NC > 0) {
 #pragma unroll
-            for (int j = 0; j < MT; ++j) {
+            for (int j = 0; j < NC; ++j) {
                 const int src = kf[j] < 0 ? 0 : kf[j];
                 const double v = make_double(__builtin_amdgcn_readlane(__double2loint(npk), src),
                                              __builtin_amdgcn_readlane(__double2hiint(npk), src));
@@ -263,10 +274,10 @@ struct Model {
     // polynomial families at abscissa x (Horner, fused multiply-adds)
     __device__ __forceinline__ double at_x(double x) const
     {
-        if constexpr (MT >= 1 && MT <= 8) {
-            double m = cf[MT - 1];
+        if constexpr (NC > 0 && !mt_is_link(MT)) {
+            double m = cf[NC - 1];
 #pragma unroll
-            for (int j = MT - 2; j >= 0; --j)
+            for (int j = NC - 2; j >= 0; --j)
                 m = mc3_fma(m, x, cf[j]);
             return m;
         } else {
@@ -276,9 +287,25 @@ struct Model {
             return m;
         }
     }
+    // a design-matrix model from one point's column values (MT_LINK0 + K: a register tile),
+    // the terms in the order of at() below
+    __device__ __forceinline__ double from_columns(const double (&a)[NC > 0 ? NC : 1]) const
+    {
+        double m = a[0] * cf[0];
+#pragma unroll
+        for (int k = 1; k < NC; ++k)
+            m = mc3_fma(a[k], cf[k], m);
+        return m;
+    }
     __device__ __forceinline__ double at(int i) const
     {
-        if constexpr (MT != MT_LINEAR) {
+        if constexpr (mt_is_link(MT)) {
+            double m = indep[i] * cf[0];
+#pragma unroll
+            for (int k = 1; k < NC; ++k)
+                m = mc3_fma(indep[(size_t)k * ndata + i], cf[k], m);
+            return m;
+        } else if constexpr (MT != MT_LINEAR) {
             return at_x(indep[i]);
         } else {
             double m = indep[i] * coef[0];
@@ -441,7 +468,9 @@ __device__ __forceinline__ double lane_tree(double (&acc)[16 / WPC], double *s_p
 template <int WPC, int MT>
 struct DataTile {
     static constexpr int NV = 16 / WPC;
+    static constexpr int NA = mt_is_link(MT) ? mt_ncoef(MT) : 1;
     double x[NV], d[NV], w[NV];
+    double a[NV][NA];          // MT_LINK0 + K: this thread's points of the K columns
 
     // The device copies of x / data / w are padded to a multiple of 1024 points
     // (x and data repeat the last point, w = 0), so the tile needs no bounds
@@ -454,8 +483,13 @@ struct DataTile {
             const int i = base + lane + 64 * (wv + WPC * v);
             d[v] = P.data[i];
             w[v] = P.w[i];
-            if constexpr (MT != MT_LINEAR)
+            if constexpr (mt_is_link(MT)) {
+#pragma unroll
+                for (int k = 0; k < NA; ++k)
+                    a[v][k] = P.indep[(size_t)k * P.npad + i];
+            } else if constexpr (MT != MT_LINEAR) {
                 x[v] = P.indep[i];
+            }
         }
     }
 };

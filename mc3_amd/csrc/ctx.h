@@ -77,6 +77,10 @@ struct mc3hip_ctx {
     hipGraphExec_t cgraph_exec = nullptr;
     bool comm_graph_failed = false;
     bool comm_warm = false;         // one eager collective has run (RCCL set up its channels)
+    // run-time specialisation (mc3hip_jit_install): the hand-laid-out loop compiled for this
+    // context's model
+    hipModule_t jit_module = nullptr;
+    hipFunction_t jit_fn = nullptr;
     // peer-to-peer hand-off
     int p2p_ranks = 0;
     std::vector<void *> p2p_opened;
@@ -162,6 +166,41 @@ inline bool lag_demc_shape(const mc3hip_ctx *c)
            P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
 }
 
+// The model tag a run-time specialisation of the one-wave loops would be compiled for, or 0:
+// members of the declared family the library has no instance for -- polynomials of 5..8
+// coefficients, design matrices of up to 10 columns -- that fit ONE register tile (ndata <=
+// 1024), every parameter a coefficient, Gaussian chisq, one GPU, a sampler flavour that exists
+// as a hand-laid-out loop (mc3hip.hip mc3hip_jit_request names it).
+inline int jit_model_tag(const mc3hip_ctx *c)
+{
+    const DevProblem &P = c->P;
+    if (P.wlike || c->wpc != 1 || P.npad > VLANES || P.trace_iters != 0 || P.tile > 0 ||
+        (c->flags & MC3HIP_FLAG_P2P) || c->p2p_ranks > 1 || c->comm != nullptr ||
+        P.zs != ZROW || P.nmodel != P.nparams || P.nfree < 1 ||
+        getenv("MC3HIP_NO_LEAN") || getenv("MC3HIP_NO_FAST"))
+        return 0;
+    int tag = 0;
+    if (c->model_kind == MC3HIP_MODEL_POLY && P.nmodel >= 5 && P.nmodel <= 8)
+        tag = P.nmodel;
+    else if (c->model_kind == MC3HIP_MODEL_LINEAR && P.nmodel >= 1 && P.nmodel <= 10)
+        tag = MT_LINK0 + P.nmodel;
+    else
+        return 0;
+    const bool plain = P.nfree == P.nparams && P.ngprior == 0 && P.nshare == 0;
+    switch (P.sampler) {
+    case MC3HIP_DEMC:          // (the support distribution: the strict headline loop only)
+        return (P.fepsilon == 0.0 || (P.thinning == 1 && P.zlag == 0)) ? tag : 0;
+    case MC3HIP_SNOOKER:
+        return (P.fepsilon == 0.0 && (P.thinning == 1 || plain)) ? tag : 0;
+    default:                   // (the random walk: two Philox slots of deviates)
+        return (P.nmodel <= 4 && (P.thinning == 1 || plain)) ? tag : 0;
+    }
+}
+inline bool jit_serves(const mc3hip_ctx *c)
+{
+    return c->jit_fn != nullptr && jit_model_tag(c) != 0;
+}
+
 // the lean persistent instance applies when nothing of the general machinery is
 // needed (run_chain.h run_chain FAST)
 inline bool fast_eligible(const mc3hip_ctx *c)
@@ -202,7 +241,7 @@ inline bool lean_one_chain_only(const mc3hip_ctx *c)
 {
     const DevProblem &P = c->P;
     const bool plain = P.nfree == P.nparams && P.ngprior == 0 && P.nshare == 0;
-    return (P.fepsilon != 0.0 && P.sampler != MC3HIP_MRW) ||
+    return jit_serves(c) || (P.fepsilon != 0.0 && P.sampler != MC3HIP_MRW) ||
            (lag_demc_shape(c) && !plain && (P.thinning != 1 || (c->flags & MC3HIP_FLAG_P2P)));
 }
 

@@ -28,6 +28,7 @@ __device__ __forceinline__ double block_gauss_model(const DevProblem &P, const M
                                                     const DataTile<WPC, MT> &tile,
                                                     const DataTile<WPC, MT> *tile1)
 {
+    static_assert(!mt_is_link(MT) || (!MULTI && !T1), "compile-time columns: one tile");
     constexpr int NV = 16 / WPC;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double acc[NV];
@@ -35,7 +36,9 @@ __device__ __forceinline__ double block_gauss_model(const DevProblem &P, const M
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         double m;
-        if constexpr (MT == MT_LINEAR)
+        if constexpr (mt_is_link(MT))
+            m = model.from_columns(tile.a[v]);
+        else if constexpr (MT == MT_LINEAR)
             m = model.at(lane + 64 * (wv + WPC * v));
         else
             m = model.at_x(tile.x[v]);

@@ -49,13 +49,12 @@ __global__ __launch_bounds__(64) void persist_fast_kernel(const DevProblem P, co
 // k's normal deviate of the NEXT refresh -- Philox slot 3 + k/2, a logarithm, a square root, a
 // sine or cosine, as run_chain's normal_draw -- is computed on the vector unit in the same
 // shadow of the partner rows' round trip as the scalar draws.
-template <int MT, bool P2P, bool FX = false, bool MULTI = false, bool BATCH = false,
-          bool COURIER = false, bool EPS = false>
-__global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const DevProblem P,
-                                                                      const int nref)
+template <int MT, bool P2P, bool FX, bool MULTI, bool BATCH, bool COURIER, bool EPS>
+__device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nref)
 {
     static_assert(!EPS || (!P2P && !MULTI && !BATCH && !COURIER), "EPS: the one-GPU headline loop");
-    const int nf = FX ? P.nfree : MT;        // FX: some coefficients are fixed (nfree < MT)
+    constexpr int NC = Model<MT>::NC;         // coefficients the model tag fixes
+    const int nf = FX ? P.nfree : NC;        // FX: some coefficients are fixed (nfree < MT)
     constexpr int ZS = ZROW;                 // doubles per Z row: one 128-byte line (NF <= 16)
     constexpr int LM = P2P ? 1 : 0;
     const int lane = COURIER ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
@@ -117,11 +116,14 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
     const long long abort_at = (P.test_abort >= 0 && lc == 0) ? (long long)P.test_abort : -1;
     int nacc = 0;
     bool alive = true;
-    int kf[MT];
-    double fx[MT];
-    if constexpr (FX)
-        coefficient_map<MT>(P, kf, fx);
-    (void)kf; (void)fx;
+    int kf[NC];
+    double fx[NC];
+    PriorLanes<NC> priors;
+    if constexpr (FX) {
+        coefficient_map<NC>(P, kf, fx);
+        priors.init(P, kf, fx, lane);
+    }
+    (void)kf; (void)fx; (void)priors;
     // log_post / zchain of the last (up to) 64 refreshes wait in lane (R - R0) mod 64 and
     // are written 64 at a time: nobody reads them inside the launch
     double lpbuf = 0.0;
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
                 block_gauss_model<1, MT, MULTI, MULTI>(P, model, nullptr, nullptr, tile,
                                                        &tile1);          // chain.py:249
             if constexpr (FX)
-                nextchisq = nextchisq + prior_from_lanes<MT>(P, npk, kf, fx);
+                nextchisq = nextchisq + priors.term(npk, lane);
             MC3_TICK(tk2);
             const bool acc = metropolis_accept(0.5 * (cur - nextchisq), u_now, lo_now,
                                                hi_now);             // chain.py:257-274
@@ -386,6 +388,14 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
 #endif
 }
 
+template <int MT, bool P2P, bool FX = false, bool MULTI = false, bool BATCH = false,
+          bool COURIER = false, bool EPS = false>
+__global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const DevProblem P,
+        const int nref)
+{
+    lean_demc_body<MT, P2P, FX, MULTI, BATCH, COURIER, EPS>(P, nref);
+}
+
 // ---------------------------------------------------------------------------------
 // The snooker sampler (the reference's default) for the same shape, written out by hand: one
 // wave per chain, fully free polynomial, thinning = 1, one GPU.  A snooker iteration needs
@@ -410,13 +420,12 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
 // lean_demc_kernel's; without it the chain wave stores them itself)
 // (zlag > 0, the declared multi-GPU cadence: the history an iteration draws from ends zlag
 // refreshes earlier -- mc3hip_problem.zlag, oracle_lockstep.c ls_run)
-template <int MT, bool FX = false, bool THIN = false, bool MULTI = false, bool P2P = false,
-          bool COURIER = false>
-__global__ __launch_bounds__(COURIER ? 128 : 64) void lean_snooker_kernel(const DevProblem P,
-                                                                         const int nref)
+template <int MT, bool FX, bool THIN, bool MULTI, bool P2P, bool COURIER>
+__device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int nref)
 {
     static_assert(!COURIER || P2P, "the courier carries rows to other ranks' replicas");
-    const int nf = FX ? P.nfree : MT;
+    constexpr int NC = Model<MT>::NC;         // coefficients the model tag fixes
+    const int nf = FX ? P.nfree : NC;
     constexpr int ZS = ZROW;
     constexpr int NB = 21;                     // refreshes per batch of draws (3 lanes each)
     const int lane = COURIER ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
@@ -474,11 +483,14 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_snooker_kernel(const 
     const long long abort_at = (P.test_abort >= 0 && lc == 0) ? (long long)P.test_abort : -1;
     int nacc = 0;
     double lpbuf = 0.0;
-    int kf[MT];
-    double fx[MT];
-    if constexpr (FX)
-        coefficient_map<MT>(P, kf, fx);
-    (void)kf; (void)fx;
+    int kf[NC];
+    double fx[NC];
+    PriorLanes<NC> priors;
+    if constexpr (FX) {
+        coefficient_map<NC>(P, kf, fx);
+        priors.init(P, kf, fx, lane);
+    }
+    (void)kf; (void)fx; (void)priors;
     // lane 3 i + s: slot s of refresh bbase + i.  A, B by slot: 0 -> the offsets (in doubles)
     // of rows iR1, iR2; 1 -> the offset of row iz, the jump flag; 2 -> gamma_s, u (as bits)
     unsigned long long A = 0, B = 0;
@@ -640,7 +652,7 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_snooker_kernel(const 
                 block_gauss_model<1, MT, MULTI, MULTI>(P, model, nullptr, nullptr, tile,
                                                        MULTI ? &tile1 : &tile);  // chain.py:249
             if constexpr (FX)
-                nextchisq = nextchisq + prior_from_lanes<MT>(P, npk, kf, fx);
+                nextchisq = nextchisq + priors.term(npk, lane);
             bool acc;
             if (__builtin_expect(!sjump, 1)) {
                 acc = metropolis_accept(0.5 * (cur - nextchisq), u_now, lo_now, hi_now);
@@ -725,6 +737,14 @@ out:
     }
 }
 
+template <int MT, bool FX = false, bool THIN = false, bool MULTI = false, bool P2P = false,
+          bool COURIER = false>
+__global__ __launch_bounds__(COURIER ? 128 : 64) void lean_snooker_kernel(const DevProblem P,
+        const int nref)
+{
+    lean_snooker_body<MT, FX, THIN, MULTI, P2P, COURIER>(P, nref);
+}
+
 // ---------------------------------------------------------------------------------
 // The random-walk sampler (chain.py:219-220) for the same shape: no other chain is looked at,
 // an iteration is its draws and its chisq -- and the draws (one Philox call for the Metropolis
@@ -739,14 +759,13 @@ out:
 // (MULTI: more than 1024 points -- the second tile stays in registers too, the rest is streamed)
 // (P2P / COURIER: the ensemble is sharded over GPUs; the rows go into every rank's replica, as
 // lean_snooker_kernel's -- nobody waits for them: the run needs them complete at its end)
-template <int MT, bool FX = false, bool THIN = false, bool MULTI = false, bool P2P = false,
-          bool COURIER = false>
-__global__ __launch_bounds__(COURIER ? 128 : 64) void lean_mrw_kernel(const DevProblem P,
-                                                                     const int nref)
+template <int MT, bool FX, bool THIN, bool MULTI, bool P2P, bool COURIER>
+__device__ __forceinline__ void lean_mrw_body(const DevProblem &P, const int nref)
 {
-    static_assert(MT >= 1 && MT <= 4, "two slots of normal deviates");
+    static_assert(Model<MT>::NC >= 1 && Model<MT>::NC <= 4, "two slots of normal deviates");
     static_assert(!COURIER || P2P, "the courier carries rows to other ranks' replicas");
-    const int nf = FX ? P.nfree : MT;
+    constexpr int NC = Model<MT>::NC;         // coefficients the model tag fixes
+    const int nf = FX ? P.nfree : NC;
     constexpr int ZS = ZROW;
     constexpr int NB = 21;
     const int lane = COURIER ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
@@ -803,11 +822,14 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_mrw_kernel(const DevP
     const long long abort_at = (P.test_abort >= 0 && lc == 0) ? (long long)P.test_abort : -1;
     int nacc = 0;
     double lpbuf = 0.0;
-    int kf[MT];
-    double fx[MT];
-    if constexpr (FX)
-        coefficient_map<MT>(P, kf, fx);
-    (void)kf; (void)fx;
+    int kf[NC];
+    double fx[NC];
+    PriorLanes<NC> priors;
+    if constexpr (FX) {
+        coefficient_map<NC>(P, kf, fx);
+        priors.init(P, kf, fx, lane);
+    }
+    (void)kf; (void)fx; (void)priors;
     // lane 3 i + s of the batch: s = 0 -> u (bu) and its window; s = 1, 2 -> rad cos, rad sin of
     // Philox slot 3 + (s - 1), i.e. the deviates of parameters 2 (s - 1) and 2 (s - 1) + 1
     double bu = 0.0, blo = 0.0, bhi = 0.0, bcs = 0.0, bsn = 0.0;
@@ -878,7 +900,7 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_mrw_kernel(const DevP
                 block_gauss_model<1, MT, MULTI, MULTI>(P, model, nullptr, nullptr, tile,
                                                        MULTI ? &tile1 : &tile);  // chain.py:249
             if constexpr (FX)
-                nextchisq = nextchisq + prior_from_lanes<MT>(P, npk, kf, fx);
+                nextchisq = nextchisq + priors.term(npk, lane);
             const bool acc = metropolis_accept(0.5 * (cur - nextchisq), u_now, lo_now, hi_now);
             xk = acc ? npk : xk;
             if (__builtin_expect(__any(acc && nextchisq < best), 0)) {
@@ -936,6 +958,14 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_mrw_kernel(const DevP
     }
 }
 
+template <int MT, bool FX = false, bool THIN = false, bool MULTI = false, bool P2P = false,
+          bool COURIER = false>
+__global__ __launch_bounds__(COURIER ? 128 : 64) void lean_mrw_kernel(const DevProblem P,
+        const int nref)
+{
+    lean_mrw_body<MT, FX, THIN, MULTI, P2P, COURIER>(P, nref);
+}
+
 // ---------------------------------------------------------------------------------
 // DEMC in the DECLARED MULTI-GPU CADENCE (mc3hip_problem.zlag = D >= 1): during refresh R a chain
 // sees the others through the rows of refresh R - 1 - D (the initial snapshot until there is
@@ -961,14 +991,14 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_mrw_kernel(const DevP
 //   without it the chain wave stores them itself: more than two ranks sharing a device).
 // Same draws, same arithmetic, same results as run_chain's with the same zlag -- on one GPU or
 // sharded over any number of them.
-template <int MT, bool P2P = false, bool FX = false, bool COURIER = false>
-__global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_lag_kernel(const DevProblem P,
-                                                                          const int nref)
+template <int MT, bool P2P, bool FX, bool COURIER>
+__device__ __forceinline__ void lean_demc_lag_body(const DevProblem &P, const int nref)
 {
     static_assert(!COURIER || P2P, "the courier carries rows to other ranks' replicas");
     constexpr int ZS = ZROW;
     constexpr int NB = 64;                     // iterations per batch of draws (one per lane)
-    const int nf = FX ? P.nfree : MT;
+    constexpr int NC = Model<MT>::NC;         // coefficients the model tag fixes
+    const int nf = FX ? P.nfree : NC;
     const int lane = COURIER ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     const int lc = blockIdx.x;
     const int c = P.chain0 + lc;
@@ -1029,11 +1059,14 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_lag_kernel(const
     const long long abort_at = (P.test_abort >= 0 && lc == 0) ? (long long)P.test_abort : -1;
     long long nacc = 0;
     double lpbuf = 0.0;
-    int kf[MT];
-    double fx[MT];
-    if constexpr (FX)
-        coefficient_map<MT>(P, kf, fx);
-    (void)kf; (void)fx;
+    int kf[NC];
+    double fx[NC];
+    PriorLanes<NC> priors;
+    if constexpr (FX) {
+        coefficient_map<NC>(P, kf, fx);
+        priors.init(P, kf, fx, lane);
+    }
+    (void)kf; (void)fx; (void)priors;
     // lane i: the draws of iteration bbase + i (chain.py:221-232, :259)
     double bu = 0.0, blo = 0.0, bhi = 0.0;
     int bo1 = 0, bo2 = 0;
@@ -1134,7 +1167,7 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_lag_kernel(const
                     block_gauss_model<1, MT, false, false>(P, model, nullptr, nullptr, tile,
                                                            &tile);           // chain.py:249
                 if constexpr (FX)
-                    nextchisq = nextchisq + prior_from_lanes<MT>(P, npk, kf, fx);
+                    nextchisq = nextchisq + priors.term(npk, lane);
                 const bool acc = metropolis_accept(0.5 * (cur - nextchisq), C.u, C.lo, C.hi);
                 xk = acc ? npk : xk;
                 if (__builtin_expect(__any(acc && nextchisq < best), 0)) {
@@ -1209,6 +1242,13 @@ out:
     }
 }
 
+template <int MT, bool P2P = false, bool FX = false, bool COURIER = false>
+__global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_lag_kernel(const DevProblem P,
+        const int nref)
+{
+    lean_demc_lag_body<MT, P2P, FX, COURIER>(P, nref);
+}
+
 // ---------------------------------------------------------------------------------
 // lean_snooker_kernel / lean_mrw_kernel for ensembles with more chains than waves can be
 // co-resident (P.mc_chains = T, 2..4; one GPU): a wave owns chains b, b + G, ... of a grid of G
@@ -1263,9 +1303,12 @@ __global__ __launch_bounds__(64) void lean_snooker_mc_kernel(const DevProblem P,
     const long long abort_at = (P.test_abort >= 0 && b == 0) ? (long long)P.test_abort : -1;
     int kf[MT];
     double fx[MT];
-    if constexpr (FX)
+    PriorLanes<MT> priors;
+    if constexpr (FX) {
         coefficient_map<MT>(P, kf, fx);
-    (void)kf; (void)fx;
+        priors.init(P, kf, fx, lane);
+    }
+    (void)kf; (void)fx; (void)priors;
     // lane 3 i + s of chain q's batch: slot s of refresh bbase + i (the fields: as
     // lean_snooker_kernel's)
     unsigned long long A[T], B[T];
@@ -1423,7 +1466,7 @@ __global__ __launch_bounds__(64) void lean_snooker_mc_kernel(const DevProblem P,
                     block_gauss_model<1, MT, false, false>(P, model, nullptr, nullptr, tile,
                                                            &tile);           // chain.py:249
                 if constexpr (FX)
-                    nextchisq = nextchisq + prior_from_lanes<MT>(P, npk, kf, fx);
+                    nextchisq = nextchisq + priors.term(npk, lane);
                 bool acc;
                 if (__builtin_expect(!sjump, 1)) {
                     acc = metropolis_accept(0.5 * (cur[q] - nextchisq), C.u, C.lo, C.hi);
@@ -1526,9 +1569,12 @@ __global__ __launch_bounds__(64) void lean_mrw_mc_kernel(const DevProblem P, con
     const long long abort_at = (P.test_abort >= 0 && b == 0) ? (long long)P.test_abort : -1;
     int kf[MT];
     double fx[MT];
-    if constexpr (FX)
+    PriorLanes<MT> priors;
+    if constexpr (FX) {
         coefficient_map<MT>(P, kf, fx);
-    (void)kf; (void)fx;
+        priors.init(P, kf, fx, lane);
+    }
+    (void)kf; (void)fx; (void)priors;
     // lane 3 i + s of chain q's batch: as lean_mrw_kernel's
     double bu[T], blo[T], bhi[T], bcs[T], bsn[T];
     long long bbase = R0;
@@ -1598,7 +1644,7 @@ __global__ __launch_bounds__(64) void lean_mrw_mc_kernel(const DevProblem P, con
                     block_gauss_model<1, MT, false, false>(P, model, nullptr, nullptr, tile,
                                                            &tile);           // chain.py:249
                 if constexpr (FX)
-                    nextchisq = nextchisq + prior_from_lanes<MT>(P, npk, kf, fx);
+                    nextchisq = nextchisq + priors.term(npk, lane);
                 const bool acc = metropolis_accept(0.5 * (cur[q] - nextchisq), u_now, lo_now,
                                                    hi_now);
                 xk[q] = acc ? npk : xk[q];
@@ -1707,9 +1753,12 @@ __global__ __launch_bounds__(64) void lean_demc_mc_kernel(const DevProblem P, co
     bool alive = true;
     int kf[MT];
     double fx[MT];
-    if constexpr (FX)
+    PriorLanes<MT> priors;
+    if constexpr (FX) {
         coefficient_map<MT>(P, kf, fx);
-    (void)kf; (void)fx;
+        priors.init(P, kf, fx, lane);
+    }
+    (void)kf; (void)fx; (void)priors;
     // the draws: lane r T + q holds those of refresh bbase + r, turn q (chain.py:221-232, :259)
     const int bq = lane % T, br = (lane / T < NB) ? lane / T : NB - 1;
     const int bl = (b + bq * G < P.nlocal) ? b + bq * G : b;
@@ -1806,7 +1855,7 @@ __global__ __launch_bounds__(64) void lean_demc_mc_kernel(const DevProblem P, co
                     block_gauss_model<1, MT, MULTI, MULTI>(P, model, nullptr, nullptr, tile,
                                                            &tile1);          // chain.py:249
                 if constexpr (FX)
-                    nextchisq = nextchisq + prior_from_lanes<MT>(P, npk, kf, fx);
+                    nextchisq = nextchisq + priors.term(npk, lane);
                 const bool acc = metropolis_accept(0.5 * (cur[q] - nextchisq), u_q[q], lo_q[q],
                                                    hi_q[q]);            // chain.py:257-274
                 xk[q] = acc ? npk : xk[q];

@@ -234,6 +234,15 @@ int fast_threads(const mc3hip_ctx *c, bool p2p)
 
 void launch_fast(mc3hip_ctx *c, int nref)
 {
+    if (jit_serves(c)) {
+        // the loop compiled for this context's model (mc3hip_jit_install): one wave per chain
+        DevProblem P = c->P;
+        int n = nref;
+        void *args[] = {&P, &n};
+        (void)hipModuleLaunchKernel(c->jit_fn, (unsigned)c->P.nlocal, 1, 1, 64, 1, 1, 0, c->stream,
+                                    args, nullptr);
+        return;
+    }
     const bool mc = c->mc_chains > 0, p2p = c->p2p_ranks > 1;
     hipLaunchKernelGGL(fast_instance(c, p2p), dim3(mc ? c->mc_grid : c->P.nlocal),
                        dim3(fast_threads(c, p2p)), mc ? c->mc_smem : fast_smem(c), c->stream,
@@ -254,6 +263,11 @@ int blocks_per_cu(const void *kernel, int threads, size_t smem)
 // one until the peers are attached, and again after a roll-back)
 int fast_blocks_per_cu(mc3hip_ctx *c)
 {
+    if (jit_serves(c)) {
+        int nb = 0;
+        return hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, c->jit_fn, 64, 0) ==
+                       hipSuccess ? nb : 0;
+    }
     const bool p2p = c->p2p_ranks > 1;
     int nb = blocks_per_cu(reinterpret_cast<const void *>(fast_instance(c, p2p)),
                            fast_threads(c, p2p), fast_smem(c));
@@ -438,7 +452,7 @@ int decide_persist(mc3hip_ctx *c)
         return c->persist_refs;
     }
     int nb = 0;
-    c->fast = fast_eligible(c);
+    c->fast = fast_eligible(c) || jit_serves(c);
     // wavelet likelihood with eight waves per chain: a ninth wave runs the chain
     c->chainwave = c->P.wlike && c->wpc == 8 && !c->P.wl_scratch &&
                    !(c->flags & MC3HIP_FLAG_P2P) &&
@@ -1081,6 +1095,8 @@ void mc3hip_destroy(mc3hip_ctx *c)
         g_rccl.CommDestroy(c->comm);
     for (void *p : c->p2p_opened)
         (void)hipIpcCloseMemHandle(p);
+    if (c->jit_module)
+        (void)hipModuleUnload(c->jit_module);
     if (c->graph_exec)
         (void)hipGraphExecDestroy(c->graph_exec);
     if (c->graph)
@@ -1115,7 +1131,9 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
                      ? ((lean_demc_eligible(c) || lean_demc_mc_eligible(c) ||
                          lean_snooker_eligible(c) || lean_mrw_eligible(c) ||
                          lean_snooker_mc_eligible(c) || lean_mrw_mc_eligible(c) ||
-                         lean_demc_lag_eligible(c)) ? 2 : 1) : 0;
+                         lean_demc_lag_eligible(c) || jit_serves(c)) ? 2 : 1) : 0;
+    plan->jit = (plan->fast == 2 && jit_serves(c)) ? 1 : 0;
+    plan->reserved1 = 0;
     if (plan->fast == 2 && c->p2p_ranks <= 1)
         plan->waves_per_chain = lean_waves(c);      // (helper waves share the data sum)
     if (plan->persistent > 0 && chainwave_runs(c, c->p2p_ranks > 1) && c->P.cw_lean)
@@ -1129,6 +1147,77 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
     plan->chains_per_workgroup = (plan->persistent > 0 && c->mc_chains > 0) ? c->mc_chains : 1;
     plan->zlag = c->P.zlag;
     plan->remote_delay_ns = c->P.remote_delay * 10;
+    return MC3HIP_OK;
+}
+
+// ---- run-time specialisation (include/mc3hip.h) -------------------------------------------
+int mc3hip_jit_request(const mc3hip_ctx *c, char *buf, int32_t capacity)
+{
+    if (!c || !buf || capacity < 1)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    buf[0] = 0;
+    // (what the library has an instance for, it runs: nothing to specialise)
+    if (fast_eligible(c))
+        return MC3HIP_OK;
+    const int tag = jit_model_tag(c);
+    if (tag == 0)
+        return MC3HIP_OK;
+    const DevProblem &P = c->P;
+    const bool plain = P.nfree == P.nparams && P.ngprior == 0 && P.nshare == 0;
+    const char *fx = plain ? "false" : "true", *thin = P.thinning > 1 ? "true" : "false";
+    int n = 0;
+    switch (P.sampler) {
+    case MC3HIP_DEMC:
+        if (P.thinning > 1 || P.zlag > 0)        // <MT, P2P, FX, COURIER>
+            n = snprintf(buf, (size_t)capacity, "lean_demc_lag_body<%d, false, %s, false>", tag, fx);
+        else                                     // <MT, P2P, FX, MULTI, BATCH, COURIER, EPS>
+            n = snprintf(buf, (size_t)capacity,
+                         "lean_demc_body<%d, false, %s, false, false, false, %s>", tag, fx,
+                         P.fepsilon != 0.0 ? "true" : "false");
+        break;
+    case MC3HIP_SNOOKER:                         // <MT, FX, THIN, MULTI, P2P, COURIER>
+        n = snprintf(buf, (size_t)capacity, "lean_snooker_body<%d, %s, %s, false, false, false>",
+                     tag, fx, thin);
+        break;
+    default:
+        n = snprintf(buf, (size_t)capacity, "lean_mrw_body<%d, %s, %s, false, false, false>", tag,
+                     fx, thin);
+        break;
+    }
+    if (n < 0 || n >= capacity) {
+        buf[0] = 0;
+        return fail(MC3HIP_ERR_ARG, "buffer of %d bytes too small for the request", capacity);
+    }
+    return MC3HIP_OK;
+}
+
+int mc3hip_jit_install(mc3hip_ctx *c, const void *code_object, int64_t bytes,
+                       const char *kernel_name)
+{
+    if (!c || !code_object || bytes <= 0 || !kernel_name)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    if (c->refresh_done != 0 || c->ckpt_valid)
+        return fail(MC3HIP_ERR_STATE, "a kernel is installed before the first mc3hip_run");
+    if (jit_model_tag(c) == 0)
+        return fail(MC3HIP_ERR_ARG, "this context's shape has no specialised loop "
+                                    "(mc3hip_jit_request says which do)");
+    HIP_TRY(hipSetDevice(c->device));
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    hipError_t e = hipModuleLoadData(&mod, code_object);
+    if (e != hipSuccess)
+        return fail(MC3HIP_ERR_HIP, "hipModuleLoadData failed: %s", hipGetErrorString(e));
+    e = hipModuleGetFunction(&fn, mod, kernel_name);
+    if (e != hipSuccess) {
+        (void)hipModuleUnload(mod);
+        return fail(MC3HIP_ERR_HIP, "kernel '%s' not in the code object: %s", kernel_name,
+                    hipGetErrorString(e));
+    }
+    if (c->jit_module)
+        (void)hipModuleUnload(c->jit_module);
+    c->jit_module = mod;
+    c->jit_fn = fn;
+    c->persist_checked = false;                  // (the launch structure is decided anew)
     return MC3HIP_OK;
 }
 

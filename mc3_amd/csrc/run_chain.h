@@ -159,9 +159,12 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
     constexpr int NKF = (FX && MT >= 1 && MT <= 8) ? MT : 1;
     int kf[NKF];
     double fx[NKF];
-    if constexpr (FX)
+    PriorLanes<NKF> priors;
+    if constexpr (FX) {
         coefficient_map<NKF>(P, kf, fx);
-    (void)kf; (void)fx;
+        priors.init(P, kf, fx, lane);
+    }
+    (void)kf; (void)fx; (void)priors;
 
     if constexpr (PERSIST && !phase_hooked(PHASE)) {     // (resident: the kernel has looked)
         // a launch queued behind one that gave up must not run: its inputs are missing
@@ -582,7 +585,7 @@ __device__ __forceinline__ void run_chain(const DevProblem &P, const long long R
                 nextchisq = block_gauss_model<WPC, MT, MULTI, MULTI>(P, model, L.part, L.flag, tile,
                                                                      &tile1);
                 if constexpr (FX)
-                    nextchisq = nextchisq + prior_from_lanes<NKF>(P, npk, kf, fx);
+                    nextchisq = nextchisq + priors.term(npk, lane);
             } else if constexpr (PHASE == PH_FINISH) {
                 nextchisq = finish_chisq<MT>(P, lc);
             } else if constexpr (phase_hooked(PHASE)) {

@@ -30,7 +30,7 @@ class DeviceChains:
                  fgamma=1.0, fepsilon=0.0, hsize=10, model='poly', nmodel=None,
                  seed=0, device=0, chain0=0, nlocal=None, M0=None, zlen=None,
                  trace_iters=0, no_graph=False, no_persist=False, p2p=False, zlag=0,
-                 no_courier=False):
+                 no_courier=False, jit=True):
         self._ctx = None
         self.lib = _lib.load()
         self.params = f64(params).copy()
@@ -109,6 +109,12 @@ class DeviceChains:
         check(self.lib.mc3hip_create(ctypes.byref(P), ctypes.byref(ctx)))
         self._ctx = ctx
         self.trace_iters = int(trace_iters)
+        # run-time specialisation of the one-wave loops for this model, where the library
+        # asks for one (mc3_amd/jit.py; MC3HIP_NO_JIT=1 / jit=False: the general chain)
+        self.jit_served = ''
+        if jit and not no_persist:
+            from . import jit as _jit
+            self.jit_served = _jit.specialise(self)
 
     @property
     def plan(self):
@@ -123,8 +129,19 @@ class DeviceChains:
                 'persistent': plan.persistent, 'fast': plan.fast,
                 'comm_graph': plan.comm_graph, 'recoveries': plan.recoveries,
                 'tile_tree': plan.tile_tree, 'resident': plan.resident,
-                'chains_per_workgroup': plan.chains_per_workgroup,
+                'chains_per_workgroup': plan.chains_per_workgroup, 'jit': plan.jit,
                 'zlag': plan.zlag, 'remote_delay_ns': plan.remote_delay_ns}
+
+    def jit_request(self):
+        """The loop instantiation the library would like compiled for this model ('' = none)."""
+        buf = ctypes.create_string_buffer(256)
+        check(self.lib.mc3hip_jit_request(self._ctx, buf, len(buf)))
+        return buf.value.decode()
+
+    def jit_install(self, image, name):
+        keep = ctypes.create_string_buffer(image, len(image))
+        check(self.lib.mc3hip_jit_install(self._ctx, ctypes.cast(keep, ctypes.c_void_p),
+                                          len(image), name.encode()))
 
     # -- lifetime --------------------------------------------------------------
     def close(self):

@@ -93,3 +93,18 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(ImportError, match='no CPU fallback'):
         _lib.load()
+
+
+def test_jit_compiles_a_request_without_a_gpu(tmp_path, monkeypatch):
+    """mc3_amd/jit.py: hipcc cross-compiles the generated unit for gfx950 here too; the code
+    object is cached under a key of the request, the headers and the flags."""
+    from mc3_amd import jit
+    monkeypatch.setenv('MC3HIP_JIT_CACHE', str(tmp_path))
+    req = 'lean_demc_body<206, false, false, false, false, false, false>'
+    image = jit.code_object(req)
+    # (a code-object bundle, or the bare ELF: hipModuleLoadData takes either)
+    assert image[:4] in (b'\x7fELF', b'__CL') and len(image) > 4000
+    files = os.listdir(str(tmp_path))
+    assert len(files) == 1
+    assert jit.code_object(req) == image                      # (from the file)
+    assert jit._key(req) != jit._key(req.replace('206', '207'))

@@ -1,0 +1,145 @@
+"""Run-time specialisation of the one-wave loops (mc3_amd/jit.py, mc3hip_jit_request /
+mc3hip_jit_install): polynomials of 5..8 coefficients and design matrices of up to 10 columns
+on the hand-laid-out loops, compiled for the very model when the context is created -- against
+the oracle, bit for bit, like every other kernel; and against the same run with the
+specialisation switched off (the general chain)."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from test_gpu_parity import assert_same, run_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from mc3_amd import engine
+    return engine
+
+
+def poly_problem(k, nchains=12, nref=80, **kw):
+    """A polynomial of k coefficients around the tutorial's quadratic on x in [0, 1]."""
+    prob = H.quad_problem(ndata=300, nchains=nchains, nsamples=nchains*nref*kw.get('thinning', 1),
+                          **kw)
+    pad = k - 3
+    prob.update(indep=prob['indep']/10.0,
+                params=np.concatenate([[10.0, -20.0, 10.0], np.zeros(pad)]),
+                pstep=np.concatenate([[1.0, 5.0, 10.0], np.full(pad, 1.0)]),
+                pmin=np.concatenate([[-10.0, -200.0, -1000.0], np.full(pad, -1e4)]),
+                pmax=np.concatenate([[40.0, 200.0, 1000.0], np.full(pad, 1e4)]))
+    return prob
+
+
+def linear_problem(k, nchains=12, nref=80, priors=False, **kw):
+    prob = H.linear_problem(ndata=700, nmodel=k, nchains=nchains,
+                            nsamples=nchains*nref*kw.get('thinning', 1), **kw)
+    if not priors:
+        for key in ('prior', 'priorlow', 'priorup'):
+            prob[key] = np.zeros(k)
+    return prob
+
+
+CASES = {
+    'poly5-demc': lambda: poly_problem(5, sampler='demc'),
+    'poly8-demc': lambda: poly_problem(8, sampler='demc'),
+    'poly6-snooker': lambda: poly_problem(6, sampler='snooker'),
+    'poly5-demc-thin': lambda: poly_problem(5, sampler='demc', thinning=3),
+    'poly7-demc-lag': lambda: poly_problem(7, sampler='demc', zlag=2),
+    'poly5-demc-eps': lambda: poly_problem(5, sampler='demc', fepsilon=0.01),
+    'poly6-snooker-thin': lambda: poly_problem(6, sampler='snooker', thinning=2),
+    'lin2-demc': lambda: linear_problem(2, sampler='demc'),
+    'lin5-demc': lambda: linear_problem(5, sampler='demc'),
+    'lin10-demc': lambda: linear_problem(10, sampler='demc'),
+    'lin10-snooker': lambda: linear_problem(10, sampler='snooker'),
+    'lin3-mrw': lambda: linear_problem(3, sampler='mrw'),
+    'lin7-demc-priors': lambda: linear_problem(7, sampler='demc', priors=True),
+    'lin10-demc-priors-thin': lambda: linear_problem(10, sampler='demc', priors=True, thinning=2),
+    'lin6-snooker-priors': lambda: linear_problem(6, sampler='snooker', priors=True),
+    'lin4-demc-eps-priors': lambda: linear_problem(4, sampler='demc', priors=True,
+                                                   fepsilon=0.02),
+}
+
+
+@pytest.mark.parametrize('case', sorted(CASES))
+def test_specialised_loops_against_the_oracle(eng, case):
+    prob = CASES[case]()
+    gpu = eng.DeviceChains(**prob)
+    assert gpu.jit_served, 'the library asked for no specialisation'
+    orc = H.make_oracle(prob, plan=gpu.plan)
+    Z0, lp0 = H.initial_population(orc)
+    orc.set_population(Z0, lp0)
+    gpu.set_population(Z0, lp0)
+    orc.run(nthreads=4)
+    for n in (1, 2, 20, 21, 22, 14):            # (several launches: each resumes from Z)
+        gpu.run(n)
+    plan = gpu.plan
+    assert plan['jit'] == 1 and plan['fast'] == 2 and plan['persistent'] > 0, (plan,
+                                                                              gpu.jit_served)
+    assert plan['recoveries'] == 0
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
+def test_the_request_names_the_loop_and_the_cache_keeps_it(eng, tmp_path, monkeypatch):
+    from mc3_amd import jit
+    monkeypatch.setenv('MC3HIP_JIT_CACHE', str(tmp_path))
+    prob = linear_problem(10, sampler='snooker')
+    with eng.DeviceChains(**prob) as gpu:
+        assert gpu.jit_served == 'lean_snooker_body<210, false, false, false, false, false>'
+        assert gpu.plan['jit'] == 1
+    made = sorted(os.listdir(str(tmp_path)))
+    assert len(made) == 1 and made[0].endswith('.hsaco')
+    stamp = os.path.getmtime(os.path.join(str(tmp_path), made[0]))
+    with eng.DeviceChains(**prob) as gpu:       # the same shape again: the file, not hipcc
+        assert gpu.plan['jit'] == 1
+    assert os.path.getmtime(os.path.join(str(tmp_path), made[0])) == stamp
+    # shapes the library serves itself, or no loop serves, ask for nothing
+    with eng.DeviceChains(**H.quad_problem(sampler='demc')) as gpu:
+        assert gpu.jit_request() == '' and gpu.plan['jit'] == 0 and gpu.plan['fast'] == 2
+    with eng.DeviceChains(**H.wavelet_problem()) as gpu:
+        assert gpu.jit_request() == ''
+    with eng.DeviceChains(**linear_problem(11, sampler='demc')) as gpu:     # too many columns
+        assert gpu.jit_request() == '' and gpu.plan['fast'] == 0
+    with eng.DeviceChains(**poly_problem(5, sampler='mrw')) as gpu:         # mrw: <= 4 deviates
+        assert gpu.jit_request() == ''
+    assert jit.KERNEL_NAME == 'mc3_jit_kernel'
+
+
+@pytest.mark.parametrize('case', ['poly5-demc', 'lin10-demc'])
+def test_without_the_specialisation_the_general_chain_gives_the_same_rows(eng, monkeypatch, case):
+    prob = CASES[case]()
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert gpu.plan['jit'] == 1
+    Z, lp, _ = gpu.rows()
+    gpu.close()
+    monkeypatch.setenv('MC3HIP_NO_JIT', '1')
+    orc2, gpu2 = run_pair(eng, prob, trace=False)
+    assert gpu2.plan['jit'] == 0 and gpu2.plan['fast'] == 0 and not gpu2.jit_served
+    Z2, lp2, _ = gpu2.rows()
+    gpu2.close()
+    np.testing.assert_array_equal(Z, Z2)
+    np.testing.assert_array_equal(lp, lp2)
+    np.testing.assert_array_equal(Z, orc.Z)
+
+
+def test_a_specialised_launch_that_gives_up_is_redone(eng, monkeypatch):
+    monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '21')
+    prob = CASES['lin5-demc']()
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert gpu.plan['recoveries'] == 1
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
+def test_more_chains_than_the_specialised_loop_holds_take_turns_on_the_general_chain(
+        eng, monkeypatch):
+    monkeypatch.setenv('MC3HIP_PERSIST_CAPACITY', '5')
+    prob = linear_problem(5, nchains=16, nref=30, sampler='demc')
+    orc, gpu = run_pair(eng, prob, trace=False)
+    plan = gpu.plan
+    assert plan['persistent'] > 0 and plan['chains_per_workgroup'] > 1 and plan['jit'] == 0, plan
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
