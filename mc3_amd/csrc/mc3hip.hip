@@ -1168,8 +1168,9 @@ int mc3hip_jit_request(const mc3hip_ctx *c, char *buf, int32_t capacity)
     int n = 0;
     switch (P.sampler) {
     case MC3HIP_DEMC:
-        if (P.thinning > 1 || P.zlag > 0)        // <MT, P2P, FX, COURIER>
-            n = snprintf(buf, (size_t)capacity, "lean_demc_lag_body<%d, false, %s, false>", tag, fx);
+        if (P.thinning > 1 || P.zlag > 0)        // <MT, P2P, FX, COURIER, DEEP>
+            n = snprintf(buf, (size_t)capacity, "lean_demc_lag_body<%d, false, %s, false, %s>", tag,
+                         fx, (P.thinning == 1 && P.zlag >= 2 && tag < MT_LINK0) ? "true" : "false");
         else                                     // <MT, P2P, FX, MULTI, BATCH, COURIER, EPS>
             n = snprintf(buf, (size_t)capacity,
                          "lean_demc_body<%d, false, %s, false, false, false, %s>", tag, fx,
