@@ -714,7 +714,7 @@ def run_rank(args):
         ctl.barrier()
         if rank == 0:
             out['config']['single_gpu_same_ensemble'] = single_gpu_segment(
-                args, build_problem, nchains, local_rank, engine)
+                args, build_problem, nchains, local_rank, engine, zlag)
         ctl.barrier()
         timer.cancel()
     ctl.barrier()
@@ -769,14 +769,23 @@ def rccl_segment(args, ctl, make_engine, build_problem, nchains, nlocal, chain0,
     return out
 
 
-def single_gpu_segment(args, build_problem, nchains, device, engine):
-    """The whole ensemble in ONE context on one GPU (no exchange at all)."""
+def single_gpu_segment(args, build_problem, nchains, device, engine, zlag=0):
+    """The whole ensemble in ONE context on one GPU (no exchange at all): in the strict
+    lockstep, and -- `same_cadence` -- in the cadence the sharded run used (the like-for-like
+    yardstick: same semantics, one GPU against N)."""
+    out = _single_gpu(args, build_problem, nchains, device, engine, 0)
+    if zlag:
+        out['same_cadence'] = _single_gpu(args, build_problem, nchains, device, engine, zlag)
+    return out
+
+
+def _single_gpu(args, build_problem, nchains, device, engine, zlag):
     # (long enough for the clocks to come back up after the idle seconds before it: with 8192
     # refreshes -- 10 ms -- the figure of one and the same kernel varied by a factor of two)
     nwarm, ntimed = (40, 200) if args.workload == 'c5' else (16384, 32768)
     prob = build_problem(nchains, nwarm + ntimed + 8, args.thinning)
     try:
-        with engine.DeviceChains(device=device, **prob) as g:
+        with engine.DeviceChains(device=device, zlag=zlag, **prob) as g:
             Z0, lp0 = initial_population(prob, lambda Z: g.eval_chisq(g.expand_free(Z)))
             g.set_population(Z0, lp0)
             g.run(nwarm)
@@ -784,7 +793,7 @@ def single_gpu_segment(args, build_problem, nchains, device, engine):
             g.run(ntimed)
             dt = time.perf_counter() - t0
             plan = g.plan
-        return {'nchains': nchains, 'million_chain_steps_per_s':
+        return {'nchains': nchains, 'zlag': zlag, 'million_chain_steps_per_s':
                 nchains*ntimed*args.thinning/dt/1e6, 'us_per_refresh': dt/ntimed*1e6,
                 'persistent': plan['persistent'], 'refreshes_timed': ntimed,
                 'chains_per_workgroup': plan.get('chains_per_workgroup', 1)}

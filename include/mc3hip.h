@@ -150,7 +150,11 @@ typedef struct mc3hip_plan {
                                190-191); results do not depend on it                          */
     int32_t jit;            /* 1: the hand-laid-out loop that runs was specialised at run time
                                for this model (mc3hip_jit_request / mc3hip_jit_install)         */
-    int32_t reserved1;      /* 0 */
+    int32_t capacity;       /* persistent launch: workgroups of the instance that runs which the
+                               device holds at once (occupancy query x CUs); the launch's grid
+                               -- nlocal, or nlocal / chains_per_workgroup -- must fit, and so
+                               must the SUM over contexts that share a device (ranks of a test
+                               set-up on one GPU: mc3_amd/parallel.py checks it)                */
     int32_t zlag;           /* the cadence this context runs (mc3hip_problem.zlag)              */
     int32_t remote_delay_ns;/* test hook MC3HIP_TEST_REMOTE_DELAY_NS (read at creation): every
                                row bound for ANOTHER rank's replica is held back that long

@@ -59,7 +59,7 @@ class Plan(ctypes.Structure):
                 ('comm_graph', ctypes.c_int32), ('recoveries', ctypes.c_int32),
                 ('tile_tree', ctypes.c_int32), ('resident', ctypes.c_int32),
                 ('chains_per_workgroup', ctypes.c_int32),
-                ('jit', ctypes.c_int32), ('reserved1', ctypes.c_int32),
+                ('jit', ctypes.c_int32), ('capacity', ctypes.c_int32),
                 ('zlag', ctypes.c_int32), ('remote_delay_ns', ctypes.c_int32)]
 
 
@@ -135,6 +135,8 @@ def load():
                 '(hipcc, gfx950).  mc3_amd has no CPU fallback.')
         lib = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SYMBOLS.items():
+            if not hasattr(lib, name) and os.environ.get('MC3HIP_LIBRARY'):
+                continue            # (a diagnostic build of another vintage)
             fn = getattr(lib, name)
             fn.restype = restype
             fn.argtypes = argtypes

@@ -469,8 +469,8 @@ template <int WPC, int MT>
 struct DataTile {
     static constexpr int NV = 16 / WPC;
     static constexpr int NA = mt_is_link(MT) ? mt_ncoef(MT) : 1;
-    double x[NV], d[NV], w[NV];
-    double a[NV][NA];          // MT_LINK0 + K: this thread's points of the K columns
+    double x[mt_is_link(MT) ? 1 : NV], d[NV], w[NV];
+    double a[mt_is_link(MT) ? NV : 1][NA];     // MT_LINK0 + K: this thread's points of the K columns
 
     // The device copies of x / data / w are padded to a multiple of 1024 points
     // (x and data repeat the last point, w = 0), so the tile needs no bounds

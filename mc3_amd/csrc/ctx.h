@@ -39,6 +39,7 @@ struct mc3hip_ctx {
     hipGraphExec_t graph_exec = nullptr;
     int graph_nodes = 0;
     int persist_refs = 0;           // refreshes per persistent launch, 0 = off
+    long long capacity = 0;         // co-resident workgroups of the persistent instance that runs
     bool persist_checked = false;
     bool fast = false;              // lean persistent instance selected
     bool chainwave = false;         // wavelet likelihood, eight waves: a ninth runs the chain

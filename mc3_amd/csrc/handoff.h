@@ -65,55 +65,6 @@ __device__ __forceinline__ void published_arrived(double &a, double &b, double &
         asm volatile("s_waitcnt vmcnt(3)" : "+v"(a), "+v"(b), "+v"(c)::"memory");
 }
 
-// Two rows asked for TWO iterations ahead (lean_demc_lag_kernel): the loads are in flight where
-// the loop turns around, so their destinations must be registers the compiler never renames or
-// copies -- fixed ACCUMULATION registers, named in the instruction and declared clobbered (SET 0:
-// a0..a3, SET 1: a4..a7; gfx90a and later load global memory straight into them).  The counted
-// wait and the read-back are ONE statement, so nothing can come between them.
-template <int SET, bool SYS>
-__device__ __forceinline__ void load_rows_fixed(const double *p0, const double *p1)
-{
-    static_assert(SET == 0 || SET == 1, "");
-    if constexpr (SET == 0) {
-        if constexpr (SYS)
-            asm volatile("global_load_dwordx2 a[0:1], %0, off sc0 sc1\n\t"
-                         "global_load_dwordx2 a[2:3], %1, off sc0 sc1"
-                         :: "v"(p0), "v"(p1) : "a0", "a1", "a2", "a3", "memory");
-        else
-            asm volatile("global_load_dwordx2 a[0:1], %0, off sc1\n\t"
-                         "global_load_dwordx2 a[2:3], %1, off sc1"
-                         :: "v"(p0), "v"(p1) : "a0", "a1", "a2", "a3", "memory");
-    } else {
-        if constexpr (SYS)
-            asm volatile("global_load_dwordx2 a[4:5], %0, off sc0 sc1\n\t"
-                         "global_load_dwordx2 a[6:7], %1, off sc0 sc1"
-                         :: "v"(p0), "v"(p1) : "a4", "a5", "a6", "a7", "memory");
-        else
-            asm volatile("global_load_dwordx2 a[4:5], %0, off sc1\n\t"
-                         "global_load_dwordx2 a[6:7], %1, off sc1"
-                         :: "v"(p0), "v"(p1) : "a4", "a5", "a6", "a7", "memory");
-    }
-}
-// ... retired once all but the wave's 3 youngest vector-memory operations are done (the caller
-// has issued at least three since: the other set's two loads and a store), and read back
-template <int SET>
-__device__ __forceinline__ void rows_fixed_arrived(double &v0, double &v1)
-{
-    int l0, h0, l1, h1;
-    if constexpr (SET == 0)
-        asm volatile("s_waitcnt vmcnt(3)\n\t"
-                     "v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\t"
-                     "v_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3"
-                     : "=v"(l0), "=v"(h0), "=v"(l1), "=v"(h1) :: "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(3)\n\t"
-                     "v_accvgpr_read_b32 %0, a4\n\tv_accvgpr_read_b32 %1, a5\n\t"
-                     "v_accvgpr_read_b32 %2, a6\n\tv_accvgpr_read_b32 %3, a7"
-                     : "=v"(l0), "=v"(h0), "=v"(l1), "=v"(h1) :: "memory");
-    v0 = make_double(l0, h0);
-    v1 = make_double(l1, h1);
-}
-
 // The ranks' replicas (peer-to-peer mode).  The pointers are read ONCE, before the loop: a load
 // of one inside it is waited for together with everything older in the wave's queue -- the
 // store into the previous peer's replica, still on its way over xGMI -- so a row's stores

@@ -14,13 +14,9 @@ chain_kernel_fn lean_lag_instance_t(const mc3hip_ctx *c, bool p2p)
     if (!lean_demc_lag_eligible(c))
         return nullptr;
     const bool fx = !lean_plain_shape(c);
-    // thinning 1 and zlag >= 2: the rows asked for two refreshes ahead (DEEP)
-    const bool deep = c->P.thinning == 1 && c->P.zlag >= 2;
 #define MC3_LAG(P2P_, COUR_)                                                        \
-    return deep ? (fx ? lean_demc_lag_kernel<MT, P2P_, true, COUR_, true>           \
-                      : lean_demc_lag_kernel<MT, P2P_, false, COUR_, true>)         \
-                : (fx ? lean_demc_lag_kernel<MT, P2P_, true, COUR_, false>          \
-                      : lean_demc_lag_kernel<MT, P2P_, false, COUR_, false>);
+    return fx ? lean_demc_lag_kernel<MT, P2P_, true, COUR_>                         \
+              : lean_demc_lag_kernel<MT, P2P_, false, COUR_>;
     if (p2p) {
         if (lean_courier(c, true)) {
             MC3_LAG(true, true)

@@ -991,7 +991,12 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_mrw_kernel(const DevP
 //   without it the chain wave stores them itself: more than two ranks sharing a device).
 // Same draws, same arithmetic, same results as run_chain's with the same zlag -- on one GPU or
 // sharded over any number of them.
-template <int MT, bool P2P, bool FX, bool COURIER, bool DEEP = false>
+// (Asking TWO refreshes ahead -- the loop is bound by the round trip of its own loads, 0.84 us
+// per iteration against the random walk's 0.58 -- was tried in round 4 with the rows landing in
+// fixed accumulation registers, two sets used in turn by a loop unrolled by two: bit-identical,
+// SLOWER (213 against 306 M chain-steps/s at 256 chains) and over the registers of two waves per
+// SIMD; not kept.)
+template <int MT, bool P2P, bool FX, bool COURIER>
 __device__ __forceinline__ void lean_demc_lag_body(const DevProblem &P, const int nref)
 {
     static_assert(!COURIER || P2P, "the courier carries rows to other ranks' replicas");
@@ -1119,145 +1124,7 @@ __device__ __forceinline__ void lean_demc_lag_body(const DevProblem &P, const in
         }
     };
     bool alive = true;
-    // ---- thinning 1, zlag >= 2: the rows asked for TWO refreshes ahead ------------------------
-    // One refresh ahead the loop is bound by the round trip of its own loads (0.84 us per
-    // iteration against the random walk's 0.58, which loads nothing): they are issued at the top
-    // of an iteration and needed at its bottom.  With zlag >= 2 the rows of refresh R + 2 (those
-    // of refresh R + 1 - zlag <= R - 1) are published when refresh R starts, so they can be
-    // asked for a whole iteration earlier.  The loads are then in flight where the loop turns
-    // around: they land in fixed accumulation registers (handoff.h load_rows_fixed), two sets
-    // used in turn by a loop unrolled by two -- no copy, no renaming, nothing for the register
-    // allocator to decide.  (Not for the run-time specialisations of design matrices, whose
-    // tiles spill into those registers.)
-    // (DEEP: an instance of its own -- the host launches it for thinning 1 and zlag >= 2 -- so that
-    // neither loop carries the other's registers)
-    static_assert(!DEEP || !mt_is_link(MT), "the specialised design-matrix tiles spill into a0..");
-    if constexpr (DEEP) {
-    {
-        struct Ahead {
-            double u, lo, hi;
-            const double *addr[2];
-        };
-        auto ask = [&](auto set, long long Rn, Ahead &A) {          // the rows refresh Rn looks at
-            if (__builtin_expect(Rn - bbase >= NB, 0))
-                fill(Rn);
-            const int idx = (int)(Rn - bbase);
-            const double *snap = seen_by(Rn);
-            A.addr[0] = snap + (__builtin_amdgcn_readlane(bo1, idx) + kk);
-            A.addr[1] = snap + (__builtin_amdgcn_readlane(bo2, idx) + kk);
-            load_rows_fixed<decltype(set)::value, P2P>(A.addr[0], A.addr[1]);
-            A.u = read_lane(bu, idx);
-            A.lo = read_lane(blo, idx);
-            A.hi = read_lane(bhi, idx);
-        };
-        using Set0 = std::integral_constant<int, 0>;
-        using Set1 = std::integral_constant<int, 1>;
-        // (the rows of refresh R0 are in S already; the batch was filled from R0)
-        Ahead A0, A1, An;
-        A0.u = S.u; A0.lo = S.lo; A0.hi = S.hi;
-        A0.addr[0] = S.addr[0]; A0.addr[1] = S.addr[1];
-        double v0 = S.val[0], v1 = S.val[1];
-        ask(Set1(), R0 + 1, A1);
-        // one refresh: its rows (v0, v1; draws in Acur) are there; the set they came from is
-        // free again and takes the rows of refresh R + 2; at the bottom the OTHER set's rows --
-        // asked for an iteration ago -- are waited for and read back
-        auto one = [&](auto mine_set, auto other_set, const long long R, Ahead &Acur,
-                       const Ahead &Aother) -> bool {
-            if (__builtin_expect(R == abort_at, 0)) {                                     // test hook
-                __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-            const Ahead C = Acur;
-            ask(mine_set, R + 2, Acur);
-            if (__builtin_expect(__any(mc3_bits(v0) == ROW_PENDING ||
-                                       mc3_bits(v1) == ROW_PENDING), 0)) {
-                const double *const a2[2] = {C.addr[0], C.addr[1]};
-                double v2[2] = {v0, v1};
-                alive = wait_rows<2, P2P>(a2, v2, ctl_rw, nullptr, [&]() {
-                    if constexpr (P2P && !COURIER) {         // (test hook: see lean_demc_kernel)
-                        if (__builtin_expect(P.remote_delay != 0, 0))
-                            late.drain(P, s_ring, peers_z, lane, mine, false);
-                    }
-                });
-                v0 = v2[0];
-                v1 = v2[1];
-                if (__builtin_expect(!alive, 0))
-                    return false;
-            }
-            // proposal and boundaries, chain.py:232-243
-            const double jump_k = gamma * (v0 - v1) + feps * 0.0;
-            const double npk = xk + jump_k;
-            const bool outk = mine && (npk < pmin_k || npk > pmax_k);
-            if (__builtin_expect(!__any(outk), 1)) {
-                Model<MT> model;
-                if constexpr (!FX)
-                    model.init_from_lanes(P, npk);
-                else
-                    model.init_from_lanes(P, npk, kf, fx);
-                double nextchisq =
-                    block_gauss_model<1, MT, false, false>(P, model, nullptr, nullptr, tile,
-                                                           &tile);           // chain.py:249
-                if constexpr (FX)
-                    nextchisq = nextchisq + priors.term(npk, lane);
-                const bool acc = metropolis_accept(0.5 * (cur - nextchisq), C.u, C.lo, C.hi);
-                xk = acc ? npk : xk;
-                if (__builtin_expect(__any(acc && nextchisq < best), 0)) {
-                    best = nextchisq;
-                    if (mine)
-                        P.bestx[(size_t)lc * nf + lane] = xk;
-                    if (lane == 0)
-                        P.best_iter[lc] = R;
-                }
-                cur = acc ? nextchisq : cur;
-                nacc += acc ? 1 : 0;
-            } else if (outk) {
-                atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
-            }
-            // Z append, chain.py:276-289
-            if (mine)
-                __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
-                                   P2P ? __HIP_MEMORY_SCOPE_SYSTEM : __HIP_MEMORY_SCOPE_AGENT);
-            // the other set's rows: at least three operations younger than them have been
-            // issued -- this refresh's two loads and the store above
-            rows_fixed_arrived<decltype(other_set)::value>(v0, v1);
-            (void)Aother;
-            if constexpr (P2P) {
-                if constexpr (COURIER) {
-                    alive = courier_hand(s_ring, s_cour, handed, lane, mine, xk, ctl_rw);
-                    if (__builtin_expect(!alive, 0))
-                        return false;
-                } else if (__builtin_expect(P.remote_delay != 0, 0)) {         // test hook
-                    late.hand(P, s_ring, peers_z, lane, mine, xk);
-                } else if (mine) {
-                    peers_z.store((size_t)(zblock - P.Z) + (size_t)c * ZS + lane, xk, P.rank);
-                }
-            }
-            const int slot = (int)(R - R0) & 63;
-            lpbuf = (lane == slot) ? -0.5 * cur : lpbuf;
-            if (__builtin_expect(slot == 63, 0)) {
-                flush_columns(64);
-                lp_row += (size_t)64 * n;
-                zc_row += (size_t)64 * n;
-            }
-            zblock += blockstride;
-            rdone = R + 1;
-            return true;
-        };
-        long long R = R0;
-        for (; R + 1 < Rend; R += 2) {
-            if (!one(Set0(), Set1(), R, A0, A1))
-                goto out;
-            if (!one(Set1(), Set0(), R + 1, A1, A0))
-                goto out;
-        }
-        if (R < Rend)
-            one(Set0(), Set1(), R, A0, A1);
-        (void)An;
-        goto out;
-    }
-    }
-    for (long long R = R0; !DEEP && R < Rend; ++R) {
+    for (long long R = R0; R < Rend; ++R) {
         if (__builtin_expect(R == abort_at, 0)) {                                         // test hook
             __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -1380,11 +1247,11 @@ out:
     }
 }
 
-template <int MT, bool P2P = false, bool FX = false, bool COURIER = false, bool DEEP = false>
+template <int MT, bool P2P = false, bool FX = false, bool COURIER = false>
 __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_lag_kernel(const DevProblem P,
         const int nref)
 {
-    lean_demc_lag_body<MT, P2P, FX, COURIER, DEEP>(P, nref);
+    lean_demc_lag_body<MT, P2P, FX, COURIER>(P, nref);
 }
 
 // ---------------------------------------------------------------------------------

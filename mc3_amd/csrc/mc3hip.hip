@@ -443,6 +443,7 @@ int decide_persist(mc3hip_ctx *c)
         if (ncol * c->P.ntiles > capacity || (long long)c->P.nlocal > 8 * ncol * c->P.ntiles)
             return 0;
         c->resident = true;
+        c->capacity = capacity;
         c->resident_chain_block = (int)cb;
         c->P.rs_lean = resident_owner_lean(c) ? 1 : 0;
         c->fast = false;
@@ -552,6 +553,7 @@ int decide_persist(mc3hip_ctx *c)
             return 0;
         }
     }
+    c->capacity = capacity;
     c->persist_refs = 16384;
     if (const char *e = getenv("MC3HIP_PERSIST_REFS"))
         c->persist_refs = atoi(e) > 0 ? atoi(e) : 0;
@@ -1133,7 +1135,8 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
                          lean_snooker_mc_eligible(c) || lean_mrw_mc_eligible(c) ||
                          lean_demc_lag_eligible(c) || jit_serves(c)) ? 2 : 1) : 0;
     plan->jit = (plan->fast == 2 && jit_serves(c)) ? 1 : 0;
-    plan->reserved1 = 0;
+    plan->capacity = plan->persistent > 0
+                         ? (int32_t)(c->capacity < 0x7fffffff ? c->capacity : 0x7fffffff) : 0;
     if (plan->fast == 2 && c->p2p_ranks <= 1)
         plan->waves_per_chain = lean_waves(c);      // (helper waves share the data sum)
     if (plan->persistent > 0 && chainwave_runs(c, c->p2p_ranks > 1) && c->P.cw_lean)
@@ -1168,9 +1171,8 @@ int mc3hip_jit_request(const mc3hip_ctx *c, char *buf, int32_t capacity)
     int n = 0;
     switch (P.sampler) {
     case MC3HIP_DEMC:
-        if (P.thinning > 1 || P.zlag > 0)        // <MT, P2P, FX, COURIER, DEEP>
-            n = snprintf(buf, (size_t)capacity, "lean_demc_lag_body<%d, false, %s, false, %s>", tag,
-                         fx, (P.thinning == 1 && P.zlag >= 2 && tag < MT_LINK0) ? "true" : "false");
+        if (P.thinning > 1 || P.zlag > 0)        // <MT, P2P, FX, COURIER>
+            n = snprintf(buf, (size_t)capacity, "lean_demc_lag_body<%d, false, %s, false>", tag, fx);
         else                                     // <MT, P2P, FX, MULTI, BATCH, COURIER, EPS>
             n = snprintf(buf, (size_t)capacity,
                          "lean_demc_body<%d, false, %s, false, false, false, %s>", tag, fx,

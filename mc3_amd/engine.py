@@ -130,6 +130,7 @@ class DeviceChains:
                 'comm_graph': plan.comm_graph, 'recoveries': plan.recoveries,
                 'tile_tree': plan.tile_tree, 'resident': plan.resident,
                 'chains_per_workgroup': plan.chains_per_workgroup, 'jit': plan.jit,
+                'capacity': plan.capacity,
                 'zlag': plan.zlag, 'remote_delay_ns': plan.remote_delay_ns}
 
     def jit_request(self):

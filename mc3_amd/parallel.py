@@ -199,6 +199,21 @@ class Communicator:
         run is refused here, on every rank alike."""
         dev = getattr(engine, '_device', None)
         plan = getattr(engine, 'plan', None) or {}
+        # the persistent kernels wait for each other's rows, so the grids of ALL the ranks on a
+        # device must be co-resident: each library checks its own grid against the device, the
+        # sum is checked here (seen in round 4: lag-loop builds that held one wave per SIMD
+        # instead of two passed the per-rank check and deadlocked beyond 1024 workgroups)
+        grid = -(-int(getattr(engine, 'nlocal', 0))//max(1, int(plan.get('chains_per_workgroup', 1))))
+        load = self.all_gather((dev, grid if plan.get('persistent') and not plan.get('resident')
+                                else 0, int(plan.get('capacity', 0))))
+        for d in {d for d, _, _ in load if d is not None}:
+            on = [(g, c) for e, g, c in load if e == d]
+            caps = [c for g, c in on if g and c]
+            if len(on) > 1 and caps and sum(g for g, _ in on) > min(caps):
+                raise RuntimeError(
+                    f'the ranks on device {d} launch {sum(g for g, _ in on)} workgroups that must '
+                    f'be co-resident; the device holds {min(caps)} of this kernel: use fewer '
+                    'chains per rank, or give every rank a GPU of its own')
         devices = self.all_gather((dev, bool(plan.get('resident'))))
         if dev is None:
             return
@@ -279,6 +294,8 @@ class Communicator:
                 if err.code != ERR_ABORTED:
                     raise
                 ok = False
+                if os.environ.get('MC3HIP_VERBOSE'):
+                    print(f'[rank {self.rank}] {err}', flush=True)
             if not self._all_ok(ok):          # (the vote is also the barrier)
                 self.recover(engine)
 

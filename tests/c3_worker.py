@@ -40,7 +40,8 @@ def main():
     plan = gpu.plan
     # the hand-laid-out loops: lean_demc_kernel<3, P2P> (strict lockstep), lean_demc_lag_kernel
     # (the declared cadence), lean_snooker_kernel / lean_mrw_kernel with their couriers
-    assert plan['fast'] == 2 and plan['persistent'] > 0 and plan['zlag'] == opts['zlag'], plan
+    if not os.environ.get('C3_WORKER_ANYPLAN'):         # (tools/dbg_ranks.py: other kernels)
+        assert plan['fast'] == 2 and plan['persistent'] > 0 and plan['zlag'] == opts['zlag'], plan
     if 'MC3HIP_TEST_REMOTE_DELAY_NS' in os.environ:
         assert plan['remote_delay_ns'] > 0, plan
     # two segments: the second persistent launch resumes from the replicas

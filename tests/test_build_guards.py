@@ -11,8 +11,6 @@ cross-compiles without a GPU) and check the ISA:
 * ``load_published_async`` (ordinary registers): between the load and the next inline-assembly
   wait, on any path of the control-flow graph, no instruction reads a destination register
   (a copy, a spill, an accumulation-register move or a use);
-* ``load_rows_fixed`` (fixed accumulation registers a0..a7, two refreshes ahead): the compiler's
-  own code never names a0..a7 anywhere in such a kernel;
 * none of these kernels carries scratch.
 """
 import concurrent.futures
@@ -173,29 +171,3 @@ def test_async_destinations_are_left_alone_until_their_wait(isa):
                         state[nxt] = new
                         work.append(nxt)
     assert checked > 50           # (the scan found the loads it is about)
-
-
-def test_the_compiler_keeps_off_the_fixed_accumulation_registers(isa):
-    seen = 0
-    for unit, text in isa.items():
-        for name, body in _kernels(text):
-            # (kernels whose INLINE ASSEMBLY loads into a[0:1]: the DEEP instances)
-            mine = any('#ASMSTART' in body[i] and 'a[0:1]' in body[i + 1]
-                       for i in range(len(body) - 1))
-            if not mine:
-                continue
-            seen += 1
-            inasm = False
-            for line in body:
-                if '#ASMSTART' in line:
-                    inasm = True
-                    continue
-                if '#ASMEND' in line:
-                    inasm = False
-                    continue
-                code = line.split(';')[0].strip()
-                if inasm or not code or code.endswith(':') or code.startswith('.'):
-                    continue
-                used = _regs(code.partition(' ')[2], 'a') & set(range(8))
-                assert not used, f'{unit}: {name}: `{code}` uses a{sorted(used)}'
-    assert seen >= 6              # (the DEEP instances of lean_demc_lag_kernel)

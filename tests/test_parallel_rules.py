@@ -16,8 +16,14 @@ class FixedComm(parallel.Communicator):
         super().__init__(rank, len(answers))
         self.answers = answers
 
+    loads = None                      # (device, grid, capacity) of every rank, when it matters
+
     def all_gather(self, obj):
-        out = list(self.answers)
+        if isinstance(obj, tuple) and len(obj) == 3:          # the co-residency vote
+            out = list(self.loads) if self.loads else \
+                [(a[0] if isinstance(a, tuple) else a, 0, 0) for a in self.answers]
+        else:
+            out = list(self.answers)
         out[self.rank] = obj
         return out
 
@@ -79,3 +85,22 @@ def test_shared_device_with_the_one_launch_tiled_plan_needs_a_share(clean_env, m
     # a GPU each: nothing to say
     monkeypatch.delenv('MC3HIP_RESIDENT_MAXCOL')
     FixedComm(0, [(0, True), (1, True)])._check_shared_device(engine(0, resident=True))
+
+
+def test_ranks_that_share_a_device_must_fit_it_together(clean_env):
+    """Every library checks its own persistent grid against the device; the SUM over the ranks
+    on one device is the communicator's business (their kernels wait for each other's rows)."""
+    eng = types.SimpleNamespace(_device=0, nlocal=256, no_courier=True,
+                                plan={'resident': 0, 'persistent': 16384, 'capacity': 1024,
+                                      'chains_per_workgroup': 1})
+    comm = FixedComm(0, [(0, False)]*5)
+    comm.loads = [(0, 256, 1024)]*5                     # 1280 workgroups, 1024 fit
+    with pytest.raises(RuntimeError, match='co-resident'):
+        comm._check_shared_device(eng)
+    comm.loads = [(0, 256, 2048)]*5
+    eng.plan['capacity'] = 2048
+    comm._check_shared_device(eng)                      # 1280 of 2048: fine
+    comm = FixedComm(0, [(0, False), (1, False), (2, False)])
+    comm.loads = [(0, 256, 256), (1, 256, 256), (2, 256, 256)]
+    eng.plan['capacity'] = 256
+    comm._check_shared_device(eng)                      # a GPU each: nothing to add up

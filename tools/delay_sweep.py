@@ -35,7 +35,7 @@ def main():
         for n in [int(v) for v in args.ranks.split(',')]:
             for zlag in [int(v) for v in args.zlags.split(',')]:
                 for delay in [int(v) for v in args.delays.split(',')]:
-                    env = dict(os.environ, MC3HIP_BENCH_DEVICE='0', MC3HIP_BENCH_WATCHDOG='240')
+                    env = dict(os.environ, MC3HIP_BENCH_DEVICE='0', MC3HIP_BENCH_WATCHDOG='90')
                     env.pop('MC3HIP_TEST_REMOTE_DELAY_NS', None)
                     if delay:
                         env['MC3HIP_TEST_REMOTE_DELAY_NS'] = str(delay)
@@ -43,8 +43,11 @@ def main():
                            '--steps', str(args.steps), '--warmup', '1', '--refreshes',
                            str(args.refreshes), '--workload', args.workload, '--zlag', str(zlag),
                            '--no-extras', '--no-cpu-baseline', '--no-e2e']
-                    res = subprocess.run(cmd, env=env, capture_output=True, text=True,
-                                         timeout=600)
+                    try:
+                        res = subprocess.run(cmd, env=env, capture_output=True, text=True,
+                                             timeout=240)
+                    except subprocess.TimeoutExpired as e:
+                        res = subprocess.CompletedProcess(cmd, 1, '', f'timeout: {e}')
                     line = next((ln for ln in reversed(res.stdout.splitlines())
                                  if ln.startswith('{')), None)
                     rec = {'ranks': n, 'delay_ns': delay, 'zlag': zlag, 'workload': args.workload}
