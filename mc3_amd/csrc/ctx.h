@@ -192,7 +192,8 @@ inline int jit_model_tag(const mc3hip_ctx *c)
     case MC3HIP_DEMC:          // (the support distribution: the strict headline loop only)
         return (P.fepsilon == 0.0 || (P.thinning == 1 && P.zlag == 0)) ? tag : 0;
     case MC3HIP_SNOOKER:
-        return (P.fepsilon == 0.0 && (P.thinning == 1 || plain)) ? tag : 0;
+        return ((P.fepsilon == 0.0 && (P.thinning == 1 || plain)) ||
+                (P.fepsilon != 0.0 && P.thinning == 1 && P.nfree <= 4)) ? tag : 0;
     default:                   // (the random walk: two Philox slots of deviates)
         return (P.nmodel <= 4 && (P.thinning == 1 || plain)) ? tag : 0;
     }
@@ -224,9 +225,12 @@ inline bool fast_eligible(const mc3hip_ctx *c)
     const bool size_ok = !multi || (plain && fx_ok && P.tile == 0);
     // (the support distribution, fepsilon != 0: the headline loop has an EPS flavour --
     // lean_demc_kernel: DEMC, strict lockstep, thinning 1, one tile, one GPU)
+    // ... and so has the snooker loop, for up to four free parameters (two Philox slots)
     const bool eps_ok = P.fepsilon == 0.0 || P.sampler == MC3HIP_MRW ||   // (chain.py:219-220)
                         (P.sampler == MC3HIP_DEMC && P.thinning == 1 && P.zlag == 0 && !p2p_flag &&
-                         !multi && P.zs == ZROW && !getenv("MC3HIP_NO_LEAN"));
+                         !multi && P.zs == ZROW && !getenv("MC3HIP_NO_LEAN")) ||
+                        (P.sampler == MC3HIP_SNOOKER && P.thinning == 1 && P.nfree <= 4 &&
+                         !p2p_flag && !multi && P.zs == ZROW && !getenv("MC3HIP_NO_LEAN"));
     return c->wpc == 1 && !P.wlike && size_ok && c->mt >= 2 && c->mt <= 4 &&
            (plain || fx_ok) && P.nmodel == P.nparams &&
            eps_ok && P.trace_iters == 0 &&
@@ -392,6 +396,7 @@ chain_kernel_fn fast_instance(const mc3hip_ctx *c, bool p2p);
 chain_kernel_fn lean_other_instance(const mc3hip_ctx *c);   // k_lean2.hip
 chain_kernel_fn lean_lag_instance(const mc3hip_ctx *c, bool p2p);   // k_lean3.hip
 chain_kernel_fn lean_other_p2p_instance(const mc3hip_ctx *c);       // k_lean4.hip
+chain_kernel_fn lean_demc_mc_instance(const mc3hip_ctx *c, bool p2p);   // k_lean5.hip
 
 // ---- k_tiled.hip: the tiled plan as three launches per iteration -------------------------
 void launch_propose(mc3hip_ctx *c, int roff, int j);

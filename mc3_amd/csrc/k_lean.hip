@@ -48,20 +48,9 @@ chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
         return f;
     if (c->P.sampler == MC3HIP_MRW)
         return fast_instance_tt<MT, MC3HIP_MRW>(c, p2p);
-    if (lean_demc_mc_eligible(c) && !p2p) {          // 2..4 chains per wave
-#define MC3_LEAN_MC(TT)                                                             \
-        if (c->mc_chains == TT) {                                                   \
-            if (c->P.npad > VLANES)                                                 \
-                return lean_demc_mc_kernel<MT, (TT < 4 ? TT : 3), false, true>;     \
-            if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)  \
-                return lean_demc_mc_kernel<MT, TT, true>;                           \
-            return lean_demc_mc_kernel<MT, TT>;                                     \
-        }
-        MC3_LEAN_MC(2)
-        MC3_LEAN_MC(3)
-        MC3_LEAN_MC(4)
-#undef MC3_LEAN_MC
-    }
+    // (2..4 chains per wave, helper waves: k_lean5.hip)
+    if (chain_kernel_fn f = lean_demc_mc_instance(c, p2p))
+        return f;
     if (lean_demc_eligible(c)) {
         if (c->P.fepsilon != 0.0)                        // (one GPU, one tile: fast_eligible)
             return lean_plain_shape(c) ? lean_demc_kernel<MT, false, false, false, false, false, true>
@@ -75,10 +64,6 @@ chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
             return lean_demc_kernel<MT, false, true>;
         if (lean_courier(c, false))
             return lean_demc_kernel<MT, false, false, false, false, true>;
-        if (lean_waves(c) == 4)
-            return lean_demc_wide_kernel<MT, 4>;
-        if (lean_waves(c) == 2)
-            return lean_demc_wide_kernel<MT, 2>;
         if (lean_batch(c))
             return lean_demc_kernel<MT, false, false, false, true>;
         return lean_demc_kernel<MT, false>;

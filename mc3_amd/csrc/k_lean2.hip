@@ -28,6 +28,10 @@ chain_kernel_fn lean_other_instance_t(const mc3hip_ctx *c)
         MC3_LEAN_SOLO_MC(lean_mrw_mc_kernel, 4)
     }
     if (lean_snooker_eligible(c)) {
+        if (c->P.fepsilon != 0.0)                   // (thinning 1, one tile: fast_eligible)
+            return lean_plain_shape(c)
+                       ? lean_snooker_kernel<MT, false, false, false, false, false, true>
+                       : lean_snooker_kernel<MT, true, false, false, false, false, true>;
         if (c->P.thinning > 1)
             return lean_snooker_kernel<MT, false, true>;
         if (c->P.npad > VLANES)

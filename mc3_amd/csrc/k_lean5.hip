@@ -1,0 +1,52 @@
+// k_lean5.hip -- instances of the hand-laid-out DEMC loop with two to four chains per wave
+// (kernels_lean.h lean_demc_mc_kernel) and with helper waves (lean_demc_wide_kernel, an
+// experiment behind MC3HIP_LEAN_WAVES); a translation unit of its own so that the library
+// builds in parallel.
+#include "ctx.h"
+#include "kernels_lean.h"
+
+namespace mc3hip {
+namespace host {
+namespace {
+
+template <int MT>
+chain_kernel_fn lean_demc_mc_instance_t(const mc3hip_ctx *c, bool p2p)
+{
+    if (lean_demc_mc_eligible(c) && !p2p) {          // 2..4 chains per wave
+#define MC3_LEAN_MC(TT)                                                             \
+        if (c->mc_chains == TT) {                                                   \
+            if (c->P.npad > VLANES)                                                 \
+                return lean_demc_mc_kernel<MT, (TT < 4 ? TT : 3), false, true>;     \
+            if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)  \
+                return lean_demc_mc_kernel<MT, TT, true>;                           \
+            return lean_demc_mc_kernel<MT, TT>;                                     \
+        }
+        MC3_LEAN_MC(2)
+        MC3_LEAN_MC(3)
+        MC3_LEAN_MC(4)
+#undef MC3_LEAN_MC
+    }
+    // (helper waves share a chain's data sum: the plain one-GPU headline shape, on request)
+    if (!p2p && lean_demc_eligible(c) && c->P.fepsilon == 0.0 && c->P.npad <= VLANES &&
+        lean_plain_shape(c) && !lean_courier(c, false)) {
+        if (lean_waves(c) == 4)
+            return lean_demc_wide_kernel<MT, 4>;
+        if (lean_waves(c) == 2)
+            return lean_demc_wide_kernel<MT, 2>;
+    }
+    return nullptr;
+}
+
+}  // namespace
+
+chain_kernel_fn lean_demc_mc_instance(const mc3hip_ctx *c, bool p2p)
+{
+    switch (c->mt) {
+    case MT_POLY2: return lean_demc_mc_instance_t<MT_POLY2>(c, p2p);
+    case MT_POLY3: return lean_demc_mc_instance_t<MT_POLY3>(c, p2p);
+    default: return lean_demc_mc_instance_t<MT_POLY4>(c, p2p);
+    }
+}
+
+}  // namespace host
+}  // namespace mc3hip

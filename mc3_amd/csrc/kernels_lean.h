@@ -420,14 +420,18 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
 // lean_demc_kernel's; without it the chain wave stores them itself)
 // (zlag > 0, the declared multi-GPU cadence: the history an iteration draws from ends zlag
 // refreshes earlier -- mc3hip_problem.zlag, oracle_lockstep.c ls_run)
-template <int MT, bool FX, bool THIN, bool MULTI, bool P2P, bool COURIER>
+template <int MT, bool FX, bool THIN, bool MULTI, bool P2P, bool COURIER, bool EPS = false>
 __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int nref)
 {
     static_assert(!COURIER || P2P, "the courier carries rows to other ranks' replicas");
     constexpr int NC = Model<MT>::NC;         // coefficients the model tag fixes
     const int nf = FX ? P.nfree : NC;
     constexpr int ZS = ZROW;
-    constexpr int NB = 21;                     // refreshes per batch of draws (3 lanes each)
+    // (EPS, fepsilon != 0, chain.py:185,217: two more Philox slots per refresh for the support
+    // distribution's deviates of up to four free parameters -- five lanes per refresh)
+    static_assert(!EPS || (!THIN && !MULTI && !P2P), "EPS: one tile, thinning 1, one GPU");
+    constexpr int LPR = EPS ? 5 : 3;           // lanes of the batch per refresh
+    constexpr int NB = 64 / LPR;               // refreshes per batch of draws
     const int lane = COURIER ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     const int lc = blockIdx.x;
     const int c = P.chain0 + lc;
@@ -498,7 +502,10 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
     const int th = THIN ? P.thinning : 1;
     const long long zlag = P.zlag;
     long long bbase = R0 * th;                 // (the batch counts iterations)
-    const int bs = lane % 3, bi = (lane / 3 < NB) ? lane / 3 : NB - 1;
+    const int bs = lane % LPR, bi = (lane / LPR < NB) ? lane / LPR : NB - 1;
+    double bcs = 0.0, bsn = 0.0;               // EPS, slots 3 and 4: rad cos, rad sin
+    const double pstep_k = (EPS && mine) ? P.fstep[lane] : 0.0;
+    (void)bcs; (void)bsn; (void)pstep_k;
     auto fill = [&](long long base) {
         const long long Rl = base + bi;
         const Draw2 d = draw2(P.seed, (uint64_t)Rl, (uint32_t)c, (uint32_t)bs);
@@ -522,6 +529,13 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
         }
         // (every lane: the lanes of slot 2 keep theirs)
         accept_window(u01(d.q1), blo, bhi);
+        if constexpr (EPS) {                   // (every lane: the lanes of slots 3, 4 keep theirs)
+            const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(d.q0)));
+            double sn, cs;
+            mc3_det_sincos2pi(u01(d.q1), &sn, &cs);
+            bcs = rad * cs;
+            bsn = rad * sn;
+        }
         bbase = base;
     };
     auto lane64 = [&](unsigned long long v, int l) {
@@ -533,11 +547,12 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
     struct Step {
         bool sj;
         double gs, u, lo, hi;
+        double normal;                         // EPS: this lane's deviate times its step
         const double *addr[3];
         double val[3];
     };
     auto prepare = [&](long long R, Step &S, bool async) {   // (R inside the current batch)
-        const int idx = 3 * (int)(R - bbase);
+        const int idx = LPR * (int)(R - bbase);
         S.addr[0] = P.Z + (lane64(A, idx) + (unsigned)kk);
         S.addr[1] = P.Z + (lane64(B, idx) + (unsigned)kk);
         S.addr[2] = P.Z + (lane64(A, idx + 1) + (unsigned)kk);
@@ -555,6 +570,13 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
         S.u = mc3_from_bits(lane64(B, idx + 2));
         S.lo = read_lane(blo, idx + 2);
         S.hi = read_lane(bhi, idx + 2);
+        S.normal = 0.0;
+        if constexpr (EPS) {
+            // lane k's deviate sits in lane idx + 3 + (k >> 1): cosine for even k, sine for odd
+            const int src = mine ? idx + 3 + (lane >> 1) : idx;
+            const double gc = lane_gather(bcs, src), gn = lane_gather(bsn, src);
+            S.normal = mine ? ((lane & 1) ? gn : gc) * pstep_k : 0.0;
+        }
     };
     fill(R0 * th);
     Step S;
@@ -636,7 +658,7 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
                 jump_k = ((gs * (zp1 - zp2)) * dz) / dd;
             }
         } else {                                                     // chain.py:216-217
-            jump_k = gamma * (z1 - z2) + feps * 0.0;
+            jump_k = gamma * (z1 - z2) + feps * (EPS ? C.normal : 0.0);
         }
         // proposal and boundaries, chain.py:235-243
         const double npk = xk + jump_k;
@@ -738,11 +760,11 @@ out:
 }
 
 template <int MT, bool FX = false, bool THIN = false, bool MULTI = false, bool P2P = false,
-          bool COURIER = false>
+          bool COURIER = false, bool EPS = false>
 __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_snooker_kernel(const DevProblem P,
         const int nref)
 {
-    lean_snooker_body<MT, FX, THIN, MULTI, P2P, COURIER>(P, nref);
+    lean_snooker_body<MT, FX, THIN, MULTI, P2P, COURIER, EPS>(P, nref);
 }
 
 // ---------------------------------------------------------------------------------

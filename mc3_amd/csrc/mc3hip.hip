@@ -1178,9 +1178,10 @@ int mc3hip_jit_request(const mc3hip_ctx *c, char *buf, int32_t capacity)
                          "lean_demc_body<%d, false, %s, false, false, false, %s>", tag, fx,
                          P.fepsilon != 0.0 ? "true" : "false");
         break;
-    case MC3HIP_SNOOKER:                         // <MT, FX, THIN, MULTI, P2P, COURIER>
-        n = snprintf(buf, (size_t)capacity, "lean_snooker_body<%d, %s, %s, false, false, false>",
-                     tag, fx, thin);
+    case MC3HIP_SNOOKER:                         // <MT, FX, THIN, MULTI, P2P, COURIER, EPS>
+        n = snprintf(buf, (size_t)capacity,
+                     "lean_snooker_body<%d, %s, %s, false, false, false, %s>", tag, fx, thin,
+                     P.fepsilon != 0.0 ? "true" : "false");
         break;
     default:
         n = snprintf(buf, (size_t)capacity, "lean_mrw_body<%d, %s, %s, false, false, false>", tag,

@@ -259,3 +259,108 @@ def test_random_wavelet_problem_either_model_kind(seed):
         np.testing.assert_array_equal(tc, orc.trace_chisq, err_msg=label)
     compare_final(gpu, orc, label)
     gpu.close()
+
+
+# ---- round 4: the declared cadence, the EPS loop, FX x thinning, the run-time specialisations --
+def round4_problem(seed):
+    """A problem from the shapes round 4 put on hand-laid-out loops: zlag >= 1 (any sampler),
+    fixed / shared coefficients and priors with thinning > 1 (demc), the support distribution
+    (demc, strict lockstep), polynomials of 5..8 coefficients and design matrices of 1..10
+    columns (compiled for the model when the context is created), ndata <= 1024."""
+    rs = np.random.RandomState(seed)
+    kind = str(rs.choice(['poly', 'polybig', 'linear', 'linear']))
+    if kind == 'poly':
+        nmodel, model = int(rs.randint(2, 5)), 'poly'
+    elif kind == 'polybig':
+        nmodel, model = int(rs.randint(5, 9)), 'poly'
+    else:
+        nmodel, model = int(rs.randint(1, 11)), 'linear'
+    sampler = str(rs.choice(['demc', 'demc', 'snooker', 'mrw']))
+    if sampler == 'mrw' and nmodel > 4:
+        sampler = 'demc'                       # (the random-walk loop draws four deviates)
+    ndata = int(rs.choice([1, 3, 64, 100, 777, 1000, 1024]))
+    nchains = int(rs.randint(3, 48))
+    fx = rs.rand() < 0.5
+    thinning = int(rs.choice([1, 1, 2, 3, 5]))
+    zlag = int(rs.choice([0, 1, 2, 3, 5]))
+    feps = 0.0
+    if sampler == 'demc' and thinning == 1 and zlag == 0 and rs.rand() < 0.7:
+        feps = float(rs.choice([0.01, 0.1]))
+    if sampler != 'demc' and fx and thinning > 1:
+        thinning = 1                           # (FX x THIN exists for demc only)
+    if sampler == 'snooker' and thinning == 1 and nmodel <= 4 and rs.rand() < 0.5:
+        feps = float(rs.choice([0.01, 0.1]))   # (the snooker loop's EPS flavour: <= 4 deviates)
+    x = np.sort(rs.uniform(-1, 1, ndata))
+    if model == 'poly':
+        indep = x
+        basis = np.array([x**k for k in range(nmodel)])
+    else:
+        indep = rs.normal(0, 1, (nmodel, ndata))
+        basis = indep
+    p_true = rs.normal(0, 1, nmodel)
+    data = p_true @ basis + rs.normal(0, 1, ndata)
+    uncert = rs.uniform(0.5, 2.0, ndata)
+    pstep = np.full(nmodel, 0.05)
+    prior, plow, pup = np.zeros(nmodel), np.zeros(nmodel), np.zeros(nmodel)
+    if fx:
+        for j in range(nmodel):
+            r = rs.rand()
+            if r < 0.25:
+                pstep[j] = 0.0
+            elif r < 0.45 and j > 0 and pstep[0] > 0:
+                pstep[j] = -1.0
+                p_true[j] = p_true[0]
+        if not np.any(pstep > 0):
+            pstep[0] = 0.05
+        for j in range(nmodel):
+            if rs.rand() < 0.4:                # (also on fixed parameters: a constant term)
+                prior[j] = p_true[j] + rs.normal(0, 0.1)
+                plow[j], pup[j] = rs.uniform(0.05, 1.0, 2)
+    if sampler == 'mrw' and np.sum(pstep > 0) > 4:
+        sampler = 'demc'
+    lo = p_true - rs.uniform(0.05, 3.0, nmodel)
+    hi = p_true + rs.uniform(0.05, 3.0, nmodel)
+    for j in range(nmodel):
+        if pstep[j] < 0:
+            lo[j], hi[j] = lo[0], hi[0]
+    prob = dict(data=data, uncert=uncert, indep=indep, params=p_true, pstep=pstep,
+                pmin=lo, pmax=hi, prior=prior, priorlow=plow, priorup=pup,
+                nchains=nchains, nsamples=nchains*thinning*int(rs.randint(20, 120)),
+                sampler=sampler, wlike=False, thinning=thinning,
+                fgamma=float(rs.uniform(0.5, 1.5)), fepsilon=feps,
+                hsize=int(rs.randint(1, 5)), model=model, nmodel=nmodel, zlag=zlag,
+                seed=int(rs.randint(0, 2**31)))
+    # does a hand-laid-out loop serve it?
+    plain = not fx or (np.all(pstep > 0) and not np.any((plow > 0) & (pup > 0)))
+    if sampler == 'demc':
+        lean = feps == 0.0 or (thinning == 1 and zlag == 0)
+    elif sampler == 'snooker':
+        lean = (feps == 0.0 and (thinning == 1 or plain)) or (feps != 0.0 and thinning == 1)
+    else:
+        lean = thinning == 1 or plain
+    jit = kind != 'poly'
+    return prob, lean, jit, f'{kind}{nmodel} {sampler} thin={thinning} zlag={zlag} eps={feps} ' \
+                            f'fx={fx} ndata={ndata} nchains={nchains} pstep={pstep}'
+
+
+@pytest.mark.parametrize('seed', range(100))
+def test_round4_kernels_random_problem(seed):
+    from mc3_amd import engine
+    prob, lean, jit, label = round4_problem(9000 + seed)
+    gpu = engine.DeviceChains(**prob)
+    plan = gpu.plan
+    label += f' plan={plan} served={gpu.jit_served!r}'
+    assert plan['persistent'] > 0 and plan['zlag'] == prob['zlag'], label
+    if lean:
+        assert plan['fast'] == 2 and plan['jit'] == int(jit), label
+    orc = H.make_oracle(prob, plan=plan)
+    Z0, lp0 = H.initial_population(orc, seed=seed)
+    orc.set_population(Z0, lp0)
+    gpu.set_population(Z0, lp0)
+    orc.run(nthreads=4)
+    nz = gpu.nzchain
+    gpu.run(nz//3)
+    gpu.run()
+    assert gpu.plan['fast'] == plan['fast'], 'the persistent launch gave up: ' + label
+    compare_final(gpu, orc, label)
+    gpu.close()

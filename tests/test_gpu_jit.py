@@ -60,6 +60,9 @@ CASES = {
     'lin6-snooker-priors': lambda: linear_problem(6, sampler='snooker', priors=True),
     'lin4-demc-eps-priors': lambda: linear_problem(4, sampler='demc', priors=True,
                                                    fepsilon=0.02),
+    'lin4-snooker-eps': lambda: linear_problem(4, sampler='snooker', fepsilon=0.02),
+    'lin3-snooker-eps-priors': lambda: linear_problem(3, sampler='snooker', priors=True,
+                                                      fepsilon=0.01),
 }
 
 
@@ -88,7 +91,7 @@ def test_the_request_names_the_loop_and_the_cache_keeps_it(eng, tmp_path, monkey
     monkeypatch.setenv('MC3HIP_JIT_CACHE', str(tmp_path))
     prob = linear_problem(10, sampler='snooker')
     with eng.DeviceChains(**prob) as gpu:
-        assert gpu.jit_served == 'lean_snooker_body<210, false, false, false, false, false>'
+        assert gpu.jit_served == 'lean_snooker_body<210, false, false, false, false, false, false>'
         assert gpu.plan['jit'] == 1
     made = sorted(os.listdir(str(tmp_path)))
     assert len(made) == 1 and made[0].endswith('.hsaco')

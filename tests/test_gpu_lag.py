@@ -250,3 +250,50 @@ def test_support_distribution_beyond_the_co_resident_waves(eng, monkeypatch):
     assert plan['persistent'] > 0 and plan['chains_per_workgroup'] > 1 and plan['fast'] == 0, plan
     assert_same(orc, gpu, trace=False)
     gpu.close()
+
+
+@pytest.mark.parametrize('case', ['plain', 'fx', 'resume', 'abort', 'tight', 'degree2', 'degree4',
+                                  'zlag'])
+def test_snooker_loop_with_the_support_distribution(eng, monkeypatch, case):
+    """fepsilon != 0 on the hand-laid-out snooker loop (mc3/chain.py:185,217): two more Philox
+    slots per refresh in the batch of draws -- five lanes per refresh, twelve refreshes per
+    batch -- the deviates gathered through the crossbar."""
+    nchains = 12
+    kw = dict(zlag=2) if case == 'zlag' else {}
+    if case == 'fx':
+        prob = H.lean_shape_problem(nchains, 90, ndata=300, sampler='snooker', fx=1,
+                                    fepsilon=0.02)
+    else:
+        prob = H.quad_problem(ndata=300, nchains=nchains, nsamples=nchains*90, sampler='snooker',
+                              fepsilon=0.01, **kw)
+    if case == 'degree2':
+        for k in ('params', 'pstep', 'pmin', 'pmax'):
+            prob[k] = prob[k][:2]
+    if case == 'degree4':
+        prob.update(params=np.append(prob['params'], 0.0), pstep=np.append(prob['pstep'], 0.001),
+                    pmin=np.append(prob['pmin'], -1.0), pmax=np.append(prob['pmax'], 1.0))
+    if case == 'tight':
+        prob.update(params=np.array([4.0, -2.5, 0.5]), pmin=np.array([3.5, -2.8, 0.45]),
+                    pmax=np.array([6.5, -2.2, 0.56]))
+    if case == 'abort':
+        monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '21')
+        orc, gpu = run_pair(eng, prob, trace=False)
+        assert gpu.plan['recoveries'] == 1
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
+        return
+    if case == 'resume':
+        gpu = eng.DeviceChains(**prob)
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nthreads=4)
+        for n in (1, 2, 11, 12, 13, 51):           # (a batch holds twelve refreshes)
+            gpu.run(n)
+    else:
+        orc, gpu = run_pair(eng, prob, trace=False)
+    plan = gpu.plan
+    assert plan['persistent'] > 0 and plan['recoveries'] == 0 and plan['fast'] == 2, plan
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
