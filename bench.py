@@ -435,6 +435,7 @@ def run_rank(args):
         ctl.barrier()
 
     recycles = [0]
+    done = [0 if args.dry_run else gpu.refresh_done]
     gpu_ms_acc = [0.0]
     run_sizes = []                 # refreshes of every timed mc3hip_run call
     zlag = int(ctl_opts.get('zlag', 0))
@@ -461,12 +462,16 @@ def run_rank(args):
             return
         left = n
         while left:
-            room = g.nzchain - g.refresh_done
+            # (the position is kept here: asking the library would settle the stream, and a
+            # launch that gave up on some rank is the next barrier's business, not this loop's)
+            room = g.nzchain - done[0]
             if room < min(left, LAUNCH_REFRESHES):
                 recycle(g)
-                room = g.nzchain - g.refresh_done
+                done[0] = g.refresh_done
+                room = g.nzchain - done[0]
             m = min(left, room)
             g.run(m, sync=False)
+            done[0] += m
             if timed:
                 gpu_ms_acc[0] += g.last_run_ms()    # HIP events on the library's stream
                 run_sizes.append(m)

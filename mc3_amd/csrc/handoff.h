@@ -103,6 +103,28 @@ struct PeerTable {
     }
 };
 
+// The same for stores that are rare (the log_post columns, 64 refreshes at a time): the table
+// stays in memory and is read when it is needed, so that no scalar registers are tied up for
+// the whole loop (sixteen of them: with a second register-resident table the peer-to-peer
+// loops spill scalars into vector lanes -- 246 registers, two waves per SIMD with nothing to
+// spare, which several ranks sharing ONE device to its last wave slot have been seen not to
+// survive).  The wait for the pointers lands behind stores that nobody polls.
+template <class T>
+struct PeerTableLazy {
+    T *const *table;
+    int n;
+    __device__ __forceinline__ void load(T *const *tab, int npeers)
+    {
+        table = tab;
+        n = npeers;
+    }
+    __device__ __forceinline__ void store(size_t off, T v) const
+    {
+        for (int r = 0; r < n; ++r)
+            __hip_atomic_store(&table[r][off], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+};
+
 // ---- the courier wave (peer-to-peer mode) ---------------------------------------------------
 // A wave's loads and stores retire through ONE counter in issue order (MI355X_MICROARCH.md,
 // s_waitcnt): a chain wave that stored its row into seven remote replicas would have the data

@@ -82,7 +82,8 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
     }
     int handed = 0;                          // COURIER: rows left in the ring so far
     (void)handed;
-    PeerTable<double> peers_z, peers_lp;
+    PeerTable<double> peers_z;
+    PeerTableLazy<double> peers_lp;      // (the log_post columns: rare, handoff.h)
     if constexpr (P2P) {
         if constexpr (!COURIER)
             peers_z.load(P.peerZ, P.npeers);
@@ -455,7 +456,8 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
     }
     int handed = 0;
     (void)handed;
-    PeerTable<double> peers_z, peers_lp;
+    PeerTable<double> peers_z;
+    PeerTableLazy<double> peers_lp;      // (the log_post columns: rare, handoff.h)
     if constexpr (P2P) {
         if constexpr (!COURIER)
             peers_z.load(P.peerZ, P.npeers);
@@ -812,7 +814,8 @@ __device__ __forceinline__ void lean_mrw_body(const DevProblem &P, const int nre
     }
     int handed = 0;
     (void)handed;
-    PeerTable<double> peers_z, peers_lp;
+    PeerTable<double> peers_z;
+    PeerTableLazy<double> peers_lp;      // (the log_post columns: rare, handoff.h)
     if constexpr (P2P) {
         if constexpr (!COURIER)
             peers_z.load(P.peerZ, P.npeers);
@@ -1049,7 +1052,8 @@ __device__ __forceinline__ void lean_demc_lag_body(const DevProblem &P, const in
     }
     int handed = 0;
     (void)handed;
-    PeerTable<double> peers_z, peers_lp;
+    PeerTable<double> peers_z;
+    PeerTableLazy<double> peers_lp;      // (the log_post columns: rare, handoff.h)
     if constexpr (P2P) {
         if constexpr (!COURIER)
             peers_z.load(P.peerZ, P.npeers);
