@@ -190,7 +190,7 @@ inline int jit_model_tag(const mc3hip_ctx *c)
     const bool plain = P.nfree == P.nparams && P.ngprior == 0 && P.nshare == 0;
     switch (P.sampler) {
     case MC3HIP_DEMC:          // (the support distribution: the strict headline loop only)
-        return (P.fepsilon == 0.0 || (P.thinning == 1 && P.zlag == 0)) ? tag : 0;
+        return (P.fepsilon == 0.0 || (P.thinning == 1 && P.zlag == 0 && P.nfree <= 4)) ? tag : 0;
     case MC3HIP_SNOOKER:
         return ((P.fepsilon == 0.0 && (P.thinning == 1 || plain)) ||
                 (P.fepsilon != 0.0 && P.thinning == 1 && P.nfree <= 4)) ? tag : 0;
@@ -228,7 +228,7 @@ inline bool fast_eligible(const mc3hip_ctx *c)
     // ... and so has the snooker loop, for up to four free parameters (two Philox slots)
     const bool eps_ok = P.fepsilon == 0.0 || P.sampler == MC3HIP_MRW ||   // (chain.py:219-220)
                         (P.sampler == MC3HIP_DEMC && P.thinning == 1 && P.zlag == 0 && !p2p_flag &&
-                         !multi && P.zs == ZROW && !getenv("MC3HIP_NO_LEAN")) ||
+                         P.nfree <= 4 && !multi && P.zs == ZROW && !getenv("MC3HIP_NO_LEAN")) ||
                         (P.sampler == MC3HIP_SNOOKER && P.thinning == 1 && P.nfree <= 4 &&
                          !p2p_flag && !multi && P.zs == ZROW && !getenv("MC3HIP_NO_LEAN"));
     return c->wpc == 1 && !P.wlike && size_ok && c->mt >= 2 && c->mt <= 4 &&

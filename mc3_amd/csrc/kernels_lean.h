@@ -130,19 +130,34 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
     double lpbuf = 0.0;
     MC3_STAMP(1);
 
-    // EPS: the support distribution's draw of a refresh (chain.py:185), lane k's own
+    // EPS: the support distribution's draws (chain.py:185) for 32 refreshes at once -- lane
+    // 2 i + s: Philox slot 3 + s of refresh nbase + i, i.e. the deviates of parameters 2 s and
+    // 2 s + 1 (rad cos, rad sin) -- ~250 vector instructions per batch instead of per refresh
+    // (drawn every refresh they did not fit the shadow of the partner rows' round trip: 156 M
+    // chain-steps/s against 217 without epsilon); a refresh gathers its own through the crossbar
+    static_assert(!EPS || Model<MT>::NC <= 4 || FX, "EPS: up to four free parameters");
     const double pstep_k = (EPS && mine) ? P.fstep[lane] : 0.0;
-    auto normal_draw = [&](uint64_t it) {
-        double nk = 0.0;
-        if (mine) {
-            const Draw2 dn = draw2(P.seed, it, (uint32_t)c, (uint32_t)(3 + (lane >> 1)));
-            const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(dn.q0)));
-            double sn, cs;
-            mc3_det_sincos2pi(u01(dn.q1), &sn, &cs);
-            nk = (rad * ((lane & 1) ? sn : cs)) * pstep_k;
-        }
-        return nk;
+    double ncs = 0.0, nsn = 0.0;
+    long long nbase = R0;
+    auto fill_normals = [&](long long base) {
+        const Draw2 dn = draw2(P.seed, (uint64_t)(base + (lane >> 1)), (uint32_t)c,
+                               (uint32_t)(3 + (lane & 1)));
+        const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(dn.q0)));
+        double sn, cs;
+        mc3_det_sincos2pi(u01(dn.q1), &sn, &cs);
+        ncs = rad * cs;
+        nsn = rad * sn;
+        nbase = base;
     };
+    auto normal_draw = [&](uint64_t it) {
+        if (__builtin_expect((long long)it - nbase >= 32, 0))
+            fill_normals((long long)it);
+        const int idx = 2 * (int)((long long)it - nbase);
+        const int src = mine ? idx + (lane >> 1) : idx;
+        const double gc = lane_gather(ncs, src), gn = lane_gather(nsn, src);
+        return mine ? ((lane & 1) ? gn : gc) * pstep_k : 0.0;
+    };
+    (void)ncs; (void)nsn; (void)nbase;
     // draws of the first refresh
     Draw2 d = draw2(P.seed, (uint64_t)R0, (uint32_t)c, 0u);
     double u = u01(d.q1);
@@ -158,8 +173,10 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
     pin_scalar(d.q0);
     pin_scalar(d.q1);
     double normal_k = 0.0;
-    if constexpr (EPS)
+    if constexpr (EPS) {
+        fill_normals(R0);
         normal_k = normal_draw((uint64_t)R0);
+    }
     (void)normal_k; (void)pstep_k;
     // BATCH: lane i holds the draws of refresh bbase + i
     double bu = 0.0, blo = 0.0, bhi = 0.0;

@@ -332,8 +332,8 @@ def round4_problem(seed):
                 seed=int(rs.randint(0, 2**31)))
     # does a hand-laid-out loop serve it?
     plain = not fx or (np.all(pstep > 0) and not np.any((plow > 0) & (pup > 0)))
-    if sampler == 'demc':
-        lean = feps == 0.0 or (thinning == 1 and zlag == 0)
+    if sampler == 'demc':                      # (the EPS flavour draws four deviates)
+        lean = feps == 0.0 or (thinning == 1 and zlag == 0 and np.sum(pstep > 0) <= 4)
     elif sampler == 'snooker':
         lean = (feps == 0.0 and (thinning == 1 or plain)) or (feps != 0.0 and thinning == 1)
     else:

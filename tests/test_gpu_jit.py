@@ -48,7 +48,7 @@ CASES = {
     'poly6-snooker': lambda: poly_problem(6, sampler='snooker'),
     'poly5-demc-thin': lambda: poly_problem(5, sampler='demc', thinning=3),
     'poly7-demc-lag': lambda: poly_problem(7, sampler='demc', zlag=2),
-    'poly5-demc-eps': lambda: poly_problem(5, sampler='demc', fepsilon=0.01),
+    'lin3-demc-eps': lambda: linear_problem(3, sampler='demc', fepsilon=0.01),
     'poly6-snooker-thin': lambda: poly_problem(6, sampler='snooker', thinning=2),
     'lin2-demc': lambda: linear_problem(2, sampler='demc'),
     'lin5-demc': lambda: linear_problem(5, sampler='demc'),
