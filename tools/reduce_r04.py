@@ -39,7 +39,7 @@ def counters(path, pick):
 
 
 for rel in ('c2_bench.json', 'c2_bench_2ranks_on_1gpu.json', 'c3_bench_8ranks_on_1gpu.json',
-            'c5_bench_4ranks_on_1gpu.json'):
+            'c3_bench_8ranks_on_1gpu_strict.json', 'c5_bench_4ranks_on_1gpu.json'):
     if have(rel):
         line = last_json_line(os.path.join(R, rel))
         if line:
