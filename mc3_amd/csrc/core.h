@@ -418,6 +418,46 @@ __device__ __forceinline__ void wave_sum3(double &a, double &b, double &c)
     a = add_ror<1>(a); b = add_ror<1>(b); c = add_ror<1>(c);
 }
 
+// The same sums for T = 2..4 chains at once, transposed: the stride-32 and stride-16 levels pair
+// the lanes of TWO (FOUR) chains per instruction and leave chain q's partial sums in its own
+// rows of 16 lanes, where the last four levels run for all chains together -- the pairing of
+// wave_sum, level for level, so every total is bit for bit wave_sum's.  Row r of the result
+// holds the total of chain r (T = 3: rows 2 and 3 both chain 2; T = 2: rows 0-1 chain 0,
+// rows 2-3 chain 1).
+__device__ __forceinline__ double pair_sum32(double x, double y)
+{
+    // lanes 0..31: x[l] + x[l + 32]; lanes 32..63: y[l - 32] + y[l]
+    const auto a = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y),
+                                                    false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y),
+                                                    false, false);
+    return make_double(a[0], b[0]) + make_double(a[1], b[1]);
+}
+__device__ __forceinline__ double pair_sum16(double x, double y)
+{
+    // rows 0, 2: x[l] + x[l + 16]; rows 1, 3: y[l - 16] + y[l]
+    const auto a = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y),
+                                                    false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y),
+                                                    false, false);
+    return make_double(a[0], b[0]) + make_double(a[1], b[1]);
+}
+template <int T>
+__device__ __forceinline__ double rows_sum(const double (&a)[T])
+{
+    static_assert(T >= 2 && T <= 4, "2..4 chains");
+    double t;
+    if constexpr (T == 2)
+        t = add_xor16(pair_sum32(a[0], a[1]));
+    else
+        t = pair_sum16(pair_sum32(a[0], a[2]), pair_sum32(a[1], a[T - 1]));
+    t = add_ror<8>(t);
+    t = add_ror<4>(t);
+    t = add_ror<2>(t);
+    t = add_ror<1>(t);
+    return t;
+}
+
 __device__ __forceinline__ double read_lane(double v, int k)
 {
     return make_double(__builtin_amdgcn_readlane(__double2loint(v), k),

@@ -13,6 +13,30 @@ __device__ __forceinline__ double block_gauss_model(const DevProblem &P, const M
                                                     const DataTile<WPC, MT> &tile,
                                                     const DataTile<WPC, MT> *tile1 = nullptr);
 
+// One lane's share of the data sum of a one-wave chain: the sixteen residuals of its virtual
+// lanes and the in-lane levels of lane_tree<1> (the several-chains-at-once loops finish the
+// tree across lanes for all their chains together, rows_sum).
+template <int MT>
+__device__ __forceinline__ double gauss_lane_share(const Model<MT> &model,
+                                                   const DataTile<1, MT> &tile)
+{
+    static_assert(!mt_is_link(MT) && MT != MT_LINEAR, "polynomial families");
+    double acc[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const double m = model.at_x(tile.x[v]);
+        const double r = (m - tile.d[v]) * tile.w[v];
+        acc[v] = mc3_fma(r, r, 0.0);
+    }
+#pragma unroll
+    for (int s = 8; s >= 1; s >>= 1) {
+#pragma unroll
+        for (int v = 0; v < s; ++v)
+            acc[v] = acc[v] + acc[v + s];
+    }
+    return acc[0];
+}
+
 template <int WPC, int MT, bool MULTI>
 __device__ double block_gauss(const DevProblem &P, const double *s_nextp, double *s_part,
                               int *s_flag, const DataTile<WPC, MT> &tile)
