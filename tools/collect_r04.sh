@@ -54,7 +54,7 @@ if has ranks; then
         > $out/c5_bench_4ranks_on_1gpu.json 2> $out/c5_bench_4ranks_on_1gpu.err
 fi
 # large ensembles: instruction mix and stall counters of the several-chains-per-wave loops
-for cfg in c3x4 c3x2mrw c3one; do
+for cfg in ${BIGCFGS:-c3x4 c3x2mrw c3one}; do
     has big || continue
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$cfg -o $cfg -- \
         python3 tools/bench_configs.py $cfg > $out/kt_$cfg.log 2>&1
