@@ -344,6 +344,18 @@ inline bool lean_demc_mc_eligible(const mc3hip_ctx *c)
            c->P.nparams == c->mt && c->P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
 }
 
+// ... and, for the plain shapes of those (every coefficient free, no priors, one tile), with the
+// chains of a wave side by side in its rows of 16 lanes: kernels_rows.h lean_*_rows_kernel
+// (MC3HIP_NO_ROWS: the turn-after-turn loops above)
+inline bool lean_rows_eligible(const mc3hip_ctx *c)
+{
+    const bool any = c->P.sampler == MC3HIP_DEMC      ? lean_demc_mc_eligible(c)
+                     : c->P.sampler == MC3HIP_SNOOKER ? lean_snooker_mc_eligible(c)
+                                                      : lean_mrw_mc_eligible(c);
+    return any && lean_plain_shape(c) && c->P.npad <= VLANES && c->mt >= 2 && c->mt <= 4 &&
+           (c->P.fepsilon == 0.0 || c->P.sampler == MC3HIP_MRW) && !getenv("MC3HIP_NO_ROWS");
+}
+
 // waves that share the data sum of a chain in the hand-laid-out DEMC loop (kernels_lean.h
 // lean_demc_wide_kernel): 1, 2 or 4.  Several only for the plain headline shape -- every
 // coefficient free, one tile, one GPU -- and only on request (MC3HIP_LEAN_WAVES=2|4): measured
@@ -397,6 +409,7 @@ chain_kernel_fn lean_other_instance(const mc3hip_ctx *c);   // k_lean2.hip
 chain_kernel_fn lean_lag_instance(const mc3hip_ctx *c, bool p2p);   // k_lean3.hip
 chain_kernel_fn lean_other_p2p_instance(const mc3hip_ctx *c);       // k_lean4.hip
 chain_kernel_fn lean_demc_mc_instance(const mc3hip_ctx *c, bool p2p);   // k_lean5.hip
+chain_kernel_fn lean_rows_instance(const mc3hip_ctx *c, bool p2p);      // k_lean6.hip
 
 // ---- k_tiled.hip: the tiled plan as three launches per iteration -------------------------
 void launch_propose(mc3hip_ctx *c, int roff, int j);

@@ -42,6 +42,9 @@ chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
     // (the loops of the declared multi-GPU cadence: k_lean3.hip)
     if (chain_kernel_fn f = lean_lag_instance(c, p2p))
         return f;
+    // (2..4 chains per wave side by side, plain shapes: k_lean6.hip)
+    if (chain_kernel_fn f = lean_rows_instance(c, p2p))
+        return f;
     // (the hand-laid-out snooker, random-walk and thinned DEMC loops: k_lean2.hip; their
     // peer-to-peer flavours with a courier wave: k_lean4.hip)
     if (chain_kernel_fn f = p2p ? lean_other_p2p_instance(c) : lean_other_instance(c))

@@ -19,9 +19,8 @@ chain_kernel_fn lean_demc_mc_instance_t(const mc3hip_ctx *c, bool p2p)
                 return lean_demc_mc_kernel<MT, (TT < 4 ? TT : 3), false, true>;     \
             if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)  \
                 return lean_demc_mc_kernel<MT, TT, true>;                           \
-            if (getenv("MC3HIP_NO_ROWS"))       /* (the chains one after another) */ \
-                return lean_demc_mc_kernel<MT, TT>;                                 \
-            return lean_demc_rows_kernel<MT, TT>;                                   \
+            /* (plain shapes: k_lean6.hip, unless MC3HIP_NO_ROWS) */                \
+            return lean_demc_mc_kernel<MT, TT>;                                     \
         }
         MC3_LEAN_MC(2)
         MC3_LEAN_MC(3)

@@ -1,0 +1,47 @@
+// k_lean6.hip -- instances of the hand-laid-out loops with the two to four chains of a wave
+// side by side in its rows of 16 lanes (kernels_rows.h): plain shapes -- every coefficient
+// free, no priors, one tile -- of ensembles with more chains than waves can be co-resident, one
+// GPU; a translation unit of its own so that the library builds in parallel.
+#include "ctx.h"
+#include "kernels_rows.h"
+
+namespace mc3hip {
+namespace host {
+namespace {
+
+template <int MT, int T>
+chain_kernel_fn lean_rows_instance_tt(const mc3hip_ctx *c)
+{
+    switch (c->P.sampler) {
+    case MC3HIP_DEMC: return lean_demc_rows_kernel<MT, T>;
+    case MC3HIP_SNOOKER: return lean_snooker_rows_kernel<MT, T>;
+    default: return lean_mrw_rows_kernel<MT, T>;
+    }
+}
+
+template <int MT>
+chain_kernel_fn lean_rows_instance_t(const mc3hip_ctx *c)
+{
+    switch (c->mc_chains) {
+    case 2: return lean_rows_instance_tt<MT, 2>(c);
+    case 3: return lean_rows_instance_tt<MT, 3>(c);
+    default: return lean_rows_instance_tt<MT, 4>(c);
+    }
+}
+
+}  // namespace
+
+// the kernel of a context that one of these loops serves, or nullptr
+chain_kernel_fn lean_rows_instance(const mc3hip_ctx *c, bool p2p)
+{
+    if (p2p || !lean_rows_eligible(c))
+        return nullptr;
+    switch (c->mt) {
+    case MT_POLY2: return lean_rows_instance_t<MT_POLY2>(c);
+    case MT_POLY3: return lean_rows_instance_t<MT_POLY3>(c);
+    default: return lean_rows_instance_t<MT_POLY4>(c);
+    }
+}
+
+}  // namespace host
+}  // namespace mc3hip

@@ -1951,215 +1951,6 @@ __global__ __launch_bounds__(64) void lean_demc_mc_kernel(const DevProblem P, co
 }
 
 // ---------------------------------------------------------------------------------
-// lean_demc_mc_kernel for the plain shape (every coefficient free, no priors, one tile), with
-// the T chains of a wave side by side in its four rows of 16 lanes instead of one after another:
-// lane 16 r + k holds coefficient k of the chain of row r (T = 4: chain r; T = 3: rows 2 and 3
-// both chain 2; T = 2: rows 0-1 chain 0, rows 2-3 chain 1; a duplicate computes and stores
-// nothing of its own).  Everything but the sixteen residuals per lane and chain then runs ONCE
-// per refresh for all the chains of the wave:
-//   * two loads bring the partner rows of all T chains (lane 16 r + k asks for coefficient k of
-//     the partners of row r's chain), one store publishes the T new rows;
-//   * proposal, boundaries, Metropolis test, best-so-far: one instruction stream, the chains in
-//     different rows;
-//   * the T data sums are reduced across lanes TOGETHER (rows_sum: the stride-32 and -16 levels
-//     pair two and four chains per instruction, the last four levels serve every row at once),
-//     with the pairing of wave_sum, so each total is bit for bit the one lean_demc_mc_kernel
-//     computes.
-// Measured on MI355X at 8192 chains (profiles/r04_c3x4_pmc.json before): lean_demc_mc_kernel
-// spends 201 vector instructions per chain-step of which 109 are FP64 arithmetic -- the rest
-// are T copies of the scalar work above and the register shuffling of T turns' control flow.
-// The hand-off protocol, the order of the draws and the arithmetic are unchanged.
-template <int MT, int T>
-__global__ __launch_bounds__(64) void lean_demc_rows_kernel(const DevProblem P, const int nref)
-{
-    static_assert(T >= 2 && T <= 4, "2..4 chains per wave");
-    static_assert(MT >= 2 && MT <= 4, "polynomials of 2..4 coefficients");
-    constexpr int ZS = ZROW;
-    constexpr int NB = 64 / T;                 // refreshes per batch of draws
-    const int lane = threadIdx.x;
-    const int row = lane >> 4, k = lane & 15;
-    const int slot = (T == 2) ? row >> 1 : (row < T ? row : T - 1);    // the chain of this row
-    const bool owner = (T == 2) ? (row & 1) == 0 : row < T;            // (not a duplicate row)
-    const int G = (int)gridDim.x, b = (int)blockIdx.x;
-    long long *ctl_rw = const_cast<long long *>(P.ctl);
-    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
-            &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
-        return;
-    DataTile<1, MT> tile;
-    tile.load(P);
-    const long long R0 = P.ctl[0];
-    const int n = P.nchains;
-    const size_t blockstride = (size_t)n * ZS;
-    const double *pbase = (R0 == 0) ? P.snap0 : P.Z + (size_t)(P.M0 + (R0 - 1) * n) * ZS;
-    double *zblock = P.Z + (size_t)(P.M0 + R0 * n) * ZS;
-    double *lp_row = P.log_post + (P.M0 + R0 * n);
-    int32_t *zc_row = P.zchain + (P.M0 + R0 * n);
-    // this row's chain (the last of the wave may not exist: its rows store nothing)
-    const bool exists = b + slot * G < P.nlocal;
-    const int l = exists ? b + slot * G : b;
-    const int c = P.chain0 + l;
-    const bool mine = k < MT;
-    const bool keeps = mine && owner && exists;              // lanes that store coefficients
-    const bool first = k == 0 && owner && exists;            // one lane per chain: the scalars
-    const int kk = mine ? k : 0;
-    double xk = mine ? pbase[(size_t)c * ZS + k] : 0.0;
-    double cur = P.chisq[l], best = P.best_chisq[l];
-    int nacc = 0;
-    const double pmin_k = mine ? P.fmin[k] : 0.0;
-    const double pmax_k = mine ? P.fmax[k] : 0.0;
-    const double gamma = P.gamma, feps = P.fepsilon;
-    const unsigned long long rowmask = 0xffffull << (16 * row);
-    const long long abort_at = (P.test_abort >= 0 && b == 0) ? (long long)P.test_abort : -1;
-    bool alive = true;
-    // the draws: lane r T + q holds those of refresh bbase + r, chain q of the wave
-    // (chain.py:221-232, :259), as lean_demc_mc_kernel's
-    const int bq = lane % T, br = (lane / T < NB) ? lane / T : NB - 1;
-    const int bl = (b + bq * G < P.nlocal) ? b + bq * G : b;
-    const int bc = P.chain0 + bl;
-    double bu, blo, bhi;
-    int bo1, bo2;
-    long long bbase;
-    auto fill = [&](long long base) {
-        const Draw2 dd = draw2(P.seed, (uint64_t)(base + br), (uint32_t)bc, 0u);
-        bu = u01(dd.q1);
-        accept_window(bu, blo, bhi);
-        int r1, r2;
-        demc_partners(dd.q0, n, bc, r1, r2);
-        bo1 = r1 * ZS;
-        bo2 = r2 * ZS;
-        bbase = base;
-    };
-    fill(R0);
-    const long long Rend = R0 + nref;
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    for (long long R = R0; R < Rend; ++R) {
-        if (__builtin_expect(R == abort_at, 0)) {                                         // test hook
-            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            break;                // (the host restores its checkpoint after an abort)
-        }
-        __builtin_amdgcn_s_sleep(1);
-        // the partner rows of every chain of the wave: one request each
-        const int from = 4 * ((int)(R - bbase) * T + slot);      // whose draws this row needs
-        const double *addr[2];
-        addr[0] = pbase + (__builtin_amdgcn_ds_bpermute(from, bo1) + kk);
-        addr[1] = pbase + (__builtin_amdgcn_ds_bpermute(from, bo2) + kk);
-        double val[2];
-        val[0] = load_published<false>(addr[0]);
-        val[1] = load_published<false>(addr[1]);
-        const double u = make_double(__builtin_amdgcn_ds_bpermute(from, __double2loint(bu)),
-                                     __builtin_amdgcn_ds_bpermute(from, __double2hiint(bu)));
-        const double lo = make_double(__builtin_amdgcn_ds_bpermute(from, __double2loint(blo)),
-                                      __builtin_amdgcn_ds_bpermute(from, __double2hiint(blo)));
-        const double hi = make_double(__builtin_amdgcn_ds_bpermute(from, __double2loint(bhi)),
-                                      __builtin_amdgcn_ds_bpermute(from, __double2hiint(bhi)));
-        __builtin_amdgcn_sched_barrier(0);
-        if (__builtin_expect(R - bbase == NB - 1, 0)) {
-            // ... and behind them, once per batch, the draws of the next NB refreshes
-            fill(R + 1);
-            asm volatile("; pin" : "+v"(bu), "+v"(blo), "+v"(bhi), "+v"(bo1), "+v"(bo2));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        // what is still the sentinel is asked for again (the rows of the refresh before are the
-        // last the other waves have published)
-        if (__builtin_expect(__any(mc3_bits(val[0]) == ROW_PENDING ||
-                                   mc3_bits(val[1]) == ROW_PENDING), 0)) {
-            alive = wait_rows<2, false>(addr, val, ctl_rw);
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            asm volatile("; rows of this refresh" : "+v"(val[0]), "+v"(val[1]));
-            if (__builtin_expect(!alive, 0))
-                break;
-        }
-        // proposal and boundaries, chain.py:232-243 (a chain with a coefficient out of bounds
-        // stays where it is: its data sum below is computed and ignored)
-        const double jump_k = gamma * (val[0] - val[1]) + feps * 0.0;
-        const double npk = xk + jump_k;
-        const bool outk = mine && (npk < pmin_k || npk > pmax_k);
-        const bool row_out = (__ballot(outk) & rowmask) != 0;
-        if (__builtin_expect(outk && owner && exists, 0))
-            atomicAdd(&P.outbounds[k], 1ull);                            // chain.py:242-243
-        // the data sums, chain.py:249: sixteen residuals per lane and chain, then all the
-        // chains' trees at once
-        double share[T];
-#pragma unroll
-        for (int q = 0; q < T; ++q) {
-            Model<MT> model;
-            model.coef = nullptr;
-            model.indep = P.indep;
-            model.nmodel = P.nmodel;
-            model.ndata = P.npad;
-            // (v_readlane + moves; through the LDS crossbar instead -- ds_bpermute, 28 vector
-            // instructions fewer per refresh -- measured 2 % SLOWER: the residuals wait for it)
-#pragma unroll
-            for (int j = 0; j < MT; ++j)
-                model.cf[j] = read_lane(npk, 16 * (T == 2 ? 2 * q : q) + j);
-            share[q] = gauss_lane_share<MT>(model, tile);
-        }
-        double nextchisq = rows_sum<T>(share);
-        // (the "+inf model => chisq = inf" trap, resolved lazily as in block_gauss_model: only a
-        // non-finite total has its model values looked at)
-        const bool bad = (mc3_bits(nextchisq) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
-        const unsigned long long badm = __ballot(bad);
-        if (__builtin_expect(badm != 0, 0)) {
-#pragma unroll
-            for (int q = 0; q < T; ++q) {
-                if (!((badm >> (16 * (T == 2 ? 2 * q : q))) & 1))
-                    continue;
-                Model<MT> model;
-                model.coef = nullptr;
-                model.indep = P.indep;
-                model.nmodel = P.nmodel;
-                model.ndata = P.npad;
-#pragma unroll
-                for (int j = 0; j < MT; ++j)
-                    model.cf[j] = read_lane(npk, 16 * (T == 2 ? 2 * q : q) + j);
-                int saw = 0;
-                for (int i = lane; i < P.ndata; i += 64)
-                    saw |= is_pos_inf(model.at(i));
-                if (__any(saw))
-                    nextchisq = (slot == q) ? mc3_from_bits(0x7ff0000000000000ull) : nextchisq;
-            }
-        }
-        // Metropolis, chain.py:257-274, every chain in its own rows
-        const bool acc = row_out ? false
-                                 : metropolis_accept(0.5 * (cur - nextchisq), u, lo, hi);
-        xk = acc ? npk : xk;
-        const bool better = acc && nextchisq < best;
-        if (__builtin_expect(__any(better), 0)) {
-            if (better) {
-                best = nextchisq;
-                if (keeps)
-                    P.bestx[(size_t)l * MT + k] = xk;
-                if (first)
-                    P.best_iter[l] = R;
-            }
-        }
-        cur = acc ? nextchisq : cur;
-        nacc += acc ? 1 : 0;
-        // Z append, chain.py:276-289: the T rows in one store
-        if (keeps)
-            __hip_atomic_store(zblock + (size_t)c * ZS + k, xk, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);                // publish (sc1)
-        if (first) {
-            lp_row[c] = -0.5 * cur;
-            zc_row[c] = c;
-        }
-        pbase = zblock;
-        zblock += blockstride;
-        lp_row += n;
-        zc_row += n;
-    }
-    if (keeps)
-        P.X[(size_t)l * MT + k] = xk;
-    if (first) {
-        P.chisq[l] = cur;
-        P.best_chisq[l] = best;
-        P.numaccept[l] = P.numaccept[l] + nacc;
-    }
-}
-
-// ---------------------------------------------------------------------------------
 // The same loop with the data sum shared by NW waves on different SIMDs of the CU: with 256
 // chains the chip has three of its four SIMDs idle, and a wave alone issues dependent FP64 at
 // a fraction of the pipe's rate (tools/probes/mfma_f64_probe.hip), so the ~1000 cycles of the

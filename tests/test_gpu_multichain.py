@@ -207,12 +207,24 @@ def test_switch_off(eng, monkeypatch):
     gpu.close()
 
 
+def layout_switch(monkeypatch, layout, case):
+    """'rows': the chains of a wave side by side (kernels_rows.h, the default for plain
+    shapes); 'turns': one after another (lean_*_mc_kernel, MC3HIP_NO_ROWS)."""
+    if layout == 'turns':
+        if case == 'priors':
+            pytest.skip('FX shapes take turns in either case')
+        monkeypatch.setenv('MC3HIP_NO_ROWS', '1')
+
+
+@pytest.mark.parametrize('layout', ['rows', 'turns'])
 @pytest.mark.parametrize('turns', [2, 3, 4])
 @pytest.mark.parametrize('case', ['resume', 'abort', 'tight', 'priors', 'ragged'])
-def test_lean_demc_loop_with_several_chains_per_wave(eng, monkeypatch, case, turns):
-    """lean_demc_mc_kernel<.., T>: launches of a few refreshes (each starts a batch of draws
-    anew and reloads the chains' states), a give-up, bounds that reject most proposals,
-    Gaussian priors (FX), an ensemble that leaves the last turn of some waves empty."""
+def test_lean_demc_loop_with_several_chains_per_wave(eng, monkeypatch, case, turns, layout):
+    """lean_demc_rows_kernel / lean_demc_mc_kernel<.., T>: launches of a few refreshes (each
+    starts a batch of draws anew and reloads the chains' states), a give-up, bounds that reject
+    most proposals, Gaussian priors (FX), an ensemble that leaves the last turn of some waves
+    empty."""
+    layout_switch(monkeypatch, layout, case)
     nchains = {2: 10, 3: 14, 4: 23}[turns] if case == 'ragged' else 5*turns
     forced(monkeypatch, 5 if case != 'ragged' else -(-nchains//turns))
     prob = H.quad_problem(ndata=400, nchains=nchains, nsamples=nchains*70, sampler='demc')
@@ -248,15 +260,18 @@ def test_lean_demc_loop_with_several_chains_per_wave(eng, monkeypatch, case, tur
     gpu.close()
 
 
+@pytest.mark.parametrize('layout', ['rows', 'turns'])
 @pytest.mark.parametrize('turns', [2, 3, 4])
 @pytest.mark.parametrize('sampler', ['snooker', 'mrw'])
 @pytest.mark.parametrize('case', ['resume', 'abort', 'tight', 'priors', 'ragged', 'thin'])
 def test_lean_snooker_and_mrw_loops_with_several_chains_per_wave(eng, monkeypatch, case, sampler,
-                                                                 turns):
-    """lean_snooker_mc_kernel / lean_mrw_mc_kernel<.., T>: launches of a few refreshes, a
+                                                                 turns, layout):
+    """lean_*_rows_kernel / lean_snooker_mc_kernel / lean_mrw_mc_kernel<.., T>: launches of a few
+    refreshes, a
     give-up, bounds that reject most proposals, Gaussian priors (FX), an ensemble that leaves
     the last turn of some waves empty, a history of one row per chain (snooker draws from the
     newest rows: the wait for a row that is still the sentinel)."""
+    layout_switch(monkeypatch, layout, case)
     nchains = {2: 10, 3: 14, 4: 23}[turns] if case == 'ragged' else 5*turns
     forced(monkeypatch, 5 if case != 'ragged' else -(-nchains//turns))
     prob = H.quad_problem(ndata=400, nchains=nchains, nsamples=nchains*70, sampler=sampler)

@@ -1,9 +1,11 @@
 #!/bin/bash
 # Round 4's kernels, long runs against the oracle (identical: True / False per line).
 cd $GRAFT_REPO_ROOT
-out=gpurun_out/r04_soak.txt
+part=${1:-all}
+out=gpurun_out/r04_soak_$part.txt
 : > $out
 run() { timeout 600 python tests/soak.py "$@" 2>&1 | grep -v Yippee | tail -1 | cut -c1-600 >> $out; }
+if [ $part != rows ]; then
 run 40000 demc 256 zlag=4
 run 40000 demc 256 zlag=1
 run 20000 demc 2048 zlag=4
@@ -16,4 +18,15 @@ run 30000 snooker 256 poly=5
 run 20000 demc 256 lin=10
 run 20000 snooker 256 lin=10 fx=1
 run 20000 demc 256 lin=5 zlag=2 thinning=2
+fi
+
+# the rows layout (kernels_rows.h): large ensembles, the chains of a wave side by side
+run 2000 demc 8192
+run 3000 demc 4096
+run 3000 demc 6000
+run 2000 snooker 8192
+run 3000 snooker 4096
+run 3000 mrw 4096
+run 2000 mrw 8192
+
 cat $out
