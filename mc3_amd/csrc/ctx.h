@@ -198,6 +198,27 @@ inline int jit_model_tag(const mc3hip_ctx *c)
         return (P.nmodel <= 4 && (P.thinning == 1 || plain)) ? tag : 0;
     }
 }
+// waves of the specialised loop's workgroup: helper waves share the data sum (gauss.h
+// SumHelpers) where one wave's registers hardly hold the tile -- design matrices of five
+// columns and more (K + 2 values per point, 16 points per lane) on the strict DEMC and the
+// snooker loops.  MC3HIP_JIT_WAVES=1|2|4 overrides (an experiment; results do not change).
+inline int jit_waves(const mc3hip_ctx *c)
+{
+    const int tag = jit_model_tag(c);
+    const DevProblem &P = c->P;
+    if (tag < MT_LINK0 || P.sampler == MC3HIP_MRW ||
+        (P.sampler == MC3HIP_DEMC && (P.thinning > 1 || P.zlag > 0)))
+        return 1;
+    if (const char *e = getenv("MC3HIP_JIT_WAVES")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4)
+            return v;
+    }
+    const int K = tag - MT_LINK0;
+    // (measured, 256 chains x 1000 points with three priors: five columns 157 / 174 / 181 M
+    // chain-steps/s with 1 / 2 / 4 waves, ten columns 112 / 136 / 157)
+    return K >= 5 ? 4 : 1;
+}
 inline bool jit_serves(const mc3hip_ctx *c)
 {
     return c->jit_fn != nullptr && jit_model_tag(c) != 0;

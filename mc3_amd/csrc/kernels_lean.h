@@ -49,15 +49,18 @@ __global__ __launch_bounds__(64) void persist_fast_kernel(const DevProblem P, co
 // k's normal deviate of the NEXT refresh -- Philox slot 3 + k/2, a logarithm, a square root, a
 // sine or cosine, as run_chain's normal_draw -- is computed on the vector unit in the same
 // shadow of the partner rows' round trip as the scalar draws.
-template <int MT, bool P2P, bool FX, bool MULTI, bool BATCH, bool COURIER, bool EPS>
+// (NW = 2, 4: helper waves share the data sum -- gauss.h SumHelpers; run-time specialised
+// design matrices whose tile one wave's registers do not hold)
+template <int MT, bool P2P, bool FX, bool MULTI, bool BATCH, bool COURIER, bool EPS, int NW = 1>
 __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nref)
 {
     static_assert(!EPS || (!P2P && !MULTI && !BATCH && !COURIER), "EPS: the one-GPU headline loop");
+    static_assert(NW == 1 || (!P2P && !MULTI && !COURIER), "helper waves: one GPU, one tile");
     constexpr int NC = Model<MT>::NC;         // coefficients the model tag fixes
     const int nf = FX ? P.nfree : NC;        // FX: some coefficients are fixed (nfree < MT)
     constexpr int ZS = ZROW;                 // doubles per Z row: one 128-byte line (NF <= 16)
     constexpr int LM = P2P ? 1 : 0;
-    const int lane = COURIER ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    const int lane = (COURIER || NW > 1) ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     const int lc = blockIdx.x;
     const int c = P.chain0 + lc;
     const bool mine = lane < nf;
@@ -68,6 +71,11 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
     __shared__ double s_ring[(COURIER || P2P) ? COURIER_RING * ZROW : 1];
     __shared__ int s_cour[4];                // 1: rows sent (every eighth), 2: done, 3: go
     (void)s_ring; (void)s_cour;
+    __shared__ double s_hpart[NW > 1 ? 64 * NW : 1], s_hcf[16];
+    __shared__ int s_hcmd[2];
+    (void)s_hpart; (void)s_hcf; (void)s_hcmd;
+    SumHelpers<MT, (NW > 1 ? NW : 2)> helpers;
+    (void)helpers;
     if constexpr (COURIER) {
         if (!courier_begin(s_ring, s_cour, ctl_rw))
             return;
@@ -75,10 +83,23 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
             courier_run<P2P>(P, s_ring, s_cour, lane, nf, c);
             return;
         }
+    } else if constexpr (NW > 1) {
+        if (!helpers.enter(s_hpart, s_hcf, s_hcmd,
+                           __hip_atomic_load(&ctl_rw[CTL_ABORT], __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT) != 0))
+            return;
     } else {
         if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
                 &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
             return;
+    }
+    DataTile<NW, MT> tile;
+    tile.load(P);
+    if constexpr (NW > 1) {
+        if (threadIdx.x >= 64) {
+            helpers.serve(P, tile);
+            return;
+        }
     }
     int handed = 0;                          // COURIER: rows left in the ring so far
     (void)handed;
@@ -94,8 +115,6 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
     late.begin(P, P.ctl[0], c, lane);
     (void)late;
     MC3_STAMP(0);
-    DataTile<1, MT> tile;
-    tile.load(P);
     DataTile<1, MT> tile1;                   // MULTI: points 1024..2047 stay in registers too
     if constexpr (MULTI)
         tile1.load(P, VLANES);
@@ -120,11 +139,18 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
     int kf[NC];
     double fx[NC];
     PriorLanes<NC> priors;
+    int hkf = 0;                               // (helper waves, FX: what coefficient `lane` is)
+    double hfx = 0.0;
     if constexpr (FX) {
         coefficient_map<NC>(P, kf, fx);
         priors.init(P, kf, fx, lane);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            hkf = (lane == j) ? kf[j] : hkf;
+            hfx = (lane == j) ? fx[j] : hfx;
+        }
     }
-    (void)kf; (void)fx; (void)priors;
+    (void)kf; (void)fx; (void)priors; (void)hkf; (void)hfx;
     // log_post / zchain of the last (up to) 64 refreshes wait in lane (R - R0) mod 64 and
     // are written 64 at a time: nobody reads them inside the launch
     double lpbuf = 0.0;
@@ -301,16 +327,30 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
         const double npk = xk + jump_k;
         const bool outk = mine && (npk < pmin_k || npk > pmax_k);
         if (__builtin_expect(!__any(outk), 1)) {
+            // (helper waves: woken first -- lane j hands them coefficient j, free parameter j or
+            // what FX maps there -- so that they work while this wave makes its own copy)
+            if constexpr (NW > 1)
+                helpers.order(FX ? (hkf < 0 ? hfx : lane_gather(npk, hkf < 0 ? 0 : hkf)) : npk,
+                              lane);
             Model<MT> model;
             if constexpr (!FX) {
                 model.init_from_lanes(P, npk);                 // every coefficient is free
             } else {
                 model.init_from_lanes(P, npk, kf, fx);         // FX: some are fixed
             }
-            double nextchisq =
-                block_gauss_model<1, MT, MULTI, MULTI>(P, model, nullptr, nullptr, tile,
-                                                       &tile1);          // chain.py:249
-            if constexpr (FX)
+            double nextchisq;                                          // chain.py:249
+            if constexpr (NW == 1) {
+                nextchisq = block_gauss_model<1, MT, MULTI, MULTI>(P, model, nullptr, nullptr,
+                                                                   tile, &tile1);
+            } else {
+                double prior = 0.0;
+                if constexpr (FX)
+                    prior = priors.term(npk, lane);
+                nextchisq = helpers.collect(P, model, tile, lane);
+                if constexpr (FX)
+                    nextchisq = nextchisq + prior;
+            }
+            if constexpr (FX && NW == 1)
                 nextchisq = nextchisq + priors.term(npk, lane);
             MC3_TICK(tk2);
             const bool acc = metropolis_accept(0.5 * (cur - nextchisq), u_now, lo_now,
@@ -384,6 +424,8 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
     }
     if constexpr (COURIER)                       // (the courier drains the ring and leaves)
         courier_end(s_cour);
+    if constexpr (NW > 1)
+        helpers.release(lane);
     if constexpr (P2P && !COURIER) {
         if (P.remote_delay != 0)
             late.drain(P, s_ring, peers_z, lane, mine, true);
@@ -438,10 +480,12 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
 // lean_demc_kernel's; without it the chain wave stores them itself)
 // (zlag > 0, the declared multi-GPU cadence: the history an iteration draws from ends zlag
 // refreshes earlier -- mc3hip_problem.zlag, oracle_lockstep.c ls_run)
-template <int MT, bool FX, bool THIN, bool MULTI, bool P2P, bool COURIER, bool EPS = false>
+template <int MT, bool FX, bool THIN, bool MULTI, bool P2P, bool COURIER, bool EPS = false,
+          int NW = 1>
 __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int nref)
 {
     static_assert(!COURIER || P2P, "the courier carries rows to other ranks' replicas");
+    static_assert(NW == 1 || (!P2P && !MULTI && !COURIER), "helper waves: one GPU, one tile");
     constexpr int NC = Model<MT>::NC;         // coefficients the model tag fixes
     const int nf = FX ? P.nfree : NC;
     constexpr int ZS = ZROW;
@@ -450,7 +494,7 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
     static_assert(!EPS || (!THIN && !MULTI && !P2P), "EPS: one tile, thinning 1, one GPU");
     constexpr int LPR = EPS ? 5 : 3;           // lanes of the batch per refresh
     constexpr int NB = 64 / LPR;               // refreshes per batch of draws
-    const int lane = COURIER ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    const int lane = (COURIER || NW > 1) ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     const int lc = blockIdx.x;
     const int c = P.chain0 + lc;
     const bool mine = lane < nf;
@@ -459,6 +503,11 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
     __shared__ double s_ring[P2P ? COURIER_RING * ZROW : 1];
     __shared__ int s_cour[4];
     (void)s_ring; (void)s_cour;
+    __shared__ double s_hpart[NW > 1 ? 64 * NW : 1], s_hcf[16];
+    __shared__ int s_hcmd[2];
+    (void)s_hpart; (void)s_hcf; (void)s_hcmd;
+    SumHelpers<MT, (NW > 1 ? NW : 2)> helpers;     // (gauss.h: helper waves share the data sum)
+    (void)helpers;
     if constexpr (COURIER) {
         if (!courier_begin(s_ring, s_cour, ctl_rw))
             return;
@@ -466,10 +515,23 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
             courier_run<true>(P, s_ring, s_cour, lane, nf, c);
             return;
         }
+    } else if constexpr (NW > 1) {
+        if (!helpers.enter(s_hpart, s_hcf, s_hcmd,
+                           __hip_atomic_load(&ctl_rw[CTL_ABORT], __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT) != 0))
+            return;
     } else {
         if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
                 &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
             return;
+    }
+    DataTile<NW, MT> tile;
+    tile.load(P);
+    if constexpr (NW > 1) {
+        if (threadIdx.x >= 64) {
+            helpers.serve(P, tile);
+            return;
+        }
     }
     int handed = 0;
     (void)handed;
@@ -484,8 +546,6 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
     DelayedRows late;
     late.begin(P, P.ctl[0], c, lane);
     (void)late;
-    DataTile<1, MT> tile;
-    tile.load(P);
     DataTile<1, MT> tile1;
     if constexpr (MULTI)
         tile1.load(P, VLANES);
@@ -509,11 +569,18 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
     int kf[NC];
     double fx[NC];
     PriorLanes<NC> priors;
+    int hkf = 0;                               // (helper waves, FX: what coefficient `lane` is)
+    double hfx = 0.0;
     if constexpr (FX) {
         coefficient_map<NC>(P, kf, fx);
         priors.init(P, kf, fx, lane);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            hkf = (lane == j) ? kf[j] : hkf;
+            hfx = (lane == j) ? fx[j] : hfx;
+        }
     }
-    (void)kf; (void)fx; (void)priors;
+    (void)kf; (void)fx; (void)priors; (void)hkf; (void)hfx;
     // lane 3 i + s: slot s of refresh bbase + i.  A, B by slot: 0 -> the offsets (in doubles)
     // of rows iR1, iR2; 1 -> the offset of row iz, the jump flag; 2 -> gamma_s, u (as bits)
     unsigned long long A = 0, B = 0;
@@ -683,16 +750,28 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
         const double npk = xk + jump_k;
         const bool outk = mine && (npk < pmin_k || npk > pmax_k);
         if (__builtin_expect(!__any(outk), 1)) {
+            if constexpr (NW > 1)                    // (helper waves: as lean_demc_body's)
+                helpers.order(FX ? (hkf < 0 ? hfx : lane_gather(npk, hkf < 0 ? 0 : hkf)) : npk,
+                              lane);
             Model<MT> model;
             if constexpr (!FX) {
                 model.init_from_lanes(P, npk);
             } else {
                 model.init_from_lanes(P, npk, kf, fx);
             }
-            double nextchisq =
-                block_gauss_model<1, MT, MULTI, MULTI>(P, model, nullptr, nullptr, tile,
-                                                       MULTI ? &tile1 : &tile);  // chain.py:249
-            if constexpr (FX)
+            double nextchisq;                                          // chain.py:249
+            if constexpr (NW == 1) {
+                nextchisq = block_gauss_model<1, MT, MULTI, MULTI>(P, model, nullptr, nullptr,
+                                                                   tile, MULTI ? &tile1 : &tile);
+            } else {
+                double prior = 0.0;
+                if constexpr (FX)
+                    prior = priors.term(npk, lane);
+                nextchisq = helpers.collect(P, model, tile, lane);
+                if constexpr (FX)
+                    nextchisq = nextchisq + prior;
+            }
+            if constexpr (FX && NW == 1)
                 nextchisq = nextchisq + priors.term(npk, lane);
             bool acc;
             if (__builtin_expect(!sjump, 1)) {
@@ -764,6 +843,8 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
 out:
     if constexpr (COURIER)
         courier_end(s_cour);
+    if constexpr (NW > 1)
+        helpers.release(lane);
     if constexpr (P2P && !COURIER) {
         if (P.remote_delay != 0)
             late.drain(P, s_ring, peers_z, lane, mine, true);
@@ -2090,6 +2171,8 @@ __global__ __launch_bounds__(64 * NW) void lean_demc_wide_kernel(const DevProble
             if (mine)
                 s_cf[lane] = npk;
             order(0);                                  // (A)
+            // (nothing of this wave's share above the barrier: gauss.h SumHelpers::sum)
+            __builtin_amdgcn_sched_barrier(0);
             double cf[MT];
 #pragma unroll
             for (int j = 0; j < MT; ++j)

@@ -239,7 +239,8 @@ void launch_fast(mc3hip_ctx *c, int nref)
         DevProblem P = c->P;
         int n = nref;
         void *args[] = {&P, &n};
-        (void)hipModuleLaunchKernel(c->jit_fn, (unsigned)c->P.nlocal, 1, 1, 64, 1, 1, 0, c->stream,
+        (void)hipModuleLaunchKernel(c->jit_fn, (unsigned)c->P.nlocal, 1, 1,
+                                    (unsigned)(64 * jit_waves(c)), 1, 1, 0, c->stream,
                                     args, nullptr);
         return;
     }
@@ -265,7 +266,8 @@ int fast_blocks_per_cu(mc3hip_ctx *c)
 {
     if (jit_serves(c)) {
         int nb = 0;
-        return hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, c->jit_fn, 64, 0) ==
+        return hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, c->jit_fn,
+                                                                  64 * jit_waves(c), 0) ==
                        hipSuccess ? nb : 0;
     }
     const bool p2p = c->p2p_ranks > 1;
@@ -1168,20 +1170,32 @@ int mc3hip_jit_request(const mc3hip_ctx *c, char *buf, int32_t capacity)
     const DevProblem &P = c->P;
     const bool plain = P.nfree == P.nparams && P.ngprior == 0 && P.nshare == 0;
     const char *fx = plain ? "false" : "true", *thin = P.thinning > 1 ? "true" : "false";
+    const int nw = jit_waves(c);                 // (helper waves: the workgroup has 64 nw threads)
     int n = 0;
     switch (P.sampler) {
     case MC3HIP_DEMC:
         if (P.thinning > 1 || P.zlag > 0)        // <MT, P2P, FX, COURIER>
             n = snprintf(buf, (size_t)capacity, "lean_demc_lag_body<%d, false, %s, false>", tag, fx);
+        else if (nw > 1)                         // <MT, P2P, FX, MULTI, BATCH, COURIER, EPS, NW>
+            n = snprintf(buf, (size_t)capacity,
+                         "lean_demc_body<%d, false, %s, false, false, false, %s, %d> "
+                         "/*threads=%d*/", tag, fx, P.fepsilon != 0.0 ? "true" : "false", nw,
+                         64 * nw);
         else                                     // <MT, P2P, FX, MULTI, BATCH, COURIER, EPS>
             n = snprintf(buf, (size_t)capacity,
                          "lean_demc_body<%d, false, %s, false, false, false, %s>", tag, fx,
                          P.fepsilon != 0.0 ? "true" : "false");
         break;
-    case MC3HIP_SNOOKER:                         // <MT, FX, THIN, MULTI, P2P, COURIER, EPS>
-        n = snprintf(buf, (size_t)capacity,
-                     "lean_snooker_body<%d, %s, %s, false, false, false, %s>", tag, fx, thin,
-                     P.fepsilon != 0.0 ? "true" : "false");
+    case MC3HIP_SNOOKER:                         // <MT, FX, THIN, MULTI, P2P, COURIER, EPS[, NW]>
+        if (nw > 1)
+            n = snprintf(buf, (size_t)capacity,
+                         "lean_snooker_body<%d, %s, %s, false, false, false, %s, %d> "
+                         "/*threads=%d*/", tag, fx, thin, P.fepsilon != 0.0 ? "true" : "false",
+                         nw, 64 * nw);
+        else
+            n = snprintf(buf, (size_t)capacity,
+                         "lean_snooker_body<%d, %s, %s, false, false, false, %s>", tag, fx, thin,
+                         P.fepsilon != 0.0 ? "true" : "false");
         break;
     default:
         n = snprintf(buf, (size_t)capacity, "lean_mrw_body<%d, %s, %s, false, false, false>", tag,

@@ -91,7 +91,9 @@ def test_the_request_names_the_loop_and_the_cache_keeps_it(eng, tmp_path, monkey
     monkeypatch.setenv('MC3HIP_JIT_CACHE', str(tmp_path))
     prob = linear_problem(10, sampler='snooker')
     with eng.DeviceChains(**prob) as gpu:
-        assert gpu.jit_served == 'lean_snooker_body<210, false, false, false, false, false, false>'
+        # (ten columns do not fit one wave's registers: four waves share the data sum)
+        assert gpu.jit_served == ('lean_snooker_body<210, false, false, false, false, false, '
+                                  'false, 4> /*threads=256*/')
         assert gpu.plan['jit'] == 1
     made = sorted(os.listdir(str(tmp_path)))
     assert len(made) == 1 and made[0].endswith('.hsaco')
