@@ -178,11 +178,14 @@ int mc3hip_get_plan(const mc3hip_ctx *ctx, mc3hip_plan *plan);
  * matrix's tile resident in registers) by the caller, who owns a compiler; the library itself
  * never needs one.
  *   mc3hip_jit_request: the expression to instantiate, e.g.
- *     "lean_demc_body<205, false, false, false, false, false, false>" (C string into buf;
+ *     "lean_demc_body<203, false, false, false, false, false, false>" (C string into buf;
  *     empty: nothing to specialise -- the library has the kernel, or the shape has no loop).
- *     The caller compiles, for gfx950 and with the library's flags (-O3 -ffp-contract=off),
+ *     A request that ends in a comment "/" "*threads=N*" "/" is for a workgroup of N threads
+ *     (helper waves share the data sum of a design matrix of five columns and more: N = 256);
+ *     without it N = 64.  The caller compiles, for gfx950 and with the library's flags
+ *     (-O3 -ffp-contract=off),
  *       #include "kernels_lean.h"
- *       extern "C" __global__ __launch_bounds__(64)
+ *       extern "C" __global__ __launch_bounds__(N)
  *       void mc3_jit_kernel(const mc3hip::DevProblem P, const int nref) { mc3hip::<expr>(P, nref); }
  *     into a code object (mc3_amd/jit.py: hipcc --genco, cached on disk by content hash);
  *   mc3hip_jit_install: hands the code object over (before the first mc3hip_run).  The context

@@ -70,6 +70,7 @@ struct WaveletHook {
         }
         if (cmd == CW_SKIP) {
             prepare();
+            block_sync<9>();                            // (S) the order has been read: see below
             return true;
         }
         wavelet_noise_terms(s_nextp, P.nparams, M, s_tab);
@@ -357,6 +358,7 @@ __device__ __forceinline__ bool lean_chain_wave(const DevProblem &P, const int n
         if (cmd == CW_SKIP) {
             oob += outk ? 1ull : 0ull;                 // chain.py:242-243
             prepare(false);
+            block_sync<9>();                           // (S) the order has been read
             CW_TICK(tk3);
         } else {
             // (An experiment that lost: whenever the next jump is known during the likelihood
@@ -737,6 +739,7 @@ __device__ __forceinline__ bool lean_chain_wave_mc(const DevProblem &P, const in
         if (cmd == CW_SKIP) {
             oob += outk ? 1ull : 0ull;                 // chain.py:242-243
             prepare(false);
+            block_sync<9>();                           // (S) the order has been read
             CW_TICK(tk3);
         } else {
             // (An experiment that lost: whenever the next jump is known during the likelihood
@@ -915,8 +918,14 @@ __global__ __launch_bounds__(576) void wavelet_cw_kernel(const DevProblem P, con
         model.init(P, L.nextp);
         if (cmd == CW_STOP)
             return;
-        if (cmd == CW_SKIP)
+        if (cmd == CW_SKIP) {
+            // (S): the chain wave writes the next order only behind this barrier.  Without it a
+            // skipped iteration had no barrier between this wave's read of the order and the
+            // chain wave's next write -- safe only because preparing an iteration takes
+            // thousands of cycles; the waves sleep here instead of at (A), at no cost
+            block_sync<9>();
             continue;
+        }
         double c;
         if (B == 32)
             c = wavelet_body<8, MT, 32, false, true>(P, L.nextp, L.part, L.flag, L.tab, L.halo,

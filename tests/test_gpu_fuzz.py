@@ -364,3 +364,51 @@ def test_round4_kernels_random_problem(seed):
     assert gpu.plan['fast'] == plan['fast'], 'the persistent launch gave up: ' + label
     compare_final(gpu, orc, label)
     gpu.close()
+
+
+@pytest.mark.parametrize('seed', range(90))
+def test_rows_kernels_random_problem(seed, monkeypatch):
+    """kernels_rows.h, fuzzed: plain polynomial shapes with two to four chains per wave
+    (MC3HIP_PERSIST_CAPACITY pretends that fewer workgroups fit), every sampler, ragged
+    ensembles, tight bounds, tiny histories; a third of the seeds on the turn-after-turn loops
+    behind MC3HIP_NO_ROWS -- both must equal the oracle exactly."""
+    from mc3_amd import engine
+    rs = np.random.RandomState(12000 + seed)
+    prob = None
+    for attempt in range(100):                 # (a plain, one-tile, unthinned draw of lean_problem)
+        cand, flavour = lean_problem(12000 + 97*seed + attempt)
+        if flavour == 'plain' and len(cand['data']) >= 3:
+            prob = cand
+            break
+    assert prob is not None
+    turns = int(rs.randint(2, 5))
+    nchains = int(rs.randint(2*turns + 1, 60))
+    capacity = -(-nchains//turns)
+    if -(-nchains//capacity) != turns:         # (e.g. 9 chains over 3 turns of 3: two would do)
+        nchains = capacity*turns - int(rs.randint(0, 2))
+    prob.update(nchains=nchains, nsamples=nchains*int(rs.randint(20, 120)),
+                sampler=str(rs.choice(['demc', 'snooker', 'mrw'])))
+    if rs.rand() < 0.3:                        # bounds that reject many proposals
+        prob['pmin'] = prob['params'] - rs.uniform(0.02, 0.2, len(prob['params']))
+        prob['pmax'] = prob['params'] + rs.uniform(0.02, 0.2, len(prob['params']))
+    monkeypatch.setenv('MC3HIP_PERSIST_CAPACITY', str(capacity))
+    layout = 'turns' if seed % 3 == 2 else 'rows'
+    if layout == 'turns':
+        monkeypatch.setenv('MC3HIP_NO_ROWS', '1')
+    gpu = engine.DeviceChains(**prob)
+    plan = gpu.plan
+    label = f"{layout} {prob['sampler']} poly{prob['nmodel']} ndata={len(prob['data'])} " \
+            f"nchains={nchains} turns={turns} hsize={prob['hsize']} plan={plan}"
+    assert plan['persistent'] > 0 and plan['fast'] == 2, label
+    assert plan['chains_per_workgroup'] == turns, label
+    orc = H.make_oracle(prob, plan=plan)
+    Z0, lp0 = H.initial_population(orc, seed=seed)
+    orc.set_population(Z0, lp0)
+    gpu.set_population(Z0, lp0)
+    orc.run(nthreads=4)
+    nz = gpu.nzchain
+    gpu.run(nz//3)
+    gpu.run()
+    assert gpu.plan['fast'] == 2 and gpu.plan['recoveries'] == 0, label
+    compare_final(gpu, orc, label)
+    gpu.close()

@@ -55,6 +55,8 @@ CONFIGS = {
                                          sampler='mrw'), {}),
     'c3x4snooker': lambda n: (H.quad_problem(ndata=1000, nchains=8192, nsamples=8192*n,
                                              sampler='snooker'), {}),
+    'c3x4mrw': lambda n: (H.quad_problem(ndata=1000, nchains=8192, nsamples=8192*n,
+                                         sampler='mrw'), {}),
     'c3onesnooker': lambda n: (H.quad_problem(ndata=1000, nchains=2048, nsamples=2048*n,
                                               sampler='snooker'), {}),
     'c4x2': lambda n: (H.wavelet_problem(ndata=16384, nchains=512, nsamples=512*n), {}),
@@ -169,8 +171,9 @@ ITERS['c5'] = 300
 ITERS['q5'] = 300
 ITERS.update(c4big=1000, c4wide=4000, c4mrw=4000, c4demc=4000, c4half=4000, c3x2=3000, c3x4=2000, c3x2snooker=3000,
              c4x2=2000, c4x4=1000)
-ITERS.update(c3x2mrw=3000, c3onesnooker=4000, p6=200, p6matrix=200, c3x4snooker=1500)
-BYTES['c3x4snooker'] = 24104
+ITERS.update(c3x2mrw=3000, c3onesnooker=4000, p6=200, p6matrix=200, c3x4snooker=1500,
+             c3x4mrw=1500)
+BYTES['c3x4snooker'] = BYTES['c3x4mrw'] = 24104
 for _smp in ('demc', 'snooker', 'mrw'):
     ITERS['c2thin10' + _smp] = 4000
     BYTES['c2thin10' + _smp] = 24104

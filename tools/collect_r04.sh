@@ -22,7 +22,7 @@ if has pmc; then
     done
 fi
 if has configs; then
-    timeout 1500 python tools/bench_configs.py c2 c2snooker c2mrw c2thin10demc c2thin10snooker c2thin10mrw c2twodemc c2twosnooker c2twomrw c3one c3onesnooker c3x2 c3x4 c3x2snooker c3x2mrw c4 c4wide c4demc c4mrw c4x2 c4x4 c5 q5 p6matrix \
+    timeout 1500 python tools/bench_configs.py c2 c2snooker c2mrw c2thin10demc c2thin10snooker c2thin10mrw c2twodemc c2twosnooker c2twomrw c3one c3onesnooker c3x2 c3x4 c3x2snooker c3x2mrw c3x4snooker c3x4mrw c4 c4wide c4demc c4mrw c4x2 c4x4 c5 q5 p6matrix \
         > $out/configs.jsonl 2> $out/configs.err
 fi
 # the shapes off the hand-laid-out loops: as they run now, and behind the switch (the general /
