@@ -365,7 +365,7 @@ inline bool lean_demc_mc_eligible(const mc3hip_ctx *c)
            c->P.nparams == c->mt && c->P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
 }
 
-// ... and, for the plain shapes of those (every coefficient free, no priors, one tile), with the
+// ... and, for the one-tile shapes of those, with the
 // chains of a wave side by side in its rows of 16 lanes: kernels_rows.h lean_*_rows_kernel
 // (MC3HIP_NO_ROWS: the turn-after-turn loops above)
 inline bool lean_rows_eligible(const mc3hip_ctx *c)
@@ -373,7 +373,7 @@ inline bool lean_rows_eligible(const mc3hip_ctx *c)
     const bool any = c->P.sampler == MC3HIP_DEMC      ? lean_demc_mc_eligible(c)
                      : c->P.sampler == MC3HIP_SNOOKER ? lean_snooker_mc_eligible(c)
                                                       : lean_mrw_mc_eligible(c);
-    return any && lean_plain_shape(c) && c->P.npad <= VLANES && c->mt >= 2 && c->mt <= 4 &&
+    return any && c->P.nfree >= 1 && c->P.npad <= VLANES && c->mt >= 2 && c->mt <= 4 &&
            (c->P.fepsilon == 0.0 || c->P.sampler == MC3HIP_MRW) && !getenv("MC3HIP_NO_ROWS");
 }
 

@@ -1,6 +1,5 @@
 // k_lean6.hip -- instances of the hand-laid-out loops with the two to four chains of a wave
-// side by side in its rows of 16 lanes (kernels_rows.h): plain shapes -- every coefficient
-// free, no priors, one tile -- of ensembles with more chains than waves can be co-resident, one
+// side by side in its rows of 16 lanes (kernels_rows.h): one-tile shapes of ensembles with more chains than waves can be co-resident, one
 // GPU; a translation unit of its own so that the library builds in parallel.
 #include "ctx.h"
 #include "kernels_rows.h"
@@ -12,10 +11,15 @@ namespace {
 template <int MT, int T>
 chain_kernel_fn lean_rows_instance_tt(const mc3hip_ctx *c)
 {
+    // (FX: fixed or shared coefficients, Gaussian priors)
+    const bool fx = !lean_plain_shape(c);
     switch (c->P.sampler) {
-    case MC3HIP_DEMC: return lean_demc_rows_kernel<MT, T>;
-    case MC3HIP_SNOOKER: return lean_snooker_rows_kernel<MT, T>;
-    default: return lean_mrw_rows_kernel<MT, T>;
+    case MC3HIP_DEMC:
+        return fx ? lean_demc_rows_kernel<MT, T, true> : lean_demc_rows_kernel<MT, T>;
+    case MC3HIP_SNOOKER:
+        return fx ? lean_snooker_rows_kernel<MT, T, true> : lean_snooker_rows_kernel<MT, T>;
+    default:
+        return fx ? lean_mrw_rows_kernel<MT, T, true> : lean_mrw_rows_kernel<MT, T>;
     }
 }
 

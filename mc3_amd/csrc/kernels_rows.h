@@ -5,8 +5,8 @@
 // Measured on MI355X at 8192 chains (profiles/r04_c3x4_pmc_before.json) that loop spends 201
 // vector instructions per chain-step of which 109 are FP64 arithmetic: the rest are T copies
 // of the scalar work of a turn and the register shuffling of T turns' control flow.  Here, for
-// the plain shape (every coefficient free, no priors, one tile, polynomials of 2..4
-// coefficients), lane 16 r + k holds coefficient k of the chain of row r (T = 4: chain r;
+// one-tile polynomials of 2..4 coefficients, lane 16 r + k holds coefficient k (FX shapes: free
+// parameter k) of the chain of row r (T = 4: chain r;
 // T = 3: rows 2 and 3 both chain 2; T = 2: rows 0-1 chain 0, rows 2-3 chain 1; a duplicate row
 // computes what its twin computes and stores nothing).  Everything but the sixteen residuals
 // per lane and chain then runs ONCE per refresh for all the chains of the wave:
@@ -63,14 +63,35 @@ __device__ __forceinline__ double row_serial_sum(double t)
     return s;
 }
 
+// ... and of lanes 0..n-1, n <= 4 known at run time (FX shapes: n free parameters, n priors)
+__device__ __forceinline__ double row_serial_sum_n(double t, int n)
+{
+    double s = 0.0;
+    if (n > 0)
+        s = s + row_bcast<0>(t);
+    if (n > 1)
+        s = s + row_bcast<1>(t);
+    if (n > 2)
+        s = s + row_bcast<2>(t);
+    if (n > 3)
+        s = s + row_bcast<3>(t);
+    return s;
+}
+
 // What the three samplers' rows loops share: the wave's chains and their states, the data
 // sums of T proposals, the bookkeeping of an accepted step, the Z append.
-template <int MT, int T>
+// (FX: some coefficients are fixed or shared, or carry Gaussian priors -- lane 16 r + k holds
+// FREE parameter k of its chain, coefficient j is free parameter kf[j] or the fixed value fx[j]
+// (handoff.h coefficient_map), lane 16 r + g works out prior g of its chain)
+template <int MT, int T, bool FX = false>
 struct RowsWave {
     static_assert(T >= 2 && T <= 4, "2..4 chains per wave");
     static_assert(MT >= 2 && MT <= 4, "polynomials of 2..4 coefficients");
     static constexpr int ZS = ZROW;
-    int lane, row, k, slot, kk, l, c, n, nacc;
+    int lane, row, k, slot, kk, l, c, n, nacc, nf;
+    int kf[MT];
+    double fx[MT];
+    PriorLanes<MT> priors;
     bool owner, exists, mine, keeps, first;
     double xk, cur, best, pmin_k, pmax_k;
     unsigned long long rowmask;
@@ -101,7 +122,12 @@ struct RowsWave {
         exists = b + slot * G < P.nlocal;
         l = exists ? b + slot * G : b;
         c = P.chain0 + l;
-        mine = k < MT;
+        nf = FX ? P.nfree : MT;
+        if constexpr (FX) {
+            coefficient_map<MT>(P, kf, fx);
+            priors.init(P, kf, fx, k);
+        }
+        mine = k < nf;
         keeps = mine && owner && exists;              // lanes that store coefficients
         first = k == 0 && owner && exists;            // one lane per chain: the scalars
         kk = mine ? k : 0;
@@ -142,9 +168,34 @@ struct RowsWave {
         // (v_readlane + moves; through the LDS crossbar instead -- ds_bpermute, 28 vector
         // instructions fewer per refresh -- measured 2 % SLOWER: the residuals wait for it)
 #pragma unroll
-        for (int j = 0; j < MT; ++j)
-            model.cf[j] = read_lane(npk, lane_of(q) + j);
+        for (int j = 0; j < MT; ++j) {
+            if constexpr (FX) {
+                const double v = read_lane(npk, lane_of(q) + (kf[j] < 0 ? 0 : kf[j]));
+                model.cf[j] = kf[j] < 0 ? fx[j] : v;
+            } else {
+                model.cf[j] = read_lane(npk, lane_of(q) + j);
+            }
+        }
         return model;
+    }
+    // the sum of lanes 0..nf-1 of every row, in lane order
+    __device__ __forceinline__ double sum_free(double t) const
+    {
+        if constexpr (FX)
+            return row_serial_sum_n(t, nf);
+        else
+            return row_serial_sum<MT>(t);
+    }
+    // PriorLanes::term for every row: lane 16 r + g works out prior g of the chain of row r
+    // (the proposed value through the crossbar, the division), the squares added in the
+    // priors' order
+    __device__ __forceinline__ double prior_term(double npk) const
+    {
+        const double got = lane_gather(npk, (lane & 48) + (priors.src < 0 ? k : priors.src));
+        const double v = priors.src >= 0 ? got : priors.fixedv;
+        const double d = v - priors.centre;
+        const double sd = (d > 0.0) ? d / priors.up : d / priors.lo;
+        return row_serial_sum_n(sd * sd, priors.n);
     }
     // the data sums of the T proposals, chain.py:249: sixteen residuals per lane and chain,
     // then all the chains' trees at once; every lane of a row receives its chain's
@@ -172,6 +223,8 @@ struct RowsWave {
                     total = (slot == q) ? mc3_from_bits(0x7ff0000000000000ull) : total;
             }
         }
+        if constexpr (FX)                            // stats.py:211-216, stats.h:96-106
+            total = total + prior_term(npk);
         return total;
     }
     // chain.py:261-289: the accepted rows move, the best fit so far, the Z append -- the T rows
@@ -185,7 +238,7 @@ struct RowsWave {
             if (better) {
                 best = nextchisq;
                 if (keeps)
-                    P.bestx[(size_t)l * MT + k] = xk;
+                    P.bestx[(size_t)l * nf + k] = xk;
                 if (first)
                     P.best_iter[l] = R;
             }
@@ -210,7 +263,7 @@ struct RowsWave {
     __device__ __forceinline__ void finish(const DevProblem &P) const
     {
         if (keeps)
-            P.X[(size_t)l * MT + k] = xk;
+            P.X[(size_t)l * nf + k] = xk;
         if (first) {
             P.chisq[l] = cur;
             P.best_chisq[l] = best;
@@ -223,7 +276,7 @@ struct RowsWave {
 // DEMC (lean_demc_mc_kernel's shape): the partner rows are rows of the refresh before, asked
 // for at the top of a refresh and waited for; lane r T + q of a batch holds the draws of
 // refresh bbase + r, chain q of the wave (chain.py:221-232, :259).
-template <int MT, int T>
+template <int MT, int T, bool FX = false>
 __global__ __launch_bounds__(64) void lean_demc_rows_kernel(const DevProblem P, const int nref)
 {
     constexpr int ZS = ZROW;
@@ -233,7 +286,7 @@ __global__ __launch_bounds__(64) void lean_demc_rows_kernel(const DevProblem P, 
             &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
         return;
     const long long R0 = P.ctl[0];
-    RowsWave<MT, T> W;
+    RowsWave<MT, T, FX> W;
     W.init(P, R0);
     const int lane = W.lane, n = W.n;
     const double *pbase = (R0 == 0) ? P.snap0 : P.Z + (size_t)(P.M0 + (R0 - 1) * n) * ZS;
@@ -314,7 +367,7 @@ __global__ __launch_bounds__(64) void lean_demc_rows_kernel(const DevProblem P, 
 // batch holds Philox slot s' (0, 3, 4 for s = 0, 1, 2) of refresh bbase + i, chain q: the
 // Metropolis draw with its window from s = 0, the pairs of normal deviates of coefficients
 // 0-1 and 2-3 from s = 1, 2 (lean_mrw_kernel's fields).
-template <int MT, int T>
+template <int MT, int T, bool FX = false>
 __global__ __launch_bounds__(64) void lean_mrw_rows_kernel(const DevProblem P, const int nref)
 {
     constexpr int NB = 64 / (3 * T);           // refreshes per batch of draws
@@ -323,7 +376,7 @@ __global__ __launch_bounds__(64) void lean_mrw_rows_kernel(const DevProblem P, c
             &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
         return;
     const long long R0 = P.ctl[0];
-    RowsWave<MT, T> W;
+    RowsWave<MT, T, FX> W;
     W.init(P, R0);
     const int lane = W.lane;
     const double pstep_k = W.mine ? P.fstep[W.k] : 0.0;
@@ -386,7 +439,7 @@ __global__ __launch_bounds__(64) void lean_mrw_rows_kernel(const DevProblem P, c
 // and the Metropolis draw with its window).  A refresh in which no chain of the wave makes a
 // snooker jump (two in three at four chains) never enters that path; in one that does, the
 // rows that do not are masked out of it.
-template <int MT, int T>
+template <int MT, int T, bool FX = false>
 __global__ __launch_bounds__(64) void lean_snooker_rows_kernel(const DevProblem P, const int nref)
 {
     constexpr int ZS = ZROW;
@@ -396,7 +449,7 @@ __global__ __launch_bounds__(64) void lean_snooker_rows_kernel(const DevProblem 
             &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
         return;
     const long long R0 = P.ctl[0];
-    RowsWave<MT, T> W;
+    RowsWave<MT, T, FX> W;
     W.init(P, R0);
     const int lane = W.lane, n = W.n;
     const double gamma = P.gamma, feps = P.fepsilon;
@@ -499,9 +552,9 @@ __global__ __launch_bounds__(64) void lean_snooker_rows_kernel(const DevProblem 
         if (__builtin_expect(any_sjump, 0)) {                            // chain.py:207-215
             const bool same = !W.row_any(W.mine && !(zk == W.xk));
             const double dz = W.xk - zk;
-            const double zp1 = row_serial_sum<MT>(z1 * dz);
-            const double zp2 = row_serial_sum<MT>(z2 * dz);
-            const double dd = row_serial_sum<MT>(dz * dz);
+            const double zp1 = W.sum_free(z1 * dz);
+            const double zp2 = W.sum_free(z2 * dz);
+            const double dd = W.sum_free(dz * dz);
             const double sj_k = same ? C.gs * (z2 - z1) : ((C.gs * (zp1 - zp2)) * dz) / dd;
             jump_k = sjump ? sj_k : jump_k;
         }
@@ -513,9 +566,9 @@ __global__ __launch_bounds__(64) void lean_snooker_rows_kernel(const DevProblem 
                        : metropolis_accept(0.5 * (W.cur - nextchisq), C.u, C.lo, C.hi);
         if (__builtin_expect(any_sjump, 0)) {                            // chain.py:251-255
             const double dc = W.xk - zk, dn = npk - zk;
-            const double cnorm = row_serial_sum<MT>(W.mine ? dc * dc : 0.0);
-            const double nnorm = row_serial_sum<MT>(W.mine ? dn * dn : 0.0);
-            const double mrfactor = mc3_det_pow_half(nnorm / cnorm, MT - 1);
+            const double cnorm = W.sum_free(W.mine ? dc * dc : 0.0);
+            const double nnorm = W.sum_free(W.mine ? dn * dn : 0.0);
+            const double mrfactor = mc3_det_pow_half(nnorm / cnorm, W.nf - 1);
             const bool acc_s = mc3_det_exp(0.5 * (W.cur - nextchisq)) * mrfactor > C.u;
             acc = (sjump && !row_out) ? acc_s : acc;
         }

@@ -366,18 +366,19 @@ def test_round4_kernels_random_problem(seed):
     gpu.close()
 
 
-@pytest.mark.parametrize('seed', range(90))
+@pytest.mark.parametrize('seed', range(150))
 def test_rows_kernels_random_problem(seed, monkeypatch):
-    """kernels_rows.h, fuzzed: plain polynomial shapes with two to four chains per wave
+    """kernels_rows.h, fuzzed: one-tile polynomial shapes (fixed / shared coefficients and priors
+    among them) with two to four chains per wave
     (MC3HIP_PERSIST_CAPACITY pretends that fewer workgroups fit), every sampler, ragged
     ensembles, tight bounds, tiny histories; a third of the seeds on the turn-after-turn loops
     behind MC3HIP_NO_ROWS -- both must equal the oracle exactly."""
     from mc3_amd import engine
     rs = np.random.RandomState(12000 + seed)
     prob = None
-    for attempt in range(100):                 # (a plain, one-tile, unthinned draw of lean_problem)
+    for attempt in range(100):                 # (a one-tile, unthinned draw of lean_problem)
         cand, flavour = lean_problem(12000 + 97*seed + attempt)
-        if flavour == 'plain' and len(cand['data']) >= 3:
+        if flavour in ('plain', 'fx') and len(cand['data']) >= 3:
             prob = cand
             break
     assert prob is not None
@@ -388,7 +389,7 @@ def test_rows_kernels_random_problem(seed, monkeypatch):
         nchains = capacity*turns - int(rs.randint(0, 2))
     prob.update(nchains=nchains, nsamples=nchains*int(rs.randint(20, 120)),
                 sampler=str(rs.choice(['demc', 'snooker', 'mrw'])))
-    if rs.rand() < 0.3:                        # bounds that reject many proposals
+    if rs.rand() < 0.3 and flavour == 'plain':  # bounds that reject many proposals
         prob['pmin'] = prob['params'] - rs.uniform(0.02, 0.2, len(prob['params']))
         prob['pmax'] = prob['params'] + rs.uniform(0.02, 0.2, len(prob['params']))
     monkeypatch.setenv('MC3HIP_PERSIST_CAPACITY', str(capacity))
@@ -397,8 +398,8 @@ def test_rows_kernels_random_problem(seed, monkeypatch):
         monkeypatch.setenv('MC3HIP_NO_ROWS', '1')
     gpu = engine.DeviceChains(**prob)
     plan = gpu.plan
-    label = f"{layout} {prob['sampler']} poly{prob['nmodel']} ndata={len(prob['data'])} " \
-            f"nchains={nchains} turns={turns} hsize={prob['hsize']} plan={plan}"
+    label = f"{layout} {flavour} {prob['sampler']} poly{prob['nmodel']} ndata={len(prob['data'])} " \
+            f"nchains={nchains} turns={turns} hsize={prob['hsize']} pstep={prob['pstep']} plan={plan}"
     assert plan['persistent'] > 0 and plan['fast'] == 2, label
     assert plan['chains_per_workgroup'] == turns, label
     orc = H.make_oracle(prob, plan=plan)

@@ -211,8 +211,6 @@ def layout_switch(monkeypatch, layout, case):
     """'rows': the chains of a wave side by side (kernels_rows.h, the default for plain
     shapes); 'turns': one after another (lean_*_mc_kernel, MC3HIP_NO_ROWS)."""
     if layout == 'turns':
-        if case == 'priors':
-            pytest.skip('FX shapes take turns in either case')
         monkeypatch.setenv('MC3HIP_NO_ROWS', '1')
 
 
