@@ -370,11 +370,14 @@ inline bool lean_demc_mc_eligible(const mc3hip_ctx *c)
 // (MC3HIP_NO_ROWS: the turn-after-turn loops above)
 inline bool lean_rows_eligible(const mc3hip_ctx *c)
 {
-    const bool any = c->P.sampler == MC3HIP_DEMC      ? lean_demc_mc_eligible(c)
-                     : c->P.sampler == MC3HIP_SNOOKER ? lean_snooker_mc_eligible(c)
-                                                      : lean_mrw_mc_eligible(c);
-    return any && c->P.nfree >= 1 && c->P.npad <= VLANES && c->mt >= 2 && c->mt <= 4 &&
-           (c->P.fepsilon == 0.0 || c->P.sampler == MC3HIP_MRW) && !getenv("MC3HIP_NO_ROWS");
+    // (every sampler, strict or in the declared cadence -- the turn-after-turn loops behind
+    // MC3HIP_NO_ROWS have no zlag flavour of DEMC and snooker: the general chain takes turns)
+    const DevProblem &P = c->P;
+    return c->fast && c->mc_chains >= 2 && c->mc_chains <= 4 && P.thinning == 1 &&
+           P.nparams == c->mt && c->mt >= 2 && c->mt <= 4 && P.zs == ZROW && P.npad <= VLANES &&
+           P.nfree >= 1 && (P.fepsilon == 0.0 || P.sampler == MC3HIP_MRW) &&
+           !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_LEAN") &&
+           !getenv("MC3HIP_NO_ROWS");
 }
 
 // waves that share the data sum of a chain in the hand-laid-out DEMC loop (kernels_lean.h

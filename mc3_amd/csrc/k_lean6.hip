@@ -15,6 +15,8 @@ chain_kernel_fn lean_rows_instance_tt(const mc3hip_ctx *c)
     const bool fx = !lean_plain_shape(c);
     switch (c->P.sampler) {
     case MC3HIP_DEMC:
+        if (c->P.zlag > 0)                   // (the declared cadence: rows asked for a refresh ahead)
+            return fx ? lean_demc_rows_lag_kernel<MT, T, true> : lean_demc_rows_lag_kernel<MT, T>;
         return fx ? lean_demc_rows_kernel<MT, T, true> : lean_demc_rows_kernel<MT, T>;
     case MC3HIP_SNOOKER:
         return fx ? lean_snooker_rows_kernel<MT, T, true> : lean_snooker_rows_kernel<MT, T>;

@@ -363,6 +363,128 @@ __global__ __launch_bounds__(64) void lean_demc_rows_kernel(const DevProblem P, 
 }
 
 // ---------------------------------------------------------------------------------
+// DEMC in the DECLARED MULTI-GPU CADENCE (mc3hip_problem.zlag = D >= 1, lean_demc_lag_kernel's
+// shape): during refresh R the chains see the others through the rows of refresh R - 1 - D
+// (the initial snapshot while that is negative), published at least a refresh ago -- so the
+// partner rows of the NEXT refresh are asked for at the top of this one by loads outside the
+// compiler's wait counts (handoff.h load_published_async), retired behind this refresh's
+// publish, and no refresh waits for a round trip.  Same draws, same arithmetic, same results
+// as run_chain's with the same zlag.
+template <int MT, int T, bool FX = false>
+__global__ __launch_bounds__(64) void lean_demc_rows_lag_kernel(const DevProblem P, const int nref)
+{
+    constexpr int ZS = ZROW;
+    constexpr int NB = 64 / T;                 // refreshes per batch of draws
+    long long *ctl_rw = const_cast<long long *>(P.ctl);
+    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
+            &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+        return;
+    const long long R0 = P.ctl[0];
+    RowsWave<MT, T, FX> W;
+    W.init(P, R0);
+    const int lane = W.lane, n = W.n;
+    const long long D = P.zlag;
+    // the rows refresh R looks at: of refresh R - 1 - D
+    auto seen_by = [&](long long R) -> const double * {
+        const long long Rs = R - 1 - D;
+        return (Rs < 0) ? P.snap0 : P.Z + (size_t)(P.M0 + Rs * n) * ZS;
+    };
+    const double gamma = P.gamma, feps = P.fepsilon;
+    const long long abort_at =
+        (P.test_abort >= 0 && blockIdx.x == 0) ? (long long)P.test_abort : -1;
+    const int br = (lane / T < NB) ? lane / T : NB - 1;
+    const int bc = W.chain_of(P, lane % T);
+    double bu, blo, bhi;
+    int bo1, bo2;
+    long long bbase;
+    auto fill = [&](long long base) {
+        const Draw2 dd = draw2(P.seed, (uint64_t)(base + br), (uint32_t)bc, 0u);
+        bu = u01(dd.q1);
+        accept_window(bu, blo, bhi);
+        int r1, r2;
+        demc_partners(dd.q0, n, bc, r1, r2);
+        bo1 = r1 * ZS;
+        bo2 = r2 * ZS;
+        bbase = base;
+    };
+    struct Step {
+        double u, lo, hi;
+        const double *addr[2];
+        double val[2];
+    };
+    // (asked for at ONE place per refresh, waited for at one: kernels_lean.h lean_snooker_mc_kernel)
+    auto ask = [&](Step &S) {
+        S.val[0] = load_published_async(S.addr[0]);
+        S.val[1] = load_published_async(S.addr[1]);
+    };
+    auto prepare = [&](long long R, Step &S) {
+        const int from = 4 * ((int)(R - bbase) * T + W.slot);    // whose draws this row needs
+        const double *sb = seen_by(R);
+        S.addr[0] = sb + (__builtin_amdgcn_ds_bpermute(from, bo1) + W.kk);
+        S.addr[1] = sb + (__builtin_amdgcn_ds_bpermute(from, bo2) + W.kk);
+        S.u = gather_f64(bu, from);
+        S.lo = gather_f64(blo, from);
+        S.hi = gather_f64(bhi, from);
+    };
+    fill(R0);
+    Step S;
+    prepare(R0, S);
+    ask(S);
+    {
+        double none = 0.0;
+        published_arrived<0>(S.val[0], S.val[1], none);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    const long long Rend = R0 + nref;
+    bool alive = true;
+    for (long long R = R0; R < Rend; ++R) {
+        if (__builtin_expect(R == abort_at, 0)) {                                         // test hook
+            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        // the rows of this refresh were asked for at the top of the one before and retired at
+        // its bottom; the next refresh's are asked for now
+        Step C = S;
+        Step Nx;
+        if (__builtin_expect(R + 1 - bbase == NB, 0))
+            fill(R + 1);
+        prepare(R + 1, Nx);
+        ask(Nx);
+        // (D = 1: a row of the refresh before may still be the sentinel)
+        if (__builtin_expect(__any(mc3_bits(C.val[0]) == ROW_PENDING ||
+                                   mc3_bits(C.val[1]) == ROW_PENDING), 0)) {
+            const double *const a2[2] = {C.addr[0], C.addr[1]};
+            double v2[2] = {C.val[0], C.val[1]};
+            alive = wait_rows<2, false>(a2, v2, ctl_rw);
+            // (nothing this path asked for is pending where it joins the other)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            asm volatile("; rows of this refresh" : "+v"(v2[0]), "+v"(v2[1]));
+            C.val[0] = v2[0];
+            C.val[1] = v2[1];
+            if (__builtin_expect(!alive, 0))
+                break;
+        }
+        const double jump_k = gamma * (C.val[0] - C.val[1]) + feps * 0.0;     // chain.py:232
+        const double npk = W.xk + jump_k;
+        const bool row_out = W.out_of_bounds(P, npk);
+        const double nextchisq = W.chisq_all(P, npk);
+        const bool acc = row_out ? false
+                                 : metropolis_accept(0.5 * (W.cur - nextchisq), C.u, C.lo, C.hi);
+        W.commit(P, acc, npk, nextchisq, R);
+        // the next refresh's rows: everything but the youngest operation of this wave -- the
+        // publish above -- has completed
+        {
+            double none = 0.0;
+            published_arrived<1>(Nx.val[0], Nx.val[1], none);
+        }
+        S = Nx;
+        W.advance();
+    }
+    W.finish(P);
+}
+
+// ---------------------------------------------------------------------------------
 // The random walk (lean_mrw_mc_kernel's shape): nothing is read.  Lane (3 i + s) T + q of a
 // batch holds Philox slot s' (0, 3, 4 for s = 0, 1, 2) of refresh bbase + i, chain q: the
 // Metropolis draw with its window from s = 0, the pairs of normal deviates of coefficients
@@ -461,9 +583,13 @@ __global__ __launch_bounds__(64) void lean_snooker_rows_kernel(const DevProblem 
     unsigned long long A, B;
     double blo, bhi;
     long long bbase = R0;
+    const long long zlag = P.zlag;
     auto fill = [&](long long base) {
         const long long Rl = base + bi;
-        const unsigned long long zsz = (unsigned long long)(P.M0 + Rl * n);
+        // (the history a refresh draws from: the rows before it -- zlag refreshes before it in
+        // the declared multi-GPU cadence, mc3hip_problem.zlag)
+        const long long Rh = Rl - zlag;
+        const unsigned long long zsz = (unsigned long long)(P.M0 + (Rh > 0 ? Rh : 0) * n);
         const Draw2 d = draw2(P.seed, (uint64_t)Rl, (uint32_t)bc, (uint32_t)bs);
         if (bs == 0) {
             const unsigned long long iR1 = bounded(d.q0, zsz);

@@ -297,3 +297,42 @@ def test_snooker_loop_with_the_support_distribution(eng, monkeypatch, case):
     assert plan['persistent'] > 0 and plan['recoveries'] == 0 and plan['fast'] == 2, plan
     assert_same(orc, gpu, trace=False)
     gpu.close()
+
+
+# ---- kernels_rows.h in the cadence: several chains per wave side by side ---------------------
+@pytest.mark.parametrize('zlag', [1, 2, 5])
+@pytest.mark.parametrize('turns', [2, 3, 4])
+@pytest.mark.parametrize('case', ['demc', 'demc-priors', 'demc-tiny-history', 'snooker',
+                                  'snooker-tiny-history', 'mrw', 'demc-resume'])
+def test_rows_loops_of_the_lagged_cadence(eng, monkeypatch, case, turns, zlag):
+    """lean_demc_rows_lag_kernel (the partner rows of the next refresh asked for a refresh ahead),
+    lean_snooker_rows_kernel (its history ends zlag refreshes earlier), lean_mrw_rows_kernel:
+    ensembles beyond the co-resident waves (MC3HIP_PERSIST_CAPACITY pretends so) in the declared
+    cadence, against the oracle in the same cadence."""
+    sampler = case.split('-')[0]
+    nchains = 5*turns - (1 if 'tiny' in case else 0)          # (ragged: the last turn not full)
+    monkeypatch.setenv('MC3HIP_PERSIST_CAPACITY', '5')
+    prob = H.quad_problem(ndata=400, nchains=nchains, nsamples=nchains*60, sampler=sampler,
+                          zlag=zlag)
+    if 'priors' in case:
+        prob.update(prior=np.array([4.0, 0.0, 0.0]), priorlow=np.array([0.5, 0.0, 0.0]),
+                    priorup=np.array([0.7, 0.0, 0.0]), pstep=np.array([1.0, 0.0, 0.1]))
+    if 'tiny' in case:
+        prob.update(hsize=1)
+    if 'resume' in case:
+        monkeypatch.setenv('MC3HIP_PERSIST_REFS', '7')
+        gpu = eng.DeviceChains(**prob)
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nthreads=4)
+        for n in (1, 2, 20, 37):
+            gpu.run(n)
+    else:
+        orc, gpu = run_pair(eng, prob, trace=False)
+    plan = gpu.plan
+    assert plan['zlag'] == zlag and plan['persistent'] > 0 and plan['fast'] == 2, plan
+    assert plan['chains_per_workgroup'] == turns and plan['recoveries'] == 0, plan
+    assert_same(orc, gpu, trace=False)
+    gpu.close()

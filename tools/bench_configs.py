@@ -193,6 +193,12 @@ for _k in ('c2lag4', 'c2lag1', 'c2lag4snooker'):
     BYTES[_k] = 24104
 ITERS['c3onelag4'] = 4000
 BYTES['c3onelag4'] = 24104
+CONFIGS['c3x4lag4'] = lambda n: (H.quad_problem(ndata=1000, nchains=8192, nsamples=8192*n,
+                                                sampler='demc', zlag=4), {})
+CONFIGS['c3x2lag4'] = lambda n: (H.quad_problem(ndata=1000, nchains=4096, nsamples=4096*n,
+                                                sampler='demc', zlag=4), {})
+ITERS.update(c3x4lag4=2000, c3x2lag4=3000)
+BYTES['c3x4lag4'] = BYTES['c3x2lag4'] = 24104
 BYTES['c4big'] = 8*2*65536 + 8*5*4 + 8
 for _k in ('c4x2', 'c4x4', 'c4wide'):
     BYTES[_k] = BYTES['c4']

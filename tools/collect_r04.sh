@@ -33,7 +33,7 @@ if has offlean; then
     MC3HIP_NO_LEAN=1 timeout 1200 python tools/bench_configs.py $OFF > $out/offlean_configs_no_lean.jsonl 2>> $out/offlean.err
 fi
 # the declared multi-GPU cadence on one GPU
-has lag && timeout 900 python tools/bench_configs.py c2lag1 c2lag4 c2lag4snooker c3onelag4 > $out/lag_configs.jsonl 2> $out/lag.err
+has lag && timeout 900 python tools/bench_configs.py c2lag1 c2lag4 c2lag4snooker c3onelag4 c3x2lag4 c3x4lag4 > $out/lag_configs.jsonl 2> $out/lag.err
 # injected xGMI latency: ranks on ONE GPU
 has sweep && timeout 3000 python tools/delay_sweep.py $out/delay_sweep.jsonl --ranks 2,4 --zlags 0,1,2,4 --delays 0,1000,2000,3000 > $out/sweep.log 2>&1
 has sweep8 && timeout 3000 python tools/delay_sweep.py $out/delay_sweep.jsonl --ranks 8 --zlags 0,1,2,4,8 --delays 0,1000,2000,3000 > $out/sweep8.log 2>&1
