@@ -111,6 +111,10 @@ WORKLOADS = {
     'c3': (c2_problem, 2048, 'strong', 8*3*NDATA + 8*3*(3 + 1) + 8,
            "C3: quadratic 3-param fit, ndata=1000, 2048 chains split over the GPUs, "
            "sampler='demc', fepsilon=0"),
+    # (not a BASELINE configuration: a large ensemble per GPU, several chains per wave --
+    # kernels_rows.h -- sharded peer to peer)
+    'c3big': (c2_problem, 4096, 'weak', 8*3*NDATA + 8*3*(3 + 1) + 8,
+              "quadratic 3-param fit, ndata=1000, 4096 chains/GPU, sampler='demc', fepsilon=0"),
     'c5': (c5_problem, 512, 'strong', 8*12*100000 + 8*10*(3 + 1) + 8,
            "C5: 10-param linear model, ndata=1e5, 512 chains split over the GPUs, Gaussian "
            "priors + bounds, sampler='demc'"),

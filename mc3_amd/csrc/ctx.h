@@ -260,6 +260,8 @@ inline bool fast_eligible(const mc3hip_ctx *c)
            !getenv("MC3HIP_NO_FAST");
 }
 
+inline bool lean_rows_shape(const mc3hip_ctx *c);
+
 // shapes that ONLY a one-chain-per-wave hand-laid-out loop serves leanly (the lean run_chain
 // instances have no such flavour): an ensemble of them beyond the co-resident waves runs the
 // general chain (mc3hip.hip decide_persist)
@@ -267,8 +269,10 @@ inline bool lean_one_chain_only(const mc3hip_ctx *c)
 {
     const DevProblem &P = c->P;
     const bool plain = P.nfree == P.nparams && P.ngprior == 0 && P.nshare == 0;
+    // (peer to peer with thinning 1: kernels_rows.h has the FX flavour)
     return jit_serves(c) || (P.fepsilon != 0.0 && P.sampler != MC3HIP_MRW) ||
-           (lag_demc_shape(c) && !plain && (P.thinning != 1 || (c->flags & MC3HIP_FLAG_P2P)));
+           (lag_demc_shape(c) && !plain &&
+            (P.thinning != 1 || ((c->flags & MC3HIP_FLAG_P2P) && !lean_rows_shape(c))));
 }
 
 // the headline shape (DEMC, thinning 1) has a loop of its own: lean_demc_kernel
@@ -368,16 +372,20 @@ inline bool lean_demc_mc_eligible(const mc3hip_ctx *c)
 // ... and, for the one-tile shapes of those, with the
 // chains of a wave side by side in its rows of 16 lanes: kernels_rows.h lean_*_rows_kernel
 // (MC3HIP_NO_ROWS: the turn-after-turn loops above)
+// (the shapes those loops serve -- on one GPU or sharded over several, peer to peer -- whatever
+// the number of chains per wave decide_persist settles on)
+inline bool lean_rows_shape(const mc3hip_ctx *c)
+{
+    const DevProblem &P = c->P;
+    return P.thinning == 1 && P.nparams == c->mt && c->mt >= 2 && c->mt <= 4 && P.zs == ZROW &&
+           P.npad <= VLANES && P.nfree >= 1 && (P.fepsilon == 0.0 || P.sampler == MC3HIP_MRW) &&
+           !getenv("MC3HIP_NO_LEAN") && !getenv("MC3HIP_NO_ROWS");
+}
 inline bool lean_rows_eligible(const mc3hip_ctx *c)
 {
     // (every sampler, strict or in the declared cadence -- the turn-after-turn loops behind
     // MC3HIP_NO_ROWS have no zlag flavour of DEMC and snooker: the general chain takes turns)
-    const DevProblem &P = c->P;
-    return c->fast && c->mc_chains >= 2 && c->mc_chains <= 4 && P.thinning == 1 &&
-           P.nparams == c->mt && c->mt >= 2 && c->mt <= 4 && P.zs == ZROW && P.npad <= VLANES &&
-           P.nfree >= 1 && (P.fepsilon == 0.0 || P.sampler == MC3HIP_MRW) &&
-           !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_LEAN") &&
-           !getenv("MC3HIP_NO_ROWS");
+    return c->fast && c->mc_chains >= 2 && c->mc_chains <= 4 && lean_rows_shape(c);
 }
 
 // waves that share the data sum of a chain in the hand-laid-out DEMC loop (kernels_lean.h

@@ -78,12 +78,66 @@ __device__ __forceinline__ double row_serial_sum_n(double t, int n)
     return s;
 }
 
+// Test hook P.remote_delay (MC3HIP_TEST_REMOTE_DELAY_NS) for these loops, peer to peer: the
+// rows of a refresh (all 64 lanes' worth) wait in a small LDS ring of the wave's own and go
+// into the other ranks' replicas, in order, at the first publish point -- or poll -- after
+// their time has come, so that the hook delays rows without holding the wave (handoff.h
+// DelayedRows, for the wave's T chains at once).  Without the hook rows are stored at once.
+constexpr int ROWS_RING = 8;                 // refreshes a wave may be ahead of its held-back rows
+struct RowsLate {
+    int handed, sent;
+    unsigned stamp;                 // lane s: when the rows in slot s were produced
+    size_t zoff, stride;
+    double *ring;                   // LDS [ROWS_RING][64]
+    __device__ __forceinline__ void begin(const DevProblem &P, long long R0, size_t lane_off,
+                                          double *lds)
+    {
+        handed = sent = 0;
+        stamp = 0;
+        zoff = (size_t)(P.M0 + R0 * P.nchains) * ZROW + lane_off;
+        stride = (size_t)P.nchains * ZROW;
+        ring = lds;
+    }
+    __device__ __forceinline__ void drain(const DevProblem &P, const PeerTable<double> &peers,
+                                          int lane, bool keeps, bool all)
+    {
+        const unsigned delay = (unsigned)P.remote_delay;
+        while (sent < handed) {
+            const unsigned t = (unsigned)__builtin_amdgcn_readlane((int)stamp, sent % ROWS_RING);
+            if (realtime_ticks() - t < delay) {
+                if (!all && handed - sent < ROWS_RING)
+                    break;
+                continue;            // (the end of the launch, or a full ring: wait for it)
+            }
+            const double v = ring[(sent % ROWS_RING) * 64 + lane];
+            if (keeps)
+                peers.store(zoff, v, P.rank);
+            ++sent;
+            zoff += stride;
+        }
+    }
+    __device__ __forceinline__ void hand(const DevProblem &P, const PeerTable<double> &peers,
+                                         int lane, bool keeps, double xk)
+    {
+        ring[(handed % ROWS_RING) * 64 + lane] = xk;
+        const unsigned now = realtime_ticks();
+        stamp = (lane == handed % ROWS_RING) ? now : stamp;
+        ++handed;
+        __builtin_amdgcn_wave_barrier();
+        drain(P, peers, lane, keeps, false);
+    }
+};
+
 // What the three samplers' rows loops share: the wave's chains and their states, the data
 // sums of T proposals, the bookkeeping of an accepted step, the Z append.
 // (FX: some coefficients are fixed or shared, or carry Gaussian priors -- lane 16 r + k holds
 // FREE parameter k of its chain, coefficient j is free parameter kf[j] or the fixed value fx[j]
 // (handoff.h coefficient_map), lane 16 r + g works out prior g of its chain)
-template <int MT, int T, bool FX = false>
+// (P2P: the ensemble is sharded over GPUs -- rows are read from the local replica at system
+// scope and go into every rank's replica, the chain wave's own stores: a refresh of T chains
+// lasts longer than a remote store's acknowledgement, so no courier wave is needed; the
+// log_post columns go out sixteen refreshes at a time)
+template <int MT, int T, bool FX = false, bool P2P = false>
 struct RowsWave {
     static_assert(T >= 2 && T <= 4, "2..4 chains per wave");
     static_assert(MT >= 2 && MT <= 4, "polynomials of 2..4 coefficients");
@@ -99,11 +153,18 @@ struct RowsWave {
     double *zblock, *lp_row;
     int32_t *zc_row;
     size_t blockstride;
+    // log_post of the last (up to) 16 refreshes waits in lane 16 r + (refresh mod 16) of its
+    // chain's row and is written 16 at a time: nobody reads it inside the launch
+    double lpb;
+    int ndone;
+    PeerTable<double> peers_z;
+    PeerTableLazy<double> peers_lp;
+    RowsLate late;                  // (P2P, test hook: rows whose time has not come)
 
     // the first lane of the rows of chain q
     static constexpr int lane_of(int q) { return 16 * (T == 2 ? 2 * q : q); }
 
-    __device__ __forceinline__ void init(const DevProblem &P, long long R0)
+    __device__ __forceinline__ void init(const DevProblem &P, long long R0, double *lds_late = nullptr)
     {
         lane = threadIdx.x;
         row = lane >> 4;
@@ -138,6 +199,26 @@ struct RowsWave {
         pmin_k = mine ? P.fmin[k] : 0.0;
         pmax_k = mine ? P.fmax[k] : 0.0;
         rowmask = 0xffffull << (16 * row);
+        lpb = 0.0;
+        ndone = 0;
+        if constexpr (P2P) {
+            peers_z.load(P.peerZ, P.npeers);
+            peers_lp.load(P.peerLP, P.npeers);
+            if (P.remote_delay != 0) {
+                for (int i = lane; i < ROWS_RING * 64; i += 64)
+                    lds_late[i] = 0.0;
+                late.begin(P, R0, (size_t)c * ZS + k, lds_late);
+            }
+        }
+    }
+    // (test hook: the held-back rows keep going out while this wave waits for somebody's --
+    // ranks that wait for each other's held-back rows would never meet otherwise)
+    __device__ __forceinline__ void while_waiting(const DevProblem &P)
+    {
+        if constexpr (P2P) {
+            if (__builtin_expect(P.remote_delay != 0, 0))
+                late.drain(P, peers_z, lane, keeps, false);
+        }
     }
     // the chain of batch lane `q` (draws are made for the chains, not for the rows)
     __device__ __forceinline__ int chain_of(const DevProblem &P, int q) const
@@ -247,21 +328,51 @@ struct RowsWave {
         nacc += acc ? 1 : 0;
         if (keeps)
             __hip_atomic_store(zblock + (size_t)c * ZS + k, xk, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+                               P2P ? __HIP_MEMORY_SCOPE_SYSTEM : __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // P2P: the rows just published, into the other ranks' replicas (test hook P.remote_delay,
+    // MC3HIP_TEST_REMOTE_DELAY_NS: through the ring, when their time has come)
+    __device__ __forceinline__ void publish_remote(const DevProblem &P)
+    {
+        if constexpr (P2P) {
+            if (__builtin_expect(P.remote_delay != 0, 0))
+                late.hand(P, peers_z, lane, keeps, xk);
+            else if (keeps)
+                peers_z.store((size_t)(zblock - P.Z) + (size_t)c * ZS + k, xk, P.rank);
+        }
+    }
+    // the column of log_post / zchain values waiting in the rows' lanes: the first `count`
+    __device__ __forceinline__ void flush_columns(const DevProblem &P, int count) const
+    {
+        if (k < count && owner && exists) {
+            const size_t off = (size_t)k * n + c;
+            if constexpr (P2P)
+                peers_lp.store((size_t)(lp_row - P.log_post) + off, lpb);
+            else
+                lp_row[off] = lpb;
+            zc_row[off] = c;
+        }
     }
     // log posterior and chain index of the new rows; on to the next refresh
-    __device__ __forceinline__ void advance()
+    __device__ __forceinline__ void advance(const DevProblem &P)
     {
-        if (first) {
-            lp_row[c] = -0.5 * cur;
-            zc_row[c] = c;
+        const int s = ndone & 15;
+        lpb = (k == s) ? -0.5 * cur : lpb;
+        if (__builtin_expect(s == 15, 0)) {
+            flush_columns(P, 16);
+            lp_row += (size_t)16 * n;
+            zc_row += (size_t)16 * n;
         }
         zblock += blockstride;
-        lp_row += n;
-        zc_row += n;
+        ndone += 1;
     }
-    __device__ __forceinline__ void finish(const DevProblem &P) const
+    __device__ __forceinline__ void finish(const DevProblem &P)
     {
+        if constexpr (P2P) {
+            if (P.remote_delay != 0)
+                late.drain(P, peers_z, lane, keeps, true);
+        }
+        flush_columns(P, ndone & 15);               // the unwritten tail (also after an early exit)
         if (keeps)
             P.X[(size_t)l * nf + k] = xk;
         if (first) {
@@ -276,7 +387,7 @@ struct RowsWave {
 // DEMC (lean_demc_mc_kernel's shape): the partner rows are rows of the refresh before, asked
 // for at the top of a refresh and waited for; lane r T + q of a batch holds the draws of
 // refresh bbase + r, chain q of the wave (chain.py:221-232, :259).
-template <int MT, int T, bool FX = false>
+template <int MT, int T, bool FX = false, bool P2P = false>
 __global__ __launch_bounds__(64) void lean_demc_rows_kernel(const DevProblem P, const int nref)
 {
     constexpr int ZS = ZROW;
@@ -286,8 +397,9 @@ __global__ __launch_bounds__(64) void lean_demc_rows_kernel(const DevProblem P, 
             &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
         return;
     const long long R0 = P.ctl[0];
-    RowsWave<MT, T, FX> W;
-    W.init(P, R0);
+    __shared__ double s_late[P2P ? ROWS_RING * 64 : 1];
+    RowsWave<MT, T, FX, P2P> W;
+    W.init(P, R0, s_late);
     const int lane = W.lane, n = W.n;
     const double *pbase = (R0 == 0) ? P.snap0 : P.Z + (size_t)(P.M0 + (R0 - 1) * n) * ZS;
     const double gamma = P.gamma, feps = P.fepsilon;
@@ -325,8 +437,8 @@ __global__ __launch_bounds__(64) void lean_demc_rows_kernel(const DevProblem P, 
         addr[0] = pbase + (__builtin_amdgcn_ds_bpermute(from, bo1) + W.kk);
         addr[1] = pbase + (__builtin_amdgcn_ds_bpermute(from, bo2) + W.kk);
         double val[2];
-        val[0] = load_published<false>(addr[0]);
-        val[1] = load_published<false>(addr[1]);
+        val[0] = load_published<P2P>(addr[0]);
+        val[1] = load_published<P2P>(addr[1]);
         const double u = gather_f64(bu, from), lo = gather_f64(blo, from),
                      hi = gather_f64(bhi, from);
         __builtin_amdgcn_sched_barrier(0);
@@ -341,7 +453,7 @@ __global__ __launch_bounds__(64) void lean_demc_rows_kernel(const DevProblem P, 
         // last the other waves have published)
         if (__builtin_expect(__any(mc3_bits(val[0]) == ROW_PENDING ||
                                    mc3_bits(val[1]) == ROW_PENDING), 0)) {
-            alive = wait_rows<2, false>(addr, val, ctl_rw);
+            alive = wait_rows<2, P2P>(addr, val, ctl_rw, nullptr, [&]() { W.while_waiting(P); });
             __builtin_amdgcn_s_waitcnt(0x0F70);
             asm volatile("; rows of this refresh" : "+v"(val[0]), "+v"(val[1]));
             if (__builtin_expect(!alive, 0))
@@ -356,8 +468,9 @@ __global__ __launch_bounds__(64) void lean_demc_rows_kernel(const DevProblem P, 
         const bool acc = row_out ? false
                                  : metropolis_accept(0.5 * (W.cur - nextchisq), u, lo, hi);
         W.commit(P, acc, npk, nextchisq, R);
+        W.publish_remote(P);
         pbase = W.zblock;
-        W.advance();
+        W.advance(P);
     }
     W.finish(P);
 }
@@ -370,7 +483,7 @@ __global__ __launch_bounds__(64) void lean_demc_rows_kernel(const DevProblem P, 
 // compiler's wait counts (handoff.h load_published_async), retired behind this refresh's
 // publish, and no refresh waits for a round trip.  Same draws, same arithmetic, same results
 // as run_chain's with the same zlag.
-template <int MT, int T, bool FX = false>
+template <int MT, int T, bool FX = false, bool P2P = false>
 __global__ __launch_bounds__(64) void lean_demc_rows_lag_kernel(const DevProblem P, const int nref)
 {
     constexpr int ZS = ZROW;
@@ -380,8 +493,9 @@ __global__ __launch_bounds__(64) void lean_demc_rows_lag_kernel(const DevProblem
             &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
         return;
     const long long R0 = P.ctl[0];
-    RowsWave<MT, T, FX> W;
-    W.init(P, R0);
+    __shared__ double s_late[P2P ? ROWS_RING * 64 : 1];
+    RowsWave<MT, T, FX, P2P> W;
+    W.init(P, R0, s_late);
     const int lane = W.lane, n = W.n;
     const long long D = P.zlag;
     // the rows refresh R looks at: of refresh R - 1 - D
@@ -414,8 +528,8 @@ __global__ __launch_bounds__(64) void lean_demc_rows_lag_kernel(const DevProblem
     };
     // (asked for at ONE place per refresh, waited for at one: kernels_lean.h lean_snooker_mc_kernel)
     auto ask = [&](Step &S) {
-        S.val[0] = load_published_async(S.addr[0]);
-        S.val[1] = load_published_async(S.addr[1]);
+        S.val[0] = load_published_async<P2P>(S.addr[0]);
+        S.val[1] = load_published_async<P2P>(S.addr[1]);
     };
     auto prepare = [&](long long R, Step &S) {
         const int from = 4 * ((int)(R - bbase) * T + W.slot);    // whose draws this row needs
@@ -456,7 +570,7 @@ __global__ __launch_bounds__(64) void lean_demc_rows_lag_kernel(const DevProblem
                                    mc3_bits(C.val[1]) == ROW_PENDING), 0)) {
             const double *const a2[2] = {C.addr[0], C.addr[1]};
             double v2[2] = {C.val[0], C.val[1]};
-            alive = wait_rows<2, false>(a2, v2, ctl_rw);
+            alive = wait_rows<2, P2P>(a2, v2, ctl_rw, nullptr, [&]() { W.while_waiting(P); });
             // (nothing this path asked for is pending where it joins the other)
             __builtin_amdgcn_s_waitcnt(0x0F70);
             asm volatile("; rows of this refresh" : "+v"(v2[0]), "+v"(v2[1]));
@@ -478,8 +592,9 @@ __global__ __launch_bounds__(64) void lean_demc_rows_lag_kernel(const DevProblem
             double none = 0.0;
             published_arrived<1>(Nx.val[0], Nx.val[1], none);
         }
+        W.publish_remote(P);                       // (behind the wait: nothing waits for these)
         S = Nx;
-        W.advance();
+        W.advance(P);
     }
     W.finish(P);
 }
@@ -489,7 +604,7 @@ __global__ __launch_bounds__(64) void lean_demc_rows_lag_kernel(const DevProblem
 // batch holds Philox slot s' (0, 3, 4 for s = 0, 1, 2) of refresh bbase + i, chain q: the
 // Metropolis draw with its window from s = 0, the pairs of normal deviates of coefficients
 // 0-1 and 2-3 from s = 1, 2 (lean_mrw_kernel's fields).
-template <int MT, int T, bool FX = false>
+template <int MT, int T, bool FX = false, bool P2P = false>
 __global__ __launch_bounds__(64) void lean_mrw_rows_kernel(const DevProblem P, const int nref)
 {
     constexpr int NB = 64 / (3 * T);           // refreshes per batch of draws
@@ -498,8 +613,9 @@ __global__ __launch_bounds__(64) void lean_mrw_rows_kernel(const DevProblem P, c
             &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
         return;
     const long long R0 = P.ctl[0];
-    RowsWave<MT, T, FX> W;
-    W.init(P, R0);
+    __shared__ double s_late[P2P ? ROWS_RING * 64 : 1];
+    RowsWave<MT, T, FX, P2P> W;
+    W.init(P, R0, s_late);
     const int lane = W.lane;
     const double pstep_k = W.mine ? P.fstep[W.k] : 0.0;
     const long long abort_at =
@@ -546,7 +662,8 @@ __global__ __launch_bounds__(64) void lean_mrw_rows_kernel(const DevProblem P, c
         const bool acc = row_out ? false
                                  : metropolis_accept(0.5 * (W.cur - nextchisq), u, lo, hi);
         W.commit(P, acc, npk, nextchisq, R);
-        W.advance();
+        W.publish_remote(P);
+        W.advance(P);
     }
     W.finish(P);
 }
@@ -561,7 +678,7 @@ __global__ __launch_bounds__(64) void lean_mrw_rows_kernel(const DevProblem P, c
 // and the Metropolis draw with its window).  A refresh in which no chain of the wave makes a
 // snooker jump (two in three at four chains) never enters that path; in one that does, the
 // rows that do not are masked out of it.
-template <int MT, int T, bool FX = false>
+template <int MT, int T, bool FX = false, bool P2P = false>
 __global__ __launch_bounds__(64) void lean_snooker_rows_kernel(const DevProblem P, const int nref)
 {
     constexpr int ZS = ZROW;
@@ -571,8 +688,9 @@ __global__ __launch_bounds__(64) void lean_snooker_rows_kernel(const DevProblem 
             &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
         return;
     const long long R0 = P.ctl[0];
-    RowsWave<MT, T, FX> W;
-    W.init(P, R0);
+    __shared__ double s_late[P2P ? ROWS_RING * 64 : 1];
+    RowsWave<MT, T, FX, P2P> W;
+    W.init(P, R0, s_late);
     const int lane = W.lane, n = W.n;
     const double gamma = P.gamma, feps = P.fepsilon;
     const long long abort_at =
@@ -620,7 +738,7 @@ __global__ __launch_bounds__(64) void lean_snooker_rows_kernel(const DevProblem 
     auto ask = [&](Step &S) {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-            S.val[j] = load_published_async(S.addr[j]);
+            S.val[j] = load_published_async<P2P>(S.addr[j]);
     };
     auto prepare = [&](long long R, Step &S) {
         const int base = 4 * (3 * T * (int)(R - bbase) + W.slot);
@@ -661,7 +779,7 @@ __global__ __launch_bounds__(64) void lean_snooker_rows_kernel(const DevProblem 
                                    mc3_bits(C.val[2]) == ROW_PENDING), 0)) {
             const double *const a3[3] = {C.addr[0], C.addr[1], C.addr[2]};
             double v3[3] = {C.val[0], C.val[1], C.val[2]};
-            alive = wait_rows<3, false>(a3, v3, ctl_rw);
+            alive = wait_rows<3, P2P>(a3, v3, ctl_rw, nullptr, [&]() { W.while_waiting(P); });
             // (nothing this path asked for is pending where it joins the other)
             __builtin_amdgcn_s_waitcnt(0x0F70);
             asm volatile("; rows of this refresh" : "+v"(v3[0]), "+v"(v3[1]), "+v"(v3[2]));
@@ -702,8 +820,9 @@ __global__ __launch_bounds__(64) void lean_snooker_rows_kernel(const DevProblem 
         // the next refresh's rows: everything but the youngest operation of this wave -- the
         // publish above -- has completed
         published_arrived<1>(Nx.val[0], Nx.val[1], Nx.val[2]);
+        W.publish_remote(P);
         S = Nx;
-        W.advance();
+        W.advance(P);
     }
     W.finish(P);
 }

@@ -510,7 +510,10 @@ int decide_persist(mc3hip_ctx *c)
         // (mc3/chain.py:163,190-191).  The fewest turns whose grid fits: the waiting state of
         // a chain costs zs + 4 doubles of LDS, which can lower the occupancy, so the query is
         // repeated with the instance and the LDS size that would run.  One GPU only.
-        if ((c->flags & MC3HIP_FLAG_P2P) || c->p2p_ranks > 1 || getenv("MC3HIP_NO_MULTICHAIN"))
+        // One GPU -- or, sharded over several, the loops with the chains of a wave side by side
+        // (kernels_rows.h: up to four chains per wave, peer to peer as well).
+        const bool p2p_ctx = (c->flags & MC3HIP_FLAG_P2P) || c->p2p_ranks > 1;
+        if (getenv("MC3HIP_NO_MULTICHAIN") || (p2p_ctx && !(c->fast && lean_rows_shape(c))))
             return 0;
         // (the nine-wave wavelet kernel takes turns only with its hand-structured chain wave;
         // should its LDS not leave room for the waiting states, the fused kernel is tried)
@@ -525,7 +528,7 @@ int decide_persist(mc3hip_ctx *c)
             const bool cw_now = attempt == 0 && cw;
             const size_t base = c->smem + (cw_now ? CW_EXTRA_DOUBLES * sizeof(double) : 0);
             const int threads = cw_now ? CW_THREADS : 64 * c->wpc;
-            for (int turns = 2; turns <= MC_MAX_TURNS && !found; ++turns) {
+            for (int turns = 2; turns <= (p2p_ctx ? 4 : MC_MAX_TURNS) && !found; ++turns) {
                 c->mc_chains = turns;                       // (selects the MC instance)
                 const size_t smem = base + (size_t)turns * (c->P.zs + 4) * sizeof(double);
                 if (smem > 160 * 1024)
@@ -536,6 +539,13 @@ int decide_persist(mc3hip_ctx *c)
                     (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
                                               (int)smem);
                 int nbm = blocks_per_cu(f, threads, smem);
+                if (p2p_ctx) {
+                    // (a context made for the peer-to-peer hand-off runs the plain instance
+                    // until the peers are attached: both must fit)
+                    const int nbp = blocks_per_cu(
+                        reinterpret_cast<const void *>(fast_instance(c, true)), threads, smem);
+                    nbm = nbp < nbm ? nbp : nbm;
+                }
                 if (nbm > 1 && getenv("MC3HIP_PERSIST_MARGIN"))
                     nbm -= 1;
                 const long long grid = ((long long)c->P.nlocal + turns - 1) / turns;

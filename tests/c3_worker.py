@@ -42,6 +42,8 @@ def main():
     # (the declared cadence), lean_snooker_kernel / lean_mrw_kernel with their couriers
     if not os.environ.get('C3_WORKER_ANYPLAN'):         # (tools/dbg_ranks.py: other kernels)
         assert plan['fast'] == 2 and plan['persistent'] > 0 and plan['zlag'] == opts['zlag'], plan
+    if 'turns' in extra:                                # (kernels_rows.h, peer to peer)
+        assert plan['chains_per_workgroup'] == int(extra['turns']), plan
     if 'MC3HIP_TEST_REMOTE_DELAY_NS' in os.environ:
         assert plan['remote_delay_ns'] > 0, plan
     # two segments: the second persistent launch resumes from the replicas

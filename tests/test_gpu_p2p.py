@@ -96,7 +96,10 @@ def lean_ranks_case(tmp_path, nranks, nref, zlag, delay_ns=0, **shape):
     per_rank = shape.get('per_rank', 256)
     nchains = per_rank*nranks
     prob = H.lean_shape_problem(nchains, nref, **{k: v for k, v in shape.items()
-                                                  if k != 'per_rank'})
+                                                  if k not in ('per_rank', 'turns')})
+    env = {'MC3HIP_TEST_REMOTE_DELAY_NS': str(delay_ns)} if delay_ns else {}
+    if 'turns' in shape:       # (several chains per wave: pretend that fewer workgroups fit)
+        env['MC3HIP_PERSIST_CAPACITY'] = str(-(-per_rank//shape['turns']))
     orc = H.make_oracle(prob, zlag=zlag)
     Z0, lp0 = H.initial_population(orc)
     out_path = str(tmp_path / 'c3')
@@ -104,8 +107,7 @@ def lean_ranks_case(tmp_path, nranks, nref, zlag, delay_ns=0, **shape):
     orc.set_population(Z0, lp0)
     orc.run(nthreads=min(32, len(os.sched_getaffinity(0))))
     launch(nranks, 'c3_worker.py', out_path, nref, f'zlag={zlag}',
-           *[f'{k}={v}' for k, v in shape.items()],
-           env={'MC3HIP_TEST_REMOTE_DELAY_NS': str(delay_ns)} if delay_ns else None)
+           *[f'{k}={v}' for k, v in shape.items()], env=env or None)
     for rank in range(nranks):
         got = np.load(f'{out_path}.rank{rank}.npz')
         s = slice(per_rank*rank, per_rank*(rank + 1))
@@ -143,6 +145,20 @@ def test_hand_laid_out_loops_peer_to_peer(tmp_path, nranks, shape):
     wave) and 8 ranks (the chain wave stores itself) on the one GPU, rows held back 1.5 us,
     in the declared cadence (demc, snooker) / as ever (mrw looks at nobody)."""
     lean_ranks_case(tmp_path, nranks, 40, 2, 1500, per_rank=24, ndata=300, **shape)
+
+
+@pytest.mark.parametrize('nranks,turns', [(2, 3), (4, 2), (2, 4)])
+@pytest.mark.parametrize('shape,zlag', [
+    (dict(sampler='demc'), 2), (dict(sampler='demc'), 0), (dict(sampler='demc', fx=1), 1),
+    (dict(sampler='snooker'), 2), (dict(sampler='snooker', fx=1), 0), (dict(sampler='mrw'), 4)],
+    ids=lambda d: '-'.join(f'{k}{v}' for k, v in d.items()) if isinstance(d, dict) else f'zlag{d}')
+def test_rows_loops_peer_to_peer(tmp_path, nranks, turns, shape, zlag):
+    """kernels_rows.h peer to peer: every rank advances its chains two to four per wave, side by
+    side (MC3HIP_PERSIST_CAPACITY pretends that fewer workgroups fit), and stores the rows of a
+    wave's chains into every replica itself -- strict lockstep and the declared cadence, rows
+    held back 1.5 us, ragged last waves (23 chains per rank)."""
+    lean_ranks_case(tmp_path, nranks, 40, zlag, 1500, per_rank=23, ndata=300, turns=turns,
+                    **shape)
 
 
 @pytest.mark.parametrize('nranks,per_rank,ndata,nmodel,sampler,zlag', [
