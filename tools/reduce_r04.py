@@ -51,6 +51,7 @@ for rel, name in (('configs.jsonl', 'configs.jsonl'),
                   ('lag_configs.jsonl', 'lag_configs.jsonl'),
                   ('delay_sweep.jsonl', 'delay_sweep.jsonl'),
                   ('delay_sweep_c3.jsonl', 'delay_sweep_c3.jsonl'),
+                  ('delay_sweep_c3big.jsonl', 'delay_sweep_c3big.jsonl'),
                   ('kt_c2/c2_kernel_stats.csv', 'c2_lean_kernel_stats.csv'),
                   ('kt_c2/c2_agent_info.csv', 'agent_info.csv'),
                   ('kt_c3x4/c3x4_kernel_stats.csv', 'c3x4_kernel_stats.csv'),
