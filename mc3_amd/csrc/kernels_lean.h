@@ -329,9 +329,13 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
         if (__builtin_expect(!__any(outk), 1)) {
             // (helper waves: woken first -- lane j hands them coefficient j, free parameter j or
             // what FX maps there -- so that they work while this wave makes its own copy)
-            if constexpr (NW > 1)
-                helpers.order(FX ? (hkf < 0 ? hfx : lane_gather(npk, hkf < 0 ? 0 : hkf)) : npk,
-                              lane);
+            if constexpr (NW > 1) {
+                // (the gather by EVERY lane, then the choice: inside the conditional it would
+                // run with the fixed coefficients' lanes switched off, and a lane that is off
+                // hands ds_bpermute a zero -- found by tools/fuzz_hunt.py)
+                const double got = lane_gather(npk, hkf < 0 ? 0 : hkf);
+                helpers.order(FX ? (hkf < 0 ? hfx : got) : npk, lane);
+            }
             Model<MT> model;
             if constexpr (!FX) {
                 model.init_from_lanes(P, npk);                 // every coefficient is free
@@ -750,9 +754,10 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
         const double npk = xk + jump_k;
         const bool outk = mine && (npk < pmin_k || npk > pmax_k);
         if (__builtin_expect(!__any(outk), 1)) {
-            if constexpr (NW > 1)                    // (helper waves: as lean_demc_body's)
-                helpers.order(FX ? (hkf < 0 ? hfx : lane_gather(npk, hkf < 0 ? 0 : hkf)) : npk,
-                              lane);
+            if constexpr (NW > 1) {                  // (helper waves: as lean_demc_body's)
+                const double got = lane_gather(npk, hkf < 0 ? 0 : hkf);
+                helpers.order(FX ? (hkf < 0 ? hfx : got) : npk, lane);
+            }
             Model<MT> model;
             if constexpr (!FX) {
                 model.init_from_lanes(P, npk);

@@ -42,6 +42,14 @@ def linear_problem(k, nchains=12, nref=80, priors=False, **kw):
     return prob
 
 
+def with_pstep(prob, pstep):
+    pstep = np.array(pstep)
+    prob['pstep'] = pstep
+    for j in np.where(pstep < 0)[0]:                 # a shared parameter starts at its source's
+        prob['params'][j] = prob['params'][int(-pstep[j]) - 1]
+    return prob
+
+
 CASES = {
     'poly5-demc': lambda: poly_problem(5, sampler='demc'),
     'poly8-demc': lambda: poly_problem(8, sampler='demc'),
@@ -63,6 +71,18 @@ CASES = {
     'lin4-snooker-eps': lambda: linear_problem(4, sampler='snooker', fepsilon=0.02),
     'lin3-snooker-eps-priors': lambda: linear_problem(3, sampler='snooker', priors=True,
                                                       fepsilon=0.01),
+    # fixed and shared coefficients under the helper waves (a conditional gather once handed
+    # the helpers zeros for the coefficients behind a fixed one: tools/fuzz_hunt.py)
+    'lin8-snooker-fixed': lambda: with_pstep(linear_problem(8, sampler='snooker'),
+                                             [0.05, 0.05, 0.05, 0.05, 0.0, 0.05, 0.05, 0.05]),
+    'lin6-demc-fixed': lambda: with_pstep(linear_problem(6, sampler='demc'),
+                                          [0.05, 0.0, 0.0, 0.0, 0.05, 0.05]),
+    'lin10-snooker-fixed-shared-lag': lambda: with_pstep(
+        linear_problem(10, sampler='snooker', zlag=1),
+        [0.05, 0.0, 0.0, -1.0, -1.0, 0.05, 0.0, 0.05, 0.05, -1.0]),
+    'lin9-demc-shared-priors': lambda: with_pstep(
+        linear_problem(9, sampler='demc', priors=True),
+        [0.05, -1.0, 0.05, 0.0, 0.05, 0.05, 0.0, 0.05, 0.05]),
 }
 
 

@@ -18,10 +18,15 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 bad = 0
 for seed in range(first, first + count):
-    kind = seed % 3 if 'big' not in sys.argv else 3
+    kind = seed % 4 if 'big' not in sys.argv else 4
     if kind == 3:
-        # ensembles beyond what is co-resident: two to five chains per wave, the shapes the
-        # lean kernels serve (python tools/fuzz_hunt.py <first> <count> big)
+        # round 4's kernels: the declared cadence, the support distribution, the run-time
+        # specialised shapes
+        prob = F.round4_problem(seed)[0]
+    elif kind == 4:
+        # ensembles beyond what is co-resident: two to five chains per wave (kernels_rows.h, the
+        # turn-after-turn loops for two tiles), the shapes the lean kernels serve
+        # (python tools/fuzz_hunt.py <first> <count> big)
         prob, _ = F.lean_problem(seed)
         rs = np.random.RandomState(seed)
         nch = int(rs.randint(2049, 10000))
