@@ -1109,8 +1109,6 @@ void mc3hip_destroy(mc3hip_ctx *c)
         g_rccl.CommDestroy(c->comm);
     for (void *p : c->p2p_opened)
         (void)hipIpcCloseMemHandle(p);
-    if (c->jit_module)
-        (void)hipModuleUnload(c->jit_module);
     if (c->graph_exec)
         (void)hipGraphExecDestroy(c->graph_exec);
     if (c->graph)
@@ -1220,6 +1218,23 @@ int mc3hip_jit_request(const mc3hip_ctx *c, char *buf, int32_t capacity)
     return MC3HIP_OK;
 }
 
+// Code objects handed over by mc3hip_jit_install, per device: loaded once, shared by every
+// context that installs the same image, and never unloaded.  (Unloading with the context was
+// seen -- tools/fuzz_hunt.py, one process creating and destroying contexts in a row, 3 runs in
+// 16 -- to let the NEXT context's first allocation land on the module's address range while
+// the pages were still mapped read-only: "Memory access fault ... Write access to a read-only
+// page" in a kernel that writes nothing but its own buffers.  A handful of 20 KB images per
+// process is what it costs.)
+namespace {
+struct LoadedModule {
+    int device;
+    std::string image;
+    hipModule_t module;
+};
+std::mutex g_modules_lock;
+std::vector<LoadedModule> g_modules;
+}  // namespace
+
 int mc3hip_jit_install(mc3hip_ctx *c, const void *code_object, int64_t bytes,
                        const char *kernel_name)
 {
@@ -1233,18 +1248,25 @@ int mc3hip_jit_install(mc3hip_ctx *c, const void *code_object, int64_t bytes,
     HIP_TRY(hipSetDevice(c->device));
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
-    hipError_t e = hipModuleLoadData(&mod, code_object);
-    if (e != hipSuccess)
-        return fail(MC3HIP_ERR_HIP, "hipModuleLoadData failed: %s", hipGetErrorString(e));
+    hipError_t e = hipSuccess;
+    {
+        std::lock_guard<std::mutex> hold(g_modules_lock);
+        const std::string image(static_cast<const char *>(code_object), (size_t)bytes);
+        for (const LoadedModule &m : g_modules)
+            if (m.device == c->device && m.image == image)
+                mod = m.module;
+        if (!mod) {
+            e = hipModuleLoadData(&mod, code_object);
+            if (e != hipSuccess)
+                return fail(MC3HIP_ERR_HIP, "hipModuleLoadData failed: %s", hipGetErrorString(e));
+            g_modules.push_back(LoadedModule{c->device, image, mod});
+        }
+    }
     e = hipModuleGetFunction(&fn, mod, kernel_name);
-    if (e != hipSuccess) {
-        (void)hipModuleUnload(mod);
+    if (e != hipSuccess)
         return fail(MC3HIP_ERR_HIP, "kernel '%s' not in the code object: %s", kernel_name,
                     hipGetErrorString(e));
-    }
-    if (c->jit_module)
-        (void)hipModuleUnload(c->jit_module);
-    c->jit_module = mod;
+    c->jit_module = mod;                         // (shared: not this context's to unload)
     c->jit_fn = fn;
     c->persist_checked = false;                  // (the launch structure is decided anew)
     return MC3HIP_OK;

@@ -37,6 +37,8 @@ for seed in range(first, first + count):
         prob, _ = F.lean_problem(seed)
     else:
         prob = F.random_problem(seed, wavelet_any_model=True)
+    if os.environ.get('FUZZ_TRACE'):      # (a fault kills the process: say which seed is next)
+        print(f'seed {seed} kind {kind}', file=sys.stderr, flush=True)
     try:
         gpu = engine.DeviceChains(**prob)
         orc = H.make_oracle(prob, plan=gpu.plan)
