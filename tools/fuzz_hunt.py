@@ -30,7 +30,8 @@ for seed in range(first, first + count):
         prob, _ = F.lean_problem(seed)
         rs = np.random.RandomState(seed)
         nch = int(rs.randint(2049, 10000))
-        prob.update(nchains=nch, nsamples=nch*int(rs.randint(6, 16))*prob['thinning'])
+        prob.update(nchains=nch, nsamples=nch*int(rs.randint(6, 16))*prob['thinning'],
+                    zlag=int(rs.choice([0, 0, 1, 2, 5])))      # (strict, or the declared cadence)
     elif kind == 0:
         prob = F.random_problem(seed)
     elif kind == 1:
