@@ -153,8 +153,8 @@ struct RowsWave {
     double *zblock, *lp_row;
     int32_t *zc_row;
     size_t blockstride;
-    // log_post of the last (up to) 16 refreshes waits in lane 16 r + (refresh mod 16) of its
-    // chain's row and is written 16 at a time: nobody reads it inside the launch
+    // P2P: log_post of the last (up to) 16 refreshes waits in lane 16 r + (refresh mod 16) of
+    // its chain's row and is written 16 at a time: nobody reads it inside the launch
     double lpb;
     int ndone;
     PeerTable<double> peers_z;
@@ -356,6 +356,18 @@ struct RowsWave {
     // log posterior and chain index of the new rows; on to the next refresh
     __device__ __forceinline__ void advance(const DevProblem &P)
     {
+        if constexpr (!P2P) {
+            // (one GPU: written as they come -- the column buffer below measured 1 % slower at
+            // 8192 chains; peer to peer it saves a remote store per peer and refresh)
+            if (first) {
+                lp_row[c] = -0.5 * cur;
+                zc_row[c] = c;
+            }
+            zblock += blockstride;
+            lp_row += n;
+            zc_row += n;
+            return;
+        }
         const int s = ndone & 15;
         lpb = (k == s) ? -0.5 * cur : lpb;
         if (__builtin_expect(s == 15, 0)) {
@@ -372,7 +384,8 @@ struct RowsWave {
             if (P.remote_delay != 0)
                 late.drain(P, peers_z, lane, keeps, true);
         }
-        flush_columns(P, ndone & 15);               // the unwritten tail (also after an early exit)
+        if constexpr (P2P)
+            flush_columns(P, ndone & 15);           // the unwritten tail (also after an early exit)
         if (keeps)
             P.X[(size_t)l * nf + k] = xk;
         if (first) {
