@@ -314,6 +314,10 @@ struct RowsWave {
                                            double nextchisq, long long R)
     {
         xk = acc ? npk : xk;
+        // (the publish first -- everybody's next refresh waits for it -- the books after)
+        if (keeps)
+            __hip_atomic_store(zblock + (size_t)c * ZS + k, xk, __ATOMIC_RELAXED,
+                               P2P ? __HIP_MEMORY_SCOPE_SYSTEM : __HIP_MEMORY_SCOPE_AGENT);
         const bool better = acc && nextchisq < best;
         if (__builtin_expect(__any(better), 0)) {
             if (better) {
@@ -326,9 +330,6 @@ struct RowsWave {
         }
         cur = acc ? nextchisq : cur;
         nacc += acc ? 1 : 0;
-        if (keeps)
-            __hip_atomic_store(zblock + (size_t)c * ZS + k, xk, __ATOMIC_RELAXED,
-                               P2P ? __HIP_MEMORY_SCOPE_SYSTEM : __HIP_MEMORY_SCOPE_AGENT);
     }
     // P2P: the rows just published, into the other ranks' replicas (test hook P.remote_delay,
     // MC3HIP_TEST_REMOTE_DELAY_NS: through the ring, when their time has come)
@@ -435,6 +436,20 @@ __global__ __launch_bounds__(64) void lean_demc_rows_kernel(const DevProblem P, 
         bbase = base;
     };
     fill(R0);
+    // this row's draws of a refresh, through the crossbar -- fetched a refresh AHEAD, in the
+    // shadow of the wait for the partner rows, so that a refresh's requests leave the moment it
+    // starts instead of a crossbar round trip later (the loop is bound by the hand-off)
+    int o1, o2;
+    double u, lo, hi;
+    auto fetch = [&](long long R) {
+        const int from = 4 * ((int)(R - bbase) * T + W.slot);    // whose draws this row needs
+        o1 = __builtin_amdgcn_ds_bpermute(from, bo1) + W.kk;
+        o2 = __builtin_amdgcn_ds_bpermute(from, bo2) + W.kk;
+        u = gather_f64(bu, from);
+        lo = gather_f64(blo, from);
+        hi = gather_f64(bhi, from);
+    };
+    fetch(R0);
     const long long Rend = R0 + nref;
     __builtin_amdgcn_s_waitcnt(0x0F70);
     for (long long R = R0; R < Rend; ++R) {
@@ -445,21 +460,21 @@ __global__ __launch_bounds__(64) void lean_demc_rows_kernel(const DevProblem P, 
         }
         __builtin_amdgcn_s_sleep(1);
         // the partner rows of every chain of the wave: one request each
-        const int from = 4 * ((int)(R - bbase) * T + W.slot);    // whose draws this row needs
         const double *addr[2];
-        addr[0] = pbase + (__builtin_amdgcn_ds_bpermute(from, bo1) + W.kk);
-        addr[1] = pbase + (__builtin_amdgcn_ds_bpermute(from, bo2) + W.kk);
+        addr[0] = pbase + o1;
+        addr[1] = pbase + o2;
         double val[2];
         val[0] = load_published<P2P>(addr[0]);
         val[1] = load_published<P2P>(addr[1]);
-        const double u = gather_f64(bu, from), lo = gather_f64(blo, from),
-                     hi = gather_f64(bhi, from);
+        const double u_now = u, lo_now = lo, hi_now = hi;
         __builtin_amdgcn_sched_barrier(0);
         if (__builtin_expect(R - bbase == NB - 1, 0)) {
             // ... and behind them, once per batch, the draws of the next NB refreshes
             fill(R + 1);
             asm volatile("; pin" : "+v"(bu), "+v"(blo), "+v"(bhi), "+v"(bo1), "+v"(bo2));
         }
+        fetch(R + 1);
+        asm volatile("; draws of the next refresh" : "+v"(o1), "+v"(o2), "+v"(u), "+v"(lo), "+v"(hi));
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         // what is still the sentinel is asked for again (the rows of the refresh before are the
@@ -479,7 +494,8 @@ __global__ __launch_bounds__(64) void lean_demc_rows_kernel(const DevProblem P, 
         const double nextchisq = W.chisq_all(P, npk);
         // Metropolis, chain.py:257-274, every chain in its own rows
         const bool acc = row_out ? false
-                                 : metropolis_accept(0.5 * (W.cur - nextchisq), u, lo, hi);
+                                 : metropolis_accept(0.5 * (W.cur - nextchisq), u_now, lo_now,
+                                                     hi_now);
         W.commit(P, acc, npk, nextchisq, R);
         W.publish_remote(P);
         pbase = W.zblock;
