@@ -343,35 +343,22 @@ inline bool lean_mrw_eligible(const mc3hip_ctx *c)
     return lean_other_sampler_eligible(c, MC3HIP_MRW) && c->mt <= 4;
 }
 
-// ... and with two to four chains per wave: lean_snooker_mc_kernel, lean_mrw_mc_kernel
-inline bool lean_other_sampler_mc_eligible(const mc3hip_ctx *c, int sampler)
-{
-    const DevProblem &P = c->P;
-    return c->fast && c->mc_chains >= 2 && c->mc_chains <= 4 && P.sampler == sampler &&
-           (P.zlag == 0 || sampler == MC3HIP_MRW) && P.thinning == 1 && P.nparams == c->mt && P.zs == ZROW && P.npad <= VLANES &&
-           !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_LEAN");
-}
-inline bool lean_snooker_mc_eligible(const mc3hip_ctx *c)
-{
-    return lean_other_sampler_mc_eligible(c, MC3HIP_SNOOKER);
-}
-inline bool lean_mrw_mc_eligible(const mc3hip_ctx *c)
-{
-    return lean_other_sampler_mc_eligible(c, MC3HIP_MRW) && c->mt <= 4;
-}
-
-// ... and so has the same shape with two to four chains per wave: lean_demc_mc_kernel
+// ... and the same shape with two tiles and two or three chains per wave, one after another:
+// lean_demc_mc_kernel (the one-tile shapes of every sampler: kernels_rows.h, below)
 inline bool lean_demc_mc_eligible(const mc3hip_ctx *c)
 {
     // (four chains per wave AND two register-resident tiles do not fit the registers)
-    return c->fast && c->mc_chains >= 2 && c->mc_chains <= (c->P.npad > VLANES ? 3 : 4) &&
-           c->P.sampler == MC3HIP_DEMC && c->P.thinning == 1 && c->P.zlag == 0 &&
-           c->P.nparams == c->mt && c->P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
+    const DevProblem &P = c->P;
+    return c->fast && c->mc_chains >= 2 && c->mc_chains <= 3 && P.npad > VLANES &&
+           P.nfree == P.nparams && P.ngprior == 0 && P.nshare == 0 &&
+           P.sampler == MC3HIP_DEMC && P.thinning == 1 && P.zlag == 0 &&
+           P.nparams == c->mt && P.zs == ZROW && !(c->flags & MC3HIP_FLAG_P2P) &&
+           c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_LEAN");
 }
 
 // ... and, for the one-tile shapes of those, with the
 // chains of a wave side by side in its rows of 16 lanes: kernels_rows.h lean_*_rows_kernel
-// (MC3HIP_NO_ROWS: the turn-after-turn loops above)
+// (MC3HIP_NO_ROWS: the general lean instance takes turns, run_chain MC)
 // (the shapes those loops serve -- on one GPU or sharded over several, peer to peer -- whatever
 // the number of chains per wave decide_persist settles on)
 inline bool lean_rows_shape(const mc3hip_ctx *c)
@@ -383,8 +370,7 @@ inline bool lean_rows_shape(const mc3hip_ctx *c)
 }
 inline bool lean_rows_eligible(const mc3hip_ctx *c)
 {
-    // (every sampler, strict or in the declared cadence -- the turn-after-turn loops behind
-    // MC3HIP_NO_ROWS have no zlag flavour of DEMC and snooker: the general chain takes turns)
+    // (every sampler, strict or in the declared cadence)
     return c->fast && c->mc_chains >= 2 && c->mc_chains <= 4 && lean_rows_shape(c);
 }
 
@@ -442,6 +428,7 @@ chain_kernel_fn lean_lag_instance(const mc3hip_ctx *c, bool p2p);   // k_lean3.h
 chain_kernel_fn lean_other_p2p_instance(const mc3hip_ctx *c);       // k_lean4.hip
 chain_kernel_fn lean_demc_mc_instance(const mc3hip_ctx *c, bool p2p);   // k_lean5.hip
 chain_kernel_fn lean_rows_instance(const mc3hip_ctx *c, bool p2p);      // k_lean6.hip
+chain_kernel_fn lean_rows_instance_p2p(const mc3hip_ctx *c);            // k_lean7.hip
 
 // ---- k_tiled.hip: the tiled plan as three launches per iteration -------------------------
 void launch_propose(mc3hip_ctx *c, int roff, int j);

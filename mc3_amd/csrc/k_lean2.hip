@@ -1,5 +1,5 @@
 // k_lean2.hip -- instances of the hand-laid-out snooker and random-walk loops (one chain per
-// wave, thinning, streamed tiles, two to four chains per wave; kernels_lean.h); a translation
+// wave, thinning, streamed tiles; kernels_lean.h); a translation
 // unit of its own so that the library builds in parallel.
 #include "ctx.h"
 #include "kernels_lean.h"
@@ -11,21 +11,12 @@ namespace {
 template <int MT>
 chain_kernel_fn lean_other_instance_t(const mc3hip_ctx *c)
 {
-    // (2..4 chains per wave of the hand-laid-out snooker / random-walk loops)
-#define MC3_LEAN_SOLO_MC(KERNEL, TT)                                                \
-        if (c->mc_chains == TT)                                                     \
-            return lean_plain_shape(c) ? KERNEL<MT, TT> : KERNEL<MT, TT, true>;
     if (lean_mrw_eligible(c)) {
         if (c->P.thinning > 1)
             return lean_mrw_kernel<MT, false, true>;
         if (c->P.npad > VLANES)
             return lean_mrw_kernel<MT, false, false, true>;
         return lean_plain_shape(c) ? lean_mrw_kernel<MT> : lean_mrw_kernel<MT, true>;
-    }
-    if (lean_mrw_mc_eligible(c)) {
-        MC3_LEAN_SOLO_MC(lean_mrw_mc_kernel, 2)
-        MC3_LEAN_SOLO_MC(lean_mrw_mc_kernel, 3)
-        MC3_LEAN_SOLO_MC(lean_mrw_mc_kernel, 4)
     }
     if (lean_snooker_eligible(c)) {
         if (c->P.fepsilon != 0.0)                   // (thinning 1, one tile: fast_eligible)
@@ -38,12 +29,6 @@ chain_kernel_fn lean_other_instance_t(const mc3hip_ctx *c)
             return lean_snooker_kernel<MT, false, false, true>;
         return lean_plain_shape(c) ? lean_snooker_kernel<MT> : lean_snooker_kernel<MT, true>;
     }
-    if (lean_snooker_mc_eligible(c)) {
-        MC3_LEAN_SOLO_MC(lean_snooker_mc_kernel, 2)
-        MC3_LEAN_SOLO_MC(lean_snooker_mc_kernel, 3)
-        MC3_LEAN_SOLO_MC(lean_snooker_mc_kernel, 4)
-    }
-#undef MC3_LEAN_SOLO_MC
     return nullptr;
 }
 

@@ -1,4 +1,4 @@
-// k_lean5.hip -- instances of the hand-laid-out DEMC loop with two to four chains per wave
+// k_lean5.hip -- instances of the hand-laid-out DEMC loop with two or three chains per wave and two tiles
 // (kernels_lean.h lean_demc_mc_kernel) and with helper waves (lean_demc_wide_kernel, an
 // experiment behind MC3HIP_LEAN_WAVES); a translation unit of its own so that the library
 // builds in parallel.
@@ -12,20 +12,11 @@ namespace {
 template <int MT>
 chain_kernel_fn lean_demc_mc_instance_t(const mc3hip_ctx *c, bool p2p)
 {
-    if (lean_demc_mc_eligible(c) && !p2p) {          // 2..4 chains per wave
-#define MC3_LEAN_MC(TT)                                                             \
-        if (c->mc_chains == TT) {                                                   \
-            if (c->P.npad > VLANES)                                                 \
-                return lean_demc_mc_kernel<MT, (TT < 4 ? TT : 3), false, true>;     \
-            if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)  \
-                return lean_demc_mc_kernel<MT, TT, true>;                           \
-            /* (plain shapes: k_lean6.hip, unless MC3HIP_NO_ROWS) */                \
-            return lean_demc_mc_kernel<MT, TT>;                                     \
-        }
-        MC3_LEAN_MC(2)
-        MC3_LEAN_MC(3)
-        MC3_LEAN_MC(4)
-#undef MC3_LEAN_MC
+    // (two tiles, two or three chains per wave; the one-tile shapes: kernels_rows.h, k_lean6.hip)
+    if (lean_demc_mc_eligible(c) && !p2p) {
+        if (c->mc_chains == 2)
+            return lean_demc_mc_kernel<MT, 2, false, true>;
+        return lean_demc_mc_kernel<MT, 3, false, true>;
     }
     // (helper waves share a chain's data sum: the plain one-GPU headline shape, on request)
     if (!p2p && lean_demc_eligible(c) && c->P.fepsilon == 0.0 && c->P.npad <= VLANES &&

@@ -1384,448 +1384,9 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_lag_kernel(const
 }
 
 // ---------------------------------------------------------------------------------
-// lean_snooker_kernel / lean_mrw_kernel for ensembles with more chains than waves can be
-// co-resident (P.mc_chains = T, 2..4; one GPU): a wave owns chains b, b + G, ... of a grid of G
-// and advances them one after another inside every refresh, their states in registers (T a
-// compile-time constant), as lean_demc_mc_kernel.  Neither sampler waits for the rows of the
-// refresh before (snooker reads the history, nearly always published long ago; the random walk
-// reads nothing), so a turn is an iteration of the one-chain loop: the draws of 21 refreshes x
-// T chains at once, snooker's rows asked for one TURN ahead by loads outside the compiler's
-// wait counts (handoff.h load_published_async) and retired behind the publish of the turn
-// between.  Same draws, same arithmetic, same results as run_chain's turns.
-template <int MT, int T, bool FX = false>
-__global__ __launch_bounds__(64) void lean_snooker_mc_kernel(const DevProblem P, const int nref)
-{
-    static_assert(T >= 2 && T <= 4, "2..4 chains per wave");
-    const int nf = FX ? P.nfree : MT;
-    constexpr int ZS = ZROW;
-    constexpr int NB = 21;                     // refreshes per batch of draws (3 lanes each)
-    const int lane = threadIdx.x;
-    const int G = (int)gridDim.x, b = (int)blockIdx.x;
-    const bool mine = lane < nf;
-    const int kk = mine ? lane : 0;
-    long long *ctl_rw = const_cast<long long *>(P.ctl);
-    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
-            &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
-        return;
-    DataTile<1, MT> tile;
-    tile.load(P);
-    const long long R0 = P.ctl[0];
-    const int n = P.nchains;
-    const size_t blockstride = (size_t)n * ZS;
-    const double *pbase = (R0 == 0) ? P.snap0 : P.Z + (size_t)(P.M0 + (R0 - 1) * n) * ZS;
-    double *zblock = P.Z + (size_t)(P.M0 + R0 * n) * ZS;
-    double *lp_row = P.log_post + (P.M0 + R0 * n);
-    int32_t *zc_row = P.zchain + (P.M0 + R0 * n);
-    bool have[T];
-    int lq[T], cq[T], nacc[T];
-    double xk[T], cur[T], best[T], lpbuf[T];
-#pragma unroll
-    for (int q = 0; q < T; ++q) {
-        have[q] = b + q * G < P.nlocal;
-        lq[q] = have[q] ? b + q * G : b;
-        cq[q] = P.chain0 + lq[q];
-        xk[q] = mine ? pbase[(size_t)cq[q] * ZS + lane] : 0.0;
-        cur[q] = P.chisq[lq[q]];
-        best[q] = P.best_chisq[lq[q]];
-        nacc[q] = 0;
-        lpbuf[q] = 0.0;
-    }
-    const double pmin_k = mine ? P.fmin[lane] : 0.0;
-    const double pmax_k = mine ? P.fmax[lane] : 0.0;
-    const double gamma = P.gamma, feps = P.fepsilon;
-    const long long abort_at = (P.test_abort >= 0 && b == 0) ? (long long)P.test_abort : -1;
-    int kf[MT];
-    double fx[MT];
-    PriorLanes<MT> priors;
-    if constexpr (FX) {
-        coefficient_map<MT>(P, kf, fx);
-        priors.init(P, kf, fx, lane);
-    }
-    (void)kf; (void)fx; (void)priors;
-    // lane 3 i + s of chain q's batch: slot s of refresh bbase + i (the fields: as
-    // lean_snooker_kernel's)
-    unsigned long long A[T], B[T];
-    double blo[T], bhi[T];
-    long long bbase = R0;
-    const int bs = lane % 3, bi = (lane / 3 < NB) ? lane / 3 : NB - 1;
-    auto fill = [&](long long base) {
-        const long long Rl = base + bi;
-        const unsigned long long zsz = (unsigned long long)(P.M0 + Rl * n);
-#pragma unroll
-        for (int q = 0; q < T; ++q) {
-            const Draw2 d = draw2(P.seed, (uint64_t)Rl, (uint32_t)cq[q], (uint32_t)bs);
-            if (bs == 0) {
-                const unsigned long long iR1 = bounded(d.q0, zsz);
-                unsigned long long iR2 = 1 + bounded(d.q1, zsz - 1);
-                if (iR2 == iR1)
-                    iR2 = 0;
-                A[q] = iR1 * ZS;
-                B[q] = iR2 * ZS;
-            } else if (bs == 1) {
-                A[q] = bounded(d.q1, zsz) * ZS;
-                B[q] = (u01(d.q0) < 0.1) ? 1ull : 0ull;
-            } else {
-                A[q] = mc3_bits(1.2 + (2.2 - 1.2) * u01(d.q0));
-                B[q] = mc3_bits(u01(d.q1));
-            }
-            accept_window(u01(d.q1), blo[q], bhi[q]);
-        }
-        bbase = base;
-    };
-    auto lane64 = [&](unsigned long long v, int l) {
-        return (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l) |
-               ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l)
-                << 32);
-    };
-    struct Step {
-        int sj;
-        double gs, u, lo, hi;
-        const double *addr[3];
-        double val[3];
-    };
-    // (R inside the current batch.  The rows are asked for by ask(), at ONE place per turn,
-    // and waited for at one: registers that loads the compiler does not see are on their way
-    // to must not meet other values at a join of two paths -- the compiler would copy one of
-    // them into place there, i.e. copy what the load has not written yet)
-    auto ask = [&](Step &S) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            S.val[j] = load_published_async(S.addr[j]);
-    };
-    auto prepare = [&](long long R, unsigned long long Aq, unsigned long long Bq, double bloq,
-                       double bhiq, Step &S) {
-        const int idx = 3 * (int)(R - bbase);
-        S.addr[0] = P.Z + (lane64(Aq, idx) + (unsigned)kk);
-        S.addr[1] = P.Z + (lane64(Bq, idx) + (unsigned)kk);
-        S.addr[2] = P.Z + (lane64(Aq, idx + 1) + (unsigned)kk);
-        S.sj = lane64(Bq, idx + 1) != 0;
-        S.gs = mc3_from_bits(lane64(Aq, idx + 2));
-        S.u = mc3_from_bits(lane64(Bq, idx + 2));
-        S.lo = read_lane(bloq, idx + 2);
-        S.hi = read_lane(bhiq, idx + 2);
-    };
-    fill(R0);
-    Step S;
-    prepare(R0, A[0], B[0], blo[0], bhi[0], S);
-    ask(S);
-    published_arrived<0>(S.val[0], S.val[1], S.val[2]);
-    // (... and so is everything else loaded so far: a load the compiler knows of, still pending
-    // at the loop head, would make it guard its registers with a wait INSIDE the loop -- for
-    // everything in flight)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    const long long Rend = R0 + nref;
-    long long rdone = R0;
-    auto flush_columns = [&](int count) {
-        if (lane < count) {
-#pragma unroll
-            for (int q = 0; q < T; ++q) {
-                if (have[q]) {
-                    lp_row[(size_t)lane * n + cq[q]] = lpbuf[q];
-                    zc_row[(size_t)lane * n + cq[q]] = cq[q];
-                }
-            }
-        }
-    };
-    bool alive = true;
-    for (long long R = R0; alive && R < Rend; ++R) {
-        if (__builtin_expect(R == abort_at, 0)) {                                         // test hook
-            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-        const int slot = (int)(R - R0) & 63;
-#pragma unroll
-        for (int q = 0; q < T; ++q) {
-            if (!have[q])
-                break;
-            // the rows of this turn were asked for at the top of the turn before and retired at
-            // its bottom; the next turn's -- the next chain of this refresh, or the first of the
-            // next refresh -- are asked for now
-            Step C = S;
-            Step Nx;
-            const int qn = (q + 1 < T) ? q + 1 : 0;
-            if (q + 1 < T && have[qn]) {
-                prepare(R, A[qn], B[qn], blo[qn], bhi[qn], Nx);
-            } else {
-                if (__builtin_expect(R + 1 - bbase == NB, 0))
-                    fill(R + 1);
-                prepare(R + 1, A[0], B[0], blo[0], bhi[0], Nx);
-            }
-            ask(Nx);
-            // (one of the newest rows may still be the sentinel)
-            if (__builtin_expect(__any(mc3_bits(C.val[0]) == ROW_PENDING ||
-                                       mc3_bits(C.val[1]) == ROW_PENDING ||
-                                       mc3_bits(C.val[2]) == ROW_PENDING), 0)) {
-                const double *const a3[3] = {C.addr[0], C.addr[1], C.addr[2]};
-                double v3[3] = {C.val[0], C.val[1], C.val[2]};
-                alive = wait_rows<3, false>(a3, v3, ctl_rw);
-                // (nothing this path asked for is pending where it joins the other)
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-                asm volatile("; rows of this turn" : "+v"(v3[0]), "+v"(v3[1]), "+v"(v3[2]));
-                C.val[0] = v3[0];
-                C.val[1] = v3[1];
-                C.val[2] = v3[2];
-                if (__builtin_expect(!alive, 0))
-                    break;
-            }
-            const double z1 = C.val[0], z2 = C.val[1], zk = C.val[2];
-            const bool sjump = C.sj != 0;
-            double jump_k;
-            if (__builtin_expect(sjump, 0)) {                            // chain.py:207-215
-                const bool same = __all(!mine || zk == xk[q]);
-                if (same) {
-                    jump_k = C.gs * (z2 - z1);
-                } else {
-                    const double dz = xk[q] - zk;
-                    const double zp1 = lane_serial_sum(z1 * dz, nf);
-                    const double zp2 = lane_serial_sum(z2 * dz, nf);
-                    const double dd = lane_serial_sum(dz * dz, nf);
-                    jump_k = ((C.gs * (zp1 - zp2)) * dz) / dd;
-                }
-            } else {                                                     // chain.py:216-217
-                jump_k = gamma * (z1 - z2) + feps * 0.0;
-            }
-            // proposal and boundaries, chain.py:235-243
-            const double npk = xk[q] + jump_k;
-            const bool outk = mine && (npk < pmin_k || npk > pmax_k);
-            if (__builtin_expect(!__any(outk), 1)) {
-                Model<MT> model;
-                if constexpr (!FX) {
-                    model.init_from_lanes(P, npk);
-                } else {
-                    model.init_from_lanes(P, npk, kf, fx);
-                }
-                double nextchisq =
-                    block_gauss_model<1, MT, false, false>(P, model, nullptr, nullptr, tile,
-                                                           &tile);           // chain.py:249
-                if constexpr (FX)
-                    nextchisq = nextchisq + priors.term(npk, lane);
-                bool acc;
-                if (__builtin_expect(!sjump, 1)) {
-                    acc = metropolis_accept(0.5 * (cur[q] - nextchisq), C.u, C.lo, C.hi);
-                } else {                                                 // chain.py:251-255
-                    const double dc = xk[q] - zk, dn = npk - zk;
-                    const double cnorm = lane_serial_sum(mine ? dc * dc : 0.0, nf);
-                    const double nnorm = lane_serial_sum(mine ? dn * dn : 0.0, nf);
-                    const double mrfactor = mc3_det_pow_half(nnorm / cnorm, nf - 1);
-                    acc = mc3_det_exp(0.5 * (cur[q] - nextchisq)) * mrfactor > C.u;
-                }
-                xk[q] = acc ? npk : xk[q];
-                if (__builtin_expect(__any(acc && nextchisq < best[q]), 0)) {
-                    best[q] = nextchisq;
-                    if (mine)
-                        P.bestx[(size_t)lq[q] * nf + lane] = xk[q];
-                    if (lane == 0)
-                        P.best_iter[lq[q]] = R;
-                }
-                cur[q] = acc ? nextchisq : cur[q];
-                nacc[q] += acc ? 1 : 0;
-            } else if (outk) {
-                atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
-            }
-            // Z append, chain.py:276-289
-            if (mine)
-                __hip_atomic_store(zblock + (size_t)cq[q] * ZS + lane, xk[q], __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);            // publish (sc1)
-            // the next turn's rows: everything but the youngest operation of this wave -- the
-            // store above at least -- has completed
-            published_arrived<1>(Nx.val[0], Nx.val[1], Nx.val[2]);
-            S = Nx;
-            lpbuf[q] = (lane == slot) ? -0.5 * cur[q] : lpbuf[q];
-        }
-        if (__builtin_expect(!alive, 0))
-            break;
-        if (__builtin_expect(slot == 63, 0)) {
-            flush_columns(64);
-            lp_row += (size_t)64 * n;
-            zc_row += (size_t)64 * n;
-        }
-        zblock += blockstride;
-        rdone = R + 1;
-    }
-    flush_columns((int)(rdone - R0) & 63);
-#pragma unroll
-    for (int q = 0; q < T; ++q) {
-        if (!have[q])
-            continue;
-        if (mine)
-            P.X[(size_t)lq[q] * nf + lane] = xk[q];
-        if (lane == 0) {
-            P.chisq[lq[q]] = cur[q];
-            P.best_chisq[lq[q]] = best[q];
-            P.numaccept[lq[q]] = P.numaccept[lq[q]] + nacc[q];
-        }
-    }
-}
-
-template <int MT, int T, bool FX = false>
-__global__ __launch_bounds__(64) void lean_mrw_mc_kernel(const DevProblem P, const int nref)
-{
-    static_assert(MT >= 1 && MT <= 4, "two slots of normal deviates");
-    static_assert(T >= 2 && T <= 4, "2..4 chains per wave");
-    const int nf = FX ? P.nfree : MT;
-    constexpr int ZS = ZROW;
-    constexpr int NB = 21;
-    const int lane = threadIdx.x;
-    const int G = (int)gridDim.x, b = (int)blockIdx.x;
-    const bool mine = lane < nf;
-    long long *ctl_rw = const_cast<long long *>(P.ctl);
-    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
-            &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
-        return;
-    DataTile<1, MT> tile;
-    tile.load(P);
-    const long long R0 = P.ctl[0];
-    const int n = P.nchains;
-    const size_t blockstride = (size_t)n * ZS;
-    const double *pbase = (R0 == 0) ? P.snap0 : P.Z + (size_t)(P.M0 + (R0 - 1) * n) * ZS;
-    double *zblock = P.Z + (size_t)(P.M0 + R0 * n) * ZS;
-    double *lp_row = P.log_post + (P.M0 + R0 * n);
-    int32_t *zc_row = P.zchain + (P.M0 + R0 * n);
-    bool have[T];
-    int lq[T], cq[T], nacc[T];
-    double xk[T], cur[T], best[T], lpbuf[T];
-#pragma unroll
-    for (int q = 0; q < T; ++q) {
-        have[q] = b + q * G < P.nlocal;
-        lq[q] = have[q] ? b + q * G : b;
-        cq[q] = P.chain0 + lq[q];
-        xk[q] = mine ? pbase[(size_t)cq[q] * ZS + lane] : 0.0;
-        cur[q] = P.chisq[lq[q]];
-        best[q] = P.best_chisq[lq[q]];
-        nacc[q] = 0;
-        lpbuf[q] = 0.0;
-    }
-    const double pmin_k = mine ? P.fmin[lane] : 0.0;
-    const double pmax_k = mine ? P.fmax[lane] : 0.0;
-    const double pstep_k = mine ? P.fstep[lane] : 0.0;
-    const long long abort_at = (P.test_abort >= 0 && b == 0) ? (long long)P.test_abort : -1;
-    int kf[MT];
-    double fx[MT];
-    PriorLanes<MT> priors;
-    if constexpr (FX) {
-        coefficient_map<MT>(P, kf, fx);
-        priors.init(P, kf, fx, lane);
-    }
-    (void)kf; (void)fx; (void)priors;
-    // lane 3 i + s of chain q's batch: as lean_mrw_kernel's
-    double bu[T], blo[T], bhi[T], bcs[T], bsn[T];
-    long long bbase = R0;
-    const int bs = lane % 3, bi = (lane / 3 < NB) ? lane / 3 : NB - 1;
-    auto fill = [&](long long base) {
-#pragma unroll
-        for (int q = 0; q < T; ++q) {
-            const Draw2 d = draw2(P.seed, (uint64_t)(base + bi), (uint32_t)cq[q],
-                                  bs == 0 ? 0u : (uint32_t)(2 + bs));
-            bu[q] = u01(d.q1);                                           // chain.py:259
-            accept_window(bu[q], blo[q], bhi[q]);
-            const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(d.q0)));
-            double sn, cs;
-            mc3_det_sincos2pi(u01(d.q1), &sn, &cs);
-            bcs[q] = rad * cs;
-            bsn[q] = rad * sn;
-        }
-        bbase = base;
-    };
-    fill(R0);
-    const int src_off = 1 + (lane >> 1);
-    const long long Rend = R0 + nref;
-    long long rdone = R0;
-    auto flush_columns = [&](int count) {
-        if (lane < count) {
-#pragma unroll
-            for (int q = 0; q < T; ++q) {
-                if (have[q]) {
-                    lp_row[(size_t)lane * n + cq[q]] = lpbuf[q];
-                    zc_row[(size_t)lane * n + cq[q]] = cq[q];
-                }
-            }
-        }
-    };
-    // (everything loaded so far retired here: see lean_mrw_kernel)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    for (long long R = R0; R < Rend; ++R) {
-        if (__builtin_expect(R == abort_at, 0)) {                                         // test hook
-            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-        if (__builtin_expect(R - bbase == NB, 0))
-            fill(R);
-        const int idx = 3 * (int)(R - bbase);
-        const int slot = (int)(R - R0) & 63;
-        const int src = mine ? idx + src_off : idx;
-#pragma unroll
-        for (int q = 0; q < T; ++q) {
-            if (!have[q])
-                break;
-            const double u_now = read_lane(bu[q], idx), lo_now = read_lane(blo[q], idx),
-                         hi_now = read_lane(bhi[q], idx);
-            const double gc = lane_gather(bcs[q], src), gs = lane_gather(bsn[q], src);
-            const double jump_k = mine ? ((lane & 1) ? gs : gc) * pstep_k : 0.0;
-            // proposal and boundaries, chain.py:235-243
-            const double npk = xk[q] + jump_k;
-            const bool outk = mine && (npk < pmin_k || npk > pmax_k);
-            if (__builtin_expect(!__any(outk), 1)) {
-                Model<MT> model;
-                if constexpr (!FX) {
-                    model.init_from_lanes(P, npk);
-                } else {
-                    model.init_from_lanes(P, npk, kf, fx);
-                }
-                double nextchisq =
-                    block_gauss_model<1, MT, false, false>(P, model, nullptr, nullptr, tile,
-                                                           &tile);           // chain.py:249
-                if constexpr (FX)
-                    nextchisq = nextchisq + priors.term(npk, lane);
-                const bool acc = metropolis_accept(0.5 * (cur[q] - nextchisq), u_now, lo_now,
-                                                   hi_now);
-                xk[q] = acc ? npk : xk[q];
-                if (__builtin_expect(__any(acc && nextchisq < best[q]), 0)) {
-                    best[q] = nextchisq;
-                    if (mine)
-                        P.bestx[(size_t)lq[q] * nf + lane] = xk[q];
-                    if (lane == 0)
-                        P.best_iter[lq[q]] = R;
-                }
-                cur[q] = acc ? nextchisq : cur[q];
-                nacc[q] += acc ? 1 : 0;
-            } else if (outk) {
-                atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
-            }
-            // Z append, chain.py:276-289
-            if (mine)
-                __hip_atomic_store(zblock + (size_t)cq[q] * ZS + lane, xk[q], __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            lpbuf[q] = (lane == slot) ? -0.5 * cur[q] : lpbuf[q];
-        }
-        if (__builtin_expect(slot == 63, 0)) {
-            flush_columns(64);
-            lp_row += (size_t)64 * n;
-            zc_row += (size_t)64 * n;
-        }
-        zblock += blockstride;
-        rdone = R + 1;
-    }
-    flush_columns((int)(rdone - R0) & 63);
-#pragma unroll
-    for (int q = 0; q < T; ++q) {
-        if (!have[q])
-            continue;
-        if (mine)
-            P.X[(size_t)lq[q] * nf + lane] = xk[q];
-        if (lane == 0) {
-            P.chisq[lq[q]] = cur[q];
-            P.best_chisq[lq[q]] = best[q];
-            P.numaccept[lq[q]] = P.numaccept[lq[q]] + nacc[q];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------
 // The same loop for ensembles with more chains than waves can be co-resident (P.mc_chains = T,
-// 2..4; one GPU): a wave owns chains b, b + G, ... b + (T - 1) G of a grid of G and advances
+// 2..3; one GPU) whose data fill TWO tiles (MULTI; the one-tile shapes of every sampler have the
+// chains of a wave side by side instead: kernels_rows.h): a wave owns chains b, b + G, ... b + (T - 1) G of a grid of G and advances
 // them one after another inside every refresh -- the turns of run_chain MC.  There a turn
 // costs ~1.1 us whatever the occupancy (tools/mc_probe.py), of which the arithmetic is ~0.5:
 // every turn waits for the round trip of its own partner rows.  Here

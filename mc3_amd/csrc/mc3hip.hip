@@ -1142,7 +1142,6 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
     plan->fast = (plan->persistent > 0 && c->fast)
                      ? ((lean_demc_eligible(c) || lean_demc_mc_eligible(c) ||
                          lean_snooker_eligible(c) || lean_mrw_eligible(c) ||
-                         lean_snooker_mc_eligible(c) || lean_mrw_mc_eligible(c) ||
                          lean_demc_lag_eligible(c) || lean_rows_eligible(c) ||
                          jit_serves(c)) ? 2 : 1) : 0;
     plan->jit = (plan->fast == 2 && jit_serves(c)) ? 1 : 0;

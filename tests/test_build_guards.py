@@ -23,7 +23,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'mc3_amd', 'csrc')
-UNITS = ('k_lean2.hip', 'k_lean3.hip', 'k_lean4.hip', 'k_lean6.hip')
+UNITS = ('k_lean2.hip', 'k_lean3.hip', 'k_lean4.hip', 'k_lean6.hip', 'k_lean7.hip')
 pytestmark = pytest.mark.timeout(900)
 
 

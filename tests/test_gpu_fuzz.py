@@ -371,8 +371,8 @@ def test_rows_kernels_random_problem(seed, monkeypatch):
     """kernels_rows.h, fuzzed: one-tile polynomial shapes (fixed / shared coefficients and priors
     among them) with two to four chains per wave
     (MC3HIP_PERSIST_CAPACITY pretends that fewer workgroups fit), every sampler, ragged
-    ensembles, tight bounds, tiny histories; a third of the seeds on the turn-after-turn loops
-    behind MC3HIP_NO_ROWS -- both must equal the oracle exactly."""
+    ensembles, tight bounds, tiny histories; a third of the seeds behind MC3HIP_NO_ROWS (the general
+    lean instance takes turns) -- both must equal the oracle exactly."""
     from mc3_amd import engine
     rs = np.random.RandomState(12000 + seed)
     prob = None
@@ -400,7 +400,7 @@ def test_rows_kernels_random_problem(seed, monkeypatch):
     plan = gpu.plan
     label = f"{layout} {flavour} {prob['sampler']} poly{prob['nmodel']} ndata={len(prob['data'])} " \
             f"nchains={nchains} turns={turns} hsize={prob['hsize']} pstep={prob['pstep']} plan={plan}"
-    assert plan['persistent'] > 0 and plan['fast'] == 2, label
+    assert plan['persistent'] > 0 and plan['fast'] == (2 if layout == 'rows' else 1), label
     assert plan['chains_per_workgroup'] == turns, label
     orc = H.make_oracle(prob, plan=plan)
     Z0, lp0 = H.initial_population(orc, seed=seed)
@@ -410,6 +410,6 @@ def test_rows_kernels_random_problem(seed, monkeypatch):
     nz = gpu.nzchain
     gpu.run(nz//3)
     gpu.run()
-    assert gpu.plan['fast'] == 2 and gpu.plan['recoveries'] == 0, label
+    assert gpu.plan['fast'] == plan['fast'] and gpu.plan['recoveries'] == 0, label
     compare_final(gpu, orc, label)
     gpu.close()

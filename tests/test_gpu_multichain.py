@@ -208,8 +208,8 @@ def test_switch_off(eng, monkeypatch):
 
 
 def layout_switch(monkeypatch, layout, case):
-    """'rows': the chains of a wave side by side (kernels_rows.h, the default for plain
-    shapes); 'turns': one after another (lean_*_mc_kernel, MC3HIP_NO_ROWS)."""
+    """'rows': the chains of a wave side by side (kernels_rows.h); 'turns': one after another on
+    the general lean instance (run_chain MC, behind MC3HIP_NO_ROWS: plan.fast == 1)."""
     if layout == 'turns':
         monkeypatch.setenv('MC3HIP_NO_ROWS', '1')
 
@@ -218,7 +218,7 @@ def layout_switch(monkeypatch, layout, case):
 @pytest.mark.parametrize('turns', [2, 3, 4])
 @pytest.mark.parametrize('case', ['resume', 'abort', 'tight', 'priors', 'ragged'])
 def test_lean_demc_loop_with_several_chains_per_wave(eng, monkeypatch, case, turns, layout):
-    """lean_demc_rows_kernel / lean_demc_mc_kernel<.., T>: launches of a few refreshes (each
+    """lean_demc_rows_kernel<.., T> (and run_chain MC behind the switch): launches of a few refreshes (each
     starts a batch of draws anew and reloads the chains' states), a give-up, bounds that reject
     most proposals, Gaussian priors (FX), an ensemble that leaves the last turn of some waves
     empty."""
@@ -251,7 +251,7 @@ def test_lean_demc_loop_with_several_chains_per_wave(eng, monkeypatch, case, tur
             gpu.run(n)
     else:
         orc, gpu = run_pair(eng, prob, trace=False)
-    check_plan(gpu, turns=turns, fast=2)
+    check_plan(gpu, turns=turns, fast=2 if layout == 'rows' else 1)
     assert_same(orc, gpu, trace=False)
     if case == 'tight':
         assert gpu.state()['outbounds'].sum() > 50
@@ -264,8 +264,8 @@ def test_lean_demc_loop_with_several_chains_per_wave(eng, monkeypatch, case, tur
 @pytest.mark.parametrize('case', ['resume', 'abort', 'tight', 'priors', 'ragged', 'thin'])
 def test_lean_snooker_and_mrw_loops_with_several_chains_per_wave(eng, monkeypatch, case, sampler,
                                                                  turns, layout):
-    """lean_*_rows_kernel / lean_snooker_mc_kernel / lean_mrw_mc_kernel<.., T>: launches of a few
-    refreshes, a
+    """lean_snooker_rows_kernel / lean_mrw_rows_kernel<.., T> (and run_chain MC behind the switch):
+    launches of a few refreshes, a
     give-up, bounds that reject most proposals, Gaussian priors (FX), an ensemble that leaves
     the last turn of some waves empty, a history of one row per chain (snooker draws from the
     newest rows: the wait for a row that is still the sentinel)."""
@@ -300,7 +300,7 @@ def test_lean_snooker_and_mrw_loops_with_several_chains_per_wave(eng, monkeypatc
             gpu.run(n)
     else:
         orc, gpu = run_pair(eng, prob, trace=False)
-    check_plan(gpu, turns=turns, fast=2)
+    check_plan(gpu, turns=turns, fast=2 if layout == 'rows' else 1)
     assert_same(orc, gpu, trace=False)
     if case == 'tight':
         assert gpu.state()['outbounds'].sum() > 50
