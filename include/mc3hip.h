@@ -107,7 +107,13 @@ typedef struct mc3hip_problem {
                                zlag), not their sum.  0 = strict (the one-GPU default).  Results
                                depend on zlag and on nothing else: not on how the chains are
                                sharded, not on the launch structure              */
-    int32_t reserved0;      /* 0 */
+    int32_t wl_nreal;       /* wavelet likelihood of a series whose length is no power of two:
+                               the caller pads data / uncert / indep to ndata = 2^M points and
+                               says here how many of them are data (0 or ndata: all).  The
+                               residuals of the padding points are exactly zero whatever the
+                               model says there -- the zero padding of src_c/_dwt.c:82-91 made
+                               well defined (the reference then transforms the UNPADDED length,
+                               _dwt.c:94, which only 2^M survives); ignored without wlike      */
 } mc3hip_problem;
 
 /* how the library sums over data points (the checker follows the same order) */

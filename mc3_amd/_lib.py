@@ -46,7 +46,7 @@ class Problem(ctypes.Structure):
         ('params', _dp), ('pstep', _dp), ('pmin', _dp), ('pmax', _dp),
         ('prior', _dp), ('priorlow', _dp), ('priorup', _dp),
         ('indep', _dp), ('data', _dp), ('uncert', _dp),
-        ('zlag', ctypes.c_int32), ('reserved0', ctypes.c_int32),
+        ('zlag', ctypes.c_int32), ('wl_nreal', ctypes.c_int32),
     ]
 
 

@@ -104,7 +104,8 @@ struct DevProblem {
     // wavelet likelihood, abscissae on np.linspace's grid (x_i = fl(fl(i*step) + x0), last
     // point = wl_xlast; checked bit for bit at creation): they are recomputed instead of
     // stored, which frees the LDS for the data values
-    int32_t wl_grid, _pad_grid;
+    int32_t wl_grid;
+    int32_t wl_nreal;       // wavelet: points that are data (<= ndata; the rest is zero padding)
     double wl_x0, wl_step, wl_xlast;
     const double *data_t;         // wavelet: the data as [j][t] (thread t's j-th point)
     double *wl_scratch;           // wavelet, ndata > 2^14: [blocks][3 ndata / 4] pre-level values

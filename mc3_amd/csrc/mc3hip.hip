@@ -734,6 +734,8 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
                         "wavelet likelihood needs power-of-two ndata (got %d)", pr->ndata);
         if (pr->ndata > (1 << 22))
             return fail(MC3HIP_ERR_ARG, "wavelet likelihood supports ndata <= 2^22");
+        if (pr->wl_nreal < 0 || pr->wl_nreal > pr->ndata)
+            return fail(MC3HIP_ERR_ARG, "wl_nreal=%d outside [0,%d]", pr->wl_nreal, pr->ndata);
     }
     if (pr->M0 < 2 || pr->zlen < pr->M0)
         return fail(MC3HIP_ERR_ARG, "bad Z sizes (M0=%lld zlen=%lld)", (long long)pr->M0,
@@ -914,7 +916,10 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
             TRY(dev_upload(c, &P.aw, aw.data(), aw.size()));
         }
     }
-    if (pr->wlike && pr->model_kind == MC3HIP_MODEL_POLY && nd >= 2 && !getenv("MC3HIP_NO_GRID")) {
+    // (a padded series, wl_nreal < ndata: the abscissae of the padding are the caller's)
+    P.wl_nreal = (pr->wlike && pr->wl_nreal > 0) ? pr->wl_nreal : pr->ndata;
+    if (pr->wlike && pr->model_kind == MC3HIP_MODEL_POLY && nd >= 2 && !getenv("MC3HIP_NO_GRID") &&
+        P.wl_nreal == pr->ndata) {
         // abscissae made by numpy.linspace (y = arange(num) * step + start, y[-1] = stop)?
         // Checked bit for bit; if so the wavelet kernel recomputes them (block_wavelet)
         const double x0 = pr->indep[0], xl = pr->indep[nd - 1];

@@ -118,6 +118,11 @@ __device__ __forceinline__ double weigh_levels(const double (&accs)[NACC], const
 // the register-resident tile.  Returns the level's sum of squared details.
 // VALUES: the block's inputs are values already (the output of the pre-levels of a large
 // data set, in global memory as a plain array), not residuals to be formed.
+// Only the first P.wl_nreal points are data (normally all; otherwise the rest pads the series to a
+// power of two, the reference's zero padding src_c/_dwt.c:82-91 made well defined:
+// mc3hip_problem.wl_nreal): the residual of a padding point is exactly zero, whatever the model
+// says there.  A padded series is never on a grid, so only the general flavour (GRID = false)
+// looks -- a compare and a select per point there, nothing on the grid flavour C4 runs.
 template <int WPC, int MT, int B, bool GRID, int CAP, bool VALUES = false>
 __device__ __forceinline__ double wavelet_level0(const DevProblem &P, const Model<MT> &model,
                                                  const double *xs, int me, int next, int Ta,
@@ -201,7 +206,12 @@ __device__ __forceinline__ double wavelet_level0(const DevProblem &P, const Mode
     // non-zero, so the detail of its pair and with it this level's sum of squares is not
     // finite -- one test per block below, and only then are the block's model values (and the
     // two halo points', which enter its last pair) looked at one by one.
-    auto resid = [&](int j) {                           // j: static index into the block
+    // points of the block, and of the next block's first two, that are data
+    constexpr bool PAD = !GRID && !VALUES;
+    const int nreal_me = PAD ? P.wl_nreal - base : B;
+    const int nreal_next = PAD ? P.wl_nreal - B * next : 2;
+    (void)nreal_me; (void)nreal_next;
+    auto resid_of = [&](int j) {                        // j: static index into the block
         if constexpr (VALUES) {
             return in0[j];
         } else if constexpr (MT == MT_LINEAR) {
@@ -211,6 +221,13 @@ __device__ __forceinline__ double wavelet_level0(const DevProblem &P, const Mode
         } else {
             return in1[j] - model_value(j, in0[j]);
         }
+    };
+    auto resid = [&](int j) {
+        const double r = resid_of(j);
+        if constexpr (PAD)
+            return ((j < B) ? j < nreal_me : j - B < nreal_next) ? r : 0.0;
+        else
+            return r;
     };
     auto rescan = [&]() {
         int seen = 0;
@@ -344,7 +361,7 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
     if constexpr (VALUES)
         accA[0] = wavelet_level0<WPC, MT, B, false, HB + 2, true>(P, model, xs, me, next, Ta,
                                                                   sawinf, v, values);
-    else if (MT != MT_LINEAR && P.wl_grid)
+    else if (MT != MT_LINEAR && P.wl_grid)                  // (never a padded series)
         accA[0] = wavelet_level0<WPC, MT, B, true, HB + 2>(P, model, xs, me, next, Ta, sawinf, v);
     else
         accA[0] = wavelet_level0<WPC, MT, B, false, HB + 2>(P, model, xs, me, next, Ta, sawinf, v);
@@ -543,7 +560,10 @@ __device__ double wavelet_large(const DevProblem &P, const double *s_nextp, doub
             const double2 da = *reinterpret_cast<const double2 *>(P.data + j0);
             const double2 db = *reinterpret_cast<const double2 *>(P.data + j2);
             double s2, d;
-            d4_pair(da.x - m0, da.y - m1, db.x - m2, db.y - m3, s2, d);
+            // (a padded series, P.wl_nreal < ndata: the padding points' residuals are zero)
+            const int nr = P.wl_nreal;
+            d4_pair(j0 < nr ? da.x - m0 : 0.0, j0 + 1 < nr ? da.y - m1 : 0.0,
+                    j2 < nr ? db.x - m2 : 0.0, j2 + 1 < nr ? db.y - m3 : 0.0, s2, d);
             bufA[i] = s2;
             acc = mc3_fma(d, d, acc);
         }

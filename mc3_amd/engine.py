@@ -29,7 +29,7 @@ class DeviceChains:
                  nsamples=None, sampler='snooker', wlike=False, thinning=1,
                  fgamma=1.0, fepsilon=0.0, hsize=10, model='poly', nmodel=None,
                  seed=0, device=0, chain0=0, nlocal=None, M0=None, zlen=None,
-                 trace_iters=0, no_graph=False, no_persist=False, p2p=False, zlag=0,
+                 trace_iters=0, no_graph=False, no_persist=False, p2p=False, zlag=0, wl_nreal=0,
                  no_courier=False, jit=True):
         self._ctx = None
         self.lib = _lib.load()
@@ -102,6 +102,8 @@ class DeviceChains:
         # the declared cadence of a run sharded over GPUs (include/mc3hip.h mc3hip_problem.zlag)
         self.zlag = int(zlag)
         P.zlag = self.zlag
+        # a wavelet series padded to 2^M points: how many are data (mc3hip_problem.wl_nreal)
+        P.wl_nreal = int(wl_nreal)
         for name in ('params', 'pstep', 'pmin', 'pmax', 'prior', 'priorlow',
                      'priorup', 'indep', 'data', 'uncert'):
             setattr(P, name, dptr(getattr(self, name)))

@@ -202,7 +202,7 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
          fgamma, fepsilon, hsize, kickoff, savefile, resume, log,
          pnames, texnames,
          seed=None, device=0, comm=None, engine_factory=None, kickoff_stream=None,
-         zlag=None, _extras=None):
+         zlag=None, wpad=False, _extras=None):
     """Run the chains and assemble the output dictionary (see module docstring).
 
     ``ncpu`` is accepted for signature compatibility and ignored: the fan-out
@@ -215,7 +215,11 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
     'numpy' (the global NumPy stream in the reference's order: with np.random.seed set,
     the population equals the reference's); ``zlag``: the declared cadence of a run sharded
     over GPUs (include/mc3hip.h mc3hip_problem.zlag; default: 0 on one GPU, the
-    communicator's choice -- parallel.DEFAULT_ZLAG -- over several).
+    communicator's choice -- parallel.DEFAULT_ZLAG -- over several); ``wpad``: the wavelet
+    likelihood of a series whose length is no power of two -- padded with zero residuals to the
+    next one, the zero padding src_c/_dwt.c:82-91 intends (the reference then transforms the
+    unpadded length, _dwt.c:94, which only a power of two survives: without the flag such a
+    series is refused).
     """
     data = np.asarray(data, float)
     params = np.array(params, float)
@@ -264,16 +268,33 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
     lowered = models.lower(func, params, indparams, indparams_dict, len(data),
                            wlike, pstep)
     data_dev = data if lowered.offset is None else data - lowered.offset
+    uncert_dev, indep_dev, padded = uncert, lowered.indep, {}
+    ndata = len(data)
+    if wlike and ndata >= 2 and ndata & (ndata - 1):
+        if not wpad:
+            raise ValueError(
+                f'the wavelet likelihood needs a power-of-two number of data points (got '
+                f'{ndata}): the reference zero-pads the residuals and then transforms the '
+                'UNPADDED length (src_c/_dwt.c:82-94), which is not defined; wpad=True pads '
+                'the series with zero residuals to the next power of two')
+        # data 0, uncert 1, the abscissae (design columns) repeat their last value: finite
+        # model values there, and residuals that are zero by decree (mc3hip_problem.wl_nreal)
+        pad = (1 << int(np.ceil(np.log2(ndata)))) - ndata
+        data_dev = np.concatenate([data_dev, np.zeros(pad)])
+        uncert_dev = np.concatenate([np.asarray(uncert, float), np.ones(pad)])
+        indep_dev = np.concatenate(
+            [indep_dev, np.repeat(indep_dev[..., -1:], pad, axis=-1)], axis=-1)
+        padded = {'wl_nreal': ndata}
     if seed is None:
         seed = comm.broadcast(random.randint(0, 100000))
     chain0, nlocal = comm.partition(nchains)
     engine = engine_factory(
-        data=data_dev, uncert=uncert, indep=lowered.indep, params=params,
+        data=data_dev, uncert=uncert_dev, indep=indep_dev, params=params,
         pstep=pstep, pmin=pmin, pmax=pmax, prior=prior, priorlow=priorlow,
         priorup=priorup, nchains=nchains, sampler=sampler, wlike=wlike,
         thinning=thinning, fgamma=fgamma, fepsilon=fepsilon, hsize=hsize,
         model=lowered.family, nmodel=lowered.ncoef, seed=seed, device=device,
-        chain0=chain0, nlocal=nlocal, M0=M0, zlen=zlen,
+        chain0=chain0, nlocal=nlocal, M0=M0, zlen=zlen, **padded,
         **comm.engine_options(device, thinning, zlag))
     view = ChainView(engine, func, indparams, indparams_dict, data, wlike,
                      lowered.offset)

@@ -187,7 +187,9 @@ def sample(
       (mc3_amd.parallel communicator for multi-GPU runs: every rank makes the same
       call and gets the same dictionary; files are written by rank 0 only), ``zlag`` (the
       declared cadence of a sharded run: the other chains are seen that many refreshes late,
-      include/mc3hip.h; default 0 on one GPU, parallel.DEFAULT_ZLAG over several).
+      include/mc3hip.h; default 0 on one GPU, parallel.DEFAULT_ZLAG over several), ``wpad``
+      (wavelet likelihood of a series whose length is no power of two: padded with zero
+      residuals to the next one; without it such a series is refused -- mcmc()).
     """
     from . import __version__
     comm = kwargs.get('comm')
@@ -264,7 +266,7 @@ def sample(
             os.makedirs(folder)
 
     extra = {k: kwargs[k] for k in ('seed', 'device', 'comm', 'engine_factory',
-                                   'kickoff_stream', 'zlag') if k in kwargs}
+                                   'kickoff_stream', 'zlag', 'wpad') if k in kwargs}
     extra['_extras'] = side = {}
     output = mcmc(
         inp.data, inp.uncert, func, inp.params, indparams, indparams_dict,

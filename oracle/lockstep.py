@@ -32,6 +32,7 @@ class _Problem(ctypes.Structure):
         ('tile', ctypes.c_int32), ('vlanes', ctypes.c_int32),
         ('wl_threads', ctypes.c_int32),
         ('tile_tree', ctypes.c_int32), ('zlag', ctypes.c_int32),
+        ('wl_nreal', ctypes.c_int32), ('reserved1', ctypes.c_int32),
         ('M0', ctypes.c_int64), ('zlen', ctypes.c_int64),
         ('seed', ctypes.c_uint64),
         ('gamma', ctypes.c_double), ('fepsilon', ctypes.c_double),
@@ -77,7 +78,7 @@ class LockstepRun:
                  nsamples=None, sampler='snooker', wlike=False, thinning=1,
                  fgamma=1.0, fepsilon=0.0, hsize=10, model='poly', nmodel=None,
                  seed=0, tile=0, vlanes=None, chain0=0, nlocal=None, M0=None,
-                 wl_threads=0, tile_tree=0, zlag=0):
+                 wl_threads=0, tile_tree=0, zlag=0, wl_nreal=0):
         L = ok.lib()
         L.ls_run.restype = ctypes.c_int
         L.ls_eval_chisq.restype = ctypes.c_int
@@ -150,6 +151,7 @@ class LockstepRun:
         P.wl_threads = int(wl_threads)      # 0: the library's default geometry
         P.tile_tree = int(tile_tree)
         P.zlag = int(zlag)           # declared multi-GPU cadence (oracle_lockstep.c ls_run)
+        P.wl_nreal = int(wl_nreal)   # wavelet series padded to 2^M: the points that are data
         self.zlag = int(zlag)
         P.M0 = self.M0
         P.zlen = self.zlen

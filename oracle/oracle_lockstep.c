@@ -59,6 +59,10 @@ typedef struct {
                              * seen `zlag` refreshes later -- DEMC partners of refresh R are the
                              * rows of refresh R-1-zlag (the initial snapshot before there is
                              * one), snooker's history ends with refresh R-1-zlag; 0 = strict */
+    int32_t wl_nreal;       /* wavelet likelihood of a series padded to ndata = 2^M points: how
+                             * many of them are data (0: all) -- the residuals of the padding
+                             * are exactly zero (include/mc3hip.h mc3hip_problem.wl_nreal) */
+    int32_t reserved1;
     int64_t M0, zlen;
     uint64_t seed;
     double gamma, fepsilon;
@@ -443,11 +447,12 @@ static double wavelet_chisq(const ls_problem *P, const double *p,
     const double sw = p[P->nparams - 1];
     const double sr2 = sr * sr, sw2 = sw * sw;
     int sawinf = 0;
+    const int nreal = (P->wl_nreal > 0 && P->wl_nreal < N) ? P->wl_nreal : N;
     for (int i = 0; i < N; i++) {
         const double m = model_at(P, p, i);
         if (m == INFINITY)
             sawinf = 1;
-        buf0[i] = P->data[i] - m;
+        buf0[i] = (i < nreal) ? P->data[i] - m : 0.0;      /* src_c/_dwt.c:89-91 */
     }
     if (sawinf)
         return INFINITY;

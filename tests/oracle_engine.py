@@ -17,7 +17,7 @@ class OracleChains:
                  fgamma=1.0, fepsilon=0.0, hsize=10, model='poly', nmodel=None,
                  seed=0, device=0, chain0=0, nlocal=None, M0=None, zlen=None,
                  trace_iters=0, no_graph=False, no_persist=False, p2p=False, nthreads=1,
-                 plan=None, zlag=0, no_courier=False):
+                 plan=None, zlag=0, no_courier=False, wl_nreal=0):
         if M0 is None:
             M0 = hsize*nchains
         if nsamples is None:
@@ -29,6 +29,7 @@ class OracleChains:
             nsamples=nsamples, sampler=sampler, wlike=wlike, thinning=thinning,
             fgamma=fgamma, fepsilon=fepsilon, hsize=hsize, model=model,
             nmodel=nmodel, seed=seed, chain0=chain0, nlocal=nlocal, M0=M0, zlag=zlag,
+            wl_nreal=wl_nreal,
             # (the summation order of the plan the library would choose for this problem:
             # tests that compare with a GPU run pass DeviceChains.plan's entries)
             **({k: plan[k] for k in ('tile', 'vlanes', 'tile_tree') if k in plan}

@@ -506,3 +506,33 @@ def test_sample_with_the_least_squares_prefit():
     want = np.sqrt(ref['best_chisq']/(100 - 3))
     assert scaled['chisq_factor'] == pytest.approx(want, rel=1e-6)
     assert scaled['red_chisq'] == pytest.approx(1.0, abs=0.05)
+
+
+def test_wavelet_series_that_is_no_power_of_two_is_padded_on_request():
+    """sample(..., wlike=True) with 1000 points: refused without ``wpad`` (the reference's zero
+    padding transforms the unpadded length, src_c/_dwt.c:82-94), padded with zero residuals to
+    1024 with it -- the oracle engine stands in for the device; outputs keep the data's length."""
+    import mc3_amd
+    from mc3_amd import utils as mu
+    from oracle_engine import OracleChains
+    x, data, uncert = H.tutorial_data(1000)
+    kw = dict(data=data, uncert=uncert, func=H.quad, indparams=[x],
+              params=np.array([3.0, -2.4, 0.5, 1.0, 0.5, 1.0]),
+              pstep=np.array([0.3, 0.1, 0.02, 0.0, 0.1, 0.1]),
+              pmin=np.array([-10.0, -20.0, -10.0, 0.0, 0.01, 0.01]),
+              pmax=np.array([40.0, 20.0, 10.0, 2.0, 10.0, 10.0]),
+              sampler='snooker', nsamples=7*60, burnin=5, nchains=7, wlike=True, grtest=False,
+              log=mu.Log(verb=0), seed=3, engine_factory=OracleChains, kickoff_stream='numpy')
+    with pytest.raises(ValueError, match='power-of-two'):
+        mc3_amd.sample(**kw)
+    np.random.seed(11)
+    out = mc3_amd.sample(wpad=True, **kw)
+    assert out['best_model'].shape == (1000,) and np.isfinite(out['best_chisq'])
+    assert out['posterior'].shape[1] == 5
+    # the chi-squared the run reports for its best fit is the padded series' (zero residuals on
+    # the padding), i.e. the reference-faithful kernel's on such residuals
+    from oracle import kernels as K
+    model = np.concatenate([out['best_model'], np.zeros(24)])
+    padded = np.concatenate([data, np.zeros(24)])
+    np.testing.assert_allclose(out['best_chisq'], K.dwt_chisq(model, padded, out['bestp']),
+                               rtol=1e-9)
