@@ -93,3 +93,28 @@ def test_sample_with_wpad_equals_the_cpu_checker(ndata, sampler):
     gpu, cpu = both(wpad=True, **kw)
     assert_same_dict(gpu, cpu)
     assert gpu['best_model'].shape == (ndata,)
+
+
+@pytest.mark.parametrize('seed', range(60))
+def test_random_wavelet_problem_with_a_padded_tail(eng, seed):
+    """test_gpu_fuzz.random_problem's wavelet problems (either model kind, 2 .. 2^14 points, every
+    sampler, thinning, fixed / shared parameters) with only the first wl_nreal points data."""
+    import test_gpu_fuzz as F
+    prob = F.random_problem(31000 + seed, wavelet_any_model=True)
+    rs = np.random.RandomState(31000 + seed)
+    n = len(prob['data'])
+    prob['wl_nreal'] = int(rs.randint(n//2 + 1, n)) if n > 2 else 1
+    gpu = eng.DeviceChains(**prob)
+    orc = H.make_oracle(prob, plan=gpu.plan)
+    try:
+        Z0, lp0 = H.initial_population(orc, seed=seed)
+    except ValueError:
+        gpu.close()
+        pytest.skip('no finite initial population')
+    orc.set_population(Z0, lp0)
+    gpu.set_population(Z0, lp0)
+    orc.run(nthreads=4)
+    gpu.run(max(1, gpu.nzchain//3))
+    gpu.run()
+    F.compare_final(gpu, orc, f'seed {seed} nreal {prob["wl_nreal"]} of {n}')
+    gpu.close()
