@@ -1,8 +1,9 @@
 // kernels_rows.h -- the hand-laid-out loops for ensembles with more chains than waves can be
 // co-resident, the chains of a wave SIDE BY SIDE in its rows of 16 lanes.
 //
-// lean_*_mc_kernel (kernels_lean.h) advance the T = 2..4 chains of a wave one after another.
-// Measured on MI355X at 8192 chains (profiles/r04_c3x4_pmc_before.json) that loop spends 201
+// Round 3's loops (lean_*_mc_kernel; of them kernels_lean.h keeps the two-tile DEMC one) advanced
+// the T = 2..4 chains of a wave one after another.  Measured on MI355X at 8192 chains
+// (profiles/r04_c3x4_pmc_before.json) that loop spends 201
 // vector instructions per chain-step of which 109 are FP64 arithmetic: the rest are T copies
 // of the scalar work of a turn and the register shuffling of T turns' control flow.  Here, for
 // one-tile polynomials of 2..4 coefficients, lane 16 r + k holds coefficient k (FX shapes: free
@@ -17,8 +18,8 @@
 //     lane and reach their rows through the LDS crossbar (ds_bpermute, no LDS memory);
 //   * the T data sums are reduced across lanes TOGETHER (core.h rows_sum: the stride-32 and
 //     -16 levels pair two and four chains per instruction, the last four levels serve every
-//     row at once) with the pairing of wave_sum, so each total is bit for bit the one the
-//     turn-after-turn loops compute.
+//     row at once) with the pairing of wave_sum, so each total is bit for bit the one a chain
+//     alone in its wave computes.
 // 8192 chains, DEMC: 123 vector instructions per chain-step (99 FP64), 1.85 -> 2.56 G
 // chain-steps/s (profiles/r04_c3x4_pmc.json).  The hand-off protocol, the draws (Philox keyed
 // by seed, refresh, chain, slot) and the arithmetic are unchanged: same results, bit for bit.
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(64) void lean_demc_rows_lag_kernel(const DevProblem
         const double *addr[2];
         double val[2];
     };
-    // (asked for at ONE place per refresh, waited for at one: kernels_lean.h lean_snooker_mc_kernel)
+    // (asked for at ONE place per refresh, waited for at one: handoff.h load_published_async)
     auto ask = [&](Step &S) {
         S.val[0] = load_published_async<P2P>(S.addr[0]);
         S.val[1] = load_published_async<P2P>(S.addr[1]);
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(64) void lean_demc_rows_lag_kernel(const DevProblem
 }
 
 // ---------------------------------------------------------------------------------
-// The random walk (lean_mrw_mc_kernel's shape): nothing is read.  Lane (3 i + s) T + q of a
+// The random walk (lean_mrw_kernel's arithmetic): nothing is read.  Lane (3 i + s) T + q of a
 // batch holds Philox slot s' (0, 3, 4 for s = 0, 1, 2) of refresh bbase + i, chain q: the
 // Metropolis draw with its window from s = 0, the pairs of normal deviates of coefficients
 // 0-1 and 2-3 from s = 1, 2 (lean_mrw_kernel's fields).
@@ -698,7 +699,7 @@ __global__ __launch_bounds__(64) void lean_mrw_rows_kernel(const DevProblem P, c
 }
 
 // ---------------------------------------------------------------------------------
-// Snooker (lean_snooker_mc_kernel's shape, chain.py:195-220, :251-255): three rows of the
+// Snooker (lean_snooker_kernel's arithmetic, chain.py:195-220, :251-255): three rows of the
 // history per chain and refresh -- nearly always published long ago -- asked for one REFRESH
 // ahead by loads outside the compiler's wait counts (handoff.h load_published_async) and
 // retired behind the publish of the refresh between.  Lane (3 i + s) T + q of a batch holds
