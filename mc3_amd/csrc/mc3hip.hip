@@ -552,6 +552,7 @@ int decide_persist(mc3hip_ctx *c)
                 long long room = (long long)nbm * prop.multiProcessorCount;
                 room = room < cap_limit ? room : cap_limit;
                 if (nbm >= 1 && grid <= room) {
+                    capacity = room;                        // (of the instance that runs)
                     c->mc_grid = (int)grid;
                     c->mc_smem = smem;
                     c->P.mc_chains = turns;
