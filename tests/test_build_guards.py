@@ -11,7 +11,9 @@ cross-compiles without a GPU) and check the ISA:
 * ``load_published_async`` (ordinary registers): between the load and the next inline-assembly
   wait, on any path of the control-flow graph, no instruction reads a destination register
   (a copy, a spill, an accumulation-register move or a use);
-* none of these kernels carries scratch.
+* none of these kernels carries scratch;
+* the same scan over run-time specialised instances (the source mc3_amd/jit.py would generate for
+  design matrices and long polynomials, compiled here as it would be on the user's machine).
 """
 import concurrent.futures
 import glob
@@ -39,17 +41,50 @@ def _isa(unit, tmp):
         return f.read()
 
 
+# ... and run-time specialised instances of the same loops (mc3_amd/jit.py compiles them on the
+# user's machine: what the library would ask for for these shapes, compiled here the same way) --
+# design matrices whose tile fills the registers are where an allocator is most tempted
+JIT_REQUESTS = (
+    'lean_snooker_body<210, false, false, false, false, false, false, 4> /*threads=256*/',
+    'lean_snooker_body<208, true, false, false, false, false, false, 4> /*threads=256*/',
+    'lean_snooker_body<8, false, false, false, false, false, false>',
+    'lean_snooker_body<204, false, true, false, false, false, false>',
+    'lean_demc_lag_body<210, false, false, false>',
+    'lean_demc_lag_body<205, false, true, false>',
+    'lean_demc_lag_body<7, false, false, false>',
+)
+
+
+def _isa_request(k, request, tmp):
+    from mc3_amd import build as b, jit
+    d = os.path.join(tmp, f'jit{k}')
+    os.makedirs(d)
+    m = re.search(r'/\*threads=(\d+)\*/', request)
+    with open(os.path.join(d, 'jit.hip'), 'w') as f:
+        f.write(jit._SOURCE % (int(m.group(1)) if m else 64, jit.KERNEL_NAME, request))
+    flags = [x for x in b.CFLAGS if x not in ('-fPIC', '-fvisibility=hidden')]
+    subprocess.run([b.hipcc()] + flags + ['--save-temps', '-I', CSRC, '-c', 'jit.hip', '-o',
+                                          '/dev/null'], cwd=d, check=True, capture_output=True)
+    (path,) = glob.glob(os.path.join(d, '*gfx950.s'))
+    with open(path) as f:
+        return f.read()
+
+
 @pytest.fixture(scope='module')
 def isa(tmp_path_factory):
     tmp = str(tmp_path_factory.mktemp('isa'))
-    with concurrent.futures.ThreadPoolExecutor(len(UNITS)) as pool:
-        return dict(zip(UNITS, pool.map(lambda u: _isa(u, tmp), UNITS)))
+    with concurrent.futures.ThreadPoolExecutor(8) as pool:
+        units = pool.map(lambda u: _isa(u, tmp), UNITS)
+        jits = pool.map(lambda kr: _isa_request(kr[0], kr[1], tmp), enumerate(JIT_REQUESTS))
+        out = dict(zip(UNITS, units))
+        out.update({f'jit: {r}': t for r, t in zip(JIT_REQUESTS, jits)})
+        return out
 
 
 def _kernels(text):
     """(name, lines of the body) of every kernel function in an assembly file."""
     lines = text.split('\n')
-    starts = [i for i, l in enumerate(lines) if re.match(r'^_Z\w+:', l)]
+    starts = [i for i, l in enumerate(lines) if re.match(r'^(_Z\w+|mc3_jit_kernel):', l)]
     for k, i in enumerate(starts):
         end = starts[k + 1] if k + 1 < len(starts) else len(lines)
         body = lines[i:end]
@@ -70,6 +105,8 @@ def _regs(operand_text, bank):
 
 def test_no_scratch_in_the_hand_laid_out_loops(isa):
     for unit, text in isa.items():
+        if unit.startswith('jit: '):          # (a ten-column tile on one wave may spill: slow, not wrong)
+            continue
         meta = text[text.index('amdhsa.kernels:'):]
         for blk in meta.split('  - .agpr_count')[1:]:
             name = re.search(r'\.name:\s+(\S+)', blk).group(1)
@@ -171,3 +208,11 @@ def test_async_destinations_are_left_alone_until_their_wait(isa):
                         state[nxt] = new
                         work.append(nxt)
     assert checked > 50           # (the scan found the loads it is about)
+
+
+def test_the_scan_sees_the_specialised_kernels(isa):
+    for unit, text in isa.items():
+        if unit.startswith('jit: '):
+            names = [name for name, _ in _kernels(text)]
+            assert names == ['mc3_jit_kernel'], (unit, names)
+            assert 'global_load_dwordx2' in text and '#ASMSTART' in text, unit
