@@ -81,138 +81,55 @@ def isa(tmp_path_factory):
         return out
 
 
-def _kernels(text):
-    """(name, lines of the body) of every kernel function in an assembly file."""
-    lines = text.split('\n')
-    starts = [i for i, l in enumerate(lines) if re.match(r'^(_Z\w+|mc3_jit_kernel):', l)]
-    for k, i in enumerate(starts):
-        end = starts[k + 1] if k + 1 < len(starts) else len(lines)
-        body = lines[i:end]
-        stop = next((j for j, l in enumerate(body) if l.startswith('.Lfunc_end')), len(body))
-        yield lines[i].split(':')[0], body[:stop]
-
-
-def _regs(operand_text, bank):
-    """Register numbers of one bank ('v' / 'a') named in an instruction's operands."""
-    out = set()
-    for m in re.finditer(r'\b%s(\d+)\b|\b%s\[(\d+):(\d+)\]' % (bank, bank), operand_text):
-        if m.group(1):
-            out.add(int(m.group(1)))
-        else:
-            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
-    return out
+from mc3_amd import isa_audit
 
 
 def test_no_scratch_in_the_hand_laid_out_loops(isa):
     for unit, text in isa.items():
         if unit.startswith('jit: '):          # (a ten-column tile on one wave may spill: slow, not wrong)
             continue
-        meta = text[text.index('amdhsa.kernels:'):]
-        for blk in meta.split('  - .agpr_count')[1:]:
-            name = re.search(r'\.name:\s+(\S+)', blk).group(1)
-            scratch = int(re.search(r'\.private_segment_fixed_size:\s+(\d+)', blk).group(1))
+        for name, scratch in isa_audit.scratch_bytes(text).items():
             assert scratch == 0, f'{unit}: {name} carries {scratch} B of scratch'
 
 
-def _blocks(body):
-    """Basic blocks of a kernel: {label: (instructions, successors)}; an instruction is
-    (in_inline_asm, mnemonic, operand text)."""
-    blocks, order = {}, []
-    label, cur, inasm = 'entry', [], False
-
-    def close(nxt):
-        blocks[label] = [cur, nxt]
-        order.append(label)
-    for line in body[1:]:
-        if '#ASMSTART' in line:
-            inasm = True
-            continue
-        if '#ASMEND' in line:
-            inasm = False
-            continue
-        m = re.match(r'^(\.LBB\d+_\d+):', line)
-        if m:
-            close(m.group(1))
-            label, cur = m.group(1), []
-            continue
-        code = line.split(';')[0].strip()
-        if not code or code.endswith(':') or code.startswith('.'):
-            continue
-        op, _, rest = code.partition(' ')
-        cur.append((inasm, op, rest))
-    close(None)
-    succ = {}
-    for k, lab in enumerate(order):
-        ins, fall = blocks[lab]
-        out = set()
-        ends = False
-        for _, op, rest in ins:
-            if op == 's_branch':
-                out.add(rest.strip())
-                ends = True
-            elif op.startswith('s_cbranch'):
-                out.add(rest.strip())
-            elif op == 's_endpgm':
-                ends = True
-        if not ends and fall is not None:
-            out.add(fall)
-        succ[lab] = out
-    return {lab: blocks[lab][0] for lab in order}, succ, order
-
-
 def test_async_destinations_are_left_alone_until_their_wait(isa):
-    """Forward data flow over the kernel's control-flow graph: the set of VGPRs an inline-assembly
+    """Forward data flow over the kernel's control-flow graph (mc3_amd/isa_audit.py, the check
+    mc3_amd/jit.py applies to what it compiles at run time): the set of VGPRs an inline-assembly
     load is still on its way to; any other instruction that names one of them on ANY path
     before an inline-assembly wait is an error."""
     checked = 0
     for unit, text in isa.items():
-        for name, body in _kernels(text):
-            blocks, succ, order = _blocks(body)
-            state = {lab: None for lab in order}        # pending set at block entry
-            state[order[0]] = frozenset()
-            work = [order[0]]
-            while work:
-                lab = work.pop()
-                pending = set(state[lab])
-                for inasm, op, rest in blocks[lab]:
-                    if inasm:
-                        if op == 'global_load_dwordx2' and not rest.lstrip().startswith('a['):
-                            pending |= _regs(rest.split(',')[0], 'v')
-                            checked += 1
-                        elif op == 's_waitcnt':
-                            pending = set()
-                        continue
-                    if op == 's_waitcnt' and 'vmcnt(0)' in rest:
-                        pending = set()       # (a full wait the compiler placed: everything is in)
-                        continue
-                    # what the instruction READS: every operand of a store / compare / atomic,
-                    # the operands behind the destination otherwise.  (Writes are not flagged:
-                    # the structurised control flow has statically possible, dynamically dead
-                    # paths -- a "break" flag routed through the loop latch -- on which the
-                    # allocator rightly reuses a register whose value is dead there.)
-                    reads_all = op.startswith(('global_store', 'scratch_store', 'buffer_store',
-                                               'flat_store', 'ds_write', 'ds_store', 'v_cmp',
-                                               'global_atomic', 'flat_atomic'))
-                    srcs = rest if reads_all else rest.partition(',')[2]
-                    touched = _regs(srcs, 'v') & pending
-                    assert not touched, (
-                        f'{unit}: {name}: {lab}: `{op} {rest}` reads v{sorted(touched)} while an '
-                        'inline-assembly load into it is still in flight')
-                    if not reads_all:         # (overwritten: the allocator holds the value dead)
-                        pending -= _regs(rest.partition(',')[0], 'v')
-                for nxt in succ[lab]:
-                    if nxt not in state:
-                        continue
-                    new = frozenset(pending) if state[nxt] is None else state[nxt] | pending
-                    if new != state[nxt]:
-                        state[nxt] = new
-                        work.append(nxt)
+        found, n = isa_audit.violations(text)
+        checked += n
+        assert not found, f'{unit}: ' + '; '.join(
+            f'{k}: {lab}: `{ins}` reads v{regs} while an inline-assembly load into it is still '
+            'in flight' for k, lab, ins, regs in found[:5])
     assert checked > 50           # (the scan found the loads it is about)
 
 
 def test_the_scan_sees_the_specialised_kernels(isa):
     for unit, text in isa.items():
         if unit.startswith('jit: '):
-            names = [name for name, _ in _kernels(text)]
+            names = [name for name, _ in isa_audit._kernels(text)]
             assert names == ['mc3_jit_kernel'], (unit, names)
             assert 'global_load_dwordx2' in text and '#ASMSTART' in text, unit
+
+
+def test_the_scan_catches_a_copy_of_an_in_flight_register():
+    """The check itself: a listing in which the allocator copies a hidden load's destination before
+    the wait."""
+    text = """_Z4testv:
+\t#ASMSTART
+\tglobal_load_dwordx2 v[10:11], v[2:3], off sc1
+\t#ASMEND
+\tv_mov_b32_e32 v20, v10
+\t#ASMSTART
+\ts_waitcnt vmcnt(1)
+\t#ASMEND
+\ts_endpgm
+.Lfunc_end0:
+"""
+    found, n = isa_audit.violations(text)
+    assert n == 1 and len(found) == 1 and found[0][3] == [10]
+    ok = text.replace('v_mov_b32_e32 v20, v10', 'v_mov_b32_e32 v20, v12')
+    assert isa_audit.violations(ok)[0] == []

@@ -108,3 +108,26 @@ def test_jit_compiles_a_request_without_a_gpu(tmp_path, monkeypatch):
     assert len(files) == 1
     assert jit.code_object(req) == image                      # (from the file)
     assert jit._key(req) != jit._key(req.replace('206', '207'))
+
+
+def test_a_specialised_loop_that_fails_the_audit_is_not_installed(tmp_path, monkeypatch, capsys):
+    """mc3_amd/jit.py audits the hidden loads of what it compiled (isa_audit.py); a loop in which
+    the allocator touched an in-flight register is neither cached nor installed: the context keeps
+    the general chain, with a word on stderr."""
+    from mc3_amd import isa_audit, jit
+    monkeypatch.setenv('MC3HIP_JIT_CACHE', str(tmp_path))
+    monkeypatch.setattr(isa_audit, 'violations',
+                        lambda text: ([('mc3_jit_kernel', '.LBB0_1', 'v_mov_b32 v1, v10', [10])], 3))
+
+    class Engine:
+        installed = None
+
+        def jit_request(self):
+            return 'lean_snooker_body<205, false, false, false, false, false, false>'
+
+        def jit_install(self, image, name):
+            self.installed = image
+    eng = Engine()
+    assert jit.specialise(eng) == '' and eng.installed is None
+    assert os.listdir(str(tmp_path)) == []
+    assert 'hidden load' in capsys.readouterr().err
