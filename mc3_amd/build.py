@@ -21,7 +21,7 @@ CSRC = os.path.join(HERE, 'csrc')
 # (the slowest first: the pool starts them in this order)
 UNITS = ['k_lean.hip', 'k_lean6.hip', 'k_lean7.hip', 'k_lean2.hip', 'k_general_w1.hip', 'k_wavelet_w1.hip', 'k_wavelet_w1b.hip',
          'k_general_w4.hip', 'k_wavelet_large.hip', 'k_resident.hip', 'k_lean5.hip',
-         'k_wavelet_w8cg.hip', 'k_wavelet_w4.hip', 'k_wavelet_w8mc.hip', 'k_wavelet_w8cw.hip',
+         'k_wavelet_w8cg.hip', 'k_wavelet_w4.hip', 'k_wavelet_w8mc.hip', 'k_wavelet_w8pp.hip', 'k_wavelet_w8cw.hip',
          'k_lean4.hip', 'k_wavelet_w8.hip', 'k_lean3.hip', 'k_tiled.hip', 'mc3hip.hip']
 SRC = os.path.join(CSRC, 'mc3hip.hip')
 LIB = os.path.join(HERE, 'libmc3hip.so')

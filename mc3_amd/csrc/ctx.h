@@ -124,6 +124,17 @@ inline bool chainwave_runs(const mc3hip_ctx *c, bool p2p)
     // (several chains per workgroup: only the hand-structured chain wave takes turns)
     return c->chainwave && !p2p && (c->mc_chains == 0 || c->P.cw_lean != 0);
 }
+// several chains per workgroup, snooker or mrw: the pipelined kernel with a tenth wave for the
+// tail (kernels_wavelet.h wavelet_pipe_kernel); same LDS as the nine-wave kernel
+inline bool chainwave_pipe(const mc3hip_ctx *c, bool p2p)
+{
+    return chainwave_runs(c, p2p) && c->mc_chains > 0 && c->P.sampler != MC3HIP_DEMC &&
+           !getenv("MC3HIP_NO_CW_PIPE");
+}
+inline int chainwave_threads(const mc3hip_ctx *c, bool p2p)
+{
+    return chainwave_pipe(c, p2p) ? CW_THREADS + 128 : CW_THREADS;
+}
 
 // Waves per chain are dispatched as {1, 4, 16}; the wavelet geometries have 1, 4 or 8:
 // the widest one rides on the dispatch slot of the widest Gaussian one.
@@ -415,6 +426,7 @@ MC3_WAVELET_UNIT(large)
 #undef MC3_WAVELET_UNIT
 // (k_wavelet_w8mc.hip: the nine-wave kernel with several chains per workgroup)
 chain_kernel_fn persist_instance_wavelet_w8mc(const mc3hip_ctx *c);
+chain_kernel_fn persist_instance_wavelet_w8pp(const mc3hip_ctx *c);   // (pipelined: ten waves)
 chain_kernel_fn persist_instance_wavelet_w8cw(const mc3hip_ctx *c);
 chain_kernel_fn persist_instance_wavelet_w8cg(const mc3hip_ctx *c);
 

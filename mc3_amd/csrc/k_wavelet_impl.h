@@ -41,7 +41,9 @@ void persist_instance_t(const mc3hip_ctx *c, bool p2p, chain_kernel_fn *out)
             // (the nine-wave kernels are compiled in units of their own: k_wavelet_w8cw.hip, the
             // hand-structured chain wave; _w8cg, the general chain; _w8mc, several chains per
             // workgroup)
-            *out = c->mc_chains > 0 ? persist_instance_wavelet_w8mc(c)
+            // (... and _w8pp, the same pipelined over the chains of a workgroup: ten waves)
+            *out = chainwave_pipe(c, p2p) ? persist_instance_wavelet_w8pp(c)
+                   : c->mc_chains > 0 ? persist_instance_wavelet_w8mc(c)
                    : c->P.cw_lean   ? persist_instance_wavelet_w8cw(c)
                                     : persist_instance_wavelet_w8cg(c);
             return;

@@ -942,4 +942,572 @@ __global__ __launch_bounds__(576) void wavelet_cw_kernel(const DevProblem P, con
     }
 }
 
+// ---- several chains per workgroup, PIPELINED (snooker and mrw) -----------------------------
+// wavelet_cw_kernel<.., MCK> above takes the chains of a workgroup one after the other, and of a
+// turn's ~12 000 cycles (tools/pipe_diag.py) the eight compute waves work about half: they wait
+// through the single-wave tail (stages B and C, the sums, the two divisions) and through the chain
+// wave's turn.  With two or more chains per workgroup nothing forces that: the NEXT turn is
+// another chain, whose proposal needs nothing of this likelihood.  Here the workgroup has ELEVEN
+// waves and time is cut into slots of one stage A each:
+//   waves 0..7   stage A of the turn issued into slot s, nothing else (wavelet_body PIPE);
+//   wave 9       the tail of the turn issued into slot s - 1 (PipeTail), at once: its chisq is in
+//                LDS ~2 300 cycles into the slot, and a word beside it says so;
+//   wave 10      the noise terms of slot s's proposal (needed at the end of stage A);
+//   wave 8       the chain: draws and row requests of the turn after the one in flight and the
+//                logarithm of the Metropolis test while the tail wave works; then the test, the
+//                Z row and the books of slot s - 1's turn; then the proposal for slot s + 1.
+// All of that happens during level 0 of stage A, the long stretch (two compute waves per SIMD:
+// ~3 700 cycles alone, ~5 000 beside the helpers, which sit on three different SIMDs); the helpers
+// then only attend the halo barriers (s_barrier counts every wave).  Proposals, noise tables and
+// orders alternate between two LDS buffers (slot parity).  A turn can only be issued when its
+// chain's previous turn has been decided (always so with two chains or more) and its history rows
+// are there; a row that is NOT there may be the one this workgroup still owes (the turn in
+// flight), so the chain wave never waits with a turn in flight: it issues an empty slot (a bubble
+// -- the tail and the decision of the turn in flight run, the compute waves idle) and asks
+// again.  A workgroup that blocks has therefore published everything it can: no cycle.
+// Same arithmetic, same draws, same order per chain: results are bit-identical.
+// Measured (MI355X, 2^14 points, snooker): 512 chains 8.12 -> 6.0 us per iteration, 1024 chains
+// 15.4 -> 11.9; every proposal evaluated (c4x2wide) 10.0 -> 7.0; mrw 9.1 -> 7.2.
+// (tools/pipe_diag.py: a diagnostic build in which the chain wave and the tail wave of workgroup 0
+// add up, per segment of a slot, the cycles they work and the cycles the segment lasts)
+#ifdef MC3HIP_PIPE_DIAG
+#define PIPE_SYNC(i)                                                                     \
+    do {                                                                                  \
+        const unsigned long long a_ = __builtin_amdgcn_s_memtime();                       \
+        dg_work[i] += a_ - dg_t0;                                                         \
+        block_sync<9>();                                                                  \
+        const unsigned long long b_ = __builtin_amdgcn_s_memtime();                       \
+        dg_dur[i] += b_ - dg_t0;                                                          \
+        dg_t0 = b_;                                                                       \
+    } while (0)
+#define PIPE_DIAG_DECL                                                                    \
+    unsigned long long dg_work[6] = {0, 0, 0, 0, 0, 0}, dg_dur[6] = {0, 0, 0, 0, 0, 0};   \
+    unsigned long long dg_part[5] = {0, 0, 0, 0, 0}, dg_p0 = 0;                           \
+    unsigned long long dg_t0 = __builtin_amdgcn_s_memtime(), dg_n = 0
+#define PIPE_PART(i)                                                                      \
+    do {                                                                                  \
+        const unsigned long long a_ = __builtin_amdgcn_s_memtime();                       \
+        if ((i) >= 0)                                                                     \
+            dg_part[(i) < 0 ? 0 : (i)] += a_ - dg_p0;                                     \
+        dg_p0 = a_;                                                                       \
+    } while (0)
+#define PIPE_DIAG_PRINT(who)                                                              \
+    do {                                                                                  \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)                                   \
+            printf("%s slots %llu | work %llu %llu %llu %llu %llu %llu | lasts %llu %llu %llu %llu %llu %llu\n", \
+                   who, dg_n, dg_work[0] / dg_n, dg_work[1] / dg_n, dg_work[2] / dg_n,    \
+                   dg_work[3] / dg_n, dg_work[4] / dg_n, dg_work[5] / dg_n,               \
+                   dg_dur[0] / dg_n, dg_dur[1] / dg_n, dg_dur[2] / dg_n, dg_dur[3] / dg_n, \
+                   dg_dur[4] / dg_n, dg_dur[5] / dg_n);                                   \
+    } while (0)
+#else
+#define PIPE_SYNC(i) block_sync<9>()
+#define PIPE_PART(i) do { } while (0)
+#define PIPE_DIAG_DECL do { } while (0)
+#define PIPE_DIAG_PRINT(who) do { } while (0)
+#endif
+
+template <int SMP>
+__device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int nref, double *np0,
+                                                double *np1, double *tab0, double *tab1,
+                                                int *s_cmd, const double *s_result,
+                                                const int nhalo, const int M, double *slots)
+{
+    static_assert(SMP != MC3HIP_DEMC, "DEMC's partner rows are the refresh before: no slack");
+    const int lane = threadIdx.x & 63;
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    int nturns = 0;
+    for (int q = 0; q < P.mc_chains; ++q)
+        nturns += (b + q * G < P.nlocal) ? 1 : 0;
+    double *Zr = own_global(P.Z), *log_post = own_global(P.log_post);
+    double *bestx = own_global(P.bestx);
+    const double *snap0 = own_global(P.snap0);
+    int32_t *zchain = own_global(P.zchain);
+    long long *best_iter = own_global(P.best_iter);
+    long long M0 = P.M0;
+    uint64_t seed = P.seed;
+    double gamma = P.gamma, fepsilon = P.fepsilon;
+    int nchains = P.nchains, nparams = P.nparams, nf = P.nfree, zs = P.zs;
+    asm volatile("; own" : "+s"(M0), "+s"(seed));
+    asm volatile("; own" : "+s"(gamma), "+s"(fepsilon), "+s"(nchains), "+s"(nparams), "+s"(nf),
+                           "+s"(zs));
+    const bool mine = lane < nf;
+    const int kk = mine ? lane : 0;
+    const long long R0 = P.ctl[0];
+    long long *ctl_rw = const_cast<long long *>(P.ctl);
+    const double *snap_first = (R0 == 0) ? snap0
+                                         : Zr + (size_t)(M0 + (R0 - 1) * nchains) * zs;
+    const int sstride = zs + 4;
+    for (int q = 0; q < nturns; ++q) {
+        const int l = b + q * G;
+        double *slot = slots + q * sstride;
+        if (mine)
+            slot[lane] = snap_first[(size_t)(P.chain0 + l) * zs + lane];
+        if (lane == 0) {
+            slot[zs] = P.chisq[l];
+            slot[zs + 1] = P.best_chisq[l];
+            slot[zs + 2] = mc3_from_bits((unsigned long long)P.numaccept[l]);
+        }
+    }
+    unsigned long long oob = 0;
+    const int jfree = mine ? P.ifree[lane] : 0;
+    const double pmin_k = mine ? P.fmin[lane] : 0.0;
+    const double pmax_k = mine ? P.fmax[lane] : 0.0;
+    const bool need_normal = (SMP == MC3HIP_MRW) || (fepsilon != 0.0);
+    const double pstep_k = (mine && need_normal) ? P.fstep[lane] : 0.0;
+    const long long abort_at = (P.test_abort >= 0 && b == 0) ? (long long)P.test_abort : -1;
+    // the fixed parameters never change: written once (both buffers), the free ones every turn
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        double *np = h ? np1 : np0;
+        if (lane < nparams)
+            np[lane] = P.params[lane];
+        if (lane + 64 < nparams)
+            np[lane + 64] = P.params[lane + 64];
+    }
+    auto normal_draw = [&](uint64_t it, int ch) {      // chain.py:185, as run_chain's
+        double nk = 0.0;
+        if (mine) {
+            const Draw2 d = draw2(seed, it, (uint32_t)ch, (uint32_t)(3 + (lane >> 1)));
+            const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(d.q0)));
+            double sn, cs;
+            mc3_det_sincos2pi(u01(d.q1), &sn, &cs);
+            nk = (rad * ((lane & 1) ? sn : cs)) * pstep_k;
+        }
+        return nk;
+    };
+    const double *ra[3] = {};
+    double rv[3] = {};
+    auto request_rows = [&](const Draws &D, long long R) {     // chain.py:195-205
+        if constexpr (SMP == MC3HIP_SNOOKER) {
+            const long long zsz = M0 + R * nchains;
+            const long long iR1 = (long long)bounded(D.d0.q0, (uint64_t)zsz);
+            long long iR2 = 1 + (long long)bounded(D.d0.q1, (uint64_t)(zsz - 1));
+            if (iR2 == iR1)
+                iR2 = 0;
+            const long long iz = (long long)bounded(D.d1.q1, (uint64_t)zsz);
+            ra[0] = Zr + (size_t)iR1 * zs + kk;
+            ra[1] = Zr + (size_t)iR2 * zs + kk;
+            ra[2] = Zr + (size_t)iz * zs + kk;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                rv[q] = load_published<false>(ra[q]);
+        }
+    };
+    // The draws of the next 21 turns in ONE Philox call, a (turn, slot) per lane (the idea of
+    // fill_draws, handoff.h, with the turn's own chain and refresh in every lane): three calls per
+    // turn were ~2 000 cycles of a slot.  `n`: the turn's index since this launch began.
+    DrawBatch batch;
+    batch.w0 = batch.w1 = batch.w2 = batch.w3 = 0u;
+    batch.base = -(long long)DRAW_BATCH - 1;           // empty
+    auto draws_of = [&](long long n) {
+        if (n < batch.base || n >= batch.base + DRAW_BATCH) {
+            const uint32_t nl = (uint32_t)n + (uint32_t)lane / 3u;
+            const uint32_t rl = nl / (uint32_t)nturns, ql = nl - rl * (uint32_t)nturns;
+            const uint64_t it = (uint64_t)R0 + rl;
+            uint32_t w[4];
+            philox4x32_10((uint32_t)it, (uint32_t)(it >> 32),
+                          (uint32_t)(P.chain0 + b + (int)ql * G), (unsigned)lane % 3u,
+                          (uint32_t)seed, (uint32_t)(seed >> 32), w);
+            batch.w0 = w[0];
+            batch.w1 = w[1];
+            batch.w2 = w[2];
+            batch.w3 = w[3];
+            batch.base = n;
+        }
+        const int l = 3 * (int)(n - batch.base);
+        Draws D;
+        D.d0 = batch_draw(batch, l);
+        D.d1 = batch_draw(batch, l + 1);
+        D.d2 = batch_draw(batch, l + 2);
+        return D;
+    };
+    // a turn on its way through the pipeline
+    struct Turn {
+        bool valid, go, sjump, outk;
+        int q, c;
+        long long R;
+        double npk, xk, zk, u, lo, hi;
+    };
+    Turn cur, pend, cand;                               // slot s, slot s - 1, slot s + 1
+    cur.valid = pend.valid = cand.valid = false;
+    // the turn to issue next, and what has been prepared for it
+    long long Rn = R0, tn = 0;
+    int qn = 0, cn = P.chain0 + b;
+    bool more = nref > 0;
+    Draws nxt = draws_of(tn);
+    request_rows(nxt, Rn);
+    double normal_ahead = need_normal ? normal_draw((uint64_t)Rn, cn) : 0.0;
+    double jump_ahead = 0.0;
+    bool jump_ready = false;
+    bool alive = true;
+
+    // What was asked for has arrived -- said HERE, before the decision's stores: loads and stores
+    // retire through one counter, and a wait behind the Z row's store waits for that store
+    // (~1 000 cycles).  The ordinary snooker jump (nine in ten) at once.
+    bool rows_there = false;
+    auto jump_early = [&]() {
+        if constexpr (SMP == MC3HIP_SNOOKER) {
+            jump_ready = false;
+            rows_there = false;
+            // (on every path, and the values named: the compiler then knows them settled, and puts
+            // no wait of its own in front of their next use -- which lies behind those stores)
+            __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0)
+            asm volatile("; rows" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]));
+            if (more) {
+                const bool there2 = !__any(mc3_bits(rv[0]) == ROW_PENDING ||
+                                           mc3_bits(rv[1]) == ROW_PENDING);
+                rows_there = there2 && !__any(mc3_bits(rv[2]) == ROW_PENDING);
+                if (there2 && !(u01(nxt.d1.q0) < 0.1)) {
+                    jump_ahead = gamma * (rv[0] - rv[1]) + fepsilon * normal_ahead;
+                    jump_ready = true;
+                }
+            }
+        }
+    };
+    // the proposal of turn (Rn, qn) into `np`; the order for the slot it opens
+    auto try_issue = [&](double *np) -> int {
+        cand.valid = false;
+        if (!alive)
+            return CW_STOP;
+        if (!more)
+            return cur.valid ? CW_SKIP : CW_STOP;       // (the last turn's tail and decision)
+        if (cur.valid && cur.q == qn)
+            return CW_SKIP;                             // (its previous turn is not decided yet)
+        if (Rn == abort_at && qn == 0) {                // test hook
+            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            alive = false;
+            return CW_STOP;
+        }
+        const double *slot = slots + qn * sstride;
+        const double xk = mine ? slot[lane] : 0.0;
+        double jump_k, zk = 0.0;
+        bool sjump = false;
+        if constexpr (SMP == MC3HIP_SNOOKER) {         // chain.py:195-217
+            if (jump_ready) {
+                jump_k = jump_ahead;
+            } else {
+                sjump = u01(nxt.d1.q0) < 0.1;
+                if (!rows_there) {
+                    if (cur.valid)
+                        return CW_SKIP;                 // (never wait with a turn in flight)
+                    alive = wait_rows<3, false>(ra, rv, ctl_rw) && alive;
+                    if (!alive)
+                        return CW_STOP;
+                }
+                const double z1 = rv[0], z2 = rv[1];
+                zk = rv[2];
+                if (sjump) {
+                    const double gs = 1.2 + (2.2 - 1.2) * u01(nxt.d2.q0);
+                    const bool same = __all(!mine || zk == xk);
+                    if (same) {
+                        jump_k = gs * (z2 - z1);
+                    } else {
+                        const double dz = xk - zk;
+                        const double zp1 = lane_serial_sum(z1 * dz, nf);
+                        const double zp2 = lane_serial_sum(z2 * dz, nf);
+                        const double dd = lane_serial_sum(dz * dz, nf);
+                        jump_k = ((gs * (zp1 - zp2)) * dz) / dd;
+                    }
+                } else {
+                    jump_k = gamma * (z1 - z2) + fepsilon * normal_ahead;
+                }
+            }
+        } else {                                        // chain.py:219-220
+            jump_k = normal_ahead;
+        }
+        const double npk = xk + jump_k;                 // chain.py:235-243
+        const bool outk = mine && (npk < pmin_k || npk > pmax_k);
+        const bool anyout = __any(outk);
+        if (mine)
+            np[jfree] = npk;
+        cand.valid = true;
+        cand.go = !anyout;
+        cand.sjump = sjump;
+        cand.outk = outk;
+        cand.q = qn;
+        cand.c = cn;
+        cand.R = Rn;
+        cand.npk = npk;
+        cand.xk = xk;
+        cand.zk = zk;
+        cand.u = (SMP == MC3HIP_SNOOKER) ? u01(nxt.d2.q1) : u01(nxt.d0.q1);   // chain.py:259
+        cand.lo = cand.hi = 0.0;
+        return anyout ? CW_SKIP : CW_GO;
+    };
+    // Metropolis, Z append and the books of a turn whose chisq is in s_result
+    auto decide = [&](const Turn &t) {
+        double *slot = slots + t.q * sstride;
+        double cur_c = slot[zs], best = slot[zs + 1];
+        long long nacc = (long long)mc3_bits(slot[zs + 2]);
+        double xk = t.xk;
+        bool accepted = false;
+        if (t.go) {
+            const double total = s_result[0];
+            // (as WaveletHook::finish: the prior term of a problem without priors is 0.0)
+            const double nextchisq = is_pos_inf(total) ? total : total + 0.0;
+            if (!t.sjump) {
+                accepted = metropolis_accept(0.5 * (cur_c - nextchisq), t.u, t.lo, t.hi);
+            } else {                                   // chain.py:251-255
+                const double dc = t.xk - t.zk, dn = t.npk - t.zk;
+                const double cnorm = lane_serial_sum(mine ? dc * dc : 0.0, nf);
+                const double nnorm = lane_serial_sum(mine ? dn * dn : 0.0, nf);
+                const double mrfactor = mc3_det_pow_half(nnorm / cnorm, nf - 1);
+                accepted = mc3_det_exp(0.5 * (cur_c - nextchisq)) * mrfactor > t.u;
+            }
+            if (accepted) {                            // chain.py:257-274
+                xk = t.npk;
+                cur_c = nextchisq;
+                nacc += 1;
+            }
+        } else {
+            oob += t.outk ? 1ull : 0ull;               // chain.py:242-243
+        }
+        const int lc = t.c - P.chain0;
+        const long long row = M0 + t.R * nchains + t.c;               // chain.py:276-289
+        if (mine)
+            __hip_atomic_store(&Zr[(size_t)row * zs + lane], xk, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);             // publish (sc1)
+        if (lane == 0) {
+            log_post[row] = -0.5 * cur_c;
+            zchain[row] = t.c;
+        }
+        if (accepted && cur_c < best) {
+            best = cur_c;
+            if (mine)
+                bestx[(size_t)lc * nf + lane] = xk;
+            if (lane == 0)
+                best_iter[lc] = t.R;
+        }
+        if (mine)
+            slot[lane] = xk;
+        if (lane == 0) {
+            slot[zs] = cur_c;
+            slot[zs + 1] = best;
+            slot[zs + 2] = mc3_from_bits((unsigned long long)nacc);
+        }
+    };
+
+    int par = 0, sn = 0;
+    PIPE_DIAG_DECL;
+    {
+        jump_early();
+        const int cmd0 = try_issue(np0);
+        if (lane == 0)
+            s_cmd[0] = cmd0;
+        cur = cand;
+    }
+    for (;;) {
+        PIPE_SYNC(0);                                  // (A) slot s: the proposal (or the order)
+        // (the order is this wave's own: read back, it is uniform without a branch on `cur`)
+        const int cmd = __builtin_amdgcn_readfirstlane(s_cmd[par]);
+        if (cmd == CW_STOP)
+            break;
+        // Level 0 of stage A is the long stretch (two compute waves per SIMD: ~3 700 cycles alone,
+        // ~5 000 beside the helpers), and all of this wave's work goes into it.
+        // While the tail wave is at the turn of slot s - 1: the turn after the one in flight -- its
+        // draws, its rows -- and the logarithm the Metropolis test is decided with.
+        PIPE_PART(-1);
+        if (cur.valid) {
+            const bool last_turn = qn + 1 == nturns;
+            qn = last_turn ? 0 : qn + 1;
+            Rn = last_turn ? Rn + 1 : Rn;
+            tn += 1;
+            cn = P.chain0 + b + qn * G;
+            more = Rn < R0 + nref;
+            if (more) {
+                nxt = draws_of(tn);
+                request_rows(nxt, Rn);
+                if (need_normal)
+                    normal_ahead = normal_draw((uint64_t)Rn, cn);
+            }
+        } else if (more) {
+            request_rows(nxt, Rn);                     // (a bubble: what was missing, again)
+        }
+        PIPE_PART(0);
+        if (pend.valid && pend.go) {
+            accept_window(pend.u, pend.lo, pend.hi);
+            asm volatile("; window" : "+v"(pend.lo), "+v"(pend.hi));
+        }
+        jump_early();
+        if (pend.valid) {
+            if (pend.go) {
+                PIPE_PART(1);
+                // the chisq: a word in LDS says so, long before the barrier does
+                while (__hip_atomic_load(&s_cmd[2], __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_WORKGROUP) != sn)
+                    __builtin_amdgcn_s_sleep(1);
+                PIPE_PART(2);
+            }
+            decide(pend);
+        }
+        PIPE_PART(3);
+        // the proposal for slot s + 1 (the other buffers: nobody reads those before (A))
+        const int cmd_next = try_issue(par ? np0 : np1);
+        PIPE_PART(4);
+        if (lane == 0)
+            s_cmd[par ^ 1] = cmd_next;
+        PIPE_SYNC(1);                                  // the halo barriers of stage A
+        PIPE_SYNC(2);
+        PIPE_SYNC(3);
+        if (nhalo > 3)
+            PIPE_SYNC(4);
+        PIPE_SYNC(5);                                  // (1) slot s
+        pend = cur;
+        cur = cand;
+        par ^= 1;
+        sn += 1;
+#ifdef MC3HIP_PIPE_DIAG
+        ++dg_n;
+#endif
+    }
+    PIPE_DIAG_PRINT("chain");
+#ifdef MC3HIP_PIPE_DIAG
+    if (blockIdx.x == 0 && lane == 0)
+        printf("chain wave: prepare %llu window %llu wait %llu decide %llu issue %llu\n",
+               dg_part[0] / dg_n, dg_part[1] / dg_n, dg_part[2] / dg_n, dg_part[3] / dg_n,
+               dg_part[4] / dg_n);
+#endif
+#ifdef MC3HIP_PIPE_DIAG
+    if (blockIdx.x == 0 && lane == 0)
+        printf("level 0 of waves 0..7: %llu %llu %llu %llu %llu %llu %llu %llu cycles (%llu likelihoods)\n",
+               mc3_pipe_diag[0] / mc3_pipe_diag[8], mc3_pipe_diag[1] / mc3_pipe_diag[8],
+               mc3_pipe_diag[2] / mc3_pipe_diag[8], mc3_pipe_diag[3] / mc3_pipe_diag[8],
+               mc3_pipe_diag[4] / mc3_pipe_diag[8], mc3_pipe_diag[5] / mc3_pipe_diag[8],
+               mc3_pipe_diag[6] / mc3_pipe_diag[8], mc3_pipe_diag[7] / mc3_pipe_diag[8],
+               mc3_pipe_diag[8]);
+#endif
+    if (mine && oob)
+        atomicAdd(&P.outbounds[lane], oob);
+    for (int q = 0; q < nturns; ++q) {
+        const int l = b + q * G;
+        const double *slot = slots + q * sstride;
+        if (mine)
+            P.X[(size_t)l * nf + lane] = slot[lane];
+        if (lane == 0) {
+            P.chisq[l] = slot[zs];
+            P.best_chisq[l] = slot[zs + 1];
+            P.numaccept[l] = (long long)mc3_bits(slot[zs + 2]);
+        }
+    }
+}
+
+template <int MT, int SMP>
+__global__ __launch_bounds__(704) void wavelet_pipe_kernel(const DevProblem P, const int nref)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const SmemLayout L = carve(smem, P, 512);           // the compute waves' areas
+    double *own = L.xs + (P.ndata > 128 ? P.ndata : 128);
+    // (the area the general chain would use behind the nine-wave kernel: the second proposal and
+    // the second noise table)
+    double *np1 = own, *tab1 = own + MC3HIP_MAX_PARAMS;
+    static_assert(MC3HIP_MAX_PARAMS + 48 <= CW_OWN, "room behind the compute waves' areas");
+    int *s_cmd = reinterpret_cast<int *>(own + CW_OWN);
+    double *s_result = own + CW_OWN + 2;
+    const int tid = threadIdx.x;
+    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
+            &P.ctl[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+        return;
+    if (tid < 512)
+        wavelet_stage<8, MT>(P, L.xs);
+    block_sync<9>();
+    const int B = P.ndata / 512;                        // 16 or 32 (mc3hip.hip choose_wpc)
+    const int nhalo = ilog2(B) - 1;                     // 3 or 4 (the waves below count on it)
+    const int M = ilog2(P.ndata);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (the chain wave and the tail wave are what a slot waits for; the noise wave has time)
+    if (wave == 8 || wave == 9)
+        __builtin_amdgcn_s_setprio(3);
+    if (wave == 8) {
+        pipe_chain_wave<SMP>(P, nref, L.nextp, np1, L.tab, tab1, s_cmd, s_result, nhalo, M,
+                             smem + P.mc_off);
+        return;
+    }
+    if (wave == 10) {
+        // ---- the noise wave: the noise terms of slot s's proposal (software exp2 / log /
+        // reciprocals, the ordered log-determinant sum: ~2 500 dependent cycles), needed by the
+        // end of stage A; a wave of its own so that the three helpers sit on three SIMDs
+        int par = 0;
+        for (;;) {
+            block_sync<9>();                            // (A) slot s
+            const int cmd = s_cmd[par];
+            if (cmd == CW_STOP)
+                return;
+            if (cmd == CW_GO)
+                wavelet_noise_terms(par ? np1 : L.nextp, P.nparams, M, par ? tab1 : L.tab);
+            for (int k = 0; k <= nhalo; ++k)
+                block_sync<9>();
+            par ^= 1;
+        }
+    }
+    if (wave == 9) {
+        // ---- the tail wave ------------------------------------------------------------------
+        PipeTail<8> tail;
+        bool have = false;
+        int par = 0, sn = 0;
+        if ((tid & 63) == 0)
+            s_cmd[2] = -1;
+        PIPE_DIAG_DECL;
+        for (;;) {
+            PIPE_SYNC(0);                               // (A) slot s
+            const int cmd = s_cmd[par];
+            if (cmd == CW_STOP)
+                break;
+            if (have) {
+                // the turn of slot s - 1 (its noise table and its flag are the other ones), all of
+                // it before the first halo barrier: level 0 takes the compute waves longer than
+                // this, and what is read here they overwrite at the END of stage A
+                tail.load(L.part, L.halo, L.flag + 2 * (par ^ 1));
+                const double *tab = par ? L.tab : tab1;
+                const double c = (B == 32) ? tail.run<32>(tab, M) : tail.run<16>(tab, M);
+                if ((tid & 63) == 0) {
+                    s_result[0] = c;
+                    __hip_atomic_store(&s_cmd[2], sn, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);     // (LDS keeps the order)
+                }
+            }
+            PIPE_SYNC(1);                               // the halo barriers of stage A
+            PIPE_SYNC(2);
+            PIPE_SYNC(3);
+            if (nhalo > 3)
+                PIPE_SYNC(4);
+            PIPE_SYNC(5);                               // (1) slot s
+            have = cmd == CW_GO;
+            par ^= 1;
+            sn += 1;
+#ifdef MC3HIP_PIPE_DIAG
+            ++dg_n;
+#endif
+        }
+        PIPE_DIAG_PRINT("tail");
+        return;
+    }
+    // ---- the compute waves -------------------------------------------------------------------
+    int par = 0;
+    for (;;) {
+        block_sync<9>();                                // (A)
+        const int cmd = s_cmd[par];
+        const double *np = par ? np1 : L.nextp;
+        double *tab = par ? tab1 : L.tab;
+        int *flag = L.flag + 2 * par;                   // ("a model value was +inf": flag[1])
+        Model<MT> model;
+        model.init(P, np);
+        if (cmd == CW_STOP)
+            return;
+        par ^= 1;
+        if (cmd != CW_GO) {
+            for (int k = 0; k <= nhalo; ++k)
+                block_sync<9>();                        // (the slot belongs to the other two waves)
+            continue;
+        }
+        if (B == 32)
+            wavelet_body<8, MT, 32, false, true, true>(P, np, L.part, flag, tab, L.halo, L.xs,
+                                                       nullptr, 0, nullptr, 0, &model);
+        else
+            wavelet_body<8, MT, 16, false, true, true>(P, np, L.part, flag, tab, L.halo, L.xs,
+                                                       nullptr, 0, nullptr, 0, &model);
+    }
+}
+
 }  // namespace mc3hip

@@ -348,7 +348,7 @@ hipError_t set_smem_attr_wavelet(mc3hip_ctx *c)
 // threads and dynamic LDS of the general persistent instance that runs
 int persist_threads(const mc3hip_ctx *c, bool p2p)
 {
-    return chainwave_runs(c, p2p) ? CW_THREADS : 64 * c->wpc;
+    return chainwave_runs(c, p2p) ? chainwave_threads(c, p2p) : 64 * c->wpc;
 }
 size_t persist_smem(const mc3hip_ctx *c, bool p2p)
 {
@@ -527,7 +527,7 @@ int decide_persist(mc3hip_ctx *c)
             }
             const bool cw_now = attempt == 0 && cw;
             const size_t base = c->smem + (cw_now ? CW_EXTRA_DOUBLES * sizeof(double) : 0);
-            const int threads = cw_now ? CW_THREADS : 64 * c->wpc;
+            const int cw_wpc = 64 * c->wpc;
             for (int turns = 2; turns <= (p2p_ctx ? 4 : MC_MAX_TURNS) && !found; ++turns) {
                 c->mc_chains = turns;                       // (selects the MC instance)
                 const size_t smem = base + (size_t)turns * (c->P.zs + 4) * sizeof(double);
@@ -538,6 +538,7 @@ int decide_persist(mc3hip_ctx *c)
                 if (f && smem > 64 * 1024)
                     (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
                                               (int)smem);
+                const int threads = cw_now ? chainwave_threads(c, false) : cw_wpc;
                 int nbm = blocks_per_cu(f, threads, smem);
                 if (p2p_ctx) {
                     // (a context made for the peer-to-peer hand-off runs the plain instance

@@ -314,7 +314,12 @@ __device__ __forceinline__ void wavelet_noise_terms(const double *s_nextp, int n
 // takes part in every workgroup barrier here, doing nothing in between): a thread folds its
 // stage-A sums with the weights right away, and the two barriers that waited for the noise
 // terms and for those sums are gone.
-template <int WPC, int MT, int B, bool VALUES = false, bool CW = false>
+#ifdef MC3HIP_PIPE_DIAG
+__device__ unsigned long long mc3_pipe_diag[16];
+#endif
+// PIPE (kernels_wavelet.h wavelet_pipe_kernel): stage A only -- everything behind barrier (1) is
+// run by a wave of its own (PipeTail below) while these waves start on the next likelihood.
+template <int WPC, int MT, int B, bool VALUES = false, bool CW = false, bool PIPE = false>
 __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double *s_nextp,
                                                double *s_part, int *s_flag, double *s_tab,
                                                double *s_halo, const double *xs,
@@ -351,6 +356,9 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
     // (software exp2 / log; cross-lane levels) side by side instead of one after the other.
     if constexpr (WPC == 1)
         wavelet_noise_terms(s_nextp, P.nparams, M, s_tab);
+#ifdef MC3HIP_PIPE_DIAG
+    const unsigned long long dg_in = __builtin_amdgcn_s_memtime();
+#endif
     MC3_LSTAMP(8);
     // ---- stage A: log2 B levels in registers ------------------------------------------
     constexpr int HB = (B / 2 > 2) ? B / 2 : 2;
@@ -365,6 +373,14 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
         accA[0] = wavelet_level0<WPC, MT, B, true, HB + 2>(P, model, xs, me, next, Ta, sawinf, v);
     else
         accA[0] = wavelet_level0<WPC, MT, B, false, HB + 2>(P, model, xs, me, next, Ta, sawinf, v);
+#ifdef MC3HIP_PIPE_DIAG
+    if (PIPE && blockIdx.x == 0 && (tid & 63) == 0) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        atomicAdd(&mc3_pipe_diag[tid >> 6], now - dg_in);
+        if (tid == 0)
+            atomicAdd(&mc3_pipe_diag[8], 1ull);
+    }
+#endif
     MC3_LSTAMP(14);
     double2 *halo = reinterpret_cast<double2 *>(s_halo);  // [2][T]
     if (N >= 4) {
@@ -397,6 +413,8 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
         if constexpr (CW)
             s_part[tid] = (active && N >= 4) ? stage_a_sum() : 0.0;
         block_sync<WPC>();                              // (1) the T values are in LDS
+        if constexpr (PIPE)
+            return 0.0;
         if (!CW && wave == WPC - 1)
             wavelet_noise_terms(s_nextp, P.nparams, M, s_tab);
         if (CW && wave == TW) {
@@ -517,6 +535,87 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
     const double S = (a0 * a0) / sS2 + (a1 * a1) / sS2;
     return (S + s_tab[25]) + Tsum;
 }
+
+// Everything of wavelet_body<WPC, MT, B, false, CW> behind barrier (1), for ONE wave that is not
+// one of the WPC: load() between (1) and the next likelihood's first barrier (the stage-A sums,
+// the T values and the flag are overwritten by the next stage A), run() whenever -- the same
+// arithmetic in the same order as the tail above, so the value is bit-identical.
+template <int WPC>
+struct PipeTail {
+    double vb[WPC + 2];
+    double pA;
+    int sawinf;
+
+    __device__ __forceinline__ void load(const double *s_part, const double *s_halo,
+                                         const int *s_flag)
+    {
+        constexpr int T = 64 * WPC;
+        const int lane = threadIdx.x & 63;
+        const double *ubuf = s_halo + 4 * T + 64;
+        double p[WPC];
+#pragma unroll
+        for (int q = 0; q < WPC; ++q)
+            p[q] = s_part[lane + 64 * q];
+#pragma unroll
+        for (int j = 0; j < WPC; ++j)
+            vb[j] = ubuf[WPC * lane + j];
+        const int hbase = (WPC * (lane + 1)) & (T - 1);
+        vb[WPC] = ubuf[hbase];
+        vb[WPC + 1] = ubuf[hbase + 1];
+        sawinf = s_flag[1];
+#pragma unroll
+        for (int s2 = WPC / 2; s2 >= 1; s2 >>= 1) {
+#pragma unroll
+            for (int q = 0; q < s2; ++q)
+                p[q] = p[q] + p[q + s2];
+        }
+        pA = p[0];
+    }
+
+    template <int B>
+    __device__ __forceinline__ double run(const double *s_tab, const int M)
+    {
+        constexpr int NLA = ilog2c(B), NLB = ilog2c(WPC);
+        const int lane = threadIdx.x & 63;
+        const int mA = M - 1;
+        double accB[NLB];
+        accB[0] = block_level<WPC, WPC + 2>(vb);
+        block_levels<WPC / 2, WPC + 2, 1, false, 1, NLB>(vb, accB, nullptr, 64, lane,
+                                                         (lane + 1) & 63, true);
+        double u = vb[0];
+        const int mC = mA - NLA - NLB;
+        int nn = 64, nC = 0;
+        double accC[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int l = 0; l < 6; ++l) {
+            if (nn >= 4) {
+                const int nh = nn >> 1;
+                const int i2 = (lane < nh) ? 2 * lane : 0;
+                const int i3 = (i2 + 2) & (nn - 1);
+                const double c0 = lane_gather(u, i2), c1 = lane_gather(u, i2 + 1);
+                const double c2 = lane_gather(u, i3), c3 = lane_gather(u, i3 + 1);
+                double s, d;
+                d4_pair(c0, c1, c2, c3, s, d);
+                accC[l] = (lane < nh) ? d * d : 0.0;
+                u = s;
+                nn = nh;
+                nC = l + 1;
+            }
+        }
+        double sA = pA, sB = weigh_levels<NLB>(accB, s_tab, mA - NLA), sC = 0.0;
+#pragma unroll
+        for (int l = 0; l < 6; ++l)
+            if (l < nC)
+                sC = mc3_fma(accC[l], s_tab[mC - l], sC);
+        wave_sum3(sA, sB, sC);
+        const double a0c = read_lane(u, 0), a1c = read_lane(u, 1);
+        if (sawinf)
+            return mc3_from_bits(0x7ff0000000000000ull);
+        const double sS2c = s_tab[24];
+        const double Sc = (a0c * a0c) / sS2c + (a1c * a1c) / sS2c;
+        return (Sc + s_tab[25]) + ((sA + sB) + sC);
+    }
+};
 
 // More than 32 points per thread (ndata > 2^14): "pre-levels" bring the pyramid down to
 // 2^14 values first.  Output i of a pre-level belongs to thread i mod T (strided, coalesced);

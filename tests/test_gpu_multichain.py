@@ -314,14 +314,37 @@ def test_lean_snooker_and_mrw_loops_with_several_chains_per_wave(eng, monkeypatc
         gpu.close()
 
 
-@pytest.mark.parametrize('case', ['plain', 'epsilon', 'tight', 'resume', 'abort', 'general'])
+@pytest.mark.parametrize('nchains,capacity,turns', [(5, 4, 2), (9, 2, 5), (7, 1, 7)])
+@pytest.mark.parametrize('sampler', ['snooker', 'mrw'])
+def test_wavelet_pipeline_uneven_and_deep(eng, monkeypatch, sampler, nchains, capacity, turns):
+    """The pipelined kernel where its slots do not fill by themselves: a workgroup with ONE chain
+    (5 chains over 3 workgroups: 2, 2, 1 -- every other slot is a bubble, the chain's previous turn
+    must be decided first), five and four chains, and the whole ensemble in one workgroup (every
+    history row snooker asks for is this workgroup's own: what is still in flight is waited for
+    with an empty slot, never with a spin)."""
+    forced(monkeypatch, capacity)
+    prob = H.wavelet_problem(ndata=8192, nchains=nchains, nsamples=nchains*80, sampler=sampler)
+    orc, gpu = run_pair(eng, prob, trace=False)
+    check_plan(gpu, turns=turns, fast=3)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
+@pytest.mark.parametrize('case', ['plain', 'epsilon', 'tight', 'resume', 'abort', 'general',
+                                  'turns'])
 @pytest.mark.parametrize('ndata,sampler', [(8192, 'snooker'), (16384, 'demc'), (8192, 'mrw'),
                                            (16384, 'snooker')])
 def test_wavelet_chain_wave_takes_turns(eng, monkeypatch, ndata, sampler, case):
-    """The nine-wave wavelet kernel with several chains per workgroup: the hand-structured
-    chain wave advances them in turn and prepares, during a likelihood, the NEXT turn's
-    proposal (another chain's).  11 chains over 4 workgroups: 3, 3, 3, 2."""
+    """The wavelet kernels with a wave of their own for the chain and several chains per
+    workgroup.  snooker and mrw: eleven waves, the chains pipelined (wavelet_pipe_kernel: the tail
+    of one chain's likelihood, the noise terms and the chain itself on three helper waves while
+    the eight compute waves are at the next chain's stage A); DEMC, and the others behind
+    MC3HIP_NO_CW_PIPE ('turns'): nine waves, the chain wave advances the chains in turn and
+    prepares, during a likelihood, the NEXT turn's proposal.  11 chains over 4 workgroups:
+    3, 3, 3, 2."""
     forced(monkeypatch, 4)
+    if case == 'turns':
+        monkeypatch.setenv('MC3HIP_NO_CW_PIPE', '1')
     prob = H.wavelet_problem(ndata=ndata, nchains=11, nsamples=11*50, sampler=sampler)
     if case == 'epsilon':
         prob.update(fepsilon=0.03, fgamma=0.8)

@@ -61,6 +61,10 @@ CONFIGS = {
                                               sampler='snooker'), {}),
     'c4x2': lambda n: (H.wavelet_problem(ndata=16384, nchains=512, nsamples=512*n), {}),
     'c4x4': lambda n: (H.wavelet_problem(ndata=16384, nchains=1024, nsamples=1024*n), {}),
+    'c4x2wide': lambda n: (H.wavelet_problem(ndata=16384, nchains=512, nsamples=512*n,
+                                             pmin=np.full(6, -1e3), pmax=np.full(6, 1e3)), {}),
+    'c4x2mrw': lambda n: (H.wavelet_problem(ndata=16384, nchains=512, nsamples=512*n,
+                                            sampler='mrw'), {}),
     'c4mrw': lambda n: (H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*n,
                                           sampler='mrw'), {}),
     'c4demc': lambda n: (H.wavelet_problem(ndata=16384, nchains=256, nsamples=256*n,
@@ -170,7 +174,7 @@ ITERS = {'c2': 20000, 'c2snooker': 20000, 'c2mrw': 20000, 'c3one': 4000, 'c4': 4
 ITERS['c5'] = 300
 ITERS['q5'] = 300
 ITERS.update(c4big=1000, c4wide=4000, c4mrw=4000, c4demc=4000, c4half=4000, c3x2=3000, c3x4=2000, c3x2snooker=3000,
-             c4x2=2000, c4x4=1000)
+             c4x2=2000, c4x4=1000, c4x2wide=2000, c4x2mrw=2000)
 ITERS.update(c3x2mrw=3000, c3onesnooker=4000, p6=200, p6matrix=200, c3x4snooker=1500,
              c3x4mrw=1500)
 BYTES['c3x4snooker'] = BYTES['c3x4mrw'] = 24104
@@ -200,7 +204,7 @@ CONFIGS['c3x2lag4'] = lambda n: (H.quad_problem(ndata=1000, nchains=4096, nsampl
 ITERS.update(c3x4lag4=2000, c3x2lag4=3000)
 BYTES['c3x4lag4'] = BYTES['c3x2lag4'] = 24104
 BYTES['c4big'] = 8*2*65536 + 8*5*4 + 8
-for _k in ('c4x2', 'c4x4', 'c4wide'):
+for _k in ('c4x2', 'c4x4', 'c4wide', 'c4x2wide', 'c4x2mrw'):
     BYTES[_k] = BYTES['c4']
 
 
