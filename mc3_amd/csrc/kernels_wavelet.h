@@ -1124,9 +1124,9 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
     };
     // a turn on its way through the pipeline
     struct Turn {
-        bool valid, go, sjump, outk;
+        bool valid, go, sjump, outk, spec;
         int q, c;
-        long long R;
+        long long R, n;
         double npk, xk, zk, u, lo, hi;
     };
     Turn cur, pend, cand;                               // slot s, slot s - 1, slot s + 1
@@ -1172,8 +1172,13 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
             return CW_STOP;
         if (!more)
             return cur.valid ? CW_SKIP : CW_STOP;       // (the last turn's tail and decision)
-        if (cur.valid && cur.q == qn)
-            return CW_SKIP;                             // (its previous turn is not decided yet)
+        // The chain's previous turn is the one in flight (one chain in this workgroup): SPECULATE
+        // ON REJECT.  Most proposals are rejected, and after a reject the next proposal starts
+        // from the state this turn started from -- so it is issued as if; if the turn in flight is
+        // accepted after all, this one is squashed (nothing of it has left the workgroup: its
+        // likelihood runs to its end unread) and issued again from the new state.  A proposal out
+        // of bounds is a reject already.
+        const bool spec = cur.valid && cur.q == qn && cur.go;
         if (Rn == abort_at && qn == 0) {                // test hook
             __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -1223,6 +1228,8 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
         if (mine)
             np[jfree] = npk;
         cand.valid = true;
+        cand.spec = spec;
+        cand.n = tn;
         cand.go = !anyout;
         cand.sjump = sjump;
         cand.outk = outk;
@@ -1237,7 +1244,7 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
         return anyout ? CW_SKIP : CW_GO;
     };
     // Metropolis, Z append and the books of a turn whose chisq is in s_result
-    auto decide = [&](const Turn &t) {
+    auto decide = [&](const Turn &t) -> bool {
         double *slot = slots + t.q * sstride;
         double cur_c = slot[zs], best = slot[zs + 1];
         long long nacc = (long long)mc3_bits(slot[zs + 2]);
@@ -1287,6 +1294,7 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
             slot[zs + 1] = best;
             slot[zs + 2] = mc3_from_bits((unsigned long long)nacc);
         }
+        return accepted;
     };
 
     int par = 0, sn = 0;
@@ -1340,7 +1348,23 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
                     __builtin_amdgcn_s_sleep(1);
                 PIPE_PART(2);
             }
-            decide(pend);
+            const bool accepted = decide(pend);
+            if (accepted && cur.valid && cur.spec && cur.q == pend.q) {
+                // the turn in flight started from a state that is no more: squashed, and what
+                // was prepared behind it rewound to it
+                cur.valid = false;
+                Rn = cur.R;
+                qn = cur.q;
+                tn = cur.n;
+                cn = cur.c;
+                more = true;
+                nxt = draws_of(tn);
+                request_rows(nxt, Rn);
+                if (need_normal)
+                    normal_ahead = normal_draw((uint64_t)Rn, cn);
+                jump_ready = false;
+                rows_there = false;
+            }
         }
         PIPE_PART(3);
         // the proposal for slot s + 1 (the other buffers: nobody reads those before (A))

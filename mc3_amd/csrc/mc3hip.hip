@@ -504,7 +504,14 @@ int decide_persist(mc3hip_ctx *c)
         if (nb < 1)
             return 0;
     }
-    if (c->P.nlocal > capacity) {
+    // The wavelet kernel pipelined over the turns of a workgroup (kernels_wavelet.h
+    // wavelet_pipe_kernel) also serves ONE chain per workgroup: the next proposal is issued as if
+    // the one in flight were rejected (most are), and issued again if it was not.
+    const bool spec_pipe = !c->fast && c->chainwave && c->P.cw_lean != 0 &&
+                           c->P.sampler != MC3HIP_DEMC && c->P.nlocal <= capacity &&
+                           !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 &&
+                           !getenv("MC3HIP_NO_CW_PIPE") && !getenv("MC3HIP_NO_CW_SPEC");
+    if (c->P.nlocal > capacity || spec_pipe) {
         // More chains than workgroups can be co-resident: a workgroup advances several per
         // refresh (run_chain MC), as the reference's workers do with their ncpp chains
         // (mc3/chain.py:163,190-191).  The fewest turns whose grid fits: the waiting state of
@@ -513,12 +520,13 @@ int decide_persist(mc3hip_ctx *c)
         // One GPU -- or, sharded over several, the loops with the chains of a wave side by side
         // (kernels_rows.h: up to four chains per wave, peer to peer as well).
         const bool p2p_ctx = (c->flags & MC3HIP_FLAG_P2P) || c->p2p_ranks > 1;
-        if (getenv("MC3HIP_NO_MULTICHAIN") || (p2p_ctx && !(c->fast && lean_rows_shape(c))))
+        if (!spec_pipe &&
+            (getenv("MC3HIP_NO_MULTICHAIN") || (p2p_ctx && !(c->fast && lean_rows_shape(c)))))
             return 0;
         // (the nine-wave wavelet kernel takes turns only with its hand-structured chain wave;
         // should its LDS not leave room for the waiting states, the fused kernel is tried)
         bool found = false;
-        for (int attempt = 0; attempt < 2 && !found; ++attempt) {
+        for (int attempt = 0; attempt < (spec_pipe ? 1 : 2) && !found; ++attempt) {
             const bool cw = !c->fast && c->chainwave && c->P.cw_lean != 0;
             if (attempt == 1) {
                 if (!cw)
@@ -528,7 +536,8 @@ int decide_persist(mc3hip_ctx *c)
             const bool cw_now = attempt == 0 && cw;
             const size_t base = c->smem + (cw_now ? CW_EXTRA_DOUBLES * sizeof(double) : 0);
             const int cw_wpc = 64 * c->wpc;
-            for (int turns = 2; turns <= (p2p_ctx ? 4 : MC_MAX_TURNS) && !found; ++turns) {
+            for (int turns = spec_pipe ? 1 : 2; turns <= (p2p_ctx ? 4 : (spec_pipe ? 1 : MC_MAX_TURNS)) && !found;
+                 ++turns) {
                 c->mc_chains = turns;                       // (selects the MC instance)
                 const size_t smem = base + (size_t)turns * (c->P.zs + 4) * sizeof(double);
                 if (smem > 160 * 1024)
@@ -564,7 +573,8 @@ int decide_persist(mc3hip_ctx *c)
         }
         if (!found) {
             c->mc_chains = 0;
-            return 0;
+            if (!spec_pipe)
+                return 0;                                   // (else: the nine-wave kernel, as ever)
         }
     }
     c->capacity = capacity;

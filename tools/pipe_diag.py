@@ -27,11 +27,12 @@ from mc3_amd import engine  # noqa: E402
 import bench_configs as BC  # noqa: E402
 
 name = ([a for a in sys.argv[1:] if not a.startswith('--')] or ['c4x2wide'])[0]
-prob, kw = BC.CONFIGS[name](600)
+N = int(os.environ.get('PIPE_DIAG_ITERS', '600'))
+prob, kw = BC.CONFIGS[name](N)
 g = engine.DeviceChains(**prob, **kw)
 Z0, lp0 = BC.population(g, prob)
 g.set_population(Z0, lp0)
-g.run(600)
+g.run(N)
 g.state()
 print(g.plan)
 g.close()
