@@ -314,6 +314,51 @@ def test_lean_snooker_and_mrw_loops_with_several_chains_per_wave(eng, monkeypatc
         gpu.close()
 
 
+@pytest.mark.parametrize('case', ['plain', 'tight', 'wide', 'abort', 'resume', 'nospec'])
+@pytest.mark.parametrize('ndata,sampler', [(8192, 'snooker'), (16384, 'mrw'), (16384, 'snooker')])
+def test_wavelet_one_chain_per_workgroup_speculates_on_reject(eng, monkeypatch, ndata, sampler, case):
+    """One chain per workgroup on the pipelined kernel: the next proposal is issued while the one
+    in flight is undecided, as if that one were rejected; after an accept it is squashed and issued
+    again from the new state.  Nothing of a squashed proposal may show: same rows, same counters
+    (accepts, out-of-bounds), same best fit as the checker -- with bounds that reject a third of
+    the proposals before the likelihood, with none, across launches, through a give-up, and behind
+    the switch (the nine-wave kernel: one proposal at a time)."""
+    prob = H.wavelet_problem(ndata=ndata, nchains=6, nsamples=6*150, sampler=sampler)
+    if case == 'tight':
+        prob.update(pmin=np.array([2.6, -2.6, 0.47, 0.0, 0.3, 0.8]),
+                    pmax=np.array([3.4, -2.2, 0.53, 2.0, 0.7, 1.2]))
+    if case == 'wide':
+        prob.update(pmin=np.full(6, -1e3), pmax=np.full(6, 1e3))
+    if case == 'nospec':
+        monkeypatch.setenv('MC3HIP_NO_CW_SPEC', '1')
+    if case == 'abort':
+        monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '40')
+    if case == 'resume':
+        monkeypatch.setenv('MC3HIP_PERSIST_REFS', '11')
+        gpu = eng.DeviceChains(**prob)
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nthreads=4)
+        for n in (1, 2, 50, 97):
+            gpu.run(n)
+    else:
+        orc, gpu = run_pair(eng, prob, trace=False)
+    plan = gpu.plan
+    if case == 'abort':                  # (the launch gave up: redone one launch per refresh)
+        assert plan['recoveries'] == 1, plan
+    else:
+        assert plan['persistent'] > 0 and plan['fast'] == 3 and plan['recoveries'] == 0, plan
+        assert plan['chains_per_workgroup'] == 1, plan
+    assert_same(orc, gpu, trace=False)
+    st = gpu.state()
+    assert st['numaccept'].sum() > 20               # (accepts there were: squashes too)
+    if case == 'tight':
+        assert st['outbounds'].sum() > 50
+    gpu.close()
+
+
 @pytest.mark.parametrize('nchains,capacity,turns', [(5, 4, 2), (9, 2, 5), (7, 1, 7)])
 @pytest.mark.parametrize('sampler', ['snooker', 'mrw'])
 def test_wavelet_pipeline_uneven_and_deep(eng, monkeypatch, sampler, nchains, capacity, turns):
