@@ -3,7 +3,7 @@
 # profiles/r04_* by tools/reduce_r04.py).  rocprofv3 is always given python3 itself; PMC passes
 # are separate runs with nothing but --pmc (+ --kernel-trace for the kernel names).
 #   bash tools/collect_r04.sh [part ...]
-# parts: bench kt pmc configs offlean lag sweep sweep8 ranks big c4 c5
+# parts: bench kt pmc configs offlean lag sweep sweep8 ranks big c4 c4x2 c5 c4family
 out=gpurun_out/r04
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -68,7 +68,7 @@ for cfg in ${BIGCFGS:-c3x4 c3x2mrw c3one}; do
         SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS --kernel-trace \
         --output-format csv -d $out/pmc3_$cfg -o $cfg -- python3 tools/bench_configs.py $cfg > $out/pmc3_$cfg.log 2>&1
 done
-for cfg in c4 c5; do
+for cfg in c4 c4x2 c5; do
     has $cfg || continue
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$cfg -o $cfg -- \
         python3 tools/bench_configs.py $cfg > $out/kt_$cfg.log 2>&1
@@ -82,4 +82,14 @@ for cfg in c4 c5; do
         SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 --kernel-trace \
         --output-format csv -d $out/pmc3_$cfg -o $cfg -- python3 tools/bench_configs.py $cfg > $out/pmc3_$cfg.log 2>&1
 done
+if has c4family; then
+    # the wavelet configurations after the pipelined kernel (tools/reduce_r04.py patches their
+    # lines in profiles/r04_configs.jsonl), and where a slot of it goes
+    timeout 900 python tools/bench_configs.py c4 c4wide c4demc c4mrw c4x2 c4x4 c4x2wide c4x2mrw \
+        > $out/c4family_configs.jsonl 2> $out/c4family_configs.err
+    for cfg in c4 c4wide c4x2 c4x2wide c4x4; do
+        echo "== $cfg" >> $out/c4_pipe_diag.txt
+        PIPE_DIAG_ITERS=2000 timeout 300 python tools/pipe_diag.py $cfg 2>&1 | grep -v "^{" | tail -4 >> $out/c4_pipe_diag.txt
+    done
+fi
 ls $out

@@ -56,9 +56,33 @@ for rel, name in (('configs.jsonl', 'configs.jsonl'),
                   ('kt_c2/c2_agent_info.csv', 'agent_info.csv'),
                   ('kt_c3x4/c3x4_kernel_stats.csv', 'c3x4_kernel_stats.csv'),
                   ('kt_c4/c4_kernel_stats.csv', 'c4_wavelet_kernel_stats.csv'),
+                  ('kt_c4x2/c4x2_kernel_stats.csv', 'c4x2_wavelet_kernel_stats.csv'),
+                  ('c4_pipe_diag.txt', 'c4_pipe_diag.txt'),
                   ('kt_c5/c5_kernel_stats.csv', 'c5_resident_kernel_stats.csv')):
     if have(rel):
         shutil.copy(os.path.join(R, rel), os.path.join(D, 'r04_' + name))
+
+# the wavelet configurations measured again after the pipelined kernel: their lines replace the
+# earlier ones in r04_configs.jsonl (which move to r04_configs_c4_before.jsonl)
+if have('c4family_configs.jsonl') and os.path.exists(os.path.join(D, 'r04_configs.jsonl')):
+    new = {}
+    for line in open(os.path.join(R, 'c4family_configs.jsonl')):
+        if line.startswith('{'):
+            new[json.loads(line)['config']] = line
+    old = open(os.path.join(D, 'r04_configs.jsonl')).read().splitlines(True)
+    before_path = os.path.join(D, 'r04_configs_c4_before.jsonl')
+    keep, before = [], []
+    for line in old:
+        name = json.loads(line)['config']
+        if name in new:
+            before.append(line)
+            keep.append(new.pop(name))
+        else:
+            keep.append(line)
+    keep += list(new.values())
+    if before and not os.path.exists(before_path):
+        open(before_path, 'w').writelines(before)
+    open(os.path.join(D, 'r04_configs.jsonl'), 'w').writelines(keep)
 
 # C2: HBM traffic of the headline kernel (one counter per pass)
 if have('pmc_c2_FETCH_SIZE/c2_counter_collection.csv'):
@@ -90,7 +114,7 @@ if have('pmc_c2_FETCH_SIZE/c2_counter_collection.csv'):
 # large ensembles: instruction mix and stall counters of the several-chains-per-wave loops
 BIG = {'c3x4': ('lean_demc_rows_kernel', 2000, 8192), 'c3x2mrw': ('lean_mrw_mc_kernel', 3000, 4096),
        'c3one': ('lean_demc_kernel', 4000, 2048),
-       'c4': ('wavelet_cw_kernel', 4000, 256), 'c5': ('resident_tile_kernel', 300, 512)}
+       'c4': ('wavelet_pipe_kernel', 4000, 256), 'c4x2': ('wavelet_pipe_kernel', 2000, 512), 'c5': ('resident_tile_kernel', 300, 512)}
 for cfg, (pick, iters, chains) in BIG.items():
     if not have(f'pmc1_{cfg}/{cfg}_counter_collection.csv'):
         continue

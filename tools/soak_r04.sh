@@ -5,6 +5,18 @@ part=${1:-all}
 out=gpurun_out/r04_soak_$part.txt
 : > $out
 run() { timeout 600 python tests/soak.py "$@" 2>&1 | grep -v Yippee | tail -1 | cut -c1-600 >> $out; }
+if [ $part = wavelet ]; then
+# the pipelined wavelet kernel (kernels_wavelet.h wavelet_pipe_kernel): one chain per workgroup
+# (speculation on reject), two and four
+run 3000 snooker 256 wavelet 16384
+run 1500 snooker 512 wavelet 16384
+run 800 snooker 1024 wavelet 16384
+run 1500 mrw 512 wavelet 16384
+run 3000 mrw 256 wavelet 8192
+run 2000 snooker 300 wavelet 8192
+cat $out
+exit 0
+fi
 if [ $part != rows ]; then
 run 40000 demc 256 zlag=4
 run 40000 demc 256 zlag=1
