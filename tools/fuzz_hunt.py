@@ -19,6 +19,8 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 bad = 0
 for seed in range(first, first + count):
     kind = seed % 4 if 'big' not in sys.argv else 4
+    if os.environ.get('FUZZ_KIND'):       # (one generator only, e.g. 2 = the wavelet likelihood)
+        kind = int(os.environ['FUZZ_KIND'])
     if kind == 3:
         # round 4's kernels: the declared cadence, the support distribution, the run-time
         # specialised shapes
