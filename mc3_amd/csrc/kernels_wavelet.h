@@ -1306,8 +1306,10 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
             s_cmd[0] = cmd0;
         cur = cand;
     }
+    PIPE_SYNC(0);                                      // (A): the first proposal (or the order)
     for (;;) {
-        PIPE_SYNC(0);                                  // (A) slot s: the proposal (or the order)
+        // (every later slot begins at barrier (1) of the one before: the proposal and the order
+        // for it were written long before that)
         // (the order is this wave's own: read back, it is uniform without a branch on `cur`)
         const int cmd = __builtin_amdgcn_readfirstlane(s_cmd[par]);
         if (cmd == CW_STOP)
@@ -1453,8 +1455,8 @@ __global__ __launch_bounds__(704) void wavelet_pipe_kernel(const DevProblem P, c
         // reciprocals, the ordered log-determinant sum: ~2 500 dependent cycles), needed by the
         // end of stage A; a wave of its own so that the three helpers sit on three SIMDs
         int par = 0;
+        block_sync<9>();                                // (A)
         for (;;) {
-            block_sync<9>();                            // (A) slot s
             const int cmd = s_cmd[par];
             if (cmd == CW_STOP)
                 return;
@@ -1473,8 +1475,8 @@ __global__ __launch_bounds__(704) void wavelet_pipe_kernel(const DevProblem P, c
         if ((tid & 63) == 0)
             s_cmd[2] = -1;
         PIPE_DIAG_DECL;
+        PIPE_SYNC(0);                                   // (A)
         for (;;) {
-            PIPE_SYNC(0);                               // (A) slot s
             const int cmd = s_cmd[par];
             if (cmd == CW_STOP)
                 break;
@@ -1509,8 +1511,8 @@ __global__ __launch_bounds__(704) void wavelet_pipe_kernel(const DevProblem P, c
     }
     // ---- the compute waves -------------------------------------------------------------------
     int par = 0;
+    block_sync<9>();                                    // (A)
     for (;;) {
-        block_sync<9>();                                // (A)
         const int cmd = s_cmd[par];
         const double *np = par ? np1 : L.nextp;
         double *tab = par ? tab1 : L.tab;
