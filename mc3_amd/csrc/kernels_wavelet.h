@@ -1076,9 +1076,10 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
         }
         return nk;
     };
-    const double *ra[3] = {};
     double rv[3] = {};
-    auto request_rows = [&](const Draws &D, long long R) {     // chain.py:195-205
+    // (the rows' addresses are a function of the draws: formed again where a row is asked for
+    // again, not carried from slot to slot -- this wave has no registers to spare)
+    auto row_addresses = [&](const Draws &D, long long R, const double *(&ra)[3]) {   // chain.py:195-205
         if constexpr (SMP == MC3HIP_SNOOKER) {
             const long long zsz = M0 + R * nchains;
             const long long iR1 = (long long)bounded(D.d0.q0, (uint64_t)zsz);
@@ -1089,6 +1090,12 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
             ra[0] = Zr + (size_t)iR1 * zs + kk;
             ra[1] = Zr + (size_t)iR2 * zs + kk;
             ra[2] = Zr + (size_t)iz * zs + kk;
+        }
+    };
+    auto request_rows = [&](const Draws &D, long long R) {
+        if constexpr (SMP == MC3HIP_SNOOKER) {
+            const double *ra[3];
+            row_addresses(D, R, ra);
 #pragma unroll
             for (int q = 0; q < 3; ++q)
                 rv[q] = load_published<false>(ra[q]);
@@ -1127,7 +1134,7 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
         bool valid, go, sjump, outk, spec;
         int q, c;
         long long R, n;
-        double npk, xk, zk, u, lo, hi;
+        double npk, zk, u;
     };
     Turn cur, pend, cand;                               // slot s, slot s - 1, slot s + 1
     cur.valid = pend.valid = cand.valid = false;
@@ -1135,8 +1142,9 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
     long long Rn = R0, tn = 0;
     int qn = 0, cn = P.chain0 + b;
     bool more = nref > 0;
-    Draws nxt = draws_of(tn);
-    request_rows(nxt, Rn);
+    // (its draws are read from the batch wherever they are needed: a dozen lane reads against a
+    // dozen registers held from slot to slot)
+    request_rows(draws_of(tn), Rn);
     double normal_ahead = need_normal ? normal_draw((uint64_t)Rn, cn) : 0.0;
     double jump_ahead = 0.0;
     bool jump_ready = false;
@@ -1158,7 +1166,7 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
                 const bool there2 = !__any(mc3_bits(rv[0]) == ROW_PENDING ||
                                            mc3_bits(rv[1]) == ROW_PENDING);
                 rows_there = there2 && !__any(mc3_bits(rv[2]) == ROW_PENDING);
-                if (there2 && !(u01(nxt.d1.q0) < 0.1)) {
+                if (there2 && !(u01(draws_of(tn).d1.q0) < 0.1)) {
                     jump_ahead = gamma * (rv[0] - rv[1]) + fepsilon * normal_ahead;
                     jump_ready = true;
                 }
@@ -1187,6 +1195,7 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
         }
         const double *slot = slots + qn * sstride;
         const double xk = mine ? slot[lane] : 0.0;
+        const Draws nxt = draws_of(tn);
         double jump_k, zk = 0.0;
         bool sjump = false;
         if constexpr (SMP == MC3HIP_SNOOKER) {         // chain.py:195-217
@@ -1197,6 +1206,8 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
                 if (!rows_there) {
                     if (cur.valid)
                         return CW_SKIP;                 // (never wait with a turn in flight)
+                    const double *ra[3];
+                    row_addresses(nxt, Rn, ra);
                     alive = wait_rows<3, false>(ra, rv, ctl_rw) && alive;
                     if (!alive)
                         return CW_STOP;
@@ -1237,27 +1248,28 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
         cand.c = cn;
         cand.R = Rn;
         cand.npk = npk;
-        cand.xk = xk;
         cand.zk = zk;
         cand.u = (SMP == MC3HIP_SNOOKER) ? u01(nxt.d2.q1) : u01(nxt.d0.q1);   // chain.py:259
-        cand.lo = cand.hi = 0.0;
         return anyout ? CW_SKIP : CW_GO;
     };
     // Metropolis, Z append and the books of a turn whose chisq is in s_result
-    auto decide = [&](const Turn &t) -> bool {
+    // (the state the turn started from is still in its chain's slot: had it changed, the turn would
+    // have been squashed)
+    auto decide = [&](const Turn &t, const double acc_lo, const double acc_hi) -> bool {
         double *slot = slots + t.q * sstride;
         double cur_c = slot[zs], best = slot[zs + 1];
         long long nacc = (long long)mc3_bits(slot[zs + 2]);
-        double xk = t.xk;
+        const double xold = mine ? slot[lane] : 0.0;
+        double xk = xold;
         bool accepted = false;
         if (t.go) {
             const double total = s_result[0];
             // (as WaveletHook::finish: the prior term of a problem without priors is 0.0)
             const double nextchisq = is_pos_inf(total) ? total : total + 0.0;
             if (!t.sjump) {
-                accepted = metropolis_accept(0.5 * (cur_c - nextchisq), t.u, t.lo, t.hi);
+                accepted = metropolis_accept(0.5 * (cur_c - nextchisq), t.u, acc_lo, acc_hi);
             } else {                                   // chain.py:251-255
-                const double dc = t.xk - t.zk, dn = t.npk - t.zk;
+                const double dc = xold - t.zk, dn = t.npk - t.zk;
                 const double cnorm = lane_serial_sum(mine ? dc * dc : 0.0, nf);
                 const double nnorm = lane_serial_sum(mine ? dn * dn : 0.0, nf);
                 const double mrfactor = mc3_det_pow_half(nnorm / cnorm, nf - 1);
@@ -1327,18 +1339,18 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
             cn = P.chain0 + b + qn * G;
             more = Rn < R0 + nref;
             if (more) {
-                nxt = draws_of(tn);
-                request_rows(nxt, Rn);
+                request_rows(draws_of(tn), Rn);
                 if (need_normal)
                     normal_ahead = normal_draw((uint64_t)Rn, cn);
             }
         } else if (more) {
-            request_rows(nxt, Rn);                     // (a bubble: what was missing, again)
+            request_rows(draws_of(tn), Rn);            // (a bubble: what was missing, again)
         }
         PIPE_PART(0);
+        double acc_lo = 0.0, acc_hi = 0.0;
         if (pend.valid && pend.go) {
-            accept_window(pend.u, pend.lo, pend.hi);
-            asm volatile("; window" : "+v"(pend.lo), "+v"(pend.hi));
+            accept_window(pend.u, acc_lo, acc_hi);
+            asm volatile("; window" : "+v"(acc_lo), "+v"(acc_hi));
         }
         jump_early();
         if (pend.valid) {
@@ -1350,7 +1362,7 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
                     __builtin_amdgcn_s_sleep(1);
                 PIPE_PART(2);
             }
-            const bool accepted = decide(pend);
+            const bool accepted = decide(pend, acc_lo, acc_hi);
             if (accepted && cur.valid && cur.spec && cur.q == pend.q) {
                 // the turn in flight started from a state that is no more: squashed, and what
                 // was prepared behind it rewound to it
@@ -1360,8 +1372,7 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
                 tn = cur.n;
                 cn = cur.c;
                 more = true;
-                nxt = draws_of(tn);
-                request_rows(nxt, Rn);
+                request_rows(draws_of(tn), Rn);
                 if (need_normal)
                     normal_ahead = normal_draw((uint64_t)Rn, cn);
                 jump_ready = false;

@@ -26,6 +26,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'mc3_amd', 'csrc')
 UNITS = ('k_lean2.hip', 'k_lean3.hip', 'k_lean4.hip', 'k_lean6.hip', 'k_lean7.hip')
+# (no hidden loads, but a scratch budget of its own: below)
+PIPE_UNIT = 'k_wavelet_w8pp.hip'
 pytestmark = pytest.mark.timeout(900)
 
 
@@ -74,9 +76,9 @@ def _isa_request(k, request, tmp):
 def isa(tmp_path_factory):
     tmp = str(tmp_path_factory.mktemp('isa'))
     with concurrent.futures.ThreadPoolExecutor(8) as pool:
-        units = pool.map(lambda u: _isa(u, tmp), UNITS)
+        units = pool.map(lambda u: _isa(u, tmp), UNITS + (PIPE_UNIT,))
         jits = pool.map(lambda kr: _isa_request(kr[0], kr[1], tmp), enumerate(JIT_REQUESTS))
-        out = dict(zip(UNITS, units))
+        out = dict(zip(UNITS + (PIPE_UNIT,), units))
         out.update({f'jit: {r}': t for r, t in zip(JIT_REQUESTS, jits)})
         return out
 
@@ -89,6 +91,12 @@ def test_no_scratch_in_the_hand_laid_out_loops(isa):
         if unit.startswith('jit: '):          # (a ten-column tile on one wave may spill: slow, not wrong)
             continue
         for name, scratch in isa_audit.scratch_bytes(text).items():
+            if unit == PIPE_UNIT and 'ILi0E' in name:
+                # (the pipelined wavelet kernel -- eleven waves, 168 registers each: C4's kernel --
+                # with the GENERIC polynomial, whose coefficient loop costs the compute waves four
+                # registers more than there are: 20 B, as in the nine-wave kernels)
+                assert scratch <= 24, f'{unit}: {name} carries {scratch} B of scratch'
+                continue
             assert scratch == 0, f'{unit}: {name} carries {scratch} B of scratch'
 
 
