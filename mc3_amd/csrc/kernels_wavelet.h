@@ -1535,7 +1535,7 @@ __global__ __launch_bounds__(704) void wavelet_pipe_kernel(const DevProblem P, c
         par ^= 1;
         if (cmd != CW_GO) {
             for (int k = 0; k <= nhalo; ++k)
-                block_sync<9>();                        // (the slot belongs to the other two waves)
+                block_sync<9>();                        // (the slot belongs to the helper waves)
             continue;
         }
         if (B == 32)
