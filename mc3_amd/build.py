@@ -151,6 +151,37 @@ def build(force=False, verbose=False, lib=LIB, extra=(), jobs=None):
     return lib
 
 
+PROBES = os.path.normpath(os.path.join(HERE, '..', 'tools', 'probes'))
+# measurement probes bench.py and the GPU tests run as child processes (built with the library,
+# they travel to the GPU box as files): the streaming-read probe behind roofline.peak_measured,
+# and rocRAND's own Philox state for the identity test of csrc/philox.h
+PROBE_UNITS = {'hbm_read_probe': ['-O3'], 'rocrand_philox_probe': ['-O2']}
+
+
+def probe_path(name):
+    return os.path.join(PROBES, '_bin', name)
+
+
+def build_probes(verbose=False):
+    """tools/probes/<name>.hip -> tools/probes/_bin/<name>, recompiled when the source changed."""
+    os.makedirs(os.path.join(PROBES, '_bin'), exist_ok=True)
+    for name, flags in PROBE_UNITS.items():
+        src, exe = os.path.join(PROBES, name + '.hip'), probe_path(name)
+        with open(src, 'rb') as f:
+            want = hashlib.sha256(f.read() + ' '.join(flags).encode()).hexdigest()
+        stamp = exe + '.srchash'
+        if os.path.exists(exe) and os.path.exists(stamp):
+            with open(stamp) as f:
+                if f.read().strip() == want:
+                    continue
+        cmd = [hipcc(), '--offload-arch=gfx950'] + flags + ['-o', exe + '.tmp', src]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        os.replace(exe + '.tmp', exe)
+        _atomic_write(stamp, want + '\n')
+
+
 def resource_usage(out=sys.stdout):
     """Registers, spills, scratch and LDS of every kernel instance, from the compiler's
     remarks (recompiles every unit; nothing is linked)."""
@@ -166,4 +197,5 @@ if __name__ == '__main__':
         resource_usage()
     else:
         build(force='--force' in sys.argv, verbose=True)
+        build_probes(verbose=True)
         print(LIB)

@@ -213,9 +213,12 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
     ``kickoff_stream``: where the trial vectors of the initial population come from --
     'philox' (default: drawn, tested and evaluated on the device, keyed by ``seed``) or
     'numpy' (the global NumPy stream in the reference's order: with np.random.seed set,
-    the population equals the reference's); ``zlag``: the declared cadence of a run sharded
-    over GPUs (include/mc3hip.h mc3hip_problem.zlag; default: 0 on one GPU, the
-    communicator's choice -- parallel.DEFAULT_ZLAG -- over several); ``wpad``: the wavelet
+    the population equals the reference's); ``zlag``: the lockstep cadence (include/mc3hip.h
+    mc3hip_problem.zlag) -- default 0, the strict lockstep, on ANY number of GPUs: like the
+    reference's, the results do not depend on how many workers share the chains; an integer
+    or 'auto' (parallel.CADENCE_ZLAG) opts into the relaxed cadence that hides the xGMI hop
+    of a sharded run.  It is written to ``output['zlag']``, the savefile and the log, and a
+    resumed run must ask for the cadence its savefile was made with; ``wpad``: the wavelet
     likelihood of a series whose length is no power of two -- padded with zero residuals to the
     next one, the zero padding src_c/_dwt.c:82-91 intends (the reference then transforms the
     unpadded length, _dwt.c:94, which only a power of two survives: without the flag such a
@@ -288,14 +291,20 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
     if seed is None:
         seed = comm.broadcast(random.randint(0, 100000))
     chain0, nlocal = comm.partition(nchains)
+    engine_opts = comm.engine_options(device, thinning, zlag)
+    zlag_run = int(engine_opts.get('zlag', 0))
+    if resume and 'zlag' in oldrun.files and int(oldrun['zlag']) != zlag_run:
+        log.error(
+            f"The savefile was written by a run in the lockstep cadence zlag = "
+            f"{int(oldrun['zlag'])}, this run asks for zlag = {zlag_run}: a resumed run must "
+            "continue the same random process (pass the same 'zlag')")
     engine = engine_factory(
         data=data_dev, uncert=uncert_dev, indep=indep_dev, params=params,
         pstep=pstep, pmin=pmin, pmax=pmax, prior=prior, priorlow=priorlow,
         priorup=priorup, nchains=nchains, sampler=sampler, wlike=wlike,
         thinning=thinning, fgamma=fgamma, fepsilon=fepsilon, hsize=hsize,
         model=lowered.family, nmodel=lowered.ncoef, seed=seed, device=device,
-        chain0=chain0, nlocal=nlocal, M0=M0, zlen=zlen, **padded,
-        **comm.engine_options(device, thinning, zlag))
+        chain0=chain0, nlocal=nlocal, M0=M0, zlen=zlen, **padded, **engine_opts)
     view = ChainView(engine, func, indparams, indparams_dict, data, wlike,
                      lowered.offset)
     bestp = np.copy(params)
@@ -358,6 +367,8 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
         'pstep': pstep,
         'ifree': ifree,
         'burnin': zburn,
+        # (not in the reference's dictionary: which lockstep cadence produced these rows)
+        'zlag': zlag_run,
     }
 
     def snapshot(final=False):
@@ -418,6 +429,9 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
 
     print("Yippee Ki Yay Monte Carlo!")
     log.msg(f"Start MCMC chains  ({time.ctime()})")
+    log.msg("Lockstep cadence: " + ("strict (zlag = 0)" if not zlag_run else
+            f"zlag = {zlag_run} (the other chains are seen {zlag_run} Z refreshes late)")
+            + (f", chains sharded over {comm.size} ranks" if comm.size > 1 else ""))
     # ten progress reports: mcmc_driver.py:297-348
     nreport = 10
     edges = np.unique(np.ceil(np.arange(1, nreport + 1)*nzchain/nreport).astype(int))

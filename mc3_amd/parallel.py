@@ -26,9 +26,16 @@ RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT); ``TorchDistComm`` is the same
 communicator over an existing ``torch.distributed`` process group, for callers who
 have one.  Neither is in the data path.
 
-The random numbers are keyed by GLOBAL chain id, so a sharded run reproduces
-the single-rank run bit for bit.  The reference has no counterpart: its workers
-share memory inside one host (mc3/mcmc_driver.py:143-221).
+The random numbers are keyed by GLOBAL chain id, so a sharded run reproduces the
+single-rank run bit for bit -- by DEFAULT: like the reference, whose semantics do not
+depend on ``ncpu`` (mc3/chain.py:221-232), a run's results do not depend on the number of
+ranks.  The strict lockstep (``zlag = 0``) is the default for every world size; the relaxed
+cadence that hides the xGMI hop (``zlag >= 1``: the other chains are seen that many refreshes
+late) is OPT-IN -- ``zlag=`` / ``zlag='auto'`` (CADENCE_ZLAG refreshes' worth)
+or MC3HIP_ZLAG -- is written to the output dictionary, the savefile and the log, and a
+resumed run refuses a savefile of another cadence (mcmc()).  N ranks with a given zlag equal
+ONE rank with the same zlag.  The reference has no counterpart: its workers share memory
+inside one host (mc3/mcmc_driver.py:143-221).
 """
 import hashlib
 import hmac
@@ -43,9 +50,26 @@ import numpy as np
 
 
 # Refreshes (of thinning 1) a row may take to reach the other ranks in the declared cadence of
-# a sharded run: an iteration of the headline loop is ~0.6 us, so four of them cover an xGMI
-# hop of up to ~2.5 us (profiles/r04_delay_sweep.jsonl: where the rate starts to fall per zlag)
-DEFAULT_ZLAG = 4
+# a sharded run (opt-in: zlag='auto'): an iteration of the headline loop is ~0.6 us, so four of
+# them cover an xGMI hop of up to ~2.5 us (profiles/r04_delay_sweep.jsonl: where the rate
+# starts to fall per zlag)
+CADENCE_ZLAG = 4
+
+
+def resolve_zlag(zlag, thinning=1):
+    """The cadence a run asks for: an integer as given; 'auto' = CADENCE_ZLAG iterations' worth
+    of refreshes; None = MC3HIP_ZLAG if set (an integer or 'auto'), else 0 -- the strict
+    lockstep, whatever the number of ranks."""
+    if zlag is None:
+        zlag = os.environ.get('MC3HIP_ZLAG', 0)
+    if isinstance(zlag, str):
+        zlag = zlag.strip().lower()
+        if zlag == 'auto':
+            return -(-CADENCE_ZLAG//max(1, int(thinning)))
+    zlag = int(zlag)
+    if zlag < 0:
+        raise ValueError(f'zlag must be >= 0 or "auto" (got {zlag})')
+    return zlag
 
 
 class SingleRank:
@@ -66,7 +90,8 @@ class SingleRank:
         return 0, nchains
 
     def engine_options(self, device=0, thinning=1, zlag=None):
-        return {} if not zlag else {'zlag': int(zlag)}
+        zlag = resolve_zlag(zlag, thinning)
+        return {'zlag': zlag} if zlag else {}
 
     def broadcast(self, obj):
         return obj
@@ -135,17 +160,16 @@ class Communicator:
         DeviceChains), decided BEFORE the engine exists -- the library sizes its persistent
         grid from the very kernel instance these select:
 
-        * ``zlag``: the declared cadence of a sharded run (include/mc3hip.h): the other
-          chains are seen ``zlag`` refreshes late, so that a row has that long to cross
-          xGMI.  Default for several ranks: DEFAULT_ZLAG iterations' worth of refreshes
-          (MC3HIP_ZLAG overrides; 0 = the strict lockstep, every iteration then pays the hop);
+        * ``zlag``: the cadence (include/mc3hip.h): the other chains are seen ``zlag`` refreshes
+          late, so that a row has that long to cross xGMI.  Default 0 -- the strict lockstep,
+          the SAME random process as one GPU (every iteration then pays the hop); 'auto' =
+          CADENCE_ZLAG iterations' worth of refreshes; MC3HIP_ZLAG when nothing is given
+          (``resolve_zlag``); rank 0's word counts;
         * ``p2p``: fine-grained, IPC-shareable Z (the peer-to-peer hand-off is wanted);
         * ``no_courier``: more than two ranks share this rank's device (a test set-up)."""
+        zlag = resolve_zlag(zlag, thinning)
         if self.size == 1:
-            return {} if not zlag else {'zlag': int(zlag)}
-        if zlag is None:
-            env = os.environ.get('MC3HIP_ZLAG')
-            zlag = int(env) if env is not None else -(-DEFAULT_ZLAG//max(1, int(thinning)))
+            return {'zlag': zlag} if zlag else {}
         opts = {'zlag': int(self.broadcast(int(zlag)))}
         if self.wants_p2p:
             devices = self.all_gather(int(device))
@@ -394,7 +418,8 @@ def _recv(sock):
 # answers with MAGIC | rank | size | HMAC-SHA256(secret, challenge | rank | size); rank 0 checks
 # it in constant time and answers with HMAC(secret, challenge | b'ok') -- so both sides prove
 # they hold the run's secret (MC3HIP_RDV_SECRET, made by the launcher, or the token of the
-# port file, which only this user can read) before a single frame is unpickled.
+# port file, which the reading side accepts only from a 0600 file of its own uid in a 0700
+# directory of its own: _read_port_file / _private_dir) before a single frame is unpickled.
 _MAGIC = b'MC3H'
 _HELLO = struct.Struct('!4sII32s')
 
@@ -428,9 +453,60 @@ def _is_loopback(addr):
     return addr in ('localhost', '::1') or addr.startswith('127.')
 
 
+def _private_dir():
+    """Where rendezvous files live: a directory only this user can enter -- MC3HIP_RDV_DIR if
+    given, else <tmp>/mc3hip_rdv_<uid> created 0700.  Either way it is CHECKED (ours, a real
+    directory, no group / other bits): in a world-writable sticky /tmp a predictable file name
+    could be planted by another user before rank 0 writes it, and the ranks would then prove
+    themselves to that user's server and unpickle its frames."""
+    d = os.environ.get('MC3HIP_RDV_DIR')
+    if not d:
+        d = os.path.join(tempfile.gettempdir(), f'mc3hip_rdv_{os.getuid()}')
+        try:
+            os.mkdir(d, 0o700)
+        except FileExistsError:
+            pass
+    st = os.lstat(d)
+    import stat as _stat
+    if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid():
+        raise PermissionError(f'SocketComm: rendezvous directory {d} is not a directory of '
+                              f'uid {os.getuid()}: refusing to meet there')
+    if st.st_mode & 0o077:
+        if os.environ.get('MC3HIP_RDV_DIR'):
+            raise PermissionError(f'SocketComm: MC3HIP_RDV_DIR={d} is open to group / others '
+                                  f'(mode {st.st_mode & 0o777:o}): make it 0700')
+        os.chmod(d, 0o700)
+    return d
+
+
 def _port_file(addr, port, run_id):
-    d = os.environ.get('MC3HIP_RDV_DIR') or tempfile.gettempdir()
-    return os.path.join(d, f'mc3hip_rdv_{addr}_{port}_{run_id}.port')
+    return os.path.join(_private_dir(), f'mc3hip_rdv_{addr}_{port}_{run_id}.port')
+
+
+def _read_port_file(path):
+    """(port, token) of the file rank 0 published -- trusted ONLY if it is a regular file of
+    this very user that nobody else can read or write (no symlink followed).  A file that
+    fails the check is an attack or a misconfiguration, never "not there yet": PermissionError,
+    which the rendezvous does not retry."""
+    import errno
+    import stat as _stat
+    try:
+        fd = os.open(path, os.O_RDONLY | os.O_NOFOLLOW)
+    except OSError as e:
+        if e.errno == errno.ELOOP:
+            raise PermissionError(f'SocketComm: {path} is a symbolic link: refusing it') from e
+        raise
+    try:
+        st = os.fstat(fd)
+        if not _stat.S_ISREG(st.st_mode) or st.st_uid != os.getuid() or st.st_mode & 0o077:
+            raise PermissionError(
+                f'SocketComm: {path} is not a private file of uid {os.getuid()} (owner '
+                f'{st.st_uid}, mode {st.st_mode & 0o7777:o}): refusing its port and token')
+        with os.fdopen(os.dup(fd)) as f:
+            p, token = f.read().split()
+    finally:
+        os.close(fd)
+    return int(p), token
 
 
 class SocketComm(Communicator):
@@ -448,12 +524,17 @@ class SocketComm(Communicator):
     * ``MC3HIP_RDV_PORT`` set: on MASTER_ADDR at that port (``MC3HIP_RDV_SECRET`` required);
     * otherwise (under ``torch.distributed.run``, whose agent keeps MASTER_PORT for its
       own store): on an ephemeral port that rank 0 publishes in a file named after
-      MASTER_ADDR / MASTER_PORT / the launcher's run id in the temporary directory --
+      MASTER_ADDR / MASTER_PORT / the launcher's run id in a directory only this user can
+      enter (``_private_dir``: <tmp>/mc3hip_rdv_<uid>, 0700, ownership and mode checked) --
       one node, which is what this package shards over.
 
     Every connection proves, in a fixed-size binary handshake (no pickle), that it holds the
-    run's secret -- ``MC3HIP_RDV_SECRET`` or the token in the port file (mode 0600) -- before
-    a frame of it is unpickled; strangers and garbage are dropped and the rendezvous goes on.
+    run's secret -- ``MC3HIP_RDV_SECRET`` or the token in the port file -- before a frame of it
+    is unpickled; strangers and garbage are dropped and the rendezvous goes on.  The port file
+    is trusted only if it is a regular file of this uid with mode 0600 (opened O_NOFOLLOW and
+    fstat'ed, ``_read_port_file``); a foreign or group / world-accessible file ends the run
+    with PermissionError on the reading ranks, and rank 0 refuses to replace a file it does
+    not own.
     Only loopback addresses unless ``MC3HIP_RDV_ALLOW_REMOTE=1``.
     """
 
@@ -503,8 +584,15 @@ class SocketComm(Communicator):
     # -- rendezvous ---------------------------------------------------------------
     def _serve(self, addr, port, port_file):
         token = os.urandom(16).hex()
-        if port_file and os.path.exists(port_file):
-            os.remove(port_file)                  # (left behind by a run that died)
+        if port_file and os.path.lexists(port_file):
+            # left behind by a run of ours that died -- anybody else's file (or one we cannot
+            # remove: a sticky directory) ends the run HERE, loudly: the other ranks would
+            # refuse it anyway (_read_port_file)
+            st = os.lstat(port_file)
+            if st.st_uid != os.getuid():
+                raise PermissionError(f'SocketComm: {port_file} exists and belongs to uid '
+                                      f'{st.st_uid}: refusing to publish the rendezvous there')
+            os.remove(port_file)
         srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         srv.bind((addr, port))
@@ -553,9 +641,7 @@ class SocketComm(Communicator):
             s = None
             try:
                 if port_file:
-                    with open(port_file) as f:
-                        p, token = f.read().split()
-                    port = int(p)
+                    port, token = _read_port_file(port_file)
                     if secret is None:
                         secret = token.encode()
                 s = socket.create_connection((addr, port), timeout=self.timeout)
@@ -567,6 +653,8 @@ class SocketComm(Communicator):
                     return
                 last = ConnectionError('rank 0 did not prove the secret of this run')
                 s.close()
+            except PermissionError:
+                raise                             # (a foreign port file: never retried)
             except (OSError, ValueError, ConnectionError, EOFError) as e:   # not there yet
                 last = e
                 if s is not None:
@@ -617,8 +705,7 @@ def free_port(addr='127.0.0.1'):
 def new_rendezvous():
     """(file, secret) for one launch of ranks on this node: rank 0 publishes its port in the
     file, everybody proves the secret."""
-    d = os.environ.get('MC3HIP_RDV_DIR') or tempfile.gettempdir()
-    return (os.path.join(d, f'mc3hip_rdv_{os.getpid()}_{os.urandom(6).hex()}.port'),
+    return (os.path.join(_private_dir(), f'mc3hip_rdv_{os.getpid()}_{os.urandom(6).hex()}.port'),
             os.urandom(16).hex())
 
 

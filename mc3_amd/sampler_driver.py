@@ -186,8 +186,9 @@ def sample(
       NumPy stream like the reference), ``comm``
       (mc3_amd.parallel communicator for multi-GPU runs: every rank makes the same
       call and gets the same dictionary; files are written by rank 0 only), ``zlag`` (the
-      declared cadence of a sharded run: the other chains are seen that many refreshes late,
-      include/mc3hip.h; default 0 on one GPU, parallel.DEFAULT_ZLAG over several), ``wpad``
+      lockstep cadence: the other chains are seen that many refreshes late, include/mc3hip.h;
+      default 0 = strict on any number of GPUs, 'auto' = parallel.CADENCE_ZLAG; recorded in
+      ``output['zlag']``, the savefile and the log), ``wpad``
       (wavelet likelihood of a series whose length is no power of two: padded with zero
       residuals to the next one; without it such a series is refused -- mcmc()).
     """

@@ -18,6 +18,9 @@ import ranks  # noqa: E402
 
 def main():
     out_path, sampler, thinning = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    extra = dict(a.split('=') for a in sys.argv[4:])
+    zlag = {} if 'zlag' not in extra else \
+        {'zlag': extra['zlag'] if extra['zlag'] == 'auto' else int(extra['zlag'])}
     comm = ranks.worker_comm(use_rccl=False)
     x, data, uncert = H.tutorial_data(100)
     np.random.seed(100 + comm.rank)          # ranks deliberately differ: rank 0's
@@ -27,7 +30,7 @@ def main():
         pmin=np.array([-10.0, -20.0, -10.0]), pmax=np.array([40.0, 20.0, 10.0]),
         sampler=sampler, nsamples=8*120*thinning, burnin=10, nchains=8,
         thinning=thinning, grtest=False, log=mu.Log(verb=0),
-        engine_factory=OracleChains, seed=99, comm=comm)
+        engine_factory=OracleChains, seed=99, comm=comm, **zlag)
     np.savez(f'{out_path}.rank{comm.rank}.npz',
              **{k: v for k, v in out.items() if k not in ('pnames', 'texnames')})
     ranks.finalize(comm)

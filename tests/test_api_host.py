@@ -71,7 +71,9 @@ def test_output_dictionary_matches_reference_layout(golden_dir):
     out = run()
     ref_keys = {k[4:] for k in g.files if k.startswith('out_')}
     assert ref_keys - set(out) == set()
-    assert set(out) - ref_keys == {'pnames', 'texnames'}
+    # ('zlag': which lockstep cadence produced the rows -- 0, the strict one, by default)
+    assert set(out) - ref_keys == {'pnames', 'texnames', 'zlag'}
+    assert out['zlag'] == 0
     for key in sorted(ref_keys):
         got, want = np.asarray(out[key]), g['out_' + key]
         assert got.shape == want.shape, key
@@ -203,6 +205,20 @@ def test_savefile_resume_and_grbreak(tmp_path):
     stopped = run(sampler='demc', nchains=8, nsamples=80000, grbreak=1.05,
                   grnmin=800, burnin=100)
     assert len(stopped['posterior']) < 80000
+    # the lockstep cadence is on record in the savefile, and a resumed run must continue the
+    # same random process: another zlag is refused, the same one carries on
+    assert int(np.load(sf)['zlag']) == 0 and first['zlag'] == 0
+    with pytest.raises(ValueError, match='cadence zlag = 0, this run asks for zlag = 2'):
+        run(savefile=sf, resume=True, sampler='demc', nchains=8, nsamples=800, seed=8, zlag=2)
+    sf2 = str(tmp_path / 'lag.npz')
+    lag = run(savefile=sf2, sampler='demc', nchains=8, nsamples=1600, zlag=2)
+    assert lag['zlag'] == 2 and int(np.load(sf2)['zlag']) == 2
+    assert not np.array_equal(lag['posterior'], first['posterior'])
+    with pytest.raises(ValueError, match='cadence zlag = 2, this run asks for zlag = 0'):
+        run(savefile=sf2, resume=True, sampler='demc', nchains=8, nsamples=800, seed=8)
+    again = run(savefile=sf2, resume=True, sampler='demc', nchains=8, nsamples=800, seed=8,
+                zlag=2)
+    np.testing.assert_array_equal(again['posterior'][:1600], lag['posterior'])
 
 
 # ---- the reference's error-path tests (tests/test_mcmc.py:328-409) ----------

@@ -20,11 +20,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.timeout(1200)
 
 
-@pytest.mark.parametrize('sampler,thinning,launcher', [
-    ('demc', 1, 'socket'), ('snooker', 2, 'socket'), ('demc', 1, 'torchrun')])
-def test_two_ranks_reproduce_single_rank(tmp_path, sampler, thinning, launcher):
+@pytest.mark.parametrize('sampler,thinning,launcher,zlag', [
+    ('demc', 1, 'socket', None), ('snooker', 2, 'socket', None), ('demc', 1, 'torchrun', None),
+    ('demc', 1, 'socket', 'auto'), ('snooker', 2, 'socket', 'auto'), ('demc', 1, 'socket', 2)])
+def test_two_ranks_reproduce_single_rank(tmp_path, sampler, thinning, launcher, zlag):
+    """a sharded run equals the single-rank run bit for bit -- with the DEFAULTS
+    (zlag None: the strict lockstep on any number of ranks, one random process like the
+    reference's, whose semantics do not depend on ncpu) and in the opt-in cadence (N ranks with
+    a zlag equal ONE rank with the same zlag); the cadence is on record in the output."""
     out_path = str(tmp_path / 'shard')
-    launch_ranks(2, 'dist_worker.py', out_path, sampler, thinning, launcher=launcher)
+    launch_ranks(2, 'dist_worker.py', out_path, sampler, thinning,
+                 *([] if zlag is None else [f'zlag={zlag}']), launcher=launcher)
 
     x, data, uncert = H.tutorial_data(100)
     np.random.seed(100)
@@ -34,14 +40,13 @@ def test_two_ranks_reproduce_single_rank(tmp_path, sampler, thinning, launcher):
         pmin=np.array([-10.0, -20.0, -10.0]), pmax=np.array([40.0, 20.0, 10.0]),
         sampler=sampler, nsamples=8*120*thinning, burnin=10, nchains=8,
         thinning=thinning, grtest=False, log=mu.Log(verb=0),
-        engine_factory=OracleChains, seed=99,
-        # (a sharded run takes the declared multi-GPU cadence by default; ONE rank in the same
-        # cadence is what it must reproduce)
-        zlag=-(-parallel.DEFAULT_ZLAG//thinning))
+        engine_factory=OracleChains, seed=99, **({} if zlag is None else {'zlag': zlag}))
+    want = 0 if zlag is None else -(-parallel.CADENCE_ZLAG//thinning) if zlag == 'auto' else zlag
+    assert single['zlag'] == want
     for rank in (0, 1):
         got = np.load(f'{out_path}.rank{rank}.npz')
         for key in ('posterior', 'zchain', 'log_post', 'chisq', 'bestp',
-                    'acceptance_rate', 'best_log_post', 'medianp', 'stdp'):
+                    'acceptance_rate', 'best_log_post', 'medianp', 'stdp', 'zlag'):
             np.testing.assert_array_equal(got[key], single[key], err_msg=key)
 
 
@@ -78,8 +83,7 @@ def test_peer_to_peer_recovery_logic_on_cpu(tmp_path, launcher):
         indparams=[x], pstep=np.array([1.0, 0.5, 0.1]),
         pmin=np.array([-10.0, -20.0, -10.0]), pmax=np.array([40.0, 20.0, 10.0]),
         sampler='demc', nsamples=8*120, burnin=10, nchains=8, grtest=True,
-        log=mu.Log(verb=0), engine_factory=OracleChains, seed=99,
-        zlag=parallel.DEFAULT_ZLAG)
+        log=mu.Log(verb=0), engine_factory=OracleChains, seed=99)
     for rank in (0, 1):
         got = np.load(f'{out_path}.rank{rank}.npz')
         for key in ('posterior', 'zchain', 'log_post', 'chisq', 'bestp',
@@ -199,8 +203,63 @@ def test_socket_comm_rendezvous_through_a_port_file(tmp_path):
             e.pop(k, None)
         return e
     stale = os.path.join(str(tmp_path), os.path.basename(stale))
-    with open(stale, 'w') as f:
-        f.write('1 deadbeef\n')           # (port 1: nobody listens there)
+    with open(os.open(stale, os.O_WRONLY | os.O_CREAT, 0o600), 'w') as f:
+        f.write('1 deadbeef\n')           # (port 1: nobody listens there; ours, 0600: trusted)
     outs = _socket_ranks(4, env, BODY)
     assert sorted(o.strip() for o in outs) == [f'rank {r} of 4 ok' for r in range(4)]
     assert not os.path.exists(stale), 'rank 0 removes its port file when it closes'
+
+
+def test_port_file_is_trusted_only_if_private_and_ours(tmp_path, monkeypatch):
+    """the token of the port file is the handshake secret under torchrun, so the
+    READING side must check who wrote it -- a regular file of this uid, mode 0600, no symlink,
+    in a directory nobody else can enter; anything else is PermissionError (not retried), and
+    rank 0 refuses to publish over a file it does not own."""
+    from mc3_amd import parallel
+    d = tmp_path / 'rdv'
+    d.mkdir(mode=0o700)
+    monkeypatch.setenv('MC3HIP_RDV_DIR', str(d))
+    good = parallel._port_file('127.0.0.1', '29998', 'runA')
+    assert os.path.dirname(good) == str(d)
+    with open(os.open(good, os.O_WRONLY | os.O_CREAT, 0o600), 'w') as f:
+        f.write('4242 cafe\n')
+    assert parallel._read_port_file(good) == (4242, 'cafe')
+    os.chmod(good, 0o644)                       # readable by others: the token is no secret
+    with pytest.raises(PermissionError, match='private'):
+        parallel._read_port_file(good)
+    os.chmod(good, 0o600)
+    link = str(d / 'link.port')
+    os.symlink(good, link)
+    with pytest.raises(PermissionError, match='symbolic'):
+        parallel._read_port_file(link)
+    # a rank that meets such a file gives up at once (no retry until the timeout)
+    os.chmod(good, 0o666)
+    import time
+    t0 = time.monotonic()
+    with pytest.raises(PermissionError):
+        parallel.SocketComm(1, 2, port_file=good, timeout=30.0)
+    assert time.monotonic() - t0 < 5.0
+    # the directory itself: open to others -> refused
+    os.chmod(str(d), 0o755)
+    with pytest.raises(PermissionError, match='0700'):
+        parallel._port_file('127.0.0.1', '1', 'x')
+    os.chmod(str(d), 0o700)
+    # the default directory is created private
+    monkeypatch.delenv('MC3HIP_RDV_DIR')
+    monkeypatch.setattr(parallel.tempfile, 'gettempdir', lambda: str(tmp_path))
+    pd = parallel._private_dir()
+    assert os.stat(pd).st_mode & 0o777 == 0o700 and os.stat(pd).st_uid == os.getuid()
+    if os.getuid() == 0:
+        # somebody else's file under the expected name: readers refuse it, rank 0 refuses to
+        # replace it
+        monkeypatch.setenv('MC3HIP_RDV_DIR', str(d))
+        os.chmod(good, 0o600)
+        os.chown(good, 65534, -1)
+        with pytest.raises(PermissionError, match='private'):
+            parallel._read_port_file(good)
+        with pytest.raises(PermissionError, match='belongs to uid'):
+            parallel.SocketComm(0, 2, port_file=good, timeout=5.0)
+        os.chown(str(d), 65534, -1)
+        with pytest.raises(PermissionError, match='not a directory of uid'):
+            parallel._private_dir()
+        os.chown(str(d), 0, -1)

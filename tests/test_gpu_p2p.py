@@ -33,8 +33,8 @@ def test_processes_peer_to_peer(tmp_path, nproc, sampler, thinning, niter, launc
     (2, 'snooker', 1, None, 2000), (8, 'snooker', 1, 2, 1000), (2, 'mrw', 1, None, 2000),
     (2, 'demc', 1, 1, 5000), (9, 'demc', 1, None, 1000)])
 def test_processes_in_the_declared_cadence(tmp_path, nproc, sampler, thinning, zlag, delay_ns):
-    """mc3_amd.sample() over several ranks in the DECLARED MULTI-GPU CADENCE (the default of a
-    sharded run: zlag = parallel.DEFAULT_ZLAG refreshes' worth; here also 1 and 2), with the
+    """mc3_amd.sample() over several ranks in the DECLARED MULTI-GPU CADENCE (opt-in:
+    zlag='auto' = parallel.CADENCE_ZLAG refreshes' worth; here also 1 and 2), with the
     rows for the other ranks' replicas held back 1-5 us (MC3HIP_TEST_REMOTE_DELAY_NS: ranks on
     one GPU then see each other as if an xGMI hop apart) -- identical, bit for bit, to ONE
     rank running the oracle's restatement of the same cadence.  Rows that arrive later than
@@ -43,8 +43,11 @@ def test_processes_in_the_declared_cadence(tmp_path, nproc, sampler, thinning, z
     from mc3_amd import parallel
     env = {'MC3HIP_TEST_REMOTE_DELAY_NS': str(delay_ns)} if delay_ns else {}
     if zlag is None:
-        zlag = -(-parallel.DEFAULT_ZLAG//thinning)
-        p2p_case(tmp_path, nproc, sampler, thinning, 300, 'socket', env=env, want_zlag=zlag)
+        # (zlag='auto': CADENCE_ZLAG iterations' worth of refreshes; ONE rank must be asked for
+        # the same number -- the strict lockstep is the default of every world size)
+        want = -(-parallel.CADENCE_ZLAG//thinning)
+        p2p_case(tmp_path, nproc, sampler, thinning, 300, 'socket', env=env, zlag='auto',
+                 want_zlag=want)
     else:
         p2p_case(tmp_path, nproc, sampler, thinning, 300, 'socket', env=env, zlag=zlag)
 
@@ -83,6 +86,7 @@ def p2p_case(tmp_path, nproc, sampler, thinning, niter, launcher, env=None, zlag
                     'acceptance_rate', 'best_log_post', 'medianp'):
             np.testing.assert_array_equal(got[key], single[key], err_msg=key)
         np.testing.assert_allclose(got['stdp'], single['stdp'], rtol=1e-12)
+        assert int(got['zlag']) == int(single['zlag'])      # (the cadence is on record)
 
 
 def launch(nproc, script, *args, env=None, timeout=1000):

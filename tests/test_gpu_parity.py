@@ -121,6 +121,49 @@ def test_device_philox_known_answers(eng):
             assert tuple(out[2]) == (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
 
 
+def test_draws_are_rocrand_philox_state_word_for_word(eng):
+    """csrc/philox.h:7-9 claims that a draw for (iteration, chain, slot) under `seed` is what
+    rocRAND's rocrand_state_philox4x32_10 yields after rocrand_init(seed, chain | slot << 32,
+    4*iteration): draw from rocRAND ITSELF (tools/probes/rocrand_philox_probe.hip, a child
+    process that includes rocrand_kernel.h) and compare with the library's rounds and the
+    checker's, word for word."""
+    import subprocess
+    from mc3_amd import _lib, build
+    from oracle import lockstep as ls
+    exe = build.probe_path('rocrand_philox_probe')
+    assert os.path.exists(exe), 'tools/probes/_bin/rocrand_philox_probe: run __graft_entry__.build()'
+    L = _lib.load()
+    rs = np.random.RandomState(11)
+    n = 4096
+    req = np.empty((n, 3), np.uint64)
+    req[:, 0] = rs.randint(0, 2**40, n, dtype=np.uint64)        # iteration (beyond 32 bits too)
+    req[:, 1] = rs.randint(0, 2**20, n, dtype=np.uint64)        # global chain id
+    req[:, 2] = rs.randint(0, 8, n, dtype=np.uint64)            # slot
+    req[0] = (0, 0, 0)
+    req[1] = (2**32 - 1, 2**20 - 1, 7)
+    req[2] = (2**32, 1, 0)                                       # carry into the counter's word 1
+    req[3] = (2**62 - 1, 255, 4)                                 # (4*iteration must not overflow)
+    up = _lib._up
+    for seed in (0, 12345, 0xdeadbeefcafef00d):
+        blob = np.array([seed, n], np.uint64).tobytes() + req.tobytes()
+        res = subprocess.run([exe], input=blob, stdout=subprocess.PIPE, timeout=120, check=True)
+        rocrand = np.frombuffer(res.stdout, np.uint32).reshape(n, 4)
+        # the library's counter layout: (iteration lo, iteration hi, chain, slot), key = seed
+        ctr = np.empty((n, 4), np.uint32)
+        ctr[:, 0] = (req[:, 0] & np.uint64(0xffffffff)).astype(np.uint32)
+        ctr[:, 1] = (req[:, 0] >> np.uint64(32)).astype(np.uint32)
+        ctr[:, 2] = req[:, 1].astype(np.uint32)
+        ctr[:, 3] = req[:, 2].astype(np.uint32)
+        key = np.array([seed & 0xffffffff, seed >> 32], np.uint32)
+        out = np.empty_like(ctr)
+        _lib.check(L.mc3hip_selftest_philox(0, ctr.ctypes.data_as(up), n,
+                                            key.ctypes.data_as(up), out.ctypes.data_as(up)))
+        np.testing.assert_array_equal(out, rocrand)
+        for i in range(0, n, 97):
+            assert tuple(rocrand[i]) == ls.philox4x32_10(tuple(int(v) for v in ctr[i]),
+                                                         (int(key[0]), int(key[1])))
+
+
 # ---- likelihood kernels against the reference's golden vectors --------------
 @pytest.mark.parametrize('ndata', [8, 32, 1000, 16384])
 def test_gauss_chisq_vs_reference_vectors(eng, golden_dir, ndata):

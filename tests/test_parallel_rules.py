@@ -55,10 +55,22 @@ def test_courier_only_with_at_most_two_ranks_per_device(clean_env):
             return obj
 
     opts = DeviceComm(0, [0, 1]).engine_options(device=0)
-    assert opts == {'zlag': parallel.DEFAULT_ZLAG, 'p2p': True, 'no_courier': False}
+    assert opts == {'zlag': 0, 'p2p': True, 'no_courier': False}     # strict by default
+    opts = DeviceComm(0, [0, 1]).engine_options(device=0, zlag='auto')
+    assert opts == {'zlag': parallel.CADENCE_ZLAG, 'p2p': True, 'no_courier': False}
     assert DeviceComm(1, [0, 0]).engine_options(device=0)['no_courier'] is False
     assert DeviceComm(3, [0, 0, 0, 1]).engine_options(device=1)['no_courier'] is True
-    assert DeviceComm(0, [0, 1]).engine_options(device=0, thinning=3)['zlag'] == 2
+    assert DeviceComm(0, [0, 1]).engine_options(device=0, thinning=3, zlag='auto')['zlag'] == 2
+    os.environ['MC3HIP_ZLAG'] = '3'
+    try:
+        assert DeviceComm(0, [0, 1]).engine_options(device=0)['zlag'] == 3
+        assert parallel.SingleRank().engine_options() == {'zlag': 3}
+        os.environ['MC3HIP_ZLAG'] = 'auto'
+        assert DeviceComm(0, [0, 1]).engine_options(device=0, thinning=2)['zlag'] == 2
+    finally:
+        del os.environ['MC3HIP_ZLAG']
+    with pytest.raises(ValueError, match='zlag'):
+        parallel.resolve_zlag(-1)
     assert DeviceComm(0, [0, 1]).engine_options(device=0, zlag=0)['zlag'] == 0
     assert 'MC3HIP_NO_COURIER' not in os.environ
     # an engine created otherwise is refused at set-up, on every rank
