@@ -65,6 +65,32 @@ __device__ __forceinline__ void published_arrived(double &a, double &b, double &
         asm volatile("s_waitcnt vmcnt(3)" : "+v"(a), "+v"(b), "+v"(c)::"memory");
 }
 
+// The store such a hand-counted wait relies on ("everything but the youngest operation -- the
+// store above at least -- has completed"): ISSUED ON EVERY PATH.  Written as `if (mine) store`
+// the compiler masks the block and skips it with s_cbranch_execz -- never taken here (some lane
+// always keeps a coefficient), but a path of the control-flow graph on which NOTHING follows
+// the hidden loads, so that vmcnt(1) would retire none of them: mc3_amd/isa_audit.py counts
+// operations per path (round 5) and rightly refuses it.  Here the lanes are chosen by EXEC
+// set in the same inline assembly; there is no branch to take.
+template <bool SYS>
+__device__ __forceinline__ void store_published_counted(double *p, double v, bool mine)
+{
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(mine);      // (a subset of EXEC)
+    uint64_t saved;
+    if constexpr (SYS)
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\t"
+                     "global_store_dwordx2 %2, %3, off sc0 sc1\n\ts_mov_b64 exec, %0"
+                     : "=&s"(saved)
+                     : "s"(mask), "v"(p), "v"(v)
+                     : "memory");
+    else
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\t"
+                     "global_store_dwordx2 %2, %3, off sc1\n\ts_mov_b64 exec, %0"
+                     : "=&s"(saved)
+                     : "s"(mask), "v"(p), "v"(v)
+                     : "memory");
+}
+
 // The ranks' replicas (peer-to-peer mode).  The pointers are read ONCE, before the loop: a load
 // of one inside it is waited for together with everything older in the wave's queue -- the
 // store into the previous peer's replica, still on its way over xGMI -- so a row's stores

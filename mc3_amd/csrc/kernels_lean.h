@@ -806,14 +806,14 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
         // follows the loads of the next iteration's rows either way and ONE wait serves both:
         // two waits on two paths for the same registers would have the compiler copy them
         // into place ahead of one of the waits -- a copy of what the loads have not written)
-        if (mine) {
-            if (!THIN || j + 1 == th)
-                __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
-                                   P2P ? __HIP_MEMORY_SCOPE_SYSTEM
-                                       : __HIP_MEMORY_SCOPE_AGENT);  // publish (sc1)
-            else
-                __hip_atomic_store(&P.X[(size_t)lc * nf + lane], xk, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+        // (store_published_counted: ONE store instruction, issued on every path, the lanes
+        // chosen by EXEC and the destination by a select -- the wait below counts on it; two
+        // stores on the two sides of a branch come out of the structuriser as flag-routed
+        // blocks with a statically possible path through neither)
+        {
+            double *const dst = (!THIN || j + 1 == th) ? zblock + (size_t)c * ZS + lane
+                                                       : &P.X[(size_t)lc * nf + lane];
+            store_published_counted<P2P>(dst, xk, mine);                      // publish
         }
         // the next iteration's rows: everything but the youngest operation of this wave -- the
         // store above at least -- has completed
@@ -1319,14 +1319,12 @@ __device__ __forceinline__ void lean_demc_lag_body(const DevProblem &P, const in
             // Z append behind the last iteration of the refresh, chain.py:276-289; the others
             // leave the state where the kernel leaves it in the end, so that ONE store follows
             // the loads of the next iteration's rows either way and one wait serves both
-            if (mine) {
-                if (j + 1 == th)
-                    __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
-                                       P2P ? __HIP_MEMORY_SCOPE_SYSTEM
-                                           : __HIP_MEMORY_SCOPE_AGENT);  // publish (sc1)
-                else
-                    __hip_atomic_store(&P.X[(size_t)lc * nf + lane], xk, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+            // (store_published_counted: ONE store instruction on every path, the destination
+            // chosen by a select -- the wait below counts on it)
+            {
+                double *const dst = (j + 1 == th) ? zblock + (size_t)c * ZS + lane
+                                                  : &P.X[(size_t)lc * nf + lane];
+                store_published_counted<P2P>(dst, xk, mine);                  // publish
             }
             published_arrived<1>(Nx.val[0], Nx.val[1], spare);
             S = Nx;

@@ -316,9 +316,10 @@ struct RowsWave {
     {
         xk = acc ? npk : xk;
         // (the publish first -- everybody's next refresh waits for it -- the books after)
-        if (keeps)
-            __hip_atomic_store(zblock + (size_t)c * ZS + k, xk, __ATOMIC_RELAXED,
-                               P2P ? __HIP_MEMORY_SCOPE_SYSTEM : __HIP_MEMORY_SCOPE_AGENT);
+        // (issued on every path, the lanes chosen by EXEC: the loops that ask for the next
+        // refresh's rows outside the compiler's wait counts retire them with vmcnt(1) BEHIND
+        // this store -- handoff.h store_published_counted)
+        store_published_counted<P2P>(zblock + (size_t)c * ZS + k, xk, keeps);
         const bool better = acc && nextchisq < best;
         if (__builtin_expect(__any(better), 0)) {
             if (better) {

@@ -61,6 +61,13 @@ def _blocks(body):
             continue
         op, _, rest = code.partition(' ')
         cur.append((inasm, op, rest))
+        if op == 's_branch' or op.startswith('s_cbranch') or op == 's_endpgm':
+            # a block ends at its branch: what follows (the compiler marks it `; %bb.N:`, a
+            # comment, not a label) is a block of its own -- the state handed to the branch's
+            # target must be the state AT the branch, not at the end of the text behind it
+            synth = f'{label}+{len(order) + 1}'
+            close(synth)
+            label, cur = synth, []
     close(None)
     succ = {}
     for k, lab in enumerate(order):
@@ -81,47 +88,100 @@ def _blocks(body):
     return {lab: blocks[lab][0] for lab in order}, succ, order
 
 
+_VMEM = ('global_load', 'global_store', 'global_atomic', 'buffer_load', 'buffer_store',
+         'buffer_atomic', 'flat_load', 'flat_store', 'flat_atomic', 'scratch_load',
+         'scratch_store')
+_KCAP = 64      # (younger-operation counts saturate here: the counter has six bits)
+
+
+def _vmcnt(rest):
+    """The N of ``s_waitcnt ... vmcnt(N) ...`` (None: the instruction does not wait on the
+    vector-memory counter)."""
+    m = re.search(r'vmcnt\((\d+)\)', rest)
+    if m:
+        return int(m.group(1))
+    m = re.match(r'\s*(0x[0-9a-fA-F]+|\d+)\s*$', rest)
+    if m:                       # a raw immediate: vmcnt = bits 3:0 and 15:14 (gfx9)
+        imm = int(m.group(1), 0)
+        n = (imm & 0xf) | ((imm >> 14) & 0x3) << 4
+        return None if n == 63 else n
+    return None
+
+
 def violations(text):
     """(kernel, block, instruction, registers) of every read of an in-flight hidden load;
-    second value: the number of hidden loads the scan followed."""
+    second value: the number of hidden loads the scan followed.
+
+    The vector-memory counter retires loads AND stores in issue order (gfx9), and
+    ``s_waitcnt vmcnt(N)`` only says "at most N still in flight": a hidden load is known to
+    have landed only if at least N vector-memory operations were issued AFTER it.  So the state
+    is {destination register: k}, k = the least number of vector-memory operations (of any
+    kind, the compiler's own included) issued after the load on any path to this point;
+    ``vmcnt(N)`` -- hand-written or the compiler's -- retires the registers with k >= N and
+    leaves the younger ones pending (round 4 treated any inline-assembly wait as a full one,
+    which was right only while the one operation left outstanding at a ``vmcnt(1)`` site was
+    a store)."""
     found, checked = [], 0
     for name, body in _kernels(text):
         blocks, succ, order = _blocks(body)
-        state = {lab: None for lab in order}        # pending set at block entry
-        state[order[0]] = frozenset()
+        state = {lab: None for lab in order}        # {register: k} at block entry
+        index = {lab: i for i, lab in enumerate(order)}
+        state[order[0]] = {}
         work = [order[0]]
         while work:
             lab = work.pop()
-            pending = set(state[lab])
+            pending = dict(state[lab])
             for inasm, op, rest in blocks[lab]:
-                if inasm:
-                    if op == 'global_load_dwordx2' and not rest.lstrip().startswith('a['):
-                        pending |= _regs(rest.split(',')[0], 'v')
+                if op == 's_waitcnt':
+                    n = _vmcnt(rest)
+                    if n is not None:
+                        pending = {r: k for r, k in pending.items() if k < n}
+                    continue
+                is_vmem = op.startswith(_VMEM)
+                hidden = inasm and op == 'global_load_dwordx2' \
+                    and not rest.lstrip().startswith('a[')
+                if not inasm or (is_vmem and not hidden):
+                    # what the instruction READS: every operand of a store / compare / atomic,
+                    # the operands behind the destination otherwise.  (Writes are not flagged:
+                    # the structurised control flow has statically possible, dynamically dead
+                    # paths -- a "break" flag routed through the loop latch -- on which the
+                    # allocator rightly reuses a register whose value is dead there.)
+                    reads_all = op.startswith(('global_store', 'scratch_store', 'buffer_store',
+                                               'flat_store', 'ds_write', 'ds_store', 'v_cmp',
+                                               'global_atomic', 'flat_atomic'))
+                    srcs = rest if reads_all else rest.partition(',')[2]
+                    touched = _regs(srcs, 'v') & set(pending)
+                    if touched and not inasm:
+                        found.append((name, lab, f'{op} {rest}', sorted(touched)))
+                    if not reads_all and not inasm:   # (overwritten: the value is held dead)
+                        for r in _regs(rest.partition(',')[0], 'v'):
+                            pending.pop(r, None)
+                if is_vmem:
+                    pending = {r: min(k + 1, _KCAP) for r, k in pending.items()}
+                    if hidden:
+                        for r in _regs(rest.split(',')[0], 'v'):
+                            pending[r] = 0
                         checked += 1
-                    elif op == 's_waitcnt':
-                        pending = set()
-                    continue
-                if op == 's_waitcnt' and 'vmcnt(0)' in rest:
-                    pending = set()       # (a full wait the compiler placed: everything is in)
-                    continue
-                # what the instruction READS: every operand of a store / compare / atomic,
-                # the operands behind the destination otherwise.  (Writes are not flagged:
-                # the structurised control flow has statically possible, dynamically dead
-                # paths -- a "break" flag routed through the loop latch -- on which the
-                # allocator rightly reuses a register whose value is dead there.)
-                reads_all = op.startswith(('global_store', 'scratch_store', 'buffer_store',
-                                           'flat_store', 'ds_write', 'ds_store', 'v_cmp',
-                                           'global_atomic', 'flat_atomic'))
-                srcs = rest if reads_all else rest.partition(',')[2]
-                touched = _regs(srcs, 'v') & pending
-                if touched:
-                    found.append((name, lab, f'{op} {rest}', sorted(touched)))
-                if not reads_all:         # (overwritten: the allocator holds the value dead)
-                    pending -= _regs(rest.partition(',')[0], 'v')
             for nxt in succ[lab]:
                 if nxt not in state:
                     continue
-                new = frozenset(pending) if state[nxt] is None else state[nxt] | pending
+                if pending and index[nxt] <= index[lab]:
+                    # A BACKWARD jump with loads still pending.  The loops ask at the top of an
+                    # iteration and wait at its bottom, so the only way to the latch without
+                    # the wait is the way OUT (a wait for a row gave up: `goto out`), which the
+                    # structuriser routes through the latch behind a flag -- statically a path
+                    # into the next iteration, dynamically the loop's exit.  Followed, it makes
+                    # every scratch use of such a register at the top of the body (the refill
+                    # of a batch of draws) a "read of an in-flight load".  Not followed; what
+                    # the scan then does NOT see: a reuse on that exit path itself, behind the
+                    # loop, where nothing reads Z rows any more.
+                    continue
+                if state[nxt] is None:
+                    new = dict(pending)
+                else:
+                    new = dict(state[nxt])
+                    for r, k in pending.items():
+                        new[r] = min(k, new.get(r, _KCAP))
                 if new != state[nxt]:
                     state[nxt] = new
                     work.append(nxt)

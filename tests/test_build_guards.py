@@ -141,3 +141,51 @@ def test_the_scan_catches_a_copy_of_an_in_flight_register():
     assert n == 1 and len(found) == 1 and found[0][3] == [10]
     ok = text.replace('v_mov_b32_e32 v20, v10', 'v_mov_b32_e32 v20, v12')
     assert isa_audit.violations(ok)[0] == []
+
+
+def test_the_scan_counts_partial_waits_in_issue_order():
+    """``s_waitcnt vmcnt(N)`` says "at most N still in flight", in issue order, loads
+    and stores alike -- it retires a hidden load only if N operations were issued AFTER it.
+    Synthetic listings: (a) load, store, vmcnt(1): the load is in (the store may be out); (b)
+    load, then a YOUNGER hidden load, vmcnt(1): the older one is in, the younger one is not --
+    a read of its destination is flagged; (c) two paths that join, one of which issued
+    nothing after the load: the join keeps it pending through vmcnt(1); (d) the compiler's
+    own partial wait counts as well, a wait on another counter does not."""
+    def listing(*body):
+        return '_Z4testv:\n' + ''.join(f'{ln}\n' if ln.endswith(':') else f'\t{ln}\n'
+                                        for ln in body) + '\ts_endpgm\n.Lfunc_end0:\n'
+
+    asm = lambda ins: ('#ASMSTART', ins, '#ASMEND')             # noqa: E731
+    load_a = asm('global_load_dwordx2 v[10:11], v[2:3], off sc1')
+    load_b = asm('global_load_dwordx2 v[12:13], v[2:3], off sc1')
+    store = asm('global_store_dwordx2 v[4:5], v[6:7], off sc1')
+    wait1 = asm('s_waitcnt vmcnt(1)')
+    use_a, use_b = 'v_add_f64 v[20:21], v[10:11], v[10:11]', 'v_add_f64 v[22:23], v[12:13], v[12:13]'
+    # (a)
+    assert isa_audit.violations(listing(*load_a, *store, *wait1, use_a))[0] == []
+    # (b)
+    found, n = isa_audit.violations(listing(*load_a, *load_b, *wait1, use_a, use_b))
+    assert n == 2 and [f[3] for f in found] == [[12, 13]]
+    assert isa_audit.violations(listing(*load_a, *load_b, *asm('s_waitcnt vmcnt(0)'),
+                                        use_a, use_b))[0] == []
+    # (the compiler's own store after the load counts too)
+    assert isa_audit.violations(listing(*load_a, 'global_store_dwordx2 v[4:5], v[6:7], off',
+                                        *wait1, use_a))[0] == []
+    # (c) the store only on one of two paths into the wait
+    joined = listing(*load_a, 's_cbranch_scc0 .LBB0_2', *store, '.LBB0_2:', *wait1, use_a)
+    assert [f[3] for f in isa_audit.violations(joined)[0]] == [[10, 11]]
+    # (d)
+    assert isa_audit.violations(listing(*load_a, *store, 's_waitcnt vmcnt(1)', use_a))[0] == []
+    assert isa_audit.violations(listing(*load_a, *store, 's_waitcnt vmcnt(2)', use_a))[0] != []
+    assert isa_audit.violations(listing(*load_a, *store, *asm('s_waitcnt lgkmcnt(0)'),
+                                        use_a))[0] != []
+    assert isa_audit.violations(listing(*load_a, 's_waitcnt 0x0f70', use_a))[0] == []
+    assert isa_audit.violations(listing(*load_a, 's_waitcnt 0xc07f', use_a))[0] != []
+    # (e) the way out of a loop routed through its latch (a backward jump taken with the loads
+    # still pending) is not followed into the next iteration; the same read on the way FORWARD is
+    loop = listing('.LBB0_1:', 'v_mov_b32_e32 v30, v10', *load_a, 's_cbranch_scc1 .LBB0_1',
+                   *store, *wait1, use_a, 's_branch .LBB0_1')
+    assert isa_audit.violations(loop)[0] == []
+    fwd = listing('.LBB0_1:', *load_a, 's_cbranch_scc1 .LBB0_3', *store, *wait1, use_a,
+                  's_branch .LBB0_1', '.LBB0_3:', 'v_mov_b32_e32 v30, v10')
+    assert [f[3] for f in isa_audit.violations(fwd)[0]] == [[10]]
