@@ -446,7 +446,10 @@ def run_rank(args):
 
     def recycle(g):
         # every rank at the same refresh, between two barriers: nobody stores into a replica
-        # while it is being rearranged
+        # while it is being rearranged.  barrier() is also the VOTE (comm.quiesce: sync on
+        # every rank, all-gather of the verdicts, roll-back everywhere if a launch gave up
+        # anywhere) -- mc3hip_recycle releases the checkpoint such a roll-back needs
+        # (include/mc3hip.h), so it must come after it
         barrier(g)
         g.recycle(keep=1 + zlag, seed=prob['seed'] + 1 + recycles[0])
         ctl.barrier()

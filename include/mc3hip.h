@@ -233,7 +233,10 @@ int mc3hip_sync(mc3hip_ctx *ctx);
  * then on (iteration numbers start over, so the key must change).  keep >= 1 + zlag, at
  * most half of the refreshes done; mrw / demc only -- snooker draws from the WHOLE history
  * (chain.py:197-205), which recycling would cut.  Ranks of a peer-to-peer run all call it
- * at the same refresh, between two barriers. */
+ * at the same refresh, between two barriers -- and, like the next mc3hip_run, only AFTER they
+ * have agreed that nobody's launch gave up (mc3hip_sync on every rank, then a vote:
+ * Communicator.quiesce): the checkpoint a roll-back would need is released here.  A rank
+ * whose own launch gave up gets MC3HIP_ERR_ABORTED and keeps its checkpoint. */
 int mc3hip_recycle(mc3hip_ctx *ctx, int64_t keep, uint64_t seed);
 /* GPU time in ms between the start and end of the last mc3hip_run (HIP events
  * recorded on the context's stream). */

@@ -131,3 +131,27 @@ def test_a_specialised_loop_that_fails_the_audit_is_not_installed(tmp_path, monk
     assert jit.specialise(eng) == '' and eng.installed is None
     assert os.listdir(str(tmp_path)) == []
     assert 'hidden load' in capsys.readouterr().err
+
+
+def test_jit_cache_directory_must_be_private(tmp_path, monkeypatch):
+    """a cached code object is loaded into the process without an audit, so the
+    cache is accepted only if it is a directory of this user that group / others cannot write
+    to; a planted or open directory is passed over for a private one."""
+    from mc3_amd import jit
+    good = tmp_path / 'cache'
+    monkeypatch.setenv('MC3HIP_JIT_CACHE', str(good))
+    assert jit.cache_dir() == str(good) and os.stat(good).st_mode & 0o077 == 0
+    os.chmod(good, 0o777)                           # (anybody could plant <key>.hsaco there)
+    monkeypatch.setattr(jit.tempfile, 'gettempdir', lambda: str(tmp_path))
+    d = jit.cache_dir()
+    assert d != str(good) and os.stat(d).st_uid == os.getuid() and os.stat(d).st_mode & 0o022 == 0
+    # the fallback under the temporary directory pre-created open by somebody: passed over too
+    os.chmod(d, 0o777)
+    monkeypatch.setattr(jit, '_FALLBACK', None)
+    e = jit.cache_dir()
+    assert e not in (str(good), d) and os.stat(e).st_mode & 0o077 == 0
+    # the compiler's version is part of the key
+    monkeypatch.setattr(jit, '_HIPCC_VERSION', 'hipcc 1')
+    k1 = jit._key('lean_demc_body<6, false, false, false, false, false, false>')
+    monkeypatch.setattr(jit, '_HIPCC_VERSION', 'hipcc 2')
+    assert jit._key('lean_demc_body<6, false, false, false, false, false, false>') != k1
