@@ -58,7 +58,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # MI355X_MICROARCH.md: dense FP64 vector / matrix
 LAUNCH_REFRESHES = 16384       # refreshes one launch of a persistent kernel covers
 STEP_LAUNCHES = 18             # persistent launches per step (C2: ~0.35 s of GPU time)
-PMC_FILES = ('r04_c2_pmc.json', 'r03_c2_pmc.json', 'r02_c2_pmc.json', 'r01g_c2_pmc.json')
+PMC_FILES = ('r05_c2_pmc.json', 'r04_c2_pmc.json', 'r03_c2_pmc.json', 'r02_c2_pmc.json',
+             'r01g_c2_pmc.json')
+SIMDS = 1024                   # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4                # MI355X_MICROARCH.md: peak engine clock (the FP64 issue peak:
+                               # one 64-lane FP64 instruction per SIMD every 4 cycles)
 
 
 def quad(p, x):
@@ -103,6 +107,22 @@ def c5_problem(nchains, nrefresh, thinning=1, ndata=100000, nmodel=10):
                 sampler='demc', model='linear', seed=2024, hsize=10)
 
 
+def c4_problem(nchains, nrefresh, thinning=1, ndata=16384):
+    """BASELINE config 4: the quadratic on linspace(0, 10, 2^14), white +
+    red noise, (gamma, sigma_r, sigma_w) appended with gamma fixed, wavelet likelihood,
+    snooker (tests/helpers.py wavelet_problem: the shape the parity tests run)."""
+    rs = np.random.RandomState(99)
+    x = np.linspace(0, 10, ndata)
+    data = quad([3.0, -2.4, 0.5], x) + rs.normal(0, 1.0, ndata) + 0.5*np.sin(2*np.pi*x)
+    return dict(data=data, uncert=np.ones(ndata), indep=x,
+                params=np.array([3.0, -2.4, 0.5, 1.0, 0.5, 1.0]),
+                pstep=np.array([0.3, 0.1, 0.02, 0.0, 0.1, 0.1]),
+                pmin=np.array([-10.0, -20.0, -10.0, 0.0, 0.01, 0.01]),
+                pmax=np.array([40.0, 20.0, 10.0, 2.0, 10.0, 10.0]),
+                nchains=nchains, nsamples=nchains*nrefresh*thinning, thinning=thinning,
+                sampler='snooker', wlike=True, model='poly', seed=4321, hsize=10)
+
+
 # name -> (problem builder, chains: per GPU (weak) or in total (strong), scaling, algorithmic
 # bytes per chain-step by SURVEY.md section 8d: 8*S*ndata + 8*nfree*(R+1) + 8, description)
 WORKLOADS = {
@@ -138,52 +158,95 @@ def initial_population(prob, eval_chisq, expand=None):
     return Z0, -0.5*eval_chisq(Z0)
 
 
-def cpu_baseline(target_seconds=10.0):
-    """The oracle (oracle/oracle_lockstep.c: the same lockstep chain update in
-    plain C, OpenMP over chains) on this box's host cores, same C2 workload,
-    bounded to ~target_seconds.  The thread count is the fastest of a short
-    calibration over 1..usable cores (a container may see more CPUs than it is
-    allowed to use)."""
-    from oracle import lockstep as ls
-    usable = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') \
+def population(g, seed=5):
+    """M0 in-bounds draws of the FREE parameters around the start with finite chisq, evaluated
+    on the device (mcmc_driver.py:229-262)."""
+    rs = np.random.RandomState(seed)
+    ifree = g.ifree
+    Z0, lp0 = np.empty((0, g.nfree)), np.empty(0)
+    while len(Z0) < g.M0:
+        trial = rs.normal(g.params[ifree], g.pstep[ifree], (2*g.M0, g.nfree))
+        full = g.expand_free(trial)
+        ok = np.all((full >= g.pmin) & (full <= g.pmax), axis=1)
+        lp = -0.5*g.eval_chisq(full[ok])
+        fin = np.isfinite(lp)
+        Z0 = np.concatenate([Z0, trial[ok][fin]])
+        lp0 = np.concatenate([lp0, lp[fin]])
+    return np.ascontiguousarray(Z0[:g.M0]), np.ascontiguousarray(lp0[:g.M0])
+
+
+def _usable_cpus():
+    return len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') \
         else (os.cpu_count() or 1)
-    prob = c2_problem(CHAINS_PER_GPU, 400000)
-    orc = ls.LockstepRun(**prob)
-    Z0, lp0 = initial_population(prob, lambda Z: orc.eval_chisq(Z))
-    orc.set_population(Z0, lp0)
 
-    def rate(nthreads, n):
+
+def cpu_baseline(target_seconds=8.0):
+    """The oracle (oracle/oracle_lockstep.c: the same lockstep chain update in plain C) on this
+    box's host cores, the same C2 workload, bounded to ~target_seconds per figure -- TWICE:
+
+    * ``port-processes`` (the figure of record: SURVEY.md 8d(ii)): worker PROCESSES with the
+      chains strided over them, worker i advancing chains i, i + ncpu, ... one after another
+      (mc3/chain.py:163,190-191) and all of them meeting once per refresh (the reference:
+      once per iteration through pipes to the hub, mcmc_driver.py:300-307; here a barrier in
+      shared memory, the cheapest meeting there is) -- ls_run_worker;
+    * ``port-threads``: OpenMP threads of one process over the chains (ls_run).
+
+    Each with the worker / thread count that is fastest in a short calibration over 1..usable
+    cores (a container may see more CPUs than it may use).  Runs in a child process of its own
+    that never loads the HIP runtime (bench.py --cpu-baseline-child): the workers are forked."""
+    from oracle import lockstep as ls
+    usable = _usable_cpus()
+    nmax = 60000
+    prob = c2_problem(CHAINS_PER_GPU, 2*nmax + 4096)
+
+    def fresh(shared):
+        orc = ls.LockstepRun(shared=shared, **prob)
+        Z0, lp0 = initial_population(prob, lambda Z: orc.eval_chisq(Z))
+        orc.set_population(Z0, lp0)
+        return orc
+
+    def measure(step, label):
+        """step(count, n) -> seconds for n refreshes with `count` workers."""
+        step(1, 20)
+        best, best_rate = 1, 100/step(1, 100)
+        for k in (2, 4, 8, 16, 32, 64, 128, 256):
+            if k > min(usable, CHAINS_PER_GPU):
+                break
+            r = 200/step(k, 200)
+            if r > best_rate:
+                best, best_rate = k, r
+            elif r < 0.5*best_rate:
+                break
+        chunk = int(max(200, best_rate))              # about one second of work
+        n, dt = 0, 0.0
         t0 = time.perf_counter()
-        orc.run(nrefresh=n, nthreads=nthreads)
-        return n/(time.perf_counter() - t0)
+        while time.perf_counter() - t0 < target_seconds and n + chunk <= nmax:
+            dt += step(best, chunk)
+            n += chunk
+        return {'value': CHAINS_PER_GPU*n/dt/1e6, 'unit': 'million chain-steps/sec',
+                'cores': best, 'kind': label, 'iterations': n, 'seconds': dt}
 
-    rate(1, 20)
-    best_threads, best_rate = 1, rate(1, 100)
-    for nt in (2, 4, 8, 16, 32, 64, 128, 256):
-        if nt > min(usable, CHAINS_PER_GPU):
-            break
-        r = rate(nt, 200)
-        if r > best_rate:
-            best_threads, best_rate = nt, r
-        elif r < 0.5*best_rate:
-            break
-    chunk = int(max(100, best_rate))            # about one second of work
-    n = 0
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < target_seconds and n + chunk <= 390000:
-        orc.run(nrefresh=chunk, nthreads=best_threads)
-        n += chunk
-    dt = time.perf_counter() - t0
-    return {
-        'value': CHAINS_PER_GPU*n/dt/1e6, 'unit': 'million chain-steps/sec',
-        'cores': best_threads, 'kind': 'port',
-        'sample': f'{n} iterations of the same 256-chain C2 workload '
-                  f'({dt:.1f} s), oracle_lockstep.c, {best_threads} OpenMP THREADS of one '
-                  f'process with a barrier per refresh (best of a calibration up to {usable} '
-                  'usable CPUs) -- not the processes with chains strided over workers of '
-                  'SURVEY.md 8d(ii); mc3\'s own multiprocessing path cannot travel to the GPU '
-                  'box and is measured in the build container: BASELINE.md section 2b',
-    }
+    orc_p = fresh(True)
+    procs = measure(lambda k, n: orc_p.run_processes(n, k), 'port-processes')
+    orc_t = fresh(False)
+
+    def threads(k, n):
+        t0 = time.perf_counter()
+        orc_t.run(nrefresh=n, nthreads=k)
+        return time.perf_counter() - t0
+    thr = measure(threads, 'port-threads')
+    procs['sample'] = (
+        f'{procs.pop("iterations")} iterations of the same 256-chain C2 workload '
+        f'({procs.pop("seconds"):.1f} s), oracle_lockstep.c ls_run_worker: {procs["cores"]} worker '
+        'PROCESSES, chains strided i + j*ncpu over them (mc3/chain.py:163,190-191), one '
+        f'meeting per refresh in shared memory (best of a calibration up to {usable} usable '
+        'CPUs).  mc3\'s own multiprocessing path cannot travel to the GPU box and is measured '
+        'in the build container: BASELINE.md section 2b')
+    thr['sample'] = (
+        f'{thr.pop("iterations")} iterations ({thr.pop("seconds"):.1f} s), the same C loop under '
+        f'{thr["cores"]} OpenMP THREADS of one process, a barrier per refresh')
+    procs['port_threads'] = thr
+    return procs
 
 
 def end_to_end():
@@ -224,6 +287,135 @@ def end_to_end():
         except Exception as e:      # noqa: BLE001 -- an extra: never fails the bench line
             out[name] = {'error': str(e)[:200]}
     return out
+
+
+# ---- the other single-GPU BASELINE configurations, each in a child process of its own ----------
+# (only C2 was driver-timed.  A fresh process per configuration: after the
+# multi-GB allocations of an earlier configuration have been freed, the streaming kernels of C5
+# were seen to run 2-3x slower in the same process.)
+def _fp64_per_chain_step(name):
+    """FP64 wave-instructions (fma + mul + add) per chain-step of a configuration's kernel, from
+    the newest committed PMC pass of it (rocprofv3 --pmc cannot run inside this process)."""
+    for rnd in ('r05', 'r04'):
+        q = os.path.join(ROOT, 'profiles', f'{rnd}_{name}_pmc.json')
+        if os.path.exists(q):
+            with open(q) as f:
+                rec = json.load(f)
+            v = rec.get('derived', {}).get('f64_fma_mul_add_per_chain_step')
+            if v:
+                return float(v), 'profiles/' + os.path.basename(q), rec['kernel']['Kernel_Name']
+    return None, None, None
+
+
+CONFIGS = {
+    # name: (problem builder, chains, warm-up refreshes, timed refreshes, algorithmic bytes per
+    # chain-step (SURVEY.md 8d), text)
+    'c3one': (c2_problem, 2048, 16384, 65536, 8*3*NDATA + 8*3*(3 + 1) + 8,
+              "C3's ensemble in ONE context: quadratic fit, ndata=1000, 2048 chains, demc, "
+              "strict lockstep"),
+    'c4': (c4_problem, 256, 4096, 32768, 8*2*16384 + 8*5*(3 + 1) + 8,
+           "C4: wavelet likelihood (_dwt), ndata=2^14, 256 chains, snooker"),
+    'c5': (c5_problem, 512, 1024, 8192, 8*12*100000 + 8*10*(3 + 1) + 8,
+           "C5's ensemble in ONE context: 10-param linear model, ndata=1e5, 512 chains, "
+           "Gaussian priors + bounds, demc"),
+}
+
+
+def config_child(name):
+    """One configuration on GPU 0: warm-up launches, then `timed` refreshes as whole persistent
+    launches; wall clock around them (stream drained on both sides) and HIP events on the
+    library's stream (mc3hip_last_run_ms, summed over the launches).  Prints ONE JSON line."""
+    from mc3_amd import engine
+    build_problem, nchains, nwarm, ntimed, bytes_per_step, text = CONFIGS[name]
+    prob = build_problem(nchains, nwarm + ntimed + 8)
+    with engine.DeviceChains(**prob) as g:
+        Z0, lp0 = population(g)
+        g.set_population(Z0, lp0)
+        g.run(nwarm)
+        plan = dict(g.plan)
+        per = plan['persistent'] or ntimed
+        gpu_ms, launches, left = 0.0, 0, ntimed
+        g.sync()
+        t0 = time.perf_counter()
+        while left:
+            m = min(left, per)
+            g.run(m, sync=False)
+            gpu_ms += g.last_run_ms()           # (waits for that launch's end event)
+            launches += 1
+            left -= m
+        g.sync()
+        dt = time.perf_counter() - t0
+        st = g.state()
+        nd, nmodel, thinning = g.ndata, g.nmodel, g.thinning
+        done = g.refresh_done
+    steps = nchains*ntimed*thinning
+    rate = steps/dt/1e6
+    rate_ev = steps/(gpu_ms*1e-3)/1e6
+    kernel = ('mc3hip::resident_tile_kernel' if plan.get('resident') else
+              {3: 'mc3hip::wavelet_pipe_kernel', 2: 'mc3hip::lean_demc_kernel',
+               1: 'mc3hip::persist_fast_kernel', 0: 'mc3hip::persist_kernel',
+               4: 'mc3hip::resident_tile_kernel'}.get(plan['fast'], 'mc3hip::persist_kernel'))
+    out = {
+        'config': name, 'workload': text, 'nchains': nchains, 'ndata': nd,
+        'refreshes_timed': ntimed, 'launches': launches, 'kernel': kernel,
+        'million_chain_steps_per_s': rate, 'us_per_iteration': dt/ntimed/thinning*1e6,
+        # HIP events on the library's stream over the same launches
+        'avg_launch_us': gpu_ms*1e3/launches,
+        'us_per_iteration_hip_events': gpu_ms*1e3/ntimed/thinning,
+        'million_chain_steps_per_s_hip_events': rate_ev,
+        'acceptance_rate': float(st['numaccept'].sum())/(nchains*done*thinning),
+        'plan': {k: plan[k] for k in ('fast', 'persistent', 'resident', 'waves_per_chain',
+                                      'chains_per_workgroup', 'tile', 'recoveries')},
+        # the contractual figure (SURVEY.md 8d algorithmic bytes against the HBM peak) --
+        # the operands are chain-invariant and sit on chip, so it may exceed 1: not a limiter
+        'hbm_contract': {'bytes_per_chain_step': bytes_per_step,
+                         'achieved_GBps': rate_ev*1e6*bytes_per_step/1e9,
+                         'frac_of_peak': rate_ev*1e6*bytes_per_step/1e9/HBM_PEAK_GBS},
+    }
+    if name == 'c5':
+        useful = rate_ev*1e6*2.0*nmodel*nd/1e12
+        out['limiter'] = {'bound': 'fp64 matrix / vector pipe (the K = 10 contraction)',
+                          'achieved_TFLOPs': useful, 'peak_TFLOPs': FP64_PEAK_TFLOPS,
+                          'frac': useful/FP64_PEAK_TFLOPS}
+    else:
+        f64, src, kname = _fp64_per_chain_step(name)
+        out['limiter'] = {
+            'bound': 'fp64 vector issue (one 64-lane FP64 instruction per SIMD per 4 cycles, '
+                     f'{SIMDS} SIMDs at {CLOCK_GHZ} GHz)',
+            'fp64_instructions_per_chain_step': f64, 'instruction_count_from': src,
+            'instruction_count_kernel': kname,
+            'frac': None if f64 is None else rate_ev*1e6*f64*4/(SIMDS*CLOCK_GHZ*1e9)}
+    print(json.dumps(out), flush=True)
+
+
+def run_children(names, timeout=600):
+    """bench.py --config-child NAME for every name, one after another; {name: record}."""
+    out = {}
+    for name in names:
+        try:
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), '--config-child',
+                                  name], capture_output=True, text=True, timeout=timeout)
+            line = next((ln for ln in reversed(res.stdout.splitlines()) if ln.startswith('{')),
+                        None)
+            out[name] = json.loads(line) if res.returncode == 0 and line else \
+                {'error': (res.stderr or res.stdout)[-300:] or f'exit code {res.returncode}'}
+        except Exception as e:      # noqa: BLE001 -- an extra: never fails the bench line
+            out[name] = {'error': str(e)[:300]}
+    return out
+
+
+def hbm_peak_probe():
+    """tools/probes/hbm_read_probe (built by __graft_entry__.build): streaming-read bandwidth of
+    THIS box, the measured denominator next to the 8 TB/s of the specification."""
+    from mc3_amd import build
+    exe = build.probe_path('hbm_read_probe')
+    try:
+        res = subprocess.run([exe, '4', '8'], capture_output=True, text=True, timeout=120)
+        rec = json.loads(res.stdout.strip().splitlines()[-1])
+        return {'GBps': rec['GBps_best'], 'GBps_mean': rec['GBps_mean'], 'bytes': rec['bytes'],
+                'shape': rec['shape'], 'source': 'tools/probes/hbm_read_probe.hip, this run'}
+    except Exception as e:      # noqa: BLE001
+        return {'error': str(e)[:200]}
 
 
 # ---- N > 1 started as one plain process: the parent of the ranks ----------------------------
@@ -402,6 +594,9 @@ def run_rank(args):
         # refresh.  Every rank takes the same branch.
         comm = ctl
         comm.wants_p2p = not os.environ.get('MC3HIP_BENCH_NO_P2P') and not args.dry_run
+        # (`value` is the STRICT lockstep unless --zlag says otherwise: the same random process
+        # at every N, the library's default on any number of ranks; the declared cadence is
+        # measured beside it -- cadence_segment -- and named `values.cadence`)
         ctl_opts.update(comm.engine_options(local_rank, args.thinning, args.zlag))
         gpu = make_engine(comm.wants_p2p)
         comm.setup(gpu)
@@ -421,8 +616,7 @@ def run_rank(args):
                 comm.setup(gpu)
         exchange = comm.mode
     else:
-        if args.zlag:
-            ctl_opts['zlag'] = args.zlag
+        ctl_opts.update(ctl.engine_options(local_rank, args.thinning, args.zlag))
         gpu = make_engine(False)
         if force_comm:
             gpu.comm_init(engine.comm_unique_id(), 0, 1)
@@ -680,12 +874,54 @@ def run_rank(args):
             'note': 'one wave per CU on 256 CUs = 1/4 of the SIMDs, ~2 % of the FP64 vector '
                     'peak: the workload (256 chains, 1000 points) cannot fill the chip; '
                     'it is latency-bound, neither bandwidth- nor FLOP-bound'}
+    # the physically meaningful fraction under ONE name for every workload, next to the
+    # contractual `frac`: what fraction of its real limiter the kernel reaches
+    rl = out['roofline']
+    if args.workload == 'c5':
+        rl['limiter'], rl['limiter_frac'] = 'fp64 matrix / vector pipe', rl['frac']
+    else:
+        rl['limiter'] = 'latency of the hand-off between workgroups + one wave\'s dependent ' \
+                        'FP64 chain (latency_model)'
+        rl['limiter_frac'] = rl['latency_frac']
+    cadence = parallel.resolve_zlag('auto', args.thinning)
+    out['values'] = {
+        'note': '`value` is the lockstep cadence named in config.zlag (default 0: strict, the '
+                'same random process at every N -- mc3_amd.sample()\'s default on any number of '
+                'ranks); `cadence` is the declared multi-GPU cadence (zlag refreshes of '
+                'latency hiding, opt-in) measured in the same run; compare N GPUs with one GPU '
+                'IN THE SAME CADENCE (single_gpu_same_ensemble)',
+        ('strict' if not plan.get('zlag') else f'zlag{plan["zlag"]}'): {
+            'zlag': plan.get('zlag', 0), 'million_chain_steps_per_s': value,
+            'exchange': exchange, 'is_value': True},
+        'cadence': None, 'single_gpu_same_ensemble': None}
     if world == 1:
         gpu.close()
+    if rank == 0 and world == 1 and not args.dry_run and not args.no_extras:
+        # one GPU in the declared cadence: the like-for-like yardstick of a sharded run's
+        # `values.cadence` (and what a rank on a GPU of its own runs at)
+        out['values']['cadence'] = _single_gpu(args, build_problem, nchains, local_rank, engine,
+                                               cadence)
+        if args.workload == 'c2':
+            # the other single-GPU BASELINE configurations, driver-timed (fresh process each)
+            out['configs'] = run_children(['c3one', 'c4', 'c5'])
+        probe = hbm_peak_probe()
+        rl['peak_measured'] = probe
+        if 'GBps' in probe and rl.get('unit') == 'GB/s':
+            rl['frac_of_peak_measured'] = rl['achieved']/probe['GBps']
+        elif 'GBps' in probe and 'hbm_contract' in rl:
+            rl['hbm_contract']['frac_of_peak_measured'] = \
+                rl['hbm_contract']['achieved']/probe['GBps']
     if rank == 0 and world == 1 and not args.dry_run and not args.no_e2e:
         out['config']['e2e'] = end_to_end()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry_run:
-        out['cpu_baseline'] = cpu_baseline()
+        # (in a child process that never loads the HIP runtime: its worker processes are forked)
+        try:
+            res = subprocess.run([sys.executable, os.path.abspath(__file__),
+                                  '--cpu-baseline-child'], capture_output=True, text=True,
+                                 timeout=300)
+            out['cpu_baseline'] = json.loads(res.stdout.strip().splitlines()[-1])
+        except Exception as e:      # noqa: BLE001
+            out['cpu_baseline'] = {'error': (str(e) + getattr(e, 'stderr', ''))[:300]}
     import threading
     emit_lock, emitted = threading.Lock(), [False]
 
@@ -721,17 +957,76 @@ def run_rank(args):
         timer = threading.Timer(limit, give_up)
         timer.daemon = True
         timer.start()
+        if not zlag:
+            out['values']['cadence'] = cadence_segment(
+                args, ctl, engine, build_problem, nchains, nlocal, chain0, local_rank, cadence,
+                shared_device)
+            ctl.barrier()
         out['config']['collective_rccl'] = rccl_segment(
             args, ctl, make_engine, build_problem, nchains, nlocal, chain0, local_rank, engine)
         ctl.barrier()
         if rank == 0:
-            out['config']['single_gpu_same_ensemble'] = single_gpu_segment(
-                args, build_problem, nchains, local_rank, engine, zlag)
+            # ONE GPU, the whole ensemble, in the strict lockstep and in the cadence: N GPUs
+            # against one in the SAME random process, either way
+            single = single_gpu_segment(args, build_problem, nchains, local_rank, engine,
+                                        zlag or cadence)
+            out['config']['single_gpu_same_ensemble'] = single
+            out['values']['single_gpu_same_ensemble'] = single
         ctl.barrier()
         timer.cancel()
     ctl.barrier()
     ctl.close()
     emit()
+
+
+def cadence_segment(args, ctl, engine, build_problem, nchains, nlocal, chain0, device, zlag,
+                    shared_device):
+    """The same sharded ensemble in the DECLARED CADENCE (the other chains seen `zlag` refreshes
+    late, so that a row has that long to cross xGMI): a second engine per rank, the same
+    exchange set-up by consensus, timed on its own.  `values.cadence`."""
+    if args.workload == 'c5':
+        nwarm, ntimed = 16, 100
+    else:
+        nwarm, ntimed = (4096, 16384) if shared_device else (16384, 4*LAUNCH_REFRESHES)
+    prob = build_problem(nchains, nwarm + ntimed + 8, args.thinning)
+    saved = (ctl.native, ctl.mode, ctl.wants_p2p)
+    g, ok, err = None, True, None
+    try:
+        ctl.wants_p2p = not os.environ.get('MC3HIP_BENCH_NO_P2P')
+        opts = ctl.engine_options(device, args.thinning, zlag)
+        g = engine.DeviceChains(device=device, chain0=chain0, nlocal=nlocal, **opts, **prob)
+        Z0, lp0 = initial_population(prob, lambda Z: g.eval_chisq(g.expand_free(Z)))
+        g.set_population(Z0, lp0)
+    except Exception as e:      # noqa: BLE001
+        ok, err = False, str(e)[:300]
+    out = None
+    if ctl._all_ok(ok):
+        ctl.setup(g)
+        if not ctl.native:
+            out = {'error': 'neither the peer-to-peer hand-off nor RCCL on every rank'}
+        else:
+            mode = ctl.mode
+            g.run(nwarm, sync=False)
+            ctl.quiesce(g)
+            g.sync()
+            ctl.barrier()
+            t0 = time.perf_counter()
+            g.run(ntimed, sync=False)
+            ctl.quiesce(g)
+            g.sync()
+            ctl.barrier()
+            dt = max(ctl.all_gather(time.perf_counter() - t0))
+            out = {'zlag': int(g.plan.get('zlag', 0)), 'exchange': ctl.mode,
+                   'exchange_at_start': mode, 'refreshes_timed': ntimed,
+                   'us_per_refresh': dt/ntimed*1e6,
+                   'million_chain_steps_per_s': nchains*ntimed*args.thinning/dt/1e6,
+                   'recoveries': g.plan['recoveries'] + ctl.recoveries, 'is_value': False}
+    else:
+        out = {'error': err or 'an engine could not be created on every rank'}
+    if g is not None:
+        g.close()
+    ctl.native, ctl.mode, ctl.wants_p2p = saved
+    return out
 
 
 def rccl_segment(args, ctl, make_engine, build_problem, nchains, nlocal, chain0, device, engine):
@@ -794,7 +1089,7 @@ def single_gpu_segment(args, build_problem, nchains, device, engine, zlag=0):
 def _single_gpu(args, build_problem, nchains, device, engine, zlag):
     # (long enough for the clocks to come back up after the idle seconds before it: with 8192
     # refreshes -- 10 ms -- the figure of one and the same kernel varied by a factor of two)
-    nwarm, ntimed = (40, 200) if args.workload == 'c5' else (16384, 32768)
+    nwarm, ntimed = (40, 200) if args.workload == 'c5' else (16384, 65536)
     prob = build_problem(nchains, nwarm + ntimed + 8, args.thinning)
     try:
         with engine.DeviceChains(device=device, zlag=zlag, **prob) as g:
@@ -822,22 +1117,36 @@ def main():
                     help='Z refreshes per step (default: up to 6 persistent launches of 16384, '
                          'as many as (steps+warmup) batches of Z fit the memory budget)')
     ap.add_argument('--thinning', type=int, default=1)
-    ap.add_argument('--zlag', type=int, default=None,
-                    help='the declared cadence: the other chains are seen that many refreshes '
-                         'late (default: 0 = strict lockstep on one GPU; over several GPUs the '
-                         'communicator\'s choice, mc3_amd.parallel.DEFAULT_ZLAG)')
+    ap.add_argument('--zlag', default=None,
+                    help='the lockstep cadence of `value`: the other chains are seen that many '
+                         'refreshes late (an integer or "auto" = parallel.CADENCE_ZLAG; default '
+                         '0 = strict lockstep at every N; the cadence is measured beside it, '
+                         '`values.cadence`)')
+    ap.add_argument('--config-child', default=None, choices=sorted(CONFIGS),
+                    help='(internal) one of the other BASELINE configurations, one JSON line')
+    ap.add_argument('--cpu-baseline-child', action='store_true',
+                    help='(internal) the CPU baseline, one JSON line; never touches the GPU')
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='c2',
                     help='c2: the headline, 256 chains per GPU (weak scaling); c3 / c5: BASELINE '
                          'configs 3 and 5, a fixed ensemble split over the GPUs (strong scaling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
-                    help='several ranks: skip the two extra segments (RCCL route, one-GPU '
-                         'yardstick) -- sweeps')
+                    help='skip the extra segments (several ranks: the cadence, the RCCL route, '
+                         'the one-GPU yardstick; one GPU: the cadence, the other BASELINE '
+                         'configurations, the HBM probe) -- sweeps and profiler passes')
     ap.add_argument('--no-e2e', action='store_true',
                     help='skip the end-to-end sample() timings (config.e2e)')
     ap.add_argument('--dry-run', action='store_true',
                     help='no GPU work: exercises the launcher / rendezvous / reporting only')
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        print(json.dumps(cpu_baseline()), flush=True)
+        return
+    if args.config_child:
+        config_child(args.config_child)
+        return
+    if args.zlag is not None and args.zlag != 'auto':
+        args.zlag = int(args.zlag)
     if 'RANK' not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -78,7 +78,10 @@ class LockstepRun:
                  nsamples=None, sampler='snooker', wlike=False, thinning=1,
                  fgamma=1.0, fepsilon=0.0, hsize=10, model='poly', nmodel=None,
                  seed=0, tile=0, vlanes=None, chain0=0, nlocal=None, M0=None,
-                 wl_threads=0, tile_tree=0, zlag=0, wl_nreal=0):
+                 wl_threads=0, tile_tree=0, zlag=0, wl_nreal=0, shared=False):
+        # shared: the state arrays live in anonymous MAP_SHARED memory, so that worker
+        # processes forked later (run_processes) advance ONE run
+        self._maps = []
         L = ok.lib()
         L.ls_run.restype = ctypes.c_int
         L.ls_eval_chisq.restype = ctypes.c_int
@@ -116,17 +119,30 @@ class LockstepRun:
         self.nzchain = int(np.ceil(nsamples/self.nchains/self.thinning))
         self.zlen = self.M0 + self.nzchain*self.nchains
         nf = self.nfree
-        self.Z = np.zeros((self.zlen, nf))
-        self.log_post = np.zeros(self.zlen)
-        self.zchain = -np.ones(self.zlen, np.int32)
-        self.X = np.zeros((self.nchains, nf))
-        self.chisq = np.zeros(self.nchains)
-        self.numaccept = np.zeros(self.nchains, np.int64)
-        self.outbounds = np.zeros(nf, np.int64)
-        self.best_chisq = np.full(self.nchains, np.inf)
-        self.best_iter = -np.ones(self.nchains, np.int64)
-        self.bestx = np.zeros((self.nchains, nf))
-        self.snap0 = np.zeros((self.nchains, nf))
+
+        def alloc(shape, dtype=np.float64, fill=0):
+            if not shared:
+                return np.full(shape, fill, dtype)
+            import mmap
+            nbytes = max(1, int(np.prod(shape))*np.dtype(dtype).itemsize)
+            m = mmap.mmap(-1, nbytes)         # (anonymous, MAP_SHARED: inherited by fork)
+            self._maps.append(m)
+            a = np.frombuffer(m, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+            if fill != 0:
+                a[...] = fill
+            return a
+        self.Z = alloc((self.zlen, nf))
+        self.log_post = alloc(self.zlen)
+        self.zchain = alloc(self.zlen, np.int32, -1)
+        self.X = alloc((self.nchains, nf))
+        self.chisq = alloc(self.nchains)
+        self.numaccept = alloc(self.nchains, np.int64)
+        self.outbounds = alloc(nf, np.int64)
+        self.best_chisq = alloc(self.nchains, fill=np.inf)
+        self.best_iter = alloc(self.nchains, np.int64, -1)
+        self.bestx = alloc((self.nchains, nf))
+        self.snap0 = alloc((self.nchains, nf))
+        self._barrier = alloc(8, np.int32) if shared else None
         self.trace_chisq = None
         self.trace_flag = None
         # gamma as the host computes it (chain.py:175)
@@ -252,6 +268,45 @@ class LockstepRun:
             raise RuntimeError(f'ls_run failed ({rc})')
         return self
 
+
+    def run_processes(self, nrefresh, ncpu):
+        """The same refreshes by `ncpu` WORKER PROCESSES, worker i advancing the chains
+        i, i + ncpu, i + 2 ncpu, ... (the reference's fan-out: mc3/chain.py:163,190-191) and
+        meeting the others once per refresh (ls_run_worker).  Needs shared=True.  Returns the
+        wall seconds from the moment all workers stand ready to the moment all are done
+        (process start-up is not the chains' time: the reference's hub starts its workers
+        once per run)."""
+        import os
+        import time
+        if self._barrier is None:
+            raise RuntimeError('run_processes needs LockstepRun(..., shared=True)')
+        self.L.ls_run_worker.restype = ctypes.c_int
+        # two barriers: [0] the workers' meeting per refresh, [1] start / end with the parent
+        self._barrier[:] = (0, 0, ncpu, 0, 0, 0, ncpu + 1, 0)
+        bar = (ctypes.c_int32*8).from_buffer(self._barrier)
+        pids = []
+        for wid in range(ncpu):
+            pid = os.fork()
+            if pid == 0:
+                rc = 1
+                try:
+                    rc = self.L.ls_run_worker(
+                        ctypes.byref(self.P), ctypes.byref(self.S), ctypes.c_int64(nrefresh),
+                        ctypes.c_int(wid), ctypes.c_int(ncpu), bar)
+                finally:
+                    os._exit(0 if rc == 0 else 3)
+            pids.append(pid)
+        start_end = ctypes.cast(ctypes.addressof(bar) + 16, ctypes.POINTER(ctypes.c_int32))
+        sense = ctypes.c_int(0)
+        self.L.ls_barrier_attend(start_end, ctypes.byref(sense))
+        t0 = time.perf_counter()
+        self.L.ls_barrier_attend(start_end, ctypes.byref(sense))
+        dt = time.perf_counter() - t0
+        bad = [os.waitpid(p, 0)[1] for p in pids]
+        if any(bad):
+            raise RuntimeError(f'worker processes failed: {bad}')
+        self.S.refresh_done += nrefresh
+        return dt
 
     def run_tape(self, kind, value, fma_dot=True, trace=True):
         """The reference's own sequential loop (ls_run_tape) fed a tape of its

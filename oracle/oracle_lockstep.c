@@ -36,6 +36,7 @@
  * load this file's library.
  */
 #include <math.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -668,10 +669,8 @@ static void chain_step(const ls_problem *P, ls_state *St, ls_scratch *S, ls_draw
         for (int k = 0; k < nf; k++) {
             const int j = P->ifree[k];
             if (nextp[j] < P->pmin[j] || nextp[j] > P->pmax[j]) {
-#ifdef _OPENMP
-#pragma omp atomic
-#endif
-                St->outbounds[k] += 1;
+                /* (shared by the chains' threads -- and by worker PROCESSES, ls_run_worker) */
+                __atomic_fetch_add(&St->outbounds[k], 1, __ATOMIC_RELAXED);
             }
         }
     } else {
@@ -731,6 +730,31 @@ static void scratch_free(ls_scratch *S)
     free(S->nextp); free(S->jump); free(S->normal); free(S->dz);
 }
 
+/* One chain's part of refresh R (`thinning` iterations and the Z append): shared by the two
+ * lockstep drivers below. */
+static void refresh_chain(const ls_problem *P, ls_state *St, ls_scratch *S, ls_draws *D, int c,
+                          int64_t R, int64_t R0, const double *snap, int64_t zsize,
+                          int64_t row0, int need_normal)
+{
+    const int nf = P->nfree;
+    for (int j = 0; j < P->thinning; j++) {
+        const int64_t iter = R * P->thinning + j;
+        const int64_t trow = (R - R0) * P->thinning + j;
+        D->iter = (uint64_t)iter;
+        D->chain = (uint32_t)c;
+        if (need_normal)
+            draw_normal(D, P, S->normal);
+        chain_step(P, St, S, D, c, iter, S->normal, snap, zsize,
+                   St->trace_chisq ? St->trace_chisq + trow * P->nchains + c : NULL,
+                   St->trace_flag ? St->trace_flag + trow * P->nchains + c : NULL);
+    }
+    /* Z append, chain.py:276-289 (strided slot M0 + ID + k*nchains) */
+    const int64_t row = row0 + c;
+    memcpy(St->Z + (size_t)row * nf, St->X + (size_t)c * nf, sizeof(double) * (size_t)nf);
+    St->log_post[row] = -0.5 * St->chisq[c];
+    St->zchain[row] = c;
+}
+
 /* LOCKSTEP driver.  Advance chains [chain0, chain0+nlocal) by nrefresh Z refreshes of
  * `thinning` iterations each: Philox draws, every chain sees the others through the
  * snapshot of the previous refresh.  Rows of the other chains must already be in Z
@@ -769,28 +793,80 @@ int ls_run(const ls_problem *P, ls_state *St, int64_t nrefresh, int nthreads)
 #ifdef _OPENMP
 #pragma omp for schedule(static)
 #endif
-            for (int c = P->chain0; c < P->chain0 + P->nlocal; c++) {
-                for (int j = 0; j < P->thinning; j++) {
-                    const int64_t iter = R * P->thinning + j;
-                    const int64_t trow = (R - R0) * P->thinning + j;
-                    D.iter = (uint64_t)iter;
-                    D.chain = (uint32_t)c;
-                    if (need_normal)
-                        draw_normal(&D, P, S.normal);
-                    chain_step(P, St, &S, &D, c, iter, S.normal, snap, zsize,
-                               St->trace_chisq ? St->trace_chisq + trow * P->nchains + c : NULL,
-                               St->trace_flag ? St->trace_flag + trow * P->nchains + c : NULL);
-                }
-                /* Z append, chain.py:276-289 (strided slot M0 + ID + k*nchains) */
-                const int64_t row = row0 + c;
-                memcpy(St->Z + (size_t)row * nf, St->X + (size_t)c * nf,
-                       sizeof(double) * (size_t)nf);
-                St->log_post[row] = -0.5 * St->chisq[c];
-                St->zchain[row] = c;
-            }
+            for (int c = P->chain0; c < P->chain0 + P->nlocal; c++)
+                refresh_chain(P, St, &S, &D, c, R, R0, snap, zsize, row0, need_normal);
         }
         scratch_free(&S);
     }
+    St->refresh_done = R0 + nrefresh;
+    return 0;
+}
+
+/* The same lockstep run as the reference's fan-out lays it out (mc3/chain.py:163,190-191;
+ * hub: mcmc_driver.py:204-221,300-307): `ncpu` WORKER PROCESSES, worker `wid` advancing the
+ * chains wid, wid + ncpu, wid + 2 ncpu, ... one after another, all workers meeting once per
+ * refresh (the reference: once per iteration, through a pipe each to the hub; here a
+ * sense-reversing barrier in memory the workers share -- the cheapest meeting there is).
+ * Every array of `St` and the barrier must live in memory shared by the workers (MAP_SHARED,
+ * mapped before they were forked: oracle/lockstep.py run_processes); the out-of-bounds
+ * counters are added to atomically (chain_step), everything else has one writer.  Results
+ * equal ls_run's bit for bit (tests/test_lockstep_oracle.py).  bench.py's cpu_baseline
+ * "port-processes" (SURVEY.md 8d(ii)). */
+typedef struct {
+    int32_t count, sense, nworkers, pad;
+} ls_barrier;
+
+static void barrier_meet(ls_barrier *b, int *local_sense)
+{
+    *local_sense = !*local_sense;
+    if (__atomic_add_fetch(&b->count, 1, __ATOMIC_ACQ_REL) == b->nworkers) {
+        __atomic_store_n(&b->count, 0, __ATOMIC_RELAXED);
+        __atomic_store_n(&b->sense, *local_sense, __ATOMIC_RELEASE);
+        return;
+    }
+    int spins = 0;
+    while (__atomic_load_n(&b->sense, __ATOMIC_ACQUIRE) != *local_sense)
+        if (++spins > 4096) {
+            sched_yield();          /* (more workers than cores must not starve each other) */
+            spins = 0;
+        }
+}
+
+/* (for the parent of the workers, which only keeps the time: start and end meeting) */
+void ls_barrier_attend(ls_barrier *b, int *local_sense) { barrier_meet(b, local_sense); }
+
+/* bar[0]: the workers' meeting per refresh (nworkers = ncpu); bar[1]: start and end of the
+ * run, attended by the parent too (nworkers = ncpu + 1) */
+int ls_run_worker(const ls_problem *P, ls_state *St, int64_t nrefresh, int wid, int ncpu,
+                  ls_barrier *bar)
+{
+    const int nf = P->nfree;
+    const int64_t R0 = St->refresh_done;
+    if (P->M0 + (R0 + nrefresh) * P->nchains > P->zlen || ncpu < 1 || wid < 0 || wid >= ncpu)
+        return -1;
+    ls_scratch S;
+    scratch_alloc(P, &S);
+    ls_draws D;
+    memset(&D, 0, sizeof D);
+    D.seed = P->seed;
+    D.sampler = P->sampler;
+    const int need_normal = (P->sampler == LS_MRW) || (P->fepsilon != 0.0);
+    for (int k = 0; k < nf; k++)
+        S.normal[k] = 0.0;
+    int sense = 0, sense_run = 0;
+    barrier_meet(&bar[1], &sense_run);                   /* everybody stands ready */
+    for (int64_t R = R0; R < R0 + nrefresh; R++) {
+        const int64_t Rs = R - 1 - (int64_t)P->zlag;
+        const double *snap = (Rs < 0) ? St->snap0
+                           : St->Z + (size_t)(P->M0 + Rs * P->nchains) * nf;
+        const int64_t zsize = P->M0 + (Rs + 1 > 0 ? Rs + 1 : 0) * P->nchains;
+        const int64_t row0 = P->M0 + R * P->nchains;
+        for (int c = P->chain0 + wid; c < P->chain0 + P->nlocal; c += ncpu)   /* chain.py:190-191 */
+            refresh_chain(P, St, &S, &D, c, R, R0, snap, zsize, row0, need_normal);
+        barrier_meet(&bar[0], &sense);                   /* mcmc_driver.py:300-307 */
+    }
+    barrier_meet(&bar[1], &sense_run);                   /* everybody is done */
+    scratch_free(&S);
     St->refresh_done = R0 + nrefresh;
     return 0;
 }

@@ -22,7 +22,12 @@ def main():
     # key=value extras: per_rank (256), ndata (1000), sampler (demc), thinning (1), zlag (the
     # communicator's default), fx (0; 1: a fixed and a shared coefficient, priors)
     extra = dict(a.split('=') for a in sys.argv[3:])
-    comm = ranks.worker_comm(use_p2p=True, use_rccl=False)
+    # exchange=rccl: the north star's collective (one in-place ncclAllGather per refresh, issued
+    # by the library) instead of the peer-to-peer hand-off; devices=own: every rank on the GPU
+    # of its LOCAL_RANK (tests/test_gpu_multidevice.py, boxes with two GPUs and more)
+    rccl = extra.get('exchange') == 'rccl'
+    device = int(os.environ.get('LOCAL_RANK', '0')) if extra.get('devices') == 'own' else 0
+    comm = ranks.worker_comm(use_p2p=not rccl, use_rccl=rccl)
     per_rank = int(extra.get('per_rank', 256))
     thinning = int(extra.get('thinning', 1))
     nchains = per_rank*comm.size
@@ -31,11 +36,37 @@ def main():
                                 fx=int(extra.get('fx', 0)))
     pop = np.load(out_path + '.pop.npz')
     c0, n = comm.partition(nchains)
-    opts = comm.engine_options(0, thinning, int(extra['zlag']) if 'zlag' in extra else None)
-    assert opts['p2p'] and opts['no_courier'] == (comm.size > 2), opts
-    gpu = engine.DeviceChains(chain0=c0, nlocal=n, device=0, **opts, **prob)
+    opts = comm.engine_options(device, thinning, int(extra['zlag']) if 'zlag' in extra else None)
+    if rccl:
+        assert 'p2p' not in opts, opts
+    else:
+        crowded = comm.size > 2 and extra.get('devices') != 'own'
+        assert opts['p2p'] and opts['no_courier'] == crowded, opts
+    gpu = engine.DeviceChains(chain0=c0, nlocal=n, device=device, **opts, **prob)
     gpu.set_population(pop['Z0'], pop['lp0'])
     comm.setup(gpu)
+    if rccl:
+        # one launch per refresh + ONE in-place all-gather of the refresh's rows, replayed from
+        # a hipGraph; RCCL itself says how many ranks the communicator spans
+        assert comm.mode == 'rccl', comm.mode
+        gpu.run(nref//3)
+        gpu.run(nref - nref//3)
+        comm.finish(gpu)
+        nranks, myrank = gpu.comm_info()
+        assert (nranks, myrank) == (comm.size, comm.rank), (nranks, myrank)
+        plan = gpu.plan
+        assert plan['comm_graph'] > 0 and plan['zlag'] == opts['zlag'], plan
+        Z, lp, zc = gpu.rows()
+        st = gpu.state()
+        np.savez(f'{out_path}.rank{comm.rank}.npz', Z=Z, lp=lp, zc=zc, zlag=plan['zlag'],
+                 numaccept=st['numaccept'], outbounds=st['outbounds'],
+                 best_chisq=st['best_chisq'], X=st['X'], chisq=st['chisq'])
+        print(f'rank {comm.rank}: rccl all-gather over {nranks} ranks on device {device}',
+              flush=True)
+        comm.barrier()
+        gpu.close()
+        ranks.finalize(comm)
+        return
     assert comm.mode == 'p2p', comm.mode
     plan = gpu.plan
     # the hand-laid-out loops: lean_demc_kernel<3, P2P> (strict lockstep), lean_demc_lag_kernel

@@ -190,3 +190,20 @@ def initial_population(orc, seed=5):
         lp0[filled] = -0.5*c
         filled += 1
     return Z0, lp0
+
+
+def gpu_count():
+    """Devices HIP shows, counted in a CHILD process (the caller's own GPU state is left alone);
+    0 when there is no runtime or no GPU."""
+    import subprocess
+    import sys
+    code = ('import ctypes\n'
+            'n = ctypes.c_int(0)\n'
+            'rc = ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(n))\n'
+            'print(n.value if rc == 0 else 0)\n')
+    try:
+        res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True,
+                             timeout=120)
+        return int(res.stdout.strip() or 0)
+    except (OSError, ValueError, subprocess.SubprocessError):
+        return 0

@@ -35,7 +35,8 @@ def main():
         pmin=np.array([-10.0, -20.0, -10.0]), pmax=np.array([40.0, 20.0, 10.0]),
         sampler=sampler, nsamples=nchains*niter*thinning, burnin=10, nchains=nchains,
         thinning=thinning, grtest=True, log=mu.Log(verb=0), seed=99, comm=comm,
-        device=0, **({'zlag': extra['zlag'] if extra['zlag'] == 'auto' else int(extra['zlag'])}
+        device=int(os.environ.get('LOCAL_RANK', '0'))
+        if os.environ.get('P2P_WORKER_DEVICES') == 'own' else 0, **({'zlag': extra['zlag'] if extra['zlag'] == 'auto' else int(extra['zlag'])}
                      if 'zlag' in extra else {}))
     if abort_at is None:
         assert comm.mode == 'p2p' and comm.recoveries == 0, (comm.mode, comm.recoveries)

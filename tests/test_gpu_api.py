@@ -143,10 +143,12 @@ def test_sample_polynomial_of_six_coefficients_over_many_points():
     np.testing.assert_array_equal(again['posterior'], gpu['posterior'])
 
 
-@pytest.mark.parametrize('sampler,builder', [('snooker', H.quad_problem),
-                                             ('demc', H.quad_problem),
-                                             ('demc', H.linear_problem)])
-def test_rccl_path_single_rank_in_a_graph(sampler, builder):
+@pytest.mark.parametrize('sampler,builder,zlag', [('snooker', H.quad_problem, 0),
+                                                  ('demc', H.quad_problem, 0),
+                                                  ('demc', H.linear_problem, 0),
+                                                  ('demc', H.quad_problem, 2),
+                                                  ('snooker', H.quad_problem, 1)])
+def test_rccl_path_single_rank_in_a_graph(sampler, builder, zlag):
     """The RCCL exchange (one rank: the all-gather is a copy) captured in a hipGraph:
     step kernel -> ring slot, in-place ncclAllGather of the slot, scatter to Z, 16
     refreshes per replay; the first refresh and the tail run eagerly.  The multi-rank
@@ -157,10 +159,12 @@ def test_rccl_path_single_rank_in_a_graph(sampler, builder):
     prob = builder(sampler=sampler, **kw)
     os.environ['MC3HIP_GRAPH_NODES'] = '16'
     try:
-        gpu = engine.DeviceChains(**prob)
+        gpu = engine.DeviceChains(zlag=zlag, **prob)
     finally:
         del os.environ['MC3HIP_GRAPH_NODES']
-    orc = H.make_oracle(prob, plan=gpu.plan)
+    # (zlag > 0: the cadence on the one-launch-per-refresh path the all-gather rides on --
+    # tests/test_gpu_multidevice.py runs it with a rank per GPU)
+    orc = H.make_oracle(prob, plan=gpu.plan, zlag=zlag)
     Z0, lp0 = H.initial_population(orc)
     orc.set_population(Z0, lp0)
     orc.run(nthreads=4)

@@ -100,7 +100,8 @@ def lean_ranks_case(tmp_path, nranks, nref, zlag, delay_ns=0, **shape):
     per_rank = shape.get('per_rank', 256)
     nchains = per_rank*nranks
     prob = H.lean_shape_problem(nchains, nref, **{k: v for k, v in shape.items()
-                                                  if k not in ('per_rank', 'turns')})
+                                                  if k not in ('per_rank', 'turns', 'devices',
+                                                               'exchange')})
     env = {'MC3HIP_TEST_REMOTE_DELAY_NS': str(delay_ns)} if delay_ns else {}
     if 'turns' in shape:       # (several chains per wave: pretend that fewer workgroups fit)
         env['MC3HIP_PERSIST_CAPACITY'] = str(-(-per_rank//shape['turns']))

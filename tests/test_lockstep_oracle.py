@@ -190,3 +190,28 @@ def test_lagged_cadence_samples_the_same_posterior():
         ra = a.numaccept.sum()/(a.nzchain*a.nchains)
         rb = b.numaccept.sum()/(b.nzchain*b.nchains)
         assert abs(ra - rb) < 0.05
+
+
+@pytest.mark.parametrize('sampler,thinning', [('demc', 1), ('snooker', 2), ('mrw', 1)])
+def test_worker_processes_equal_threads(sampler, thinning):
+    """oracle_lockstep.c ls_run_worker (bench.py's cpu_baseline "port-processes", SURVEY.md
+    8d(ii)): the run laid out as the reference's fan-out -- worker PROCESSES, worker i advancing
+    chains i, i + ncpu, ... (mc3/chain.py:163,190-191), one meeting per refresh in shared
+    memory -- equals the threaded run bit for bit, whatever the number of workers, also when
+    they do not divide the chains and across two calls."""
+    prob = H.quad_problem(nchains=13, nsamples=13*120*thinning, sampler=sampler,
+                          thinning=thinning)
+    ref = H.make_oracle(prob)
+    Z0, lp0 = H.initial_population(ref)
+    ref.set_population(Z0, lp0)
+    ref.run(nthreads=3)
+    for first, second in ((4, 3), (1, 13), (16, 2)):
+        orc = H.make_oracle(prob, shared=True)
+        orc.set_population(Z0, lp0)
+        assert orc.run_processes(50, first) > 0.0
+        orc.run_processes(orc.nzchain - 50, second)
+        for key in ('Z', 'log_post', 'zchain', 'numaccept', 'outbounds', 'X', 'chisq',
+                    'best_chisq', 'best_iter', 'bestx'):
+            np.testing.assert_array_equal(getattr(orc, key), getattr(ref, key), err_msg=key)
+    with pytest.raises(RuntimeError, match='shared=True'):
+        H.make_oracle(prob).run_processes(1, 2)
