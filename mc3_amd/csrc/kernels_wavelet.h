@@ -1430,7 +1430,367 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
     }
 }
 
-template <int MT, int SMP>
+// ---- ONE chain per workgroup (C4): the chain wave of the pipelined kernel, again -------------
+// pipe_chain_wave above serves any number of chains per workgroup and pays for it: the chains'
+// states wait in LDS, every turn's draws are read out of a Philox batch word by word, its row
+// addresses are 64-bit multiplications on one wave, the logarithm of its Metropolis draw is ~50
+// dependent FP64 instructions -- ~5 000 cycles of ONE wave per slot (tools/pipe_diag.py:
+// prepare 750, window 650, decide 1 500, issue 1 900), as long as level 0 of the compute waves
+// beside it, and every vector instruction of it is taken from the compute waves of its SIMD
+// (prio 3: the second compute wave of SIMD 0 needs 5 000 cycles for a level 0 that takes 3 600
+// alone).  With ONE chain per workgroup (256 chains on 256 CUs: BASELINE config C4) the turn is
+// the refresh and nothing of that is needed: this is the machinery of lean_snooker_body
+// (kernels_lean.h) in the pipeline's slots --
+//   * the state (xk, chisq, best, counters) lives in registers;
+//   * everything a turn needs of its draws is worked out for 21 turns at once, a (turn, slot) per
+//     lane: the offsets of its three history rows, the snooker-jump flag, gamma_s, the Metropolis
+//     draw AND the window of its logarithm (handoff.h accept_window) -- a turn reads its values
+//     out of the lanes (v_readlane), the logarithm has left the slot altogether;
+//   * the slot itself is the sequence of pipe_chain_wave -- ask for the next turn's rows; rows
+//     there? jump; wait for the tail's word; decide the turn before (row, books); squash and
+//     rewind after an accept; propose -- so the protocol with the ten other waves (orders and
+//     proposals by slot parity, the chisq word, the barriers) is unchanged.
+// Same draws, same arithmetic in the same order: bit-identical (tests/test_gpu_multichain.py,
+// the same cases as before).  Snooker without the support distribution (fepsilon = 0); the random
+// walk and fepsilon != 0 keep pipe_chain_wave.
+template <int SMP>
+__device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const int nref,
+                                                    double *np0, double *np1, int *s_cmd,
+                                                    const double *s_result, const int nhalo)
+{
+    static_assert(SMP == MC3HIP_SNOOKER, "the history rows of a turn are what is prepared ahead");
+    const int lane = threadIdx.x & 63;
+    const int b = (int)blockIdx.x;
+    const int c = P.chain0 + b;
+    double *Zr = own_global(P.Z), *log_post = own_global(P.log_post);
+    int32_t *zchain = own_global(P.zchain);
+    const int nchains = P.nchains, nparams = P.nparams, nf = P.nfree, zs = P.zs;
+    const long long M0 = P.M0;
+    const double gamma = P.gamma;
+    const bool mine = lane < nf;
+    const int kk = mine ? lane : 0;
+    const long long R0 = P.ctl[0];
+    long long *ctl_rw = const_cast<long long *>(P.ctl);
+    double xk;
+    {
+        const double *snap_first = (R0 == 0) ? own_global(P.snap0)
+                                             : Zr + (size_t)(M0 + (R0 - 1) * nchains) * zs;
+        xk = mine ? snap_first[(size_t)c * zs + lane] : 0.0;
+    }
+    double cur_c = P.chisq[b], best = P.best_chisq[b];
+    // (accepted turns of this launch as a 32-bit count, out-of-bounds trials 64-bit per lane:
+    // two 64-bit "+= " in two branches are sunk into ONE store through a pointer that is the
+    // one or the other -- and both counters then live in scratch)
+    int nacc = 0;
+    unsigned long long oob = 0;
+    const int jfree = mine ? P.ifree[lane] : 0;
+    const double pmin_k = mine ? P.fmin[lane] : 0.0;
+    const double pmax_k = mine ? P.fmax[lane] : 0.0;
+    const long long abort_at = (P.test_abort >= 0 && b == 0) ? (long long)P.test_abort : -1;
+    // the fixed parameters never change: written once (both buffers), the free ones every turn
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        double *np = h ? np1 : np0;
+        if (lane < nparams)
+            np[lane] = P.params[lane];
+        if (lane + 64 < nparams)
+            np[lane + 64] = P.params[lane + 64];
+    }
+    // ---- the draws of NB turns at once: lane 3 i + s = slot s of turn bbase + i ----------------
+    // A, B by slot: 0 -> the offsets (in doubles) of rows iR1, iR2; 1 -> the offset of row iz,
+    // the jump flag; 2 -> gamma_s, u (as bits); blo / bhi: the window of log u (slot 2's lanes)
+    constexpr int LPR = 3, NB = 21;
+    unsigned long long A = 0, B = 0;
+    double blo = 0.0, bhi = 0.0;
+    long long bbase = 0;                                // (in turns since this launch began)
+    const int bs = lane % LPR, bi = (lane / LPR < NB) ? lane / LPR : NB - 1;
+    auto fill = [&](long long n0) {                     // chain.py:195-205,259
+        const long long Rl = R0 + n0 + bi;
+        const Draw2 d = draw2(P.seed, (uint64_t)Rl, (uint32_t)c, (uint32_t)bs);
+        const unsigned long long zsz = (unsigned long long)(M0 + Rl * nchains);
+        if (bs == 0) {
+            const unsigned long long iR1 = bounded(d.q0, zsz);
+            unsigned long long iR2 = 1 + bounded(d.q1, zsz - 1);
+            if (iR2 == iR1)
+                iR2 = 0;
+            A = iR1 * (unsigned long long)zs;
+            B = iR2 * (unsigned long long)zs;
+        } else if (bs == 1) {
+            A = bounded(d.q1, zsz) * (unsigned long long)zs;
+            B = (u01(d.q0) < 0.1) ? 1ull : 0ull;
+        } else {
+            A = mc3_bits(1.2 + (2.2 - 1.2) * u01(d.q0));
+            B = mc3_bits(u01(d.q1));
+        }
+        accept_window(u01(d.q1), blo, bhi);             // (every lane: slot 2's keep theirs)
+        bbase = n0;
+    };
+    auto lane64 = [&](unsigned long long v, int l) {
+        return (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l) |
+               ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l)
+                << 32);
+    };
+    // (ONE place refills -- the top of a slot, below -- and it keeps the turn before in the
+    // batch: a squash rewinds by one turn at most)
+    auto in_batch = [&](long long n) { return LPR * (int)(n - bbase); };
+    double rv[3] = {};
+    // (the rows' addresses are formed again where a row is asked for again, not carried from
+    // slot to slot: an array of pointers that lives across the loop ends up in scratch)
+    auto row_addresses = [&](long long n, const double *(&ra)[3]) {
+        const int idx = in_batch(n);
+        ra[0] = Zr + (lane64(A, idx) + (unsigned)kk);
+        ra[1] = Zr + (lane64(B, idx) + (unsigned)kk);
+        ra[2] = Zr + (lane64(A, idx + 1) + (unsigned)kk);
+    };
+    auto request_rows = [&](long long n) {
+        const double *ra[3];
+        row_addresses(n, ra);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            rv[q] = load_published<false>(ra[q]);
+    };
+    // a turn on its way through the pipeline
+    struct Turn {
+        bool valid, go, sjump, outk, spec;
+        long long n;                                    // (its refresh: R0 + n)
+        double npk, zk, u, lo, hi;
+    };
+    Turn cur, pend, cand;                               // slot s, slot s - 1, slot s + 1
+    cur.valid = pend.valid = cand.valid = false;
+    long long tn = 0;                                   // the turn to issue next
+    bool more = nref > 0;
+    fill(0);
+    request_rows(tn);
+    double jump_ahead = 0.0;
+    bool jump_ready = false, rows_there = false, alive = true;
+
+    // What was asked for has arrived -- said HERE, before the decision's stores: loads and stores
+    // retire through one counter, and a wait behind the Z row's store waits for that store
+    // (~1 000 cycles).  The ordinary snooker jump (nine in ten) at once.
+    auto jump_early = [&]() {
+        jump_ready = false;
+        rows_there = false;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0)
+        asm volatile("; rows" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]));
+        if (more) {
+            const bool there2 = !__any(mc3_bits(rv[0]) == ROW_PENDING ||
+                                       mc3_bits(rv[1]) == ROW_PENDING);
+            rows_there = there2 && !__any(mc3_bits(rv[2]) == ROW_PENDING);
+            const int idx = in_batch(tn);
+            const bool sj = __builtin_amdgcn_readlane((int)(unsigned)B, idx + 1) != 0;
+            if (there2 && !sj) {
+                jump_ahead = gamma * (rv[0] - rv[1]) + P.fepsilon * 0.0;   // chain.py:217
+                jump_ready = true;
+            }
+        }
+    };
+    // the proposal of turn tn into `np`; the order for the slot it opens
+    auto try_issue = [&](double *np) -> int {
+        cand.valid = false;
+        if (!alive)
+            return CW_STOP;
+        if (!more)
+            return cur.valid ? CW_SKIP : CW_STOP;       // (the last turn's tail and decision)
+        // SPECULATE ON REJECT (pipe_chain_wave): the chain's previous turn is the one in flight
+        const bool spec = cur.valid && cur.go;
+        if (R0 + tn == abort_at) {                      // test hook
+            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            alive = false;
+            return CW_STOP;
+        }
+        const int idx = in_batch(tn);
+        double jump_k, zk = 0.0;
+        bool sjump = false;
+        if (jump_ready) {                               // chain.py:195-217
+            jump_k = jump_ahead;
+        } else {
+            sjump = __builtin_amdgcn_readlane((int)(unsigned)B, idx + 1) != 0;
+            if (!rows_there) {
+                if (cur.valid)
+                    return CW_SKIP;                     // (never wait with a turn in flight)
+                const double *ra[3];
+                row_addresses(tn, ra);
+                alive = wait_rows<3, false>(ra, rv, ctl_rw) && alive;
+                if (!alive)
+                    return CW_STOP;
+            }
+            const double z1 = rv[0], z2 = rv[1];
+            zk = rv[2];
+            if (sjump) {
+                const double gs = mc3_from_bits(lane64(A, idx + 2));
+                const bool same = __all(!mine || zk == xk);
+                if (same) {
+                    jump_k = gs * (z2 - z1);
+                } else {
+                    const double dz = xk - zk;
+                    const double zp1 = lane_serial_sum(z1 * dz, nf);
+                    const double zp2 = lane_serial_sum(z2 * dz, nf);
+                    const double dd = lane_serial_sum(dz * dz, nf);
+                    jump_k = ((gs * (zp1 - zp2)) * dz) / dd;
+                }
+            } else {
+                jump_k = gamma * (z1 - z2) + P.fepsilon * 0.0;
+            }
+        }
+        const double npk = xk + jump_k;                 // chain.py:235-243
+        const bool outk = mine && (npk < pmin_k || npk > pmax_k);
+        const bool anyout = __any(outk);
+        if (mine)
+            np[jfree] = npk;
+        cand.valid = true;
+        cand.spec = spec;
+        cand.n = tn;
+        cand.go = !anyout;
+        cand.sjump = sjump;
+        cand.outk = outk;
+        cand.npk = npk;
+        cand.zk = zk;
+        cand.u = mc3_from_bits(lane64(B, idx + 2));     // chain.py:259
+        cand.lo = read_lane(blo, idx + 2);
+        cand.hi = read_lane(bhi, idx + 2);
+        return anyout ? CW_SKIP : CW_GO;
+    };
+    // Metropolis, Z append and the books of a turn whose chisq is in s_result (the state the
+    // turn started from is still xk: had it changed, the turn would have been squashed)
+    auto decide = [&](const Turn &t) -> bool {
+        const double xold = xk;
+        bool accepted = false;
+        if (t.go) {
+            const double total = s_result[0];
+            // (as WaveletHook::finish: the prior term of a problem without priors is 0.0)
+            const double nextchisq = is_pos_inf(total) ? total : total + 0.0;
+            if (__builtin_expect(!t.sjump, 1)) {
+                accepted = metropolis_accept(0.5 * (cur_c - nextchisq), t.u, t.lo, t.hi);
+            } else {                                   // chain.py:251-255
+                const double dc = xold - t.zk, dn = t.npk - t.zk;
+                const double cnorm = lane_serial_sum(mine ? dc * dc : 0.0, nf);
+                const double nnorm = lane_serial_sum(mine ? dn * dn : 0.0, nf);
+                const double mrfactor = mc3_det_pow_half(nnorm / cnorm, nf - 1);
+                accepted = mc3_det_exp(0.5 * (cur_c - nextchisq)) * mrfactor > t.u;
+            }
+            if (accepted) {                            // chain.py:257-274
+                xk = t.npk;
+                cur_c = nextchisq;
+                nacc += 1;
+            }
+        } else {
+            oob += t.outk ? 1ull : 0ull;               // chain.py:242-243
+        }
+        const long long row = M0 + (R0 + t.n) * nchains + c;          // chain.py:276-289
+        if (mine)
+            __hip_atomic_store(&Zr[(size_t)row * zs + lane], xk, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);             // publish (sc1)
+        if (lane == 0) {
+            log_post[row] = -0.5 * cur_c;
+            zchain[row] = c;
+        }
+        if (__builtin_expect(accepted && cur_c < best, 0)) {
+            best = cur_c;
+            if (mine)
+                P.bestx[(size_t)b * nf + lane] = xk;
+            if (lane == 0)
+                P.best_iter[b] = R0 + t.n;
+        }
+        return accepted;
+    };
+
+    int par = 0, sn = 0;
+    PIPE_DIAG_DECL;
+    {
+        jump_early();
+        const int cmd0 = try_issue(np0);
+        if (lane == 0)
+            s_cmd[0] = cmd0;
+        cur = cand;
+    }
+    PIPE_SYNC(0);                                      // (A): the first proposal (or the order)
+    for (;;) {
+        // (the order is this wave's own: read back, it is uniform without a branch on `cur`)
+        const int cmd = __builtin_amdgcn_readfirstlane(s_cmd[par]);
+        if (cmd == CW_STOP)
+            break;
+        PIPE_PART(-1);
+        // the turn after the one in flight: its rows (a bubble: what was missing, again)
+        if (cur.valid) {
+            tn += 1;
+            more = tn < nref;
+            if (__builtin_expect(tn >= bbase + NB, 0))
+                fill(tn - 1);
+        }
+        if (more)
+            request_rows(tn);
+        PIPE_PART(0);
+        PIPE_PART(1);
+        jump_early();
+        if (pend.valid) {
+            if (pend.go) {
+                // the chisq: a word in LDS says so, long before the barrier does
+                while (__hip_atomic_load(&s_cmd[2], __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_WORKGROUP) != sn)
+                    __builtin_amdgcn_s_sleep(1);
+            }
+            PIPE_PART(2);
+            const bool accepted = decide(pend);
+            if (accepted && cur.valid && cur.spec) {
+                // the turn in flight started from a state that is no more: squashed, and what
+                // was prepared behind it rewound to it
+                cur.valid = false;
+                tn = cur.n;
+                more = true;
+                request_rows(tn);
+                jump_ready = false;
+                rows_there = false;
+            }
+        } else {
+            PIPE_PART(2);
+        }
+        PIPE_PART(3);
+        // the proposal for slot s + 1 (the other buffer: nobody reads it before (A))
+        const int cmd_next = try_issue(par ? np0 : np1);
+        PIPE_PART(4);
+        if (lane == 0)
+            s_cmd[par ^ 1] = cmd_next;
+        PIPE_SYNC(1);                                  // the halo barriers of stage A
+        PIPE_SYNC(2);
+        PIPE_SYNC(3);
+        if (nhalo > 3)
+            PIPE_SYNC(4);
+        PIPE_SYNC(5);                                  // (1) slot s
+        pend = cur;
+        cur = cand;
+        par ^= 1;
+        sn += 1;
+#ifdef MC3HIP_PIPE_DIAG
+        ++dg_n;
+#endif
+    }
+    PIPE_DIAG_PRINT("chain");
+#ifdef MC3HIP_PIPE_DIAG
+    if (blockIdx.x == 0 && lane == 0) {
+        printf("chain wave (one chain): prepare %llu window %llu wait %llu decide %llu issue %llu\n",
+               dg_part[0] / dg_n, dg_part[1] / dg_n, dg_part[2] / dg_n, dg_part[3] / dg_n,
+               dg_part[4] / dg_n);
+        printf("level 0 of waves 0..7: %llu %llu %llu %llu %llu %llu %llu %llu cycles (%llu likelihoods)\n",
+               mc3_pipe_diag[0] / mc3_pipe_diag[8], mc3_pipe_diag[1] / mc3_pipe_diag[8],
+               mc3_pipe_diag[2] / mc3_pipe_diag[8], mc3_pipe_diag[3] / mc3_pipe_diag[8],
+               mc3_pipe_diag[4] / mc3_pipe_diag[8], mc3_pipe_diag[5] / mc3_pipe_diag[8],
+               mc3_pipe_diag[6] / mc3_pipe_diag[8], mc3_pipe_diag[7] / mc3_pipe_diag[8],
+               mc3_pipe_diag[8]);
+    }
+#endif
+    if (mine && oob)
+        atomicAdd(&P.outbounds[lane], oob);
+    if (mine)
+        P.X[(size_t)b * nf + lane] = xk;
+    if (lane == 0) {
+        P.chisq[b] = cur_c;
+        P.best_chisq[b] = best;
+        P.numaccept[b] += (long long)nacc;
+    }
+}
+
+template <int MT, int SMP, bool ONE = false>
 __global__ __launch_bounds__(704) void wavelet_pipe_kernel(const DevProblem P, const int nref)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1457,8 +1817,11 @@ __global__ __launch_bounds__(704) void wavelet_pipe_kernel(const DevProblem P, c
     if (wave == 8 || wave == 9)
         __builtin_amdgcn_s_setprio(3);
     if (wave == 8) {
-        pipe_chain_wave<SMP>(P, nref, L.nextp, np1, L.tab, tab1, s_cmd, s_result, nhalo, M,
-                             smem + P.mc_off);
+        if constexpr (ONE)
+            pipe_chain_wave_one<SMP>(P, nref, L.nextp, np1, s_cmd, s_result, nhalo);
+        else
+            pipe_chain_wave<SMP>(P, nref, L.nextp, np1, L.tab, tab1, s_cmd, s_result, nhalo, M,
+                                 smem + P.mc_off);
         return;
     }
     if (wave == 10) {
