@@ -119,7 +119,7 @@ struct DevProblem {
     int32_t mc_chains, mc_off;
     // chain-wave wavelet kernel: the hand-structured chain wave serves this problem
     // (kernels_wavelet.h lean_chain_wave, host::cw_lean_eligible)
-    int32_t cw_lean;
+    int32_t cw_lean;              // (bit 0: the shape; bit 1: out-of-bounds turns ride)
     // resident tiled plans: the hand-structured owner serves this problem (resident.h
     // lean_resident_owner, host::rs_lean_eligible)
     int32_t rs_lean;
@@ -457,6 +457,15 @@ __device__ __forceinline__ double rows_sum(const double (&a)[T])
     t = add_ror<2>(t);
     t = add_ror<1>(t);
     return t;
+}
+
+// a double that is the same in every lane, in scalar registers from here on
+__device__ __forceinline__ double uniform_double(double v)
+{
+    const unsigned long long b = mc3_bits(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    return mc3_from_bits(((unsigned long long)hi << 32) | lo);
 }
 
 __device__ __forceinline__ double read_lane(double v, int k)

@@ -1502,9 +1502,9 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
     constexpr int LPR = 3, NB = 21;
     unsigned long long A = 0, B = 0;
     double blo = 0.0, bhi = 0.0;
-    long long bbase = 0;                                // (in turns since this launch began)
+    int bbase = 0;                                      // (in turns since this launch began)
     const int bs = lane % LPR, bi = (lane / LPR < NB) ? lane / LPR : NB - 1;
-    auto fill = [&](long long n0) {                     // chain.py:195-205,259
+    auto fill = [&](int n0) {                           // chain.py:195-205,259
         const long long Rl = R0 + n0 + bi;
         const Draw2 d = draw2(P.seed, (uint64_t)Rl, (uint32_t)c, (uint32_t)bs);
         const unsigned long long zsz = (unsigned long long)(M0 + Rl * nchains);
@@ -1532,37 +1532,65 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
     };
     // (ONE place refills -- the top of a slot, below -- and it keeps the turn before in the
     // batch: a squash rewinds by one turn at most)
-    auto in_batch = [&](long long n) { return LPR * (int)(n - bbase); };
-    double rv[3] = {};
+    auto in_batch = [&](int n) { return LPR * (n - bbase); };
+    double rv[3] = {}, rw[3] = {};                     // the rows of turn tn, of turn tn + 1
     // (the rows' addresses are formed again where a row is asked for again, not carried from
     // slot to slot: an array of pointers that lives across the loop ends up in scratch)
-    auto row_addresses = [&](long long n, const double *(&ra)[3]) {
+    auto row_addresses = [&](int n, const double *(&ra)[3]) {
         const int idx = in_batch(n);
         ra[0] = Zr + (lane64(A, idx) + (unsigned)kk);
         ra[1] = Zr + (lane64(B, idx) + (unsigned)kk);
         ra[2] = Zr + (lane64(A, idx + 1) + (unsigned)kk);
     };
-    auto request_rows = [&](long long n) {
+    // the rows of turn n AND of the turn behind it (RIDE, below: should turn n's proposal be out
+    // of bounds, the next turn is proposed in the same slot -- its rows must be under way)
+    auto request_rows = [&](int n, bool second) {
         const double *ra[3];
         row_addresses(n, ra);
 #pragma unroll
         for (int q = 0; q < 3; ++q)
             rv[q] = load_published<false>(ra[q]);
+        if (second) {
+            row_addresses(n + 1, ra);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                rw[q] = load_published<false>(ra[q]);
+        }
     };
     // a turn on its way through the pipeline
+    // RIDE: a proposal out of bounds is a reject whatever its likelihood would have been
+    // (chain.py:239-243), and pipe_chain_wave gives it a slot of its own all the same -- the
+    // compute waves idle through it while this wave decides and proposes (C4: 29 % of the turns).
+    // Here such a turn RIDES with the one behind it: the next turn is proposed at once, from the
+    // same state, into the same slot; the rider's Z row and out-of-bounds count are written when
+    // the turn BEFORE it has been decided (rejected: the state the rider started from stands;
+    // accepted: rider and turn are squashed and proposed again) -- `rider` / `router` of the turn
+    // it rides with.  One rider per turn; a second proposal out of bounds takes a slot as ever.
+    // (what is the same in every lane as BITS of one word -- a flag of its own is a lane mask,
+    // two scalar registers, and three turns of seven flags plus their Metropolis draws and
+    // windows were ~60 scalar registers on top of the launch arguments: spilled to vector lanes,
+    // every use a v_readlane.  The draw and its window are read out of the batch again when the
+    // turn is decided: it keeps the last three turns for that.)
     struct Turn {
-        bool valid, go, sjump, outk, spec;
-        long long n;                                    // (its refresh: R0 + n)
-        double npk, zk, u, lo, hi;
+        int f;                                          // T_VALID | T_GO | ...
+        int n;                                          // (its refresh: R0 + n)
+        int lb;                                         // per lane: bit 0 outk, bit 1 router
+        double npk, zk;
     };
+    constexpr int T_VALID = 1, T_GO = 2, T_SJUMP = 4, T_SPEC = 8, T_RIDER = 16;
     Turn cur, pend, cand;                               // slot s, slot s - 1, slot s + 1
-    cur.valid = pend.valid = cand.valid = false;
-    long long tn = 0;                                   // the turn to issue next
+    cur.f = pend.f = cand.f = 0;
+    cur.n = pend.n = cand.n = 0;
+    cur.lb = pend.lb = cand.lb = 0;
+    cur.npk = pend.npk = cand.npk = 0.0;
+    cur.zk = pend.zk = cand.zk = 0.0;
+    int tn = 0;                                         // the turn to issue next
     bool more = nref > 0;
+    const bool ride_on = (P.cw_lean & 2) != 0 && nref > 1;
     fill(0);
-    request_rows(tn);
-    double jump_ahead = 0.0;
-    bool jump_ready = false, rows_there = false, alive = true;
+    request_rows(tn, ride_on);
+    double jump_ahead = 0.0, jump_second = 0.0;
+    bool jump_ready = false, rows_there = false, second_ready = false, alive = true;
 
     // What was asked for has arrived -- said HERE, before the decision's stores: loads and stores
     // retire through one counter, and a wait behind the Z row's store waits for that store
@@ -1570,8 +1598,10 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
     auto jump_early = [&]() {
         jump_ready = false;
         rows_there = false;
+        second_ready = false;
         __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0)
         asm volatile("; rows" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]));
+        asm volatile("; rows" : "+v"(rw[0]), "+v"(rw[1]), "+v"(rw[2]));
         if (more) {
             const bool there2 = !__any(mc3_bits(rv[0]) == ROW_PENDING ||
                                        mc3_bits(rv[1]) == ROW_PENDING);
@@ -1582,17 +1612,27 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
                 jump_ahead = gamma * (rv[0] - rv[1]) + P.fepsilon * 0.0;   // chain.py:217
                 jump_ready = true;
             }
+            // the turn behind it, should it ride: an ordinary jump whose two rows are there
+            if (ride_on && tn + 1 < nref) {
+                const bool sj2 = __builtin_amdgcn_readlane((int)(unsigned)B, idx + LPR + 1) != 0;
+                const bool there_w = !__any(mc3_bits(rw[0]) == ROW_PENDING ||
+                                            mc3_bits(rw[1]) == ROW_PENDING);
+                if (there_w && !sj2) {
+                    jump_second = gamma * (rw[0] - rw[1]) + P.fepsilon * 0.0;
+                    second_ready = true;
+                }
+            }
         }
     };
     // the proposal of turn tn into `np`; the order for the slot it opens
     auto try_issue = [&](double *np) -> int {
-        cand.valid = false;
+        cand.f = 0;
         if (!alive)
             return CW_STOP;
         if (!more)
-            return cur.valid ? CW_SKIP : CW_STOP;       // (the last turn's tail and decision)
+            return (cur.f & T_VALID) ? CW_SKIP : CW_STOP;   // (the last turn's tail and decision)
         // SPECULATE ON REJECT (pipe_chain_wave): the chain's previous turn is the one in flight
-        const bool spec = cur.valid && cur.go;
+        const bool spec = (cur.f & (T_VALID | T_GO)) == (T_VALID | T_GO);
         if (R0 + tn == abort_at) {                      // test hook
             __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -1607,7 +1647,7 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
         } else {
             sjump = __builtin_amdgcn_readlane((int)(unsigned)B, idx + 1) != 0;
             if (!rows_there) {
-                if (cur.valid)
+                if (cur.f & T_VALID)
                     return CW_SKIP;                     // (never wait with a turn in flight)
                 const double *ra[3];
                 row_addresses(tn, ra);
@@ -1633,41 +1673,67 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
                 jump_k = gamma * (z1 - z2) + P.fepsilon * 0.0;
             }
         }
-        const double npk = xk + jump_k;                 // chain.py:235-243
-        const bool outk = mine && (npk < pmin_k || npk > pmax_k);
-        const bool anyout = __any(outk);
+        double npk = xk + jump_k;                       // chain.py:235-243
+        bool outk = mine && (npk < pmin_k || npk > pmax_k);
+        bool anyout = __any(outk);
+        int f = T_VALID | (spec ? T_SPEC : 0), lb = 0;
+        cand.n = tn;
+        if (anyout && second_ready && R0 + tn + 1 != abort_at) {
+            // RIDE: turn tn is rejected by the bounds; turn tn + 1 starts from the same state
+            f |= T_RIDER;
+            lb = outk ? 2 : 0;
+            cand.n = tn + 1;
+            sjump = false;
+            zk = 0.0;
+            npk = xk + jump_second;
+            outk = mine && (npk < pmin_k || npk > pmax_k);
+            anyout = __any(outk);
+        }
         if (mine)
             np[jfree] = npk;
-        cand.valid = true;
-        cand.spec = spec;
-        cand.n = tn;
-        cand.go = !anyout;
-        cand.sjump = sjump;
-        cand.outk = outk;
+        cand.f = f | (anyout ? 0 : T_GO) | (sjump ? T_SJUMP : 0);
+        cand.lb = lb | (outk ? 1 : 0);
         cand.npk = npk;
         cand.zk = zk;
-        cand.u = mc3_from_bits(lane64(B, idx + 2));     // chain.py:259
-        cand.lo = read_lane(blo, idx + 2);
-        cand.hi = read_lane(bhi, idx + 2);
         return anyout ? CW_SKIP : CW_GO;
+    };
+    // the Z row and the books of the turn that rides with `t` -- rejected by the bounds, the
+    // state it started from stands (chain.py:239-243,276-289)
+    auto settle_rider = [&](const Turn &t) {
+        oob += (t.lb & 2) ? 1ull : 0ull;
+        const long long row = M0 + (R0 + t.n - 1) * nchains + c;
+        if (mine)
+            __hip_atomic_store(&Zr[(size_t)row * zs + lane], xk, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);             // publish (sc1)
+        if (lane == 0) {
+            log_post[row] = -0.5 * cur_c;
+            zchain[row] = c;
+        }
     };
     // Metropolis, Z append and the books of a turn whose chisq is in s_result (the state the
     // turn started from is still xk: had it changed, the turn would have been squashed)
     auto decide = [&](const Turn &t) -> bool {
         const double xold = xk;
         bool accepted = false;
-        if (t.go) {
-            const double total = s_result[0];
+        if (t.f & T_GO) {
+            // (the same word in every lane -- SAID so: a value read from LDS is a per-lane value
+            // to the compiler, the Metropolis test on it a per-lane branch, and everything the
+            // squash behind it assigns would be kept per lane from then on)
+            const double total = uniform_double(s_result[0]);
             // (as WaveletHook::finish: the prior term of a problem without priors is 0.0)
             const double nextchisq = is_pos_inf(total) ? total : total + 0.0;
-            if (__builtin_expect(!t.sjump, 1)) {
-                accepted = metropolis_accept(0.5 * (cur_c - nextchisq), t.u, t.lo, t.hi);
+            // the turn's Metropolis draw and the window of its logarithm: still in the batch
+            const int at = in_batch(t.n) + 2;
+            const double u = mc3_from_bits(lane64(B, at));            // chain.py:259
+            if (__builtin_expect(!(t.f & T_SJUMP), 1)) {
+                accepted = metropolis_accept(0.5 * (cur_c - nextchisq), u, read_lane(blo, at),
+                                             read_lane(bhi, at));
             } else {                                   // chain.py:251-255
                 const double dc = xold - t.zk, dn = t.npk - t.zk;
                 const double cnorm = lane_serial_sum(mine ? dc * dc : 0.0, nf);
                 const double nnorm = lane_serial_sum(mine ? dn * dn : 0.0, nf);
                 const double mrfactor = mc3_det_pow_half(nnorm / cnorm, nf - 1);
-                accepted = mc3_det_exp(0.5 * (cur_c - nextchisq)) * mrfactor > t.u;
+                accepted = mc3_det_exp(0.5 * (cur_c - nextchisq)) * mrfactor > u;
             }
             if (accepted) {                            // chain.py:257-274
                 xk = t.npk;
@@ -1675,7 +1741,7 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
                 nacc += 1;
             }
         } else {
-            oob += t.outk ? 1ull : 0ull;               // chain.py:242-243
+            oob += (t.lb & 1) ? 1ull : 0ull;           // chain.py:242-243
         }
         const long long row = M0 + (R0 + t.n) * nchains + c;          // chain.py:276-289
         if (mine)
@@ -1710,47 +1776,90 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
         const int cmd = __builtin_amdgcn_readfirstlane(s_cmd[par]);
         if (cmd == CW_STOP)
             break;
+        // The control state of the pipeline is the same in every lane -- SAID so once per slot:
+        // left to itself the compiler keeps the turn counter in vector registers and the turns'
+        // flags as lane masks (every `if` a save / restore of EXEC, every batch index a
+        // v_readfirstlane in front of its v_readlane).
+        {
+            auto ub = [](bool v) { return __builtin_amdgcn_readfirstlane(v ? 1 : 0) != 0; };
+            tn = __builtin_amdgcn_readfirstlane(tn);
+            bbase = __builtin_amdgcn_readfirstlane(bbase);
+            more = ub(more);
+            alive = ub(alive);
+            cur.f = __builtin_amdgcn_readfirstlane(cur.f);
+            cur.n = __builtin_amdgcn_readfirstlane(cur.n);
+            pend.f = __builtin_amdgcn_readfirstlane(pend.f);
+            pend.n = __builtin_amdgcn_readfirstlane(pend.n);
+            cur_c = uniform_double(cur_c);
+            best = uniform_double(best);
+        }
         PIPE_PART(-1);
         // the turn after the one in flight: its rows (a bubble: what was missing, again)
-        if (cur.valid) {
-            tn += 1;
+        if (cur.f & T_VALID) {
+            tn = cur.n + 1;
             more = tn < nref;
-            if (__builtin_expect(tn >= bbase + NB, 0))
-                fill(tn - 1);
+            // (the batch holds turns tn - 3 .. tn + 1: the turn about to be decided -- the one
+            // before the one in flight and its rider -- reads its Metropolis draw there, a
+            // squash rewinds by two at most, a rider looks one turn ahead)
+            if (__builtin_expect(tn + 1 >= bbase + NB, 0))
+                fill(tn >= 3 ? tn - 3 : 0);
         }
         if (more)
-            request_rows(tn);
+            request_rows(tn, ride_on && tn + 1 < nref);
         PIPE_PART(0);
-        PIPE_PART(1);
         jump_early();
-        if (pend.valid) {
-            if (pend.go) {
+        // THE PROPOSAL FIRST, as if the turn about to be decided were rejected (85 in 100 are):
+        // the tail wave needs ~2 000 cycles of the slot for that turn's chisq, and this wave
+        // used to idle through most of them and then decide AND propose behind it -- the
+        // slot's longest dependent path.  Formed here the proposal costs nothing on that path;
+        // after an accept it is formed again from the new state (as the turn in flight is).
+        // Never where forming it could wait for rows: the turn to be decided is still in flight.
+        const int buf = par ^ 1;
+        bool formed = false;
+        int cmd_next = CW_SKIP;
+        if (alive && more && (jump_ready || rows_there) && R0 + tn != abort_at) {
+            cmd_next = try_issue(buf ? np1 : np0);
+            formed = true;
+        }
+        PIPE_PART(1);
+        if (pend.f & T_VALID) {
+            if (pend.f & T_GO) {
                 // the chisq: a word in LDS says so, long before the barrier does
-                while (__hip_atomic_load(&s_cmd[2], __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_WORKGROUP) != sn)
+                // (the word is the same in every lane, and said so: a per-lane exit of this
+                // loop is a per-lane exit in the compiler's eyes)
+                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(
+                           &s_cmd[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != sn)
                     __builtin_amdgcn_s_sleep(1);
             }
             PIPE_PART(2);
             const bool accepted = decide(pend);
-            if (accepted && cur.valid && cur.spec) {
-                // the turn in flight started from a state that is no more: squashed, and what
-                // was prepared behind it rewound to it
-                cur.valid = false;
-                tn = cur.n;
+            if (accepted && (cur.f & (T_VALID | T_SPEC)) == (T_VALID | T_SPEC)) {
+                // the turn in flight (and its rider) started from a state that is no more:
+                // squashed, and what was prepared behind it rewound to it
+                tn = cur.n - ((cur.f & T_RIDER) ? 1 : 0);
+                cur.f = 0;
                 more = true;
-                request_rows(tn);
+                request_rows(tn, ride_on && tn + 1 < nref);
                 jump_ready = false;
                 rows_there = false;
+                second_ready = false;
             }
+            if (accepted)
+                formed = false;                         // (the state has changed: again)
         } else {
             PIPE_PART(2);
         }
+        // the turn before the one in flight is settled: so is the rider between them
+        if ((cur.f & (T_VALID | T_RIDER)) == (T_VALID | T_RIDER))
+            settle_rider(cur);
         PIPE_PART(3);
-        // the proposal for slot s + 1 (the other buffer: nobody reads it before (A))
-        const int cmd_next = try_issue(par ? np0 : np1);
+        // the proposal for slot s + 1 (the other buffer: nobody reads it before (A)), unless it
+        // stands already
+        if (!formed)
+            cmd_next = try_issue(buf ? np1 : np0);
         PIPE_PART(4);
         if (lane == 0)
-            s_cmd[par ^ 1] = cmd_next;
+            s_cmd[buf] = cmd_next;
         PIPE_SYNC(1);                                  // the halo barriers of stage A
         PIPE_SYNC(2);
         PIPE_SYNC(3);
@@ -1814,8 +1923,18 @@ __global__ __launch_bounds__(704) void wavelet_pipe_kernel(const DevProblem P, c
     const int M = ilog2(P.ndata);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // (the chain wave and the tail wave are what a slot waits for; the noise wave has time)
-    if (wave == 8 || wave == 9)
-        __builtin_amdgcn_s_setprio(3);
+    // (MC3HIP_CW_PRIO / MC3HIP_TAIL_PRIO: tools/variant_lib.py builds the library with other
+    // priorities for the two -- measurements only)
+#ifndef MC3HIP_CW_PRIO
+#define MC3HIP_CW_PRIO 3
+#endif
+#ifndef MC3HIP_TAIL_PRIO
+#define MC3HIP_TAIL_PRIO 3
+#endif
+    if (wave == 8)
+        __builtin_amdgcn_s_setprio(MC3HIP_CW_PRIO);
+    if (wave == 9)
+        __builtin_amdgcn_s_setprio(MC3HIP_TAIL_PRIO);
     if (wave == 8) {
         if constexpr (ONE)
             pipe_chain_wave_one<SMP>(P, nref, L.nextp, np1, s_cmd, s_result, nhalo);

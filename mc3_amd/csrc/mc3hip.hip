@@ -460,7 +460,11 @@ int decide_persist(mc3hip_ctx *c)
     c->chainwave = c->P.wlike && c->wpc == 8 && !c->P.wl_scratch &&
                    !(c->flags & MC3HIP_FLAG_P2P) &&
                    c->smem + CW_EXTRA_DOUBLES * sizeof(double) <= 160 * 1024;
-    c->P.cw_lean = (c->chainwave && cw_lean_eligible(c) && !getenv("MC3HIP_NO_CW_LEAN")) ? 1 : 0;
+    // (bit 1: an out-of-bounds proposal rides with the turn behind it, kernels_wavelet.h
+    // pipe_chain_wave_one; MC3HIP_NO_CW_RIDE gives it a slot of its own as before)
+    c->P.cw_lean = (c->chainwave && cw_lean_eligible(c) && !getenv("MC3HIP_NO_CW_LEAN"))
+                       ? (getenv("MC3HIP_NO_CW_RIDE") ? 1 : 3)
+                       : 0;
     // Helper waves for the hand-laid-out DEMC loop (lean_demc_wide_kernel) are NOT the
     // default: measured on MI355X (tools/lean_waves.py, profiles/r03_lean_waves.jsonl) two /
     // four waves per chain run C2 at 203 / 207 M chain-steps/s against 219 for one -- the two

@@ -314,7 +314,7 @@ def test_lean_snooker_and_mrw_loops_with_several_chains_per_wave(eng, monkeypatc
         gpu.close()
 
 
-@pytest.mark.parametrize('case', ['plain', 'tight', 'wide', 'abort', 'resume', 'nospec'])
+@pytest.mark.parametrize('case', ['plain', 'tight', 'wide', 'abort', 'resume', 'nospec', 'noone'])
 @pytest.mark.parametrize('ndata,sampler', [(8192, 'snooker'), (16384, 'mrw'), (16384, 'snooker')])
 def test_wavelet_one_chain_per_workgroup_speculates_on_reject(eng, monkeypatch, ndata, sampler, case):
     """One chain per workgroup on the pipelined kernel: the next proposal is issued while the one
@@ -322,7 +322,9 @@ def test_wavelet_one_chain_per_workgroup_speculates_on_reject(eng, monkeypatch, 
     again from the new state.  Nothing of a squashed proposal may show: same rows, same counters
     (accepts, out-of-bounds), same best fit as the checker -- with bounds that reject a third of
     the proposals before the likelihood, with none, across launches, through a give-up, and behind
-    the switch (the nine-wave kernel: one proposal at a time)."""
+    the switches (the nine-wave kernel: one proposal at a time; the general chain wave of the
+    pipeline).  150 refreshes: the batch of draws (21 turns) is refilled seven times, squashes
+    rewind across refills."""
     prob = H.wavelet_problem(ndata=ndata, nchains=6, nsamples=6*150, sampler=sampler)
     if case == 'tight':
         prob.update(pmin=np.array([2.6, -2.6, 0.47, 0.0, 0.3, 0.8]),
@@ -331,6 +333,11 @@ def test_wavelet_one_chain_per_workgroup_speculates_on_reject(eng, monkeypatch, 
         prob.update(pmin=np.full(6, -1e3), pmax=np.full(6, 1e3))
     if case == 'nospec':
         monkeypatch.setenv('MC3HIP_NO_CW_SPEC', '1')
+    if case == 'noone':
+        # (snooker: the chain wave that serves any number of chains per workgroup instead of
+        # the one with its state in registers and its draws a batch ahead, pipe_chain_wave_one
+        # -- which every other snooker case here runs)
+        monkeypatch.setenv('MC3HIP_NO_CW_ONE', '1')
     if case == 'abort':
         monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '40')
     if case == 'resume':
