@@ -1436,23 +1436,38 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
 // addresses are 64-bit multiplications on one wave, the logarithm of its Metropolis draw is ~50
 // dependent FP64 instructions -- ~5 000 cycles of ONE wave per slot (tools/pipe_diag.py:
 // prepare 750, window 650, decide 1 500, issue 1 900), as long as level 0 of the compute waves
-// beside it, and every vector instruction of it is taken from the compute waves of its SIMD
-// (prio 3: the second compute wave of SIMD 0 needs 5 000 cycles for a level 0 that takes 3 600
-// alone).  With ONE chain per workgroup (256 chains on 256 CUs: BASELINE config C4) the turn is
-// the refresh and nothing of that is needed: this is the machinery of lean_snooker_body
+// beside it, and every vector instruction of it is taken from the compute waves of its SIMD.
+// With ONE chain per workgroup (256 chains on 256 CUs: BASELINE config C4) the turn is the
+// refresh and nothing of that is needed: this is the machinery of lean_snooker_body
 // (kernels_lean.h) in the pipeline's slots --
-//   * the state (xk, chisq, best, counters) lives in registers;
+//   * the state (xk, chisq, best, counters) lives in registers, what is the same in every lane
+//     in SCALAR registers (said so once per slot), a turn's flags as bits of one word;
 //   * everything a turn needs of its draws is worked out for 21 turns at once, a (turn, slot) per
 //     lane: the offsets of its three history rows, the snooker-jump flag, gamma_s, the Metropolis
 //     draw AND the window of its logarithm (handoff.h accept_window) -- a turn reads its values
 //     out of the lanes (v_readlane), the logarithm has left the slot altogether;
-//   * the slot itself is the sequence of pipe_chain_wave -- ask for the next turn's rows; rows
-//     there? jump; wait for the tail's word; decide the turn before (row, books); squash and
-//     rewind after an accept; propose -- so the protocol with the ten other waves (orders and
-//     proposals by slot parity, the chisq word, the barriers) is unchanged.
+//   * HISTORY ROWS THREE TURNS AHEAD.  A row is a random line of gigabytes of Z: ~1 200 cycles
+//     from the request to the value, and pipe_chain_wave pays them every slot (asks at the top,
+//     waits before the jump) and again after every squash.  Here the rows of turns T, T + 1 and
+//     T + 2 are held (rv, rw, rx); a slot ENDS by asking for what the next one will lack -- one
+//     turn's rows in the steady state -- so they travel through the barriers, and the rows the
+//     turn in flight was proposed from are kept (cs_v, cs_w): a squash proposes again from
+//     registers.  A row that was not written yet when it was asked for (the sentinel) is asked
+//     for again where it is needed, as ever;
+//   * RIDE: a proposal out of bounds is a reject whatever its likelihood would have been
+//     (chain.py:239-243), and pipe_chain_wave gives it a slot of its own all the same -- the
+//     compute waves idle through it (C4: 29 % of the turns).  Here such a turn rides with the one
+//     behind it: the next turn is proposed at once, from the same state, into the same slot; the
+//     rider's Z row and out-of-bounds count are written when the turn BEFORE it has been
+//     decided (rejected: the state the rider started from stands; accepted: rider and turn are
+//     squashed and proposed again).  One rider per turn;
+//   * THE PROPOSAL BEFORE THE DECISION, as if the turn about to be decided were rejected (85 in
+//     100 are): formed while the tail wave works, again after an accept;
+//   * the protocol with the ten other waves (orders and proposals by slot parity, the chisq
+//     word, the barriers) is pipe_chain_wave's.
 // Same draws, same arithmetic in the same order: bit-identical (tests/test_gpu_multichain.py,
 // the same cases as before).  Snooker without the support distribution (fepsilon = 0); the random
-// walk and fepsilon != 0 keep pipe_chain_wave.
+// walk and fepsilon != 0 keep pipe_chain_wave.  MC3HIP_NO_CW_ONE, MC3HIP_NO_CW_RIDE: the switches.
 template <int SMP>
 __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const int nref,
                                                     double *np0, double *np1, int *s_cmd,
@@ -1530,10 +1545,15 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
                ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l)
                 << 32);
     };
-    // (ONE place refills -- the top of a slot, below -- and it keeps the turn before in the
-    // batch: a squash rewinds by one turn at most)
+    // (ONE place refills -- the top of a slot, below -- and it keeps the last three turns in the
+    // batch: the turn about to be decided reads its Metropolis draw there, a squash rewinds by two)
     auto in_batch = [&](int n) { return LPR * (n - bbase); };
-    double rv[3] = {}, rw[3] = {};                     // the rows of turn tn, of turn tn + 1
+    // the history rows of turns tv, tv + 1, tv + 2; `have`: bit k = set k has been asked for
+    double rv[3] = {}, rw[3] = {}, rx[3] = {};
+    int tv = 0, have = 0;
+    // ... and those the turn in flight was proposed from (its first turn's and the next one's)
+    double cs_v[3] = {}, cs_w[3] = {};
+    int cs_t = 0, cs_have = 0;
     // (the rows' addresses are formed again where a row is asked for again, not carried from
     // slot to slot: an array of pointers that lives across the loop ends up in scratch)
     auto row_addresses = [&](int n, const double *(&ra)[3]) {
@@ -1542,35 +1562,18 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
         ra[1] = Zr + (lane64(B, idx) + (unsigned)kk);
         ra[2] = Zr + (lane64(A, idx + 1) + (unsigned)kk);
     };
-    // the rows of turn n AND of the turn behind it (RIDE, below: should turn n's proposal be out
-    // of bounds, the next turn is proposed in the same slot -- its rows must be under way)
-    auto request_rows = [&](int n, bool second) {
+    auto request = [&](int n, double (&r)[3]) {
         const double *ra[3];
         row_addresses(n, ra);
 #pragma unroll
         for (int q = 0; q < 3; ++q)
-            rv[q] = load_published<false>(ra[q]);
-        if (second) {
-            row_addresses(n + 1, ra);
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                rw[q] = load_published<false>(ra[q]);
-        }
+            r[q] = load_published<false>(ra[q]);
     };
-    // a turn on its way through the pipeline
-    // RIDE: a proposal out of bounds is a reject whatever its likelihood would have been
-    // (chain.py:239-243), and pipe_chain_wave gives it a slot of its own all the same -- the
-    // compute waves idle through it while this wave decides and proposes (C4: 29 % of the turns).
-    // Here such a turn RIDES with the one behind it: the next turn is proposed at once, from the
-    // same state, into the same slot; the rider's Z row and out-of-bounds count are written when
-    // the turn BEFORE it has been decided (rejected: the state the rider started from stands;
-    // accepted: rider and turn are squashed and proposed again) -- `rider` / `router` of the turn
-    // it rides with.  One rider per turn; a second proposal out of bounds takes a slot as ever.
     // (what is the same in every lane as BITS of one word -- a flag of its own is a lane mask,
     // two scalar registers, and three turns of seven flags plus their Metropolis draws and
     // windows were ~60 scalar registers on top of the launch arguments: spilled to vector lanes,
     // every use a v_readlane.  The draw and its window are read out of the batch again when the
-    // turn is decided: it keeps the last three turns for that.)
+    // turn is decided.)
     struct Turn {
         int f;                                          // T_VALID | T_GO | ...
         int n;                                          // (its refresh: R0 + n)
@@ -1587,14 +1590,13 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
     int tn = 0;                                         // the turn to issue next
     bool more = nref > 0;
     const bool ride_on = (P.cw_lean & 2) != 0 && nref > 1;
-    fill(0);
-    request_rows(tn, ride_on);
     double jump_ahead = 0.0, jump_second = 0.0;
     bool jump_ready = false, rows_there = false, second_ready = false, alive = true;
 
-    // What was asked for has arrived -- said HERE, before the decision's stores: loads and stores
-    // retire through one counter, and a wait behind the Z row's store waits for that store
-    // (~1 000 cycles).  The ordinary snooker jump (nine in ten) at once.
+    // What is held of turn tn's rows (and of the next turn's, should this one ride) -- looked
+    // at BEFORE the decision's stores: loads and stores retire through one counter, and a wait
+    // behind the Z row's store waits for that store (~1 000 cycles).  The ordinary snooker jump
+    // (nine in ten) at once.  tv == tn here.
     auto jump_early = [&]() {
         jump_ready = false;
         rows_there = false;
@@ -1602,7 +1604,8 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
         __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0)
         asm volatile("; rows" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]));
         asm volatile("; rows" : "+v"(rw[0]), "+v"(rw[1]), "+v"(rw[2]));
-        if (more) {
+        asm volatile("; rows" : "+v"(rx[0]), "+v"(rx[1]), "+v"(rx[2]));
+        if (more && (have & 1)) {
             const bool there2 = !__any(mc3_bits(rv[0]) == ROW_PENDING ||
                                        mc3_bits(rv[1]) == ROW_PENDING);
             rows_there = there2 && !__any(mc3_bits(rv[2]) == ROW_PENDING);
@@ -1613,7 +1616,7 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
                 jump_ready = true;
             }
             // the turn behind it, should it ride: an ordinary jump whose two rows are there
-            if (ride_on && tn + 1 < nref) {
+            if (ride_on && (have & 2) && tn + 1 < nref) {
                 const bool sj2 = __builtin_amdgcn_readlane((int)(unsigned)B, idx + LPR + 1) != 0;
                 const bool there_w = !__any(mc3_bits(rw[0]) == ROW_PENDING ||
                                             mc3_bits(rw[1]) == ROW_PENDING);
@@ -1651,6 +1654,12 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
                     return CW_SKIP;                     // (never wait with a turn in flight)
                 const double *ra[3];
                 row_addresses(tn, ra);
+                if (!(have & 1)) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        rv[q] = load_published<false>(ra[q]);
+                    have |= 1;
+                }
                 alive = wait_rows<3, false>(ra, rv, ctl_rw) && alive;
                 if (!alive)
                     return CW_STOP;
@@ -1760,14 +1769,68 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
         }
         return accepted;
     };
+    // The end of a slot's work: the rows the NEXT slot proposes from.  Its turn is the one behind
+    // `cand` (or this one again: a bubble); what is held of it moves up, what is not is asked for
+    // now -- and travels through the barriers.  Before that, the rows `cand` was proposed from are
+    // put aside: should it be squashed, it is proposed again from them.
+    auto rows_ahead = [&]() {
+        const int t_next = (cand.f & T_VALID) ? cand.n + 1 : tn;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            cs_v[q] = rv[q];
+            cs_w[q] = rw[q];
+        }
+        cs_t = tv;
+        cs_have = have & 3;
+        const int d = t_next - tv;
+        if (d == 1) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                rv[q] = rw[q];
+                rw[q] = rx[q];
+            }
+            have >>= 1;
+        } else if (d == 2) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                rv[q] = rx[q];
+            have >>= 2;
+        } else if (d == 0) {
+            // (a bubble: rows of this turn were not there -- asked for again)
+            if (!rows_there)
+                have &= ~1;
+        } else {
+            have = 0;
+        }
+        tv = t_next;
+        if (!(have & 1) && tv < nref)
+            request(tv, rv);
+        if (!(have & 2) && tv + 1 < nref)
+            request(tv + 1, rw);
+        if (!(have & 4) && tv + 2 < nref)
+            request(tv + 2, rx);
+        have = (tv < nref ? 1 : 0) | (tv + 1 < nref ? 2 : 0) | (tv + 2 < nref ? 4 : 0);
+    };
 
     int par = 0, sn = 0;
     PIPE_DIAG_DECL;
+    fill(0);
     {
+        request(0, rv);
+        have = 1;
+        if (nref > 1) {
+            request(1, rw);
+            have |= 2;
+        }
+        if (nref > 2) {
+            request(2, rx);
+            have |= 4;
+        }
         jump_early();
         const int cmd0 = try_issue(np0);
         if (lane == 0)
             s_cmd[0] = cmd0;
+        rows_ahead();
         cur = cand;
     }
     PIPE_SYNC(0);                                      // (A): the first proposal (or the order)
@@ -1783,6 +1846,10 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
         {
             auto ub = [](bool v) { return __builtin_amdgcn_readfirstlane(v ? 1 : 0) != 0; };
             tn = __builtin_amdgcn_readfirstlane(tn);
+            tv = __builtin_amdgcn_readfirstlane(tv);
+            have = __builtin_amdgcn_readfirstlane(have);
+            cs_t = __builtin_amdgcn_readfirstlane(cs_t);
+            cs_have = __builtin_amdgcn_readfirstlane(cs_have);
             bbase = __builtin_amdgcn_readfirstlane(bbase);
             more = ub(more);
             alive = ub(alive);
@@ -1794,26 +1861,20 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
             best = uniform_double(best);
         }
         PIPE_PART(-1);
-        // the turn after the one in flight: its rows (a bubble: what was missing, again)
+        // the turn after the one in flight (tv is there already: rows_ahead)
         if (cur.f & T_VALID) {
             tn = cur.n + 1;
             more = tn < nref;
-            // (the batch holds turns tn - 3 .. tn + 1: the turn about to be decided -- the one
-            // before the one in flight and its rider -- reads its Metropolis draw there, a
-            // squash rewinds by two at most, a rider looks one turn ahead)
-            if (__builtin_expect(tn + 1 >= bbase + NB, 0))
+            // (the batch holds turns tn - 3 .. tn + 4: the turn about to be decided reads its
+            // Metropolis draw there, a squash rewinds by two at most, rows are asked for up to
+            // four turns ahead)
+            if (__builtin_expect(tn + 4 >= bbase + NB, 0))
                 fill(tn >= 3 ? tn - 3 : 0);
         }
-        if (more)
-            request_rows(tn, ride_on && tn + 1 < nref);
         PIPE_PART(0);
         jump_early();
-        // THE PROPOSAL FIRST, as if the turn about to be decided were rejected (85 in 100 are):
-        // the tail wave needs ~2 000 cycles of the slot for that turn's chisq, and this wave
-        // used to idle through most of them and then decide AND propose behind it -- the
-        // slot's longest dependent path.  Formed here the proposal costs nothing on that path;
-        // after an accept it is formed again from the new state (as the turn in flight is).
-        // Never where forming it could wait for rows: the turn to be decided is still in flight.
+        // THE PROPOSAL FIRST, as if the turn about to be decided were rejected.  Never where
+        // forming it could wait for rows: the turn to be decided is still in flight.
         const int buf = par ^ 1;
         bool formed = false;
         int cmd_next = CW_SKIP;
@@ -1835,14 +1896,18 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
             const bool accepted = decide(pend);
             if (accepted && (cur.f & (T_VALID | T_SPEC)) == (T_VALID | T_SPEC)) {
                 // the turn in flight (and its rider) started from a state that is no more:
-                // squashed, and what was prepared behind it rewound to it
-                tn = cur.n - ((cur.f & T_RIDER) ? 1 : 0);
+                // squashed, and proposed again -- from the rows it was proposed from
                 cur.f = 0;
+                tn = cs_t;
                 more = true;
-                request_rows(tn, ride_on && tn + 1 < nref);
-                jump_ready = false;
-                rows_there = false;
-                second_ready = false;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    rv[q] = cs_v[q];
+                    rw[q] = cs_w[q];
+                }
+                tv = cs_t;
+                have = cs_have;
+                jump_early();
             }
             if (accepted)
                 formed = false;                         // (the state has changed: again)
@@ -1857,9 +1922,10 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
         // stands already
         if (!formed)
             cmd_next = try_issue(buf ? np1 : np0);
-        PIPE_PART(4);
         if (lane == 0)
             s_cmd[buf] = cmd_next;
+        rows_ahead();
+        PIPE_PART(4);
         PIPE_SYNC(1);                                  // the halo barriers of stage A
         PIPE_SYNC(2);
         PIPE_SYNC(3);
