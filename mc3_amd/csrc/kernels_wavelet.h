@@ -1997,10 +1997,15 @@ __global__ __launch_bounds__(704) void wavelet_pipe_kernel(const DevProblem P, c
 #ifndef MC3HIP_TAIL_PRIO
 #define MC3HIP_TAIL_PRIO 3
 #endif
+#if MC3HIP_CW_PRIO == MC3HIP_TAIL_PRIO
+    if (wave == 8 || wave == 9)
+        __builtin_amdgcn_s_setprio(MC3HIP_CW_PRIO);
+#else
     if (wave == 8)
         __builtin_amdgcn_s_setprio(MC3HIP_CW_PRIO);
     if (wave == 9)
         __builtin_amdgcn_s_setprio(MC3HIP_TAIL_PRIO);
+#endif
     if (wave == 8) {
         if constexpr (ONE)
             pipe_chain_wave_one<SMP>(P, nref, L.nextp, np1, s_cmd, s_result, nhalo);
