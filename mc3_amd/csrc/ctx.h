@@ -44,6 +44,11 @@ struct mc3hip_ctx {
     bool fast = false;              // lean persistent instance selected
     bool chainwave = false;         // wavelet likelihood, eight waves: a ninth runs the chain
                                     // (kernels_wavelet.h wavelet_cw_kernel)
+    // 2 049 ... 16 384 points, the plain strict DEMC shape, an ensemble that is co-resident at
+    // four / eight waves per chain: tiles the waves of a chain keep in registers between them
+    // (kernels_lean.h lean_demc_wide_kernel NT; 0 = not this context).  Set at creation
+    // (mc3hip.hip wide_tiles_shape), taken back by decide_persist if the grid does not fit.
+    int wide_tiles = 0;
     int lean_waves_default = 1;     // waves per chain of the hand-laid-out DEMC loop (ctx.h
                                     // lean_waves), decided with the grid in decide_persist
     int mc_chains = 0;              // chains a workgroup of the persistent kernel advances per
@@ -235,6 +240,8 @@ inline bool jit_serves(const mc3hip_ctx *c)
     return c->jit_fn != nullptr && jit_model_tag(c) != 0;
 }
 
+inline int wide_tiles(const mc3hip_ctx *c);
+
 // the lean persistent instance applies when nothing of the general machinery is
 // needed (run_chain.h run_chain FAST)
 inline bool fast_eligible(const mc3hip_ctx *c)
@@ -263,7 +270,7 @@ inline bool fast_eligible(const mc3hip_ctx *c)
                          P.nfree <= 4 && !multi && P.zs == ZROW && !getenv("MC3HIP_NO_LEAN")) ||
                         (P.sampler == MC3HIP_SNOOKER && P.thinning == 1 && P.nfree <= 4 &&
                          !p2p_flag && !multi && P.zs == ZROW && !getenv("MC3HIP_NO_LEAN"));
-    return c->wpc == 1 && !P.wlike && size_ok && c->mt >= 2 && c->mt <= 4 &&
+    return (c->wpc == 1 || wide_tiles(c) > 0) && !P.wlike && size_ok && c->mt >= 2 && c->mt <= 4 &&
            (plain || fx_ok) && P.nmodel == P.nparams &&
            eps_ok && P.trace_iters == 0 &&
            (P.sampler == MC3HIP_DEMC || P.sampler == MC3HIP_SNOOKER ||
@@ -389,9 +396,18 @@ inline bool lean_rows_eligible(const mc3hip_ctx *c)
 // lean_demc_wide_kernel): 1, 2 or 4.  Several only for the plain headline shape -- every
 // coefficient free, one tile, one GPU -- and only on request (MC3HIP_LEAN_WAVES=2|4): measured
 // slower than one wave (mc3hip.hip decide_persist).
+inline int wide_tiles(const mc3hip_ctx *c)
+{
+    return (c->wide_tiles > 0 && !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 &&
+            c->comm == nullptr && c->mc_chains == 0)
+               ? c->wide_tiles : 0;
+}
 inline int lean_waves(const mc3hip_ctx *c)
 {
     const DevProblem &P = c->P;
+    if (const int nt = wide_tiles(c))
+        if (c->fast)
+            return nt > 8 ? 8 : 4;
     const bool plain = P.nparams == P.nfree && P.ngprior == 0 && P.nshare == 0 &&
                        P.npad <= VLANES && !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1;
     if (!lean_demc_eligible(c) || !plain)

@@ -39,14 +39,28 @@ __device__ __forceinline__ double gauss_lane_share(const Model<MT> &model,
 
 // A thread's share of the data sum when WPC waves share a chain's (only) tile: the residuals of
 // its 16 / WPC virtual lanes and the in-thread levels of lane_tree<WPC> (every model family).
-template <int WPC, int MT>
+// (NT: tiles of 1024 points the thread keeps a share of -- a virtual lane adds up its points
+// tile after tile, the canonical order of mc3hip_plan.tile = 0; polynomial families)
+template <int WPC, int MT, int NT = 1>
 __device__ __forceinline__ double gauss_thread_share(const Model<MT> &model,
-                                                     const DataTile<WPC, MT> &tile)
+                                                     const DataTile<WPC, MT> (&tiles)[NT])
 {
+    static_assert(NT == 1 || (!mt_is_link(MT) && MT != MT_LINEAR), "several tiles: polynomials");
     constexpr int NV = 16 / WPC;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const DataTile<WPC, MT> &tile = tiles[0];
     double acc[NV];
-    if constexpr (mt_is_link(MT)) {
+    if constexpr (NT > 1) {
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const double m = model.at_x(tiles[q].x[v]);
+                const double r = (m - tiles[q].d[v]) * tiles[q].w[v];
+                acc[v] = mc3_fma(r, r, q == 0 ? 0.0 : acc[v]);
+            }
+        }
+    } else if constexpr (mt_is_link(MT)) {
         // (column by column across the thread's points -- Model::from_columns' terms in its
         // order for every point, but the points' dependent chains side by side: written point
         // by point the compiler left half of them one fused multiply-add after the other)
@@ -107,9 +121,9 @@ __device__ __forceinline__ double gauss_thread_share(const Model<MT> &model,
 // bounds; a waiting wave costs its SIMD nothing.  Who leaves is decided by wave 0 alone and
 // said through LDS: a wave that left on its own would no longer be counted by the barrier the
 // others wait at.
-template <int MT, int NW>
+template <int MT, int NW, int NT = 1>
 struct SumHelpers {
-    static_assert(NW == 2 || NW == 4, "2 or 4 waves share the data sum");
+    static_assert(NW == 2 || NW == 4 || NW == 8, "2, 4 or 8 waves share the data sum");
     static constexpr int NC = Model<MT>::NC;
     double *s_part, *s_cf;
     int *s_cmd;                                  // [0]: 0 = a sum, 2 = leave; [1]: entry verdict
@@ -128,7 +142,8 @@ struct SumHelpers {
         return s_cmd[1] == 0;
     }
     // waves 1..NW-1: until wave 0 says leave
-    __device__ __forceinline__ void serve(const DevProblem &P, const DataTile<NW, MT> &tile)
+    __device__ __forceinline__ void serve(const DevProblem &P,
+                                          const DataTile<NW, MT> (&tile)[NT])
     {
         for (;;) {
             block_sync<NW>();                          // (A) the order of this iteration
@@ -136,7 +151,7 @@ struct SumHelpers {
                 return;
             Model<MT> model;
             model.init(P, s_cf);
-            s_part[threadIdx.x] = gauss_thread_share<NW, MT>(model, tile);
+            s_part[threadIdx.x] = gauss_thread_share<NW, MT, NT>(model, tile);
             block_sync<NW>();                          // (B) the partial sums are in LDS
         }
     }
@@ -154,9 +169,9 @@ struct SumHelpers {
         __builtin_amdgcn_sched_barrier(0);
     }
     __device__ __forceinline__ double collect(const DevProblem &P, const Model<MT> &model,
-                                              const DataTile<NW, MT> &tile, int lane)
+                                              const DataTile<NW, MT> (&tile)[NT], int lane)
     {
-        const double t0 = gauss_thread_share<NW, MT>(model, tile);
+        const double t0 = gauss_thread_share<NW, MT, NT>(model, tile);
         block_sync<NW>();                              // (B)
         double p[NW];
         p[0] = t0;

@@ -19,6 +19,16 @@ chain_kernel_fn lean_other_instance_t(const mc3hip_ctx *c)
         return lean_plain_shape(c) ? lean_mrw_kernel<MT> : lean_mrw_kernel<MT, true>;
     }
     if (lean_snooker_eligible(c)) {
+        // (2 049 ... 16 384 points: the tiles in the registers of four / eight waves per chain)
+        if (c->P.fepsilon == 0.0 && c->P.thinning == 1 && lean_plain_shape(c)) {
+            switch (wide_tiles(c)) {
+            case 2: return lean_snooker_wide_kernel<MT, 4, 2>;
+            case 4: return lean_snooker_wide_kernel<MT, 4, 4>;
+            case 8: return lean_snooker_wide_kernel<MT, 4, 8>;
+            case 16: return lean_snooker_wide_kernel<MT, 8, 16>;
+            default: break;
+            }
+        }
         if (c->P.fepsilon != 0.0)                   // (thinning 1, one tile: fast_eligible)
             return lean_plain_shape(c)
                        ? lean_snooker_kernel<MT, false, false, false, false, false, true>

@@ -12,6 +12,16 @@ namespace {
 template <int MT>
 chain_kernel_fn lean_demc_mc_instance_t(const mc3hip_ctx *c, bool p2p)
 {
+    // (2 049 ... 16 384 points: the tiles in the registers of four / eight waves per chain)
+    if (!p2p && lean_demc_eligible(c) && c->P.fepsilon == 0.0 && lean_plain_shape(c)) {
+        switch (wide_tiles(c)) {
+        case 2: return lean_demc_wide_kernel<MT, 4, 2>;
+        case 4: return lean_demc_wide_kernel<MT, 4, 4>;
+        case 8: return lean_demc_wide_kernel<MT, 4, 8>;
+        case 16: return lean_demc_wide_kernel<MT, 8, 16>;
+        default: break;
+        }
+    }
     // (two tiles, two or three chains per wave; the one-tile shapes: kernels_rows.h, k_lean6.hip)
     if (lean_demc_mc_eligible(c) && !p2p) {
         if (c->mc_chains == 2)

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(64) void persist_fast_kernel(const DevProblem P, co
 template <int MT, bool P2P, bool FX, bool MULTI, bool BATCH, bool COURIER, bool EPS, int NW = 1>
 __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nref)
 {
+    constexpr int NT = 1;
     static_assert(!EPS || (!P2P && !MULTI && !BATCH && !COURIER), "EPS: the one-GPU headline loop");
     static_assert(NW == 1 || (!P2P && !MULTI && !COURIER), "helper waves: one GPU, one tile");
     constexpr int NC = Model<MT>::NC;         // coefficients the model tag fixes
@@ -74,7 +75,7 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
     __shared__ double s_hpart[NW > 1 ? 64 * NW : 1], s_hcf[16];
     __shared__ int s_hcmd[2];
     (void)s_hpart; (void)s_hcf; (void)s_hcmd;
-    SumHelpers<MT, (NW > 1 ? NW : 2)> helpers;
+    SumHelpers<MT, (NW > 1 ? NW : 2), NT> helpers;
     (void)helpers;
     if constexpr (COURIER) {
         if (!courier_begin(s_ring, s_cour, ctl_rw))
@@ -93,11 +94,23 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
                 &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
             return;
     }
-    DataTile<NW, MT> tile;
-    tile.load(P);
+    // (NT tiles of 1024 points in the registers of the NW waves between them; tiles beyond the
+    // data: weight 0)
+    DataTile<NW, MT> tiles[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        if (q == 0 || q * VLANES < P.npad) {
+            tiles[q].load(P, q * VLANES);
+        } else if constexpr (NT > 1) {
+#pragma unroll
+            for (int v = 0; v < 16 / NW; ++v)
+                tiles[q].x[v] = tiles[q].d[v] = tiles[q].w[v] = 0.0;
+        }
+    }
+    const DataTile<NW, MT> &tile = tiles[0];
     if constexpr (NW > 1) {
         if (threadIdx.x >= 64) {
-            helpers.serve(P, tile);
+            helpers.serve(P, tiles);
             return;
         }
     }
@@ -350,7 +363,7 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
                 double prior = 0.0;
                 if constexpr (FX)
                     prior = priors.term(npk, lane);
-                nextchisq = helpers.collect(P, model, tile, lane);
+                nextchisq = helpers.collect(P, model, tiles, lane);
                 if constexpr (FX)
                     nextchisq = nextchisq + prior;
             }
@@ -485,7 +498,7 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const Dev
 // (zlag > 0, the declared multi-GPU cadence: the history an iteration draws from ends zlag
 // refreshes earlier -- mc3hip_problem.zlag, oracle_lockstep.c ls_run)
 template <int MT, bool FX, bool THIN, bool MULTI, bool P2P, bool COURIER, bool EPS = false,
-          int NW = 1>
+          int NW = 1, int NT = 1>
 __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int nref)
 {
     static_assert(!COURIER || P2P, "the courier carries rows to other ranks' replicas");
@@ -510,7 +523,7 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
     __shared__ double s_hpart[NW > 1 ? 64 * NW : 1], s_hcf[16];
     __shared__ int s_hcmd[2];
     (void)s_hpart; (void)s_hcf; (void)s_hcmd;
-    SumHelpers<MT, (NW > 1 ? NW : 2)> helpers;     // (gauss.h: helper waves share the data sum)
+    SumHelpers<MT, (NW > 1 ? NW : 2), NT> helpers;     // (gauss.h: helper waves share the data sum)
     (void)helpers;
     if constexpr (COURIER) {
         if (!courier_begin(s_ring, s_cour, ctl_rw))
@@ -529,11 +542,23 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
                 &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
             return;
     }
-    DataTile<NW, MT> tile;
-    tile.load(P);
+    // (NT tiles of 1024 points in the registers of the NW waves between them; tiles beyond the
+    // data: weight 0)
+    DataTile<NW, MT> tiles[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        if (q == 0 || q * VLANES < P.npad) {
+            tiles[q].load(P, q * VLANES);
+        } else if constexpr (NT > 1) {
+#pragma unroll
+            for (int v = 0; v < 16 / NW; ++v)
+                tiles[q].x[v] = tiles[q].d[v] = tiles[q].w[v] = 0.0;
+        }
+    }
+    const DataTile<NW, MT> &tile = tiles[0];
     if constexpr (NW > 1) {
         if (threadIdx.x >= 64) {
-            helpers.serve(P, tile);
+            helpers.serve(P, tiles);
             return;
         }
     }
@@ -772,7 +797,7 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
                 double prior = 0.0;
                 if constexpr (FX)
                     prior = priors.term(npk, lane);
-                nextchisq = helpers.collect(P, model, tile, lane);
+                nextchisq = helpers.collect(P, model, tiles, lane);
                 if constexpr (FX)
                     nextchisq = nextchisq + prior;
             }
@@ -870,6 +895,16 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_snooker_kernel(const 
         const int nref)
 {
     lean_snooker_body<MT, FX, THIN, MULTI, P2P, COURIER, EPS>(P, nref);
+}
+
+// 2 049 ... 16 384 points, the plain shape with few chains: the tiles in the registers of four
+// (eight) waves per chain -- wave 0 runs the loop above, the others add up their share of every
+// tile between two barriers (gauss.h SumHelpers; lean_demc_wide_kernel is the same for DEMC)
+template <int MT, int NW, int NT>
+__global__ __launch_bounds__(64 * NW) void lean_snooker_wide_kernel(const DevProblem P,
+                                                                    const int nref)
+{
+    lean_snooker_body<MT, false, false, false, false, false, false, NW, NT>(P, nref);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1606,10 +1641,19 @@ __global__ __launch_bounds__(64) void lean_demc_mc_kernel(const DevProblem P, co
 // the canonical order of DataTile<NW>, so the result is bit for bit the one-wave kernel's)
 // and hand them back through LDS.  Two raw barriers per iteration (LDS traffic only: no
 // vector-memory drain), no flag polling: a waiting wave costs its SIMD nothing.
-template <int MT, int NW>
+// NT > 1 (round 5, the mid-range of tools/mid_range.py): 2 049 ... 16 384 points.  One wave keeps
+// two 1024-point tiles in registers and STREAMS the rest from L2 every iteration (3.0 us at
+// 4096 points); from 4097 points on a context used to leave the hand-laid-out loops altogether
+// (the general chain with four waves: 4.7 us at 8192 points, then the one-launch tiled plan at
+// its flat ~6.7 us).  Here NW waves keep NT tiles between them for the whole launch -- thread
+// t owns virtual lanes t + 64 NW j of EVERY tile, a virtual lane adds up its points tile after
+// tile (the canonical order of mc3hip_plan.tile = 0: bit for bit what the streamed loop and
+// the general chain compute) -- four waves up to eight tiles, eight waves up to sixteen (one
+// workgroup per CU: 256 chains).  Tiles beyond the data are weight 0 (fma(0, 0, acc) = acc).
+template <int MT, int NW, int NT = 1>
 __global__ __launch_bounds__(64 * NW) void lean_demc_wide_kernel(const DevProblem P, const int nref)
 {
-    static_assert(NW == 2 || NW == 4, "2 or 4 waves share the data sum");
+    static_assert(NW == 2 || NW == 4 || NW == 8, "2, 4 or 8 waves share the data sum");
     constexpr int ZS = ZROW;
     constexpr int NV = 16 / NW;
     __shared__ double s_part[64 * NW];
@@ -1623,19 +1667,31 @@ __global__ __launch_bounds__(64 * NW) void lean_demc_wide_kernel(const DevProble
     if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
             &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
         return;
-    // this thread's share of the (only) 1024-point tile: virtual lanes lane + 64 (wave + NW v)
-    DataTile<NW, MT> tile;
-    tile.load(P);
+    // this thread's share of the 1024-point tiles: virtual lanes lane + 64 (wave + NW v)
+    DataTile<NW, MT> tile[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        if (q * VLANES < P.npad) {
+            tile[q].load(P, q * VLANES);
+        } else {                                       // (no such tile: weight 0)
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                tile[q].x[v] = tile[q].d[v] = tile[q].w[v] = 0.0;
+        }
+    }
     auto partial = [&](const double (&cf)[MT]) {
         double acc[NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            double m = cf[MT - 1];
+        for (int q = 0; q < NT; ++q) {
 #pragma unroll
-            for (int j = MT - 2; j >= 0; --j)
-                m = mc3_fma(m, tile.x[v], cf[j]);
-            const double r = (m - tile.d[v]) * tile.w[v];
-            acc[v] = mc3_fma(r, r, 0.0);
+            for (int v = 0; v < NV; ++v) {
+                double m = cf[MT - 1];
+#pragma unroll
+                for (int j = MT - 2; j >= 0; --j)
+                    m = mc3_fma(m, tile[q].x[v], cf[j]);
+                const double r = (m - tile[q].d[v]) * tile[q].w[v];
+                acc[v] = mc3_fma(r, r, q == 0 ? 0.0 : acc[v]);
+            }
         }
 #pragma unroll
         for (int s = NV / 2; s >= 1; s >>= 1) {

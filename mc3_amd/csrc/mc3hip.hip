@@ -496,6 +496,21 @@ int decide_persist(mc3hip_ctx *c)
     capacity = capacity < cap_limit ? capacity : cap_limit;
     if (nb < 1)
         return 0;
+    if (c->fast && c->wide_tiles > 0 && c->P.nlocal > capacity) {
+        // the wide loop (tiles in the registers of four / eight waves per chain) holds one chain
+        // per workgroup: an ensemble that is not co-resident that way runs what it ran before
+        c->wide_tiles = 0;
+        c->fast = fast_eligible(c) || jit_serves(c);
+        if (c->fast)
+            nb = fast_blocks_per_cu(c);
+        else
+            persist_blocks_per_cu(c, &nb);
+        const int pc = (nb > 1 && getenv("MC3HIP_PERSIST_MARGIN")) ? nb - 1 : nb;
+        capacity = (long long)pc * prop.multiProcessorCount;
+        capacity = capacity < cap_limit ? capacity : cap_limit;
+        if (nb < 1)
+            return 0;
+    }
     if (c->fast && c->P.nlocal > capacity && lean_one_chain_only(c)) {
         // fixed coefficients / priors with thinning > 1 or peer to peer, the support
         // distribution: only a one-chain-per-wave loop is lean there; more chains than it can
@@ -894,9 +909,38 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
                 mid_resident = ncol * nt <= cus && (long long)pr->nlocal <= 8 * ncol * nt;
             }
         }
-        const bool big = nd >= 4 * 4096 ||
-                         (mid_resident && nd >= 2 * 4096 &&
-                          (long long)nd * pr->nlocal >= 4194304LL);
+        // 2 049 ... 16 384 points of the plain strict DEMC shape with few chains: the tiles in
+        // the registers of four (eight) waves per chain, kernels_lean.h lean_demc_wide_kernel --
+        // 1.5-2 us per iteration where the streamed one-wave loop takes 2.5-3, the general chain
+        // 4-7 and the one-launch tiled plan its flat ~6.7 (tools/mid_range.py).  MC3HIP_NO_WIDE.
+        {
+            const long long tiles = ((long long)nd + VLANES - 1) / VLANES;
+            hipDeviceProp_t prop;
+            const long long cus = hipGetDeviceProperties(&prop, c->device) == hipSuccess
+                                      ? prop.multiProcessorCount : 256;
+            const bool shape = !pr->wlike && !linear_model && pr->nmodel >= 2 && pr->nmodel <= 4 &&
+                               pr->nmodel == pr->nparams && P.nfree == pr->nparams &&
+                               P.ngprior == 0 && P.nshare == 0 &&
+                               (pr->sampler == MC3HIP_DEMC || pr->sampler == MC3HIP_SNOOKER) &&
+                               pr->thinning == 1 && pr->zlag == 0 && pr->fepsilon == 0.0 &&
+                               pr->trace_iters == 0 && pr->nlocal == pr->nchains &&
+                               !(pr->flags & (MC3HIP_FLAG_P2P | MC3HIP_FLAG_NO_PERSIST)) &&
+                               !getenv("MC3HIP_NO_WIDE") && !getenv("MC3HIP_NO_LEAN") &&
+                               !getenv("MC3HIP_NO_FAST") && !getenv("MC3HIP_NO_PERSIST") &&
+                               !getenv("MC3HIP_WPC");
+            c->wide_tiles = 0;
+            // (co-residency is decided by the occupancy query of the very instance --
+            // decide_persist, which takes the choice back if the grid does not fit: two tiles
+            // three workgroups of four waves per CU, four tiles two, eight tiles one)
+            if (shape && tiles >= 2 && tiles <= 8 &&
+                pr->nlocal <= (tiles <= 2 ? 3 : (tiles <= 4 ? 2 : 1)) * cus)
+                c->wide_tiles = tiles <= 2 ? 2 : (tiles <= 4 ? 4 : 8);
+            else if (shape && tiles > 8 && tiles <= 16 && pr->nlocal <= cus)
+                c->wide_tiles = 16;
+        }
+        const bool big = c->wide_tiles == 0 &&
+                         (nd >= 4 * 4096 || (mid_resident && nd >= 2 * 4096 &&
+                                             (long long)nd * pr->nlocal >= 4194304LL));
         const bool tiled = !pr->wlike && big && pr->nlocal >= 16 && pr->nmodel <= 16 &&
                            !getenv("MC3HIP_NO_TILED");
         P.tile = tiled ? ((pr->nmodel <= 4 && !mfma_model) ? 4096 : 2048) : 0;

@@ -97,6 +97,13 @@ def test_no_scratch_in_the_hand_laid_out_loops(isa):
                 # registers more than there are: 20 B, as in the nine-wave kernels)
                 assert scratch <= 24, f'{unit}: {name} carries {scratch} B of scratch'
                 continue
+            if 'wide_kernel' in name and 'ELi8ELi16E' in name:
+                # (sixteen 1024-point tiles in the registers of eight waves, kernels_lean.h
+                # lean_*_wide_kernel<MT, 8, 16>: 192 registers of data beside the chain's own
+                # state -- a few dozen values spill; 1.7 / 2.8 us per iteration at 16 384 points
+                # against the 6.7 / 7.9 of the plans these shapes ran before)
+                assert scratch <= 320, f'{unit}: {name} carries {scratch} B of scratch'
+                continue
             assert scratch == 0, f'{unit}: {name} carries {scratch} B of scratch'
 
 

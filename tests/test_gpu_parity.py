@@ -468,13 +468,19 @@ def test_lean_instances_with_a_shared_coefficient(eng, sampler):
 
 
 @pytest.mark.parametrize('ndata', [1500, 2048, 2049, 3000, 4096, 4097])
-def test_lean_demc_with_more_than_one_tile(eng, ndata):
-    """More than 1024 points on the lean DEMC loop: two 1024-point tiles in registers, the
-    rest streamed (<= 4096 points); beyond that the general instance on four waves."""
+@pytest.mark.parametrize('wide', [True, False])
+def test_lean_demc_with_more_than_one_tile(eng, monkeypatch, ndata, wide):
+    """More than 1024 points on the lean DEMC loop: the tiles in the registers of four waves
+    (lean_demc_wide_kernel) -- or, behind MC3HIP_NO_WIDE and for ensembles that are not
+    co-resident that way, two 1024-point tiles in the registers of ONE wave and the rest streamed
+    (<= 4096 points), beyond that the general instance on four waves."""
+    if not wide:
+        monkeypatch.setenv('MC3HIP_NO_WIDE', '1')
     prob = H.quad_problem(ndata=ndata, nchains=32, nsamples=32*150, sampler='demc')
     orc, gpu = run_pair(eng, prob, trace=False)
     assert gpu.plan['persistent'] > 0
-    assert (gpu.plan['fast'] == 2) == (ndata <= 4096)
+    assert (gpu.plan['fast'] == 2) == (wide or ndata <= 4096)
+    assert gpu.plan['waves_per_chain'] == (4 if wide or ndata > 4096 else 1), gpu.plan
     assert_same(orc, gpu, trace=False)
     gpu.close()
 
@@ -856,6 +862,72 @@ def test_lean_demc_helper_waves_resume_and_abort(eng, monkeypatch, waves):
     monkeypatch.delenv('MC3HIP_TEST_ABORT_AT')
 
 
+@pytest.mark.parametrize('ndata,want', [(1025, 4), (2048, 4), (2049, 4), (3000, 4), (4096, 4),
+                                        (4097, 4), (6000, 4), (8192, 4), (8193, 8), (12000, 8),
+                                        (16384, 8)])
+@pytest.mark.parametrize('case', ['plain', 'tight', 'resume', 'snooker', 'snooker-tight',
+                                  'snooker-resume'])
+def test_lean_loops_with_the_tiles_in_the_registers_of_several_waves(eng, monkeypatch, ndata, want,
+                                                                     case):
+    """1 025 ... 16 384 points of the plain strict DEMC and snooker shapes with few chains
+    (lean_demc_wide_kernel / lean_snooker_wide_kernel NT: four waves keep up to eight 1024-point
+    tiles between them, eight waves up to sixteen -- where one wave streamed the tiles beyond
+    its second from L2, the general chain took over from 4097 points and the tiled plan from
+    16 384): a virtual lane adds
+    up its points tile after tile, so the sum is the canonical one bit for bit -- against the
+    oracle, with bounds that reject, across launches, and behind the switch the kernels these
+    shapes ran before (the same results)."""
+    nref = 60
+    sampler = 'snooker' if case.startswith('snooker') else 'demc'
+    case = case.replace('snooker-', '').replace('snooker', 'plain')
+    prob = H.quad_problem(ndata=ndata, nchains=6, nsamples=6*nref, sampler=sampler)
+    if case == 'tight':
+        prob.update(pmin=np.array([9.2, -2.4, 0.08]), pmax=np.array([10.8, -1.6, 0.12]))
+    if case == 'resume':
+        monkeypatch.setenv('MC3HIP_PERSIST_REFS', '17')
+        gpu = eng.DeviceChains(**prob)
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nthreads=4)
+        for n in (1, 3, 30, 26):
+            gpu.run(n)
+    else:
+        orc, gpu = run_pair(eng, prob, trace=False)
+    plan = gpu.plan
+    assert plan['fast'] == 2 and plan['persistent'] > 0 and plan['tile'] == 0, plan
+    assert plan['waves_per_chain'] == want, plan
+    assert_same(orc, gpu, trace=False)
+    if case == 'tight':
+        assert gpu.state()['outbounds'].sum() > 20
+    gpu.close()
+    # behind the switch: what these shapes ran before
+    if case == 'plain':
+        monkeypatch.setenv('MC3HIP_NO_WIDE', '1')
+        orc2, gpu2 = run_pair(eng, prob, trace=False)
+        assert_same(orc2, gpu2, trace=False)
+        np.testing.assert_array_equal(orc2.Z, orc.Z)
+        gpu2.close()
+
+
+def test_wide_tiles_give_up_and_ensembles_that_do_not_fit(eng, monkeypatch):
+    """The wide loop through a give-up (redone from the checkpoint, one launch per refresh), and
+    an ensemble that is not co-resident at four waves per chain: back to what it ran before."""
+    prob = H.quad_problem(ndata=5000, nchains=6, nsamples=6*60, sampler='demc')
+    monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '23')
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert gpu.plan['recoveries'] == 1, gpu.plan
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+    monkeypatch.delenv('MC3HIP_TEST_ABORT_AT')
+    monkeypatch.setenv('MC3HIP_PERSIST_CAPACITY', '4')
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert gpu.plan['fast'] != 2 or gpu.plan['chains_per_workgroup'] > 1, gpu.plan
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
 # ---- wavelet likelihood: the hand-structured chain wave (kernels_wavelet.h) -------------
 def _cw_problem(sampler, ndata, case):
     prob = H.wavelet_problem(ndata=ndata, nchains=12, nsamples=12*160, sampler=sampler)
@@ -1071,10 +1143,12 @@ def test_lean_snooker_and_mrw_loops_with_thinning(eng, monkeypatch, case, thinni
 
 @pytest.mark.parametrize('sampler', ['snooker', 'mrw'])
 @pytest.mark.parametrize('ndata', [1025, 2048, 2049, 4096])
-def test_lean_snooker_and_mrw_loops_with_streamed_tiles(eng, ndata, sampler):
+def test_lean_snooker_and_mrw_loops_with_streamed_tiles(eng, monkeypatch, ndata, sampler):
     """The MULTI instances of lean_snooker_kernel / lean_mrw_kernel: two tiles in registers, the
     third and fourth streamed inside the loop (loads the compiler tracks next to the ones it
-    does not)."""
+    does not).  (Snooker: what runs behind MC3HIP_NO_WIDE and for ensembles that are not
+    co-resident at four waves per chain -- lean_snooker_wide_kernel otherwise.)"""
+    monkeypatch.setenv('MC3HIP_NO_WIDE', '1')
     prob = H.quad_problem(ndata=ndata, nchains=14, nsamples=14*150, sampler=sampler)
     if sampler == 'mrw':
         prob['pstep'] = np.array([0.05, 0.02, 0.003])

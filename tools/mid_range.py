@@ -63,7 +63,7 @@ def sweep(name, shapes, build):
         group.sort(key=lambda r: r['ndata'])
         for k, r in enumerate(group):
             nb = [group[q]['giga_points_per_s'] for q in (k - 1, k + 1) if 0 <= q < len(group)]
-            r['cliff'] = bool(nb) and all(r['giga_points_per_s'] < 0.5*v for v in nb)
+            r['cliff'] = len(nb) == 2 and all(r['giga_points_per_s'] < 0.5*v for v in nb)
     for r in rows:
         print(json.dumps(r), flush=True)
 
