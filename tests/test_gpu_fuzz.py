@@ -413,3 +413,50 @@ def test_rows_kernels_random_problem(seed, monkeypatch):
     assert gpu.plan['fast'] == plan['fast'] and gpu.plan['recoveries'] == 0, label
     compare_final(gpu, orc, label)
     gpu.close()
+
+
+def wide_problem(seed):
+    """1 025 ... 16 384 points of the plain strict DEMC / snooker shapes with few chains: the
+    tiles in the registers of four / eight waves per chain (lean_*_wide_kernel)."""
+    rs = np.random.RandomState(640000 + seed)
+    nmodel = int(rs.randint(2, 5))
+    ndata = int(rs.choice([int(rs.randint(1025, 16385)), 1025, 2048, 2049, 4096, 4097, 8192, 8193,
+                           16383, 16384]))
+    sampler = str(rs.choice(['demc', 'snooker']))
+    nchains = int(rs.randint(3, 24))
+    x = rs.uniform(-1, 1, ndata)                       # (unsorted: any abscissae)
+    p_true = rs.normal(0, 1, nmodel)
+    data = p_true @ np.array([x**k for k in range(nmodel)]) + rs.normal(0, 1, ndata)
+    uncert = rs.uniform(0.5, 2.0, ndata)
+    lo = p_true - rs.uniform(0.02, 3.0, nmodel)
+    hi = p_true + rs.uniform(0.02, 3.0, nmodel)
+    return dict(data=data, uncert=uncert, indep=x, params=p_true, pstep=np.full(nmodel, 0.02),
+                pmin=lo, pmax=hi, nchains=nchains, nsamples=nchains*int(rs.randint(20, 90)),
+                sampler=sampler, wlike=False, thinning=1, fgamma=float(rs.uniform(0.5, 1.5)),
+                fepsilon=0.0, hsize=int(rs.randint(1, 5)), model='poly', nmodel=nmodel,
+                seed=int(rs.randint(0, 2**31)))
+
+
+@pytest.mark.parametrize('seed', range(60))
+def test_wide_kernels_random_problem(seed):
+    """The round-5 loops with the data in the registers of several waves, fuzzed: the library
+    must pick them (fast == 2, four or eight waves per chain) and equal the oracle exactly --
+    across two launches."""
+    from mc3_amd import engine
+    prob = wide_problem(seed)
+    gpu = engine.DeviceChains(**prob)
+    plan = gpu.plan
+    nd = len(prob['data'])
+    label = f"{prob['sampler']} poly{prob['nmodel']} ndata={nd} nchains={prob['nchains']} plan={plan}"
+    assert plan['persistent'] > 0 and plan['fast'] == 2 and plan['tile'] == 0, label
+    assert plan['waves_per_chain'] == (8 if nd > 8192 else 4), label
+    orc = H.make_oracle(prob, plan=plan)
+    Z0, lp0 = H.initial_population(orc, seed=seed)
+    orc.set_population(Z0, lp0)
+    gpu.set_population(Z0, lp0)
+    orc.run(nthreads=4)
+    gpu.run(gpu.nzchain//3)
+    gpu.run()
+    assert gpu.plan['fast'] == 2 and gpu.plan['recoveries'] == 0, label
+    compare_final(gpu, orc, label)
+    gpu.close()
