@@ -49,6 +49,9 @@ struct mc3hip_ctx {
     // (kernels_lean.h lean_demc_wide_kernel NT; 0 = not this context).  Set at creation
     // (mc3hip.hip wide_tiles_shape), taken back by decide_persist if the grid does not fit.
     int wide_tiles = 0;
+    // wavelet likelihood, one wave per chain (<= 2048 points), the shapes of cw_lean_eligible,
+    // snooker without the support distribution: kernels_wavelet.h wavelet_one_kernel
+    bool wl_one = false;
     int lean_waves_default = 1;     // waves per chain of the hand-laid-out DEMC loop (ctx.h
                                     // lean_waves), decided with the grid in decide_persist
     int mc_chains = 0;              // chains a workgroup of the persistent kernel advances per

@@ -60,6 +60,11 @@ void persist_instance_t(const mc3hip_ctx *c, bool p2p, chain_kernel_fn *out)
         *out = p2p ? persist_kernel<WW, MT, true, LARGE, true>
                    : mc ? persist_kernel<WW, MT, true, LARGE, false, true>
                         : persist_kernel<WW, MT, true, LARGE>;
+        // (one wave per chain, snooker, the common shape: the chain written out by hand)
+        if constexpr (WW == 1 && !LARGE) {
+            if (!p2p && !mc && c->wl_one)
+                *out = wavelet_one_kernel<MT>;
+        }
     }
 }
 

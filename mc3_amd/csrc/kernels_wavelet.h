@@ -2100,4 +2100,214 @@ __global__ __launch_bounds__(704) void wavelet_pipe_kernel(const DevProblem P, c
     }
 }
 
+// ---- ONE wave per chain: wavelet likelihoods of up to 2 048 points, by hand ------------------
+// Below 8 192 points there was no chain wave: the general chain (run_chain behind
+// persist_kernel) ran these shapes -- 3.8 us per iteration at 64 points, 5.6 at 2 048, of which
+// the likelihood itself is the smaller part (tools/mid_range.py).  This is pipe_chain_wave_one's
+// bookkeeping -- state in registers, a turn's draws / row offsets / Metropolis window 21 turns at
+// a time, history rows asked for a turn ahead (they travel while the likelihood runs) -- around
+// wavelet_body<1>: propose, bounds, transform, decide, publish, one turn after the other.  Snooker
+// without the support distribution, the shapes of host::cw_lean_eligible (thinning 1, no trace,
+// no priors, no shared parameters, strict lockstep), one chain per workgroup, one GPU.  Same
+// draws, same arithmetic in the same order as run_chain: bit-identical
+// (tests/test_gpu_parity.py).  MC3HIP_NO_WL_ONE: the general chain.
+template <int MT>
+__global__ __launch_bounds__(64) void wavelet_one_kernel(const DevProblem P, const int nref)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const SmemLayout L = carve(smem, P, 64);
+    const int lane = threadIdx.x & 63;
+    const int b = (int)blockIdx.x;
+    const int c = P.chain0 + b;
+    long long *ctl_rw = const_cast<long long *>(P.ctl);
+    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
+            &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+        return;
+    wavelet_stage<1, MT>(P, L.xs);
+    double *np = L.nextp;
+    if (lane < P.nparams)
+        np[lane] = P.params[lane];
+    if (lane + 64 < P.nparams)
+        np[lane + 64] = P.params[lane + 64];
+    block_sync<1>();
+    double *Zr = own_global(P.Z), *log_post = own_global(P.log_post);
+    int32_t *zchain = own_global(P.zchain);
+    const int nchains = P.nchains, nf = P.nfree, zs = P.zs;
+    const long long M0 = P.M0;
+    const double gamma = P.gamma;
+    const bool mine = lane < nf;
+    const int kk = mine ? lane : 0;
+    const long long R0 = P.ctl[0];
+    double xk;
+    {
+        const double *snap_first = (R0 == 0) ? own_global(P.snap0)
+                                             : Zr + (size_t)(M0 + (R0 - 1) * nchains) * zs;
+        xk = mine ? snap_first[(size_t)c * zs + lane] : 0.0;
+    }
+    double cur_c = P.chisq[b], best = P.best_chisq[b];
+    int nacc = 0;
+    unsigned long long oob = 0;
+    const int jfree = mine ? P.ifree[lane] : 0;
+    const double pmin_k = mine ? P.fmin[lane] : 0.0;
+    const double pmax_k = mine ? P.fmax[lane] : 0.0;
+    const long long abort_at = (P.test_abort >= 0 && b == 0) ? (long long)P.test_abort : -1;
+    // the draws of NB turns at once (pipe_chain_wave_one): lane 3 i + s = slot s of turn bbase + i
+    constexpr int LPR = 3, NB = 21;
+    unsigned long long A = 0, B = 0;
+    double blo = 0.0, bhi = 0.0;
+    int bbase = 0;
+    const int bs = lane % LPR, bi = (lane / LPR < NB) ? lane / LPR : NB - 1;
+    auto fill = [&](int n0) {                           // chain.py:195-205,259
+        const long long Rl = R0 + n0 + bi;
+        const Draw2 d = draw2(P.seed, (uint64_t)Rl, (uint32_t)c, (uint32_t)bs);
+        const unsigned long long zsz = (unsigned long long)(M0 + Rl * nchains);
+        if (bs == 0) {
+            const unsigned long long iR1 = bounded(d.q0, zsz);
+            unsigned long long iR2 = 1 + bounded(d.q1, zsz - 1);
+            if (iR2 == iR1)
+                iR2 = 0;
+            A = iR1 * (unsigned long long)zs;
+            B = iR2 * (unsigned long long)zs;
+        } else if (bs == 1) {
+            A = bounded(d.q1, zsz) * (unsigned long long)zs;
+            B = (u01(d.q0) < 0.1) ? 1ull : 0ull;
+        } else {
+            A = mc3_bits(1.2 + (2.2 - 1.2) * u01(d.q0));
+            B = mc3_bits(u01(d.q1));
+        }
+        accept_window(u01(d.q1), blo, bhi);
+        bbase = n0;
+    };
+    auto lane64 = [&](unsigned long long v, int l) {
+        return (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l) |
+               ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l)
+                << 32);
+    };
+    auto row_addresses = [&](int n, const double *(&ra)[3]) {
+        const int idx = LPR * (n - bbase);
+        ra[0] = Zr + (lane64(A, idx) + (unsigned)kk);
+        ra[1] = Zr + (lane64(B, idx) + (unsigned)kk);
+        ra[2] = Zr + (lane64(A, idx + 1) + (unsigned)kk);
+    };
+    double rv[3] = {}, rw[3] = {};
+    fill(0);
+    if (nref > 0) {
+        const double *ra[3];
+        row_addresses(0, ra);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            rv[q] = load_published<false>(ra[q]);
+    }
+    int done = 0;
+    for (int n = 0; n < nref; ++n) {
+        if (__builtin_expect(R0 + n == abort_at, 0)) {                 // test hook
+            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        // this turn's rows: asked for a turn ago (a row that was not written yet: asked again)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("; rows" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]));
+        int idx = LPR * (n - bbase);
+        const bool sjump = __builtin_amdgcn_readlane((int)(unsigned)B, idx + 1) != 0;
+        {
+            const bool there2 = !__any(mc3_bits(rv[0]) == ROW_PENDING ||
+                                       mc3_bits(rv[1]) == ROW_PENDING);
+            const bool there3 = there2 && !__any(mc3_bits(rv[2]) == ROW_PENDING);
+            if (__builtin_expect(!(sjump ? there3 : there2), 0)) {
+                const double *ra[3];
+                row_addresses(n, ra);
+                if (!wait_rows<3, false>(ra, rv, ctl_rw))
+                    break;
+            }
+        }
+        const double z1 = rv[0], z2 = rv[1], zk = rv[2];
+        const double gs = mc3_from_bits(lane64(A, idx + 2));
+        const double u = mc3_from_bits(lane64(B, idx + 2));           // chain.py:259
+        const double lo = read_lane(blo, idx + 2), hi = read_lane(bhi, idx + 2);
+        // the next turn's rows travel while this one's likelihood runs
+        if (n + 1 < nref) {
+            if (__builtin_expect(n + 1 >= bbase + NB, 0))
+                fill(n + 1);
+            const double *ra[3];
+            row_addresses(n + 1, ra);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                rw[q] = load_published<false>(ra[q]);
+        }
+        double jump_k;
+        if (__builtin_expect(sjump, 0)) {                             // chain.py:207-215
+            const bool same = __all(!mine || zk == xk);
+            if (same) {
+                jump_k = gs * (z2 - z1);
+            } else {
+                const double dz = xk - zk;
+                const double zp1 = lane_serial_sum(z1 * dz, nf);
+                const double zp2 = lane_serial_sum(z2 * dz, nf);
+                const double dd = lane_serial_sum(dz * dz, nf);
+                jump_k = ((gs * (zp1 - zp2)) * dz) / dd;
+            }
+        } else {
+            jump_k = gamma * (z1 - z2) + P.fepsilon * 0.0;             // chain.py:217
+        }
+        const double npk = xk + jump_k;                               // chain.py:235-243
+        const bool outk = mine && (npk < pmin_k || npk > pmax_k);
+        bool accepted = false;
+        if (!__any(outk)) {
+            if (mine)
+                np[jfree] = npk;
+            block_sync<1>();
+            const double total = block_wavelet<1, MT, false>(P, np, L.part, L.flag, L.tab, L.halo,
+                                                             L.xs);
+            // (as WaveletHook::finish: the prior term of a problem without priors is 0.0)
+            const double nextchisq = is_pos_inf(total) ? total : total + 0.0;
+            if (__builtin_expect(!sjump, 1)) {
+                accepted = metropolis_accept(0.5 * (cur_c - nextchisq), u, lo, hi);
+            } else {                                                  // chain.py:251-255
+                const double dc = xk - zk, dn = npk - zk;
+                const double cnorm = lane_serial_sum(mine ? dc * dc : 0.0, nf);
+                const double nnorm = lane_serial_sum(mine ? dn * dn : 0.0, nf);
+                const double mrfactor = mc3_det_pow_half(nnorm / cnorm, nf - 1);
+                accepted = mc3_det_exp(0.5 * (cur_c - nextchisq)) * mrfactor > u;
+            }
+            if (accepted) {                                           // chain.py:257-274
+                xk = npk;
+                cur_c = nextchisq;
+                nacc += 1;
+            }
+        } else {
+            oob += outk ? 1ull : 0ull;                                // chain.py:242-243
+        }
+        const long long row = M0 + (R0 + n) * nchains + c;            // chain.py:276-289
+        if (mine)
+            __hip_atomic_store(&Zr[(size_t)row * zs + lane], xk, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);             // publish (sc1)
+        if (lane == 0) {
+            log_post[row] = -0.5 * cur_c;
+            zchain[row] = c;
+        }
+        if (__builtin_expect(accepted && cur_c < best, 0)) {
+            best = cur_c;
+            if (mine)
+                P.bestx[(size_t)b * nf + lane] = xk;
+            if (lane == 0)
+                P.best_iter[b] = R0 + n;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            rv[q] = rw[q];
+        done = n + 1;
+    }
+    (void)done;
+    if (mine && oob)
+        atomicAdd(&P.outbounds[lane], oob);
+    if (mine)
+        P.X[(size_t)b * nf + lane] = xk;
+    if (lane == 0) {
+        P.chisq[b] = cur_c;
+        P.best_chisq[b] = best;
+        P.numaccept[b] += (long long)nacc;
+    }
+}
+
 }  // namespace mc3hip

@@ -460,6 +460,10 @@ int decide_persist(mc3hip_ctx *c)
     c->chainwave = c->P.wlike && c->wpc == 8 && !c->P.wl_scratch &&
                    !(c->flags & MC3HIP_FLAG_P2P) &&
                    c->smem + CW_EXTRA_DOUBLES * sizeof(double) <= 160 * 1024;
+    c->wl_one = !c->fast && c->P.wlike && c->wpc == 1 && !c->P.wl_scratch &&
+                cw_lean_eligible(c) && c->P.sampler == MC3HIP_SNOOKER && c->P.fepsilon == 0.0 &&
+                !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_WL_ONE") &&
+                !getenv("MC3HIP_NO_CW_LEAN");
     // (bit 1: an out-of-bounds proposal rides with the turn behind it, kernels_wavelet.h
     // pipe_chain_wave_one; MC3HIP_NO_CW_RIDE gives it a slot of its own as before)
     c->P.cw_lean = (c->chainwave && cw_lean_eligible(c) && !getenv("MC3HIP_NO_CW_LEAN"))
@@ -1216,6 +1220,8 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
         plan->waves_per_chain = lean_waves(c);      // (helper waves share the data sum)
     if (plan->persistent > 0 && chainwave_runs(c, c->p2p_ranks > 1) && c->P.cw_lean)
         plan->fast = 3;                             // (wavelet: the hand-structured chain wave)
+    if (plan->persistent > 0 && c->wl_one && c->mc_chains == 0 && c->p2p_ranks <= 1)
+        plan->fast = 3;                             // (... and its one-wave form)
     if (plan->persistent > 0 && c->resident && c->P.rs_lean)
         plan->fast = 4;                             // (resident plans: the hand-structured owner)
     plan->tile_tree = tile_uses_mfma(c) ? 2 : 0;

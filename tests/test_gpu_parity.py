@@ -287,6 +287,55 @@ def test_wavelet_chains_bit_exact(eng, ndata):
     gpu.close()
 
 
+@pytest.mark.parametrize('ndata', [2, 4, 8, 16, 64, 100, 128, 256, 512, 1024, 2048])
+@pytest.mark.parametrize('case', ['plain', 'tight', 'wide', 'resume', 'abort', 'switch'])
+def test_wavelet_one_wave_chain_by_hand(eng, monkeypatch, ndata, case):
+    """wavelet_one_kernel (round 5): up to 2 048 points, one wave per chain, snooker -- the chain
+    written out by hand around wavelet_body<1> (state in registers, draws 21 turns at a time,
+    rows a turn ahead) where the general chain ran: identical rows, counters, best fit to the
+    checker for every block size, with bounds that reject a third of the proposals, with none,
+    across launches (160 refreshes: the batch of draws is refilled seven times), through a
+    give-up, and behind the switch the general chain (the same results).  A series whose length
+    is no power of two (100 points) is padded by the caller (wl_nreal)."""
+    if ndata == 100:
+        prob = H.wavelet_problem(ndata=128, nchains=6, nsamples=6*160)
+        prob.update(wl_nreal=100)
+    else:
+        prob = H.wavelet_problem(ndata=ndata, nchains=6, nsamples=6*160)
+    if case == 'tight':
+        prob.update(pmin=np.array([2.6, -2.6, 0.47, 0.0, 0.3, 0.8]),
+                    pmax=np.array([3.4, -2.2, 0.53, 2.0, 0.7, 1.2]))
+    if case == 'wide':
+        prob.update(pmin=np.full(6, -1e3), pmax=np.full(6, 1e3))
+    if case == 'switch':
+        monkeypatch.setenv('MC3HIP_NO_WL_ONE', '1')
+    if case == 'abort':
+        monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '40')
+    if case == 'resume':
+        monkeypatch.setenv('MC3HIP_PERSIST_REFS', '23')
+        gpu = eng.DeviceChains(**prob)
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nthreads=4)
+        for n in (1, 2, 50, 107):
+            gpu.run(n)
+    else:
+        orc, gpu = run_pair(eng, prob, trace=False)
+    plan = gpu.plan
+    if case == 'abort':
+        assert plan['recoveries'] == 1, plan
+    else:
+        assert plan['persistent'] > 0 and plan['waves_per_chain'] == 1 and \
+            plan['recoveries'] == 0, plan
+        assert plan['fast'] == (0 if case == 'switch' else 3), plan
+    assert_same(orc, gpu, trace=False)
+    if case == 'tight' and ndata >= 64:
+        assert gpu.state()['outbounds'].sum() > 50
+    gpu.close()
+
+
 @pytest.mark.parametrize('ndata', [32768, 131072])
 def test_wavelet_beyond_2_14_points(eng, ndata):
     """More than 32 points per thread: strided pre-levels through global memory bring the
