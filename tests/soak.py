@@ -45,8 +45,9 @@ elif 'poly' in extras:
 elif int(extras.get('fx', 0)):
     prob = H.lean_shape_problem(nchains, niter, ndata=1000, sampler=sampler, fx=1, **kw)
 else:
-    prob = H.quad_problem(ndata=1000, nchains=nchains, nsamples=nchains*niter*thin,
-                          sampler=sampler, **kw)
+    # (ndata=8192: the tiles in the registers of several waves, round 5)
+    prob = H.quad_problem(ndata=int(extras.get('ndata', 1000)), nchains=nchains,
+                          nsamples=nchains*niter*thin, sampler=sampler, **kw)
 orc = H.make_oracle(prob)
 Z0, lp0 = H.initial_population(orc)
 orc.set_population(Z0, lp0)

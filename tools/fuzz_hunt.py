@@ -34,6 +34,9 @@ for seed in range(first, first + count):
         nch = int(rs.randint(2049, 10000))
         prob.update(nchains=nch, nsamples=nch*int(rs.randint(6, 16))*prob['thinning'],
                     zlag=int(rs.choice([0, 0, 1, 2, 5])))      # (strict, or the declared cadence)
+    elif kind == 5:
+        # round 5: 1 025 ... 16 384 points in the registers of several waves (FUZZ_KIND=5)
+        prob = F.wide_problem(seed)
     elif kind == 0:
         prob = F.random_problem(seed)
     elif kind == 1:
