@@ -166,6 +166,11 @@ typedef struct mc3hip_plan {
                                row bound for ANOTHER rank's replica is held back that long
                                before it is stored -- several ranks on one GPU then behave like
                                ranks an xGMI hop apart; 0 in production                        */
+    int32_t owner_waves;    /* resident tiled plan: > 0 = the chains' owners are that many waves
+                               of their own behind a workgroup's eight tile waves, and a tile
+                               wave makes up its blocks of sixteen chains at run time from the
+                               proposals that are there (resident_async_kernel: nobody waits
+                               for the ensemble's slowest chain); 0 = the phases in step      */
 } mc3hip_plan;
 
 /* Replaces Chain.__init__ + the shared-memory allocation of mcmc()

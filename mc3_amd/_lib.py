@@ -60,7 +60,8 @@ class Plan(ctypes.Structure):
                 ('tile_tree', ctypes.c_int32), ('resident', ctypes.c_int32),
                 ('chains_per_workgroup', ctypes.c_int32),
                 ('jit', ctypes.c_int32), ('capacity', ctypes.c_int32),
-                ('zlag', ctypes.c_int32), ('remote_delay_ns', ctypes.c_int32)]
+                ('zlag', ctypes.c_int32), ('remote_delay_ns', ctypes.c_int32),
+                ('owner_waves', ctypes.c_int32)]
 
 
 class Mc3HipError(RuntimeError):

@@ -100,7 +100,8 @@ struct DevProblem {
     // double its own "ready" flag (all-ones = not there yet, as for Z rows)
     double *rs_prop;              // [2][nlocal][RS_ROW] proposed coefficients, by iteration parity
     double *rs_part;              // [nlocal][rs_ntp]    per-tile data sums of the running iteration
-    int32_t rs_ntp, _pad_rs;      // ntiles rounded up to whole 128-byte lines
+    int32_t rs_ntp;               // ntiles rounded up to whole 128-byte lines
+    int32_t rs_sched_rows;        // rs_sched: rows per column of chains
     // wavelet likelihood, abscissae on np.linspace's grid (x_i = fl(fl(i*step) + x0), last
     // point = wl_xlast; checked bit for bit at creation): they are recomputed instead of
     // stored, which frees the LDS for the data values
@@ -123,12 +124,21 @@ struct DevProblem {
     // resident tiled plans: the hand-structured owner serves this problem (resident.h
     // lean_resident_owner, host::rs_lean_eligible)
     int32_t rs_lean;
+    // resident_async_kernel: the blocks of sixteen chains a column's scheduler wave has made up,
+    // in the order every tile wave of the column takes them -- [columns][rs_sched_rows][16]
+    // words (rs_gen << 32 | chains of the block << 8 | chain of the slot); a word of another
+    // launch's rs_gen = not there yet
+    int32_t rs_gen;
+    unsigned long long *rs_sched;
 };
 
 constexpr int PH_FUSED = 0, PH_PROPOSE = 1, PH_FINISH = 2, PH_RESIDENT = 3, PH_CHAINWAVE = 4;
 // the phases in which ONE wave runs the chain and the data term comes back through a hook
 constexpr bool phase_hooked(int phase) { return phase == PH_RESIDENT || phase == PH_CHAINWAVE; }
 constexpr int RS_ROW = 16;          // doubles per published proposal row: one 128-byte line
+constexpr int RA_CMAX = 128;        // resident_async_kernel: chains of a column (two per lane of a
+                                    // tile wave), owner waves of a workgroup at most
+constexpr int RA_OWNERS = 3;        // (a twelfth wave, in the workgroups of tile 0: the scheduler)
 constexpr int RS_WCAP = 256;        // chains whose group totals a workgroup collects in LDS
                                     // before it adds them up (resident tiled plan)
 constexpr int SC_STRIDE = MC3HIP_MAX_PARAMS + 16;   // doubles per sc_nextp row (zero padded)

@@ -71,6 +71,11 @@ struct mc3hip_ctx {
     int tile_chain_block = 0;       // chains per workgroup column of the tile kernel
     bool resident = false;          // tiled plan as one persistent launch (resident_tile_kernel)
     int resident_chain_block = 0;   // its column height
+    // ... with the owners as waves of their own and the blocks of chains made up at run time
+    // (resident_async_kernel): that many owner waves behind the eight tile waves, 0 = the
+    // kernel in step
+    int resident_owner_waves = 0;
+    size_t rs_sched_words = 0;      // (its scheduler's rows, DevProblem::rs_sched: words allocated)
     bool ckpt_settled = false;      // peer-to-peer: the launches since the checkpoint completed
                                     // HERE; confirmed by the caller's next mc3hip_run
     double *moments = nullptr;      // scratch of mc3hip_chain_moments (2 x nchains x nfree)
@@ -126,6 +131,13 @@ inline bool rs_lean_eligible(const mc3hip_ctx *c)
 inline bool resident_owner_lean(const mc3hip_ctx *c)
 {
     return rs_lean_eligible(c) && !getenv("MC3HIP_NO_RS_LEAN");
+}
+// ... and the shapes resident_async_kernel takes (the grid permitting: decide_persist): design
+// matrices through the matrix cores with the hand-structured owner
+inline bool resident_async_shape(const mc3hip_ctx *c)
+{
+    return resident_owner_lean(c) && c->mt == MT_LINEAR && c->P.tile == 2048 &&
+           !getenv("MC3HIP_NO_RS_ASYNC");
 }
 inline bool chainwave_runs(const mc3hip_ctx *c, bool p2p)
 {
@@ -470,6 +482,10 @@ hipError_t tile_set_attr(mc3hip_ctx *c);
 // ---- k_resident.hip: the tiled plan as one persistent launch -----------------------------
 resident_kernel_fn resident_kernel(const mc3hip_ctx *c, bool p2p);
 size_t resident_lds_bytes(const mc3hip_ctx *c);
+// (the kernel that runs, its workgroup: the one in step, or resident_async_kernel when
+// c->resident_owner_waves > 0)
+resident_kernel_fn resident_async_kernel_of(const mc3hip_ctx *c, bool p2p);
+size_t resident_async_lds_bytes(const mc3hip_ctx *c);
 
 }  // namespace host
 }  // namespace mc3hip

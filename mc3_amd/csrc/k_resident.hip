@@ -17,7 +17,19 @@ constexpr size_t RESIDENT_LDS_BYTES_REGS = (RS_WCAP * 16 + 2 + 8 * RESIDENT_OWN)
 // polynomials (ResidentPoly): two exchange buffers [16][512], the give-up word, the areas
 constexpr size_t RESIDENT_POLY_LDS_BYTES = (2 * 16 * 512 + 2 + 8 * RESIDENT_OWN) * sizeof(double);
 
+// resident_async_kernel: the waves' row totals [RA_CMAX][8], counters, blocks made up, the
+// give-up word, the owners' areas, the operand blocks beyond two
+constexpr size_t RESIDENT_ASYNC_LDS_DOUBLES =
+    (RA_CMAX + 1) * 8 + RA_CMAX / 2 + 1 + 144 + 2 + RA_OWNERS * RESIDENT_OWN;
+
 }  // namespace
+
+size_t resident_async_lds_bytes(const mc3hip_ctx *c)
+{
+    // (operand blocks beyond two live in LDS, [16][512] each)
+    const int kb = (c->P.nmodel + 4) / 4;
+    return (RESIDENT_ASYNC_LDS_DOUBLES + (kb > 2 ? (kb - 2) * 16 * 512 : 0)) * sizeof(double);
+}
 
 size_t resident_lds_bytes(const mc3hip_ctx *c)
 {
@@ -45,6 +57,24 @@ resident_kernel_fn pick(const mc3hip_ctx *c)
     }
 }
 }  // namespace
+
+namespace {
+template <bool P2P>
+resident_kernel_fn pick_async(const mc3hip_ctx *c)
+{
+    switch ((c->P.nmodel + 4) / 4) {
+    case 1: return resident_async_kernel<1, P2P>;
+    case 2: return resident_async_kernel<2, P2P>;
+    case 3: return resident_async_kernel<3, P2P>;
+    default: return resident_async_kernel<4, P2P>;
+    }
+}
+}  // namespace
+
+resident_kernel_fn resident_async_kernel_of(const mc3hip_ctx *c, bool p2p)
+{
+    return p2p ? pick_async<true>(c) : pick_async<false>(c);
+}
 
 // (the owner -- hand-structured or general -- is a function of the problem alone, so the
 // occupancy query that sizes the grid and the launch agree: ctx.h resident_owner_lean)

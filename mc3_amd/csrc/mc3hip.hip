@@ -210,6 +210,14 @@ void launch_resident(mc3hip_ctx *c, int nref)
 {
     const int cb = c->resident_chain_block;
     const int ncol = (c->P.nlocal + cb - 1) / cb;
+    if (c->resident_owner_waves > 0) {
+        // (the scheduler's blocks of this launch are told from any other's by its number)
+        c->P.rs_gen = (c->P.rs_gen == 0x7fffffff) ? 1 : c->P.rs_gen + 1;
+        hipLaunchKernelGGL(resident_async_kernel_of(c, c->p2p_ranks > 1), dim3(c->P.ntiles, ncol),
+                           dim3(512 + 64 * (c->resident_owner_waves + 1)),
+                           resident_async_lds_bytes(c), c->stream, c->P, nref, cb);
+        return;
+    }
     hipLaunchKernelGGL(resident_kernel(c, c->p2p_ranks > 1), dim3(c->P.ntiles, ncol), dim3(512),
                        resident_lds_bytes(c), c->stream, c->P, nref, cb);
 }
@@ -448,6 +456,43 @@ int decide_persist(mc3hip_ctx *c)
         c->capacity = capacity;
         c->resident_chain_block = (int)cb;
         c->P.rs_lean = resident_owner_lean(c) ? 1 : 0;
+        // the owners as waves of their own, the blocks of chains made up at run time
+        // (resident.h resident_async_kernel): one workgroup per CU, a column of at most
+        // RA_CMAX chains, at most RA_OWNERS chains to own per workgroup
+        c->resident_owner_waves = 0;
+        const long long nwg = ncol * c->P.ntiles;
+        const long long owners = ((long long)c->P.nlocal + nwg - 1) / nwg;
+        if (resident_async_shape(c) && cb <= RA_CMAX && owners <= RA_OWNERS &&
+            nwg <= prop.multiProcessorCount) {
+            bool fits = true;
+            for (int p2p = 0; p2p < 2; ++p2p) {
+                if (p2p != (c->p2p_ranks > 1 ? 1 : 0) && !(c->flags & MC3HIP_FLAG_P2P))
+                    continue;
+                const void *f = reinterpret_cast<const void *>(
+                    resident_async_kernel_of(c, p2p != 0));
+                (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)resident_async_lds_bytes(c));
+                fits = fits && blocks_per_cu(f, 512 + 64 * ((int)owners + 1),
+                                             resident_async_lds_bytes(c)) >= 1;
+            }
+            // the scheduler's blocks: a row of sixteen words per block of a launch's iterations
+            const long long refs = getenv("MC3HIP_PERSIST_REFS") &&
+                                   atoi(getenv("MC3HIP_PERSIST_REFS")) > 0
+                                       ? atoi(getenv("MC3HIP_PERSIST_REFS")) : 16384;
+            const long long rows = refs * ((cb + 15) / 16);
+            const size_t words = (size_t)ncol * rows * 16;
+            if (fits && words > c->rs_sched_words) {
+                c->rs_sched_words = words;
+                fits = dev_alloc(c, &c->P.rs_sched, words) == MC3HIP_OK &&
+                       hipMemset(c->P.rs_sched, 0, words * sizeof(unsigned long long)) ==
+                           hipSuccess;
+                c->P.rs_gen = 0;
+            }
+            if (fits) {
+                c->resident_owner_waves = (int)owners;
+                c->P.rs_sched_rows = (int)rows;
+            }
+        }
         c->fast = false;
         c->persist_refs = 16384;
         if (const char *e = getenv("MC3HIP_PERSIST_REFS"))
@@ -1120,8 +1165,10 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
     }
     TRY(dev_alloc(c, &c->ctl, 4));
     P.ctl = c->ctl;
-    TRY(dev_alloc(c, &P.stamps, 32));
-    HIP_TRY_C(hipMemset(P.stamps, 0, 32 * sizeof(unsigned long long)));
+    // (32 phase stamps; the rest is the timeline of one iteration that a -DMC3HIP_TIMELINE
+    // build of a kernel writes: tools/timeline_c5.py)
+    TRY(dev_alloc(c, &P.stamps, 65536));
+    HIP_TRY_C(hipMemset(P.stamps, 0, 65536 * sizeof(unsigned long long)));
     HIP_TRY_C(hipMemset(c->ctl, 0, 4 * sizeof(long long)));
     // all-ones = "row not written yet" (the persistent kernel's hand-off sentinel)
     HIP_TRY_C(hipMemset(P.Z, 0xff, zl * zs * sizeof(double)));
@@ -1231,6 +1278,7 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
     plan->chains_per_workgroup = (plan->persistent > 0 && c->mc_chains > 0) ? c->mc_chains : 1;
     plan->zlag = c->P.zlag;
     plan->remote_delay_ns = c->P.remote_delay * 10;
+    plan->owner_waves = (plan->persistent > 0 && c->resident) ? c->resident_owner_waves : 0;
     return MC3HIP_OK;
 }
 
@@ -2631,10 +2679,12 @@ int mc3hip_debug_stamps(mc3hip_ctx *c, uint64_t *out16)
         if (rc_settle)
             return rc_settle;
     }
-    // (MC3HIP_STAMP_PAGE=1: the second group of sixteen, the resident tiled plan's phases)
+    // (MC3HIP_STAMP_PAGE=1: the second group of sixteen, the resident tiled plan's phases;
+    // pages 2..4095: a timeline build's records)
     const char *page = getenv("MC3HIP_STAMP_PAGE");
-    HIP_TRY(hipMemcpy(out16, c->P.stamps + ((page && atoi(page) == 1) ? 16 : 0),
-                      16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    const int pg = (page && atoi(page) > 0 && atoi(page) < 4096) ? atoi(page) : 0;
+    HIP_TRY(hipMemcpy(out16, c->P.stamps + 16 * (size_t)pg, 16 * sizeof(uint64_t),
+                      hipMemcpyDeviceToHost));
     return MC3HIP_OK;
 }
 

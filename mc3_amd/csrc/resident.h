@@ -6,6 +6,21 @@
 
 namespace mc3hip {
 
+// -DMC3HIP_TIMELINE=R (with MC3HIP_STAMPS): who did what when in iteration R of a launch, on the
+// 100 MHz clock all CUs share -- P.stamps[1024 + 4 c + k]: chain c's owner (partner rows there,
+// proposal published, sums collected, row published); [4096 + 16 col + b]: the scheduler
+// published block b; [8192 + 32 wg + 4 b + k]: tile wave 0 of a workgroup (block b taken,
+// rows there, products begun, sums left); [16384 + c]: the block chain c was in
+#ifdef MC3HIP_TIMELINE
+#define MC3_TL(cond, slot)                                                                \
+    do {                                                                                  \
+        if (cond)                                                                         \
+            P.stamps[slot] = __builtin_amdgcn_s_memrealtime();                            \
+    } while (0)
+#else
+#define MC3_TL(cond, slot) do { } while (0)
+#endif
+
 // ---- resident tiled plan --------------------------------------------------------------
 // The tiled plan as ONE launch (design-matrix models through the matrix cores; one GPU, or
 // one launch per GPU with the Z rows published to every rank).  The grid is the tile kernel's
@@ -145,13 +160,15 @@ struct ResidentOwner {
     }
 };
 
-template <int KB>
+template <int KB, int KRMAX = 3>
 struct ResidentTile : ResidentOwner {
     // operand rows of the tile: blocks of four rows in registers (up to three: 96 registers);
     // a fourth block (12..15 coefficients + the data) lives in LDS, 64 KB, one read per product
-    static constexpr int KR = (KB == 4) ? 3 : KB;
+    // (KRMAX = 2, resident_async_kernel: two in registers, the others in LDS)
+    static constexpr int KR = (KB > KRMAX) ? KRMAX : KB;
+    static constexpr int KL = KB - KR;              // blocks in LDS
     double bop[8][2][KR];
-    const double *s_b;      // LDS [16][512]: this thread's operands of row block KR
+    const double *s_b;      // LDS [KL][16][512]: this thread's operands of row blocks KR..
     double *s_w;            // LDS [RS_WCAP][16]: row totals of the chains done so far ([8..15] = 0)
     int *s_stop;            // LDS: a wave of this workgroup has given up
     int t, c0, c1, wv;
@@ -183,9 +200,9 @@ struct ResidentTile : ResidentOwner {
                     const int k = 4 * kb + g;
                     const double v = (k <= K) ? P.aw[(size_t)k * P.npad + i] : 0.0;
                     if (kb < KR)
-                        bop[vb][h][kb] = v;
+                        bop[vb][h][kb < KR ? kb : 0] = v;
                     else
-                        lds_b[(2 * vb + h) * 512 + threadIdx.x] = v;
+                        lds_b[((kb - KR) * 16 + 2 * vb + h) * 512 + threadIdx.x] = v;
                 }
             }
         }
@@ -435,7 +452,9 @@ struct ResidentPoly : ResidentOwner {
 // next draws and log u are computed while the partner rows travel, the partners of the next
 // iteration are asked for right behind the own row, and the launch arguments are scalars of
 // their own.  Same arithmetic in the same order: bit-identical to run_chain's.
-template <int MT, bool P2P, class H>
+// ASYNC: the owner is a wave of its own (resident_async_kernel below): nothing of the tile phase
+// is its business, it publishes, waits for the sums and goes on.
+template <int MT, bool P2P, class H, bool ASYNC = false>
 __device__ __forceinline__ void lean_resident_owner(const DevProblem &P, const int nref, H &T,
                                                     const int lc, double *area)
 {
@@ -546,6 +565,10 @@ __device__ __forceinline__ void lean_resident_owner(const DevProblem &P, const i
             normal_ahead = normal_draw((uint64_t)(R + 1));
         alive = wait_rows<2, P2P>(ra, rv, ctl_rw) && alive;
         MC3_TICK(tk1);
+#ifdef MC3HIP_TIMELINE
+        const bool tl_on = ASYNC && R - R0 == MC3HIP_TIMELINE && lane == 0;
+        MC3_TL(tl_on, 1024 + 4 * lc);
+#endif
         const double jump_k = gamma * (rv[0] - rv[1]) + fepsilon * normal_k;
         // proposal and boundaries, chain.py:235-243
         const double npk = xk + jump_k;
@@ -555,7 +578,17 @@ __device__ __forceinline__ void lean_resident_owner(const DevProblem &P, const i
             s_nextp[jfree] = npk;
         T.publish(P, lc, s_nextp);
         MC3_TICK(tkP);
-        alive = T.tile_phase(P, alive && !give_up);
+#ifdef MC3HIP_TIMELINE
+        MC3_TL(tl_on, 1024 + 4 * lc + 1);
+#endif
+        if constexpr (ASYNC) {
+            // (a wait that timed out has told everybody: ctl[CTL_ABORT])
+            if (!alive || give_up)
+                break;
+            T.par ^= 1;
+        } else {
+            alive = T.tile_phase(P, alive && !give_up);
+        }
         MC3_TICK(tkT);
         if (!alive)
             break;
@@ -563,6 +596,13 @@ __device__ __forceinline__ void lean_resident_owner(const DevProblem &P, const i
         // reused)
         const double total = T.collect(P, lc);
         MC3_TICK(tkC);
+#ifdef MC3HIP_TIMELINE
+        MC3_TL(tl_on, 1024 + 4 * lc + 2);
+#endif
+        if constexpr (ASYNC) {
+            if (T.failed)
+                break;
+        }
         bool accepted = false;
         if (!anyout) {
             const double nextchisq = T.template finish<MT>(P, total, s_nextp);
@@ -585,6 +625,9 @@ __device__ __forceinline__ void lean_resident_owner(const DevProblem &P, const i
             __hip_atomic_store(&Zr[(size_t)row * zs + lane], xk, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);           // publish (sc1)
         }
+#ifdef MC3HIP_TIMELINE
+        MC3_TL(tl_on, 1024 + 4 * lc + 3);
+#endif
         // the partners' rows of this refresh: asked for right behind the own row
         request_rows(nxt.q0, R + 1);
         if (lane == 0) {
@@ -708,6 +751,568 @@ __global__ __launch_bounds__(512) void resident_poly_kernel(const DevProblem P, 
             for (int j = 0; j < P.thinning; ++j)
                 if (!T.tile_phase(P, true))
                     return;
+    }
+}
+
+
+// ---- the resident tiled plan with nobody in step with anybody ------------------------------
+// resident_tile_kernel above runs an iteration as three phases the whole grid goes through
+// together: the owners propose, every workgroup adds up its tile for the chains of its column,
+// the owners collect and decide -- and while the owners work (10 500 of C5's 71 000 cycles,
+// tools/ticks.py c5) the matrix pipes idle, as they do while a column waits for its slowest
+// proposal.  Nothing in the algorithm asks for that: chain c's proposal of iteration R + 1
+// needs its own decision of iteration R and those of its TWO partners (chain.py:221-232), not
+// the whole ensemble's, and a block of sixteen chains in the matrix instruction is sixteen
+// independent columns of the product -- WHICH sixteen chains share a block changes no bit of
+// any chain's sum.  So here
+//   * the owners are waves of their own (8 .. 8 + RA_OWNERS - 1 of every workgroup, one chain
+//     each: lean_resident_owner<.., ASYNC>), not tile waves: a chain is decided as soon as its
+//     sums are there, whatever the tile waves are at;
+//   * the blocks of an iteration are made up at run time, per column of chains, from the
+//     chains whose proposal IS THERE: a scheduler wave (the twelfth wave of the column's
+//     workgroup of tile 0) looks at element 0 of the rows, takes up to sixteen chains, lowest
+//     first -- never fewer than would add a block to the iteration -- and publishes the block
+//     (P.rs_sched); all chains of iteration R before any of R + 1, which keeps the two-row
+//     parity scheme of rs_prop and the slots of rs_part what they were (a chain's proposal of
+//     R + 1 exists only after every wave of every tile has added its share of R).  Every tile
+//     wave of the column takes the blocks in that order, each at its own pace, a block ahead
+//     of its products.  (ONE order per column: a chain's sum is complete when the LAST of the
+//     column's 49 x 8 waves has taken it -- with every wave making up its own blocks, each
+//     chain was in somebody's last block, and the iteration was in step again: 39 us.)
+//   * the eight waves' row totals of a chain meet in LDS without a barrier: a wave leaves its
+//     total and counts itself in (ds_inc, wrapping at eight); the wave that counts last adds
+//     the eight up -- strides 4..1, the order tile_phase's sixteen-lane tree has -- and
+//     publishes the tile's sum.
+// At the start of an iteration the chains whose partners were decided early in the previous
+// one are there (two thirds of them), and by the time those are done so are the others: the
+// tile waves only wait when the owners' path is longer than five blocks of matrix work.
+// Same arithmetic in the same order for every chain: the checker cannot tell which of the two
+// kernels ran (tests/test_gpu_resident.py).
+// (RA_CMAX chains of a column, RA_OWNERS owner waves: core.h)
+// the steps of a block's sixteen before which a tile wave looks for the next block (the second
+// time if the first look found nothing)
+#ifndef MC3HIP_RA_TAKE_AT
+#define MC3HIP_RA_TAKE_AT 6
+#endif
+#ifndef MC3HIP_RA_TAKE_AGAIN
+#define MC3HIP_RA_TAKE_AGAIN 12
+#endif
+constexpr int RA_TAKE_AT = MC3HIP_RA_TAKE_AT, RA_TAKE_AGAIN = MC3HIP_RA_TAKE_AGAIN;
+#ifndef MC3HIP_RA_PRIO
+#define MC3HIP_RA_PRIO 2
+#endif
+
+__device__ __forceinline__ unsigned lds_offset(const void *p)
+{
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
+}
+
+// A wave's row totals of the four chains of a lane (slots g, g + 4, g + 8, g + 12 of its block)
+// into their slots, and the wave counted in for each: old[r] = 7 = it is the last of the eight.
+// One inline assembly -- a counter must not overtake its total, no fence the compiler knows
+// would let the proposal rows already asked for stay in flight, and four LDS round trips one
+// after the other (with the adding-up of a chain between them) were a third of the time
+// between two blocks.
+__device__ __forceinline__ void tile_part_arrive4(double *const (&slot)[4], const double (&v)[4],
+                                                  unsigned *const (&cnt)[4], unsigned (&old)[4])
+{
+    asm volatile("ds_write_b64 %4, %8\n\tds_inc_rtn_u32 %0, %12, %16\n\t"
+                 "ds_write_b64 %5, %9\n\tds_inc_rtn_u32 %1, %13, %16\n\t"
+                 "ds_write_b64 %6, %10\n\tds_inc_rtn_u32 %2, %14, %16\n\t"
+                 "ds_write_b64 %7, %11\n\tds_inc_rtn_u32 %3, %15, %16\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3])
+                 : "v"(lds_offset(slot[0])), "v"(lds_offset(slot[1])), "v"(lds_offset(slot[2])),
+                   "v"(lds_offset(slot[3])), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]),
+                   "v"(lds_offset(cnt[0])), "v"(lds_offset(cnt[1])), "v"(lds_offset(cnt[2])),
+                   "v"(lds_offset(cnt[3])), "v"(7u)
+                 : "memory");
+}
+
+__device__ __forceinline__ unsigned long long load_sched(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// false: the launch is being given up (said to everybody if it was this wave that lost patience)
+__device__ __forceinline__ bool async_patience(unsigned &spins, long long *ctl)
+{
+    if (__builtin_expect((++spins & 255u) == 0u, 0)) {
+        const int ab = __builtin_amdgcn_readfirstlane(
+            (int)(__hip_atomic_load(&ctl[CTL_ABORT], __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT) != 0));
+        if (ab != 0 || spins > (1u << 22)) {
+            if (ab == 0)
+                __hip_atomic_store(&ctl[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+    return true;
+}
+
+// The scheduler wave of a column of n chains (c0 ..): the blocks of every iteration of the
+// launch, in P.rs_sched's rows of the column.  sel: 16 ints of LDS of its own.
+__device__ __forceinline__ void resident_scheduler(const DevProblem &P, const int nref,
+                                                   const int col, const int c0, const int n,
+                                                   int *sel)
+{
+    long long *ctl = const_cast<long long *>(P.ctl);
+    const int lane = threadIdx.x & 63;
+    const size_t pstride = (size_t)P.nlocal * RS_ROW;
+    unsigned long long *rows = P.rs_sched + (size_t)col * P.rs_sched_rows * 16;
+    const unsigned long long gen = (unsigned long long)(unsigned)P.rs_gen << 32;
+    const int l0 = (lane < n) ? lane : 0, l1 = (lane + 64 < n) ? lane + 64 : 0;
+    unsigned spins = 0;
+    long long seq = 0;
+    for (int R = 0; R < nref; ++R) {
+        const double *prop = P.rs_prop + (size_t)(R & 1) * pstride;
+        // chains lane and lane + 64 of the column: still to do in this iteration
+        bool rem0 = lane < n, rem1 = lane + 64 < n;
+        int nrem = n;
+        while (nrem > 0) {
+            // is the proposal there?  (element 0 of the row; a tile wave waits for the rest
+            // when it uses the row)
+            const double f0 = load_published(prop + (size_t)(c0 + l0) * RS_ROW);
+            const double f1 = (n > 64) ? load_published(prop + (size_t)(c0 + l1) * RS_ROW)
+                                       : mc3_from_bits(ROW_PENDING);
+            const bool r0 = rem0 && mc3_bits(f0) != ROW_PENDING;
+            const bool r1 = rem1 && mc3_bits(f1) != ROW_PENDING;
+            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(r0);
+            const unsigned long long m1 = __builtin_amdgcn_ballot_w64(r1);
+            const int p0 = __builtin_popcountll(m0), p1 = __builtin_popcountll(m1);
+            const int nready = p0 + p1;
+            const int ragged = nrem - 16 * ((nrem + 15) / 16 - 1);     // 1..16
+            if (nready < ragged) {
+                if (!async_patience(spins, ctl))
+                    return;
+                continue;
+            }
+            spins = 0;
+            const int rank0 = (int)__builtin_amdgcn_mbcnt_hi(
+                (unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u));
+            const int rank1 = (p0 < 16 ? p0 : 16) + (int)__builtin_amdgcn_mbcnt_hi(
+                (unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
+            const bool t0 = r0 && rank0 < 16, t1 = r1 && rank1 < 16;
+            const int nt = nready < 16 ? nready : 16;
+            __builtin_amdgcn_wave_barrier();
+            if (t0)
+                sel[rank0] = lane;
+            if (t1)
+                sel[rank1] = lane + 64;
+            __builtin_amdgcn_wave_barrier();
+            // (slots beyond the block: its first chain again, multiplied and not used)
+            const int id = sel[(lane & 15) < nt ? (lane & 15) : 0];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 16)
+                __hip_atomic_store(&rows[seq * 16 + lane],
+                                   gen | ((unsigned long long)nt << 8) | (unsigned long long)id,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef MC3HIP_TIMELINE
+            if (R == MC3HIP_TIMELINE) {
+                const int b_ = (n - nrem) / 16;
+                MC3_TL(lane == 0 && b_ < 16, 4096 + 16 * col + b_);
+                if (lane < nt)
+                    P.stamps[16384 + c0 + id] = (unsigned long long)b_;
+            }
+#endif
+            ++seq;
+            rem0 = rem0 && !t0;
+            rem1 = rem1 && !t1;
+            nrem -= nt;
+        }
+    }
+}
+
+// (diagnostic build: the tile wave's phases on the 100 MHz clock -- the shader clock's own
+// count stalls while FP64 matrix instructions run: 5 018 "cycles" for a pair of blocks that
+// takes 3.18 us, tools/probes/tile_products_probe.hip)
+#ifdef MC3HIP_STAMPS
+#define MC3_RTICK(var)                                                                    \
+    do {                                                                                  \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");    \
+    } while (0)
+#else
+#define MC3_RTICK(var) do { } while (0)
+#endif
+
+// (two blocks of operand rows in registers, the others in LDS: with twelve waves on the CU a
+// wave has 168 registers, and three blocks -- 96 of them -- leave too few for the rest)
+template <int KB>
+struct ResidentTileAsync : ResidentTile<KB, 2> {
+    static constexpr int KR = ResidentTile<KB, 2>::KR;
+    static constexpr int KL = ResidentTile<KB, 2>::KL;
+
+    // a tile wave, for the whole launch.  s_part [RA_CMAX][8]: the waves' row totals of a
+    // chain; s_cnt [RA_CMAX]: waves counted in; s_sel [9][2][16]: the chains of a wave's blocks
+    // (the one in hand, the next); s_prog [8]: blocks taken so far, by wave.
+    // A turn of the loop multiplies the block in hand and, meanwhile, takes the one after: it
+    // looks at the scheduler's next row twice -- RA_TAKE_AT steps into the products (the row
+    // was asked for at the end of the turn before) and, if it was not there, again at step
+    // RA_TAKE_AGAIN -- and asks for the rows of the chains it finds, which travel behind the
+    // rest of the products.  A turn with no block in hand (the launch's first, or both looks of
+    // the turn before found nothing) only looks.
+    // Where loads go is laid out by hand: two places that load into the SAME variables meet at
+    // a join where the compiler copies one into the other -- and waits for the load to copy
+    // it, i.e. before the products the load should travel behind.  So the next row is asked
+    // for in ONE place (the end of a turn), the second look has variables of its own (w2, the
+    // rows of its chains in aop2), and what was loaded is copied only where it is waited for
+    // anyway.  The sums are published AFTER the wait for the next block's rows: the wait is
+    // for everything the wave has in flight (vmcnt(0)), and behind a store that is a round trip
+    // for its acknowledgement.
+    __device__ __forceinline__ void run(const DevProblem &P, const int nref, double *s_part,
+                                        unsigned *s_cnt, int *s_sel, int *s_prog)
+    {
+        long long *ctl = const_cast<long long *>(P.ctl);
+        const int lane = this->lane, j = lane & 15, g = lane >> 4;
+        const int wv = this->wv, c0 = this->c0, n = this->c1 - this->c0, t = this->t;
+        int *const sel2 = s_sel + 32 * wv;
+        const unsigned long long *rows =
+            P.rs_sched + (size_t)blockIdx.y * P.rs_sched_rows * 16 + j;
+        const unsigned gen = (unsigned)P.rs_gen;
+        int R = 0, nrem = n;
+        bool done = false;                  // every block of the launch has been taken
+        bool have = false;                  // a block is in hand: a[], cur_nt, cur_sel
+        long long seq = 0;                  // the scheduler's next block
+        unsigned long long w = load_sched(rows), w2 = 0;
+        double aop1[KB], aop2[KB], a[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+            aop1[kb] = aop2[kb] = a[kb] = 0.0;
+        int nt = 0, lc_next = c0, buf = 0, cur_nt = 0;
+        const int *cur_sel = sel2;
+        int wo = 0;
+        unsigned spins = 0;
+#ifdef MC3HIP_TIMELINE
+        int tl_next = -1, tl_cur = -1;
+#endif
+#ifdef MC3HIP_STAMPS
+        // (diagnostic build: wave 0 of workgroup 0 -- blocks multiplied, turns with nothing in
+        // hand, cycles multiplying, waiting for rows, in all)
+        unsigned long long tq_blocks = 0, tq_idle = 0, tq_mul = 0, tq_wait = 0, tq_begin = 0;
+        unsigned long long tq_arrive = 0, tq_finish = 0, tq_turn = 0, tq_last = 0;
+        MC3_RTICK(tq_begin);
+#endif
+                // the scheduler's next block, if word ww says it is there (word j = slot j's chain)
+        auto take = [&](const unsigned long long ww) -> bool {
+            if (!__all((unsigned)(ww >> 32) == gen))
+                return false;
+            nt = __builtin_amdgcn_readfirstlane((int)((unsigned)ww >> 8) & 0xff);
+            const int id = (int)((unsigned)ww & 0xffu);
+            int *const sel = sel2 + 16 * buf;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 16)
+                sel[lane] = id;
+            __builtin_amdgcn_wave_barrier();
+            lc_next = (R & 1) * P.nlocal + c0 + id;
+            buf ^= 1;
+#ifndef MC3HIP_RA_NO_BALANCE
+            // The two tile waves of a SIMD (v and v ^ 4) share its FP64 pipe, and the arbiter
+            // serves the older one first: left alone, waves 0..3 run blocks ahead of 4..7 --
+            // and a chain's sum is complete when the LAST wave has added its share
+            // (tools/timeline_c5.py: sums collected 10 us after wave 0 had left the block).
+            // The one that is behind goes first.
+            {
+                s_prog[wv] = (int)seq;
+                const int other = s_prog[wv ^ 4];
+                if ((int)seq > other)
+                    __builtin_amdgcn_s_setprio(0);
+                else
+                    __builtin_amdgcn_s_setprio(1);
+            }
+#endif
+#ifdef MC3HIP_TIMELINE
+            tl_next = (R == MC3HIP_TIMELINE && wv == 0) ? (n - nrem) / 16 : -1;
+            MC3_TL(tl_next >= 0 && tl_next < 8 && lane == 0,
+                   8192 + 32 * (blockIdx.y * gridDim.x + blockIdx.x) + 4 * tl_next);
+#endif
+            ++seq;
+            nrem -= nt;
+            if (nrem == 0) {
+                if (R + 1 == nref) {
+                    done = true;
+                } else {
+                    ++R;
+                    nrem = n;
+                }
+            }
+            return true;
+        };
+        for (;;) {
+            unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0;
+            (void)tq0; (void)tq1; (void)tq2; (void)tq3; (void)tq4;
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};      // chain of slot g + 4 r: this lane's points
+            // Steps S0 .. S1 - 1 of the block in hand, in the order they are to be issued: the
+            // products of step s + 1 BEFORE the four multiply-adds of step s (whose products
+            // have long left the pipe by then: no wait), the LDS operands two steps ahead --
+            // one wave alone keeps the FP64 pipe busy that way, whatever its partner on the
+            // SIMD is doing.  (tools/probes/tile_products_probe.hip: 3.19 us per block and
+            // pair of waves, 3.65 in the compiler's order.)
+            constexpr int KLX = KL > 0 ? KL : 1;
+            auto lds_ops = [&](const int st, double(&bl)[KLX]) {
+#pragma unroll
+                for (int q = 0; q < KL; ++q)
+                    bl[q] = this->s_b[wo + (q * 16 + st) * 512];
+            };
+            auto chain = [&](const int st, const double(&bl)[KLX]) {
+                const int vb = st >> 1, h = st & 1;
+                mc3_v4d m = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+                    m = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                        a[kb],
+                        (kb < KR) ? this->bop[vb][h][kb < KR ? kb : 0] : bl[kb < KR ? 0 : kb - KR],
+                        m, 0, 0, 0);
+                return m;
+            };
+            auto products = [&](const int S0, const int S1) {
+                if (S0 >= S1)
+                    return;
+                double bl[3][KLX];
+                lds_ops(S0, bl[S0 % 3]);
+                if (S0 + 1 < S1)
+                    lds_ops(S0 + 1, bl[(S0 + 1) % 3]);
+                mc3_v4d m[2];
+                m[S0 & 1] = chain(S0, bl[S0 % 3]);
+#pragma unroll
+                for (int st = S0; st < S1; ++st) {
+                    if (st + 1 < S1) {
+                        if (st + 2 < S1)
+                            lds_ops(st + 2, bl[(st + 2) % 3]);
+                        m[(st + 1) & 1] = chain(st + 1, bl[(st + 1) % 3]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[r] = mc3_fma(m[st & 1][r], m[st & 1][r], acc[r]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            static_assert(RA_TAKE_AT < RA_TAKE_AGAIN && RA_TAKE_AGAIN < 16, "");
+            if (have) {
+                MC3_RTICK(tq0);
+#ifdef MC3HIP_TIMELINE
+                MC3_TL(tl_cur >= 0 && tl_cur < 8 && lane == 0,
+                       8192 + 32 * (blockIdx.y * gridDim.x + blockIdx.x) + 4 * tl_cur + 2);
+#endif
+                asm volatile("; operands of this block" : "+v"(wo));
+                products(0, RA_TAKE_AT);
+            }
+            // the first look
+            bool hit1 = false, hit2 = false;
+            int lc1 = lc_next;
+            const bool look = !done;
+            if (look) {
+                hit1 = take(w);
+                lc1 = lc_next;
+                // the rows of the block's chains (nothing there: the last one's again, unused)
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+                    aop1[kb] = load_published(P.rs_prop + (size_t)lc1 * RS_ROW + 4 * kb + g);
+                if (!hit1)
+                    w2 = load_sched(rows + seq * 16);
+            }
+            if (have)
+                products(RA_TAKE_AT, RA_TAKE_AGAIN);
+            // the second look
+            if (look && !hit1) {
+                hit2 = take(w2);
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+                    aop2[kb] = load_published(P.rs_prop + (size_t)lc_next * RS_ROW + 4 * kb + g);
+            }
+            if (have)
+                products(RA_TAKE_AGAIN, 16);
+            const bool ok = hit1 || hit2;
+            MC3_RTICK(tq2);
+#ifndef MC3HIP_RA_NO_SUMS_PRIO
+            // (from here to the sums' publication every instruction is between a block's
+            // products and its chains' owners: ahead of the partner's products)
+            if (have)
+                __builtin_amdgcn_s_setprio(3);
+#endif
+            // the rows of the block taken: there by now (only a row that is late is asked for
+            // a second time: the addresses again, from the row's number)
+            if (hit1) {
+                const double *addr[KB];
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+                    addr[kb] = P.rs_prop + (size_t)lc1 * RS_ROW + 4 * kb + g;
+                if (!wait_rows<KB>(addr, aop1, ctl))
+                    return;
+            } else if (hit2) {
+                const double *addr[KB];
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+                    addr[kb] = P.rs_prop + (size_t)lc_next * RS_ROW + 4 * kb + g;
+                if (!wait_rows<KB>(addr, aop2, ctl))
+                    return;
+            }
+            MC3_RTICK(tq3);
+            if (have) {
+                // The sums of the block multiplied -- AFTER the wait above: that wait is for
+                // everything the wave has in flight, and behind a store it is a round trip
+                // for the store's acknowledgement.  (Left for later still -- behind the next
+                // block's first products, where they would cost the pipe nothing -- they reach
+                // the owners two microseconds later, and the tile waves run out of proposals:
+                // 33.2 us per iteration against 29.5.)
+                // the 16 lanes of a row (strides 8..1; lane j = 0 has the defined order)
+                double sr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double sg = add_ror<8>(acc[r]);
+                    sg = add_ror<4>(sg);
+                    sg = add_ror<2>(sg);
+                    sr[r] = add_ror<1>(sg);
+                }
+                if (j == 0) {
+                    // (a slot beyond the block's chains goes to a row of LDS that nobody reads)
+                    double *slot[4];
+                    unsigned *cnt[4];
+                    unsigned old[4];
+                    int ch[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ch[r] = (g + 4 * r < cur_nt) ? cur_sel[g + 4 * r] : RA_CMAX;
+                        slot[r] = &s_part[ch[r] * 8 + wv];
+                        cnt[r] = &s_cnt[ch[r]];
+                    }
+                    tile_part_arrive4(slot, sr, cnt, old);
+                    MC3_RTICK(tq4);
+                    // the chains this wave counted last for (normally none, or all of them):
+                    // the tile's eight rows of each (strides 4..1)
+                    if (old[0] == 7u || old[1] == 7u || old[2] == 7u || old[3] == 7u) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const double *p = s_part + ch[r] * 8;
+                            double sg = ((p[0] + p[4]) + (p[2] + p[6])) +
+                                        ((p[1] + p[5]) + (p[3] + p[7]));
+                            if (mc3_bits(sg) == ROW_PENDING)   // (a NaN that looks like "not there yet")
+                                sg = mc3_from_bits(0x7ff8000000000000ull);
+                            if (old[r] == 7u && ch[r] != RA_CMAX)
+                                __hip_atomic_store(
+                                    &P.rs_part[(size_t)(c0 + ch[r]) * P.rs_ntp + t], sg,
+                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (r == 1)
+                                __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_setprio(1);
+                spins = 0;
+                MC3_RTICK(tq1);
+#ifdef MC3HIP_TIMELINE
+                MC3_TL(tl_cur >= 0 && tl_cur < 8 && lane == 0,
+                       8192 + 32 * (blockIdx.y * gridDim.x + blockIdx.x) + 4 * tl_cur + 3);
+#endif
+#ifdef MC3HIP_STAMPS
+                tq_blocks += 1;
+                tq_mul += tq2 - tq0;
+                tq_wait += tq3 - tq2;
+                if (j == 0) {
+                    tq_arrive += tq4 - tq3;
+                    tq_finish += tq1 - tq4;
+                }
+                if (tq_last != 0)
+                    tq_turn += tq0 - tq_last;
+                tq_last = tq1;
+#endif
+            } else if (!ok) {
+                if (done)
+                    break;                              // the launch's last block is behind us
+                // nothing in hand, nothing there: look again -- not for ever
+#ifdef MC3HIP_STAMPS
+                tq_idle += 1;
+#endif
+                if (!async_patience(spins, ctl))
+                    return;
+            }
+            have = ok;
+#ifdef MC3HIP_TIMELINE
+            tl_cur = ok ? tl_next : -1;
+            MC3_TL(tl_cur >= 0 && tl_cur < 8 && lane == 0,
+                   8192 + 32 * (blockIdx.y * gridDim.x + blockIdx.x) + 4 * tl_cur + 1);
+#endif
+            if (ok) {
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+                    a[kb] = hit1 ? aop1[kb] : aop2[kb];
+                cur_nt = nt;
+                cur_sel = sel2 + 16 * (buf ^ 1);
+            }
+            // the scheduler's row after the block taken (or the same one again)
+            if (!done)
+                w = load_sched(rows + seq * 16);
+        }
+#ifdef MC3HIP_STAMPS
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+            unsigned long long tq_end = 0;
+            MC3_RTICK(tq_end);
+            P.stamps[20] += tq_blocks; P.stamps[21] += tq_idle; P.stamps[22] += tq_mul;
+            P.stamps[23] += tq_wait; P.stamps[24] += tq_end - tq_begin;
+            P.stamps[25] += tq_arrive; P.stamps[26] += tq_finish; P.stamps[27] += tq_turn;
+        }
+#endif
+    }
+};
+
+// grid = tiles x columns of chains as resident_tile_kernel's; 8 tile waves, up to RA_OWNERS
+// owner waves (wave 8 + v of workgroup w owns chain w + v * workgroups), and in the workgroups
+// of tile 0 the column's scheduler behind them.  LDS: the waves' row totals [RA_CMAX][8],
+// their counters, the blocks' chains, the give-up word, an area per owner, and the blocks of
+// operand rows beyond two, [16][512] each.
+template <int KB, bool P2P = false>
+__global__ __launch_bounds__(512 + 64 * (RA_OWNERS + 1)) void resident_async_kernel(
+    const DevProblem P, const int nref, const int chain_block)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int OWN = 64 + MC3HIP_MAX_PARAMS + 2 + 48 + 4;     // carve() of a one-wave chain
+    double *s_part = smem;                              // (row RA_CMAX: nobody's)
+    unsigned *s_cnt = reinterpret_cast<unsigned *>(smem + (RA_CMAX + 1) * 8);
+    int *s_sel = reinterpret_cast<int *>(smem + (RA_CMAX + 1) * 8 + RA_CMAX / 2 + 1);
+    int *s_stop = reinterpret_cast<int *>(smem + (RA_CMAX + 1) * 8 + RA_CMAX / 2 + 1 + 144);
+    double *s_own = smem + (RA_CMAX + 1) * 8 + RA_CMAX / 2 + 1 + 144 + 2;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = (int)(blockDim.x >> 6);
+    ResidentTileAsync<KB> T;
+    if (wv < 8)
+        T.load(P, blockIdx.x, blockIdx.y, chain_block, smem, s_stop, s_own + RA_OWNERS * OWN);
+    if (threadIdx.x < RA_CMAX + 2)
+        s_cnt[threadIdx.x] = 0u;
+    if (threadIdx.x < 8)
+        s_sel[32 * 8 + 16 + threadIdx.x] = 0;           // (the tile waves' progress)
+    // a launch queued behind one that gave up must not run: its inputs are missing
+    if (threadIdx.x == 0)
+        *s_stop = (__hip_atomic_load(&P.ctl[CTL_ABORT], __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0;
+    __syncthreads();
+    if (*s_stop != 0)
+        return;
+    if (wv < 8) {
+        T.run(P, nref, s_part, s_cnt, s_sel, s_sel + 32 * 8 + 16);
+        return;
+    }
+    // (owners and scheduler: few instructions, and every one of them on the path between a
+    // block's sums and the next proposals -- ahead of the tile waves' products)
+    __builtin_amdgcn_s_setprio(MC3HIP_RA_PRIO);
+    if (wv == nwaves - 1) {
+        if (blockIdx.x == 0) {
+            const int c0 = blockIdx.y * chain_block;
+            const int c1 = (c0 + chain_block < P.nlocal) ? c0 + chain_block : P.nlocal;
+            resident_scheduler(P, nref, blockIdx.y, c0, c1 - c0, s_sel + 32 * 8);
+        }
+        return;
+    }
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    const int own_chain = wg + (int)(gridDim.x * gridDim.y) * (wv - 8);
+    if (own_chain < P.nlocal) {
+        ResidentOwner O;
+        O.lane = threadIdx.x & 63;
+        O.par = 0;
+        O.failed = false;
+        O.set_owner(P, own_chain, s_own + (wv - 8) * OWN);
+        lean_resident_owner<MT_LINEAR, P2P, ResidentOwner, true>(P, nref, O, own_chain,
+                                                                 s_own + (wv - 8) * OWN);
     }
 }
 

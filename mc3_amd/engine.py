@@ -133,7 +133,8 @@ class DeviceChains:
                 'tile_tree': plan.tile_tree, 'resident': plan.resident,
                 'chains_per_workgroup': plan.chains_per_workgroup, 'jit': plan.jit,
                 'capacity': plan.capacity,
-                'zlag': plan.zlag, 'remote_delay_ns': plan.remote_delay_ns}
+                'zlag': plan.zlag, 'remote_delay_ns': plan.remote_delay_ns,
+                'owner_waves': plan.owner_waves}
 
     def jit_request(self):
         """The loop instantiation the library would like compiled for this model ('' = none)."""

@@ -168,6 +168,8 @@ def test_config_c5_resident(eng):
     prob = H.linear_problem(ndata=100000, nchains=512, nsamples=512*8)
     orc, gpu = run_pair(eng, prob, trace=False)
     assert gpu.plan['resident'] == 1
+    # (three chains to own per workgroup: the owners are waves of their own)
+    assert gpu.plan['owner_waves'] == 3, gpu.plan
     assert_same(orc, gpu, trace=False)
     gpu.close()
 
@@ -471,4 +473,98 @@ def test_resident_lean_owner_resume_abort_and_switch(eng, kind):
         orc, gpu = run_pair(eng, prob, trace=False)
         assert gpu.plan['resident'] == 1 and gpu.plan['fast'] == 0
         assert_same(orc, gpu, trace=False)
+        gpu.close()
+
+
+# ---- the owners as waves of their own, the blocks of chains made up at run time ----------
+# (resident_async_kernel, resident.h: DEMC, thinning 1, no trace, no shared parameters, design
+# matrices through the matrix cores, at most three chains to own per workgroup)
+def _async_case(case):
+    if case == 'c5like':        # three blocks of operand rows (the third in LDS), priors
+        return linear(ndata=30000, nmodel=10, nchains=96, niter=30)
+    if case == 'one_block':     # 2..3 coefficients + the data: one block of operand rows
+        return linear(ndata=20000, nmodel=3, nchains=40, niter=30)
+    if case == 'two_blocks':
+        return linear(ndata=20000, nmodel=7, nchains=64, niter=30)
+    if case == 'four_blocks':   # 12..15 coefficients: two blocks of operand rows in LDS
+        return linear(ndata=20000, nmodel=14, nchains=48, niter=20)
+    if case == 'ragged':        # columns of 32, 32 and 19 chains: a block of three behind one of 16
+        return linear(ndata=24000, nmodel=9, nchains=83, niter=30)
+    if case == 'epsilon':
+        return linear(ndata=20000, nmodel=8, nchains=64, niter=30, fepsilon=0.01)
+    if case == 'tight':         # most proposals out of bounds: sums consumed, not used
+        prob = linear(nmodel=6, nchains=64, niter=60)
+        prob['pmin'] = prob['params'] - 1.2*np.abs(prob['pstep'])
+        prob['pmax'] = prob['params'] + 1.2*np.abs(prob['pstep'])
+        return prob
+    if case == 'tiles69':       # the owner collects the sums 64 at a time
+        return linear(ndata=140000, nmodel=10, nchains=96, niter=6)
+    if case == 'long_column':   # 128 chains per column: both halves of the scheduler's lanes
+        return linear(ndata=100000, nmodel=10, nchains=512, niter=6)
+    raise ValueError(case)
+
+
+@pytest.mark.parametrize('case', ['c5like', 'one_block', 'two_blocks', 'four_blocks', 'ragged',
+                                  'epsilon', 'tight', 'tiles69', 'long_column'])
+def test_resident_async_bit_exact(eng, case):
+    """Owner waves apart from the tile waves, a scheduler wave per column making up the blocks
+    of sixteen chains from the proposals that are there: which chains share a block, and
+    when, changes no bit -- the same rows, counters and best fits as the oracle, and as the
+    kernel that goes through an iteration in step (MC3HIP_NO_RS_ASYNC=1)."""
+    prob = _async_case(case)
+    kw = {'long_column': dict(MC3HIP_RESIDENT_MAXCOL=4),
+          'ragged': dict(MC3HIP_RESIDENT_MAXCOL=3)}.get(case, {})
+    with env(**kw):
+        orc, gpu = run_pair(eng, prob, trace=False)
+        plan = gpu.plan
+        assert plan['resident'] == 1 and plan['fast'] == 4 and plan['recoveries'] == 0, plan
+        assert plan['owner_waves'] >= 1, plan
+        assert_same(orc, gpu, trace=False)
+        if case == 'tight':
+            assert gpu.state()['outbounds'].sum() > 50
+        gpu.close()
+        with env(MC3HIP_NO_RS_ASYNC=1):
+            orc, gpu = run_pair(eng, prob, trace=False)
+            assert gpu.plan['resident'] == 1 and gpu.plan['owner_waves'] == 0, gpu.plan
+            assert_same(orc, gpu, trace=False)
+            gpu.close()
+
+
+def test_resident_async_many_launches_resume_and_abort(eng):
+    """Launches of 5 refreshes (the scheduler's rows are told apart by the launch's number),
+    the run split over several calls; a wave that gives up at refresh 9 ends the launch for
+    everybody -- tile waves, owners, schedulers -- and the run is redone from the checkpoint."""
+    prob = linear(ndata=24000, nmodel=10, nchains=80, niter=60)
+    with env(MC3HIP_PERSIST_REFS=5):
+        gpu = eng.DeviceChains(**prob)
+        assert gpu.plan['owner_waves'] >= 1 and gpu.plan['persistent'] == 5, gpu.plan
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nrefresh=60, trace=False, nthreads=4)
+        for n in (1, 4, 22, 33):
+            gpu.run(n)
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
+    with env(MC3HIP_TEST_ABORT_AT=9):
+        orc, gpu = run_pair(eng, prob, trace=False)
+        assert gpu.plan['recoveries'] == 1
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
+
+
+def test_resident_async_shapes_it_leaves_to_the_kernel_in_step(eng):
+    """More than three chains to own per workgroup (10 tiles x 1 column, 40 chains), snooker,
+    thinning: the kernel in step, as before."""
+    prob = linear(ndata=20000, nmodel=7, nchains=40, niter=12)
+    with env(MC3HIP_RESIDENT_MAXCOL=1):
+        orc, gpu = run_pair(eng, prob, trace=False)
+        assert gpu.plan['resident'] == 1 and gpu.plan['owner_waves'] == 0, gpu.plan
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
+    for kw in (dict(sampler='snooker'), dict(thinning=2)):
+        orc, gpu = run_pair(eng, linear(nmodel=7, nchains=40, niter=10, **kw))
+        assert gpu.plan['resident'] == 1 and gpu.plan['owner_waves'] == 0, gpu.plan
+        assert_same(orc, gpu)
         gpu.close()

@@ -55,6 +55,15 @@ if len(sys.argv) > 1 and sys.argv[1] in ('c5', 'q5'):
     for k, v in rows:
         print(f'  {k:62s} {v/n:9.0f} cycles')
     print(f'  {"sum":62s} {sum(v for _, v in rows)/n:9.0f}')
+    if g.plan.get('owner_waves', 0) > 0 and b1[4] > 0:
+        # resident_async_kernel: tile wave 0 of workgroup 0 (per iteration of the launch)
+        # (on the 100 MHz clock: the shader clock's count stalls under FP64 matrix instructions)
+        u = lambda v: v/NIT/100.0                       # noqa: E731
+        print(f'  tile wave 0 of workgroup 0: blocks multiplied {b1[4]/NIT:.2f} per iteration, '
+              f'turns with nothing in hand {b1[5]/NIT:.2f}; us per iteration: products (with the '
+              f'looks for the next block) {u(b1[6]):.2f}, waiting for rows {u(b1[7]):.2f}, row '
+              f'totals left and counted {u(b1[9]):.2f}, chains finished {u(b1[10]):.2f}, from '
+              f'there to the next block\'s products {u(b1[11]):.2f}, in all {u(b1[8]):.2f}')
     sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == 'c4cw':
     # python tools/ticks.py c4cw [sampler] [wide]    C4 (wide: bounds that reject nothing) with the chain-wave kernel: phases of the chain
