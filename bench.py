@@ -351,7 +351,8 @@ def config_child(name):
     steps = nchains*ntimed*thinning
     rate = steps/dt/1e6
     rate_ev = steps/(gpu_ms*1e-3)/1e6
-    kernel = ('mc3hip::resident_tile_kernel' if plan.get('resident') else
+    kernel = (('mc3hip::resident_async_kernel' if plan.get('owner_waves') else
+               'mc3hip::resident_tile_kernel') if plan.get('resident') else
               {3: 'mc3hip::wavelet_pipe_kernel', 2: 'mc3hip::lean_demc_kernel',
                1: 'mc3hip::persist_fast_kernel', 0: 'mc3hip::persist_kernel',
                4: 'mc3hip::resident_tile_kernel'}.get(plan['fast'], 'mc3hip::persist_kernel'))
@@ -724,7 +725,8 @@ def run_rank(args):
     per = plan['persistent'] if (not multi or exchange == 'p2p') else 0
     if per > 0:
         launches = sum(-(-m//per) for m in run_sizes) if run_sizes else -(-nref_timed//per)
-        kernel = 'mc3hip::resident_tile_kernel' if plan.get('resident') else \
+        kernel = ('mc3hip::resident_async_kernel' if plan.get('owner_waves') else
+                  'mc3hip::resident_tile_kernel') if plan.get('resident') else \
             {2: 'mc3hip::lean_demc_lag_kernel' if plan.get('zlag') else 'mc3hip::lean_demc_kernel',
              1: 'mc3hip::persist_fast_kernel', 0: 'mc3hip::persist_kernel',
              4: 'mc3hip::resident_tile_kernel'}[plan['fast']]

@@ -119,7 +119,7 @@ if have('pmc_c2_FETCH_SIZE/c2_counter_collection.csv'):
 # large ensembles: instruction mix and stall counters of the several-chains-per-wave loops
 BIG = {'c3x4': ('lean_demc_rows_kernel', 2000, 8192), 'c3x2mrw': ('lean_mrw_mc_kernel', 3000, 4096),
        'c3one': ('lean_demc_kernel', 4000, 2048),
-       'c4': ('wavelet_pipe_kernel', 4000, 256), 'c4x2': ('wavelet_pipe_kernel', 2000, 512), 'c5': ('resident_tile_kernel', 300, 512)}
+       'c4': ('wavelet_pipe_kernel', 4000, 256), 'c4x2': ('wavelet_pipe_kernel', 2000, 512), 'c5': ('resident_async_kernel', 300, 512)}
 for cfg, (pick, iters, chains) in BIG.items():
     if not have(f'pmc1_{cfg}/{cfg}_counter_collection.csv'):
         continue
