@@ -220,13 +220,15 @@ inline int jit_model_tag(const mc3hip_ctx *c)
         return 0;
     const bool plain = P.nfree == P.nparams && P.ngprior == 0 && P.nshare == 0;
     switch (P.sampler) {
+    // (the support distribution's deviates and the random walk's: a Philox slot per two
+    // coefficients, as many as the model has -- round 5; before: four at most)
     case MC3HIP_DEMC:          // (the support distribution: the strict headline loop only)
-        return (P.fepsilon == 0.0 || (P.thinning == 1 && P.zlag == 0 && P.nfree <= 4)) ? tag : 0;
+        return (P.fepsilon == 0.0 || (P.thinning == 1 && P.zlag == 0)) ? tag : 0;
     case MC3HIP_SNOOKER:
         return ((P.fepsilon == 0.0 && (P.thinning == 1 || plain)) ||
-                (P.fepsilon != 0.0 && P.thinning == 1 && P.nfree <= 4)) ? tag : 0;
-    default:                   // (the random walk: two Philox slots of deviates)
-        return (P.nmodel <= 4 && (P.thinning == 1 || plain)) ? tag : 0;
+                (P.fepsilon != 0.0 && P.thinning == 1 && P.zlag == 0)) ? tag : 0;
+    default:
+        return (P.thinning == 1 || plain) ? tag : 0;
     }
 }
 // waves of the specialised loop's workgroup: helper waves share the data sum (gauss.h

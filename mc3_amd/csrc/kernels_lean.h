@@ -174,13 +174,17 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
     // 2 s + 1 (rad cos, rad sin) -- ~250 vector instructions per batch instead of per refresh
     // (drawn every refresh they did not fit the shadow of the partner rows' round trip: 156 M
     // chain-steps/s against 217 without epsilon); a refresh gathers its own through the crossbar
-    static_assert(!EPS || Model<MT>::NC <= 4 || FX, "EPS: up to four free parameters");
+    // (more than four free parameters -- models specialised at run time: ES = 4 / 8 slots of
+    // deviates per refresh, 16 / 8 refreshes at once; lane ES i + s: slot 3 + s of refresh
+    // nbase + i)
+    constexpr int ES = Model<MT>::NC <= 4 ? 2 : (Model<MT>::NC <= 8 ? 4 : 8);
+    constexpr int ESH = ES == 2 ? 1 : (ES == 4 ? 2 : 3);
     const double pstep_k = (EPS && mine) ? P.fstep[lane] : 0.0;
     double ncs = 0.0, nsn = 0.0;
     long long nbase = R0;
     auto fill_normals = [&](long long base) {
-        const Draw2 dn = draw2(P.seed, (uint64_t)(base + (lane >> 1)), (uint32_t)c,
-                               (uint32_t)(3 + (lane & 1)));
+        const Draw2 dn = draw2(P.seed, (uint64_t)(base + (lane >> ESH)), (uint32_t)c,
+                               (uint32_t)(3 + (lane & (ES - 1))));
         const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(dn.q0)));
         double sn, cs;
         mc3_det_sincos2pi(u01(dn.q1), &sn, &cs);
@@ -189,9 +193,9 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
         nbase = base;
     };
     auto normal_draw = [&](uint64_t it) {
-        if (__builtin_expect((long long)it - nbase >= 32, 0))
+        if (__builtin_expect((long long)it - nbase >= 64 / ES, 0))
             fill_normals((long long)it);
-        const int idx = 2 * (int)((long long)it - nbase);
+        const int idx = ES * (int)((long long)it - nbase);
         const int src = mine ? idx + (lane >> 1) : idx;
         const double gc = lane_gather(ncs, src), gn = lane_gather(nsn, src);
         return mine ? ((lane & 1) ? gn : gc) * pstep_k : 0.0;
@@ -507,9 +511,11 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
     const int nf = FX ? P.nfree : NC;
     constexpr int ZS = ZROW;
     // (EPS, fepsilon != 0, chain.py:185,217: two more Philox slots per refresh for the support
-    // distribution's deviates of up to four free parameters -- five lanes per refresh)
+    // distribution's deviates of up to four free parameters -- five lanes per refresh; a slot
+    // per two coefficients beyond four: the models specialised at run time, up to ten)
     static_assert(!EPS || (!THIN && !MULTI && !P2P), "EPS: one tile, thinning 1, one GPU");
-    constexpr int LPR = EPS ? 5 : 3;           // lanes of the batch per refresh
+    constexpr int NSE = NC <= 4 ? 2 : (NC + 1) / 2;
+    constexpr int LPR = EPS ? 3 + NSE : 3;     // lanes of the batch per refresh
     constexpr int NB = 64 / LPR;               // refreshes per batch of draws
     const int lane = (COURIER || NW > 1) ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     const int lc = blockIdx.x;
@@ -915,6 +921,8 @@ __global__ __launch_bounds__(64 * NW) void lean_snooker_wide_kernel(const DevPro
 // Here they are made for 21 refreshes at once, one (refresh, slot) per lane -- lane 3 i: the
 // Metropolis draw and the window of its logarithm; lanes 3 i + 1, 3 i + 2: the deviates of
 // parameters 0, 1 and 2, 3 -- and an iteration gathers its own (v_readlane, ds_bpermute).
+// (More than four coefficients -- the models specialised at run time, up to ten: a slot of
+// deviates per two of them, 16 / 12 / 10 refreshes at once for 5-6 / 7-8 / 9-10 coefficients.)
 // Same draws, same arithmetic, same results as run_chain's.
 // (THIN: thinning > 1 -- the iterations between two refreshes publish nothing; the draws are
 // keyed by the iteration, R thinning + j, as run_chain's)
@@ -924,12 +932,18 @@ __global__ __launch_bounds__(64 * NW) void lean_snooker_wide_kernel(const DevPro
 template <int MT, bool FX, bool THIN, bool MULTI, bool P2P, bool COURIER>
 __device__ __forceinline__ void lean_mrw_body(const DevProblem &P, const int nref)
 {
-    static_assert(Model<MT>::NC >= 1 && Model<MT>::NC <= 4, "two slots of normal deviates");
+    static_assert(Model<MT>::NC >= 1 && Model<MT>::NC <= 16, "one lane per coefficient of a row");
     static_assert(!COURIER || P2P, "the courier carries rows to other ranks' replicas");
     constexpr int NC = Model<MT>::NC;         // coefficients the model tag fixes
     const int nf = FX ? P.nfree : NC;
     constexpr int ZS = ZROW;
-    constexpr int NB = 21;
+    // Philox slots of normal deviates per iteration (two deviates each; two slots up to four
+    // coefficients, as the instances built with the library have always had: the models
+    // specialised at run time have up to ten), lanes of the batch per iteration, iterations
+    // per batch
+    constexpr int NS = NC <= 4 ? 2 : (NC + 1) / 2;
+    constexpr int LPR = NS + 1;
+    constexpr int NB = 64 / LPR;
     const int lane = COURIER ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     const int lc = blockIdx.x;
     const int c = P.chain0 + lc;
@@ -993,12 +1007,12 @@ __device__ __forceinline__ void lean_mrw_body(const DevProblem &P, const int nre
         priors.init(P, kf, fx, lane);
     }
     (void)kf; (void)fx; (void)priors;
-    // lane 3 i + s of the batch: s = 0 -> u (bu) and its window; s = 1, 2 -> rad cos, rad sin of
-    // Philox slot 3 + (s - 1), i.e. the deviates of parameters 2 (s - 1) and 2 (s - 1) + 1
+    // lane LPR i + s of the batch: s = 0 -> u (bu) and its window; s = 1 .. NS -> rad cos, rad
+    // sin of Philox slot 3 + (s - 1), i.e. the deviates of parameters 2 (s - 1) and 2 (s - 1) + 1
     double bu = 0.0, blo = 0.0, bhi = 0.0, bcs = 0.0, bsn = 0.0;
     const int th = THIN ? P.thinning : 1;
     long long bbase = R0 * th;                 // (the batch counts iterations)
-    const int bs = lane % 3, bi = (lane / 3 < NB) ? lane / 3 : NB - 1;
+    const int bs = lane % LPR, bi = (lane / LPR < NB) ? lane / LPR : NB - 1;
     auto fill = [&](long long base) {
         const Draw2 d = draw2(P.seed, (uint64_t)(base + bi), (uint32_t)c,
                               bs == 0 ? 0u : (uint32_t)(2 + bs));
@@ -1012,7 +1026,7 @@ __device__ __forceinline__ void lean_mrw_body(const DevProblem &P, const int nre
         bbase = base;
     };
     fill(R0 * th);
-    // lane k's deviate of a refresh sits in lane 3 i + 1 + (k >> 1): cosine branch for even k
+    // lane k's deviate of a refresh sits in lane LPR i + 1 + (k >> 1): cosine branch for even k
     const int src_off = 1 + (lane >> 1);
     const long long Rend = R0 + nref;
     long long rdone = R0;
@@ -1042,7 +1056,7 @@ __device__ __forceinline__ void lean_mrw_body(const DevProblem &P, const int nre
         const long long it = R * th + j;
         if (__builtin_expect(it - bbase == NB, 0))
             fill(it);
-        const int idx = 3 * (int)(it - bbase);
+        const int idx = LPR * (int)(it - bbase);
         const double u_now = read_lane(bu, idx), lo_now = read_lane(blo, idx),
                      hi_now = read_lane(bhi, idx);
         const int src = mine ? idx + src_off : idx;

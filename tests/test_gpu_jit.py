@@ -71,6 +71,24 @@ CASES = {
     'lin4-snooker-eps': lambda: linear_problem(4, sampler='snooker', fepsilon=0.02),
     'lin3-snooker-eps-priors': lambda: linear_problem(3, sampler='snooker', priors=True,
                                                       fepsilon=0.01),
+    # round 5: the random walk and the support distribution's deviates (fepsilon != 0) for more
+    # than four coefficients -- a Philox slot per two of them (chain.py:185,219-220,232)
+    'poly5-mrw': lambda: poly_problem(5, sampler='mrw'),
+    'poly8-mrw-thin': lambda: poly_problem(8, sampler='mrw', thinning=3),
+    'lin6-mrw-priors': lambda: linear_problem(6, sampler='mrw', priors=True),
+    'lin10-mrw': lambda: linear_problem(10, sampler='mrw'),
+    'lin9-mrw-fixed-shared': lambda: with_pstep(
+        linear_problem(9, sampler='mrw'),
+        [0.05, 0.0, 0.05, -1.0, 0.05, 0.05, 0.0, 0.05, -3.0]),
+    'poly6-demc-eps': lambda: poly_problem(6, sampler='demc', fepsilon=0.01),
+    'lin7-demc-eps-priors': lambda: linear_problem(7, sampler='demc', priors=True,
+                                                   fepsilon=0.02),
+    'lin10-demc-eps': lambda: linear_problem(10, sampler='demc', fepsilon=0.01),
+    'poly7-snooker-eps': lambda: poly_problem(7, sampler='snooker', fepsilon=0.01),
+    'lin10-snooker-eps-priors': lambda: linear_problem(10, sampler='snooker', priors=True,
+                                                       fepsilon=0.02),
+    'lin5-snooker-eps-fixed': lambda: with_pstep(
+        linear_problem(5, sampler='snooker', fepsilon=0.02), [0.05, 0.05, 0.0, 0.05, 0.05]),
     # fixed and shared coefficients under the helper waves (a conditional gather once handed
     # the helpers zeros for the coefficients behind a fixed one: tools/fuzz_hunt.py)
     'lin8-snooker-fixed': lambda: with_pstep(linear_problem(8, sampler='snooker'),
@@ -128,8 +146,8 @@ def test_the_request_names_the_loop_and_the_cache_keeps_it(eng, tmp_path, monkey
         assert gpu.jit_request() == ''
     with eng.DeviceChains(**linear_problem(11, sampler='demc')) as gpu:     # too many columns
         assert gpu.jit_request() == '' and gpu.plan['fast'] == 0
-    with eng.DeviceChains(**poly_problem(5, sampler='mrw')) as gpu:         # mrw: <= 4 deviates
-        assert gpu.jit_request() == ''
+    with eng.DeviceChains(**poly_problem(5, sampler='mrw')) as gpu:  # (round 5: served too)
+        assert gpu.jit_served == 'lean_mrw_body<5, false, false, false, false, false>'
     assert jit.KERNEL_NAME == 'mc3_jit_kernel'
 
 

@@ -131,6 +131,11 @@ def _link(n, k, sampler='demc'):
                             sampler=sampler), {}
 
 
+def _with(pair, **kw):
+    pair[0].update(kw)
+    return pair
+
+
 def _shared(n, sampler='demc', thinning=1):
     # the quadratic plus a cubic coefficient shared with the linear one (pstep = -2) -- and
     # tiny in effect: x is scaled to [0, 1]
@@ -158,6 +163,14 @@ OFF_LEAN = {
     'off_shared_thin10': lambda n: _shared(n, thinning=10),
     'off_poly5_snooker': lambda n: _polyk(n, 5, 'snooker'),
     'off_lin10_snooker': lambda n: _link(n, 10, 'snooker'),
+    # round 5: the random walk and the support distribution's deviates beyond four coefficients
+    'off_poly5_mrw': lambda n: _polyk(n, 5, 'mrw'),
+    'off_poly8_mrw': lambda n: _polyk(n, 8, 'mrw'),
+    'off_lin10_mrw': lambda n: _link(n, 10, 'mrw'),
+    'off_poly6_eps': lambda n: _with(_polyk(n, 6), fepsilon=0.01),
+    'off_lin10_eps': lambda n: _with(_link(n, 10), fepsilon=0.01),
+    'off_poly6_eps_snooker': lambda n: _with(_polyk(n, 6, 'snooker'), fepsilon=0.01),
+    'off_lin10_eps_snooker': lambda n: _with(_link(n, 10, 'snooker'), fepsilon=0.01),
 }
 CONFIGS.update(OFF_LEAN)
 # the declared multi-GPU cadence on one GPU (zlag 4)
