@@ -49,6 +49,11 @@ struct mc3hip_ctx {
     // (kernels_lean.h lean_demc_wide_kernel NT; 0 = not this context).  Set at creation
     // (mc3hip.hip wide_tiles_shape), taken back by decide_persist if the grid does not fit.
     int wide_tiles = 0;
+    // ... and of the same sizes with what those loops do not carry -- fixed / shared
+    // coefficients, priors, the support distribution, the random walk: 2, 4 or 8 tiles in the
+    // registers of FOUR waves of a loop specialised at run time (lean_*_body<.., NW = 4, NT>;
+    // mc3hip_jit_request); 0 = not this context
+    int wide_jit_tiles = 0;
     // wavelet likelihood, one wave per chain (<= 2048 points), the shapes of cw_lean_eligible,
     // snooker without the support distribution: kernels_wavelet.h wavelet_one_kernel
     bool wl_one = false;
@@ -206,10 +211,17 @@ inline bool lag_demc_shape(const mc3hip_ctx *c)
 inline int jit_model_tag(const mc3hip_ctx *c)
 {
     const DevProblem &P = c->P;
-    if (P.wlike || c->wpc != 1 || P.npad > VLANES || P.trace_iters != 0 || P.tile > 0 ||
+    if (P.wlike || P.trace_iters != 0 || P.tile > 0 ||
         (c->flags & MC3HIP_FLAG_P2P) || c->p2p_ranks > 1 || c->comm != nullptr ||
         P.zs != ZROW || P.nmodel != P.nparams || P.nfree < 1 ||
         getenv("MC3HIP_NO_LEAN") || getenv("MC3HIP_NO_FAST"))
+        return 0;
+    // more than 1024 points: polynomials of 2..4 coefficients, the tiles in the registers of
+    // four waves (the shapes lean_demc_wide_kernel / lean_snooker_wide_kernel do not carry)
+    if (c->wide_jit_tiles > 0)
+        return (c->model_kind == MC3HIP_MODEL_POLY && P.nmodel >= 2 && P.nmodel <= 4 &&
+                P.thinning == 1 && P.zlag == 0 && c->mc_chains == 0) ? P.nmodel : 0;
+    if (c->wpc != 1 || P.npad > VLANES)
         return 0;
     int tag = 0;
     if (c->model_kind == MC3HIP_MODEL_POLY && P.nmodel >= 5 && P.nmodel <= 8)
@@ -239,6 +251,8 @@ inline int jit_waves(const mc3hip_ctx *c)
 {
     const int tag = jit_model_tag(c);
     const DevProblem &P = c->P;
+    if (tag != 0 && c->wide_jit_tiles > 0)
+        return 4;
     if (tag < MT_LINK0 || P.sampler == MC3HIP_MRW ||
         (P.sampler == MC3HIP_DEMC && (P.thinning > 1 || P.zlag > 0)))
         return 1;

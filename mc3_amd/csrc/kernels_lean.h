@@ -51,10 +51,14 @@ __global__ __launch_bounds__(64) void persist_fast_kernel(const DevProblem P, co
 // shadow of the partner rows' round trip as the scalar draws.
 // (NW = 2, 4: helper waves share the data sum -- gauss.h SumHelpers; run-time specialised
 // design matrices whose tile one wave's registers do not hold)
-template <int MT, bool P2P, bool FX, bool MULTI, bool BATCH, bool COURIER, bool EPS, int NW = 1>
+// (NT = 2, 4, 8 with NW = 4: more than 1024 points in the registers of four waves -- what
+// lean_demc_wide_kernel does for the plain shape, here for fixed / shared coefficients, priors,
+// the support distribution; specialised at run time, round 5)
+template <int MT, bool P2P, bool FX, bool MULTI, bool BATCH, bool COURIER, bool EPS, int NW = 1,
+          int NT = 1>
 __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nref)
 {
-    constexpr int NT = 1;
+    static_assert(NT == 1 || NW > 1, "several tiles: in the registers of several waves");
     static_assert(!EPS || (!P2P && !MULTI && !BATCH && !COURIER), "EPS: the one-GPU headline loop");
     static_assert(NW == 1 || (!P2P && !MULTI && !COURIER), "helper waves: one GPU, one tile");
     constexpr int NC = Model<MT>::NC;         // coefficients the model tag fixes
@@ -929,11 +933,15 @@ __global__ __launch_bounds__(64 * NW) void lean_snooker_wide_kernel(const DevPro
 // (MULTI: more than 1024 points -- the second tile stays in registers too, the rest is streamed)
 // (P2P / COURIER: the ensemble is sharded over GPUs; the rows go into every rank's replica, as
 // lean_snooker_kernel's -- nobody waits for them: the run needs them complete at its end)
-template <int MT, bool FX, bool THIN, bool MULTI, bool P2P, bool COURIER>
+// (NW = 4, NT = 2, 4, 8: more than 1024 points in the registers of four waves, the helper waves
+// of gauss.h SumHelpers sharing the data sum -- specialised at run time, round 5)
+template <int MT, bool FX, bool THIN, bool MULTI, bool P2P, bool COURIER, int NW = 1, int NT = 1>
 __device__ __forceinline__ void lean_mrw_body(const DevProblem &P, const int nref)
 {
     static_assert(Model<MT>::NC >= 1 && Model<MT>::NC <= 16, "one lane per coefficient of a row");
     static_assert(!COURIER || P2P, "the courier carries rows to other ranks' replicas");
+    static_assert(NW == 1 || (!P2P && !MULTI && !COURIER), "helper waves: one GPU");
+    static_assert(NT == 1 || NW > 1, "several tiles: in the registers of several waves");
     constexpr int NC = Model<MT>::NC;         // coefficients the model tag fixes
     const int nf = FX ? P.nfree : NC;
     constexpr int ZS = ZROW;
@@ -944,7 +952,7 @@ __device__ __forceinline__ void lean_mrw_body(const DevProblem &P, const int nre
     constexpr int NS = NC <= 4 ? 2 : (NC + 1) / 2;
     constexpr int LPR = NS + 1;
     constexpr int NB = 64 / LPR;
-    const int lane = COURIER ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    const int lane = (COURIER || NW > 1) ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     const int lc = blockIdx.x;
     const int c = P.chain0 + lc;
     const bool mine = lane < nf;
@@ -952,6 +960,11 @@ __device__ __forceinline__ void lean_mrw_body(const DevProblem &P, const int nre
     __shared__ double s_ring[P2P ? COURIER_RING * ZROW : 1];
     __shared__ int s_cour[4];
     (void)s_ring; (void)s_cour;
+    __shared__ double s_hpart[NW > 1 ? 64 * NW : 1], s_hcf[16];
+    __shared__ int s_hcmd[2];
+    (void)s_hpart; (void)s_hcf; (void)s_hcmd;
+    SumHelpers<MT, (NW > 1 ? NW : 2), NT> helpers;     // (gauss.h: helper waves share the data sum)
+    (void)helpers;
     if constexpr (COURIER) {
         if (!courier_begin(s_ring, s_cour, ctl_rw))
             return;
@@ -959,6 +972,11 @@ __device__ __forceinline__ void lean_mrw_body(const DevProblem &P, const int nre
             courier_run<true>(P, s_ring, s_cour, lane, nf, c);
             return;
         }
+    } else if constexpr (NW > 1) {
+        if (!helpers.enter(s_hpart, s_hcf, s_hcmd,
+                           __hip_atomic_load(&ctl_rw[CTL_ABORT], __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT) != 0))
+            return;
     } else {
         if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
                 &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
@@ -977,8 +995,26 @@ __device__ __forceinline__ void lean_mrw_body(const DevProblem &P, const int nre
     DelayedRows late;
     late.begin(P, P.ctl[0], c, lane);
     (void)late;
-    DataTile<1, MT> tile;
-    tile.load(P);
+    // (NT tiles of 1024 points in the registers of the NW waves between them; tiles beyond the
+    // data: weight 0)
+    DataTile<NW, MT> tiles[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        if (q == 0 || q * VLANES < P.npad) {
+            tiles[q].load(P, q * VLANES);
+        } else if constexpr (NT > 1) {
+#pragma unroll
+            for (int v = 0; v < 16 / NW; ++v)
+                tiles[q].x[v] = tiles[q].d[v] = tiles[q].w[v] = 0.0;
+        }
+    }
+    const DataTile<NW, MT> &tile = tiles[0];
+    if constexpr (NW > 1) {
+        if (threadIdx.x >= 64) {
+            helpers.serve(P, tiles);
+            return;
+        }
+    }
     DataTile<1, MT> tile1;
     if constexpr (MULTI)
         tile1.load(P, VLANES);
@@ -1002,11 +1038,18 @@ __device__ __forceinline__ void lean_mrw_body(const DevProblem &P, const int nre
     int kf[NC];
     double fx[NC];
     PriorLanes<NC> priors;
+    int hkf = 0;                               // (helper waves, FX: what coefficient `lane` is)
+    double hfx = 0.0;
     if constexpr (FX) {
         coefficient_map<NC>(P, kf, fx);
         priors.init(P, kf, fx, lane);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            hkf = (lane == j) ? kf[j] : hkf;
+            hfx = (lane == j) ? fx[j] : hfx;
+        }
     }
-    (void)kf; (void)fx; (void)priors;
+    (void)kf; (void)fx; (void)priors; (void)hkf; (void)hfx;
     // lane LPR i + s of the batch: s = 0 -> u (bu) and its window; s = 1 .. NS -> rad cos, rad
     // sin of Philox slot 3 + (s - 1), i.e. the deviates of parameters 2 (s - 1) and 2 (s - 1) + 1
     double bu = 0.0, blo = 0.0, bhi = 0.0, bcs = 0.0, bsn = 0.0;
@@ -1067,17 +1110,31 @@ __device__ __forceinline__ void lean_mrw_body(const DevProblem &P, const int nre
         const double npk = xk + jump_k;
         const bool outk = mine && (npk < pmin_k || npk > pmax_k);
         if (__builtin_expect(!__any(outk), 1)) {
+            // (helper waves: woken first, as in lean_demc_body)
+            if constexpr (NW > 1) {
+                const double got = lane_gather(npk, hkf < 0 ? 0 : hkf);
+                helpers.order(FX ? (hkf < 0 ? hfx : got) : npk, lane);
+            }
             Model<MT> model;
             if constexpr (!FX) {
                 model.init_from_lanes(P, npk);
             } else {
                 model.init_from_lanes(P, npk, kf, fx);
             }
-            double nextchisq =
-                block_gauss_model<1, MT, MULTI, MULTI>(P, model, nullptr, nullptr, tile,
-                                                       MULTI ? &tile1 : &tile);  // chain.py:249
-            if constexpr (FX)
-                nextchisq = nextchisq + priors.term(npk, lane);
+            double nextchisq;                                        // chain.py:249
+            if constexpr (NW == 1) {
+                nextchisq = block_gauss_model<1, MT, MULTI, MULTI>(P, model, nullptr, nullptr,
+                                                                   tile, MULTI ? &tile1 : &tile);
+                if constexpr (FX)
+                    nextchisq = nextchisq + priors.term(npk, lane);
+            } else {
+                double prior = 0.0;
+                if constexpr (FX)
+                    prior = priors.term(npk, lane);
+                nextchisq = helpers.collect(P, model, tiles, lane);
+                if constexpr (FX)
+                    nextchisq = nextchisq + prior;
+            }
             const bool acc = metropolis_accept(0.5 * (cur - nextchisq), u_now, lo_now, hi_now);
             xk = acc ? npk : xk;
             if (__builtin_expect(__any(acc && nextchisq < best), 0)) {
@@ -1120,6 +1177,8 @@ __device__ __forceinline__ void lean_mrw_body(const DevProblem &P, const int nre
     }
     if constexpr (COURIER)
         courier_end(s_cour);
+    if constexpr (NW > 1)
+        helpers.release(lane);
     if constexpr (P2P && !COURIER) {
         if (P.remote_delay != 0)
             late.drain(P, s_ring, peers_z, lane, mine, true);

@@ -986,6 +986,22 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
                 c->wide_tiles = tiles <= 2 ? 2 : (tiles <= 4 ? 4 : 8);
             else if (shape && tiles > 8 && tiles <= 16 && pr->nlocal <= cus)
                 c->wide_tiles = 16;
+            // the same sizes (up to eight tiles) with fixed / shared coefficients, priors, the
+            // support distribution, or the random walk: lean_*_body<.., NW = 4, NT> specialised
+            // at run time (ctx.h jit_model_tag; without a compiler at hand: the general chain,
+            // as before)
+            const bool shape_jit = !pr->wlike && !linear_model && pr->nmodel >= 2 &&
+                                   pr->nmodel <= 4 && pr->nmodel == pr->nparams && P.nfree >= 1 &&
+                                   pr->thinning == 1 && pr->zlag == 0 && pr->trace_iters == 0 &&
+                                   pr->nlocal == pr->nchains &&
+                                   !(pr->flags & (MC3HIP_FLAG_P2P | MC3HIP_FLAG_NO_PERSIST)) &&
+                                   !getenv("MC3HIP_NO_WIDE") && !getenv("MC3HIP_NO_LEAN") &&
+                                   !getenv("MC3HIP_NO_FAST") && !getenv("MC3HIP_NO_PERSIST") &&
+                                   !getenv("MC3HIP_NO_JIT") && !getenv("MC3HIP_WPC");
+            c->wide_jit_tiles = 0;
+            if (c->wide_tiles == 0 && shape_jit && tiles >= 2 && tiles <= 8 &&
+                pr->nlocal <= (tiles <= 2 ? 3 : (tiles <= 4 ? 2 : 1)) * cus)
+                c->wide_jit_tiles = tiles <= 2 ? 2 : (tiles <= 4 ? 4 : 8);
         }
         const bool big = c->wide_tiles == 0 &&
                          (nd >= 4 * 4096 || (mid_resident && nd >= 2 * 4096 &&
@@ -1264,7 +1280,8 @@ int mc3hip_get_plan(const mc3hip_ctx *c, mc3hip_plan *plan)
     plan->capacity = plan->persistent > 0
                          ? (int32_t)(c->capacity < 0x7fffffff ? c->capacity : 0x7fffffff) : 0;
     if (plan->fast == 2 && c->p2p_ranks <= 1)
-        plan->waves_per_chain = lean_waves(c);      // (helper waves share the data sum)
+        plan->waves_per_chain = plan->jit ? jit_waves(c)
+                                          : lean_waves(c);  // (helper waves share the data sum)
     if (plan->persistent > 0 && chainwave_runs(c, c->p2p_ranks > 1) && c->P.cw_lean)
         plan->fast = 3;                             // (wavelet: the hand-structured chain wave)
     if (plan->persistent > 0 && c->wl_one && c->mc_chains == 0 && c->p2p_ranks <= 1)
@@ -1288,8 +1305,9 @@ int mc3hip_jit_request(const mc3hip_ctx *c, char *buf, int32_t capacity)
     if (!c || !buf || capacity < 1)
         return fail(MC3HIP_ERR_ARG, "null argument");
     buf[0] = 0;
-    // (what the library has an instance for, it runs: nothing to specialise)
-    if (fast_eligible(c))
+    // (what the library has an instance for, it runs: nothing to specialise -- but for the
+    // random walk beyond 1024 points, whose library instance streams the tiles it cannot keep)
+    if (fast_eligible(c) && !(c->wide_jit_tiles > 0 && c->P.sampler == MC3HIP_MRW))
         return MC3HIP_OK;
     const int tag = jit_model_tag(c);
     if (tag == 0)
@@ -1299,6 +1317,33 @@ int mc3hip_jit_request(const mc3hip_ctx *c, char *buf, int32_t capacity)
     const char *fx = plain ? "false" : "true", *thin = P.thinning > 1 ? "true" : "false";
     const int nw = jit_waves(c);                 // (helper waves: the workgroup has 64 nw threads)
     int n = 0;
+    if (c->wide_jit_tiles > 0) {
+        // more than 1024 points: NT tiles in the registers of four waves
+        const char *eps = P.fepsilon != 0.0 ? "true" : "false";
+        const int nt = c->wide_jit_tiles;
+        switch (P.sampler) {
+        case MC3HIP_DEMC:      // <MT, P2P, FX, MULTI, BATCH, COURIER, EPS, NW, NT>
+            n = snprintf(buf, (size_t)capacity,
+                         "lean_demc_body<%d, false, %s, false, false, false, %s, 4, %d> "
+                         "/*threads=256*/", tag, fx, eps, nt);
+            break;
+        case MC3HIP_SNOOKER:   // <MT, FX, THIN, MULTI, P2P, COURIER, EPS, NW, NT>
+            n = snprintf(buf, (size_t)capacity,
+                         "lean_snooker_body<%d, %s, false, false, false, false, %s, 4, %d> "
+                         "/*threads=256*/", tag, fx, eps, nt);
+            break;
+        default:               // <MT, FX, THIN, MULTI, P2P, COURIER, NW, NT>
+            n = snprintf(buf, (size_t)capacity,
+                         "lean_mrw_body<%d, %s, false, false, false, false, 4, %d> "
+                         "/*threads=256*/", tag, fx, nt);
+            break;
+        }
+        if (n < 0 || n >= capacity) {
+            buf[0] = 0;
+            return fail(MC3HIP_ERR_ARG, "buffer of %d bytes too small for the request", capacity);
+        }
+        return MC3HIP_OK;
+    }
     switch (P.sampler) {
     case MC3HIP_DEMC:
         if (P.thinning > 1 || P.zlag > 0)        // <MT, P2P, FX, COURIER>

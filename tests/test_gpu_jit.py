@@ -42,6 +42,24 @@ def linear_problem(k, nchains=12, nref=80, priors=False, **kw):
     return prob
 
 
+def quad_wide(ndata, nchains=10, nref=80, priors=False, ncoef=3, **kw):
+    """The tutorial's quadratic (or a line / a cubic through it) on more than 1024 points."""
+    prob = H.quad_problem(ndata=ndata, nchains=nchains, nsamples=nchains*nref, **kw)
+    prob.update(params=np.array([10.0, -2.0, 0.1, 0.001])[:ncoef],
+                pstep=np.array([1.0, 0.5, 0.1, 0.002])[:ncoef],
+                pmin=np.array([-10.0, -20.0, -10.0, -1.0])[:ncoef],
+                pmax=np.array([40.0, 20.0, 10.0, 1.0])[:ncoef])
+    if priors:
+        prob.update(prior=np.array([3.0, 0.0, 0.5, 0.0])[:ncoef],
+                    priorlow=np.array([0.5, 0.0, 0.02, 0.0])[:ncoef],
+                    priorup=np.array([0.25, 0.0, 0.04, 0.0])[:ncoef])
+    else:
+        for key in ('prior', 'priorlow', 'priorup'):
+            if key in prob:
+                prob[key] = np.zeros(ncoef)
+    return prob
+
+
 def with_pstep(prob, pstep):
     pstep = np.array(pstep)
     prob['pstep'] = pstep
@@ -89,6 +107,20 @@ CASES = {
                                                        fepsilon=0.02),
     'lin5-snooker-eps-fixed': lambda: with_pstep(
         linear_problem(5, sampler='snooker', fepsilon=0.02), [0.05, 0.05, 0.0, 0.05, 0.05]),
+    # round 5: more than 1024 points with what the wide loops of the library do not carry --
+    # 2, 4 or 8 tiles in the registers of four waves (lean_*_body<.., NW = 4, NT>)
+    'wide-quad3000-demc-fixed': lambda: with_pstep(quad_wide(3000, sampler='demc'),
+                                                   [1.0, 0.0, 0.1]),
+    'wide-quad2048-demc-eps-priors': lambda: quad_wide(2048, sampler='demc', fepsilon=0.01,
+                                                       priors=True),
+    'wide-quad5000-snooker-priors': lambda: quad_wide(5000, sampler='snooker', priors=True),
+    'wide-quad8192-snooker-eps': lambda: quad_wide(8192, sampler='snooker', fepsilon=0.01),
+    'wide-quad7000-mrw': lambda: quad_wide(7000, sampler='mrw'),
+    'wide-quad1500-mrw-shared': lambda: with_pstep(quad_wide(1500, sampler='mrw'),
+                                                   [1.0, 0.5, -2.0]),
+    'wide-line4096-demc-priors': lambda: quad_wide(4096, sampler='demc', priors=True, ncoef=2),
+    'wide-cubic6000-mrw-fixed': lambda: with_pstep(quad_wide(6000, sampler='mrw', ncoef=4),
+                                                   [1.0, 0.5, 0.0, 0.002]),
     # fixed and shared coefficients under the helper waves (a conditional gather once handed
     # the helpers zeros for the coefficients behind a fixed one: tools/fuzz_hunt.py)
     'lin8-snooker-fixed': lambda: with_pstep(linear_problem(8, sampler='snooker'),
