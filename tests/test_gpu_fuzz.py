@@ -460,3 +460,121 @@ def test_wide_kernels_random_problem(seed):
     assert gpu.plan['fast'] == 2 and gpu.plan['recoveries'] == 0, label
     compare_final(gpu, orc, label)
     gpu.close()
+
+
+def resident_async_problem(seed):
+    """Design matrices of 2..11 columns on 16 384 ... 70 000 points, DEMC, thinning 1: the
+    resident tiled plan with the owners as waves of their own and the blocks of sixteen chains
+    made up at run time (resident_async_kernel) -- ragged columns of chains, ragged last tiles,
+    fixed coefficients, priors, the support distribution, tight bounds."""
+    rs = np.random.RandomState(650000 + seed)
+    nmodel = int(rs.randint(2, 12))
+    ndata = int(rs.choice([int(rs.randint(16384, 70000)), 16384, 16385, 20480, 32768, 40961]))
+    nchains = int(rs.choice([int(rs.randint(16, 200)), 16, 17, 33, 48, 64, 129]))
+    t = np.sort(rs.uniform(-1, 1, ndata))
+    A = np.array([np.cos(0.7*k*t + 0.3*k) for k in range(nmodel)])
+    p_true = rs.uniform(-1, 1, nmodel)
+    data = p_true @ A + rs.normal(0, 1, ndata)
+    uncert = rs.uniform(0.5, 2.0, ndata)
+    pstep = np.full(nmodel, 0.03)
+    params = p_true + rs.normal(0, 0.02, nmodel)
+    if nmodel > 3 and rs.rand() < 0.4:
+        pstep[int(rs.randint(1, nmodel))] = 0.0                  # a fixed coefficient
+    width = rs.uniform(0.05, 3.0) if rs.rand() < 0.3 else 5.0    # tight bounds: many rejected
+    prior = np.zeros(nmodel)
+    plow = np.zeros(nmodel)
+    pup = np.zeros(nmodel)
+    if rs.rand() < 0.5:
+        k = int(rs.randint(0, nmodel))
+        if pstep[k] > 0:
+            prior[k], plow[k], pup[k] = p_true[k], rs.uniform(0.2, 2), rs.uniform(0.2, 2)
+    return dict(data=data, uncert=uncert, indep=A, params=params, pstep=pstep,
+                pmin=params - width, pmax=params + width, prior=prior, priorlow=plow,
+                priorup=pup, nchains=nchains, nsamples=nchains*int(rs.randint(8, 40)),
+                sampler='demc', wlike=False, thinning=1, fgamma=float(rs.uniform(0.5, 1.5)),
+                fepsilon=float(rs.choice([0.0, 0.0, 0.01])), hsize=int(rs.randint(1, 4)),
+                model='linear', seed=int(rs.randint(0, 2**31)))
+
+
+@pytest.mark.parametrize('seed', range(40))
+def test_resident_async_random_problem(seed):
+    """resident_async_kernel fuzzed (which chains share a block, and when it is multiplied, is
+    decided at run time by what has been proposed: every run takes another path through the
+    same arithmetic) -- the oracle's rows, counters and best fits exactly, across two
+    launches."""
+    from mc3_amd import engine
+    prob = resident_async_problem(seed)
+    gpu = engine.DeviceChains(**prob)
+    plan = gpu.plan
+    label = (f"linear{len(prob['params'])} ndata={len(prob['data'])} nchains={prob['nchains']} "
+             f"plan={plan}")
+    assert plan['resident'] == 1 and plan['fast'] == 4 and plan['tile'] == 2048, label
+    orc = H.make_oracle(prob, plan=plan)
+    try:
+        Z0, lp0 = H.initial_population(orc, seed=seed)
+    except ValueError:
+        gpu.close()
+        pytest.skip('no initial population within these bounds')
+    orc.set_population(Z0, lp0)
+    gpu.set_population(Z0, lp0)
+    orc.run(nthreads=4)
+    gpu.run(max(1, gpu.nzchain//3))
+    gpu.run()
+    compare_final(gpu, orc, label)
+    assert gpu.plan['recoveries'] == 0, label
+    gpu.close()
+
+
+def wide_offlean_problem(seed):
+    """1 025 ... 8 192 points with what the library's wide loops do not carry -- fixed / shared
+    coefficients, priors, the support distribution, the random walk: lean_*_body<.., NW = 4, NT>
+    specialised at run time (ctx.h wide_jit_tiles)."""
+    rs = np.random.RandomState(660000 + seed)
+    prob = wide_problem(seed)
+    nmodel = len(prob['params'])
+    nd = int(rs.choice([int(rs.randint(1025, 8193)), 1025, 2048, 2049, 4096, 4097, 8192]))
+    x = rs.uniform(-1, 1, nd)
+    p_true = prob['params']
+    prob.update(indep=x, uncert=rs.uniform(0.5, 2.0, nd),
+                data=p_true @ np.array([x**k for k in range(nmodel)]) + rs.normal(0, 1, nd),
+                sampler=str(rs.choice(['demc', 'snooker', 'mrw'])))
+    what = int(rs.randint(0, 4))
+    pstep = prob['pstep'].copy()
+    prior = np.zeros(nmodel)
+    plow = np.zeros(nmodel)
+    pup = np.zeros(nmodel)
+    if what == 0 and nmodel > 2:
+        pstep[int(rs.randint(1, nmodel))] = 0.0
+    elif what == 1:
+        k = int(rs.randint(0, nmodel))
+        prior[k], plow[k], pup[k] = p_true[k], rs.uniform(0.2, 2), rs.uniform(0.2, 2)
+    elif what == 2 and prob['sampler'] != 'mrw':
+        prob['fepsilon'] = 0.01
+    elif prob['sampler'] != 'mrw':
+        prob['sampler'] = 'mrw'
+    prob.update(pstep=pstep, prior=prior, priorlow=plow, priorup=pup)
+    return prob
+
+
+@pytest.mark.parametrize('seed', range(40))
+def test_wide_offlean_random_problem(seed):
+    from mc3_amd import engine
+    prob = wide_offlean_problem(seed)
+    gpu = engine.DeviceChains(**prob)
+    plan = gpu.plan
+    label = (f"{prob['sampler']} poly{len(prob['params'])} ndata={len(prob['data'])} "
+             f"nchains={prob['nchains']} served={gpu.jit_served} plan={plan}")
+    assert plan['persistent'] > 0 and plan['fast'] == 2 and plan['tile'] == 0, label
+    orc = H.make_oracle(prob, plan=plan)
+    try:
+        Z0, lp0 = H.initial_population(orc, seed=seed)
+    except ValueError:
+        gpu.close()
+        pytest.skip('no initial population within these bounds')
+    orc.set_population(Z0, lp0)
+    gpu.set_population(Z0, lp0)
+    orc.run(nthreads=4)
+    gpu.run(max(1, gpu.nzchain//3))
+    gpu.run()
+    compare_final(gpu, orc, label)
+    gpu.close()

@@ -17,6 +17,7 @@ import test_gpu_fuzz as F  # noqa: E402
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 bad = 0
+async_plans = 0                 # (contexts that ran resident_async_kernel)
 for seed in range(first, first + count):
     kind = seed % 4 if 'big' not in sys.argv else 4
     if os.environ.get('FUZZ_KIND'):       # (one generator only, e.g. 2 = the wavelet likelihood)
@@ -37,6 +38,12 @@ for seed in range(first, first + count):
     elif kind == 5:
         # round 5: 1 025 ... 16 384 points in the registers of several waves (FUZZ_KIND=5)
         prob = F.wide_problem(seed)
+    elif kind == 6:
+        # round 5: the resident tiled plan with nobody in step (FUZZ_KIND=6)
+        prob = F.resident_async_problem(seed)
+    elif kind == 7:
+        # round 5: the wide loops specialised at run time (FUZZ_KIND=7)
+        prob = F.wide_offlean_problem(seed)
     elif kind == 0:
         prob = F.random_problem(seed)
     elif kind == 1:
@@ -50,6 +57,7 @@ for seed in range(first, first + count):
         print(f'seed {seed} kind {kind}', file=sys.stderr, flush=True)
     try:
         gpu = engine.DeviceChains(**prob)
+        async_plans += 1 if gpu.plan.get('owner_waves', 0) > 0 else 0
         orc = H.make_oracle(prob, plan=gpu.plan)
         try:
             Z0, lp0 = H.initial_population(orc, seed=seed)
@@ -66,4 +74,5 @@ for seed in range(first, first + count):
     except Exception as e:      # noqa: BLE001
         bad += 1
         print(f'FAIL seed {seed} kind {kind}: {str(e)[:300]}', flush=True)
-print(f'{count} seeds from {first}: {bad} failures')
+print(f'{count} seeds from {first}: {bad} failures'
+      + (f' ({async_plans} contexts with owner waves)' if async_plans else ''))
