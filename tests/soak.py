@@ -28,7 +28,9 @@ if len(argv) > 5 and argv[4] == 'wavelet':
     prob = H.wavelet_problem(ndata=int(argv[5]), nchains=nchains, nsamples=nchains*niter,
                              sampler=sampler, **kw)
 elif 'lin' in extras:
-    prob = H.linear_problem(ndata=1000, nmodel=int(extras['lin']), nchains=nchains,
+    # (ndata=100000 nchains=512 lin=10 fx=1: C5, the resident tiled plan with nobody in step)
+    prob = H.linear_problem(ndata=int(extras.get('ndata', 1000)), nmodel=int(extras['lin']),
+                            nchains=nchains,
                             nsamples=nchains*niter*thin, sampler=sampler, **kw)
     if not int(extras.get('fx', 0)):
         for key in ('prior', 'priorlow', 'priorup'):
@@ -48,10 +50,10 @@ else:
     # (ndata=8192: the tiles in the registers of several waves, round 5)
     prob = H.quad_problem(ndata=int(extras.get('ndata', 1000)), nchains=nchains,
                           nsamples=nchains*niter*thin, sampler=sampler, **kw)
-orc = H.make_oracle(prob)
+gpu = engine.DeviceChains(**prob)
+orc = H.make_oracle(prob, plan=gpu.plan)    # (the plan: the order a tiled plan adds up in)
 Z0, lp0 = H.initial_population(orc)
 orc.set_population(Z0, lp0)
-gpu = engine.DeviceChains(**prob)
 gpu.set_population(Z0, lp0)
 t0 = time.perf_counter()
 gpu.run()

@@ -25,6 +25,18 @@ run 20000 snooker 256 ndata=4096
 run 12000 snooker 256 ndata=8192
 run 6000 snooker 256 ndata=16384
 run 20000 demc 512 ndata=3000
+# the resident tiled plan with nobody in step (resident_async_kernel): C5, and a ragged shape
+run 300 demc 512 lin=10 ndata=100000 fx=1
+run 1500 demc 83 lin=7 ndata=30000 fx=1
+run 1000 demc 200 lin=11 ndata=20000 fepsilon=0.01
+# the random walk / the support distribution beyond four coefficients; the wide loops
+# specialised at run time
+run 20000 mrw 256 poly=8
+run 20000 demc 256 lin=10 fepsilon=0.01
+run 20000 snooker 256 poly=6 fepsilon=0.01
+run 20000 mrw 256 ndata=8192
+run 20000 snooker 256 ndata=4096 fepsilon=0.01
+run 20000 demc 256 ndata=2048 fepsilon=0.01
 # the headline loop and its neighbours on the final library
 run 100000 demc 256
 run 60000 snooker 256
