@@ -138,11 +138,14 @@ inline bool resident_owner_lean(const mc3hip_ctx *c)
     return rs_lean_eligible(c) && !getenv("MC3HIP_NO_RS_LEAN");
 }
 // ... and the shapes resident_async_kernel takes (the grid permitting: decide_persist): design
-// matrices through the matrix cores with the hand-structured owner
+// matrices through the matrix cores -- any sampler, thinning, shared parameters (the owners
+// hand-structured where resident_owner_lean says so, the general chain otherwise)
 inline bool resident_async_shape(const mc3hip_ctx *c)
 {
-    return resident_owner_lean(c) && c->mt == MT_LINEAR && c->P.tile == 2048 &&
-           !getenv("MC3HIP_NO_RS_ASYNC");
+    // (four blocks of operand rows beside the general chain: an operand spilled and reloaded at
+    // the head of every block -- the kernel in step serves those)
+    return c->mt == MT_LINEAR && c->P.tile == 2048 && !getenv("MC3HIP_NO_RS_ASYNC") &&
+           (resident_owner_lean(c) || (c->P.nmodel + 4) / 4 <= 3);
 }
 inline bool chainwave_runs(const mc3hip_ctx *c, bool p2p)
 {

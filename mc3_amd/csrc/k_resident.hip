@@ -26,9 +26,11 @@ constexpr size_t RESIDENT_ASYNC_LDS_DOUBLES =
 
 size_t resident_async_lds_bytes(const mc3hip_ctx *c)
 {
-    // (operand blocks beyond two live in LDS, [16][512] each)
+    // (operand blocks beyond two -- beside the general chain as owner: beyond one, up to three
+    // blocks in all -- live in LDS, [16][512] each)
     const int kb = (c->P.nmodel + 4) / 4;
-    return (RESIDENT_ASYNC_LDS_DOUBLES + (kb > 2 ? (kb - 2) * 16 * 512 : 0)) * sizeof(double);
+    const int kr = (resident_owner_lean(c) || kb == 4) ? 2 : 1;
+    return (RESIDENT_ASYNC_LDS_DOUBLES + (kb > kr ? (kb - kr) * 16 * 512 : 0)) * sizeof(double);
 }
 
 size_t resident_lds_bytes(const mc3hip_ctx *c)
@@ -59,21 +61,23 @@ resident_kernel_fn pick(const mc3hip_ctx *c)
 }  // namespace
 
 namespace {
-template <bool P2P>
+template <bool P2P, bool LEAN>
 resident_kernel_fn pick_async(const mc3hip_ctx *c)
 {
     switch ((c->P.nmodel + 4) / 4) {
-    case 1: return resident_async_kernel<1, P2P>;
-    case 2: return resident_async_kernel<2, P2P>;
-    case 3: return resident_async_kernel<3, P2P>;
-    default: return resident_async_kernel<4, P2P>;
+    case 1: return resident_async_kernel<1, P2P, LEAN>;
+    case 2: return resident_async_kernel<2, P2P, LEAN>;
+    case 3: return resident_async_kernel<3, P2P, LEAN>;
+    default: return resident_async_kernel<4, P2P, LEAN>;
     }
 }
 }  // namespace
 
 resident_kernel_fn resident_async_kernel_of(const mc3hip_ctx *c, bool p2p)
 {
-    return p2p ? pick_async<true>(c) : pick_async<false>(c);
+    const bool lean = resident_owner_lean(c);
+    return p2p ? (lean ? pick_async<true, true>(c) : pick_async<true, false>(c))
+               : (lean ? pick_async<false, true>(c) : pick_async<false, false>(c));
 }
 
 // (the owner -- hand-structured or general -- is a function of the problem alone, so the

@@ -160,6 +160,19 @@ struct ResidentOwner {
     }
 };
 
+// resident_async_kernel: the owner is a wave of its own -- nothing of the tile phase is its
+// business (what run_chain calls through its hook at that point only turns the parity over)
+struct ResidentOwnerAsync : ResidentOwner {
+    __device__ __forceinline__ bool tile_phase(const DevProblem &, bool alive_in)
+    {
+        // (a wait that timed out, or the test hook, has told everybody: ctl[CTL_ABORT])
+        if (!alive_in || failed)
+            return false;
+        par ^= 1;
+        return true;
+    }
+};
+
 template <int KB, int KRMAX = 3>
 struct ResidentTile : ResidentOwner {
     // operand rows of the tile: blocks of four rows in registers (up to three: 96 registers);
@@ -938,10 +951,13 @@ __device__ __forceinline__ void resident_scheduler(const DevProblem &P, const in
 
 // (two blocks of operand rows in registers, the others in LDS: with twelve waves on the CU a
 // wave has 168 registers, and three blocks -- 96 of them -- leave too few for the rest)
-template <int KB>
-struct ResidentTileAsync : ResidentTile<KB, 2> {
-    static constexpr int KR = ResidentTile<KB, 2>::KR;
-    static constexpr int KL = ResidentTile<KB, 2>::KL;
+// (KRMAX = 1 beside the general chain as owner: its scalar state, spilled to vector lanes, takes
+// registers from every wave of the kernel -- an operand of the tile was reloaded from scratch at
+// the head of every block, a wait for everything the wave has in flight)
+template <int KB, int KRMAX = 2>
+struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
+    static constexpr int KR = ResidentTile<KB, KRMAX>::KR;
+    static constexpr int KL = ResidentTile<KB, KRMAX>::KL;
 
     // a tile wave, for the whole launch.  s_part [RA_CMAX][8]: the waves' row totals of a
     // chain; s_cnt [RA_CMAX]: waves counted in; s_sel [9][2][16]: the chains of a wave's blocks
@@ -1261,7 +1277,9 @@ struct ResidentTileAsync : ResidentTile<KB, 2> {
 // of tile 0 the column's scheduler behind them.  LDS: the waves' row totals [RA_CMAX][8],
 // their counters, the blocks' chains, the give-up word, an area per owner, and the blocks of
 // operand rows beyond two, [16][512] each.
-template <int KB, bool P2P = false>
+// (LEAN: the owners run lean_resident_owner -- DEMC, thinning 1, no trace, no shared parameters;
+// otherwise the general run_chain: any sampler, thinning, shared parameters)
+template <int KB, bool P2P = false, bool LEAN = true>
 __global__ __launch_bounds__(512 + 64 * (RA_OWNERS + 1)) void resident_async_kernel(
     const DevProblem P, const int nref, const int chain_block)
 {
@@ -1274,7 +1292,7 @@ __global__ __launch_bounds__(512 + 64 * (RA_OWNERS + 1)) void resident_async_ker
     double *s_own = smem + (RA_CMAX + 1) * 8 + RA_CMAX / 2 + 1 + 144 + 2;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = (int)(blockDim.x >> 6);
-    ResidentTileAsync<KB> T;
+    ResidentTileAsync<KB, (LEAN || KB == 4) ? 2 : 1> T;
     if (wv < 8)
         T.load(P, blockIdx.x, blockIdx.y, chain_block, smem, s_stop, s_own + RA_OWNERS * OWN);
     if (threadIdx.x < RA_CMAX + 2)
@@ -1288,8 +1306,10 @@ __global__ __launch_bounds__(512 + 64 * (RA_OWNERS + 1)) void resident_async_ker
     __syncthreads();
     if (*s_stop != 0)
         return;
+    // (rounds of proposals of the launch: thinning iterations to a refresh)
+    const int rounds = nref * P.thinning;
     if (wv < 8) {
-        T.run(P, nref, s_part, s_cnt, s_sel, s_sel + 32 * 8 + 16);
+        T.run(P, rounds, s_part, s_cnt, s_sel, s_sel + 32 * 8 + 16);
         return;
     }
     // (owners and scheduler: few instructions, and every one of them on the path between a
@@ -1299,20 +1319,25 @@ __global__ __launch_bounds__(512 + 64 * (RA_OWNERS + 1)) void resident_async_ker
         if (blockIdx.x == 0) {
             const int c0 = blockIdx.y * chain_block;
             const int c1 = (c0 + chain_block < P.nlocal) ? c0 + chain_block : P.nlocal;
-            resident_scheduler(P, nref, blockIdx.y, c0, c1 - c0, s_sel + 32 * 8);
+            resident_scheduler(P, rounds, blockIdx.y, c0, c1 - c0, s_sel + 32 * 8);
         }
         return;
     }
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     const int own_chain = wg + (int)(gridDim.x * gridDim.y) * (wv - 8);
     if (own_chain < P.nlocal) {
-        ResidentOwner O;
+        ResidentOwnerAsync O;
         O.lane = threadIdx.x & 63;
         O.par = 0;
         O.failed = false;
         O.set_owner(P, own_chain, s_own + (wv - 8) * OWN);
-        lean_resident_owner<MT_LINEAR, P2P, ResidentOwner, true>(P, nref, O, own_chain,
-                                                                 s_own + (wv - 8) * OWN);
+        if constexpr (LEAN)
+            lean_resident_owner<MT_LINEAR, P2P, ResidentOwnerAsync, true>(
+                P, nref, O, own_chain, s_own + (wv - 8) * OWN);
+        else
+            run_chain<1, MT_LINEAR, false, false, true, -1, false, PH_RESIDENT, P2P, 0, false,
+                      ResidentOwnerAsync>(P, P.ctl[0], nref, 0, -1, &O, own_chain,
+                                          s_own + (wv - 8) * OWN);
     }
 }
 

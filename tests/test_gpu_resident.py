@@ -555,16 +555,51 @@ def test_resident_async_many_launches_resume_and_abort(eng):
 
 
 def test_resident_async_shapes_it_leaves_to_the_kernel_in_step(eng):
-    """More than three chains to own per workgroup (10 tiles x 1 column, 40 chains), snooker,
-    thinning: the kernel in step, as before."""
+    """More than three chains to own per workgroup (10 tiles x 1 column, 40 chains), four blocks
+    of operand rows beside the general chain as owner: the kernel in step, as before."""
     prob = linear(ndata=20000, nmodel=7, nchains=40, niter=12)
     with env(MC3HIP_RESIDENT_MAXCOL=1):
         orc, gpu = run_pair(eng, prob, trace=False)
         assert gpu.plan['resident'] == 1 and gpu.plan['owner_waves'] == 0, gpu.plan
         assert_same(orc, gpu, trace=False)
         gpu.close()
-    for kw in (dict(sampler='snooker'), dict(thinning=2)):
-        orc, gpu = run_pair(eng, linear(nmodel=7, nchains=40, niter=10, **kw))
-        assert gpu.plan['resident'] == 1 and gpu.plan['owner_waves'] == 0, gpu.plan
+    orc, gpu = run_pair(eng, linear(nmodel=14, nchains=40, niter=10, sampler='snooker'))
+    assert gpu.plan['resident'] == 1 and gpu.plan['owner_waves'] == 0, gpu.plan
+    assert_same(orc, gpu)
+    gpu.close()
+
+
+@pytest.mark.parametrize('kw', [dict(sampler='snooker'), dict(sampler='mrw'),
+                                dict(sampler='demc', thinning=3),
+                                dict(sampler='snooker', thinning=2, nmodel=10),
+                                dict(sampler='snooker', fepsilon=0.01, nmodel=11),
+                                dict(sampler='mrw', nmodel=3), dict(sampler='demc', shared=True),
+                                dict(sampler='snooker', nmodel=10, nchains=96, ndata=40000)])
+def test_resident_async_general_owner_bit_exact(eng, kw):
+    """The other samplers, thinning, shared parameters, the trace: the general chain as owner
+    wave of resident_async_kernel (what it calls at the tile phase only turns the proposal
+    rows' parity over) -- against the oracle, with the per-iteration trace, and against the
+    kernel in step."""
+    kw = dict(kw)
+    shared = kw.pop('shared', False)
+    prob = linear(**dict(dict(nmodel=7, nchains=40, niter=20), **kw))
+    if shared:
+        prob['pstep'] = prob['pstep'].copy()
+        prob['params'] = prob['params'].copy()
+        prob['pstep'][5] = -2
+        prob['params'][5] = prob['params'][1]
+    orc, gpu = run_pair(eng, prob)
+    assert gpu.plan['resident'] == 1 and gpu.plan['owner_waves'] >= 1, gpu.plan
+    assert gpu.plan['fast'] == 0 and gpu.plan['recoveries'] == 0, gpu.plan
+    assert_same(orc, gpu)
+    gpu.close()
+    with env(MC3HIP_NO_RS_ASYNC=1):
+        orc, gpu = run_pair(eng, prob)
+        assert gpu.plan['owner_waves'] == 0
         assert_same(orc, gpu)
+        gpu.close()
+    with env(MC3HIP_TEST_ABORT_AT=7):
+        orc, gpu = run_pair(eng, prob, trace=False)
+        assert gpu.plan['recoveries'] == 1
+        assert_same(orc, gpu, trace=False)
         gpu.close()

@@ -77,6 +77,10 @@ CONFIGS = {
     'c4big': lambda n: (H.wavelet_problem(ndata=65536, nchains=256, nsamples=256*n), {}),
     'c4half': lambda n: (H.wavelet_problem(ndata=16384, nchains=128, nsamples=128*n), {}),
     'c5': lambda n: (H.linear_problem(ndata=100000, nchains=512, nsamples=512*n), {}),
+    'c5snooker': lambda n: (H.linear_problem(ndata=100000, nchains=512, nsamples=512*n,
+                                             sampler='snooker'), {}),
+    'c5mrw': lambda n: (H.linear_problem(ndata=100000, nchains=512, nsamples=512*n,
+                                         sampler='mrw'), {}),
     'c5share': lambda n: (H.linear_problem(ndata=100000, nchains=512, nsamples=512*n),
                           dict(chain0=0, nlocal=128)),
     # the tiled plan of polynomial models (vector tile kernel, three launches per iteration)
@@ -182,9 +186,10 @@ CONFIGS['c3onelag4'] = lambda n: (H.quad_problem(ndata=1000, nchains=2048, nsamp
 CONFIGS['p6'] = lambda n: _poly6(n, False)
 CONFIGS['p6matrix'] = lambda n: _poly6(n, True)
 BYTES = {'c2mrw': 24104, 'q5': 8*3*100000 + 8*3*4 + 8, 'c4mrw': 8*2*16384 + 8*5*4 + 8, 'c4demc': 8*2*16384 + 8*5*4 + 8, 'c4half': 8*2*16384 + 8*5*4 + 8, 'c2': 24104, 'c2snooker': 24104, 'c3one': 24104, 'c4': 8*2*16384 + 8*5*4 + 8,
-         'c5': 8*12*100000 + 8*10*4 + 8, 'c5share': 8*12*100000 + 8*10*4 + 8}
+         'c5': 8*12*100000 + 8*10*4 + 8, 'c5snooker': 8*12*100000 + 8*10*4 + 8,
+         'c5mrw': 8*12*100000 + 8*10*4 + 8, 'c5share': 8*12*100000 + 8*10*4 + 8}
 ITERS = {'c2': 20000, 'c2snooker': 20000, 'c2mrw': 20000, 'c3one': 4000, 'c4': 4000, 'c5': 30, 'c5share': 1}
-ITERS['c5'] = 300
+ITERS['c5'] = ITERS['c5snooker'] = ITERS['c5mrw'] = 300
 ITERS['q5'] = 300
 ITERS.update(c4big=1000, c4wide=4000, c4mrw=4000, c4demc=4000, c4half=4000, c3x2=3000, c3x4=2000, c3x2snooker=3000,
              c4x2=2000, c4x4=1000, c4x2wide=2000, c4x2mrw=2000)
