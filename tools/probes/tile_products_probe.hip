@@ -6,6 +6,9 @@
 // hand-off, no proposal rows, no sums to publish.  PIPE: the products of step s + 1 issued
 // before the multiply-adds of step s (resident_async_kernel's order); otherwise the compiler's.
 // LDSB: the third operand block read from LDS (two blocks in registers), else all in registers.
+// PIPE 2 / 3: the products two steps ahead / two steps' dependent products side by side -- no
+// faster than one step ahead (one wave alone: 1.89-1.92 us per block either way; the four
+// multiply-adds of a step cost the pipe ~46 cycles beside the matrix instructions' 192).
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o tile_products_probe tile_products_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -21,7 +24,7 @@ __device__ __forceinline__ double add_ror(double v)
     return v + __hiloint2double(h2, l2);
 }
 
-template <bool PIPE, bool LDSB, int WAVES>
+template <int PIPE, bool LDSB, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void blocks(double *out, unsigned long long *cyc,
                                                      int nblocks)
 {
@@ -53,7 +56,43 @@ __global__ __launch_bounds__(64 * WAVES) void blocks(double *out, unsigned long 
                 a[2], LDSB ? lds[wo + st * 64 * WAVES + threadIdx.x] : bop[st][KR - 1], m, 0, 0, 0);
             return m;
         };
-        if (PIPE) {
+        if (PIPE == 3) {
+            // two steps' chains side by side (the dependent products of one between those of
+            // the other), a pair of steps ahead of the multiply-adds: four product tuples
+            v4d m[4];
+            m[0] = chain(0);
+            m[1] = chain(1);
+#pragma unroll
+            for (int st = 0; st < 16; st += 2) {
+                if (st + 2 < 16) {
+                    m[(st + 2) & 3] = chain(st + 2);
+                    m[(st + 3) & 3] = chain(st + 3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[r] = __builtin_fma(m[st & 3][r], m[st & 3][r], acc[r]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[r] = __builtin_fma(m[(st + 1) & 3][r], m[(st + 1) & 3][r], acc[r]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (PIPE == 2) {
+            // the products TWO steps ahead of the multiply-adds (three product tuples)
+            v4d m[3];
+            m[0] = chain(0);
+            m[1] = chain(1);
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                if (st + 2 < 16)
+                    m[(st + 2) % 3] = chain(st + 2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[r] = __builtin_fma(m[st % 3][r], m[st % 3][r], acc[r]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (PIPE) {
             v4d m[2];
             m[0] = chain(0);
 #pragma unroll
@@ -89,7 +128,7 @@ __global__ __launch_bounds__(64 * WAVES) void blocks(double *out, unsigned long 
         cyc[0] = t1 - t0;
 }
 
-template <bool PIPE, bool LDSB, int WAVES>
+template <int PIPE, bool LDSB, int WAVES>
 void run(double *d, unsigned long long *c, const char *what, int grid = 245)
 {
     const int nb = 2000;
@@ -120,18 +159,24 @@ int main()
     unsigned long long *c;
     hipMalloc(&d, 245 * 1024 * sizeof(double));
     hipMalloc(&c, 64);
-    run<false, false, 8>(d, c, "compiler's order, three blocks in registers");
-    run<true, false, 8>(d, c, "products a step ahead, three in registers");
-    run<false, true, 8>(d, c, "compiler's order, third block in LDS");
-    run<true, true, 8>(d, c, "products a step ahead, third block in LDS");
-    run<false, false, 4>(d, c, "compiler's order, three blocks in registers");
-    run<true, false, 4>(d, c, "products a step ahead, three in registers");
-    run<true, true, 4>(d, c, "products a step ahead, third block in LDS");
+    run<0, false, 8>(d, c, "compiler's order, three blocks in registers");
+    run<1, false, 8>(d, c, "products a step ahead, three in registers");
+    run<0, true, 8>(d, c, "compiler's order, third block in LDS");
+    run<1, true, 8>(d, c, "products a step ahead, third block in LDS");
+    run<0, false, 4>(d, c, "compiler's order, three blocks in registers");
+    run<1, false, 4>(d, c, "products a step ahead, three in registers");
+    run<1, true, 4>(d, c, "products a step ahead, third block in LDS");
+    run<2, false, 8>(d, c, "products two steps ahead, three in registers");
+    run<2, false, 4>(d, c, "products two steps ahead, three in registers");
+    run<2, true, 8>(d, c, "products two steps ahead, third block in LDS");
+    run<3, false, 8>(d, c, "two steps' products side by side, a pair ahead");
+    run<3, false, 4>(d, c, "two steps' products side by side, a pair ahead");
+    run<3, true, 8>(d, c, "two steps side by side, third block in LDS");
     // is it the pipe or the power?  the same loop on fewer CUs (a wave's time per block would
     // not change if the pipe of its SIMD were all that bounds it)
     for (int grid : {8, 32, 64, 128, 192, 245, 256})
-        run<true, false, 8>(d, c, "products a step ahead, three in registers", grid);
+        run<1, false, 8>(d, c, "products a step ahead, three in registers", grid);
     for (int grid : {8, 64, 245})
-        run<true, false, 4>(d, c, "products a step ahead, three in registers", grid);
+        run<1, false, 4>(d, c, "products a step ahead, three in registers", grid);
     return 0;
 }
