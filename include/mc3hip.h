@@ -187,7 +187,10 @@ int mc3hip_get_plan(const mc3hip_ctx *ctx, mc3hip_plan *plan);
  * coefficients, design matrices of up to 10 columns, ndata <= 1024, one GPU -- the same loop
  * source is compiled for the very model (coefficient count a compile-time constant, the design
  * matrix's tile resident in registers) by the caller, who owns a compiler; the library itself
- * never needs one.
+ * never needs one.  So are (round 5) polynomials of 2..4 coefficients on 1 025 ... 8 192 points
+ * with what the library's own loops for those sizes do not carry -- a fixed or shared
+ * coefficient, a Gaussian prior, fepsilon != 0, the random walk: the tiles in the registers of
+ * four waves ("lean_mrw_body<3, true, false, false, false, false, 4, 8> /" "*threads=256*" "/").
  *   mc3hip_jit_request: the expression to instantiate, e.g.
  *     "lean_demc_body<203, false, false, false, false, false, false>" (C string into buf;
  *     empty: nothing to specialise -- the library has the kernel, or the shape has no loop).
