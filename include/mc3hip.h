@@ -57,6 +57,13 @@ extern "C" {
                                       device, a test set-up: the two-wave workgroups of all
                                       of them would not be co-resident)                    */
 
+#define MC3HIP_FLAG_NO_JIT     16u /* the caller will not specialise anything at run time (it has
+                                      no compiler, or was told not to): shapes are planned
+                                      without the loops mc3hip_jit_request would name -- where
+                                      that changes the data layout (8 193 ... 16 384 points: the
+                                      tiled plan instead of tiles in the registers of eight
+                                      waves) the choice is made at creation                 */
+
 #define MC3HIP_MAX_FREE     64
 #define MC3HIP_MAX_PARAMS  128
 

@@ -51,7 +51,7 @@ struct mc3hip_ctx {
     int wide_tiles = 0;
     // ... and of the same sizes with what those loops do not carry -- fixed / shared
     // coefficients, priors, the support distribution, the random walk: 2, 4 or 8 tiles in the
-    // registers of FOUR waves of a loop specialised at run time (lean_*_body<.., NW = 4, NT>;
+    // registers of FOUR waves (16 of EIGHT) of a loop specialised at run time (lean_*_body<.., NW = 4, NT>;
     // mc3hip_jit_request); 0 = not this context
     int wide_jit_tiles = 0;
     // wavelet likelihood, one wave per chain (<= 2048 points), the shapes of cw_lean_eligible,
@@ -255,7 +255,7 @@ inline int jit_waves(const mc3hip_ctx *c)
     const int tag = jit_model_tag(c);
     const DevProblem &P = c->P;
     if (tag != 0 && c->wide_jit_tiles > 0)
-        return 4;
+        return c->wide_jit_tiles > 8 ? 8 : 4;
     if (tag < MT_LINK0 || P.sampler == MC3HIP_MRW ||
         (P.sampler == MC3HIP_DEMC && (P.thinning > 1 || P.zlag > 0)))
         return 1;

@@ -997,13 +997,19 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
                                    !(pr->flags & (MC3HIP_FLAG_P2P | MC3HIP_FLAG_NO_PERSIST)) &&
                                    !getenv("MC3HIP_NO_WIDE") && !getenv("MC3HIP_NO_LEAN") &&
                                    !getenv("MC3HIP_NO_FAST") && !getenv("MC3HIP_NO_PERSIST") &&
-                                   !getenv("MC3HIP_NO_JIT") && !getenv("MC3HIP_WPC");
+                                   !getenv("MC3HIP_NO_JIT") && !getenv("MC3HIP_WPC") &&
+                                   !(pr->flags & MC3HIP_FLAG_NO_JIT);
             c->wide_jit_tiles = 0;
             if (c->wide_tiles == 0 && shape_jit && tiles >= 2 && tiles <= 8 &&
                 pr->nlocal <= (tiles <= 2 ? 3 : (tiles <= 4 ? 2 : 1)) * cus)
                 c->wide_jit_tiles = tiles <= 2 ? 2 : (tiles <= 4 ? 4 : 8);
+            // (sixteen tiles in the registers of EIGHT waves, one workgroup per CU: instead of
+            // the tiled plan -- so only for a caller that will specialise)
+            else if (c->wide_tiles == 0 && shape_jit && tiles > 8 && tiles <= 16 &&
+                     pr->nlocal <= cus)
+                c->wide_jit_tiles = 16;
         }
-        const bool big = c->wide_tiles == 0 &&
+        const bool big = c->wide_tiles == 0 && c->wide_jit_tiles == 0 &&
                          (nd >= 4 * 4096 || (mid_resident && nd >= 2 * 4096 &&
                                              (long long)nd * pr->nlocal >= 4194304LL));
         const bool tiled = !pr->wlike && big && pr->nlocal >= 16 && pr->nmodel <= 16 &&
@@ -1324,18 +1330,18 @@ int mc3hip_jit_request(const mc3hip_ctx *c, char *buf, int32_t capacity)
         switch (P.sampler) {
         case MC3HIP_DEMC:      // <MT, P2P, FX, MULTI, BATCH, COURIER, EPS, NW, NT>
             n = snprintf(buf, (size_t)capacity,
-                         "lean_demc_body<%d, false, %s, false, false, false, %s, 4, %d> "
-                         "/*threads=256*/", tag, fx, eps, nt);
+                         "lean_demc_body<%d, false, %s, false, false, false, %s, %d, %d> "
+                         "/*threads=%d*/", tag, fx, eps, nw, nt, 64 * nw);
             break;
         case MC3HIP_SNOOKER:   // <MT, FX, THIN, MULTI, P2P, COURIER, EPS, NW, NT>
             n = snprintf(buf, (size_t)capacity,
-                         "lean_snooker_body<%d, %s, false, false, false, false, %s, 4, %d> "
-                         "/*threads=256*/", tag, fx, eps, nt);
+                         "lean_snooker_body<%d, %s, false, false, false, false, %s, %d, %d> "
+                         "/*threads=%d*/", tag, fx, eps, nw, nt, 64 * nw);
             break;
         default:               // <MT, FX, THIN, MULTI, P2P, COURIER, NW, NT>
             n = snprintf(buf, (size_t)capacity,
-                         "lean_mrw_body<%d, %s, false, false, false, false, 4, %d> "
-                         "/*threads=256*/", tag, fx, nt);
+                         "lean_mrw_body<%d, %s, false, false, false, false, %d, %d> "
+                         "/*threads=%d*/", tag, fx, nw, nt, 64 * nw);
             break;
         }
         if (n < 0 || n >= capacity) {

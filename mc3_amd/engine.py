@@ -91,9 +91,14 @@ class DeviceChains:
         P.model_kind = {'poly': _lib.MODEL_POLY, 'linear': _lib.MODEL_LINEAR}[model]
         P.nmodel = self.nmodel
         P.thinning = self.thinning
+        # (no run-time specialisation -- switched off, or no compiler at hand: the library plans
+        # without it, include/mc3hip.h MC3HIP_FLAG_NO_JIT)
+        from . import jit as _jit
+        self._jit = bool(jit) and not no_persist and _jit.available()
         P.flags = (_lib.FLAG_NO_GRAPH if no_graph else 0) | \
             (_lib.FLAG_NO_PERSIST if no_persist else 0) | \
-            (_lib.FLAG_P2P if p2p else 0) | (_lib.FLAG_NO_COURIER if no_courier else 0)
+            (_lib.FLAG_P2P if p2p else 0) | (_lib.FLAG_NO_COURIER if no_courier else 0) | \
+            (0 if self._jit else _lib.FLAG_NO_JIT)
         self.no_courier = bool(no_courier)
         P.trace_iters = int(trace_iters)
         P.M0, P.zlen = self.M0, self.zlen
@@ -114,8 +119,7 @@ class DeviceChains:
         # run-time specialisation of the one-wave loops for this model, where the library
         # asks for one (mc3_amd/jit.py; MC3HIP_NO_JIT=1 / jit=False: the general chain)
         self.jit_served = ''
-        if jit and not no_persist:
-            from . import jit as _jit
+        if self._jit:
             self.jit_served = _jit.specialise(self)
 
     @property

@@ -118,6 +118,11 @@ CASES = {
     'wide-quad7000-mrw': lambda: quad_wide(7000, sampler='mrw'),
     'wide-quad1500-mrw-shared': lambda: with_pstep(quad_wide(1500, sampler='mrw'),
                                                    [1.0, 0.5, -2.0]),
+    # ... and 8 193 ... 16 384 points: sixteen tiles in the registers of EIGHT waves
+    'wide-quad16384-demc-priors': lambda: quad_wide(16384, sampler='demc', priors=True),
+    'wide-quad12000-mrw': lambda: quad_wide(12000, sampler='mrw'),
+    'wide-quad9000-snooker-eps-fixed': lambda: with_pstep(
+        quad_wide(9000, sampler='snooker', fepsilon=0.01), [1.0, 0.0, 0.1]),
     'wide-line4096-demc-priors': lambda: quad_wide(4096, sampler='demc', priors=True, ncoef=2),
     'wide-cubic6000-mrw-fixed': lambda: with_pstep(quad_wide(6000, sampler='mrw', ncoef=4),
                                                    [1.0, 0.5, 0.0, 0.002]),
