@@ -552,6 +552,22 @@ struct DataTile {
             }
         }
     }
+    // a tile beyond the data (the loops with several tiles in the registers of several waves):
+    // weight 0, and values the model is finite at -- every point adds fma(0, 0, acc) = acc
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            d[v] = w[v] = 0.0;
+            if constexpr (mt_is_link(MT)) {
+#pragma unroll
+                for (int k = 0; k < NA; ++k)
+                    a[v][k] = 0.0;
+            } else {
+                x[v] = 0.0;
+            }
+        }
+    }
 };
 
 constexpr double D4C0 = 0.4829629131445341, D4C1 = 0.83651630373780772,

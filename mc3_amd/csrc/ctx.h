@@ -54,6 +54,7 @@ struct mc3hip_ctx {
     // registers of FOUR waves (16 of EIGHT) of a loop specialised at run time (lean_*_body<.., NW = 4, NT>;
     // mc3hip_jit_request); 0 = not this context
     int wide_jit_tiles = 0;
+    int wide_jit_waves = 0;         // (4 or 8)
     // wavelet likelihood, one wave per chain (<= 2048 points), the shapes of cw_lean_eligible,
     // snooker without the support distribution: kernels_wavelet.h wavelet_one_kernel
     bool wl_one = false;
@@ -221,9 +222,18 @@ inline int jit_model_tag(const mc3hip_ctx *c)
         return 0;
     // more than 1024 points: polynomials of 2..4 coefficients, the tiles in the registers of
     // four waves (the shapes lean_demc_wide_kernel / lean_snooker_wide_kernel do not carry)
-    if (c->wide_jit_tiles > 0)
-        return (c->model_kind == MC3HIP_MODEL_POLY && P.nmodel >= 2 && P.nmodel <= 4 &&
-                P.thinning == 1 && P.zlag == 0 && c->mc_chains == 0) ? P.nmodel : 0;
+    // (... and of the models that are specialised anyway: polynomials of 5..8 coefficients,
+    // design matrices of up to ten columns as far as a thread's share of the tiles -- K + 2
+    // values per point -- fits its registers: mc3hip.hip wide_jit_geometry)
+    if (c->wide_jit_tiles > 0) {
+        if (P.thinning != 1 || P.zlag != 0 || c->mc_chains != 0)
+            return 0;
+        if (c->model_kind == MC3HIP_MODEL_POLY && P.nmodel >= 2 && P.nmodel <= 8)
+            return P.nmodel;
+        if (c->model_kind == MC3HIP_MODEL_LINEAR && P.nmodel >= 1 && P.nmodel <= 10)
+            return MT_LINK0 + P.nmodel;
+        return 0;
+    }
     if (c->wpc != 1 || P.npad > VLANES)
         return 0;
     int tag = 0;
@@ -255,7 +265,7 @@ inline int jit_waves(const mc3hip_ctx *c)
     const int tag = jit_model_tag(c);
     const DevProblem &P = c->P;
     if (tag != 0 && c->wide_jit_tiles > 0)
-        return c->wide_jit_tiles > 8 ? 8 : 4;
+        return c->wide_jit_waves;
     if (tag < MT_LINK0 || P.sampler == MC3HIP_MRW ||
         (P.sampler == MC3HIP_DEMC && (P.thinning > 1 || P.zlag > 0)))
         return 1;

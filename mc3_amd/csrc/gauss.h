@@ -45,12 +45,34 @@ template <int WPC, int MT, int NT = 1>
 __device__ __forceinline__ double gauss_thread_share(const Model<MT> &model,
                                                      const DataTile<WPC, MT> (&tiles)[NT])
 {
-    static_assert(NT == 1 || (!mt_is_link(MT) && MT != MT_LINEAR), "several tiles: polynomials");
+    static_assert(NT == 1 || MT != MT_LINEAR, "several tiles: the columns known at compile time");
     constexpr int NV = 16 / WPC;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const DataTile<WPC, MT> &tile = tiles[0];
     double acc[NV];
-    if constexpr (NT > 1) {
+    if constexpr (NT > 1 && mt_is_link(MT)) {
+        // (design matrices beyond one tile, round 5: column by column across the thread's
+        // points of a tile, as below; tile after tile)
+        constexpr int NC = Model<MT>::NC;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            double m[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                m[v] = tiles[q].a[v][0] * model.cf[0];
+#pragma unroll
+            for (int k = 1; k < NC; ++k) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+                    m[v] = mc3_fma(tiles[q].a[v][k], model.cf[k], m[v]);
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const double r = (m[v] - tiles[q].d[v]) * tiles[q].w[v];
+                acc[v] = mc3_fma(r, r, q == 0 ? 0.0 : acc[v]);
+            }
+        }
+    } else if constexpr (NT > 1) {
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
 #pragma unroll

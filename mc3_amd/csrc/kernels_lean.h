@@ -106,9 +106,7 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
         if (q == 0 || q * VLANES < P.npad) {
             tiles[q].load(P, q * VLANES);
         } else if constexpr (NT > 1) {
-#pragma unroll
-            for (int v = 0; v < 16 / NW; ++v)
-                tiles[q].x[v] = tiles[q].d[v] = tiles[q].w[v] = 0.0;
+            tiles[q].clear();
         }
     }
     const DataTile<NW, MT> &tile = tiles[0];
@@ -560,9 +558,7 @@ __device__ __forceinline__ void lean_snooker_body(const DevProblem &P, const int
         if (q == 0 || q * VLANES < P.npad) {
             tiles[q].load(P, q * VLANES);
         } else if constexpr (NT > 1) {
-#pragma unroll
-            for (int v = 0; v < 16 / NW; ++v)
-                tiles[q].x[v] = tiles[q].d[v] = tiles[q].w[v] = 0.0;
+            tiles[q].clear();
         }
     }
     const DataTile<NW, MT> &tile = tiles[0];
@@ -1003,9 +999,7 @@ __device__ __forceinline__ void lean_mrw_body(const DevProblem &P, const int nre
         if (q == 0 || q * VLANES < P.npad) {
             tiles[q].load(P, q * VLANES);
         } else if constexpr (NT > 1) {
-#pragma unroll
-            for (int v = 0; v < 16 / NW; ++v)
-                tiles[q].x[v] = tiles[q].d[v] = tiles[q].w[v] = 0.0;
+            tiles[q].clear();
         }
     }
     const DataTile<NW, MT> &tile = tiles[0];
@@ -1747,9 +1741,7 @@ __global__ __launch_bounds__(64 * NW) void lean_demc_wide_kernel(const DevProble
         if (q * VLANES < P.npad) {
             tile[q].load(P, q * VLANES);
         } else {                                       // (no such tile: weight 0)
-#pragma unroll
-            for (int v = 0; v < NV; ++v)
-                tile[q].x[v] = tile[q].d[v] = tile[q].w[v] = 0.0;
+            tile[q].clear();
         }
     }
     auto partial = [&](const double (&cf)[MT]) {

@@ -990,8 +990,10 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
             // support distribution, or the random walk: lean_*_body<.., NW = 4, NT> specialised
             // at run time (ctx.h jit_model_tag; without a compiler at hand: the general chain,
             // as before)
-            const bool shape_jit = !pr->wlike && !linear_model && pr->nmodel >= 2 &&
-                                   pr->nmodel <= 4 && pr->nmodel == pr->nparams && P.nfree >= 1 &&
+            const bool model_jit = linear_model ? (pr->nmodel >= 1 && pr->nmodel <= 10)
+                                                : (pr->nmodel >= 2 && pr->nmodel <= 8);
+            const bool shape_jit = !pr->wlike && model_jit && pr->nmodel == pr->nparams &&
+                                   P.nfree >= 1 &&
                                    pr->thinning == 1 && pr->zlag == 0 && pr->trace_iters == 0 &&
                                    pr->nlocal == pr->nchains &&
                                    !(pr->flags & (MC3HIP_FLAG_P2P | MC3HIP_FLAG_NO_PERSIST)) &&
@@ -1000,18 +1002,36 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
                                    !getenv("MC3HIP_NO_JIT") && !getenv("MC3HIP_WPC") &&
                                    !(pr->flags & MC3HIP_FLAG_NO_JIT);
             c->wide_jit_tiles = 0;
-            if (c->wide_tiles == 0 && shape_jit && tiles >= 2 && tiles <= 8 &&
-                pr->nlocal <= (tiles <= 2 ? 3 : (tiles <= 4 ? 2 : 1)) * cus)
-                c->wide_jit_tiles = tiles <= 2 ? 2 : (tiles <= 4 ? 4 : 8);
-            // (sixteen tiles in the registers of EIGHT waves, one workgroup per CU: instead of
-            // the tiled plan -- so only for a caller that will specialise)
-            else if (c->wide_tiles == 0 && shape_jit && tiles > 8 && tiles <= 16 &&
-                     pr->nlocal <= cus)
-                c->wide_jit_tiles = 16;
+            c->wide_jit_waves = 0;
+            if (c->wide_tiles == 0 && shape_jit && tiles >= 2 && tiles <= 16) {
+                // a thread's share of the tiles in doubles: NT tiles x 16 / NW points x (x, data,
+                // weight -- or K columns, data, weight); up to ~98 leave the loop its registers
+                // at two waves per SIMD.  Four waves per chain (two or more workgroups per CU)
+                // where that fits, eight (one workgroup per CU: 256 chains) otherwise
+                const long long per_point = linear_model ? pr->nmodel + 2 : 3;
+                const int nt = tiles <= 2 ? 2 : (tiles <= 4 ? 4 : (tiles <= 8 ? 8 : 16));
+                const long long d4 = (long long)nt * 4 * per_point, d8 = (long long)nt * 2 * per_point;
+                if (nt <= 8 && d4 <= 98 &&
+                    pr->nlocal <= (d4 <= 34 ? 3 : (d4 <= 60 ? 2 : 1)) * cus) {
+                    c->wide_jit_tiles = nt;
+                    c->wide_jit_waves = 4;
+                } else if (d8 <= 98 && pr->nlocal <= cus) {
+                    // (sixteen tiles, or what four waves do not hold: instead of the general
+                    // chain or of the tiled plan -- chosen here, so only for a caller that will
+                    // specialise)
+                    c->wide_jit_tiles = nt;
+                    c->wide_jit_waves = 8;
+                }
+            }
         }
+        // (design matrices beyond what a loop specialised at run time keeps in registers -- ten
+        // columns from 4 097 points, five from 8 193 -- ran the general chain up to 16 383
+        // points: 21-37 us per iteration of 256 chains at 8 192, where the one-launch tiled plan
+        // through the matrix cores takes ~7)
         const bool big = c->wide_tiles == 0 && c->wide_jit_tiles == 0 &&
                          (nd >= 4 * 4096 || (mid_resident && nd >= 2 * 4096 &&
-                                             (long long)nd * pr->nlocal >= 4194304LL));
+                                             (long long)nd * pr->nlocal >= 4194304LL) ||
+                          (mid_resident && mfma_model && pr->nmodel >= 5 && nd > 2 * 2048));
         const bool tiled = !pr->wlike && big && pr->nlocal >= 16 && pr->nmodel <= 16 &&
                            !getenv("MC3HIP_NO_TILED");
         P.tile = tiled ? ((pr->nmodel <= 4 && !mfma_model) ? 4096 : 2048) : 0;

@@ -578,3 +578,66 @@ def test_wide_offlean_random_problem(seed):
     gpu.run()
     compare_final(gpu, orc, label)
     gpu.close()
+
+
+def wide_models_problem(seed):
+    """The models that are specialised at run time -- polynomials of 5..8 coefficients, design
+    matrices of 1..10 columns -- on 1 025 ... 16 384 points: tiles in the registers of four /
+    eight waves where a thread's share fits, the tiled plans otherwise; any sampler, fixed
+    coefficients, priors, the support distribution; ragged last tiles."""
+    rs = np.random.RandomState(670000 + seed)
+    linear = bool(rs.rand() < 0.6)
+    nmodel = int(rs.randint(1, 11)) if linear else int(rs.randint(5, 9))
+    nd = int(rs.choice([int(rs.randint(1025, 16385)), 1025, 2048, 2049, 4096, 4097, 5000, 8192,
+                        8193, 12000]))
+    nchains = int(rs.randint(3, 40))
+    t = np.sort(rs.uniform(-1, 1, nd))
+    p_true = rs.uniform(-1, 1, nmodel)
+    if linear:
+        A = np.array([np.cos(0.9*k*t + 0.2*k) for k in range(nmodel)])
+        data = p_true @ A + rs.normal(0, 1, nd)
+        indep, model = A, 'linear'
+    else:
+        data = p_true @ np.array([t**k for k in range(nmodel)]) + rs.normal(0, 1, nd)
+        indep, model = t, 'poly'
+    pstep = np.full(nmodel, 0.03)
+    if nmodel > 2 and rs.rand() < 0.3:
+        pstep[int(rs.randint(1, nmodel))] = 0.0
+    prior = np.zeros(nmodel)
+    plow = np.zeros(nmodel)
+    pup = np.zeros(nmodel)
+    if rs.rand() < 0.4:
+        k = int(rs.randint(0, nmodel))
+        if pstep[k] > 0:
+            prior[k], plow[k], pup[k] = p_true[k], rs.uniform(0.2, 2), rs.uniform(0.2, 2)
+    sampler = str(rs.choice(['demc', 'snooker', 'mrw']))
+    return dict(data=data, uncert=rs.uniform(0.5, 2.0, nd), indep=indep, params=p_true.copy(),
+                pstep=pstep, pmin=p_true - rs.uniform(0.5, 4.0, nmodel),
+                pmax=p_true + rs.uniform(0.5, 4.0, nmodel), prior=prior, priorlow=plow,
+                priorup=pup, nchains=nchains, nsamples=nchains*int(rs.randint(10, 50)),
+                sampler=sampler, wlike=False, thinning=1, fgamma=float(rs.uniform(0.5, 1.5)),
+                fepsilon=float(rs.choice([0.0, 0.0, 0.01])) if sampler != 'mrw' else 0.0,
+                hsize=int(rs.randint(1, 4)), model=model, seed=int(rs.randint(0, 2**31)))
+
+
+@pytest.mark.parametrize('seed', range(60))
+def test_wide_models_random_problem(seed):
+    from mc3_amd import engine
+    prob = wide_models_problem(seed)
+    gpu = engine.DeviceChains(**prob)
+    plan = gpu.plan
+    label = (f"{prob['sampler']} {prob['model']}{len(prob['params'])} ndata={len(prob['data'])} "
+             f"nchains={prob['nchains']} served={gpu.jit_served} plan={plan}")
+    orc = H.make_oracle(prob, plan=plan)
+    try:
+        Z0, lp0 = H.initial_population(orc, seed=seed)
+    except ValueError:
+        gpu.close()
+        pytest.skip('no initial population within these bounds')
+    orc.set_population(Z0, lp0)
+    gpu.set_population(Z0, lp0)
+    orc.run(nthreads=4)
+    gpu.run(max(1, gpu.nzchain//3))
+    gpu.run()
+    compare_final(gpu, orc, label)
+    gpu.close()

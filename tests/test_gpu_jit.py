@@ -20,10 +20,10 @@ def eng():
     return engine
 
 
-def poly_problem(k, nchains=12, nref=80, **kw):
+def poly_problem(k, nchains=12, nref=80, ndata=300, **kw):
     """A polynomial of k coefficients around the tutorial's quadratic on x in [0, 1]."""
-    prob = H.quad_problem(ndata=300, nchains=nchains, nsamples=nchains*nref*kw.get('thinning', 1),
-                          **kw)
+    prob = H.quad_problem(ndata=ndata, nchains=nchains,
+                          nsamples=nchains*nref*kw.get('thinning', 1), **kw)
     pad = k - 3
     prob.update(indep=prob['indep']/10.0,
                 params=np.concatenate([[10.0, -20.0, 10.0], np.zeros(pad)]),
@@ -33,8 +33,8 @@ def poly_problem(k, nchains=12, nref=80, **kw):
     return prob
 
 
-def linear_problem(k, nchains=12, nref=80, priors=False, **kw):
-    prob = H.linear_problem(ndata=700, nmodel=k, nchains=nchains,
+def linear_problem(k, nchains=12, nref=80, priors=False, ndata=700, **kw):
+    prob = H.linear_problem(ndata=ndata, nmodel=k, nchains=nchains,
                             nsamples=nchains*nref*kw.get('thinning', 1), **kw)
     if not priors:
         for key in ('prior', 'priorlow', 'priorup'):
@@ -123,6 +123,19 @@ CASES = {
     'wide-quad12000-mrw': lambda: quad_wide(12000, sampler='mrw'),
     'wide-quad9000-snooker-eps-fixed': lambda: with_pstep(
         quad_wide(9000, sampler='snooker', fepsilon=0.01), [1.0, 0.0, 0.1]),
+    # ... and the models that are specialised anyway, beyond one register tile
+    'wide-poly6-3000-snooker': lambda: poly_problem(6, sampler='snooker', ndata=3000),
+    'wide-poly8-8000-mrw': lambda: poly_problem(8, sampler='mrw', ndata=8000),
+    'wide-poly5-12000-demc-eps': lambda: poly_problem(5, sampler='demc', fepsilon=0.01,
+                                                      ndata=12000),
+    'wide-lin5-2048-demc-priors': lambda: linear_problem(5, sampler='demc', priors=True,
+                                                         ndata=2048),
+    'wide-lin10-2000-snooker': lambda: linear_problem(10, sampler='snooker', ndata=2000),
+    'wide-lin10-4096-mrw': lambda: linear_problem(10, sampler='mrw', ndata=4096),
+    'wide-lin4-5000-demc-eps': lambda: linear_problem(4, sampler='demc', fepsilon=0.01,
+                                                      ndata=5000),
+    'wide-lin2-8000-snooker-priors': lambda: linear_problem(2, sampler='snooker', priors=True,
+                                                            ndata=8000),
     'wide-line4096-demc-priors': lambda: quad_wide(4096, sampler='demc', priors=True, ncoef=2),
     'wide-cubic6000-mrw-fixed': lambda: with_pstep(quad_wide(6000, sampler='mrw', ncoef=4),
                                                    [1.0, 0.5, 0.0, 0.002]),

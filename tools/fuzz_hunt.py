@@ -44,6 +44,9 @@ for seed in range(first, first + count):
     elif kind == 7:
         # round 5: the wide loops specialised at run time (FUZZ_KIND=7)
         prob = F.wide_offlean_problem(seed)
+    elif kind == 8:
+        # round 5: the models specialised at run time, beyond one register tile (FUZZ_KIND=8)
+        prob = F.wide_models_problem(seed)
     elif kind == 0:
         prob = F.random_problem(seed)
     elif kind == 1:
