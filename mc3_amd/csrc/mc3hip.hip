@@ -462,7 +462,18 @@ int decide_persist(mc3hip_ctx *c)
         c->resident_owner_waves = 0;
         const long long nwg = ncol * c->P.ntiles;
         const long long owners = ((long long)c->P.nlocal + nwg - 1) / nwg;
-        if (resident_async_shape(c) && cb <= RA_CMAX && owners <= RA_OWNERS &&
+        // ... where it pays: an iteration in step costs ~6 us of hand-offs + 3.4 us per block
+        // of sixteen chains of a column; with nobody in step the hand-offs overlap with the
+        // blocks, but a chain's own round -- sum, decision, row, the partners' proposals, the
+        // scheduler, the rows of the block -- is ~8 round trips of 1.2 us, and below ~20 us of
+        // matrix work per iteration THAT is what an iteration takes (tools/
+        // sweep_resident_async.py: 256 chains x 16 384 points x 10 columns 8.2 us in step, 11.3
+        // not; 512 x 100 000 29.9 / 29.3, with snooker 31.9 / 30.1).  DEMC, whose proposals wait
+        // for two partners' decisions, from six blocks per column; the samplers that wait for
+        // nobody from four.  (MC3HIP_RS_ASYNC=1: whatever the size -- the tests.)
+        const bool async_pays = getenv("MC3HIP_RS_ASYNC") != nullptr ||
+                                cb / 16 >= (resident_owner_lean(c) ? 6 : 4);
+        if (resident_async_shape(c) && async_pays && cb <= RA_CMAX && owners <= RA_OWNERS &&
             nwg <= prop.multiProcessorCount) {
             bool fits = true;
             for (int p2p = 0; p2p < 2; ++p2p) {
@@ -1031,7 +1042,7 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         const bool big = c->wide_tiles == 0 && c->wide_jit_tiles == 0 &&
                          (nd >= 4 * 4096 || (mid_resident && nd >= 2 * 4096 &&
                                              (long long)nd * pr->nlocal >= 4194304LL) ||
-                          (mid_resident && mfma_model && pr->nmodel >= 5 && nd > 2 * 2048));
+                          (mid_resident && mfma_model && nd > 2 * 2048));
         const bool tiled = !pr->wlike && big && pr->nlocal >= 16 && pr->nmodel <= 16 &&
                            !getenv("MC3HIP_NO_TILED");
         P.tile = tiled ? ((pr->nmodel <= 4 && !mfma_model) ? 4096 : 2048) : 0;

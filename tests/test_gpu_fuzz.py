@@ -497,13 +497,14 @@ def resident_async_problem(seed):
 
 
 @pytest.mark.parametrize('seed', range(40))
-def test_resident_async_random_problem(seed):
+def test_resident_async_random_problem(seed, monkeypatch):
     """resident_async_kernel fuzzed (which chains share a block, and when it is multiplied, is
     decided at run time by what has been proposed: every run takes another path through the
     same arithmetic) -- the oracle's rows, counters and best fits exactly, across two
     launches."""
     from mc3_amd import engine
     prob = resident_async_problem(seed)
+    monkeypatch.setenv('MC3HIP_RS_ASYNC', '1')      # (whatever the size: decide_persist)
     gpu = engine.DeviceChains(**prob)
     plan = gpu.plan
     label = (f"linear{len(prob['params'])} ndata={len(prob['data'])} nchains={prob['nchains']} "

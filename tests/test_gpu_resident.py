@@ -512,8 +512,10 @@ def test_resident_async_bit_exact(eng, case):
     when, changes no bit -- the same rows, counters and best fits as the oracle, and as the
     kernel that goes through an iteration in step (MC3HIP_NO_RS_ASYNC=1)."""
     prob = _async_case(case)
-    kw = {'long_column': dict(MC3HIP_RESIDENT_MAXCOL=4),
-          'ragged': dict(MC3HIP_RESIDENT_MAXCOL=3)}.get(case, {})
+    # (MC3HIP_RS_ASYNC=1: whatever the size -- the library itself takes this kernel from six
+    # blocks of sixteen chains per column on, decide_persist)
+    kw = dict({'long_column': dict(MC3HIP_RESIDENT_MAXCOL=4),
+               'ragged': dict(MC3HIP_RESIDENT_MAXCOL=3)}.get(case, {}), MC3HIP_RS_ASYNC=1)
     with env(**kw):
         orc, gpu = run_pair(eng, prob, trace=False)
         plan = gpu.plan
@@ -535,7 +537,7 @@ def test_resident_async_many_launches_resume_and_abort(eng):
     the run split over several calls; a wave that gives up at refresh 9 ends the launch for
     everybody -- tile waves, owners, schedulers -- and the run is redone from the checkpoint."""
     prob = linear(ndata=24000, nmodel=10, nchains=80, niter=60)
-    with env(MC3HIP_PERSIST_REFS=5):
+    with env(MC3HIP_PERSIST_REFS=5, MC3HIP_RS_ASYNC=1):
         gpu = eng.DeviceChains(**prob)
         assert gpu.plan['owner_waves'] >= 1 and gpu.plan['persistent'] == 5, gpu.plan
         orc = H.make_oracle(prob, plan=gpu.plan)
@@ -547,7 +549,7 @@ def test_resident_async_many_launches_resume_and_abort(eng):
             gpu.run(n)
         assert_same(orc, gpu, trace=False)
         gpu.close()
-    with env(MC3HIP_TEST_ABORT_AT=9):
+    with env(MC3HIP_TEST_ABORT_AT=9, MC3HIP_RS_ASYNC=1):
         orc, gpu = run_pair(eng, prob, trace=False)
         assert gpu.plan['recoveries'] == 1
         assert_same(orc, gpu, trace=False)
@@ -558,15 +560,24 @@ def test_resident_async_shapes_it_leaves_to_the_kernel_in_step(eng):
     """More than three chains to own per workgroup (10 tiles x 1 column, 40 chains), four blocks
     of operand rows beside the general chain as owner: the kernel in step, as before."""
     prob = linear(ndata=20000, nmodel=7, nchains=40, niter=12)
-    with env(MC3HIP_RESIDENT_MAXCOL=1):
+    with env(MC3HIP_RESIDENT_MAXCOL=1, MC3HIP_RS_ASYNC=1):
         orc, gpu = run_pair(eng, prob, trace=False)
         assert gpu.plan['resident'] == 1 and gpu.plan['owner_waves'] == 0, gpu.plan
         assert_same(orc, gpu, trace=False)
         gpu.close()
-    orc, gpu = run_pair(eng, linear(nmodel=14, nchains=40, niter=10, sampler='snooker'))
-    assert gpu.plan['resident'] == 1 and gpu.plan['owner_waves'] == 0, gpu.plan
-    assert_same(orc, gpu)
-    gpu.close()
+    with env(MC3HIP_RS_ASYNC=1):
+        orc, gpu = run_pair(eng, linear(nmodel=14, nchains=40, niter=10, sampler='snooker'))
+        assert gpu.plan['resident'] == 1 and gpu.plan['owner_waves'] == 0, gpu.plan
+        assert_same(orc, gpu)
+        gpu.close()
+    # small problems: fewer than six (DEMC) / four (the other samplers) blocks of sixteen chains
+    # per column -- an iteration in step is shorter than a chain's round through the hand-offs
+    for smp in ('demc', 'snooker'):
+        orc, gpu = run_pair(eng, linear(ndata=30000, nmodel=10, nchains=96, niter=6,
+                                        sampler=smp), trace=False)
+        assert gpu.plan['resident'] == 1 and gpu.plan['owner_waves'] == 0, gpu.plan
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
 
 
 @pytest.mark.parametrize('kw', [dict(sampler='snooker'), dict(sampler='mrw'),
@@ -588,17 +599,18 @@ def test_resident_async_general_owner_bit_exact(eng, kw):
         prob['params'] = prob['params'].copy()
         prob['pstep'][5] = -2
         prob['params'][5] = prob['params'][1]
-    orc, gpu = run_pair(eng, prob)
-    assert gpu.plan['resident'] == 1 and gpu.plan['owner_waves'] >= 1, gpu.plan
-    assert gpu.plan['fast'] == 0 and gpu.plan['recoveries'] == 0, gpu.plan
-    assert_same(orc, gpu)
-    gpu.close()
+    with env(MC3HIP_RS_ASYNC=1):
+        orc, gpu = run_pair(eng, prob)
+        assert gpu.plan['resident'] == 1 and gpu.plan['owner_waves'] >= 1, gpu.plan
+        assert gpu.plan['fast'] == 0 and gpu.plan['recoveries'] == 0, gpu.plan
+        assert_same(orc, gpu)
+        gpu.close()
     with env(MC3HIP_NO_RS_ASYNC=1):
         orc, gpu = run_pair(eng, prob)
         assert gpu.plan['owner_waves'] == 0
         assert_same(orc, gpu)
         gpu.close()
-    with env(MC3HIP_TEST_ABORT_AT=7):
+    with env(MC3HIP_TEST_ABORT_AT=7, MC3HIP_RS_ASYNC=1):
         orc, gpu = run_pair(eng, prob, trace=False)
         assert gpu.plan['recoveries'] == 1
         assert_same(orc, gpu, trace=False)

@@ -39,7 +39,8 @@ for seed in range(first, first + count):
         # round 5: 1 025 ... 16 384 points in the registers of several waves (FUZZ_KIND=5)
         prob = F.wide_problem(seed)
     elif kind == 6:
-        # round 5: the resident tiled plan with nobody in step (FUZZ_KIND=6)
+        # round 5: the resident tiled plan with nobody in step (FUZZ_KIND=6), whatever the size
+        os.environ['MC3HIP_RS_ASYNC'] = '1'
         prob = F.resident_async_problem(seed)
     elif kind == 7:
         # round 5: the wide loops specialised at run time (FUZZ_KIND=7)

@@ -27,8 +27,10 @@ run 6000 snooker 256 ndata=16384
 run 20000 demc 512 ndata=3000
 # the resident tiled plan with nobody in step (resident_async_kernel): C5, and a ragged shape
 run 300 demc 512 lin=10 ndata=100000 fx=1
-run 1500 demc 83 lin=7 ndata=30000 fx=1
-run 1000 demc 200 lin=11 ndata=20000 fepsilon=0.01
+MC3HIP_RS_ASYNC=1 run 1500 demc 83 lin=7 ndata=30000 fx=1
+MC3HIP_RS_ASYNC=1 run 1000 demc 200 lin=11 ndata=20000 fepsilon=0.01
+MC3HIP_RS_ASYNC=1 run 1000 snooker 96 lin=10 ndata=40000 fx=1
+run 200 snooker 512 lin=10 ndata=100000 fx=1
 # the random walk / the support distribution beyond four coefficients; the wide loops
 # specialised at run time
 run 20000 mrw 256 poly=8
