@@ -226,12 +226,36 @@ inline int jit_model_tag(const mc3hip_ctx *c)
     // design matrices of up to ten columns as far as a thread's share of the tiles -- K + 2
     // values per point -- fits its registers: mc3hip.hip wide_jit_geometry)
     if (c->wide_jit_tiles > 0) {
-        if (P.thinning != 1 || P.zlag != 0 || c->mc_chains != 0)
+        // (thinning > 1: the snooker and random-walk loops have a flavour for it -- not with the
+        // support distribution; DEMC's is the one-tile loop of the declared cadence)
+        const bool thin_ok = P.thinning == 1 ||
+                             (P.sampler == MC3HIP_MRW) ||
+                             (P.sampler == MC3HIP_SNOOKER && P.fepsilon == 0.0);
+        if (!thin_ok || P.zlag != 0 || c->mc_chains != 0)
             return 0;
         if (c->model_kind == MC3HIP_MODEL_POLY && P.nmodel >= 2 && P.nmodel <= 8)
             return P.nmodel;
         if (c->model_kind == MC3HIP_MODEL_LINEAR && P.nmodel >= 1 && P.nmodel <= 10)
             return MT_LINK0 + P.nmodel;
+        return 0;
+    }
+    // What is left of the polynomials of 2..4 coefficients (the library's own instances: the
+    // plain shapes, and one tile with fixed coefficients / priors at thinning 1): ONE wave,
+    //  * one tile, fixed coefficients / priors AND thinning > 1 (snooker, random walk);
+    //  * 1 025 ... 4 096 points (two tiles in registers, the others streamed: MULTI) with fixed
+    //    coefficients / priors or thinning > 1, where the ensemble is too large for the tiles to
+    //    sit in the registers of four waves per chain (snooker and the random walk; DEMC with
+    //    thinning 1 and without the support distribution).
+    if (c->model_kind == MC3HIP_MODEL_POLY && P.nmodel >= 2 && P.nmodel <= 4 && c->wpc == 1 &&
+        P.zlag == 0 && c->mc_chains == 0 && P.npad <= 4 * VLANES) {
+        const bool plain = P.nfree == P.nparams && P.ngprior == 0 && P.nshare == 0;
+        const bool other = P.sampler == MC3HIP_MRW ||
+                           (P.sampler == MC3HIP_SNOOKER && P.fepsilon == 0.0);
+        if (P.npad <= VLANES)
+            return (!plain && P.thinning > 1 && other) ? P.nmodel : 0;
+        if ((!plain || P.thinning > 1) &&
+            (other || (P.sampler == MC3HIP_DEMC && P.thinning == 1 && P.fepsilon == 0.0)))
+            return P.nmodel;
         return 0;
     }
     if (c->wpc != 1 || P.npad > VLANES)
@@ -266,6 +290,8 @@ inline int jit_waves(const mc3hip_ctx *c)
     const DevProblem &P = c->P;
     if (tag != 0 && c->wide_jit_tiles > 0)
         return c->wide_jit_waves;
+    if (tag != 0 && tag <= 4)                   // (the leftovers of the small polynomials)
+        return 1;
     if (tag < MT_LINK0 || P.sampler == MC3HIP_MRW ||
         (P.sampler == MC3HIP_DEMC && (P.thinning > 1 || P.zlag > 0)))
         return 1;

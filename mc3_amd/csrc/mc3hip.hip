@@ -1004,8 +1004,9 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
             const bool model_jit = linear_model ? (pr->nmodel >= 1 && pr->nmodel <= 10)
                                                 : (pr->nmodel >= 2 && pr->nmodel <= 8);
             const bool shape_jit = !pr->wlike && model_jit && pr->nmodel == pr->nparams &&
-                                   P.nfree >= 1 &&
-                                   pr->thinning == 1 && pr->zlag == 0 && pr->trace_iters == 0 &&
+                                   P.nfree >= 1 && pr->zlag == 0 && pr->trace_iters == 0 &&
+                                   (pr->thinning == 1 || pr->sampler == MC3HIP_MRW ||
+                                    (pr->sampler == MC3HIP_SNOOKER && pr->fepsilon == 0.0)) &&
                                    pr->nlocal == pr->nchains &&
                                    !(pr->flags & (MC3HIP_FLAG_P2P | MC3HIP_FLAG_NO_PERSIST)) &&
                                    !getenv("MC3HIP_NO_WIDE") && !getenv("MC3HIP_NO_LEAN") &&
@@ -1366,13 +1367,37 @@ int mc3hip_jit_request(const mc3hip_ctx *c, char *buf, int32_t capacity)
             break;
         case MC3HIP_SNOOKER:   // <MT, FX, THIN, MULTI, P2P, COURIER, EPS, NW, NT>
             n = snprintf(buf, (size_t)capacity,
-                         "lean_snooker_body<%d, %s, false, false, false, false, %s, %d, %d> "
-                         "/*threads=%d*/", tag, fx, eps, nw, nt, 64 * nw);
+                         "lean_snooker_body<%d, %s, %s, false, false, false, %s, %d, %d> "
+                         "/*threads=%d*/", tag, fx, thin, eps, nw, nt, 64 * nw);
             break;
         default:               // <MT, FX, THIN, MULTI, P2P, COURIER, NW, NT>
             n = snprintf(buf, (size_t)capacity,
-                         "lean_mrw_body<%d, %s, false, false, false, false, %d, %d> "
-                         "/*threads=%d*/", tag, fx, nw, nt, 64 * nw);
+                         "lean_mrw_body<%d, %s, %s, false, false, false, %d, %d> "
+                         "/*threads=%d*/", tag, fx, thin, nw, nt, 64 * nw);
+            break;
+        }
+        if (n < 0 || n >= capacity) {
+            buf[0] = 0;
+            return fail(MC3HIP_ERR_ARG, "buffer of %d bytes too small for the request", capacity);
+        }
+        return MC3HIP_OK;
+    }
+    if (tag <= 4) {
+        // the leftovers of the polynomials of 2..4 coefficients (ctx.h jit_model_tag): one wave
+        const char *multi = P.npad > VLANES ? "true" : "false";
+        switch (P.sampler) {
+        case MC3HIP_DEMC:      // <MT, P2P, FX, MULTI, BATCH, COURIER, EPS>
+            n = snprintf(buf, (size_t)capacity,
+                         "lean_demc_body<%d, false, %s, %s, false, false, false>", tag, fx, multi);
+            break;
+        case MC3HIP_SNOOKER:   // <MT, FX, THIN, MULTI, P2P, COURIER, EPS>
+            n = snprintf(buf, (size_t)capacity,
+                         "lean_snooker_body<%d, %s, %s, %s, false, false, false>", tag, fx, thin,
+                         multi);
+            break;
+        default:               // <MT, FX, THIN, MULTI, P2P, COURIER>
+            n = snprintf(buf, (size_t)capacity, "lean_mrw_body<%d, %s, %s, %s, false, false>", tag,
+                         fx, thin, multi);
             break;
         }
         if (n < 0 || n >= capacity) {

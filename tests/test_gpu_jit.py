@@ -44,7 +44,8 @@ def linear_problem(k, nchains=12, nref=80, priors=False, ndata=700, **kw):
 
 def quad_wide(ndata, nchains=10, nref=80, priors=False, ncoef=3, **kw):
     """The tutorial's quadratic (or a line / a cubic through it) on more than 1024 points."""
-    prob = H.quad_problem(ndata=ndata, nchains=nchains, nsamples=nchains*nref, **kw)
+    prob = H.quad_problem(ndata=ndata, nchains=nchains,
+                          nsamples=nchains*nref*kw.get('thinning', 1), **kw)
     prob.update(params=np.array([10.0, -2.0, 0.1, 0.001])[:ncoef],
                 pstep=np.array([1.0, 0.5, 0.1, 0.002])[:ncoef],
                 pmin=np.array([-10.0, -20.0, -10.0, -1.0])[:ncoef],
@@ -123,6 +124,21 @@ CASES = {
     'wide-quad12000-mrw': lambda: quad_wide(12000, sampler='mrw'),
     'wide-quad9000-snooker-eps-fixed': lambda: with_pstep(
         quad_wide(9000, sampler='snooker', fepsilon=0.01), [1.0, 0.0, 0.1]),
+    # what was left of the small polynomials: thinning with fixed coefficients / priors, thinning
+    # on the wide loops, ensembles too large for the wide loops (one wave, two tiles in registers)
+    'left-quad1000-snooker-priors-thin3': lambda: quad_wide(1000, sampler='snooker', priors=True,
+                                                            thinning=3),
+    'left-quad700-mrw-fixed-thin2': lambda: with_pstep(quad_wide(700, sampler='mrw', thinning=2),
+                                                       [1.0, 0.0, 0.1]),
+    'left-quad3000-snooker-thin3': lambda: quad_wide(3000, sampler='snooker', thinning=3),
+    'left-quad5000-mrw-priors-thin2': lambda: quad_wide(5000, sampler='mrw', priors=True,
+                                                        thinning=2),
+    'left-quad2048-demc-priors-800chains': lambda: quad_wide(2048, sampler='demc', priors=True,
+                                                             nchains=800, nref=80),
+    'left-quad3000-snooker-fixed-600chains': lambda: with_pstep(
+        quad_wide(3000, sampler='snooker', nchains=600, nref=80), [1.0, 0.0, 0.1]),
+    'left-quad4096-mrw-thin2-600chains': lambda: quad_wide(4096, sampler='mrw', thinning=2,
+                                                           nchains=600, nref=80),
     # ... and the models that are specialised anyway, beyond one register tile
     'wide-poly6-3000-snooker': lambda: poly_problem(6, sampler='snooker', ndata=3000),
     'wide-poly8-8000-mrw': lambda: poly_problem(8, sampler='mrw', ndata=8000),
