@@ -230,7 +230,8 @@ inline int jit_model_tag(const mc3hip_ctx *c)
         // support distribution; DEMC's is the one-tile loop of the declared cadence)
         const bool thin_ok = P.thinning == 1 ||
                              (P.sampler == MC3HIP_MRW) ||
-                             (P.sampler == MC3HIP_SNOOKER && P.fepsilon == 0.0);
+                             (P.sampler == MC3HIP_SNOOKER && P.fepsilon == 0.0) ||
+                             (P.sampler == MC3HIP_DEMC && P.fepsilon == 0.0);
         if (!thin_ok || P.zlag != 0 || c->mc_chains != 0)
             return 0;
         if (c->model_kind == MC3HIP_MODEL_POLY && P.nmodel >= 2 && P.nmodel <= 8)

@@ -1226,15 +1226,20 @@ __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_mrw_kernel(const DevP
 // fixed accumulation registers, two sets used in turn by a loop unrolled by two: bit-identical,
 // SLOWER (213 against 306 M chain-steps/s at 256 chains) and over the registers of two waves per
 // SIMD; not kept.)
-template <int MT, bool P2P, bool FX, bool COURIER>
+// (NW = 4 / 8, NT = 2 ... 16: more than 1024 points in the registers of several waves, the helper
+// waves of gauss.h SumHelpers sharing the data sum -- thinning > 1 beyond one tile, specialised
+// at run time, round 5)
+template <int MT, bool P2P, bool FX, bool COURIER, int NW = 1, int NT = 1>
 __device__ __forceinline__ void lean_demc_lag_body(const DevProblem &P, const int nref)
 {
     static_assert(!COURIER || P2P, "the courier carries rows to other ranks' replicas");
+    static_assert(NW == 1 || (!P2P && !COURIER), "helper waves: one GPU");
+    static_assert(NT == 1 || NW > 1, "several tiles: in the registers of several waves");
     constexpr int ZS = ZROW;
     constexpr int NB = 64;                     // iterations per batch of draws (one per lane)
     constexpr int NC = Model<MT>::NC;         // coefficients the model tag fixes
     const int nf = FX ? P.nfree : NC;
-    const int lane = COURIER ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    const int lane = (COURIER || NW > 1) ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     const int lc = blockIdx.x;
     const int c = P.chain0 + lc;
     const bool mine = lane < nf;
@@ -1243,6 +1248,11 @@ __device__ __forceinline__ void lean_demc_lag_body(const DevProblem &P, const in
     __shared__ double s_ring[P2P ? COURIER_RING * ZROW : 1];
     __shared__ int s_cour[4];
     (void)s_ring; (void)s_cour;
+    __shared__ double s_hpart[NW > 1 ? 64 * NW : 1], s_hcf[16];
+    __shared__ int s_hcmd[2];
+    (void)s_hpart; (void)s_hcf; (void)s_hcmd;
+    SumHelpers<MT, (NW > 1 ? NW : 2), NT> helpers;     // (gauss.h: helper waves share the data sum)
+    (void)helpers;
     if constexpr (COURIER) {
         if (!courier_begin(s_ring, s_cour, ctl_rw))
             return;
@@ -1250,6 +1260,11 @@ __device__ __forceinline__ void lean_demc_lag_body(const DevProblem &P, const in
             courier_run<true>(P, s_ring, s_cour, lane, nf, c);
             return;
         }
+    } else if constexpr (NW > 1) {
+        if (!helpers.enter(s_hpart, s_hcf, s_hcmd,
+                           __hip_atomic_load(&ctl_rw[CTL_ABORT], __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT) != 0))
+            return;
     } else {
         if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
                 &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
@@ -1268,8 +1283,23 @@ __device__ __forceinline__ void lean_demc_lag_body(const DevProblem &P, const in
     DelayedRows late;
     late.begin(P, P.ctl[0], c, lane);
     (void)late;
-    DataTile<1, MT> tile;
-    tile.load(P);
+    // (NT tiles of 1024 points in the registers of the NW waves between them; tiles beyond the
+    // data: weight 0)
+    DataTile<NW, MT> tiles[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        if (q == 0 || q * VLANES < P.npad)
+            tiles[q].load(P, q * VLANES);
+        else if constexpr (NT > 1)
+            tiles[q].clear();
+    }
+    const DataTile<NW, MT> &tile = tiles[0];
+    if constexpr (NW > 1) {
+        if (threadIdx.x >= 64) {
+            helpers.serve(P, tiles);
+            return;
+        }
+    }
     const long long R0 = P.ctl[0];
     const int n = P.nchains;
     const int th = P.thinning;
@@ -1298,11 +1328,18 @@ __device__ __forceinline__ void lean_demc_lag_body(const DevProblem &P, const in
     int kf[NC];
     double fx[NC];
     PriorLanes<NC> priors;
+    int hkf = 0;                               // (helper waves, FX: what coefficient `lane` is)
+    double hfx = 0.0;
     if constexpr (FX) {
         coefficient_map<NC>(P, kf, fx);
         priors.init(P, kf, fx, lane);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            hkf = (lane == j) ? kf[j] : hkf;
+            hfx = (lane == j) ? fx[j] : hfx;
+        }
     }
-    (void)kf; (void)fx; (void)priors;
+    (void)kf; (void)fx; (void)priors; (void)hkf; (void)hfx;
     // lane i: the draws of iteration bbase + i (chain.py:221-232, :259)
     double bu = 0.0, blo = 0.0, bhi = 0.0;
     int bo1 = 0, bo2 = 0;
@@ -1394,16 +1431,29 @@ __device__ __forceinline__ void lean_demc_lag_body(const DevProblem &P, const in
             const double npk = xk + jump_k;
             const bool outk = mine && (npk < pmin_k || npk > pmax_k);
             if (__builtin_expect(!__any(outk), 1)) {
+                if constexpr (NW > 1) {                // (helper waves: woken first)
+                    const double got = lane_gather(npk, hkf < 0 ? 0 : hkf);
+                    helpers.order(FX ? (hkf < 0 ? hfx : got) : npk, lane);
+                }
                 Model<MT> model;
                 if constexpr (!FX)
                     model.init_from_lanes(P, npk);
                 else
                     model.init_from_lanes(P, npk, kf, fx);
-                double nextchisq =
-                    block_gauss_model<1, MT, false, false>(P, model, nullptr, nullptr, tile,
-                                                           &tile);           // chain.py:249
-                if constexpr (FX)
-                    nextchisq = nextchisq + priors.term(npk, lane);
+                double nextchisq;                                        // chain.py:249
+                if constexpr (NW == 1) {
+                    nextchisq = block_gauss_model<1, MT, false, false>(P, model, nullptr, nullptr,
+                                                                       tile, &tile);
+                    if constexpr (FX)
+                        nextchisq = nextchisq + priors.term(npk, lane);
+                } else {
+                    double prior = 0.0;
+                    if constexpr (FX)
+                        prior = priors.term(npk, lane);
+                    nextchisq = helpers.collect(P, model, tiles, lane);
+                    if constexpr (FX)
+                        nextchisq = nextchisq + prior;
+                }
                 const bool acc = metropolis_accept(0.5 * (cur - nextchisq), C.u, C.lo, C.hi);
                 xk = acc ? npk : xk;
                 if (__builtin_expect(__any(acc && nextchisq < best), 0)) {
@@ -1462,6 +1512,8 @@ __device__ __forceinline__ void lean_demc_lag_body(const DevProblem &P, const in
 out:
     if constexpr (COURIER)
         courier_end(s_cour);
+    if constexpr (NW > 1)
+        helpers.release(lane);
     if constexpr (P2P && !COURIER) {
         if (P.remote_delay != 0)
             late.drain(P, s_ring, peers_z, lane, mine, true);

@@ -1006,7 +1006,8 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
             const bool shape_jit = !pr->wlike && model_jit && pr->nmodel == pr->nparams &&
                                    P.nfree >= 1 && pr->zlag == 0 && pr->trace_iters == 0 &&
                                    (pr->thinning == 1 || pr->sampler == MC3HIP_MRW ||
-                                    (pr->sampler == MC3HIP_SNOOKER && pr->fepsilon == 0.0)) &&
+                                    ((pr->sampler == MC3HIP_SNOOKER ||
+                                      pr->sampler == MC3HIP_DEMC) && pr->fepsilon == 0.0)) &&
                                    pr->nlocal == pr->nchains &&
                                    !(pr->flags & (MC3HIP_FLAG_P2P | MC3HIP_FLAG_NO_PERSIST)) &&
                                    !getenv("MC3HIP_NO_WIDE") && !getenv("MC3HIP_NO_LEAN") &&
@@ -1361,6 +1362,11 @@ int mc3hip_jit_request(const mc3hip_ctx *c, char *buf, int32_t capacity)
         const int nt = c->wide_jit_tiles;
         switch (P.sampler) {
         case MC3HIP_DEMC:      // <MT, P2P, FX, MULTI, BATCH, COURIER, EPS, NW, NT>
+            if (P.thinning > 1)                  // <MT, P2P, FX, COURIER, NW, NT>
+                n = snprintf(buf, (size_t)capacity,
+                             "lean_demc_lag_body<%d, false, %s, false, %d, %d> /*threads=%d*/",
+                             tag, fx, nw, nt, 64 * nw);
+            else
             n = snprintf(buf, (size_t)capacity,
                          "lean_demc_body<%d, false, %s, false, false, false, %s, %d, %d> "
                          "/*threads=%d*/", tag, fx, eps, nw, nt, 64 * nw);

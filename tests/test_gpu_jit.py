@@ -133,6 +133,10 @@ CASES = {
     'left-quad3000-snooker-thin3': lambda: quad_wide(3000, sampler='snooker', thinning=3),
     'left-quad5000-mrw-priors-thin2': lambda: quad_wide(5000, sampler='mrw', priors=True,
                                                         thinning=2),
+    'left-quad3000-demc-thin3': lambda: quad_wide(3000, sampler='demc', thinning=3),
+    'left-quad8192-demc-priors-thin2': lambda: quad_wide(8192, sampler='demc', priors=True,
+                                                         thinning=2),
+    'left-poly6-5000-demc-thin4': lambda: poly_problem(6, sampler='demc', ndata=5000, thinning=4),
     'left-quad2048-demc-priors-800chains': lambda: quad_wide(2048, sampler='demc', priors=True,
                                                              nchains=800, nref=80),
     'left-quad3000-snooker-fixed-600chains': lambda: with_pstep(
