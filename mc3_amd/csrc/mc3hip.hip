@@ -571,6 +571,19 @@ int decide_persist(mc3hip_ctx *c)
         if (nb < 1)
             return 0;
     }
+    if (c->fast && jit_serves(c) && fast_eligible(c) && c->P.nlocal > capacity) {
+        // a loop specialised at run time holds one chain per workgroup; where the library has an
+        // instance of its own for the shape (the random walk beyond one tile: streamed tiles),
+        // an ensemble that is not co-resident with the specialised loop runs that one, several
+        // chains per workgroup
+        c->jit_fn = nullptr;
+        nb = fast_blocks_per_cu(c);
+        const int pc = (nb > 1 && getenv("MC3HIP_PERSIST_MARGIN")) ? nb - 1 : nb;
+        capacity = (long long)pc * prop.multiProcessorCount;
+        capacity = capacity < cap_limit ? capacity : cap_limit;
+        if (nb < 1)
+            return 0;
+    }
     if (c->fast && c->P.nlocal > capacity && lean_one_chain_only(c)) {
         // fixed coefficients / priors with thinning > 1 or peer to peer, the support
         // distribution: only a one-chain-per-wave loop is lean there; more chains than it can
