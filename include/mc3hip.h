@@ -190,8 +190,8 @@ int mc3hip_get_plan(const mc3hip_ctx *ctx, mc3hip_plan *plan);
 
 /* Run-time specialisation ("the model ... JIT-specialised into the kernel").  The library is
  * built with the hand-laid-out one-wave loops for polynomials of 2..4 coefficients; for the
- * other members of the declared family that fit one register tile -- polynomials of 5..8
- * coefficients, design matrices of up to 10 columns, ndata <= 1024, one GPU -- the same loop
+ * other members of the declared family that fit one register tile -- polynomials of 5..16
+ * coefficients, design matrices of up to 16 columns, ndata <= 1024, one GPU -- the same loop
  * source is compiled for the very model (coefficient count a compile-time constant, the design
  * matrix's tile resident in registers) by the caller, who owns a compiler; the library itself
  * never needs one.  So are (round 5) polynomials of 2..4 coefficients on 1 025 ... 8 192 points

@@ -44,7 +44,7 @@ constexpr bool mt_is_link(int MT) { return MT > MT_LINK0 && MT <= MT_LINK0 + 16;
 // coefficients a model tag fixes at compile time (0: a run-time count)
 constexpr int mt_ncoef(int MT)
 {
-    return mt_is_link(MT) ? MT - MT_LINK0 : ((MT >= 1 && MT <= 8) ? MT : 0);
+    return mt_is_link(MT) ? MT - MT_LINK0 : ((MT >= 1 && MT <= 16) ? MT : 0);
 }
 
 struct DevProblem {

@@ -234,9 +234,9 @@ inline int jit_model_tag(const mc3hip_ctx *c)
                              (P.sampler == MC3HIP_DEMC && P.fepsilon == 0.0);
         if (!thin_ok || P.zlag != 0 || c->mc_chains != 0)
             return 0;
-        if (c->model_kind == MC3HIP_MODEL_POLY && P.nmodel >= 2 && P.nmodel <= 8)
+        if (c->model_kind == MC3HIP_MODEL_POLY && P.nmodel >= 2 && P.nmodel <= 16)
             return P.nmodel;
-        if (c->model_kind == MC3HIP_MODEL_LINEAR && P.nmodel >= 1 && P.nmodel <= 10)
+        if (c->model_kind == MC3HIP_MODEL_LINEAR && P.nmodel >= 1 && P.nmodel <= 16)
             return MT_LINK0 + P.nmodel;
         return 0;
     }
@@ -262,9 +262,10 @@ inline int jit_model_tag(const mc3hip_ctx *c)
     if (c->wpc != 1 || P.npad > VLANES)
         return 0;
     int tag = 0;
-    if (c->model_kind == MC3HIP_MODEL_POLY && P.nmodel >= 5 && P.nmodel <= 8)
+    // (as many coefficients as a row of Z has lanes: 16 -- round 5; before: 8 / 10)
+    if (c->model_kind == MC3HIP_MODEL_POLY && P.nmodel >= 5 && P.nmodel <= 16)
         tag = P.nmodel;
-    else if (c->model_kind == MC3HIP_MODEL_LINEAR && P.nmodel >= 1 && P.nmodel <= 10)
+    else if (c->model_kind == MC3HIP_MODEL_LINEAR && P.nmodel >= 1 && P.nmodel <= 16)
         tag = MT_LINK0 + P.nmodel;
     else
         return 0;
@@ -293,7 +294,9 @@ inline int jit_waves(const mc3hip_ctx *c)
         return c->wide_jit_waves;
     if (tag != 0 && tag <= 4)                   // (the leftovers of the small polynomials)
         return 1;
-    if (tag < MT_LINK0 || P.sampler == MC3HIP_MRW ||
+    // (the random walk's loop has had helper waves since round 5: from eleven columns on -- up
+    // to ten its one wave is as fast)
+    if (tag < MT_LINK0 || (P.sampler == MC3HIP_MRW && tag - MT_LINK0 <= 10) ||
         (P.sampler == MC3HIP_DEMC && (P.thinning > 1 || P.zlag > 0)))
         return 1;
     if (const char *e = getenv("MC3HIP_JIT_WAVES")) {

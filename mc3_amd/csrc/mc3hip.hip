@@ -1014,8 +1014,8 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
             // support distribution, or the random walk: lean_*_body<.., NW = 4, NT> specialised
             // at run time (ctx.h jit_model_tag; without a compiler at hand: the general chain,
             // as before)
-            const bool model_jit = linear_model ? (pr->nmodel >= 1 && pr->nmodel <= 10)
-                                                : (pr->nmodel >= 2 && pr->nmodel <= 8);
+            const bool model_jit = linear_model ? (pr->nmodel >= 1 && pr->nmodel <= 16)
+                                                : (pr->nmodel >= 2 && pr->nmodel <= 16);
             const bool shape_jit = !pr->wlike && model_jit && pr->nmodel == pr->nparams &&
                                    P.nfree >= 1 && pr->zlag == 0 && pr->trace_iters == 0 &&
                                    (pr->thinning == 1 || pr->sampler == MC3HIP_MRW ||
@@ -1051,13 +1051,13 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
             }
         }
         // (design matrices beyond what a loop specialised at run time keeps in registers -- ten
-        // columns from 4 097 points, five from 8 193 -- ran the general chain up to 16 383
+        // columns from 4 097 points, five from 8 193, twelve from 2 049 -- ran the general chain up to 16 383
         // points: 21-37 us per iteration of 256 chains at 8 192, where the one-launch tiled plan
         // through the matrix cores takes ~7)
         const bool big = c->wide_tiles == 0 && c->wide_jit_tiles == 0 &&
                          (nd >= 4 * 4096 || (mid_resident && nd >= 2 * 4096 &&
                                              (long long)nd * pr->nlocal >= 4194304LL) ||
-                          (mid_resident && mfma_model && nd > 2 * 2048));
+                          (mid_resident && mfma_model && nd > 2048));
         const bool tiled = !pr->wlike && big && pr->nlocal >= 16 && pr->nmodel <= 16 &&
                            !getenv("MC3HIP_NO_TILED");
         P.tile = tiled ? ((pr->nmodel <= 4 && !mfma_model) ? 4096 : 2048) : 0;
@@ -1450,9 +1450,14 @@ int mc3hip_jit_request(const mc3hip_ctx *c, char *buf, int32_t capacity)
                          "lean_snooker_body<%d, %s, %s, false, false, false, %s>", tag, fx, thin,
                          P.fepsilon != 0.0 ? "true" : "false");
         break;
-    default:
-        n = snprintf(buf, (size_t)capacity, "lean_mrw_body<%d, %s, %s, false, false, false>", tag,
-                     fx, thin);
+    default:                                     // <MT, FX, THIN, MULTI, P2P, COURIER[, NW, NT]>
+        if (nw > 1)
+            n = snprintf(buf, (size_t)capacity,
+                         "lean_mrw_body<%d, %s, %s, false, false, false, %d, 1> /*threads=%d*/",
+                         tag, fx, thin, nw, 64 * nw);
+        else
+            n = snprintf(buf, (size_t)capacity, "lean_mrw_body<%d, %s, %s, false, false, false>",
+                         tag, fx, thin);
         break;
     }
     if (n < 0 || n >= capacity) {

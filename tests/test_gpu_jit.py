@@ -124,6 +124,19 @@ CASES = {
     'wide-quad12000-mrw': lambda: quad_wide(12000, sampler='mrw'),
     'wide-quad9000-snooker-eps-fixed': lambda: with_pstep(
         quad_wide(9000, sampler='snooker', fepsilon=0.01), [1.0, 0.0, 0.1]),
+    # as many coefficients as a row of Z has lanes (round 5; before: 8 / 10)
+    'poly10-demc': lambda: poly_problem(10, sampler='demc'),
+    'poly12-snooker-thin': lambda: poly_problem(12, sampler='snooker', thinning=2),
+    'poly16-mrw': lambda: poly_problem(16, sampler='mrw'),
+    'lin12-demc-priors': lambda: linear_problem(12, sampler='demc', priors=True),
+    'lin16-snooker': lambda: linear_problem(16, sampler='snooker'),
+    'lin13-mrw-fixed': lambda: with_pstep(linear_problem(13, sampler='mrw'),
+                                          [0.05]*6 + [0.0] + [0.05]*6),
+    'lin11-demc-eps': lambda: linear_problem(11, sampler='demc', fepsilon=0.01),
+    'wide-poly10-4000-demc': lambda: poly_problem(10, sampler='demc', ndata=4000),
+    'wide-lin12-2000-snooker-priors': lambda: linear_problem(12, sampler='snooker', priors=True,
+                                                             ndata=2000),
+    'wide-lin15-2000-mrw': lambda: linear_problem(15, sampler='mrw', ndata=2000),
     # what was left of the small polynomials: thinning with fixed coefficients / priors, thinning
     # on the wide loops, ensembles too large for the wide loops (one wave, two tiles in registers)
     'left-quad1000-snooker-priors-thin3': lambda: quad_wide(1000, sampler='snooker', priors=True,
@@ -214,7 +227,7 @@ def test_the_request_names_the_loop_and_the_cache_keeps_it(eng, tmp_path, monkey
         assert gpu.jit_request() == '' and gpu.plan['jit'] == 0 and gpu.plan['fast'] == 2
     with eng.DeviceChains(**H.wavelet_problem()) as gpu:
         assert gpu.jit_request() == ''
-    with eng.DeviceChains(**linear_problem(11, sampler='demc')) as gpu:     # too many columns
+    with eng.DeviceChains(**linear_problem(17, sampler='demc')) as gpu:     # too many columns
         assert gpu.jit_request() == '' and gpu.plan['fast'] == 0
     with eng.DeviceChains(**poly_problem(5, sampler='mrw')) as gpu:  # (round 5: served too)
         assert gpu.jit_served == 'lean_mrw_body<5, false, false, false, false, false>'
