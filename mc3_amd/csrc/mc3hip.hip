@@ -490,8 +490,12 @@ int decide_persist(mc3hip_ctx *c)
             const long long refs = getenv("MC3HIP_PERSIST_REFS") &&
                                    atoi(getenv("MC3HIP_PERSIST_REFS")) > 0
                                        ? atoi(getenv("MC3HIP_PERSIST_REFS")) : 16384;
-            const long long rows = refs * ((cb + 15) / 16);
+            // (a row per block of every round of proposals of a launch: `thinning` rounds to a
+            // refresh)
+            const long long rows = refs * c->P.thinning * ((cb + 15) / 16);
             const size_t words = (size_t)ncol * rows * 16;
+            // (a large thinning makes a launch's rounds many: not beyond 1 GiB of rows)
+            fits = fits && words * sizeof(unsigned long long) <= ((size_t)1 << 30);
             if (fits && words > c->rs_sched_words) {
                 c->rs_sched_words = words;
                 fits = dev_alloc(c, &c->P.rs_sched, words) == MC3HIP_OK &&

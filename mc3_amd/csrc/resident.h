@@ -902,6 +902,11 @@ __device__ __forceinline__ void resident_scheduler(const DevProblem &P, const in
                 continue;
             }
             spins = 0;
+            if (seq >= (long long)P.rs_sched_rows) {
+                // (never with the rows the host sizes: a row per block of a launch's rounds)
+                __hip_atomic_store(&ctl[CTL_ABORT], 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
             const int rank0 = (int)__builtin_amdgcn_mbcnt_hi(
                 (unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u));
             const int rank1 = (p0 < 16 ? p0 : 16) + (int)__builtin_amdgcn_mbcnt_hi(

@@ -556,6 +556,18 @@ def test_resident_async_many_launches_resume_and_abort(eng):
         gpu.close()
 
 
+def test_resident_async_thinning_fills_a_launch(eng):
+    """A launch of 40 refreshes at thinning 3: 120 rounds of proposals -- the scheduler's rows
+    are sized for the rounds of a launch, not for its refreshes."""
+    prob = linear(ndata=20000, nmodel=7, nchains=40, niter=120, sampler='snooker', thinning=3)
+    with env(MC3HIP_PERSIST_REFS=40, MC3HIP_RS_ASYNC=1):
+        orc, gpu = run_pair(eng, prob, trace=False)
+        assert gpu.plan['owner_waves'] >= 1 and gpu.plan['persistent'] == 40, gpu.plan
+        assert gpu.plan['recoveries'] == 0
+        assert_same(orc, gpu, trace=False)
+        gpu.close()
+
+
 def test_resident_async_shapes_it_leaves_to_the_kernel_in_step(eng):
     """More than three chains to own per workgroup (10 tiles x 1 column, 40 chains), four blocks
     of operand rows beside the general chain as owner: the kernel in step, as before."""
