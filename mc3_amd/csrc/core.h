@@ -139,6 +139,12 @@ constexpr int RS_ROW = 16;          // doubles per published proposal row: one 1
 constexpr int RA_CMAX = 128;        // resident_async_kernel: chains of a column (two per lane of a
                                     // tile wave), owner waves of a workgroup at most
 constexpr int RA_OWNERS = 3;        // (a twelfth wave, in the workgroups of tile 0: the scheduler)
+// LDS ahead of the owners' areas, in doubles: the waves' row totals of a chain, [2][RA_CMAX + 1][8]
+// (two sets of slots, by the round's parity: a column's chains change from round to round;
+// row RA_CMAX: nobody's), the counters [2][RA_CMAX + 1], the blocks made up and the tile
+// waves' progress (144), the give-up word (2)
+constexpr int RA_PART = 2 * (RA_CMAX + 1) * 8, RA_CNT = RA_CMAX + 1;
+constexpr int RA_HEAD = RA_PART + RA_CNT + 144 + 2;
 constexpr int RS_WCAP = 256;        // chains whose group totals a workgroup collects in LDS
                                     // before it adds them up (resident tiled plan)
 constexpr int SC_STRIDE = MC3HIP_MAX_PARAMS + 16;   // doubles per sc_nextp row (zero padded)

@@ -17,10 +17,9 @@ constexpr size_t RESIDENT_LDS_BYTES_REGS = (RS_WCAP * 16 + 2 + 8 * RESIDENT_OWN)
 // polynomials (ResidentPoly): two exchange buffers [16][512], the give-up word, the areas
 constexpr size_t RESIDENT_POLY_LDS_BYTES = (2 * 16 * 512 + 2 + 8 * RESIDENT_OWN) * sizeof(double);
 
-// resident_async_kernel: the waves' row totals [RA_CMAX][8], counters, blocks made up, the
-// give-up word, the owners' areas, the operand blocks beyond two
-constexpr size_t RESIDENT_ASYNC_LDS_DOUBLES =
-    (RA_CMAX + 1) * 8 + RA_CMAX / 2 + 1 + 144 + 2 + RA_OWNERS * RESIDENT_OWN;
+// resident_async_kernel: the waves' row totals, counters, blocks made up, the give-up word
+// (core.h RA_HEAD), the owners' areas, the operand blocks beyond two
+constexpr size_t RESIDENT_ASYNC_LDS_DOUBLES = RA_HEAD + RA_OWNERS * RESIDENT_OWN;
 
 }  // namespace
 

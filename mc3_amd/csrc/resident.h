@@ -796,9 +796,19 @@ __global__ __launch_bounds__(512) void resident_poly_kernel(const DevProblem P, 
 //     total and counts itself in (ds_inc, wrapping at eight); the wave that counts last adds
 //     the eight up -- strides 4..1, the order tile_phase's sixteen-lane tree has -- and
 //     publishes the tile's sum.
+//   * WHICH chains a column of workgroups serves changes from round to round
+//     (ResidentColumns): the ensemble's blocks do not divide by the columns as a rule (C5: 32
+//     blocks, 5 columns), and the columns that carry one block more take turns at it.
 // At the start of an iteration the chains whose partners were decided early in the previous
 // one are there (two thirds of them), and by the time those are done so are the others: the
 // tile waves only wait when the owners' path is longer than five blocks of matrix work.
+// (What an iteration costs, measured by cutting the blocks short -- MC3HIP_RA_FAKE_END, wrong
+// sums, right timing -- for C5: 10.3 us + 1.125 us per step of the sixteen of a block, i.e. a
+// step of a block costs 0.16 us where the pipe alone would need 0.20 for the pair of waves,
+// and ten microseconds per iteration are the chains' own round -- sums, owner, scheduler,
+// rows: round trips -- showing through wherever the next blocks are not there yet.  Giving
+// the two waves of a SIMD different priorities so that they run half a block apart changes
+// nothing: 28.2-28.5 us at 4, 8 and 12 steps apart as without.)
 // Same arithmetic in the same order for every chain: the checker cannot tell which of the two
 // kernels ran (tests/test_gpu_resident.py).
 // (RA_CMAX chains of a column, RA_OWNERS owner waves: core.h)
@@ -842,6 +852,65 @@ __device__ __forceinline__ void tile_part_arrive4(double *const (&slot)[4], cons
                  : "memory");
 }
 
+// The same for ONE chain per lane (row_totals4 below leaves the four chains of a sixteen-lane
+// row in its four quads): a quarter of the LDS operations per wave, one chain to finish per
+// lane instead of four one after the other.
+__device__ __forceinline__ unsigned tile_part_arrive1(double *slot, const double v, unsigned *cnt)
+{
+    unsigned old;
+    asm volatile("ds_write_b64 %1, %2\n\tds_inc_rtn_u32 %0, %3, %4\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(old)
+                 : "v"(lds_offset(slot)), "v"(v), "v"(lds_offset(cnt)), "v"(7u)
+                 : "memory");
+    return old;
+}
+
+// lane l of a sixteen-lane row receives lane l ^ 4's value (two row shifts, each written to
+// the banks it is valid for)
+__device__ __forceinline__ double row_xor4(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    int lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x104, 0xf, 0x5, false);      // row_shl:4
+    int hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x104, 0xf, 0x5, false);
+    lo2 = __builtin_amdgcn_update_dpp(lo2, lo, 0x114, 0xf, 0xa, false);        // row_shr:4
+    hi2 = __builtin_amdgcn_update_dpp(hi2, hi, 0x114, 0xf, 0xa, false);
+    return make_double(lo2, hi2);
+}
+template <int CTRL>
+__device__ __forceinline__ double add_quad_perm(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    const int hi2 = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return v + make_double(lo2, hi2);
+}
+
+// The sixteen-lane totals of the four accumulators of a lane (chains r = 0..3 of its row),
+// transposed: five additions instead of sixteen on a pipe the wave shares with its partner's
+// matrix instructions.  Stride 8 pairs the lanes of TWO chains per addition (a lane keeps the
+// chains of its half of the row and hands over the other two), stride 4 those of the two it
+// kept, strides 2 and 1 run inside a quad: lane j ends with the total of chain j >> 2 -- the
+// pairs (j, j + 8), (.., + 4), (.., + 2), (.., + 1) of four add_ror trees, level for level, so
+// every total is bit for bit theirs (an addition's operands change sides, which changes no
+// bit of a sum).
+__device__ __forceinline__ double row_totals4(const double (&acc)[4], const int j)
+{
+    const bool hi8 = (j & 8) != 0, hi4 = (j & 4) != 0;
+    const double k0 = hi8 ? acc[2] : acc[0], s0 = hi8 ? acc[0] : acc[2];
+    const double k1 = hi8 ? acc[3] : acc[1], s1 = hi8 ? acc[1] : acc[3];
+    const int s0l = __builtin_amdgcn_mov_dpp(__double2loint(s0), 0x128, 0xf, 0xf, true);
+    const int s0h = __builtin_amdgcn_mov_dpp(__double2hiint(s0), 0x128, 0xf, 0xf, true);
+    const int s1l = __builtin_amdgcn_mov_dpp(__double2loint(s1), 0x128, 0xf, 0xf, true);
+    const int s1h = __builtin_amdgcn_mov_dpp(__double2hiint(s1), 0x128, 0xf, 0xf, true);
+    const double t0 = k0 + make_double(s0l, s0h);      // chain 0 (lanes 0..7) / 2 (lanes 8..15)
+    const double t1 = k1 + make_double(s1l, s1h);      // chain 1 / 3
+    const double k = hi4 ? t1 : t0, s = hi4 ? t0 : t1;
+    double u = k + row_xor4(s);
+    u = add_quad_perm<0x4e>(u);                        // quad_perm [2, 3, 0, 1]
+    return add_quad_perm<0xb1>(u);                     // quad_perm [1, 0, 3, 2]
+}
+
 __device__ __forceinline__ unsigned long long load_sched(const unsigned long long *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -864,21 +933,63 @@ __device__ __forceinline__ bool async_patience(unsigned &spins, long long *ctl)
     return true;
 }
 
-// The scheduler wave of a column of n chains (c0 ..): the blocks of every iteration of the
-// launch, in P.rs_sched's rows of the column.  sel: 16 ints of LDS of its own.
+// Which chains a column of workgroups serves, round by round.  The ensemble is nb = ceil(nlocal /
+// 16) blocks of sixteen chains; ncol columns share them as evenly as whole blocks allow -- base
+// = nb / ncol each, and one more for nb % ncol of them -- and WHICH columns carry the extra
+// block moves on by one column per round: over ncol rounds every workgroup has multiplied
+// the same number of blocks, nb / ncol per round (C5: 6.4, where columns of fixed height do 7, 7,
+// 7, 7, 4 and the chip waits for the sevens).  The owners know nothing of columns (a chain's
+// proposal row and its tile sums are found by the chain's number), and the scheduler and the
+// tile waves of a column count the launch's rounds the same way.
+struct ResidentColumns {
+    int base, rem, ncol, nlocal, col, rot;
+    __device__ __forceinline__ void init(const DevProblem &P, const int column, const int ncolumns)
+    {
+        const int nb = (P.nlocal + 15) / 16;
+        ncol = ncolumns;
+        base = nb / ncol;
+        rem = nb - base * ncol;
+        nlocal = P.nlocal;
+        col = column;
+        rot = 0;
+    }
+    // the chains of the column in the current round: c0 .., n of them (n >= 1)
+    __device__ __forceinline__ void chains(int &c0, int &n) const
+    {
+        // columns k with (k + rot) mod ncol < rem carry base + 1 blocks: how many before col
+        const int e = rot + col;
+        const int e1 = e < ncol ? e : ncol;
+        int extra = (e1 < rem ? e1 : rem) - rot;
+        extra = extra > 0 ? extra : 0;
+        if (e > ncol)
+            extra += (e - ncol < rem) ? e - ncol : rem;
+        const int pos = e < ncol ? e : e - ncol;
+        const int b0 = col * base + extra, nb = base + (pos < rem ? 1 : 0);
+        c0 = 16 * b0;
+        const int c1 = 16 * (b0 + nb);
+        n = (c1 < nlocal ? c1 : nlocal) - c0;
+    }
+    __device__ __forceinline__ void next_round() { rot = (rot + 1 == ncol) ? 0 : rot + 1; }
+};
+
+// The scheduler wave of a column: the blocks of every iteration of the launch, in
+// P.rs_sched's rows of the column.  sel: 16 ints of LDS of its own.
 __device__ __forceinline__ void resident_scheduler(const DevProblem &P, const int nref,
-                                                   const int col, const int c0, const int n,
-                                                   int *sel)
+                                                   const int col, const int ncol, int *sel)
 {
     long long *ctl = const_cast<long long *>(P.ctl);
     const int lane = threadIdx.x & 63;
     const size_t pstride = (size_t)P.nlocal * RS_ROW;
     unsigned long long *rows = P.rs_sched + (size_t)col * P.rs_sched_rows * 16;
     const unsigned long long gen = (unsigned long long)(unsigned)P.rs_gen << 32;
-    const int l0 = (lane < n) ? lane : 0, l1 = (lane + 64 < n) ? lane + 64 : 0;
     unsigned spins = 0;
     long long seq = 0;
-    for (int R = 0; R < nref; ++R) {
+    ResidentColumns C;
+    C.init(P, col, ncol);
+    for (int R = 0; R < nref; ++R, C.next_round()) {
+        int c0, n;
+        C.chains(c0, n);
+        const int l0 = (lane < n) ? lane : 0, l1 = (lane + 64 < n) ? lane + 64 : 0;
         const double *prop = P.rs_prop + (size_t)(R & 1) * pstride;
         // chains lane and lane + 64 of the column: still to do in this iteration
         bool rem0 = lane < n, rem1 = lane + 64 < n;
@@ -964,8 +1075,9 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
     static constexpr int KR = ResidentTile<KB, KRMAX>::KR;
     static constexpr int KL = ResidentTile<KB, KRMAX>::KL;
 
-    // a tile wave, for the whole launch.  s_part [RA_CMAX][8]: the waves' row totals of a
-    // chain; s_cnt [RA_CMAX]: waves counted in; s_sel [9][2][16]: the chains of a wave's blocks
+    // a tile wave, for the whole launch.  s_part [2][RA_CMAX + 1][8]: the waves' row totals of
+    // a chain of the column (by the round's parity: ResidentColumns); s_cnt [2][RA_CMAX + 1]:
+    // waves counted in; s_sel [9][2][16]: the chains of a wave's blocks
     // (the one in hand, the next); s_prog [8]: blocks taken so far, by wave.
     // A turn of the loop multiplies the block in hand and, meanwhile, takes the one after: it
     // looks at the scheduler's next row twice -- RA_TAKE_AT steps into the products (the row
@@ -986,7 +1098,11 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
     {
         long long *ctl = const_cast<long long *>(P.ctl);
         const int lane = this->lane, j = lane & 15, g = lane >> 4;
-        const int wv = this->wv, c0 = this->c0, n = this->c1 - this->c0, t = this->t;
+        const int wv = this->wv, t = this->t;
+        ResidentColumns C;
+        C.init(P, blockIdx.y, gridDim.y);
+        int c0, n;                          // the column's chains in round R
+        C.chains(c0, n);
         int *const sel2 = s_sel + 32 * wv;
         const unsigned long long *rows =
             P.rs_sched + (size_t)blockIdx.y * P.rs_sched_rows * 16 + j;
@@ -1001,6 +1117,9 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
         for (int kb = 0; kb < KB; ++kb)
             aop1[kb] = aop2[kb] = a[kb] = 0.0;
         int nt = 0, lc_next = c0, buf = 0, cur_nt = 0;
+        // (of the block taken / in hand: the first chain of its round's column, and which of
+        // the two sets of LDS slots -- by the round's parity -- its sums meet in)
+        int next_c0 = c0, next_slots = 0, cur_c0 = c0, cur_slots = 0;
         const int *cur_sel = sel2;
         int wo = 0;
         unsigned spins = 0;
@@ -1026,6 +1145,8 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
                 sel[lane] = id;
             __builtin_amdgcn_wave_barrier();
             lc_next = (R & 1) * P.nlocal + c0 + id;
+            next_c0 = c0;
+            next_slots = (R & 1) * (RA_CMAX + 1);
             buf ^= 1;
 #ifndef MC3HIP_RA_NO_BALANCE
             // The two tile waves of a SIMD (v and v ^ 4) share its FP64 pipe, and the arbiter
@@ -1054,6 +1175,8 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
                     done = true;
                 } else {
                     ++R;
+                    C.next_round();
+                    C.chains(c0, n);
                     nrem = n;
                 }
             }
@@ -1142,8 +1265,13 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
                 for (int kb = 0; kb < KB; ++kb)
                     aop2[kb] = load_published(P.rs_prop + (size_t)lc_next * RS_ROW + 4 * kb + g);
             }
-            if (have)
+            if (have) {
+#ifdef MC3HIP_RA_FAKE_END          // (timing experiment: a block cut short -- wrong sums)
+                products(RA_TAKE_AGAIN, MC3HIP_RA_FAKE_END);
+#else
                 products(RA_TAKE_AGAIN, 16);
+#endif
+            }
             const bool ok = hit1 || hit2;
             MC3_RTICK(tq2);
 #ifndef MC3HIP_RA_NO_SUMS_PRIO
@@ -1177,46 +1305,26 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
                 // block's first products, where they would cost the pipe nothing -- they reach
                 // the owners two microseconds later, and the tile waves run out of proposals:
                 // 33.2 us per iteration against 29.5.)
-                // the 16 lanes of a row (strides 8..1; lane j = 0 has the defined order)
-                double sr[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double sg = add_ror<8>(acc[r]);
-                    sg = add_ror<4>(sg);
-                    sg = add_ror<2>(sg);
-                    sr[r] = add_ror<1>(sg);
-                }
-                if (j == 0) {
+                // the 16 lanes of a row, the four chains of a lane together: lane j has the
+                // total of slot g + 4 (j >> 2) (strides 8..1, the order add_ror's tree has)
+                const double sr = row_totals4(acc, j);
+                if ((j & 3) == 0) {
                     // (a slot beyond the block's chains goes to a row of LDS that nobody reads)
-                    double *slot[4];
-                    unsigned *cnt[4];
-                    unsigned old[4];
-                    int ch[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        ch[r] = (g + 4 * r < cur_nt) ? cur_sel[g + 4 * r] : RA_CMAX;
-                        slot[r] = &s_part[ch[r] * 8 + wv];
-                        cnt[r] = &s_cnt[ch[r]];
-                    }
-                    tile_part_arrive4(slot, sr, cnt, old);
+                    const int sl = g + (j & 12);
+                    const int ch = (sl < cur_nt) ? cur_sel[sl] : RA_CMAX;
+                    const unsigned old = tile_part_arrive1(&s_part[(cur_slots + ch) * 8 + wv], sr,
+                                                           &s_cnt[cur_slots + ch]);
                     MC3_RTICK(tq4);
-                    // the chains this wave counted last for (normally none, or all of them):
-                    // the tile's eight rows of each (strides 4..1)
-                    if (old[0] == 7u || old[1] == 7u || old[2] == 7u || old[3] == 7u) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const double *p = s_part + ch[r] * 8;
-                            double sg = ((p[0] + p[4]) + (p[2] + p[6])) +
-                                        ((p[1] + p[5]) + (p[3] + p[7]));
-                            if (mc3_bits(sg) == ROW_PENDING)   // (a NaN that looks like "not there yet")
-                                sg = mc3_from_bits(0x7ff8000000000000ull);
-                            if (old[r] == 7u && ch[r] != RA_CMAX)
-                                __hip_atomic_store(
-                                    &P.rs_part[(size_t)(c0 + ch[r]) * P.rs_ntp + t], sg,
-                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (r == 1)
-                                __builtin_amdgcn_sched_barrier(0);
-                        }
+                    // the chain this wave counted last for: the tile's eight rows (strides 4..1)
+                    if (old == 7u) {
+                        const double *p = s_part + (cur_slots + ch) * 8;
+                        double sg = ((p[0] + p[4]) + (p[2] + p[6])) +
+                                    ((p[1] + p[5]) + (p[3] + p[7]));
+                        if (mc3_bits(sg) == ROW_PENDING)   // (a NaN that looks like "not there yet")
+                            sg = mc3_from_bits(0x7ff8000000000000ull);
+                        if (ch != RA_CMAX)
+                            __hip_atomic_store(&P.rs_part[(size_t)(cur_c0 + ch) * P.rs_ntp + t], sg,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
                 __builtin_amdgcn_s_setprio(1);
@@ -1260,12 +1368,23 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
                     a[kb] = hit1 ? aop1[kb] : aop2[kb];
                 cur_nt = nt;
                 cur_sel = sel2 + 16 * (buf ^ 1);
+                cur_c0 = next_c0;
+                cur_slots = next_slots;
             }
             // the scheduler's row after the block taken (or the same one again)
             if (!done)
                 w = load_sched(rows + seq * 16);
         }
 #ifdef MC3HIP_STAMPS
+        if (lane == 0) {
+            // every tile wave: ticks waiting for rows, turns with nothing in hand, ticks in the
+            // products, in all (tools/tile_wave_spread.py)
+            unsigned long long tq_end = 0;
+            MC3_RTICK(tq_end);
+            unsigned long long *st =
+                P.stamps + 4096 + 4 * ((blockIdx.y * gridDim.x + blockIdx.x) * 8 + wv);
+            st[0] += tq_wait; st[1] += tq_idle; st[2] += tq_mul; st[3] += tq_end - tq_begin;
+        }
         if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
             unsigned long long tq_end = 0;
             MC3_RTICK(tq_end);
@@ -1290,17 +1409,17 @@ __global__ __launch_bounds__(512 + 64 * (RA_OWNERS + 1)) void resident_async_ker
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int OWN = 64 + MC3HIP_MAX_PARAMS + 2 + 48 + 4;     // carve() of a one-wave chain
-    double *s_part = smem;                              // (row RA_CMAX: nobody's)
-    unsigned *s_cnt = reinterpret_cast<unsigned *>(smem + (RA_CMAX + 1) * 8);
-    int *s_sel = reinterpret_cast<int *>(smem + (RA_CMAX + 1) * 8 + RA_CMAX / 2 + 1);
-    int *s_stop = reinterpret_cast<int *>(smem + (RA_CMAX + 1) * 8 + RA_CMAX / 2 + 1 + 144);
-    double *s_own = smem + (RA_CMAX + 1) * 8 + RA_CMAX / 2 + 1 + 144 + 2;
+    double *s_part = smem;                              // (core.h RA_HEAD)
+    unsigned *s_cnt = reinterpret_cast<unsigned *>(smem + RA_PART);
+    int *s_sel = reinterpret_cast<int *>(smem + RA_PART + RA_CNT);
+    int *s_stop = reinterpret_cast<int *>(smem + RA_PART + RA_CNT + 144);
+    double *s_own = smem + RA_HEAD;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = (int)(blockDim.x >> 6);
     ResidentTileAsync<KB, (LEAN || KB == 4) ? 2 : 1> T;
     if (wv < 8)
         T.load(P, blockIdx.x, blockIdx.y, chain_block, smem, s_stop, s_own + RA_OWNERS * OWN);
-    if (threadIdx.x < RA_CMAX + 2)
+    if (threadIdx.x < 2 * RA_CNT)
         s_cnt[threadIdx.x] = 0u;
     if (threadIdx.x < 8)
         s_sel[32 * 8 + 16 + threadIdx.x] = 0;           // (the tile waves' progress)
@@ -1322,9 +1441,7 @@ __global__ __launch_bounds__(512 + 64 * (RA_OWNERS + 1)) void resident_async_ker
     __builtin_amdgcn_s_setprio(MC3HIP_RA_PRIO);
     if (wv == nwaves - 1) {
         if (blockIdx.x == 0) {
-            const int c0 = blockIdx.y * chain_block;
-            const int c1 = (c0 + chain_block < P.nlocal) ? c0 + chain_block : P.nlocal;
-            resident_scheduler(P, rounds, blockIdx.y, c0, c1 - c0, s_sel + 32 * 8);
+            resident_scheduler(P, rounds, blockIdx.y, gridDim.y, s_sel + 32 * 8);
         }
         return;
     }
