@@ -8,7 +8,9 @@ namespace mc3hip {
 // (defined in wavelet.h, which only the wavelet kernels' translation unit includes)
 template <int WPC, int MT>
 __device__ __forceinline__ void wavelet_stage(const DevProblem &P, double *xs);
-template <int WPC, int MT, bool LARGE = false>
+// (NX: one wave, the noise terms left in s_tab by a helper wave of the workgroup -- a
+// workgroup barrier where they are first used: kernels_wavelet.h wavelet_one_kernel)
+template <int WPC, int MT, bool LARGE = false, bool NX = false>
 __device__ double block_wavelet(const DevProblem &P, const double *s_nextp, double *s_part,
                                 int *s_flag, double *s_tab, double *s_halo, const double *xs);
 

@@ -63,7 +63,9 @@ void persist_instance_t(const mc3hip_ctx *c, bool p2p, chain_kernel_fn *out)
         // (one wave per chain, snooker, the common shape: the chain written out by hand)
         if constexpr (WW == 1 && !LARGE) {
             if (!p2p && !mc && c->wl_one)
-                *out = wavelet_one_kernel<MT>;
+                *out = c->P.sampler == MC3HIP_SNOOKER ? wavelet_one_kernel<MT>
+                       : c->P.sampler == MC3HIP_MRW   ? wavelet_one_other_kernel<MT, MC3HIP_MRW>
+                                                      : wavelet_one_other_kernel<MT, MC3HIP_DEMC>;
         }
     }
 }

@@ -2100,6 +2100,21 @@ __global__ __launch_bounds__(704) void wavelet_pipe_kernel(const DevProblem P, c
     }
 }
 
+// The helper wave of the one-wave kernels below (wave 1 of a workgroup of two): the noise
+// terms of every proposal, while wave 0 transforms.  Barrier (A): a proposal is in np -- or
+// (flag[3]) the launch is over; barrier (B): wavelet_body<1, .., NX>, where the terms are used.
+__device__ __forceinline__ void wavelet_one_helper(const DevProblem &P, const SmemLayout &L)
+{
+    const int M = ilog2(P.ndata);
+    for (;;) {
+        block_sync<2>();                                // (A)
+        if (L.flag[3] != 0)
+            return;
+        wavelet_noise_terms(L.nextp, P.nparams, M, L.tab);
+        block_sync<2>();                                // (B)
+    }
+}
+
 // ---- ONE wave per chain: wavelet likelihoods of up to 2 048 points, by hand ------------------
 // Below 8 192 points there was no chain wave: the general chain (run_chain behind
 // persist_kernel) ran these shapes -- 3.8 us per iteration at 64 points, 5.6 at 2 048, of which
@@ -2112,7 +2127,7 @@ __global__ __launch_bounds__(704) void wavelet_pipe_kernel(const DevProblem P, c
 // draws, same arithmetic in the same order as run_chain: bit-identical
 // (tests/test_gpu_parity.py).  MC3HIP_NO_WL_ONE: the general chain.
 template <int MT>
-__global__ __launch_bounds__(64) void wavelet_one_kernel(const DevProblem P, const int nref)
+__global__ __launch_bounds__(128) void wavelet_one_kernel(const DevProblem P, const int nref)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const SmemLayout L = carve(smem, P, 64);
@@ -2123,6 +2138,13 @@ __global__ __launch_bounds__(64) void wavelet_one_kernel(const DevProblem P, con
     if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
             &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
         return;
+    // (wave 1: the noise terms -- wavelet_one_helper)
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0) {
+        wavelet_one_helper(P, L);
+        return;
+    }
+    if (lane == 0)
+        L.flag[3] = 0;
     wavelet_stage<1, MT>(P, L.xs);
     double *np = L.nextp;
     if (lane < P.nparams)
@@ -2256,9 +2278,9 @@ __global__ __launch_bounds__(64) void wavelet_one_kernel(const DevProblem P, con
         if (!__any(outk)) {
             if (mine)
                 np[jfree] = npk;
-            block_sync<1>();
-            const double total = block_wavelet<1, MT, false>(P, np, L.part, L.flag, L.tab, L.halo,
-                                                             L.xs);
+            block_sync<2>();                            // (A) the helper wave's turn begins
+            const double total = block_wavelet<1, MT, false, true>(P, np, L.part, L.flag, L.tab,
+                                                                   L.halo, L.xs);
             // (as WaveletHook::finish: the prior term of a problem without priors is 0.0)
             const double nextchisq = is_pos_inf(total) ? total : total + 0.0;
             if (__builtin_expect(!sjump, 1)) {
@@ -2299,6 +2321,9 @@ __global__ __launch_bounds__(64) void wavelet_one_kernel(const DevProblem P, con
         done = n + 1;
     }
     (void)done;
+    if (lane == 0)
+        L.flag[3] = 1;                                  // (the helper wave leaves)
+    block_sync<2>();
     if (mine && oob)
         atomicAdd(&P.outbounds[lane], oob);
     if (mine)
@@ -2309,5 +2334,166 @@ __global__ __launch_bounds__(64) void wavelet_one_kernel(const DevProblem P, con
         P.numaccept[b] += (long long)nacc;
     }
 }
+
+// The same for the two samplers that need no history: the random walk (chain.py:219-220 -- no
+// rows at all, a normal draw per free parameter) and DEMC without the support distribution
+// (chain.py:221-232 -- the two partners' rows of the refresh before, asked for right behind the
+// own row).  The draws of a turn are one scalar Philox call, made a turn ahead like the normal
+// draws (they run in the shadow of the partners' rows).  Same shapes as above.
+template <int MT, int SMP>
+__global__ __launch_bounds__(128) void wavelet_one_other_kernel(const DevProblem P, const int nref)
+{
+    static_assert(SMP == MC3HIP_MRW || SMP == MC3HIP_DEMC, "");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const SmemLayout L = carve(smem, P, 64);
+    const int lane = threadIdx.x & 63;
+    const int b = (int)blockIdx.x;
+    const int c = P.chain0 + b;
+    long long *ctl_rw = const_cast<long long *>(P.ctl);
+    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
+            &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+        return;
+    // (wave 1: the noise terms -- wavelet_one_helper)
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0) {
+        wavelet_one_helper(P, L);
+        return;
+    }
+    if (lane == 0)
+        L.flag[3] = 0;
+    wavelet_stage<1, MT>(P, L.xs);
+    double *np = L.nextp;
+    if (lane < P.nparams)
+        np[lane] = P.params[lane];
+    if (lane + 64 < P.nparams)
+        np[lane + 64] = P.params[lane + 64];
+    block_sync<1>();
+    double *Zr = own_global(P.Z), *log_post = own_global(P.log_post);
+    const double *snap0 = own_global(P.snap0);
+    int32_t *zchain = own_global(P.zchain);
+    const int nchains = P.nchains, nf = P.nfree, zs = P.zs;
+    const long long M0 = P.M0;
+    const uint64_t seed = P.seed;
+    const double gamma = P.gamma, fepsilon = P.fepsilon;
+    const bool mine = lane < nf;
+    const int kk = mine ? lane : 0;
+    const long long R0 = P.ctl[0];
+    double xk;
+    {
+        const double *snap_first = (R0 == 0) ? snap0 : Zr + (size_t)(M0 + (R0 - 1) * nchains) * zs;
+        xk = mine ? snap_first[(size_t)c * zs + lane] : 0.0;
+    }
+    double cur_c = P.chisq[b], best = P.best_chisq[b];
+    int nacc = 0;
+    unsigned long long oob = 0;
+    const int jfree = mine ? P.ifree[lane] : 0;
+    const double pmin_k = mine ? P.fmin[lane] : 0.0;
+    const double pmax_k = mine ? P.fmax[lane] : 0.0;
+    const bool need_normal = (SMP == MC3HIP_MRW) || (fepsilon != 0.0);
+    const double pstep_k = (mine && need_normal) ? P.fstep[lane] : 0.0;
+    const long long abort_at = (P.test_abort >= 0 && b == 0) ? (long long)P.test_abort : -1;
+    auto normal_draw = [&](uint64_t it) {              // chain.py:185, as run_chain's
+        double nk = 0.0;
+        if (mine) {
+            const Draw2 d = draw2(seed, it, (uint32_t)c, (uint32_t)(3 + (lane >> 1)));
+            const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(d.q0)));
+            double sn, cs;
+            mc3_det_sincos2pi(u01(d.q1), &sn, &cs);
+            nk = (rad * ((lane & 1) ? sn : cs)) * pstep_k;
+        }
+        return nk;
+    };
+    const double *ra[2] = {nullptr, nullptr};
+    double rv[2] = {0.0, 0.0};
+    auto request_rows = [&](uint64_t q0, long long R) {
+        const long long Rs = R - 1;
+        const double *snap = (Rs < 0) ? snap0 : Zr + (size_t)(M0 + Rs * nchains) * zs;
+        int r1, r2;
+        demc_partners(q0, nchains, c, r1, r2);
+        ra[0] = snap + (size_t)r1 * zs + kk;
+        ra[1] = snap + (size_t)r2 * zs + kk;
+        rv[0] = load_published<false>(ra[0]);
+        rv[1] = load_published<false>(ra[1]);
+    };
+    Draw2 nxt = draw2(seed, (uint64_t)R0, (uint32_t)c, 0u);
+    if constexpr (SMP == MC3HIP_DEMC)
+        request_rows(nxt.q0, R0);
+    double normal_ahead = need_normal ? normal_draw((uint64_t)R0) : 0.0;
+    for (int n = 0; n < nref; ++n) {
+        const long long R = R0 + n;
+        if (__builtin_expect(R == abort_at, 0)) {                      // test hook
+            __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        const double u = u01(nxt.q1);                                  // chain.py:259
+        const double normal_k = normal_ahead;
+        nxt = draw2(seed, (uint64_t)(R + 1), (uint32_t)c, 0u);
+        double lo, hi;
+        accept_window(u, lo, hi);
+        if (need_normal)
+            normal_ahead = normal_draw((uint64_t)(R + 1));
+        double jump_k;
+        if constexpr (SMP == MC3HIP_MRW) {                             // chain.py:219-220
+            jump_k = normal_k;
+        } else {                                                       // chain.py:221-232
+            if (!wait_rows<2, false>(ra, rv, ctl_rw))
+                break;
+            jump_k = gamma * (rv[0] - rv[1]) + fepsilon * normal_k;
+        }
+        const double npk = xk + jump_k;                                // chain.py:235-243
+        const bool outk = mine && (npk < pmin_k || npk > pmax_k);
+        bool accepted = false;
+        if (!__any(outk)) {
+            if (mine)
+                np[jfree] = npk;
+            block_sync<2>();                            // (A) the helper wave's turn begins
+            const double total = block_wavelet<1, MT, false, true>(P, np, L.part, L.flag, L.tab,
+                                                                   L.halo, L.xs);
+            // (as WaveletHook::finish: the prior term of a problem without priors is 0.0)
+            const double nextchisq = is_pos_inf(total) ? total : total + 0.0;
+            accepted = metropolis_accept(0.5 * (cur_c - nextchisq), u, lo, hi);
+            if (accepted) {                                            // chain.py:257-274
+                xk = npk;
+                cur_c = nextchisq;
+                nacc += 1;
+            }
+        } else {
+            oob += outk ? 1ull : 0ull;                                 // chain.py:242-243
+        }
+        const long long row = M0 + R * nchains + c;                    // chain.py:276-289
+        if (mine)
+            __hip_atomic_store(&Zr[(size_t)row * zs + lane], xk, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);              // publish (sc1)
+        // the partners' rows of this refresh: asked for right behind the own row
+        if constexpr (SMP == MC3HIP_DEMC) {
+            if (n + 1 < nref)
+                request_rows(nxt.q0, R + 1);
+        }
+        if (lane == 0) {
+            log_post[row] = -0.5 * cur_c;
+            zchain[row] = c;
+        }
+        if (__builtin_expect(accepted && cur_c < best, 0)) {
+            best = cur_c;
+            if (mine)
+                P.bestx[(size_t)b * nf + lane] = xk;
+            if (lane == 0)
+                P.best_iter[b] = R;
+        }
+    }
+    if (lane == 0)
+        L.flag[3] = 1;                                  // (the helper wave leaves)
+    block_sync<2>();
+    if (mine && oob)
+        atomicAdd(&P.outbounds[lane], oob);
+    if (mine)
+        P.X[(size_t)b * nf + lane] = xk;
+    if (lane == 0) {
+        P.chisq[b] = cur_c;
+        P.best_chisq[b] = best;
+        P.numaccept[b] += (long long)nacc;
+    }
+}
+
 
 }  // namespace mc3hip

@@ -356,6 +356,9 @@ hipError_t set_smem_attr_wavelet(mc3hip_ctx *c)
 // threads and dynamic LDS of the general persistent instance that runs
 int persist_threads(const mc3hip_ctx *c, bool p2p)
 {
+    // (the one-wave wavelet chains written out by hand: a helper wave beside the chain's)
+    if (c->wl_one && c->mc_chains == 0 && !p2p)
+        return 128;
     return chainwave_runs(c, p2p) ? chainwave_threads(c, p2p) : 64 * c->wpc;
 }
 size_t persist_smem(const mc3hip_ctx *c, bool p2p)
@@ -521,7 +524,7 @@ int decide_persist(mc3hip_ctx *c)
                    !(c->flags & MC3HIP_FLAG_P2P) &&
                    c->smem + CW_EXTRA_DOUBLES * sizeof(double) <= 160 * 1024;
     c->wl_one = !c->fast && c->P.wlike && c->wpc == 1 && !c->P.wl_scratch &&
-                cw_lean_eligible(c) && c->P.sampler == MC3HIP_SNOOKER && c->P.fepsilon == 0.0 &&
+                cw_lean_eligible(c) && (c->P.fepsilon == 0.0 || c->P.sampler == MC3HIP_MRW) &&
                 !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_WL_ONE") &&
                 !getenv("MC3HIP_NO_CW_LEAN");
     // (bit 1: an out-of-bounds proposal rides with the turn behind it, kernels_wavelet.h

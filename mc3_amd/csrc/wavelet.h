@@ -319,7 +319,12 @@ __device__ unsigned long long mc3_pipe_diag[16];
 #endif
 // PIPE (kernels_wavelet.h wavelet_pipe_kernel): stage A only -- everything behind barrier (1) is
 // run by a wave of its own (PipeTail below) while these waves start on the next likelihood.
-template <int WPC, int MT, int B, bool VALUES = false, bool CW = false, bool PIPE = false>
+// NX (one wave): the noise terms are a HELPER wave's work -- it is computing them while this
+// wave transforms, and a barrier of the two stands where they are first used (stage A's sums,
+// behind the whole transform: ~1.1 us of dependent software exp2 / log / the log-determinant's
+// serial additions out of the chain's way).
+template <int WPC, int MT, int B, bool VALUES = false, bool CW = false, bool PIPE = false,
+          bool NX = false>
 __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double *s_nextp,
                                                double *s_part, int *s_flag, double *s_tab,
                                                double *s_halo, const double *xs,
@@ -354,7 +359,8 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
     // One wave: the noise terms first.  Several waves: the LAST wave computes them after its
     // share of stage A, while wave 0 is busy with stages B and C -- two long dependent chains
     // (software exp2 / log; cross-lane levels) side by side instead of one after the other.
-    if constexpr (WPC == 1)
+    static_assert(!NX || WPC == 1, "");
+    if constexpr (WPC == 1 && !NX)
         wavelet_noise_terms(s_nextp, P.nparams, M, s_tab);
 #ifdef MC3HIP_PIPE_DIAG
     const unsigned long long dg_in = __builtin_amdgcn_s_memtime();
@@ -515,6 +521,8 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
         sawinf = s_flag[1];
         sumA = sumA + wave_sum(weigh_levels<NLB>(accB, s_tab, mA - NLA));      // (A + B)
     } else {
+        if constexpr (NX)
+            block_sync<2>();                            // the helper wave's noise terms are in LDS
         sumA = wave_sum((active && N >= 4) ? stage_a_sum() : 0.0);
         sawinf = __any(sawinf) ? 1 : 0;
     }
@@ -703,10 +711,11 @@ __device__ double wavelet_large(const DevProblem &P, const double *s_nextp, doub
 // LARGE (a kernel instance of its own, so that the resident path keeps its register
 // allocation): ndata > 2^14, eight waves, pre-levels through global memory.
 // (declared, with LARGE = false by default, in chisq.h)
-template <int WPC, int MT, bool LARGE>
+template <int WPC, int MT, bool LARGE, bool NX>
 __device__ double block_wavelet(const DevProblem &P, const double *s_nextp, double *s_part,
                                 int *s_flag, double *s_tab, double *s_halo, const double *xs)
 {
+    static_assert(!NX || (WPC == 1 && !LARGE), "");
     constexpr int T = 64 * WPC;
     if constexpr (LARGE) {
         static_assert(WPC == 8, "the large-data path has eight waves");
@@ -714,7 +723,8 @@ __device__ double block_wavelet(const DevProblem &P, const double *s_nextp, doub
     }
     const int B = (P.ndata / 2 < T) ? 2 : P.ndata / T;
 #define MC3_WL_BODY(BB)                                                                       \
-    return wavelet_body<WPC, MT, BB>(P, s_nextp, s_part, s_flag, s_tab, s_halo, xs)
+    return wavelet_body<WPC, MT, BB, false, false, false, NX>(P, s_nextp, s_part, s_flag, s_tab, \
+                                                              s_halo, xs)
     if constexpr (WPC == 8) {
         if (B == 32)
             MC3_WL_BODY(32);

@@ -336,6 +336,53 @@ def test_wavelet_one_wave_chain_by_hand(eng, monkeypatch, ndata, case):
     gpu.close()
 
 
+@pytest.mark.parametrize('sampler', ['mrw', 'demc', 'mrw-eps'])
+@pytest.mark.parametrize('ndata', [2, 16, 100, 256, 1024, 2048])
+@pytest.mark.parametrize('case', ['plain', 'tight', 'resume', 'abort', 'switch'])
+def test_wavelet_one_wave_chain_other_samplers(eng, monkeypatch, ndata, sampler, case):
+    """wavelet_one_other_kernel: the same one-wave chain for the samplers that need no history --
+    the random walk (with a support-distribution factor too: it plays no part in chain.py:219-220)
+    and DEMC (the partners' rows of the refresh before, handed over in the launch): identical
+    rows, counters, best fit to the checker, with bounds that bite, across launches, through a
+    give-up, and behind the switch the general chain."""
+    smp = sampler.split('-')[0]
+    if ndata == 100:
+        prob = H.wavelet_problem(ndata=128, nchains=6, nsamples=6*120, sampler=smp)
+        prob.update(wl_nreal=100)
+    else:
+        prob = H.wavelet_problem(ndata=ndata, nchains=6, nsamples=6*120, sampler=smp)
+    if sampler == 'mrw-eps':
+        prob.update(fepsilon=0.01)
+    if case == 'tight':
+        prob.update(pmin=np.array([2.6, -2.6, 0.47, 0.0, 0.3, 0.8]),
+                    pmax=np.array([3.4, -2.2, 0.53, 2.0, 0.7, 1.2]))
+    if case == 'switch':
+        monkeypatch.setenv('MC3HIP_NO_WL_ONE', '1')
+    if case == 'abort':
+        monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '40')
+    if case == 'resume':
+        monkeypatch.setenv('MC3HIP_PERSIST_REFS', '23')
+        gpu = eng.DeviceChains(**prob)
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nthreads=4)
+        for n in (1, 2, 50, 67):
+            gpu.run(n)
+    else:
+        orc, gpu = run_pair(eng, prob, trace=False)
+    plan = gpu.plan
+    if case == 'abort':
+        assert plan['recoveries'] == 1, plan
+    else:
+        assert plan['persistent'] > 0 and plan['waves_per_chain'] == 1 and \
+            plan['recoveries'] == 0, plan
+        assert plan['fast'] == (0 if case == 'switch' else 3), plan
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
 @pytest.mark.parametrize('ndata', [32768, 131072])
 def test_wavelet_beyond_2_14_points(eng, ndata):
     """More than 32 points per thread: strided pre-levels through global memory bring the

@@ -7,7 +7,7 @@ the plan the library picked, us per iteration, M chain-steps/s and the PER-POINT
 (chains x points per second), the figure neighbours are compared by: a shape below 0.5x the
 per-point rate of BOTH its neighbours in the sweep is marked `"cliff": true`.
 
-    python tools/mid_range.py [gauss|wavelet|offlean ...]  > profiles/rNN_mid_range.jsonl
+    python tools/mid_range.py [gauss|wavelet|offlean|wlone ...]  > profiles/rNN_mid_range.jsonl
 """
 import json
 import os
@@ -86,6 +86,18 @@ def main():
         sweep('wavelet-demc', [(1 << m, 256) for m in (8, 10, 12, 13, 14)],
               lambda nd, nc, n: H.wavelet_problem(ndata=nd, nchains=nc, nsamples=nc*n,
                                                   sampler='demc'))
+    if 'wlone' in parts:
+        # the one-wave wavelet chains written out by hand (wavelet_one_kernel /
+        # wavelet_one_other_kernel) against the general chain behind MC3HIP_NO_WL_ONE
+        for smp in ('snooker', 'demc', 'mrw'):
+            for off in (False, True):
+                if off:
+                    os.environ['MC3HIP_NO_WL_ONE'] = '1'
+                sweep(f'wavelet-{smp}' + ('-general-chain' if off else ''),
+                      [(1 << m, 256) for m in (6, 8, 10, 11)],
+                      lambda nd, nc, n, smp=smp: H.wavelet_problem(ndata=nd, nchains=nc,
+                                                                   nsamples=nc*n, sampler=smp))
+                os.environ.pop('MC3HIP_NO_WL_ONE', None)
     if 'offlean' in parts:
         # the shapes no hand-laid-out loop serves
         def poly(k, sampler, **kw):
