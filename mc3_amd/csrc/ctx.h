@@ -56,7 +56,7 @@ struct mc3hip_ctx {
     int wide_jit_tiles = 0;
     int wide_jit_waves = 0;         // (4 or 8)
     // wavelet likelihood, one wave per chain (<= 2048 points), the shapes of cw_lean_eligible,
-    // snooker without the support distribution: kernels_wavelet.h wavelet_one_kernel
+    // the one-wave wavelet chains written out by hand: kernels_wavelet.h wavelet_one_kernel
     bool wl_one = false;
     int lean_waves_default = 1;     // waves per chain of the hand-laid-out DEMC loop (ctx.h
                                     // lean_waves), decided with the grid in decide_persist

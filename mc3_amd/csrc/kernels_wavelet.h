@@ -2122,7 +2122,7 @@ __device__ __forceinline__ void wavelet_one_helper(const DevProblem &P, const Sm
 // bookkeeping -- state in registers, a turn's draws / row offsets / Metropolis window 21 turns at
 // a time, history rows asked for a turn ahead (they travel while the likelihood runs) -- around
 // wavelet_body<1>: propose, bounds, transform, decide, publish, one turn after the other.  Snooker
-// without the support distribution, the shapes of host::cw_lean_eligible (thinning 1, no trace,
+// (the support distribution's deviates, if any, drawn in the turn), the shapes of host::cw_lean_eligible (thinning 1, no trace,
 // no priors, no shared parameters, strict lockstep), one chain per workgroup, one GPU.  Same
 // draws, same arithmetic in the same order as run_chain: bit-identical
 // (tests/test_gpu_parity.py).  MC3HIP_NO_WL_ONE: the general chain.
@@ -2173,6 +2173,20 @@ __global__ __launch_bounds__(128) void wavelet_one_kernel(const DevProblem P, co
     const double pmin_k = mine ? P.fmin[lane] : 0.0;
     const double pmax_k = mine ? P.fmax[lane] : 0.0;
     const long long abort_at = (P.test_abort >= 0 && b == 0) ? (long long)P.test_abort : -1;
+    // (the support distribution, chain.py:185,217: a normal deviate per free parameter and turn)
+    const bool need_normal = P.fepsilon != 0.0;
+    const double pstep_k = (mine && need_normal) ? P.fstep[lane] : 0.0;
+    auto normal_draw = [&](uint64_t it) {              // as run_chain's
+        double nk = 0.0;
+        if (mine) {
+            const Draw2 d = draw2(P.seed, it, (uint32_t)c, (uint32_t)(3 + (lane >> 1)));
+            const double rad = __builtin_sqrt(-2.0 * mc3_det_log(u01_open(d.q0)));
+            double sn, cs;
+            mc3_det_sincos2pi(u01(d.q1), &sn, &cs);
+            nk = (rad * ((lane & 1) ? sn : cs)) * pstep_k;
+        }
+        return nk;
+    };
     // the draws of NB turns at once (pipe_chain_wave_one): lane 3 i + s = slot s of turn bbase + i
     constexpr int LPR = 3, NB = 21;
     unsigned long long A = 0, B = 0;
@@ -2270,7 +2284,8 @@ __global__ __launch_bounds__(128) void wavelet_one_kernel(const DevProblem P, co
                 jump_k = ((gs * (zp1 - zp2)) * dz) / dd;
             }
         } else {
-            jump_k = gamma * (z1 - z2) + P.fepsilon * 0.0;             // chain.py:217
+            const double normal_k = need_normal ? normal_draw((uint64_t)(R0 + n)) : 0.0;
+            jump_k = gamma * (z1 - z2) + P.fepsilon * normal_k;        // chain.py:217
         }
         const double npk = xk + jump_k;                               // chain.py:235-243
         const bool outk = mine && (npk < pmin_k || npk > pmax_k);
@@ -2336,8 +2351,7 @@ __global__ __launch_bounds__(128) void wavelet_one_kernel(const DevProblem P, co
 }
 
 // The same for the two samplers that need no history: the random walk (chain.py:219-220 -- no
-// rows at all, a normal draw per free parameter) and DEMC without the support distribution
-// (chain.py:221-232 -- the two partners' rows of the refresh before, asked for right behind the
+// rows at all, a normal draw per free parameter) and DEMC (chain.py:221-232 -- the two partners' rows of the refresh before, asked for right behind the
 // own row).  The draws of a turn are one scalar Philox call, made a turn ahead like the normal
 // draws (they run in the shadow of the partners' rows).  Same shapes as above.
 template <int MT, int SMP>

@@ -524,7 +524,7 @@ int decide_persist(mc3hip_ctx *c)
                    !(c->flags & MC3HIP_FLAG_P2P) &&
                    c->smem + CW_EXTRA_DOUBLES * sizeof(double) <= 160 * 1024;
     c->wl_one = !c->fast && c->P.wlike && c->wpc == 1 && !c->P.wl_scratch &&
-                cw_lean_eligible(c) && (c->P.fepsilon == 0.0 || c->P.sampler == MC3HIP_MRW) &&
+                cw_lean_eligible(c) &&
                 !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_WL_ONE") &&
                 !getenv("MC3HIP_NO_CW_LEAN");
     // (bit 1: an out-of-bounds proposal rides with the turn behind it, kernels_wavelet.h

@@ -336,13 +336,14 @@ def test_wavelet_one_wave_chain_by_hand(eng, monkeypatch, ndata, case):
     gpu.close()
 
 
-@pytest.mark.parametrize('sampler', ['mrw', 'demc', 'mrw-eps'])
+@pytest.mark.parametrize('sampler', ['mrw', 'demc', 'mrw-eps', 'demc-eps', 'snooker-eps'])
 @pytest.mark.parametrize('ndata', [2, 16, 100, 256, 1024, 2048])
 @pytest.mark.parametrize('case', ['plain', 'tight', 'resume', 'abort', 'switch'])
 def test_wavelet_one_wave_chain_other_samplers(eng, monkeypatch, ndata, sampler, case):
     """wavelet_one_other_kernel: the same one-wave chain for the samplers that need no history --
     the random walk (with a support-distribution factor too: it plays no part in chain.py:219-220)
-    and DEMC (the partners' rows of the refresh before, handed over in the launch): identical
+    and DEMC (the partners' rows of the refresh before, handed over in the launch) -- and the
+    support distribution (chain.py:185,217) in DEMC's and snooker's one-wave chains: identical
     rows, counters, best fit to the checker, with bounds that bite, across launches, through a
     give-up, and behind the switch the general chain."""
     smp = sampler.split('-')[0]
@@ -351,7 +352,7 @@ def test_wavelet_one_wave_chain_other_samplers(eng, monkeypatch, ndata, sampler,
         prob.update(wl_nreal=100)
     else:
         prob = H.wavelet_problem(ndata=ndata, nchains=6, nsamples=6*120, sampler=smp)
-    if sampler == 'mrw-eps':
+    if sampler.endswith('-eps'):
         prob.update(fepsilon=0.01)
     if case == 'tight':
         prob.update(pmin=np.array([2.6, -2.6, 0.47, 0.0, 0.3, 0.8]),
