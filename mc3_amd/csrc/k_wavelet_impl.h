@@ -61,11 +61,13 @@ void persist_instance_t(const mc3hip_ctx *c, bool p2p, chain_kernel_fn *out)
                    : mc ? persist_kernel<WW, MT, true, LARGE, false, true>
                         : persist_kernel<WW, MT, true, LARGE>;
         // (one wave per chain, snooker, the common shape: the chain written out by hand)
-        if constexpr (WW == 1 && !LARGE) {
+        // (... and four: 4 096 points)
+        if constexpr ((WW == 1 || WW == 4) && !LARGE) {
             if (!p2p && !mc && c->wl_one)
-                *out = c->P.sampler == MC3HIP_SNOOKER ? wavelet_one_kernel<MT>
-                       : c->P.sampler == MC3HIP_MRW   ? wavelet_one_other_kernel<MT, MC3HIP_MRW>
-                                                      : wavelet_one_other_kernel<MT, MC3HIP_DEMC>;
+                *out = c->P.sampler == MC3HIP_SNOOKER ? wavelet_one_kernel<MT, WW>
+                       : c->P.sampler == MC3HIP_MRW
+                           ? wavelet_one_other_kernel<MT, MC3HIP_MRW, WW>
+                           : wavelet_one_other_kernel<MT, MC3HIP_DEMC, WW>;
         }
     }
 }

@@ -2115,6 +2115,47 @@ __device__ __forceinline__ void wavelet_one_helper(const DevProblem &P, const Sm
     }
 }
 
+// 4 096 points -- four waves per chain -- in the same kernels (WPC = 4): the chain is wave 0's,
+// waves 1..3 take part in every likelihood (the noise terms are the last wave's, behind its
+// share of stage A: wavelet_body) and in nothing else.  Barrier (A) as above.
+template <int MT, int WPC>
+__device__ __forceinline__ void wavelet_one_followers(const DevProblem &P, const SmemLayout &L)
+{
+    if constexpr (WPC == 1) {
+        wavelet_one_helper(P, L);
+    } else {
+        for (;;) {
+            block_sync<WPC>();                          // (A)
+            if (L.flag[3] != 0)
+                return;
+            (void)block_wavelet<WPC, MT, false>(P, L.nextp, L.part, L.flag, L.tab, L.halo, L.xs);
+        }
+    }
+}
+// wave 0: the likelihood of the proposal in L.nextp
+template <int MT, int WPC>
+__device__ __forceinline__ double wavelet_one_likelihood(const DevProblem &P, const SmemLayout &L)
+{
+    if constexpr (WPC == 1) {
+        block_sync<2>();                                // (A) the helper wave's turn begins
+        return block_wavelet<1, MT, false, true>(P, L.nextp, L.part, L.flag, L.tab, L.halo, L.xs);
+    } else {
+        block_sync<WPC>();                              // (A) everybody's
+        return block_wavelet<WPC, MT, false>(P, L.nextp, L.part, L.flag, L.tab, L.halo, L.xs);
+    }
+}
+// wave 0, the launch over: the other waves leave
+template <int WPC>
+__device__ __forceinline__ void wavelet_one_leave(const SmemLayout &L)
+{
+    if ((threadIdx.x & 63) == 0)
+        L.flag[3] = 1;
+    if constexpr (WPC == 1)
+        block_sync<2>();
+    else
+        block_sync<WPC>();
+}
+
 // ---- ONE wave per chain: wavelet likelihoods of up to 2 048 points, by hand ------------------
 // Below 8 192 points there was no chain wave: the general chain (run_chain behind
 // persist_kernel) ran these shapes -- 3.8 us per iteration at 64 points, 5.6 at 2 048, of which
@@ -2126,11 +2167,12 @@ __device__ __forceinline__ void wavelet_one_helper(const DevProblem &P, const Sm
 // no priors, no shared parameters, strict lockstep), one chain per workgroup, one GPU.  Same
 // draws, same arithmetic in the same order as run_chain: bit-identical
 // (tests/test_gpu_parity.py).  MC3HIP_NO_WL_ONE: the general chain.
-template <int MT>
-__global__ __launch_bounds__(128) void wavelet_one_kernel(const DevProblem P, const int nref)
+template <int MT, int WPC = 1>
+__global__ __launch_bounds__(WPC == 1 ? 128 : 64 * WPC) void wavelet_one_kernel(const DevProblem P,
+                                                                               const int nref)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const SmemLayout L = carve(smem, P, 64);
+    const SmemLayout L = carve(smem, P, 64 * WPC);
     const int lane = threadIdx.x & 63;
     const int b = (int)blockIdx.x;
     const int c = P.chain0 + b;
@@ -2138,14 +2180,19 @@ __global__ __launch_bounds__(128) void wavelet_one_kernel(const DevProblem P, co
     if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
             &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
         return;
-    // (wave 1: the noise terms -- wavelet_one_helper)
-    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0) {
-        wavelet_one_helper(P, L);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if constexpr (WPC > 1)
+        wavelet_stage<WPC, MT>(P, L.xs);                // (everybody's share of the abscissae)
+    // (one wave: wave 1 has the noise terms, wavelet_one_helper; four: waves 1..3 their share
+    // of every likelihood)
+    if (wave != 0) {
+        wavelet_one_followers<MT, WPC>(P, L);
         return;
     }
     if (lane == 0)
         L.flag[3] = 0;
-    wavelet_stage<1, MT>(P, L.xs);
+    if constexpr (WPC == 1)
+        wavelet_stage<1, MT>(P, L.xs);
     double *np = L.nextp;
     if (lane < P.nparams)
         np[lane] = P.params[lane];
@@ -2293,9 +2340,7 @@ __global__ __launch_bounds__(128) void wavelet_one_kernel(const DevProblem P, co
         if (!__any(outk)) {
             if (mine)
                 np[jfree] = npk;
-            block_sync<2>();                            // (A) the helper wave's turn begins
-            const double total = block_wavelet<1, MT, false, true>(P, np, L.part, L.flag, L.tab,
-                                                                   L.halo, L.xs);
+            const double total = wavelet_one_likelihood<MT, WPC>(P, L);
             // (as WaveletHook::finish: the prior term of a problem without priors is 0.0)
             const double nextchisq = is_pos_inf(total) ? total : total + 0.0;
             if (__builtin_expect(!sjump, 1)) {
@@ -2336,9 +2381,7 @@ __global__ __launch_bounds__(128) void wavelet_one_kernel(const DevProblem P, co
         done = n + 1;
     }
     (void)done;
-    if (lane == 0)
-        L.flag[3] = 1;                                  // (the helper wave leaves)
-    block_sync<2>();
+    wavelet_one_leave<WPC>(L);
     if (mine && oob)
         atomicAdd(&P.outbounds[lane], oob);
     if (mine)
@@ -2354,12 +2397,13 @@ __global__ __launch_bounds__(128) void wavelet_one_kernel(const DevProblem P, co
 // rows at all, a normal draw per free parameter) and DEMC (chain.py:221-232 -- the two partners' rows of the refresh before, asked for right behind the
 // own row).  The draws of a turn are one scalar Philox call, made a turn ahead like the normal
 // draws (they run in the shadow of the partners' rows).  Same shapes as above.
-template <int MT, int SMP>
-__global__ __launch_bounds__(128) void wavelet_one_other_kernel(const DevProblem P, const int nref)
+template <int MT, int SMP, int WPC = 1>
+__global__ __launch_bounds__(WPC == 1 ? 128 : 64 * WPC) void wavelet_one_other_kernel(
+    const DevProblem P, const int nref)
 {
     static_assert(SMP == MC3HIP_MRW || SMP == MC3HIP_DEMC, "");
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const SmemLayout L = carve(smem, P, 64);
+    const SmemLayout L = carve(smem, P, 64 * WPC);
     const int lane = threadIdx.x & 63;
     const int b = (int)blockIdx.x;
     const int c = P.chain0 + b;
@@ -2367,14 +2411,19 @@ __global__ __launch_bounds__(128) void wavelet_one_other_kernel(const DevProblem
     if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
             &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
         return;
-    // (wave 1: the noise terms -- wavelet_one_helper)
-    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0) {
-        wavelet_one_helper(P, L);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if constexpr (WPC > 1)
+        wavelet_stage<WPC, MT>(P, L.xs);                // (everybody's share of the abscissae)
+    // (one wave: wave 1 has the noise terms, wavelet_one_helper; four: waves 1..3 their share
+    // of every likelihood)
+    if (wave != 0) {
+        wavelet_one_followers<MT, WPC>(P, L);
         return;
     }
     if (lane == 0)
         L.flag[3] = 0;
-    wavelet_stage<1, MT>(P, L.xs);
+    if constexpr (WPC == 1)
+        wavelet_stage<1, MT>(P, L.xs);
     double *np = L.nextp;
     if (lane < P.nparams)
         np[lane] = P.params[lane];
@@ -2460,9 +2509,7 @@ __global__ __launch_bounds__(128) void wavelet_one_other_kernel(const DevProblem
         if (!__any(outk)) {
             if (mine)
                 np[jfree] = npk;
-            block_sync<2>();                            // (A) the helper wave's turn begins
-            const double total = block_wavelet<1, MT, false, true>(P, np, L.part, L.flag, L.tab,
-                                                                   L.halo, L.xs);
+            const double total = wavelet_one_likelihood<MT, WPC>(P, L);
             // (as WaveletHook::finish: the prior term of a problem without priors is 0.0)
             const double nextchisq = is_pos_inf(total) ? total : total + 0.0;
             accepted = metropolis_accept(0.5 * (cur_c - nextchisq), u, lo, hi);
@@ -2495,9 +2542,7 @@ __global__ __launch_bounds__(128) void wavelet_one_other_kernel(const DevProblem
                 P.best_iter[b] = R;
         }
     }
-    if (lane == 0)
-        L.flag[3] = 1;                                  // (the helper wave leaves)
-    block_sync<2>();
+    wavelet_one_leave<WPC>(L);
     if (mine && oob)
         atomicAdd(&P.outbounds[lane], oob);
     if (mine)

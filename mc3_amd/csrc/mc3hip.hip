@@ -357,8 +357,9 @@ hipError_t set_smem_attr_wavelet(mc3hip_ctx *c)
 int persist_threads(const mc3hip_ctx *c, bool p2p)
 {
     // (the one-wave wavelet chains written out by hand: a helper wave beside the chain's)
+    // (four waves per chain -- 4 096 points --: the chain is wave 0's)
     if (c->wl_one && c->mc_chains == 0 && !p2p)
-        return 128;
+        return c->wpc == 1 ? 128 : 64 * c->wpc;
     return chainwave_runs(c, p2p) ? chainwave_threads(c, p2p) : 64 * c->wpc;
 }
 size_t persist_smem(const mc3hip_ctx *c, bool p2p)
@@ -523,7 +524,7 @@ int decide_persist(mc3hip_ctx *c)
     c->chainwave = c->P.wlike && c->wpc == 8 && !c->P.wl_scratch &&
                    !(c->flags & MC3HIP_FLAG_P2P) &&
                    c->smem + CW_EXTRA_DOUBLES * sizeof(double) <= 160 * 1024;
-    c->wl_one = !c->fast && c->P.wlike && c->wpc == 1 && !c->P.wl_scratch &&
+    c->wl_one = !c->fast && c->P.wlike && (c->wpc == 1 || c->wpc == 4) && !c->P.wl_scratch &&
                 cw_lean_eligible(c) &&
                 !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_WL_ONE") &&
                 !getenv("MC3HIP_NO_CW_LEAN");

@@ -287,10 +287,10 @@ def test_wavelet_chains_bit_exact(eng, ndata):
     gpu.close()
 
 
-@pytest.mark.parametrize('ndata', [2, 4, 8, 16, 64, 100, 128, 256, 512, 1024, 2048])
+@pytest.mark.parametrize('ndata', [2, 4, 8, 16, 64, 100, 128, 256, 512, 1024, 2048, 4096])
 @pytest.mark.parametrize('case', ['plain', 'tight', 'wide', 'resume', 'abort', 'switch'])
 def test_wavelet_one_wave_chain_by_hand(eng, monkeypatch, ndata, case):
-    """wavelet_one_kernel (round 5): up to 2 048 points, one wave per chain, snooker -- the chain
+    """wavelet_one_kernel (round 5): up to 2 048 points, one wave per chain (4 096: four), snooker -- the chain
     written out by hand around wavelet_body<1> (state in registers, draws 21 turns at a time,
     rows a turn ahead) where the general chain ran: identical rows, counters, best fit to the
     checker for every block size, with bounds that reject a third of the proposals, with none,
@@ -327,8 +327,9 @@ def test_wavelet_one_wave_chain_by_hand(eng, monkeypatch, ndata, case):
     if case == 'abort':
         assert plan['recoveries'] == 1, plan
     else:
-        assert plan['persistent'] > 0 and plan['waves_per_chain'] == 1 and \
-            plan['recoveries'] == 0, plan
+        # (4 096 points: four waves per chain, the chain wave 0's)
+        assert plan['persistent'] > 0 and plan['recoveries'] == 0 and \
+            plan['waves_per_chain'] == (4 if ndata == 4096 else 1), plan
         assert plan['fast'] == (0 if case == 'switch' else 3), plan
     assert_same(orc, gpu, trace=False)
     if case == 'tight' and ndata >= 64:
@@ -337,7 +338,7 @@ def test_wavelet_one_wave_chain_by_hand(eng, monkeypatch, ndata, case):
 
 
 @pytest.mark.parametrize('sampler', ['mrw', 'demc', 'mrw-eps', 'demc-eps', 'snooker-eps'])
-@pytest.mark.parametrize('ndata', [2, 16, 100, 256, 1024, 2048])
+@pytest.mark.parametrize('ndata', [2, 16, 100, 256, 1024, 2048, 4096])
 @pytest.mark.parametrize('case', ['plain', 'tight', 'resume', 'abort', 'switch'])
 def test_wavelet_one_wave_chain_other_samplers(eng, monkeypatch, ndata, sampler, case):
     """wavelet_one_other_kernel: the same one-wave chain for the samplers that need no history --
@@ -377,8 +378,8 @@ def test_wavelet_one_wave_chain_other_samplers(eng, monkeypatch, ndata, sampler,
     if case == 'abort':
         assert plan['recoveries'] == 1, plan
     else:
-        assert plan['persistent'] > 0 and plan['waves_per_chain'] == 1 and \
-            plan['recoveries'] == 0, plan
+        assert plan['persistent'] > 0 and plan['recoveries'] == 0 and \
+            plan['waves_per_chain'] == (4 if ndata == 4096 else 1), plan
         assert plan['fast'] == (0 if case == 'switch' else 3), plan
     assert_same(orc, gpu, trace=False)
     gpu.close()

@@ -94,7 +94,7 @@ def main():
                 if off:
                     os.environ['MC3HIP_NO_WL_ONE'] = '1'
                 sweep(f'wavelet-{smp}' + ('-general-chain' if off else ''),
-                      [(1 << m, 256) for m in (6, 8, 10, 11)],
+                      [(1 << m, 256) for m in (6, 8, 10, 11, 12)],
                       lambda nd, nc, n, smp=smp: H.wavelet_problem(ndata=nd, nchains=nc,
                                                                    nsamples=nc*n, sampler=smp))
                 os.environ.pop('MC3HIP_NO_WL_ONE', None)
