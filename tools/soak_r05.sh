@@ -16,6 +16,15 @@ run 3000 snooker 100 wavelet 16384
 run 12000 snooker 256 wavelet 2048
 run 20000 snooker 256 wavelet 256
 run 20000 snooker 64 wavelet 64
+# ... for the random walk and DEMC (wavelet_one_other_kernel), with the support distribution,
+# and on four waves (4 096 points)
+run 12000 mrw 256 wavelet 2048
+run 12000 demc 256 wavelet 1024
+run 12000 demc 100 wavelet 256 fepsilon=0.01
+run 12000 snooker 256 wavelet 512 fepsilon=0.01
+run 8000 snooker 256 wavelet 4096
+run 8000 demc 256 wavelet 4096
+run 8000 mrw 128 wavelet 4096
 # the tiles in the registers of several waves (lean_*_wide_kernel)
 run 20000 demc 256 ndata=2048
 run 20000 demc 256 ndata=4096
