@@ -1157,10 +1157,19 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
             {
                 s_prog[wv] = (int)seq;
                 const int other = s_prog[wv ^ 4];
+#ifdef MC3HIP_RA_BEHIND_FIRST          // (experiment: the one behind ABOVE the owners)
+                if ((int)seq > other)
+                    __builtin_amdgcn_s_setprio(0);
+                else if ((int)seq < other)
+                    __builtin_amdgcn_s_setprio(MC3HIP_RA_BEHIND_FIRST);
+                else
+                    __builtin_amdgcn_s_setprio(1);
+#else
                 if ((int)seq > other)
                     __builtin_amdgcn_s_setprio(0);
                 else
                     __builtin_amdgcn_s_setprio(1);
+#endif
             }
 #endif
 #ifdef MC3HIP_TIMELINE
@@ -1274,9 +1283,11 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
             }
             const bool ok = hit1 || hit2;
             MC3_RTICK(tq2);
-#ifndef MC3HIP_RA_NO_SUMS_PRIO
+#ifdef MC3HIP_RA_SUMS_PRIO
             // (from here to the sums' publication every instruction is between a block's
-            // products and its chains' owners: ahead of the partner's products)
+            // products and its chains' owners: ahead of the partner's products?  In a long
+            // launch the wave's own priority serves better: C5 25.46 us per iteration with
+            // this, 25.19 without -- bench.py --config-child c5, +-0.02 from run to run)
             if (have)
                 __builtin_amdgcn_s_setprio(3);
 #endif
@@ -1327,7 +1338,9 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
+#ifndef MC3HIP_RA_KEEP_PRIO            // (experiment: what the last take decided stays)
                 __builtin_amdgcn_s_setprio(1);
+#endif
                 spins = 0;
                 MC3_RTICK(tq1);
 #ifdef MC3HIP_TIMELINE
@@ -1440,6 +1453,9 @@ __global__ __launch_bounds__(512 + 64 * (RA_OWNERS + 1)) void resident_async_ker
     // block's sums and the next proposals -- ahead of the tile waves' products)
     __builtin_amdgcn_s_setprio(MC3HIP_RA_PRIO);
     if (wv == nwaves - 1) {
+#ifdef MC3HIP_RA_SCHED_PRIO            // (experiment: the scheduler apart from the owners)
+        __builtin_amdgcn_s_setprio(MC3HIP_RA_SCHED_PRIO);
+#endif
         if (blockIdx.x == 0) {
             resident_scheduler(P, rounds, blockIdx.y, gridDim.y, s_sel + 32 * 8);
         }

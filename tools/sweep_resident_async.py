@@ -18,12 +18,16 @@ for k in (3, 10):
         for nd in (12000, 16384, 24000, 32768, 50000, 100000):
             for smp in ('demc', 'snooker'):
                 row = dict(K=k, nchains=nchains, ndata=nd, sampler=smp)
+                # (the async leg forced -- MC3HIP_RS_ASYNC=1 -- whatever decide_persist's rule
+                # says; launches long enough that their beginning, in step, weighs little)
                 for tag, env in (('async', None), ('in_step', '1')):
                     if env:
                         os.environ['MC3HIP_NO_RS_ASYNC'] = env
+                        os.environ.pop('MC3HIP_RS_ASYNC', None)
                     else:
                         os.environ.pop('MC3HIP_NO_RS_ASYNC', None)
-                    n = 400
+                        os.environ['MC3HIP_RS_ASYNC'] = '1'
+                    n = int(os.environ.get('SWEEP_ITERS', 2000))
                     prob = H.linear_problem(ndata=nd, nmodel=k, nchains=nchains,
                                             nsamples=nchains*(n + n//5 + 8), sampler=smp)
                     g = engine.DeviceChains(**prob)
@@ -36,4 +40,5 @@ for k in (3, 10):
                     row['resident'] = g.plan['resident']
                     g.close()
                 os.environ.pop('MC3HIP_NO_RS_ASYNC', None)
+                os.environ.pop('MC3HIP_RS_ASYNC', None)
                 print(json.dumps(row), flush=True)
