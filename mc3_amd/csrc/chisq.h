@@ -32,17 +32,24 @@ __device__ __forceinline__ double block_chisq(const DevProblem &P, const double 
     return c + prior_term(P, s_nextp);
 }
 
-// chisq of a chain from the per-tile sums (tiles added in order) plus the prior
-// term.  The +inf-model trap of chain.py:322-323 is resolved lazily: a +inf model
+// chisq of a chain from the per-tile sums plus the prior term.  The tiles' sums are added as
+// the wave's halving tree, sixty-four at a time (a lane per tile, lanes beyond the tiles 0.0;
+// groups of sixty-four in order) -- the order of ResidentOwner::collect and of the checker
+// (oracle_lockstep.c tiles_sum): six dependent additions for C5's 49 tiles where adding
+// them one after the other was 49, each behind whatever the FP64 pipe is busy with.  The +inf-model trap of chain.py:322-323 is resolved lazily: a +inf model
 // value always makes the sum non-finite (w > 0), so only a non-finite sum needs
 // the scan that tells "+inf model" (chisq = inf) from any other overflow.
 template <int MT>
 __device__ __forceinline__ double finish_chisq(const DevProblem &P, int lc)
 {
     const double *np = P.sc_nextp + (size_t)lc * SC_STRIDE;
+    const int lane = threadIdx.x & 63;
     double total = 0.0;
-    for (int t = 0; t < P.ntiles; ++t)
-        total = total + P.sc_part[(size_t)lc * P.ntiles + t];
+    for (int t0 = 0; t0 < P.ntiles; t0 += 64) {
+        const double v = (t0 + lane < P.ntiles) ? P.sc_part[(size_t)lc * P.ntiles + t0 + lane]
+                                                : 0.0;
+        total = total + wave_sum(v);
+    }
     const bool finite = (mc3_bits(total) & 0x7ff0000000000000ull) != 0x7ff0000000000000ull;
     if (!finite) {
         Model<MT> model;

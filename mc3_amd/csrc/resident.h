@@ -86,8 +86,8 @@ struct ResidentOwner {
         }
     }
 
-    // owner, after the tile phase: the data sum of chain lc, tiles added in order; hands the
-    // slots and the row this iteration used back
+    // owner, after the tile phase: the data sum of chain lc, the tiles' sums added as the wave's
+    // halving tree; hands the slots and the row this iteration used back
     __device__ __forceinline__ double collect(const DevProblem &P, int lc)
     {
         long long *ctl = const_cast<long long *>(P.ctl);
@@ -100,19 +100,9 @@ struct ResidentOwner {
             double val[1] = {load_published(mine)};
             if (!wait_rows<1>(addr, val, ctl))
                 failed = true;
-            // (in order, eight broadcasts at a time ahead of their dependent additions)
-            int k = 0;
-            for (; k + 8 <= n; k += 8) {
-                double v8[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    v8[u] = read_lane(val[0], k + u);
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    total = total + v8[u];
-            }
-            for (; k < n; ++k)
-                total = total + read_lane(val[0], k);
+            // (the wave's halving tree over the tiles, lanes beyond them 0.0: chisq.h
+            // finish_chisq's order)
+            total = total + wave_sum(lane < n ? val[0] : 0.0);
             if (lane < n)
                 __hip_atomic_store(mine, mc3_from_bits(ROW_PENDING), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);

@@ -291,6 +291,21 @@ static double tile_sum(double *part, int n, int waves_first)
     return halving_tree(part, ng);
 }
 
+/* The tiled plan's per-tile sums of a chain: sixty-four at a time as a halving tree (a lane of
+ * the owner wave per tile, lanes beyond the tiles 0.0), the groups of sixty-four added in
+ * order (csrc/chisq.h finish_chisq, csrc/resident.h ResidentOwner::collect). */
+static double tiles_sum(const double *tt, int nt)
+{
+    double total = 0.0;
+    for (int t0 = 0; t0 < nt; t0 += 64) {
+        double g[64];
+        for (int l = 0; l < 64; l++)
+            g[l] = (t0 + l < nt) ? tt[t0 + l] : 0.0;
+        total = total + halving_tree(g, 64);
+    }
+    return total;
+}
+
 /* tile_tree = 2 (design matrices through the matrix cores, tile = 2048 points): the weights
  * are folded into the operands -- column k of the design matrix and the data are multiplied
  * by w = 1/uncert ONCE, each product rounded, when the problem is set up -- so a residual is
@@ -307,7 +322,8 @@ static double gauss_chisq_weighted_rows(const ls_problem *P, const double *p)
     const int tile = P->tile, K = P->nmodel;
     const int npad = (P->ndata + tile - 1) / tile * tile;
     const double *A = P->indep;
-    double total = 0.0;
+    const int nt = npad / tile;
+    double *tt = (double *)malloc((size_t)nt * sizeof(double));
     for (int t0 = 0; t0 < npad; t0 += tile) {
         double rows[8];
         for (int wv = 0; wv < 8; wv++) {
@@ -328,8 +344,10 @@ static double gauss_chisq_weighted_rows(const ls_problem *P, const double *p)
             }
             rows[wv] = halving_tree(lanes, 16);
         }
-        total = total + halving_tree(rows, 8);
+        tt[t0 / tile] = halving_tree(rows, 8);
     }
+    const double total = tiles_sum(tt, nt);
+    free(tt);
     if (!(total - total == 0.0)) {                        /* inf or NaN: was a model value +inf? */
         for (int i = 0; i < P->ndata; i++)
             if (model_at(P, p, i) == INFINITY)
@@ -356,6 +374,9 @@ static double gauss_chisq(const ls_problem *P, const double *p, double *part)
     const int tile = (P->tile > 0) ? P->tile : npad;
     int sawinf = 0;
     double total = 0.0;
+    /* (the tiled plan, P->tile > 0: the tiles' sums as tiles_sum; otherwise there is one) */
+    const int nt = npad / tile;
+    double *tt = (P->tile > 0) ? (double *)malloc((size_t)nt * sizeof(double)) : NULL;
     for (int t0 = 0; t0 < npad; t0 += tile) {
         const int t1 = (t0 + tile < npad) ? t0 + tile : npad;
         for (int l = 0; l < VL; l++) {
@@ -371,7 +392,14 @@ static double gauss_chisq(const ls_problem *P, const double *p, double *part)
             }
             part[l] = acc;
         }
-        total = total + tile_sum(part, VL, P->tile_tree);
+        if (tt)
+            tt[t0 / tile] = tile_sum(part, VL, P->tile_tree);
+        else
+            total = total + tile_sum(part, VL, P->tile_tree);
+    }
+    if (tt) {
+        total = tiles_sum(tt, nt);
+        free(tt);
     }
     if (sawinf || total == INFINITY)
         return INFINITY;
