@@ -15,7 +15,7 @@ namespace mc3hip {
 // 16 at a time: every thread produces 16 partial sums, one LDS exchange, then
 // wave g reduces chain g over the 1024 lanes in the canonical order (strides
 // 512..64 across waves, 32..1 inside the wave).  Output: sc_part[chain][tile];
-// the finish kernel adds the tiles in order.
+// the finish kernel adds the tiles' sums as the wave's halving tree (chisq.h finish_chisq).
 // KX > 0: the number of coefficients is known at compile time (polynomials of 2..4
 // coefficients, the same family the fused kernels specialise): the Horner chain is KX - 1
 // fused multiply-adds instead of KMAX steps of "is this coefficient there?" selects, which
