@@ -983,15 +983,21 @@ __device__ __forceinline__ void resident_scheduler(const DevProblem &P, const in
         const double *prop = P.rs_prop + (size_t)(R & 1) * pstride;
         // chains lane and lane + 64 of the column: still to do in this iteration
         bool rem0 = lane < n, rem1 = lane + 64 < n;
+        bool r0 = false, r1 = false;        // ... and known to be there
+        bool poll = true;
         int nrem = n;
         while (nrem > 0) {
             // is the proposal there?  (element 0 of the row; a tile wave waits for the rest
-            // when it uses the row)
-            const double f0 = load_published(prop + (size_t)(c0 + l0) * RS_ROW);
-            const double f1 = (n > 64) ? load_published(prop + (size_t)(c0 + l1) * RS_ROW)
-                                       : mc3_from_bits(ROW_PENDING);
-            const bool r0 = rem0 && mc3_bits(f0) != ROW_PENDING;
-            const bool r1 = rem1 && mc3_bits(f1) != ROW_PENDING;
+            // when it uses the row)  After a block: the next one at once, without asking
+            // again, if the chains already known to be there make one up.
+            if (poll) {
+                const double f0 = load_published(prop + (size_t)(c0 + l0) * RS_ROW);
+                const double f1 = (n > 64) ? load_published(prop + (size_t)(c0 + l1) * RS_ROW)
+                                           : mc3_from_bits(ROW_PENDING);
+                r0 = rem0 && mc3_bits(f0) != ROW_PENDING;
+                r1 = rem1 && mc3_bits(f1) != ROW_PENDING;
+            }
+            poll = true;
             const unsigned long long m0 = __builtin_amdgcn_ballot_w64(r0);
             const unsigned long long m1 = __builtin_amdgcn_ballot_w64(r1);
             const int p0 = __builtin_popcountll(m0), p1 = __builtin_popcountll(m1);
@@ -1038,7 +1044,10 @@ __device__ __forceinline__ void resident_scheduler(const DevProblem &P, const in
             ++seq;
             rem0 = rem0 && !t0;
             rem1 = rem1 && !t1;
+            r0 = r0 && !t0;
+            r1 = r1 && !t1;
             nrem -= nt;
+            poll = false;
         }
     }
 }
