@@ -403,6 +403,19 @@ int mc3hip_selftest_philox(int32_t device, const uint32_t *ctr, int32_t n,
  * the last step-kernel launch (workgroup 0); the product build returns zeros. */
 int mc3hip_debug_stamps(mc3hip_ctx *ctx, uint64_t *out16);
 
+/* Launch ledger (test infrastructure; no counterpart in the reference, whose one code path is
+ * mc3/chain.py:183-299): which of the library's kernel instances this process has launched, and
+ * how often -- one line each, "<launches> <of which with no MC3HIP_* switch in the environment>
+ * <offset of the instance's host stub in libmc3hip.so> <device kernel name> [<switch> ...]"
+ * (a loop specialised at run time: offset 0x0, name "jit:<kernel>").  The
+ * test suite adds the ledgers of its processes up and fails if an instance the library carries
+ * was never launched beside the oracle (tests/test_zz_instance_coverage.py).  At most cap - 1
+ * bytes and a terminating 0 are written; *needed = the size of the whole text. */
+int mc3hip_debug_launch_counts(char *buf, int64_t cap, int64_t *needed);
+/* ... and the chain kernel the context launched last, labelled the same way ("" before the
+ * first launch): the soak tests assert the kernel they mean to check is the one that ran. */
+int mc3hip_debug_last_kernel(mc3hip_ctx *ctx, char *buf, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

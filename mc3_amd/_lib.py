@@ -119,6 +119,8 @@ SYMBOLS = {
     'mc3hip_p2p_rollback': (ctypes.c_int, [_vp, _lp, _lp]),
     'mc3hip_comm_destroy': (ctypes.c_int, [_vp]),
     'mc3hip_debug_stamps': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
+    'mc3hip_debug_launch_counts': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int64, _lp]),
+    'mc3hip_debug_last_kernel': (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int64]),
     'mc3hip_selftest_math': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, _dp, ctypes.c_int32, _dp]),
     'mc3hip_selftest_philox': (ctypes.c_int, [ctypes.c_int32, _up, ctypes.c_int32, _up, _up]),
 }
@@ -150,6 +152,22 @@ def check(rc):
     if rc != OK:
         msg = load().mc3hip_last_error()
         raise Mc3HipError(rc, msg.decode() if msg else '')
+
+
+def launch_counts():
+    """The library's launch ledger of THIS process (include/mc3hip.h
+    mc3hip_debug_launch_counts): [(launches, launches with no MC3HIP_* switch in the
+    environment, stub offset in libmc3hip.so, device kernel name, [switches seen])]."""
+    lib = load()
+    need = ctypes.c_int64()
+    check(lib.mc3hip_debug_launch_counts(None, 0, ctypes.byref(need)))
+    buf = ctypes.create_string_buffer(int(need.value) + 4096)
+    check(lib.mc3hip_debug_launch_counts(buf, len(buf), ctypes.byref(need)))
+    rows = []
+    for line in buf.value.decode().splitlines():
+        n, plain, off, name, *switches = line.split(' ')
+        rows.append((int(n), int(plain), int(off, 16), name, switches))
+    return rows
 
 
 def f64(a):

@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "core.h"
@@ -104,6 +105,10 @@ struct mc3hip_ctx {
     // peer-to-peer hand-off
     int p2p_ranks = 0;
     std::vector<void *> p2p_opened;
+    // the chain kernel this context launched last (launch ledger below; nullptr: none yet, or
+    // the run-time specialisation, whose name is jit_name)
+    const void *last_kernel = nullptr;
+    std::string jit_name;
 };
 
 namespace mc3hip {
@@ -115,6 +120,26 @@ typedef void (*chain_kernel_fn)(const DevProblem, const int);
 typedef void (*resident_kernel_fn)(const DevProblem, const int, const int);
 
 constexpr int WL_EVAL_BLOCKS = 256;
+
+// ---- launch ledger (mc3hip.hip): how often every kernel instance of the library was launched
+// by this process, by host stub address -- mc3hip_debug_launch_counts reads it, the test suite's
+// instance-coverage report (tests/test_zz_instance_coverage.py) is made from it.  A launch is
+// one call per many thousand refreshes (or one graph capture): a mutex and a short table.
+const void *ledger_note(const void *kernel);
+// every kernel of the library is launched through this, so that none escapes the ledger
+#define MC3_LAUNCH(kernel, ...)                                                            \
+    do {                                                                                   \
+        auto mc3_k_ = (kernel);                                                            \
+        ::mc3hip::host::ledger_note(reinterpret_cast<const void *>(mc3_k_));               \
+        hipLaunchKernelGGL(mc3_k_, __VA_ARGS__);                                           \
+    } while (0)
+// ... a chain kernel also leaves its name with the context (mc3hip_debug_last_kernel)
+#define MC3_LAUNCH_CHAIN(c, kernel, ...)                                                   \
+    do {                                                                                   \
+        auto mc3_k_ = (kernel);                                                            \
+        (c)->last_kernel = ::mc3hip::host::ledger_note(reinterpret_cast<const void *>(mc3_k_)); \
+        hipLaunchKernelGGL(mc3_k_, __VA_ARGS__);                                           \
+    } while (0)
 
 // the wavelet kernel with a wave of its own for the chain (kernels_wavelet.h): nine waves, and
 // behind the compute waves' LDS areas the chain wave's own area, the command word, the result

@@ -20,10 +20,10 @@ template <int MT>
 void launch_step_t(mc3hip_ctx *c, int roff)
 {
     if (c->P.npad > VLANES)
-        hipLaunchKernelGGL((step_kernel<WPC, MT, false, true>), dim3(c->P.nlocal), dim3(64 * WPC),
+        MC3_LAUNCH_CHAIN(c, (step_kernel<WPC, MT, false, true>), dim3(c->P.nlocal), dim3(64 * WPC),
                            c->smem, c->stream, c->P, roff);
     else
-        hipLaunchKernelGGL((step_kernel<WPC, MT, false, false>), dim3(c->P.nlocal),
+        MC3_LAUNCH_CHAIN(c, (step_kernel<WPC, MT, false, false>), dim3(c->P.nlocal),
                            dim3(64 * WPC), c->smem, c->stream, c->P, roff);
 }
 
@@ -45,7 +45,7 @@ void persist_instance_t(const mc3hip_ctx *c, bool p2p, chain_kernel_fn *out)
 template <int MT>
 void launch_eval_t(mc3hip_ctx *c, int n)
 {
-    hipLaunchKernelGGL((eval_chisq_kernel<WPC, MT, false>), dim3(n), dim3(64 * WPC), c->smem,
+    MC3_LAUNCH((eval_chisq_kernel<WPC, MT, false>), dim3(n), dim3(64 * WPC), c->smem,
                        c->stream, c->P, (const double *)c->eval_params, c->eval_out);
 }
 

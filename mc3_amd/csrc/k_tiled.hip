@@ -10,13 +10,13 @@ namespace {
 template <int MT>
 void launch_propose_t(mc3hip_ctx *c, int roff, int j)
 {
-    hipLaunchKernelGGL((propose_kernel<MT>), dim3(c->P.nlocal), dim3(64), c->smem, c->stream,
+    MC3_LAUNCH((propose_kernel<MT>), dim3(c->P.nlocal), dim3(64), c->smem, c->stream,
                        c->P, roff, j);
 }
 template <int MT>
 void launch_finish_t(mc3hip_ctx *c, int roff, int j)
 {
-    hipLaunchKernelGGL((finish_kernel<MT>), dim3(c->P.nlocal), dim3(64), c->smem, c->stream,
+    MC3_LAUNCH((finish_kernel<MT>), dim3(c->P.nlocal), dim3(64), c->smem, c->stream,
                        c->P, roff, j);
 }
 #define DISPATCH_MT1(FN, ...)                                                       \
@@ -36,7 +36,7 @@ void launch_tile_t(mc3hip_ctx *c)
 {
     const int ncol = (c->P.nlocal + c->tile_chain_block - 1) / c->tile_chain_block;
     constexpr int TP = KMAX <= 4 ? 4 : 2;
-    hipLaunchKernelGGL((tile_chisq_kernel<KMAX, LINEAR, TP, KX>), dim3(c->P.ntiles, ncol),
+    MC3_LAUNCH_CHAIN(c, (tile_chisq_kernel<KMAX, LINEAR, TP, KX>), dim3(c->P.ntiles, ncol),
                        dim3(1024), TILE_LDS_BYTES, c->stream, c->P,
                        c->tile_chain_block, (const double *)c->P.sc_nextp,
                        (const int32_t *)c->P.sc_flag);
@@ -46,7 +46,7 @@ template <int KB>
 void launch_tile_mfma_t(mc3hip_ctx *c)
 {
     const int ncol = (c->P.nlocal + c->tile_chain_block - 1) / c->tile_chain_block;
-    hipLaunchKernelGGL((tile_chisq_mfma_kernel<KB>), dim3(c->P.ntiles, ncol), dim3(512),
+    MC3_LAUNCH_CHAIN(c, (tile_chisq_mfma_kernel<KB>), dim3(c->P.ntiles, ncol), dim3(512),
                        0, c->stream, c->P, c->tile_chain_block,
                        (const double *)c->P.sc_nextp, (const int32_t *)c->P.sc_flag);
 }

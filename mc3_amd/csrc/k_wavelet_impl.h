@@ -27,7 +27,7 @@ constexpr bool LARGE = false;
 template <int MT>
 void launch_step_t(mc3hip_ctx *c, int roff)
 {
-    hipLaunchKernelGGL((step_kernel<WW, MT, true, LARGE>), dim3(c->P.nlocal), dim3(64 * WW),
+    MC3_LAUNCH_CHAIN(c, (step_kernel<WW, MT, true, LARGE>), dim3(c->P.nlocal), dim3(64 * WW),
                        c->smem, c->stream, c->P, roff);
 }
 
@@ -75,7 +75,7 @@ void persist_instance_t(const mc3hip_ctx *c, bool p2p, chain_kernel_fn *out)
 template <int MT>
 void launch_eval_t(mc3hip_ctx *c, int n)
 {
-    hipLaunchKernelGGL((eval_chisq_kernel<WW, MT, true, LARGE>), dim3(n), dim3(64 * WW), c->smem,
+    MC3_LAUNCH((eval_chisq_kernel<WW, MT, true, LARGE>), dim3(n), dim3(64 * WW), c->smem,
                        c->stream, c->P, (const double *)c->eval_params, c->eval_out);
 }
 

@@ -29,6 +29,87 @@
 using namespace mc3hip;
 using namespace mc3hip::host;
 
+// ---- launch ledger (ctx.h) -------------------------------------------------------------------
+extern char **environ;
+namespace {
+struct LedgerRow {
+    const void *kernel;          // host stub of an instance of this library, or nullptr:
+    std::string name;            // ... a kernel specialised at run time, by name
+    unsigned long long launches; // all launches, and those with no MC3HIP_* switch in the
+    unsigned long long plain;    // environment: what the dispatch picks when left alone
+    std::string switches;        // the switches seen beside the others (" NAME NAME ...")
+};
+std::mutex g_ledger_lock;
+std::vector<LedgerRow> g_ledger;
+
+// the MC3HIP_* variables of the environment that steer the dispatch (everything but the test
+// suite's own plumbing), " NAME" each
+std::string ledger_switches()
+{
+    std::string out;
+    for (char **e = environ; e && *e; ++e) {
+        if (strncmp(*e, "MC3HIP_", 7) != 0)
+            continue;
+        const char *eq = strchr(*e, '=');
+        const std::string name(*e, eq ? (size_t)(eq - *e) : strlen(*e));
+        // (not switches of the dispatch: the tests' plumbing, the rendezvous of the ranks, the
+        // hooks that let several ranks share ONE device or make a launch give up, the cadence)
+        static const char *const plumbing[] = {
+            "MC3HIP_LEDGER_DIR", "MC3HIP_LIBRARY", "MC3HIP_JIT_CACHE", "MC3HIP_RDV_",
+            "MC3HIP_BENCH_", "MC3HIP_COMM_TIMEOUT", "MC3HIP_VERBOSE", "MC3HIP_ZLAG",
+            "MC3HIP_RESIDENT_MAXCOL", "MC3HIP_PERSIST_CAPACITY", "MC3HIP_TEST_"};
+        bool skip = false;
+        for (const char *p : plumbing)
+            skip = skip || name.compare(0, strlen(p), p) == 0;
+        if (skip)
+            continue;
+        out += " " + name;
+    }
+    return out;
+}
+
+void ledger_count(LedgerRow &r)
+{
+    const std::string sw = ledger_switches();
+    ++r.launches;
+    if (sw.empty()) {
+        ++r.plain;
+        return;
+    }
+    size_t at = 0;
+    while (at < sw.size()) {                         // (each " NAME" once)
+        const size_t end = sw.find(' ', at + 1);
+        const std::string one = sw.substr(at, end == std::string::npos ? end : end - at);
+        if ((r.switches + " ").find(one + " ") == std::string::npos)
+            r.switches += one;
+        at = end;
+    }
+}
+
+void ledger_note_named(const std::string &name)
+{
+    std::lock_guard<std::mutex> hold(g_ledger_lock);
+    for (LedgerRow &r : g_ledger)
+        if (!r.kernel && r.name == name)
+            return ledger_count(r);
+    g_ledger.push_back(LedgerRow{nullptr, name, 0, 0, std::string()});
+    ledger_count(g_ledger.back());
+}
+}  // namespace
+
+const void *mc3hip::host::ledger_note(const void *kernel)
+{
+    std::lock_guard<std::mutex> hold(g_ledger_lock);
+    for (LedgerRow &r : g_ledger)
+        if (r.kernel == kernel) {
+            ledger_count(r);
+            return kernel;
+        }
+    g_ledger.push_back(LedgerRow{kernel, std::string(), 0, 0, std::string()});
+    ledger_count(g_ledger.back());
+    return kernel;
+}
+
 namespace {
 
 thread_local std::string g_err;
@@ -213,12 +294,12 @@ void launch_resident(mc3hip_ctx *c, int nref)
     if (c->resident_owner_waves > 0) {
         // (the scheduler's blocks of this launch are told from any other's by its number)
         c->P.rs_gen = (c->P.rs_gen == 0x7fffffff) ? 1 : c->P.rs_gen + 1;
-        hipLaunchKernelGGL(resident_async_kernel_of(c, c->p2p_ranks > 1), dim3(c->P.ntiles, ncol),
+        MC3_LAUNCH_CHAIN(c, resident_async_kernel_of(c, c->p2p_ranks > 1), dim3(c->P.ntiles, ncol),
                            dim3(512 + 64 * (c->resident_owner_waves + 1)),
                            resident_async_lds_bytes(c), c->stream, c->P, nref, cb);
         return;
     }
-    hipLaunchKernelGGL(resident_kernel(c, c->p2p_ranks > 1), dim3(c->P.ntiles, ncol), dim3(512),
+    MC3_LAUNCH_CHAIN(c, resident_kernel(c, c->p2p_ranks > 1), dim3(c->P.ntiles, ncol), dim3(512),
                        resident_lds_bytes(c), c->stream, c->P, nref, cb);
 }
 
@@ -247,13 +328,15 @@ void launch_fast(mc3hip_ctx *c, int nref)
         DevProblem P = c->P;
         int n = nref;
         void *args[] = {&P, &n};
+        ledger_note_named(c->jit_name);
+        c->last_kernel = nullptr;
         (void)hipModuleLaunchKernel(c->jit_fn, (unsigned)c->P.nlocal, 1, 1,
                                     (unsigned)(64 * jit_waves(c)), 1, 1, 0, c->stream,
                                     args, nullptr);
         return;
     }
     const bool mc = c->mc_chains > 0, p2p = c->p2p_ranks > 1;
-    hipLaunchKernelGGL(fast_instance(c, p2p), dim3(mc ? c->mc_grid : c->P.nlocal),
+    MC3_LAUNCH_CHAIN(c, fast_instance(c, p2p), dim3(mc ? c->mc_grid : c->P.nlocal),
                        dim3(fast_threads(c, p2p)), mc ? c->mc_smem : fast_smem(c), c->stream,
                        c->P, nref);
 }
@@ -293,7 +376,7 @@ template <int MT>
 void launch_model_t(mc3hip_ctx *c)
 {
     const int nb = (c->P.ndata + 255) / 256;
-    hipLaunchKernelGGL((eval_model_kernel<MT>), dim3(nb > 1024 ? 1024 : nb), dim3(256), 0,
+    MC3_LAUNCH((eval_model_kernel<MT>), dim3(nb > 1024 ? 1024 : nb), dim3(256), 0,
                        c->stream, c->P, (const double *)c->eval_params, c->model_out);
 }
 
@@ -370,7 +453,7 @@ size_t persist_smem(const mc3hip_ctx *c, bool p2p)
 void launch_persist(mc3hip_ctx *c, int nref)
 {
     const bool mc = c->mc_chains > 0, p2p = c->p2p_ranks > 1;
-    hipLaunchKernelGGL(persist_instance(c, p2p), dim3(mc ? c->mc_grid : c->P.nlocal),
+    MC3_LAUNCH_CHAIN(c, persist_instance(c, p2p), dim3(mc ? c->mc_grid : c->P.nlocal),
                        dim3(persist_threads(c, p2p)), mc ? c->mc_smem : persist_smem(c, p2p),
                        c->stream, c->P, nref);
 }
@@ -758,7 +841,7 @@ static int rows_to_device(mc3hip_ctx *c, double *padded, const double *host, siz
         HIP_TRY(hipMemcpyAsync(c->stage, host + r * nf, m * nf * sizeof(double),
                                hipMemcpyHostToDevice, c->stream));
         const int blocks = (int)((m * nf + 255) / 256 < 4096 ? (m * nf + 255) / 256 : 4096);
-        hipLaunchKernelGGL(unpack_rows_kernel, dim3(blocks), dim3(256), 0, c->stream,
+        MC3_LAUNCH(unpack_rows_kernel, dim3(blocks), dim3(256), 0, c->stream,
                            padded + r * zs, (const double *)c->stage, (long long)m, (int)nf,
                            (int)zs);
         HIP_TRY(hipGetLastError());
@@ -775,7 +858,7 @@ static int rows_to_host(mc3hip_ctx *c, double *host, const double *padded, size_
         const size_t m = nrows - r < chunk ? nrows - r : chunk;
         RC_TRY(stage_reserve(c, m * nf));
         const int blocks = (int)((m * nf + 255) / 256 < 4096 ? (m * nf + 255) / 256 : 4096);
-        hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, c->stream, c->stage,
+        MC3_LAUNCH(pack_rows_kernel, dim3(blocks), dim3(256), 0, c->stream, c->stage,
                            padded + r * zs, (long long)m, (int)nf, (int)zs);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(host + r * nf, c->stage, m * nf * sizeof(double),
@@ -1525,6 +1608,7 @@ int mc3hip_jit_install(mc3hip_ctx *c, const void *code_object, int64_t bytes,
                     hipGetErrorString(e));
     c->jit_module = mod;                         // (shared: not this context's to unload)
     c->jit_fn = fn;
+    c->jit_name = std::string("jit:") + kernel_name;
     c->persist_checked = false;                  // (the launch structure is decided anew)
     return MC3HIP_OK;
 }
@@ -1577,7 +1661,7 @@ static int checkpoint_copy(mc3hip_ctx *c, bool save)
         total += words[k];
     }
     const int blocks = (int)((total + 255) / 256 < 64 ? (total + 255) / 256 : 64);
-    hipLaunchKernelGGL(checkpoint_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, c->stream,
+    MC3_LAUNCH(checkpoint_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, c->stream,
                        it, reinterpret_cast<unsigned long long *>(c->ckpt), save ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return MC3HIP_OK;
@@ -1617,7 +1701,7 @@ static int build_comm_graph(mc3hip_ctx *c)
             ok = g_rccl.AllGather(base + (size_t)c->P.chain0 * zs, base,
                                   (size_t)c->P.nlocal * zs, NCCL_FLOAT64, c->comm,
                                   c->stream) == 0;
-            hipLaunchKernelGGL(ring_in_kernel, dim3(nb > 64 ? 64 : nb), dim3(256), 0, c->stream,
+            MC3_LAUNCH(ring_in_kernel, dim3(nb > 64 ? 64 : nb), dim3(256), 0, c->stream,
                                c->P, r);
         }
         hipGraph_t g = nullptr;
@@ -1654,7 +1738,7 @@ static int enqueue_per_refresh(mc3hip_ctx *c, int64_t R, int64_t Rend, long long
     const bool want_cgraph = c->graph_nodes > 0 && c->comm != nullptr && !c->comm_graph_failed;
     while (R < Rend) {
         int64_t left = Rend - R;
-        hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl, (long long)R,
+        MC3_LAUNCH(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl, (long long)R,
                            first ? run0 : -1LL);
         first = false;
         if (use_graph && left >= c->graph_nodes) {
@@ -1796,7 +1880,7 @@ int mc3hip_run(mc3hip_ctx *c, int64_t nrefresh)
         while (R < Rend) {
             const int64_t left = Rend - R;
             const int n = (int)(left < persist ? left : persist);
-            hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl,
+            MC3_LAUNCH(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl,
                                (long long)R, first ? run0 : -1LL);
             if (c->resident)
                 launch_resident(c, n);
@@ -2026,7 +2110,7 @@ static int chain_moments(mc3hip_ctx *c, int64_t nrefresh, int64_t burn, double *
     if (!c->moments)
         RC_TRY(dev_alloc(c, &c->moments, 2 * n));       // freed with the context
     double *dm = c->moments, *dv = dm + n;
-    hipLaunchKernelGGL(chain_moments_kernel, dim3(c->P.nchains), dim3(256), 0, c->stream,
+    MC3_LAUNCH(chain_moments_kernel, dim3(c->P.nchains), dim3(256), 0, c->stream,
                        (const double *)c->P.Z, (long long)c->P.M0, c->P.nchains, c->P.nfree,
                        c->P.zs, (long long)nrefresh, (long long)burn, dm, dv);
     hipError_t e = hipGetLastError();
@@ -2105,13 +2189,13 @@ int mc3hip_posterior_summary(mc3hip_ctx *c, int64_t nrefresh, int64_t burn, int3
     SelectState *st = reinterpret_cast<SelectState *>(at); at += (sbytes + 255) & ~size_t(255);
     unsigned int *hist = reinterpret_cast<unsigned int *>(at); at += (hbytes + 255) & ~size_t(255);
     double *ost = reinterpret_cast<double *>(at);
-    hipLaunchKernelGGL(summary_pass1_kernel, dim3(nblocks), dim3(256), 0, c->stream,
+    MC3_LAUNCH(summary_pass1_kernel, dim3(nblocks), dim3(256), 0, c->stream,
                        (const double *)P.Z, row0, n, nf, P.zs, keys, part);
-    hipLaunchKernelGGL(summary_finish1_kernel, dim3(1), dim3(256), 0, c->stream,
+    MC3_LAUNCH(summary_finish1_kernel, dim3(1), dim3(256), 0, c->stream,
                        (const double *)part, nblocks, nf, n, res);
-    hipLaunchKernelGGL(summary_pass2_kernel, dim3(nblocks), dim3(256), 0, c->stream,
+    MC3_LAUNCH(summary_pass2_kernel, dim3(nblocks), dim3(256), 0, c->stream,
                        (const double *)P.Z, row0, n, nf, P.zs, (const double *)res, part);
-    hipLaunchKernelGGL(summary_finish2_kernel, dim3(1), dim3(256), 0, c->stream,
+    MC3_LAUNCH(summary_finish2_kernel, dim3(1), dim3(256), 0, c->stream,
                        (const double *)part, nblocks, nf, n, res);
     if (nranks > 0) {
         std::vector<SelectState> h((size_t)nf);
@@ -2124,13 +2208,13 @@ int mc3hip_posterior_summary(mc3hip_ctx *c, int64_t nrefresh, int64_t burn, int3
         HIP_TRY(hipMemsetAsync(hist, 0, hbytes, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));          // (h goes out of scope below)
         for (int pass = 0; pass < 8; ++pass) {
-            hipLaunchKernelGGL(select_hist_kernel, dim3(nblocks, nf), dim3(256), 0, c->stream,
+            MC3_LAUNCH(select_hist_kernel, dim3(nblocks, nf), dim3(256), 0, c->stream,
                                (const uint64_t *)keys, n, nranks, pass,
                                (const SelectState *)st, hist);
-            hipLaunchKernelGGL(select_pick_kernel, dim3(nf), dim3(256), 0, c->stream, nranks,
+            MC3_LAUNCH(select_pick_kernel, dim3(nf), dim3(256), 0, c->stream, nranks,
                                pass, st, hist);
         }
-        hipLaunchKernelGGL(select_result_kernel, dim3(1), dim3(nf * SEL_MAXR), 0, c->stream,
+        MC3_LAUNCH(select_result_kernel, dim3(1), dim3(nf * SEL_MAXR), 0, c->stream,
                            (const SelectState *)st, nf, SEL_MAXR, ost);
     }
     HIP_TRY(hipGetLastError());
@@ -2163,7 +2247,7 @@ int mc3hip_get_chisq(mc3hip_ctx *c, int64_t row0, int64_t nrows, double *chisq)
         const size_t m = (size_t)nrows - r < chunk ? (size_t)nrows - r : chunk;
         RC_TRY(stage_reserve(c, m));
         const int blocks = (int)((m + 255) / 256 < 4096 ? (m + 255) / 256 : 4096);
-        hipLaunchKernelGGL(rows_chisq_kernel, dim3(blocks), dim3(256), 0, c->stream, c->P,
+        MC3_LAUNCH(rows_chisq_kernel, dim3(blocks), dim3(256), 0, c->stream, c->P,
                            (long long)(row0 + r), (long long)m, c->stage);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(chisq + r, c->stage, m * sizeof(double), hipMemcpyDeviceToHost,
@@ -2254,10 +2338,10 @@ int mc3hip_init_population(mc3hip_ctx *c, int32_t kickoff, uint64_t seed, double
     long long host_st[4] = {0, 0, 0, 0};
     long long t0 = 0;
     while ((size_t)host_st[0] < M0 && host_st[1] < 100 * (long long)M0) {
-        hipLaunchKernelGGL(init_trials_kernel, dim3((block + 127) / 128), dim3(128), 0, c->stream,
+        MC3_LAUNCH(init_trials_kernel, dim3((block + 127) / 128), dim3(128), 0, c->stream,
                            P, kickoff, seed, t0, block, c->eval_params, freep, inside);
         launch_eval(c, block);
-        hipLaunchKernelGGL(init_scan_kernel, dim3(1), dim3(64), 0, c->stream, P, block,
+        MC3_LAUNCH(init_scan_kernel, dim3(1), dim3(64), 0, c->stream, P, block,
                            (const double *)c->eval_params, (const double *)freep,
                            (const int32_t *)inside, (const double *)c->eval_out, st, stale, dZ0,
                            dlp0);
@@ -2319,7 +2403,7 @@ int mc3hip_dwt_daub4(int32_t device, const double *in, int32_t n, int32_t invers
     if (e == hipSuccess)
         e = hipMemcpy(a, in, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(daub4_kernel, dim3(1), dim3(1024), 0, 0, a, tmp, nw, inverse ? 1 : 0);
+        MC3_LAUNCH(daub4_kernel, dim3(1), dim3(1024), 0, 0, a, tmp, nw, inverse ? 1 : 0);
         e = hipGetLastError();
     }
     if (e == hipSuccess)
@@ -2418,7 +2502,7 @@ int mc3hip_residuals(int32_t device, const double *model, const double *data,
     double *dout = S.up(nullptr, (size_t)n + np, &e);
     if (e == hipSuccess) {
         const int nb = (n + np + 255) / 256;
-        hipLaunchKernelGGL(residuals_kernel, dim3(nb > 1024 ? 1024 : nb), dim3(256), 0, 0,
+        MC3_LAUNCH(residuals_kernel, dim3(nb > 1024 ? 1024 : nb), dim3(256), 0, 0,
                            (const double *)dm, (const double *)dd, (const double *)du, n,
                            (const double *)dof, (const double *)dlo, (const double *)dup, np, dout);
         e = hipGetLastError();
@@ -2445,11 +2529,11 @@ int mc3hip_chisq(int32_t device, const double *model, const double *data, const 
     double total = 0.0;
     if (e == hipSuccess) {
         const int nb = (n + 255) / 256;
-        hipLaunchKernelGGL(residuals_kernel, dim3(nb > 1024 ? 1024 : nb), dim3(256), 0, 0,
+        MC3_LAUNCH(residuals_kernel, dim3(nb > 1024 ? 1024 : nb), dim3(256), 0, 0,
                            (const double *)dm, (const double *)dd, (const double *)du, n,
                            (const double *)nullptr, (const double *)nullptr,
                            (const double *)nullptr, 0, dres);
-        hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, 0, (const double *)dres, n,
+        MC3_LAUNCH(sumsq_kernel, dim3(1), dim3(1024), 0, 0, (const double *)dres, n,
                            (const double *)nullptr, dout);
         e = hipGetLastError();
     }
@@ -2494,10 +2578,10 @@ int mc3hip_dwt_chisq(int32_t device, const double *params, int32_t nparams, cons
     double T = 0.0, head[2] = {0.0, 0.0};
     if (e == hipSuccess) {
         const int nb = (n + 255) / 256;
-        hipLaunchKernelGGL(diff_kernel, dim3(nb > 1024 ? 1024 : nb), dim3(256), 0, 0,
+        MC3_LAUNCH(diff_kernel, dim3(nb > 1024 ? 1024 : nb), dim3(256), 0, 0,
                            (const double *)dd, (const double *)dm, n, n, dres);   // data - model
-        hipLaunchKernelGGL(daub4_kernel, dim3(1), dim3(1024), 0, 0, dres, dtmp, n, 0);
-        hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, 0, (const double *)dres, n,
+        MC3_LAUNCH(daub4_kernel, dim3(1), dim3(1024), 0, 0, dres, dtmp, n, 0);
+        MC3_LAUNCH(sumsq_kernel, dim3(1), dim3(1024), 0, 0, (const double *)dres, n,
                            (const double *)dinv, dout);
         e = hipGetLastError();
     }
@@ -2525,7 +2609,7 @@ int mc3hip_kde_pdf(int32_t device, const double *sample, int32_t n, const double
     if (e == hipSuccess) {
         // scipy.stats.gaussian_kde: sum_i exp(-(x - s_i)^2 / (2 cov)) / (n sqrt(2 pi cov))
         const double norm = 1.0 / ((double)n * std::sqrt(2.0 * 3.14159265358979323846 * cov));
-        hipLaunchKernelGGL(kde_kernel, dim3(m), dim3(256), 0, 0, (const double *)ds, n,
+        MC3_LAUNCH(kde_kernel, dim3(m), dim3(256), 0, 0, (const double *)ds, n,
                            (const double *)dx, 0.5 / cov, norm, dp);
         e = hipGetLastError();
     }
@@ -2681,13 +2765,13 @@ int mc3hip_comm_gather_log_post(mc3hip_ctx *c)
         double *send = c->stage, *recv = c->stage + (size_t)n * P.nlocal;
         const int nb = (int)(((size_t)n * P.nchains + 255) / 256 < 2048
                                  ? ((size_t)n * P.nchains + 255) / 256 : 2048);
-        hipLaunchKernelGGL(logpost_pack_kernel, dim3(nb), dim3(256), 0, c->stream, P,
+        MC3_LAUNCH(logpost_pack_kernel, dim3(nb), dim3(256), 0, c->stream, P,
                            (long long)R, (long long)n, send);
         int rc = g_rccl.AllGather(send, recv, (size_t)n * P.nlocal, NCCL_FLOAT64, c->comm,
                                   c->stream);
         if (rc != 0)
             return fail(MC3HIP_ERR_COMM, "ncclAllGather(log_post) failed (%d)", rc);
-        hipLaunchKernelGGL(logpost_unpack_kernel, dim3(nb), dim3(256), 0, c->stream, P,
+        MC3_LAUNCH(logpost_unpack_kernel, dim3(nb), dim3(256), 0, c->stream, P,
                            (long long)R, (long long)n, (const double *)recv);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));      // the staging buffer is reused
@@ -2827,6 +2911,67 @@ int mc3hip_debug_stamps(mc3hip_ctx *c, uint64_t *out16)
     return MC3HIP_OK;
 }
 
+namespace {
+// "<library offset of the host stub> <device kernel name>" of an instance of this library: the
+// offset is what `nm libmc3hip.so` lists the stub under (the stubs are hidden symbols: dladdr
+// knows the library's base, not their names), the name is the runtime's
+static void ledger_label(const void *kernel, std::string *out)
+{
+    char buf[64];
+    Dl_info info;
+    unsigned long long off = 0;
+    if (dladdr(kernel, &info) && info.dli_fbase)
+        off = (unsigned long long)((const char *)kernel - (const char *)info.dli_fbase);
+    snprintf(buf, sizeof buf, "0x%llx ", off);
+    const char *name = hipKernelNameRefByPtr(kernel, nullptr);
+    *out = std::string(buf) + (name ? name : "?");
+}
+}  // namespace
+
+/* The launch ledger as text, one line per kernel instance this PROCESS has launched:
+ * "<launches> <of which with no MC3HIP_* switch set> <offset of the host stub in libmc3hip.so>
+ * <device kernel name> [<switch seen> ...]" (run-time specialisations: offset 0x0, name
+ * "jit:<kernel>").  Writes at most cap - 1 bytes and a
+ * terminating 0; *needed = bytes the whole text takes (with the 0). */
+int mc3hip_debug_launch_counts(char *buf, int64_t cap, int64_t *needed)
+{
+    if (!needed || (cap > 0 && !buf))
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    std::string text;
+    {
+        std::lock_guard<std::mutex> hold(g_ledger_lock);
+        for (const LedgerRow &r : g_ledger) {
+            std::string label = "0x0 " + r.name;
+            if (r.kernel)
+                ledger_label(r.kernel, &label);
+            text += std::to_string(r.launches) + " " + std::to_string(r.plain) + " " + label +
+                    r.switches + "\n";
+        }
+    }
+    *needed = (int64_t)text.size() + 1;
+    if (cap > 0) {
+        const size_t n = text.size() < (size_t)cap - 1 ? text.size() : (size_t)cap - 1;
+        memcpy(buf, text.data(), n);
+        buf[n] = 0;
+    }
+    return MC3HIP_OK;
+}
+
+/* The chain kernel this context launched last, as mc3hip_debug_launch_counts labels it
+ * ("" before the first launch). */
+int mc3hip_debug_last_kernel(mc3hip_ctx *c, char *buf, int64_t cap)
+{
+    if (!c || !buf || cap < 1)
+        return fail(MC3HIP_ERR_ARG, "null argument");
+    std::string text;
+    if (c->last_kernel)
+        ledger_label(c->last_kernel, &text);
+    else if (c->jit_fn && !c->jit_name.empty() && c->refresh_done > 0)
+        text = "0x0 " + c->jit_name;
+    snprintf(buf, (size_t)cap, "%s", text.c_str());
+    return MC3HIP_OK;
+}
+
 int mc3hip_selftest_math(int32_t device, int32_t op, const double *in, int32_t n, double *out)
 {
     if (!in || !out || n < 1)
@@ -2836,7 +2981,7 @@ int mc3hip_selftest_math(int32_t device, int32_t op, const double *in, int32_t n
     Scratch S(device, 2 * (size_t)n, 2, &e);       // released on every way out
     double *di = S.up(in, (size_t)n, &e), *dout = S.up(nullptr, (size_t)n, &e);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(selftest_math_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op,
+        MC3_LAUNCH(selftest_math_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op,
                            (const double *)di, n, dout);
         e = hipGetLastError();
     }
@@ -2859,7 +3004,7 @@ int mc3hip_selftest_philox(int32_t device, const uint32_t *ctr, int32_t n, const
         S.up(reinterpret_cast<const double *>(ctr), (size_t)n * 2, &e));
     uint32_t *dout = reinterpret_cast<uint32_t *>(S.up(nullptr, (size_t)n * 2, &e));
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(selftest_philox_kernel, dim3((n + 255) / 256), dim3(256), 0, 0,
+        MC3_LAUNCH(selftest_philox_kernel, dim3((n + 255) / 256), dim3(256), 0, 0,
                            (const uint32_t *)dc, n, key[0], key[1], dout);
         e = hipGetLastError();
     }

@@ -140,6 +140,14 @@ class DeviceChains:
                 'zlag': plan.zlag, 'remote_delay_ns': plan.remote_delay_ns,
                 'owner_waves': plan.owner_waves}
 
+    @property
+    def last_kernel(self):
+        """Device name of the chain kernel this context launched last ('' before the first
+        launch; 'jit:<kernel>' for a loop specialised at run time)."""
+        buf = ctypes.create_string_buffer(1024)
+        check(self.lib.mc3hip_debug_last_kernel(self._ctx, buf, len(buf)))
+        return buf.value.decode().partition(' ')[2]
+
     def jit_request(self):
         """The loop instantiation the library would like compiled for this model ('' = none)."""
         buf = ctypes.create_string_buffer(256)

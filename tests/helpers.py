@@ -1,6 +1,10 @@
 """Shared problem builders for the parity tests (CPU oracle and GPU)."""
 import numpy as np
 
+import ledger   # (a process that uses these builders leaves its launch ledger: tests/ledger.py)
+
+ledger.install()
+
 
 
 def quad(p, x):

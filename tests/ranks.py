@@ -9,6 +9,10 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import ledger  # noqa: E402   (a rank leaves its launch ledger when it ends: tests/ledger.py)
+
+ledger.install()
 
 
 def launch_ranks(nproc, script, *args, env=None, launcher='socket', timeout=1000):
