@@ -406,7 +406,7 @@ int mc3hip_debug_stamps(mc3hip_ctx *ctx, uint64_t *out16);
 /* Launch ledger (test infrastructure; no counterpart in the reference, whose one code path is
  * mc3/chain.py:183-299): which of the library's kernel instances this process has launched, and
  * how often -- one line each, "<launches> <of which with no MC3HIP_* switch in the environment>
- * <offset of the instance's host stub in libmc3hip.so> <device kernel name> [<switch> ...]"
+ * <offset of the instance's handle in libmc3hip.so> <device kernel name> [<switch> ...]"
  * (a loop specialised at run time: offset 0x0, name "jit:<kernel>").  The
  * test suite adds the ledgers of its processes up and fails if an instance the library carries
  * was never launched beside the oracle (tests/test_zz_instance_coverage.py).  At most cap - 1

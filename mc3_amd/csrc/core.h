@@ -130,6 +130,17 @@ struct DevProblem {
     // launch's rs_gen = not there yet
     int32_t rs_gen;
     unsigned long long *rs_sched;
+    // ... and which round of proposals of which launch a chain's proposal row belongs to:
+    // [nlocal] words (rs_gen << 32 | rounds published so far in this launch), stored by the
+    // owner behind the row.  The scheduler takes chain c into round R only when the word says
+    // so: a row of parity R & 1 that is still there from round R - 2 (the owner resets it
+    // when it collects R - 2's sums -- and nothing else orders a column's scheduler behind
+    // that, since the columns' chains change from round to round) is not mistaken for R's.
+    unsigned long long *rs_tag;
+    // test hook (MC3HIP_TEST_SLOW_COLUMN = "column:ticks", read at creation): the tile waves
+    // of that column of resident_async_kernel wait `ticks` of the 100 MHz clock before every
+    // block -- the columns then drift apart as far as the hand-off allows (0 ticks: off)
+    int32_t test_slow_col, test_slow_ticks;
 };
 
 constexpr int PH_FUSED = 0, PH_PROPOSE = 1, PH_FINISH = 2, PH_RESIDENT = 3, PH_CHAINWAVE = 4;

@@ -122,7 +122,7 @@ typedef void (*resident_kernel_fn)(const DevProblem, const int, const int);
 constexpr int WL_EVAL_BLOCKS = 256;
 
 // ---- launch ledger (mc3hip.hip): how often every kernel instance of the library was launched
-// by this process, by host stub address -- mc3hip_debug_launch_counts reads it, the test suite's
+// by this process, by the address of the kernel's handle -- mc3hip_debug_launch_counts reads it, the test suite's
 // instance-coverage report (tests/test_zz_instance_coverage.py) is made from it.  A launch is
 // one call per many thousand refreshes (or one graph capture): a mutex and a short table.
 const void *ledger_note(const void *kernel);

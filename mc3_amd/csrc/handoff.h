@@ -25,6 +25,20 @@ __device__ __forceinline__ double load_published(const double *p)
         return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// A launch queued behind one that gave up must not run -- its inputs are missing -- and the
+// decision is ONE per workgroup: thread 0 looks, everybody goes by what it saw.  (Each wave
+// looking for itself can disagree with its neighbours when the word flips between their
+// loads: the waves that stay then pass the barriers alone and wait for partners that left.)
+// `word`: an int of LDS nobody writes before the barrier in here.
+__device__ __forceinline__ bool launch_given_up(const long long *ctl, int *word)
+{
+    if (threadIdx.x == 0)
+        *word = (__hip_atomic_load(&ctl[CTL_ABORT], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0;
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(*word) != 0;
+}
+
 // The same load issued from inline assembly: the compiler's wait-count bookkeeping does not
 // know it, so no wait for it is inserted anywhere -- in particular not the `vmcnt(0)` the
 // compiler puts at a loop head when loads and stores are both in flight, which would wait for

@@ -870,8 +870,7 @@ __global__ __launch_bounds__(576) void wavelet_cw_kernel(const DevProblem P, con
     double *s_result = own + CW_OWN + 2;
     const int tid = threadIdx.x;
     // a launch queued behind one that gave up must not run: its inputs are missing
-    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
-            &P.ctl[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+    if (launch_given_up(P.ctl, s_cmd + 3))             // (one decision per workgroup)
         return;
     if (tid < 512)
         wavelet_stage<8, MT>(P, L.xs);
@@ -1978,8 +1977,7 @@ __global__ __launch_bounds__(704) void wavelet_pipe_kernel(const DevProblem P, c
     int *s_cmd = reinterpret_cast<int *>(own + CW_OWN);
     double *s_result = own + CW_OWN + 2;
     const int tid = threadIdx.x;
-    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
-            &P.ctl[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+    if (launch_given_up(P.ctl, s_cmd + 3))             // (one decision per workgroup)
         return;
     if (tid < 512)
         wavelet_stage<8, MT>(P, L.xs);
@@ -2177,8 +2175,9 @@ __global__ __launch_bounds__(WPC == 1 ? 128 : 64 * WPC) void wavelet_one_kernel(
     const int b = (int)blockIdx.x;
     const int c = P.chain0 + b;
     long long *ctl_rw = const_cast<long long *>(P.ctl);
-    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
-            &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+    // (one decision per workgroup, in the word that tells the follower waves the launch is
+    // over: none of them can be left behind a wave that saw another value)
+    if (launch_given_up(ctl_rw, &L.flag[3]))
         return;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if constexpr (WPC > 1)
@@ -2408,8 +2407,9 @@ __global__ __launch_bounds__(WPC == 1 ? 128 : 64 * WPC) void wavelet_one_other_k
     const int b = (int)blockIdx.x;
     const int c = P.chain0 + b;
     long long *ctl_rw = const_cast<long long *>(P.ctl);
-    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(
-            &ctl_rw[CTL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+    // (one decision per workgroup, in the word that tells the follower waves the launch is
+    // over: none of them can be left behind a wave that saw another value)
+    if (launch_given_up(ctl_rw, &L.flag[3]))
         return;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if constexpr (WPC > 1)

@@ -33,7 +33,7 @@ using namespace mc3hip::host;
 extern char **environ;
 namespace {
 struct LedgerRow {
-    const void *kernel;          // host stub of an instance of this library, or nullptr:
+    const void *kernel;          // handle of an instance of this library, or nullptr:
     std::string name;            // ... a kernel specialised at run time, by name
     unsigned long long launches; // all launches, and those with no MC3HIP_* switch in the
     unsigned long long plain;    // environment: what the dispatch picks when left alone
@@ -1280,6 +1280,8 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
             TRY(dev_alloc(c, &P.rs_part, nl * (size_t)P.rs_ntp));
             HIP_TRY_C(hipMemset(P.rs_prop, 0xff, 2 * nl * (size_t)RS_ROW * sizeof(double)));
             HIP_TRY_C(hipMemset(P.rs_part, 0xff, nl * (size_t)P.rs_ntp * sizeof(double)));
+            TRY(dev_alloc(c, &P.rs_tag, nl));
+            HIP_TRY_C(hipMemset(P.rs_tag, 0, nl * sizeof(unsigned long long)));
         }
         c->tile_kmax = pr->nmodel <= 4 ? 4 : pr->nmodel <= 8 ? 8 : pr->nmodel <= 12 ? 12 : 16;
         // chains per workgroup column (a multiple of the 16-chain block): one workgroup fits
@@ -1315,6 +1317,15 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
     P.remote_delay = 0;
     if (const char *rd = getenv("MC3HIP_TEST_REMOTE_DELAY_NS"))
         P.remote_delay = atoi(rd) > 0 ? (atoi(rd) + 5) / 10 : 0;
+    // test hook: one column of resident_async_kernel's tile waves held back before every block
+    P.test_slow_col = P.test_slow_ticks = 0;
+    if (const char *sc = getenv("MC3HIP_TEST_SLOW_COLUMN")) {
+        int col = 0, ticks = 0;
+        if (sscanf(sc, "%d:%d", &col, &ticks) == 2 && col >= 0 && ticks > 0) {
+            P.test_slow_col = col;
+            P.test_slow_ticks = ticks;
+        }
+    }
     {
         // checkpoint area: X, bestx [nl*nf]; chisq, best_chisq [nl]; numaccept,
         // best_iter [nl]; outbounds [nf] -- all 8-byte words
@@ -2912,9 +2923,10 @@ int mc3hip_debug_stamps(mc3hip_ctx *c, uint64_t *out16)
 }
 
 namespace {
-// "<library offset of the host stub> <device kernel name>" of an instance of this library: the
-// offset is what `nm libmc3hip.so` lists the stub under (the stubs are hidden symbols: dladdr
-// knows the library's base, not their names), the name is the runtime's
+// "<library offset of the handle> <device kernel name>" of an instance of this library: the
+// offset is what `nm libmc3hip.so` lists the handle under (what a launch is given is the
+// kernel's handle, a hidden data object of the kernel's name: dladdr knows the library's base,
+// not the object's name), the name is the runtime's
 static void ledger_label(const void *kernel, std::string *out)
 {
     char buf[64];
@@ -2929,7 +2941,7 @@ static void ledger_label(const void *kernel, std::string *out)
 }  // namespace
 
 /* The launch ledger as text, one line per kernel instance this PROCESS has launched:
- * "<launches> <of which with no MC3HIP_* switch set> <offset of the host stub in libmc3hip.so>
+ * "<launches> <of which with no MC3HIP_* switch set> <offset of the kernel's handle in libmc3hip.so>
  * <device kernel name> [<switch seen> ...]" (run-time specialisations: offset 0x0, name
  * "jit:<kernel>").  Writes at most cap - 1 bytes and a
  * terminating 0; *needed = bytes the whole text takes (with the 0). */

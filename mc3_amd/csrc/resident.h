@@ -153,6 +153,19 @@ struct ResidentOwner {
 // resident_async_kernel: the owner is a wave of its own -- nothing of the tile phase is its
 // business (what run_chain calls through its hook at that point only turns the parity over)
 struct ResidentOwnerAsync : ResidentOwner {
+    // (rs_gen << 32 | rounds of proposals published so far in this launch: DevProblem::rs_tag)
+    unsigned long long tag;
+    // the proposal row, and behind it the word that says which round's it is.  The word may
+    // overtake the row on its way: whoever reads it knows that the row's elements were reset
+    // before either left (publish() waits for the resets of collect() to land first), and an
+    // element that is not there yet says so itself.
+    __device__ __forceinline__ void publish(const DevProblem &P, int lc, const double *s_nextp)
+    {
+        ResidentOwner::publish(P, lc, s_nextp);
+        tag += 1;
+        if (lane == 0)
+            __hip_atomic_store(&P.rs_tag[lc], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __device__ __forceinline__ bool tile_phase(const DevProblem &, bool alive_in)
     {
         // (a wait that timed out, or the test hook, has told everybody: ctl[CTL_ABORT])
@@ -969,7 +982,6 @@ __device__ __forceinline__ void resident_scheduler(const DevProblem &P, const in
 {
     long long *ctl = const_cast<long long *>(P.ctl);
     const int lane = threadIdx.x & 63;
-    const size_t pstride = (size_t)P.nlocal * RS_ROW;
     unsigned long long *rows = P.rs_sched + (size_t)col * P.rs_sched_rows * 16;
     const unsigned long long gen = (unsigned long long)(unsigned)P.rs_gen << 32;
     unsigned spins = 0;
@@ -980,22 +992,22 @@ __device__ __forceinline__ void resident_scheduler(const DevProblem &P, const in
         int c0, n;
         C.chains(c0, n);
         const int l0 = (lane < n) ? lane : 0, l1 = (lane + 64 < n) ? lane + 64 : 0;
-        const double *prop = P.rs_prop + (size_t)(R & 1) * pstride;
+        // (the word a chain's owner leaves behind its proposal of this round: rs_tag)
+        const unsigned long long want = gen | (unsigned long long)(unsigned)(R + 1);
         // chains lane and lane + 64 of the column: still to do in this iteration
         bool rem0 = lane < n, rem1 = lane + 64 < n;
         bool r0 = false, r1 = false;        // ... and known to be there
         bool poll = true;
         int nrem = n;
         while (nrem > 0) {
-            // is the proposal there?  (element 0 of the row; a tile wave waits for the rest
-            // when it uses the row)  After a block: the next one at once, without asking
-            // again, if the chains already known to be there make one up.
+            // is the proposal of THIS round there?  (the owner's word for the chain; a tile wave
+            // waits for the row's elements when it uses the row)  After a block: the next one
+            // at once, without asking again, if the chains already known to be there make one up.
             if (poll) {
-                const double f0 = load_published(prop + (size_t)(c0 + l0) * RS_ROW);
-                const double f1 = (n > 64) ? load_published(prop + (size_t)(c0 + l1) * RS_ROW)
-                                           : mc3_from_bits(ROW_PENDING);
-                r0 = rem0 && mc3_bits(f0) != ROW_PENDING;
-                r1 = rem1 && mc3_bits(f1) != ROW_PENDING;
+                const unsigned long long f0 = load_sched(P.rs_tag + c0 + l0);
+                const unsigned long long f1 = (n > 64) ? load_sched(P.rs_tag + c0 + l1) : 0ull;
+                r0 = rem0 && f0 == want;
+                r1 = rem1 && f1 == want;
             }
             poll = true;
             const unsigned long long m0 = __builtin_amdgcn_ballot_w64(r0);
@@ -1092,9 +1104,17 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
     // anyway.  The sums are published AFTER the wait for the next block's rows: the wait is
     // for everything the wave has in flight (vmcnt(0)), and behind a store that is a round trip
     // for its acknowledgement.
+    // s_done [8] (behind s_prog): blocks whose row totals a wave has left in the slots so far.
+    // The slots of a chain are keyed by its place in the column and the round's parity, and
+    // the columns' chains change from round to round: a wave enters round R only when all
+    // eight have left R - 2's slots (nothing else keeps two waves of a workgroup less than two
+    // rounds apart) -- it looks at the scheduler's row again instead, as if nothing were there.
     __device__ __forceinline__ void run(const DevProblem &P, const int nref, double *s_part,
                                         unsigned *s_cnt, int *s_sel, int *s_prog)
     {
+        int *const s_done = s_prog + 8;
+        int fin = 0;                        // blocks whose totals this wave has left
+        int gate_old = 0, gate_new = 0;     // blocks up to the end of rounds R - 2, R - 1
         long long *ctl = const_cast<long long *>(P.ctl);
         const int lane = this->lane, j = lane & 15, g = lane >> 4;
         const int wv = this->wv, t = this->t;
@@ -1136,6 +1156,12 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
         auto take = [&](const unsigned long long ww) -> bool {
             if (!__all((unsigned)(ww >> 32) == gen))
                 return false;
+            if (nrem == n && R >= 2) {      // (a round's first block)
+                const int d = __hip_atomic_load(&s_done[lane & 7], __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (!__all(d >= gate_old))
+                    return false;
+            }
             nt = __builtin_amdgcn_readfirstlane((int)((unsigned)ww >> 8) & 0xff);
             const int id = (int)((unsigned)ww & 0xffu);
             int *const sel = sel2 + 16 * buf;
@@ -1179,6 +1205,8 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
             ++seq;
             nrem -= nt;
             if (nrem == 0) {
+                gate_old = gate_new;
+                gate_new = (int)seq;
                 if (R + 1 == nref) {
                     done = true;
                 } else {
@@ -1241,6 +1269,15 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
                 }
             };
             static_assert(RA_TAKE_AT < RA_TAKE_AGAIN && RA_TAKE_AGAIN < 16, "");
+            if (have && P.test_slow_ticks > 0 && (int)blockIdx.y == P.test_slow_col) {
+                // test hook: this column's tile waves are slow (core.h test_slow_col)
+                unsigned long long t0, t1;
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+                do {
+                    __builtin_amdgcn_s_sleep(8);
+                    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+                } while (t1 - t0 < (unsigned long long)P.test_slow_ticks);
+            }
             if (have) {
                 MC3_RTICK(tq0);
 #ifdef MC3HIP_TIMELINE
@@ -1337,6 +1374,10 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
+                ++fin;
+                if (lane == 0)
+                    __hip_atomic_store(&s_done[wv], fin, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifndef MC3HIP_RA_KEEP_PRIO            // (experiment: what the last take decided stays)
                 __builtin_amdgcn_s_setprio(1);
 #endif
@@ -1433,8 +1474,8 @@ __global__ __launch_bounds__(512 + 64 * (RA_OWNERS + 1)) void resident_async_ker
         T.load(P, blockIdx.x, blockIdx.y, chain_block, smem, s_stop, s_own + RA_OWNERS * OWN);
     if (threadIdx.x < 2 * RA_CNT)
         s_cnt[threadIdx.x] = 0u;
-    if (threadIdx.x < 8)
-        s_sel[32 * 8 + 16 + threadIdx.x] = 0;           // (the tile waves' progress)
+    if (threadIdx.x < 16)
+        s_sel[32 * 8 + 16 + threadIdx.x] = 0;           // (the tile waves' progress: s_prog, s_done)
     // a launch queued behind one that gave up must not run: its inputs are missing
     if (threadIdx.x == 0)
         *s_stop = (__hip_atomic_load(&P.ctl[CTL_ABORT], __ATOMIC_RELAXED,
@@ -1467,6 +1508,7 @@ __global__ __launch_bounds__(512 + 64 * (RA_OWNERS + 1)) void resident_async_ker
         O.lane = threadIdx.x & 63;
         O.par = 0;
         O.failed = false;
+        O.tag = (unsigned long long)(unsigned)P.rs_gen << 32;
         O.set_owner(P, own_chain, s_own + (wv - 8) * OWN);
         if constexpr (LEAN)
             lean_resident_owner<MT_LINEAR, P2P, ResidentOwnerAsync, true>(

@@ -277,11 +277,20 @@ class LockstepRun:
         (process start-up is not the chains' time: the reference's hub starts its workers
         once per run)."""
         import os
+        import signal
         import time
         if self._barrier is None:
             raise RuntimeError('run_processes needs LockstepRun(..., shared=True)')
+        # what ls_run_worker would refuse -- BEFORE anybody is forked: a worker that returns
+        # without attending the first meeting leaves the others (and the parent) waiting
+        ncpu, nrefresh = int(ncpu), int(nrefresh)
+        if ncpu < 1 or nrefresh < 0:
+            raise ValueError(f'run_processes: ncpu = {ncpu}, nrefresh = {nrefresh}')
+        if self.M0 + (int(self.S.refresh_done) + nrefresh)*self.nchains > self.zlen:
+            raise ValueError('run_processes: Z has no room for that many refreshes')
         self.L.ls_run_worker.restype = ctypes.c_int
         # two barriers: [0] the workers' meeting per refresh, [1] start / end with the parent
+        # (the fourth word of each: "called off", ls_barrier_abandon)
         self._barrier[:] = (0, 0, ncpu, 0, 0, 0, ncpu + 1, 0)
         bar = (ctypes.c_int32*8).from_buffer(self._barrier)
         pids = []
@@ -290,19 +299,57 @@ class LockstepRun:
             if pid == 0:
                 rc = 1
                 try:
+                    if os.environ.get('ORACLE_TEST_WORKER_DIES') == str(wid):
+                        os._exit(7)                    # (test hook: this worker never shows up)
                     rc = self.L.ls_run_worker(
                         ctypes.byref(self.P), ctypes.byref(self.S), ctypes.c_int64(nrefresh),
                         ctypes.c_int(wid), ctypes.c_int(ncpu), bar)
                 finally:
                     os._exit(0 if rc == 0 else 3)
             pids.append(pid)
+        workers = ctypes.cast(ctypes.addressof(bar), ctypes.POINTER(ctypes.c_int32))
         start_end = ctypes.cast(ctypes.addressof(bar) + 16, ctypes.POINTER(ctypes.c_int32))
         sense = ctypes.c_int(0)
-        self.L.ls_barrier_attend(start_end, ctypes.byref(sense))
+        status = {}
+
+        def attend():
+            """The parent's half of a start / end meeting, looking after the children while it
+            waits: one that is gone for another reason than success can never show up, so the
+            run is called off, the others are ended, and the caller hears of it."""
+            if self.L.ls_barrier_arrive(start_end, ctypes.byref(sense)):
+                return
+            while True:
+                for _ in range(2000):
+                    if self.L.ls_barrier_passed(start_end, sense) != 0:
+                        return
+                for p in pids:
+                    if p not in status:
+                        done, st = os.waitpid(p, os.WNOHANG)
+                        if done:
+                            status[p] = st
+                if any(st != 0 for st in status.values()):
+                    self.L.ls_barrier_abandon(workers)
+                    self.L.ls_barrier_abandon(start_end)
+                    deadline = time.time() + 5.0
+                    for p in pids:
+                        while p not in status:
+                            done, st = os.waitpid(p, os.WNOHANG)
+                            if done:
+                                status[p] = st
+                            elif time.time() > deadline:
+                                os.kill(p, signal.SIGKILL)
+                                status[p] = os.waitpid(p, 0)[1]
+                            else:
+                                time.sleep(0.01)
+                    raise RuntimeError(f'worker processes failed: '
+                                       f'{[status[p] for p in pids]}')
+                time.sleep(0.0005)
+
+        attend()
         t0 = time.perf_counter()
-        self.L.ls_barrier_attend(start_end, ctypes.byref(sense))
+        attend()
         dt = time.perf_counter() - t0
-        bad = [os.waitpid(p, 0)[1] for p in pids]
+        bad = [status[p] if p in status else os.waitpid(p, 0)[1] for p in pids]
         if any(bad):
             raise RuntimeError(f'worker processes failed: {bad}')
         self.S.refresh_done += nrefresh

@@ -844,24 +844,50 @@ typedef struct {
     int32_t count, sense, nworkers, pad;
 } ls_barrier;
 
-static void barrier_meet(ls_barrier *b, int *local_sense)
+/* 0 = everybody met; -1 = the meeting was called off (ls_barrier_abandon: a worker died or
+ * was never started, and the others must not spin for ever -- the `pad` word says so) */
+static int barrier_meet(ls_barrier *b, int *local_sense)
 {
     *local_sense = !*local_sense;
     if (__atomic_add_fetch(&b->count, 1, __ATOMIC_ACQ_REL) == b->nworkers) {
         __atomic_store_n(&b->count, 0, __ATOMIC_RELAXED);
         __atomic_store_n(&b->sense, *local_sense, __ATOMIC_RELEASE);
-        return;
+        return 0;
     }
     int spins = 0;
-    while (__atomic_load_n(&b->sense, __ATOMIC_ACQUIRE) != *local_sense)
+    while (__atomic_load_n(&b->sense, __ATOMIC_ACQUIRE) != *local_sense) {
+        if (__atomic_load_n(&b->pad, __ATOMIC_RELAXED) != 0)
+            return -1;
         if (++spins > 4096) {
             sched_yield();          /* (more workers than cores must not starve each other) */
             spins = 0;
         }
+    }
+    return 0;
 }
 
 /* (for the parent of the workers, which only keeps the time: start and end meeting) */
-void ls_barrier_attend(ls_barrier *b, int *local_sense) { barrier_meet(b, local_sense); }
+int ls_barrier_attend(ls_barrier *b, int *local_sense) { return barrier_meet(b, local_sense); }
+/* ... in two halves, so that the parent can look after its children while it waits: count
+ * oneself in (1 = that completed the meeting), then ask whether it is over (1), still on (0)
+ * or called off (-1) */
+int ls_barrier_arrive(ls_barrier *b, int *local_sense)
+{
+    *local_sense = !*local_sense;
+    if (__atomic_add_fetch(&b->count, 1, __ATOMIC_ACQ_REL) == b->nworkers) {
+        __atomic_store_n(&b->count, 0, __ATOMIC_RELAXED);
+        __atomic_store_n(&b->sense, *local_sense, __ATOMIC_RELEASE);
+        return 1;
+    }
+    return 0;
+}
+int ls_barrier_passed(ls_barrier *b, int local_sense)
+{
+    if (__atomic_load_n(&b->sense, __ATOMIC_ACQUIRE) == local_sense)
+        return 1;
+    return __atomic_load_n(&b->pad, __ATOMIC_RELAXED) != 0 ? -1 : 0;
+}
+void ls_barrier_abandon(ls_barrier *b) { __atomic_store_n(&b->pad, 1, __ATOMIC_RELEASE); }
 
 /* bar[0]: the workers' meeting per refresh (nworkers = ncpu); bar[1]: start and end of the
  * run, attended by the parent too (nworkers = ncpu + 1) */
@@ -882,8 +908,8 @@ int ls_run_worker(const ls_problem *P, ls_state *St, int64_t nrefresh, int wid, 
     for (int k = 0; k < nf; k++)
         S.normal[k] = 0.0;
     int sense = 0, sense_run = 0;
-    barrier_meet(&bar[1], &sense_run);                   /* everybody stands ready */
-    for (int64_t R = R0; R < R0 + nrefresh; R++) {
+    int called_off = barrier_meet(&bar[1], &sense_run);  /* everybody stands ready */
+    for (int64_t R = R0; R < R0 + nrefresh && !called_off; R++) {
         const int64_t Rs = R - 1 - (int64_t)P->zlag;
         const double *snap = (Rs < 0) ? St->snap0
                            : St->Z + (size_t)(P->M0 + Rs * P->nchains) * nf;
@@ -891,10 +917,13 @@ int ls_run_worker(const ls_problem *P, ls_state *St, int64_t nrefresh, int wid, 
         const int64_t row0 = P->M0 + R * P->nchains;
         for (int c = P->chain0 + wid; c < P->chain0 + P->nlocal; c += ncpu)   /* chain.py:190-191 */
             refresh_chain(P, St, &S, &D, c, R, R0, snap, zsize, row0, need_normal);
-        barrier_meet(&bar[0], &sense);                   /* mcmc_driver.py:300-307 */
+        called_off = barrier_meet(&bar[0], &sense);      /* mcmc_driver.py:300-307 */
     }
-    barrier_meet(&bar[1], &sense_run);                   /* everybody is done */
+    if (!called_off)
+        called_off = barrier_meet(&bar[1], &sense_run);  /* everybody is done */
     scratch_free(&S);
+    if (called_off)
+        return -2;                  /* (another worker is gone: the parent called the run off) */
     St->refresh_done = R0 + nrefresh;
     return 0;
 }

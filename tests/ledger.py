@@ -1,7 +1,7 @@
 """The test suite's side of the library's launch ledger (include/mc3hip.h
 mc3hip_debug_launch_counts): every process of a test session -- pytest itself and the rank /
 worker scripts it starts -- leaves its ledger in $MC3HIP_LEDGER_DIR when it ends; the sum, set
-against the kernel instances libmc3hip.so carries (the `__device_stub__` symbols `nm` lists),
+against the kernel instances libmc3hip.so carries (their handles, as `nm` lists them),
 is the instance-coverage report of tests/test_zz_instance_coverage.py."""
 import atexit
 import os
@@ -68,23 +68,27 @@ def collected():
     return total
 
 
-_STUB = re.compile(r'__device_stub__')
-
-
 def instances(lib_path=None):
-    """{stub offset: demangled kernel instance} of every kernel libmc3hip.so carries."""
+    """{handle offset: demangled kernel instance} of every kernel libmc3hip.so carries.  What the
+    host passes to a launch is the kernel's HANDLE -- a data object of the kernel's own name --
+    and the ledger records its offset; the host stub of the same instance
+    (`__device_stub__<name>`) is a function beside it.  An instance = a name that has both."""
     from mc3_amd import _lib
     lib_path = lib_path or _lib.LIB_PATH
     out = subprocess.run(['nm', '-C', '--defined-only', lib_path], capture_output=True,
                          text=True, check=True).stdout
-    found = {}
+    stubs, handles = set(), {}
     for line in out.splitlines():
         parts = line.split(' ', 2)
-        if len(parts) == 3 and _STUB.search(parts[2]):
-            name = parts[2].replace('mc3hip::__device_stub__', 'mc3hip::')
-            name = name.replace('__device_stub__', '')
-            found[int(parts[0], 16)] = name
-    return found
+        if len(parts) != 3:
+            continue
+        addr, kind, name = parts
+        if '__device_stub__' in name:
+            stubs.add(name.replace('mc3hip::__device_stub__', 'mc3hip::')
+                      .replace('__device_stub__', ''))
+        elif kind in 'VvDdBbRr':
+            handles[name] = int(addr, 16)
+    return {handles[name]: name for name in stubs if name in handles}
 
 
 def family(name):
@@ -132,6 +136,12 @@ def report(total=None):
     for name in never:
         lines.append(f'  {name}')
     lines.append('')
+    stray = sorted((k, v) for k, v in total.items() if not isinstance(k, str) and k not in inst)
+    if stray:
+        lines.append(f'ledger rows that match no instance of the library: {len(stray)}')
+        for k, v in stray:
+            lines.append(f'  {v[0]:8d}  {hex(k)}  {v[2]}')
+        lines.append('')
     lines.append('launches per instance:')
     for off, name in sorted(inst.items(), key=lambda kv: kv[1]):
         if off in total:

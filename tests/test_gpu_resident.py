@@ -627,3 +627,24 @@ def test_resident_async_general_owner_bit_exact(eng, kw):
         assert gpu.plan['recoveries'] == 1
         assert_same(orc, gpu, trace=False)
         gpu.close()
+
+
+@pytest.mark.parametrize('sampler,slow', [('mrw', '0:400'), ('snooker', '1:400'),
+                                          ('demc', '2:300'), ('mrw', '2:1500')])
+def test_resident_async_columns_drift_apart(eng, sampler, slow):
+    """One column's tile waves held back before every block (test hook MC3HIP_TEST_SLOW_COLUMN =
+    column:ticks of the 100 MHz clock): with the random walk and the snooker update no chain
+    waits for another, so the other columns run ahead as far as the hand-off lets them -- and
+    the columns' chains change from round to round (112 chains = 7 blocks for 4 columns: three
+    of them carry a block more, in turns), so a chain enters a column that is rounds ahead of the
+    one it leaves.  A proposal row is taken for a round only with its owner's word that it IS
+    that round's (DevProblem::rs_tag), and a wave enters a round only when its workgroup has
+    left the slots of the round before last: 300 rounds, every row as the oracle's."""
+    prob = linear(ndata=20000, nmodel=7, nchains=112, niter=300, sampler=sampler)
+    with env(MC3HIP_RS_ASYNC=1, MC3HIP_RESIDENT_MAXCOL=4, MC3HIP_TEST_SLOW_COLUMN=slow):
+        orc, gpu = run_pair(eng, prob, trace=False)
+        plan = gpu.plan
+        assert plan['resident'] == 1 and plan['owner_waves'] >= 1 and plan['recoveries'] == 0, plan
+        assert 'resident_async_kernel' in gpu.last_kernel
+        assert_same(orc, gpu, trace=False)
+        gpu.close()

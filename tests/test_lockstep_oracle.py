@@ -215,3 +215,25 @@ def test_worker_processes_equal_threads(sampler, thinning):
             np.testing.assert_array_equal(getattr(orc, key), getattr(ref, key), err_msg=key)
     with pytest.raises(RuntimeError, match='shared=True'):
         H.make_oracle(prob).run_processes(1, 2)
+
+
+def test_worker_processes_that_fail_end_the_run(monkeypatch):
+    """A worker that never reaches the first meeting (test hook), or arguments the workers
+    would refuse: the parent neither spins for ever nor leaves workers behind -- it calls the
+    meetings off, ends the others and raises."""
+    import time
+    prob = H.quad_problem(nchains=8, nsamples=8*40, sampler='demc')
+    orc = H.make_oracle(prob, shared=True)
+    Z0, lp0 = H.initial_population(orc)
+    orc.set_population(Z0, lp0)
+    with pytest.raises(ValueError, match='no room'):
+        orc.run_processes(orc.nzchain + 1, 2)
+    with pytest.raises(ValueError, match='ncpu'):
+        orc.run_processes(1, 0)
+    monkeypatch.setenv('ORACLE_TEST_WORKER_DIES', '1')
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match='worker processes failed'):
+        orc.run_processes(10, 3)
+    assert time.time() - t0 < 30.0
+    monkeypatch.delenv('ORACLE_TEST_WORKER_DIES')
+    assert orc.run_processes(10, 3) > 0.0          # and the run can go on afterwards
