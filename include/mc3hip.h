@@ -57,12 +57,18 @@ extern "C" {
                                       device, a test set-up: the two-wave workgroups of all
                                       of them would not be co-resident)                    */
 
-#define MC3HIP_FLAG_NO_JIT     16u /* the caller will not specialise anything at run time (it has
-                                      no compiler, or was told not to): shapes are planned
-                                      without the loops mc3hip_jit_request would name -- where
-                                      that changes the data layout (8 193 ... 16 384 points: the
-                                      tiled plan instead of tiles in the registers of eight
-                                      waves) the choice is made at creation                 */
+#define MC3HIP_FLAG_NO_JIT     16u /* (rounds 4-5: "the caller will not specialise"; since round 6
+                                      that is the DEFAULT and this bit is ignored)          */
+#define MC3HIP_FLAG_JIT        32u /* the caller WILL specialise at run time: it asks
+                                      mc3hip_jit_request for the loop to compile and hands the
+                                      code object to mc3hip_jit_install before the first
+                                      mc3hip_run.  Only with this bit is a shape planned FOR such
+                                      a loop where that changes the data layout (2 049 ... 16 384
+                                      points with fixed / shared coefficients, priors, the random
+                                      walk, design matrices: tiles in the registers of four or
+                                      eight waves instead of the tiled plan) -- a caller with
+                                      flags = 0, or one whose compiler failed, gets the plan the
+                                      library serves with its own instances                  */
 
 #define MC3HIP_MAX_FREE     64
 #define MC3HIP_MAX_PARAMS  128

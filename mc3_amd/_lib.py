@@ -26,6 +26,7 @@ FLAG_NO_PERSIST = 2
 FLAG_P2P = 4
 FLAG_NO_COURIER = 8
 FLAG_NO_JIT = 16
+FLAG_JIT = 32
 MAX_FREE, MAX_PARAMS = 64, 128
 
 SAMPLERS = {'mrw': MRW, 'demc': DEMC, 'snooker': SNOOKER}

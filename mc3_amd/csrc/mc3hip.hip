@@ -1117,7 +1117,7 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
                                    !getenv("MC3HIP_NO_WIDE") && !getenv("MC3HIP_NO_LEAN") &&
                                    !getenv("MC3HIP_NO_FAST") && !getenv("MC3HIP_NO_PERSIST") &&
                                    !getenv("MC3HIP_NO_JIT") && !getenv("MC3HIP_WPC") &&
-                                   !(pr->flags & MC3HIP_FLAG_NO_JIT);
+                                   (pr->flags & MC3HIP_FLAG_JIT);
             c->wide_jit_tiles = 0;
             c->wide_jit_waves = 0;
             if (c->wide_tiles == 0 && shape_jit && tiles >= 2 && tiles <= 16) {

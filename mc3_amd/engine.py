@@ -8,6 +8,7 @@ mirrors the attributes ``update_output`` reads from a Chain
 (mc3/stats/stats.py:813-871).
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -91,14 +92,16 @@ class DeviceChains:
         P.model_kind = {'poly': _lib.MODEL_POLY, 'linear': _lib.MODEL_LINEAR}[model]
         P.nmodel = self.nmodel
         P.thinning = self.thinning
-        # (no run-time specialisation -- switched off, or no compiler at hand: the library plans
-        # without it, include/mc3hip.h MC3HIP_FLAG_NO_JIT)
+        # (run-time specialisation is something the caller promises, include/mc3hip.h
+        # MC3HIP_FLAG_JIT: only with a compiler at hand and not switched off -- otherwise the
+        # library plans with its own instances)
         from . import jit as _jit
-        self._jit = bool(jit) and not no_persist and _jit.available()
-        P.flags = (_lib.FLAG_NO_GRAPH if no_graph else 0) | \
+        self._jit = bool(jit) and not no_persist and _jit.available() and \
+            not os.environ.get('MC3HIP_NO_JIT')
+        base_flags = (_lib.FLAG_NO_GRAPH if no_graph else 0) | \
             (_lib.FLAG_NO_PERSIST if no_persist else 0) | \
-            (_lib.FLAG_P2P if p2p else 0) | (_lib.FLAG_NO_COURIER if no_courier else 0) | \
-            (0 if self._jit else _lib.FLAG_NO_JIT)
+            (_lib.FLAG_P2P if p2p else 0) | (_lib.FLAG_NO_COURIER if no_courier else 0)
+        P.flags = base_flags | (_lib.FLAG_JIT if self._jit else 0)
         self.no_courier = bool(no_courier)
         P.trace_iters = int(trace_iters)
         P.M0, P.zlen = self.M0, self.zlen
@@ -121,6 +124,17 @@ class DeviceChains:
         self.jit_served = ''
         if self._jit:
             self.jit_served = _jit.specialise(self)
+            if not self.jit_served and self.jit_request():
+                # the promise could not be kept (the compiler failed, or the audit refused the
+                # code object): the context was planned FOR the specialised loop -- make it
+                # again without the promise, so that the library's own plan runs the shape
+                self.lib.mc3hip_destroy(self._ctx)
+                self._ctx = None
+                self._jit = False
+                P.flags = base_flags
+                ctx = ctypes.c_void_p()
+                check(self.lib.mc3hip_create(ctypes.byref(P), ctypes.byref(ctx)))
+                self._ctx = ctx
 
     @property
     def plan(self):

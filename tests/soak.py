@@ -72,6 +72,6 @@ same = (np.array_equal(Z, orc.Z) and np.array_equal(lp, orc.log_post)
 niter *= thin
 print(f'{sampler} {extras}: {niter} iterations x {nchains} chains x {len(prob["data"])} points: GPU {tg:.2f} s '
       f'({nchains*niter/tg/1e6:.1f} M/s, '
-      f'plan {gpu.plan}), oracle {to:.1f} s on {nthreads} threads; identical: {same}; '
+      f'plan {gpu.plan}, kernel {gpu.last_kernel}), oracle {to:.1f} s on {nthreads} threads; identical: {same}; '
       f'accepted {int(st["numaccept"].sum())}')
 sys.exit(0 if same else 1)

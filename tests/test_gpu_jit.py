@@ -269,3 +269,40 @@ def test_more_chains_than_the_specialised_loop_holds_take_turns_on_the_general_c
     assert plan['persistent'] > 0 and plan['chains_per_workgroup'] > 1 and plan['jit'] == 0, plan
     assert_same(orc, gpu, trace=False)
     gpu.close()
+
+
+def test_a_plan_that_depends_on_the_specialisation_needs_the_callers_promise(eng, monkeypatch):
+    """16 384 points, a quadratic with Gaussian priors, 64 chains: with the promise to specialise (MC3HIP_FLAG_JIT,
+    what DeviceChains passes when a compiler is at hand) the library plans tiles in the
+    registers of eight waves per chain; a caller that does not promise (flags = 0: jit=False) --
+    or whose compiler fails -- gets the plan the library serves with its own instances (the
+    one-launch tiled plan), not the general chain behind a layout made for a loop that never
+    came.  All three runs give the oracle's rows."""
+    from mc3_amd import jit
+    prob = quad_wide(16384, nchains=64, nref=12, priors=True)
+    orc, gpu = run_pair(eng, prob, trace=False)
+    served = gpu.plan
+    assert served['jit'] == 1 and served['tile'] == 0, served
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+    with eng.DeviceChains(jit=False, **prob) as gpu:
+        plain = gpu.plan
+        assert plain['jit'] == 0 and plain['tile'] == 4096, plain
+        orc2 = H.make_oracle(prob, plan=plain)
+        Z0, lp0 = H.initial_population(orc2)
+        orc2.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc2.run(nthreads=4)
+        gpu.run()
+        assert gpu.plan['resident'] == 1, gpu.plan
+        assert_same(orc2, gpu, trace=False)
+
+    def broken(request, verbose=False):
+        raise RuntimeError('no compiler today')
+    monkeypatch.setattr(jit, 'code_object', broken)
+    with eng.DeviceChains(**prob) as gpu:
+        assert not gpu.jit_served
+        assert gpu.plan['jit'] == 0 and gpu.plan['tile'] == 4096, gpu.plan
+        gpu.set_population(Z0, lp0)
+        gpu.run()
+        assert_same(orc2, gpu, trace=False)
