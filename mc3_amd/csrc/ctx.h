@@ -59,8 +59,6 @@ struct mc3hip_ctx {
     // wavelet likelihood, one wave per chain (<= 2048 points), the shapes of cw_lean_eligible,
     // the one-wave wavelet chains written out by hand: kernels_wavelet.h wavelet_one_kernel
     bool wl_one = false;
-    int lean_waves_default = 1;     // waves per chain of the hand-laid-out DEMC loop (ctx.h
-                                    // lean_waves), decided with the grid in decide_persist
     int mc_chains = 0;              // chains a workgroup of the persistent kernel advances per
                                     // refresh (0: one workgroup per chain), its grid and the
     int mc_grid = 0;                // dynamic LDS with the chains' waiting state appended
@@ -121,6 +119,24 @@ typedef void (*resident_kernel_fn)(const DevProblem, const int, const int);
 
 constexpr int WL_EVAL_BLOCKS = 256;
 
+// ---- the environment, read in ONE place ------------------------------------------------------
+// Every variable the library looks at goes through env_text().  The RELEASE library knows the
+// variables DESIGN.md section 8a documents: sizes (MC3HIP_PERSIST_REFS, _PERSIST_CAPACITY,
+// _RESIDENT_MAXCOL, _GRAPH_NODES), the test hooks (MC3HIP_TEST_*), and switches that send a
+// shape down a path the library ALSO takes by itself for other shapes (the general chain
+// instead of a hand-laid-out loop, the three-launch tiled plan instead of the resident one, the
+// kernel in step instead of resident_async_kernel, ...) -- what the tests use to reach those
+// paths with small problems.  The A/B switches of experiments (priorities, superseded kernel
+// flavours, forced wave counts) exist only in a development build (-DMC3HIP_DEV, python -m
+// mc3_amd.build --dev): in the release library dev_env_text() is a constant and the code behind
+// such a switch is not compiled.
+inline const char *env_text(const char *name) { return getenv(name); }
+#ifdef MC3HIP_DEV
+inline const char *dev_env_text(const char *name) { return env_text(name); }
+#else
+constexpr const char *dev_env_text(const char *) { return nullptr; }
+#endif
+
 // ---- launch ledger (mc3hip.hip): how often every kernel instance of the library was launched
 // by this process, by the address of the kernel's handle -- mc3hip_debug_launch_counts reads it, the test suite's
 // instance-coverage report (tests/test_zz_instance_coverage.py) is made from it.  A launch is
@@ -161,7 +177,7 @@ inline bool rs_lean_eligible(const mc3hip_ctx *c)
 }
 inline bool resident_owner_lean(const mc3hip_ctx *c)
 {
-    return rs_lean_eligible(c) && !getenv("MC3HIP_NO_RS_LEAN");
+    return rs_lean_eligible(c) && !env_text("MC3HIP_NO_RS_LEAN");
 }
 // ... and the shapes resident_async_kernel takes (the grid permitting: decide_persist): design
 // matrices through the matrix cores -- any sampler, thinning, shared parameters (the owners
@@ -170,7 +186,7 @@ inline bool resident_async_shape(const mc3hip_ctx *c)
 {
     // (four blocks of operand rows beside the general chain: an operand spilled and reloaded at
     // the head of every block -- the kernel in step serves those)
-    return c->mt == MT_LINEAR && c->P.tile == 2048 && !getenv("MC3HIP_NO_RS_ASYNC") &&
+    return c->mt == MT_LINEAR && c->P.tile == 2048 && !env_text("MC3HIP_NO_RS_ASYNC") &&
            (resident_owner_lean(c) || (c->P.nmodel + 4) / 4 <= 3);
 }
 inline bool chainwave_runs(const mc3hip_ctx *c, bool p2p)
@@ -182,8 +198,7 @@ inline bool chainwave_runs(const mc3hip_ctx *c, bool p2p)
 // tail (kernels_wavelet.h wavelet_pipe_kernel); same LDS as the nine-wave kernel
 inline bool chainwave_pipe(const mc3hip_ctx *c, bool p2p)
 {
-    return chainwave_runs(c, p2p) && c->mc_chains > 0 && c->P.sampler != MC3HIP_DEMC &&
-           !getenv("MC3HIP_NO_CW_PIPE");
+    return chainwave_runs(c, p2p) && c->mc_chains > 0 && c->P.sampler != MC3HIP_DEMC;
 }
 inline int chainwave_threads(const mc3hip_ctx *c, bool p2p)
 {
@@ -208,7 +223,7 @@ inline bool tile_uses_mfma(const mc3hip_ctx *c)
 {
     // (2..15 coefficients: with the data as one more operand row, at most four blocks of four)
     return c->mt == MT_LINEAR && c->P.tile == 2048 && c->P.nmodel >= 2 && c->P.nmodel <= 15 &&
-           c->P.aw != nullptr && !getenv("MC3HIP_NO_MFMA");
+           c->P.aw != nullptr;
 }
 
 // resident tiled plan: design-matrix models through the matrix cores, or polynomials of
@@ -229,7 +244,7 @@ inline bool lag_demc_shape(const mc3hip_ctx *c)
     // (... and of the strict lockstep with thinning > 1, zlag = 0: only the first iteration of
     // a refresh then asks for rows that are just being published and waits for them)
     return (P.zlag > 0 || P.thinning > 1) && P.sampler == MC3HIP_DEMC && P.npad <= VLANES &&
-           P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
+           P.zs == ZROW && !env_text("MC3HIP_NO_LEAN");
 }
 
 // The model tag a run-time specialisation of the one-wave loops would be compiled for, or 0:
@@ -243,7 +258,7 @@ inline int jit_model_tag(const mc3hip_ctx *c)
     if (P.wlike || P.trace_iters != 0 || P.tile > 0 ||
         (c->flags & MC3HIP_FLAG_P2P) || c->p2p_ranks > 1 || c->comm != nullptr ||
         P.zs != ZROW || P.nmodel != P.nparams || P.nfree < 1 ||
-        getenv("MC3HIP_NO_LEAN") || getenv("MC3HIP_NO_FAST"))
+        env_text("MC3HIP_NO_LEAN") || dev_env_text("MC3HIP_NO_FAST"))
         return 0;
     // more than 1024 points: polynomials of 2..4 coefficients, the tiles in the registers of
     // four waves (the shapes lean_demc_wide_kernel / lean_snooker_wide_kernel do not carry)
@@ -324,7 +339,7 @@ inline int jit_waves(const mc3hip_ctx *c)
     if (tag < MT_LINK0 || (P.sampler == MC3HIP_MRW && tag - MT_LINK0 <= 10) ||
         (P.sampler == MC3HIP_DEMC && (P.thinning > 1 || P.zlag > 0)))
         return 1;
-    if (const char *e = getenv("MC3HIP_JIT_WAVES")) {
+    if (const char *e = dev_env_text("MC3HIP_JIT_WAVES")) {
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4)
             return v;
@@ -355,7 +370,7 @@ inline bool fast_eligible(const mc3hip_ctx *c)
     // instances have no FX x P2P flavour)
     const bool p2p_flag = (c->flags & MC3HIP_FLAG_P2P) != 0;
     const bool lean_p2p_other = (P.sampler == MC3HIP_SNOOKER || P.sampler == MC3HIP_MRW) &&
-                                P.npad <= VLANES && P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
+                                P.npad <= VLANES && P.zs == ZROW && !env_text("MC3HIP_NO_LEAN");
     const bool fx_ok = P.nfree >= 1 &&
                        ((P.thinning == 1 && (!p2p_flag || lean_p2p_other)) || lag_demc_shape(c));
     // more than one 1024-point tile (streamed): plain problems, one GPU, thinning = 1
@@ -366,15 +381,15 @@ inline bool fast_eligible(const mc3hip_ctx *c)
     // ... and so has the snooker loop, for up to four free parameters (two Philox slots)
     const bool eps_ok = P.fepsilon == 0.0 || P.sampler == MC3HIP_MRW ||   // (chain.py:219-220)
                         (P.sampler == MC3HIP_DEMC && P.thinning == 1 && P.zlag == 0 && !p2p_flag &&
-                         P.nfree <= 4 && !multi && P.zs == ZROW && !getenv("MC3HIP_NO_LEAN")) ||
+                         P.nfree <= 4 && !multi && P.zs == ZROW && !env_text("MC3HIP_NO_LEAN")) ||
                         (P.sampler == MC3HIP_SNOOKER && P.thinning == 1 && P.nfree <= 4 &&
-                         !p2p_flag && !multi && P.zs == ZROW && !getenv("MC3HIP_NO_LEAN"));
+                         !p2p_flag && !multi && P.zs == ZROW && !env_text("MC3HIP_NO_LEAN"));
     return (c->wpc == 1 || wide_tiles(c) > 0) && !P.wlike && size_ok && c->mt >= 2 && c->mt <= 4 &&
            (plain || fx_ok) && P.nmodel == P.nparams &&
            eps_ok && P.trace_iters == 0 &&
            (P.sampler == MC3HIP_DEMC || P.sampler == MC3HIP_SNOOKER ||
             P.sampler == MC3HIP_MRW) &&
-           !getenv("MC3HIP_NO_FAST");
+           !env_text("MC3HIP_NO_LEAN");         // (the switch: the general chain for everything)
 }
 
 inline bool lean_rows_shape(const mc3hip_ctx *c);
@@ -396,7 +411,7 @@ inline bool lean_one_chain_only(const mc3hip_ctx *c)
 inline bool lean_demc_eligible(const mc3hip_ctx *c)
 {
     return c->fast && c->mc_chains == 0 && c->P.sampler == MC3HIP_DEMC && c->P.thinning == 1 &&
-           c->P.zlag == 0 && c->P.nparams == c->mt && c->P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
+           c->P.zlag == 0 && c->P.nparams == c->mt && c->P.zs == ZROW && !env_text("MC3HIP_NO_LEAN");
 }
 // ... and so has the declared multi-GPU cadence: lean_demc_lag_kernel
 inline bool lean_demc_lag_eligible(const mc3hip_ctx *c)
@@ -412,12 +427,11 @@ inline bool lean_snooker_eligible(const mc3hip_ctx *c);
 inline bool lean_mrw_eligible(const mc3hip_ctx *c);
 inline bool lean_courier(const mc3hip_ctx *c, bool p2p)
 {
-    if (!p2p)       // (one GPU: an experiment, MC3HIP_LEAN_COURIER=1; measured slower)
-        return getenv("MC3HIP_LEAN_COURIER") && lean_demc_eligible(c) && lean_plain_shape(c) &&
-               c->P.npad <= VLANES && !(c->flags & MC3HIP_FLAG_P2P) && c->P.nlocal <= 1024;
+    if (!p2p)       // (one GPU: a courier wave was measured slower -- docs/HISTORY.md, round 3)
+        return false;
     return (lean_demc_eligible(c) || lean_demc_lag_eligible(c) || lean_snooker_eligible(c) ||
             lean_mrw_eligible(c)) &&
-           !(c->flags & MC3HIP_FLAG_NO_COURIER) && !getenv("MC3HIP_NO_COURIER");
+           !(c->flags & MC3HIP_FLAG_NO_COURIER) && !env_text("MC3HIP_NO_COURIER");
 }
 
 // the headline loop with the draws of 64 refreshes computed at once (lean_demc_kernel BATCH):
@@ -425,7 +439,7 @@ inline bool lean_courier(const mc3hip_ctx *c, bool p2p)
 // bound by the instructions it issues, below that by the hand-off (MC3HIP_LEAN_BATCH=0|1 forces)
 inline bool lean_batch(const mc3hip_ctx *c)
 {
-    if (const char *e = getenv("MC3HIP_LEAN_BATCH"))
+    if (const char *e = env_text("MC3HIP_LEAN_BATCH"))
         return atoi(e) != 0;
     return c->P.nlocal > 1024;
 }
@@ -449,7 +463,7 @@ inline bool lean_other_sampler_eligible(const mc3hip_ctx *c, int sampler)
     return c->fast && c->mc_chains == 0 && P.sampler == sampler &&
            (P.thinning == 1 || plain) &&
            (P.npad <= VLANES || (plain && P.thinning == 1 && !p2p)) &&
-           P.nparams == c->mt && P.zs == ZROW && !getenv("MC3HIP_NO_LEAN");
+           P.nparams == c->mt && P.zs == ZROW && !env_text("MC3HIP_NO_LEAN");
 }
 inline bool lean_snooker_eligible(const mc3hip_ctx *c)
 {
@@ -470,7 +484,7 @@ inline bool lean_demc_mc_eligible(const mc3hip_ctx *c)
            P.nfree == P.nparams && P.ngprior == 0 && P.nshare == 0 &&
            P.sampler == MC3HIP_DEMC && P.thinning == 1 && P.zlag == 0 &&
            P.nparams == c->mt && P.zs == ZROW && !(c->flags & MC3HIP_FLAG_P2P) &&
-           c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_LEAN");
+           c->p2p_ranks <= 1 && !env_text("MC3HIP_NO_LEAN");
 }
 
 // ... and, for the one-tile shapes of those, with the
@@ -483,7 +497,7 @@ inline bool lean_rows_shape(const mc3hip_ctx *c)
     const DevProblem &P = c->P;
     return P.thinning == 1 && P.nparams == c->mt && c->mt >= 2 && c->mt <= 4 && P.zs == ZROW &&
            P.npad <= VLANES && P.nfree >= 1 && (P.fepsilon == 0.0 || P.sampler == MC3HIP_MRW) &&
-           !getenv("MC3HIP_NO_LEAN") && !getenv("MC3HIP_NO_ROWS");
+           !env_text("MC3HIP_NO_LEAN");
 }
 inline bool lean_rows_eligible(const mc3hip_ctx *c)
 {
@@ -491,10 +505,9 @@ inline bool lean_rows_eligible(const mc3hip_ctx *c)
     return c->fast && c->mc_chains >= 2 && c->mc_chains <= 4 && lean_rows_shape(c);
 }
 
-// waves that share the data sum of a chain in the hand-laid-out DEMC loop (kernels_lean.h
-// lean_demc_wide_kernel): 1, 2 or 4.  Several only for the plain headline shape -- every
-// coefficient free, one tile, one GPU -- and only on request (MC3HIP_LEAN_WAVES=2|4): measured
-// slower than one wave (mc3hip.hip decide_persist).
+// waves that share the data sum of a chain in the hand-laid-out loops: four (eight) where the
+// tiles of more than 1024 points sit in their registers (kernels_lean.h lean_demc_wide_kernel,
+// lean_snooker_wide_kernel), one otherwise
 inline int wide_tiles(const mc3hip_ctx *c)
 {
     return (c->wide_tiles > 0 && !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 &&
@@ -507,16 +520,10 @@ inline int lean_waves(const mc3hip_ctx *c)
     if (const int nt = wide_tiles(c))
         if (c->fast)
             return nt > 8 ? 8 : 4;
-    const bool plain = P.nparams == P.nfree && P.ngprior == 0 && P.nshare == 0 &&
-                       P.npad <= VLANES && !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1;
-    if (!lean_demc_eligible(c) || !plain)
-        return 1;
-    if (const char *e = getenv("MC3HIP_LEAN_WAVES")) {
-        const int v = atoi(e);
-        if (v == 1 || v == 2 || v == 4)
-            return v;
-    }
-    return c->lean_waves_default;
+    // (helper waves for the ONE-tile headline loop -- two / four waves sharing a chain's data sum
+    // -- were measured slower than one at every ensemble size, profiles/r03_lean_waves.jsonl,
+    // and went with round 6)
+    return 1;
 }
 
 // ---- k_general_w{1,4,16}.hip: one workgroup per chain, Gaussian chisq, by waves per chain ---

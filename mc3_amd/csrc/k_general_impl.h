@@ -16,15 +16,20 @@ namespace {
 
 constexpr int WPC = MC3_WPC;
 
+// (four waves per chain are chosen for more than 4 096 points only -- mc3hip.hip choose_wpc --
+// so their instances are the several-tile ones)
+constexpr bool ONE_TILE = WPC == 1;
+
 template <int MT>
 void launch_step_t(mc3hip_ctx *c, int roff)
 {
-    if (c->P.npad > VLANES)
+    if (!ONE_TILE || c->P.npad > VLANES) {
         MC3_LAUNCH_CHAIN(c, (step_kernel<WPC, MT, false, true>), dim3(c->P.nlocal), dim3(64 * WPC),
                            c->smem, c->stream, c->P, roff);
-    else
+    } else if constexpr (ONE_TILE) {
         MC3_LAUNCH_CHAIN(c, (step_kernel<WPC, MT, false, false>), dim3(c->P.nlocal),
                            dim3(64 * WPC), c->smem, c->stream, c->P, roff);
+    }
 }
 
 // the exact instance (tile count, peer-to-peer stores) that will be launched
@@ -32,14 +37,15 @@ template <int MT>
 void persist_instance_t(const mc3hip_ctx *c, bool p2p, chain_kernel_fn *out)
 {
     const bool mc = c->mc_chains > 0 && !p2p;          // several chains per workgroup
-    if (c->P.npad > VLANES)
+    if (!ONE_TILE || c->P.npad > VLANES) {
         *out = p2p ? persist_kernel<WPC, MT, false, true, true>
                    : mc ? persist_kernel<WPC, MT, false, true, false, true>
                         : persist_kernel<WPC, MT, false, true>;
-    else
+    } else if constexpr (ONE_TILE) {
         *out = p2p ? persist_kernel<WPC, MT, false, false, true>
                    : mc ? persist_kernel<WPC, MT, false, false, false, true>
                         : persist_kernel<WPC, MT, false, false>;
+    }
 }
 
 template <int MT>

@@ -8,7 +8,10 @@ namespace mc3hip {
 namespace host {
 namespace {
 
-// the same choices with several chains per wave (c->mc_chains > 0; one GPU)
+// Several chains per wave taking TURNS (run_chain MC; one GPU): what is left to the lean
+// instances of run_chain since the hand-laid-out loops took over the one-chain-per-wave shapes
+// (round 3) and two to four chains side by side (kernels_rows.h, round 4) -- ensembles of more
+// than four chains per wave, thinned or streamed-tile shapes with more chains than waves.
 template <int MT, int SMP>
 chain_kernel_fn fast_instance_mc(const mc3hip_ctx *c)
 {
@@ -23,17 +26,9 @@ chain_kernel_fn fast_instance_mc(const mc3hip_ctx *c)
 template <int MT, int SMP>
 chain_kernel_fn fast_instance_tt(const mc3hip_ctx *c, bool p2p)
 {
-    if (c->mc_chains > 0 && !p2p)
-        return fast_instance_mc<MT, SMP>(c);
-    if (p2p)
-        return c->P.thinning == 1 ? persist_fast_kernel<MT, SMP, true, 1>
-                                  : persist_fast_kernel<MT, SMP, true, 0>;
-    if (c->P.npad > VLANES)                        // streamed tiles (plain, thinning = 1 only)
-        return persist_fast_kernel<MT, SMP, false, 1, false, true>;
-    if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)   // FX
-        return persist_fast_kernel<MT, SMP, false, 1, true>;
-    return c->P.thinning == 1 ? persist_fast_kernel<MT, SMP, false, 1>
-                              : persist_fast_kernel<MT, SMP, false, 0>;
+    // (one chain per wave, or peer to peer: a hand-laid-out loop serves every shape
+    // fast_eligible lets through -- nothing here)
+    return (c->mc_chains > 0 && !p2p) ? fast_instance_mc<MT, SMP>(c) : nullptr;
 }
 
 template <int MT>
@@ -65,8 +60,6 @@ chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
             return lean_demc_kernel<MT, false, false, true>;
         if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)
             return lean_demc_kernel<MT, false, true>;
-        if (lean_courier(c, false))
-            return lean_demc_kernel<MT, false, false, false, false, true>;
         if (lean_batch(c))
             return lean_demc_kernel<MT, false, false, false, true>;
         return lean_demc_kernel<MT, false>;

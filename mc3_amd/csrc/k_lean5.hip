@@ -28,14 +28,6 @@ chain_kernel_fn lean_demc_mc_instance_t(const mc3hip_ctx *c, bool p2p)
             return lean_demc_mc_kernel<MT, 2, false, true>;
         return lean_demc_mc_kernel<MT, 3, false, true>;
     }
-    // (helper waves share a chain's data sum: the plain one-GPU headline shape, on request)
-    if (!p2p && lean_demc_eligible(c) && c->P.fepsilon == 0.0 && c->P.npad <= VLANES &&
-        lean_plain_shape(c) && !lean_courier(c, false)) {
-        if (lean_waves(c) == 4)
-            return lean_demc_wide_kernel<MT, 4>;
-        if (lean_waves(c) == 2)
-            return lean_demc_wide_kernel<MT, 2>;
-    }
     return nullptr;
 }
 

@@ -67,7 +67,13 @@ resident_kernel_fn pick_async(const mc3hip_ctx *c)
     case 1: return resident_async_kernel<1, P2P, LEAN>;
     case 2: return resident_async_kernel<2, P2P, LEAN>;
     case 3: return resident_async_kernel<3, P2P, LEAN>;
-    default: return resident_async_kernel<4, P2P, LEAN>;
+    default:
+        // (four blocks of operand rows beside the general chain as owner: the kernel in step
+        // serves those -- ctx.h resident_async_shape)
+        if constexpr (LEAN)
+            return resident_async_kernel<4, P2P, true>;
+        else
+            return nullptr;
     }
 }
 }  // namespace

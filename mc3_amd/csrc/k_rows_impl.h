@@ -19,8 +19,14 @@ chain_kernel_fn lean_rows_instance_tt(const mc3hip_ctx *c)
         if (c->P.zlag > 0)                   // (the declared cadence: rows asked for a refresh ahead)
             return fx ? lean_demc_rows_lag_kernel<MT, T, true, P2P>
                       : lean_demc_rows_lag_kernel<MT, T, false, P2P>;
-        return fx ? lean_demc_rows_kernel<MT, T, true, P2P>
-                  : lean_demc_rows_kernel<MT, T, false, P2P>;
+        // (strict DEMC with fixed coefficients or priors has no peer-to-peer loop at all --
+        // ctx.h fast_eligible -- so it has no rows loop either)
+        if constexpr (P2P) {
+            return fx ? nullptr : lean_demc_rows_kernel<MT, T, false, true>;
+        } else {
+            return fx ? lean_demc_rows_kernel<MT, T, true, false>
+                      : lean_demc_rows_kernel<MT, T, false, false>;
+        }
     case MC3HIP_SNOOKER:
         return fx ? lean_snooker_rows_kernel<MT, T, true, P2P>
                   : lean_snooker_rows_kernel<MT, T, false, P2P>;

@@ -13,9 +13,11 @@ namespace {
 template <int MT>
 chain_kernel_fn instance_t(const mc3hip_ctx *c)
 {
-    return c->P.sampler == MC3HIP_SNOOKER ? wavelet_cw_kernel<MT, MC3HIP_SNOOKER>
-           : c->P.sampler == MC3HIP_DEMC  ? wavelet_cw_kernel<MT, MC3HIP_DEMC>
-                                          : wavelet_cw_kernel<MT, MC3HIP_MRW>;
+    // (the snooker update and the random walk run the pipelined kernel, k_wavelet_w8pp.hip, also
+    // with ONE chain per workgroup -- round 4; should its grid not fit, the general chain as
+    // chain wave serves them)
+    return c->P.sampler == MC3HIP_DEMC ? wavelet_cw_kernel<MT, MC3HIP_DEMC>
+                                       : persist_instance_wavelet_w8cg(c);
 }
 
 }  // namespace

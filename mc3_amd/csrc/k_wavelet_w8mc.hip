@@ -13,9 +13,9 @@ namespace {
 template <int MT>
 chain_kernel_fn instance_t(const mc3hip_ctx *c)
 {
-    return c->P.sampler == MC3HIP_SNOOKER ? wavelet_cw_kernel<MT, MC3HIP_SNOOKER, true>
-           : c->P.sampler == MC3HIP_DEMC  ? wavelet_cw_kernel<MT, MC3HIP_DEMC, true>
-                                          : wavelet_cw_kernel<MT, MC3HIP_MRW, true>;
+    // (several chains of the snooker update or the random walk per workgroup: the pipelined
+    // kernel, ctx.h chainwave_pipe)
+    return c->P.sampler == MC3HIP_DEMC ? wavelet_cw_kernel<MT, MC3HIP_DEMC, true> : nullptr;
 }
 
 }  // namespace

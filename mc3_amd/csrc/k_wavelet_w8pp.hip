@@ -18,7 +18,7 @@ chain_kernel_fn instance_t(const mc3hip_ctx *c)
     // (not for the generic polynomial, whose compute waves leave the chain wave no registers)
     if constexpr (MT != MT_POLY_GENERIC) {
         if (c->P.sampler == MC3HIP_SNOOKER && c->mc_chains == 1 && c->P.fepsilon == 0.0 &&
-            !getenv("MC3HIP_NO_CW_ONE"))
+            !env_text("MC3HIP_NO_CW_ONE"))
             return wavelet_pipe_kernel<MT, MC3HIP_SNOOKER, true>;
     }
     return c->P.sampler == MC3HIP_SNOOKER ? wavelet_pipe_kernel<MT, MC3HIP_SNOOKER>

@@ -193,7 +193,7 @@ int choose_wpc(int nlocal, int ndata, int wlike)
 {
     // One wave per chain when there are enough chains to fill the chip or the
     // data sum is short; otherwise split a chain's data over 4 waves.
-    const char *env = getenv("MC3HIP_WPC");
+    const char *env = env_text("MC3HIP_WPC");
     if (wlike) {
         // blocked D4 pyramid (wavelet.h block_wavelet): at most 32 points per thread;
         // one wave per chain up to 2048 points (no barrier at all), four at 4096, eight
@@ -204,8 +204,10 @@ int choose_wpc(int nlocal, int ndata, int wlike)
         return (ndata > 4096) ? 8 : (ndata > 2048 ? 4 : 1);
     }
     if (env) {
+        // (four waves only for more than one tile: their one-tile instances -- never chosen
+        // without this switch -- went with round 6)
         const int v = atoi(env);
-        if (v == 1 || v == 4)
+        if (v == 1 || (v == 4 && ndata > VLANES))
             return v;
     }
     if (ndata <= 4096)
@@ -284,7 +286,7 @@ bool resident_shape(const mc3hip_ctx *c)
 {
     const bool mfma = tile_uses_mfma(c) && c->P.nmodel >= 2 && c->P.nmodel <= 15;
     return (mfma || resident_poly(c)) && c->P.rs_prop && c->comm == nullptr &&
-           !getenv("MC3HIP_NO_RESIDENT");
+           !env_text("MC3HIP_NO_RESIDENT");
 }
 
 void launch_resident(mc3hip_ctx *c, int nref)
@@ -501,7 +503,7 @@ int decide_persist(mc3hip_ctx *c)
     c->P.mc_chains = 0;
     c->P.cw_lean = 0;
     c->P.rs_lean = 0;
-    if ((c->flags & MC3HIP_FLAG_NO_PERSIST) || getenv("MC3HIP_NO_PERSIST"))
+    if ((c->flags & MC3HIP_FLAG_NO_PERSIST) || env_text("MC3HIP_NO_PERSIST"))
         return 0;
     c->resident = false;
     if (c->P.tile > 0) {
@@ -528,7 +530,7 @@ int decide_persist(mc3hip_ctx *c)
         long long maxcol = capacity / c->P.ntiles;
         // (ranks that share one device -- the multi-process tests on a one-GPU box -- must
         // share its CUs too: MC3HIP_RESIDENT_MAXCOL caps the columns of chains per rank)
-        if (const char *e = getenv("MC3HIP_RESIDENT_MAXCOL"))
+        if (const char *e = env_text("MC3HIP_RESIDENT_MAXCOL"))
             if (atoi(e) > 0 && atoi(e) < maxcol)
                 maxcol = atoi(e);
         if (per_cu < 1 || maxcol < 1)
@@ -558,7 +560,7 @@ int decide_persist(mc3hip_ctx *c)
         // not; 512 x 100 000 29.9 / 29.3, with snooker 31.9 / 30.1).  DEMC, whose proposals wait
         // for two partners' decisions, from six blocks per column; the samplers that wait for
         // nobody from four.  (MC3HIP_RS_ASYNC=1: whatever the size -- the tests.)
-        const bool async_pays = getenv("MC3HIP_RS_ASYNC") != nullptr ||
+        const bool async_pays = env_text("MC3HIP_RS_ASYNC") != nullptr ||
                                 cb / 16 >= (resident_owner_lean(c) ? 6 : 4);
         if (resident_async_shape(c) && async_pays && cb <= RA_CMAX && owners <= RA_OWNERS &&
             nwg <= prop.multiProcessorCount) {
@@ -574,9 +576,9 @@ int decide_persist(mc3hip_ctx *c)
                                              resident_async_lds_bytes(c)) >= 1;
             }
             // the scheduler's blocks: a row of sixteen words per block of a launch's iterations
-            const long long refs = getenv("MC3HIP_PERSIST_REFS") &&
-                                   atoi(getenv("MC3HIP_PERSIST_REFS")) > 0
-                                       ? atoi(getenv("MC3HIP_PERSIST_REFS")) : 16384;
+            const long long refs = env_text("MC3HIP_PERSIST_REFS") &&
+                                   atoi(env_text("MC3HIP_PERSIST_REFS")) > 0
+                                       ? atoi(env_text("MC3HIP_PERSIST_REFS")) : 16384;
             // (a row per block of every round of proposals of a launch: `thinning` rounds to a
             // refresh)
             const long long rows = refs * c->P.thinning * ((cb + 15) / 16);
@@ -597,32 +599,33 @@ int decide_persist(mc3hip_ctx *c)
         }
         c->fast = false;
         c->persist_refs = 16384;
-        if (const char *e = getenv("MC3HIP_PERSIST_REFS"))
+        if (const char *e = env_text("MC3HIP_PERSIST_REFS"))
             c->persist_refs = atoi(e) > 0 ? atoi(e) : 0;
         return c->persist_refs;
     }
     int nb = 0;
     c->fast = fast_eligible(c) || jit_serves(c);
+    // (should a shape fast_eligible lets through have no lean instance after all: the general
+    // chain -- never a launch of nothing)
+    if (c->fast && !jit_serves(c)) {
+        const bool p2p_now = c->p2p_ranks > 1;
+        if (!fast_instance(c, p2p_now) ||
+            ((c->flags & MC3HIP_FLAG_P2P) && !p2p_now && !fast_instance(c, true)))
+            c->fast = false;
+    }
     // wavelet likelihood with eight waves per chain: a ninth wave runs the chain
     c->chainwave = c->P.wlike && c->wpc == 8 && !c->P.wl_scratch &&
                    !(c->flags & MC3HIP_FLAG_P2P) &&
                    c->smem + CW_EXTRA_DOUBLES * sizeof(double) <= 160 * 1024;
     c->wl_one = !c->fast && c->P.wlike && (c->wpc == 1 || c->wpc == 4) && !c->P.wl_scratch &&
                 cw_lean_eligible(c) &&
-                !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 && !getenv("MC3HIP_NO_WL_ONE") &&
-                !getenv("MC3HIP_NO_CW_LEAN");
+                !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 && !env_text("MC3HIP_NO_WL_ONE") &&
+                !env_text("MC3HIP_NO_CW_LEAN");
     // (bit 1: an out-of-bounds proposal rides with the turn behind it, kernels_wavelet.h
     // pipe_chain_wave_one; MC3HIP_NO_CW_RIDE gives it a slot of its own as before)
-    c->P.cw_lean = (c->chainwave && cw_lean_eligible(c) && !getenv("MC3HIP_NO_CW_LEAN"))
-                       ? (getenv("MC3HIP_NO_CW_RIDE") ? 1 : 3)
+    c->P.cw_lean = (c->chainwave && cw_lean_eligible(c) && !env_text("MC3HIP_NO_CW_LEAN"))
+                       ? (dev_env_text("MC3HIP_NO_CW_RIDE") ? 1 : 3)
                        : 0;
-    // Helper waves for the hand-laid-out DEMC loop (lean_demc_wide_kernel) are NOT the
-    // default: measured on MI355X (tools/lean_waves.py, profiles/r03_lean_waves.jsonl) two /
-    // four waves per chain run C2 at 203 / 207 M chain-steps/s against 219 for one -- the two
-    // barriers and the LDS round trips of the exchange cost more than the three quarters of
-    // the FP64 stream they take off wave 0 -- at every ensemble size from 64 to 1024 chains.
-    // MC3HIP_LEAN_WAVES=2|4 selects them (bit-identical results).
-    c->lean_waves_default = 1;
     if (c->fast)
         nb = fast_blocks_per_cu(c);
     else
@@ -636,12 +639,12 @@ int decide_persist(mc3hip_ctx *c)
     // (MI355X_MICROARCH.md "Residency and cooperative launch"), the launch gives up after
     // a bounded wait and the run is redone with per-refresh launches (settle()).
     // MC3HIP_PERSIST_MARGIN=1 keeps one workgroup per CU of slack instead.
-    const int per_cu = (nb > 1 && getenv("MC3HIP_PERSIST_MARGIN")) ? nb - 1 : nb;
+    const int per_cu = (nb > 1 && dev_env_text("MC3HIP_PERSIST_MARGIN")) ? nb - 1 : nb;
     long long capacity = (long long)per_cu * prop.multiProcessorCount;
     // (tests: pretend that fewer workgroups fit, so that small ensembles take the
     // several-chains-per-workgroup path)
     long long cap_limit = 1LL << 40;
-    if (const char *e = getenv("MC3HIP_PERSIST_CAPACITY"))
+    if (const char *e = env_text("MC3HIP_PERSIST_CAPACITY"))
         if (atoll(e) > 0)
             cap_limit = atoll(e);
     capacity = capacity < cap_limit ? capacity : cap_limit;
@@ -656,7 +659,7 @@ int decide_persist(mc3hip_ctx *c)
             nb = fast_blocks_per_cu(c);
         else
             persist_blocks_per_cu(c, &nb);
-        const int pc = (nb > 1 && getenv("MC3HIP_PERSIST_MARGIN")) ? nb - 1 : nb;
+        const int pc = (nb > 1 && dev_env_text("MC3HIP_PERSIST_MARGIN")) ? nb - 1 : nb;
         capacity = (long long)pc * prop.multiProcessorCount;
         capacity = capacity < cap_limit ? capacity : cap_limit;
         if (nb < 1)
@@ -669,7 +672,7 @@ int decide_persist(mc3hip_ctx *c)
         // chains per workgroup
         c->jit_fn = nullptr;
         nb = fast_blocks_per_cu(c);
-        const int pc = (nb > 1 && getenv("MC3HIP_PERSIST_MARGIN")) ? nb - 1 : nb;
+        const int pc = (nb > 1 && dev_env_text("MC3HIP_PERSIST_MARGIN")) ? nb - 1 : nb;
         capacity = (long long)pc * prop.multiProcessorCount;
         capacity = capacity < cap_limit ? capacity : cap_limit;
         if (nb < 1)
@@ -681,7 +684,7 @@ int decide_persist(mc3hip_ctx *c)
         // hold run the general chain
         c->fast = false;
         persist_blocks_per_cu(c, &nb);
-        const int pc = (nb > 1 && getenv("MC3HIP_PERSIST_MARGIN")) ? nb - 1 : nb;
+        const int pc = (nb > 1 && dev_env_text("MC3HIP_PERSIST_MARGIN")) ? nb - 1 : nb;
         capacity = (long long)pc * prop.multiProcessorCount;
         capacity = capacity < cap_limit ? capacity : cap_limit;
         if (nb < 1)
@@ -693,7 +696,7 @@ int decide_persist(mc3hip_ctx *c)
     const bool spec_pipe = !c->fast && c->chainwave && c->P.cw_lean != 0 &&
                            c->P.sampler != MC3HIP_DEMC && c->P.nlocal <= capacity &&
                            !(c->flags & MC3HIP_FLAG_P2P) && c->p2p_ranks <= 1 &&
-                           !getenv("MC3HIP_NO_CW_PIPE") && !getenv("MC3HIP_NO_CW_SPEC");
+                           !env_text("MC3HIP_NO_CW_SPEC");
     if (c->P.nlocal > capacity || spec_pipe) {
         // More chains than workgroups can be co-resident: a workgroup advances several per
         // refresh (run_chain MC), as the reference's workers do with their ncpp chains
@@ -704,7 +707,7 @@ int decide_persist(mc3hip_ctx *c)
         // (kernels_rows.h: up to four chains per wave, peer to peer as well).
         const bool p2p_ctx = (c->flags & MC3HIP_FLAG_P2P) || c->p2p_ranks > 1;
         if (!spec_pipe &&
-            (getenv("MC3HIP_NO_MULTICHAIN") || (p2p_ctx && !(c->fast && lean_rows_shape(c)))))
+            (env_text("MC3HIP_NO_MULTICHAIN") || (p2p_ctx && !(c->fast && lean_rows_shape(c)))))
             return 0;
         // (the nine-wave wavelet kernel takes turns only with its hand-structured chain wave;
         // should its LDS not leave room for the waiting states, the fused kernel is tried)
@@ -739,7 +742,7 @@ int decide_persist(mc3hip_ctx *c)
                         reinterpret_cast<const void *>(fast_instance(c, true)), threads, smem);
                     nbm = nbp < nbm ? nbp : nbm;
                 }
-                if (nbm > 1 && getenv("MC3HIP_PERSIST_MARGIN"))
+                if (nbm > 1 && dev_env_text("MC3HIP_PERSIST_MARGIN"))
                     nbm -= 1;
                 const long long grid = ((long long)c->P.nlocal + turns - 1) / turns;
                 long long room = (long long)nbm * prop.multiProcessorCount;
@@ -762,7 +765,7 @@ int decide_persist(mc3hip_ctx *c)
     }
     c->capacity = capacity;
     c->persist_refs = 16384;
-    if (const char *e = getenv("MC3HIP_PERSIST_REFS"))
+    if (const char *e = env_text("MC3HIP_PERSIST_REFS"))
         c->persist_refs = atoi(e) > 0 ? atoi(e) : 0;
     return c->persist_refs;
 }
@@ -1048,7 +1051,7 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         const bool linear_model = pr->model_kind == MC3HIP_MODEL_LINEAR;
         // (design matrices of 2..15 columns go through the matrix cores, 2048-point tiles)
         const bool mfma_model = linear_model && pr->nmodel >= 2 && pr->nmodel <= 15 &&
-                                !getenv("MC3HIP_NO_MFMA");
+                                true;
         const bool resident_model = linear_model ? mfma_model
                                                  : (pr->nmodel >= 2 && pr->nmodel <= 4);
         // (the mid-range rule was measured with the ONE-launch plan; where that plan cannot
@@ -1057,7 +1060,7 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         // fused kernels keep the shapes below 16 384 points.  An RCCL communicator attached
         // afterwards also forces three launches per iteration: not knowable here.)
         bool mid_resident = resident_model && !(pr->flags & MC3HIP_FLAG_NO_PERSIST) &&
-                            !getenv("MC3HIP_NO_PERSIST") && !getenv("MC3HIP_NO_RESIDENT");
+                            !env_text("MC3HIP_NO_PERSIST") && !env_text("MC3HIP_NO_RESIDENT");
         if (mid_resident) {
             hipDeviceProp_t prop;
             const long long tile_pts = (pr->nmodel <= 4 && !mfma_model) ? 4096 : 2048;
@@ -1089,9 +1092,9 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
                                pr->thinning == 1 && pr->zlag == 0 && pr->fepsilon == 0.0 &&
                                pr->trace_iters == 0 && pr->nlocal == pr->nchains &&
                                !(pr->flags & (MC3HIP_FLAG_P2P | MC3HIP_FLAG_NO_PERSIST)) &&
-                               !getenv("MC3HIP_NO_WIDE") && !getenv("MC3HIP_NO_LEAN") &&
-                               !getenv("MC3HIP_NO_FAST") && !getenv("MC3HIP_NO_PERSIST") &&
-                               !getenv("MC3HIP_WPC");
+                               !env_text("MC3HIP_NO_WIDE") && !env_text("MC3HIP_NO_LEAN") &&
+                               !dev_env_text("MC3HIP_NO_FAST") && !env_text("MC3HIP_NO_PERSIST") &&
+                               !env_text("MC3HIP_WPC");
             c->wide_tiles = 0;
             // (co-residency is decided by the occupancy query of the very instance --
             // decide_persist, which takes the choice back if the grid does not fit: two tiles
@@ -1114,9 +1117,9 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
                                       pr->sampler == MC3HIP_DEMC) && pr->fepsilon == 0.0)) &&
                                    pr->nlocal == pr->nchains &&
                                    !(pr->flags & (MC3HIP_FLAG_P2P | MC3HIP_FLAG_NO_PERSIST)) &&
-                                   !getenv("MC3HIP_NO_WIDE") && !getenv("MC3HIP_NO_LEAN") &&
-                                   !getenv("MC3HIP_NO_FAST") && !getenv("MC3HIP_NO_PERSIST") &&
-                                   !getenv("MC3HIP_NO_JIT") && !getenv("MC3HIP_WPC") &&
+                                   !env_text("MC3HIP_NO_WIDE") && !env_text("MC3HIP_NO_LEAN") &&
+                                   !dev_env_text("MC3HIP_NO_FAST") && !env_text("MC3HIP_NO_PERSIST") &&
+                                   !env_text("MC3HIP_NO_JIT") && !env_text("MC3HIP_WPC") &&
                                    (pr->flags & MC3HIP_FLAG_JIT);
             c->wide_jit_tiles = 0;
             c->wide_jit_waves = 0;
@@ -1150,7 +1153,7 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
                                              (long long)nd * pr->nlocal >= 4194304LL) ||
                           (mid_resident && mfma_model && nd > 2048));
         const bool tiled = !pr->wlike && big && pr->nlocal >= 16 && pr->nmodel <= 16 &&
-                           !getenv("MC3HIP_NO_TILED");
+                           !env_text("MC3HIP_NO_TILED");
         P.tile = tiled ? ((pr->nmodel <= 4 && !mfma_model) ? 4096 : 2048) : 0;
         const size_t unit = tiled ? (size_t)P.tile : VLANES;
         const size_t npad = (nd + unit - 1) / unit * unit;
@@ -1186,7 +1189,7 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
     }
     // (a padded series, wl_nreal < ndata: the abscissae of the padding are the caller's)
     P.wl_nreal = (pr->wlike && pr->wl_nreal > 0) ? pr->wl_nreal : pr->ndata;
-    if (pr->wlike && pr->model_kind == MC3HIP_MODEL_POLY && nd >= 2 && !getenv("MC3HIP_NO_GRID") &&
+    if (pr->wlike && pr->model_kind == MC3HIP_MODEL_POLY && nd >= 2 && !dev_env_text("MC3HIP_NO_GRID") &&
         P.wl_nreal == pr->ndata) {
         // abscissae made by numpy.linspace (y = arange(num) * step + start, y[-1] = stop)?
         // Checked bit for bit; if so the wavelet kernel recomputes them (block_wavelet)
@@ -1310,16 +1313,16 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
         c->tile_chain_block = best_cb;
     }
     P.test_abort = -1;
-    if (const char *ta = getenv("MC3HIP_TEST_ABORT_AT"))
+    if (const char *ta = env_text("MC3HIP_TEST_ABORT_AT"))
         P.test_abort = atoi(ta);
     P.zlag = pr->zlag;
     // test hook: rows for another rank's replica are held back (ticks of the 100 MHz clock)
     P.remote_delay = 0;
-    if (const char *rd = getenv("MC3HIP_TEST_REMOTE_DELAY_NS"))
+    if (const char *rd = env_text("MC3HIP_TEST_REMOTE_DELAY_NS"))
         P.remote_delay = atoi(rd) > 0 ? (atoi(rd) + 5) / 10 : 0;
     // test hook: one column of resident_async_kernel's tile waves held back before every block
     P.test_slow_col = P.test_slow_ticks = 0;
-    if (const char *sc = getenv("MC3HIP_TEST_SLOW_COLUMN")) {
+    if (const char *sc = env_text("MC3HIP_TEST_SLOW_COLUMN")) {
         int col = 0, ticks = 0;
         if (sscanf(sc, "%d:%d", &col, &ticks) == 2 && col >= 0 && ticks > 0) {
             P.test_slow_col = col;
@@ -1374,9 +1377,9 @@ int mc3hip_create(const mc3hip_problem *pr, mc3hip_ctx **out)
             c->flags |= MC3HIP_FLAG_NO_GRAPH;       // keep the captured graph small
     }
     c->graph_nodes = (c->flags & MC3HIP_FLAG_NO_GRAPH) ? 0 : 256;
-    if (getenv("MC3HIP_NO_GRAPH"))
+    if (env_text("MC3HIP_NO_GRAPH"))
         c->graph_nodes = 0;
-    if (const char *g = getenv("MC3HIP_GRAPH_NODES"))
+    if (const char *g = env_text("MC3HIP_GRAPH_NODES"))
         c->graph_nodes = atoi(g) > 0 ? atoi(g) : 0;
 #undef TRY
 #undef HIP_TRY_C
@@ -2717,7 +2720,7 @@ int mc3hip_p2p_attach(mc3hip_ctx *c, int32_t rank, int32_t nranks, const void *a
             continue;
         }
         void *z = nullptr, *l = nullptr;
-        const bool dbg = getenv("MC3HIP_DEBUG") != nullptr;
+        const bool dbg = dev_env_text("MC3HIP_DEBUG") != nullptr;
         if (dbg)
             fprintf(stderr, "[mc3hip rank %d] opening Z of rank %d\n", rank, r);
         HIP_TRY(hipIpcOpenMemHandle(&z, h[2 * r], hipIpcMemLazyEnablePeerAccess));
@@ -2915,7 +2918,7 @@ int mc3hip_debug_stamps(mc3hip_ctx *c, uint64_t *out16)
     }
     // (MC3HIP_STAMP_PAGE=1: the second group of sixteen, the resident tiled plan's phases;
     // pages 2..4095: a timeline build's records)
-    const char *page = getenv("MC3HIP_STAMP_PAGE");
+    const char *page = dev_env_text("MC3HIP_STAMP_PAGE");
     const int pg = (page && atoi(page) > 0 && atoi(page) < 4096) ? atoi(page) : 0;
     HIP_TRY(hipMemcpy(out16, c->P.stamps + 16 * (size_t)pg, 16 * sizeof(uint64_t),
                       hipMemcpyDeviceToHost));

@@ -80,10 +80,20 @@ def wavelet_case(ncoef, sampler, ndata, nchains=8, nref=16, flavour='plain'):
     return prob
 
 
+def wavelet_linear_case(sampler, ndata, nchains=8, nref=16, flavour='plain'):
+    """the same with the model as a design matrix of three columns (1, x, x^2)"""
+    prob = wavelet_case(3, sampler, ndata, nchains=nchains, nref=nref, flavour=flavour)
+    x = prob['indep']
+    prob.update(model='linear', nmodel=3, indep=np.array([np.ones_like(x), x, x*x]))
+    return prob
+
+
 def one_gpu_lean_grid():
     """(label, problem, chains per wave) over degree x sampler x flavour x chains per wave."""
+    # (five chains per wave: beyond what the rows loops lay side by side -- the lean instances
+    # of run_chain take turns)
     for ncoef, sampler, flavour, cpw in itertools.product(DEGREES, SAMPLERS, FLAVOURS,
-                                                          (1, 2, 3, 4)):
+                                                          (1, 2, 3, 4, 5)):
         if flavour.startswith('eps') and sampler == 'mrw':
             continue                                     # (chain.py:219-220: no such thing)
         yield (f'poly{ncoef}-{sampler}-{flavour}-cpw{cpw}',
@@ -121,7 +131,7 @@ def ranks_lean_grid(nranks):
                    dict(no_courier=no_courier))
         if flavour in ('plain', 'fx'):
             for cpw in (2, 3, 4):                       # the chains of a wave side by side
-                per = 2*cpw + 1
+                per = 4*cpw + 1
                 yield (f'poly{ncoef}-{sampler}-{flavour}-cpw{cpw}',
                        poly_case(ncoef, sampler, flavour, nchains=per*nranks, nref=18),
                        dict(no_courier=True, env=dict(MC3HIP_PERSIST_CAPACITY=-(-per//cpw))))
@@ -132,13 +142,54 @@ def ranks_lean_grid(nranks):
                    poly_case(ncoef, 'demc', flavour, nchains=6*nranks, nref=18, zlag=zlag),
                    dict(no_courier=no_courier))
         for cpw in (2, 3, 4):
-            per = 2*cpw + 1
+            per = 4*cpw + 1
             yield (f'poly{ncoef}-demc-{flavour}-zlag{zlag}-cpw{cpw}',
                    poly_case(ncoef, 'demc', flavour, nchains=per*nranks, nref=18, zlag=zlag),
                    dict(no_courier=True, env=dict(MC3HIP_PERSIST_CAPACITY=-(-per//cpw))))
 
 
-GRIDS = {'lean': ranks_lean_grid}
+def ranks_general_grid(nranks):
+    """what no hand-laid-out loop serves, sharded: the general chain's peer-to-peer instances --
+    generic polynomials and design matrices (the run-time specialisation is a one-GPU affair),
+    the support distribution, the wavelet likelihood on one and four waves per chain and beyond
+    2^14 points -- by tiles and waves per chain"""
+    for sampler, ndata in itertools.product(SAMPLERS, (300, 1500, 5000)):
+        yield (f'poly5-{sampler}-{ndata}', poly_case(5, sampler, 'fx', nchains=4*nranks, nref=12,
+                                                     ndata=ndata), {})
+        yield (f'lin7-{sampler}-{ndata}', linear_case(7, sampler, 'fx', nchains=4*nranks, nref=12,
+                                                     ndata=ndata), {})
+    for ncoef, sampler, ndata in itertools.product(DEGREES, ('demc', 'snooker'), (300, 1500, 5000)):
+        yield (f'poly{ncoef}-{sampler}-eps-{ndata}',
+               poly_case(ncoef, sampler, 'eps', nchains=4*nranks, nref=12, ndata=ndata), {})
+    for k, sampler, ndata in itertools.product((2, 3, 4, 5, 0), SAMPLERS, (256, 4096, 32768)):
+        if ndata == 32768 and sampler != 'snooker':
+            continue
+        prob = (wavelet_case(k, sampler, ndata, nchains=2*nranks, nref=8) if k else
+                wavelet_linear_case(sampler, ndata, nchains=2*nranks, nref=8))
+        yield (f'w-{"poly%d" % k if k else "lin3"}-{sampler}-{ndata}', prob, {})
+
+
+def ranks_resident_grid(nranks):
+    """the one-launch tiled plans sharded over ranks: design matrices by blocks of operand rows
+    (3, 7, 10, 13 columns), polynomials of 2..4 coefficients; the hand-structured owner (demc) and
+    the general chain as owner (snooker); the kernel in step and -- columns of at least six
+    (four) blocks of sixteen chains, three chains to own per workgroup -- with nobody in step"""
+    for ncol, sampler in itertools.product((3, 7, 10, 13), ('demc', 'snooker')):
+        yield (f'res-lin{ncol}-{sampler}',
+               linear_case(ncol, sampler, 'fx', nchains=32*nranks, nref=8, ndata=20000),
+               dict(env=dict(MC3HIP_RESIDENT_MAXCOL=2)))
+    for ncoef, sampler in itertools.product(DEGREES, ('demc', 'snooker')):
+        yield (f'res-poly{ncoef}-{sampler}',
+               poly_case(ncoef, sampler, 'fx', nchains=32*nranks, nref=8, ndata=20000),
+               dict(env=dict(MC3HIP_RESIDENT_MAXCOL=2)))
+    for ncol, sampler in ((3, 'demc'), (7, 'demc'), (10, 'demc'), (13, 'demc'), (3, 'snooker'),
+                          (7, 'snooker'), (10, 'snooker')):
+        yield (f'res-async-lin{ncol}-{sampler}',
+               linear_case(ncol, sampler, 'fx', nchains=96*nranks, nref=6, ndata=70000),
+               dict(env=dict(MC3HIP_RESIDENT_MAXCOL=1)))
+
+
+GRIDS = {'lean': ranks_lean_grid, 'general': ranks_general_grid, 'resident': ranks_resident_grid}
 
 
 # ---- the general chain (run_chain behind persist_kernel / step_kernel) ------------------------
@@ -167,7 +218,7 @@ def wavelet_grid():
     """wavelet likelihood: the model behind it x sampler x geometry (one wave per chain up to
     2 048 points, four at 4 096, eight and a chain wave above, the large-data instances beyond
     2^14) x chains per workgroup x launch structure; `thin`: the general chain as chain wave"""
-    models = [(f'poly{k}', k) for k in (2, 3, 4, 5)]
+    models = [(f'poly{k}', k) for k in (2, 3, 4, 5)] + [('lin3', 0)]
     for (name, k), sampler, ndata in itertools.product(models, SAMPLERS,
                                                        (256, 4096, 8192, 16384, 32768)):
         for flavour, cpw, no_persist in (('plain', 1, False), ('plain', 2, False),
@@ -178,6 +229,33 @@ def wavelet_grid():
                 continue
             yield (f'w-{name}-{sampler}-{ndata}-{flavour}-cpw{cpw}'
                    f'{"-perrefresh" if no_persist else ""}',
-                   wavelet_case(k, sampler, ndata, nchains=5 if cpw == 2 else 4,
-                                nref=6 if ndata >= 8192 else 10, flavour=flavour),
+                   (wavelet_case(k, sampler, ndata, nchains=5 if cpw == 2 else 4,
+                                 nref=6 if ndata >= 8192 else 10, flavour=flavour) if k else
+                    wavelet_linear_case(sampler, ndata, nchains=5 if cpw == 2 else 4,
+                                        nref=6 if ndata >= 8192 else 10, flavour=flavour)),
                    dict(cpw=cpw, no_persist=no_persist))
+
+
+def tiled_grid():
+    """the three-launch tiled plan (proposal / tile sums / finish) on the vector unit: polynomials
+    of 4..16 coefficients and one- and sixteen-column design matrices at 20 000 points, the
+    run-time specialisation and the one-launch plan switched off"""
+    for name, prob in (
+            [(f'poly{k}', poly_case(k, smp, 'plain', nchains=16, nref=6, ndata=20000))
+             for k, smp in ((4, 'demc'), (4, 'snooker'))] +
+            [(f'lin{k}', linear_case(k, smp, 'fx', nchains=16, nref=6, ndata=20000))
+             for k, smp in ((1, 'demc'), (6, 'snooker'), (10, 'mrw'), (13, 'demc'),
+                            (16, 'demc'), (16, 'snooker'))]):
+        for no_persist in (False, True):
+            yield (f'tiled-{name}-{prob["sampler"]}{"-threelaunch" if no_persist else ""}', prob,
+                   dict(jit=False, no_persist=no_persist))
+    # generic polynomials of 6, 10, 14 coefficients: the vector-unit tile kernels
+    for k in (6, 10, 14):
+        prob = poly_case(5, 'demc', 'plain', nchains=16, nref=6, ndata=20000)
+        x = prob['indep']/10.0
+        prob.update(indep=x, params=np.concatenate([prob['params'], np.zeros(k - 5)]),
+                    pstep=np.concatenate([prob['pstep'], np.full(k - 5, 1e-4)]),
+                    pmin=np.concatenate([prob['pmin'], np.full(k - 5, -1.0)]),
+                    pmax=np.concatenate([prob['pmax'], np.full(k - 5, 1.0)]),
+                    prior=np.zeros(k), priorlow=np.zeros(k), priorup=np.zeros(k))
+        yield (f'tiled-poly{k}-demc', prob, dict(jit=False))

@@ -94,8 +94,9 @@ def test_no_scratch_in_the_hand_laid_out_loops(isa):
             if unit == PIPE_UNIT and 'ILi0E' in name:
                 # (the pipelined wavelet kernel -- eleven waves, 168 registers each: C4's kernel --
                 # with the GENERIC polynomial, whose coefficient loop costs the compute waves four
-                # registers more than there are: 20 B, as in the nine-wave kernels)
-                assert scratch <= 24, f'{unit}: {name} carries {scratch} B of scratch'
+                # registers more than there are: 20 B, as in the nine-wave kernels; 28 B since round
+                # 6, where the give-up decision of a launch became one per workgroup)
+                assert scratch <= 32, f'{unit}: {name} carries {scratch} B of scratch'
                 continue
             if 'wide_kernel' in name and 'ELi8ELi16E' in name:
                 # (sixteen 1024-point tiles in the registers of eight waves, kernels_lean.h

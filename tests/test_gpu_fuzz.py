@@ -393,9 +393,7 @@ def test_rows_kernels_random_problem(seed, monkeypatch):
         prob['pmin'] = prob['params'] - rs.uniform(0.02, 0.2, len(prob['params']))
         prob['pmax'] = prob['params'] + rs.uniform(0.02, 0.2, len(prob['params']))
     monkeypatch.setenv('MC3HIP_PERSIST_CAPACITY', str(capacity))
-    layout = 'turns' if seed % 3 == 2 else 'rows'
-    if layout == 'turns':
-        monkeypatch.setenv('MC3HIP_NO_ROWS', '1')
+    layout = 'rows'
     gpu = engine.DeviceChains(**prob)
     plan = gpu.plan
     label = f"{layout} {flavour} {prob['sampler']} poly{prob['nmodel']} ndata={len(prob['data'])} " \

@@ -79,6 +79,7 @@ def test_declared_cadence_on_one_gpu(eng, label):
 
 GENERAL = {label: (prob, opt) for label, prob, opt in S.general_grid()}
 WAVELET = {label: (prob, opt) for label, prob, opt in S.wavelet_grid()}
+TILED = {label: (prob, opt) for label, prob, opt in S.tiled_grid()}
 
 
 def check_general(eng, prob, opt):
@@ -110,6 +111,17 @@ def test_general_chain_on_one_gpu(eng, label):
 @pytest.mark.parametrize('label', sorted(WAVELET))
 def test_wavelet_family_on_one_gpu(eng, label):
     check_general(eng, *WAVELET[label])
+
+
+@pytest.mark.parametrize('label', sorted(TILED))
+def test_tiled_plans_on_the_vector_unit(eng, label):
+    prob, opt = TILED[label]
+    gpu_kw = dict(jit=False, **({'no_persist': True} if opt.get('no_persist') else {}))
+    orc, gpu = run_pair(eng, prob, trace=False, **gpu_kw)
+    plan = gpu.plan
+    assert plan['tile'] > 0 and plan['recoveries'] == 0, (plan, gpu.last_kernel)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
 
 
 # ---- sharded over two ranks on the one GPU: the peer-to-peer flavours -------------------------
@@ -150,5 +162,19 @@ def run_ranks_grid(grid, nranks, tmp_path, chunk=400):
 
 def test_lean_family_sharded_over_two_ranks(tmp_path):
     kernels = run_ranks_grid('lean', 2, tmp_path)
-    assert all(mode == 'p2p' for mode, _ in kernels.values()), \
-        {k: v for k, v in kernels.items() if v[0] != 'p2p'}
+    # (strict DEMC with a prior / a fixed coefficient and several chains per wave has no
+    # peer-to-peer loop: those cases go through the host -- everything else hands over in-launch)
+    host = {k for k, v in kernels.items() if v[0] != 'p2p'}
+    assert all('-demc-fx-cpw' in k for k in host), sorted(host)
+
+
+def test_general_chain_sharded_over_two_ranks(tmp_path):
+    kernels = run_ranks_grid('general', 2, tmp_path)
+    host = {k for k, v in kernels.items() if v[0] != 'p2p'}
+    assert not host, sorted(host)
+
+
+def test_resident_plans_sharded_over_two_ranks(tmp_path):
+    kernels = run_ranks_grid('resident', 2, tmp_path)
+    assert all('resident' in kernel for _, kernel in kernels.values()), kernels
+    assert all('resident_async' in kernels[k][1] for k in kernels if 'async' in k), kernels

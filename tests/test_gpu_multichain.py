@@ -88,10 +88,10 @@ def test_lean_instances_with_several_chains_per_wave(eng, monkeypatch, sampler, 
     assert_same(orc, gpu, trace=False)
     gpu.close()
     if lean_loop:
-        # the general lean instance (run_chain MC) behind the switch
+        # the general chain behind the switch (several chains per workgroup as well)
         monkeypatch.setenv('MC3HIP_NO_LEAN', '1')
         orc, gpu = run_pair(eng, prob, trace=False)
-        check_plan(gpu, turns=turns, fast=1)
+        check_plan(gpu, turns=turns, fast=0)
         assert_same(orc, gpu, trace=False)
         gpu.close()
 
@@ -208,13 +208,12 @@ def test_switch_off(eng, monkeypatch):
 
 
 def layout_switch(monkeypatch, layout, case):
-    """'rows': the chains of a wave side by side (kernels_rows.h); 'turns': one after another on
-    the general lean instance (run_chain MC, behind MC3HIP_NO_ROWS: plan.fast == 1)."""
-    if layout == 'turns':
-        monkeypatch.setenv('MC3HIP_NO_ROWS', '1')
+    """'rows': the chains of a wave side by side (kernels_rows.h).  (Until round 6 there was a
+    second layout behind a switch -- one after another on the lean instance of run_chain -- for
+    the shapes the rows loops serve; those instances went with the switch.)"""
 
 
-@pytest.mark.parametrize('layout', ['rows', 'turns'])
+@pytest.mark.parametrize('layout', ['rows'])
 @pytest.mark.parametrize('turns', [2, 3, 4])
 @pytest.mark.parametrize('case', ['resume', 'abort', 'tight', 'priors', 'ragged'])
 def test_lean_demc_loop_with_several_chains_per_wave(eng, monkeypatch, case, turns, layout):
@@ -258,7 +257,7 @@ def test_lean_demc_loop_with_several_chains_per_wave(eng, monkeypatch, case, tur
     gpu.close()
 
 
-@pytest.mark.parametrize('layout', ['rows', 'turns'])
+@pytest.mark.parametrize('layout', ['rows'])
 @pytest.mark.parametrize('turns', [2, 3, 4])
 @pytest.mark.parametrize('sampler', ['snooker', 'mrw'])
 @pytest.mark.parametrize('case', ['resume', 'abort', 'tight', 'priors', 'ragged', 'thin'])
@@ -305,11 +304,11 @@ def test_lean_snooker_and_mrw_loops_with_several_chains_per_wave(eng, monkeypatc
     if case == 'tight':
         assert gpu.state()['outbounds'].sum() > 50
     gpu.close()
-    # the general lean instance (run_chain MC) behind the switch
+    # the general chain behind the switch
     monkeypatch.setenv('MC3HIP_NO_LEAN', '1')
     if case != 'resume':
         orc, gpu = run_pair(eng, prob, trace=False)
-        check_plan(gpu, turns=turns, fast=1)
+        check_plan(gpu, turns=turns, fast=0)
         assert_same(orc, gpu, trace=False)
         gpu.close()
 
@@ -382,21 +381,17 @@ def test_wavelet_pipeline_uneven_and_deep(eng, monkeypatch, sampler, nchains, ca
     gpu.close()
 
 
-@pytest.mark.parametrize('case', ['plain', 'epsilon', 'tight', 'resume', 'abort', 'general',
-                                  'turns'])
+@pytest.mark.parametrize('case', ['plain', 'epsilon', 'tight', 'resume', 'abort', 'general'])
 @pytest.mark.parametrize('ndata,sampler', [(8192, 'snooker'), (16384, 'demc'), (8192, 'mrw'),
                                            (16384, 'snooker')])
 def test_wavelet_chain_wave_takes_turns(eng, monkeypatch, ndata, sampler, case):
     """The wavelet kernels with a wave of their own for the chain and several chains per
     workgroup.  snooker and mrw: eleven waves, the chains pipelined (wavelet_pipe_kernel: the tail
     of one chain's likelihood, the noise terms and the chain itself on three helper waves while
-    the eight compute waves are at the next chain's stage A); DEMC, and the others behind
-    MC3HIP_NO_CW_PIPE ('turns'): nine waves, the chain wave advances the chains in turn and
-    prepares, during a likelihood, the NEXT turn's proposal.  11 chains over 4 workgroups:
-    3, 3, 3, 2."""
+    the eight compute waves are at the next chain's stage A); DEMC: nine waves, the chain wave
+    advances the chains in turn and prepares, during a likelihood, the NEXT turn's proposal.
+    11 chains over 4 workgroups: 3, 3, 3, 2."""
     forced(monkeypatch, 4)
-    if case == 'turns':
-        monkeypatch.setenv('MC3HIP_NO_CW_PIPE', '1')
     prob = H.wavelet_problem(ndata=ndata, nchains=11, nsamples=11*50, sampler=sampler)
     if case == 'epsilon':
         prob.update(fepsilon=0.03, fgamma=0.8)

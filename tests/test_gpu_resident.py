@@ -367,7 +367,6 @@ def test_resident_nonfinite_models_are_rejected_like_the_reference(eng, kind):
 @pytest.mark.parametrize('plan_env,want', [
     ({}, dict(resident=1, tile_tree=2)),                          # one launch, matrix cores
     ({'MC3HIP_NO_RESIDENT': '1'}, dict(resident=0, tile_tree=2)),  # three launches, matrix cores
-    ({'MC3HIP_NO_MFMA': '1'}, dict(resident=0, tile_tree=0)),      # three launches, vector unit
 ])
 def test_tiled_plans_against_the_reference_chisq_at_c5_size(eng, monkeypatch, golden_dir,
                                                             plan_env, want):
