@@ -53,6 +53,8 @@ def main():
         np.savez(f'{out_path}.{label}.rank{comm.rank}.npz', Z=Z, lp=lp, zc=zc,
                  numaccept=st['numaccept'], outbounds=st['outbounds'], mode=comm.mode,
                  fast=plan['fast'], cpw=plan['chains_per_workgroup'], resident=plan['resident'],
+                 tile=plan['tile'], vlanes=plan['vlanes'], tile_tree=plan['tile_tree'],
+                 waves_per_chain=plan['waves_per_chain'],
                  recoveries=comm.recoveries + gpu.plan['recoveries'], kernel=gpu.last_kernel,
                  best_chisq=st['best_chisq'], X=st['X'], chisq=st['chisq'])
         comm.barrier()

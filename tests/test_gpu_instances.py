@@ -131,16 +131,23 @@ def run_ranks_grid(grid, nranks, tmp_path, chunk=400):
     import ranks
     cases = list(S.GRIDS[grid](nranks))
     out = str(tmp_path/'s')
-    oracles = {}
+    pops = {}
     for label, prob, opt in cases:
         orc = H.make_oracle(prob)
         Z0, lp0 = H.initial_population(orc)
-        orc.set_population(Z0, lp0)
-        orc.run(nthreads=8)
         np.savez(f'{out}.{label}.pop.npz', Z0=Z0, lp0=lp0)
-        oracles[label] = orc
+        pops[label] = (Z0, lp0)
     for first in range(0, len(cases), chunk):
         ranks.launch_ranks(nranks, 'sweep_worker.py', out, grid, first, chunk, timeout=900)
+    oracles = {}
+    for label, prob, opt in cases:
+        # (the oracle adds up in the order the library reports: the plan of rank 0)
+        got = np.load(f'{out}.{label}.rank0.npz')
+        plan = {k: int(got[k]) for k in ('tile', 'vlanes', 'tile_tree', 'waves_per_chain')}
+        orc = H.make_oracle(prob, plan=plan)
+        orc.set_population(*pops[label])
+        orc.run(nthreads=8)
+        oracles[label] = orc
     kernels = {}
     for label, prob, opt in cases:
         orc = oracles[label]
