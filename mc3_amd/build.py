@@ -30,9 +30,11 @@ OBJDIR = os.path.join(HERE, '..', 'build', 'obj')
 
 # -ffp-contract=off is part of the arithmetic contract (include/mc3hip_detmath.h):
 # fused multiply-adds happen only where the source spells them out.
+# --offload-compress: the gfx950 code objects are stored compressed in the library (the HIP
+# runtime unpacks them when it loads the library): 15.6 -> ~6 MB for the 628 kernel instances.
 CFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
-          '-fvisibility=hidden']
-LDFLAGS = ['--offload-arch=gfx950', '-shared', '-fPIC']
+          '-fvisibility=hidden', '--offload-compress']
+LDFLAGS = ['--offload-arch=gfx950', '-shared', '-fPIC', '--offload-compress']
 FLAGS = CFLAGS          # (what tools that build a diagnostic variant start from)
 
 _INCLUDE = re.compile(r'^\s*#\s*include\s*"([^"]+)"', re.M)

@@ -42,7 +42,8 @@ def main():
     else:
         crowded = comm.size > 2 and extra.get('devices') != 'own'
         assert opts['p2p'] and opts['no_courier'] == crowded, opts
-    gpu = engine.DeviceChains(chain0=c0, nlocal=n, device=device, **opts, **prob)
+    gpu = ranks.first_gpu_call(comm, lambda: engine.DeviceChains(
+        chain0=c0, nlocal=n, device=device, **opts, **prob))
     gpu.set_population(pop['Z0'], pop['lp0'])
     comm.setup(gpu)
     if rccl:

@@ -198,9 +198,13 @@ def initial_population(orc, seed=5):
 
 def gpu_count():
     """Devices HIP shows, counted in a CHILD process (the caller's own GPU state is left alone);
-    0 when there is no runtime or no GPU."""
+    0 when there is no runtime or no GPU.  (MC3_TEST_FAKE_GPUS=n: the rehearsal of the node's
+    tests on a box without one, tests/test_multidevice_dry_run.py.)"""
+    import os
     import subprocess
     import sys
+    if os.environ.get('MC3_TEST_FAKE_GPUS'):
+        return int(os.environ['MC3_TEST_FAKE_GPUS'])
     code = ('import ctypes\n'
             'n = ctypes.c_int(0)\n'
             'rc = ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(n))\n'

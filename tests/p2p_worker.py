@@ -29,7 +29,7 @@ def main():
     comm = ranks.worker_comm(use_p2p=True, use_rccl=False)
     x, data, uncert = H.tutorial_data(100)
     np.random.seed(100 + comm.rank)
-    out = mc3_amd.sample(
+    out = ranks.first_gpu_call(comm, lambda: mc3_amd.sample(
         data=data, uncert=uncert, func=H.quad, params=np.array([10.0, -2.0, 0.1]),
         indparams=[x], pstep=np.array([1.0, 0.5, 0.1]),
         pmin=np.array([-10.0, -20.0, -10.0]), pmax=np.array([40.0, 20.0, 10.0]),
@@ -37,7 +37,7 @@ def main():
         thinning=thinning, grtest=True, log=mu.Log(verb=0), seed=99, comm=comm,
         device=int(os.environ.get('LOCAL_RANK', '0'))
         if os.environ.get('P2P_WORKER_DEVICES') == 'own' else 0, **({'zlag': extra['zlag'] if extra['zlag'] == 'auto' else int(extra['zlag'])}
-                     if 'zlag' in extra else {}))
+                     if 'zlag' in extra else {})))
     if abort_at is None:
         assert comm.mode == 'p2p' and comm.recoveries == 0, (comm.mode, comm.recoveries)
     else:

@@ -62,6 +62,30 @@ def worker_comm(**kw):
     return parallel.TorchDistComm(**kw)
 
 
+def dry_run():
+    """MC3_TEST_DRY_RUN=1 (tests/test_multidevice_dry_run.py, a box WITHOUT a GPU): a worker goes
+    as far as its first GPU call -- arguments, rendezvous, partition, the communicator's
+    options, the problem, the population file -- and stops there."""
+    return os.environ.get('MC3_TEST_DRY_RUN') == '1'
+
+
+def first_gpu_call(comm, make):
+    """`make()` is the worker's first call into the GPU (a context, or sample()).  In a dry
+    run it must fail with the LIBRARY's word that there is no device -- not with a TypeError
+    three lines earlier --, and the ranks leave together; otherwise its result."""
+    if not dry_run():
+        return make()
+    from mc3_amd import _lib
+    try:
+        make()
+    except _lib.Mc3HipError as err:
+        assert err.code == _lib.ERR_HIP, err
+        print(f'rank {comm.rank} of {comm.size}: dry run reached the first GPU call', flush=True)
+        finalize(comm)
+        sys.exit(0)
+    raise AssertionError('dry run on a box that HAS a GPU: unset MC3_TEST_DRY_RUN')
+
+
 def finalize(comm):
     comm.barrier()
     if hasattr(comm, 'dist'):

@@ -64,7 +64,7 @@ def _isa_request(k, request, tmp):
     m = re.search(r'/\*threads=(\d+)\*/', request)
     with open(os.path.join(d, 'jit.hip'), 'w') as f:
         f.write(jit._SOURCE % (int(m.group(1)) if m else 64, jit.KERNEL_NAME, request))
-    flags = [x for x in b.CFLAGS if x not in ('-fPIC', '-fvisibility=hidden')]
+    flags = [x for x in b.CFLAGS if x not in ('-fPIC', '-fvisibility=hidden', '--offload-compress')]
     subprocess.run([b.hipcc()] + flags + ['--save-temps', '-I', CSRC, '-c', 'jit.hip', '-o',
                                           '/dev/null'], cwd=d, check=True, capture_output=True)
     (path,) = glob.glob(os.path.join(d, '*gfx950.s'))
