@@ -902,6 +902,131 @@ def test_persistent_launch_gives_up_and_run_is_redone(eng, sampler):
     gpu.close()
 
 
+@pytest.mark.parametrize('ndata,want', [(1025, 4), (2048, 4), (2049, 4), (3000, 4), (4096, 4),
+                                        (4097, 4), (6000, 4), (8192, 4), (8193, 8), (12000, 8),
+                                        (16384, 8)])
+@pytest.mark.parametrize('case', ['plain', 'tight', 'resume', 'snooker', 'snooker-tight',
+                                  'snooker-resume'])
+def test_lean_loops_with_the_tiles_in_the_registers_of_several_waves(eng, monkeypatch, ndata, want,
+                                                                     case):
+    """1 025 ... 16 384 points of the plain strict DEMC and snooker shapes with few chains
+    (lean_demc_wide_kernel / lean_snooker_wide_kernel NT: four waves keep up to eight 1024-point
+    tiles between them, eight waves up to sixteen -- where one wave streamed the tiles beyond
+    its second from L2, the general chain took over from 4097 points and the tiled plan from
+    16 384): a virtual lane adds
+    up its points tile after tile, so the sum is the canonical one bit for bit -- against the
+    oracle, with bounds that reject, across launches, and behind the switch the kernels these
+    shapes ran before (the same results)."""
+    nref = 60
+    sampler = 'snooker' if case.startswith('snooker') else 'demc'
+    case = case.replace('snooker-', '').replace('snooker', 'plain')
+    prob = H.quad_problem(ndata=ndata, nchains=6, nsamples=6*nref, sampler=sampler)
+    if case == 'tight':
+        prob.update(pmin=np.array([9.2, -2.4, 0.08]), pmax=np.array([10.8, -1.6, 0.12]))
+    if case == 'resume':
+        monkeypatch.setenv('MC3HIP_PERSIST_REFS', '17')
+        gpu = eng.DeviceChains(**prob)
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nthreads=4)
+        for n in (1, 3, 30, 26):
+            gpu.run(n)
+    else:
+        orc, gpu = run_pair(eng, prob, trace=False)
+    plan = gpu.plan
+    assert plan['fast'] == 2 and plan['persistent'] > 0 and plan['tile'] == 0, plan
+    assert plan['waves_per_chain'] == want, plan
+    assert_same(orc, gpu, trace=False)
+    if case == 'tight':
+        assert gpu.state()['outbounds'].sum() > 20
+    gpu.close()
+    # behind the switch: what these shapes ran before
+    if case == 'plain':
+        monkeypatch.setenv('MC3HIP_NO_WIDE', '1')
+        orc2, gpu2 = run_pair(eng, prob, trace=False)
+        assert_same(orc2, gpu2, trace=False)
+        np.testing.assert_array_equal(orc2.Z, orc.Z)
+        gpu2.close()
+
+
+def test_wide_tiles_give_up_and_ensembles_that_do_not_fit(eng, monkeypatch):
+    """The wide loop through a give-up (redone from the checkpoint, one launch per refresh), and
+    an ensemble that is not co-resident at four waves per chain: back to what it ran before."""
+    prob = H.quad_problem(ndata=5000, nchains=6, nsamples=6*60, sampler='demc')
+    monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '23')
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert gpu.plan['recoveries'] == 1, gpu.plan
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+    monkeypatch.delenv('MC3HIP_TEST_ABORT_AT')
+    monkeypatch.setenv('MC3HIP_PERSIST_CAPACITY', '4')
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert gpu.plan['fast'] != 2 or gpu.plan['chains_per_workgroup'] > 1, gpu.plan
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
+# ---- wavelet likelihood: the hand-structured chain wave (kernels_wavelet.h) -------------
+def _cw_problem(sampler, ndata, case):
+    prob = H.wavelet_problem(ndata=ndata, nchains=12, nsamples=12*160, sampler=sampler)
+    if case == 'epsilon':
+        prob.update(fepsilon=0.03, fgamma=0.8)
+    elif case == 'tight':           # most proposals leave the box: the likelihood is skipped
+        prob.update(pmin=np.array([2.6, -2.6, 0.47, 0.0, 0.3, 0.8]),
+                    pmax=np.array([3.4, -2.2, 0.53, 2.0, 0.7, 1.2]))
+    elif case == 'wide':            # none does
+        prob.update(pmin=np.full(6, -1e3), pmax=np.full(6, 1e3))
+    return prob
+
+
+@pytest.mark.parametrize('case', ['plain', 'epsilon', 'tight', 'wide'])
+@pytest.mark.parametrize('ndata', [8192, 16384])
+@pytest.mark.parametrize('sampler', ['snooker', 'demc', 'mrw'])
+def test_wavelet_lean_chain_wave_bit_exact(eng, sampler, ndata, case):
+    """Without trace / priors / shared parameters / thinning the ninth wave of the wavelet
+    kernel runs lean_chain_wave instead of the general run_chain: same rows, counters, best
+    fits as the oracle (and therefore as the general chain, which the traced tests run)."""
+    orc, gpu = run_pair(eng, _cw_problem(sampler, ndata, case), trace=False)
+    plan = gpu.plan
+    assert plan['fast'] == 3 and plan['persistent'] > 0 and plan['recoveries'] == 0, plan
+    assert_same(orc, gpu, trace=False)
+    if case == 'tight':
+        assert gpu.state()['outbounds'].sum() > 100
+    gpu.close()
+
+
+@pytest.mark.parametrize('sampler', ['snooker', 'demc', 'mrw'])
+def test_wavelet_lean_chain_wave_resume_abort_and_switch(eng, monkeypatch, sampler):
+    prob = _cw_problem(sampler, 16384, 'plain')
+    # several launches: every launch starts without anything prepared ahead
+    gpu = eng.DeviceChains(**prob)
+    orc = H.make_oracle(prob, plan=gpu.plan)
+    Z0, lp0 = H.initial_population(orc)
+    orc.set_population(Z0, lp0)
+    gpu.set_population(Z0, lp0)
+    orc.run(nthreads=4)
+    for n in (1, 2, 64, 65, 28):
+        gpu.run(n)
+    assert gpu.plan['fast'] == 3
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+    # a launch that gives up (test hook) is redone from the checkpoint
+    monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '21')
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert gpu.plan['recoveries'] == 1
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+    monkeypatch.delenv('MC3HIP_TEST_ABORT_AT')
+    # the general chain behind the same kernel
+    monkeypatch.setenv('MC3HIP_NO_CW_LEAN', '1')
+    orc, gpu = run_pair(eng, prob, trace=False)
+    assert gpu.plan['fast'] == 0 and gpu.plan['persistent'] > 0
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
 @pytest.mark.parametrize('case', ['quad', 'tight', 'ragged', 'resume'])
 def test_lean_demc_with_the_draws_of_64_refreshes_at_once(eng, monkeypatch, case):
     """lean_demc_kernel BATCH (the default beyond 1024 chains, forced here): Philox, log u and
