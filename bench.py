@@ -303,7 +303,7 @@ def end_to_end():
 def _fp64_per_chain_step(name):
     """FP64 wave-instructions (fma + mul + add) per chain-step of a configuration's kernel, from
     the newest committed PMC pass of it (rocprofv3 --pmc cannot run inside this process)."""
-    for rnd in ('r05', 'r04'):
+    for rnd in ('r06', 'r05', 'r04'):
         q = os.path.join(ROOT, 'profiles', f'{rnd}_{name}_pmc.json')
         if os.path.exists(q):
             with open(q) as f:
@@ -355,6 +355,7 @@ def config_child(name):
         st = g.state()
         nd, nmodel, thinning = g.ndata, g.nmodel, g.thinning
         done = g.refresh_done
+        launched = g.last_kernel        # (the library's own word: mc3hip_debug_last_kernel)
     steps = nchains*ntimed*thinning
     rate = steps/dt/1e6
     rate_ev = steps/(gpu_ms*1e-3)/1e6
@@ -366,6 +367,7 @@ def config_child(name):
     out = {
         'config': name, 'workload': text, 'nchains': nchains, 'ndata': nd,
         'refreshes_timed': ntimed, 'launches': launches, 'kernel': kernel,
+        'kernel_launched': launched,
         'million_chain_steps_per_s': rate, 'us_per_iteration': dt/ntimed/thinning*1e6,
         # HIP events on the library's stream over the same launches
         'avg_launch_us': gpu_ms*1e3/launches,

@@ -1,6 +1,10 @@
 """Build libmc3hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-    python -m mc3_amd.build [--force] [--resource-usage]
+    python -m mc3_amd.build [--force] [--resource-usage] [--dev]
+
+--dev: a DEVELOPMENT build beside the product, mc3_amd/libmc3hip_dev.so (-DMC3HIP_DEV: the A/B
+switches of experiments, csrc/ctx.h dev_env_text, and the diagnostic macros of csrc/core.h exist
+only there); MC3HIP_LIBRARY=<path> makes the package load it.
 
 The library is several translation units (csrc/mc3hip.hip + one csrc/k_*.hip per kernel
 family) compiled in parallel and linked into ONE shared object.  An object is recompiled
@@ -197,6 +201,9 @@ def resource_usage(out=sys.stdout):
 if __name__ == '__main__':
     if '--resource-usage' in sys.argv:
         resource_usage()
+    elif '--dev' in sys.argv:
+        build(force='--force' in sys.argv, verbose=True,
+              lib=os.path.join(HERE, 'libmc3hip_dev.so'), extra=['-DMC3HIP_DEV'])
     else:
         build(force='--force' in sys.argv, verbose=True)
         build_probes(verbose=True)

@@ -14,6 +14,23 @@
 // Arithmetic contract: compiled with -ffp-contract=off; fused multiply-adds only
 // where written (model, squared-residual accumulation, D4 taps, detmath).
 #pragma once
+// Diagnostic instrumentation (phase stamps, the timeline of a round, the pipelined wavelet
+// kernel's slot accounting) and the tuning constants of resident_async_kernel exist in a
+// DEVELOPMENT build only (-DMC3HIP_DEV: tools/stamps.py, tools/pipe_diag.py, tools/variant_lib.py,
+// python -m mc3_amd.build --dev): without that flag none of these macros has any effect, whatever
+// else is on the command line.
+#ifndef MC3HIP_DEV
+#undef MC3HIP_STAMPS
+#undef MC3HIP_TICKS_ONLY
+#undef MC3HIP_NO_LSTAMP
+#undef MC3HIP_TIMELINE
+#undef MC3HIP_PIPE_DIAG
+#undef MC3HIP_RA_TAKE_AT
+#undef MC3HIP_RA_TAKE_AGAIN
+#undef MC3HIP_RA_PRIO
+#undef MC3HIP_CW_PRIO
+#undef MC3HIP_TAIL_PRIO
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "philox.h"

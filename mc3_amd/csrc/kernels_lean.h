@@ -258,6 +258,18 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
             zc_row[(size_t)lane * n] = c;
         }
     };
+    // one GPU, no courier: the row is published where it is decided (below), not at the end of
+    // the refresh's bookkeeping
+    constexpr bool EARLY = !P2P && !COURIER;
+    auto publish_early = [&](const double row_k) {
+        // (every poll has long returned -- said here for the compiler's wait-count bookkeeping,
+        // as at the end of the refresh)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (mine)
+            __hip_atomic_store(zblock + (size_t)c * ZS + lane, row_k, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);            // publish (sc1)
+    };
+    (void)publish_early;
     // every load issued so far is complete before the loop is entered, so that no path
     // through it carries a pending load to the latch (see the note after wait_rows)
     __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -379,6 +391,11 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
             const bool acc = metropolis_accept(0.5 * (cur - nextchisq), u_now, lo_now,
                                                hi_now);             // chain.py:257-274
             xk = acc ? npk : xk;
+            // (one GPU: the row leaves the moment it is decided -- the best-fit test, the
+            // counters and the bookkeeping columns are nobody's critical path, the row is its
+            // two partners')
+            if constexpr (EARLY)
+                publish_early(xk);
             if (__builtin_expect(__any(acc && nextchisq < best), 0)) {
                 best = nextchisq;
                 if (mine)
@@ -388,8 +405,11 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
             }
             cur = acc ? nextchisq : cur;
             nacc += acc ? 1 : 0;
-        } else if (outk) {
-            atomicAdd(&P.outbounds[lane], 1ull);                     // chain.py:242-243
+        } else {
+            if constexpr (EARLY)
+                publish_early(xk);                                   // (the state as it was)
+            if (outk)
+                atomicAdd(&P.outbounds[lane], 1ull);                 // chain.py:242-243
         }
 #ifdef MC3HIP_STAMPS
         MC3_TICK(tk3);
@@ -405,7 +425,9 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
         // bookkeeping from guarding the poll registers at the loop latch, where a wait would
         // stall on the acknowledgement of the row about to be published (loads and stores
         // share the counter on gfx9).
-        __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0), already true
+        // (EARLY: said before the row left -- here it would wait for the row's acknowledgement)
+        if constexpr (!EARLY)
+            __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0), already true
         // Z append, chain.py:276-289: publish the row ...
         if constexpr (COURIER) {
             // ... into the local replica, and hand it to the courier for the others
@@ -427,7 +449,7 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
             } else if (mine) {
                 peers_z.store(zoff, xk);                             // ... into every replica
             }
-        } else {
+        } else if constexpr (!EARLY) {
             if (mine)
                 __hip_atomic_store(zblock + (size_t)c * ZS + lane, xk, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);        // publish (sc1)

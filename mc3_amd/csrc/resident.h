@@ -1173,7 +1173,6 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
             next_c0 = c0;
             next_slots = (R & 1) * (RA_CMAX + 1);
             buf ^= 1;
-#ifndef MC3HIP_RA_NO_BALANCE
             // The two tile waves of a SIMD (v and v ^ 4) share its FP64 pipe, and the arbiter
             // serves the older one first: left alone, waves 0..3 run blocks ahead of 4..7 --
             // and a chain's sum is complete when the LAST wave has added its share
@@ -1182,21 +1181,11 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
             {
                 s_prog[wv] = (int)seq;
                 const int other = s_prog[wv ^ 4];
-#ifdef MC3HIP_RA_BEHIND_FIRST          // (experiment: the one behind ABOVE the owners)
-                if ((int)seq > other)
-                    __builtin_amdgcn_s_setprio(0);
-                else if ((int)seq < other)
-                    __builtin_amdgcn_s_setprio(MC3HIP_RA_BEHIND_FIRST);
-                else
-                    __builtin_amdgcn_s_setprio(1);
-#else
                 if ((int)seq > other)
                     __builtin_amdgcn_s_setprio(0);
                 else
                     __builtin_amdgcn_s_setprio(1);
-#endif
             }
-#endif
 #ifdef MC3HIP_TIMELINE
             tl_next = (R == MC3HIP_TIMELINE && wv == 0) ? (n - nrem) / 16 : -1;
             MC3_TL(tl_next >= 0 && tl_next < 8 && lane == 0,
@@ -1311,22 +1300,10 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
                     aop2[kb] = load_published(P.rs_prop + (size_t)lc_next * RS_ROW + 4 * kb + g);
             }
             if (have) {
-#ifdef MC3HIP_RA_FAKE_END          // (timing experiment: a block cut short -- wrong sums)
-                products(RA_TAKE_AGAIN, MC3HIP_RA_FAKE_END);
-#else
                 products(RA_TAKE_AGAIN, 16);
-#endif
             }
             const bool ok = hit1 || hit2;
             MC3_RTICK(tq2);
-#ifdef MC3HIP_RA_SUMS_PRIO
-            // (from here to the sums' publication every instruction is between a block's
-            // products and its chains' owners: ahead of the partner's products?  In a long
-            // launch the wave's own priority serves better: C5 25.46 us per iteration with
-            // this, 25.19 without -- bench.py --config-child c5, +-0.02 from run to run)
-            if (have)
-                __builtin_amdgcn_s_setprio(3);
-#endif
             // the rows of the block taken: there by now (only a row that is late is asked for
             // a second time: the addresses again, from the row's number)
             if (hit1) {
@@ -1378,9 +1355,7 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
                 if (lane == 0)
                     __hip_atomic_store(&s_done[wv], fin, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifndef MC3HIP_RA_KEEP_PRIO            // (experiment: what the last take decided stays)
                 __builtin_amdgcn_s_setprio(1);
-#endif
                 spins = 0;
                 MC3_RTICK(tq1);
 #ifdef MC3HIP_TIMELINE
@@ -1493,9 +1468,6 @@ __global__ __launch_bounds__(512 + 64 * (RA_OWNERS + 1)) void resident_async_ker
     // block's sums and the next proposals -- ahead of the tile waves' products)
     __builtin_amdgcn_s_setprio(MC3HIP_RA_PRIO);
     if (wv == nwaves - 1) {
-#ifdef MC3HIP_RA_SCHED_PRIO            // (experiment: the scheduler apart from the owners)
-        __builtin_amdgcn_s_setprio(MC3HIP_RA_SCHED_PRIO);
-#endif
         if (blockIdx.x == 0) {
             resident_scheduler(P, rounds, blockIdx.y, gridDim.y, s_sel + 32 * 8);
         }

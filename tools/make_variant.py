@@ -9,7 +9,7 @@ sys.path.insert(0,'/root/repo')
 from mc3_amd import build as b
 def mk(name, extra):
     obj=f'/root/repo/build/kres_{name}.o'
-    cmd=[b.hipcc()]+b.CFLAGS+list(extra)+['-c', os.path.join(b.CSRC,'k_resident.hip'), '-o', obj]
+    cmd=[b.hipcc()]+b.CFLAGS+['-DMC3HIP_DEV']+list(extra)+['-c', os.path.join(b.CSRC,'k_resident.hip'), '-o', obj]
     subprocess.check_call(cmd)
     objs=['/root/repo/build/obj/'+u[:-4]+'.o' for u in b.UNITS if u!='k_resident.hip']+[obj]
     os.makedirs('/root/repo/_variants', exist_ok=True)

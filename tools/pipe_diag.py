@@ -19,7 +19,7 @@ from mc3_amd import build as b, _lib  # noqa: E402
 
 lib = os.path.join(ROOT, 'mc3_amd', 'libmc3hip_pipediag.so')
 if '--build' in sys.argv or not os.path.exists(lib):
-    b.build(force=True, verbose=False, lib=lib, extra=['-DMC3HIP_PIPE_DIAG'])
+    b.build(force=True, verbose=False, lib=lib, extra=['-DMC3HIP_DEV', '-DMC3HIP_PIPE_DIAG'])
     if '--build' in sys.argv:
         sys.exit(0)
 _lib.LIB_PATH = lib

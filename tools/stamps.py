@@ -27,7 +27,7 @@ if '--build' in sys.argv or not os.path.exists(lib):
     # scalar pins of the lean kernels); `--lstamp` tries anyway.  Without them `c4` reports
     # only the three coarse phases; DESIGN.md's C4 breakdown comes from ablation builds.
     extra = [] if '--lstamp' in sys.argv else ['-DMC3HIP_NO_LSTAMP']
-    b.build(force=True, verbose=True, lib=lib, extra=['-DMC3HIP_STAMPS'] + extra)
+    b.build(force=True, verbose=True, lib=lib, extra=['-DMC3HIP_DEV', '-DMC3HIP_STAMPS'] + extra)
     if '--build' in sys.argv:
         sys.exit(0)
 _lib.LIB_PATH = lib

@@ -20,7 +20,7 @@ def main():
     b.build()                                   # (the product's objects are current)
     objdir = os.path.normpath(b.OBJDIR)
     vobj = os.path.join(objdir, f'variant_{name}_{os.path.splitext(unit)[0]}.o')
-    subprocess.check_call([b.hipcc()] + b.CFLAGS + flags + ['-c', os.path.join(b.CSRC, unit),
+    subprocess.check_call([b.hipcc()] + b.CFLAGS + ['-DMC3HIP_DEV'] + flags + ['-c', os.path.join(b.CSRC, unit),
                                                            '-o', vobj])
     objs = [vobj if u == unit else os.path.join(objdir, os.path.splitext(u)[0] + '.o')
             for u in b.UNITS]
