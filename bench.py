@@ -180,6 +180,18 @@ def _usable_cpus():
         else (os.cpu_count() or 1)
 
 
+def _cpu_quota_cores():
+    """CPUs' worth of time the cgroup grants per period (None = no quota): a box may SHOW 256
+    CPUs and GRANT 16 -- threads beyond the quota only take turns (and get the whole process
+    frozen for the rest of the period: profiles/r06_e2e_stall.txt)."""
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()[:2]
+        return None if quota == 'max' else int(quota)/int(period)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(target_seconds=8.0):
     """The oracle (oracle/oracle_lockstep.c: the same lockstep chain update in plain C) on this
     box's host cores, the same C2 workload, bounded to ~target_seconds per figure -- TWICE:
@@ -246,6 +258,8 @@ def cpu_baseline(target_seconds=8.0):
     thr['sample'] = (
         f'{thr.pop("iterations")} iterations ({thr.pop("seconds"):.1f} s), the same C loop under '
         f'{thr["cores"]} OpenMP THREADS of one process, a barrier per refresh')
+    host = {'cpus_visible': usable, 'cpu_quota_cores': _cpu_quota_cores()}
+    procs['host'] = thr['host'] = host
     # The figure of record is the FASTER of the two -- a GPU / CPU ratio taken from the slower
     # one would flatter the GPU (round 5: 1.34 by processes beside 1.72 by threads in one run);
     # the other stays beside it under its own name.
@@ -256,41 +270,59 @@ def cpu_baseline(target_seconds=8.0):
     return procs
 
 
-def end_to_end():
-    """mc3_amd.sample() as a user calls it (an ordinary Python callable as the model, the
-    initial population, ten reports with the Gelman-Rubin test, the posterior statistics, the
-    output dictionary) -- wall seconds, NOT part of `value`: the rows next to the hot path
-     measured where the driver can see them.  Each after one small
-    warm-up call (library load, first launches)."""
+E2E_CASES = ('c2_1e7_samples', 'c5_1e5_samples', 'c5_1e6_samples')
+
+
+def end_to_end_child(name):
+    """ONE end-to-end case in this (fresh) process: mc3_amd.sample() as a user calls it -- an
+    ordinary Python callable as the model, the initial population, ten reports with the
+    Gelman-Rubin test, the posterior statistics, the output dictionary -- after one small
+    warm-up call (library load, first launches).  Prints one JSON line."""
     import io
     import contextlib
     import mc3_amd
     from mc3_amd import utils as mu
+    if name.startswith('c2'):
+        p2 = c2_problem(CHAINS_PER_GPU, 1)
+        kw = dict(data=p2['data'], uncert=p2['uncert'], func=quad, params=p2['params'],
+                  indparams=[p2['indep']], pstep=p2['pstep'], pmin=p2['pmin'], pmax=p2['pmax'],
+                  sampler='demc', burnin=100, nchains=CHAINS_PER_GPU, grtest=True, seed=3)
+        nsamples = 1e7
+    else:
+        p5 = c5_problem(512, 1)
+        kw = dict(data=p5['data'], uncert=p5['uncert'], func=lambda p, A: p @ A,
+                  params=p5['params'], indparams=[p5['indep']], pstep=p5['pstep'],
+                  pmin=p5['pmin'], pmax=p5['pmax'], prior=p5['prior'],
+                  priorlow=p5['priorlow'], priorup=p5['priorup'],
+                  sampler='demc', burnin=20, nchains=512, grtest=True, seed=3)
+        nsamples = 1e6 if '1e6' in name else 1e5
+    with contextlib.redirect_stdout(io.StringIO()):
+        mc3_amd.sample(nsamples=kw['nchains']*(kw['burnin'] + 100), log=mu.Log(verb=0), **kw)
+        time.sleep(0.3)
+        best = None
+        for _ in range(3):                   # (the best of three: the box's other tenants)
+            t0 = time.perf_counter()
+            res = mc3_amd.sample(nsamples=nsamples, log=mu.Log(verb=0), **kw)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+    print(json.dumps({'wall_s': best, 'samples': int(len(res['posterior'])),
+                      'million_samples_per_s': len(res['posterior'])/best/1e6,
+                      'acceptance_rate': float(res['acceptance_rate']),
+                      'host_threads': __import__('mc3_amd.sampler_driver', fromlist=['x'])
+                      .host_threads()}), flush=True)
+
+
+def end_to_end():
+    """mc3_amd.sample() end to end -- wall seconds, NOT part of `value`: the rows next to the
+    hot path measured where the driver can see them.  Each case in
+    a child process of its own (round 6: in one process the second case inherited the first's
+    freed multi-GB allocations and ran 2-3x slower)."""
     out = {}
-    p2 = c2_problem(CHAINS_PER_GPU, 1)
-    p5 = c5_problem(512, 1)
-    cases = {
-        'c2_1e7_samples': (dict(
-            data=p2['data'], uncert=p2['uncert'], func=quad, params=p2['params'],
-            indparams=[p2['indep']], pstep=p2['pstep'], pmin=p2['pmin'], pmax=p2['pmax'],
-            sampler='demc', burnin=100, nchains=CHAINS_PER_GPU, grtest=True, seed=3), 1e7),
-        'c5_1e5_samples': (dict(
-            data=p5['data'], uncert=p5['uncert'], func=lambda p, A: p @ A, params=p5['params'],
-            indparams=[p5['indep']], pstep=p5['pstep'], pmin=p5['pmin'], pmax=p5['pmax'],
-            prior=p5['prior'], priorlow=p5['priorlow'], priorup=p5['priorup'],
-            sampler='demc', burnin=20, nchains=512, grtest=True, seed=3), 1e5),
-    }
-    for name, (kw, nsamples) in cases.items():
+    for name in E2E_CASES:
         try:
-            with contextlib.redirect_stdout(io.StringIO()):
-                mc3_amd.sample(nsamples=kw['nchains']*(kw['burnin'] + 100), log=mu.Log(verb=0),
-                               **kw)
-                t0 = time.perf_counter()
-                res = mc3_amd.sample(nsamples=nsamples, log=mu.Log(verb=0), **kw)
-                dt = time.perf_counter() - t0
-            out[name] = {'wall_s': dt, 'samples': int(len(res['posterior'])),
-                         'million_samples_per_s': len(res['posterior'])/dt/1e6,
-                         'acceptance_rate': float(res['acceptance_rate'])}
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), '--e2e-child', name],
+                                 capture_output=True, text=True, timeout=300)
+            out[name] = json.loads(res.stdout.strip().splitlines()[-1])
         except Exception as e:      # noqa: BLE001 -- an extra: never fails the bench line
             out[name] = {'error': str(e)[:200]}
     return out
@@ -1145,6 +1177,8 @@ def main():
                     help='skip the extra segments (several ranks: the cadence, the RCCL route, '
                          'the one-GPU yardstick; one GPU: the cadence, the other BASELINE '
                          'configurations, the HBM probe) -- sweeps and profiler passes')
+    ap.add_argument('--e2e-child', default=None, choices=E2E_CASES,
+                    help='(internal) one end-to-end sample() case in this process')
     ap.add_argument('--no-e2e', action='store_true',
                     help='skip the end-to-end sample() timings (config.e2e)')
     ap.add_argument('--dry-run', action='store_true',
@@ -1152,6 +1186,9 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_child:
         print(json.dumps(cpu_baseline()), flush=True)
+        return
+    if args.e2e_child:
+        end_to_end_child(args.e2e_child)
         return
     if args.config_child:
         config_child(args.config_child)

@@ -267,6 +267,14 @@ int mc3hip_last_run_ms(mc3hip_ctx *ctx, float *ms);
  * rows [row0, row0+nrows) of Z / log_post / zchain.  Any pointer may be NULL. */
 int mc3hip_get_rows(mc3hip_ctx *ctx, int64_t row0, int64_t nrows, double *Z,
                     double *log_post, int32_t *zchain);
+
+/* The same for rows that can no longer change -- the initial population and the refreshes an
+ * mc3hip_sync has confirmed -- on a stream of the call's own: neither waits for nor disturbs a
+ * run in flight, so a long run's host copy (what mcmc() hands to update_output,
+ * mc3/mcmc_driver.py:350-352, mc3/stats/stats.py:805-852) is made while the next segment
+ * computes.  One-GPU runs; MC3HIP_ERR_STATE for rows beyond the confirmed refreshes. */
+int mc3hip_get_rows_settled(mc3hip_ctx *ctx, int64_t row0, int64_t nrows, double *Z,
+                            double *log_post, int32_t *zchain);
 /* Overwrite rows of Z / log_post that ANOTHER rank owns (host-staged exchange for
  * callers that cannot use the RCCL path below; same visibility rule: rows of
  * refresh R must be in place before refresh R+1 runs). */

@@ -89,6 +89,8 @@ SYMBOLS = {
     'mc3hip_recycle': (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_uint64]),
     'mc3hip_last_run_ms': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     'mc3hip_get_rows': (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, _dp, _dp, _ip]),
+    'mc3hip_get_rows_settled': (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, _dp, _dp,
+                                               _ip]),
     'mc3hip_put_rows': (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, _dp, _dp]),
     'mc3hip_get_state': (ctypes.c_int, [_vp, _dp, _dp, _lp, _lp, _dp, _lp, _dp, _lp]),
     'mc3hip_get_trace': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _ip]),

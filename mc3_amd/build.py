@@ -161,7 +161,8 @@ PROBES = os.path.normpath(os.path.join(HERE, '..', 'tools', 'probes'))
 # measurement probes bench.py and the GPU tests run as child processes (built with the library,
 # they travel to the GPU box as files): the streaming-read probe behind roofline.peak_measured,
 # and rocRAND's own Philox state for the identity test of csrc/philox.h
-PROBE_UNITS = {'hbm_read_probe': ['-O3'], 'rocrand_philox_probe': ['-O2']}
+PROBE_UNITS = {'hbm_read_probe': ['-O3'], 'rocrand_philox_probe': ['-O2'],
+               'sync_stall_probe': ['-O2']}
 
 
 def probe_path(name):

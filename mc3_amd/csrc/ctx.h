@@ -65,6 +65,12 @@ struct mc3hip_ctx {
     size_t mc_smem = 0;
     double *stage = nullptr;        // dense staging for Z row transfers (grow-only)
     size_t stage_doubles = 0;
+    // rows of refreshes an mc3hip_sync has confirmed are read back on a stream of their own,
+    // beside whatever runs on `stream` (mc3hip_get_rows_settled)
+    hipStream_t copy_stream = nullptr;
+    double *stage2 = nullptr;
+    size_t stage2_doubles = 0;
+    int64_t confirmed_done = 0;     // refreshes complete and not subject to a redo
     // checkpoint of the per-chain state taken before the first persistent launch that
     // has not been confirmed yet (recovery if a launch gives up)
     char *ckpt = nullptr;

@@ -1410,6 +1410,10 @@ void mc3hip_destroy(mc3hip_ctx *c)
         (void)hipFree(p);
     if (c->stage)
         (void)hipFree(c->stage);
+    if (c->stage2)
+        (void)hipFree(c->stage2);
+    if (c->copy_stream)
+        (void)hipStreamDestroy(c->copy_stream);
     if (c->ev0)
         (void)hipEventDestroy(c->ev0);
     if (c->ev1)
@@ -1806,10 +1810,12 @@ static int settle(mc3hip_ctx *c)
         // single GPU: the launches since the checkpoint are complete.  Peer-to-peer: complete
         // HERE; another rank may have given up, so the checkpoint stays until the caller,
         // having agreed with the other ranks, starts the next run
-        if (c->p2p_ranks > 1)
+        if (c->p2p_ranks > 1) {
             c->ckpt_settled = true;
-        else
+        } else {
             c->ckpt_valid = false;
+            c->confirmed_done = c->refresh_done;
+        }
         return MC3HIP_OK;
     }
     if (c->p2p_ranks > 1)
@@ -1847,6 +1853,7 @@ static int settle(mc3hip_ctx *c)
     if (rc)
         return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->confirmed_done = c->refresh_done;
     return MC3HIP_OK;
 }
 
@@ -2037,6 +2044,62 @@ int mc3hip_get_rows(mc3hip_ctx *c, int64_t row0, int64_t nrows, double *Z, doubl
                 zchain[r - row0] = (int32_t)((r - c->P.M0) % c->P.nchains);
         }
     }
+    return MC3HIP_OK;
+}
+
+/* Rows that can no longer change -- the initial population and the refreshes an mc3hip_sync
+ * has confirmed (single GPU; a sharded run confirms by agreement of the ranks and uses
+ * mc3hip_get_rows) -- read back on a stream of their own: the call neither waits for nor
+ * disturbs a run that is in flight, so the host copy of a long run is made while the next
+ * segment computes (mc3_amd/mcmc_driver.py).  MC3HIP_ERR_STATE for rows beyond the confirmed. */
+int mc3hip_get_rows_settled(mc3hip_ctx *c, int64_t row0, int64_t nrows, double *Z, double *log_post,
+                            int32_t *zchain)
+{
+    if (!c)
+        return fail(MC3HIP_ERR_ARG, "null context");
+    if (row0 < 0 || nrows < 0 || row0 + nrows > c->zlen)
+        return fail(MC3HIP_ERR_ARG, "rows [%lld,%lld) outside Z", (long long)row0,
+                    (long long)(row0 + nrows));
+    if (c->p2p_ranks > 1 || c->comm != nullptr || c->P.nlocal < c->P.nchains)
+        return fail(MC3HIP_ERR_STATE, "mc3hip_get_rows_settled serves one-GPU runs");
+    if (row0 + nrows > c->P.M0 + c->confirmed_done * c->P.nchains)
+        return fail(MC3HIP_ERR_STATE, "rows [%lld,%lld): only %lld refreshes are confirmed",
+                    (long long)row0, (long long)(row0 + nrows), (long long)c->confirmed_done);
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->copy_stream)
+        HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (Z) {
+        const size_t nf = (size_t)c->P.nfree, zs = (size_t)c->P.zs;
+        const size_t chunk = STAGE_MAX_DOUBLES / nf ? STAGE_MAX_DOUBLES / nf : 1;
+        const double *padded = c->P.Z + (size_t)row0 * zs;
+        for (size_t r = 0; r < (size_t)nrows; r += chunk) {
+            const size_t m = (size_t)nrows - r < chunk ? (size_t)nrows - r : chunk;
+            if (m * nf > c->stage2_doubles) {
+                if (c->stage2)
+                    HIP_TRY(hipFree(c->stage2));
+                c->stage2 = nullptr;
+                c->stage2_doubles = 0;
+                void *p = nullptr;
+                HIP_TRY(hipMalloc(&p, m * nf * sizeof(double)));
+                c->stage2 = static_cast<double *>(p);
+                c->stage2_doubles = m * nf;
+            }
+            const int blocks = (int)((m * nf + 255) / 256 < 4096 ? (m * nf + 255) / 256 : 4096);
+            MC3_LAUNCH(pack_rows_kernel, dim3(blocks), dim3(256), 0, c->copy_stream, c->stage2,
+                       padded + r * zs, (long long)m, (int)nf, (int)zs);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(Z + r * nf, c->stage2, m * nf * sizeof(double),
+                                   hipMemcpyDeviceToHost, c->copy_stream));
+            HIP_TRY(hipStreamSynchronize(c->copy_stream));
+        }
+    }
+    if (log_post)
+        HIP_TRY(hipMemcpyAsync(log_post, c->P.log_post + row0, (size_t)nrows * sizeof(double),
+                               hipMemcpyDeviceToHost, c->copy_stream));
+    if (zchain)
+        HIP_TRY(hipMemcpyAsync(zchain, c->P.zchain + row0, (size_t)nrows * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, c->copy_stream));
+    HIP_TRY(hipStreamSynchronize(c->copy_stream));
     return MC3HIP_OK;
 }
 

@@ -253,6 +253,14 @@ class DeviceChains:
                                        dptr(lp), iptr(zc)))
         return Z, lp, zc
 
+    def rows_settled_into(self, row0, Z, lp, zc):
+        """Rows [row0, row0 + len(Z)) of refreshes a sync has confirmed, straight into the
+        caller's (C-contiguous) arrays, on a stream of their own: a run in flight is neither
+        waited for nor disturbed (include/mc3hip.h mc3hip_get_rows_settled; one GPU)."""
+        assert Z.flags.c_contiguous and lp.flags.c_contiguous and zc.flags.c_contiguous
+        check(self.lib.mc3hip_get_rows_settled(self._ctx, int(row0), len(Z), dptr(Z), dptr(lp),
+                                               iptr(zc)))
+
     def put_rows(self, row0, Z, log_post=None):
         """Install rows another rank produced (host-staged exchange)."""
         Z = f64(Z)

@@ -403,17 +403,26 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
     host = {'rows': 0}
     checkpoint = _Checkpointer()
 
-    def pull_rows(nrows):
+    # one GPU, a run that started here: the rows of a confirmed segment are copied to the host
+    # while the NEXT segment computes (engine.rows_settled_into: a stream of its own)
+    overlap = comm.size == 1 and hasattr(engine, 'rows_settled_into')
+
+    def pull_rows(nrows, settled=False):
         """Rows [0, nrows) on the host, fetching only what was not fetched before (one
-        host copy for the whole run, filled as the reports come)."""
+        host copy for the whole run, filled as the reports come -- or, `settled`, behind
+        the launch of the next segment)."""
         if host['rows'] == 0:
             host['Z'] = np.empty((zlen, nfree))
             host['lp'] = np.empty(zlen)
             host['zc'] = np.empty(zlen, np.int32)
         r0 = host['rows']
         if nrows > r0:
-            Z, lp, zc = engine.rows(r0, nrows - r0)
-            host['Z'][r0:nrows], host['lp'][r0:nrows], host['zc'][r0:nrows] = Z, lp, zc
+            if settled:
+                engine.rows_settled_into(r0, host['Z'][r0:nrows], host['lp'][r0:nrows],
+                                         host['zc'][r0:nrows])
+            else:
+                Z, lp, zc = engine.rows(r0, nrows - r0)
+                host['Z'][r0:nrows], host['lp'][r0:nrows], host['zc'][r0:nrows] = Z, lp, zc
             if r0 < M0:
                 host['zc'][:M0] = zchain0
             host['rows'] = nrows
@@ -448,6 +457,8 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
                 # (not waited for here: snapshot() synchronises -- and, on several GPUs,
                 # is where the ranks agree that the segment completed everywhere)
                 engine.run(todo, sync=False)
+                if overlap and done > 0:
+                    pull_rows(M0 + done*nchains, settled=True)    # (the segment before)
                 done = int(edge)
             nrows = snapshot()
             log.progressbar((nrows + 1.0 - pre_zsize)/(nzchain*nchains))

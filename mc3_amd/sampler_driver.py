@@ -16,6 +16,8 @@ import importlib
 import os
 import sys
 
+import functools
+
 import numpy as np
 
 from . import stats as ms
@@ -158,7 +160,36 @@ def _summary_table(log, inp, output):
         indent=2)
 
 
-def sample(
+def host_threads():
+    """Threads the host-side array math of a run may use: what this process may actually
+    burn -- its CPU affinity AND its cgroup's CPU quota -- and never more than 8.
+
+    Why the library cares (profiles/r06_e2e_stall.txt): the model callable is probed on the host
+    and the statistics of the output are NumPy; on a box that SHOWS 256 CPUs but GRANTS 16
+    (cgroup cpu.max 1600000 100000) OpenBLAS starts 64 threads for a matrix-vector product of a
+    millisecond, the quota of the 100 ms period is gone at once and the kernel freezes every
+    thread of the process for the rest of it -- the "~70 ms wait inside the HIP runtime" of rounds
+    2-5, seen in whatever HIP call the main thread happened to be in.  sample() on C5 with 1e5
+    samples: 100-200 ms per call before, 45 ms with the pools limited."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            with open(path) as f:
+                words = f.read().split()
+            if path.endswith('cpu.max'):
+                if words and words[0] != 'max':
+                    n = min(n, max(1, int(words[0])//int(words[1])))
+            elif words and int(words[0]) > 0:
+                with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                    n = min(n, max(1, int(words[0])//int(f.read().split()[0])))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(8, n))
+
+
+def _sample(
         data=None, uncert=None, func=None, params=None, indparams=[],
         indparams_dict={},
         pmin=None, pmax=None, pstep=None,
@@ -327,3 +358,26 @@ def sample(
             log.msg(log.logname, indent=2)
         log.close()
     return output
+
+
+def _limited(*args, **kwargs):
+    """mc3.sample's signature and output dictionary (`_sample` has the documentation);
+    the host-side thread pools (BLAS, OpenMP) are limited to `host_threads()` for the
+    duration of the call where threadpoolctl is at hand (MC3_AMD_HOST_THREADS=n overrides;
+    0 leaves the pools alone)."""
+    import os
+    want = os.environ.get('MC3_AMD_HOST_THREADS')
+    limit = host_threads() if want is None else int(want)
+    if limit > 0:
+        try:
+            from threadpoolctl import threadpool_limits
+        except ImportError:
+            threadpool_limits = None
+        if threadpool_limits is not None:
+            with threadpool_limits(limits=limit):
+                return _sample(*args, **kwargs)
+    return _sample(*args, **kwargs)
+
+
+# (the signature, the defaults and the documentation a caller sees are _sample's -- mc3.sample's)
+sample = functools.wraps(_sample)(_limited)

@@ -337,7 +337,10 @@ def update_output(output, chain, hsize, engine=None):
     output['bestp'] = chain.bestp
     if not np.all(chain.chainsize > (zburn + hsize)):
         return None
-    zmask = mu.burn_mask(output['zchain'], zburn)
+    # (rows that came from the device engine of a run that started here are in the regular
+    # layout by construction: the scan over zchain that would establish it is skipped)
+    zmask = mu.burn_mask(output['zchain'], zburn,
+                         layout=(0, engine.nchains) if on_device else None)
     regular = on_device and len(zmask) == (engine.refresh_done - zburn)*engine.nchains
     if regular:
         summary = summarise(engine=engine, burn=zburn)

@@ -13,8 +13,23 @@ def default_parnames(npars):
     return np.array([f'Param {i+1}' for i in range(npars)])
 
 
-def burn_mask(zchain, burnin, sort=True):
-    """The index array of ``burn`` alone (no row is copied)."""
+def burn_mask(zchain, burnin, sort=True, layout=None):
+    """The index array of ``burn`` alone (no row is copied).  ``layout = (first, nchains)``: the
+    caller KNOWS the rows are `first` initial ones and then chains 0..nchains-1 in turn (the
+    device's layout, mc3/chain.py:164,288) -- the scan that establishes it is skipped."""
+    if layout is not None:
+        first, nchains = layout
+        niter = (len(zchain) - first)//nchains
+        it = np.arange(min(burnin, niter), niter, dtype=np.int64)
+        if sort:
+            zmask = np.empty((nchains, len(it)), np.int64)
+            np.add(np.arange(nchains, dtype=np.int64)[:, None] + first, (it*nchains)[None, :],
+                   out=zmask)
+        else:
+            zmask = np.empty((len(it), nchains), np.int64)
+            np.add((it*nchains)[:, None] + first, np.arange(nchains, dtype=np.int64)[None, :],
+                   out=zmask)
+        return zmask.reshape(-1)
     return burn(Z=np.empty((len(zchain), 0)), zchain=zchain, burnin=burnin, sort=sort)[2]
 
 
