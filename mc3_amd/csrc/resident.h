@@ -1351,10 +1351,12 @@ struct ResidentTileAsync : ResidentTile<KB, KRMAX> {
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
+                // (every lane writes the one word, from inline assembly: masking the store down
+                // to a lane, or leaving it to the compiler to place, cost 0.1-0.7 us per
+                // iteration of C5 -- A/B on one box, docs/HISTORY.md round 6)
                 ++fin;
-                if (lane == 0)
-                    __hip_atomic_store(&s_done[wv], fin, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                asm volatile("ds_write_b32 %0, %1"
+                             :: "v"(lds_offset(&s_done[wv])), "v"(fin) : "memory");
                 __builtin_amdgcn_s_setprio(1);
                 spins = 0;
                 MC3_RTICK(tq1);
