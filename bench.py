@@ -58,7 +58,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # MI355X_MICROARCH.md: dense FP64 vector / matrix
 LAUNCH_REFRESHES = 16384       # refreshes one launch of a persistent kernel covers
 STEP_LAUNCHES = 18             # persistent launches per step (C2: ~0.35 s of GPU time)
-PMC_FILES = ('r05_c2_pmc.json', 'r04_c2_pmc.json', 'r03_c2_pmc.json', 'r02_c2_pmc.json',
+PMC_FILES = ('r06_c2_pmc.json', 'r05_c2_pmc.json', 'r04_c2_pmc.json', 'r03_c2_pmc.json', 'r02_c2_pmc.json',
              'r01g_c2_pmc.json')
 SIMDS = 1024                   # 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4                # MI355X_MICROARCH.md: peak engine clock (the FP64 issue peak:
