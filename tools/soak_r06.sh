@@ -56,11 +56,11 @@ fi
 if [ $part != soak ]; then
 out=gpurun_out/r06/fuzz_hunt.txt
 : > $out
-echo "== python tools/fuzz_hunt.py 300000 1600 (all generators)" >> $out
-timeout 1500 python tools/fuzz_hunt.py 300000 1600 >> $out 2>&1
-echo "== FUZZ_KIND=5 python tools/fuzz_hunt.py 310000 400 (the wide loops)" >> $out
-FUZZ_KIND=5 timeout 900 python tools/fuzz_hunt.py 310000 400 >> $out 2>&1
-echo "== FUZZ_KIND=2 python tools/fuzz_hunt.py 320000 600 (wavelet likelihood, either model kind)" >> $out
-FUZZ_KIND=2 timeout 900 python tools/fuzz_hunt.py 320000 600 >> $out 2>&1
+echo "== python tools/fuzz_hunt.py 400000 1600 (all generators)" >> $out
+timeout 1500 python tools/fuzz_hunt.py 400000 1600 >> $out 2>&1
+echo "== FUZZ_KIND=5 python tools/fuzz_hunt.py 410000 400 (the wide loops)" >> $out
+FUZZ_KIND=5 timeout 900 python tools/fuzz_hunt.py 410000 400 >> $out 2>&1
+echo "== FUZZ_KIND=2 python tools/fuzz_hunt.py 420000 600 (wavelet likelihood, either model kind)" >> $out
+FUZZ_KIND=2 timeout 900 python tools/fuzz_hunt.py 420000 600 >> $out 2>&1
 tail -20 $out
 fi
