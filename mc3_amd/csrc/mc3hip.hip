@@ -1802,8 +1802,12 @@ static int settle(mc3hip_ctx *c)
 {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->persist_refs <= 0)
+    if (c->persist_refs <= 0) {
+        // (one launch per refresh: nothing can give up, what has run is final)
+        if (c->p2p_ranks <= 1)
+            c->confirmed_done = c->refresh_done;
         return MC3HIP_OK;
+    }
     long long ab = 0;
     HIP_TRY(hipMemcpy(&ab, c->ctl + CTL_ABORT, sizeof ab, hipMemcpyDeviceToHost));
     if (ab == 0) {
@@ -1997,6 +2001,7 @@ int mc3hip_recycle(mc3hip_ctx *c, int64_t keep, uint64_t seed)
     }
     P.seed = seed;
     c->refresh_done = keep;
+    c->confirmed_done = keep;       // (the rows moved: what mc3hip_get_rows_settled may read)
     c->ckpt_valid = false;
     c->ckpt_settled = false;
     c->logpost_gathered = keep;

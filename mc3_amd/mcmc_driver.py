@@ -458,7 +458,10 @@ def mcmc(data, uncert, func, params, indparams, indparams_dict,
                 # is where the ranks agree that the segment completed everywhere)
                 engine.run(todo, sync=False)
                 if overlap and done > 0:
-                    pull_rows(M0 + done*nchains, settled=True)    # (the segment before)
+                    try:
+                        pull_rows(M0 + done*nchains, settled=True)    # (the segment before)
+                    except RuntimeError:
+                        overlap = False     # (rows not confirmed yet: the last pull takes them)
                 done = int(edge)
             nrows = snapshot()
             log.progressbar((nrows + 1.0 - pre_zsize)/(nzchain*nchains))

@@ -548,3 +548,34 @@ def test_chisq_of_mid_run_rows_against_the_reference_kernels(golden_dir):
         P = gpu.expand_free(Z)
     want = [ok.dwt_chisq(quad(p[0:3], prob['indep']), prob['data'], p) for p in P]
     np.testing.assert_allclose(-2.0*lp, want, rtol=1e-10)
+
+
+@pytest.mark.parametrize('no_persist', [False, True])
+def test_rows_of_confirmed_refreshes_are_read_while_the_next_segment_runs(no_persist):
+    """mc3hip_get_rows_settled (round 6: what mcmc() copies to the host while the next segment
+    computes): the rows a sync has confirmed, on a stream of the call's own -- equal to
+    mc3hip_get_rows', refused beyond the confirmed refreshes, also for a context that launches
+    once per refresh; and sample() end to end equals the run that pulls everything at the end."""
+    from mc3_amd import engine, _lib
+    prob = H.quad_problem(ndata=1000, nchains=64, nsamples=64*4000, sampler='demc')
+    with engine.DeviceChains(no_persist=no_persist, **prob) as gpu:
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        n1 = 1500 if not no_persist else 40
+        gpu.run(n1)                                   # (synchronised: confirmed)
+        nrows = gpu.M0 + n1*64
+        Z = np.empty((nrows, gpu.nfree)); lp = np.empty(nrows); zc = np.empty(nrows, np.int32)
+        gpu.run(gpu.nzchain - n1 if not no_persist else 40, sync=False)     # in flight
+        gpu.rows_settled_into(0, Z, lp, zc)
+        with pytest.raises(_lib.Mc3HipError, match='confirmed'):
+            gpu.rows_settled_into(nrows - 8, np.empty((16, gpu.nfree)), np.empty(16),
+                                  np.empty(16, np.int32))
+        gpu.sync()
+        Z2, lp2, zc2 = gpu.rows(0, nrows)
+        np.testing.assert_array_equal(Z, Z2)
+        np.testing.assert_array_equal(lp, lp2)
+        np.testing.assert_array_equal(zc, zc2)
+        orc.run(nrefresh=n1, nthreads=8)
+        np.testing.assert_array_equal(Z[gpu.M0:], orc.Z[gpu.M0:nrows])
