@@ -155,3 +155,22 @@ def test_jit_cache_directory_must_be_private(tmp_path, monkeypatch):
     k1 = jit._key('lean_demc_body<6, false, false, false, false, false, false>')
     monkeypatch.setattr(jit, '_HIPCC_VERSION', 'hipcc 2')
     assert jit._key('lean_demc_body<6, false, false, false, false, false, false>') != k1
+
+
+def test_launch_ledger_without_a_gpu():
+    """The launch ledger (mc3hip_debug_launch_counts): empty before any launch, argument errors
+    by code; and tests/ledger.py finds every kernel instance of the library by its handle --
+    what the GPU suite's last test sets the ledgers of its processes against."""
+    from mc3_amd import _lib
+    lib = _lib.load()
+    assert _lib.launch_counts() == []
+    assert lib.mc3hip_debug_launch_counts(None, 0, None) == _lib.ERR_ARG
+    assert lib.mc3hip_debug_last_kernel(None, None, 0) == _lib.ERR_ARG
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import ledger
+    inst = ledger.instances()
+    fams = {ledger.family(n) for n in inst.values()}
+    assert len(inst) >= 500 and {'lean_demc_kernel', 'resident_async_kernel',
+                                 'wavelet_pipe_kernel', 'persist_kernel'} <= fams
+    text, never = ledger.report({})
+    assert len(never) == len(inst) and 'never launched' in text
