@@ -1394,6 +1394,16 @@ void mc3hip_destroy(mc3hip_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
+    // (the graph that captured the all-gather goes BEFORE the communicator: RCCL counts the
+    // captured launches as references to it, and ncclCommDestroy waits for the last one --
+    // for ever, with more than one rank; found in round 6, the first time the collective ran
+    // with two ranks, tools/rccl_ranks_as_hosts_try.py)
+    if (c->cgraph_exec)
+        (void)hipGraphExecDestroy(c->cgraph_exec);
+    if (c->cgraph)
+        (void)hipGraphDestroy(c->cgraph);
+    c->cgraph_exec = nullptr;
+    c->cgraph = nullptr;
     if (c->comm && g_rccl.CommDestroy)
         g_rccl.CommDestroy(c->comm);
     for (void *p : c->p2p_opened)
@@ -1402,10 +1412,6 @@ void mc3hip_destroy(mc3hip_ctx *c)
         (void)hipGraphExecDestroy(c->graph_exec);
     if (c->graph)
         (void)hipGraphDestroy(c->graph);
-    if (c->cgraph_exec)
-        (void)hipGraphExecDestroy(c->cgraph_exec);
-    if (c->cgraph)
-        (void)hipGraphDestroy(c->cgraph);
     for (void *p : c->allocs)
         (void)hipFree(p);
     if (c->stage)

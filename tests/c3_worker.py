@@ -26,6 +26,18 @@ def main():
     # by the library) instead of the peer-to-peer hand-off; devices=own: every rank on the GPU
     # of its LOCAL_RANK (tests/test_gpu_multidevice.py, boxes with two GPUs and more)
     rccl = extra.get('exchange') == 'rccl'
+    if rccl and os.environ.get('MC3_TEST_RCCL_RANKS_AS_HOSTS'):
+        # several ranks on ONE GPU (the development box): RCCL refuses two ranks of a host on one
+        # device ("Duplicate GPU detected") -- told that every rank is a host of its own it
+        # takes them as nodes of a cluster and connects them through its socket transport over
+        # the loopback interface.  Not a fast path, but the collective of the north star with
+        # N > 1 ranks: bootstrap, ring set-up, the in-place all-gather per refresh, RCCL's own
+        # rank count -- on the box the suite runs on (tests/test_gpu_p2p.py).
+        os.environ['NCCL_HOSTID'] = f"mc3hip-test-host-{os.environ.get('RANK', '0')}"
+        os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
+        os.environ.setdefault('NCCL_IB_DISABLE', '1')
+        os.environ.setdefault('NCCL_NET', 'Socket')
+        os.environ.setdefault('NCCL_SHM_DISABLE', '1')
     device = int(os.environ.get('LOCAL_RANK', '0')) if extra.get('devices') == 'own' else 0
     comm = ranks.worker_comm(use_p2p=not rccl, use_rccl=rccl)
     per_rank = int(extra.get('per_rank', 256))

@@ -105,6 +105,10 @@ def lean_ranks_case(tmp_path, nranks, nref, zlag, delay_ns=0, **shape):
     env = {'MC3HIP_TEST_REMOTE_DELAY_NS': str(delay_ns)} if delay_ns else {}
     if 'turns' in shape:       # (several chains per wave: pretend that fewer workgroups fit)
         env['MC3HIP_PERSIST_CAPACITY'] = str(-(-per_rank//shape['turns']))
+    if shape.get('exchange') == 'rccl' and shape.get('devices') != 'own':
+        # (the ranks share ONE GPU: each is told it is a host of its own, tests/c3_worker.py)
+        env['MC3_TEST_RCCL_RANKS_AS_HOSTS'] = '1'
+        env.setdefault('NCCL_DEBUG', 'ERROR')
     orc = H.make_oracle(prob, zlag=zlag)
     Z0, lp0 = H.initial_population(orc)
     out_path = str(tmp_path / 'c3')
@@ -268,3 +272,19 @@ def test_resident_tiled_plan_abort_is_recovered_by_all_ranks(tmp_path):
         np.testing.assert_array_equal(got['lp'], orc.log_post)
         np.testing.assert_array_equal(got['numaccept'], orc.numaccept[s])
         np.testing.assert_array_equal(got['chisq'], orc.chisq[s])
+
+
+@pytest.mark.parametrize('nranks,zlag', [(2, 0), (2, 2), (4, 0), (4, 1)])
+def test_rccl_all_gather_with_more_than_one_rank_on_the_one_gpu(tmp_path, nranks, zlag):
+    """The collective of the north star with N > 1 ranks, on the box the suite runs on: one
+    launch per refresh + ONE in-place ncclAllGather of the refresh's Z rows, replayed from a
+    hipGraph, over 2 and 4 ranks.  RCCL refuses two ranks of one host on one device, so every
+    rank is told it is a host of its own (NCCL_HOSTID) and RCCL connects them as the nodes of a
+    cluster, through its socket transport over the loopback interface: not a fast path -- but
+    the bootstrap, the ring, the all-gather in place, the captured graph and its teardown are
+    RCCL's own with more than one rank (round 6: the first such run found mc3hip_destroy
+    waiting for ever in ncclCommDestroy -- the captured graph must go first).  tests/c3_worker.py
+    asserts RCCL's own rank count and plan.comm_graph > 0; every replica == the oracle's run of
+    the whole ensemble, strict and in a cadence.  (With a GPU per rank: test_gpu_multidevice.py.)
+    Reference: mc3/mcmc_driver.py:204-221,300-307."""
+    lean_ranks_case(tmp_path, nranks, 45, zlag, per_rank=32, ndata=300, exchange='rccl')
