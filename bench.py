@@ -1087,18 +1087,6 @@ def rccl_segment(args, ctl, make_engine, build_problem, nchains, nlocal, chain0,
     except Exception as e:      # noqa: BLE001
         ok, err = False, str(e)
     saved = (ctl.native, ctl.mode)
-    devices = ctl.all_gather(int(device))
-    ranks_as_hosts = len(set(devices)) < len(devices)
-    if ranks_as_hosts:
-        # several ranks on ONE GPU (a test set-up; the driver gives every rank its own): RCCL
-        # refuses two ranks of a host on one device, so every rank calls itself a host and RCCL
-        # connects them through its socket transport over the loopback interface -- the
-        # collective runs with its real rank count, its rate says nothing about xGMI
-        os.environ['NCCL_HOSTID'] = f'mc3hip-bench-host-{ctl.rank}'
-        for key, val in (('NCCL_SOCKET_IFNAME', 'lo'), ('NCCL_IB_DISABLE', '1'),
-                         ('NCCL_NET', 'Socket'), ('NCCL_SHM_DISABLE', '1'),
-                         ('NCCL_DEBUG', 'ERROR')):
-            os.environ.setdefault(key, val)
     if ctl._all_ok(ok):
         ctl._setup_rccl(g)
         ok = ctl.mode == 'rccl'
@@ -1123,10 +1111,7 @@ def rccl_segment(args, ctl, make_engine, build_problem, nchains, nlocal, chain0,
                'us_per_refresh': dt/ntimed*1e6,
                'million_chain_steps_per_s': nchains*ntimed*args.thinning/dt/1e6,
                'hipgraph_refreshes_per_replay': plan['comm_graph'],
-               'payload_bytes_per_rank': nlocal*128,
-               'transport': ('RCCL socket transport over loopback: the ranks share ONE GPU and '
-                             'each calls itself a host (NCCL_HOSTID) -- functional, not a rate '
-                             'for xGMI') if ranks_as_hosts else 'RCCL\'s own choice'}
+               'payload_bytes_per_rank': nlocal*128}
     else:
         out = {'error': err or 'not available on every rank'}
     if g is not None:
