@@ -274,6 +274,12 @@ def test_resident_tiled_plan_abort_is_recovered_by_all_ranks(tmp_path):
         np.testing.assert_array_equal(got['chisq'], orc.chisq[s])
 
 
+@pytest.mark.skipif(not os.environ.get('MC3_TEST_RCCL_ON_ONE_GPU'),
+                    reason='opt-in (MC3_TEST_RCCL_ON_ONE_GPU=1): RCCL over its socket transport '
+                           'between ranks that share ONE GPU -- passed on three boxes in round 6 '
+                           '(profiles/r06_rccl_ranks_on_one_gpu.txt), but a heavier run of the '
+                           'same set-up (bench.py, 10 000 refreshes) coincided with the loss of '
+                           'a box, so the suite does not run it unasked')
 @pytest.mark.parametrize('nranks,zlag', [(2, 0), (2, 2), (4, 0), (4, 1)])
 def test_rccl_all_gather_with_more_than_one_rank_on_the_one_gpu(tmp_path, nranks, zlag):
     """The collective of the north star with N > 1 ranks, on the box the suite runs on: one
