@@ -80,8 +80,9 @@ hipError_t tile_set_attr(mc3hip_ctx *c)
     case 4: if (lin) { TILE_ATTR(4, true) } else { TILE_ATTR(4, false) } break;
     // (design matrices of 2..15 columns go through the matrix cores: tile_uses_mfma; the
     // vector-unit tile kernel keeps the one- and the sixteen-column instances)
-    case 8: if (!lin) { TILE_ATTR(8, false) } break;
-    case 12: if (!lin) { TILE_ATTR(12, false) } break;
+    // (should one of those ever come this way: the sixteen-column instance holds them too)
+    case 8: if (lin) { TILE_ATTR(16, true) } else { TILE_ATTR(8, false) } break;
+    case 12: if (lin) { TILE_ATTR(16, true) } else { TILE_ATTR(12, false) } break;
     default: if (lin) { TILE_ATTR(16, true) } else { TILE_ATTR(16, false) } break;
     }
 #undef TILE_ATTR
@@ -108,8 +109,8 @@ void launch_tile(mc3hip_ctx *c)
     const bool lin = c->mt == MT_LINEAR;
     switch (c->tile_kmax) {
     case 4: lin ? launch_tile_t<4, true>(c) : launch_tile_t<4, false>(c); break;
-    case 8: if (!lin) launch_tile_t<8, false>(c); break;
-    case 12: if (!lin) launch_tile_t<12, false>(c); break;
+    case 8: lin ? launch_tile_t<16, true>(c) : launch_tile_t<8, false>(c); break;
+    case 12: lin ? launch_tile_t<16, true>(c) : launch_tile_t<12, false>(c); break;
     default: lin ? launch_tile_t<16, true>(c) : launch_tile_t<16, false>(c); break;
     }
 }
