@@ -440,20 +440,6 @@ inline bool lean_courier(const mc3hip_ctx *c, bool p2p)
            !(c->flags & MC3HIP_FLAG_NO_COURIER) && !env_text("MC3HIP_NO_COURIER");
 }
 
-// the headline loop with the draws of 64 consecutive refreshes computed at once (lean_demc_kernel
-// BATCH).  Written for ensembles of more than one wave per SIMD, where the loop is bound by the
-// instructions it issues; since the row is published where it is decided (round 6) it is the
-// faster flavour at every size -- 64 / 256 / 512 / 1024 chains: 57.9 / 227.1 / 438.8 / 814.7 M
-// chain-steps/s against 56.4 / 222.5 / 431.7 / 773.8 with the draws made refresh by refresh
-// (profiles/r06_handoff_variants.txt) -- and the default (MC3HIP_LEAN_BATCH=0: the other one).
-inline bool lean_batch(const mc3hip_ctx *c)
-{
-    (void)c;
-    if (const char *e = env_text("MC3HIP_LEAN_BATCH"))
-        return atoi(e) != 0;
-    return true;
-}
-
 // every coefficient free, no Gaussian priors, no shared parameters (otherwise: the FX instances)
 inline bool lean_plain_shape(const mc3hip_ctx *c)
 {

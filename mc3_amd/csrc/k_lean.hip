@@ -60,9 +60,12 @@ chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
             return lean_demc_kernel<MT, false, false, true>;
         if (c->P.nfree != c->P.nparams || c->P.ngprior > 0 || c->P.nshare > 0)
             return lean_demc_kernel<MT, false, true>;
-        if (lean_batch(c))
-            return lean_demc_kernel<MT, false, false, false, true>;
-        return lean_demc_kernel<MT, false>;
+        // the plain shape: the draws of 64 refreshes at once (BATCH).  Written for ensembles of
+        // more than one wave per SIMD; since the row is published where it is decided (round 6)
+        // it is the faster flavour at every size -- 64 / 256 / 512 / 1024 chains: 57.9 / 227.1 /
+        // 438.8 / 814.7 M chain-steps/s against 56.4 / 222.5 / 431.7 / 773.8 with the draws made
+        // refresh by refresh (profiles/r06_handoff_variants.txt) -- and the only one built
+        return lean_demc_kernel<MT, false, false, false, true>;
     }
     if (c->P.sampler == MC3HIP_DEMC)
         return fast_instance_tt<MT, MC3HIP_DEMC>(c, p2p);

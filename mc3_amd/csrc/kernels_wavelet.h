@@ -972,20 +972,20 @@ __global__ __launch_bounds__(576) void wavelet_cw_kernel(const DevProblem P, con
 #ifdef MC3HIP_PIPE_DIAG
 #define PIPE_SYNC(i)                                                                     \
     do {                                                                                  \
-        const unsigned long long a_ = __builtin_amdgcn_s_memtime();                       \
+        const unsigned long long a_ = (10ull * __builtin_amdgcn_s_memrealtime());                       \
         dg_work[i] += a_ - dg_t0;                                                         \
         block_sync<9>();                                                                  \
-        const unsigned long long b_ = __builtin_amdgcn_s_memtime();                       \
+        const unsigned long long b_ = (10ull * __builtin_amdgcn_s_memrealtime());                       \
         dg_dur[i] += b_ - dg_t0;                                                          \
         dg_t0 = b_;                                                                       \
     } while (0)
 #define PIPE_DIAG_DECL                                                                    \
     unsigned long long dg_work[6] = {0, 0, 0, 0, 0, 0}, dg_dur[6] = {0, 0, 0, 0, 0, 0};   \
     unsigned long long dg_part[5] = {0, 0, 0, 0, 0}, dg_p0 = 0;                           \
-    unsigned long long dg_t0 = __builtin_amdgcn_s_memtime(), dg_n = 0
+    unsigned long long dg_t0 = (10ull * __builtin_amdgcn_s_memrealtime()), dg_n = 0
 #define PIPE_PART(i)                                                                      \
     do {                                                                                  \
-        const unsigned long long a_ = __builtin_amdgcn_s_memtime();                       \
+        const unsigned long long a_ = (10ull * __builtin_amdgcn_s_memrealtime());                       \
         if ((i) >= 0)                                                                     \
             dg_part[(i) < 0 ? 0 : (i)] += a_ - dg_p0;                                     \
         dg_p0 = a_;                                                                       \
@@ -1407,12 +1407,22 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
 #endif
 #ifdef MC3HIP_PIPE_DIAG
     if (blockIdx.x == 0 && lane == 0)
-        printf("level 0 of waves 0..7: %llu %llu %llu %llu %llu %llu %llu %llu cycles (%llu likelihoods)\n",
+        printf("level 0 of waves 0..7: %llu %llu %llu %llu %llu %llu %llu %llu ns (%llu likelihoods)\n",
                mc3_pipe_diag[0] / mc3_pipe_diag[8], mc3_pipe_diag[1] / mc3_pipe_diag[8],
                mc3_pipe_diag[2] / mc3_pipe_diag[8], mc3_pipe_diag[3] / mc3_pipe_diag[8],
                mc3_pipe_diag[4] / mc3_pipe_diag[8], mc3_pipe_diag[5] / mc3_pipe_diag[8],
                mc3_pipe_diag[6] / mc3_pipe_diag[8], mc3_pipe_diag[7] / mc3_pipe_diag[8],
                mc3_pipe_diag[8]);
+        printf("from the slot's start to level 0's, waves 0..7: %llu %llu %llu %llu %llu %llu %llu %llu ns\n",
+               mc3_pipe_diag[24] / mc3_pipe_diag[8], mc3_pipe_diag[25] / mc3_pipe_diag[8],
+               mc3_pipe_diag[26] / mc3_pipe_diag[8], mc3_pipe_diag[27] / mc3_pipe_diag[8],
+               mc3_pipe_diag[28] / mc3_pipe_diag[8], mc3_pipe_diag[29] / mc3_pipe_diag[8],
+               mc3_pipe_diag[30] / mc3_pipe_diag[8], mc3_pipe_diag[31] / mc3_pipe_diag[8]);
+        printf("stage A up to its last barrier, waves 0..7: %llu %llu %llu %llu %llu %llu %llu %llu ns\n",
+               mc3_pipe_diag[16] / mc3_pipe_diag[8], mc3_pipe_diag[17] / mc3_pipe_diag[8],
+               mc3_pipe_diag[18] / mc3_pipe_diag[8], mc3_pipe_diag[19] / mc3_pipe_diag[8],
+               mc3_pipe_diag[20] / mc3_pipe_diag[8], mc3_pipe_diag[21] / mc3_pipe_diag[8],
+               mc3_pipe_diag[22] / mc3_pipe_diag[8], mc3_pipe_diag[23] / mc3_pipe_diag[8]);
 #endif
     if (mine && oob)
         atomicAdd(&P.outbounds[lane], oob);
@@ -1945,12 +1955,22 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
         printf("chain wave (one chain): prepare %llu window %llu wait %llu decide %llu issue %llu\n",
                dg_part[0] / dg_n, dg_part[1] / dg_n, dg_part[2] / dg_n, dg_part[3] / dg_n,
                dg_part[4] / dg_n);
-        printf("level 0 of waves 0..7: %llu %llu %llu %llu %llu %llu %llu %llu cycles (%llu likelihoods)\n",
+        printf("level 0 of waves 0..7: %llu %llu %llu %llu %llu %llu %llu %llu ns (%llu likelihoods)\n",
                mc3_pipe_diag[0] / mc3_pipe_diag[8], mc3_pipe_diag[1] / mc3_pipe_diag[8],
                mc3_pipe_diag[2] / mc3_pipe_diag[8], mc3_pipe_diag[3] / mc3_pipe_diag[8],
                mc3_pipe_diag[4] / mc3_pipe_diag[8], mc3_pipe_diag[5] / mc3_pipe_diag[8],
                mc3_pipe_diag[6] / mc3_pipe_diag[8], mc3_pipe_diag[7] / mc3_pipe_diag[8],
                mc3_pipe_diag[8]);
+        printf("from the slot's start to level 0's, waves 0..7: %llu %llu %llu %llu %llu %llu %llu %llu ns\n",
+               mc3_pipe_diag[24] / mc3_pipe_diag[8], mc3_pipe_diag[25] / mc3_pipe_diag[8],
+               mc3_pipe_diag[26] / mc3_pipe_diag[8], mc3_pipe_diag[27] / mc3_pipe_diag[8],
+               mc3_pipe_diag[28] / mc3_pipe_diag[8], mc3_pipe_diag[29] / mc3_pipe_diag[8],
+               mc3_pipe_diag[30] / mc3_pipe_diag[8], mc3_pipe_diag[31] / mc3_pipe_diag[8]);
+        printf("stage A up to its last barrier, waves 0..7: %llu %llu %llu %llu %llu %llu %llu %llu ns\n",
+               mc3_pipe_diag[16] / mc3_pipe_diag[8], mc3_pipe_diag[17] / mc3_pipe_diag[8],
+               mc3_pipe_diag[18] / mc3_pipe_diag[8], mc3_pipe_diag[19] / mc3_pipe_diag[8],
+               mc3_pipe_diag[20] / mc3_pipe_diag[8], mc3_pipe_diag[21] / mc3_pipe_diag[8],
+               mc3_pipe_diag[22] / mc3_pipe_diag[8], mc3_pipe_diag[23] / mc3_pipe_diag[8]);
     }
 #endif
     if (mine && oob)
@@ -2017,17 +2037,27 @@ __global__ __launch_bounds__(704) void wavelet_pipe_kernel(const DevProblem P, c
         // reciprocals, the ordered log-determinant sum: ~2 500 dependent cycles), needed by the
         // end of stage A; a wave of its own so that the three helpers sit on three SIMDs
         int par = 0;
-        block_sync<9>();                                // (A)
+        PIPE_DIAG_DECL;
+        PIPE_SYNC(0);                                   // (A)
         for (;;) {
             const int cmd = s_cmd[par];
             if (cmd == CW_STOP)
-                return;
+                break;
             if (cmd == CW_GO)
                 wavelet_noise_terms(par ? np1 : L.nextp, P.nparams, M, par ? tab1 : L.tab);
-            for (int k = 0; k <= nhalo; ++k)
-                block_sync<9>();
+            PIPE_SYNC(1);                               // the halo barriers of stage A
+            PIPE_SYNC(2);
+            PIPE_SYNC(3);
+            if (nhalo > 3)
+                PIPE_SYNC(4);
+            PIPE_SYNC(5);                               // (1) slot s
             par ^= 1;
+#ifdef MC3HIP_PIPE_DIAG
+            ++dg_n;
+#endif
         }
+        PIPE_DIAG_PRINT("noise");
+        return;
     }
     if (wave == 9) {
         // ---- the tail wave ------------------------------------------------------------------
@@ -2075,6 +2105,12 @@ __global__ __launch_bounds__(704) void wavelet_pipe_kernel(const DevProblem P, c
     int par = 0;
     block_sync<9>();                                    // (A)
     for (;;) {
+#ifdef MC3HIP_PIPE_DIAG
+        const unsigned long long dg_slot0 = 10ull * __builtin_amdgcn_s_memrealtime();
+#define PIPE_DIAG_SLOT0 , dg_slot0
+#else
+#define PIPE_DIAG_SLOT0
+#endif
         const int cmd = s_cmd[par];
         const double *np = par ? np1 : L.nextp;
         double *tab = par ? tab1 : L.tab;
@@ -2091,10 +2127,11 @@ __global__ __launch_bounds__(704) void wavelet_pipe_kernel(const DevProblem P, c
         }
         if (B == 32)
             wavelet_body<8, MT, 32, false, true, true>(P, np, L.part, flag, tab, L.halo, L.xs,
-                                                       nullptr, 0, nullptr, 0, &model);
+                                                       nullptr, 0, nullptr, 0, &model PIPE_DIAG_SLOT0);
         else
             wavelet_body<8, MT, 16, false, true, true>(P, np, L.part, flag, tab, L.halo, L.xs,
-                                                       nullptr, 0, nullptr, 0, &model);
+                                                       nullptr, 0, nullptr, 0, &model PIPE_DIAG_SLOT0);
+#undef PIPE_DIAG_SLOT0
     }
 }
 

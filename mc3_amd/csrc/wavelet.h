@@ -315,7 +315,7 @@ __device__ __forceinline__ void wavelet_noise_terms(const double *s_nextp, int n
 // stage-A sums with the weights right away, and the two barriers that waited for the noise
 // terms and for those sums are gone.
 #ifdef MC3HIP_PIPE_DIAG
-__device__ unsigned long long mc3_pipe_diag[16];
+__device__ unsigned long long mc3_pipe_diag[32];   // [0..7] level 0, [8] likelihoods, [16..23] stage A up to its last barrier, [24..31] from the slot's start to level 0's
 #endif
 // PIPE (kernels_wavelet.h wavelet_pipe_kernel): stage A only -- everything behind barrier (1) is
 // run by a wave of its own (PipeTail below) while these waves start on the next likelihood.
@@ -330,7 +330,11 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
                                                double *s_halo, const double *xs,
                                                const double *values = nullptr, int npre = 0,
                                                const double *accP = nullptr, int sawinf0 = 0,
-                                               const Model<MT> *ready_model = nullptr)
+                                               const Model<MT> *ready_model = nullptr
+#ifdef MC3HIP_PIPE_DIAG
+                                               , unsigned long long dg_slot0 = 0
+#endif
+                                               )
 {
     constexpr int T = 64 * WPC;
     constexpr int NLA = ilog2c(B);                      // levels of stage A (N >= 4)
@@ -363,7 +367,7 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
     if constexpr (WPC == 1 && !NX)
         wavelet_noise_terms(s_nextp, P.nparams, M, s_tab);
 #ifdef MC3HIP_PIPE_DIAG
-    const unsigned long long dg_in = __builtin_amdgcn_s_memtime();
+    const unsigned long long dg_in = (10ull * __builtin_amdgcn_s_memrealtime());
 #endif
     MC3_LSTAMP(8);
     // ---- stage A: log2 B levels in registers ------------------------------------------
@@ -381,8 +385,9 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
         accA[0] = wavelet_level0<WPC, MT, B, false, HB + 2>(P, model, xs, me, next, Ta, sawinf, v);
 #ifdef MC3HIP_PIPE_DIAG
     if (PIPE && blockIdx.x == 0 && (tid & 63) == 0) {
-        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        const unsigned long long now = (10ull * __builtin_amdgcn_s_memrealtime());
         atomicAdd(&mc3_pipe_diag[tid >> 6], now - dg_in);
+        atomicAdd(&mc3_pipe_diag[24 + (tid >> 6)], dg_in - dg_slot0);
         if (tid == 0)
             atomicAdd(&mc3_pipe_diag[8], 1ull);
     }
@@ -418,6 +423,10 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
             s_flag[1] = 1;
         if constexpr (CW)
             s_part[tid] = (active && N >= 4) ? stage_a_sum() : 0.0;
+#ifdef MC3HIP_PIPE_DIAG
+        if (PIPE && blockIdx.x == 0 && (tid & 63) == 0)
+            atomicAdd(&mc3_pipe_diag[16 + (tid >> 6)], (10ull * __builtin_amdgcn_s_memrealtime()) - dg_in);
+#endif
         block_sync<WPC>();                              // (1) the T values are in LDS
         if constexpr (PIPE)
             return 0.0;

@@ -110,13 +110,6 @@ def one_gpu_big_ensembles_grid():
                    poly_case(ncoef, sampler, 'multi', nchains=800, nref=4), 1)
 
 
-def one_gpu_unbatched_grid():
-    """the headline loop with the draws made refresh by refresh (MC3HIP_LEAN_BATCH=0: the default
-    until round 6, below 1 025 chains)"""
-    for ncoef in DEGREES:
-        yield (f'poly{ncoef}-demc-unbatched', poly_case(ncoef, 'demc', 'plain', nchains=12, nref=80), 1)
-
-
 def one_gpu_lag_grid():
     """the declared cadence on one GPU: zlag 1 and 3, with and without thinning"""
     for ncoef, flavour, cpw, zlag in itertools.product(DEGREES, ('plain', 'fx', 'thin', 'thinfx'),

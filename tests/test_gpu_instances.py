@@ -71,15 +71,6 @@ def test_lean_family_on_one_gpu(eng, label):
     check(eng, prob, cpw)
 
 
-@pytest.mark.parametrize('label', [label for label, _, _ in S.one_gpu_unbatched_grid()])
-def test_headline_loop_with_the_draws_made_refresh_by_refresh(eng, label):
-    prob = {lab: p for lab, p, _ in S.one_gpu_unbatched_grid()}[label]
-    with env(MC3HIP_LEAN_BATCH=0):
-        plan, kernel = check(eng, prob, 1)
-    plain = 'Lb0E'*6 in kernel or ', '.join(['false']*6) in kernel    # (mangled or not)
-    assert plan['fast'] == 2 and 'lean_demc_kernel' in kernel and plain, kernel
-
-
 @pytest.mark.parametrize('label', sorted(LAG))
 def test_declared_cadence_on_one_gpu(eng, label):
     prob, cpw = LAG[label]

@@ -1027,14 +1027,11 @@ def test_wavelet_lean_chain_wave_resume_abort_and_switch(eng, monkeypatch, sampl
     gpu.close()
 
 
-@pytest.mark.parametrize('batch', ['1', '0'])
 @pytest.mark.parametrize('case', ['quad', 'tight', 'ragged', 'resume'])
-def test_lean_demc_with_the_draws_of_64_refreshes_at_once(eng, monkeypatch, case, batch):
-    """lean_demc_kernel BATCH (the default at every size since round 6; '0': the flavour that
-    makes its draws refresh by refresh): Philox, log u and the partners of 64 consecutive
-    refreshes computed at once, one refresh per lane; launches that start and stop inside a
-    batch."""
-    monkeypatch.setenv('MC3HIP_LEAN_BATCH', batch)
+def test_lean_demc_with_the_draws_of_64_refreshes_at_once(eng, case):
+    """lean_demc_kernel BATCH (the plain shape's loop at every size since round 6): Philox, log u
+    and the partners of 64 consecutive refreshes computed at once, one refresh per lane; launches
+    that start and stop inside a batch."""
     if case == 'ragged':
         prob = H.quad_problem(ndata=37, nchains=9, nsamples=9*400)
     elif case == 'tight':
