@@ -1418,6 +1418,16 @@ __device__ __forceinline__ void pipe_chain_wave(const DevProblem &P, const int n
                mc3_pipe_diag[26] / mc3_pipe_diag[8], mc3_pipe_diag[27] / mc3_pipe_diag[8],
                mc3_pipe_diag[28] / mc3_pipe_diag[8], mc3_pipe_diag[29] / mc3_pipe_diag[8],
                mc3_pipe_diag[30] / mc3_pipe_diag[8], mc3_pipe_diag[31] / mc3_pipe_diag[8]);
+        printf("arrival at the first halo barrier, waves 0..7: %llu %llu %llu %llu %llu %llu %llu %llu ns\n",
+               mc3_pipe_diag[32] / mc3_pipe_diag[8], mc3_pipe_diag[33] / mc3_pipe_diag[8],
+               mc3_pipe_diag[34] / mc3_pipe_diag[8], mc3_pipe_diag[35] / mc3_pipe_diag[8],
+               mc3_pipe_diag[36] / mc3_pipe_diag[8], mc3_pipe_diag[37] / mc3_pipe_diag[8],
+               mc3_pipe_diag[38] / mc3_pipe_diag[8], mc3_pipe_diag[39] / mc3_pipe_diag[8]);
+        printf("arrival at the second halo barrier, waves 0..7: %llu %llu %llu %llu %llu %llu %llu %llu ns\n",
+               mc3_pipe_diag[40] / mc3_pipe_diag[8], mc3_pipe_diag[41] / mc3_pipe_diag[8],
+               mc3_pipe_diag[42] / mc3_pipe_diag[8], mc3_pipe_diag[43] / mc3_pipe_diag[8],
+               mc3_pipe_diag[44] / mc3_pipe_diag[8], mc3_pipe_diag[45] / mc3_pipe_diag[8],
+               mc3_pipe_diag[46] / mc3_pipe_diag[8], mc3_pipe_diag[47] / mc3_pipe_diag[8]);
         printf("stage A up to its last barrier, waves 0..7: %llu %llu %llu %llu %llu %llu %llu %llu ns\n",
                mc3_pipe_diag[16] / mc3_pipe_diag[8], mc3_pipe_diag[17] / mc3_pipe_diag[8],
                mc3_pipe_diag[18] / mc3_pipe_diag[8], mc3_pipe_diag[19] / mc3_pipe_diag[8],
@@ -1966,6 +1976,16 @@ __device__ __forceinline__ void pipe_chain_wave_one(const DevProblem &P, const i
                mc3_pipe_diag[26] / mc3_pipe_diag[8], mc3_pipe_diag[27] / mc3_pipe_diag[8],
                mc3_pipe_diag[28] / mc3_pipe_diag[8], mc3_pipe_diag[29] / mc3_pipe_diag[8],
                mc3_pipe_diag[30] / mc3_pipe_diag[8], mc3_pipe_diag[31] / mc3_pipe_diag[8]);
+        printf("arrival at the first halo barrier, waves 0..7: %llu %llu %llu %llu %llu %llu %llu %llu ns\n",
+               mc3_pipe_diag[32] / mc3_pipe_diag[8], mc3_pipe_diag[33] / mc3_pipe_diag[8],
+               mc3_pipe_diag[34] / mc3_pipe_diag[8], mc3_pipe_diag[35] / mc3_pipe_diag[8],
+               mc3_pipe_diag[36] / mc3_pipe_diag[8], mc3_pipe_diag[37] / mc3_pipe_diag[8],
+               mc3_pipe_diag[38] / mc3_pipe_diag[8], mc3_pipe_diag[39] / mc3_pipe_diag[8]);
+        printf("arrival at the second halo barrier, waves 0..7: %llu %llu %llu %llu %llu %llu %llu %llu ns\n",
+               mc3_pipe_diag[40] / mc3_pipe_diag[8], mc3_pipe_diag[41] / mc3_pipe_diag[8],
+               mc3_pipe_diag[42] / mc3_pipe_diag[8], mc3_pipe_diag[43] / mc3_pipe_diag[8],
+               mc3_pipe_diag[44] / mc3_pipe_diag[8], mc3_pipe_diag[45] / mc3_pipe_diag[8],
+               mc3_pipe_diag[46] / mc3_pipe_diag[8], mc3_pipe_diag[47] / mc3_pipe_diag[8]);
         printf("stage A up to its last barrier, waves 0..7: %llu %llu %llu %llu %llu %llu %llu %llu ns\n",
                mc3_pipe_diag[16] / mc3_pipe_diag[8], mc3_pipe_diag[17] / mc3_pipe_diag[8],
                mc3_pipe_diag[18] / mc3_pipe_diag[8], mc3_pipe_diag[19] / mc3_pipe_diag[8],

@@ -72,10 +72,18 @@ __device__ __forceinline__ double block_level(double (&v)[CAP])
 // exchanged through `hb` (two buffers of `stride` double2, indexed by level parity);
 // SYNC = workgroup barrier (stage A) or none (one wave, stage B).  accs[LEV], accs[LEV+1],
 // ... receive the levels' sums of squared details (weighted later, in level order).
+#ifdef MC3HIP_PIPE_DIAG
+__device__ unsigned long long mc3_pipe_diag[64];   // [0..7] level 0, [8] likelihoods, [16..23] stage A up to its last barrier, [24..31] from the slot's start to level 0's, [32..39] arrival at the first halo barrier, [40..47] at the second
+#define PIPE_DIAG_ARG , unsigned long long dg0 = 0
+#define PIPE_DIAG_PASS , dg0
+#else
+#define PIPE_DIAG_ARG
+#define PIPE_DIAG_PASS
+#endif
 template <int NV, int CAP, int WPC, bool SYNC, int LEV, int NACC>
 __device__ __forceinline__ void block_levels(double (&v)[CAP], double (&accs)[NACC],
                                              double2 *hb, int stride, int me, int next,
-                                             bool active)
+                                             bool active PIPE_DIAG_ARG)
 {
     if constexpr (NV >= 2) {
         static_assert(LEV < NACC, "one slot per level");
@@ -83,6 +91,18 @@ __device__ __forceinline__ void block_levels(double (&v)[CAP], double (&accs)[NA
             double2 *h = hb + (LEV & 1) * stride;
             if (active)
                 h[me] = make_double2(v[0], v[1]);
+#ifdef MC3HIP_PIPE_DIAG
+            if (dg0 != 0 && LEV <= 2) {
+                // (everything this wave has issued is done -- THEN the clock)
+#pragma unroll
+                for (int q = 0; q < NV; ++q)
+                    asm volatile("; done" : "+v"(v[q]));
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+                const unsigned long long now = 10ull * __builtin_amdgcn_s_memrealtime();
+                if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)
+                    atomicAdd(&mc3_pipe_diag[32 + 8 * (LEV - 1) + (threadIdx.x >> 6)], now - dg0);
+            }
+#endif
             block_sync<WPC>();
             const double2 hv = h[next];
             v[NV] = hv.x;
@@ -94,7 +114,8 @@ __device__ __forceinline__ void block_levels(double (&v)[CAP], double (&accs)[NA
             v[NV + 1] = wave_rol1(v[1]);
         }
         accs[LEV] = block_level<NV, CAP>(v);
-        block_levels<NV / 2, CAP, WPC, SYNC, LEV + 1, NACC>(v, accs, hb, stride, me, next, active);
+        block_levels<NV / 2, CAP, WPC, SYNC, LEV + 1, NACC>(v, accs, hb, stride, me, next, active
+                                                            PIPE_DIAG_PASS);
     }
 }
 
@@ -314,9 +335,6 @@ __device__ __forceinline__ void wavelet_noise_terms(const double *s_nextp, int n
 // takes part in every workgroup barrier here, doing nothing in between): a thread folds its
 // stage-A sums with the weights right away, and the two barriers that waited for the noise
 // terms and for those sums are gone.
-#ifdef MC3HIP_PIPE_DIAG
-__device__ unsigned long long mc3_pipe_diag[32];   // [0..7] level 0, [8] likelihoods, [16..23] stage A up to its last barrier, [24..31] from the slot's start to level 0's
-#endif
 // PIPE (kernels_wavelet.h wavelet_pipe_kernel): stage A only -- everything behind barrier (1) is
 // run by a wave of its own (PipeTail below) while these waves start on the next likelihood.
 // NX (one wave): the noise terms are a HELPER wave's work -- it is computing them while this
@@ -395,8 +413,13 @@ __device__ __forceinline__ double wavelet_body(const DevProblem &P, const double
     MC3_LSTAMP(14);
     double2 *halo = reinterpret_cast<double2 *>(s_halo);  // [2][T]
     if (N >= 4) {
+#ifdef MC3HIP_PIPE_DIAG
+        block_levels<B / 2, HB + 2, WPC, true, 1, (NLA > 0 ? NLA : 1)>(v, accA, halo, T, me, next,
+                                                                        active, PIPE ? dg_slot0 : 0);
+#else
         block_levels<B / 2, HB + 2, WPC, true, 1, (NLA > 0 ? NLA : 1)>(v, accA, halo, T, me, next,
                                                                         active);
+#endif
         nn = Ta;                                        // one value per thread
     }
     MC3_LSTAMP(9);
