@@ -196,14 +196,15 @@ def cpu_baseline(target_seconds=8.0):
     """The oracle (oracle/oracle_lockstep.c: the same lockstep chain update in plain C) on this
     box's host cores, the same C2 workload, bounded to ~target_seconds per figure -- TWICE:
 
-    * ``port-processes`` (the reference's layout): worker PROCESSES with the
+    * ``layout: processes`` (the reference's layout): worker PROCESSES with the
       chains strided over them, worker i advancing chains i, i + ncpu, ... one after another
       (mc3/chain.py:163,190-191) and all of them meeting once per refresh (the reference:
       once per iteration through pipes to the hub, mcmc_driver.py:300-307; here a barrier in
       shared memory, the cheapest meeting there is) -- ls_run_worker;
-    * ``port-threads``: OpenMP threads of one process over the chains (ls_run).
+    * ``layout: threads``: OpenMP threads of one process over the chains (ls_run).
 
-    ``value`` is the faster of the two (``kind`` says which), the other is reported beside it
+    ``value`` is the faster of the two (``layout`` says which; ``kind`` is "port" for both: the
+    oracle, not a build of the reference), the other is reported beside it
     (``port_threads`` / ``port_processes``).  Each with the worker / thread count that is
     fastest in a short calibration over 1..usable cores (a container may see more CPUs than it may use).  Runs in a child process of its own
     that never loads the HIP runtime (bench.py --cpu-baseline-child): the workers are forked."""
@@ -236,18 +237,20 @@ def cpu_baseline(target_seconds=8.0):
         while time.perf_counter() - t0 < target_seconds and n + chunk <= nmax:
             dt += step(best, chunk)
             n += chunk
+        # (`kind`: the contract's word -- the oracle, not a build of the reference; `layout`: which
+        # of the two ways of putting it on the cores)
         return {'value': CHAINS_PER_GPU*n/dt/1e6, 'unit': 'million chain-steps/sec',
-                'cores': best, 'kind': label, 'iterations': n, 'seconds': dt}
+                'cores': best, 'kind': 'port', 'layout': label, 'iterations': n, 'seconds': dt}
 
     orc_p = fresh(True)
-    procs = measure(lambda k, n: orc_p.run_processes(n, k), 'port-processes')
+    procs = measure(lambda k, n: orc_p.run_processes(n, k), 'processes')
     orc_t = fresh(False)
 
     def threads(k, n):
         t0 = time.perf_counter()
         orc_t.run(nrefresh=n, nthreads=k)
         return time.perf_counter() - t0
-    thr = measure(threads, 'port-threads')
+    thr = measure(threads, 'threads')
     procs['sample'] = (
         f'{procs.pop("iterations")} iterations of the same 256-chain C2 workload '
         f'({procs.pop("seconds"):.1f} s), oracle_lockstep.c ls_run_worker: {procs["cores"]} worker '

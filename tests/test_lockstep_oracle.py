@@ -194,7 +194,7 @@ def test_lagged_cadence_samples_the_same_posterior():
 
 @pytest.mark.parametrize('sampler,thinning', [('demc', 1), ('snooker', 2), ('mrw', 1)])
 def test_worker_processes_equal_threads(sampler, thinning):
-    """oracle_lockstep.c ls_run_worker (bench.py's cpu_baseline "port-processes", SURVEY.md
+    """oracle_lockstep.c ls_run_worker (bench.py's cpu_baseline layout "processes", SURVEY.md
     8d(ii)): the run laid out as the reference's fan-out -- worker PROCESSES, worker i advancing
     chains i, i + ncpu, ... (mc3/chain.py:163,190-191), one meeting per refresh in shared
     memory -- equals the threaded run bit for bit, whatever the number of workers, also when
