@@ -162,7 +162,8 @@ PROBES = os.path.normpath(os.path.join(HERE, '..', 'tools', 'probes'))
 # they travel to the GPU box as files): the streaming-read probe behind roofline.peak_measured,
 # and rocRAND's own Philox state for the identity test of csrc/philox.h
 PROBE_UNITS = {'hbm_read_probe': ['-O3'], 'rocrand_philox_probe': ['-O2'],
-               'sync_stall_probe': ['-O2'], 'fp64_operand_probe': ['-O2']}
+               'sync_stall_probe': ['-O2'], 'fp64_operand_probe': ['-O2'],
+               'wave_sum_probe': ['-O2']}
 
 
 def probe_path(name):
