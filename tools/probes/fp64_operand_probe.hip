@@ -40,8 +40,17 @@ __global__ void chains(double *out, int n, double as_in)
                 asm volatile("v_add_f64 %0, %0, %1" : "+v"(x[i]) : "v"(b));
             else if constexpr (MODE == 4)
                 asm volatile("v_add_f64 %0, %1, %0" : "+v"(x[i]) : "s"(as));
-            else
+            else if constexpr (MODE == 5)
                 asm volatile("v_mul_f64 %0, %1, %0" : "+v"(x[i]) : "s"(as));
+            else {
+                // an addition, then its result through two 32-bit moves (what a level of the
+                // wave sum does between two additions: profiles/r06_wave_sum_probe.txt)
+                asm volatile("v_add_f64 %0, %0, %1" : "+v"(x[i]) : "v"(b));
+                int lo = __double2loint(x[i]), hi = __double2hiint(x[i]);
+                asm volatile("v_mov_b32 %0, %0" : "+v"(lo));
+                asm volatile("v_mov_b32 %0, %0" : "+v"(hi));
+                x[i] = __hiloint2double(hi, lo);
+            }
         }
     }
     double s = 0;
@@ -67,7 +76,7 @@ void run(double *d, int waves, const char *name)
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     const double ns_per_op_simd = ms * 1e6 / n / NV / waves;
-    printf("  %-5s %2d chains, %d wave(s)/SIMD: %6.2f ns per instruction and SIMD = %5.2f cycles at 2.4 GHz\n",
+    printf("  %-8s %2d chains, %d wave(s)/SIMD: %6.2f ns per instruction and SIMD = %5.2f cycles at 2.4 GHz\n",
            name, NV, waves, ns_per_op_simd, ns_per_op_simd * 2.4);
 }
 
@@ -80,10 +89,12 @@ void all(double *d, int waves)
     run<3, NV>(d, waves, "add");
     run<4, NV>(d, waves, "adds");
     run<5, NV>(d, waves, "mul");
+    run<6, NV>(d, waves, "add+2mov");
 }
 
-int main()
+int main(int argc, char **)
 {
+    const bool quick = argc > 1;          // (any argument: one wave per SIMD only)
     double *d;
     hipMalloc(&d, 64 << 20);
     for (int waves = 1; waves <= 3; ++waves) {
@@ -92,6 +103,8 @@ int main()
         all<4>(d, waves);
         all<8>(d, waves);
         all<32>(d, waves);
+        if (quick)
+            break;
     }
     return 0;
 }
