@@ -27,7 +27,13 @@ __global__ void chains(double *out, int n, double as_in)
 #pragma unroll
     for (int i = 0; i < NV; ++i)
         x[i] = lane * 1e-9 * (i + 1);
-    for (int it = 0; it < n; ++it) {
+    // (UNROLL passes through the chains per trip of the loop: with one instruction per trip the
+    // loop's own branch -- a taken branch stalls the wave for several ns -- was half of what the
+    // first version of this probe reported for a single chain)
+    constexpr int UNROLL = NV >= 16 ? 2 : 32 / NV;
+    for (int it = 0; it < n; it += UNROLL) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             if constexpr (MODE == 0)
@@ -63,7 +69,7 @@ __global__ void chains(double *out, int n, double as_in)
 template <int MODE, int NV>
 void run(double *d, int waves, const char *name)
 {
-    const int n = 60000;     // (tens of milliseconds per launch: the clock has come up)
+    const int n = 61440;     // (tens of milliseconds per launch: the clock has come up)
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
