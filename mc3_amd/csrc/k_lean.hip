@@ -65,7 +65,10 @@ chain_kernel_fn fast_instance_t(const mc3hip_ctx *c, bool p2p)
         // it is the faster flavour at every size -- 64 / 256 / 512 / 1024 chains: 57.9 / 227.1 /
         // 438.8 / 814.7 M chain-steps/s against 56.4 / 222.5 / 431.7 / 773.8 with the draws made
         // refresh by refresh (profiles/r06_handoff_variants.txt) -- and the only one built
-        return lean_demc_kernel<MT, false, false, false, true>;
+        // (more than 1 024 chains -- two and more waves per SIMD --: the wait laid out by hand,
+        // kernels_lean.h BIG)
+        return c->P.nlocal > 1024 ? lean_demc_kernel<MT, false, false, false, true, false, false, true>
+                                  : lean_demc_kernel<MT, false, false, false, true>;
     }
     if (c->P.sampler == MC3HIP_DEMC)
         return fast_instance_tt<MT, MC3HIP_DEMC>(c, p2p);

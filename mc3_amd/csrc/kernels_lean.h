@@ -54,10 +54,14 @@ __global__ __launch_bounds__(64) void persist_fast_kernel(const DevProblem P, co
 // (NT = 2, 4, 8 with NW = 4: more than 1024 points in the registers of four waves -- what
 // lean_demc_wide_kernel does for the plain shape, here for fixed / shared coefficients, priors,
 // the support distribution; specialised at run time, round 5)
+// BIG (the plain shape with the draws of 64 refreshes at once, more than 1 024 chains: two and more
+// waves per SIMD): the wait for the partners' rows laid out by hand and a longer pause in front
+// of the polls -- see the wait below.
 template <int MT, bool P2P, bool FX, bool MULTI, bool BATCH, bool COURIER, bool EPS, int NW = 1,
-          int NT = 1>
+          int NT = 1, bool BIG = false>
 __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nref)
 {
+    static_assert(!BIG || (BATCH && !P2P && !FX && !MULTI && !COURIER && NW == 1), "BIG: the plain shape");
     static_assert(NT == 1 || NW > 1, "several tiles: in the registers of several waves");
     static_assert(!EPS || (!P2P && !MULTI && !BATCH && !COURIER), "EPS: the one-GPU headline loop");
     static_assert(NW == 1 || (!P2P && !MULTI && !COURIER), "helper waves: one GPU, one tile");
@@ -291,7 +295,10 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
         // partner rows of this refresh (chain.py:221-232), requested first
         // (a short pause lets the stores of the previous refresh clear the memory pipeline
         // ahead of the polls: +3 % measured, 64..192 cycles all the same)
-        __builtin_amdgcn_s_sleep(1);
+        // (BIG: 320 cycles -- 2 048 chains 1 364 / 1 383 / 1 390 / 1 399 / 1 410 / 1 399 M
+        // chain-steps/s for 0 / 64 / 128 / 192 / 320 / 512 cycles with the wait below; 256
+        // chains lose with every cycle beyond 64)
+        __builtin_amdgcn_s_sleep(BIG ? 5 : 1);
         if constexpr (BATCH) {
             const int idx = (int)(R - bbase);
             off1 = __builtin_amdgcn_readlane(bo1, idx) + kk;
@@ -345,11 +352,56 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
                     late.drain(P, s_ring, peers_z, lane, mine, false);
             }
         };
+        if constexpr (BIG) {
+            // The wait, laid out by hand.  In the compiler's layout of poll_ring's two nested
+            // loops three taken branches and six register copies lie between the arrival of the
+            // later row and the proposal (a taken branch costs a wave ~13 ns,
+            // profiles/r06_fp64_operand_probe.txt).  Here the rows are used from the registers
+            // they arrive in, both rows there at the first look is the straight line (no branch
+            // taken), and the loop that asks again -- only for what is still missing, at once --
+            // has one way out, its end.  With two and more waves per SIMD this is worth 2-4 %
+            // (2 048 chains: 1 354 -> 1 383, 1 410 with the longer pause above); with one wave per
+            // SIMD it LOSES 1 % (256 chains: 227.1 -> 224.5 whatever the pause): there the
+            // ensemble's period answers to when the polls are sent, not to what follows them,
+            // and those chains keep poll_ring.
+            static_assert(KR == 1, "one poll in flight");
+            bool pend0 = __any(mc3_bits(ring[0][0]) == ROW_PENDING);
+            bool pend1 = __any(mc3_bits(ring[0][1]) == ROW_PENDING);
+            if (__builtin_expect(pend0 || pend1, 0)) {
+                unsigned spins = 0;
+                do {
+                    if (pend0)
+                        ring[0][0] = load_published<LM>(addr[0]);
+                    if (pend1)
+                        ring[0][1] = load_published<LM>(addr[1]);
 #ifdef MC3HIP_STAMPS
-        alive = poll_ring<KR, LM>(addr, ring, val, ctl_rw, &ta14, idle);
-#else
-        alive = poll_ring<KR, LM>(addr, ring, val, ctl_rw, nullptr, idle);
+                    ta14 += 1;
 #endif
+                    if (__builtin_expect((++spins & 255u) == 0u, 0)) {
+                        // (the launch given up elsewhere, or nothing for seconds: poll_ring's rule)
+                        const int ab = __builtin_amdgcn_readfirstlane(
+                            (int)(__hip_atomic_load(&ctl_rw[CTL_ABORT], __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT) != 0));
+                        if (ab != 0 || spins > (1u << 22)) {
+                            if (ab == 0)
+                                __hip_atomic_store(&ctl_rw[CTL_ABORT], 1LL, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                            alive = false;                 // (one way out of the loop: its end)
+                        }
+                    }
+                    pend0 = __any((int)alive & (int)(mc3_bits(ring[0][0]) == ROW_PENDING));
+                    pend1 = __any((int)alive & (int)(mc3_bits(ring[0][1]) == ROW_PENDING));
+                } while (pend0 || pend1);
+            }
+            val[0] = ring[0][0];
+            val[1] = ring[0][1];
+        } else {
+#ifdef MC3HIP_STAMPS
+            alive = poll_ring<KR, LM>(addr, ring, val, ctl_rw, &ta14, idle);
+#else
+            alive = poll_ring<KR, LM>(addr, ring, val, ctl_rw, nullptr, idle);
+#endif
+        }
         MC3_TICK(tk1);
         if (__builtin_expect(!alive, 0))
             break;
@@ -494,11 +546,11 @@ __device__ __forceinline__ void lean_demc_body(const DevProblem &P, const int nr
 }
 
 template <int MT, bool P2P, bool FX = false, bool MULTI = false, bool BATCH = false,
-          bool COURIER = false, bool EPS = false>
+          bool COURIER = false, bool EPS = false, bool BIG = false>
 __global__ __launch_bounds__(COURIER ? 128 : 64) void lean_demc_kernel(const DevProblem P,
         const int nref)
 {
-    lean_demc_body<MT, P2P, FX, MULTI, BATCH, COURIER, EPS>(P, nref);
+    lean_demc_body<MT, P2P, FX, MULTI, BATCH, COURIER, EPS, 1, 1, BIG>(P, nref);
 }
 
 // ---------------------------------------------------------------------------------

@@ -104,7 +104,10 @@ def one_gpu_big_ensembles_grid():
     """ensembles beyond one wave per SIMD (the draws of 64 refreshes at once), and more than one
     tile with too many chains for the tiles to sit in the registers of four waves each"""
     for ncoef in DEGREES:
-        yield (f'poly{ncoef}-demc-batch', poly_case(ncoef, 'demc', 'plain', nchains=1100, nref=6), 1)
+        # (more than 1 024 chains: lean_demc_kernel BIG, the wait laid out by hand; the run crosses
+        # a batch of 64 refreshes' draws)
+        yield (f'poly{ncoef}-demc-batch', poly_case(ncoef, 'demc', 'plain', nchains=1100, nref=70,
+                                                    ndata=100), 1)
         for sampler in SAMPLERS:
             yield (f'poly{ncoef}-{sampler}-multi-800',
                    poly_case(ncoef, sampler, 'multi', nchains=800, nref=4), 1)

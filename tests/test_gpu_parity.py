@@ -1057,6 +1057,36 @@ def test_lean_demc_with_the_draws_of_64_refreshes_at_once(eng, case):
     gpu.close()
 
 
+@pytest.mark.parametrize('case', ['launches', 'giveup'])
+def test_lean_demc_big_ensemble_wait_laid_out_by_hand(eng, monkeypatch, case):
+    """lean_demc_kernel BIG (more than 1 024 chains: kernels_lean.h): the wait for the partners'
+    rows with its own loop -- launches that start and stop inside a batch of draws, and a launch
+    that gives up (test hook: chain 0 raises the flag at refresh 21, every other chain finds it
+    from inside its wait) and is redone from the checkpoint."""
+    prob = H.quad_problem(ndata=100, nchains=1100, nsamples=1100*200)
+    if case == 'giveup':
+        monkeypatch.setenv('MC3HIP_TEST_ABORT_AT', '21')
+        orc, gpu = run_pair(eng, prob, trace=False)
+        assert gpu.plan['recoveries'] == 1, gpu.plan
+    else:
+        gpu = eng.DeviceChains(**prob)
+        orc = H.make_oracle(prob, plan=gpu.plan)
+        Z0, lp0 = H.initial_population(orc)
+        orc.set_population(Z0, lp0)
+        gpu.set_population(Z0, lp0)
+        orc.run(nthreads=8)
+        for n in (1, 2, 64, 65, 68):
+            gpu.run(n)
+        assert gpu.plan['recoveries'] == 0, gpu.plan
+        kernel = gpu.last_kernel
+        assert gpu.plan['fast'] == 2 and 'lean_demc_kernel' in kernel, (gpu.plan, kernel)
+        # (the last template argument, mangled or not)
+        assert 'Lb1EEEvNS' in kernel or ', true>(' in kernel, kernel
+    # (after a launch that gave up the context goes on a launch per refresh: its plan says so)
+    assert_same(orc, gpu, trace=False)
+    gpu.close()
+
+
 # ---- wavelet likelihood x design-matrix model ---------------------------------------------
 @pytest.mark.parametrize('trace', [True, False])
 @pytest.mark.parametrize('ndata,nmodel,sampler', [
