@@ -18,6 +18,7 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 bad = 0
 async_plans = 0                 # (contexts that ran resident_async_kernel)
+kernels = {}                    # (the chain kernel each context launched last)
 for seed in range(first, first + count):
     kind = seed % 4 if 'big' not in sys.argv else 4
     if os.environ.get('FUZZ_KIND'):       # (one generator only, e.g. 2 = the wavelet likelihood)
@@ -48,6 +49,19 @@ for seed in range(first, first + count):
     elif kind == 8:
         # round 5: the models specialised at run time, beyond one register tile (FUZZ_KIND=8)
         prob = F.wide_models_problem(seed)
+    elif kind == 9:
+        # round 6: the headline loop beyond 1 024 chains (lean_demc_kernel BIG: the wait laid out
+        # by hand) -- the plain DEMC shapes of the lean generator with 1 025 ... 2 048 chains
+        # (FUZZ_KIND=9); tight bounds come with the generator
+        for sub in range(1000):
+            prob, _ = F.lean_problem(seed*1000 + sub)
+            if prob['sampler'] == 'demc' and prob.get('thinning', 1) == 1 and \
+                    len(prob['data']) <= 1024 and np.all(np.asarray(prob['pstep']) > 0) and \
+                    not np.any(np.asarray(prob.get('priorlow', [0])) > 0):
+                break
+        rs = np.random.RandomState(seed)
+        nch = int(rs.randint(1025, 2049))
+        prob.update(nchains=nch, nsamples=nch*int(rs.randint(6, 90)))
     elif kind == 0:
         prob = F.random_problem(seed)
     elif kind == 1:
@@ -74,9 +88,13 @@ for seed in range(first, first + count):
         gpu.run(max(1, gpu.nzchain//3))
         gpu.run()
         F.compare_final(gpu, orc, f'seed {seed}')
+        kernels[gpu.last_kernel] = kernels.get(gpu.last_kernel, 0) + 1
         gpu.close()
     except Exception as e:      # noqa: BLE001
         bad += 1
         print(f'FAIL seed {seed} kind {kind}: {str(e)[:300]}', flush=True)
 print(f'{count} seeds from {first}: {bad} failures'
       + (f' ({async_plans} contexts with owner waves)' if async_plans else ''))
+if os.environ.get('FUZZ_KERNELS'):
+    for name, n in sorted(kernels.items(), key=lambda kv: -kv[1]):
+        print(f'{n:6d}  {name}')
