@@ -51,6 +51,9 @@ run 20000 demc 256 ndata=2048 fepsilon=0.01
 # the headline loop and its neighbours on the final library
 run 100000 demc 256
 run 60000 snooker 256
+# ... beyond 1 024 chains (lean_demc_kernel BIG: the wait laid out by hand), two sizes
+run 40000 demc 2048
+run 40000 demc 1500
 cat $out
 fi
 if [ $part != soak ]; then
