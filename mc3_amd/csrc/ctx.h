@@ -512,7 +512,6 @@ inline int wide_tiles(const mc3hip_ctx *c)
 }
 inline int lean_waves(const mc3hip_ctx *c)
 {
-    const DevProblem &P = c->P;
     if (const int nt = wide_tiles(c))
         if (c->fast)
             return nt > 8 ? 8 : 4;
