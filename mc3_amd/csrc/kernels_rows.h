@@ -460,7 +460,13 @@ __global__ __launch_bounds__(64) void lean_demc_rows_kernel(const DevProblem P, 
                                __HIP_MEMORY_SCOPE_AGENT);
             break;                // (the host restores its checkpoint after an abort)
         }
-        __builtin_amdgcn_s_sleep(1);
+        // (a pause in front of the polls, as in lean_demc_kernel -- the stores of the refresh
+        // before clear the memory pipeline, and the partners' rows are likelier there at the first
+        // look.  One GPU, 64 / 192 / 320 / 512 / 768 / 1 024 cycles: 4 096 chains 1 978 / 1 979 /
+        // 1 974 / 1 990-2 002 / 2 001 / 1 909 M chain-steps/s, 8 192 chains 2 593 / 2 638 / 2 654 /
+        // 2 679-2 688 / 2 666 / 2 603 -- 512 since round 6; peer to peer the stores are the
+        // courier's or go to other devices: 64 as before)
+        __builtin_amdgcn_s_sleep(P2P ? 1 : 8);
         // the partner rows of every chain of the wave: one request each
         const double *addr[2];
         addr[0] = pbase + o1;
